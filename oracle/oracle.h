@@ -1,0 +1,209 @@
+/*
+ * oracle.h -- TEST INFRASTRUCTURE ONLY.  Never linked into, imported by or
+ * executed from the product path (spandsp_amd/).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it.
+ *
+ * A plain-C, single-channel, sample-serial CPU restatement of the reference's
+ * algorithms for the hot path named in BASELINE.json (Goertzel banks and their
+ * decision logic, the vector primitives, the V.29 receiver, the G.168 echo
+ * canceller).  Every function cites the reference file:line it follows
+ * (paths relative to /root/reference/).  Build: strict IEEE binary32,
+ * `gcc -O2 -ffp-contract=off -fwrapv` (see oracle/Makefile).
+ *
+ * PARITY PINNING: tests/test_oracle_pin.py checks every function here against
+ * (a) the real reference compiled into oracle/_ref/libspandsp_ref.so when
+ * that file is present, and (b) the golden vectors under tests/golden/ that
+ * were generated from that build by tests/golden/make_golden.py.
+ */
+#if !defined(SPANDSP_AMD_ORACLE_H)
+#define SPANDSP_AMD_ORACLE_H
+
+#include <stdint.h>
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* One record per observable action, in the order the reference would perform
+   it.  kind: 1 = tone report callback (a=code, b=level, c=duration/delay)
+              2 = digits callback (a=len; characters appended to the sink text)
+              3 = put_bit (a=bit or negative SIG_STATUS_*)
+              4 = super-tone segment callback (a=f1, b=f2, c=duration ms)
+   Same layout as glue_event_t in oracle/ref_glue/ref_glue.c so the two
+   streams compare with memcmp. */
+typedef struct
+{
+    int32_t kind;
+    int32_t a;
+    int32_t b;
+    int32_t c;
+} orc_event_t;
+
+typedef struct
+{
+    orc_event_t *ev;
+    int n;
+    int cap;
+    char *text;
+    int ntext;
+    int captext;
+} orc_sink_t;
+
+ORC_API orc_sink_t *orc_sink_new(void);
+ORC_API void orc_sink_free(orc_sink_t *k);
+ORC_API void orc_sink_clear(orc_sink_t *k);
+ORC_API int orc_sink_count(const orc_sink_t *k);
+ORC_API const orc_event_t *orc_sink_events(const orc_sink_t *k);
+ORC_API int orc_sink_ntext(const orc_sink_t *k);
+ORC_API const char *orc_sink_text(const orc_sink_t *k);
+void orc_sink_push(orc_sink_t *k, int kind, int a, int b, int c);
+void orc_sink_text_append(orc_sink_t *k, const char *s, int len);
+
+/* Per-block trace record for the tone detectors (what the GPU kernels also
+   emit in debug mode): the raw block decision before debouncing plus the
+   Goertzel energies the decision saw. */
+#define ORC_MAX_BINS 64
+typedef struct
+{
+    int32_t hit;            /* raw block result (ASCII code, 0 = none); super-tone: k1 */
+    int32_t aux;            /* DTMF: in_digit after the block; Bell: accepted digit or 0; R2: current digit; super-tone: k2 */
+    float total_energy;     /* sum x*x over the block (DTMF, super-tone), else 0 */
+    float e[ORC_MAX_BINS];  /* goertzel_result per bin (NaN-free; bins not evaluated are left 0) */
+} orc_block_t;
+
+/* ---- Goertzel primitive ---------------------------------------------------- */
+ORC_API float orc_goertzel_fac(float freq);
+typedef struct
+{
+    float v2;
+    float v3;
+    float fac;
+    int samples;
+    int current_sample;
+} orc_goertzel_t;
+ORC_API void orc_goertzel_init(orc_goertzel_t *g, float freq, int samples);
+ORC_API int orc_goertzel_update(orc_goertzel_t *g, const int16_t amp[], int samples);
+ORC_API float orc_goertzel_result(orc_goertzel_t *g);
+
+/* ---- DTMF -------------------------------------------------------------------- */
+typedef struct
+{
+    float fac[8];           /* row 0..3 then col 0..3 */
+    float v2[8];
+    float v3[8];
+    float energy;
+    float threshold;
+    float normal_twist;
+    float reverse_twist;
+    float z350[2];
+    float z440[2];
+    int filter_dialtone;
+    int current_sample;
+    int duration;
+    int last_hit;
+    int in_digit;
+    int mode;               /* 0 = buffer digits (dtmf_rx_get), 1 = digits callback, 2 = realtime callback */
+    int lost_digits;
+    int current_digits;
+    char digits[129];
+} orc_dtmf_t;
+
+ORC_API int orc_dtmf_sizeof(void);
+ORC_API void orc_dtmf_init(orc_dtmf_t *s, int mode);
+ORC_API void orc_dtmf_parms(orc_dtmf_t *s, int filter_dialtone, float twist, float reverse_twist, float threshold);
+/* blocks (may be NULL): receives one orc_block_t per completed 102-sample block,
+   up to max_blocks; returns the number of completed blocks. */
+ORC_API int orc_dtmf_rx(orc_dtmf_t *s, const int16_t amp[], int samples, orc_sink_t *sink, orc_block_t *blocks, int max_blocks);
+ORC_API int orc_dtmf_get(orc_dtmf_t *s, char *buf, int max);
+ORC_API int orc_dtmf_status(const orc_dtmf_t *s);
+ORC_API void orc_dtmf_fillin(orc_dtmf_t *s, int samples);
+
+/* ---- Bell MF / R2 MF ------------------------------------------------------------ */
+typedef struct
+{
+    float fac[6];
+    float v2[6];
+    float v3[6];
+    int hits[5];
+    int current_sample;
+    int mode;               /* 0 = buffer digits, 1 = digits callback */
+    int lost_digits;
+    int current_digits;
+    char digits[129];
+} orc_bell_mf_t;
+
+ORC_API int orc_bell_mf_sizeof(void);
+ORC_API void orc_bell_mf_init(orc_bell_mf_t *s, int mode);
+ORC_API int orc_bell_mf_rx(orc_bell_mf_t *s, const int16_t amp[], int samples, orc_sink_t *sink, orc_block_t *blocks, int max_blocks);
+ORC_API int orc_bell_mf_get(orc_bell_mf_t *s, char *buf, int max);
+
+typedef struct
+{
+    float fac[6];
+    float v2[6];
+    float v3[6];
+    int fwd;
+    int current_sample;
+    int current_digit;
+    int use_callback;
+} orc_r2_mf_t;
+
+ORC_API int orc_r2_mf_sizeof(void);
+ORC_API void orc_r2_mf_init(orc_r2_mf_t *s, int fwd, int use_callback);
+ORC_API int orc_r2_mf_rx(orc_r2_mf_t *s, const int16_t amp[], int samples, orc_sink_t *sink, orc_block_t *blocks, int max_blocks);
+
+/* ---- Super tone --------------------------------------------------------------------- */
+#define ORC_ST_MAX_TONES    32
+#define ORC_ST_MAX_STEPS    16
+typedef struct
+{
+    int f1;
+    int f2;
+    int min_duration;       /* in samples (ms*8) */
+    int max_duration;
+} orc_st_step_t;
+
+typedef struct
+{
+    int used_frequencies;
+    int monitored_frequencies;
+    int pitches[64][2];
+    float fac[64];
+    int tones;
+    int steps[ORC_ST_MAX_TONES];
+    orc_st_step_t list[ORC_ST_MAX_TONES][ORC_ST_MAX_STEPS];
+} orc_st_desc_t;
+
+typedef struct
+{
+    const orc_st_desc_t *desc;
+    float energy;
+    int detected_tone;
+    int rotation;
+    int current_sample;
+    int use_segment_cb;
+    struct
+    {
+        int f1;
+        int f2;
+        int min_duration;
+    } seg[11];
+    float v2[64];
+    float v3[64];
+} orc_st_t;
+
+ORC_API int orc_st_desc_sizeof(void);
+ORC_API int orc_st_sizeof(void);
+ORC_API void orc_st_desc_init(orc_st_desc_t *d);
+ORC_API int orc_st_add_tone(orc_st_desc_t *d);
+ORC_API int orc_st_add_element(orc_st_desc_t *d, int tone, int f1, int f2, int min_ms, int max_ms);
+ORC_API void orc_st_init(orc_st_t *s, const orc_st_desc_t *d, int use_segment_cb);
+ORC_API int orc_st_rx(orc_st_t *s, const int16_t amp[], int samples, orc_sink_t *sink, orc_block_t *blocks, int max_blocks);
+
+#if defined(__cplusplus)
+}
+#endif
+
+#endif

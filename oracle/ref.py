@@ -1,0 +1,376 @@
+"""ctypes binding of oracle/_ref/libspandsp_ref.so -- the REAL reference, compiled
+from /root/reference/src by oracle/Makefile (sources are not copied here).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  The .so is built in the
+dev container and travels to the GPU box with the snapshot; /root/reference
+itself is never read at run time.
+"""
+import contextlib
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import REF_SO
+
+EVENT_DTYPE = np.dtype([("kind", "<i4"), ("a", "<i4"), ("b", "<i4"), ("c", "<i4")])
+
+_lib = None
+
+
+def available():
+    return os.path.exists(REF_SO)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(REF_SO)
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        sigs = {
+            # glue
+            "glue_sink_new": (vp, []), "glue_sink_free": (None, [vp]), "glue_sink_clear": (None, [vp]),
+            "glue_sink_count": (ci, [vp]), "glue_sink_events": (vp, [vp]),
+            "glue_sink_ndigits": (ci, [vp]), "glue_sink_digits": (C.c_char_p, [vp]),
+            "glue_dtmf_rx_new": (vp, [vp, ci, ci]),
+            "glue_dtmf_rx_snapshot": (None, [vp, vp, vp]),
+            "glue_dtmf_rx_consts": (None, [vp, vp]),
+            "glue_bell_mf_rx_new": (vp, [vp, ci]),
+            "glue_bell_mf_rx_snapshot": (None, [vp, vp, vp]),
+            "glue_r2_mf_rx_new": (vp, [vp, ci, ci]),
+            "glue_r2_mf_rx_snapshot": (None, [vp, vp, vp]),
+            "glue_super_tone_rx_new": (vp, [vp, vp, ci]),
+            "glue_super_tone_desc_bins": (ci, [vp, vp]),
+            "glue_super_tone_rx_snapshot": (None, [vp, vp, vp]),
+            "glue_goertzel_fac": (cf, [cf, ci]),
+            "glue_goertzel_new": (vp, [cf, ci]),
+            "glue_goertzel_snapshot": (None, [vp, vp, vp]),
+            "glue_echo_run": (None, [vp, vp, vp, vp, ci, ci]),
+            "glue_echo_taps": (ci, [vp]),
+            "glue_echo_snapshot": (None, [vp, vp, vp, vp, vp]),
+            "glue_v29_rx_new": (vp, [ci, vp]), "glue_v27ter_rx_new": (vp, [ci, vp]), "glue_v17_rx_new": (vp, [ci, vp]),
+            "glue_v29_tx_new": (vp, [ci, ci, vp]), "glue_v27ter_tx_new": (vp, [ci, ci, vp]), "glue_v17_tx_new": (vp, [ci, ci, vp]),
+            "glue_sizeof": (ci, [C.c_char_p]),
+            # reference public API (src/spandsp/*.h)
+            "dtmf_rx": (ci, [vp, vp, ci]), "dtmf_rx_get": (C.c_size_t, [vp, C.c_char_p, ci]),
+            "dtmf_rx_status": (ci, [vp]), "dtmf_rx_fillin": (ci, [vp, ci]),
+            "dtmf_rx_parms": (None, [vp, ci, cf, cf, cf]), "dtmf_rx_free": (ci, [vp]),
+            "dtmf_tx_init": (vp, [vp, vp, vp]), "dtmf_tx_put": (ci, [vp, C.c_char_p, ci]),
+            "dtmf_tx": (ci, [vp, vp, ci]), "dtmf_tx_set_level": (None, [vp, ci, ci]),
+            "dtmf_tx_set_timing": (None, [vp, ci, ci]), "dtmf_tx_free": (ci, [vp]),
+            "bell_mf_rx": (ci, [vp, vp, ci]), "bell_mf_rx_get": (C.c_size_t, [vp, C.c_char_p, ci]),
+            "bell_mf_rx_free": (ci, [vp]),
+            "bell_mf_tx_init": (vp, [vp]), "bell_mf_tx_put": (ci, [vp, C.c_char_p, ci]),
+            "bell_mf_tx": (ci, [vp, vp, ci]), "bell_mf_tx_free": (ci, [vp]),
+            "r2_mf_rx": (ci, [vp, vp, ci]), "r2_mf_rx_get": (ci, [vp]), "r2_mf_rx_free": (ci, [vp]),
+            "r2_mf_tx_init": (vp, [vp, ci]), "r2_mf_tx_put": (ci, [vp, C.c_char]),
+            "r2_mf_tx": (ci, [vp, vp, ci]), "r2_mf_tx_free": (ci, [vp]),
+            "super_tone_rx_make_descriptor": (vp, [vp]), "super_tone_rx_free_descriptor": (ci, [vp]),
+            "super_tone_rx_add_tone": (ci, [vp]), "super_tone_rx_add_element": (ci, [vp, ci, ci, ci, ci, ci]),
+            "super_tone_rx": (ci, [vp, vp, ci]), "super_tone_rx_free": (ci, [vp]),
+            "goertzel_update": (ci, [vp, vp, ci]), "goertzel_result": (cf, [vp]), "goertzel_free": (ci, [vp]),
+            "tone_gen_descriptor_init": (vp, [vp, ci, ci, ci, ci, ci, ci, ci, ci, ci]),
+            "tone_gen_descriptor_free": (None, [vp]),
+            "tone_gen_init": (vp, [vp, vp]), "tone_gen": (ci, [vp, vp, ci]), "tone_gen_free": (ci, [vp]),
+            "awgn_init_dbm0": (vp, [vp, ci, cf]), "awgn": (C.c_int16, [vp]), "awgn_free": (ci, [vp]),
+            "echo_can_init": (vp, [ci, ci]), "echo_can_free": (ci, [vp]), "echo_can_flush": (None, [vp]),
+            "echo_can_adaption_mode": (None, [vp, ci]),
+            "echo_can_update": (C.c_int16, [vp, C.c_int16, C.c_int16]),
+            "echo_can_hpf_tx": (C.c_int16, [vp, C.c_int16]),
+            "v29_rx": (ci, [vp, vp, ci]), "v29_rx_free": (ci, [vp]), "v29_rx_restart": (ci, [vp, ci, ci]),
+            "v29_rx_signal_cutoff": (None, [vp, cf]),
+            "v29_tx": (ci, [vp, vp, ci]), "v29_tx_free": (ci, [vp]), "v29_tx_power": (None, [vp, cf]),
+            "v27ter_rx": (ci, [vp, vp, ci]), "v27ter_rx_free": (ci, [vp]),
+            "v27ter_tx": (ci, [vp, vp, ci]), "v27ter_tx_free": (ci, [vp]), "v27ter_tx_power": (None, [vp, cf]),
+            "v17_rx": (ci, [vp, vp, ci]), "v17_rx_free": (ci, [vp]),
+            "v17_tx": (ci, [vp, vp, ci]), "v17_tx_free": (ci, [vp]), "v17_tx_power": (None, [vp, cf]),
+            "vec_dot_prodf": (cf, [vp, vp, ci]), "vec_circular_dot_prodf": (cf, [vp, vp, ci, ci]),
+            "vec_lmsf": (None, [vp, vp, ci, cf]), "vec_circular_lmsf": (None, [vp, vp, ci, ci, cf]),
+        }
+        for name, (res, args) in sigs.items():
+            if not hasattr(L, name):
+                continue
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+@contextlib.contextmanager
+def quiet_stdout():
+    """echo.c of this snapshot printf()s on every sample; silence fd 1 around calls."""
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    null = os.open(os.devnull, os.O_WRONLY)
+    try:
+        os.dup2(null, 1)
+        yield
+    finally:
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(saved, 1)
+        os.close(null)
+        os.close(saved)
+
+
+def _i16(a):
+    return np.ascontiguousarray(a, dtype=np.int16)
+
+
+class Sink:
+    def __init__(self):
+        self.p = lib().glue_sink_new()
+
+    def __del__(self):
+        try:
+            lib().glue_sink_free(self.p)
+        except Exception:
+            pass
+
+    def clear(self):
+        lib().glue_sink_clear(self.p)
+
+    def events(self):
+        n = lib().glue_sink_count(self.p)
+        if n == 0:
+            return np.zeros(0, EVENT_DTYPE)
+        addr = lib().glue_sink_events(self.p)
+        buf = (C.c_char*(n*EVENT_DTYPE.itemsize)).from_address(addr)
+        return np.frombuffer(buf, dtype=EVENT_DTYPE).copy()
+
+    def text(self):
+        return lib().glue_sink_digits(self.p)[:lib().glue_sink_ndigits(self.p)].decode("latin1")
+
+
+class DtmfRx:
+    """mode 0 = buffered digits, 1 = digits callback, 2 = realtime callback (same numbering as the oracle)."""
+
+    def __init__(self, mode=0):
+        self.sink = Sink()
+        self.p = lib().glue_dtmf_rx_new(self.sink.p, int(mode == 1), int(mode == 2))
+
+    def __del__(self):
+        try:
+            lib().dtmf_rx_free(self.p)
+        except Exception:
+            pass
+
+    def parms(self, filter_dialtone=-1, twist=-1.0, reverse_twist=-1.0, threshold=-99.0):
+        lib().dtmf_rx_parms(self.p, filter_dialtone, twist, reverse_twist, threshold)
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().dtmf_rx(self.p, amp.ctypes.data, len(amp))
+
+    def get(self, maxlen=128):
+        out = C.create_string_buffer(maxlen + 1)
+        lib().dtmf_rx_get(self.p, out, maxlen)
+        return out.value.decode("latin1")
+
+    def status(self):
+        return lib().dtmf_rx_status(self.p)
+
+    def fillin(self, samples):
+        lib().dtmf_rx_fillin(self.p, samples)
+
+    def snapshot(self):
+        f = np.zeros(17, np.float32)
+        i = np.zeros(6, np.int32)
+        lib().glue_dtmf_rx_snapshot(self.p, f.ctypes.data, i.ctypes.data)
+        return {"v2": f[0:8].copy(), "v3": f[8:16].copy(), "energy": float(f[16]),
+                "current_sample": int(i[0]), "duration": int(i[1]), "last_hit": int(i[2]),
+                "in_digit": int(i[3]), "lost_digits": int(i[4]), "current_digits": int(i[5])}
+
+    def consts(self):
+        f = np.zeros(11, np.float32)
+        lib().glue_dtmf_rx_consts(self.p, f.ctypes.data)
+        return {"fac": f[0:8].copy(), "threshold": float(f[8]), "normal_twist": float(f[9]), "reverse_twist": float(f[10])}
+
+
+class BellMfRx:
+    def __init__(self, mode=0):
+        self.sink = Sink()
+        self.p = lib().glue_bell_mf_rx_new(self.sink.p, int(mode == 1))
+
+    def __del__(self):
+        try:
+            lib().bell_mf_rx_free(self.p)
+        except Exception:
+            pass
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().bell_mf_rx(self.p, amp.ctypes.data, len(amp))
+
+    def get(self, maxlen=128):
+        out = C.create_string_buffer(maxlen + 1)
+        lib().bell_mf_rx_get(self.p, out, maxlen)
+        return out.value.decode("latin1")
+
+    def snapshot(self):
+        f = np.zeros(18, np.float32)
+        i = np.zeros(8, np.int32)
+        lib().glue_bell_mf_rx_snapshot(self.p, f.ctypes.data, i.ctypes.data)
+        return {"v2": f[0:6].copy(), "v3": f[6:12].copy(), "fac": f[12:18].copy(),
+                "current_sample": int(i[0]), "hits": i[1:6].copy(), "lost_digits": int(i[6]),
+                "current_digits": int(i[7])}
+
+
+class R2MfRx:
+    def __init__(self, fwd=True, use_callback=True):
+        self.sink = Sink()
+        self.p = lib().glue_r2_mf_rx_new(self.sink.p, int(fwd), int(use_callback))
+
+    def __del__(self):
+        try:
+            lib().r2_mf_rx_free(self.p)
+        except Exception:
+            pass
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().r2_mf_rx(self.p, amp.ctypes.data, len(amp))
+
+    def get(self):
+        return lib().r2_mf_rx_get(self.p)
+
+    def snapshot(self):
+        f = np.zeros(18, np.float32)
+        i = np.zeros(2, np.int32)
+        lib().glue_r2_mf_rx_snapshot(self.p, f.ctypes.data, i.ctypes.data)
+        return {"v2": f[0:6].copy(), "v3": f[6:12].copy(), "fac": f[12:18].copy(),
+                "current_sample": int(i[0]), "current_digit": int(i[1])}
+
+
+class SuperToneDesc:
+    def __init__(self):
+        self.p = lib().super_tone_rx_make_descriptor(None)
+
+    def add_tone(self):
+        return lib().super_tone_rx_add_tone(self.p)
+
+    def add_element(self, tone, f1, f2, min_ms, max_ms):
+        return lib().super_tone_rx_add_element(self.p, tone, f1, f2, min_ms, max_ms)
+
+    @property
+    def fac(self):
+        f = np.zeros(64, np.float32)
+        n = lib().glue_super_tone_desc_bins(self.p, f.ctypes.data)
+        return f[:n].copy()
+
+
+class SuperToneRx:
+    def __init__(self, desc, use_segment_cb=False):
+        self.desc = desc
+        self.sink = Sink()
+        self.p = lib().glue_super_tone_rx_new(desc.p, self.sink.p, int(use_segment_cb))
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().super_tone_rx(self.p, amp.ctypes.data, len(amp))
+
+    def snapshot(self):
+        m = len(self.desc.fac)
+        f = np.zeros(1 + 2*m, np.float32)
+        i = np.zeros(36, np.int32)
+        lib().glue_super_tone_rx_snapshot(self.p, f.ctypes.data, i.ctypes.data)
+        return {"energy": float(f[0]), "v2": f[1:1 + m].copy(), "v3": f[1 + m:1 + 2*m].copy(),
+                "detected_tone": int(i[0]), "rotation": int(i[1]), "current_sample": int(i[2]),
+                "segments": i[3:36].reshape(11, 3).copy()}
+
+
+class Goertzel:
+    def __init__(self, freq, samples):
+        self.p = lib().glue_goertzel_new(freq, samples)
+
+    def update(self, amp):
+        amp = _i16(amp)
+        return lib().goertzel_update(self.p, amp.ctypes.data, len(amp))
+
+    def result(self):
+        return lib().goertzel_result(self.p)
+
+
+# ---- signal sources (the reference's own transmitters / noise) ----------------
+def dtmf_tx(digits, level=None, twist=None, on_ms=None, off_ms=None, max_samples=1 << 22):
+    L = lib()
+    tx = L.dtmf_tx_init(None, None, None)
+    if level is not None:
+        L.dtmf_tx_set_level(tx, level, twist or 0)
+    if on_ms is not None:
+        L.dtmf_tx_set_timing(tx, on_ms, off_ms)
+    L.dtmf_tx_put(tx, digits.encode(), -1)
+    out = []
+    buf = np.zeros(4096, np.int16)
+    total = 0
+    while total < max_samples:
+        n = L.dtmf_tx(tx, buf.ctypes.data, len(buf))
+        if n <= 0:
+            break
+        out.append(buf[:n].copy())
+        total += n
+    L.dtmf_tx_free(tx)
+    return np.concatenate(out) if out else np.zeros(0, np.int16)
+
+
+def bell_mf_tx(digits, max_samples=1 << 22):
+    L = lib()
+    tx = L.bell_mf_tx_init(None)
+    L.bell_mf_tx_put(tx, digits.encode(), -1)
+    out = []
+    buf = np.zeros(4096, np.int16)
+    total = 0
+    while total < max_samples:
+        n = L.bell_mf_tx(tx, buf.ctypes.data, len(buf))
+        if n <= 0:
+            break
+        out.append(buf[:n].copy())
+        total += n
+    L.bell_mf_tx_free(tx)
+    return np.concatenate(out) if out else np.zeros(0, np.int16)
+
+
+def r2_mf_tx(digits, fwd=True, on_samples=800, off_samples=400):
+    """R2 tones are continuous; key each digit for on_samples then silence."""
+    L = lib()
+    tx = L.r2_mf_tx_init(None, int(fwd))
+    out = []
+    for d in digits:
+        L.r2_mf_tx_put(tx, d.encode())
+        buf = np.zeros(on_samples, np.int16)
+        L.r2_mf_tx(tx, buf.ctypes.data, on_samples)
+        out.append(buf)
+        L.r2_mf_tx_put(tx, b"\0")
+        buf = np.zeros(off_samples, np.int16)
+        L.r2_mf_tx(tx, buf.ctypes.data, off_samples)
+        out.append(buf)
+    L.r2_mf_tx_free(tx)
+    return np.concatenate(out)
+
+
+def tone_pair(f1, l1, f2, l2, samples, d1=None):
+    """tone_gen with one cadence section held on (tone_generate.c:67-229)."""
+    L = lib()
+    d = L.tone_gen_descriptor_init(None, f1, l1, f2, l2, d1 if d1 is not None else 1, 0, 0, 0, 1)
+    g = L.tone_gen_init(None, d)
+    buf = np.zeros(samples, np.int16)
+    L.tone_gen(g, buf.ctypes.data, samples)
+    L.tone_gen_free(g)
+    L.tone_gen_descriptor_free(d)
+    return buf
+
+
+def awgn(seed, level_dbm0, samples):
+    L = lib()
+    s = L.awgn_init_dbm0(None, seed, level_dbm0)
+    out = np.array([L.awgn(s) for _ in range(samples)], dtype=np.int16)
+    L.awgn_free(s)
+    return out
+
+
+def saturated_add(a, b):
+    return np.clip(a.astype(np.int32) + b.astype(np.int32), -32768, 32767).astype(np.int16)

@@ -1,0 +1,233 @@
+"""ctypes binding of oracle/liboracle.so (our plain-C restatement).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import ORACLE_SO, build
+
+EVENT_DTYPE = np.dtype([("kind", "<i4"), ("a", "<i4"), ("b", "<i4"), ("c", "<i4")])
+BLOCK_DTYPE = np.dtype([("hit", "<i4"), ("aux", "<i4"), ("total_energy", "<f4"), ("e", "<f4", (64,))])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        L = C.CDLL(ORACLE_SO)
+        vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+        sigs = {
+            "orc_sink_new": (vp, []),
+            "orc_sink_free": (None, [vp]),
+            "orc_sink_clear": (None, [vp]),
+            "orc_sink_count": (ci, [vp]),
+            "orc_sink_events": (vp, [vp]),
+            "orc_sink_ntext": (ci, [vp]),
+            "orc_sink_text": (C.c_char_p, [vp]),
+            "orc_goertzel_fac": (cf, [cf]),
+            "orc_goertzel_init": (None, [vp, cf, ci]),
+            "orc_goertzel_update": (ci, [vp, vp, ci]),
+            "orc_goertzel_result": (cf, [vp]),
+            "orc_dtmf_sizeof": (ci, []),
+            "orc_dtmf_init": (None, [vp, ci]),
+            "orc_dtmf_parms": (None, [vp, ci, cf, cf, cf]),
+            "orc_dtmf_rx": (ci, [vp, vp, ci, vp, vp, ci]),
+            "orc_dtmf_get": (ci, [vp, C.c_char_p, ci]),
+            "orc_dtmf_status": (ci, [vp]),
+            "orc_dtmf_fillin": (None, [vp, ci]),
+            "orc_bell_mf_sizeof": (ci, []),
+            "orc_bell_mf_init": (None, [vp, ci]),
+            "orc_bell_mf_rx": (ci, [vp, vp, ci, vp, vp, ci]),
+            "orc_bell_mf_get": (ci, [vp, C.c_char_p, ci]),
+            "orc_r2_mf_sizeof": (ci, []),
+            "orc_r2_mf_init": (None, [vp, ci, ci]),
+            "orc_r2_mf_rx": (ci, [vp, vp, ci, vp, vp, ci]),
+            "orc_st_desc_sizeof": (ci, []),
+            "orc_st_sizeof": (ci, []),
+            "orc_st_desc_init": (None, [vp]),
+            "orc_st_add_tone": (ci, [vp]),
+            "orc_st_add_element": (ci, [vp, ci, ci, ci, ci, ci]),
+            "orc_st_init": (None, [vp, vp, ci]),
+            "orc_st_rx": (ci, [vp, vp, ci, vp, vp, ci]),
+        }
+        for name, (res, args) in sigs.items():
+            if not hasattr(L, name):
+                continue
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _i16(a):
+    a = np.ascontiguousarray(a, dtype=np.int16)
+    return a
+
+
+class Sink:
+    def __init__(self):
+        self.p = lib().orc_sink_new()
+
+    def __del__(self):
+        try:
+            lib().orc_sink_free(self.p)
+        except Exception:
+            pass
+
+    def clear(self):
+        lib().orc_sink_clear(self.p)
+
+    def events(self):
+        n = lib().orc_sink_count(self.p)
+        if n == 0:
+            return np.zeros(0, EVENT_DTYPE)
+        addr = lib().orc_sink_events(self.p)
+        buf = (C.c_char*(n*EVENT_DTYPE.itemsize)).from_address(addr)
+        return np.frombuffer(buf, dtype=EVENT_DTYPE).copy()
+
+    def text(self):
+        return lib().orc_sink_text(self.p).decode("latin1")
+
+
+class _Detector:
+    """Common shape: opaque state blob + rx(amp) -> per-block trace."""
+    _rx = None
+
+    def __init__(self, size):
+        self.buf = np.zeros(size + 16, np.uint8)
+        self.p = self.buf.ctypes.data
+        self.sink = Sink()
+
+    def rx(self, amp, want_blocks=True):
+        amp = _i16(amp)
+        maxb = len(amp)//64 + 4 if want_blocks else 0
+        blocks = np.zeros(maxb, BLOCK_DTYPE)
+        n = getattr(lib(), self._rx)(self.p, amp.ctypes.data, len(amp), self.sink.p,
+                                     blocks.ctypes.data if want_blocks else None, maxb)
+        return blocks[:n] if want_blocks else n
+
+
+class Dtmf(_Detector):
+    _rx = "orc_dtmf_rx"
+    # field offsets of orc_dtmf_t (floats then ints), see oracle.h
+    def __init__(self, mode=0):
+        super().__init__(lib().orc_dtmf_sizeof())
+        lib().orc_dtmf_init(self.p, mode)
+
+    def parms(self, filter_dialtone=-1, twist=-1.0, reverse_twist=-1.0, threshold=-99.0):
+        lib().orc_dtmf_parms(self.p, filter_dialtone, twist, reverse_twist, threshold)
+
+    def get(self, maxlen=128):
+        out = C.create_string_buffer(maxlen + 1)
+        lib().orc_dtmf_get(self.p, out, maxlen)
+        return out.value.decode("latin1")
+
+    def status(self):
+        return lib().orc_dtmf_status(self.p)
+
+    def fillin(self, samples):
+        lib().orc_dtmf_fillin(self.p, samples)
+
+    def snapshot(self):
+        f = self.buf[:4*35].view(np.float32)
+        i = self.buf[4*35:4*35 + 4*9].view(np.int32)
+        return {
+            "fac": f[0:8].copy(), "v2": f[8:16].copy(), "v3": f[16:24].copy(), "energy": float(f[24]),
+            "threshold": float(f[25]), "normal_twist": float(f[26]), "reverse_twist": float(f[27]),
+            "z350": f[28:30].copy(), "z440": f[30:32].copy(),
+            "filter_dialtone": int(f[32:33].view(np.int32)[0]),
+            "current_sample": int(f[33:34].view(np.int32)[0]),
+            "duration": int(f[34:35].view(np.int32)[0]),
+            "last_hit": int(i[0]), "in_digit": int(i[1]), "mode": int(i[2]),
+            "lost_digits": int(i[3]), "current_digits": int(i[4]),
+        }
+
+
+class BellMf(_Detector):
+    _rx = "orc_bell_mf_rx"
+
+    def __init__(self, mode=0):
+        super().__init__(lib().orc_bell_mf_sizeof())
+        lib().orc_bell_mf_init(self.p, mode)
+
+    def get(self, maxlen=128):
+        out = C.create_string_buffer(maxlen + 1)
+        lib().orc_bell_mf_get(self.p, out, maxlen)
+        return out.value.decode("latin1")
+
+    def snapshot(self):
+        f = self.buf[:4*18].view(np.float32)
+        i = self.buf[4*18:4*18 + 4*9].view(np.int32)
+        return {"fac": f[0:6].copy(), "v2": f[6:12].copy(), "v3": f[12:18].copy(),
+                "hits": i[0:5].copy(), "current_sample": int(i[5]), "mode": int(i[6]),
+                "lost_digits": int(i[7]), "current_digits": int(i[8])}
+
+
+class R2Mf(_Detector):
+    _rx = "orc_r2_mf_rx"
+
+    def __init__(self, fwd=True, use_callback=True):
+        super().__init__(lib().orc_r2_mf_sizeof())
+        lib().orc_r2_mf_init(self.p, int(fwd), int(use_callback))
+
+    def snapshot(self):
+        f = self.buf[:4*18].view(np.float32)
+        i = self.buf[4*18:4*18 + 4*4].view(np.int32)
+        return {"fac": f[0:6].copy(), "v2": f[6:12].copy(), "v3": f[12:18].copy(),
+                "fwd": int(i[0]), "current_sample": int(i[1]), "current_digit": int(i[2])}
+
+
+class SuperToneDesc:
+    def __init__(self):
+        self.buf = np.zeros(lib().orc_st_desc_sizeof() + 16, np.uint8)
+        self.p = self.buf.ctypes.data
+        lib().orc_st_desc_init(self.p)
+
+    def add_tone(self):
+        return lib().orc_st_add_tone(self.p)
+
+    def add_element(self, tone, f1, f2, min_ms, max_ms):
+        return lib().orc_st_add_element(self.p, tone, f1, f2, min_ms, max_ms)
+
+    @property
+    def monitored(self):
+        return int(self.buf[4:8].view(np.int32)[0])
+
+    @property
+    def fac(self):
+        off = 4*(2 + 128)
+        return self.buf[off:off + 4*64].view(np.float32)[:self.monitored].copy()
+
+
+class SuperTone(_Detector):
+    _rx = "orc_st_rx"
+
+    def __init__(self, desc, use_segment_cb=False):
+        super().__init__(lib().orc_st_sizeof())
+        self.desc = desc
+        lib().orc_st_init(self.p, desc.p, int(use_segment_cb))
+
+
+class Goertzel:
+    def __init__(self, freq, samples):
+        self.buf = np.zeros(32, np.uint8)
+        self.p = self.buf.ctypes.data
+        lib().orc_goertzel_init(self.p, freq, samples)
+
+    def update(self, amp):
+        amp = _i16(amp)
+        return lib().orc_goertzel_update(self.p, amp.ctypes.data, len(amp))
+
+    def result(self):
+        return lib().orc_goertzel_result(self.p)
+
+
+def goertzel_fac(freq):
+    return lib().orc_goertzel_fac(freq)
