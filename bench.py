@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json headline metric on MI355X.
+
+Workload (N=1): BASELINE.json configs[1] -- "Batched DTMF Goertzel bank: 65 536
+channels x 160-sample frames, 1 MI355X".  One STEP = one 20 ms tick: one pass of
+the hot path (spangpu_bank_rx -> tone_bank_kernel<DtmfDet>) over the next
+160-sample frame of all channels, inputs already resident in HBM, channel-major
+[frame][channel][160] int16 exactly as N spandsp callers would hand them over.
+Successive steps walk successive frames of a continuous synthetic signal (cadenced
+DTMF digits + noise per SURVEY.md 8(d)), so the detectors do real work.
+
+Multi-GPU (--gpus N via torch.distributed.run): channels shard across ranks
+(65 536 per GPU, weak scaling, no data-path collective); after each step the
+per-channel block records are gathered to rank 0 with RCCL (the only exchange the
+path has).  value = samples processed by all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FRAME = 160                     # samples per channel per step (20 ms at 8 kHz)
+ALG_READ_BYTES = 400            # 320 B PCM + 80 B state per channel-frame
+ALG_WRITE_BYTES = 84
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def synth_dtmf_frames(n_ch, n_frames, device, seed):
+    """Cadenced DTMF + noise for n_ch channels, returned as int16 [n_frames, n_ch, FRAME]
+    on `device` (synthetic data; recipe of SURVEY.md 8(d) config 2)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    row = torch.tensor([697.0, 770.0, 852.0, 941.0], device=device)
+    col = torch.tensor([1209.0, 1336.0, 1477.0, 1633.0], device=device)
+    on, off = 400, 440                                      # 50 ms / 55 ms (dtmf.c:67-69)
+    period = on + off
+    n_samples = n_frames*FRAME
+    n_sym = n_samples//period + 2
+    keys = torch.randint(0, 16, (n_ch, n_sym), device=device, generator=g)
+    start = torch.randint(0, period, (n_ch, 1), device=device, generator=g)
+    lvl = torch.empty(n_ch, 1, device=device).uniform_(-25.0, -7.0, generator=g)
+    tw = torch.empty(n_ch, 1, device=device).uniform_(-4.0, 8.0, generator=g)
+    fo = torch.empty(n_ch, 2, device=device).uniform_(-0.015, 0.015, generator=g)
+    nz = torch.empty(n_ch, 1, device=device).uniform_(-50.0, -25.0, generator=g)
+    quiet = torch.rand(n_ch, 1, device=device, generator=g) < 0.25
+    a_lo = 32768.0*torch.pow(10.0, (lvl - 3.14)/20.0)
+    a_hi = 32768.0*torch.pow(10.0, (lvl - tw - 3.14)/20.0)
+    sigma = 32768.0*torch.pow(10.0, (nz - 3.14)/20.0)/(2.0**0.5)
+    out = torch.empty(n_frames, n_ch, FRAME, dtype=torch.int16, device=device)
+    chunk = 8                                               # frames per synthesis chunk
+    for f0 in range(0, n_frames, chunk):
+        f1 = min(n_frames, f0 + chunk)
+        t = torch.arange(f0*FRAME, f1*FRAME, device=device, dtype=torch.float32).unsqueeze(0)
+        rel = t - start
+        sym = torch.clamp(torch.floor(rel/period), 0, n_sym - 1).long()
+        inside = (rel >= 0) & ((rel - torch.floor(rel/period)*period) < on) & (~quiet)
+        k = torch.gather(keys, 1, sym.expand(n_ch, -1))
+        f_lo = row[k >> 2]*(1.0 + fo[:, 0:1])
+        f_hi = col[k & 3]*(1.0 + fo[:, 1:2])
+        # phase in float64 to keep the tones clean over long signals
+        ph_lo = (2.0*np.pi/8000.0)*f_lo.double()*t.double()
+        ph_hi = (2.0*np.pi/8000.0)*f_hi.double()*t.double() + 1.0
+        x = a_lo*torch.sin(ph_lo).float() + a_hi*torch.sin(ph_hi).float()
+        x = torch.where(inside, x, torch.zeros_like(x))
+        x = x + sigma*torch.randn(x.shape, device=device, generator=g)
+        x = torch.clamp(torch.trunc(x), -32768, 32767).to(torch.int16)
+        out[f0:f1] = x.view(n_ch, f1 - f0, FRAME).permute(1, 0, 2)
+    return out
+
+
+def cpu_baseline(frames_host, loops):
+    """Time the CPU path on the host cores over a bounded sample of the same workload.
+
+    Uses the real reference (oracle/_ref/libspandsp_ref.so, dtmf_rx() per channel)
+    when that build is present, else our C restatement (oracle/liboracle.so).  One
+    Python thread per core, each driving a static slice of channels through a C batch
+    loop (ctypes releases the GIL)."""
+    import oracle
+    from oracle import ref, restated
+    n_frames, n_ch, _ = frames_host.shape
+    cores = os.cpu_count() or 1
+    cores = max(1, min(cores, n_ch))
+    bounds = np.linspace(0, n_ch, cores + 1).astype(int)
+    kind = "reference" if oracle.have_ref() else "port"
+    if kind == "reference":
+        L = ref.lib()
+        L.glue_dtmf_rx_batch.restype = None
+        L.glue_dtmf_rx_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
+        states = [L.glue_dtmf_rx_new(None, 0, 0) for _ in range(n_ch)]
+        arr = (ctypes.c_void_p*n_ch)(*states)
+
+        def work(lo, hi):
+            base = ctypes.addressof(arr) + lo*ctypes.sizeof(ctypes.c_void_p)
+            for _ in range(loops):
+                for f in range(n_frames):
+                    L.glue_dtmf_rx_batch(base, frames_host[f, lo:hi].ctypes.data, hi - lo, FRAME, FRAME)
+    else:
+        L = restated.lib()
+        L.orc_dtmf_rx_batch.restype = None
+        L.orc_dtmf_rx_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
+        sz = L.orc_dtmf_sizeof()
+        blob = np.zeros(n_ch*sz, np.uint8)
+        for c in range(n_ch):
+            L.orc_dtmf_init(blob.ctypes.data + c*sz, 0)
+
+        def work(lo, hi):
+            for _ in range(loops):
+                for f in range(n_frames):
+                    L.orc_dtmf_rx_batch(blob.ctypes.data + lo*sz, frames_host[f, lo:hi].ctypes.data, hi - lo, FRAME, FRAME)
+    threads = [threading.Thread(target=work, args=(int(bounds[i]), int(bounds[i + 1]))) for i in range(cores)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    dt = time.perf_counter() - t0
+    samples = float(n_frames)*loops*n_ch*FRAME
+    return {
+        "value": samples/dt/1e6,
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": kind,
+        "sample": "%d channels x %d frames of %d samples (%d distinct frames cycled %dx), %s dtmf_rx on %d host threads, %.1f s"
+                  % (n_ch, n_frames*loops, FRAME, n_frames, loops,
+                     "reference (oracle/_ref)" if kind == "reference" else "C restatement (oracle/)", cores, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--channels", type=int, default=65536, help="channels per GPU (BASELINE config 2: 65536)")
+    ap.add_argument("--distinct-frames", type=int, default=100, help="distinct 20 ms frames resident in HBM (cycled)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-channels", type=int, default=16384)
+    ap.add_argument("--cpu-frames", type=int, default=40)
+    ap.add_argument("--cpu-loops", type=int, default=15)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from spandsp_amd import engine
+    from spandsp_amd.parallel import ResultGather, shard_range
+
+    n_ch = args.channels
+    lo, hi = shard_range(n_ch*world, world, rank)
+    assert hi - lo == n_ch
+    frames = synth_dtmf_frames(n_ch, args.distinct_frames, dev, seed=0x5EED0000 + rank)
+    torch.cuda.synchronize()
+
+    bank = engine.ToneBank(engine.DTMF, n_ch, device=local_rank)
+    stream = torch.cuda.current_stream()
+    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    gather = ResultGather(world, rank, n_ch, max_blocks=2, device=dev) if world > 1 else None
+    frame_bytes = n_ch*FRAME*2
+    base_ptr = frames.data_ptr()
+    nf = args.distinct_frames
+
+    def step(i):
+        bank.rx_device(ctypes.c_void_p(base_ptr + (i % nf)*frame_bytes), FRAME, FRAME)
+        if gather is not None:
+            gather.submit(bank)
+
+    for i in range(args.warmup):
+        step(i)
+    if gather is not None:
+        gather.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if gather is not None:
+        gather.drain()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stream_ms = ev0.elapsed_time(ev1)
+
+    # ---- per-launch kernel duration with HIP events on the launch stream (roofline) ----
+    roof = None
+    if rank == 0:
+        k = min(args.steps, 200)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
+        for i in range(k):
+            evs[i][0].record(stream)
+            bank.rx_device(ctypes.c_void_p(base_ptr + (i % nf)*frame_bytes), FRAME, FRAME)
+            evs[i][1].record(stream)
+        torch.cuda.synchronize()
+        per = sorted(a.elapsed_time(b) for a, b in evs)
+        avg_ms = sum(per)/len(per)
+        achieved = n_ch*ALG_READ_BYTES/(avg_ms*1e-3)/1e9
+        roof = {
+            "bound": "hbm",
+            "kernel": "tone_bank_kernel<DtmfDet<false>>",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved/HBM_PEAK_GBPS,
+            "traffic": None,
+            "alg_read_bytes_per_launch": n_ch*ALG_READ_BYTES,
+            "alg_write_bytes_per_launch": n_ch*ALG_WRITE_BYTES,
+            "avg_launch_us": avg_ms*1e3,
+            "median_launch_us": per[len(per)//2]*1e3,
+            "stream_us_per_step_timed_region": stream_ms*1e3/args.steps,
+        }
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                roof["traffic"] = json.load(open(tfile)).get("dtmf_bytes_per_launch")
+            except Exception:
+                pass
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        nc = min(args.cpu_channels, n_ch)
+        host = frames[:min(args.cpu_frames, nf), :nc].contiguous().cpu().numpy()
+        cpu = cpu_baseline(host, args.cpu_loops)
+
+    if rank == 0:
+        total_samples = float(args.steps)*n_ch*world*FRAME
+        value = total_samples/dt/1e6
+        line = {
+            "metric": "Msamples/s of batched DTMF Goertzel detect (8 kHz channels at real-time = value*1e6/8000)",
+            "value": value,
+            "unit": "Msamples/s",
+            "realtime_channels": value*1e6/8000.0,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt*1e3/args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: batched DTMF Goertzel bank, %d channels/GPU x %d-sample frames, "
+                            "channel-major int16 resident in HBM, %d distinct frames cycled" % (n_ch, FRAME, nf),
+                "channels_per_gpu": n_ch,
+                "frame_samples": FRAME,
+                "parallelism": "channels sharded x%d, RCCL gather of block records" % world if world > 1 else "single GPU",
+            },
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+/*
+ * spangpu.h -- C ABI of libspangpu.so: the MI355X (gfx950) batched engine behind
+ * spandsp's tone-detect / modem-demod / echo-cancel entry points.
+ *
+ * This is the drop-in boundary: plain C, pointers and sizes only.  A "bank" owns
+ * the device-resident (HBM, structure-of-arrays) state of N independent 8 kHz
+ * channels of one detector kind; one spangpu_bank_rx() call advances every
+ * channel of the bank by one frame with one kernel launch.  The per-channel
+ * spandsp-named entry points (dtmf_rx() ...) in include/spangpu_spandsp.h are a
+ * thin C shim over this ABI.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * reference tree):
+ *   spangpu_bank_create(SPANGPU_DTMF)       dtmf_rx_init()            src/dtmf.c:447-504, src/spandsp/dtmf.h:216
+ *   spangpu_bank_rx() on a DTMF bank        dtmf_rx() x N channels    src/dtmf.c:132-361,  src/spandsp/dtmf.h:177
+ *   spangpu_bank_create(SPANGPU_BELL_MF)    bell_mf_rx_init()         src/bell_r2_mf.c:693-735
+ *   spangpu_bank_rx() on a Bell MF bank     bell_mf_rx() x N          src/bell_r2_mf.c:507-673
+ *   spangpu_bank_create(SPANGPU_R2_MF)      r2_mf_rx_init()           src/bell_r2_mf.c:889-937
+ *   spangpu_bank_rx() on an R2 MF bank      r2_mf_rx() x N            src/bell_r2_mf.c:750-880
+ *   spangpu_bank_create(SPANGPU_SUPER_TONE) super_tone_rx_init()      src/super_tone_rx.c:507-554
+ *   spangpu_bank_rx() on a super-tone bank  super_tone_rx() x N       src/super_tone_rx.c:454-490 (+ :289-362 on device,
+ *                                                                     cadence matcher :164-228,:364-448 in the host shim)
+ *   spangpu_bank_create(SPANGPU_GOERTZEL)   goertzel_init() x bins    src/tone_detect.c:71-92
+ *   spangpu_bank_rx() on a Goertzel bank    goertzel_update()/goertzel_result() x N x bins   src/tone_detect.c:123-205
+ *   spangpu_bank_reset_channel()            xxx_rx_init() on a live object / dtmf_rx_fillin()  src/dtmf.c:363-379
+ *
+ * Threading: a bank is single-submitter (like a spandsp state object); distinct
+ * banks are independent.  All work of a bank is ordered on one HIP stream.
+ * Errors: negative int codes, never exceptions; a missing GPU / HIP runtime is
+ * SPANGPU_ERR_NO_DEVICE -- there is NO CPU fallback in this library.
+ */
+#if !defined(SPANGPU_H)
+#define SPANGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+#define SPANGPU_API __attribute__((visibility("default")))
+
+/* ---- error codes ------------------------------------------------------------ */
+#define SPANGPU_OK                  0
+#define SPANGPU_ERR_NO_DEVICE       (-1)    /* no HIP device / runtime: the product path fails loudly */
+#define SPANGPU_ERR_BAD_ARG         (-2)
+#define SPANGPU_ERR_NO_MEMORY       (-3)
+#define SPANGPU_ERR_HIP             (-4)    /* a HIP call failed; see spangpu_last_error() */
+#define SPANGPU_ERR_STATE           (-5)    /* call not valid in the bank's current state */
+#define SPANGPU_ERR_UNSUPPORTED     (-6)
+
+/* ---- bank kinds ------------------------------------------------------------- */
+#define SPANGPU_DTMF                1
+#define SPANGPU_BELL_MF             2
+#define SPANGPU_R2_MF               3
+#define SPANGPU_SUPER_TONE          4
+#define SPANGPU_GOERTZEL            5
+#define SPANGPU_V29                 6
+#define SPANGPU_V27TER              7
+#define SPANGPU_V17                 8
+#define SPANGPU_ECHO                9
+
+/* ---- where a caller's frame buffer lives / how it is laid out ------------------ */
+#define SPANGPU_MEM_HOST            0       /* pageable or pinned host memory: copied H2D on the bank stream */
+#define SPANGPU_MEM_DEVICE          1       /* already resident in HBM (e.g. a torch tensor's data_ptr) */
+
+#define SPANGPU_LAYOUT_CHANNEL_MAJOR 0      /* amp[channel][sample]: what N spandsp callers naturally hold */
+#define SPANGPU_LAYOUT_SAMPLE_MAJOR  1      /* amp[sample][channel]: pre-interleaved */
+
+#define SPANGPU_MAX_BINS            16      /* bins per channel in one Goertzel / super-tone bank */
+
+/* ---- report modes for DTMF (which of the reference's delivery paths is replayed) */
+#define SPANGPU_REPORT_DIGITS       0       /* digits[] buffer / digits_rx_callback_t   (dtmf.c:318-340) */
+#define SPANGPU_REPORT_REALTIME     2       /* span_tone_report_func_t on/off reports    (dtmf.c:309-316) */
+
+typedef struct spangpu_bank_s spangpu_bank_t;
+
+/* Parameters of a tone-detector bank.  Zero-initialise, then set what you need. */
+typedef struct
+{
+    int32_t report_mode;        /* DTMF: SPANGPU_REPORT_*                                              */
+    int32_t filter_dialtone;    /* DTMF: 1 = apply the 350/440 Hz notches (dtmf.c:167-183)             */
+    float twist_db;             /* DTMF: <= 0 keeps the default 8 dB  (dtmf_rx_parms, dtmf.c:421-445)  */
+    float reverse_twist_db;     /* DTMF: <= 0 keeps the default 4 dB                                   */
+    float threshold_dbm0;       /* DTMF: 0 or <= -99 keeps the default -42 dBm0                        */
+    int32_t r2_fwd;             /* R2 MF: 1 = forward tone set, 0 = backward                           */
+    int32_t n_bins;             /* GOERTZEL / SUPER_TONE: bins per channel (<= SPANGPU_MAX_BINS)       */
+    int32_t block_len;          /* GOERTZEL: samples per block (super-tone is fixed at 128)            */
+    float bin_fac[SPANGPU_MAX_BINS]; /* GOERTZEL / SUPER_TONE: 2cos(2 pi f/8000) per bin, as
+                                   make_goertzel_descriptor() computes it (tone_detect.c:60-68);
+                                   spangpu_goertzel_fac() below reproduces it on the host             */
+    int32_t trace;              /* 1 = also write per-block Goertzel energies (parity / diagnostics)   */
+} spangpu_tone_params_t;
+
+/* One completed detection block of one channel, decoded from the device records. */
+typedef struct
+{
+    int32_t channel;
+    int32_t block;              /* index of the block within the last spangpu_bank_rx() call           */
+    int32_t hit;                /* raw block decision: DTMF/Bell/R2 ASCII code or 0; super-tone k1     */
+    int32_t code;               /* DTMF: debounced digit state after the block; Bell: accepted digit   */
+                                /* or 0; R2: current digit; super-tone: k2                             */
+    int32_t flags;              /* SPANGPU_BLK_*                                                       */
+    int32_t duration;           /* DTMF realtime mode: duration reported with the event                */
+    float energy;               /* DTMF / super-tone: total block energy (sum x*x)                     */
+} spangpu_block_t;
+
+#define SPANGPU_BLK_VALID           0x01    /* a block completed in this slot                          */
+#define SPANGPU_BLK_CHANGE          0x02    /* DTMF: debouncer changed state (dtmf.c:304)              */
+#define SPANGPU_BLK_REPORT          0x04    /* DTMF realtime: a report is due (dtmf.c:312); Bell: digit
+                                               accepted (bell_r2_mf.c:629-655); R2: digit changed      */
+#define SPANGPU_BLK_TONE_OFF        0x08    /* DTMF realtime: the report is a tone-off (level -99)     */
+
+/* ---- library -------------------------------------------------------------------- */
+SPANGPU_API int spangpu_device_count(void);
+SPANGPU_API const char *spangpu_last_error(void);
+SPANGPU_API const char *spangpu_version(void);
+SPANGPU_API float spangpu_goertzel_fac(float freq_hz);
+
+/* ---- banks ------------------------------------------------------------------------ */
+SPANGPU_API int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_channels,
+                                    const void *params, size_t params_size);
+SPANGPU_API int spangpu_bank_destroy(spangpu_bank_t *bank);
+SPANGPU_API int spangpu_bank_kind(const spangpu_bank_t *bank);
+SPANGPU_API int spangpu_bank_channels(const spangpu_bank_t *bank);
+/* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL = the bank's own stream. */
+SPANGPU_API int spangpu_bank_set_stream(spangpu_bank_t *bank, void *hip_stream);
+
+/* Advance every channel by `samples` samples.  `amp` is int16 PCM; for
+   CHANNEL_MAJOR, channel c starts at amp + c*stride (stride in samples, must be a
+   multiple of 8 and >= samples rounded up to 8 for device buffers); for
+   SAMPLE_MAJOR, sample s of channel c is amp[s*stride + c].  Asynchronous: returns
+   after the launch is queued on the bank stream.  Returns 0, like dtmf_rx(). */
+SPANGPU_API int spangpu_bank_rx(spangpu_bank_t *bank, const int16_t *amp, int mem, int layout,
+                                int samples, long long stride);
+/* Wait for everything queued on the bank's stream. */
+SPANGPU_API int spangpu_bank_sync(spangpu_bank_t *bank);
+/* After spangpu_bank_rx(): copy the block records of the last call to the host
+   and decode them in (channel, block) order.  Only VALID slots are returned. `out` may be
+   NULL to query the count.  Returns the number of records or a negative error. */
+SPANGPU_API int spangpu_bank_blocks(spangpu_bank_t *bank, spangpu_block_t *out, int max);
+/* Queue a device-to-device copy of the last call's raw record words ([blocks][channel] uint32,
+   hit | code<<8 | flags<<16) into a caller-owned device buffer (e.g. the send buffer of an RCCL
+   gather).  Returns the number of bytes, or a negative error. */
+SPANGPU_API long long spangpu_bank_copy_records(spangpu_bank_t *bank, void *dst_device, size_t dst_bytes);
+/* Parity / diagnostics tap: per-block Goertzel energies of the last call, laid out
+   [block][bin][channel] (bank created with trace=1).  Returns blocks-per-call. */
+SPANGPU_API int spangpu_bank_trace(spangpu_bank_t *bank, float *energies, size_t max_floats);
+/* Re-initialise one channel (what xxx_rx_init() on a live object does), or only
+   its filters (what dtmf_rx_fillin() does, dtmf.c:363-379) when fillin_only != 0. */
+SPANGPU_API int spangpu_bank_reset_channel(spangpu_bank_t *bank, int channel, int fillin_only);
+/* Import / export the device state of one channel as flat arrays (migration and
+   differential tests).  Layout documented per kind in DESIGN.md. */
+SPANGPU_API int spangpu_bank_get_state(spangpu_bank_t *bank, int channel, float *fstate, int max_f,
+                                       int32_t *istate, int max_i);
+SPANGPU_API int spangpu_bank_set_state(spangpu_bank_t *bank, int channel, const float *fstate, int n_f,
+                                       const int32_t *istate, int n_i);
+/* Time, in milliseconds, spent by the kernels of the last spangpu_bank_rx() call
+   (HIP events on the bank stream); negative if unavailable. */
+SPANGPU_API float spangpu_bank_last_kernel_ms(spangpu_bank_t *bank);
+/* Bracket each spangpu_bank_rx() launch with HIP events on the bank stream (off by default). */
+SPANGPU_API int spangpu_bank_set_timing(spangpu_bank_t *bank, int on);
+/* Bins compiled into the kernel this bank uses (>= the requested n_bins; trace stride). */
+SPANGPU_API int spangpu_bank_bins(const spangpu_bank_t *bank);
+
+#if defined(__cplusplus)
+}
+#endif
+
+#endif

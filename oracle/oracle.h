@@ -116,6 +116,8 @@ ORC_API void orc_dtmf_parms(orc_dtmf_t *s, int filter_dialtone, float twist, flo
 /* blocks (may be NULL): receives one orc_block_t per completed 102-sample block,
    up to max_blocks; returns the number of completed blocks. */
 ORC_API int orc_dtmf_rx(orc_dtmf_t *s, const int16_t amp[], int samples, orc_sink_t *sink, orc_block_t *blocks, int max_blocks);
+/* n channel objects laid out contiguously (orc_dtmf_sizeof() apart); channel c reads amp + c*stride */
+ORC_API void orc_dtmf_rx_batch(orc_dtmf_t *s, const int16_t amp[], int n, long long stride, int samples);
 ORC_API int orc_dtmf_get(orc_dtmf_t *s, char *buf, int max);
 ORC_API int orc_dtmf_status(const orc_dtmf_t *s);
 ORC_API void orc_dtmf_fillin(orc_dtmf_t *s, int samples);

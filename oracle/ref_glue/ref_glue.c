@@ -200,6 +200,15 @@ GLUE void glue_dtmf_rx_consts(dtmf_rx_state_t *s, float out[11])
     out[10] = s->reverse_twist;
 }
 
+/* Batch driver for the CPU baseline: run dtmf_rx() over n channel objects, channel c
+   reading amp + c*stride.  One C call per frame keeps Python out of the timed loop. */
+GLUE void glue_dtmf_rx_batch(dtmf_rx_state_t **s, const int16_t *amp, int n, long long stride, int samples)
+{
+    int c;
+    for (c = 0;  c < n;  c++)
+        dtmf_rx(s[c], amp + c*stride, samples);
+}
+
 /* ---- Bell MF / R2 MF ------------------------------------------------------ */
 GLUE bell_mf_rx_state_t *glue_bell_mf_rx_new(glue_sink_t *k, int use_digits_cb)
 {

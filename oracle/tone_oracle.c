@@ -348,6 +348,14 @@ int orc_dtmf_rx(orc_dtmf_t *s, const int16_t amp[], int samples, orc_sink_t *sin
     return nblocks;
 }
 
+void orc_dtmf_rx_batch(orc_dtmf_t *s, const int16_t amp[], int n, long long stride, int samples)
+{
+    int c;
+
+    for (c = 0;  c < n;  c++)
+        orc_dtmf_rx(&s[c], amp + c*stride, samples, NULL, NULL, 0);
+}
+
 /* dtmf.c:394-408 */
 int orc_dtmf_get(orc_dtmf_t *s, char *buf, int max)
 {

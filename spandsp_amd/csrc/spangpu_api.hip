@@ -1,0 +1,621 @@
+// spangpu_api.hip -- the C ABI of libspangpu.so (include/spangpu.h): bank lifetime,
+// frame submission, record decode.  Device code is in tone_dev.hpp (and the modem /
+// echo headers); this file owns HBM allocations, the bank stream and launch geometry.
+//
+// There is deliberately no CPU implementation behind these entry points: without a
+// HIP device every call that needs one returns SPANGPU_ERR_NO_DEVICE.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/spangpu.h"
+#include "tone_dev.hpp"
+
+using namespace spg;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do                                                                                  \
+    {                                                                                   \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(SPANGPU_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    }                                                                                   \
+    while (0)
+
+struct spangpu_bank_s
+{
+    int device;
+    int kind;
+    int n_ch;
+    hipStream_t stream;
+    bool own_stream;
+    bool timing;
+    spangpu_tone_params_t tp;
+    // geometry of the detector
+    int nb;                 // bins compiled into the kernel used
+    int nsf;                // float state words per channel
+    int block_len;
+    float fac[kMaxBins];
+    float threshold;
+    float normal_twist;
+    float reverse_twist;
+    // device state
+    float *sf;
+    int32_t *si;
+    // per-call outputs (capacity = maxb_cap blocks)
+    int maxb_cap;
+    uint32_t *rec;
+    float *rec_energy;
+    int32_t *rec_dur;
+    float *trace;
+    // host mirrors (pinned)
+    uint32_t *h_rec;
+    float *h_energy;
+    int32_t *h_dur;
+    // staging for host-resident frames
+    int16_t *d_amp;
+    size_t d_amp_cap;       // in samples
+    // last call
+    int last_maxb;
+    int last_samples;
+    hipEvent_t ev0;
+    hipEvent_t ev1;
+    bool ev_valid;
+};
+
+template <class Det>
+static void launch_tone(const ToneLaunch &L, hipStream_t st)
+{
+    const int waves = (L.n_ch + kWave - 1)/kWave;
+    const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
+    hipLaunchKernelGGL(tone_bank_kernel<Det>, dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
+}
+
+extern "C" {
+
+int spangpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+const char *spangpu_last_error(void)
+{
+    return g_err;
+}
+
+const char *spangpu_version(void)
+{
+    return "spangpu 0.1 (gfx950)";
+}
+
+// make_goertzel_descriptor(), tone_detect.c:60-68: the argument is formed in double
+// (M_PI is a double) and narrowed to float at the cosf() call.
+float spangpu_goertzel_fac(float freq_hz)
+{
+    const double two_pi = 2.0f*3.14159265358979323846264338327;
+    const float ratio = freq_hz/8000.0f;
+    return 2.0f*cosf((float) (two_pi*ratio));
+}
+
+static void free_outputs(spangpu_bank_t *b)
+{
+    if (b->rec) (void) hipFree(b->rec);
+    if (b->rec_energy) (void) hipFree(b->rec_energy);
+    if (b->rec_dur) (void) hipFree(b->rec_dur);
+    if (b->trace) (void) hipFree(b->trace);
+    if (b->h_rec) (void) hipHostFree(b->h_rec);
+    if (b->h_energy) (void) hipHostFree(b->h_energy);
+    if (b->h_dur) (void) hipHostFree(b->h_dur);
+    b->rec = nullptr;
+    b->rec_energy = nullptr;
+    b->rec_dur = nullptr;
+    b->trace = nullptr;
+    b->h_rec = nullptr;
+    b->h_energy = nullptr;
+    b->h_dur = nullptr;
+    b->maxb_cap = 0;
+}
+
+static int ensure_outputs(spangpu_bank_t *b, int maxb)
+{
+    if (maxb <= b->maxb_cap)
+        return SPANGPU_OK;
+    free_outputs(b);
+    const size_t n = (size_t) maxb*b->n_ch;
+    HIP_TRY(hipMalloc(&b->rec, n*sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc(&b->h_rec, n*sizeof(uint32_t)));
+    const bool want_energy = (b->kind == SPANGPU_DTMF  &&  b->tp.report_mode == SPANGPU_REPORT_REALTIME)
+                             ||  b->kind == SPANGPU_SUPER_TONE;
+    if (want_energy)
+    {
+        HIP_TRY(hipMalloc(&b->rec_energy, n*sizeof(float)));
+        HIP_TRY(hipHostMalloc(&b->h_energy, n*sizeof(float)));
+        HIP_TRY(hipMemsetAsync(b->rec_energy, 0, n*sizeof(float), b->stream));
+    }
+    if (b->kind == SPANGPU_DTMF  &&  b->tp.report_mode == SPANGPU_REPORT_REALTIME)
+    {
+        HIP_TRY(hipMalloc(&b->rec_dur, n*sizeof(int32_t)));
+        HIP_TRY(hipHostMalloc(&b->h_dur, n*sizeof(int32_t)));
+        HIP_TRY(hipMemsetAsync(b->rec_dur, 0, n*sizeof(int32_t), b->stream));
+    }
+    if (b->tp.trace  ||  b->kind == SPANGPU_GOERTZEL)
+    {
+        HIP_TRY(hipMalloc(&b->trace, n*(b->nb + 1)*sizeof(float)));
+        HIP_TRY(hipMemsetAsync(b->trace, 0, n*(b->nb + 1)*sizeof(float), b->stream));
+    }
+    b->maxb_cap = maxb;
+    return SPANGPU_OK;
+}
+
+int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_channels,
+                        const void *params, size_t params_size)
+{
+    if (bank == nullptr  ||  n_channels <= 0)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad bank/n_channels");
+    *bank = nullptr;
+    if (spangpu_device_count() <= 0)
+        return fail(SPANGPU_ERR_NO_DEVICE, "no HIP device: libspangpu has no CPU fallback");
+    if (device < 0  ||  device >= spangpu_device_count())
+        return fail(SPANGPU_ERR_BAD_ARG, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+
+    spangpu_bank_t *b = (spangpu_bank_t *) calloc(1, sizeof(*b));
+    if (b == nullptr)
+        return fail(SPANGPU_ERR_NO_MEMORY, "calloc");
+    b->device = device;
+    b->kind = kind;
+    b->n_ch = n_channels;
+    if (params)
+        memcpy(&b->tp, params, (params_size < sizeof(b->tp))  ?  params_size  :  sizeof(b->tp));
+
+    switch (kind)
+    {
+    case SPANGPU_DTMF:
+    {
+        // dtmf.c:104-119
+        static const float freqs[8] = {697.0f, 770.0f, 852.0f, 941.0f, 1209.0f, 1336.0f, 1477.0f, 1633.0f};
+        b->nb = 8;
+        b->nsf = 17 + ((b->tp.filter_dialtone)  ?  4  :  0);
+        b->block_len = 102;
+        for (int i = 0;  i < 8;  i++)
+            b->fac[i] = spangpu_goertzel_fac(freqs[i]);
+        b->threshold = 171029200.0f;
+        b->normal_twist = 6.309f;
+        b->reverse_twist = 2.512f;
+        // dtmf_rx_parms(), dtmf.c:421-445.  A zeroed params struct keeps the defaults.
+        if (params)
+        {
+            if (b->tp.twist_db > 0.0f)
+                b->normal_twist = powf(10.0f, b->tp.twist_db/10.0f);
+            if (b->tp.reverse_twist_db > 0.0f)
+                b->reverse_twist = powf(10.0f, b->tp.reverse_twist_db/10.0f);
+            if (b->tp.threshold_dbm0 > -99.0f  &&  b->tp.threshold_dbm0 != 0.0f)
+                b->threshold = (float) ((102*102*32768.0f*32768.0f/2.0f)*powf(10.0f, (b->tp.threshold_dbm0 - 3.14f)/10.0f));
+        }
+        break;
+    }
+    case SPANGPU_BELL_MF:
+    {
+        static const int freqs[6] = {700, 900, 1100, 1300, 1500, 1700};         // bell_r2_mf.c:251-254
+        b->nb = 6;
+        b->nsf = 12;
+        b->block_len = 120;
+        for (int i = 0;  i < 6;  i++)
+            b->fac[i] = spangpu_goertzel_fac((float) freqs[i]);
+        break;
+    }
+    case SPANGPU_R2_MF:
+    {
+        static const int fwd[6] = {1380, 1500, 1620, 1740, 1860, 1980};         // bell_r2_mf.c:264-267
+        static const int back[6] = {1140, 1020, 900, 780, 660, 540};            // bell_r2_mf.c:269-272
+        b->nb = 6;
+        b->nsf = 12;
+        b->block_len = 133;
+        for (int i = 0;  i < 6;  i++)
+            b->fac[i] = spangpu_goertzel_fac((float) ((b->tp.r2_fwd)  ?  fwd[i]  :  back[i]));
+        break;
+    }
+    case SPANGPU_SUPER_TONE:
+    case SPANGPU_GOERTZEL:
+    {
+        const int m = b->tp.n_bins;
+        if (m < ((kind == SPANGPU_SUPER_TONE)  ?  2  :  1)  ||  m > SPANGPU_MAX_BINS)
+        {
+            free(b);
+            return fail(SPANGPU_ERR_BAD_ARG, "n_bins %d out of range", m);
+        }
+        b->nb = (m <= 4)  ?  4  :  (m <= 8)  ?  8  :  (m <= 12)  ?  12  :  16;
+        b->nsf = 2*b->nb + ((kind == SPANGPU_SUPER_TONE)  ?  1  :  0);
+        b->block_len = (kind == SPANGPU_SUPER_TONE)  ?  128  :  b->tp.block_len;
+        if (b->block_len <= 0  ||  b->block_len > 65535)
+        {
+            free(b);
+            return fail(SPANGPU_ERR_BAD_ARG, "block_len %d out of range", b->block_len);
+        }
+        for (int i = 0;  i < m;  i++)
+            b->fac[i] = b->tp.bin_fac[i];
+        break;
+    }
+    default:
+        free(b);
+        return fail(SPANGPU_ERR_UNSUPPORTED, "bank kind %d not available from this entry point", kind);
+    }
+
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e != hipSuccess)
+    {
+        free(b);
+        return fail(SPANGPU_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    b->own_stream = true;
+    const size_t nf = (size_t) b->nsf*b->n_ch;
+    if (hipMalloc(&b->sf, nf*sizeof(float)) != hipSuccess
+        ||  hipMalloc(&b->si, (size_t) 2*b->n_ch*sizeof(int32_t)) != hipSuccess)
+    {
+        spangpu_bank_destroy(b);
+        return fail(SPANGPU_ERR_NO_MEMORY, "hipMalloc of bank state failed");
+    }
+    (void) hipMemsetAsync(b->sf, 0, nf*sizeof(float), b->stream);
+    (void) hipMemsetAsync(b->si, 0, (size_t) 2*b->n_ch*sizeof(int32_t), b->stream);
+    (void) hipEventCreate(&b->ev0);
+    (void) hipEventCreate(&b->ev1);
+    (void) hipStreamSynchronize(b->stream);
+    *bank = b;
+    return SPANGPU_OK;
+}
+
+int spangpu_bank_destroy(spangpu_bank_t *b)
+{
+    if (b == nullptr)
+        return SPANGPU_OK;
+    (void) hipSetDevice(b->device);
+    if (b->stream)
+        (void) hipStreamSynchronize(b->stream);
+    free_outputs(b);
+    if (b->sf) (void) hipFree(b->sf);
+    if (b->si) (void) hipFree(b->si);
+    if (b->d_amp) (void) hipFree(b->d_amp);
+    if (b->ev0) (void) hipEventDestroy(b->ev0);
+    if (b->ev1) (void) hipEventDestroy(b->ev1);
+    if (b->own_stream  &&  b->stream)
+        (void) hipStreamDestroy(b->stream);
+    free(b);
+    return SPANGPU_OK;
+}
+
+int spangpu_bank_kind(const spangpu_bank_t *b) { return b  ?  b->kind  :  SPANGPU_ERR_BAD_ARG; }
+int spangpu_bank_channels(const spangpu_bank_t *b) { return b  ?  b->n_ch  :  SPANGPU_ERR_BAD_ARG; }
+
+int spangpu_bank_set_stream(spangpu_bank_t *b, void *hip_stream)
+{
+    if (b == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "null bank");
+    (void) hipStreamSynchronize(b->stream);
+    if (b->own_stream)
+        (void) hipStreamDestroy(b->stream);
+    if (hip_stream)
+    {
+        b->stream = (hipStream_t) hip_stream;
+        b->own_stream = false;
+    }
+    else
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        b->own_stream = true;
+    }
+    return SPANGPU_OK;
+}
+
+int spangpu_bank_set_timing(spangpu_bank_t *b, int on)
+{
+    if (b == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "null bank");
+    b->timing = (on != 0);
+    return SPANGPU_OK;
+}
+
+int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, int samples, long long stride)
+{
+    if (b == nullptr  ||  amp == nullptr  ||  samples < 0)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (layout != SPANGPU_LAYOUT_CHANNEL_MAJOR  &&  layout != SPANGPU_LAYOUT_SAMPLE_MAJOR)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad layout");
+    if (samples == 0)
+        return 0;
+    HIP_TRY(hipSetDevice(b->device));
+    if (stride <= 0)
+        stride = (layout == SPANGPU_LAYOUT_CHANNEL_MAJOR)  ?  samples  :  b->n_ch;
+
+    const int maxb = (samples + b->block_len - 1)/b->block_len;
+    int rc = ensure_outputs(b, (maxb > 0)  ?  maxb  :  1);
+    if (rc != SPANGPU_OK)
+        return rc;
+
+    const int16_t *d_amp = amp;
+    long long d_stride = stride;
+    if (mem == SPANGPU_MEM_HOST)
+    {
+        if (layout == SPANGPU_LAYOUT_CHANNEL_MAJOR)
+        {
+            const long long padded = (samples + 7) & ~7LL;
+            const size_t need = (size_t) padded*b->n_ch + 8;
+            if (need > b->d_amp_cap)
+            {
+                if (b->d_amp) (void) hipFree(b->d_amp);
+                b->d_amp = nullptr;
+                b->d_amp_cap = 0;
+                HIP_TRY(hipMalloc(&b->d_amp, need*sizeof(int16_t)));
+                b->d_amp_cap = need;
+            }
+            HIP_TRY(hipMemcpy2DAsync(b->d_amp, padded*sizeof(int16_t), amp, stride*sizeof(int16_t),
+                                     samples*sizeof(int16_t), b->n_ch, hipMemcpyHostToDevice, b->stream));
+            d_stride = padded;
+        }
+        else
+        {
+            const size_t need = (size_t) samples*b->n_ch + 8;
+            if (need > b->d_amp_cap)
+            {
+                if (b->d_amp) (void) hipFree(b->d_amp);
+                b->d_amp = nullptr;
+                b->d_amp_cap = 0;
+                HIP_TRY(hipMalloc(&b->d_amp, need*sizeof(int16_t)));
+                b->d_amp_cap = need;
+            }
+            HIP_TRY(hipMemcpy2DAsync(b->d_amp, b->n_ch*sizeof(int16_t), amp, stride*sizeof(int16_t),
+                                     b->n_ch*sizeof(int16_t), samples, hipMemcpyHostToDevice, b->stream));
+            d_stride = b->n_ch;
+        }
+        d_amp = b->d_amp;
+    }
+    else if (mem != SPANGPU_MEM_DEVICE)
+    {
+        return fail(SPANGPU_ERR_BAD_ARG, "bad mem kind");
+    }
+
+    ToneLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.amp = d_amp;
+    L.stride = d_stride;
+    L.samples = samples;
+    L.n_ch = b->n_ch;
+    L.layout = layout;
+    L.aligned16 = (layout == SPANGPU_LAYOUT_CHANNEL_MAJOR
+                   &&  (((uintptr_t) d_amp) & 15) == 0
+                   &&  (d_stride & 7) == 0
+                   &&  d_stride >= ((samples + 7) & ~7))  ?  1  :  0;
+    L.sf = b->sf;
+    L.si = b->si;
+    L.rec = b->rec;
+    L.rec_energy = b->rec_energy;
+    L.rec_dur = b->rec_dur;
+    L.trace = b->trace;
+    L.maxb = maxb;
+    L.nbins = (b->kind == SPANGPU_SUPER_TONE  ||  b->kind == SPANGPU_GOERTZEL)  ?  b->tp.n_bins  :  b->nb;
+    L.block_len = b->block_len;
+    L.realtime = (b->kind == SPANGPU_DTMF  &&  b->tp.report_mode == SPANGPU_REPORT_REALTIME)  ?  1  :  0;
+    for (int i = 0;  i < kMaxBins;  i++)
+        L.fac[i] = b->fac[i];
+    L.threshold = b->threshold;
+    L.normal_twist = b->normal_twist;
+    L.reverse_twist = b->reverse_twist;
+
+    if (b->timing)
+        HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    switch (b->kind)
+    {
+    case SPANGPU_DTMF:
+        if (b->tp.filter_dialtone)
+            launch_tone<DtmfDet<true>>(L, b->stream);
+        else
+            launch_tone<DtmfDet<false>>(L, b->stream);
+        break;
+    case SPANGPU_BELL_MF:
+        launch_tone<BellMfDet>(L, b->stream);
+        break;
+    case SPANGPU_R2_MF:
+        launch_tone<R2MfDet>(L, b->stream);
+        break;
+    case SPANGPU_SUPER_TONE:
+        switch (b->nb)
+        {
+        case 4:  launch_tone<MultiDet<4, true>>(L, b->stream);  break;
+        case 8:  launch_tone<MultiDet<8, true>>(L, b->stream);  break;
+        case 12: launch_tone<MultiDet<12, true>>(L, b->stream); break;
+        default: launch_tone<MultiDet<16, true>>(L, b->stream); break;
+        }
+        break;
+    case SPANGPU_GOERTZEL:
+        switch (b->nb)
+        {
+        case 4:  launch_tone<MultiDet<4, false>>(L, b->stream);  break;
+        case 8:  launch_tone<MultiDet<8, false>>(L, b->stream);  break;
+        case 12: launch_tone<MultiDet<12, false>>(L, b->stream); break;
+        default: launch_tone<MultiDet<16, false>>(L, b->stream); break;
+        }
+        break;
+    default:
+        return fail(SPANGPU_ERR_UNSUPPORTED, "kind %d", b->kind);
+    }
+    HIP_TRY(hipGetLastError());
+    if (b->timing)
+    {
+        HIP_TRY(hipEventRecord(b->ev1, b->stream));
+        b->ev_valid = true;
+    }
+    b->last_maxb = maxb;
+    b->last_samples = samples;
+    return 0;
+}
+
+int spangpu_bank_sync(spangpu_bank_t *b)
+{
+    if (b == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "null bank");
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return SPANGPU_OK;
+}
+
+float spangpu_bank_last_kernel_ms(spangpu_bank_t *b)
+{
+    float ms = -1.0f;
+    if (b == nullptr  ||  !b->ev_valid)
+        return -1.0f;
+    if (hipEventSynchronize(b->ev1) != hipSuccess)
+        return -1.0f;
+    if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess)
+        return -1.0f;
+    return ms;
+}
+
+int spangpu_bank_blocks(spangpu_bank_t *b, spangpu_block_t *out, int max)
+{
+    if (b == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "null bank");
+    if (b->last_maxb <= 0)
+        return 0;
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t n = (size_t) b->last_maxb*b->n_ch;
+    HIP_TRY(hipMemcpyAsync(b->h_rec, b->rec, n*sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    if (b->rec_energy)
+        HIP_TRY(hipMemcpyAsync(b->h_energy, b->rec_energy, n*sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    if (b->rec_dur)
+        HIP_TRY(hipMemcpyAsync(b->h_dur, b->rec_dur, n*sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    int count = 0;
+    const bool bias = (b->kind == SPANGPU_SUPER_TONE);
+    for (int ch = 0;  ch < b->n_ch;  ch++)
+    {
+        for (int k = 0;  k < b->last_maxb;  k++)
+        {
+            const size_t idx = (size_t) k*b->n_ch + ch;
+            const uint32_t r = b->h_rec[idx];
+            const int flags = (int) (r >> 16);
+            if (!(flags & SPANGPU_BLK_VALID))
+                continue;
+            if (out  &&  count < max)
+            {
+                spangpu_block_t *o = &out[count];
+                o->channel = ch;
+                o->block = k;
+                o->hit = (int) (r & 0xFF) - (bias  ?  1  :  0);
+                o->code = (int) ((r >> 8) & 0xFF) - (bias  ?  1  :  0);
+                o->flags = flags;
+                o->duration = (b->h_dur  &&  (flags & SPANGPU_BLK_REPORT))  ?  b->h_dur[idx]  :  0;
+                o->energy = (b->h_energy)  ?  b->h_energy[idx]  :  0.0f;
+            }
+            count++;
+        }
+    }
+    return count;
+}
+
+long long spangpu_bank_copy_records(spangpu_bank_t *b, void *dst_device, size_t dst_bytes)
+{
+    if (b == nullptr  ||  dst_device == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "null argument");
+    const size_t bytes = (size_t) b->last_maxb*b->n_ch*sizeof(uint32_t);
+    if (bytes > dst_bytes)
+        return fail(SPANGPU_ERR_BAD_ARG, "record buffer too small: need %zu bytes", bytes);
+    if (bytes == 0)
+        return 0;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(dst_device, b->rec, bytes, hipMemcpyDeviceToDevice, b->stream));
+    return (long long) bytes;
+}
+
+int spangpu_bank_trace(spangpu_bank_t *b, float *energies, size_t max_floats)
+{
+    if (b == nullptr  ||  energies == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "null argument");
+    if (b->trace == nullptr)
+        return fail(SPANGPU_ERR_STATE, "bank was created without trace");
+    const size_t n = (size_t) b->last_maxb*(b->nb + 1)*b->n_ch;
+    if (n > max_floats)
+        return fail(SPANGPU_ERR_BAD_ARG, "trace buffer too small: need %zu floats", n);
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(energies, b->trace, n*sizeof(float), hipMemcpyDeviceToHost));
+    return b->last_maxb;
+}
+
+int spangpu_bank_bins(const spangpu_bank_t *b)
+{
+    return b  ?  b->nb  :  SPANGPU_ERR_BAD_ARG;
+}
+
+// State import/export: fstate[nsf] in device order (v2[nb], v3[nb], [energy], [z350[2], z440[2]]),
+// istate[4] = {current_sample, w0 byte 2, w0 byte 3, w1}.
+int spangpu_bank_get_state(spangpu_bank_t *b, int channel, float *fstate, int max_f, int32_t *istate, int max_i)
+{
+    if (b == nullptr  ||  channel < 0  ||  channel >= b->n_ch  ||  max_f < b->nsf  ||  max_i < 4)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy2D(fstate, sizeof(float), b->sf + channel, (size_t) b->n_ch*sizeof(float),
+                        sizeof(float), b->nsf, hipMemcpyDeviceToHost));
+    int32_t w[2];
+    HIP_TRY(hipMemcpy2D(w, sizeof(int32_t), b->si + channel, (size_t) b->n_ch*sizeof(int32_t),
+                        sizeof(int32_t), 2, hipMemcpyDeviceToHost));
+    istate[0] = w[0] & 0xFFFF;
+    istate[1] = (w[0] >> 16) & 0xFF;
+    istate[2] = (w[0] >> 24) & 0xFF;
+    istate[3] = w[1];
+    return b->nsf;
+}
+
+int spangpu_bank_set_state(spangpu_bank_t *b, int channel, const float *fstate, int n_f, const int32_t *istate, int n_i)
+{
+    if (b == nullptr  ||  channel < 0  ||  channel >= b->n_ch  ||  n_f != b->nsf  ||  n_i != 4)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy2D(b->sf + channel, (size_t) b->n_ch*sizeof(float), fstate, sizeof(float),
+                        sizeof(float), b->nsf, hipMemcpyHostToDevice));
+    int32_t w[2];
+    w[0] = (istate[0] & 0xFFFF) | ((istate[1] & 0xFF) << 16) | ((int32_t) ((uint32_t) (istate[2] & 0xFF) << 24));
+    w[1] = istate[3];
+    HIP_TRY(hipMemcpy2D(b->si + channel, (size_t) b->n_ch*sizeof(int32_t), w, sizeof(int32_t),
+                        sizeof(int32_t), 2, hipMemcpyHostToDevice));
+    return SPANGPU_OK;
+}
+
+int spangpu_bank_reset_channel(spangpu_bank_t *b, int channel, int fillin_only)
+{
+    if (b == nullptr  ||  channel < 0  ||  channel >= b->n_ch)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    float f[64];
+    int32_t w[4];
+    int rc = spangpu_bank_get_state(b, channel, f, 64, w, 4);
+    if (rc < 0)
+        return rc;
+    // Goertzel states, block energy and block position always restart (dtmf.c:363-379);
+    // a full reset also clears the filters and the hit history (dtmf.c:447-504).
+    const int nclear = (fillin_only)  ?  (2*b->nb + ((b->nsf > 2*b->nb)  ?  1  :  0))  :  b->nsf;
+    for (int i = 0;  i < nclear;  i++)
+        f[i] = 0.0f;
+    w[0] = 0;
+    if (!fillin_only)
+        w[1] = w[2] = w[3] = 0;
+    return spangpu_bank_set_state(b, channel, f, b->nsf, w, 4);
+}
+
+}   // extern "C"

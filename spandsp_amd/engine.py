@@ -1,0 +1,185 @@
+"""ctypes harness over libspangpu.so (include/spangpu.h).
+
+Plumbing only: every call goes to the HIP library; nothing is computed here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libspangpu.so")
+
+# include/spangpu.h
+DTMF, BELL_MF, R2_MF, SUPER_TONE, GOERTZEL, V29, V27TER, V17, ECHO = range(1, 10)
+MEM_HOST, MEM_DEVICE = 0, 1
+CHANNEL_MAJOR, SAMPLE_MAJOR = 0, 1
+REPORT_DIGITS, REPORT_REALTIME = 0, 2
+BLK_VALID, BLK_CHANGE, BLK_REPORT, BLK_TONE_OFF = 1, 2, 4, 8
+MAX_BINS = 16
+
+BLOCK_DTYPE = np.dtype([("channel", "<i4"), ("block", "<i4"), ("hit", "<i4"), ("code", "<i4"),
+                        ("flags", "<i4"), ("duration", "<i4"), ("energy", "<f4")])
+
+
+class ToneParams(C.Structure):
+    _fields_ = [("report_mode", C.c_int32), ("filter_dialtone", C.c_int32),
+                ("twist_db", C.c_float), ("reverse_twist_db", C.c_float), ("threshold_dbm0", C.c_float),
+                ("r2_fwd", C.c_int32), ("n_bins", C.c_int32), ("block_len", C.c_int32),
+                ("bin_fac", C.c_float*MAX_BINS), ("trace", C.c_int32)]
+
+
+class SpanGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("spangpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libspangpu.so; raise loudly if it is missing (there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, ci, cf, ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+        sigs = {
+            "spangpu_device_count": (ci, []),
+            "spangpu_last_error": (C.c_char_p, []),
+            "spangpu_version": (C.c_char_p, []),
+            "spangpu_goertzel_fac": (cf, [cf]),
+            "spangpu_bank_create": (ci, [C.POINTER(vp), ci, ci, ci, vp, C.c_size_t]),
+            "spangpu_bank_destroy": (ci, [vp]),
+            "spangpu_bank_kind": (ci, [vp]),
+            "spangpu_bank_channels": (ci, [vp]),
+            "spangpu_bank_set_stream": (ci, [vp, vp]),
+            "spangpu_bank_rx": (ci, [vp, vp, ci, ci, ci, ll]),
+            "spangpu_bank_sync": (ci, [vp]),
+            "spangpu_bank_blocks": (ci, [vp, vp, ci]),
+            "spangpu_bank_trace": (ci, [vp, vp, C.c_size_t]),
+            "spangpu_bank_copy_records": (ll, [vp, vp, C.c_size_t]),
+            "spangpu_bank_reset_channel": (ci, [vp, ci, ci]),
+            "spangpu_bank_get_state": (ci, [vp, ci, vp, ci, vp, ci]),
+            "spangpu_bank_set_state": (ci, [vp, ci, vp, ci, vp, ci]),
+            "spangpu_bank_last_kernel_ms": (cf, [vp]),
+            "spangpu_bank_set_timing": (ci, [vp, ci]),
+            "spangpu_bank_bins": (ci, [vp]),
+        }
+        for name, (res, args) in sigs.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise SpanGpuError(rc, lib().spangpu_last_error().decode("latin1"))
+    return rc
+
+
+def device_count():
+    return lib().spangpu_device_count()
+
+
+def goertzel_fac(freq):
+    return lib().spangpu_goertzel_fac(freq)
+
+
+class ToneBank:
+    """N channels of one tone detector kind, state resident in HBM."""
+
+    def __init__(self, kind, n_channels, device=0, report_mode=REPORT_DIGITS, filter_dialtone=False,
+                 twist_db=0.0, reverse_twist_db=0.0, threshold_dbm0=0.0, r2_fwd=True,
+                 bin_fac=None, block_len=0, trace=False):
+        p = ToneParams()
+        p.report_mode = report_mode
+        p.filter_dialtone = int(filter_dialtone)
+        p.twist_db = twist_db
+        p.reverse_twist_db = reverse_twist_db
+        p.threshold_dbm0 = threshold_dbm0
+        p.r2_fwd = int(r2_fwd)
+        if bin_fac is not None:
+            p.n_bins = len(bin_fac)
+            for i, f in enumerate(bin_fac):
+                p.bin_fac[i] = f
+        p.block_len = block_len
+        p.trace = int(trace)
+        self.kind = kind
+        self.n = n_channels
+        self.h = C.c_void_p()
+        _check(lib().spangpu_bank_create(C.byref(self.h), device, kind, n_channels, C.byref(p), C.sizeof(p)))
+        self.nbins = lib().spangpu_bank_bins(self.h)
+
+    def close(self):
+        if self.h:
+            lib().spangpu_bank_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(lib().spangpu_bank_set_stream(self.h, hip_stream))
+
+    def set_timing(self, on=True):
+        _check(lib().spangpu_bank_set_timing(self.h, int(on)))
+
+    def rx_host(self, frames, layout=CHANNEL_MAJOR):
+        """frames: int16 [n_channels, samples] (channel-major) or [samples, n_channels]."""
+        frames = np.ascontiguousarray(frames, dtype=np.int16)
+        if layout == CHANNEL_MAJOR:
+            assert frames.shape[0] == self.n
+            samples, stride = frames.shape[1], frames.shape[1]
+        else:
+            assert frames.shape[1] == self.n
+            samples, stride = frames.shape[0], frames.shape[1]
+        _check(lib().spangpu_bank_rx(self.h, frames.ctypes.data, MEM_HOST, layout, samples, stride))
+        # the H2D copy is queued asynchronously from pageable memory: keep the source alive until done
+        self.sync()
+
+    def rx_device(self, ptr, samples, stride=0, layout=CHANNEL_MAJOR):
+        _check(lib().spangpu_bank_rx(self.h, ptr, MEM_DEVICE, layout, samples, stride))
+
+    def sync(self):
+        _check(lib().spangpu_bank_sync(self.h))
+
+    def blocks(self):
+        n = _check(lib().spangpu_bank_blocks(self.h, None, 0))
+        out = np.zeros(n, BLOCK_DTYPE)
+        if n:
+            _check(lib().spangpu_bank_blocks(self.h, out.ctypes.data, n))
+        return out
+
+    def copy_records(self, dst_ptr, dst_bytes):
+        return _check(lib().spangpu_bank_copy_records(self.h, dst_ptr, dst_bytes))
+
+    def trace(self, max_blocks=8):
+        buf = np.zeros(max_blocks*(self.nbins + 1)*self.n, np.float32)
+        nb = _check(lib().spangpu_bank_trace(self.h, buf.ctypes.data, buf.size))
+        return buf[:nb*(self.nbins + 1)*self.n].reshape(nb, self.nbins + 1, self.n)
+
+    def get_state(self, channel):
+        f = np.zeros(64, np.float32)
+        i = np.zeros(4, np.int32)
+        nsf = _check(lib().spangpu_bank_get_state(self.h, channel, f.ctypes.data, 64, i.ctypes.data, 4))
+        return f[:nsf].copy(), i
+
+    def set_state(self, channel, f, i):
+        f = np.ascontiguousarray(f, np.float32)
+        i = np.ascontiguousarray(i, np.int32)
+        _check(lib().spangpu_bank_set_state(self.h, channel, f.ctypes.data, len(f), i.ctypes.data, len(i)))
+
+    def reset_channel(self, channel, fillin_only=False):
+        _check(lib().spangpu_bank_reset_channel(self.h, channel, int(fillin_only)))
+
+    def last_kernel_ms(self):
+        return lib().spangpu_bank_last_kernel_ms(self.h)

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (oracle/_ref/libspandsp_ref.so,
+compiled from /root/reference/src by oracle/Makefile).  Run in the dev container:
+
+    python tests/golden/make_golden.py
+
+Fixtures are data only: int16 input signals (produced by the reference's own
+transmitters / AWGN, or by tests/synth.py) and the reference receiver's outputs
+(state snapshots as uint32 words, event streams, digit strings)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import synth  # noqa: E402
+from oracle import ref  # noqa: E402
+from test_oracle_pin import ALL_FREQS, bits, build_st_desc, st_signal  # noqa: E402
+
+
+def save(name, **kw):
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **kw)
+    print("wrote", name, {k: getattr(v, "shape", v) for k, v in kw.items()})
+
+
+def main():
+    assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+    L = ref.lib()
+    save("goertzel_fac", freq=np.array(ALL_FREQS, np.float32),
+         fac_bits=np.array([bits([L.glue_goertzel_fac(f, 102)])[0] for f in ALL_FREQS], np.uint32))
+
+    sig = ref.dtmf_tx("123A456B789C*0#D")
+    x = ref.saturated_add(sig, ref.awgn(1234567, -30.0, len(sig)))
+    x = np.concatenate([x, synth.dtmf_channels(2, 8000, seed=7)[0][1]])
+    for name, mode, filt, chunk in [("dtmf_mode0", 0, 0, 160), ("dtmf_mode1", 1, 0, 37), ("dtmf_mode2", 2, 0, 160),
+                                    ("dtmf_filter", 0, 1, 160)]:
+        xx = x
+        r = ref.DtmfRx(mode)
+        if filt:
+            t = np.arange(len(x))
+            dial = 3000.0*np.sin(2*np.pi*350.0*t/8000.0) + 3000.0*np.sin(2*np.pi*440.0*t/8000.0)
+            xx = np.clip(x + dial, -32768, 32767).astype(np.int16)
+            r.parms(1, 9.0, 5.0, -39.0)
+        snaps = []
+        for k in range(0, len(xx), chunk):
+            r.rx(xx[k:k + chunk])
+            s = r.snapshot()
+            snaps.append(np.concatenate([bits(s["v2"]), bits(s["v3"]), bits([s["energy"]]),
+                                         np.array([s["current_sample"], s["duration"], s["last_hit"], s["in_digit"]], np.uint32)]))
+        save(name, amp=xx, mode=mode, filter=filt, twist=9.0, reverse_twist=5.0, threshold=-39.0, chunk=chunk,
+             snapshots=np.stack(snaps), events=r.sink.events(), text=r.sink.text(), digits=r.get())
+
+    sig = ref.bell_mf_tx("*1234567890#ABC")
+    x = ref.saturated_add(sig, ref.awgn(7, -35.0, len(sig)))
+    r = ref.BellMfRx(1)
+    snaps = []
+    for k in range(0, len(x), 160):
+        r.rx(x[k:k + 160])
+        s = r.snapshot()
+        snaps.append(np.concatenate([bits(s["v2"]), bits(s["v3"]), np.array([s["current_sample"]], np.uint32)]))
+    save("bell_mf", amp=x, snapshots=np.stack(snaps), events=r.sink.events(), text=r.sink.text())
+
+    for fwd in (True, False):
+        sig = ref.r2_mf_tx("1234567890BCDEF", fwd)
+        x = ref.saturated_add(sig, ref.awgn(9, -40.0, len(sig)))
+        r = ref.R2MfRx(fwd)
+        snaps = []
+        for k in range(0, len(x), 160):
+            r.rx(x[k:k + 160])
+            s = r.snapshot()
+            snaps.append(np.concatenate([bits(s["v2"]), bits(s["v3"]), np.array([s["current_sample"]], np.uint32)]))
+        save("r2_mf_fwd" if fwd else "r2_mf_back", amp=x, snapshots=np.stack(snaps), events=r.sink.events())
+
+    x = st_signal()
+    d = build_st_desc(ref.SuperToneDesc)
+    r = ref.SuperToneRx(d, True)
+    for k in range(0, len(x), 160):
+        r.rx(x[k:k + 160])
+    save("super_tone", amp=x, fac_bits=bits(d.fac), events=r.sink.events())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""Seeded synthetic telephony signals for the parity tests (numpy, host side).
+
+Recipes follow SURVEY.md section 8(d): tone pairs at per-channel level / twist /
+frequency offset with AWGN, cadenced like the reference's transmitters
+(dtmf.c:67-69: 50 ms on / 55 ms off; bell_r2_mf.c:105-124: 68 ms on / 68 ms off).
+"""
+import numpy as np
+
+DTMF_KEYS = "123A456B789C*0#D"
+DTMF_ROW = [697.0, 770.0, 852.0, 941.0]
+DTMF_COL = [1209.0, 1336.0, 1477.0, 1633.0]
+BELL_FREQS = [700.0, 900.0, 1100.0, 1300.0, 1500.0, 1700.0]
+R2_FWD = [1380.0, 1500.0, 1620.0, 1740.0, 1860.0, 1980.0]
+R2_BACK = [1140.0, 1020.0, 900.0, 780.0, 660.0, 540.0]
+
+
+def dbm0_to_amp(db):
+    # a 3.14 dBm0 sine has peak 32768 (telephony.h:129); amplitude = peak
+    return 32768.0*np.power(10.0, (np.asarray(db) - 3.14)/20.0)
+
+
+def _finish(x):
+    return np.clip(np.trunc(x), -32768, 32767).astype(np.int16)
+
+
+def tone_pair_channels(n_ch, n_samples, pairs, seed, on=400, off=440, level_db=(-25.0, -7.0),
+                       twist_db=(-4.0, 8.0), freq_off=0.015, noise_db=(-50.0, -25.0), quiet_fraction=0.25):
+    """Generic cadenced two-tone generator.
+
+    pairs: list of (f_low, f_high) tuples a channel may send.  Returns (int16
+    [n_ch, n_samples], keys [n_ch, n_symbols] indices into pairs (-1 = silent channel)).
+    """
+    rng = np.random.default_rng(seed)
+    period = on + off
+    n_sym = n_samples//period + 2
+    t = np.arange(n_samples, dtype=np.float64)
+    keys = rng.integers(0, len(pairs), size=(n_ch, n_sym))
+    start = rng.integers(0, period, size=n_ch)
+    lvl = rng.uniform(level_db[0], level_db[1], size=n_ch)
+    tw = rng.uniform(twist_db[0], twist_db[1], size=n_ch)
+    fo = rng.uniform(-freq_off, freq_off, size=(n_ch, 2))
+    nz = rng.uniform(noise_db[0], noise_db[1], size=n_ch)
+    quiet = rng.uniform(size=n_ch) < quiet_fraction
+    out = np.zeros((n_ch, n_samples), np.int16)
+    pl = np.array([p[0] for p in pairs])
+    ph = np.array([p[1] for p in pairs])
+    for c in range(n_ch):
+        rel = t - start[c]
+        sym = np.floor(rel/period).astype(np.int64)
+        inside = (rel >= 0) & ((rel - sym*period) < on)
+        sym = np.clip(sym, 0, n_sym - 1)
+        k = keys[c][sym]
+        f1 = pl[k]*(1.0 + fo[c, 0])
+        f2 = ph[k]*(1.0 + fo[c, 1])
+        a_lo = dbm0_to_amp(lvl[c])
+        a_hi = dbm0_to_amp(lvl[c] - tw[c])      # positive twist: low tone stronger
+        x = a_lo*np.sin(2.0*np.pi*f1*t/8000.0) + a_hi*np.sin(2.0*np.pi*f2*t/8000.0 + 1.0)
+        x = np.where(inside & (not quiet[c]), x, 0.0)
+        sigma = dbm0_to_amp(nz[c])/np.sqrt(2.0)
+        x = x + rng.normal(0.0, sigma, size=n_samples)
+        out[c] = _finish(x)
+        if quiet[c]:
+            keys[c] = -1
+    return out, keys
+
+
+def dtmf_channels(n_ch, n_samples, seed):
+    pairs = [(DTMF_ROW[i >> 2], DTMF_COL[i & 3]) for i in range(16)]
+    return tone_pair_channels(n_ch, n_samples, pairs, seed)
+
+
+def bell_mf_channels(n_ch, n_samples, seed):
+    pairs = [(BELL_FREQS[i], BELL_FREQS[j]) for i in range(6) for j in range(i + 1, 6)]
+    return tone_pair_channels(n_ch, n_samples, pairs, seed, on=544, off=544, level_db=(-20.0, -5.0),
+                              twist_db=(-4.0, 4.0), noise_db=(-55.0, -35.0))
+
+
+def r2_mf_channels(n_ch, n_samples, seed, fwd=True):
+    fr = R2_FWD if fwd else R2_BACK
+    pairs = [(fr[i], fr[j]) for i in range(6) for j in range(i + 1, 6)]
+    return tone_pair_channels(n_ch, n_samples, pairs, seed, on=800, off=480, level_db=(-25.0, -5.0),
+                              twist_db=(-5.0, 5.0), noise_db=(-55.0, -35.0))
+
+
+def call_progress_channels(n_ch, n_samples, seed):
+    """Cadenced call-progress tones for the super-tone detector (single and dual)."""
+    pairs = [(400.0, 0.0), (1100.0, 0.0), (350.0, 440.0), (480.0, 620.0), (440.0, 480.0), (950.0, 0.0)]
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_samples, dtype=np.float64)
+    out = np.zeros((n_ch, n_samples), np.int16)
+    for c in range(n_ch):
+        k = rng.integers(0, len(pairs))
+        on = int(rng.integers(1600, 6400))
+        off = int(rng.integers(0, 6400))
+        start = int(rng.integers(0, 2000))
+        rel = t - start
+        inside = (rel >= 0) & ((rel % (on + off)) < on)
+        a = dbm0_to_amp(rng.uniform(-30.0, -8.0))
+        f1, f2 = pairs[k]
+        x = a*np.sin(2.0*np.pi*f1*t/8000.0)
+        if f2 > 0.0:
+            x = x + a*np.sin(2.0*np.pi*f2*t/8000.0 + 0.5)
+        x = np.where(inside, x, 0.0)
+        x = x + rng.normal(0.0, dbm0_to_amp(rng.uniform(-60.0, -40.0))/np.sqrt(2.0), size=n_samples)
+        out[c] = _finish(x)
+    return out

