@@ -176,7 +176,11 @@ def main():
     torch.cuda.synchronize()
 
     bank = engine.ToneBank(engine.DTMF, n_ch, device=local_rank)
-    stream = torch.cuda.current_stream()
+    # A dedicated (non-null) torch stream carries every launch, event and collective of the
+    # timed region, so torch.cuda.Event timing sees exactly the stream the kernels run on.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
     gather = ResultGather(world, rank, n_ch, max_blocks=2, device=dev) if world > 1 else None
     frame_bytes = n_ch*FRAME*2

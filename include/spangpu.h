@@ -117,6 +117,10 @@ SPANGPU_API int spangpu_device_count(void);
 SPANGPU_API const char *spangpu_last_error(void);
 SPANGPU_API const char *spangpu_version(void);
 SPANGPU_API float spangpu_goertzel_fac(float freq_hz);
+/* Tuning knob for the tone banks: lanes per channel used by the kernels (results are
+   identical): 1 = one channel per lane, 2 = a channel's bins split over two lanes (more
+   wavefronts for small banks), 0 = choose from the bank size (default). */
+SPANGPU_API int spangpu_tune_lanes_per_channel(int lpc);
 
 /* ---- banks ------------------------------------------------------------------------ */
 SPANGPU_API int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_channels,

@@ -78,15 +78,48 @@ struct spangpu_bank_s
     bool ev_valid;
 };
 
+// Lanes per channel: 2 while the bank is too small to put >= 4 one-channel-per-lane waves
+// on every SIMD (1024 SIMDs x 64 lanes x 4), else 1.  SPANGPU_LPC=1|2 overrides (tuning).
+static int g_forced_lpc = -1;
+
+static int pick_lpc(int n_ch)
+{
+    if (g_forced_lpc < 0)
+    {
+        const char *e = getenv("SPANGPU_LPC");
+        g_forced_lpc = (e  &&  (e[0] == '1'  ||  e[0] == '2'))  ?  (e[0] - '0')  :  0;
+    }
+    if (g_forced_lpc)
+        return g_forced_lpc;
+    return (n_ch < 262144)  ?  2  :  1;
+}
+
 template <class Det>
 static void launch_tone(const ToneLaunch &L, hipStream_t st)
 {
-    const int waves = (L.n_ch + kWave - 1)/kWave;
-    const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
-    hipLaunchKernelGGL(tone_bank_kernel<Det>, dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
+    if (pick_lpc(L.n_ch) == 2)
+    {
+        const int waves = (L.n_ch + 31)/32;
+        const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
+        hipLaunchKernelGGL((tone_bank_kernel<Det, 2>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
+    }
+    else
+    {
+        const int waves = (L.n_ch + kWave - 1)/kWave;
+        const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
+        hipLaunchKernelGGL((tone_bank_kernel<Det, 1>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
+    }
 }
 
 extern "C" {
+
+int spangpu_tune_lanes_per_channel(int lpc)
+{
+    if (lpc != 0  &&  lpc != 1  &&  lpc != 2)
+        return fail(SPANGPU_ERR_BAD_ARG, "lanes per channel must be 0 (auto), 1 or 2");
+    g_forced_lpc = lpc;
+    return SPANGPU_OK;
+}
 
 int spangpu_device_count(void)
 {
@@ -193,7 +226,7 @@ int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_chann
         // dtmf.c:104-119
         static const float freqs[8] = {697.0f, 770.0f, 852.0f, 941.0f, 1209.0f, 1336.0f, 1477.0f, 1633.0f};
         b->nb = 8;
-        b->nsf = 17 + ((b->tp.filter_dialtone)  ?  4  :  0);
+        b->nsf = 21;     // v2[8] v3[8] energy z350[2] z440[2] (filter words unused when the notch is off)
         b->block_len = 102;
         for (int i = 0;  i < 8;  i++)
             b->fac[i] = spangpu_goertzel_fac(freqs[i]);

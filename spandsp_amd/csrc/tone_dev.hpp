@@ -2,18 +2,27 @@
 // decisions and the LDS-staged frame walker shared by the DTMF / Bell MF / R2 MF /
 // super-tone / generic Goertzel bank kernels (gfx950, wave64).
 //
-// Mapping: ONE CHANNEL PER LANE.  A wavefront owns 64 consecutive channels; their
-// 2*NB recurrence registers stay in VGPRs for the whole frame.  PCM arrives
-// channel-major (amp[ch][samples], what spandsp callers hold), so a wave's tile is
-// one contiguous HBM region; it is fetched with 16-byte coalesced loads, 32 samples
-// (64 B per channel) at a time, and transposed through a per-wave LDS tile with a
-// 17-dword row pitch so the per-lane row reads are bank-conflict free.  The taps
-// (2cos(w)) are wave-uniform and live in SGPRs.  No MFMA: the work is 8 (or 6, or
-// M) independent 3-op recurrences per sample per channel.
+// Mapping.  LPC = lanes per channel.
+//   LPC = 1: one channel per lane, a wavefront owns 64 consecutive channels and all
+//            NB bins of each (the throughput mapping: least VALU work per sample).
+//   LPC = 2: a wavefront owns 32 channels; lanes 0-31 run the first half of the bins
+//            (DTMF: the four row tones), lanes 32-63 the second half (the column
+//            tones).  Twice the wavefronts for the same bank, so a 65 536-channel bank
+//            puts 2 waves on every SIMD instead of 1.  On CDNA4 a lone wave issues at
+//            most one instruction per ~4 cycles whatever its type (measured: 50 % VALU
+//            activity, every SALU/LDS instruction serialised behind the VALU stream);
+//            a second resident wave overlaps them.  The halves exchange their block
+//            energies with one cross-lane swap per bin at block end.
+// The 2*bins recurrence registers stay in VGPRs for the whole frame.  PCM arrives
+// channel-major (amp[ch][samples], what spandsp callers hold); it is staged HBM -> LDS
+// by LDS-DMA in 80-sample segments, double buffered, and each lane walks its own row
+// (see "Frame staging").  No MFMA: the work is independent 3-op recurrences, issued
+// as v_pk_mul_f32 / v_pk_add_f32 pairs.
 //
 // Numerics: every multiply and add is rounded separately, in the reference's order
-// (this translation unit is compiled with -ffp-contract=off), so all float state and
-// all decisions are bit-identical to the reference's strict-IEEE build:
+// (this translation unit is compiled with -ffp-contract=off; packed ops round each half
+// independently), so all float state and all decisions are bit-identical to the
+// reference's strict-IEEE build:
 //   recurrence   v3' = (fac*v2 - v1) + x                 src/spandsp/tone_detect.h:172-192
 //   block result 2*((v3*v3 + v2*v2) - (v2*v3)*fac)      src/tone_detect.c:160-205
 #pragma once
@@ -26,8 +35,6 @@ namespace spg {
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
-constexpr int kSegSamples = 32;             // samples staged per LDS tile (64 B per channel)
-constexpr int kRowPitch = 17;               // dwords per LDS row: 16 data + 1 pad (odd => conflict-free)
 constexpr int kMaxBins = 16;
 
 // Kernel argument block (passed by value; lives in SGPRs / kernarg segment).
@@ -38,7 +45,7 @@ struct ToneLaunch
     int samples;                // samples per channel in this call
     int n_ch;
     int layout;                 // 0 channel-major, 1 sample-major
-    int aligned16;              // channel-major rows are 16-byte aligned (fast coalesced loader)
+    int aligned16;              // channel-major rows are 16-byte aligned and padded to 8 samples (LDS-DMA loader)
     float *sf;                  // float state  [NSF][n_ch]
     int32_t *si;                // int state    [2][n_ch]
     uint32_t *rec;              // block records [maxb][n_ch]
@@ -55,46 +62,63 @@ struct ToneLaunch
     float reverse_twist;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // ---------------------------------------------------------------------------------
-// Per-lane filter bank state
+// Per-lane filter bank state: NBL bins held as NBL/2 packed pairs.  One step is
+// written in three phases (all products, all subtractions, all additions) separated
+// by scheduling barriers: left alone, hipcc's scheduler serialises one bin pair across
+// several samples, so every packed op waits on its predecessor.
 // ---------------------------------------------------------------------------------
-template <int NB>
+template <int NBL>
 struct Bank
 {
-    float v2[NB];
-    float v3[NB];
+    static constexpr int NP = NBL/2;
+    static_assert((NBL & 1) == 0, "bins are processed in packed pairs");
+    f32x2 a[NP];            // v2 pairs
+    f32x2 b[NP];            // v3 pairs
 
-    __device__ __forceinline__ void step(const float (&fac)[NB], float x)
+    __device__ __forceinline__ float v2(int i) const { return (i & 1)  ?  a[i >> 1].y  :  a[i >> 1].x; }
+    __device__ __forceinline__ float v3(int i) const { return (i & 1)  ?  b[i >> 1].y  :  b[i >> 1].x; }
+    __device__ __forceinline__ void set_v2(int i, float v) { if (i & 1) a[i >> 1].y = v; else a[i >> 1].x = v; }
+    __device__ __forceinline__ void set_v3(int i, float v) { if (i & 1) b[i >> 1].y = v; else b[i >> 1].x = v; }
+
+    // tone_detect.h:172-192: v3' = (fac*v2 - v1) + x, all bins
+    __device__ __forceinline__ void step(const f32x2 (&fac)[NP], float x)
     {
+        const f32x2 xx = {x, x};
+        f32x2 t[NP];
 #pragma unroll
-        for (int i = 0;  i < NB;  i++)
+        for (int i = 0;  i < NP;  i++)
+            t[i] = fac[i]*b[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
+            t[i] = t[i] - a[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
         {
-            const float v1 = v2[i];
-            v2[i] = v3[i];
-            v3[i] = fac[i]*v2[i] - v1 + x;
+            a[i] = b[i];
+            b[i] = t[i] + xx;
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
-    // goertzel_result(): one zero sample, energy, reset (tone_detect.c:160-205)
-    __device__ __forceinline__ float finish(int i, float f)
-    {
-        const float v1 = v2[i];
-        const float a = v3[i];              // becomes v2
-        const float b = f*a - v1;           // becomes v3
-        float r = b*b + a*a - a*b*f;
-        r *= 2.0f;
-        v2[i] = 0.0f;
-        v3[i] = 0.0f;
-        return r;
-    }
-
-    __device__ __forceinline__ void reset()
+    // goertzel_result() for every bin: one zero sample, energy, reset (tone_detect.c:160-205)
+    __device__ __forceinline__ void finish(const f32x2 (&fac)[NP], float (&e)[NBL])
     {
 #pragma unroll
-        for (int i = 0;  i < NB;  i++)
+        for (int i = 0;  i < NP;  i++)
         {
-            v2[i] = 0.0f;
-            v3[i] = 0.0f;
+            const f32x2 p = b[i];               // becomes v2
+            const f32x2 q = fac[i]*p - a[i];    // becomes v3
+            f32x2 r = q*q + p*p - p*q*fac[i];
+            r *= 2.0f;
+            e[2*i] = r.x;
+            e[2*i + 1] = r.y;
+            a[i] = f32x2{0.0f, 0.0f};
+            b[i] = f32x2{0.0f, 0.0f};
         }
     }
 };
@@ -128,9 +152,20 @@ constexpr uint64_t pack8(const char *s)
 
 // ---------------------------------------------------------------------------------
 // Detector policies.  Each supplies: NB, NSF (floats of state per channel), whether a
-// block energy is accumulated, the optional input filter, and the block-end decision.
-// Integer state is two 32-bit words per channel: w0 = current_sample (16 bits) | ...
+// block energy is accumulated, the optional input filter, and the block-end decision
+// `decide()` over the NB Goertzel energies.  Integer state is two 32-bit words per
+// channel: w0 = current_sample (16 bits) | detector bytes, w1 = detector word.
+// `store` is false for lanes that must not write (shadow lanes; the second lane of a
+// channel when LPC = 2) -- they still update their private copy of w0/w1.
 // ---------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ void write_trace(const ToneLaunch &L, const float (&e)[NB], float total, int ch, int nb)
+{
+#pragma unroll
+    for (int i = 0;  i < NB;  i++)
+        L.trace[((size_t) nb*(NB + 1) + i)*L.n_ch + ch] = e[i];
+    L.trace[((size_t) nb*(NB + 1) + NB)*L.n_ch + ch] = total;
+}
 
 // ---- DTMF (src/dtmf.c:132-361) ------------------------------------------------------
 template <bool FILTER>
@@ -138,9 +173,8 @@ struct DtmfDet
 {
     static constexpr int NB = 8;
     static constexpr bool kEnergy = true;
-    static constexpr int kExtra = FILTER  ?  4  :  0;       // z350[2], z440[2]
-    static constexpr int NSF = 2*NB + 1 + kExtra;
-    static constexpr bool kRuntimeBlock = false;
+    static constexpr bool kDuration = true;
+    static constexpr int NSF = 2*NB + 1 + 4;                // v2, v3, energy, z350[2], z440[2]
     __device__ static __forceinline__ int block_len(const ToneLaunch &) { return 102; }    // dtmf.c:71
 
     float z[FILTER  ?  4  :  1];
@@ -182,22 +216,13 @@ struct DtmfDet
         return x;
     }
 
-    // Block end: energies, decision (dtmf.c:209-258), debounce (dtmf.c:304-347).
+    // Decision (dtmf.c:209-258) and debounce (dtmf.c:304-347).
     // w0 = cs | last_hit<<16 | in_digit<<24 ; w1 = duration.
-    __device__ __forceinline__ void block_end(const ToneLaunch &L, Bank<NB> &bk, float &energy,
-                                              uint32_t &w0, int32_t &w1, int ch, int nb, bool live)
+    __device__ __forceinline__ void decide(const ToneLaunch &L, const float (&e)[NB], float &energy,
+                                           uint32_t &w0, int32_t &w1, int ch, int nb, bool store)
     {
-        float e[NB];
-#pragma unroll
-        for (int i = 0;  i < NB;  i++)
-            e[i] = bk.finish(i, L.fac[i]);
-        if (L.trace  &&  live)
-        {
-#pragma unroll
-            for (int i = 0;  i < NB;  i++)
-                L.trace[((size_t) nb*(NB + 1) + i)*L.n_ch + ch] = e[i];
-            L.trace[((size_t) nb*(NB + 1) + NB)*L.n_ch + ch] = energy;
-        }
+        if (L.trace  &&  store)
+            write_trace<NB>(L, e, energy, ch, nb);
         int br = 0;
         int bc = 0;
         float er = e[0];
@@ -247,7 +272,7 @@ struct DtmfDet
                     flags |= kBlkToneOff;
                 if (L.realtime)
                 {
-                    if (L.rec_dur  &&  live)
+                    if (L.rec_dur  &&  store)
                         L.rec_dur[(size_t) nb*L.n_ch + ch] = w1;
                     w1 = 0;
                 }
@@ -256,10 +281,12 @@ struct DtmfDet
             code = hit;
         }
         last_hit = hit;
-        if (L.rec_energy  &&  live)
-            L.rec_energy[(size_t) nb*L.n_ch + ch] = energy;
-        if (live)
+        if (store)
+        {
+            if (L.rec_energy)
+                L.rec_energy[(size_t) nb*L.n_ch + ch] = energy;
             L.rec[(size_t) nb*L.n_ch + ch] = make_rec(raw, code, flags);
+        }
         energy = 0.0f;
         w0 = ((uint32_t) last_hit << 16) | ((uint32_t) in_digit << 24);       // cs = 0
     }
@@ -281,8 +308,8 @@ __device__ __forceinline__ int mf_pick_pair(const float (&e)[6], float threshold
         best = 1;
         second = 0;
     }
-    float eb = e[best];
-    float es = e[second];
+    float eb = (e[0] > e[1])  ?  e[0]  :  e[1];
+    float es = (e[0] > e[1])  ?  e[1]  :  e[0];
 #pragma unroll
     for (int i = 2;  i < 6;  i++)
     {
@@ -317,28 +344,19 @@ struct BellMfDet
 {
     static constexpr int NB = 6;
     static constexpr bool kEnergy = false;
+    static constexpr bool kDuration = false;
     static constexpr int NSF = 2*NB;
-    static constexpr bool kRuntimeBlock = false;
     __device__ static __forceinline__ int block_len(const ToneLaunch &) { return 120; }    // bell_r2_mf.c:204
     __device__ __forceinline__ void load_extra(const ToneLaunch &, int) {}
     __device__ __forceinline__ void store_extra(const ToneLaunch &, int) {}
     __device__ __forceinline__ float prefilter(float x) { return x; }
 
     // w0 = cs | hits[0]<<16 | hits[1]<<24 ; w1 = hits[2] | hits[3]<<8 | hits[4]<<16
-    __device__ __forceinline__ void block_end(const ToneLaunch &L, Bank<NB> &bk, float &,
-                                              uint32_t &w0, int32_t &w1, int ch, int nb, bool live)
+    __device__ __forceinline__ void decide(const ToneLaunch &L, const float (&e)[NB], float &,
+                                           uint32_t &w0, int32_t &w1, int ch, int nb, bool store)
     {
-        float e[NB];
-#pragma unroll
-        for (int i = 0;  i < NB;  i++)
-            e[i] = bk.finish(i, L.fac[i]);
-        if (L.trace  &&  live)
-        {
-#pragma unroll
-            for (int i = 0;  i < NB;  i++)
-                L.trace[((size_t) nb*(NB + 1) + i)*L.n_ch + ch] = e[i];
-            L.trace[((size_t) nb*(NB + 1) + NB)*L.n_ch + ch] = 0.0f;
-        }
+        if (L.trace  &&  store)
+            write_trace<NB>(L, e, 0.0f, ch, nb);
         // bell_r2_mf.c:236-238
         const int idx = mf_pick_pair(e, 3343803100.0f, 3.981f, 12.589f);
         constexpr uint64_t k0 = pack8("1247C-35");
@@ -365,7 +383,7 @@ struct BellMfDet
             flags |= kBlkReport;
             code = hit;
         }
-        if (live)
+        if (store)
             L.rec[(size_t) nb*L.n_ch + ch] = make_rec(hit, code, flags);
         // bell_r2_mf.c:657-661: shift the hit history
         w0 = ((uint32_t) h1 << 16) | ((uint32_t) h2 << 24);
@@ -377,28 +395,19 @@ struct R2MfDet
 {
     static constexpr int NB = 6;
     static constexpr bool kEnergy = false;
+    static constexpr bool kDuration = false;
     static constexpr int NSF = 2*NB;
-    static constexpr bool kRuntimeBlock = false;
     __device__ static __forceinline__ int block_len(const ToneLaunch &) { return 133; }    // bell_r2_mf.c:206
     __device__ __forceinline__ void load_extra(const ToneLaunch &, int) {}
     __device__ __forceinline__ void store_extra(const ToneLaunch &, int) {}
     __device__ __forceinline__ float prefilter(float x) { return x; }
 
     // w0 = cs | current_digit<<16
-    __device__ __forceinline__ void block_end(const ToneLaunch &L, Bank<NB> &bk, float &,
-                                              uint32_t &w0, int32_t &, int ch, int nb, bool live)
+    __device__ __forceinline__ void decide(const ToneLaunch &L, const float (&e)[NB], float &,
+                                           uint32_t &w0, int32_t &, int ch, int nb, bool store)
     {
-        float e[NB];
-#pragma unroll
-        for (int i = 0;  i < NB;  i++)
-            e[i] = bk.finish(i, L.fac[i]);
-        if (L.trace  &&  live)
-        {
-#pragma unroll
-            for (int i = 0;  i < NB;  i++)
-                L.trace[((size_t) nb*(NB + 1) + i)*L.n_ch + ch] = e[i];
-            L.trace[((size_t) nb*(NB + 1) + NB)*L.n_ch + ch] = 0.0f;
-        }
+        if (L.trace  &&  store)
+            write_trace<NB>(L, e, 0.0f, ch, nb);
         // bell_r2_mf.c:240-242
         const int idx = mf_pick_pair(e, 1031766650.0f, 5.012f, 12.589f);
         constexpr uint64_t k0 = pack8("1247B-35");
@@ -410,7 +419,7 @@ struct R2MfDet
         int flags = kBlkValid;
         if (current != digit)
             flags |= kBlkReport;                                    // bell_r2_mf.c:869-875
-        if (live)
+        if (store)
             L.rec[(size_t) nb*L.n_ch + ch] = make_rec(digit, digit, flags);
         w0 = (uint32_t) digit << 16;
     }
@@ -423,17 +432,16 @@ struct MultiDet
 {
     static constexpr int NB = NBINS;
     static constexpr bool kEnergy = SUPER;
+    static constexpr bool kDuration = false;
     static constexpr int NSF = 2*NB + (SUPER  ?  1  :  0);
-    static constexpr bool kRuntimeBlock = !SUPER;
     __device__ static __forceinline__ int block_len(const ToneLaunch &L) { return SUPER  ?  128  :  L.block_len; }
     __device__ __forceinline__ void load_extra(const ToneLaunch &, int) {}
     __device__ __forceinline__ void store_extra(const ToneLaunch &, int) {}
     __device__ __forceinline__ float prefilter(float x) { return x; }
 
-    __device__ __forceinline__ void block_end(const ToneLaunch &L, Bank<NB> &bk, float &energy,
-                                              uint32_t &w0, int32_t &, int ch, int nb, bool live)
+    __device__ __forceinline__ void decide(const ToneLaunch &L, const float (&ein)[NB], float &energy,
+                                           uint32_t &w0, int32_t &, int ch, int nb, bool store)
     {
-        float e[NB];
         const int m = L.nbins;
         if (SUPER)
         {
@@ -441,12 +449,10 @@ struct MultiDet
             int k2 = -1;
             // super_tone_rx.c:301-309: below the total-energy gate the bins are reset unread
             const bool loud = !(energy < 2104205.6f);               // super_tone_rx.c:75
+            float e[NB];
 #pragma unroll
             for (int i = 0;  i < NB;  i++)
-            {
-                const float r = bk.finish(i, L.fac[i]);
-                e[i] = loud  ?  r  :  0.0f;
-            }
+                e[i] = loud  ?  ein[i]  :  0.0f;
             if (loud)
             {
                 // super_tone_rx.c:320-347 (requires m >= 2)
@@ -456,14 +462,16 @@ struct MultiDet
                 {
                     k1 = 0;
                     k2 = 1;
+                    e1 = e[0];
+                    e2 = e[1];
                 }
                 else
                 {
                     k1 = 1;
                     k2 = 0;
+                    e1 = e[1];
+                    e2 = e[0];
                 }
-                e1 = e[k1 == 0  ?  0  :  1];
-                e2 = e[k2 == 0  ?  0  :  1];
 #pragma unroll
                 for (int j = 2;  j < NB;  j++)
                 {
@@ -500,62 +508,186 @@ struct MultiDet
                     k2 = t;
                 }
             }
-            if (L.rec_energy  &&  live)
-                L.rec_energy[(size_t) nb*L.n_ch + ch] = energy;
-            if (live)
+            if (store)
+            {
+                if (L.rec_energy)
+                    L.rec_energy[(size_t) nb*L.n_ch + ch] = energy;
                 L.rec[(size_t) nb*L.n_ch + ch] = make_rec(k1 + 1, k2 + 1, kBlkValid);
-            if (L.trace  &&  live)
-                L.trace[((size_t) nb*(NB + 1) + NB)*L.n_ch + ch] = energy;
+                if (L.trace)
+                    write_trace<NB>(L, e, energy, ch, nb);
+            }
             energy = 0.0f;
         }
-        else
+        else if (store)
         {
-#pragma unroll
-            for (int i = 0;  i < NB;  i++)
-                e[i] = bk.finish(i, L.fac[i]);
-            if (live)
-                L.rec[(size_t) nb*L.n_ch + ch] = make_rec(0, 0, kBlkValid);
-            if (L.trace  &&  live)
-                L.trace[((size_t) nb*(NB + 1) + NB)*L.n_ch + ch] = 0.0f;
-        }
-        if (L.trace  &&  live)
-        {
-#pragma unroll
-            for (int i = 0;  i < NB;  i++)
-                L.trace[((size_t) nb*(NB + 1) + i)*L.n_ch + ch] = e[i];
+            L.rec[(size_t) nb*L.n_ch + ch] = make_rec(0, 0, kBlkValid);
+            if (L.trace)
+                write_trace<NB>(L, ein, 0.0f, ch, nb);
         }
         w0 = 0;
     }
 };
 
 // ---------------------------------------------------------------------------------
+// Frame staging.  The rows of one 80-sample segment (160 B per channel) of a wave's
+// channels are copied HBM -> LDS by the LDS-DMA path (global_load_lds_dwordx4: 16 B per
+// lane, 1 KiB per instruction, no VGPR round trip) into one of two per-wave LDS
+// buffers.  The LDS image is lane-linear (dest = base + lane*16), i.e. row-major
+// [rows][80] int16 with a 160-byte pitch; each lane then reads its own row 8 samples
+// (ds_read_b128) at a time.  (A 160-byte pitch gives 2-way bank conflicts on those
+// reads; LDS traffic is a few % of the kernel's cycles, so linear-and-coalesced beats
+// padded-and-scattered here.)  The DMA of segment s+1 is in flight while segment s is
+// consumed.  The DMA is issued from inline asm (hipcc neither counts it in its s_waitcnt
+// bookkeeping nor drains it early); completion is awaited with an explicit
+// s_waitcnt vmcnt(0) immediately before the first read of the buffer.
+// ---------------------------------------------------------------------------------
+constexpr int kSeg = 80;                            // samples per LDS segment
+constexpr int kRowBytes = kSeg*2;                   // 160 B per channel row
+constexpr int kChunksPerRow = kRowBytes/16;         // 10 x 16 B
+
+__device__ __forceinline__ float s16_lo(int w) { return (float) (short) (w & 0xFFFF); }
+__device__ __forceinline__ float s16_hi(int w) { return (float) (short) (w >> 16); }
+
+// NDMA LDS-DMA instructions: lane copies 16 B from its own global address g[j] to
+// lds_base + j*1024 + lane*16.  M0 carries the wave-uniform LDS base; it is
+// compiler-reserved, so it is saved and restored inside the same statement (and each
+// write of M0 is followed by the one wait state the LDS-DMA read of it needs).
+#define SPG_DMA_FIRST   "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+#define SPG_DMA_NEXT(n) "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %" #n ", off\n\t"
+#define SPG_DMA_LAST    "s_mov_b32 m0, %0"
+
+template <int NDMA>
+__device__ __forceinline__ void dma_issue(const void *const (&g)[NDMA], uint32_t lds_base);
+
+template <>
+__device__ __forceinline__ void dma_issue<5>(const void *const (&g)[5], uint32_t lds_base)
+{
+    uint32_t keep;
+    asm volatile(SPG_DMA_FIRST SPG_DMA_NEXT(3) SPG_DMA_NEXT(4) SPG_DMA_NEXT(5) SPG_DMA_NEXT(6) SPG_DMA_LAST
+                 : "=&s"(keep)
+                 : "s"(lds_base), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4])
+                 : "memory", "scc");
+}
+
+template <>
+__device__ __forceinline__ void dma_issue<10>(const void *const (&g)[10], uint32_t lds_base)
+{
+    uint32_t keep;
+    asm volatile(SPG_DMA_FIRST SPG_DMA_NEXT(3) SPG_DMA_NEXT(4) SPG_DMA_NEXT(5) SPG_DMA_NEXT(6) SPG_DMA_NEXT(7)
+                 SPG_DMA_NEXT(8) SPG_DMA_NEXT(9) SPG_DMA_NEXT(10) SPG_DMA_NEXT(11) SPG_DMA_LAST
+                 : "=&s"(keep)
+                 : "s"(lds_base), "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]),
+                   "v"(g[5]), "v"(g[6]), "v"(g[7]), "v"(g[8]), "v"(g[9])
+                 : "memory", "scc");
+}
+
+__device__ __forceinline__ void dma_wait_all()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------
 // The bank kernel
 // ---------------------------------------------------------------------------------
-template <class Det>
+// ABL is a tuning-probe knob (tools/probe.hip) that removes one cost at a time; the
+// library only instantiates ABL = 0.
+template <class Det, int LPC, int ABL = 0>
 __global__ __launch_bounds__(kWave*kWavesPerBlock)
 void tone_bank_kernel(const ToneLaunch L)
 {
     constexpr int NB = Det::NB;
-    __shared__ int tile[kWavesPerBlock][kWave*kRowPitch];
+    constexpr int NBH = (LPC == 1)  ?  NB  :  (NB + 1)/2;      // real bins per lane
+    constexpr int NBL = (NBH + 1) & ~1;                         // padded to packed pairs
+    constexpr int CPW = kWave/LPC;                              // channels per wave
+    constexpr int NDMA = CPW*kChunksPerRow/kWave;               // LDS-DMA instructions per segment
+    constexpr int kBufBytes = CPW*kRowBytes;
+    __shared__ __attribute__((aligned(16))) char lds[kWavesPerBlock][2][kBufBytes];
 
     const int lane = threadIdx.x & (kWave - 1);
-    const int wv = threadIdx.x >> 6;
-    const int ch0 = (blockIdx.x*kWavesPerBlock + wv)*kWave;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ch0 = (blockIdx.x*kWavesPerBlock + wv)*CPW;
     if (ch0 >= L.n_ch)
         return;                                     // whole wave idle (wave-uniform exit)
-    const bool live = (ch0 + lane) < L.n_ch;
-    const int ch = live  ?  (ch0 + lane)  :  (L.n_ch - 1);      // dead lanes shadow the last channel, never store
+    const int cl = (LPC == 1)  ?  lane  :  (lane & (CPW - 1));  // channel within the wave
+    const int sub = (LPC == 1)  ?  0  :  (lane >> 5);           // which half of the bins
+    const bool live = (ch0 + cl) < L.n_ch;
+    const int ch = live  ?  (ch0 + cl)  :  (L.n_ch - 1);        // shadow lanes follow the last channel, never store
+    const bool store = live  &&  (sub == 0);
+
+    const bool fast_loader = (L.layout == 0)  &&  L.aligned16;
+    const int nseg = (L.samples + kSeg - 1)/kSeg;
+    const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) char *) &lds[wv][0][0];
+
+    // Per-lane DMA geometry, fixed for the launch: chunk c = j*64 + lane covers row c/10,
+    // 16-byte column c%10 of a segment.  Rows outside the bank follow the last channel and
+    // sample offsets past the (8-sample padded) frame re-read its last chunk; neither is
+    // ever consumed.
+    const int spad = (L.samples + 7) & ~7;
+    size_t dma_row[NDMA];
+    int dma_col8[NDMA];
+#pragma unroll
+    for (int j = 0;  j < NDMA;  j++)
+    {
+        const int c = j*kWave + lane;
+        const int r = c/kChunksPerRow;
+        dma_col8[j] = (c - r*kChunksPerRow)*8;
+        dma_row[j] = (size_t) min(ch0 + r, L.n_ch - 1)*(size_t) L.stride*2;
+    }
+    auto issue_dma = [&](int seg, int buf)
+    {
+        const void *g[NDMA];
+#pragma unroll
+        for (int j = 0;  j < NDMA;  j++)
+            g[j] = (const char *) L.amp + dma_row[j] + (size_t) (2*min(seg*kSeg + dma_col8[j], spad - 8));
+        dma_issue<NDMA>(g, __builtin_amdgcn_readfirstlane(lds0 + buf*kBufBytes));
+    };
+    // Both LDS buffers are free at kernel start: put the first TWO segments (a whole
+    // 160-sample frame) in flight before anything else, under the state loads.
+    if (fast_loader  &&  !(ABL & 16))
+    {
+        issue_dma(0, 0);
+        if (nseg > 1)
+            issue_dma(1, 1);
+    }
 
     // ---- load per-channel state (coalesced: SoA, lane == channel) -------------------
-    Bank<NB> bk;
+    Bank<NBL> bk;
     Det det;
-    float fac[NB];
+    f32x2 fac[NBL/2];
 #pragma unroll
-    for (int i = 0;  i < NB;  i++)
+    for (int i = 0;  i < NBL;  i++)
     {
-        fac[i] = L.fac[i];
-        bk.v2[i] = L.sf[(size_t) i*L.n_ch + ch];
-        bk.v3[i] = L.sf[(size_t) (NB + i)*L.n_ch + ch];
+        float f = 0.0f;
+        float s2 = 0.0f;
+        float s3 = 0.0f;
+        if (LPC == 1)
+        {
+            f = L.fac[i];
+            s2 = L.sf[(size_t) i*L.n_ch + ch];
+            s3 = L.sf[(size_t) (NB + i)*L.n_ch + ch];
+        }
+        else
+        {
+            // lane half `sub` owns global bins sub*NBH + i, i < NBH
+            const bool real0 = (i < NBH);
+            const bool real1 = (i < NBH)  &&  (NBH + i < NB);
+            const float f0 = real0  ?  L.fac[(i < kMaxBins)  ?  i  :  0]  :  0.0f;
+            const float f1 = real1  ?  L.fac[(NBH + i < kMaxBins)  ?  (NBH + i)  :  0]  :  0.0f;
+            f = sub  ?  f1  :  f0;
+            const bool real = sub  ?  real1  :  real0;
+            if (real)
+            {
+                const int gi = sub*NBH + i;
+                s2 = L.sf[(size_t) gi*L.n_ch + ch];
+                s3 = L.sf[(size_t) (NB + gi)*L.n_ch + ch];
+            }
+        }
+        if (i & 1)
+            fac[i >> 1].y = f;
+        else
+            fac[i >> 1].x = f;
+        bk.set_v2(i, s2);
+        bk.set_v3(i, s3);
     }
     float energy = 0.0f;
     if (Det::kEnergy)
@@ -572,59 +704,71 @@ void tone_bank_kernel(const ToneLaunch L)
     const int cs_first = __builtin_amdgcn_readfirstlane(cs);
     const bool uniform = __all(cs == cs_first);
 
-    int *mytile = &tile[wv][0];
-    const short *row = (const short *) &mytile[lane*kRowPitch];
-
     int nb = 0;                 // blocks completed by this lane in this call
     int take_acc = 0;           // samples since the last duration update (dtmf.c:202-204)
 
-    // ---- prefetch registers for the coalesced channel-major loader -------------------
-    // Tile = 64 rows x 64 B; chunk c = j*64 + lane -> row c>>2, 16-byte column c&3.
-    int4 g[4];
-    auto fetch = [&](int seg_base)
+    auto one_sample = [&](float xin)
     {
-#pragma unroll
-        for (int j = 0;  j < 4;  j++)
-        {
-            const int c = j*kWave + lane;
-            const int r = c >> 2;
-            const int col = c & 3;
-            const int s0 = seg_base + col*8;
-            g[j] = make_int4(0, 0, 0, 0);
-            if ((ch0 + r) < L.n_ch  &&  s0 < L.samples)
-                g[j] = *(const int4 *) (L.amp + (size_t) (ch0 + r)*L.stride + s0);
-        }
+        const float x = det.prefilter(xin);
+        if (Det::kEnergy  &&  !(ABL & 1))
+            energy += x*x;
+        if (!(ABL & 8))
+            bk.step(fac, x);
+        else
+            energy += x;
     };
-    auto commit = [&]()
+    auto end_block = [&]()
     {
-#pragma unroll
-        for (int j = 0;  j < 4;  j++)
+        if (Det::kDuration)
         {
-            const int c = j*kWave + lane;
-            int *p = &mytile[(c >> 2)*kRowPitch + (c & 3)*4];
-            p[0] = g[j].x;
-            p[1] = g[j].y;
-            p[2] = g[j].z;
-            p[3] = g[j].w;
+            if (w1 < INT_MAX - take_acc)
+                w1 += take_acc;
         }
-    };
-    const bool fast_loader = (L.layout == 0)  &&  L.aligned16;
-    if (fast_loader)
-        fetch(0);
-
-    for (int seg_base = 0;  seg_base < L.samples;  seg_base += kSegSamples)
-    {
-        const int seglen = min(kSegSamples, L.samples - seg_base);
-        // ---- stage this segment into the wave's LDS tile ------------------------------
-        if (fast_loader)
+        take_acc = 0;
+        if (ABL & 4)
         {
-            commit();
-            if (seg_base + kSegSamples < L.samples)
-                fetch(seg_base + kSegSamples);
+            nb++;
+            return;
+        }
+        float el[NBL];
+        bk.finish(fac, el);
+        float e[NB];
+        if (LPC == 1)
+        {
+#pragma unroll
+            for (int i = 0;  i < NB;  i++)
+                e[i] = el[i];
         }
         else
         {
-            short *wrow = (short *) &mytile[lane*kRowPitch];
+            // exchange with the lane that holds the other half of this channel's bins
+#pragma unroll
+            for (int i = 0;  i < NBH;  i++)
+            {
+                const float other = __shfl_xor(el[i], 32);
+                e[i] = sub  ?  other  :  el[i];
+                if (NBH + i < NB)
+                    e[NBH + i] = sub  ?  el[i]  :  other;
+            }
+        }
+        det.decide(L, e, energy, w0, w1, ch, nb, store);
+        nb++;
+    };
+
+    for (int seg = 0;  seg < nseg;  seg++)
+    {
+        const int seg_base = seg*kSeg;
+        const int seglen = min(kSeg, L.samples - seg_base);
+        const int buf = seg & 1;
+        char *mybuf = &lds[wv][buf][0];
+        // ---- make this segment resident in LDS -------------------------------------------
+        if (fast_loader)
+        {
+            dma_wait_all();
+        }
+        else if (sub == 0)
+        {
+            short *wrow = (short *) (mybuf + cl*kRowBytes);
             if (L.layout == 0)
             {
                 const int16_t *src = L.amp + (size_t) ch*L.stride + seg_base;
@@ -638,95 +782,105 @@ void tone_bank_kernel(const ToneLaunch L)
                     wrow[j] = src[(size_t) j*L.stride];
             }
         }
-        // (single wave per tile: LDS operations of one wave complete in order, no barrier)
+        // (single wave per buffer: LDS operations of one wave complete in order, no barrier)
+        const int4 *rowv = (const int4 *) (mybuf + cl*kRowBytes);
+        const short *row = (const short *) rowv;
 
         // ---- consume it ------------------------------------------------------------------
         if (uniform)
         {
-            int pos = 0;
             int cs_s = __builtin_amdgcn_readfirstlane(cs);
-            while (pos < seglen)
+            const int nchunks = (seglen + 7) >> 3;
+            int4 cur = rowv[0];
+            for (int q = 0;  q < nchunks;  q++)
             {
-                int run = block - cs_s;
-                if (run > seglen - pos)
-                    run = seglen - pos;
-                int k = 0;
-                for (  ;  k + 4 <= run;  k += 4)
+                const int4 nxt = rowv[(q + 1 < nchunks)  ?  (q + 1)  :  q];    // one chunk ahead
+                const int n = min(8, seglen - q*8);
+                // Start the next segment's DMA from INSIDE the chunk loop: hipcc drains vmcnt(0)
+                // in the loop preheader, which would serialise a DMA issued before the loop.
+                if (q == 0  &&  fast_loader  &&  seg >= 1  &&  seg + 1 < nseg  &&  !(ABL & 16))
+                    issue_dma(seg + 1, buf ^ 1);
+                if (ABL & 2)
+                    cur = make_int4(0x00010002, 0x00030004, 0x00050006, 0x00070008);
+                if (n == 8  &&  cs_s + 8 <= block)
                 {
-                    const float x0 = det.prefilter((float) row[pos + k]);
-                    const float x1 = det.prefilter((float) row[pos + k + 1]);
-                    const float x2 = det.prefilter((float) row[pos + k + 2]);
-                    const float x3 = det.prefilter((float) row[pos + k + 3]);
-                    if (Det::kEnergy)
-                        energy += x0*x0;
-                    bk.step(fac, x0);
-                    if (Det::kEnergy)
-                        energy += x1*x1;
-                    bk.step(fac, x1);
-                    if (Det::kEnergy)
-                        energy += x2*x2;
-                    bk.step(fac, x2);
-                    if (Det::kEnergy)
-                        energy += x3*x3;
-                    bk.step(fac, x3);
+                    one_sample(s16_lo(cur.x));
+                    one_sample(s16_hi(cur.x));
+                    one_sample(s16_lo(cur.y));
+                    one_sample(s16_hi(cur.y));
+                    one_sample(s16_lo(cur.z));
+                    one_sample(s16_hi(cur.z));
+                    one_sample(s16_lo(cur.w));
+                    one_sample(s16_hi(cur.w));
+                    cs_s += 8;
+                    take_acc += 8;
+                    if (cs_s == block)
+                    {
+                        end_block();
+                        cs_s = 0;
+                    }
                 }
-                for (  ;  k < run;  k++)
+                else
                 {
-                    const float x = det.prefilter((float) row[pos + k]);
-                    if (Det::kEnergy)
-                        energy += x*x;
-                    bk.step(fac, x);
+                    // a block boundary (or the end of the call) falls inside this chunk
+                    for (int j = 0;  j < n;  j++)
+                    {
+                        const int w = (j < 2)  ?  cur.x  :  (j < 4)  ?  cur.y  :  (j < 6)  ?  cur.z  :  cur.w;
+                        one_sample((float) (short) (w >> ((j & 1)*16)));
+                        cs_s++;
+                        take_acc++;
+                        if (cs_s == block)
+                        {
+                            end_block();
+                            cs_s = 0;
+                        }
+                    }
                 }
-                pos += run;
-                cs_s += run;
-                take_acc += run;
-                if (cs_s >= block)
-                {
-                    if (w1 < INT_MAX - take_acc)
-                        w1 += take_acc;
-                    take_acc = 0;
-                    det.block_end(L, bk, energy, w0, w1, ch, nb, live);
-                    nb++;
-                    cs_s = 0;
-                }
+                cur = nxt;
             }
             cs = cs_s;
         }
         else
         {
-            // Divergent block phases inside the wave: correct, slower.
+            // Divergent block phases inside the wave: correct, slower.  (With LPC = 2 the two
+            // lanes of a channel share its phase, so they reach end_block() together.)
             for (int pos = 0;  pos < seglen;  pos++)
             {
-                const float x = det.prefilter((float) row[pos]);
-                if (Det::kEnergy)
-                    energy += x*x;
-                bk.step(fac, x);
+                if (pos == 0  &&  fast_loader  &&  seg >= 1  &&  seg + 1 < nseg)
+                    issue_dma(seg + 1, buf ^ 1);
+                one_sample((float) row[pos]);
                 cs++;
                 take_acc++;
                 if (cs >= block)
                 {
-                    if (w1 < INT_MAX - take_acc)
-                        w1 += take_acc;
-                    take_acc = 0;
-                    det.block_end(L, bk, energy, w0, w1, ch, nb, live);
-                    nb++;
+                    end_block();
                     cs = 0;
                 }
             }
         }
     }
-    if (take_acc > 0  &&  w1 < INT_MAX - take_acc)
-        w1 += take_acc;
+    if (Det::kDuration)
+    {
+        if (take_acc > 0  &&  w1 < INT_MAX - take_acc)
+            w1 += take_acc;
+    }
 
     // ---- write back ---------------------------------------------------------------------------
     if (live)
     {
 #pragma unroll
-        for (int i = 0;  i < NB;  i++)
+        for (int i = 0;  i < NBH;  i++)
         {
-            L.sf[(size_t) i*L.n_ch + ch] = bk.v2[i];
-            L.sf[(size_t) (NB + i)*L.n_ch + ch] = bk.v3[i];
+            const int gi = sub*NBH + i;
+            if (gi < NB)
+            {
+                L.sf[(size_t) gi*L.n_ch + ch] = bk.v2(i);
+                L.sf[(size_t) (NB + gi)*L.n_ch + ch] = bk.v3(i);
+            }
         }
+    }
+    if (store)
+    {
         if (Det::kEnergy)
             L.sf[(size_t) (2*NB)*L.n_ch + ch] = energy;
         det.store_extra(L, ch);

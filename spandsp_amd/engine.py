@@ -52,6 +52,7 @@ def lib():
             "spangpu_last_error": (C.c_char_p, []),
             "spangpu_version": (C.c_char_p, []),
             "spangpu_goertzel_fac": (cf, [cf]),
+            "spangpu_tune_lanes_per_channel": (ci, [ci]),
             "spangpu_bank_create": (ci, [C.POINTER(vp), ci, ci, ci, vp, C.c_size_t]),
             "spangpu_bank_destroy": (ci, [vp]),
             "spangpu_bank_kind": (ci, [vp]),
@@ -85,6 +86,10 @@ def _check(rc):
 
 def device_count():
     return lib().spangpu_device_count()
+
+
+def tune_lanes_per_channel(lpc):
+    _check(lib().spangpu_tune_lanes_per_channel(lpc))
 
 
 def goertzel_fac(freq):

@@ -18,6 +18,15 @@ _libm.log10f.restype = C.c_float
 _libm.log10f.argtypes = [C.c_float]
 
 
+@pytest.fixture(params=[1, 2], autouse=True)
+def lanes_per_channel(request, built):
+    """Every parity test runs under both kernel mappings (1 and 2 lanes per channel)."""
+    from spandsp_amd import engine
+    engine.tune_lanes_per_channel(request.param)
+    yield request.param
+    engine.tune_lanes_per_channel(0)
+
+
 def f32_bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 

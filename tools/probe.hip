@@ -193,7 +193,7 @@ static void probe_stream()
     CK(hipFree(out));
 }
 
-template <class Det>
+template <class Det, int LPC = 1, int ABL = 0>
 static void probe_tone(const char *name, int n_ch, int samples, int n_frames, int block_len, bool divergent)
 {
     ToneLaunch L;
@@ -236,18 +236,18 @@ static void probe_tone(const char *name, int n_ch, int samples, int n_frames, in
     L.threshold = 171029200.0f;
     L.normal_twist = 6.309f;
     L.reverse_twist = 2.512f;
-    const int waves = (n_ch + kWave - 1)/kWave;
+    const int waves = (n_ch + kWave/LPC - 1)/(kWave/LPC);
     const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
     int f = 0;
     float ms = time_ms([&] {
         L.amp = amp + (size_t) (f % n_frames)*frame_elems;
         f++;
-        hipLaunchKernelGGL(tone_bank_kernel<Det>, dim3(blocks), dim3(kWave*kWavesPerBlock), 0, 0, L);
+        hipLaunchKernelGGL((tone_bank_kernel<Det, LPC, ABL>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, 0, L);
     }, 50);
     const double smp = (double) n_ch*samples;
     const double rd = (double) n_ch*(samples*2 + 80);
-    printf("%-10s ch=%8d samples=%5d %s: %9.2f us/launch  %8.1f Gsamples/s  alg-read %7.1f GB/s (%4.1f%% of 8 TB/s)\n",
-           name, n_ch, samples, divergent  ?  "divergent"  :  "uniform  ", ms*1e3, smp/ms/1e6, rd/ms/1e6, rd/ms/1e6/80.0);
+    printf("%-10s abl=%2d lpc=%d ch=%8d samples=%5d %s: %9.2f us/launch  %8.1f Gsamples/s  alg-read %7.1f GB/s (%4.1f%% of 8 TB/s)\n",
+           name, ABL, LPC, n_ch, samples, divergent  ?  "divergent"  :  "uniform  ", ms*1e3, smp/ms/1e6, rd/ms/1e6, rd/ms/1e6/80.0);
     CK(hipFree(amp));
     CK(hipFree(L.sf));
     CK(hipFree(L.si));
@@ -259,9 +259,41 @@ int main(int argc, char **argv)
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
     printf("device: %s  CUs=%d  clock=%d MHz  memclk=%d MHz\n", p.name, p.multiProcessorCount, p.clockRate/1000, p.memoryClockRate/1000);
+    const bool tone_only = (argc > 1  &&  strcmp(argv[1], "tone") == 0);
+    if (argc > 1  &&  strcmp(argv[1], "abl") == 0)
+    {
+        probe_tone<DtmfDet<false>, 1, 0>("dtmf", 1048576, 160, 8, 102, false);
+        probe_tone<DtmfDet<false>, 1, 1>("dtmf", 1048576, 160, 8, 102, false);
+        probe_tone<DtmfDet<false>, 1, 2>("dtmf", 1048576, 160, 8, 102, false);
+        probe_tone<DtmfDet<false>, 1, 4>("dtmf", 1048576, 160, 8, 102, false);
+        probe_tone<DtmfDet<false>, 1, 8>("dtmf", 1048576, 160, 8, 102, false);
+        probe_tone<DtmfDet<false>, 1, 16>("dtmf", 1048576, 160, 8, 102, false);
+        probe_tone<DtmfDet<false>, 1, 7>("dtmf", 1048576, 160, 8, 102, false);
+        probe_tone<DtmfDet<false>, 1, 23>("dtmf", 1048576, 160, 8, 102, false);
+        probe_tone<DtmfDet<false>, 1, 31>("dtmf", 1048576, 160, 8, 102, false);
+        probe_tone<DtmfDet<false>, 2, 0>("dtmf", 65536, 160, 64, 102, false);
+        probe_tone<DtmfDet<false>, 2, 4>("dtmf", 65536, 160, 64, 102, false);
+        probe_tone<DtmfDet<false>, 2, 7>("dtmf", 65536, 160, 64, 102, false);
+        probe_tone<DtmfDet<false>, 2, 23>("dtmf", 65536, 160, 64, 102, false);
+        probe_tone<DtmfDet<false>, 2, 31>("dtmf", 65536, 160, 64, 102, false);
+        return 0;
+    }
+    if (tone_only)
+    {
+        probe_tone<DtmfDet<false>, 2>("dtmf", 65536, 160, 64, 102, false);
+        probe_tone<DtmfDet<false>, 2>("dtmf", 65536, 800, 16, 102, false);
+        return 0;
+    }
     probe_valu();
     probe_stream();
     probe_tone<DtmfDet<false>>("dtmf", 65536, 160, 64, 102, false);
+    probe_tone<DtmfDet<false>, 2>("dtmf", 65536, 160, 64, 102, false);
+    probe_tone<DtmfDet<false>, 2>("dtmf", 131072, 160, 32, 102, false);
+    probe_tone<DtmfDet<false>, 2>("dtmf", 262144, 160, 16, 102, false);
+    probe_tone<DtmfDet<false>, 2>("dtmf", 1048576, 160, 8, 102, false);
+    probe_tone<DtmfDet<false>, 2>("dtmf", 65536, 800, 16, 102, false);
+    probe_tone<DtmfDet<false>, 2>("dtmf", 65536, 160, 64, 102, true);
+    probe_tone<BellMfDet, 2>("bell", 131072, 160, 32, 120, false);
     probe_tone<DtmfDet<false>>("dtmf", 131072, 160, 32, 102, false);
     probe_tone<DtmfDet<false>>("dtmf", 262144, 160, 16, 102, false);
     probe_tone<DtmfDet<false>>("dtmf", 1048576, 160, 8, 102, false);
