@@ -138,6 +138,10 @@ SPANGPU_API int spangpu_bank_set_stream(spangpu_bank_t *bank, void *hip_stream);
    after the launch is queued on the bank stream.  Returns 0, like dtmf_rx(). */
 SPANGPU_API int spangpu_bank_rx(spangpu_bank_t *bank, const int16_t *amp, int mem, int layout,
                                 int samples, long long stride);
+/* Evaluate the current (partial) block of every channel now and restart it: what
+   goertzel_result() called mid-block does (tone_detect.c:160-205).  The results are read
+   with spangpu_bank_blocks() / spangpu_bank_trace() as after spangpu_bank_rx(). */
+SPANGPU_API int spangpu_bank_force_block(spangpu_bank_t *bank);
 /* Wait for everything queued on the bank's stream. */
 SPANGPU_API int spangpu_bank_sync(spangpu_bank_t *bank);
 /* After spangpu_bank_rx(): copy the block records of the last call to the host

@@ -1,0 +1,140 @@
+/*
+ * spangpu_spandsp.h -- the spandsp-named, per-channel C entry points of libspangpu.so.
+ *
+ * Source-compatible with the reference's public tone-detector API: same names, argument
+ * order, return values and callback types, so an existing caller (FreeSWITCH mod_spandsp,
+ * adsi.c, v18.c ...) re-links unchanged.  State objects are opaque (the reference exposes
+ * them only through its private headers).  Behind each object is one channel slot of a
+ * GPU bank (include/spangpu.h):
+ *
+ *   - xxx_rx_init(NULL, ...) makes a PRIVATE one-channel bank: xxx_rx() then runs the frame
+ *     on the GPU and replays callbacks before it returns -- same observable behaviour, per
+ *     call, as the reference (this is the plumbing configuration);
+ *   - spangpu_group_create() + spangpu_xxx_rx_attach() put N objects on ONE bank: each
+ *     xxx_rx() stages its frame, and when the last attached channel of the tick has staged
+ *     (or on spangpu_group_flush()) a single kernel launch advances all N channels and the
+ *     callbacks of every channel are replayed in channel order, each channel's events in
+ *     sample order.  This is the production configuration (thousands of channels / launch).
+ *
+ * Reference declarations being replaced (relative to the reference tree):
+ *   dtmf_rx_init/_release/_free            src/spandsp/dtmf.h:216-228     src/dtmf.c:447-519
+ *   dtmf_rx                                src/spandsp/dtmf.h:177         src/dtmf.c:132-361
+ *   dtmf_rx_fillin/_status/_get            src/spandsp/dtmf.h:185-201     src/dtmf.c:363-408
+ *   dtmf_rx_parms/_set_realtime_callback   src/spandsp/dtmf.h:153-170     src/dtmf.c:410-445
+ *   bell_mf_rx_init/_rx/_get/_release/_free  src/spandsp/bell_r2_mf.h:199-228  src/bell_r2_mf.c:507-748
+ *   r2_mf_rx_init/_rx/_get/_release/_free  src/spandsp/bell_r2_mf.h:236-266  src/bell_r2_mf.c:750-951
+ *   super_tone_rx_* (descriptor + detector)  src/spandsp/super_tone_rx.h:76-164  src/super_tone_rx.c:81-568
+ *   goertzel_*  / make_goertzel_descriptor src/spandsp/tone_detect.h:86-124  src/tone_detect.c:60-205
+ * Callback types: digits_rx_callback_t (dtmf.h:76), span_tone_report_func_t and
+ * tone_segment_func_t (super_tone_rx.h:56-58).
+ */
+#if !defined(SPANGPU_SPANDSP_H)
+#define SPANGPU_SPANDSP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "spangpu.h"
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+typedef void (*digits_rx_callback_t)(void *user_data, const char *digits, int len);
+typedef void (*span_tone_report_func_t)(void *user_data, int code, int level, int delay);
+typedef void (*tone_segment_func_t)(void *data, int f1, int f2, int duration);
+
+#define MAX_DTMF_DIGITS         128
+#define MAX_BELL_MF_DIGITS      128
+
+typedef struct dtmf_rx_state_s dtmf_rx_state_t;
+typedef struct bell_mf_rx_state_s bell_mf_rx_state_t;
+typedef struct r2_mf_rx_state_s r2_mf_rx_state_t;
+typedef struct super_tone_rx_descriptor_s super_tone_rx_descriptor_t;
+typedef struct super_tone_rx_state_s super_tone_rx_state_t;
+typedef struct goertzel_state_s goertzel_state_t;
+typedef struct
+{
+    float fac;
+    int samples;
+} goertzel_descriptor_t;
+
+/* ---- channel groups: N spandsp objects on one GPU bank ----------------------------- */
+typedef struct spangpu_group_s spangpu_group_t;
+
+/* kind: SPANGPU_DTMF / _BELL_MF / _R2_MF / _SUPER_TONE.  params may be NULL (defaults).
+   max_samples bounds the samples one xxx_rx() call may carry (e.g. 160). */
+SPANGPU_API spangpu_group_t *spangpu_group_create(int device, int kind, int n_channels, int max_samples,
+                                                  const spangpu_tone_params_t *params);
+SPANGPU_API int spangpu_group_destroy(spangpu_group_t *g);
+/* Run the tick now: every attached channel must have staged a frame of the same length.
+   Returns the number of channels processed, or a negative SPANGPU_ERR_*. */
+SPANGPU_API int spangpu_group_flush(spangpu_group_t *g);
+SPANGPU_API spangpu_bank_t *spangpu_group_bank(spangpu_group_t *g);
+
+SPANGPU_API dtmf_rx_state_t *spangpu_dtmf_rx_attach(spangpu_group_t *g, int channel,
+                                                    digits_rx_callback_t callback, void *user_data);
+SPANGPU_API bell_mf_rx_state_t *spangpu_bell_mf_rx_attach(spangpu_group_t *g, int channel,
+                                                          digits_rx_callback_t callback, void *user_data);
+SPANGPU_API r2_mf_rx_state_t *spangpu_r2_mf_rx_attach(spangpu_group_t *g, int channel,
+                                                      span_tone_report_func_t callback, void *user_data);
+SPANGPU_API super_tone_rx_state_t *spangpu_super_tone_rx_attach(spangpu_group_t *g, int channel,
+                                                                super_tone_rx_descriptor_t *desc,
+                                                                span_tone_report_func_t callback, void *user_data);
+
+/* Bank parameters (bin count and taps) for a super-tone group whose channels all use `desc`. */
+SPANGPU_API int spangpu_super_tone_params(const super_tone_rx_descriptor_t *desc, spangpu_tone_params_t *params);
+
+/* ---- DTMF (src/spandsp/dtmf.h) -------------------------------------------------------- */
+SPANGPU_API dtmf_rx_state_t *dtmf_rx_init(dtmf_rx_state_t *s, digits_rx_callback_t callback, void *user_data);
+SPANGPU_API int dtmf_rx_release(dtmf_rx_state_t *s);
+SPANGPU_API int dtmf_rx_free(dtmf_rx_state_t *s);
+SPANGPU_API void dtmf_rx_set_realtime_callback(dtmf_rx_state_t *s, span_tone_report_func_t callback, void *user_data);
+SPANGPU_API void dtmf_rx_parms(dtmf_rx_state_t *s, int filter_dialtone, float twist, float reverse_twist, float threshold);
+SPANGPU_API int dtmf_rx(dtmf_rx_state_t *s, const int16_t amp[], int samples);
+SPANGPU_API int dtmf_rx_fillin(dtmf_rx_state_t *s, int samples);
+SPANGPU_API int dtmf_rx_status(dtmf_rx_state_t *s);
+SPANGPU_API size_t dtmf_rx_get(dtmf_rx_state_t *s, char *digits, int max);
+
+/* ---- Bell MF / R2 MF (src/spandsp/bell_r2_mf.h) ------------------------------------------ */
+SPANGPU_API bell_mf_rx_state_t *bell_mf_rx_init(bell_mf_rx_state_t *s, digits_rx_callback_t callback, void *user_data);
+SPANGPU_API int bell_mf_rx_release(bell_mf_rx_state_t *s);
+SPANGPU_API int bell_mf_rx_free(bell_mf_rx_state_t *s);
+SPANGPU_API int bell_mf_rx(bell_mf_rx_state_t *s, const int16_t amp[], int samples);
+SPANGPU_API size_t bell_mf_rx_get(bell_mf_rx_state_t *s, char *buf, int max);
+
+SPANGPU_API r2_mf_rx_state_t *r2_mf_rx_init(r2_mf_rx_state_t *s, bool fwd, span_tone_report_func_t callback, void *user_data);
+SPANGPU_API int r2_mf_rx_release(r2_mf_rx_state_t *s);
+SPANGPU_API int r2_mf_rx_free(r2_mf_rx_state_t *s);
+SPANGPU_API int r2_mf_rx(r2_mf_rx_state_t *s, const int16_t amp[], int samples);
+SPANGPU_API int r2_mf_rx_get(r2_mf_rx_state_t *s);
+
+/* ---- Super tone (src/spandsp/super_tone_rx.h) ----------------------------------------------- */
+SPANGPU_API super_tone_rx_descriptor_t *super_tone_rx_make_descriptor(super_tone_rx_descriptor_t *desc);
+SPANGPU_API int super_tone_rx_free_descriptor(super_tone_rx_descriptor_t *desc);
+SPANGPU_API int super_tone_rx_add_tone(super_tone_rx_descriptor_t *desc);
+SPANGPU_API int super_tone_rx_add_element(super_tone_rx_descriptor_t *desc, int tone, int f1, int f2, int min, int max);
+SPANGPU_API super_tone_rx_state_t *super_tone_rx_init(super_tone_rx_state_t *s, super_tone_rx_descriptor_t *desc,
+                                                      span_tone_report_func_t callback, void *user_data);
+SPANGPU_API int super_tone_rx_release(super_tone_rx_state_t *s);
+SPANGPU_API int super_tone_rx_free(super_tone_rx_state_t *s);
+SPANGPU_API void super_tone_rx_tone_callback(super_tone_rx_state_t *s, span_tone_report_func_t callback, void *user_data);
+SPANGPU_API void super_tone_rx_segment_callback(super_tone_rx_state_t *s, tone_segment_func_t callback);
+SPANGPU_API int super_tone_rx(super_tone_rx_state_t *s, const int16_t amp[], int samples);
+SPANGPU_API int super_tone_rx_fillin(super_tone_rx_state_t *s, int samples);
+
+/* ---- Goertzel (src/spandsp/tone_detect.h) ------------------------------------------------------ */
+SPANGPU_API void make_goertzel_descriptor(goertzel_descriptor_t *t, float freq, int samples);
+SPANGPU_API goertzel_state_t *goertzel_init(goertzel_state_t *s, goertzel_descriptor_t *t);
+SPANGPU_API int goertzel_release(goertzel_state_t *s);
+SPANGPU_API int goertzel_free(goertzel_state_t *s);
+SPANGPU_API void goertzel_reset(goertzel_state_t *s);
+SPANGPU_API int goertzel_update(goertzel_state_t *s, const int16_t amp[], int samples);
+SPANGPU_API float goertzel_result(goertzel_state_t *s);
+
+#if defined(__cplusplus)
+}
+#endif
+
+#endif

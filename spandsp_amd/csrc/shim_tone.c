@@ -1,0 +1,1286 @@
+/*
+ * shim_tone.c -- host side (plain C) of the spandsp-named tone-detector entry points
+ * declared in include/spangpu_spandsp.h.  No signal processing happens here: frames are
+ * staged into a bank (include/spangpu.h), the HIP kernels produce one record per
+ * completed detection block, and this file replays those records through the caller's
+ * callbacks / digit buffers in exactly the order and with exactly the arguments the
+ * reference would have used:
+ *   DTMF delivery      src/dtmf.c:304-358        Bell MF delivery  src/bell_r2_mf.c:636-672
+ *   R2 MF reports      src/bell_r2_mf.c:869-876  super-tone cadence matcher src/super_tone_rx.c:164-228,364-448
+ * Without a GPU every init fails (returns NULL): there is no CPU implementation.
+ */
+#include <limits.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "spangpu_spandsp.h"
+
+#define SUPER_TONE_BINS     128             /* src/spandsp/private/super_tone_rx.h:29 */
+
+/* ------------------------------------------------------------------------------------ */
+/* Channel groups                                                                       */
+/* ------------------------------------------------------------------------------------ */
+struct spangpu_group_s
+{
+    spangpu_bank_t *bank;
+    int kind;
+    int n_ch;
+    int max_samples;
+    int16_t *stage;             /* [n_ch][max_samples] */
+    void **handles;             /* per channel: the attached state object or NULL */
+    uint8_t *staged;
+    int n_attached;
+    int n_staged;
+    int tick_samples;
+    spangpu_block_t *blocks;
+    int blocks_cap;
+    spangpu_tone_params_t params;
+};
+
+struct dtmf_rx_state_s
+{
+    spangpu_group_t *grp;
+    int channel;
+    int private_grp;
+    digits_rx_callback_t digits_callback;
+    void *digits_callback_data;
+    span_tone_report_func_t realtime_callback;
+    void *realtime_callback_data;
+    int last_hit;
+    int in_digit;
+    int lost_digits;
+    int current_digits;
+    char digits[MAX_DTMF_DIGITS + 1];
+    /* bank parameters of a private object (applied when its bank is (re)built) */
+    spangpu_tone_params_t params;
+    int dirty;
+};
+
+struct bell_mf_rx_state_s
+{
+    spangpu_group_t *grp;
+    int channel;
+    int private_grp;
+    digits_rx_callback_t digits_callback;
+    void *digits_callback_data;
+    int lost_digits;
+    int current_digits;
+    char digits[MAX_BELL_MF_DIGITS + 1];
+};
+
+struct r2_mf_rx_state_s
+{
+    spangpu_group_t *grp;
+    int channel;
+    int private_grp;
+    span_tone_report_func_t callback;
+    void *callback_data;
+    int fwd;
+    int current_digit;
+};
+
+typedef struct
+{
+    int f1;
+    int f2;
+    int recognition_duration;
+    int min_duration;
+    int max_duration;
+} st_segment_t;
+
+struct super_tone_rx_descriptor_s
+{
+    int used_frequencies;
+    int monitored_frequencies;
+    int pitches[SUPER_TONE_BINS/2][2];
+    int tones;
+    st_segment_t **tone_list;
+    int *tone_segs;
+    float fac[SUPER_TONE_BINS/2];
+    int owned;
+};
+
+struct super_tone_rx_state_s
+{
+    spangpu_group_t *grp;
+    int channel;
+    int private_grp;
+    super_tone_rx_descriptor_t *desc;
+    int detected_tone;
+    int rotation;
+    span_tone_report_func_t tone_callback;
+    tone_segment_func_t segment_callback;
+    void *callback_data;
+    st_segment_t segments[11];
+};
+
+struct goertzel_state_s
+{
+    spangpu_bank_t *bank;
+    float fac;
+    int samples;
+    int current_sample;
+    int has_pending;
+    float pending;
+    int owned;
+};
+
+static void replay(spangpu_group_t *g, int channel, const spangpu_block_t *b, int n);
+static void end_of_call(spangpu_group_t *g, int channel);
+
+spangpu_group_t *spangpu_group_create(int device, int kind, int n_channels, int max_samples,
+                                      const spangpu_tone_params_t *params)
+{
+    spangpu_group_t *g;
+
+    if (n_channels <= 0  ||  max_samples <= 0)
+        return NULL;
+    if ((g = (spangpu_group_t *) calloc(1, sizeof(*g))) == NULL)
+        return NULL;
+    g->kind = kind;
+    g->n_ch = n_channels;
+    g->max_samples = max_samples;
+    if (params)
+        g->params = *params;
+    if (spangpu_bank_create(&g->bank, device, kind, n_channels, &g->params, sizeof(g->params)) != SPANGPU_OK)
+    {
+        free(g);
+        return NULL;
+    }
+    g->stage = (int16_t *) calloc((size_t) n_channels*max_samples, sizeof(int16_t));
+    g->handles = (void **) calloc(n_channels, sizeof(void *));
+    g->staged = (uint8_t *) calloc(n_channels, 1);
+    if (g->stage == NULL  ||  g->handles == NULL  ||  g->staged == NULL)
+    {
+        spangpu_group_destroy(g);
+        return NULL;
+    }
+    return g;
+}
+
+int spangpu_group_destroy(spangpu_group_t *g)
+{
+    if (g == NULL)
+        return SPANGPU_OK;
+    spangpu_bank_destroy(g->bank);
+    free(g->stage);
+    free(g->handles);
+    free(g->staged);
+    free(g->blocks);
+    free(g);
+    return SPANGPU_OK;
+}
+
+spangpu_bank_t *spangpu_group_bank(spangpu_group_t *g)
+{
+    return (g)  ?  g->bank  :  NULL;
+}
+
+int spangpu_group_flush(spangpu_group_t *g)
+{
+    int rc;
+    int n;
+    int i;
+    int start;
+    int ch;
+
+    if (g == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    if (g->n_staged == 0)
+        return 0;
+    if (g->n_staged != g->n_attached)
+        return SPANGPU_ERR_STATE;       /* a channel that has not called xxx_rx() must not advance */
+    rc = spangpu_bank_rx(g->bank, g->stage, SPANGPU_MEM_HOST, SPANGPU_LAYOUT_CHANNEL_MAJOR, g->tick_samples, g->max_samples);
+    if (rc < 0)
+        return rc;
+    n = spangpu_bank_blocks(g->bank, NULL, 0);
+    if (n < 0)
+        return n;
+    if (n > g->blocks_cap)
+    {
+        free(g->blocks);
+        g->blocks_cap = n + 64;
+        if ((g->blocks = (spangpu_block_t *) malloc(sizeof(spangpu_block_t)*g->blocks_cap)) == NULL)
+        {
+            g->blocks_cap = 0;
+            return SPANGPU_ERR_NO_MEMORY;
+        }
+    }
+    if (n > 0  &&  (n = spangpu_bank_blocks(g->bank, g->blocks, g->blocks_cap)) < 0)
+        return n;
+    /* Records arrive in (channel, block) order: replay channel by channel. */
+    start = 0;
+    for (ch = 0;  ch < g->n_ch;  ch++)
+    {
+        i = start;
+        while (i < n  &&  g->blocks[i].channel == ch)
+            i++;
+        if (g->handles[ch])
+        {
+            replay(g, ch, &g->blocks[start], i - start);
+            end_of_call(g, ch);
+        }
+        start = i;
+    }
+    n = g->n_staged;
+    memset(g->staged, 0, g->n_ch);
+    g->n_staged = 0;
+    g->tick_samples = 0;
+    return n;
+}
+
+/* Stage one channel's frame; run the tick when every attached channel has staged. */
+static int group_stage(spangpu_group_t *g, int channel, const int16_t amp[], int samples)
+{
+    if (samples <= 0)
+        return 0;
+    if (samples > g->max_samples)
+        return SPANGPU_ERR_BAD_ARG;
+    if (g->staged[channel])
+        return SPANGPU_ERR_STATE;       /* second frame before the tick ran */
+    if (g->n_staged == 0)
+        g->tick_samples = samples;
+    else if (samples != g->tick_samples)
+        return SPANGPU_ERR_BAD_ARG;     /* all channels of a tick carry the same frame length */
+    memcpy(g->stage + (size_t) channel*g->max_samples, amp, sizeof(int16_t)*samples);
+    g->staged[channel] = 1;
+    g->n_staged++;
+    if (g->n_staged == g->n_attached)
+        return spangpu_group_flush(g);
+    return 0;
+}
+
+static int group_attach(spangpu_group_t *g, int channel, void *handle)
+{
+    if (g == NULL  ||  channel < 0  ||  channel >= g->n_ch  ||  g->handles[channel])
+        return -1;
+    g->handles[channel] = handle;
+    g->n_attached++;
+    spangpu_bank_reset_channel(g->bank, channel, 0);
+    return 0;
+}
+
+static void group_detach(spangpu_group_t *g, int channel)
+{
+    if (g  &&  g->handles[channel])
+    {
+        g->handles[channel] = NULL;
+        g->n_attached--;
+        if (g->staged[channel])
+        {
+            g->staged[channel] = 0;
+            g->n_staged--;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* DTMF                                                                                 */
+/* ------------------------------------------------------------------------------------ */
+static void dtmf_replay(dtmf_rx_state_t *s, const spangpu_block_t *b, int n)
+{
+    int i;
+    int level;
+
+    for (i = 0;  i < n;  i++)
+    {
+        if (b[i].flags & SPANGPU_BLK_CHANGE)
+        {
+            if (s->realtime_callback)
+            {
+                /* dtmf.c:309-316 */
+                if (b[i].flags & SPANGPU_BLK_REPORT)
+                {
+                    if (b[i].flags & SPANGPU_BLK_TONE_OFF)
+                        level = -99;
+                    else
+                        level = (int) (long int) (10.0f*log10f(b[i].energy) - 107.255f);  /* dtmf.c:110,314 */
+                    s->realtime_callback(s->realtime_callback_data, b[i].code, level, b[i].duration);
+                }
+            }
+            else if (b[i].code)
+            {
+                /* dtmf.c:320-340 */
+                if (s->current_digits < MAX_DTMF_DIGITS)
+                {
+                    s->digits[s->current_digits++] = (char) b[i].code;
+                    s->digits[s->current_digits] = '\0';
+                    if (s->digits_callback)
+                    {
+                        s->digits_callback(s->digits_callback_data, s->digits, s->current_digits);
+                        s->current_digits = 0;
+                    }
+                }
+                else
+                {
+                    s->lost_digits++;
+                }
+            }
+            s->in_digit = b[i].code;
+            s->last_hit = b[i].code;
+        }
+        else
+        {
+            s->last_hit = b[i].hit;
+        }
+    }
+}
+
+static void dtmf_end_of_call(dtmf_rx_state_t *s)
+{
+    /* dtmf.c:352-358 */
+    if (s->current_digits  &&  s->digits_callback)
+    {
+        s->digits_callback(s->digits_callback_data, s->digits, s->current_digits);
+        s->digits[0] = '\0';
+        s->current_digits = 0;
+    }
+}
+
+/* A private object owns a one-channel group; its bank is rebuilt when a parameter that
+   is compiled into the bank (report mode, dial-tone filter, thresholds) changes. */
+static int dtmf_private_rebuild(dtmf_rx_state_t *s, int max_samples)
+{
+    float f[64];
+    int32_t w[4];
+    int have_state = 0;
+    int nf = 0;
+
+    if (s->grp)
+    {
+        if (!s->dirty  &&  max_samples <= s->grp->max_samples)
+            return 0;
+        nf = spangpu_bank_get_state(s->grp->bank, 0, f, 64, w, 4);
+        have_state = (nf > 0);
+        if (max_samples < s->grp->max_samples)
+            max_samples = s->grp->max_samples;
+        spangpu_group_destroy(s->grp);
+        s->grp = NULL;
+    }
+    s->params.report_mode = (s->realtime_callback)  ?  SPANGPU_REPORT_REALTIME  :  SPANGPU_REPORT_DIGITS;
+    if ((s->grp = spangpu_group_create(0, SPANGPU_DTMF, 1, (max_samples < 160)  ?  160  :  max_samples, &s->params)) == NULL)
+        return -1;
+    s->grp->handles[0] = s;
+    s->grp->n_attached = 1;
+    if (have_state)
+        spangpu_bank_set_state(s->grp->bank, 0, f, nf, w, 4);
+    s->dirty = 0;
+    return 0;
+}
+
+dtmf_rx_state_t *dtmf_rx_init(dtmf_rx_state_t *s, digits_rx_callback_t callback, void *user_data)
+{
+    int fresh = (s == NULL);
+
+    if (spangpu_device_count() <= 0)
+        return NULL;
+    if (fresh)
+    {
+        if ((s = (dtmf_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+            return NULL;
+        s->private_grp = 1;
+    }
+    else if (s->private_grp)
+    {
+        /* re-initialise in place (dtmf.c:460-467) */
+        spangpu_group_destroy(s->grp);
+        memset(s, 0, sizeof(*s));
+        s->private_grp = 1;
+    }
+    else
+    {
+        spangpu_group_t *g = s->grp;
+        int ch = s->channel;
+
+        memset(s, 0, sizeof(*s));
+        s->grp = g;
+        s->channel = ch;
+        spangpu_bank_reset_channel(g->bank, ch, 0);
+    }
+    s->digits_callback = callback;
+    s->digits_callback_data = user_data;
+    s->dirty = 1;
+    if (s->private_grp  &&  dtmf_private_rebuild(s, 160) < 0)
+    {
+        if (fresh)
+            free(s);
+        return NULL;
+    }
+    return s;
+}
+
+dtmf_rx_state_t *spangpu_dtmf_rx_attach(spangpu_group_t *g, int channel, digits_rx_callback_t callback, void *user_data)
+{
+    dtmf_rx_state_t *s;
+
+    if (g == NULL  ||  g->kind != SPANGPU_DTMF)
+        return NULL;
+    if ((s = (dtmf_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+        return NULL;
+    if (group_attach(g, channel, s) < 0)
+    {
+        free(s);
+        return NULL;
+    }
+    s->grp = g;
+    s->channel = channel;
+    s->digits_callback = callback;
+    s->digits_callback_data = user_data;
+    return s;
+}
+
+int dtmf_rx_release(dtmf_rx_state_t *s)
+{
+    (void) s;
+    return 0;
+}
+
+int dtmf_rx_free(dtmf_rx_state_t *s)
+{
+    if (s == NULL)
+        return 0;
+    if (s->private_grp)
+        spangpu_group_destroy(s->grp);
+    else
+        group_detach(s->grp, s->channel);
+    free(s);
+    return 0;
+}
+
+void dtmf_rx_set_realtime_callback(dtmf_rx_state_t *s, span_tone_report_func_t callback, void *user_data)
+{
+    float f[64];
+    int32_t w[4];
+    int nf;
+
+    s->realtime_callback = callback;
+    s->realtime_callback_data = user_data;
+    /* dtmf.c:415: the duration restarts */
+    if (s->grp  &&  (nf = spangpu_bank_get_state(s->grp->bank, s->channel, f, 64, w, 4)) > 0)
+    {
+        w[3] = 0;
+        spangpu_bank_set_state(s->grp->bank, s->channel, f, nf, w, 4);
+    }
+    if (s->private_grp)
+    {
+        s->dirty = 1;
+        dtmf_private_rebuild(s, 160);
+    }
+    /* On a shared group the report mode is a property of the bank (spangpu_tone_params_t). */
+}
+
+void dtmf_rx_parms(dtmf_rx_state_t *s, int filter_dialtone, float twist, float reverse_twist, float threshold)
+{
+    float f[64];
+    int32_t w[4];
+    int nf;
+
+    if (!s->private_grp)
+        return;                 /* shared banks take their parameters at spangpu_group_create() */
+    if (filter_dialtone >= 0)
+    {
+        /* dtmf.c:428-434: the notch states restart */
+        if (s->grp  &&  (nf = spangpu_bank_get_state(s->grp->bank, 0, f, 64, w, 4)) >= 21)
+        {
+            f[17] = f[18] = f[19] = f[20] = 0.0f;
+            spangpu_bank_set_state(s->grp->bank, 0, f, nf, w, 4);
+        }
+        s->params.filter_dialtone = filter_dialtone;
+    }
+    if (twist >= 0.0f)
+        s->params.twist_db = twist;
+    if (reverse_twist >= 0.0f)
+        s->params.reverse_twist_db = reverse_twist;
+    if (threshold > -99.0f)
+        s->params.threshold_dbm0 = threshold;
+    s->dirty = 1;
+    dtmf_private_rebuild(s, 160);
+}
+
+int dtmf_rx(dtmf_rx_state_t *s, const int16_t amp[], int samples)
+{
+    int pos;
+    int n;
+
+    if (s == NULL  ||  s->grp == NULL)
+        return -1;
+    if (!s->private_grp)
+        return (group_stage(s->grp, s->channel, amp, samples) < 0)  ?  -1  :  0;
+    /* private object: run the frame now, in pieces no longer than the staging row */
+    for (pos = 0;  pos < samples;  pos += n)
+    {
+        n = samples - pos;
+        if (n > s->grp->max_samples)
+            n = s->grp->max_samples;
+        if (group_stage(s->grp, 0, amp + pos, n) < 0)
+            return -1;
+    }
+    return 0;
+}
+
+int dtmf_rx_fillin(dtmf_rx_state_t *s, int samples)
+{
+    (void) samples;
+    if (s  &&  s->grp)
+        spangpu_bank_reset_channel(s->grp->bank, s->channel, 1);
+    return 0;
+}
+
+int dtmf_rx_status(dtmf_rx_state_t *s)
+{
+    if (s->in_digit)
+        return s->in_digit;
+    if (s->last_hit)
+        return 'x';
+    return 0;
+}
+
+size_t dtmf_rx_get(dtmf_rx_state_t *s, char *buf, int max)
+{
+    if (max > s->current_digits)
+        max = s->current_digits;
+    if (max > 0)
+    {
+        memcpy(buf, s->digits, max);
+        memmove(s->digits, s->digits + max, s->current_digits - max);
+        s->current_digits -= max;
+    }
+    buf[max] = '\0';
+    return max;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Bell MF                                                                              */
+/* ------------------------------------------------------------------------------------ */
+static void bell_replay(bell_mf_rx_state_t *s, const spangpu_block_t *b, int n)
+{
+    int i;
+
+    for (i = 0;  i < n;  i++)
+    {
+        if (!(b[i].flags & SPANGPU_BLK_REPORT))
+            continue;
+        /* bell_r2_mf.c:636-655 */
+        if (s->current_digits < MAX_BELL_MF_DIGITS)
+        {
+            s->digits[s->current_digits++] = (char) b[i].code;
+            s->digits[s->current_digits] = '\0';
+            if (s->digits_callback)
+            {
+                s->digits_callback(s->digits_callback_data, s->digits, s->current_digits);
+                s->current_digits = 0;
+            }
+        }
+        else
+        {
+            s->lost_digits++;
+        }
+    }
+}
+
+static void bell_end_of_call(bell_mf_rx_state_t *s)
+{
+    /* bell_r2_mf.c:665-671 */
+    if (s->current_digits  &&  s->digits_callback)
+    {
+        s->digits_callback(s->digits_callback_data, s->digits, s->current_digits);
+        s->digits[0] = '\0';
+        s->current_digits = 0;
+    }
+}
+
+bell_mf_rx_state_t *bell_mf_rx_init(bell_mf_rx_state_t *s, digits_rx_callback_t callback, void *user_data)
+{
+    if (spangpu_device_count() <= 0)
+        return NULL;
+    if (s == NULL)
+    {
+        if ((s = (bell_mf_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+            return NULL;
+        s->private_grp = 1;
+        if ((s->grp = spangpu_group_create(0, SPANGPU_BELL_MF, 1, 160, NULL)) == NULL)
+        {
+            free(s);
+            return NULL;
+        }
+        s->grp->handles[0] = s;
+        s->grp->n_attached = 1;
+    }
+    else
+    {
+        spangpu_bank_reset_channel(s->grp->bank, s->channel, 0);
+        s->lost_digits = 0;
+        s->current_digits = 0;
+        s->digits[0] = '\0';
+    }
+    s->digits_callback = callback;
+    s->digits_callback_data = user_data;
+    return s;
+}
+
+bell_mf_rx_state_t *spangpu_bell_mf_rx_attach(spangpu_group_t *g, int channel, digits_rx_callback_t callback, void *user_data)
+{
+    bell_mf_rx_state_t *s;
+
+    if (g == NULL  ||  g->kind != SPANGPU_BELL_MF)
+        return NULL;
+    if ((s = (bell_mf_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+        return NULL;
+    if (group_attach(g, channel, s) < 0)
+    {
+        free(s);
+        return NULL;
+    }
+    s->grp = g;
+    s->channel = channel;
+    s->digits_callback = callback;
+    s->digits_callback_data = user_data;
+    return s;
+}
+
+int bell_mf_rx_release(bell_mf_rx_state_t *s)
+{
+    (void) s;
+    return 0;
+}
+
+int bell_mf_rx_free(bell_mf_rx_state_t *s)
+{
+    if (s == NULL)
+        return 0;
+    if (s->private_grp)
+        spangpu_group_destroy(s->grp);
+    else
+        group_detach(s->grp, s->channel);
+    free(s);
+    return 0;
+}
+
+static int stage_any(spangpu_group_t *g, int private_grp, int channel, const int16_t amp[], int samples)
+{
+    int pos;
+    int n;
+
+    if (g == NULL)
+        return -1;
+    if (!private_grp)
+        return (group_stage(g, channel, amp, samples) < 0)  ?  -1  :  0;
+    for (pos = 0;  pos < samples;  pos += n)
+    {
+        n = samples - pos;
+        if (n > g->max_samples)
+            n = g->max_samples;
+        if (group_stage(g, 0, amp + pos, n) < 0)
+            return -1;
+    }
+    return 0;
+}
+
+int bell_mf_rx(bell_mf_rx_state_t *s, const int16_t amp[], int samples)
+{
+    return stage_any(s->grp, s->private_grp, s->channel, amp, samples);
+}
+
+size_t bell_mf_rx_get(bell_mf_rx_state_t *s, char *buf, int max)
+{
+    if (max > s->current_digits)
+        max = s->current_digits;
+    if (max > 0)
+    {
+        memcpy(buf, s->digits, max);
+        memmove(s->digits, s->digits + max, s->current_digits - max);
+        s->current_digits -= max;
+    }
+    buf[max] = '\0';
+    return max;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* R2 MF                                                                                */
+/* ------------------------------------------------------------------------------------ */
+static void r2_replay(r2_mf_rx_state_t *s, const spangpu_block_t *b, int n)
+{
+    int i;
+
+    for (i = 0;  i < n;  i++)
+    {
+        /* bell_r2_mf.c:869-876 */
+        if ((b[i].flags & SPANGPU_BLK_REPORT)  &&  s->callback)
+            s->callback(s->callback_data, b[i].code, (b[i].code)  ?  -10  :  -99, 0);
+        s->current_digit = b[i].code;
+    }
+}
+
+r2_mf_rx_state_t *r2_mf_rx_init(r2_mf_rx_state_t *s, bool fwd, span_tone_report_func_t callback, void *user_data)
+{
+    spangpu_tone_params_t p;
+
+    if (spangpu_device_count() <= 0)
+        return NULL;
+    if (s == NULL)
+    {
+        if ((s = (r2_mf_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+            return NULL;
+        s->private_grp = 1;
+        memset(&p, 0, sizeof(p));
+        p.r2_fwd = fwd;
+        if ((s->grp = spangpu_group_create(0, SPANGPU_R2_MF, 1, 160, &p)) == NULL)
+        {
+            free(s);
+            return NULL;
+        }
+        s->grp->handles[0] = s;
+        s->grp->n_attached = 1;
+    }
+    else
+    {
+        spangpu_bank_reset_channel(s->grp->bank, s->channel, 0);
+    }
+    s->fwd = fwd;
+    s->callback = callback;
+    s->callback_data = user_data;
+    s->current_digit = 0;
+    return s;
+}
+
+r2_mf_rx_state_t *spangpu_r2_mf_rx_attach(spangpu_group_t *g, int channel, span_tone_report_func_t callback, void *user_data)
+{
+    r2_mf_rx_state_t *s;
+
+    if (g == NULL  ||  g->kind != SPANGPU_R2_MF)
+        return NULL;
+    if ((s = (r2_mf_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+        return NULL;
+    if (group_attach(g, channel, s) < 0)
+    {
+        free(s);
+        return NULL;
+    }
+    s->grp = g;
+    s->channel = channel;
+    s->fwd = g->params.r2_fwd;
+    s->callback = callback;
+    s->callback_data = user_data;
+    return s;
+}
+
+int r2_mf_rx_release(r2_mf_rx_state_t *s)
+{
+    (void) s;
+    return 0;
+}
+
+int r2_mf_rx_free(r2_mf_rx_state_t *s)
+{
+    if (s == NULL)
+        return 0;
+    if (s->private_grp)
+        spangpu_group_destroy(s->grp);
+    else
+        group_detach(s->grp, s->channel);
+    free(s);
+    return 0;
+}
+
+int r2_mf_rx(r2_mf_rx_state_t *s, const int16_t amp[], int samples)
+{
+    return stage_any(s->grp, s->private_grp, s->channel, amp, samples);
+}
+
+int r2_mf_rx_get(r2_mf_rx_state_t *s)
+{
+    return s->current_digit;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Super tone: descriptor building and cadence matching on the host                      */
+/* ------------------------------------------------------------------------------------ */
+super_tone_rx_descriptor_t *super_tone_rx_make_descriptor(super_tone_rx_descriptor_t *desc)
+{
+    int owned = 0;
+
+    if (desc == NULL)
+    {
+        if ((desc = (super_tone_rx_descriptor_t *) malloc(sizeof(*desc))) == NULL)
+            return NULL;
+        owned = 1;
+    }
+    memset(desc, 0, sizeof(*desc));
+    desc->owned = owned;
+    return desc;
+}
+
+int super_tone_rx_free_descriptor(super_tone_rx_descriptor_t *desc)
+{
+    int i;
+
+    if (desc)
+    {
+        for (i = 0;  i < desc->tones;  i++)
+            free(desc->tone_list[i]);
+        free(desc->tone_list);
+        free(desc->tone_segs);
+        if (desc->owned)
+            free(desc);
+    }
+    return 0;
+}
+
+/* super_tone_rx.c:81-123 (including its habit of storing the pitch index, not the bin
+   number, for a merged entry) */
+static int st_add_freq(super_tone_rx_descriptor_t *desc, int freq)
+{
+    int i;
+
+    if (freq == 0)
+        return -1;
+    for (i = 0;  i < desc->used_frequencies;  i++)
+    {
+        if (desc->pitches[i][0] == freq)
+            return desc->pitches[i][1];
+    }
+    for (i = 0;  i < desc->used_frequencies;  i++)
+    {
+        if ((desc->pitches[i][0] - 10) <= freq  &&  freq <= (desc->pitches[i][0] + 10))
+        {
+            desc->pitches[desc->used_frequencies][0] = freq;
+            desc->pitches[desc->used_frequencies][1] = i;
+            desc->fac[desc->pitches[i][1]] = spangpu_goertzel_fac((float) (freq + desc->pitches[i][0])/2);
+            desc->used_frequencies++;
+            return desc->pitches[i][1];
+        }
+    }
+    desc->pitches[i][0] = freq;
+    desc->pitches[i][1] = desc->monitored_frequencies;
+    desc->fac[desc->monitored_frequencies++] = spangpu_goertzel_fac((float) freq);
+    desc->used_frequencies++;
+    return desc->pitches[i][1];
+}
+
+int super_tone_rx_add_tone(super_tone_rx_descriptor_t *desc)
+{
+    if (desc->tones%5 == 0)
+    {
+        desc->tone_list = (st_segment_t **) realloc(desc->tone_list, (desc->tones + 5)*sizeof(st_segment_t *));
+        desc->tone_segs = (int *) realloc(desc->tone_segs, (desc->tones + 5)*sizeof(int));
+    }
+    desc->tone_list[desc->tones] = NULL;
+    desc->tone_segs[desc->tones] = 0;
+    desc->tones++;
+    return desc->tones - 1;
+}
+
+int super_tone_rx_add_element(super_tone_rx_descriptor_t *desc, int tone, int f1, int f2, int min, int max)
+{
+    int step = desc->tone_segs[tone];
+
+    if (step%5 == 0)
+        desc->tone_list[tone] = (st_segment_t *) realloc(desc->tone_list[tone], (step + 5)*sizeof(st_segment_t));
+    desc->tone_list[tone][step].f1 = st_add_freq(desc, f1);
+    desc->tone_list[tone][step].f2 = st_add_freq(desc, f2);
+    desc->tone_list[tone][step].min_duration = min*8;
+    desc->tone_list[tone][step].max_duration = (max == 0)  ?  0x7FFFFFFF  :  max*8;
+    desc->tone_segs[tone]++;
+    return step;
+}
+
+/* super_tone_rx.c:164-228 */
+static int st_test_cadence(const st_segment_t *pattern, int steps, const st_segment_t *test, int rotation)
+{
+    int i;
+    int j;
+
+    if (rotation >= 0)
+    {
+        j = 0;
+        if (steps < 0)
+        {
+            steps = -steps;
+            j = (rotation + steps - 2)%steps;
+            if (pattern[j].f1 != test[8].f1  ||  pattern[j].f2 != test[8].f2)
+                return 0;
+            if (pattern[j].min_duration > test[8].min_duration*SUPER_TONE_BINS
+                ||  pattern[j].max_duration < test[8].min_duration*SUPER_TONE_BINS)
+            {
+                return 0;
+            }
+        }
+        if (steps)
+            j = (rotation + steps - 1)%steps;
+        if (pattern[j].f1 != test[9].f1  ||  pattern[j].f2 != test[9].f2)
+            return 0;
+        if (pattern[j].max_duration < test[9].min_duration*SUPER_TONE_BINS)
+            return 0;
+    }
+    else
+    {
+        for (i = 0;  i < steps;  i++)
+        {
+            j = i + 10 - steps;
+            if (pattern[i].f1 != test[j].f1  ||  pattern[i].f2 != test[j].f2)
+                return 0;
+            if (pattern[i].min_duration > test[j].min_duration*SUPER_TONE_BINS
+                ||  pattern[i].max_duration < test[j].min_duration*SUPER_TONE_BINS)
+            {
+                return 0;
+            }
+        }
+    }
+    return 1;
+}
+
+/* One 128-sample block decided on the device as (k1, k2): super_tone_rx.c:364-448 */
+static void st_block(super_tone_rx_state_t *s, int k1, int k2)
+{
+    super_tone_rx_descriptor_t *d = s->desc;
+    int j;
+
+    if (k1 != s->segments[10].f1  ||  k2 != s->segments[10].f2)
+    {
+        s->segments[10].f1 = k1;
+        s->segments[10].f2 = k2;
+        s->segments[9].min_duration++;
+    }
+    else
+    {
+        if (k1 != s->segments[9].f1  ||  k2 != s->segments[9].f2)
+        {
+            if (s->detected_tone >= 0)
+            {
+                if (!st_test_cadence(d->tone_list[s->detected_tone], -d->tone_segs[s->detected_tone], s->segments, s->rotation++))
+                {
+                    s->detected_tone = -1;
+                    s->tone_callback(s->callback_data, s->detected_tone, -10, 0);
+                }
+            }
+            if (s->segment_callback)
+            {
+                s->segment_callback(s->callback_data, s->segments[9].f1, s->segments[9].f2,
+                                    s->segments[9].min_duration*SUPER_TONE_BINS/8);
+            }
+            memmove(&s->segments[0], &s->segments[1], 9*sizeof(s->segments[0]));
+            s->segments[9].f1 = k1;
+            s->segments[9].f2 = k2;
+            s->segments[9].min_duration = 1;
+        }
+        else
+        {
+            if (s->detected_tone >= 0)
+            {
+                if (!st_test_cadence(d->tone_list[s->detected_tone], d->tone_segs[s->detected_tone], s->segments, s->rotation))
+                {
+                    s->detected_tone = -1;
+                    s->tone_callback(s->callback_data, s->detected_tone, -10, 0);
+                }
+            }
+            s->segments[9].min_duration++;
+        }
+    }
+    if (s->detected_tone < 0)
+    {
+        for (j = 0;  j < d->tones;  j++)
+        {
+            if (st_test_cadence(d->tone_list[j], d->tone_segs[j], s->segments, -1))
+            {
+                s->detected_tone = j;
+                s->rotation = 0;
+                s->tone_callback(s->callback_data, s->detected_tone, -10, 0);
+                break;
+            }
+        }
+    }
+}
+
+static void st_replay(super_tone_rx_state_t *s, const spangpu_block_t *b, int n)
+{
+    int i;
+
+    for (i = 0;  i < n;  i++)
+        st_block(s, b[i].hit, b[i].code);
+}
+
+static void st_reset(super_tone_rx_state_t *s, super_tone_rx_descriptor_t *desc, span_tone_report_func_t callback, void *user_data)
+{
+    int i;
+
+    for (i = 0;  i < 11;  i++)
+    {
+        s->segments[i].f1 = -1;
+        s->segments[i].f2 = -1;
+        s->segments[i].min_duration = 0;
+    }
+    s->segment_callback = NULL;
+    s->tone_callback = callback;
+    s->callback_data = user_data;
+    s->desc = desc;
+    s->detected_tone = -1;
+    s->rotation = 0;
+}
+
+static void st_params(const super_tone_rx_descriptor_t *desc, spangpu_tone_params_t *p)
+{
+    int i;
+
+    memset(p, 0, sizeof(*p));
+    p->n_bins = desc->monitored_frequencies;
+    for (i = 0;  i < desc->monitored_frequencies  &&  i < SPANGPU_MAX_BINS;  i++)
+        p->bin_fac[i] = desc->fac[i];
+}
+
+super_tone_rx_state_t *super_tone_rx_init(super_tone_rx_state_t *s, super_tone_rx_descriptor_t *desc,
+                                          span_tone_report_func_t callback, void *user_data)
+{
+    spangpu_tone_params_t p;
+
+    if (desc == NULL  ||  callback == NULL)
+        return NULL;                                        /* super_tone_rx.c:514-519 */
+    if (desc->monitored_frequencies < 2  ||  desc->monitored_frequencies > SPANGPU_MAX_BINS)
+        return NULL;
+    if (spangpu_device_count() <= 0)
+        return NULL;
+    if (s == NULL)
+    {
+        if ((s = (super_tone_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+            return NULL;
+        s->private_grp = 1;
+        st_params(desc, &p);
+        if ((s->grp = spangpu_group_create(0, SPANGPU_SUPER_TONE, 1, 160, &p)) == NULL)
+        {
+            free(s);
+            return NULL;
+        }
+        s->grp->handles[0] = s;
+        s->grp->n_attached = 1;
+    }
+    else
+    {
+        spangpu_bank_reset_channel(s->grp->bank, s->channel, 0);
+    }
+    st_reset(s, desc, callback, user_data);
+    return s;
+}
+
+super_tone_rx_state_t *spangpu_super_tone_rx_attach(spangpu_group_t *g, int channel, super_tone_rx_descriptor_t *desc,
+                                                    span_tone_report_func_t callback, void *user_data)
+{
+    super_tone_rx_state_t *s;
+
+    if (g == NULL  ||  g->kind != SPANGPU_SUPER_TONE  ||  desc == NULL  ||  callback == NULL)
+        return NULL;
+    if ((s = (super_tone_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+        return NULL;
+    if (group_attach(g, channel, s) < 0)
+    {
+        free(s);
+        return NULL;
+    }
+    s->grp = g;
+    s->channel = channel;
+    st_reset(s, desc, callback, user_data);
+    return s;
+}
+
+/* Bank parameters for a group whose channels all use `desc` (one descriptor per bank). */
+int spangpu_super_tone_params(const super_tone_rx_descriptor_t *desc, spangpu_tone_params_t *params)
+{
+    if (desc == NULL  ||  params == NULL  ||  desc->monitored_frequencies < 2  ||  desc->monitored_frequencies > SPANGPU_MAX_BINS)
+        return SPANGPU_ERR_BAD_ARG;
+    st_params(desc, params);
+    return SPANGPU_OK;
+}
+
+int super_tone_rx_release(super_tone_rx_state_t *s)
+{
+    (void) s;
+    return 0;
+}
+
+int super_tone_rx_free(super_tone_rx_state_t *s)
+{
+    if (s == NULL)
+        return 0;
+    if (s->private_grp)
+        spangpu_group_destroy(s->grp);
+    else
+        group_detach(s->grp, s->channel);
+    free(s);
+    return 0;
+}
+
+void super_tone_rx_tone_callback(super_tone_rx_state_t *s, span_tone_report_func_t callback, void *user_data)
+{
+    s->tone_callback = callback;
+    s->callback_data = user_data;
+}
+
+void super_tone_rx_segment_callback(super_tone_rx_state_t *s, tone_segment_func_t callback)
+{
+    s->segment_callback = callback;
+}
+
+int super_tone_rx(super_tone_rx_state_t *s, const int16_t amp[], int samples)
+{
+    if (stage_any(s->grp, s->private_grp, s->channel, amp, samples) < 0)
+        return -1;
+    return samples;                                         /* super_tone_rx.c:489 */
+}
+
+int super_tone_rx_fillin(super_tone_rx_state_t *s, int samples)
+{
+    (void) s;
+    (void) samples;
+    return 0;                                               /* super_tone_rx.c:493-497 */
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Goertzel: one bin, one channel, on a generic bank                                     */
+/* ------------------------------------------------------------------------------------ */
+void make_goertzel_descriptor(goertzel_descriptor_t *t, float freq, int samples)
+{
+    t->fac = spangpu_goertzel_fac(freq);
+    t->samples = samples;
+}
+
+goertzel_state_t *goertzel_init(goertzel_state_t *s, goertzel_descriptor_t *t)
+{
+    spangpu_tone_params_t p;
+    int owned = 0;
+
+    if (spangpu_device_count() <= 0  ||  t == NULL)
+        return NULL;
+    if (s == NULL)
+    {
+        if ((s = (goertzel_state_t *) calloc(1, sizeof(*s))) == NULL)
+            return NULL;
+        owned = 1;
+    }
+    else if (s->bank)
+    {
+        spangpu_bank_destroy(s->bank);
+        owned = s->owned;
+    }
+    memset(s, 0, sizeof(*s));
+    s->owned = owned;
+    s->fac = t->fac;
+    s->samples = t->samples;
+    memset(&p, 0, sizeof(p));
+    p.n_bins = 1;
+    p.block_len = t->samples;
+    p.bin_fac[0] = t->fac;
+    if (spangpu_bank_create(&s->bank, 0, SPANGPU_GOERTZEL, 1, &p, sizeof(p)) != SPANGPU_OK)
+    {
+        if (owned)
+            free(s);
+        return NULL;
+    }
+    return s;
+}
+
+int goertzel_release(goertzel_state_t *s)
+{
+    (void) s;
+    return 0;
+}
+
+int goertzel_free(goertzel_state_t *s)
+{
+    if (s)
+    {
+        spangpu_bank_destroy(s->bank);
+        if (s->owned)
+            free(s);
+    }
+    return 0;
+}
+
+void goertzel_reset(goertzel_state_t *s)
+{
+    spangpu_bank_reset_channel(s->bank, 0, 0);
+    s->current_sample = 0;
+    s->has_pending = 0;
+}
+
+/* tone_detect.c:123-156: consumes at most the remainder of the block */
+int goertzel_update(goertzel_state_t *s, const int16_t amp[], int samples)
+{
+    float e[8];
+
+    if (samples > s->samples - s->current_sample)
+        samples = s->samples - s->current_sample;
+    if (samples <= 0)
+        return 0;
+    if (spangpu_bank_rx(s->bank, amp, SPANGPU_MEM_HOST, SPANGPU_LAYOUT_CHANNEL_MAJOR, samples, samples) < 0)
+        return 0;
+    s->current_sample += samples;
+    if (s->current_sample >= s->samples)
+    {
+        /* the block completed on the device: its energy is waiting for goertzel_result() */
+        if (spangpu_bank_trace(s->bank, e, 8) >= 1)
+        {
+            s->pending = e[0];
+            s->has_pending = 1;
+        }
+    }
+    else
+    {
+        spangpu_bank_sync(s->bank);
+    }
+    return samples;
+}
+
+/* tone_detect.c:160-205: evaluate (pushing one zero sample) and reset */
+float goertzel_result(goertzel_state_t *s)
+{
+    float e[8];
+    float r = 0.0f;
+
+    if (s->has_pending)
+    {
+        r = s->pending;
+    }
+    else if (spangpu_bank_force_block(s->bank) == SPANGPU_OK  &&  spangpu_bank_trace(s->bank, e, 8) >= 1)
+    {
+        r = e[0];
+    }
+    s->has_pending = 0;
+    s->current_sample = 0;
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------ */
+static void replay(spangpu_group_t *g, int channel, const spangpu_block_t *b, int n)
+{
+    void *h = g->handles[channel];
+
+    switch (g->kind)
+    {
+    case SPANGPU_DTMF:
+        dtmf_replay((dtmf_rx_state_t *) h, b, n);
+        break;
+    case SPANGPU_BELL_MF:
+        bell_replay((bell_mf_rx_state_t *) h, b, n);
+        break;
+    case SPANGPU_R2_MF:
+        r2_replay((r2_mf_rx_state_t *) h, b, n);
+        break;
+    case SPANGPU_SUPER_TONE:
+        st_replay((super_tone_rx_state_t *) h, b, n);
+        break;
+    }
+}
+
+static void end_of_call(spangpu_group_t *g, int channel)
+{
+    void *h = g->handles[channel];
+
+    switch (g->kind)
+    {
+    case SPANGPU_DTMF:
+        dtmf_end_of_call((dtmf_rx_state_t *) h);
+        break;
+    case SPANGPU_BELL_MF:
+        bell_end_of_call((bell_mf_rx_state_t *) h);
+        break;
+    }
+}

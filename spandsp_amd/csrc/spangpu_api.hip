@@ -365,6 +365,82 @@ int spangpu_bank_set_timing(spangpu_bank_t *b, int on)
     return SPANGPU_OK;
 }
 
+static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stride, int samples, int layout, int maxb, int force_end)
+{
+    ToneLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.amp = d_amp;
+    L.stride = d_stride;
+    L.samples = samples;
+    L.n_ch = b->n_ch;
+    L.layout = layout;
+    L.aligned16 = (layout == SPANGPU_LAYOUT_CHANNEL_MAJOR
+                   &&  (((uintptr_t) d_amp) & 15) == 0
+                   &&  (d_stride & 7) == 0
+                   &&  d_stride >= ((samples + 7) & ~7))  ?  1  :  0;
+    L.sf = b->sf;
+    L.si = b->si;
+    L.rec = b->rec;
+    L.rec_energy = b->rec_energy;
+    L.rec_dur = b->rec_dur;
+    L.trace = b->trace;
+    L.maxb = maxb;
+    L.nbins = (b->kind == SPANGPU_SUPER_TONE  ||  b->kind == SPANGPU_GOERTZEL)  ?  b->tp.n_bins  :  b->nb;
+    L.block_len = b->block_len;
+    L.force_end = force_end;
+    L.realtime = (b->kind == SPANGPU_DTMF  &&  b->tp.report_mode == SPANGPU_REPORT_REALTIME)  ?  1  :  0;
+    for (int i = 0;  i < kMaxBins;  i++)
+        L.fac[i] = b->fac[i];
+    L.threshold = b->threshold;
+    L.normal_twist = b->normal_twist;
+    L.reverse_twist = b->reverse_twist;
+
+    if (b->timing)
+        HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    switch (b->kind)
+    {
+    case SPANGPU_DTMF:
+        if (b->tp.filter_dialtone)
+            launch_tone<DtmfDet<true>>(L, b->stream);
+        else
+            launch_tone<DtmfDet<false>>(L, b->stream);
+        break;
+    case SPANGPU_BELL_MF:
+        launch_tone<BellMfDet>(L, b->stream);
+        break;
+    case SPANGPU_R2_MF:
+        launch_tone<R2MfDet>(L, b->stream);
+        break;
+    case SPANGPU_SUPER_TONE:
+        switch (b->nb)
+        {
+        case 4:  launch_tone<MultiDet<4, true>>(L, b->stream);  break;
+        case 8:  launch_tone<MultiDet<8, true>>(L, b->stream);  break;
+        case 12: launch_tone<MultiDet<12, true>>(L, b->stream); break;
+        default: launch_tone<MultiDet<16, true>>(L, b->stream); break;
+        }
+        break;
+    case SPANGPU_GOERTZEL:
+        switch (b->nb)
+        {
+        case 4:  launch_tone<MultiDet<4, false>>(L, b->stream);  break;
+        case 8:  launch_tone<MultiDet<8, false>>(L, b->stream);  break;
+        case 12: launch_tone<MultiDet<12, false>>(L, b->stream); break;
+        default: launch_tone<MultiDet<16, false>>(L, b->stream); break;
+        }
+        break;
+    default:
+        return fail(SPANGPU_ERR_UNSUPPORTED, "kind %d", b->kind);
+    }
+    HIP_TRY(hipGetLastError());
+    if (b->timing)
+    {
+        HIP_TRY(hipEventRecord(b->ev1, b->stream));
+        b->ev_valid = true;
+    }
+    return SPANGPU_OK;
+}
+
 int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, int samples, long long stride)
 {
     if (b == nullptr  ||  amp == nullptr  ||  samples < 0)
@@ -424,79 +500,28 @@ int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, 
         return fail(SPANGPU_ERR_BAD_ARG, "bad mem kind");
     }
 
-    ToneLaunch L;
-    memset(&L, 0, sizeof(L));
-    L.amp = d_amp;
-    L.stride = d_stride;
-    L.samples = samples;
-    L.n_ch = b->n_ch;
-    L.layout = layout;
-    L.aligned16 = (layout == SPANGPU_LAYOUT_CHANNEL_MAJOR
-                   &&  (((uintptr_t) d_amp) & 15) == 0
-                   &&  (d_stride & 7) == 0
-                   &&  d_stride >= ((samples + 7) & ~7))  ?  1  :  0;
-    L.sf = b->sf;
-    L.si = b->si;
-    L.rec = b->rec;
-    L.rec_energy = b->rec_energy;
-    L.rec_dur = b->rec_dur;
-    L.trace = b->trace;
-    L.maxb = maxb;
-    L.nbins = (b->kind == SPANGPU_SUPER_TONE  ||  b->kind == SPANGPU_GOERTZEL)  ?  b->tp.n_bins  :  b->nb;
-    L.block_len = b->block_len;
-    L.realtime = (b->kind == SPANGPU_DTMF  &&  b->tp.report_mode == SPANGPU_REPORT_REALTIME)  ?  1  :  0;
-    for (int i = 0;  i < kMaxBins;  i++)
-        L.fac[i] = b->fac[i];
-    L.threshold = b->threshold;
-    L.normal_twist = b->normal_twist;
-    L.reverse_twist = b->reverse_twist;
-
-    if (b->timing)
-        HIP_TRY(hipEventRecord(b->ev0, b->stream));
-    switch (b->kind)
-    {
-    case SPANGPU_DTMF:
-        if (b->tp.filter_dialtone)
-            launch_tone<DtmfDet<true>>(L, b->stream);
-        else
-            launch_tone<DtmfDet<false>>(L, b->stream);
-        break;
-    case SPANGPU_BELL_MF:
-        launch_tone<BellMfDet>(L, b->stream);
-        break;
-    case SPANGPU_R2_MF:
-        launch_tone<R2MfDet>(L, b->stream);
-        break;
-    case SPANGPU_SUPER_TONE:
-        switch (b->nb)
-        {
-        case 4:  launch_tone<MultiDet<4, true>>(L, b->stream);  break;
-        case 8:  launch_tone<MultiDet<8, true>>(L, b->stream);  break;
-        case 12: launch_tone<MultiDet<12, true>>(L, b->stream); break;
-        default: launch_tone<MultiDet<16, true>>(L, b->stream); break;
-        }
-        break;
-    case SPANGPU_GOERTZEL:
-        switch (b->nb)
-        {
-        case 4:  launch_tone<MultiDet<4, false>>(L, b->stream);  break;
-        case 8:  launch_tone<MultiDet<8, false>>(L, b->stream);  break;
-        case 12: launch_tone<MultiDet<12, false>>(L, b->stream); break;
-        default: launch_tone<MultiDet<16, false>>(L, b->stream); break;
-        }
-        break;
-    default:
-        return fail(SPANGPU_ERR_UNSUPPORTED, "kind %d", b->kind);
-    }
-    HIP_TRY(hipGetLastError());
-    if (b->timing)
-    {
-        HIP_TRY(hipEventRecord(b->ev1, b->stream));
-        b->ev_valid = true;
-    }
+    rc = launch_bank(b, d_amp, d_stride, samples, layout, maxb, 0);
+    if (rc < 0)
+        return rc;
     b->last_maxb = maxb;
     b->last_samples = samples;
     return 0;
+}
+
+int spangpu_bank_force_block(spangpu_bank_t *b)
+{
+    if (b == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "null bank");
+    HIP_TRY(hipSetDevice(b->device));
+    int rc = ensure_outputs(b, 1);
+    if (rc != SPANGPU_OK)
+        return rc;
+    rc = launch_bank(b, nullptr, 0, 0, SPANGPU_LAYOUT_CHANNEL_MAJOR, 1, 1);
+    if (rc < 0)
+        return rc;
+    b->last_maxb = 1;
+    b->last_samples = 0;
+    return SPANGPU_OK;
 }
 
 int spangpu_bank_sync(spangpu_bank_t *b)

@@ -56,6 +56,7 @@ struct ToneLaunch
     int nbins;                  // run-time bin count (<= NB) for super-tone / generic banks
     int block_len;              // run-time block length for the generic bank
     int realtime;               // DTMF: realtime report mode (duration is zeroed on a report)
+    int force_end;              // evaluate the block now, whatever its fill (goertzel_result() mid-block)
     float fac[kMaxBins];
     float threshold;
     float normal_twist;
@@ -614,7 +615,7 @@ void tone_bank_kernel(const ToneLaunch L)
     const int ch = live  ?  (ch0 + cl)  :  (L.n_ch - 1);        // shadow lanes follow the last channel, never store
     const bool store = live  &&  (sub == 0);
 
-    const bool fast_loader = (L.layout == 0)  &&  L.aligned16;
+    const bool fast_loader = (L.layout == 0)  &&  L.aligned16  &&  (L.samples > 0);
     const int nseg = (L.samples + kSeg - 1)/kSeg;
     const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) char *) &lds[wv][0][0];
 
@@ -858,6 +859,11 @@ void tone_bank_kernel(const ToneLaunch L)
                 }
             }
         }
+    }
+    if (L.force_end)
+    {
+        end_block();
+        cs = 0;
     }
     if (Det::kDuration)
     {
