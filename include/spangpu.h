@@ -172,6 +172,40 @@ SPANGPU_API int spangpu_bank_set_timing(spangpu_bank_t *bank, int on);
 /* Bins compiled into the kernel this bank uses (>= the requested n_bins; trace stride). */
 SPANGPU_API int spangpu_bank_bins(const spangpu_bank_t *bank);
 
+/* ---- echo canceller banks --------------------------------------------------------------
+ * N independent G.168 line echo cancellers, state resident in HBM (per channel: 32-bit
+ * LMS taps, four 16-bit tap sets, FIR history, ~40 control words).  Replaces, per channel:
+ *   spangpu_echo_create()         echo_can_init()            src/echo.c:254-301, src/spandsp/echo.h:145
+ *   spangpu_echo_update()         echo_can_hpf_tx() + echo_can_update() per sample
+ *                                                            src/echo.c:421-669, src/spandsp/echo.h:176-183
+ *   spangpu_echo_adaption_mode()  echo_can_adaption_mode()   src/echo.c:324-328
+ *   spangpu_echo_flush()          echo_can_flush()           src/echo.c:331-372
+ *   spangpu_echo_destroy()        echo_can_free()            src/echo.c:309-322
+ * The adaption-mode bits are the reference's (src/spandsp/echo.h:118-127). */
+typedef struct spangpu_echo_s spangpu_echo_t;
+
+#define SPANGPU_ECHO_SCALARS        48      /* control words per channel in get/set_state */
+
+SPANGPU_API int spangpu_echo_create(spangpu_echo_t **ec, int device, int n_channels, int taps, int adaption_mode);
+SPANGPU_API int spangpu_echo_destroy(spangpu_echo_t *ec);
+SPANGPU_API int spangpu_echo_channels(const spangpu_echo_t *ec);
+SPANGPU_API int spangpu_echo_taps(const spangpu_echo_t *ec);
+SPANGPU_API int spangpu_echo_set_stream(spangpu_echo_t *ec, void *hip_stream);
+SPANGPU_API int spangpu_echo_sync(spangpu_echo_t *ec);
+/* Run `samples` samples of every channel: clean[c][i] = echo_can_update(ec_c, tx'[c][i], rx[c][i])
+   with tx' = echo_can_hpf_tx(ec_c, tx) when use_hpf_tx != 0 (the calling sequence of
+   tests/echo_tests.c:577-594).  Channel c's samples start at tx/rx/clean + c*stride. */
+SPANGPU_API int spangpu_echo_update(spangpu_echo_t *ec, const int16_t *tx, const int16_t *rx, int16_t *clean,
+                                    int mem, int samples, long long stride, int use_hpf_tx);
+SPANGPU_API int spangpu_echo_adaption_mode(spangpu_echo_t *ec, int channel, int adaption_mode);
+SPANGPU_API int spangpu_echo_flush(spangpu_echo_t *ec, int channel);
+/* One channel's state in the reference's terms: control words (order: DESIGN.md), taps32[taps],
+   taps16[4][taps], FIR history[taps] in its physical circular order.  Any pointer may be NULL. */
+SPANGPU_API int spangpu_echo_get_state(spangpu_echo_t *ec, int channel, int32_t *scalars, int32_t *taps32,
+                                       int16_t *taps16, int16_t *history);
+SPANGPU_API int spangpu_echo_set_state(spangpu_echo_t *ec, int channel, const int32_t *scalars, const int32_t *taps32,
+                                       const int16_t *taps16, const int16_t *history);
+
 #if defined(__cplusplus)
 }
 #endif

@@ -204,6 +204,65 @@ ORC_API int orc_st_add_element(orc_st_desc_t *d, int tone, int f1, int f2, int m
 ORC_API void orc_st_init(orc_st_t *s, const orc_st_desc_t *d, int use_segment_cb);
 ORC_API int orc_st_rx(orc_st_t *s, const int16_t amp[], int samples, orc_sink_t *sink, orc_block_t *blocks, int max_blocks);
 
+/* ---- G.168 echo canceller ------------------------------------------------------------- */
+#define ORC_ECHO_MAX_TAPS       256
+#define ORC_ECHO_USE_ADAPTION   0x01        /* src/spandsp/echo.h:118-127 */
+#define ORC_ECHO_USE_NLP        0x02
+#define ORC_ECHO_USE_CNG        0x04
+#define ORC_ECHO_USE_CLIP       0x08
+#define ORC_ECHO_USE_SUPPRESSOR 0x10
+#define ORC_ECHO_USE_TX_HPF     0x20
+#define ORC_ECHO_USE_RX_HPF     0x40
+#define ORC_ECHO_DISABLE        0x80
+
+typedef struct
+{
+    /* scalar words, in the order tests read them (see oracle/restated.py ECHO_FIELDS) */
+    int32_t tx_power[4];
+    int32_t rx_power[3];
+    int32_t clean_rx_power;
+    int32_t rx_power_threshold;
+    int32_t nonupdate_dwell;
+    int32_t curr_pos;
+    int32_t taps;
+    int32_t tap_mask;
+    int32_t adaption_mode;
+    int32_t supp_test1;
+    int32_t supp_test2;
+    int32_t supp1;
+    int32_t supp2;
+    int32_t vad;
+    int32_t cng;
+    int32_t geigel_max;
+    int32_t geigel_lag;
+    int32_t dtd_onset;
+    int32_t tap_set;
+    int32_t tap_rotate_counter;
+    int32_t latest_correction;
+    int32_t narrowband_count;
+    int32_t narrowband_score;
+    int32_t fir_curr_pos;
+    int32_t tx_hpf[2];
+    int32_t rx_hpf[2];
+    int32_t cng_level;
+    int32_t cng_rndnum;
+    int32_t cng_filter;
+    int32_t fir_set;            /* which tap set fir_state.coeffs points at */
+    int32_t last_acf[9];
+    int32_t taps32[ORC_ECHO_MAX_TAPS];
+    int16_t taps16[4][ORC_ECHO_MAX_TAPS];
+    int16_t history[ORC_ECHO_MAX_TAPS];
+} orc_echo_t;
+
+ORC_API int orc_echo_sizeof(void);
+ORC_API int orc_echo_init(orc_echo_t *ec, int taps, int adaption_mode);
+ORC_API void orc_echo_adaption_mode(orc_echo_t *ec, int adaption_mode);
+ORC_API void orc_echo_flush(orc_echo_t *ec);
+ORC_API int16_t orc_echo_hpf_tx(orc_echo_t *ec, int16_t tx);
+ORC_API int16_t orc_echo_update(orc_echo_t *ec, int16_t tx, int16_t rx);
+ORC_API void orc_echo_run(orc_echo_t *ec, const int16_t tx[], const int16_t rx[], int16_t clean[], int n, int use_hpf_tx);
+ORC_API void orc_echo_run_batch(orc_echo_t *s, const int16_t tx[], const int16_t rx[], int16_t clean[], int n_ch, long long stride, int n, int use_hpf_tx);
+
 #if defined(__cplusplus)
 }
 #endif

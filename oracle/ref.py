@@ -45,6 +45,7 @@ def lib():
             "glue_goertzel_fac": (cf, [cf, ci]),
             "glue_goertzel_new": (vp, [cf, ci]),
             "glue_goertzel_snapshot": (None, [vp, vp, vp]),
+            "glue_install_padded_allocator": (None, [ci]),
             "glue_echo_run": (None, [vp, vp, vp, vp, ci, ci]),
             "glue_echo_taps": (ci, [vp]),
             "glue_echo_snapshot": (None, [vp, vp, vp, vp, vp]),
@@ -374,3 +375,54 @@ def awgn(seed, level_dbm0, samples):
 
 def saturated_add(a, b):
     return np.clip(a.astype(np.int32) + b.astype(np.int32), -32768, 32767).astype(np.int16)
+
+
+ECHO_FIELDS = ["tx_power0", "tx_power1", "tx_power2", "tx_power3", "rx_power0", "rx_power1", "rx_power2",
+               "clean_rx_power", "rx_power_threshold", "nonupdate_dwell", "curr_pos", "taps", "tap_mask",
+               "adaption_mode", "supp_test1", "supp_test2", "supp1", "supp2", "vad", "cng", "geigel_max",
+               "geigel_lag", "dtd_onset", "tap_set", "tap_rotate_counter", "latest_correction",
+               "narrowband_count", "narrowband_score", "fir_curr_pos", "tx_hpf0", "tx_hpf1", "rx_hpf0",
+               "rx_hpf1", "cng_level", "cng_rndnum", "cng_filter"]
+
+
+class EchoCan:
+    """echo_can_init()/echo_can_update() of the real reference, on a zero-padded heap and
+    with its per-sample debug printf()s sent to /dev/null."""
+
+    def __init__(self, taps, mode):
+        lib().glue_install_padded_allocator(1)
+        self.p = lib().echo_can_init(taps, mode)
+        lib().glue_install_padded_allocator(0)
+        self.taps = taps
+
+    def __del__(self):
+        try:
+            lib().echo_can_free(self.p)
+        except Exception:
+            pass
+
+    def flush(self):
+        lib().echo_can_flush(self.p)
+
+    def adaption_mode(self, mode):
+        lib().echo_can_adaption_mode(self.p, mode)
+
+    def run(self, tx, rx, use_hpf_tx=False):
+        tx = _i16(tx)
+        rx = _i16(rx)
+        out = np.zeros(len(tx), np.int16)
+        with quiet_stdout():
+            lib().glue_echo_run(self.p, tx.ctypes.data, rx.ctypes.data, out.ctypes.data, len(tx), int(use_hpf_tx))
+        return out
+
+    def snapshot(self):
+        i = np.zeros(64, np.int32)
+        t32 = np.zeros(self.taps, np.int32)
+        t16 = np.zeros(4*self.taps, np.int16)
+        h = np.zeros(self.taps, np.int16)
+        lib().glue_echo_snapshot(self.p, i.ctypes.data, t32.ctypes.data, t16.ctypes.data, h.ctypes.data)
+        d = {k: int(v) for k, v in zip(ECHO_FIELDS, i)}
+        d["taps32"] = t32
+        d["taps16"] = t16.reshape(4, self.taps)
+        d["history"] = h
+        return d

@@ -313,6 +313,27 @@ GLUE void glue_goertzel_snapshot(goertzel_state_t *s, float out[3], int32_t iout
 }
 
 /* ---- Echo canceller --------------------------------------------------------- */
+/* narrowband_detect() (echo.c:133-139) reads the FIR history up to index 255 whatever
+   `taps` is.  Give the reference a zero-filled, padded heap through its own allocator hook
+   (span_mem_allocators, alloc.c:142) so that those reads are deterministic (zero). */
+static void *padded_alloc(size_t size)
+{
+    return calloc(1, size + 1024);
+}
+
+static void *padded_realloc(void *ptr, size_t size)
+{
+    return realloc(ptr, size + 1024);
+}
+
+GLUE void glue_install_padded_allocator(int on)
+{
+    if (on)
+        span_mem_allocators(padded_alloc, padded_realloc, free, NULL, NULL);
+    else
+        span_mem_allocators(NULL, NULL, NULL, NULL, NULL);
+}
+
 /* Runs n samples through echo_can_update (optionally echo_can_hpf_tx first, as
    tests/echo_tests.c:577-594 does) and stores the clean signal. */
 GLUE void glue_echo_run(echo_can_state_t *ec, const int16_t tx[], const int16_t rx[], int16_t clean[], int n, int use_hpf_tx)

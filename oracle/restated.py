@@ -55,6 +55,12 @@ def lib():
             "orc_st_add_element": (ci, [vp, ci, ci, ci, ci, ci]),
             "orc_st_init": (None, [vp, vp, ci]),
             "orc_st_rx": (ci, [vp, vp, ci, vp, vp, ci]),
+            "orc_echo_sizeof": (ci, []),
+            "orc_echo_init": (ci, [vp, ci, ci]),
+            "orc_echo_adaption_mode": (None, [vp, ci]),
+            "orc_echo_flush": (None, [vp]),
+            "orc_echo_run": (None, [vp, vp, vp, vp, ci, ci]),
+            "orc_echo_run_batch": (None, [vp, vp, vp, vp, ci, C.c_longlong, ci, ci]),
         }
         for name, (res, args) in sigs.items():
             if not hasattr(L, name):
@@ -231,3 +237,46 @@ class Goertzel:
 
 def goertzel_fac(freq):
     return lib().orc_goertzel_fac(freq)
+
+
+ECHO_FIELDS = ["tx_power0", "tx_power1", "tx_power2", "tx_power3", "rx_power0", "rx_power1", "rx_power2",
+               "clean_rx_power", "rx_power_threshold", "nonupdate_dwell", "curr_pos", "taps", "tap_mask",
+               "adaption_mode", "supp_test1", "supp_test2", "supp1", "supp2", "vad", "cng", "geigel_max",
+               "geigel_lag", "dtd_onset", "tap_set", "tap_rotate_counter", "latest_correction",
+               "narrowband_count", "narrowband_score", "fir_curr_pos", "tx_hpf0", "tx_hpf1", "rx_hpf0",
+               "rx_hpf1", "cng_level", "cng_rndnum", "cng_filter", "fir_set"]
+ECHO_MAX_TAPS = 256
+
+
+class EchoCan:
+    def __init__(self, taps, mode):
+        self.buf = np.zeros(lib().orc_echo_sizeof() + 16, np.uint8)
+        self.p = self.buf.ctypes.data
+        assert lib().orc_echo_init(self.p, taps, mode) == 0
+        self.taps = taps
+
+    def flush(self):
+        lib().orc_echo_flush(self.p)
+
+    def adaption_mode(self, mode):
+        lib().orc_echo_adaption_mode(self.p, mode)
+
+    def run(self, tx, rx, use_hpf_tx=False):
+        tx = _i16(tx)
+        rx = _i16(rx)
+        out = np.zeros(len(tx), np.int16)
+        lib().orc_echo_run(self.p, tx.ctypes.data, rx.ctypes.data, out.ctypes.data, len(tx), int(use_hpf_tx))
+        return out
+
+    def snapshot(self):
+        n = len(ECHO_FIELDS)
+        w = self.buf[:4*(n + 9)].view(np.int32)
+        d = {k: int(v) for k, v in zip(ECHO_FIELDS, w[:n])}
+        d["last_acf"] = w[n:n + 9].copy()
+        off = 4*(n + 9)
+        d["taps32"] = self.buf[off:off + 4*ECHO_MAX_TAPS].view(np.int32)[:self.taps].copy()
+        off += 4*ECHO_MAX_TAPS
+        d["taps16"] = self.buf[off:off + 2*4*ECHO_MAX_TAPS].view(np.int16).reshape(4, ECHO_MAX_TAPS)[:, :self.taps].copy()
+        off += 2*4*ECHO_MAX_TAPS
+        d["history"] = self.buf[off:off + 2*ECHO_MAX_TAPS].view(np.int16)[:self.taps].copy()
+        return d

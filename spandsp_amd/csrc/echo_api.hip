@@ -1,0 +1,349 @@
+// echo_api.hip -- C ABI of the batched G.168 line echo canceller (include/spangpu.h,
+// "echo canceller banks").  Device code: echo_dev.hpp.  No CPU implementation exists
+// behind these entry points.
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/spangpu.h"
+#include "echo_dev.hpp"
+
+using namespace spg;
+
+extern "C" int spangpu_set_error(int code, const char *msg);
+
+#define ECHO_TRY(expr)                                                                      \
+    do                                                                                      \
+    {                                                                                       \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+        {                                                                                   \
+            char m_[256];                                                                   \
+            snprintf(m_, sizeof(m_), "%s failed: %s", #expr, hipGetErrorString(e_));        \
+            return spangpu_set_error(SPANGPU_ERR_HIP, m_);                                  \
+        }                                                                                   \
+    }                                                                                       \
+    while (0)
+
+struct spangpu_echo_s
+{
+    int device;
+    int n_ch;
+    int taps;
+    int tpl;
+    hipStream_t stream;
+    bool own_stream;
+    int32_t *scal;
+    int32_t *taps32;
+    int16_t *taps16;
+    int16_t *hist;
+    int16_t *d_io;          // staging for host-resident tx / rx / clean: [3][n_ch][cap]
+    size_t io_cap;          // samples per channel
+};
+
+__global__ void echo_set_scalar_kernel(int32_t *scal, int lo, int hi, int idx, int value)
+{
+    const int c = lo + blockIdx.x*blockDim.x + threadIdx.x;
+    if (c < hi)
+        scal[(size_t) c*kEchoScalars + idx] = value;
+}
+
+static void init_scalars(int32_t *s, int taps, int mode)
+{
+    // echo_can_init(), echo.c:254-301
+    memset(s, 0, sizeof(int32_t)*kEchoScalars);
+    s[ES_TAPS] = taps;
+    s[ES_CURR_POS] = taps - 1;
+    s[ES_FIR_CURR_POS] = taps - 1;
+    s[ES_TAP_MASK] = taps - 1;
+    s[ES_RX_POWER_THRESHOLD] = 10000000;
+    s[ES_TAP_ROTATE_COUNTER] = 1600;
+    s[ES_CNG_LEVEL] = 1000;
+    s[ES_ADAPTION_MODE] = mode;
+}
+
+extern "C" {
+
+int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int taps, int adaption_mode)
+{
+    if (out == nullptr  ||  n_channels <= 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    *out = nullptr;
+    if (taps != 32  &&  taps != 64  &&  taps != 128  &&  taps != 256)
+        return spangpu_set_error(SPANGPU_ERR_UNSUPPORTED, "echo canceller length must be 32, 64, 128 or 256 taps");
+    if (spangpu_device_count() <= 0)
+        return spangpu_set_error(SPANGPU_ERR_NO_DEVICE, "no HIP device: libspangpu has no CPU fallback");
+    if (device < 0  ||  device >= spangpu_device_count())
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "device out of range");
+    ECHO_TRY(hipSetDevice(device));
+    spangpu_echo_t *e = (spangpu_echo_t *) calloc(1, sizeof(*e));
+    if (e == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "calloc");
+    e->device = device;
+    e->n_ch = n_channels;
+    e->taps = taps;
+    e->tpl = taps/kEchoGroup;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+        free(e);
+        return spangpu_set_error(SPANGPU_ERR_HIP, "hipStreamCreate failed");
+    }
+    e->own_stream = true;
+    const size_t n = (size_t) n_channels;
+    if (hipMalloc(&e->scal, n*kEchoScalars*sizeof(int32_t)) != hipSuccess
+        ||  hipMalloc(&e->taps32, n*taps*sizeof(int32_t)) != hipSuccess
+        ||  hipMalloc(&e->taps16, n*4*taps*sizeof(int16_t)) != hipSuccess
+        ||  hipMalloc(&e->hist, n*taps*sizeof(int16_t)) != hipSuccess)
+    {
+        spangpu_echo_destroy(e);
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "hipMalloc of echo state failed");
+    }
+    (void) hipMemsetAsync(e->taps32, 0, n*taps*sizeof(int32_t), e->stream);
+    (void) hipMemsetAsync(e->taps16, 0, n*4*taps*sizeof(int16_t), e->stream);
+    (void) hipMemsetAsync(e->hist, 0, n*taps*sizeof(int16_t), e->stream);
+    int32_t *h = (int32_t *) malloc(n*kEchoScalars*sizeof(int32_t));
+    if (h == nullptr)
+    {
+        spangpu_echo_destroy(e);
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "malloc");
+    }
+    for (size_t c = 0;  c < n;  c++)
+        init_scalars(h + c*kEchoScalars, taps, adaption_mode);
+    hipError_t rc = hipMemcpyAsync(e->scal, h, n*kEchoScalars*sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+    (void) hipStreamSynchronize(e->stream);
+    free(h);
+    if (rc != hipSuccess)
+    {
+        spangpu_echo_destroy(e);
+        return spangpu_set_error(SPANGPU_ERR_HIP, "state upload failed");
+    }
+    *out = e;
+    return SPANGPU_OK;
+}
+
+int spangpu_echo_destroy(spangpu_echo_t *e)
+{
+    if (e == nullptr)
+        return SPANGPU_OK;
+    (void) hipSetDevice(e->device);
+    if (e->stream)
+        (void) hipStreamSynchronize(e->stream);
+    if (e->scal) (void) hipFree(e->scal);
+    if (e->taps32) (void) hipFree(e->taps32);
+    if (e->taps16) (void) hipFree(e->taps16);
+    if (e->hist) (void) hipFree(e->hist);
+    if (e->d_io) (void) hipFree(e->d_io);
+    if (e->own_stream  &&  e->stream)
+        (void) hipStreamDestroy(e->stream);
+    free(e);
+    return SPANGPU_OK;
+}
+
+int spangpu_echo_channels(const spangpu_echo_t *e) { return e  ?  e->n_ch  :  SPANGPU_ERR_BAD_ARG; }
+int spangpu_echo_taps(const spangpu_echo_t *e) { return e  ?  e->taps  :  SPANGPU_ERR_BAD_ARG; }
+
+int spangpu_echo_set_stream(spangpu_echo_t *e, void *hip_stream)
+{
+    if (e == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null bank");
+    (void) hipStreamSynchronize(e->stream);
+    if (e->own_stream)
+        (void) hipStreamDestroy(e->stream);
+    if (hip_stream)
+    {
+        e->stream = (hipStream_t) hip_stream;
+        e->own_stream = false;
+    }
+    else
+    {
+        ECHO_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    return SPANGPU_OK;
+}
+
+int spangpu_echo_sync(spangpu_echo_t *e)
+{
+    if (e == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null bank");
+    ECHO_TRY(hipStreamSynchronize(e->stream));
+    return SPANGPU_OK;
+}
+
+int spangpu_echo_update(spangpu_echo_t *e, const int16_t *tx, const int16_t *rx, int16_t *clean,
+                        int mem, int samples, long long stride, int use_hpf_tx)
+{
+    if (e == nullptr  ||  tx == nullptr  ||  rx == nullptr  ||  clean == nullptr  ||  samples < 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (samples == 0)
+        return 0;
+    if (stride <= 0)
+        stride = samples;
+    ECHO_TRY(hipSetDevice(e->device));
+    EchoLaunch L;
+    memset(&L, 0, sizeof(L));
+    if (mem == SPANGPU_MEM_HOST)
+    {
+        if ((size_t) samples > e->io_cap)
+        {
+            if (e->d_io) (void) hipFree(e->d_io);
+            e->d_io = nullptr;
+            e->io_cap = 0;
+            ECHO_TRY(hipMalloc(&e->d_io, (size_t) 3*e->n_ch*samples*sizeof(int16_t)));
+            e->io_cap = samples;
+        }
+        int16_t *dtx = e->d_io;
+        int16_t *drx = e->d_io + (size_t) e->n_ch*e->io_cap;
+        int16_t *dcl = e->d_io + (size_t) 2*e->n_ch*e->io_cap;
+        ECHO_TRY(hipMemcpy2DAsync(dtx, e->io_cap*sizeof(int16_t), tx, stride*sizeof(int16_t), samples*sizeof(int16_t),
+                                  e->n_ch, hipMemcpyHostToDevice, e->stream));
+        ECHO_TRY(hipMemcpy2DAsync(drx, e->io_cap*sizeof(int16_t), rx, stride*sizeof(int16_t), samples*sizeof(int16_t),
+                                  e->n_ch, hipMemcpyHostToDevice, e->stream));
+        L.tx = dtx;
+        L.rx = drx;
+        L.clean = dcl;
+        L.stride = (long long) e->io_cap;
+    }
+    else if (mem == SPANGPU_MEM_DEVICE)
+    {
+        L.tx = tx;
+        L.rx = rx;
+        L.clean = clean;
+        L.stride = stride;
+    }
+    else
+    {
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad mem kind");
+    }
+    L.samples = samples;
+    L.n_ch = e->n_ch;
+    L.use_hpf_tx = use_hpf_tx;
+    L.scal = e->scal;
+    L.taps32 = e->taps32;
+    L.taps16 = e->taps16;
+    L.hist = e->hist;
+    const int waves = (e->n_ch + kEchoChPerWave - 1)/kEchoChPerWave;
+    const int blocks = (waves + 3)/4;
+    switch (e->tpl)
+    {
+    case 2:  hipLaunchKernelGGL(echo_bank_kernel<2>, dim3(blocks), dim3(256), 0, e->stream, L);  break;
+    case 4:  hipLaunchKernelGGL(echo_bank_kernel<4>, dim3(blocks), dim3(256), 0, e->stream, L);  break;
+    case 8:  hipLaunchKernelGGL(echo_bank_kernel<8>, dim3(blocks), dim3(256), 0, e->stream, L);  break;
+    default: hipLaunchKernelGGL(echo_bank_kernel<16>, dim3(blocks), dim3(256), 0, e->stream, L); break;
+    }
+    ECHO_TRY(hipGetLastError());
+    if (mem == SPANGPU_MEM_HOST)
+    {
+        ECHO_TRY(hipMemcpy2DAsync(clean, stride*sizeof(int16_t), L.clean, e->io_cap*sizeof(int16_t), samples*sizeof(int16_t),
+                                  e->n_ch, hipMemcpyDeviceToHost, e->stream));
+        ECHO_TRY(hipStreamSynchronize(e->stream));
+    }
+    return 0;
+}
+
+// State export in the REFERENCE's layout: scal[48] as enumerated in echo_dev.hpp (same order
+// as the fields of echo_can_state_t that matter), taps32[T], taps16[4][T], and the FIR
+// history in its physical (circular) order.
+int spangpu_echo_get_state(spangpu_echo_t *e, int channel, int32_t *scal, int32_t *taps32, int16_t *taps16, int16_t *history)
+{
+    if (e == nullptr  ||  channel < 0  ||  channel >= e->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    ECHO_TRY(hipSetDevice(e->device));
+    ECHO_TRY(hipStreamSynchronize(e->stream));
+    const int T = e->taps;
+    int32_t s[kEchoScalars];
+    ECHO_TRY(hipMemcpy(s, e->scal + (size_t) channel*kEchoScalars, sizeof(s), hipMemcpyDeviceToHost));
+    if (scal)
+        memcpy(scal, s, sizeof(s));
+    if (taps32)
+        ECHO_TRY(hipMemcpy(taps32, e->taps32 + (size_t) channel*T, T*sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (taps16)
+        ECHO_TRY(hipMemcpy(taps16, e->taps16 + (size_t) channel*4*T, 4*T*sizeof(int16_t), hipMemcpyDeviceToHost));
+    if (history)
+    {
+        int16_t w[256];
+        ECHO_TRY(hipMemcpy(w, e->hist + (size_t) channel*T, T*sizeof(int16_t), hipMemcpyDeviceToHost));
+        // window order -> physical order: w[i] = history[(i + curr_pos + 1) mod T]
+        for (int i = 0;  i < T;  i++)
+            history[(i + s[ES_CURR_POS] + 1)%T] = w[i];
+    }
+    return SPANGPU_OK;
+}
+
+int spangpu_echo_set_state(spangpu_echo_t *e, int channel, const int32_t *scal, const int32_t *taps32, const int16_t *taps16, const int16_t *history)
+{
+    if (e == nullptr  ||  channel < 0  ||  channel >= e->n_ch  ||  scal == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    ECHO_TRY(hipSetDevice(e->device));
+    ECHO_TRY(hipStreamSynchronize(e->stream));
+    const int T = e->taps;
+    ECHO_TRY(hipMemcpy(e->scal + (size_t) channel*kEchoScalars, scal, kEchoScalars*sizeof(int32_t), hipMemcpyHostToDevice));
+    if (taps32)
+        ECHO_TRY(hipMemcpy(e->taps32 + (size_t) channel*T, taps32, T*sizeof(int32_t), hipMemcpyHostToDevice));
+    if (taps16)
+        ECHO_TRY(hipMemcpy(e->taps16 + (size_t) channel*4*T, taps16, 4*T*sizeof(int16_t), hipMemcpyHostToDevice));
+    if (history)
+    {
+        int16_t w[256];
+        for (int i = 0;  i < T;  i++)
+            w[i] = history[(i + scal[ES_CURR_POS] + 1)%T];
+        ECHO_TRY(hipMemcpy(e->hist + (size_t) channel*T, w, T*sizeof(int16_t), hipMemcpyHostToDevice));
+    }
+    return SPANGPU_OK;
+}
+
+// echo_can_adaption_mode(), echo.c:324-328 (channel < 0: every channel)
+int spangpu_echo_adaption_mode(spangpu_echo_t *e, int channel, int adaption_mode)
+{
+    if (e == nullptr  ||  channel >= e->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    ECHO_TRY(hipSetDevice(e->device));
+    ECHO_TRY(hipStreamSynchronize(e->stream));
+    const int lo = (channel < 0)  ?  0  :  channel;
+    const int hi = (channel < 0)  ?  e->n_ch  :  (channel + 1);
+    hipLaunchKernelGGL(echo_set_scalar_kernel, dim3((hi - lo + 255)/256), dim3(256), 0, e->stream,
+                       e->scal, lo, hi, (int) ES_ADAPTION_MODE, adaption_mode);
+    ECHO_TRY(hipGetLastError());
+    ECHO_TRY(hipStreamSynchronize(e->stream));
+    return SPANGPU_OK;
+}
+
+// echo_can_flush(), echo.c:331-372
+int spangpu_echo_flush(spangpu_echo_t *e, int channel)
+{
+    if (e == nullptr  ||  channel < 0  ||  channel >= e->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    ECHO_TRY(hipSetDevice(e->device));
+    ECHO_TRY(hipStreamSynchronize(e->stream));
+    const int T = e->taps;
+    int32_t s[kEchoScalars];
+    ECHO_TRY(hipMemcpy(s, e->scal + (size_t) channel*kEchoScalars, sizeof(s), hipMemcpyDeviceToHost));
+    s[ES_TX_POWER0] = s[ES_TX_POWER1] = s[ES_TX_POWER2] = s[ES_TX_POWER3] = 0;
+    s[ES_RX_POWER0] = s[ES_RX_POWER1] = s[ES_RX_POWER2] = 0;
+    s[ES_CLEAN_RX_POWER] = 0;
+    s[ES_NONUPDATE_DWELL] = 0;
+    s[ES_FIR_CURR_POS] = T - 1;
+    s[ES_CURR_POS] = T - 1;
+    s[ES_SUPP_TEST1] = s[ES_SUPP_TEST2] = s[ES_SUPP1] = s[ES_SUPP2] = 0;
+    s[ES_VAD] = 0;
+    s[ES_CNG_LEVEL] = 1000;
+    s[ES_CNG_FILTER] = 0;
+    s[ES_GEIGEL_MAX] = s[ES_GEIGEL_LAG] = 0;
+    s[ES_DTD_ONSET] = 0;
+    s[ES_TAP_SET] = 0;                      // fir_state.coeffs (ES_FIR_SET) is deliberately NOT reset
+    s[ES_TAP_ROTATE_COUNTER] = 1600;
+    s[ES_LATEST_CORRECTION] = 0;
+    for (int i = 0;  i < 9;  i++)
+        s[ES_LAST_ACF + i] = 0;
+    s[ES_NARROWBAND_COUNT] = 0;
+    s[ES_NARROWBAND_SCORE] = 0;
+    ECHO_TRY(hipMemcpy(e->scal + (size_t) channel*kEchoScalars, s, sizeof(s), hipMemcpyHostToDevice));
+    ECHO_TRY(hipMemset(e->taps32 + (size_t) channel*T, 0, T*sizeof(int32_t)));
+    ECHO_TRY(hipMemset(e->taps16 + (size_t) channel*4*T, 0, 4*T*sizeof(int16_t)));
+    ECHO_TRY(hipMemset(e->hist + (size_t) channel*T, 0, T*sizeof(int16_t)));
+    return SPANGPU_OK;
+}
+
+}   // extern "C"

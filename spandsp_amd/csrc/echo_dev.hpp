@@ -1,0 +1,552 @@
+// echo_dev.hpp -- device side of the batched G.168 line echo canceller
+// (reference: src/echo.c:120-661, src/spandsp/fir.h:121-183).
+//
+// Mapping: SIXTEEN LANES PER CHANNEL, four channels per wavefront.  A 16-lane group is
+// exactly one DPP row.  Lane j of a group owns taps [j*TPL, (j+1)*TPL) of its channel for
+// the whole frame, in registers: the 32-bit LMS taps, the 16-bit FIR coefficients of the
+// active tap set, and the matching slice of the FIR history.  The history is held in
+// "window order" (w[0] = newest sample), so tap i always meets w[i]; advancing a sample
+// shifts the window by one, which costs ONE row_shr:1 DPP move per lane because the
+// sample loop is unrolled by TPL and the within-lane shift becomes register renaming.
+// Per sample: TPL v_mad_i32_i24 (FIR) + a 4-step DPP row reduction + the scalar control
+// (replicated in the 16 lanes, pure integer) + 2*TPL integer ops (LMS update).  No MFMA
+// (per-channel operands, skinny integer dot products), no floating point except the
+// 32x9 autocorrelation of narrowband_detect.
+//
+// Everything is 32-bit two's complement with wrap-around, as the reference's int
+// arithmetic is on its build (products of 16-bit values through the 24-bit multiplier are
+// exact in the low 32 bits).  The two accidents of the reference snapshot described in
+// DESIGN.md (the fir_taps16[-1] alias onto the FIR history, and the 256-wrap of
+// narrowband_detect) are part of the behaviour and are reproduced.
+//
+// Tap-set bookkeeping: the active set (tap_set) lives in registers and is written back at
+// frame end and at the rare set events (rotation every 1600 adapted samples, double-talk
+// revert, narrow-band revert, divergence zap); the other three sets stay in HBM.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace spg {
+
+// Call f(idx + PH, integral_constant<PH>) for PH = 0..N-1 (compile-time phases).
+template <int PH, int N, class F>
+__device__ __forceinline__ void for_each_phase(F &f, int idx)
+{
+    if constexpr (PH < N)
+    {
+        f(idx + PH, std::integral_constant<int, PH>{});
+        for_each_phase<PH + 1, N>(f, idx);
+    }
+}
+
+constexpr int kEchoScalars = 48;        // int32 words per channel (layout below)
+constexpr int kEchoGroup = 16;          // lanes per channel
+constexpr int kEchoChPerWave = 4;
+
+// Scalar word indices (the control fields of echo_can_state_t, src/spandsp/private/echo.h, in order)
+enum
+{
+    ES_TX_POWER0 = 0, ES_TX_POWER1, ES_TX_POWER2, ES_TX_POWER3,
+    ES_RX_POWER0, ES_RX_POWER1, ES_RX_POWER2,
+    ES_CLEAN_RX_POWER, ES_RX_POWER_THRESHOLD, ES_NONUPDATE_DWELL, ES_CURR_POS, ES_TAPS, ES_TAP_MASK,
+    ES_ADAPTION_MODE, ES_SUPP_TEST1, ES_SUPP_TEST2, ES_SUPP1, ES_SUPP2, ES_VAD, ES_CNG, ES_GEIGEL_MAX,
+    ES_GEIGEL_LAG, ES_DTD_ONSET, ES_TAP_SET, ES_TAP_ROTATE_COUNTER, ES_LATEST_CORRECTION,
+    ES_NARROWBAND_COUNT, ES_NARROWBAND_SCORE, ES_FIR_CURR_POS, ES_TX_HPF0, ES_TX_HPF1, ES_RX_HPF0,
+    ES_RX_HPF1, ES_CNG_LEVEL, ES_CNG_RNDNUM, ES_CNG_FILTER, ES_FIR_SET,
+    ES_LAST_ACF = 37        // 9 words
+};
+
+constexpr int kModeAdaption = 0x01;     // src/spandsp/echo.h:118-127
+constexpr int kModeNlp = 0x02;
+constexpr int kModeCng = 0x04;
+constexpr int kModeTxHpf = 0x20;
+constexpr int kModeRxHpf = 0x40;
+
+struct EchoLaunch
+{
+    const int16_t *tx;          // [n_ch][stride]
+    const int16_t *rx;
+    int16_t *clean;
+    long long stride;
+    int samples;
+    int n_ch;
+    int use_hpf_tx;             // apply echo_can_hpf_tx() to tx first (tests/echo_tests.c:577-594)
+    int32_t *scal;              // [n_ch][kEchoScalars]
+    int32_t *taps32;            // [n_ch][T]
+    int16_t *taps16;            // [n_ch][4][T]
+    int16_t *hist;              // [n_ch][T], window order: hist[i] = history[(i + curr_pos) mod T]
+};
+
+__device__ __forceinline__ int echo_hpf(int32_t &c0, int32_t &c1, int amp)
+{
+    // echo.c:382-419
+    int32_t z = (int32_t) ((uint32_t) amp << 15);
+    z -= (z >> 4);
+    c0 += z - (c0 >> 3) - c1;
+    c1 = z;
+    z = c0 >> 15;
+    z = max(-32768, min(32767, z));         // saturate16()
+    return z;
+}
+
+__device__ __forceinline__ int top_bit_u32(uint32_t v)
+{
+    return (v == 0)  ?  -1  :  (31 - __builtin_clz(v));     // bit_operations.h:45-140
+}
+
+// x86-64 cvttss2si semantics of the reference build: NaN / out of range -> INT32_MIN
+__device__ __forceinline__ int32_t f2i_x86(float v)
+{
+    if (!(v < 2147483648.0f)  ||  !(v >= -2147483648.0f))
+        return (int32_t) 0x80000000u;
+    return (int32_t) v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false);
+}
+
+// Sum over the 16 lanes of a DPP row, result in every lane (wrap-around add).
+__device__ __forceinline__ int row_sum16(int v)
+{
+    v += dpp_mov<0x128>(0, v);      // row_ror:8
+    v += dpp_mov<0x124>(0, v);      // row_ror:4
+    v += dpp_mov<0x122>(0, v);      // row_ror:2
+    v += dpp_mov<0x121>(0, v);      // row_ror:1
+    return v;
+}
+
+template <int TPL>
+__global__ __launch_bounds__(256)
+void echo_bank_kernel(const EchoLaunch L)
+{
+    constexpr int T = TPL*kEchoGroup;
+    constexpr int kMaxFrame = 320;                  // samples staged per pass
+    __shared__ int io[4][kEchoChPerWave][kMaxFrame];        // tx | rx<<16 per sample, then the clean output
+    __shared__ int bounce[4][kEchoChPerWave][T];            // tap-set / history gathers at set events
+    __shared__ float acfbuf[4][kEchoChPerWave][48];         // narrowband_detect scratch
+
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int g = lane >> 4;
+    const int j = lane & 15;
+    const int ch_raw = ((blockIdx.x*4 + wv)*kEchoChPerWave) + g;
+    const bool live = ch_raw < L.n_ch;
+    const int ch = live  ?  ch_raw  :  (L.n_ch - 1);
+    const bool leader = live  &&  (j == 0);
+
+    int32_t *sc = L.scal + (size_t) ch*kEchoScalars;
+    int32_t *g32 = L.taps32 + (size_t) ch*T + j*TPL;
+    int16_t *g16 = L.taps16 + (size_t) ch*4*T + j*TPL;     // + set*T
+    int16_t *gh = L.hist + (size_t) ch*T + j*TPL;
+
+    // ---- scalars (replicated in the 16 lanes of the group) --------------------------------
+    int tx_power0 = sc[ES_TX_POWER0];
+    int tx_power1 = sc[ES_TX_POWER1];
+    int tx_power2 = sc[ES_TX_POWER2];
+    int tx_power3 = sc[ES_TX_POWER3];
+    int rx_power0 = sc[ES_RX_POWER0];
+    int rx_power1 = sc[ES_RX_POWER1];
+    int clean_rx_power = sc[ES_CLEAN_RX_POWER];
+    int nonupdate_dwell = sc[ES_NONUPDATE_DWELL];
+    int curr_pos = sc[ES_CURR_POS];
+    const int mode = sc[ES_ADAPTION_MODE];
+    int cng = sc[ES_CNG];
+    int dtd_onset = sc[ES_DTD_ONSET];
+    int tap_set = sc[ES_TAP_SET];
+    int tap_rotate_counter = sc[ES_TAP_ROTATE_COUNTER];
+    int narrowband_count = sc[ES_NARROWBAND_COUNT];
+    int narrowband_score = sc[ES_NARROWBAND_SCORE];
+    int32_t tx_hpf0 = sc[ES_TX_HPF0];
+    int32_t tx_hpf1 = sc[ES_TX_HPF1];
+    int32_t rx_hpf0 = sc[ES_RX_HPF0];
+    int32_t rx_hpf1 = sc[ES_RX_HPF1];
+    int cng_level = sc[ES_CNG_LEVEL];
+    int cng_rndnum = sc[ES_CNG_RNDNUM];
+    int cng_filter = sc[ES_CNG_FILTER];
+    int fir_set = sc[ES_FIR_SET];
+    int vad = sc[ES_VAD];
+    int my_acf = (j < 9)  ?  sc[ES_LAST_ACF + j]  :  0;         // lane k holds last_acf[k]
+
+    // ---- per-lane tap slices ------------------------------------------------------------------
+    int t32[TPL];               // fir_taps32
+    int t16[TPL];               // fir_taps16[tap_set], sign-extended
+    int f16[TPL];               // fir_taps16[fir_set] (== t16 unless a flush left them apart)
+    int w[TPL];                 // history window slice, physical register order (see `phase`)
+#pragma unroll
+    for (int k = 0;  k < TPL;  k++)
+    {
+        t32[k] = g32[k];
+        t16[k] = g16[tap_set*T + k];
+        f16[k] = g16[fir_set*T + k];
+        w[k] = gh[k];
+    }
+
+    auto load_set = [&](int set, int (&dst)[TPL])
+    {
+#pragma unroll
+        for (int k = 0;  k < TPL;  k++)
+            dst[k] = g16[set*T + k];
+    };
+    auto store_set = [&](int set, const int (&src)[TPL])
+    {
+        if (live)
+        {
+#pragma unroll
+            for (int k = 0;  k < TPL;  k++)
+                g16[set*T + k] = (int16_t) src[k];
+        }
+    };
+
+    for (int base = 0;  base < L.samples;  base += kMaxFrame)
+    {
+        const int n = min(kMaxFrame, L.samples - base);
+        // ---- stage tx/rx of this pass into LDS (each group copies its own channel) ----------
+        for (int i = j;  i < n;  i += kEchoGroup)
+        {
+            const int a = (uint16_t) L.tx[(size_t) ch*L.stride + base + i];
+            const int b = (uint16_t) L.rx[(size_t) ch*L.stride + base + i];
+            io[wv][g][i] = a | (b << 16);
+        }
+        // (one wave per io/bounce/acfbuf slice; LDS ops of a wave complete in order)
+
+        // One sample.  PH is the compile-time rotation phase of the history registers:
+        // logical window slot k of this lane lives in w[(k - PH) mod TPL].
+        auto sample = [&](int idx, auto ph_tag)
+        {
+            constexpr int PH = decltype(ph_tag)::value;
+            const int word = io[wv][g][idx];
+            int tx = (int) (short) (word & 0xFFFF);
+            int rx = (int) (short) (word >> 16);
+            if (L.use_hpf_tx  &&  (mode & kModeTxHpf))
+                tx = echo_hpf(tx_hpf0, tx_hpf1, tx);            // echo.c:663-669
+            if (mode & kModeRxHpf)
+                rx = echo_hpf(rx_hpf0, rx_hpf1, rx);            // echo.c:430
+
+            // fir16(): history[curr_pos] = tx, i.e. the window shifts by one (fir.h:168-183).
+            // The register that held this lane's oldest slot receives the previous lane's
+            // oldest sample; lane 0 of the group receives tx.
+            constexpr int NEWP = (TPL - 1 - PH + 8*TPL)%TPL;     // physical reg of logical slot TPL-1 before the shift
+            w[NEWP] = dpp_mov<0x111>(tx, w[NEWP]);              // row_shr:1, lane 0 keeps `old` = tx
+            // after the shift the phase is PH + 1: logical k -> w[(k - PH - 1) mod TPL]
+            int y = 0;
+#pragma unroll
+            for (int k = 0;  k < TPL;  k++)
+                y += __mul24(f16[k], w[(k - PH - 1 + 8*TPL)%TPL]);
+            y = row_sum16(y);
+            const int echo_value = (int) (short) (y >> 15);
+            int clean_rx = rx - echo_value;                     // echo.c:452
+            if (nonupdate_dwell > 0)
+                nonupdate_dwell--;
+            // echo.c:463-469
+            tx_power3 += ((abs(tx) - tx_power3) >> 5);
+            tx_power2 += ((tx*tx - tx_power2) >> 8);
+            tx_power1 += ((tx*tx - tx_power1) >> 5);
+            tx_power0 += ((tx*tx - tx_power0) >> 3);
+            rx_power1 += ((rx*rx - rx_power1) >> 6);
+            rx_power0 += ((rx*rx - rx_power0) >> 3);
+            clean_rx_power += ((int) ((uint32_t) clean_rx*(uint32_t) clean_rx) - clean_rx_power) >> 6;
+
+            if (tx_power0 > 64*64)                              // MIN_TX_POWER_FOR_ADAPTION
+            {
+                if (tx_power1 > rx_power0)
+                {
+                    if (nonupdate_dwell == 0)
+                    {
+                        if (++narrowband_count >= 160)
+                        {
+                            narrowband_count = 0;
+                            // ---- narrowband_detect(), echo.c:120-175 ---------------------------
+                            // window samples 0..31 -> LDS, then lanes 0..8 each own one lag
+#pragma unroll
+                            for (int k = 0;  k < TPL;  k++)
+                            {
+                                const int i = j*TPL + k;
+                                if (i < 32)
+                                {
+                                    const bool inside = (T == 256)  ||  (curr_pos + i < T);
+                                    acfbuf[wv][g][i] = inside  ?  (float) w[(k - PH - 1 + 8*TPL)%TPL]  :  0.0f;
+                                }
+                            }
+                            float temp = 0.0f;
+                            if (j < 9)
+                            {
+                                for (int i = j;  i < 32;  i++)
+                                    temp += acfbuf[wv][g][i]*acfbuf[wv][g][i - j];
+                                acfbuf[wv][g][32 + j] = temp;
+                            }
+                            const float scale = (float) 0x1FFFFFFF/acfbuf[wv][g][32];
+                            const int acf = f2i_x86(temp*scale);
+                            bool hit = false;
+                            if (my_acf >= 0  &&  acf >= 0)
+                                hit = ((my_acf >> 1) < acf)  &&  (acf < (int) ((uint32_t) my_acf << 1));
+                            else if (my_acf < 0  &&  acf < 0)
+                                hit = ((my_acf >> 1) > acf)  &&  (acf > (int) ((uint32_t) my_acf << 1));
+                            const unsigned long long bal = __ballot(hit  &&  j < 9);
+                            const int score = __popcll((bal >> (g*16)) & 0x1FFull);
+                            if (j < 9)
+                                my_acf = acf;
+                            if (score > 6)
+                            {
+                                if (narrowband_score == 0)
+                                {
+                                    // fir_taps16[3] <- fir_taps16[(tap_set + 1)%3]   (echo.c:494-496)
+                                    int tmp[TPL];
+                                    load_set((tap_set + 1)%3, tmp);
+                                    store_set(3, tmp);
+                                    if (fir_set == 3)
+                                        load_set(3, f16);
+                                }
+                                narrowband_score += score;
+                            }
+                            else
+                            {
+                                if (narrowband_score > 200)
+                                {
+                                    // echo.c:504-510: revert to the set saved in [3]
+                                    load_set(3, t16);
+                                    const int d2 = (tap_set - 1)%3;
+                                    if (d2 >= 0)
+                                    {
+                                        store_set(d2, t16);
+                                    }
+                                    else
+                                    {
+                                        // fir_taps16[-1] is the FIR history: history[p] <- set[p]
+#pragma unroll
+                                        for (int k = 0;  k < TPL;  k++)
+                                            bounce[wv][g][j*TPL + k] = t16[k];
+#pragma unroll
+                                        for (int k = 0;  k < TPL;  k++)
+                                            w[(k - PH - 1 + 8*TPL)%TPL] = bounce[wv][g][(j*TPL + k + curr_pos)%T];
+                                    }
+#pragma unroll
+                                    for (int k = 0;  k < TPL;  k++)
+                                        t32[k] = (int) ((uint32_t) t16[k] << 15);
+                                    if (fir_set == tap_set)
+                                    {
+#pragma unroll
+                                        for (int k = 0;  k < TPL;  k++)
+                                            f16[k] = t16[k];
+                                    }
+                                    else if (fir_set == d2)
+                                    {
+                                        load_set(fir_set, f16);
+                                    }
+                                    tap_rotate_counter = 1600;
+                                }
+                                narrowband_score = 0;
+                            }
+                        }
+                        dtd_onset = 0;
+                        if (--tap_rotate_counter <= 0)
+                        {
+                            // echo.c:518-527: rotate to the next tap set
+                            tap_rotate_counter = 1600;
+                            store_set(tap_set, t16);
+                            tap_set++;
+                            if (tap_set > 2)
+                                tap_set = 0;
+                            fir_set = tap_set;
+                            load_set(tap_set, t16);
+#pragma unroll
+                            for (int k = 0;  k < TPL;  k++)
+                                f16[k] = t16[k];
+                        }
+                        if ((mode & kModeAdaption)  &&  narrowband_score == 0)
+                        {
+                            // echo.c:530-553 + lms_adapt(), echo.c:232-249
+                            int factor = clean_rx;
+                            int sh;
+                            if (tx > 4*tx_power3)
+                                sh = top_bit_u32((uint32_t) tx) - 8;
+                            else
+                                sh = top_bit_u32((uint32_t) tx_power3) - 8;
+                            if (sh > 0)
+                                factor >>= sh;
+                            const bool same = (fir_set == tap_set);
+#pragma unroll
+                            for (int k = 0;  k < TPL;  k++)
+                            {
+                                t32[k] += __mul24(w[(k - PH - 1 + 8*TPL)%TPL], factor);
+                                t16[k] = (int) (short) (t32[k] >> 15);
+                                if (same)
+                                    f16[k] = t16[k];
+                            }
+                        }
+                    }
+                }
+                else
+                {
+                    if (!dtd_onset)
+                    {
+                        // echo.c:562-573: double talk -- fall back to the older tap set
+                        const int src = (tap_set + 1)%3;
+                        const int d2 = (tap_set - 1)%3;
+                        load_set(src, t16);
+                        if (d2 >= 0)
+                        {
+                            store_set(d2, t16);
+                        }
+                        else
+                        {
+#pragma unroll
+                            for (int k = 0;  k < TPL;  k++)
+                                bounce[wv][g][j*TPL + k] = t16[k];
+#pragma unroll
+                            for (int k = 0;  k < TPL;  k++)
+                                w[(k - PH - 1 + 8*TPL)%TPL] = bounce[wv][g][(j*TPL + k + curr_pos)%T];
+                        }
+#pragma unroll
+                        for (int k = 0;  k < TPL;  k++)
+                            t32[k] = (int) ((uint32_t) t16[k] << 15);
+                        if (fir_set == tap_set)
+                        {
+#pragma unroll
+                            for (int k = 0;  k < TPL;  k++)
+                                f16[k] = t16[k];
+                        }
+                        else if (fir_set == d2)
+                        {
+                            load_set(fir_set, f16);
+                        }
+                        tap_rotate_counter = 1600;
+                        dtd_onset = 1;
+                    }
+                    nonupdate_dwell = 600;                      // NONUPDATE_DWELL_TIME
+                }
+            }
+
+            // echo.c:579-582 (vad) has no feedback into the canceller and is overwritten every
+            // sample: it is evaluated once, from the final powers, at write-back.
+            // echo.c:583-591
+            if (rx_power1 > 2048*2048  &&  clean_rx_power > 4*rx_power1)
+            {
+                // The canceller is making things worse: zap every tap set
+#pragma unroll
+                for (int k = 0;  k < TPL;  k++)
+                {
+                    t32[k] = 0;
+                    t16[k] = 0;
+                    f16[k] = 0;
+                }
+                store_set(0, t16);
+                store_set(1, t16);
+                store_set(2, t16);
+                store_set(3, t16);
+            }
+
+            // echo.c:613-651
+            if (mode & kModeNlp)
+            {
+                if (rx_power1 < 30000000)
+                {
+                    if (!cng)
+                    {
+                        cng_level = clean_rx_power;
+                        cng = 1;
+                    }
+                    if (mode & kModeCng)
+                    {
+                        cng_rndnum = (int) (1664525U*(uint32_t) cng_rndnum + 1013904223U);
+                        cng_filter = ((cng_rndnum & 0xFFFF) - 32768 + 5*cng_filter) >> 3;
+                        clean_rx = (int) ((uint32_t) cng_filter*(uint32_t) cng_level) >> 17;
+                    }
+                    else
+                    {
+                        clean_rx = 0;
+                    }
+                }
+                else
+                {
+                    cng = 0;
+                }
+            }
+            else
+            {
+                cng = 0;
+            }
+            // echo.c:655-658
+            if (curr_pos <= 0)
+                curr_pos = T;
+            curr_pos--;
+            if (j == 0)
+                io[wv][g][idx] = (int) (short) clean_rx;        // reuse the slot for the output
+        };
+
+        // ---- walk the pass: TPL samples per unrolled round (phases 0..TPL-1) ------------------
+        int idx = 0;
+        for (  ;  idx + TPL <= n;  idx += TPL)
+        {
+            for_each_phase<0, TPL>(sample, idx);
+        }
+        // tail (frame length not a multiple of TPL): phase 0, then rotate the registers once
+        for (  ;  idx < n;  idx++)
+        {
+            sample(idx, std::integral_constant<int, 0>{});
+            const int last = w[TPL - 1];
+#pragma unroll
+            for (int k = TPL - 1;  k > 0;  k--)
+                w[k] = w[k - 1];
+            w[0] = last;
+        }
+
+        // ---- clean samples out (each group writes its own channel) ---------------------------
+        if (live)
+        {
+            for (int i = j;  i < n;  i += kEchoGroup)
+                L.clean[(size_t) ch*L.stride + base + i] = (int16_t) io[wv][g][i];
+        }
+    }
+
+    // ---- write back -----------------------------------------------------------------------------
+    if (live)
+    {
+#pragma unroll
+        for (int k = 0;  k < TPL;  k++)
+        {
+            g32[k] = t32[k];
+            g16[tap_set*T + k] = (int16_t) t16[k];
+            gh[k] = (int16_t) w[k];
+        }
+        if (j < 9)
+            sc[ES_LAST_ACF + j] = my_acf;
+    }
+    if (leader)
+    {
+        if (L.samples > 0)
+            vad = (rx_power1)  ?  ((int) ((uint32_t) 8000*(uint32_t) clean_rx_power)/rx_power1)  :  0;
+        sc[ES_TX_POWER0] = tx_power0;
+        sc[ES_TX_POWER1] = tx_power1;
+        sc[ES_TX_POWER2] = tx_power2;
+        sc[ES_TX_POWER3] = tx_power3;
+        sc[ES_RX_POWER0] = rx_power0;
+        sc[ES_RX_POWER1] = rx_power1;
+        sc[ES_CLEAN_RX_POWER] = clean_rx_power;
+        sc[ES_NONUPDATE_DWELL] = nonupdate_dwell;
+        sc[ES_CURR_POS] = curr_pos;
+        sc[ES_FIR_CURR_POS] = curr_pos;
+        sc[ES_CNG] = cng;
+        sc[ES_DTD_ONSET] = dtd_onset;
+        sc[ES_TAP_SET] = tap_set;
+        sc[ES_TAP_ROTATE_COUNTER] = tap_rotate_counter;
+        sc[ES_NARROWBAND_COUNT] = narrowband_count;
+        sc[ES_NARROWBAND_SCORE] = narrowband_score;
+        sc[ES_TX_HPF0] = tx_hpf0;
+        sc[ES_TX_HPF1] = tx_hpf1;
+        sc[ES_RX_HPF0] = rx_hpf0;
+        sc[ES_RX_HPF1] = rx_hpf1;
+        sc[ES_CNG_LEVEL] = cng_level;
+        sc[ES_CNG_RNDNUM] = cng_rndnum;
+        sc[ES_CNG_FILTER] = cng_filter;
+        sc[ES_FIR_SET] = fir_set;
+        sc[ES_VAD] = vad;
+        sc[ES_LATEST_CORRECTION] = 0;
+    }
+}
+
+}   // namespace spg

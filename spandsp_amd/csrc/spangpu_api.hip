@@ -111,6 +111,11 @@ static void launch_tone(const ToneLaunch &L, hipStream_t st)
     }
 }
 
+extern "C" int spangpu_set_error(int code, const char *msg)
+{
+    return fail(code, "%s", msg);
+}
+
 extern "C" {
 
 int spangpu_tune_lanes_per_channel(int lpc)

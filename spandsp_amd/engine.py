@@ -69,6 +69,18 @@ def lib():
             "spangpu_bank_last_kernel_ms": (cf, [vp]),
             "spangpu_bank_set_timing": (ci, [vp, ci]),
             "spangpu_bank_bins": (ci, [vp]),
+            "spangpu_bank_force_block": (ci, [vp]),
+            "spangpu_echo_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
+            "spangpu_echo_destroy": (ci, [vp]),
+            "spangpu_echo_channels": (ci, [vp]),
+            "spangpu_echo_taps": (ci, [vp]),
+            "spangpu_echo_set_stream": (ci, [vp, vp]),
+            "spangpu_echo_sync": (ci, [vp]),
+            "spangpu_echo_update": (ci, [vp, vp, vp, vp, ci, ci, ll, ci]),
+            "spangpu_echo_adaption_mode": (ci, [vp, ci, ci]),
+            "spangpu_echo_flush": (ci, [vp, ci]),
+            "spangpu_echo_get_state": (ci, [vp, ci, vp, vp, vp, vp]),
+            "spangpu_echo_set_state": (ci, [vp, ci, vp, vp, vp, vp]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(L, name)
@@ -188,3 +200,70 @@ class ToneBank:
 
     def last_kernel_ms(self):
         return lib().spangpu_bank_last_kernel_ms(self.h)
+
+
+ECHO_SCALARS = 48
+ECHO_FIELDS = ["tx_power0", "tx_power1", "tx_power2", "tx_power3", "rx_power0", "rx_power1", "rx_power2",
+               "clean_rx_power", "rx_power_threshold", "nonupdate_dwell", "curr_pos", "taps", "tap_mask",
+               "adaption_mode", "supp_test1", "supp_test2", "supp1", "supp2", "vad", "cng", "geigel_max",
+               "geigel_lag", "dtd_onset", "tap_set", "tap_rotate_counter", "latest_correction",
+               "narrowband_count", "narrowband_score", "fir_curr_pos", "tx_hpf0", "tx_hpf1", "rx_hpf0",
+               "rx_hpf1", "cng_level", "cng_rndnum", "cng_filter", "fir_set"]
+
+
+class EchoBank:
+    """N G.168 line echo cancellers, state resident in HBM."""
+
+    def __init__(self, n_channels, taps, adaption_mode, device=0):
+        self.n = n_channels
+        self.taps = taps
+        self.h = C.c_void_p()
+        _check(lib().spangpu_echo_create(C.byref(self.h), device, n_channels, taps, adaption_mode))
+
+    def close(self):
+        if self.h:
+            lib().spangpu_echo_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(lib().spangpu_echo_set_stream(self.h, hip_stream))
+
+    def sync(self):
+        _check(lib().spangpu_echo_sync(self.h))
+
+    def update_host(self, tx, rx, use_hpf_tx=False):
+        tx = np.ascontiguousarray(tx, np.int16)
+        rx = np.ascontiguousarray(rx, np.int16)
+        assert tx.shape == rx.shape and tx.shape[0] == self.n
+        clean = np.zeros_like(tx)
+        _check(lib().spangpu_echo_update(self.h, tx.ctypes.data, rx.ctypes.data, clean.ctypes.data, MEM_HOST,
+                                         tx.shape[1], tx.shape[1], int(use_hpf_tx)))
+        return clean
+
+    def update_device(self, tx_ptr, rx_ptr, clean_ptr, samples, stride, use_hpf_tx=False):
+        _check(lib().spangpu_echo_update(self.h, tx_ptr, rx_ptr, clean_ptr, MEM_DEVICE, samples, stride, int(use_hpf_tx)))
+
+    def adaption_mode(self, mode, channel=-1):
+        _check(lib().spangpu_echo_adaption_mode(self.h, channel, mode))
+
+    def flush(self, channel):
+        _check(lib().spangpu_echo_flush(self.h, channel))
+
+    def get_state(self, channel):
+        s = np.zeros(ECHO_SCALARS, np.int32)
+        t32 = np.zeros(self.taps, np.int32)
+        t16 = np.zeros(4*self.taps, np.int16)
+        h = np.zeros(self.taps, np.int16)
+        _check(lib().spangpu_echo_get_state(self.h, channel, s.ctypes.data, t32.ctypes.data, t16.ctypes.data, h.ctypes.data))
+        d = {k: int(v) for k, v in zip(ECHO_FIELDS, s)}
+        d["last_acf"] = s[37:46].copy()
+        d["taps32"] = t32
+        d["taps16"] = t16.reshape(4, self.taps)
+        d["history"] = h
+        return d

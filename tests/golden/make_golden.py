@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
 from oracle import ref  # noqa: E402
-from test_oracle_pin import ALL_FREQS, bits, build_st_desc, st_signal  # noqa: E402
+from test_oracle_pin import ALL_FREQS, ECHO_CASES, bits, build_st_desc, echo_scenario, st_signal  # noqa: E402
 
 
 def save(name, **kw):
@@ -81,6 +81,16 @@ def main():
     for k in range(0, len(x), 160):
         r.rx(x[k:k + 160])
     save("super_tone", amp=x, fac_bits=bits(d.fac), events=r.sink.events())
+
+    import zlib
+    for taps, mode in ECHO_CASES[:2]:
+        tx, rx = echo_scenario(taps, seed=taps + mode)
+        r = ref.EchoCan(taps, mode)
+        clean = np.concatenate([r.run(tx[k:k + 160], rx[k:k + 160], True) for k in range(0, len(tx), 160)])
+        s = r.snapshot()
+        save("echo_%d_%02x" % (taps, mode), tx_crc=zlib.crc32(tx.tobytes()), rx_crc=zlib.crc32(rx.tobytes()),
+             clean=clean, taps32=s["taps32"], taps16=s["taps16"], history=s["history"],
+             fields=np.array(ref.ECHO_FIELDS), values=np.array([s[k] for k in ref.ECHO_FIELDS]))
 
 
 if __name__ == "__main__":

