@@ -1,0 +1,80 @@
+"""CPU (gloo, world_size 2) test of the multi-GPU plumbing in spandsp_amd/parallel.py:
+channel sharding and the double-buffered gather of result records to rank 0.  The bank is
+faked (records are a known function of rank / step / channel) -- no GPU compute here."""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_shard_range_covers_everything():
+    from spandsp_amd.parallel import shard_range
+    for total in (1, 7, 64, 65536, 1048576 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+class FakeBank:
+    """Stands in for engine.ToneBank.copy_records(): writes the step's record words."""
+
+    def __init__(self, rank, n):
+        self.rank = rank
+        self.n = n
+        self.step = 0
+
+    def copy_records(self, dst_ptr, dst_bytes):
+        words = (np.arange(self.n, dtype=np.int64)*3 + self.rank*1000003 + self.step*17).astype(np.int32)
+        assert dst_bytes >= words.nbytes
+        ctypes.memmove(dst_ptr, words.ctypes.data, words.nbytes)
+        self.step += 1
+        return words.nbytes
+
+
+def _worker(rank, world, port, n_ch, steps, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spandsp_amd.parallel import ResultGather
+    g = ResultGather(world, rank, n_ch, max_blocks=2, device=torch.device("cpu"))
+    bank = FakeBank(rank, 2*n_ch)
+    ok = True
+    for s in range(steps):
+        g.submit(bank)
+        if rank == 0 and s >= 2:
+            # by now the gather of step s-2 has completed
+            pass
+    g.drain()
+    if rank == 0:
+        got = g.latest().numpy()
+        last = steps - 1
+        for r in range(world):
+            want = (np.arange(2*n_ch, dtype=np.int64)*3 + r*1000003 + last*17).astype(np.int32)
+            ok = ok and np.array_equal(got[r], want)
+        out.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_result_gather_gloo_world2():
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 257, 5, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=10) is True
