@@ -263,6 +263,74 @@ ORC_API int16_t orc_echo_update(orc_echo_t *ec, int16_t tx, int16_t rx);
 ORC_API void orc_echo_run(orc_echo_t *ec, const int16_t tx[], const int16_t rx[], int16_t clean[], int n, int use_hpf_tx);
 ORC_API void orc_echo_run_batch(orc_echo_t *s, const int16_t tx[], const int16_t rx[], int16_t clean[], int n_ch, long long stride, int n, int use_hpf_tx);
 
+/* ---- modem receivers ------------------------------------------------------------------------ */
+typedef struct
+{
+    const float *rrc_re;        /* [48][27] V.29 rx pulse shaper, real part */
+    const float *rrc_im;
+    const float *sine;          /* [2048] dds_float.c sine table */
+    const uint16_t *sqrt_tab;   /* [193] fixed_sqrt_table */
+    float godard[7];            /* low[3], high[3], mixed */
+    float godard_coarse_trigger;
+    float godard_fine_trigger;
+    int godard_coarse_step;
+    int godard_fine_step;
+} orc_modem_tables_t;
+
+ORC_API void orc_modem_set_tables(const orc_modem_tables_t *t);
+
+typedef struct
+{
+    /* floats first, then ints (tests read the struct as words; see oracle/restated.py V29_LAYOUT) */
+    float agc_scaling;
+    float agc_scaling_save;
+    float eq_delta;
+    float training_error;
+    float carrier_track_p;
+    float carrier_track_i;
+    float g_low[2];
+    float g_high[2];
+    float g_dc[2];
+    float g_baud_phase;
+    float rrc_filter[27];
+    float eq_coeff[33][2];
+    float eq_coeff_save[33][2];
+    float eq_buf[33][2];
+    int32_t bit_rate;
+    int32_t rrc_filter_step;
+    uint32_t scramble_reg;
+    int32_t training_scramble_reg;
+    int32_t training_cd;
+    int32_t old_train;
+    int32_t training_stage;
+    int32_t training_count;
+    int32_t last_sample;
+    int32_t signal_present;
+    uint32_t carrier_phase;
+    int32_t carrier_phase_rate;
+    int32_t carrier_phase_rate_save;
+    int32_t power_reading;
+    int32_t carrier_on_power;
+    int32_t carrier_off_power;
+    int32_t eq_step;
+    int32_t eq_put_step;
+    int32_t eq_skip;
+    int32_t baud_half;
+    int32_t last_angles[2];
+    int32_t diff_angles[16];
+    int32_t constellation_state;
+    int32_t g_total_correction;
+    int32_t high_sample;
+    int32_t low_samples;
+    int32_t carrier_drop_pending;
+} orc_v29_t;
+
+ORC_API int orc_v29_sizeof(void);
+ORC_API int orc_v29_init(orc_v29_t *s, int bit_rate);
+ORC_API int orc_v29_restart(orc_v29_t *s, int bit_rate, int old_train);
+ORC_API void orc_v29_set_signal_cutoff(orc_v29_t *s, float cutoff);
+ORC_API int orc_v29_rx(orc_v29_t *s, const int16_t amp[], int len, orc_sink_t *sink);
+
 #if defined(__cplusplus)
 }
 #endif

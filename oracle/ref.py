@@ -52,6 +52,8 @@ def lib():
             "glue_v29_rx_new": (vp, [ci, vp]), "glue_v27ter_rx_new": (vp, [ci, vp]), "glue_v17_rx_new": (vp, [ci, vp]),
             "glue_v29_tx_new": (vp, [ci, ci, vp]), "glue_v27ter_tx_new": (vp, [ci, ci, vp]), "glue_v17_tx_new": (vp, [ci, ci, vp]),
             "glue_sizeof": (ci, [C.c_char_p]),
+            "glue_modem_tables": (None, [vp, vp, vp, vp, vp, vp]),
+            "glue_v29_rx_snapshot": (None, [vp, vp, vp]),
             # reference public API (src/spandsp/*.h)
             "dtmf_rx": (ci, [vp, vp, ci]), "dtmf_rx_get": (C.c_size_t, [vp, C.c_char_p, ci]),
             "dtmf_rx_status": (ci, [vp]), "dtmf_rx_fillin": (ci, [vp, ci]),
@@ -426,3 +428,48 @@ class EchoCan:
         d["taps16"] = t16.reshape(4, self.taps)
         d["history"] = h
         return d
+
+
+def modem_tables():
+    """The constant tables of the reference build's V.29 receiver, as numpy arrays."""
+    t = {"rrc_re": np.zeros(48*27, np.float32), "rrc_im": np.zeros(48*27, np.float32),
+         "sine": np.zeros(2048, np.float32), "sqrt_tab": np.zeros(193, np.uint16),
+         "godard": np.zeros(9, np.float32), "steps": np.zeros(2, np.int32)}
+    lib().glue_modem_tables(t["rrc_re"].ctypes.data, t["rrc_im"].ctypes.data, t["sine"].ctypes.data,
+                            t["sqrt_tab"].ctypes.data, t["godard"].ctypes.data, t["steps"].ctypes.data)
+    return t
+
+
+class V29Rx:
+    def __init__(self, bit_rate=9600):
+        self.sink = Sink()
+        self.p = lib().glue_v29_rx_new(bit_rate, self.sink.p)
+
+    def __del__(self):
+        try:
+            lib().v29_rx_free(self.p)
+        except Exception:
+            pass
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().v29_rx(self.p, amp.ctypes.data, len(amp))
+
+    def snapshot(self):
+        f = np.zeros(238, np.float32)
+        w = np.zeros(43, np.int32)
+        lib().glue_v29_rx_snapshot(self.p, f.ctypes.data, w.ctypes.data)
+        return f, w
+
+
+def v29_tx(bit_rate, n_samples, seed=1, tep=False, level_dbm0=None):
+    """v29_tx() of the reference carrying a PRBS; returns int16 samples."""
+    L = lib()
+    st = C.c_uint32(seed & 0x7FFF or 1)
+    tx = L.glue_v29_tx_new(bit_rate, int(tep), C.addressof(st))
+    if level_dbm0 is not None:
+        L.v29_tx_power(tx, level_dbm0)
+    buf = np.zeros(n_samples, np.int16)
+    n = L.v29_tx(tx, buf.ctypes.data, n_samples)
+    L.v29_tx_free(tx)
+    return buf[:n]

@@ -55,6 +55,11 @@ def lib():
             "orc_st_add_element": (ci, [vp, ci, ci, ci, ci, ci]),
             "orc_st_init": (None, [vp, vp, ci]),
             "orc_st_rx": (ci, [vp, vp, ci, vp, vp, ci]),
+            "orc_modem_set_tables": (None, [vp]),
+            "orc_v29_sizeof": (ci, []),
+            "orc_v29_init": (ci, [vp, ci]),
+            "orc_v29_restart": (ci, [vp, ci, ci]),
+            "orc_v29_rx": (ci, [vp, vp, ci, vp]),
             "orc_echo_sizeof": (ci, []),
             "orc_echo_init": (ci, [vp, ci, ci]),
             "orc_echo_adaption_mode": (None, [vp, ci]),
@@ -280,3 +285,51 @@ class EchoCan:
         off += 2*4*ECHO_MAX_TAPS
         d["history"] = self.buf[off:off + 2*ECHO_MAX_TAPS].view(np.int16)[:self.taps].copy()
         return d
+
+
+class _ModemTables(C.Structure):
+    _fields_ = [("rrc_re", C.c_void_p), ("rrc_im", C.c_void_p), ("sine", C.c_void_p), ("sqrt_tab", C.c_void_p),
+                ("godard", C.c_float*7), ("coarse_trigger", C.c_float), ("fine_trigger", C.c_float),
+                ("coarse_step", C.c_int), ("fine_step", C.c_int)]
+
+
+_tables_keepalive = None
+
+
+def set_modem_tables(t):
+    """t: dict of numpy arrays as returned by oracle.ref.modem_tables() / the golden fixture."""
+    global _tables_keepalive
+    keep = {k: np.ascontiguousarray(t[k]) for k in ("rrc_re", "rrc_im", "sine", "sqrt_tab")}
+    m = _ModemTables()
+    m.rrc_re = keep["rrc_re"].ctypes.data
+    m.rrc_im = keep["rrc_im"].ctypes.data
+    m.sine = keep["sine"].ctypes.data
+    m.sqrt_tab = keep["sqrt_tab"].ctypes.data
+    for i in range(7):
+        m.godard[i] = float(t["godard"][i])
+    m.coarse_trigger = float(t["godard"][7])
+    m.fine_trigger = float(t["godard"][8])
+    m.coarse_step = int(t["steps"][0])
+    m.fine_step = int(t["steps"][1])
+    lib().orc_modem_set_tables(C.byref(m))
+    _tables_keepalive = (keep, m)
+
+
+class V29:
+    N_FLOATS = 238
+    N_INTS = 43
+
+    def __init__(self, bit_rate=9600):
+        self.buf = np.zeros(lib().orc_v29_sizeof() + 16, np.uint8)
+        self.p = self.buf.ctypes.data
+        self.sink = Sink()
+        assert lib().orc_v29_init(self.p, bit_rate) == 0
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().orc_v29_rx(self.p, amp.ctypes.data, len(amp), self.sink.p)
+
+    def snapshot(self):
+        f = self.buf[:4*self.N_FLOATS].view(np.float32).copy()
+        w = self.buf[4*self.N_FLOATS:4*(self.N_FLOATS + self.N_INTS)].view(np.int32).copy()
+        return f, w

@@ -1,0 +1,24 @@
+/* modem_tables.h -- constant tables of the modem receivers, built on the host at load time
+   (see modem_tables.c for the recipes and their reference citations). */
+#if !defined(SPG_MODEM_TABLES_H)
+#define SPG_MODEM_TABLES_H
+
+#include <stdint.h>
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+#define SPG_SINE_LEN    2048
+
+void spg_make_sine_table(float out[SPG_SINE_LEN]);
+void spg_make_sqrt_table(uint16_t out[193]);
+/* re/im: [coeff_sets][coeffs_per_filter] */
+int spg_make_rx_pulseshaper(int coeff_sets, int coeffs_per_filter, double carrier_hz, double baud_rate,
+                            double excess_bandwidth, float *re, float *im);
+
+#if defined(__cplusplus)
+}
+#endif
+
+#endif
