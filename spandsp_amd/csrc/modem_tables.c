@@ -173,3 +173,42 @@ int spg_make_rx_pulseshaper(int coeff_sets, int coeffs_per_filter, double carrie
     free(coeffs);
     return 0;
 }
+
+/* make_modem_godard_descriptor.c:59-78, printed with "%10.6f" (:186-196) */
+void spg_make_godard(double carrier, double baud_rate, double alpha, float out[7])
+{
+    const double pi = 3.14159265358979323846;
+    double low_edge = 2.0*pi*(carrier - baud_rate/2.0)/8000.0;
+    double high_edge = 2.0*pi*(carrier + baud_rate/2.0)/8000.0;
+
+    out[0] = via_text(2.0*alpha*cos(low_edge), 6);
+    out[1] = via_text(-alpha*alpha, 6);
+    out[2] = via_text(-alpha*sin(low_edge), 6);
+    out[3] = via_text(2.0*alpha*cos(high_edge), 6);
+    out[4] = via_text(-alpha*alpha, 6);
+    out[5] = via_text(-alpha*sin(high_edge), 6);
+    out[6] = via_text(-alpha*alpha*(sin(high_edge)*cos(low_edge) - sin(low_edge)*cos(high_edge)), 6);
+}
+
+/* The V.29 9600 bps decision regions (v29rx.c:119-143): for each half-unit cell of the
+   [-5, 5) x [-5, 5) plane, the index of the constellation point it decodes to.  One row of
+   the 20 x 20 map per string, value = character - 'a'. */
+void spg_make_v29_space_map(uint8_t out[400])
+{
+    static const char *rows[20] =
+    {
+        "nnnnnnmmmmmmmmllllll", "nnnnnnnmmmmmmlllllll", "nnnnnnneeeeeelllllll", "nnnnnnneeeeeelllllll",
+        "nnnnnnneeeeeelllllll", "nnnnnnnfeeeedlllllll", "onnnnnffffddddlllllk", "oogggfffffdddddccckk",
+        "ooggggffffddddcccckk", "ooggggffffddddcccckk", "oogggghhhhbbbbcccckk", "oogggghhhhbbbbcccckk",
+        "ooggghhhhhbbbbbccckk", "oppppphhhhbbbbjjjjjk", "ppppppphaaaabjjjjjjj", "pppppppaaaaaajjjjjjj",
+        "pppppppaaaaaajjjjjjj", "pppppppaaaaaajjjjjjj", "pppppppiiiiiijjjjjjj", "ppppppiiiiiiiijjjjjj"
+    };
+    int i;
+    int j;
+
+    for (i = 0;  i < 20;  i++)
+    {
+        for (j = 0;  j < 20;  j++)
+            out[i*20 + j] = (uint8_t) (rows[i][j] - 'a');
+    }
+}

@@ -17,6 +17,9 @@ void spg_make_sqrt_table(uint16_t out[193]);
 int spg_make_rx_pulseshaper(int coeff_sets, int coeffs_per_filter, double carrier_hz, double baud_rate,
                             double excess_bandwidth, float *re, float *im);
 
+void spg_make_godard(double carrier, double baud_rate, double alpha, float out[7]);
+void spg_make_v29_space_map(uint8_t out[400]);
+
 #if defined(__cplusplus)
 }
 #endif

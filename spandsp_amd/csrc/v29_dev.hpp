@@ -1,0 +1,793 @@
+// v29_dev.hpp -- device side of the batched V.29 receiver (reference: src/v29rx.c:400-965,
+// src/godard.c:144-220, src/vector_float.c:890-939, src/complex_vector_float.c:137-219,
+// src/power_meter.c:65, src/math_fixed.c:158, src/dds_float.c:2135-2177, spandsp/arctan2.h).
+//
+// Mapping: ONE CHANNEL PER LANE, one wavefront (64 channels) per workgroup.  The receiver is
+// a per-channel state machine (carrier detect, AGC, polyphase RRC, Godard timing recovery,
+// T/2 equaliser with LMS training, PI carrier loop, slicer, descrambler, training FSM); the
+// only regular arithmetic is three short inner products per T/2 instant with per-channel
+// operands and per-channel circular offsets -- nothing a matrix core can use.  So:
+//   * scalars and the 33 complex equaliser taps (always indexed by a compile-time i) live in
+//     VGPRs;
+//   * the two circular buffers (RRC delay line, equaliser delay line) live in a per-lane LDS
+//     row, stored twice back to back so x[(pos + i) mod n] is the contiguous x2[pos + i];
+//   * the polyphase RRC table (48 x 27 x {re, im}) and the sine table live once per
+//     workgroup in LDS and are gathered by per-lane row;
+//   * inner products keep the reference's exact summation tree: ascending coefficient
+//     index, the circular split summed separately and added last (a per-lane split point,
+//     handled by snapshotting the accumulator instead of branching).
+// Lanes diverge on the T/2 and baud instants and on the training stage; expect VALU/LDS
+// bound behaviour and a low HBM figure for this kernel.
+//
+// Numerics: fp32, every op rounded separately (-ffp-contract=off), float->int conversions
+// with the x86 out-of-range result the reference build has; the single libm dependency of
+// the reference path (cosf/sinf of the training phase spin, v29rx.c:618-623) is evaluated
+// in double and rounded, which equals the reference's result on the builds compared.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace spg {
+
+constexpr int kV29Floats = 238;             // float words of state per channel (layout: V29 word map below)
+constexpr int kV29Ints = 43;
+constexpr int kV29Words = kV29Floats + kV29Ints;
+constexpr int kRrcSets = 48;
+constexpr int kRrcLen = 27;
+constexpr int kEqLen = 33;
+constexpr int kLanePitch = 2*kRrcLen + 4*kEqLen + 1;   // 187 floats per lane, odd => conflict-free same-index access
+
+// State word map (identical to the reference-ordered snapshot the tests use):
+//   floats: 0 agc_scaling, 1 agc_scaling_save, 2 eq_delta, 3 training_error, 4 carrier_track_p,
+//           5 carrier_track_i, 6-7 godard low[2], 8-9 godard high[2], 10-11 godard dc[2],
+//           12 baud_phase, 13-39 rrc_filter[27], 40-105 eq_coeff[33][2], 106-171 eq_coeff_save,
+//           172-237 eq_buf[33][2]
+//   ints:   0 bit_rate, 1 rrc_filter_step, 2 scramble_reg, 3 training_scramble_reg, 4 training_cd,
+//           5 old_train, 6 training_stage, 7 training_count, 8 last_sample, 9 signal_present,
+//           10 carrier_phase, 11 carrier_phase_rate, 12 carrier_phase_rate_save, 13 power reading,
+//           14 carrier_on_power, 15 carrier_off_power, 16 eq_step, 17 eq_put_step, 18 eq_skip,
+//           19 baud_half, 20-21 last_angles, 22-37 diff_angles, 38 constellation_state,
+//           39 total timing correction, 40 high_sample, 41 low_samples, 42 carrier_drop_pending
+enum
+{
+    VF_AGC = 0, VF_AGC_SAVE, VF_EQ_DELTA, VF_TRAIN_ERR, VF_TRACK_P, VF_TRACK_I,
+    VF_GLOW = 6, VF_GHIGH = 8, VF_GDC = 10, VF_BAUD_PHASE = 12, VF_RRC = 13, VF_EQ_COEFF = 40,
+    VF_EQ_SAVE = 106, VF_EQ_BUF = 172
+};
+enum
+{
+    VI_BIT_RATE = 0, VI_RRC_STEP, VI_SCRAMBLE, VI_TRAIN_SCRAMBLE, VI_TRAINING_CD, VI_OLD_TRAIN, VI_STAGE,
+    VI_TRAIN_COUNT, VI_LAST_SAMPLE, VI_SIGNAL_PRESENT, VI_CARRIER_PHASE, VI_PHASE_RATE, VI_PHASE_RATE_SAVE,
+    VI_POWER, VI_ON_POWER, VI_OFF_POWER, VI_EQ_STEP, VI_EQ_PUT_STEP, VI_EQ_SKIP, VI_BAUD_HALF,
+    VI_LAST_ANGLES = 20, VI_DIFF_ANGLES = 22, VI_CONSTEL = 38, VI_TOTAL_CORR = 39, VI_HIGH_SAMPLE = 40,
+    VI_LOW_SAMPLES = 41, VI_DROP_PENDING = 42
+};
+
+enum
+{
+    V29_NORMAL = 0, V29_SYMBOL_ACQUISITION, V29_LOG_PHASE, V29_WAIT_FOR_CDCD, V29_TRAIN_ON_CDCD,
+    V29_TRAIN_ON_CDCD_AND_TEST, V29_TEST_ONES, V29_PARKED
+};
+
+struct V29Tables
+{
+    float rrc_re[kRrcSets*kRrcLen];
+    float rrc_im[kRrcSets*kRrcLen];
+    float sine[2048];
+    float godard[7];
+    float coarse_trigger;
+    float fine_trigger;
+    int coarse_step;
+    int fine_step;
+    uint16_t sqrt_tab[194];
+    uint8_t space_map[400];
+};
+
+struct V29Launch
+{
+    const int16_t *amp;
+    long long stride;
+    int samples;
+    int n_ch;
+    uint32_t *state;            // [kV29Words][n_ch]
+    int8_t *events;             // [n_ch][ev_cap]: 0/1 bits and negative SIG_STATUS_* codes, in order
+    int32_t *ev_count;          // [n_ch]
+    int ev_cap;
+    const V29Tables *tab;
+};
+
+__device__ __forceinline__ int32_t v29_f2i(float v)
+{
+    // (int32_t) of the reference build (x86-64 cvttss2si): NaN / out of range -> INT32_MIN
+    if (!(v < 2147483648.0f)  ||  !(v >= -2147483648.0f))
+        return (int32_t) 0x80000000u;
+    return (int32_t) v;
+}
+
+// spandsp/arctan2.h:47-80
+__device__ __forceinline__ int32_t v29_arctan2(float y, float x)
+{
+    if (y == 0.0f)
+        return (x < 0.0f)  ?  (int32_t) 0x80000000u  :  0;
+    if (x == 0.0f)
+        return (y < 0.0f)  ?  (int32_t) 0xc0000000u  :  0x40000000;
+    const float abs_y = fabsf(y);
+    float angle;
+    if (x < 0.0f)
+        angle = 3.0f - (x + abs_y)/(abs_y - x);
+    else
+        angle = 1.0f - (x - abs_y)/(abs_y + x);
+    angle *= 536870912.0f;
+    if (y < 0.0f)
+        angle = -angle;
+    return v29_f2i(angle);
+}
+
+__global__ __launch_bounds__(64)
+void v29_bank_kernel(const V29Launch L)
+{
+    __shared__ float t_rrc_re[kRrcSets*kRrcLen];
+    __shared__ float t_rrc_im[kRrcSets*kRrcLen];
+    __shared__ float t_sine[2048];
+    __shared__ float t_const[32];
+    __shared__ uint16_t t_sqrt[194];
+    __shared__ uint8_t t_map[400];
+    __shared__ float lanes[64*kLanePitch];
+
+    const int lane = threadIdx.x;
+    const int ch_raw = blockIdx.x*64 + lane;
+    const bool live = ch_raw < L.n_ch;
+    const int ch = live  ?  ch_raw  :  (L.n_ch - 1);
+    const V29Tables &TB = *L.tab;
+
+    // ---- tables -> LDS ----------------------------------------------------------------------
+    for (int i = lane;  i < kRrcSets*kRrcLen;  i += 64)
+    {
+        t_rrc_re[i] = TB.rrc_re[i];
+        t_rrc_im[i] = TB.rrc_im[i];
+    }
+    for (int i = lane;  i < 2048;  i += 64)
+        t_sine[i] = TB.sine[i];
+    for (int i = lane;  i < 194;  i += 64)
+        t_sqrt[i] = TB.sqrt_tab[i];
+    for (int i = lane;  i < 400;  i += 64)
+        t_map[i] = TB.space_map[i];
+    if (lane < 16)
+    {
+        // v29tx_constellation_maps.h:58-77
+        const float re[16] = {3, 1, 0, -1, -3, -1, 0, 1, 5, 3, 0, -3, -5, -3, 0, 3};
+        const float im[16] = {0, 1, 3, 1, 0, -1, -3, -1, 0, 3, 5, 3, 0, -3, -5, -3};
+        t_const[2*lane] = re[lane];
+        t_const[2*lane + 1] = im[lane];
+    }
+    const float g0 = TB.godard[0];
+    const float g1 = TB.godard[1];
+    const float g2 = TB.godard[2];
+    const float g3 = TB.godard[3];
+    const float g4 = TB.godard[4];
+    const float g5 = TB.godard[5];
+    const float g6 = TB.godard[6];
+    const float fine_trigger = TB.fine_trigger;
+    const float coarse_trigger = TB.coarse_trigger;
+    const int fine_step = TB.fine_step;
+    const int coarse_step = TB.coarse_step;
+    __syncthreads();
+
+    // ---- state -> registers / LDS ---------------------------------------------------------------
+    const size_t N = (size_t) L.n_ch;
+    auto ldf = [&](int w) { return __uint_as_float(L.state[(size_t) w*N + ch]); };
+    auto ldi = [&](int w) { return (int32_t) L.state[(size_t) (kV29Floats + w)*N + ch]; };
+    auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
+    auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV29Floats + w)*N + ch] = (uint32_t) v; };
+
+    float *rrc2 = &lanes[lane*kLanePitch];              // [2*27]
+    float *eqb2 = rrc2 + 2*kRrcLen;                     // [2*33][2]
+
+    float agc_scaling = ldf(VF_AGC);
+    float agc_scaling_save = ldf(VF_AGC_SAVE);
+    const float eq_delta = ldf(VF_EQ_DELTA);
+    float training_error = ldf(VF_TRAIN_ERR);
+    float carrier_track_p = ldf(VF_TRACK_P);
+    float carrier_track_i = ldf(VF_TRACK_I);
+    float glow0 = ldf(VF_GLOW);
+    float glow1 = ldf(VF_GLOW + 1);
+    float ghigh0 = ldf(VF_GHIGH);
+    float ghigh1 = ldf(VF_GHIGH + 1);
+    float gdc0 = ldf(VF_GDC);
+    float gdc1 = ldf(VF_GDC + 1);
+    float baud_phase = ldf(VF_BAUD_PHASE);
+    for (int i = 0;  i < kRrcLen;  i++)
+    {
+        const float v = ldf(VF_RRC + i);
+        rrc2[i] = v;
+        rrc2[kRrcLen + i] = v;
+    }
+    float cre[kEqLen];
+    float cim[kEqLen];
+#pragma unroll
+    for (int i = 0;  i < kEqLen;  i++)
+    {
+        cre[i] = ldf(VF_EQ_COEFF + 2*i);
+        cim[i] = ldf(VF_EQ_COEFF + 2*i + 1);
+    }
+    for (int i = 0;  i < kEqLen;  i++)
+    {
+        const float a = ldf(VF_EQ_BUF + 2*i);
+        const float b = ldf(VF_EQ_BUF + 2*i + 1);
+        eqb2[2*i] = a;
+        eqb2[2*i + 1] = b;
+        eqb2[2*(kEqLen + i)] = a;
+        eqb2[2*(kEqLen + i) + 1] = b;
+    }
+    const int bit_rate = ldi(VI_BIT_RATE);
+    int rrc_step = ldi(VI_RRC_STEP);
+    uint32_t scramble_reg = (uint32_t) ldi(VI_SCRAMBLE);
+    int training_scramble_reg = ldi(VI_TRAIN_SCRAMBLE);
+    const int training_cd = ldi(VI_TRAINING_CD);
+    int old_train = ldi(VI_OLD_TRAIN);
+    int stage = ldi(VI_STAGE);
+    int training_count = ldi(VI_TRAIN_COUNT);
+    int last_sample = ldi(VI_LAST_SAMPLE);
+    int signal_present = ldi(VI_SIGNAL_PRESENT);
+    uint32_t carrier_phase = (uint32_t) ldi(VI_CARRIER_PHASE);
+    int32_t carrier_phase_rate = ldi(VI_PHASE_RATE);
+    int32_t carrier_phase_rate_save = ldi(VI_PHASE_RATE_SAVE);
+    int32_t power_reading = ldi(VI_POWER);
+    const int32_t carrier_on_power = ldi(VI_ON_POWER);
+    const int32_t carrier_off_power = ldi(VI_OFF_POWER);
+    int eq_step = ldi(VI_EQ_STEP);
+    int eq_put_step = ldi(VI_EQ_PUT_STEP);
+    int eq_skip = ldi(VI_EQ_SKIP);
+    int baud_half = ldi(VI_BAUD_HALF);
+    int32_t last_angle0 = ldi(VI_LAST_ANGLES);
+    int32_t last_angle1 = ldi(VI_LAST_ANGLES + 1);
+    int constellation_state = ldi(VI_CONSTEL);
+    int total_corr = ldi(VI_TOTAL_CORR);
+    int high_sample = ldi(VI_HIGH_SAMPLE);
+    int low_samples = ldi(VI_LOW_SAMPLES);
+    int drop_pending = ldi(VI_DROP_PENDING);
+    // diff_angles[16] is only touched during WAIT_FOR_CDCD: keep it in the state array in HBM
+    auto diff_ld = [&](int k) { return ldi(VI_DIFF_ANGLES + (k & 0xF)); };
+    auto diff_st = [&](int k, int32_t v) { if (live) sti(VI_DIFF_ANGLES + (k & 0xF), v); };
+
+    int8_t *evp = L.events + (size_t) ch*L.ev_cap;
+    int n_ev = 0;
+    auto emit = [&](int v)
+    {
+        if (live  &&  n_ev < L.ev_cap)
+            evp[n_ev] = (int8_t) v;
+        n_ev++;
+    };
+
+    // v29rx.c:1019-1098 (old_train == false, the only way the receive path calls it)
+    auto restart = [&]()
+    {
+        for (int i = 0;  i < 2*kRrcLen;  i++)
+            rrc2[i] = 0.0f;
+        rrc_step = 0;
+        scramble_reg = 0;
+        training_scramble_reg = 0x2A;
+        stage = V29_SYMBOL_ACQUISITION;
+        training_count = 0;
+        signal_present = 0;
+        high_sample = 0;
+        low_samples = 0;
+        drop_pending = 0;
+        old_train = 0;
+        for (int k = 0;  k < 16;  k++)
+            diff_st(k, 0);
+        carrier_phase = 0;
+        power_reading = 0;
+        constellation_state = 0;
+        carrier_phase_rate = v29_f2i(1700.0f*65536.0f*65536.0f/8000);
+#pragma unroll
+        for (int i = 0;  i < kEqLen;  i++)
+        {
+            cre[i] = 0.0f;
+            cim[i] = 0.0f;
+        }
+        cre[16] = 3.0f;                                     // V29_EQUALIZER_PRE_LEN
+        for (int i = 0;  i < 4*kEqLen;  i++)
+            eqb2[i] = 0.0f;
+        eq_put_step = kRrcSets*10/(3*2) - 1;
+        eq_step = 0;
+        agc_scaling_save = 0.0f;
+        agc_scaling = (1.25f/1.0f)/735.0f;
+        carrier_track_i = 8000.0f;
+        carrier_track_p = 8000000.0f;
+        last_sample = 0;
+        eq_skip = 0;
+        glow0 = glow1 = ghigh0 = ghigh1 = gdc0 = gdc1 = 0.0f;
+        baud_phase = 0.0f;
+        total_corr = 0;
+        baud_half = 0;
+    };
+
+    // vec_circular_dot_prodf(rrc_filter, coeffs[row], 27, rrc_step)   (vector_float.c:890-939)
+    auto rrc_dot = [&](const float *table, int row)
+    {
+        const float *y = table + row*kRrcLen;
+        const float *x = rrc2 + rrc_step;
+        const int split = kRrcLen - rrc_step;
+        float a = 0.0f;
+        float first = 0.0f;
+#pragma unroll
+        for (int i = 0;  i < kRrcLen;  i++)
+        {
+            if (i == split)
+            {
+                first = a;
+                a = 0.0f;
+            }
+            a += x[i]*y[i];
+        }
+        return first + a;
+    };
+
+    auto track_carrier = [&](float zre, float zim, float tre, float tim)
+    {
+        // v29rx.c:297-331
+        const float error = zim*tre - zre*tim;
+        carrier_phase_rate += v29_f2i(carrier_track_i*error);
+        carrier_phase += (uint32_t) v29_f2i(carrier_track_p*error);
+    };
+    auto tune_equalizer = [&](float zre, float zim, float tre, float tim)
+    {
+        // v29rx.c:281-291 + cvec_circular_lmsf (complex_vector_float.c:201-219)
+        const float ere = (tre - zre)*eq_delta;
+        const float eim = (tim - zim)*eq_delta;
+        const float *x = eqb2 + 2*eq_step;
+#pragma unroll
+        for (int i = 0;  i < kEqLen;  i++)
+        {
+            const float xr = x[2*i];
+            const float xi = x[2*i + 1];
+            cre[i] = cre[i]*0.9999f + (xi*eim + xr*ere);
+            cim[i] = cim[i]*0.9999f + (xr*eim - xi*ere);
+        }
+    };
+    auto put_bit = [&](int bit)
+    {
+        // v29rx.c:365-397
+        bit &= 1;
+        const int out_bit = (bit ^ (int) (scramble_reg >> 17) ^ (int) (scramble_reg >> 22)) & 1;
+        scramble_reg = (scramble_reg << 1) | (uint32_t) bit;
+        if (stage == V29_NORMAL)
+            emit(out_bit);
+    };
+    auto scrambled_training_bit = [&]()
+    {
+        // v29rx.c:350-362
+        const int bit = training_scramble_reg & 1;
+        training_scramble_reg >>= 1;
+        if (bit ^ (training_scramble_reg & 1))
+            training_scramble_reg |= 0x40;
+        return bit;
+    };
+    auto decode_baud = [&](float zre, float zim)
+    {
+        // v29rx.c:400-481
+        int nearest;
+        if (bit_rate == 4800)
+        {
+            const int b1 = (zim > zre);
+            const int b2 = (zim < -zre);
+            nearest = ((b2 << 1) | (b1 ^ b2)) << 1;
+            const int idx = ((nearest - constellation_state) >> 1) & 3;
+            const int raw_bits = (0x1320 >> (4*idx)) & 0xF;            // phase_steps_4800 = {0, 2, 3, 1}
+            put_bit(raw_bits);
+            put_bit(raw_bits >> 1);
+        }
+        else
+        {
+            int re = (int) ((zre + 5.0f)*2.0f);
+            int im = (int) ((zim + 5.0f)*2.0f);
+            re = max(0, min(19, re));
+            im = max(0, min(19, im));
+            nearest = t_map[re*20 + im];
+            if (bit_rate == 9600)
+                put_bit(nearest >> 3);
+            else
+                nearest &= 7;
+            const int idx = (nearest - constellation_state) & 7;
+            int raw_bits = (int) ((0x51376204u >> (4*idx)) & 0xF);  // phase_steps_9600 = {4,0,2,6,7,3,1,5}
+            put_bit(raw_bits);
+            put_bit(raw_bits >> 1);
+            put_bit(raw_bits >> 2);
+        }
+        const float tre = t_const[2*nearest];
+        const float tim = t_const[2*nearest + 1];
+        track_carrier(zre, zim, tre, tim);
+        if (--eq_skip <= 0)
+        {
+            eq_skip = 10;
+            tune_equalizer(zre, zim, tre, tim);
+        }
+        constellation_state = nearest;
+    };
+    auto park = [&]()
+    {
+        agc_scaling_save = 0.0f;
+        stage = V29_PARKED;
+        emit(-5);                                           // SIG_STATUS_TRAINING_FAILED
+    };
+
+    const int16_t *src = L.amp + (size_t) ch*L.stride;
+    for (int n = 0;  n < L.samples;  n++)
+    {
+        const int amp = src[n];
+        // ---- v29_rx(), v29rx.c:885-961 --------------------------------------------------------
+        rrc2[rrc_step] = (float) amp;
+        rrc2[rrc_step + kRrcLen] = (float) amp;
+        if (++rrc_step >= kRrcLen)
+            rrc_step = 0;
+
+        // signal_detect(), v29rx.c:788-865 (with the IAXMODEM_STUFF this snapshot #defines)
+        int power;
+        {
+            const int x = amp >> 1;
+            int diff = (int) (short) (x - last_sample);
+            last_sample = x;
+            power_reading += ((diff*diff - power_reading) >> 4);
+            power = power_reading;
+            diff = (int) (short) abs(diff);
+            if (10*diff < high_sample)
+            {
+                if (++low_samples > 120)
+                {
+                    power_reading = 0;
+                    high_sample = 0;
+                    low_samples = 0;
+                }
+            }
+            else
+            {
+                low_samples = 0;
+                if (diff > high_sample)
+                    high_sample = diff;
+            }
+            if (signal_present > 0)
+            {
+                if (drop_pending  ||  power < carrier_off_power)
+                {
+                    if (--signal_present <= 0)
+                    {
+                        restart();
+                        emit(-1);                           // SIG_STATUS_CARRIER_DOWN
+                        power = 0;
+                    }
+                    else
+                    {
+                        drop_pending = 1;
+                    }
+                }
+            }
+            else
+            {
+                if (power < carrier_on_power)
+                {
+                    power = 0;
+                }
+                else
+                {
+                    signal_present = 1;
+                    drop_pending = 0;
+                    emit(-2);                               // SIG_STATUS_CARRIER_UP
+                }
+            }
+        }
+        if (power == 0  ||  stage == V29_PARKED)
+            continue;
+
+        eq_put_step -= kRrcSets;
+        int step = -eq_put_step;
+        if (step < 0)
+            step += kRrcSets;
+        step = max(0, min(kRrcSets - 1, step));
+        float v = rrc_dot(t_rrc_re, step);
+        const float sre = v*agc_scaling;
+        {
+            // godard_ted_rx(), godard.c:144-162
+            float t = glow0*g0 + glow1*g1 + sre;
+            glow1 = glow0;
+            glow0 = t;
+            t = ghigh0*g3 + ghigh1*g4 + sre;
+            ghigh1 = ghigh0;
+            ghigh0 = t;
+        }
+        if (eq_put_step <= 0)
+        {
+            if (agc_scaling_save == 0.0f)
+            {
+                // fixed_sqrt32(), math_fixed.c:158-169
+                int root_power;
+                {
+                    uint32_t xx = (uint32_t) power;
+                    const int top = 31 - __builtin_clz(xx);
+                    const int shift = 30 - (top & ~1);
+                    xx <<= shift;
+                    root_power = t_sqrt[((xx >> 24) & 0xFF) - 64] >> (shift >> 1);
+                }
+                if (root_power == 0)
+                    root_power = 1;
+                agc_scaling = (1.25f/1.0f)/(float) root_power;
+            }
+            v = rrc_dot(t_rrc_im, step);
+            const float sim = v*agc_scaling;
+            // dds_lookup_complexf(), dds_float.c:2135,2177
+            const float dre = t_sine[(uint32_t) (carrier_phase + (1u << 30)) >> 21];
+            const float dim = t_sine[carrier_phase >> 21];
+            const float hre = sre*dre - sim*dim;
+            const float him = -sre*dim - sim*dre;
+            eq_put_step += kRrcSets*10/(3*2);
+
+            // ---- process_half_baud(), v29rx.c:484-786 ----------------------------------------
+            eqb2[2*eq_step] = hre;
+            eqb2[2*eq_step + 1] = him;
+            eqb2[2*(eq_step + kEqLen)] = hre;
+            eqb2[2*(eq_step + kEqLen) + 1] = him;
+            if (++eq_step >= kEqLen)
+                eq_step = 0;
+            baud_half ^= 1;
+            if (baud_half == 0)
+            {
+                {
+                    // godard_ted_per_baud(), godard.c:165-220
+                    float cv = glow1*ghigh0*g2 - glow0*ghigh1*g5 + glow1*ghigh1*g6;
+                    const float p = cv - gdc1;
+                    gdc1 = gdc0;
+                    gdc0 = cv;
+                    baud_phase -= p;
+                    cv = fabsf(baud_phase);
+                    if (cv > fine_trigger)
+                    {
+                        int i = (cv > coarse_trigger)  ?  coarse_step  :  fine_step;
+                        if (baud_phase < 0.0f)
+                            i = -i;
+                        total_corr += i;
+                        eq_put_step += i;
+                    }
+                }
+                // equalizer_get(): cvec_circular_dot_prodf (complex_vector_float.c:137-196)
+                float zre;
+                float zim;
+                {
+                    const float *x = eqb2 + 2*eq_step;
+                    const int split = kEqLen - eq_step;
+                    float are = 0.0f;
+                    float aim = 0.0f;
+                    float fre = 0.0f;
+                    float fim = 0.0f;
+#pragma unroll
+                    for (int i = 0;  i < kEqLen;  i++)
+                    {
+                        if (i == split)
+                        {
+                            fre = are;
+                            fim = aim;
+                            are = 0.0f;
+                            aim = 0.0f;
+                        }
+                        const float xr = x[2*i];
+                        const float xi = x[2*i + 1];
+                        are += (xr*cre[i] - xi*cim[i]);
+                        aim += (xr*cim[i] + xi*cre[i]);
+                    }
+                    zre = fre + are;
+                    zim = fim + aim;
+                }
+
+                switch (stage)
+                {
+                case V29_NORMAL:
+                    decode_baud(zre, zim);
+                    break;
+                case V29_SYMBOL_ACQUISITION:
+                    if (++training_count >= 60)
+                    {
+                        stage = V29_LOG_PHASE;
+                        for (int k = 0;  k < 16;  k++)
+                            diff_st(k, 0);
+                        last_angle0 = v29_arctan2(zim, zre);
+                        if (agc_scaling_save == 0.0f)
+                            agc_scaling_save = agc_scaling;
+                    }
+                    break;
+                case V29_LOG_PHASE:
+                    last_angle1 = v29_arctan2(zim, zre);
+                    training_count = 1;
+                    stage = V29_WAIT_FOR_CDCD;
+                    break;
+                case V29_WAIT_FOR_CDCD:
+                {
+                    const int32_t angle = v29_arctan2(zim, zre);
+                    int i = training_count + 1;
+                    const int32_t prev = (i & 1)  ?  last_angle1  :  last_angle0;
+                    int32_t ang = (int32_t) ((uint32_t) angle - (uint32_t) prev);
+                    if (i & 1)
+                        last_angle1 = angle;
+                    else
+                        last_angle0 = angle;
+                    diff_st(i, (int32_t) ((uint32_t) diff_ld(i - 2) + (uint32_t) (ang >> 4)));
+                    if ((ang > 0x20000000  ||  ang < (int32_t) 0xE0000000u)  &&  training_count >= 13)
+                    {
+                        i = (training_count - 8) & ~1;
+                        if (i > 1)
+                        {
+                            const int jj = i & 0xF;
+                            ang = (int32_t) ((uint32_t) diff_ld(jj) + (uint32_t) diff_ld(jj | 1))/(i - 1);
+                            carrier_phase_rate += 3*16*(ang/20);
+                        }
+                        if (carrier_phase_rate < v29_f2i((1700.0f - 20.0f)*65536.0f*65536.0f/8000)
+                            ||  carrier_phase_rate > v29_f2i((1700.0f + 20.0f)*65536.0f*65536.0f/8000))
+                        {
+                            park();
+                            break;
+                        }
+                        // v29rx.c:618-624: spin the equaliser delay line and the carrier
+                        const float p = ((uint32_t) angle)*2.0f*3.1415926f/(65536.0f*65536.0f);
+                        const float zc = (float) cos((double) p);
+                        const float zs = -(float) sin((double) p);
+                        for (int k = 0;  k < kEqLen;  k++)
+                        {
+                            const float xr = eqb2[2*k];
+                            const float xi = eqb2[2*k + 1];
+                            const float nr = xr*zc - xi*zs;
+                            const float ni = xr*zs + xi*zc;
+                            eqb2[2*k] = nr;
+                            eqb2[2*k + 1] = ni;
+                            eqb2[2*(k + kEqLen)] = nr;
+                            eqb2[2*(k + kEqLen) + 1] = ni;
+                        }
+                        carrier_phase += (uint32_t) angle;
+                        const int bit = scrambled_training_bit();
+                        constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;   // cdcd_pos = {0,11,0,3,0,2}
+                        training_count = 1;
+                        stage = V29_TRAIN_ON_CDCD;
+                        emit(-3);                           // SIG_STATUS_TRAINING_IN_PROGRESS
+                        break;
+                    }
+                    if (++training_count > 128)
+                        park();
+                    break;
+                }
+                case V29_TRAIN_ON_CDCD:
+                {
+                    const int bit = scrambled_training_bit();
+                    constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;
+                    const float tre = t_const[2*constellation_state];
+                    const float tim = t_const[2*constellation_state + 1];
+                    track_carrier(zre, zim, tre, tim);
+                    tune_equalizer(zre, zim, tre, tim);
+                    if (++training_count >= 384 - 48)
+                    {
+                        stage = V29_TRAIN_ON_CDCD_AND_TEST;
+                        training_error = 0.0f;
+                        carrier_track_i = 200.0f;
+                        carrier_track_p = 1000000.0f;
+                    }
+                    break;
+                }
+                case V29_TRAIN_ON_CDCD_AND_TEST:
+                {
+                    const int bit = scrambled_training_bit();
+                    constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;
+                    const float tre = t_const[2*constellation_state];
+                    const float tim = t_const[2*constellation_state + 1];
+                    track_carrier(zre, zim, tre, tim);
+                    tune_equalizer(zre, zim, tre, tim);
+                    const float dre2 = zre - tre;
+                    const float dim2 = zim - tim;
+                    training_error += dre2*dre2 + dim2*dim2;
+                    if (++training_count >= 384)
+                    {
+                        if (training_error < 48.0f*2.0f)
+                        {
+                            training_error = 0.0f;
+                            training_count = 0;
+                            constellation_state = 0;
+                            stage = V29_TEST_ONES;
+                        }
+                        else
+                        {
+                            park();
+                        }
+                    }
+                    break;
+                }
+                case V29_TEST_ONES:
+                {
+                    decode_baud(zre, zim);
+                    const float tre = t_const[2*constellation_state];
+                    const float tim = t_const[2*constellation_state + 1];
+                    const float dre2 = zre - tre;
+                    const float dim2 = zim - tim;
+                    training_error += dre2*dre2 + dim2*dim2;
+                    if (++training_count >= 48)
+                    {
+                        if (training_error < 48.0f*1.0f)
+                        {
+                            emit(-4);                       // SIG_STATUS_TRAINING_SUCCEEDED
+                            signal_present = 60;
+                            stage = V29_NORMAL;
+                            if (live)
+                            {
+#pragma unroll
+                                for (int k = 0;  k < kEqLen;  k++)
+                                {
+                                    stf(VF_EQ_SAVE + 2*k, cre[k]);
+                                    stf(VF_EQ_SAVE + 2*k + 1, cim[k]);
+                                }
+                            }
+                            carrier_phase_rate_save = carrier_phase_rate;
+                            agc_scaling_save = agc_scaling;
+                        }
+                        else
+                        {
+                            park();
+                        }
+                    }
+                    break;
+                }
+                default:
+                    break;
+                }
+            }
+        }
+        carrier_phase += (uint32_t) carrier_phase_rate;
+    }
+
+    // ---- write back -----------------------------------------------------------------------------
+    if (live)
+    {
+        stf(VF_AGC, agc_scaling);
+        stf(VF_AGC_SAVE, agc_scaling_save);
+        stf(VF_TRAIN_ERR, training_error);
+        stf(VF_TRACK_P, carrier_track_p);
+        stf(VF_TRACK_I, carrier_track_i);
+        stf(VF_GLOW, glow0);
+        stf(VF_GLOW + 1, glow1);
+        stf(VF_GHIGH, ghigh0);
+        stf(VF_GHIGH + 1, ghigh1);
+        stf(VF_GDC, gdc0);
+        stf(VF_GDC + 1, gdc1);
+        stf(VF_BAUD_PHASE, baud_phase);
+        for (int i = 0;  i < kRrcLen;  i++)
+            stf(VF_RRC + i, rrc2[i]);
+#pragma unroll
+        for (int i = 0;  i < kEqLen;  i++)
+        {
+            stf(VF_EQ_COEFF + 2*i, cre[i]);
+            stf(VF_EQ_COEFF + 2*i + 1, cim[i]);
+        }
+        for (int i = 0;  i < 2*kEqLen;  i++)
+            stf(VF_EQ_BUF + i, eqb2[i]);
+        sti(VI_RRC_STEP, rrc_step);
+        sti(VI_SCRAMBLE, (int32_t) scramble_reg);
+        sti(VI_TRAIN_SCRAMBLE, training_scramble_reg);
+        sti(VI_OLD_TRAIN, old_train);
+        sti(VI_STAGE, stage);
+        sti(VI_TRAIN_COUNT, training_count);
+        sti(VI_LAST_SAMPLE, last_sample);
+        sti(VI_SIGNAL_PRESENT, signal_present);
+        sti(VI_CARRIER_PHASE, (int32_t) carrier_phase);
+        sti(VI_PHASE_RATE, carrier_phase_rate);
+        sti(VI_PHASE_RATE_SAVE, carrier_phase_rate_save);
+        sti(VI_POWER, power_reading);
+        sti(VI_EQ_STEP, eq_step);
+        sti(VI_EQ_PUT_STEP, eq_put_step);
+        sti(VI_EQ_SKIP, eq_skip);
+        sti(VI_BAUD_HALF, baud_half);
+        sti(VI_LAST_ANGLES, last_angle0);
+        sti(VI_LAST_ANGLES + 1, last_angle1);
+        sti(VI_CONSTEL, constellation_state);
+        sti(VI_TOTAL_CORR, total_corr);
+        sti(VI_HIGH_SAMPLE, high_sample);
+        sti(VI_LOW_SAMPLES, low_samples);
+        sti(VI_DROP_PENDING, drop_pending);
+        L.ev_count[ch] = n_ev;
+    }
+}
+
+}   // namespace spg

@@ -70,6 +70,16 @@ def lib():
             "spangpu_bank_set_timing": (ci, [vp, ci]),
             "spangpu_bank_bins": (ci, [vp]),
             "spangpu_bank_force_block": (ci, [vp]),
+            "spangpu_v29_create": (ci, [C.POINTER(vp), ci, ci, ci]),
+            "spangpu_v29_destroy": (ci, [vp]),
+            "spangpu_v29_channels": (ci, [vp]),
+            "spangpu_v29_set_stream": (ci, [vp, vp]),
+            "spangpu_v29_sync": (ci, [vp]),
+            "spangpu_v29_rx": (ci, [vp, vp, ci, ci, ll]),
+            "spangpu_v29_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_v29_get_state": (ci, [vp, ci, vp, vp]),
+            "spangpu_v29_restart": (ci, [vp, ci]),
+            "spangpu_modem_tables": (ci, [vp, vp, vp, vp, vp]),
             "spangpu_echo_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
             "spangpu_echo_destroy": (ci, [vp]),
             "spangpu_echo_channels": (ci, [vp]),
@@ -267,3 +277,65 @@ class EchoBank:
         d["taps16"] = t16.reshape(4, self.taps)
         d["history"] = h
         return d
+
+
+def modem_tables():
+    """The constant modem tables as built by libspangpu (host code, no GPU needed)."""
+    t = {"rrc_re": np.zeros(48*27, np.float32), "rrc_im": np.zeros(48*27, np.float32),
+         "sine": np.zeros(2048, np.float32), "sqrt_tab": np.zeros(193, np.uint16), "godard": np.zeros(7, np.float32)}
+    _check(lib().spangpu_modem_tables(t["rrc_re"].ctypes.data, t["rrc_im"].ctypes.data, t["sine"].ctypes.data,
+                                      t["sqrt_tab"].ctypes.data, t["godard"].ctypes.data))
+    return t
+
+
+class V29Bank:
+    """N V.29 receivers, state resident in HBM."""
+
+    def __init__(self, n_channels, bit_rate=9600, device=0):
+        self.n = n_channels
+        self.h = C.c_void_p()
+        _check(lib().spangpu_v29_create(C.byref(self.h), device, n_channels, bit_rate))
+
+    def close(self):
+        if self.h:
+            lib().spangpu_v29_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(lib().spangpu_v29_set_stream(self.h, hip_stream))
+
+    def sync(self):
+        _check(lib().spangpu_v29_sync(self.h))
+
+    def rx_host(self, frames):
+        frames = np.ascontiguousarray(frames, np.int16)
+        assert frames.shape[0] == self.n
+        _check(lib().spangpu_v29_rx(self.h, frames.ctypes.data, MEM_HOST, frames.shape[1], frames.shape[1]))
+
+    def rx_device(self, ptr, samples, stride):
+        _check(lib().spangpu_v29_rx(self.h, ptr, MEM_DEVICE, samples, stride))
+
+    def events(self):
+        """List (per channel) of int8 arrays: 0/1 bits and negative SIG_STATUS codes, in order."""
+        ev = C.c_void_p()
+        cnt = C.c_void_p()
+        cap = _check(lib().spangpu_v29_events(self.h, C.byref(ev), C.byref(cnt)))
+        counts = np.frombuffer((C.c_char*(4*self.n)).from_address(cnt.value), dtype=np.int32).copy()
+        raw = np.frombuffer((C.c_char*(cap*self.n)).from_address(ev.value), dtype=np.int8).reshape(self.n, cap)
+        assert counts.max(initial=0) <= cap, "event buffer overflow"
+        return [raw[c, :counts[c]].copy() for c in range(self.n)]
+
+    def get_state(self, channel):
+        f = np.zeros(238, np.float32)
+        w = np.zeros(43, np.int32)
+        _check(lib().spangpu_v29_get_state(self.h, channel, f.ctypes.data, w.ctypes.data))
+        return f, w
+
+    def restart(self, channel):
+        _check(lib().spangpu_v29_restart(self.h, channel))

@@ -19,7 +19,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
 from oracle import ref  # noqa: E402
-from test_oracle_pin import ALL_FREQS, ECHO_CASES, bits, build_st_desc, echo_scenario, st_signal  # noqa: E402
+from test_oracle_pin import (ALL_FREQS, ECHO_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
+                             v29_run, v29_scenario)
 
 
 def save(name, **kw):
@@ -91,6 +92,13 @@ def main():
         save("echo_%d_%02x" % (taps, mode), tx_crc=zlib.crc32(tx.tobytes()), rx_crc=zlib.crc32(rx.tobytes()),
              clean=clean, taps32=s["taps32"], taps16=s["taps16"], history=s["history"],
              fields=np.array(ref.ECHO_FIELDS), values=np.array([s[k] for k in ref.ECHO_FIELDS]))
+
+    save("modem_tables", **ref.modem_tables())
+    for bit_rate, seed, noise in V29_CASES:
+        x = v29_scenario(bit_rate, seed, noise)
+        ev, f, w = v29_run(ref.V29Rx(bit_rate), x, (160,))
+        assert len(ev) > 1500 and -1 in ev
+        save("v29_%d" % bit_rate, amp=x, events=ev.astype(np.int8), fwords=f, iwords=w)
 
 
 if __name__ == "__main__":

@@ -263,6 +263,65 @@ def test_echo_live(built, taps, mode):
 
 
 # ---------------------------------------------------------------------------------
+# V.29 receiver
+# ---------------------------------------------------------------------------------
+V29_CASES = [(9600, 11, -45.0), (7200, 12, -40.0), (4800, 13, -36.0)]
+
+
+def v29_scenario(bit_rate, seed, noise_dbm0, n_signal=5200, lead=230, tail=700):
+    """Silence, a V.29 transmission (training + PRBS data) from the reference's own modulator, silence; AWGN over
+    all of it.  Needs oracle/_ref (the committed fixtures hold the result)."""
+    from oracle import ref
+    sig = ref.v29_tx(bit_rate, n_signal, seed=seed)
+    x = np.concatenate([np.zeros(lead, np.int16), sig, np.zeros(tail, np.int16)])
+    return ref.saturated_add(x, ref.awgn(seed*7919, noise_dbm0, len(x)))
+
+
+def v29_run(rx, x, chunks):
+    k = 0
+    i = 0
+    while k < len(x):
+        n = chunks[i % len(chunks)]
+        rx.rx(x[k:k + n])
+        k += n
+        i += 1
+    ev = rx.sink.events()
+    assert np.all(ev["kind"] == 3)
+    f, w = rx.snapshot()
+    return ev["a"].astype(np.int32), bits(f), w
+
+
+def use_golden_modem_tables():
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, "modem_tables.npz"))
+    orc.set_modem_tables({k: g[k] for k in g.files})
+
+
+@needs_ref
+def test_modem_tables_fixture_is_current(built):
+    from oracle import ref
+    g = np.load(os.path.join(GOLDEN, "modem_tables.npz"))
+    t = ref.modem_tables()
+    for k in t:
+        assert t[k].tobytes() == g[k].tobytes(), k
+
+
+@needs_ref
+@pytest.mark.parametrize("bit_rate,seed,noise", V29_CASES + [(9600, 21, -30.0), (9600, 22, -60.0)])
+@pytest.mark.parametrize("chunks", [(160,), (1, 7, 333, 64)])
+def test_v29_live(built, bit_rate, seed, noise, chunks):
+    from oracle import ref, restated as orc
+    use_golden_modem_tables()
+    x = v29_scenario(bit_rate, seed, noise)
+    ev_r, f_r, w_r = v29_run(ref.V29Rx(bit_rate), x, chunks)
+    ev_o, f_o, w_o = v29_run(orc.V29(bit_rate), x, chunks)
+    assert len(ev_r) > 1500 and -1 in ev_r          # trained, carried data, and dropped carrier
+    assert np.array_equal(ev_r, ev_o)
+    assert np.array_equal(w_r, w_o)
+    assert np.array_equal(f_r, f_o)
+
+
+# ---------------------------------------------------------------------------------
 # frozen pins: golden vectors generated from the reference build
 # ---------------------------------------------------------------------------------
 def test_golden_files_present():
@@ -342,3 +401,14 @@ def test_golden_echo(built, taps, mode):
     assert np.array_equal(s["taps32"], g["taps32"]) and np.array_equal(s["taps16"], g["taps16"])
     assert np.array_equal(s["history"], g["history"])
     assert [s[k] for k in g["fields"]] == list(g["values"])
+
+
+@pytest.mark.parametrize("bit_rate", [9600, 7200, 4800])
+def test_golden_v29(built, bit_rate):
+    from oracle import restated as orc
+    use_golden_modem_tables()
+    g = np.load(os.path.join(GOLDEN, "v29_%d.npz" % bit_rate))
+    ev, f, w = v29_run(orc.V29(bit_rate), g["amp"], (160,))
+    assert np.array_equal(ev, g["events"].astype(np.int32))
+    assert np.array_equal(f, g["fwords"])
+    assert np.array_equal(w, g["iwords"])
