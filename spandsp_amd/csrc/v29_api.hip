@@ -264,7 +264,13 @@ int spangpu_v29_rx(spangpu_v29_t *m, const int16_t *amp, int mem, int samples, l
     L.ev_count = m->ev_count;
     L.ev_cap = m->ev_cap;
     L.tab = m->tab;
-    hipLaunchKernelGGL(v29_bank_kernel, dim3((m->n_ch + 63)/64), dim3(64), 0, m->stream, L);
+    // enough workgroups to put a wave on every SIMD (256 CUs x 4) before filling the waves
+    if (m->n_ch >= 64*1024)
+        hipLaunchKernelGGL(v29_bank_kernel<64>, dim3((m->n_ch + 63)/64), dim3(64), 0, m->stream, L);
+    else if (m->n_ch >= 32*1024)
+        hipLaunchKernelGGL(v29_bank_kernel<32>, dim3((m->n_ch + 31)/32), dim3(64), 0, m->stream, L);
+    else
+        hipLaunchKernelGGL(v29_bank_kernel<16>, dim3((m->n_ch + 15)/16), dim3(64), 0, m->stream, L);
     V29_TRY(hipGetLastError());
     m->last_cap = m->ev_cap;
     if (mem == SPANGPU_MEM_HOST)

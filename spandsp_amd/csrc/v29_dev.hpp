@@ -124,28 +124,34 @@ __device__ __forceinline__ int32_t v29_arctan2(float y, float x)
     return v29_f2i(angle);
 }
 
+// CPW = channels per workgroup (one wavefront): 64 when the bank is big enough to fill every SIMD of the chip with
+// full waves, fewer (idle upper lanes) for small banks so that the channels still spread over all 1024 SIMDs.
+template <int CPW>
 __global__ __launch_bounds__(64)
 void v29_bank_kernel(const V29Launch L)
 {
+    // coefficient tables transposed to [tap][set]: lanes on different polyphase sets hit different banks
     __shared__ float t_rrc_re[kRrcSets*kRrcLen];
     __shared__ float t_rrc_im[kRrcSets*kRrcLen];
     __shared__ float t_sine[2048];
     __shared__ float t_const[32];
     __shared__ uint16_t t_sqrt[194];
     __shared__ uint8_t t_map[400];
-    __shared__ float lanes[64*kLanePitch];
+    // per-lane delay lines, index-major [word][CPW]: lane l always uses bank (l mod 64) whatever its position
+    __shared__ float lanes[CPW*(kLanePitch - 1)];
 
     const int lane = threadIdx.x;
-    const int ch_raw = blockIdx.x*64 + lane;
-    const bool live = ch_raw < L.n_ch;
-    const int ch = live  ?  ch_raw  :  (L.n_ch - 1);
+    const int ch = blockIdx.x*CPW + lane;
+    const bool live = true;
     const V29Tables &TB = *L.tab;
 
     // ---- tables -> LDS ----------------------------------------------------------------------
     for (int i = lane;  i < kRrcSets*kRrcLen;  i += 64)
     {
-        t_rrc_re[i] = TB.rrc_re[i];
-        t_rrc_im[i] = TB.rrc_im[i];
+        const int set = i/kRrcLen;
+        const int tap = i - set*kRrcLen;
+        t_rrc_re[tap*kRrcSets + set] = TB.rrc_re[i];
+        t_rrc_im[tap*kRrcSets + set] = TB.rrc_im[i];
     }
     for (int i = lane;  i < 2048;  i += 64)
         t_sine[i] = TB.sine[i];
@@ -173,6 +179,8 @@ void v29_bank_kernel(const V29Launch L)
     const int fine_step = TB.fine_step;
     const int coarse_step = TB.coarse_step;
     __syncthreads();
+    if (lane >= CPW  ||  ch >= L.n_ch)
+        return;
 
     // ---- state -> registers / LDS ---------------------------------------------------------------
     const size_t N = (size_t) L.n_ch;
@@ -181,8 +189,10 @@ void v29_bank_kernel(const V29Launch L)
     auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV29Floats + w)*N + ch] = (uint32_t) v; };
 
-    float *rrc2 = &lanes[lane*kLanePitch];              // [2*27]
-    float *eqb2 = rrc2 + 2*kRrcLen;                     // [2*33][2]
+    float *rrc2 = &lanes[lane];                         // [2*27] words, stride CPW
+    float *eqb2 = rrc2 + 2*kRrcLen*CPW;                 // [2*33][2] words, stride CPW
+#define RRC2(k)     rrc2[(k)*CPW]
+#define EQB2(k)     eqb2[(k)*CPW]
 
     float agc_scaling = ldf(VF_AGC);
     float agc_scaling_save = ldf(VF_AGC_SAVE);
@@ -200,8 +210,8 @@ void v29_bank_kernel(const V29Launch L)
     for (int i = 0;  i < kRrcLen;  i++)
     {
         const float v = ldf(VF_RRC + i);
-        rrc2[i] = v;
-        rrc2[kRrcLen + i] = v;
+        RRC2(i) = v;
+        RRC2(kRrcLen + i) = v;
     }
     float cre[kEqLen];
     float cim[kEqLen];
@@ -215,10 +225,10 @@ void v29_bank_kernel(const V29Launch L)
     {
         const float a = ldf(VF_EQ_BUF + 2*i);
         const float b = ldf(VF_EQ_BUF + 2*i + 1);
-        eqb2[2*i] = a;
-        eqb2[2*i + 1] = b;
-        eqb2[2*(kEqLen + i)] = a;
-        eqb2[2*(kEqLen + i) + 1] = b;
+        EQB2(2*i) = a;
+        EQB2(2*i + 1) = b;
+        EQB2(2*(kEqLen + i)) = a;
+        EQB2(2*(kEqLen + i) + 1) = b;
     }
     const int bit_rate = ldi(VI_BIT_RATE);
     int rrc_step = ldi(VI_RRC_STEP);
@@ -264,7 +274,7 @@ void v29_bank_kernel(const V29Launch L)
     auto restart = [&]()
     {
         for (int i = 0;  i < 2*kRrcLen;  i++)
-            rrc2[i] = 0.0f;
+            RRC2(i) = 0.0f;
         rrc_step = 0;
         scramble_reg = 0;
         training_scramble_reg = 0x2A;
@@ -289,7 +299,7 @@ void v29_bank_kernel(const V29Launch L)
         }
         cre[16] = 3.0f;                                     // V29_EQUALIZER_PRE_LEN
         for (int i = 0;  i < 4*kEqLen;  i++)
-            eqb2[i] = 0.0f;
+            EQB2(i) = 0.0f;
         eq_put_step = kRrcSets*10/(3*2) - 1;
         eq_step = 0;
         agc_scaling_save = 0.0f;
@@ -307,8 +317,8 @@ void v29_bank_kernel(const V29Launch L)
     // vec_circular_dot_prodf(rrc_filter, coeffs[row], 27, rrc_step)   (vector_float.c:890-939)
     auto rrc_dot = [&](const float *table, int row)
     {
-        const float *y = table + row*kRrcLen;
-        const float *x = rrc2 + rrc_step;
+        const float *y = table + row;
+        const float *x = rrc2 + rrc_step*CPW;
         const int split = kRrcLen - rrc_step;
         float a = 0.0f;
         float first = 0.0f;
@@ -320,7 +330,7 @@ void v29_bank_kernel(const V29Launch L)
                 first = a;
                 a = 0.0f;
             }
-            a += x[i]*y[i];
+            a += x[i*CPW]*y[i*kRrcSets];
         }
         return first + a;
     };
@@ -337,12 +347,12 @@ void v29_bank_kernel(const V29Launch L)
         // v29rx.c:281-291 + cvec_circular_lmsf (complex_vector_float.c:201-219)
         const float ere = (tre - zre)*eq_delta;
         const float eim = (tim - zim)*eq_delta;
-        const float *x = eqb2 + 2*eq_step;
+        const float *x = eqb2 + 2*eq_step*CPW;
 #pragma unroll
         for (int i = 0;  i < kEqLen;  i++)
         {
-            const float xr = x[2*i];
-            const float xi = x[2*i + 1];
+            const float xr = x[2*i*CPW];
+            const float xi = x[(2*i + 1)*CPW];
             cre[i] = cre[i]*0.9999f + (xi*eim + xr*ere);
             cim[i] = cim[i]*0.9999f + (xr*eim - xi*ere);
         }
@@ -418,8 +428,8 @@ void v29_bank_kernel(const V29Launch L)
     {
         const int amp = src[n];
         // ---- v29_rx(), v29rx.c:885-961 --------------------------------------------------------
-        rrc2[rrc_step] = (float) amp;
-        rrc2[rrc_step + kRrcLen] = (float) amp;
+        RRC2(rrc_step) = (float) amp;
+        RRC2(rrc_step + kRrcLen) = (float) amp;
         if (++rrc_step >= kRrcLen)
             rrc_step = 0;
 
@@ -523,10 +533,10 @@ void v29_bank_kernel(const V29Launch L)
             eq_put_step += kRrcSets*10/(3*2);
 
             // ---- process_half_baud(), v29rx.c:484-786 ----------------------------------------
-            eqb2[2*eq_step] = hre;
-            eqb2[2*eq_step + 1] = him;
-            eqb2[2*(eq_step + kEqLen)] = hre;
-            eqb2[2*(eq_step + kEqLen) + 1] = him;
+            EQB2(2*eq_step) = hre;
+            EQB2(2*eq_step + 1) = him;
+            EQB2(2*(eq_step + kEqLen)) = hre;
+            EQB2(2*(eq_step + kEqLen) + 1) = him;
             if (++eq_step >= kEqLen)
                 eq_step = 0;
             baud_half ^= 1;
@@ -553,7 +563,7 @@ void v29_bank_kernel(const V29Launch L)
                 float zre;
                 float zim;
                 {
-                    const float *x = eqb2 + 2*eq_step;
+                    const float *x = eqb2 + 2*eq_step*CPW;
                     const int split = kEqLen - eq_step;
                     float are = 0.0f;
                     float aim = 0.0f;
@@ -569,8 +579,8 @@ void v29_bank_kernel(const V29Launch L)
                             are = 0.0f;
                             aim = 0.0f;
                         }
-                        const float xr = x[2*i];
-                        const float xi = x[2*i + 1];
+                        const float xr = x[2*i*CPW];
+                        const float xi = x[(2*i + 1)*CPW];
                         are += (xr*cre[i] - xi*cim[i]);
                         aim += (xr*cim[i] + xi*cre[i]);
                     }
@@ -631,14 +641,14 @@ void v29_bank_kernel(const V29Launch L)
                         const float zs = -(float) sin((double) p);
                         for (int k = 0;  k < kEqLen;  k++)
                         {
-                            const float xr = eqb2[2*k];
-                            const float xi = eqb2[2*k + 1];
+                            const float xr = EQB2(2*k);
+                            const float xi = EQB2(2*k + 1);
                             const float nr = xr*zc - xi*zs;
                             const float ni = xr*zs + xi*zc;
-                            eqb2[2*k] = nr;
-                            eqb2[2*k + 1] = ni;
-                            eqb2[2*(k + kEqLen)] = nr;
-                            eqb2[2*(k + kEqLen) + 1] = ni;
+                            EQB2(2*k) = nr;
+                            EQB2(2*k + 1) = ni;
+                            EQB2(2*(k + kEqLen)) = nr;
+                            EQB2(2*(k + kEqLen) + 1) = ni;
                         }
                         carrier_phase += (uint32_t) angle;
                         const int bit = scrambled_training_bit();
@@ -754,7 +764,7 @@ void v29_bank_kernel(const V29Launch L)
         stf(VF_GDC + 1, gdc1);
         stf(VF_BAUD_PHASE, baud_phase);
         for (int i = 0;  i < kRrcLen;  i++)
-            stf(VF_RRC + i, rrc2[i]);
+            stf(VF_RRC + i, RRC2(i));
 #pragma unroll
         for (int i = 0;  i < kEqLen;  i++)
         {
@@ -762,7 +772,7 @@ void v29_bank_kernel(const V29Launch L)
             stf(VF_EQ_COEFF + 2*i + 1, cim[i]);
         }
         for (int i = 0;  i < 2*kEqLen;  i++)
-            stf(VF_EQ_BUF + i, eqb2[i]);
+            stf(VF_EQ_BUF + i, EQB2(i));
         sti(VI_RRC_STEP, rrc_step);
         sti(VI_SCRAMBLE, (int32_t) scramble_reg);
         sti(VI_TRAIN_SCRAMBLE, training_scramble_reg);
@@ -789,5 +799,8 @@ void v29_bank_kernel(const V29Launch L)
         L.ev_count[ch] = n_ev;
     }
 }
+
+#undef RRC2
+#undef EQB2
 
 }   // namespace spg
