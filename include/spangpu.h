@@ -206,31 +206,33 @@ SPANGPU_API int spangpu_echo_get_state(spangpu_echo_t *ec, int channel, int32_t 
 SPANGPU_API int spangpu_echo_set_state(spangpu_echo_t *ec, int channel, const int32_t *scalars, const int32_t *taps32,
                                        const int16_t *taps16, const int16_t *history);
 
-/* ---- V.29 receiver banks ----------------------------------------------------------------
- * N independent V.29 receivers (9600 / 7200 / 4800 bps), state resident in HBM.  Replaces, per
- * channel:
- *   spangpu_v29_create()   v29_rx_init(NULL, bit_rate, put_bit, user)   src/v29rx.c:1100-1131, src/spandsp/v29rx.h:151
- *   spangpu_v29_rx()       v29_rx(s, amp, len)                          src/v29rx.c:867-965,  src/spandsp/v29rx.h:187
- *   spangpu_v29_restart()  v29_rx_restart(s, bit_rate, false)           src/v29rx.c:1019-1098
- *   spangpu_v29_events()   the put_bit / status callback stream         src/v29rx.c:171-178,380-397
- * The demodulated bit stream and the SIG_STATUS_* events (spandsp/async.h:66-103) are
- * delivered per channel, in the order the reference would have made its callbacks. */
-typedef struct spangpu_v29_s spangpu_v29_t;
+/* ---- Modem receiver banks --------------------------------------------------------------
+ * N independent V.29 (9600 / 7200 / 4800 bps) or V.27ter (4800 / 2400 bps) receivers, state
+ * resident in HBM.  Replaces, per channel:
+ *   spangpu_modem_create()   v29_rx_init(NULL, bit_rate, put_bit, user)      src/v29rx.c:1100-1131, src/spandsp/v29rx.h:151
+ *                            v27ter_rx_init(NULL, bit_rate, put_bit, user)   src/v27ter_rx.c:1162-1190, src/spandsp/v27ter_rx.h:84
+ *   spangpu_modem_rx()       v29_rx(s, amp, len)                             src/v29rx.c:867-965,  src/spandsp/v29rx.h:187
+ *                            v27ter_rx(s, amp, len)                          src/v27ter_rx.c:863-1028, src/spandsp/v27ter_rx.h:120
+ *   spangpu_modem_restart()  v29_rx_restart / v27ter_rx_restart(s, rate, false)   src/v29rx.c:1019, src/v27ter_rx.c:1091
+ *   spangpu_modem_events()   the put_bit / status callback stream            src/v29rx.c:171-178,380-397
+ * The demodulated bit stream and the SIG_STATUS_* events (spandsp/async.h:66-103) are delivered
+ * per channel, in the order the reference would have made its callbacks: for channel c,
+ * counts[c] entries at events + c*cap, each 0/1 (a descrambled data bit) or a negative
+ * SIG_STATUS_* code. */
+typedef struct spangpu_modem_s spangpu_modem_t;
 
-#define SPANGPU_V29_FLOAT_WORDS     238
-#define SPANGPU_V29_INT_WORDS       43
-
-SPANGPU_API int spangpu_v29_create(spangpu_v29_t **modem, int device, int n_channels, int bit_rate);
-SPANGPU_API int spangpu_v29_destroy(spangpu_v29_t *modem);
-SPANGPU_API int spangpu_v29_channels(const spangpu_v29_t *modem);
-SPANGPU_API int spangpu_v29_set_stream(spangpu_v29_t *modem, void *hip_stream);
-SPANGPU_API int spangpu_v29_sync(spangpu_v29_t *modem);
-SPANGPU_API int spangpu_v29_rx(spangpu_v29_t *modem, const int16_t *amp, int mem, int samples, long long stride);
-SPANGPU_API int spangpu_v29_events(spangpu_v29_t *modem, const int8_t **events, const int32_t **counts);
-SPANGPU_API int spangpu_v29_get_state(spangpu_v29_t *modem, int channel, float *fwords, int32_t *iwords);
-SPANGPU_API int spangpu_v29_restart(spangpu_v29_t *modem, int channel);
-/* The constant tables the modem receivers use, as built by this library (any pointer may be NULL). */
-SPANGPU_API int spangpu_modem_tables(float *rrc_re, float *rrc_im, float *sine, uint16_t *sqrt_tab, float *godard);
+SPANGPU_API int spangpu_modem_create(spangpu_modem_t **modem, int device, int kind, int n_channels, int bit_rate);
+SPANGPU_API int spangpu_modem_destroy(spangpu_modem_t *modem);
+SPANGPU_API int spangpu_modem_channels(const spangpu_modem_t *modem);
+SPANGPU_API int spangpu_modem_set_stream(spangpu_modem_t *modem, void *hip_stream);
+SPANGPU_API int spangpu_modem_sync(spangpu_modem_t *modem);
+SPANGPU_API int spangpu_modem_rx(spangpu_modem_t *modem, const int16_t *amp, int mem, int samples, long long stride);
+SPANGPU_API int spangpu_modem_events(spangpu_modem_t *modem, const int8_t **events, const int32_t **counts);
+SPANGPU_API int spangpu_modem_state_words(int kind, int *n_floats, int *n_ints);
+SPANGPU_API int spangpu_modem_get_state(spangpu_modem_t *modem, int channel, uint32_t *words);
+SPANGPU_API int spangpu_modem_restart(spangpu_modem_t *modem, int channel);
+/* The constant tables the modem receivers use, as built by this library (host code; see modem_api.hip for `which`). */
+SPANGPU_API int spangpu_modem_table(int which, float *out, int max);
 
 #if defined(__cplusplus)
 }

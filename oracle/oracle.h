@@ -275,6 +275,17 @@ typedef struct
     float godard_fine_trigger;
     int godard_coarse_step;
     int godard_fine_step;
+    const float *v27_4800_re;   /* [8][27]  V.27ter 4800 bps rx pulse shaper */
+    const float *v27_4800_im;
+    const float *v27_2400_re;   /* [12][27] V.27ter 2400 bps rx pulse shaper */
+    const float *v27_2400_im;
+    const float *v17_re;        /* [192][27] V.17 rx pulse shaper */
+    const float *v17_im;
+    float v17_godard[7];
+    float v17_godard_coarse_trigger;
+    float v17_godard_fine_trigger;
+    int v17_godard_coarse_step;
+    int v17_godard_fine_step;
 } orc_modem_tables_t;
 
 ORC_API void orc_modem_set_tables(const orc_modem_tables_t *t);
@@ -325,11 +336,65 @@ typedef struct
     int32_t carrier_drop_pending;
 } orc_v29_t;
 
+ORC_API float orc_trig_cosf(float x);
+ORC_API float orc_trig_sinf(float x);
 ORC_API int orc_v29_sizeof(void);
 ORC_API int orc_v29_init(orc_v29_t *s, int bit_rate);
 ORC_API int orc_v29_restart(orc_v29_t *s, int bit_rate, int old_train);
 ORC_API void orc_v29_set_signal_cutoff(orc_v29_t *s, float cutoff);
 ORC_API int orc_v29_rx(orc_v29_t *s, const int16_t amp[], int len, orc_sink_t *sink);
+
+typedef struct
+{
+    /* floats first, then ints */
+    float agc_scaling;
+    float agc_scaling_save;
+    float eq_delta;
+    float training_error;
+    float carrier_track_p;
+    float carrier_track_i;
+    float rrc_filter[27];
+    float eq_coeff[32][2];
+    float eq_coeff_save[32][2];
+    float eq_buf[32][2];
+    int32_t bit_rate;
+    int32_t rrc_filter_step;
+    uint32_t scramble_reg;
+    int32_t scrambler_pattern_count;
+    int32_t training_bc;
+    int32_t old_train;
+    int32_t training_stage;
+    int32_t training_count;
+    int32_t last_sample;
+    int32_t signal_present;
+    int32_t carrier_drop_pending;
+    int32_t low_samples;
+    int32_t high_sample;
+    int32_t constellation_state;
+    uint32_t carrier_phase;
+    int32_t carrier_phase_rate;
+    int32_t carrier_phase_rate_save;
+    int32_t power_reading;
+    int32_t carrier_on_power;
+    int32_t carrier_off_power;
+    int32_t eq_step;
+    int32_t eq_put_step;
+    int32_t eq_skip;
+    int32_t baud_half;
+    int32_t gardner_integrate;
+    int32_t gardner_step;
+    int32_t total_baud_timing_correction;
+    int32_t last_angles[2];
+    int32_t diff_angles[16];
+} orc_v27ter_t;
+
+#define ORC_V27TER_FLOATS   225
+#define ORC_V27TER_INTS     45
+
+ORC_API int orc_v27ter_sizeof(void);
+ORC_API int orc_v27ter_init(orc_v27ter_t *s, int bit_rate);
+ORC_API int orc_v27ter_restart(orc_v27ter_t *s, int bit_rate, int old_train);
+ORC_API int orc_v27ter_rx(orc_v27ter_t *s, const int16_t amp[], int len, orc_sink_t *sink);
 
 #if defined(__cplusplus)
 }

@@ -54,6 +54,8 @@ def lib():
             "glue_sizeof": (ci, [C.c_char_p]),
             "glue_modem_tables": (None, [vp, vp, vp, vp, vp, vp]),
             "glue_v29_rx_snapshot": (None, [vp, vp, vp]),
+            "glue_v27ter_rx_snapshot": (None, [vp, vp, vp]),
+            "glue_v27ter_tables": (None, [vp, vp, vp, vp]),
             # reference public API (src/spandsp/*.h)
             "dtmf_rx": (ci, [vp, vp, ci]), "dtmf_rx_get": (C.c_size_t, [vp, C.c_char_p, ci]),
             "dtmf_rx_status": (ci, [vp]), "dtmf_rx_fillin": (ci, [vp, ci]),
@@ -437,6 +439,10 @@ def modem_tables():
          "godard": np.zeros(9, np.float32), "steps": np.zeros(2, np.int32)}
     lib().glue_modem_tables(t["rrc_re"].ctypes.data, t["rrc_im"].ctypes.data, t["sine"].ctypes.data,
                             t["sqrt_tab"].ctypes.data, t["godard"].ctypes.data, t["steps"].ctypes.data)
+    for k, n in (("v27_4800_re", 8), ("v27_4800_im", 8), ("v27_2400_re", 12), ("v27_2400_im", 12)):
+        t[k] = np.zeros(n*27, np.float32)
+    lib().glue_v27ter_tables(t["v27_4800_re"].ctypes.data, t["v27_4800_im"].ctypes.data,
+                             t["v27_2400_re"].ctypes.data, t["v27_2400_im"].ctypes.data)
     return t
 
 
@@ -460,6 +466,41 @@ class V29Rx:
         w = np.zeros(43, np.int32)
         lib().glue_v29_rx_snapshot(self.p, f.ctypes.data, w.ctypes.data)
         return f, w
+
+
+class V27terRx:
+    def __init__(self, bit_rate=4800):
+        self.sink = Sink()
+        self.p = lib().glue_v27ter_rx_new(bit_rate, self.sink.p)
+
+    def __del__(self):
+        try:
+            lib().v27ter_rx_free(self.p)
+        except Exception:
+            pass
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().v27ter_rx(self.p, amp.ctypes.data, len(amp))
+
+    def snapshot(self):
+        f = np.zeros(225, np.float32)
+        w = np.zeros(45, np.int32)
+        lib().glue_v27ter_rx_snapshot(self.p, f.ctypes.data, w.ctypes.data)
+        return f, w
+
+
+def v27ter_tx(bit_rate, n_samples, seed=1, tep=False, level_dbm0=None):
+    """v27ter_tx() of the reference carrying a PRBS; returns int16 samples."""
+    L = lib()
+    st = C.c_uint32(seed & 0x7FFF or 1)
+    tx = L.glue_v27ter_tx_new(bit_rate, int(tep), C.addressof(st))
+    if level_dbm0 is not None:
+        L.v27ter_tx_power(tx, level_dbm0)
+    buf = np.zeros(n_samples, np.int16)
+    n = L.v27ter_tx(tx, buf.ctypes.data, n_samples)
+    L.v27ter_tx_free(tx)
+    return buf[:n]
 
 
 def v29_tx(bit_rate, n_samples, seed=1, tep=False, level_dbm0=None):

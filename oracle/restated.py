@@ -60,6 +60,10 @@ def lib():
             "orc_v29_init": (ci, [vp, ci]),
             "orc_v29_restart": (ci, [vp, ci, ci]),
             "orc_v29_rx": (ci, [vp, vp, ci, vp]),
+            "orc_v27ter_sizeof": (ci, []),
+            "orc_v27ter_init": (ci, [vp, ci]),
+            "orc_v27ter_restart": (ci, [vp, ci, ci]),
+            "orc_v27ter_rx": (ci, [vp, vp, ci, vp]),
             "orc_echo_sizeof": (ci, []),
             "orc_echo_init": (ci, [vp, ci, ci]),
             "orc_echo_adaption_mode": (None, [vp, ci]),
@@ -290,7 +294,12 @@ class EchoCan:
 class _ModemTables(C.Structure):
     _fields_ = [("rrc_re", C.c_void_p), ("rrc_im", C.c_void_p), ("sine", C.c_void_p), ("sqrt_tab", C.c_void_p),
                 ("godard", C.c_float*7), ("coarse_trigger", C.c_float), ("fine_trigger", C.c_float),
-                ("coarse_step", C.c_int), ("fine_step", C.c_int)]
+                ("coarse_step", C.c_int), ("fine_step", C.c_int),
+                ("v27_4800_re", C.c_void_p), ("v27_4800_im", C.c_void_p),
+                ("v27_2400_re", C.c_void_p), ("v27_2400_im", C.c_void_p),
+                ("v17_re", C.c_void_p), ("v17_im", C.c_void_p),
+                ("v17_godard", C.c_float*7), ("v17_coarse_trigger", C.c_float), ("v17_fine_trigger", C.c_float),
+                ("v17_coarse_step", C.c_int), ("v17_fine_step", C.c_int)]
 
 
 _tables_keepalive = None
@@ -311,6 +320,17 @@ def set_modem_tables(t):
     m.fine_trigger = float(t["godard"][8])
     m.coarse_step = int(t["steps"][0])
     m.fine_step = int(t["steps"][1])
+    for k in ("v27_4800_re", "v27_4800_im", "v27_2400_re", "v27_2400_im", "v17_re", "v17_im"):
+        if k in t:
+            keep[k] = np.ascontiguousarray(t[k])
+            setattr(m, k, keep[k].ctypes.data)
+    if "v17_godard" in t:
+        for i in range(7):
+            m.v17_godard[i] = float(t["v17_godard"][i])
+        m.v17_coarse_trigger = float(t["v17_godard"][7])
+        m.v17_fine_trigger = float(t["v17_godard"][8])
+        m.v17_coarse_step = int(t["v17_steps"][0])
+        m.v17_fine_step = int(t["v17_steps"][1])
     lib().orc_modem_set_tables(C.byref(m))
     _tables_keepalive = (keep, m)
 
@@ -328,6 +348,26 @@ class V29:
     def rx(self, amp):
         amp = _i16(amp)
         return lib().orc_v29_rx(self.p, amp.ctypes.data, len(amp), self.sink.p)
+
+    def snapshot(self):
+        f = self.buf[:4*self.N_FLOATS].view(np.float32).copy()
+        w = self.buf[4*self.N_FLOATS:4*(self.N_FLOATS + self.N_INTS)].view(np.int32).copy()
+        return f, w
+
+
+class V27ter:
+    N_FLOATS = 225
+    N_INTS = 45
+
+    def __init__(self, bit_rate=4800):
+        self.buf = np.zeros(lib().orc_v27ter_sizeof() + 16, np.uint8)
+        self.p = self.buf.ctypes.data
+        self.sink = Sink()
+        assert lib().orc_v27ter_init(self.p, bit_rate) == 0
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().orc_v27ter_rx(self.p, amp.ctypes.data, len(amp), self.sink.p)
 
     def snapshot(self):
         f = self.buf[:4*self.N_FLOATS].view(np.float32).copy()

@@ -18,20 +18,19 @@
  * (orc_modem_set_tables); they are data taken from the reference build (tests/golden/
  * modem_tables.npz) -- the product builds its own and is tested against the same data.
  *
- * One deliberate difference, so that the GPU path can be pinned bit-for-bit to THIS file:
- * the phase "spin" at the end of training (v29rx.c:618-623) uses cosf/sinf; libm's float
- * trig is not reproducible across implementations (glibc dispatches FMA/non-FMA variants),
- * so both this oracle and the device evaluate cos/sin in double and round to float.  The
- * oracle is in turn pinned to the real reference with: bits and status events exact, integer
- * state exact, float state within 2e-6 relative (tests/test_oracle_pin.py).
+ * The phase "spin" at the end of training (v29rx.c:618-623) calls libm's cosf/sinf: restated in
+ * modem_common.h (glibc's sincosf algorithm, verified against libm over the whole argument range),
+ * so this file, the device code and the reference build all produce the same bits.
  */
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "oracle.h"
+#include "modem_common.h"
 
-static orc_modem_tables_t T;
+orc_modem_tables_t orc_modem_T;
+#define T orc_modem_T
 
 void orc_modem_set_tables(const orc_modem_tables_t *t)
 {
@@ -77,17 +76,9 @@ static const char *SPACE_MAP[20] =
 
 int orc_v29_sizeof(void) { return (int) sizeof(orc_v29_t); }
 
-/* power_meter.c:82-92 */
-static int32_t level_dbm0(float level)
-{
-    float l;
-
-    level -= (3.14f + 3.02f);
-    if (level > 0.0)
-        level = 0.0;
-    l = powf(10.0f, level/10.0f)*(32767.0f*32767.0f);
-    return (int32_t) l;
-}
+/* test hooks for the libm restatement in modem_common.h */
+float orc_trig_cosf(float x) { return orc_cosf(x); }
+float orc_trig_sinf(float x) { return orc_sinf(x); }
 
 /* v29rx.c:163-169 */
 void orc_v29_set_signal_cutoff(orc_v29_t *s, float cutoff)
@@ -190,62 +181,6 @@ int orc_v29_init(orc_v29_t *s, int bit_rate)
 static void report_status(orc_sink_t *sink, int status)
 {
     orc_sink_push(sink, 3, status, 0, 0);       /* v29rx.c:171-178: status through put_bit */
-}
-
-/* vector_float.c:890-939 */
-static float circular_dot(const float x[], const float y[], int n, int pos)
-{
-    float z = 0.0f;
-    float z1 = 0.0f;
-    int i;
-
-    for (i = 0;  i < n - pos;  i++)
-        z += x[pos + i]*y[i];
-    for (i = 0;  i < pos;  i++)
-        z1 += x[i]*y[n - pos + i];
-    z += z1;
-    return z;
-}
-
-/* spandsp/arctan2.h:47-80 */
-static int32_t arctan2_i(float y, float x)
-{
-    float abs_y;
-    float angle;
-
-    if (y == 0.0f)
-        return (x < 0.0f)  ?  (int32_t) 0x80000000u  :  0;
-    if (x == 0.0f)
-        return (y < 0.0f)  ?  (int32_t) 0xc0000000u  :  0x40000000;
-    abs_y = fabsf(y);
-    if (x < 0.0f)
-        angle = 3.0f - (x + abs_y)/(abs_y - x);
-    else
-        angle = 1.0f - (x - abs_y)/(abs_y + x);
-    angle *= 536870912.0f;
-    if (y < 0.0f)
-        angle = -angle;
-    return (int32_t) angle;
-}
-
-/* math_fixed.c:158-169 */
-static int fixed_sqrt32(uint32_t x)
-{
-    int shift;
-    int top;
-
-    if (x == 0)
-        return 0;
-    top = 31;
-    while (!(x & 0x80000000u))
-    {
-        x <<= 1;
-        top--;
-    }
-    x >>= (31 - top);
-    shift = 30 - (top & ~1);
-    x <<= shift;
-    return T.sqrt_tab[((x >> 24) & 0xFF) - 64] >> (shift >> 1);
 }
 
 /* godard.c:144-162 */
@@ -500,8 +435,8 @@ static void process_half_baud(orc_v29_t *s, orc_sink_t *sink, const float sample
             }
             /* spin the equaliser buffer and the carrier (v29rx.c:618-624); see the header note on cos/sin */
             p = ((uint32_t) angle)*2.0f*3.1415926f/(65536.0f*65536.0f);        /* dds_phase_to_radians */
-            c = (float) cos((double) p);
-            sn = -(float) sin((double) p);
+            c = orc_cosf(p);
+            sn = -orc_sinf(p);
             zz[0] = c;
             zz[1] = sn;
             for (i = 0;  i < EQ_LEN;  i++)

@@ -1,0 +1,508 @@
+// modem_api.hip -- C ABI of the batched modem receivers (include/spangpu.h, "Modem receiver banks").
+// Device code: v29_dev.hpp, v27ter_dev.hpp; constant tables: modem_tables.c.  No CPU implementation
+// exists behind these entry points.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/spangpu.h"
+#include "modem_tables.h"
+#include "v29_dev.hpp"
+#include "v27ter_dev.hpp"
+
+using namespace spg;
+
+extern "C" int spangpu_set_error(int code, const char *msg);
+
+#define V29_TRY(expr)                                                                       \
+    do                                                                                      \
+    {                                                                                       \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+        {                                                                                   \
+            char m_[256];                                                                   \
+            snprintf(m_, sizeof(m_), "%s failed: %s", #expr, hipGetErrorString(e_));        \
+            return spangpu_set_error(SPANGPU_ERR_HIP, m_);                                  \
+        }                                                                                   \
+    }                                                                                       \
+    while (0)
+
+struct spangpu_modem_s
+{
+    int kind;
+    int n_words;
+    int n_floats;
+    int device;
+    int n_ch;
+    int bit_rate;
+    hipStream_t stream;
+    bool own_stream;
+    uint32_t *state;            // [kV29Words][n_ch]
+    void *tab;
+    int16_t *d_amp;
+    size_t amp_cap;
+    int8_t *events;
+    int32_t *ev_count;
+    int ev_cap;
+    int8_t *h_events;
+    int32_t *h_count;
+    int last_cap;
+};
+
+// power_meter_level_dbm0(), power_meter.c:82-92
+static int32_t level_dbm0(float level)
+{
+    level -= (3.14f + 3.02f);
+    if (level > 0.0)
+        level = 0.0;
+    const float l = powf(10.0f, level/10.0f)*(32767.0f*32767.0f);
+    return (int32_t) l;
+}
+
+// v29_rx_init() + v29_rx_restart(.., false), v29rx.c:1019-1131, as one channel's state words
+static int v29_initial_words(uint32_t *w, int bit_rate, float cutoff_dbm0)
+{
+    float f[kV29Floats];
+    int32_t i[kV29Ints];
+    memset(f, 0, sizeof(f));
+    memset(i, 0, sizeof(i));
+    switch (bit_rate)
+    {
+    case 9600: i[VI_TRAINING_CD] = 0; break;
+    case 7200: i[VI_TRAINING_CD] = 2; break;
+    case 4800: i[VI_TRAINING_CD] = 4; break;
+    default: return -1;
+    }
+    i[VI_BIT_RATE] = bit_rate;
+    i[VI_TRAIN_SCRAMBLE] = 0x2A;
+    i[VI_STAGE] = V29_SYMBOL_ACQUISITION;
+    i[VI_PHASE_RATE] = (int32_t) (1700.0f*65536.0f*65536.0f/8000);
+    i[VI_ON_POWER] = (int32_t) (level_dbm0(cutoff_dbm0 + 2.5f)*0.4f);       // v29rx.c:163-169
+    i[VI_OFF_POWER] = (int32_t) (level_dbm0(cutoff_dbm0 - 2.5f)*0.4f);
+    i[VI_EQ_PUT_STEP] = kRrcSets*10/(3*2) - 1;
+    f[VF_EQ_COEFF + 2*16] = 3.0f;                                           // equalizer_reset()
+    f[VF_EQ_DELTA] = 0.21f/kEqLen;
+    f[VF_AGC] = (1.25f/1.0f)/735.0f;
+    f[VF_TRACK_I] = 8000.0f;
+    f[VF_TRACK_P] = 8000000.0f;
+    memcpy(w, f, sizeof(f));
+    memcpy(w + kV29Floats, i, sizeof(i));
+    return 0;
+}
+
+// v27ter_rx_init() + v27ter_rx_restart(), v27ter_rx.c:1091-1190
+static int v27_initial_words(uint32_t *w, int bit_rate, float cutoff_dbm0)
+{
+    float f[kV27Floats];
+    int32_t i[kV27Ints];
+    memset(f, 0, sizeof(f));
+    memset(i, 0, sizeof(i));
+    if (bit_rate != 4800  &&  bit_rate != 2400)
+        return -1;
+    i[WI_BIT_RATE] = bit_rate;
+    i[WI_SCRAMBLE] = 0x3C;
+    i[WI_STAGE] = V27_SYMBOL_ACQUISITION;
+    i[WI_PHASE_RATE] = (int32_t) (1800.0f*65536.0f*65536.0f/8000);
+    i[WI_ON_POWER] = (int32_t) (level_dbm0(cutoff_dbm0 + 2.5f)*0.4f);
+    i[WI_OFF_POWER] = (int32_t) (level_dbm0(cutoff_dbm0 - 2.5f)*0.4f);
+    i[WI_EQ_PUT_STEP] = (bit_rate == 4800)  ?  8*5/2  :  12*20/(3*2);
+    i[WI_GARDNER_STEP] = 512;
+    f[WF_EQ_COEFF + 2*17] = 1.414f;
+    f[WF_EQ_DELTA] = 0.25f/kV27EqLen;
+    f[WF_AGC] = (1.414f/1.000000f)/283.0f;
+    f[WF_TRACK_I] = 200000.0f;
+    f[WF_TRACK_P] = 10000000.0f;
+    memcpy(w, f, sizeof(f));
+    memcpy(w + kV27Floats, i, sizeof(i));
+    return 0;
+}
+
+static int initial_words(int kind, uint32_t *w, int bit_rate)
+{
+    switch (kind)
+    {
+    case SPANGPU_V29:
+        return v29_initial_words(w, bit_rate, -28.5f);
+    case SPANGPU_V27TER:
+        return v27_initial_words(w, bit_rate, -45.5f);
+    }
+    return -1;
+}
+
+static constexpr int kMaxWords = 1024;
+
+extern "C" {
+
+int spangpu_modem_state_words(int kind, int *n_floats, int *n_ints)
+{
+    int nf;
+    int ni;
+    switch (kind)
+    {
+    case SPANGPU_V29: nf = kV29Floats; ni = kV29Ints; break;
+    case SPANGPU_V27TER: nf = kV27Floats; ni = kV27Ints; break;
+    default: return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "not a modem kind");
+    }
+    if (n_floats) *n_floats = nf;
+    if (n_ints) *n_ints = ni;
+    return nf + ni;
+}
+
+int spangpu_modem_create(spangpu_modem_t **out, int device, int kind, int n_channels, int bit_rate)
+{
+    if (out == nullptr  ||  n_channels <= 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    *out = nullptr;
+    uint32_t w[kMaxWords];
+    const int n_words = spangpu_modem_state_words(kind, nullptr, nullptr);
+    if (n_words < 0)
+        return n_words;
+    if (initial_words(kind, w, bit_rate) < 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bit rate not valid for this modem (V.29: 9600/7200/4800, V.27ter: 4800/2400)");
+    if (spangpu_device_count() <= 0)
+        return spangpu_set_error(SPANGPU_ERR_NO_DEVICE, "no HIP device: libspangpu has no CPU fallback");
+    if (device < 0  ||  device >= spangpu_device_count())
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "device out of range");
+    V29_TRY(hipSetDevice(device));
+    spangpu_modem_t *m = (spangpu_modem_t *) calloc(1, sizeof(*m));
+    if (m == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "calloc");
+    m->kind = kind;
+    m->n_words = n_words;
+    spangpu_modem_state_words(kind, &m->n_floats, nullptr);
+    m->device = device;
+    m->n_ch = n_channels;
+    m->bit_rate = bit_rate;
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+        free(m);
+        return spangpu_set_error(SPANGPU_ERR_HIP, "hipStreamCreate failed");
+    }
+    m->own_stream = true;
+    const size_t n = (size_t) n_channels;
+    const size_t tab_bytes = (kind == SPANGPU_V29)  ?  sizeof(V29Tables)  :  sizeof(V27Tables);
+    void *ht = calloc(1, tab_bytes);
+    uint32_t *hs = (uint32_t *) malloc(n*n_words*sizeof(uint32_t));
+    if (ht == nullptr  ||  hs == nullptr
+        ||  hipMalloc(&m->state, n*n_words*sizeof(uint32_t)) != hipSuccess
+        ||  hipMalloc(&m->tab, tab_bytes) != hipSuccess
+        ||  hipMalloc(&m->ev_count, n*sizeof(int32_t)) != hipSuccess
+        ||  hipHostMalloc(&m->h_count, n*sizeof(int32_t)) != hipSuccess)
+    {
+        free(ht);
+        free(hs);
+        spangpu_modem_destroy(m);
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "allocation of V.29 bank failed");
+    }
+    // constant tables (modem_tables.c): V.29 rx pulse shaper = 48 x 27, 1700 Hz, 2400 baud, 50 % excess
+    // bandwidth (make_modem_filter.c:403-411); Godard = 1700 Hz, 2400 baud, alpha 0.99, triggers 1000 / 30,
+    // steps 5 / 1 (src/Makefile.am:559-560)
+    if (kind == SPANGPU_V29)
+    {
+        V29Tables *t = (V29Tables *) ht;
+        spg_make_rx_pulseshaper(kRrcSets, kRrcLen, 1700.0, 2400.0, 0.5, t->rrc_re, t->rrc_im);
+        spg_make_sine_table(t->sine);
+        spg_make_sqrt_table(t->sqrt_tab);
+        spg_make_godard(1700.0, 2400.0, 0.99, t->godard);
+        t->coarse_trigger = 1000.0f;
+        t->fine_trigger = 30.0f;
+        t->coarse_step = 5;
+        t->fine_step = 1;
+        spg_make_v29_space_map(t->space_map);
+    }
+    else
+    {
+        // V.27ter rx pulse shapers: 1800 Hz carrier, 50 % excess bandwidth; 8 sets at 1600 baud, 12 sets at 1200 baud
+        // (make_modem_filter.c:379-402)
+        V27Tables *t = (V27Tables *) ht;
+        spg_make_rx_pulseshaper(8, kRrcLen, 1800.0, 1600.0, 0.5, t->re4800, t->im4800);
+        spg_make_rx_pulseshaper(12, kRrcLen, 1800.0, 1200.0, 0.5, t->re2400, t->im2400);
+        spg_make_sine_table(t->sine);
+        spg_make_sqrt_table(t->sqrt_tab);
+    }
+    for (int k = 0;  k < n_words;  k++)
+    {
+        for (size_t c = 0;  c < n;  c++)
+            hs[(size_t) k*n + c] = w[k];
+    }
+    hipError_t rc1 = hipMemcpy(m->tab, ht, tab_bytes, hipMemcpyHostToDevice);
+    hipError_t rc2 = hipMemcpy(m->state, hs, n*n_words*sizeof(uint32_t), hipMemcpyHostToDevice);
+    free(ht);
+    free(hs);
+    if (rc1 != hipSuccess  ||  rc2 != hipSuccess)
+    {
+        spangpu_modem_destroy(m);
+        return spangpu_set_error(SPANGPU_ERR_HIP, "state upload failed");
+    }
+    *out = m;
+    return SPANGPU_OK;
+}
+
+int spangpu_modem_destroy(spangpu_modem_t *m)
+{
+    if (m == nullptr)
+        return SPANGPU_OK;
+    (void) hipSetDevice(m->device);
+    if (m->stream)
+        (void) hipStreamSynchronize(m->stream);
+    if (m->state) (void) hipFree(m->state);
+    if (m->tab) (void) hipFree(m->tab);
+    if (m->d_amp) (void) hipFree(m->d_amp);
+    if (m->events) (void) hipFree(m->events);
+    if (m->ev_count) (void) hipFree(m->ev_count);
+    if (m->h_events) (void) hipHostFree(m->h_events);
+    if (m->h_count) (void) hipHostFree(m->h_count);
+    if (m->own_stream  &&  m->stream)
+        (void) hipStreamDestroy(m->stream);
+    free(m);
+    return SPANGPU_OK;
+}
+
+int spangpu_modem_channels(const spangpu_modem_t *m) { return m  ?  m->n_ch  :  SPANGPU_ERR_BAD_ARG; }
+
+int spangpu_modem_set_stream(spangpu_modem_t *m, void *hip_stream)
+{
+    if (m == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null bank");
+    (void) hipStreamSynchronize(m->stream);
+    if (m->own_stream)
+        (void) hipStreamDestroy(m->stream);
+    if (hip_stream)
+    {
+        m->stream = (hipStream_t) hip_stream;
+        m->own_stream = false;
+    }
+    else
+    {
+        V29_TRY(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+        m->own_stream = true;
+    }
+    return SPANGPU_OK;
+}
+
+int spangpu_modem_sync(spangpu_modem_t *m)
+{
+    if (m == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null bank");
+    V29_TRY(hipStreamSynchronize(m->stream));
+    return SPANGPU_OK;
+}
+
+int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int samples, long long stride)
+{
+    if (m == nullptr  ||  amp == nullptr  ||  samples < 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (samples == 0)
+        return 0;
+    if (stride <= 0)
+        stride = samples;
+    V29_TRY(hipSetDevice(m->device));
+    // at most 4 bits per baud, a baud every 8000/2400 samples, plus a handful of status events
+    const int cap = ((samples*3*4 + 9)/10 + 8 + 15) & ~15;
+    if (cap > m->ev_cap)
+    {
+        if (m->events) (void) hipFree(m->events);
+        if (m->h_events) (void) hipHostFree(m->h_events);
+        m->events = nullptr;
+        m->h_events = nullptr;
+        m->ev_cap = 0;
+        V29_TRY(hipMalloc(&m->events, (size_t) m->n_ch*cap));
+        V29_TRY(hipHostMalloc(&m->h_events, (size_t) m->n_ch*cap));
+        m->ev_cap = cap;
+    }
+    const int16_t *d_amp = amp;
+    long long d_stride = stride;
+    if (mem == SPANGPU_MEM_HOST)
+    {
+        if ((size_t) samples > m->amp_cap)
+        {
+            if (m->d_amp) (void) hipFree(m->d_amp);
+            m->d_amp = nullptr;
+            m->amp_cap = 0;
+            V29_TRY(hipMalloc(&m->d_amp, (size_t) m->n_ch*samples*sizeof(int16_t)));
+            m->amp_cap = samples;
+        }
+        V29_TRY(hipMemcpy2DAsync(m->d_amp, m->amp_cap*sizeof(int16_t), amp, stride*sizeof(int16_t),
+                                 samples*sizeof(int16_t), m->n_ch, hipMemcpyHostToDevice, m->stream));
+        d_amp = m->d_amp;
+        d_stride = (long long) m->amp_cap;
+    }
+    else if (mem != SPANGPU_MEM_DEVICE)
+    {
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad mem kind");
+    }
+    // enough workgroups to put a wave on every SIMD (256 CUs x 4) before filling the waves
+    const int cpw = (m->n_ch >= 64*1024)  ?  64  :  (m->n_ch >= 32*1024)  ?  32  :  16;
+    const dim3 grid((m->n_ch + cpw - 1)/cpw);
+    if (m->kind == SPANGPU_V29)
+    {
+        V29Launch L;
+        memset(&L, 0, sizeof(L));
+        L.amp = d_amp;
+        L.stride = d_stride;
+        L.samples = samples;
+        L.n_ch = m->n_ch;
+        L.state = m->state;
+        L.events = m->events;
+        L.ev_count = m->ev_count;
+        L.ev_cap = m->ev_cap;
+        L.tab = (const V29Tables *) m->tab;
+        if (cpw == 64)
+            hipLaunchKernelGGL(v29_bank_kernel<64>, grid, dim3(64), 0, m->stream, L);
+        else if (cpw == 32)
+            hipLaunchKernelGGL(v29_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
+        else
+            hipLaunchKernelGGL(v29_bank_kernel<16>, grid, dim3(64), 0, m->stream, L);
+    }
+    else
+    {
+        V27Launch L;
+        memset(&L, 0, sizeof(L));
+        L.amp = d_amp;
+        L.stride = d_stride;
+        L.samples = samples;
+        L.n_ch = m->n_ch;
+        L.bit_rate = m->bit_rate;
+        L.state = m->state;
+        L.events = m->events;
+        L.ev_count = m->ev_count;
+        L.ev_cap = m->ev_cap;
+        L.tab = (const V27Tables *) m->tab;
+        if (cpw == 64)
+            hipLaunchKernelGGL(v27ter_bank_kernel<64>, grid, dim3(64), 0, m->stream, L);
+        else if (cpw == 32)
+            hipLaunchKernelGGL(v27ter_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
+        else
+            hipLaunchKernelGGL(v27ter_bank_kernel<16>, grid, dim3(64), 0, m->stream, L);
+    }
+    V29_TRY(hipGetLastError());
+    m->last_cap = m->ev_cap;
+    if (mem == SPANGPU_MEM_HOST)
+        V29_TRY(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+// The put_bit stream of the last spangpu_modem_rx() call: for channel c, counts[c] entries at
+// events + c*cap, each 0/1 (a descrambled data bit) or a negative SIG_STATUS_* code
+// (spandsp/async.h:66-103), in the order v29_rx() would have called put_bit().  Returns cap.
+int spangpu_modem_events(spangpu_modem_t *m, const int8_t **events, const int32_t **counts)
+{
+    if (m == nullptr  ||  events == nullptr  ||  counts == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (m->last_cap <= 0)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "no spangpu_modem_rx() yet");
+    V29_TRY(hipSetDevice(m->device));
+    V29_TRY(hipMemcpyAsync(m->h_events, m->events, (size_t) m->n_ch*m->last_cap, hipMemcpyDeviceToHost, m->stream));
+    V29_TRY(hipMemcpyAsync(m->h_count, m->ev_count, (size_t) m->n_ch*sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    V29_TRY(hipStreamSynchronize(m->stream));
+    *events = m->h_events;
+    *counts = m->h_count;
+    return m->last_cap;
+}
+
+// One channel's state as spangpu_modem_state_words() 32 bit words: the float words, then the int words
+// (order: "State word map" in v29_dev.hpp / v27ter_dev.hpp).
+int spangpu_modem_get_state(spangpu_modem_t *m, int channel, uint32_t *words)
+{
+    if (m == nullptr  ||  channel < 0  ||  channel >= m->n_ch  ||  words == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    V29_TRY(hipSetDevice(m->device));
+    V29_TRY(hipStreamSynchronize(m->stream));
+    V29_TRY(hipMemcpy2D(words, sizeof(uint32_t), m->state + channel, (size_t) m->n_ch*sizeof(uint32_t),
+                        sizeof(uint32_t), m->n_words, hipMemcpyDeviceToHost));
+    return m->n_words;
+}
+
+// xxx_rx_restart(s, bit_rate, false) for one channel (v29rx.c:1019-1098, v27ter_rx.c:1091-1160)
+int spangpu_modem_restart(spangpu_modem_t *m, int channel)
+{
+    if (m == nullptr  ||  channel < 0  ||  channel >= m->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    V29_TRY(hipSetDevice(m->device));
+    V29_TRY(hipStreamSynchronize(m->stream));
+    uint32_t w[kMaxWords];
+    uint32_t old[kMaxWords];
+    initial_words(m->kind, w, m->bit_rate);
+    V29_TRY(hipMemcpy2D(old, sizeof(uint32_t), m->state + channel, (size_t) m->n_ch*sizeof(uint32_t),
+                        sizeof(uint32_t), m->n_words, hipMemcpyDeviceToHost));
+    // what a restart keeps: the cutoff powers, the saved equaliser / carrier rate / AGC, and fields it never touches
+    const int nf = m->n_floats;
+    if (m->kind == SPANGPU_V29)
+    {
+        static const int keep_i[] = {VI_ON_POWER, VI_OFF_POWER, VI_PHASE_RATE_SAVE, VI_LAST_ANGLES, VI_LAST_ANGLES + 1};
+        for (int k : keep_i)
+            w[nf + k] = old[nf + k];
+        for (int k = 0;  k < 2*kEqLen;  k++)
+            w[VF_EQ_SAVE + k] = old[VF_EQ_SAVE + k];
+        w[VF_TRAIN_ERR] = old[VF_TRAIN_ERR];
+    }
+    else
+    {
+        static const int keep_i[] = {WI_ON_POWER, WI_OFF_POWER, WI_PHASE_RATE_SAVE, WI_LAST_ANGLES, WI_LAST_ANGLES + 1};
+        for (int k : keep_i)
+            w[nf + k] = old[nf + k];
+        for (int k = 0;  k < 2*kV27EqLen;  k++)
+            w[WF_EQ_SAVE + k] = old[WF_EQ_SAVE + k];
+        w[WF_AGC_SAVE] = old[WF_AGC_SAVE];
+    }
+    V29_TRY(hipMemcpy2D(m->state + channel, (size_t) m->n_ch*sizeof(uint32_t), w, sizeof(uint32_t),
+                        sizeof(uint32_t), m->n_words, hipMemcpyHostToDevice));
+    return SPANGPU_OK;
+}
+
+// The constant tables this library builds (for tests).  which: 0 sine [2048], 1 sqrt (as float) [193],
+// 10/11 V.29 rx pulse shaper re/im [48*27], 12 V.29 Godard [7], 20/21 V.27ter 4800 re/im [8*27],
+// 22/23 V.27ter 2400 re/im [12*27].  Returns the number of values written.
+int spangpu_modem_table(int which, float *out, int max)
+{
+    static float re[192*27];
+    static float im[192*27];
+    uint16_t sq[193];
+    int n = 0;
+    const float *src = re;
+    if (out == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null output");
+    switch (which)
+    {
+    case 0:
+        n = 2048;
+        if (n <= max) spg_make_sine_table(out);
+        return (n <= max)  ?  n  :  spangpu_set_error(SPANGPU_ERR_BAD_ARG, "buffer too small");
+    case 1:
+        n = 193;
+        spg_make_sqrt_table(sq);
+        for (int i = 0;  i < n  &&  i < max;  i++)
+            out[i] = (float) sq[i];
+        return n;
+    case 10: case 11:
+        n = 48*27;
+        spg_make_rx_pulseshaper(48, 27, 1700.0, 2400.0, 0.5, re, im);
+        src = (which & 1)  ?  im  :  re;
+        break;
+    case 12:
+        n = 7;
+        spg_make_godard(1700.0, 2400.0, 0.99, re);
+        break;
+    case 20: case 21:
+        n = 8*27;
+        spg_make_rx_pulseshaper(8, 27, 1800.0, 1600.0, 0.5, re, im);
+        src = (which & 1)  ?  im  :  re;
+        break;
+    case 22: case 23:
+        n = 12*27;
+        spg_make_rx_pulseshaper(12, 27, 1800.0, 1200.0, 0.5, re, im);
+        src = (which & 1)  ?  im  :  re;
+        break;
+    default:
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "unknown table");
+    }
+    if (n > max)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "buffer too small");
+    memcpy(out, src, n*sizeof(float));
+    return n;
+}
+
+}   // extern "C"

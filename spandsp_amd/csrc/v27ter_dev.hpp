@@ -1,0 +1,704 @@
+// v27ter_dev.hpp -- device side of the batched V.27ter receiver (reference: src/v27ter_rx.c:197-1028;
+// primitives as in v29_dev.hpp).  Same mapping as the V.29 bank: one channel per lane, per-lane
+// delay lines index-major in LDS, equaliser taps in VGPRs, the reference's summation order kept.
+// Differences from V.29 that shape the kernel: the pulse-shaping filter only runs at the T/2
+// instants (no per-sample timing-error filter; symbol timing is a Gardner detector on the
+// equaliser delay line), 32 taps, an 8-point PSK slicer, and a descrambler with the V.27ter
+// repeated-pattern guard.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "v29_dev.hpp"
+
+namespace spg {
+
+constexpr int kV27Floats = 225;
+constexpr int kV27Ints = 45;
+constexpr int kV27Words = kV27Floats + kV27Ints;
+constexpr int kV27EqLen = 32;
+constexpr int kV27MaxSets = 12;
+constexpr int kV27LaneWords = 2*kRrcLen + 4*kV27EqLen;     // 182
+
+// State word map (reference-ordered snapshot used by the tests):
+//   floats: 0 agc_scaling, 1 agc_scaling_save, 2 eq_delta, 3 training_error, 4 carrier_track_p, 5 carrier_track_i,
+//           6-32 rrc_filter[27], 33-96 eq_coeff[32][2], 97-160 eq_coeff_save, 161-224 eq_buf
+//   ints:   0 bit_rate, 1 rrc_filter_step, 2 scramble_reg, 3 scrambler_pattern_count, 4 training_bc, 5 old_train,
+//           6 training_stage, 7 training_count, 8 last_sample, 9 signal_present, 10 carrier_drop_pending, 11 low_samples,
+//           12 high_sample, 13 constellation_state, 14 carrier_phase, 15 carrier_phase_rate, 16 carrier_phase_rate_save,
+//           17 power reading, 18 carrier_on_power, 19 carrier_off_power, 20 eq_step, 21 eq_put_step, 22 eq_skip,
+//           23 baud_half, 24 gardner_integrate, 25 gardner_step, 26 total timing correction, 27-28 last_angles,
+//           29-44 diff_angles
+enum
+{
+    WF_AGC = 0, WF_AGC_SAVE, WF_EQ_DELTA, WF_TRAIN_ERR, WF_TRACK_P, WF_TRACK_I,
+    WF_RRC = 6, WF_EQ_COEFF = 33, WF_EQ_SAVE = 97, WF_EQ_BUF = 161
+};
+enum
+{
+    WI_BIT_RATE = 0, WI_RRC_STEP, WI_SCRAMBLE, WI_PATTERN_COUNT, WI_TRAINING_BC, WI_OLD_TRAIN, WI_STAGE, WI_TRAIN_COUNT,
+    WI_LAST_SAMPLE, WI_SIGNAL_PRESENT, WI_DROP_PENDING, WI_LOW_SAMPLES, WI_HIGH_SAMPLE, WI_CONSTEL, WI_CARRIER_PHASE,
+    WI_PHASE_RATE, WI_PHASE_RATE_SAVE, WI_POWER, WI_ON_POWER, WI_OFF_POWER, WI_EQ_STEP, WI_EQ_PUT_STEP, WI_EQ_SKIP,
+    WI_BAUD_HALF, WI_GARDNER_INT, WI_GARDNER_STEP, WI_TOTAL_CORR, WI_LAST_ANGLES = 27, WI_DIFF_ANGLES = 29
+};
+
+enum
+{
+    V27_NORMAL = 0, V27_SYMBOL_ACQUISITION, V27_LOG_PHASE, V27_WAIT_FOR_HOP, V27_TRAIN_ON_ABAB, V27_TEST_ONES, V27_PARKED
+};
+
+struct V27Tables
+{
+    float re4800[8*kRrcLen];
+    float im4800[8*kRrcLen];
+    float re2400[12*kRrcLen];
+    float im2400[12*kRrcLen];
+    float sine[2048];
+    uint16_t sqrt_tab[194];
+};
+
+struct V27Launch
+{
+    const int16_t *amp;
+    long long stride;
+    int samples;
+    int n_ch;
+    int bit_rate;               // bank-wide: 4800 or 2400
+    uint32_t *state;            // [kV27Words][n_ch]
+    int8_t *events;
+    int32_t *ev_count;
+    int ev_cap;
+    const V27Tables *tab;
+};
+
+template <int CPW>
+__global__ __launch_bounds__(64)
+void v27ter_bank_kernel(const V27Launch L)
+{
+    __shared__ float t_rrc_re[kV27MaxSets*kRrcLen];     // [tap][set]
+    __shared__ float t_rrc_im[kV27MaxSets*kRrcLen];
+    __shared__ float t_sine[2048];
+    __shared__ uint16_t t_sqrt[194];
+    __shared__ float lanes[CPW*kV27LaneWords];
+
+    const int lane = threadIdx.x;
+    const int ch = blockIdx.x*CPW + lane;
+    const V27Tables &TB = *L.tab;
+    const bool fast = (L.bit_rate == 4800);
+    const int sets = fast  ?  8  :  12;
+    const int put_add = fast  ?  8*5/2  :  12*20/(3*2);
+
+    {
+        const float *sre = fast  ?  TB.re4800  :  TB.re2400;
+        const float *sim = fast  ?  TB.im4800  :  TB.im2400;
+        for (int i = lane;  i < sets*kRrcLen;  i += 64)
+        {
+            const int set = i/kRrcLen;
+            const int tap = i - set*kRrcLen;
+            t_rrc_re[tap*kV27MaxSets + set] = sre[i];
+            t_rrc_im[tap*kV27MaxSets + set] = sim[i];
+        }
+    }
+    for (int i = lane;  i < 2048;  i += 64)
+        t_sine[i] = TB.sine[i];
+    for (int i = lane;  i < 194;  i += 64)
+        t_sqrt[i] = TB.sqrt_tab[i];
+    __syncthreads();
+    if (lane >= CPW  ||  ch >= L.n_ch)
+        return;
+
+    const size_t N = (size_t) L.n_ch;
+    auto ldf = [&](int w) { return __uint_as_float(L.state[(size_t) w*N + ch]); };
+    auto ldi = [&](int w) { return (int32_t) L.state[(size_t) (kV27Floats + w)*N + ch]; };
+    auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
+    auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV27Floats + w)*N + ch] = (uint32_t) v; };
+
+    float *rrc2 = &lanes[lane];                         // [2*27] words, stride CPW
+    float *eqb2 = rrc2 + 2*kRrcLen*CPW;                 // [2*32][2] words, stride CPW
+#define RRC2(k)     rrc2[(k)*CPW]
+#define EQB2(k)     eqb2[(k)*CPW]
+    constexpr int EQN = kV27EqLen;
+
+    float agc_scaling = ldf(WF_AGC);
+    float agc_scaling_save = ldf(WF_AGC_SAVE);
+    const float eq_delta = ldf(WF_EQ_DELTA);
+    float training_error = ldf(WF_TRAIN_ERR);
+    float carrier_track_p = ldf(WF_TRACK_P);
+    float carrier_track_i = ldf(WF_TRACK_I);
+    for (int i = 0;  i < kRrcLen;  i++)
+    {
+        const float v = ldf(WF_RRC + i);
+        RRC2(i) = v;
+        RRC2(kRrcLen + i) = v;
+    }
+    float cre[EQN];
+    float cim[EQN];
+#pragma unroll
+    for (int i = 0;  i < EQN;  i++)
+    {
+        cre[i] = ldf(WF_EQ_COEFF + 2*i);
+        cim[i] = ldf(WF_EQ_COEFF + 2*i + 1);
+    }
+    for (int i = 0;  i < 2*EQN;  i++)
+    {
+        const float a = ldf(WF_EQ_BUF + i);
+        EQB2(i) = a;
+        EQB2(2*EQN + i) = a;
+    }
+    int rrc_step = ldi(WI_RRC_STEP);
+    uint32_t scramble_reg = (uint32_t) ldi(WI_SCRAMBLE);
+    int pattern_count = ldi(WI_PATTERN_COUNT);
+    int training_bc = ldi(WI_TRAINING_BC);
+    int stage = ldi(WI_STAGE);
+    int training_count = ldi(WI_TRAIN_COUNT);
+    int last_sample = ldi(WI_LAST_SAMPLE);
+    int signal_present = ldi(WI_SIGNAL_PRESENT);
+    int drop_pending = ldi(WI_DROP_PENDING);
+    int low_samples = ldi(WI_LOW_SAMPLES);
+    int high_sample = ldi(WI_HIGH_SAMPLE);
+    int constellation_state = ldi(WI_CONSTEL);
+    uint32_t carrier_phase = (uint32_t) ldi(WI_CARRIER_PHASE);
+    int32_t carrier_phase_rate = ldi(WI_PHASE_RATE);
+    int32_t carrier_phase_rate_save = ldi(WI_PHASE_RATE_SAVE);
+    int32_t power_reading = ldi(WI_POWER);
+    const int32_t carrier_on_power = ldi(WI_ON_POWER);
+    const int32_t carrier_off_power = ldi(WI_OFF_POWER);
+    int eq_step = ldi(WI_EQ_STEP);
+    int eq_put_step = ldi(WI_EQ_PUT_STEP);
+    int eq_skip = ldi(WI_EQ_SKIP);
+    int baud_half = ldi(WI_BAUD_HALF);
+    int gardner_integrate = ldi(WI_GARDNER_INT);
+    int gardner_step = ldi(WI_GARDNER_STEP);
+    int total_corr = ldi(WI_TOTAL_CORR);
+    int32_t last_angle0 = ldi(WI_LAST_ANGLES);
+    int32_t last_angle1 = ldi(WI_LAST_ANGLES + 1);
+    auto diff_ld = [&](int k) { return ldi(WI_DIFF_ANGLES + (k & 0xF)); };
+    auto diff_st = [&](int k, int32_t v) { sti(WI_DIFF_ANGLES + (k & 0xF), v); };
+
+    int8_t *evp = L.events + (size_t) ch*L.ev_cap;
+    int n_ev = 0;
+    auto emit = [&](int v)
+    {
+        if (n_ev < L.ev_cap)
+            evp[n_ev] = (int8_t) v;
+        n_ev++;
+    };
+
+    // v27ter_rx_restart() as the receive path reaches it (v27ter_rx.c:1091-1160; s->old_train is never set)
+    auto restart = [&]()
+    {
+        for (int i = 0;  i < 2*kRrcLen;  i++)
+            RRC2(i) = 0.0f;
+        training_error = 0.0f;
+        rrc_step = 0;
+        scramble_reg = 0x3C;
+        pattern_count = 0;
+        stage = V27_SYMBOL_ACQUISITION;
+        training_bc = 0;
+        training_count = 0;
+        signal_present = 0;
+        high_sample = 0;
+        low_samples = 0;
+        drop_pending = 0;
+        for (int k = 0;  k < 16;  k++)
+            diff_st(k, 0);
+        carrier_phase = 0;
+        carrier_track_i = 200000.0f;
+        carrier_track_p = 10000000.0f;
+        power_reading = 0;
+        constellation_state = 0;
+        carrier_phase_rate = v29_f2i(1800.0f*65536.0f*65536.0f/8000);
+        agc_scaling = (1.414f/1.000000f)/283.0f;
+#pragma unroll
+        for (int i = 0;  i < EQN;  i++)
+        {
+            cre[i] = 0.0f;
+            cim[i] = 0.0f;
+        }
+        cre[17] = 1.414f;                                   // V27TER_EQUALIZER_PRE_LEN + 1
+        for (int i = 0;  i < 4*EQN;  i++)
+            EQB2(i) = 0.0f;
+        eq_put_step = put_add;
+        eq_step = 0;
+        eq_skip = 0;
+        last_sample = 0;
+        gardner_integrate = 0;
+        total_corr = 0;
+        gardner_step = 512;
+        baud_half = 0;
+    };
+
+    auto rrc_dot = [&](const float *table, int row)
+    {
+        const float *y = table + row;
+        const float *x = rrc2 + rrc_step*CPW;
+        const int split = kRrcLen - rrc_step;
+        float a = 0.0f;
+        float first = 0.0f;
+#pragma unroll
+        for (int i = 0;  i < kRrcLen;  i++)
+        {
+            if (i == split)
+            {
+                first = a;
+                a = 0.0f;
+            }
+            a += x[i*CPW]*y[i*kV27MaxSets];
+        }
+        return first + a;
+    };
+    auto track_carrier = [&](float zre, float zim, float tre, float tim)
+    {
+        const float error = zim*tre - zre*tim;
+        carrier_phase_rate += v29_f2i(carrier_track_i*error);
+        carrier_phase += (uint32_t) v29_f2i(carrier_track_p*error);
+    };
+    auto tune_equalizer = [&](float zre, float zim, float tre, float tim)
+    {
+        const float ere = (tre - zre)*eq_delta;
+        const float eim = (tim - zim)*eq_delta;
+        const float *x = eqb2 + 2*eq_step*CPW;
+#pragma unroll
+        for (int i = 0;  i < EQN;  i++)
+        {
+            const float xr = x[2*i*CPW];
+            const float xi = x[(2*i + 1)*CPW];
+            cre[i] = cre[i]*0.9999f + (xi*eim + xr*ere);
+            cim[i] = cim[i]*0.9999f + (xr*eim - xi*ere);
+        }
+    };
+    // v27ter_rx.c:380-414
+    auto descramble = [&](int in_bit)
+    {
+        const bool training = (stage > V27_NORMAL  &&  stage < V27_TEST_ONES);
+        in_bit &= 1;
+        int out_bit = (in_bit ^ (int) (scramble_reg >> 5) ^ (int) (scramble_reg >> 6)) & 1;
+        if (pattern_count >= 33)
+        {
+            out_bit ^= 1;
+            pattern_count = 0;
+        }
+        else if (training)
+        {
+            pattern_count = 0;
+        }
+        else
+        {
+            const uint32_t m = ((scramble_reg >> 7) ^ (uint32_t) in_bit) & ((scramble_reg >> 8) ^ (uint32_t) in_bit)
+                             & ((scramble_reg >> 11) ^ (uint32_t) in_bit) & 1u;
+            pattern_count = m  ?  0  :  (pattern_count + 1);
+        }
+        scramble_reg = (scramble_reg << 1) | (uint32_t) (training  ?  out_bit  :  in_bit);
+        return out_bit;
+    };
+    auto put_bit = [&](int bit)
+    {
+        const int out_bit = descramble(bit);
+        if (stage == V27_NORMAL)
+            emit(out_bit);
+    };
+    auto target_of = [&](int k, float &tre, float &tim)
+    {
+        // v27ter_constellation[8], v27ter_rx.c:125-134
+        const float mag = (k & 1)  ?  1.0f  :  1.414f;
+        const int q = k >> 1;                               // 0: +re, 1: +im, 2: -re, 3: -im (even k); diagonals for odd k
+        if (k & 1)
+        {
+            tre = (q == 0  ||  q == 3)  ?  1.0f  :  -1.0f;
+            tim = (q == 0  ||  q == 1)  ?  1.0f  :  -1.0f;
+        }
+        else
+        {
+            tre = (q == 0)  ?  mag  :  (q == 2)  ?  -mag  :  0.0f;
+            tim = (q == 1)  ?  mag  :  (q == 3)  ?  -mag  :  0.0f;
+        }
+    };
+    // v27ter_rx.c:441-484
+    auto decode_baud = [&](float zre, float zim)
+    {
+        int nearest;
+        if (!fast)
+        {
+            const int b1 = (zim > zre);
+            const int b2 = (zim < -zre);
+            nearest = (b2 << 1) | (b1 ^ b2);
+            const int raw_bits = (0x1320 >> (4*((nearest - constellation_state) & 3))) & 0xF;      // {0, 2, 3, 1}
+            put_bit(raw_bits);
+            put_bit(raw_bits >> 1);
+            constellation_state = nearest;
+            nearest <<= 1;
+        }
+        else
+        {
+            const float abs_re = fabsf(zre);
+            const float abs_im = fabsf(zim);
+            if (abs_im*1.0f > abs_re*0.4142136f  &&  abs_im*1.0f < abs_re*2.4142136f)
+            {
+                const int b1 = (zre < 0.0f);
+                const int b2 = (zim < 0.0f);
+                nearest = (b2 << 2) | ((b1 ^ b2) << 1) | 1;
+            }
+            else
+            {
+                const int b1 = (zim > zre);
+                const int b2 = (zim < -zre);
+                nearest = (b2 << 2) | ((b1 ^ b2) << 1);
+            }
+            const int raw_bits = (int) ((0x51376204u >> (4*((nearest - constellation_state) & 7))) & 0xF);  // {4,0,2,6,7,3,1,5}
+            put_bit(raw_bits);
+            put_bit(raw_bits >> 1);
+            put_bit(raw_bits >> 2);
+            constellation_state = nearest;
+        }
+        float tre;
+        float tim;
+        target_of(nearest, tre, tim);
+        track_carrier(zre, zim, tre, tim);
+        if (--eq_skip <= 0)
+        {
+            eq_skip = 100;
+            tune_equalizer(zre, zim, tre, tim);
+        }
+    };
+    auto park = [&]()
+    {
+        stage = V27_PARKED;
+        emit(-5);                                           // SIG_STATUS_TRAINING_FAILED
+    };
+
+    const int16_t *src = L.amp + (size_t) ch*L.stride;
+    for (int n = 0;  n < L.samples;  n++)
+    {
+        const int amp = src[n];
+        RRC2(rrc_step) = (float) amp;
+        RRC2(rrc_step + kRrcLen) = (float) amp;
+        if (++rrc_step >= kRrcLen)
+            rrc_step = 0;
+
+        // signal_detect(), v27ter_rx.c:779-861 (IAXMODEM_STUFF is #defined at v27ter_rx.c:1)
+        int power;
+        {
+            const int x = amp >> 1;
+            int diff = (int) (short) (x - last_sample);
+            last_sample = x;
+            power_reading += ((diff*diff - power_reading) >> 4);
+            power = power_reading;
+            diff = (int) (short) abs(diff);
+            if (10*diff < high_sample)
+            {
+                if (++low_samples > 120)
+                {
+                    power_reading = 0;
+                    high_sample = 0;
+                    low_samples = 0;
+                }
+            }
+            else
+            {
+                low_samples = 0;
+                if (diff > high_sample)
+                    high_sample = diff;
+            }
+            if (signal_present > 0)
+            {
+                if (drop_pending  ||  power < carrier_off_power)
+                {
+                    if (--signal_present <= 0)
+                    {
+                        restart();
+                        emit(-1);                           // SIG_STATUS_CARRIER_DOWN
+                        power = 0;
+                    }
+                    else
+                    {
+                        drop_pending = 1;
+                    }
+                }
+            }
+            else
+            {
+                if (power < carrier_on_power)
+                {
+                    power = 0;
+                }
+                else
+                {
+                    signal_present = 1;
+                    drop_pending = 0;
+                    emit(-2);                               // SIG_STATUS_CARRIER_UP
+                }
+            }
+        }
+        if (power == 0  ||  stage == V27_PARKED)
+            continue;
+
+        eq_put_step -= sets;
+        if (eq_put_step <= 0)
+        {
+            if (stage == V27_SYMBOL_ACQUISITION)
+            {
+                int root_power;
+                {
+                    uint32_t xx = (uint32_t) power;
+                    const int top = 31 - __builtin_clz(xx);
+                    const int shift = 30 - (top & ~1);
+                    xx <<= shift;
+                    root_power = t_sqrt[((xx >> 24) & 0xFF) - 64] >> (shift >> 1);
+                }
+                if (root_power == 0)
+                    root_power = 1;
+                agc_scaling = (1.414f/1.000000f)/(float) root_power;
+            }
+            const int step = min(-eq_put_step, sets - 1);
+            float v = rrc_dot(t_rrc_re, step);
+            const float sre = v*agc_scaling;
+            v = rrc_dot(t_rrc_im, step);
+            const float sim = v*agc_scaling;
+            const float dre = t_sine[(uint32_t) (carrier_phase + (1u << 30)) >> 21];
+            const float dim = t_sine[carrier_phase >> 21];
+            const float hre = sre*dre - sim*dim;
+            const float him = -sre*dim - sim*dre;
+            eq_put_step += put_add;
+
+            // ---- process_half_baud(), v27ter_rx.c:531-777 ----
+            EQB2(2*eq_step) = hre;
+            EQB2(2*eq_step + 1) = him;
+            EQB2(2*(eq_step + EQN)) = hre;
+            EQB2(2*(eq_step + EQN) + 1) = him;
+            if (++eq_step >= EQN)
+                eq_step = 0;
+            baud_half ^= 1;
+            if (baud_half == 0)
+            {
+                {
+                    // symbol_sync(), v27ter_rx.c:486-528
+                    const int k3 = (eq_step - 3) & (EQN - 1);
+                    const int k2 = (eq_step - 2) & (EQN - 1);
+                    const int k1 = (eq_step - 1) & (EQN - 1);
+                    float p = EQB2(2*k3) - EQB2(2*k1);
+                    p *= EQB2(2*k2);
+                    float q = EQB2(2*k3 + 1) - EQB2(2*k1 + 1);
+                    q *= EQB2(2*k2 + 1);
+                    gardner_integrate += (p + q > 0.0f)  ?  gardner_step  :  -gardner_step;
+                    if (abs(gardner_integrate) >= 128)
+                    {
+                        eq_put_step += gardner_integrate/128;
+                        total_corr += gardner_integrate/128;
+                        gardner_integrate = 0;
+                    }
+                }
+                float zre;
+                float zim;
+                {
+                    const float *x = eqb2 + 2*eq_step*CPW;
+                    const int split = EQN - eq_step;
+                    float are = 0.0f;
+                    float aim = 0.0f;
+                    float fre = 0.0f;
+                    float fim = 0.0f;
+#pragma unroll
+                    for (int i = 0;  i < EQN;  i++)
+                    {
+                        if (i == split)
+                        {
+                            fre = are;
+                            fim = aim;
+                            are = 0.0f;
+                            aim = 0.0f;
+                        }
+                        const float xr = x[2*i*CPW];
+                        const float xi = x[(2*i + 1)*CPW];
+                        are += (xr*cre[i] - xi*cim[i]);
+                        aim += (xr*cim[i] + xi*cre[i]);
+                    }
+                    zre = fre + are;
+                    zim = fim + aim;
+                }
+
+                switch (stage)
+                {
+                case V27_NORMAL:
+                    decode_baud(zre, zim);
+                    break;
+                case V27_SYMBOL_ACQUISITION:
+                    if (++training_count >= 30)
+                    {
+                        gardner_step = 32;
+                        stage = V27_LOG_PHASE;
+                        for (int k = 0;  k < 16;  k++)
+                            diff_st(k, 0);
+                        last_angle0 = v29_arctan2(zim, zre);
+                    }
+                    break;
+                case V27_LOG_PHASE:
+                    last_angle1 = v29_arctan2(zim, zre);
+                    training_count = 1;
+                    stage = V27_WAIT_FOR_HOP;
+                    break;
+                case V27_WAIT_FOR_HOP:
+                {
+                    int32_t angle = v29_arctan2(zim, zre);
+                    int i = training_count + 1;
+                    const int32_t prev = (i & 1)  ?  last_angle1  :  last_angle0;
+                    int32_t ang = (int32_t) ((uint32_t) angle - (uint32_t) prev);
+                    if (i & 1)
+                        last_angle1 = angle;
+                    else
+                        last_angle0 = angle;
+                    diff_st(i, (int32_t) ((uint32_t) diff_ld(i - 2) + (uint32_t) (ang >> 4)));
+                    if ((ang > 0x20000000  ||  ang < (int32_t) 0xE0000000u)  &&  training_count >= 13)
+                    {
+                        i = (training_count - 8) & ~1;
+                        if (i > 1)
+                        {
+                            const int jj = i & 0xF;
+                            ang = (int32_t) ((uint32_t) diff_ld(jj) + (uint32_t) diff_ld(jj | 1))/(i - 1);
+                            if (fast)
+                                carrier_phase_rate += 16*(ang/10);
+                            else
+                                carrier_phase_rate += 3*16*(ang/40);
+                        }
+                        if (carrier_phase_rate < v29_f2i((1800.0f - 20.0f)*65536.0f*65536.0f/8000)
+                            ||  carrier_phase_rate > v29_f2i((1800.0f + 20.0f)*65536.0f*65536.0f/8000))
+                        {
+                            park();
+                            break;
+                        }
+                        angle = (int32_t) ((uint32_t) angle + 0x80000000u);
+                        const float p = ((uint32_t) angle)*2.0f*3.1415926f/(65536.0f*65536.0f);
+                        const float zc = spg_sincosf(p, true);
+                        const float zs = -spg_sincosf(p, false);
+                        for (int k = 0;  k < EQN;  k++)
+                        {
+                            const float xr = EQB2(2*k);
+                            const float xi = EQB2(2*k + 1);
+                            const float nr = xr*zc - xi*zs;
+                            const float ni = xr*zs + xi*zc;
+                            EQB2(2*k) = nr;
+                            EQB2(2*k + 1) = ni;
+                            EQB2(2*(k + EQN)) = nr;
+                            EQB2(2*(k + EQN) + 1) = ni;
+                        }
+                        carrier_phase += (uint32_t) angle;
+                        gardner_step = 2;
+                        training_bc = 1;
+                        training_bc ^= descramble(1);
+                        descramble(1);
+                        descramble(1);
+                        constellation_state = training_bc  ?  4  :  0;
+                        training_count = 1;
+                        stage = V27_TRAIN_ON_ABAB;
+                        emit(-3);                           // SIG_STATUS_TRAINING_IN_PROGRESS
+                    }
+                    else if (++training_count > 50)
+                    {
+                        park();
+                    }
+                    break;
+                }
+                case V27_TRAIN_ON_ABAB:
+                {
+                    training_bc ^= descramble(1);
+                    descramble(1);
+                    descramble(1);
+                    constellation_state = training_bc  ?  4  :  0;
+                    const float tre = training_bc  ?  -1.414f  :  1.414f;
+                    track_carrier(zre, zim, tre, 0.0f);
+                    tune_equalizer(zre, zim, tre, 0.0f);
+                    carrier_track_i = 400.0f + (200000.0f - 400.0f)*(float) (1074 - training_count)/(float) 1074;
+                    carrier_track_p = 1000000.0f + (10000000.0f - 1000000.0f)*(float) (1074 - training_count)/(float) 1074;
+                    if (++training_count >= 1074)
+                    {
+                        constellation_state = fast  ?  4  :  2;
+                        training_count = 0;
+                        stage = V27_TEST_ONES;
+                    }
+                    break;
+                }
+                case V27_TEST_ONES:
+                {
+                    decode_baud(zre, zim);
+                    float tre;
+                    float tim;
+                    target_of(fast  ?  constellation_state  :  (constellation_state << 1), tre, tim);
+                    const float dre2 = zre - tre;
+                    const float dim2 = zim - tim;
+                    training_error += (dre2*dre2 + dim2*dim2);
+                    if (++training_count >= 8)
+                    {
+                        if (training_error < (fast  ?  8.0f*0.25f  :  8.0f*0.5f))
+                        {
+                            emit(-4);                       // SIG_STATUS_TRAINING_SUCCEEDED
+                            signal_present = fast  ?  90  :  120;
+                            stage = V27_NORMAL;
+#pragma unroll
+                            for (int k = 0;  k < EQN;  k++)
+                            {
+                                stf(WF_EQ_SAVE + 2*k, cre[k]);
+                                stf(WF_EQ_SAVE + 2*k + 1, cim[k]);
+                            }
+                            carrier_phase_rate_save = carrier_phase_rate;
+                            agc_scaling_save = agc_scaling;
+                        }
+                        else
+                        {
+                            park();
+                        }
+                    }
+                    break;
+                }
+                default:
+                    break;
+                }
+            }
+        }
+        carrier_phase += (uint32_t) carrier_phase_rate;
+    }
+
+    stf(WF_AGC, agc_scaling);
+    stf(WF_AGC_SAVE, agc_scaling_save);
+    stf(WF_TRAIN_ERR, training_error);
+    stf(WF_TRACK_P, carrier_track_p);
+    stf(WF_TRACK_I, carrier_track_i);
+    for (int i = 0;  i < kRrcLen;  i++)
+        stf(WF_RRC + i, RRC2(i));
+#pragma unroll
+    for (int i = 0;  i < EQN;  i++)
+    {
+        stf(WF_EQ_COEFF + 2*i, cre[i]);
+        stf(WF_EQ_COEFF + 2*i + 1, cim[i]);
+    }
+    for (int i = 0;  i < 2*EQN;  i++)
+        stf(WF_EQ_BUF + i, EQB2(i));
+    sti(WI_RRC_STEP, rrc_step);
+    sti(WI_SCRAMBLE, (int32_t) scramble_reg);
+    sti(WI_PATTERN_COUNT, pattern_count);
+    sti(WI_TRAINING_BC, training_bc);
+    sti(WI_STAGE, stage);
+    sti(WI_TRAIN_COUNT, training_count);
+    sti(WI_LAST_SAMPLE, last_sample);
+    sti(WI_SIGNAL_PRESENT, signal_present);
+    sti(WI_DROP_PENDING, drop_pending);
+    sti(WI_LOW_SAMPLES, low_samples);
+    sti(WI_HIGH_SAMPLE, high_sample);
+    sti(WI_CONSTEL, constellation_state);
+    sti(WI_CARRIER_PHASE, (int32_t) carrier_phase);
+    sti(WI_PHASE_RATE, carrier_phase_rate);
+    sti(WI_PHASE_RATE_SAVE, carrier_phase_rate_save);
+    sti(WI_POWER, power_reading);
+    sti(WI_EQ_STEP, eq_step);
+    sti(WI_EQ_PUT_STEP, eq_put_step);
+    sti(WI_EQ_SKIP, eq_skip);
+    sti(WI_BAUD_HALF, baud_half);
+    sti(WI_GARDNER_INT, gardner_integrate);
+    sti(WI_GARDNER_STEP, gardner_step);
+    sti(WI_TOTAL_CORR, total_corr);
+    sti(WI_LAST_ANGLES, last_angle0);
+    sti(WI_LAST_ANGLES + 1, last_angle1);
+    L.ev_count[ch] = n_ev;
+#undef RRC2
+#undef EQB2
+}
+
+}   // namespace spg

@@ -21,8 +21,8 @@
 //
 // Numerics: fp32, every op rounded separately (-ffp-contract=off), float->int conversions
 // with the x86 out-of-range result the reference build has; the single libm dependency of
-// the reference path (cosf/sinf of the training phase spin, v29rx.c:618-623) is evaluated
-// in double and rounded, which equals the reference's result on the builds compared.
+// the reference path (cosf/sinf of the training phase spin, v29rx.c:618-623) is computed
+// with the C library's own algorithm (spg_sincosf below), so it has the same bits too.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -96,6 +96,67 @@ struct V29Launch
     int ev_cap;
     const V29Tables *tab;
 };
+
+// cosf()/sinf() of glibc >= 2.28 (sysdeps/ieee754/flt-32/sincosf.h: reduction by pi/2 and a polynomial, all in
+// double, one rounding to float), which is what the reference build's libm computes; checked on the host against
+// libm for every float in [0, 2*pi], the only range the receivers use.
+__device__ __noinline__ float spg_sincosf(float y, bool want_cos)
+{
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10,
+                 c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    double x = (double) y;
+    int n = want_cos  ?  1  :  0;
+    double sg = 1.0;
+    const uint32_t top = (__float_as_uint(y) >> 20) & 0x7FF;
+    if (top < 0x3F4)
+    {
+        if (top < 0x398)
+            return want_cos  ?  1.0f  :  y;
+    }
+    else
+    {
+        const double r = x*0x1.45F306DC9C883p+23;
+        const int q = ((int32_t) r + 0x800000) >> 24;
+        x = x - (double) q*0x1.921FB54442D18p0;
+        const double x_red = x;
+        if (((q & 3) == 1)  ||  ((q & 3) == 2))
+            x = -x;
+        if (q & 2)
+            sg = -1.0;
+        n = want_cos  ?  (q ^ 1)  :  q;
+        const double x2 = x_red*x_red;
+        if ((n & 1) == 0)
+        {
+            const double x3 = x*x2;
+            const double t1 = s2 + x2*s3;
+            const double x7 = x3*x2;
+            const double s = x + x3*s1;
+            return (float) (s + x7*t1);
+        }
+        const double x4 = x2*x2;
+        const double k2 = sg*c3 + x2*(sg*c4);
+        const double k1 = sg*c0 + x2*(sg*c1);
+        const double x6 = x4*x2;
+        const double c = k1 + x4*(sg*c2);
+        return (float) (c + x6*k2);
+    }
+    const double x2 = x*x;
+    if ((n & 1) == 0)
+    {
+        const double x3 = x*x2;
+        const double t1 = s2 + x2*s3;
+        const double x7 = x3*x2;
+        const double s = x + x3*s1;
+        return (float) (s + x7*t1);
+    }
+    const double x4 = x2*x2;
+    const double k2 = c3 + x2*c4;
+    const double k1 = c0 + x2*c1;
+    const double x6 = x4*x2;
+    const double c = k1 + x4*c2;
+    return (float) (c + x6*k2);
+}
 
 __device__ __forceinline__ int32_t v29_f2i(float v)
 {
@@ -637,8 +698,8 @@ void v29_bank_kernel(const V29Launch L)
                         }
                         // v29rx.c:618-624: spin the equaliser delay line and the carrier
                         const float p = ((uint32_t) angle)*2.0f*3.1415926f/(65536.0f*65536.0f);
-                        const float zc = (float) cos((double) p);
-                        const float zs = -(float) sin((double) p);
+                        const float zc = spg_sincosf(p, true);
+                        const float zs = -spg_sincosf(p, false);
                         for (int k = 0;  k < kEqLen;  k++)
                         {
                             const float xr = EQB2(2*k);

@@ -70,16 +70,17 @@ def lib():
             "spangpu_bank_set_timing": (ci, [vp, ci]),
             "spangpu_bank_bins": (ci, [vp]),
             "spangpu_bank_force_block": (ci, [vp]),
-            "spangpu_v29_create": (ci, [C.POINTER(vp), ci, ci, ci]),
-            "spangpu_v29_destroy": (ci, [vp]),
-            "spangpu_v29_channels": (ci, [vp]),
-            "spangpu_v29_set_stream": (ci, [vp, vp]),
-            "spangpu_v29_sync": (ci, [vp]),
-            "spangpu_v29_rx": (ci, [vp, vp, ci, ci, ll]),
-            "spangpu_v29_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
-            "spangpu_v29_get_state": (ci, [vp, ci, vp, vp]),
-            "spangpu_v29_restart": (ci, [vp, ci]),
-            "spangpu_modem_tables": (ci, [vp, vp, vp, vp, vp]),
+            "spangpu_modem_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
+            "spangpu_modem_destroy": (ci, [vp]),
+            "spangpu_modem_channels": (ci, [vp]),
+            "spangpu_modem_set_stream": (ci, [vp, vp]),
+            "spangpu_modem_sync": (ci, [vp]),
+            "spangpu_modem_rx": (ci, [vp, vp, ci, ci, ll]),
+            "spangpu_modem_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_modem_state_words": (ci, [ci, C.POINTER(ci), C.POINTER(ci)]),
+            "spangpu_modem_get_state": (ci, [vp, ci, vp]),
+            "spangpu_modem_restart": (ci, [vp, ci]),
+            "spangpu_modem_table": (ci, [ci, vp, ci]),
             "spangpu_echo_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
             "spangpu_echo_destroy": (ci, [vp]),
             "spangpu_echo_channels": (ci, [vp]),
@@ -279,26 +280,40 @@ class EchoBank:
         return d
 
 
+V29 = 6
+V27TER = 7
+V17 = 8
+
+_TABLES = {"sine": 0, "sqrt_tab": 1, "rrc_re": 10, "rrc_im": 11, "godard": 12, "v27_4800_re": 20, "v27_4800_im": 21,
+           "v27_2400_re": 22, "v27_2400_im": 23}
+
+
 def modem_tables():
     """The constant modem tables as built by libspangpu (host code, no GPU needed)."""
-    t = {"rrc_re": np.zeros(48*27, np.float32), "rrc_im": np.zeros(48*27, np.float32),
-         "sine": np.zeros(2048, np.float32), "sqrt_tab": np.zeros(193, np.uint16), "godard": np.zeros(7, np.float32)}
-    _check(lib().spangpu_modem_tables(t["rrc_re"].ctypes.data, t["rrc_im"].ctypes.data, t["sine"].ctypes.data,
-                                      t["sqrt_tab"].ctypes.data, t["godard"].ctypes.data))
+    t = {}
+    buf = np.zeros(192*27, np.float32)
+    for name, which in _TABLES.items():
+        n = _check(lib().spangpu_modem_table(which, buf.ctypes.data, len(buf)))
+        t[name] = buf[:n].astype(np.uint16) if name == "sqrt_tab" else buf[:n].copy()
     return t
 
 
-class V29Bank:
-    """N V.29 receivers, state resident in HBM."""
+class ModemBank:
+    """N modem receivers of one kind and bit rate, state resident in HBM."""
 
-    def __init__(self, n_channels, bit_rate=9600, device=0):
+    def __init__(self, kind, n_channels, bit_rate, device=0):
         self.n = n_channels
+        self.kind = kind
+        nf = C.c_int()
+        ni = C.c_int()
+        self.n_words = _check(lib().spangpu_modem_state_words(kind, C.byref(nf), C.byref(ni)))
+        self.n_floats, self.n_ints = nf.value, ni.value
         self.h = C.c_void_p()
-        _check(lib().spangpu_v29_create(C.byref(self.h), device, n_channels, bit_rate))
+        _check(lib().spangpu_modem_create(C.byref(self.h), device, kind, n_channels, bit_rate))
 
     def close(self):
         if self.h:
-            lib().spangpu_v29_destroy(self.h)
+            lib().spangpu_modem_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
@@ -308,34 +323,43 @@ class V29Bank:
             pass
 
     def set_stream(self, hip_stream):
-        _check(lib().spangpu_v29_set_stream(self.h, hip_stream))
+        _check(lib().spangpu_modem_set_stream(self.h, hip_stream))
 
     def sync(self):
-        _check(lib().spangpu_v29_sync(self.h))
+        _check(lib().spangpu_modem_sync(self.h))
 
     def rx_host(self, frames):
         frames = np.ascontiguousarray(frames, np.int16)
         assert frames.shape[0] == self.n
-        _check(lib().spangpu_v29_rx(self.h, frames.ctypes.data, MEM_HOST, frames.shape[1], frames.shape[1]))
+        _check(lib().spangpu_modem_rx(self.h, frames.ctypes.data, MEM_HOST, frames.shape[1], frames.shape[1]))
 
     def rx_device(self, ptr, samples, stride):
-        _check(lib().spangpu_v29_rx(self.h, ptr, MEM_DEVICE, samples, stride))
+        _check(lib().spangpu_modem_rx(self.h, ptr, MEM_DEVICE, samples, stride))
 
     def events(self):
         """List (per channel) of int8 arrays: 0/1 bits and negative SIG_STATUS codes, in order."""
         ev = C.c_void_p()
         cnt = C.c_void_p()
-        cap = _check(lib().spangpu_v29_events(self.h, C.byref(ev), C.byref(cnt)))
+        cap = _check(lib().spangpu_modem_events(self.h, C.byref(ev), C.byref(cnt)))
         counts = np.frombuffer((C.c_char*(4*self.n)).from_address(cnt.value), dtype=np.int32).copy()
         raw = np.frombuffer((C.c_char*(cap*self.n)).from_address(ev.value), dtype=np.int8).reshape(self.n, cap)
         assert counts.max(initial=0) <= cap, "event buffer overflow"
         return [raw[c, :counts[c]].copy() for c in range(self.n)]
 
     def get_state(self, channel):
-        f = np.zeros(238, np.float32)
-        w = np.zeros(43, np.int32)
-        _check(lib().spangpu_v29_get_state(self.h, channel, f.ctypes.data, w.ctypes.data))
-        return f, w
+        w = np.zeros(self.n_words, np.uint32)
+        _check(lib().spangpu_modem_get_state(self.h, channel, w.ctypes.data))
+        return w[:self.n_floats].view(np.float32).copy(), w[self.n_floats:].view(np.int32).copy()
 
     def restart(self, channel):
-        _check(lib().spangpu_v29_restart(self.h, channel))
+        _check(lib().spangpu_modem_restart(self.h, channel))
+
+
+class V29Bank(ModemBank):
+    def __init__(self, n_channels, bit_rate=9600, device=0):
+        super().__init__(V29, n_channels, bit_rate, device)
+
+
+class V27terBank(ModemBank):
+    def __init__(self, n_channels, bit_rate=4800, device=0):
+        super().__init__(V27TER, n_channels, bit_rate, device)

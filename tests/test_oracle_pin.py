@@ -321,6 +321,56 @@ def test_v29_live(built, bit_rate, seed, noise, chunks):
     assert np.array_equal(f_r, f_o)
 
 
+def test_trig_restatement(built):
+    """The cosf/sinf restatement (oracle/modem_common.h) against this machine's libm, on a sample of [0, 2*pi]
+    (the exhaustive 1.09e9-value comparison is recorded in the header of modem_common.h)."""
+    import ctypes
+    from oracle import restated as orc
+    L = orc.lib()
+    m = ctypes.CDLL("libm.so.6")
+    for f in (L.orc_trig_cosf, L.orc_trig_sinf, m.cosf, m.sinf):
+        f.restype = ctypes.c_float
+        f.argtypes = [ctypes.c_float]
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(0.0, 2.0*np.pi, 20000), np.linspace(0.0, 2.0*np.pi, 4097),
+                         (np.arange(1 << 12)*(2.0*np.pi/65536.0/65536.0)*(1 << 20))]).astype(np.float32)
+    for x in xs:
+        x = float(x)
+        assert bits([L.orc_trig_cosf(x)])[0] == bits([m.cosf(x)])[0], x
+        assert bits([L.orc_trig_sinf(x)])[0] == bits([m.sinf(x)])[0], x
+
+
+# ---------------------------------------------------------------------------------
+# V.27ter receiver
+# ---------------------------------------------------------------------------------
+V27_CASES = [(4800, 31, -50.0), (2400, 32, -50.0)]
+
+
+def v27ter_scenario(bit_rate, seed, noise_dbm0, n_signal=9200, lead=230, tail=900):
+    """As v29_scenario, from the reference's V.27ter modulator (training is 1074 + 58 symbols long)."""
+    from oracle import ref
+    sig = ref.v27ter_tx(bit_rate, n_signal, seed=seed)
+    x = np.concatenate([np.zeros(lead, np.int16), sig, np.zeros(tail, np.int16)])
+    return ref.saturated_add(x, ref.awgn(seed*7919, noise_dbm0, len(x)))
+
+
+@needs_ref
+@pytest.mark.parametrize("bit_rate,seed,noise", V27_CASES + [(4800, 41, -40.0), (2400, 42, -60.0), (4800, 43, -55.0)])
+@pytest.mark.parametrize("chunks", [(160,), (1, 7, 333, 64)])
+def test_v27ter_live(built, bit_rate, seed, noise, chunks):
+    from oracle import ref, restated as orc
+    use_golden_modem_tables()
+    x = v27ter_scenario(bit_rate, seed, noise)
+    ev_r, f_r, w_r = v29_run(ref.V27terRx(bit_rate), x, chunks)
+    ev_o, f_o, w_o = v29_run(orc.V27ter(bit_rate), x, chunks)
+    assert -2 in ev_r and -1 in ev_r
+    if noise < -45.0:
+        assert -4 in ev_r and len(ev_r) > 300        # trained and carried data
+    assert np.array_equal(ev_r, ev_o)
+    assert np.array_equal(w_r, w_o)
+    assert np.array_equal(f_r, f_o)
+
+
 # ---------------------------------------------------------------------------------
 # frozen pins: golden vectors generated from the reference build
 # ---------------------------------------------------------------------------------
@@ -409,6 +459,17 @@ def test_golden_v29(built, bit_rate):
     use_golden_modem_tables()
     g = np.load(os.path.join(GOLDEN, "v29_%d.npz" % bit_rate))
     ev, f, w = v29_run(orc.V29(bit_rate), g["amp"], (160,))
+    assert np.array_equal(ev, g["events"].astype(np.int32))
+    assert np.array_equal(f, g["fwords"])
+    assert np.array_equal(w, g["iwords"])
+
+
+@pytest.mark.parametrize("bit_rate", [4800, 2400])
+def test_golden_v27ter(built, bit_rate):
+    from oracle import restated as orc
+    use_golden_modem_tables()
+    g = np.load(os.path.join(GOLDEN, "v27ter_%d.npz" % bit_rate))
+    ev, f, w = v29_run(orc.V27ter(bit_rate), g["amp"], (160,))
     assert np.array_equal(ev, g["events"].astype(np.int32))
     assert np.array_equal(f, g["fwords"])
     assert np.array_equal(w, g["iwords"])
