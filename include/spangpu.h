@@ -233,6 +233,7 @@ SPANGPU_API int spangpu_modem_get_state(spangpu_modem_t *modem, int channel, uin
 SPANGPU_API int spangpu_modem_restart(spangpu_modem_t *modem, int channel);
 /* The constant tables the modem receivers use, as built by this library (host code; see modem_api.hip for `which`). */
 SPANGPU_API int spangpu_modem_table(int which, float *out, int max);
+SPANGPU_API int spangpu_v17_rx_maps(uint8_t *maps, uint8_t *map_4800);
 
 #if defined(__cplusplus)
 }

@@ -286,6 +286,9 @@ typedef struct
     float v17_godard_fine_trigger;
     int v17_godard_coarse_step;
     int v17_godard_fine_step;
+    const float *v17_constellation;     /* [128 + 64 + 32 + 16 + 4][2]: 14400, 12000, 9600, 7200, 4800 bps */
+    const uint8_t *v17_maps;            /* [4][36][36][8] */
+    const uint8_t *v17_map_4800;        /* [36][36] */
 } orc_modem_tables_t;
 
 ORC_API void orc_modem_set_tables(const orc_modem_tables_t *t);
@@ -387,6 +390,65 @@ typedef struct
     int32_t last_angles[2];
     int32_t diff_angles[16];
 } orc_v27ter_t;
+
+typedef struct
+{
+    /* floats first, then ints */
+    float agc_scaling;
+    float agc_scaling_save;
+    float eq_delta;
+    float training_error;
+    float carrier_track_p;
+    float carrier_track_i;
+    float g_low[2];
+    float g_high[2];
+    float g_dc[2];
+    float g_baud_phase;
+    float rrc_filter[27];
+    float eq_coeff[33][2];
+    float eq_coeff_save[33][2];
+    float eq_buf[33][2];
+    float distances[8];
+    int32_t bit_rate;
+    int32_t rrc_filter_step;
+    int32_t diff;
+    uint32_t scramble_reg;
+    int32_t scrambler_tap;
+    int32_t short_train;
+    int32_t training_stage;
+    int32_t training_count;
+    int32_t last_sample;
+    int32_t signal_present;
+    int32_t carrier_drop_pending;
+    int32_t low_samples;
+    int32_t high_sample;
+    uint32_t carrier_phase;
+    int32_t carrier_phase_rate;
+    int32_t carrier_phase_rate_save;
+    int32_t power_reading;
+    int32_t carrier_on_power;
+    int32_t carrier_off_power;
+    int32_t eq_step;
+    int32_t eq_put_step;
+    int32_t eq_skip;
+    int32_t baud_half;
+    int32_t last_angles[2];
+    int32_t diff_angles[16];
+    int32_t space_map;
+    int32_t bits_per_symbol;
+    int32_t trellis_ptr;
+    int32_t g_total_correction;
+    int32_t full_path_to_past_state_locations[16][8];
+    int32_t past_state_locations[16][8];
+} orc_v17_t;
+
+#define ORC_V17_FLOATS      246
+#define ORC_V17_INTS        301
+
+ORC_API int orc_v17_sizeof(void);
+ORC_API int orc_v17_init(orc_v17_t *s, int bit_rate);
+ORC_API int orc_v17_restart(orc_v17_t *s, int bit_rate, int short_train);
+ORC_API int orc_v17_rx(orc_v17_t *s, const int16_t amp[], int len, orc_sink_t *sink);
 
 #define ORC_V27TER_FLOATS   225
 #define ORC_V27TER_INTS     45

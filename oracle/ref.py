@@ -55,6 +55,13 @@ def lib():
             "glue_modem_tables": (None, [vp, vp, vp, vp, vp, vp]),
             "glue_v29_rx_snapshot": (None, [vp, vp, vp]),
             "glue_v27ter_rx_snapshot": (None, [vp, vp, vp]),
+            "glue_v17_rx_snapshot": (None, [vp, vp, vp]),
+            "glue_v17_tables": (None, [vp, vp, vp, vp]),
+            "glue_v17_constellations": (None, [vp]),
+            "glue_v17_constel_maps": (None, [vp, vp]),
+            "v17_rx": (ci, [vp, vp, ci]), "v17_rx_free": (ci, [vp]), "v17_rx_restart": (ci, [vp, ci, ci]),
+            "v17_tx": (ci, [vp, vp, ci]), "v17_tx_free": (ci, [vp]), "v17_tx_power": (None, [vp, cf]),
+            "v17_tx_restart": (ci, [vp, ci, ci, ci]),
             "glue_v27ter_tables": (None, [vp, vp, vp, vp]),
             # reference public API (src/spandsp/*.h)
             "dtmf_rx": (ci, [vp, vp, ci]), "dtmf_rx_get": (C.c_size_t, [vp, C.c_char_p, ci]),
@@ -443,7 +450,23 @@ def modem_tables():
         t[k] = np.zeros(n*27, np.float32)
     lib().glue_v27ter_tables(t["v27_4800_re"].ctypes.data, t["v27_4800_im"].ctypes.data,
                              t["v27_2400_re"].ctypes.data, t["v27_2400_im"].ctypes.data)
+    t["v17_re"] = np.zeros(192*27, np.float32)
+    t["v17_im"] = np.zeros(192*27, np.float32)
+    t["v17_godard"] = np.zeros(9, np.float32)
+    t["v17_steps"] = np.zeros(2, np.int32)
+    lib().glue_v17_tables(t["v17_re"].ctypes.data, t["v17_im"].ctypes.data, t["v17_godard"].ctypes.data,
+                          t["v17_steps"].ctypes.data)
     return t
+
+
+def v17_signal_space():
+    """The reference's V.17 constellations (244 points, 14400/12000/9600/7200/4800) and receiver soft-decision maps."""
+    c = np.zeros(244*2, np.float32)
+    maps = np.zeros(4*36*36*8, np.uint8)
+    m48 = np.zeros(36*36, np.uint8)
+    lib().glue_v17_constellations(c.ctypes.data)
+    lib().glue_v17_constel_maps(maps.ctypes.data, m48.ctypes.data)
+    return {"v17_constellation": c, "v17_maps": maps, "v17_map_4800": m48}
 
 
 class V29Rx:
@@ -488,6 +511,46 @@ class V27terRx:
         w = np.zeros(45, np.int32)
         lib().glue_v27ter_rx_snapshot(self.p, f.ctypes.data, w.ctypes.data)
         return f, w
+
+
+class V17Rx:
+    def __init__(self, bit_rate=14400):
+        self.sink = Sink()
+        self.p = lib().glue_v17_rx_new(bit_rate, self.sink.p)
+
+    def __del__(self):
+        try:
+            lib().v17_rx_free(self.p)
+        except Exception:
+            pass
+
+    def restart(self, bit_rate, short_train):
+        return lib().v17_rx_restart(self.p, bit_rate, int(short_train))
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().v17_rx(self.p, amp.ctypes.data, len(amp))
+
+    def snapshot(self):
+        f = np.zeros(246, np.float32)
+        w = np.zeros(301, np.int32)
+        lib().glue_v17_rx_snapshot(self.p, f.ctypes.data, w.ctypes.data)
+        return f, w
+
+
+def v17_tx(bit_rate, n_samples, seed=1, tep=False, short_train=False, level_dbm0=None):
+    """v17_tx() of the reference carrying a PRBS; returns int16 samples."""
+    L = lib()
+    st = C.c_uint32(seed & 0x7FFF or 1)
+    tx = L.glue_v17_tx_new(bit_rate, int(tep), C.addressof(st))
+    if short_train:
+        L.v17_tx_restart(tx, bit_rate, int(tep), 1)
+    if level_dbm0 is not None:
+        L.v17_tx_power(tx, level_dbm0)
+    buf = np.zeros(n_samples, np.int16)
+    n = L.v17_tx(tx, buf.ctypes.data, n_samples)
+    L.v17_tx_free(tx)
+    return buf[:n]
 
 
 def v27ter_tx(bit_rate, n_samples, seed=1, tep=False, level_dbm0=None):

@@ -60,6 +60,10 @@ def lib():
             "orc_v29_init": (ci, [vp, ci]),
             "orc_v29_restart": (ci, [vp, ci, ci]),
             "orc_v29_rx": (ci, [vp, vp, ci, vp]),
+            "orc_v17_sizeof": (ci, []),
+            "orc_v17_init": (ci, [vp, ci]),
+            "orc_v17_restart": (ci, [vp, ci, ci]),
+            "orc_v17_rx": (ci, [vp, vp, ci, vp]),
             "orc_v27ter_sizeof": (ci, []),
             "orc_v27ter_init": (ci, [vp, ci]),
             "orc_v27ter_restart": (ci, [vp, ci, ci]),
@@ -299,7 +303,8 @@ class _ModemTables(C.Structure):
                 ("v27_2400_re", C.c_void_p), ("v27_2400_im", C.c_void_p),
                 ("v17_re", C.c_void_p), ("v17_im", C.c_void_p),
                 ("v17_godard", C.c_float*7), ("v17_coarse_trigger", C.c_float), ("v17_fine_trigger", C.c_float),
-                ("v17_coarse_step", C.c_int), ("v17_fine_step", C.c_int)]
+                ("v17_coarse_step", C.c_int), ("v17_fine_step", C.c_int),
+                ("v17_constellation", C.c_void_p), ("v17_maps", C.c_void_p), ("v17_map_4800", C.c_void_p)]
 
 
 _tables_keepalive = None
@@ -320,7 +325,8 @@ def set_modem_tables(t):
     m.fine_trigger = float(t["godard"][8])
     m.coarse_step = int(t["steps"][0])
     m.fine_step = int(t["steps"][1])
-    for k in ("v27_4800_re", "v27_4800_im", "v27_2400_re", "v27_2400_im", "v17_re", "v17_im"):
+    for k in ("v27_4800_re", "v27_4800_im", "v27_2400_re", "v27_2400_im", "v17_re", "v17_im", "v17_constellation",
+              "v17_maps", "v17_map_4800"):
         if k in t:
             keep[k] = np.ascontiguousarray(t[k])
             setattr(m, k, keep[k].ctypes.data)
@@ -368,6 +374,29 @@ class V27ter:
     def rx(self, amp):
         amp = _i16(amp)
         return lib().orc_v27ter_rx(self.p, amp.ctypes.data, len(amp), self.sink.p)
+
+    def snapshot(self):
+        f = self.buf[:4*self.N_FLOATS].view(np.float32).copy()
+        w = self.buf[4*self.N_FLOATS:4*(self.N_FLOATS + self.N_INTS)].view(np.int32).copy()
+        return f, w
+
+
+class V17:
+    N_FLOATS = 246
+    N_INTS = 301
+
+    def __init__(self, bit_rate=14400):
+        self.buf = np.zeros(lib().orc_v17_sizeof() + 16, np.uint8)
+        self.p = self.buf.ctypes.data
+        self.sink = Sink()
+        assert lib().orc_v17_init(self.p, bit_rate) == 0
+
+    def restart(self, bit_rate, short_train):
+        return lib().orc_v17_restart(self.p, bit_rate, int(short_train))
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().orc_v17_rx(self.p, amp.ctypes.data, len(amp), self.sink.p)
 
     def snapshot(self):
         f = self.buf[:4*self.N_FLOATS].view(np.float32).copy()

@@ -455,7 +455,8 @@ int spangpu_modem_restart(spangpu_modem_t *m, int channel)
 
 // The constant tables this library builds (for tests).  which: 0 sine [2048], 1 sqrt (as float) [193],
 // 10/11 V.29 rx pulse shaper re/im [48*27], 12 V.29 Godard [7], 20/21 V.27ter 4800 re/im [8*27],
-// 22/23 V.27ter 2400 re/im [12*27].  Returns the number of values written.
+// 22/23 V.27ter 2400 re/im [12*27], 30/31 V.17 re/im [192*27], 32 V.17 Godard [7], 33 V.17 constellations [244*2].
+// Returns the number of values written.
 int spangpu_modem_table(int which, float *out, int max)
 {
     static float re[192*27];
@@ -496,6 +497,32 @@ int spangpu_modem_table(int which, float *out, int max)
         spg_make_rx_pulseshaper(12, 27, 1800.0, 1200.0, 0.5, re, im);
         src = (which & 1)  ?  im  :  re;
         break;
+    case 30: case 31:
+        n = 192*27;
+        spg_make_rx_pulseshaper(192, 27, 1800.0, 2400.0, 0.5, re, im);
+        src = (which & 1)  ?  im  :  re;
+        break;
+    case 32:
+        n = 7;
+        spg_make_godard(1800.0, 2400.0, 0.99, re);
+        break;
+    case 33:
+    {
+        // the five V.17 / V.32bis constellations back to back: 14400, 12000, 9600, 7200, 4800 bps, {re, im} each
+        static const int rates[5] = {14400, 12000, 9600, 7200, 4800};
+        int8_t pts[128][2];
+        n = 0;
+        for (int r = 0;  r < 5;  r++)
+        {
+            const int m = spg_make_v17_constellation(rates[r], pts);
+            for (int i = 0;  i < m;  i++)
+            {
+                re[n++] = pts[i][0];
+                re[n++] = pts[i][1];
+            }
+        }
+        break;
+    }
     default:
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "unknown table");
     }
@@ -503,6 +530,15 @@ int spangpu_modem_table(int which, float *out, int max)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "buffer too small");
     memcpy(out, src, n*sizeof(float));
     return n;
+}
+
+// The V.17 receiver's soft-decision maps as built by this library: maps [4*36*36*8], map_4800 [36*36].
+int spangpu_v17_rx_maps(uint8_t *maps, uint8_t *map_4800)
+{
+    if (maps == nullptr  ||  map_4800 == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null output");
+    spg_make_v17_rx_maps(maps, map_4800);
+    return SPANGPU_OK;
 }
 
 }   // extern "C"

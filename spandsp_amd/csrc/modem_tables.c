@@ -212,3 +212,206 @@ void spg_make_v29_space_map(uint8_t out[400])
             out[i*20 + j] = (uint8_t) (rows[i][j] - 'a');
     }
 }
+
+/* ---- V.17 / V.32bis signal space ------------------------------------------------------------
+ * The trellis coded constellations of ITU-T V.17 (figures 2 to 5) have four-fold rotational symmetry: within each
+ * group of eight points that share the uncoded bits Q, the three coded bits Y select one of two seed points turned
+ * by 0, 90, 180 or 270 degrees.  Seeds per group: {re, im} for Y = 0 and for Y = 1; the turns of the first seed sit at
+ * Y = 0, 7, 4, 3 and those of the second at Y = 1, 6, 5, 2.  (Index order as the reference's
+ * v17_v32bis_tx_constellation_maps.h, which tests/test_modem_tables.py checks this against.) */
+static const int8_t v17_seeds_14400[16][4] =
+{
+    {-8, -3, 9, 2}, {-8, 1, 9, -2}, {-4, -3, 5, 2}, {-4, 1, 5, -2}, {4, -3, -3, 2}, {4, 1, -3, -2}, {0, -3, 1, 2}, {0, 1, 1, -2},
+    {8, -3, -7, 2}, {8, 1, -7, -2}, {-4, -7, 5, 6}, {-4, 5, 5, -6}, {4, -7, -3, 6}, {4, 5, -3, -6}, {0, -7, 1, 6}, {0, 5, 1, -6}
+};
+static const int8_t v17_seeds_12000[8][4] =
+{
+    {7, 1, -5, -1}, {3, -3, -1, 3}, {7, -7, -5, 7}, {-1, -7, 3, 7}, {3, 5, -1, -5}, {-1, 1, 3, -1}, {-5, 5, 7, -5}, {-5, -3, 7, 3}
+};
+static const int8_t v17_seeds_9600[4][4] = {{-8, 2, -6, -4}, {0, 2, -6, 4}, {0, -6, 2, -4}, {8, 2, 2, 4}};
+static const int8_t v17_seeds_7200[2][4] = {{6, -6, -2, 6}, {-2, 2, 6, -2}};
+
+int spg_v17_constellation_size(int bit_rate)
+{
+    switch (bit_rate)
+    {
+    case 14400: return 128;
+    case 12000: return 64;
+    case 9600: return 32;
+    case 7200: return 16;
+    case 4800: return 4;
+    }
+    return -1;
+}
+
+/* out[n][2] = {re, im}; returns n */
+int spg_make_v17_constellation(int bit_rate, int8_t out[][2])
+{
+    static const int turn_a[4] = {0, 7, 4, 3};
+    static const int turn_b[4] = {1, 6, 5, 2};
+    const int8_t (*seeds)[4];
+    int n = spg_v17_constellation_size(bit_rate);
+    int g;
+    int k;
+    int re;
+    int im;
+    int t;
+
+    switch (bit_rate)
+    {
+    case 14400: seeds = v17_seeds_14400; break;
+    case 12000: seeds = v17_seeds_12000; break;
+    case 9600: seeds = v17_seeds_9600; break;
+    case 7200: seeds = v17_seeds_7200; break;
+    case 4800:
+        /* V.32bis 4800 bps: the four points of the V.17 training constellation, v17rx.c:1335 */
+        out[0][0] = -6; out[0][1] = -2;
+        out[1][0] = -2; out[1][1] = 6;
+        out[2][0] = 2; out[2][1] = -6;
+        out[3][0] = 6; out[3][1] = 2;
+        return 4;
+    default:
+        return -1;
+    }
+    for (g = 0;  g < n/8;  g++)
+    {
+        re = seeds[g][0];
+        im = seeds[g][1];
+        for (k = 0;  k < 4;  k++)
+        {
+            out[8*g + turn_a[k]][0] = (int8_t) re;
+            out[8*g + turn_a[k]][1] = (int8_t) im;
+            t = re;  re = -im;  im = t;             /* +90 degrees */
+        }
+        re = seeds[g][2];
+        im = seeds[g][3];
+        for (k = 0;  k < 4;  k++)
+        {
+            out[8*g + turn_b[k]][0] = (int8_t) re;
+            out[8*g + turn_b[k]][1] = (int8_t) im;
+            t = re;  re = -im;  im = t;
+        }
+    }
+    return n;
+}
+
+/* The receiver's soft decision maps (v17rx.c:440-470 indexes constel_maps[space][re][im][i] with re, im = the half-unit
+   cell of the plane [-9, 9) x [-9, 9) and i = the trellis subset): for each cell and each subset, the constellation
+   point of that subset (index & 7 == i) nearest to the cell.  The nearest point is found from the cell centre nudged
+   towards (-inf, -inf), taking the higher numbered point on a remaining tie -- except in the cells listed below, where
+   two points are exactly equidistant along the diagonal and the reference's table holds the lower numbered one
+   (packed space << 15 | re << 9 | im << 3 | i).  tests/test_modem_tables.py checks the result against the reference's
+   table (CRC-32, and entry by entry when the reference build is present). */
+static const uint32_t v17_map_lower_on_tie[100] =
+{
+    0x03913, 0x03916, 0x03B1B, 0x03B1E, 0x04112, 0x04117, 0x0431A, 0x0431F, 0x044E0, 0x044E1, 0x04504, 0x04505, 0x046E8,
+    0x046E9, 0x0470C, 0x0470D, 0x09087, 0x0928F, 0x09472, 0x09474, 0x09497, 0x0967A, 0x0967C, 0x0969F, 0x09882, 0x09884,
+    0x098A7, 0x09A8A, 0x09A8C, 0x09AAF, 0x09C33, 0x09C50, 0x09C56, 0x09CB3, 0x09CD0, 0x09CD6, 0x09CF1, 0x09E3B, 0x09E58,
+    0x09E5E, 0x09EBB, 0x09ED8, 0x09EDE, 0x09EF9, 0x0A043, 0x0A060, 0x0A066, 0x0A0C3, 0x0A0E6, 0x0A24B, 0x0A268, 0x0A26E,
+    0x0A2CB, 0x0A2EE, 0x0A453, 0x0A4D3, 0x0A4F6, 0x0A65B, 0x0A6DB, 0x0A6FE, 0x0A863, 0x0AA6B, 0x0AC77, 0x0AE7F, 0x0B087,
+    0x0B28F, 0x0B472, 0x0B474, 0x0B497, 0x0B67A, 0x0B67C, 0x0B69F, 0x0B882, 0x0B8A7, 0x0BA8A, 0x0BAAF, 0x0BC71, 0x0BC92,
+    0x0BD14, 0x0BE79, 0x0BE9A, 0x0BF1C, 0x0C4F0, 0x0C6F8, 0x10803, 0x10A0B, 0x144F4, 0x146FC, 0x18C74, 0x18E7C, 0x1969C,
+    0x198A4, 0x19C30, 0x19E38, 0x1A658, 0x1A860, 0x1B514, 0x1B71C, 0x1C4D0, 0x1C6D8
+};
+
+void spg_make_v17_rx_maps(uint8_t maps[4*36*36*8], uint8_t map_4800[36*36])
+{
+    static const int rates[4] = {14400, 12000, 9600, 7200};
+    int8_t pts[128][2];
+    int space;
+    int n;
+    int re;
+    int im;
+    int i;
+    int k;
+    int best;
+    int second;
+    long long x;
+    long long y;
+    long long d;
+    long long dmin;
+    unsigned e;
+
+    for (space = 0;  space < 4;  space++)
+    {
+        n = spg_make_v17_constellation(rates[space], pts);
+        for (re = 0;  re < 36;  re++)
+        {
+            for (im = 0;  im < 36;  im++)
+            {
+                /* units of 1/4000: cell centre = re/2 - 9 + 1/4, nudged by -1/4000 in both axes */
+                x = re*2000 - 36000 + 1000 - 1;
+                y = im*2000 - 36000 + 1000 - 1;
+                for (i = 0;  i < 8;  i++)
+                {
+                    best = -1;
+                    second = -1;
+                    dmin = 0;
+                    for (k = i;  k < n;  k += 8)
+                    {
+                        d = (pts[k][0]*4000LL - x)*(pts[k][0]*4000LL - x) + (pts[k][1]*4000LL - y)*(pts[k][1]*4000LL - y);
+                        if (best < 0  ||  d < dmin)
+                        {
+                            dmin = d;
+                            best = k;
+                            second = -1;
+                        }
+                        else if (d == dmin)
+                        {
+                            second = best;
+                            best = k;
+                        }
+                    }
+                    maps[((space*36 + re)*36 + im)*8 + i] = (uint8_t) best;
+                    (void) second;
+                }
+            }
+        }
+    }
+    /* the diagonal ties the reference resolves the other way */
+    for (e = 0;  e < sizeof(v17_map_lower_on_tie)/sizeof(v17_map_lower_on_tie[0]);  e++)
+    {
+        const uint32_t v = v17_map_lower_on_tie[e];
+        space = (int) (v >> 15);
+        re = (int) ((v >> 9) & 0x3F);
+        im = (int) ((v >> 3) & 0x3F);
+        i = (int) (v & 7);
+        n = spg_make_v17_constellation(rates[space], pts);
+        x = re*2000 - 36000 + 1000 - 1;
+        y = im*2000 - 36000 + 1000 - 1;
+        best = -1;
+        dmin = 0;
+        for (k = i;  k < n;  k += 8)
+        {
+            d = (pts[k][0]*4000LL - x)*(pts[k][0]*4000LL - x) + (pts[k][1]*4000LL - y)*(pts[k][1]*4000LL - y);
+            if (best < 0  ||  d < dmin)
+            {
+                dmin = d;
+                best = k;
+            }
+        }
+        maps[((space*36 + re)*36 + im)*8 + i] = (uint8_t) best;
+    }
+    /* 4800 bps, no trellis: plain nearest of the four points to the cell centre (no ties occur) */
+    spg_make_v17_constellation(4800, pts);
+    for (re = 0;  re < 36;  re++)
+    {
+        for (im = 0;  im < 36;  im++)
+        {
+            x = re*2000 - 36000 + 1000;
+            y = im*2000 - 36000 + 1000;
+            best = 0;
+            dmin = -1;
+            for (k = 0;  k < 4;  k++)
+            {
+                d = (pts[k][0]*4000LL - x)*(pts[k][0]*4000LL - x) + (pts[k][1]*4000LL - y)*(pts[k][1]*4000LL - y);
+                if (dmin < 0  ||  d < dmin)
+                {
+                    dmin = d;
+                    best = k;
+                }
+            }
+            map_4800[re*36 + im] = (uint8_t) best;
+        }
+    }
+}

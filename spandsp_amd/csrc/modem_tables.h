@@ -19,6 +19,9 @@ int spg_make_rx_pulseshaper(int coeff_sets, int coeffs_per_filter, double carrie
 
 void spg_make_godard(double carrier, double baud_rate, double alpha, float out[7]);
 void spg_make_v29_space_map(uint8_t out[400]);
+int spg_v17_constellation_size(int bit_rate);
+int spg_make_v17_constellation(int bit_rate, int8_t out[][2]);
+void spg_make_v17_rx_maps(uint8_t maps[4*36*36*8], uint8_t map_4800[36*36]);
 
 #if defined(__cplusplus)
 }

@@ -81,6 +81,7 @@ def lib():
             "spangpu_modem_get_state": (ci, [vp, ci, vp]),
             "spangpu_modem_restart": (ci, [vp, ci]),
             "spangpu_modem_table": (ci, [ci, vp, ci]),
+            "spangpu_v17_rx_maps": (ci, [vp, vp]),
             "spangpu_echo_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
             "spangpu_echo_destroy": (ci, [vp]),
             "spangpu_echo_channels": (ci, [vp]),
@@ -285,7 +286,7 @@ V27TER = 7
 V17 = 8
 
 _TABLES = {"sine": 0, "sqrt_tab": 1, "rrc_re": 10, "rrc_im": 11, "godard": 12, "v27_4800_re": 20, "v27_4800_im": 21,
-           "v27_2400_re": 22, "v27_2400_im": 23}
+           "v27_2400_re": 22, "v27_2400_im": 23, "v17_re": 30, "v17_im": 31, "v17_godard": 32, "v17_constellation": 33}
 
 
 def modem_tables():
@@ -296,6 +297,16 @@ def modem_tables():
         n = _check(lib().spangpu_modem_table(which, buf.ctypes.data, len(buf)))
         t[name] = buf[:n].astype(np.uint16) if name == "sqrt_tab" else buf[:n].copy()
     return t
+
+
+def v17_signal_space():
+    """V.17 constellations (244 x {re, im}) and receiver soft-decision maps as built by libspangpu (host code)."""
+    buf = np.zeros(488, np.float32)
+    _check(lib().spangpu_modem_table(33, buf.ctypes.data, len(buf)))
+    maps = np.zeros(4*36*36*8, np.uint8)
+    m48 = np.zeros(36*36, np.uint8)
+    _check(lib().spangpu_v17_rx_maps(maps.ctypes.data, m48.ctypes.data))
+    return {"v17_constellation": buf, "v17_maps": maps, "v17_map_4800": m48}
 
 
 class ModemBank:

@@ -19,8 +19,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
 from oracle import ref  # noqa: E402
-from test_oracle_pin import (ALL_FREQS, ECHO_CASES, V27_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
-                             v27ter_scenario, v29_run, v29_scenario)
+from test_oracle_pin import (ALL_FREQS, ECHO_CASES, V17_CASES, V27_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
+                             v17_scenario, v27ter_scenario, v29_run, v29_scenario)
 
 
 def save(name, **kw):
@@ -104,6 +104,11 @@ def main():
         ev, f, w = v29_run(ref.V27terRx(bit_rate), x, (160,))
         assert len(ev) > 400 and -4 in ev and -1 in ev
         save("v27ter_%d" % bit_rate, amp=x, events=ev.astype(np.int8), fwords=f, iwords=w)
+    for bit_rate, seed, noise in V17_CASES:
+        x = v17_scenario(bit_rate, seed, noise)
+        ev, f, w = v29_run(ref.V17Rx(bit_rate), x, (160,))
+        assert np.count_nonzero(ev == -4) == 2 and -1 in ev
+        save("v17_%d" % bit_rate, amp=x, events=ev.astype(np.int8), fwords=f, iwords=w)
 
 
 if __name__ == "__main__":
