@@ -417,8 +417,9 @@ def test_v17_live(built, bit_rate, seed, noise, chunks):
     x = v17_scenario(bit_rate, seed, noise)
     ev_r, f_r, w_r = v29_run(ref.V17Rx(bit_rate), x, chunks)
     ev_o, f_o, w_o = v29_run(orc.V17(bit_rate), x, chunks)
-    assert -2 in ev_r and -1 in ev_r
+    assert -2 in ev_r
     if noise < -45.0:
+        assert -1 in ev_r
         assert np.count_nonzero(ev_r == -4) == 2 and len(ev_r) > 1200        # both bursts trained and carried data
     assert np.array_equal(ev_r, ev_o)
     assert np.array_equal(w_r, w_o)
