@@ -207,12 +207,14 @@ SPANGPU_API int spangpu_echo_set_state(spangpu_echo_t *ec, int channel, const in
                                        const int16_t *taps16, const int16_t *history);
 
 /* ---- Modem receiver banks --------------------------------------------------------------
- * N independent V.29 (9600 / 7200 / 4800 bps) or V.27ter (4800 / 2400 bps) receivers, state
- * resident in HBM.  Replaces, per channel:
+ * N independent V.29 (9600 / 7200 / 4800 bps), V.27ter (4800 / 2400 bps) or V.17 (14400 / 12000 /
+ * 9600 / 7200 bps, plus V.32bis 4800) receivers, state resident in HBM.  Replaces, per channel:
  *   spangpu_modem_create()   v29_rx_init(NULL, bit_rate, put_bit, user)      src/v29rx.c:1100-1131, src/spandsp/v29rx.h:151
  *                            v27ter_rx_init(NULL, bit_rate, put_bit, user)   src/v27ter_rx.c:1162-1190, src/spandsp/v27ter_rx.h:84
+ *                            v17_rx_init(NULL, bit_rate, put_bit, user)      src/v17rx.c:1502-1535, src/spandsp/v17rx.h:241
  *   spangpu_modem_rx()       v29_rx(s, amp, len)                             src/v29rx.c:867-965,  src/spandsp/v29rx.h:187
  *                            v27ter_rx(s, amp, len)                          src/v27ter_rx.c:863-1028, src/spandsp/v27ter_rx.h:120
+ *                            v17_rx(s, amp, len)                             src/v17rx.c:1212-1318, src/spandsp/v17rx.h:279
  *   spangpu_modem_restart()  v29_rx_restart / v27ter_rx_restart(s, rate, false)   src/v29rx.c:1019, src/v27ter_rx.c:1091
  *   spangpu_modem_events()   the put_bit / status callback stream            src/v29rx.c:171-178,380-397
  * The demodulated bit stream and the SIG_STATUS_* events (spandsp/async.h:66-103) are delivered

@@ -1,5 +1,5 @@
 // modem_api.hip -- C ABI of the batched modem receivers (include/spangpu.h, "Modem receiver banks").
-// Device code: v29_dev.hpp, v27ter_dev.hpp; constant tables: modem_tables.c.  No CPU implementation
+// Device code: v29_dev.hpp, v27ter_dev.hpp, v17_dev.hpp; constant tables: modem_tables.c.  No CPU implementation
 // exists behind these entry points.
 
 #include <hip/hip_runtime.h>
@@ -12,6 +12,7 @@
 #include "modem_tables.h"
 #include "v29_dev.hpp"
 #include "v27ter_dev.hpp"
+#include "v17_dev.hpp"
 
 using namespace spg;
 
@@ -120,10 +121,51 @@ static int v27_initial_words(uint32_t *w, int bit_rate, float cutoff_dbm0)
     return 0;
 }
 
+// v17_rx_init() + v17_rx_restart(.., false), v17rx.c:1399-1535
+static int v17_initial_words(uint32_t *w, int bit_rate, float cutoff_dbm0)
+{
+    float f[kV17Floats];
+    int32_t i[kV17Ints];
+    memset(f, 0, sizeof(f));
+    memset(i, 0, sizeof(i));
+    switch (bit_rate)
+    {
+    case 14400: i[XI_SPACE_MAP] = 0; i[XI_BITS_PER_SYMBOL] = 6; break;
+    case 12000: i[XI_SPACE_MAP] = 1; i[XI_BITS_PER_SYMBOL] = 5; break;
+    case 9600: i[XI_SPACE_MAP] = 2; i[XI_BITS_PER_SYMBOL] = 4; break;
+    case 7200: i[XI_SPACE_MAP] = 3; i[XI_BITS_PER_SYMBOL] = 3; break;
+    case 4800: i[XI_SPACE_MAP] = 0; i[XI_BITS_PER_SYMBOL] = 2; break;
+    default: return -1;
+    }
+    i[XI_BIT_RATE] = bit_rate;
+    i[XI_DIFF] = 1;
+    i[XI_SCRAMBLE] = 0x2ECDD5;
+    i[XI_SCRAMBLER_TAP] = 18 - 1;
+    i[XI_STAGE] = V17_SYMBOL_ACQUISITION;
+    i[XI_TRELLIS_PTR] = 14;
+    i[XI_PHASE_RATE] = (int32_t) (1800.0f*65536.0f*65536.0f/8000);
+    i[XI_PHASE_RATE_SAVE] = i[XI_PHASE_RATE];
+    i[XI_ON_POWER] = (int32_t) (level_dbm0(cutoff_dbm0 + 2.5f)*0.4f);
+    i[XI_OFF_POWER] = (int32_t) (level_dbm0(cutoff_dbm0 - 2.5f)*0.4f);
+    i[XI_EQ_PUT_STEP] = kV17Sets*10/(3*2) - 1;
+    f[VF_EQ_COEFF + 2*16] = 3.0f;
+    f[VF_EQ_DELTA] = 0.21f/kEqLen;
+    f[VF_AGC] = (2.17f/1.000000f)/735.0f;
+    f[VF_TRACK_I] = 5000.0f;
+    f[VF_TRACK_P] = 40000.0f;
+    for (int k = 1;  k < 8;  k++)
+        f[XF_DIST + k] = 99.0f*1.0f;
+    memcpy(w, f, sizeof(f));
+    memcpy(w + kV17Floats, i, sizeof(i));
+    return 0;
+}
+
 static int initial_words(int kind, uint32_t *w, int bit_rate)
 {
     switch (kind)
     {
+    case SPANGPU_V17:
+        return v17_initial_words(w, bit_rate, -45.5f);
     case SPANGPU_V29:
         return v29_initial_words(w, bit_rate, -28.5f);
     case SPANGPU_V27TER:
@@ -144,6 +186,7 @@ int spangpu_modem_state_words(int kind, int *n_floats, int *n_ints)
     {
     case SPANGPU_V29: nf = kV29Floats; ni = kV29Ints; break;
     case SPANGPU_V27TER: nf = kV27Floats; ni = kV27Ints; break;
+    case SPANGPU_V17: nf = kV17Floats; ni = kV17Ints; break;
     default: return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "not a modem kind");
     }
     if (n_floats) *n_floats = nf;
@@ -161,7 +204,7 @@ int spangpu_modem_create(spangpu_modem_t **out, int device, int kind, int n_chan
     if (n_words < 0)
         return n_words;
     if (initial_words(kind, w, bit_rate) < 0)
-        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bit rate not valid for this modem (V.29: 9600/7200/4800, V.27ter: 4800/2400)");
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bit rate not valid for this modem (V.29: 9600/7200/4800, V.27ter: 4800/2400, V.17: 14400/12000/9600/7200/4800)");
     if (spangpu_device_count() <= 0)
         return spangpu_set_error(SPANGPU_ERR_NO_DEVICE, "no HIP device: libspangpu has no CPU fallback");
     if (device < 0  ||  device >= spangpu_device_count())
@@ -183,7 +226,7 @@ int spangpu_modem_create(spangpu_modem_t **out, int device, int kind, int n_chan
     }
     m->own_stream = true;
     const size_t n = (size_t) n_channels;
-    const size_t tab_bytes = (kind == SPANGPU_V29)  ?  sizeof(V29Tables)  :  sizeof(V27Tables);
+    const size_t tab_bytes = (kind == SPANGPU_V29)  ?  sizeof(V29Tables)  :  (kind == SPANGPU_V17)  ?  sizeof(V17Tables)  :  sizeof(V27Tables);
     void *ht = calloc(1, tab_bytes);
     uint32_t *hs = (uint32_t *) malloc(n*n_words*sizeof(uint32_t));
     if (ht == nullptr  ||  hs == nullptr
@@ -212,6 +255,54 @@ int spangpu_modem_create(spangpu_modem_t **out, int device, int kind, int n_chan
         t->coarse_step = 5;
         t->fine_step = 1;
         spg_make_v29_space_map(t->space_map);
+    }
+    else if (kind == SPANGPU_V17)
+    {
+        // V.17 rx pulse shaper: 192 phases x 27 taps, 1800 Hz, 2400 baud, 50 % excess bandwidth (make_modem_filter.c:327-339),
+        // Godard: 1800 Hz, 2400 baud, alpha 0.99, triggers 1000 / 100, steps 15 / 1 (src/Makefile.am:490-491)
+        V17Tables *t = (V17Tables *) ht;
+        float *re = (float *) malloc(2*kV17Sets*kRrcLen*sizeof(float));
+        uint8_t *maps = (uint8_t *) malloc(4*36*36*8 + 36*36);
+        int8_t pts[128][2];
+        if (re == nullptr  ||  maps == nullptr)
+        {
+            free(re);
+            free(maps);
+            free(ht);
+            free(hs);
+            spangpu_modem_destroy(m);
+            return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "table scratch");
+        }
+        float *im = re + kV17Sets*kRrcLen;
+        spg_make_rx_pulseshaper(kV17Sets, kRrcLen, 1800.0, 2400.0, 0.5, re, im);
+        for (int set = 0;  set < kV17Sets;  set++)
+        {
+            for (int tap = 0;  tap < kRrcLen;  tap++)
+            {
+                t->rrc_re[tap*kV17Sets + set] = re[set*kRrcLen + tap];
+                t->rrc_im[tap*kV17Sets + set] = im[set*kRrcLen + tap];
+            }
+        }
+        spg_make_sine_table(t->sine);
+        spg_make_sqrt_table(t->sqrt_tab);
+        spg_make_godard(1800.0, 2400.0, 0.99, t->godard);
+        t->coarse_trigger = 1000.0f;
+        t->fine_trigger = 100.0f;
+        t->coarse_step = 15;
+        t->fine_step = 1;
+        const int np = spg_make_v17_constellation(bit_rate, pts);
+        for (int k = 0;  k < np;  k++)
+        {
+            t->con[2*k] = (float) pts[k][0];
+            t->con[2*k + 1] = (float) pts[k][1];
+        }
+        spg_make_v17_rx_maps(maps, maps + 4*36*36*8);
+        if (bit_rate == 4800)
+            memcpy(t->map, maps + 4*36*36*8, 36*36);
+        else
+            memcpy(t->map, maps + (size_t) w[kV17Floats + XI_SPACE_MAP]*36*36*8, 36*36*8);
+        free(re);
+        free(maps);
     }
     else
     {
@@ -300,8 +391,8 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
     if (stride <= 0)
         stride = samples;
     V29_TRY(hipSetDevice(m->device));
-    // at most 4 bits per baud, a baud every 8000/2400 samples, plus a handful of status events
-    const int cap = ((samples*3*4 + 9)/10 + 8 + 15) & ~15;
+    // at most 4 (V.17: 6) bits per baud, a baud every 8000/2400 samples, plus a handful of status events
+    const int cap = ((samples*3*((m->kind == SPANGPU_V17)  ?  6  :  4) + 9)/10 + 8 + 15) & ~15;
     if (cap > m->ev_cap)
     {
         if (m->events) (void) hipFree(m->events);
@@ -356,6 +447,27 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
             hipLaunchKernelGGL(v29_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
         else
             hipLaunchKernelGGL(v29_bank_kernel<16>, grid, dim3(64), 0, m->stream, L);
+    }
+    else if (m->kind == SPANGPU_V17)
+    {
+        V17Launch L;
+        memset(&L, 0, sizeof(L));
+        L.amp = d_amp;
+        L.stride = d_stride;
+        L.samples = samples;
+        L.n_ch = m->n_ch;
+        L.bit_rate = m->bit_rate;
+        L.state = m->state;
+        L.events = m->events;
+        L.ev_count = m->ev_count;
+        L.ev_cap = m->ev_cap;
+        L.tab = (const V17Tables *) m->tab;
+        if (cpw == 64)
+            hipLaunchKernelGGL(v17_bank_kernel<64>, grid, dim3(64), 0, m->stream, L);
+        else if (cpw == 32)
+            hipLaunchKernelGGL(v17_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
+        else
+            hipLaunchKernelGGL(v17_bank_kernel<16>, grid, dim3(64), 0, m->stream, L);
     }
     else
     {
@@ -438,6 +550,15 @@ int spangpu_modem_restart(spangpu_modem_t *m, int channel)
         for (int k = 0;  k < 2*kEqLen;  k++)
             w[VF_EQ_SAVE + k] = old[VF_EQ_SAVE + k];
         w[VF_TRAIN_ERR] = old[VF_TRAIN_ERR];
+    }
+    else if (m->kind == SPANGPU_V17)
+    {
+        // v17_rx_restart(s, bit_rate, false): a long-training restart
+        static const int keep_i[] = {XI_ON_POWER, XI_OFF_POWER, XI_PHASE_RATE_SAVE};
+        for (int k : keep_i)
+            w[nf + k] = old[nf + k];
+        for (int k = 0;  k < 2*kEqLen;  k++)
+            w[VF_EQ_SAVE + k] = old[VF_EQ_SAVE + k];
     }
     else
     {

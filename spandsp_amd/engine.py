@@ -374,3 +374,8 @@ class V29Bank(ModemBank):
 class V27terBank(ModemBank):
     def __init__(self, n_channels, bit_rate=4800, device=0):
         super().__init__(V27TER, n_channels, bit_rate, device)
+
+
+class V17Bank(ModemBank):
+    def __init__(self, n_channels, bit_rate=14400, device=0):
+        super().__init__(V17, n_channels, bit_rate, device)
