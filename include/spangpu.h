@@ -232,7 +232,13 @@ SPANGPU_API int spangpu_modem_rx(spangpu_modem_t *modem, const int16_t *amp, int
 SPANGPU_API int spangpu_modem_events(spangpu_modem_t *modem, const int8_t **events, const int32_t **counts);
 SPANGPU_API int spangpu_modem_state_words(int kind, int *n_floats, int *n_ints);
 SPANGPU_API int spangpu_modem_get_state(spangpu_modem_t *modem, int channel, uint32_t *words);
+SPANGPU_API int spangpu_modem_set_state(spangpu_modem_t *modem, int channel, const uint32_t *words);
 SPANGPU_API int spangpu_modem_restart(spangpu_modem_t *modem, int channel);
+/* v29_rx_restart(s, rate, old_train) / v27ter_rx_restart(s, rate, old_train) / v17_rx_restart(s, rate, short_train) */
+SPANGPU_API int spangpu_modem_restart_ex(spangpu_modem_t *modem, int channel, int bit_rate, int train_flag);
+/* xxx_rx_fillin(s, len) (v29rx.c:967) and xxx_rx_set_signal_cutoff(s, cutoff) (v29rx.c:163) */
+SPANGPU_API int spangpu_modem_fillin(spangpu_modem_t *modem, int channel, int len);
+SPANGPU_API int spangpu_modem_set_signal_cutoff(spangpu_modem_t *modem, int channel, float cutoff_dbm0);
 /* The constant tables the modem receivers use, as built by this library (host code; see modem_api.hip for `which`). */
 SPANGPU_API int spangpu_modem_table(int which, float *out, int max);
 SPANGPU_API int spangpu_v17_rx_maps(uint8_t *maps, uint8_t *map_4800);

@@ -25,8 +25,15 @@
  *   r2_mf_rx_init/_rx/_get/_release/_free  src/spandsp/bell_r2_mf.h:236-266  src/bell_r2_mf.c:750-951
  *   super_tone_rx_* (descriptor + detector)  src/spandsp/super_tone_rx.h:76-164  src/super_tone_rx.c:81-568
  *   goertzel_*  / make_goertzel_descriptor src/spandsp/tone_detect.h:86-124  src/tone_detect.c:60-205
+ *   v29_rx_init/_restart/_release/_free/_set_put_bit/_set_modem_status_handler/_rx/_fillin/_equalizer_state/
+ *     _carrier_frequency/_symbol_timing_correction/_signal_power/_set_signal_cutoff
+ *                                          src/spandsp/v29rx.h:151-244    src/v29rx.c:139-196,867-1148
+ *   v27ter_rx_* (same set)                 src/spandsp/v27ter_rx.h:71-165 src/v27ter_rx.c:136-170,863-1210
+ *   v17_rx_* (same set)                    src/spandsp/v17rx.h:236-333    src/v17rx.c:165-212,1212-1541
  * Callback types: digits_rx_callback_t (dtmf.h:76), span_tone_report_func_t and
- * tone_segment_func_t (super_tone_rx.h:56-58).
+ * tone_segment_func_t (super_tone_rx.h:56-58), span_put_bit_func_t and span_modem_status_func_t
+ * (async.h:123,131).  Not provided: xxx_rx_set_qam_report_handler (the per-symbol constellation
+ * tap stays on the device) and xxx_rx_get_logging_state.
  */
 #if !defined(SPANGPU_SPANDSP_H)
 #define SPANGPU_SPANDSP_H
@@ -59,6 +66,84 @@ typedef struct
     float fac;
     int samples;
 } goertzel_descriptor_t;
+
+/* ---- modem receivers ------------------------------------------------------------------ */
+typedef void (*span_put_bit_func_t)(void *user_data, int bit);
+typedef void (*span_modem_status_func_t)(void *user_data, int status);
+
+typedef struct
+{
+    float re;
+    float im;
+} complexf_t;
+
+/* spandsp/async.h:66-103: the status codes a receiver passes through put_bit / the status handler */
+enum
+{
+    SIG_STATUS_CARRIER_DOWN = -1,
+    SIG_STATUS_CARRIER_UP = -2,
+    SIG_STATUS_TRAINING_IN_PROGRESS = -3,
+    SIG_STATUS_TRAINING_SUCCEEDED = -4,
+    SIG_STATUS_TRAINING_FAILED = -5
+};
+
+typedef struct v29_rx_state_s v29_rx_state_t;
+typedef struct v27ter_rx_state_s v27ter_rx_state_t;
+typedef struct v17_rx_state_s v17_rx_state_t;
+typedef struct spangpu_modem_group_s spangpu_modem_group_t;
+
+/* N receivers of one kind (SPANGPU_V29 / _V27TER / _V17) and bit rate on one bank; as for the tone groups, each
+   xxx_rx() stages its frame and the last attached channel of the tick (or spangpu_modem_group_flush()) launches. */
+SPANGPU_API spangpu_modem_group_t *spangpu_modem_group_create(int device, int kind, int n_channels, int bit_rate, int max_samples);
+SPANGPU_API int spangpu_modem_group_destroy(spangpu_modem_group_t *g);
+SPANGPU_API int spangpu_modem_group_flush(spangpu_modem_group_t *g);
+SPANGPU_API spangpu_modem_t *spangpu_modem_group_bank(spangpu_modem_group_t *g);
+
+SPANGPU_API v29_rx_state_t *v29_rx_init(v29_rx_state_t *s, int bit_rate, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API v29_rx_state_t *spangpu_v29_rx_attach(spangpu_modem_group_t *g, int channel, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API int v29_rx(v29_rx_state_t *s, const int16_t amp[], int len);
+SPANGPU_API int v29_rx_fillin(v29_rx_state_t *s, int len);
+SPANGPU_API int v29_rx_release(v29_rx_state_t *s);
+SPANGPU_API int v29_rx_free(v29_rx_state_t *s);
+SPANGPU_API void v29_rx_set_put_bit(v29_rx_state_t *s, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API void v29_rx_set_modem_status_handler(v29_rx_state_t *s, span_modem_status_func_t handler, void *user_data);
+SPANGPU_API int v29_rx_equalizer_state(v29_rx_state_t *s, complexf_t **coeffs);
+SPANGPU_API float v29_rx_carrier_frequency(v29_rx_state_t *s);
+SPANGPU_API float v29_rx_symbol_timing_correction(v29_rx_state_t *s);
+SPANGPU_API float v29_rx_signal_power(v29_rx_state_t *s);
+SPANGPU_API void v29_rx_set_signal_cutoff(v29_rx_state_t *s, float cutoff);
+
+SPANGPU_API v27ter_rx_state_t *v27ter_rx_init(v27ter_rx_state_t *s, int bit_rate, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API v27ter_rx_state_t *spangpu_v27ter_rx_attach(spangpu_modem_group_t *g, int channel, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API int v27ter_rx(v27ter_rx_state_t *s, const int16_t amp[], int len);
+SPANGPU_API int v27ter_rx_fillin(v27ter_rx_state_t *s, int len);
+SPANGPU_API int v27ter_rx_release(v27ter_rx_state_t *s);
+SPANGPU_API int v27ter_rx_free(v27ter_rx_state_t *s);
+SPANGPU_API void v27ter_rx_set_put_bit(v27ter_rx_state_t *s, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API void v27ter_rx_set_modem_status_handler(v27ter_rx_state_t *s, span_modem_status_func_t handler, void *user_data);
+SPANGPU_API int v27ter_rx_equalizer_state(v27ter_rx_state_t *s, complexf_t **coeffs);
+SPANGPU_API float v27ter_rx_carrier_frequency(v27ter_rx_state_t *s);
+SPANGPU_API float v27ter_rx_symbol_timing_correction(v27ter_rx_state_t *s);
+SPANGPU_API float v27ter_rx_signal_power(v27ter_rx_state_t *s);
+SPANGPU_API void v27ter_rx_set_signal_cutoff(v27ter_rx_state_t *s, float cutoff);
+
+SPANGPU_API v17_rx_state_t *v17_rx_init(v17_rx_state_t *s, int bit_rate, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API v17_rx_state_t *spangpu_v17_rx_attach(spangpu_modem_group_t *g, int channel, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API int v17_rx(v17_rx_state_t *s, const int16_t amp[], int len);
+SPANGPU_API int v17_rx_fillin(v17_rx_state_t *s, int len);
+SPANGPU_API int v17_rx_release(v17_rx_state_t *s);
+SPANGPU_API int v17_rx_free(v17_rx_state_t *s);
+SPANGPU_API void v17_rx_set_put_bit(v17_rx_state_t *s, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API void v17_rx_set_modem_status_handler(v17_rx_state_t *s, span_modem_status_func_t handler, void *user_data);
+SPANGPU_API int v17_rx_equalizer_state(v17_rx_state_t *s, complexf_t **coeffs);
+SPANGPU_API float v17_rx_carrier_frequency(v17_rx_state_t *s);
+SPANGPU_API float v17_rx_symbol_timing_correction(v17_rx_state_t *s);
+SPANGPU_API float v17_rx_signal_power(v17_rx_state_t *s);
+SPANGPU_API void v17_rx_set_signal_cutoff(v17_rx_state_t *s, float cutoff);
+
+SPANGPU_API int v29_rx_restart(v29_rx_state_t *s, int bit_rate, bool old_train);
+SPANGPU_API int v27ter_rx_restart(v27ter_rx_state_t *s, int bit_rate, bool old_train);
+SPANGPU_API int v17_rx_restart(v17_rx_state_t *s, int bit_rate, int short_train);
 
 /* ---- channel groups: N spandsp objects on one GPU bank ----------------------------- */
 typedef struct spangpu_group_s spangpu_group_t;

@@ -515,63 +515,324 @@ int spangpu_modem_events(spangpu_modem_t *m, const int8_t **events, const int32_
     return m->last_cap;
 }
 
+}   // extern "C"
+
+// ---- host-side state edits: restart, fill-in, cutoff ---------------------------------------------
+// These are the control-plane calls of the reference API; they run on the host against one channel's words.
+
+static void zero_f(uint32_t *w, int first, int count)
+{
+    memset(w + first, 0, count*sizeof(uint32_t));
+}
+
+static void put_f(uint32_t *w, int idx, float v)
+{
+    memcpy(w + idx, &v, sizeof(float));
+}
+
+// v29_rx_restart(), v29rx.c:1019-1098
+static int v29_restart_words(uint32_t *w, int bit_rate, int old_train)
+{
+    int32_t *iw = (int32_t *) (w + kV29Floats);
+    switch (bit_rate)
+    {
+    case 9600: iw[VI_TRAINING_CD] = 0; break;
+    case 7200: iw[VI_TRAINING_CD] = 2; break;
+    case 4800: iw[VI_TRAINING_CD] = 4; break;
+    default: return -1;
+    }
+    iw[VI_BIT_RATE] = bit_rate;
+    zero_f(w, VF_RRC, kRrcLen);
+    iw[VI_RRC_STEP] = 0;
+    iw[VI_SCRAMBLE] = 0;
+    iw[VI_TRAIN_SCRAMBLE] = 0x2A;
+    iw[VI_STAGE] = V29_SYMBOL_ACQUISITION;
+    iw[VI_TRAIN_COUNT] = 0;
+    iw[VI_SIGNAL_PRESENT] = 0;
+    iw[VI_HIGH_SAMPLE] = 0;
+    iw[VI_LOW_SAMPLES] = 0;
+    iw[VI_DROP_PENDING] = 0;
+    iw[VI_OLD_TRAIN] = old_train  ?  1  :  0;
+    memset(&iw[VI_DIFF_ANGLES], 0, 16*sizeof(int32_t));
+    iw[VI_CARRIER_PHASE] = 0;
+    iw[VI_POWER] = 0;
+    iw[VI_CONSTEL] = 0;
+    if (old_train)
+    {
+        iw[VI_PHASE_RATE] = iw[VI_PHASE_RATE_SAVE];
+        memcpy(w + VF_EQ_COEFF, w + VF_EQ_SAVE, 2*kEqLen*sizeof(uint32_t));
+        w[VF_AGC] = w[VF_AGC_SAVE];
+    }
+    else
+    {
+        iw[VI_PHASE_RATE] = (int32_t) (1700.0f*65536.0f*65536.0f/8000);
+        zero_f(w, VF_EQ_COEFF, 2*kEqLen);
+        put_f(w, VF_EQ_COEFF + 2*16, 3.0f);
+        put_f(w, VF_AGC_SAVE, 0.0f);
+        put_f(w, VF_AGC, (1.25f/1.0f)/735.0f);
+    }
+    zero_f(w, VF_EQ_BUF, 2*kEqLen);
+    put_f(w, VF_EQ_DELTA, 0.21f/kEqLen);
+    iw[VI_EQ_PUT_STEP] = kRrcSets*10/(3*2) - 1;
+    iw[VI_EQ_STEP] = 0;
+    put_f(w, VF_TRACK_I, 8000.0f);
+    put_f(w, VF_TRACK_P, 8000000.0f);
+    iw[VI_LAST_SAMPLE] = 0;
+    iw[VI_EQ_SKIP] = 0;
+    zero_f(w, VF_GLOW, 7);
+    iw[VI_TOTAL_CORR] = 0;
+    iw[VI_BAUD_HALF] = 0;
+    return 0;
+}
+
+// v27ter_rx_restart(), v27ter_rx.c:1091-1160 (old_train is accepted and, as in the reference, has no effect)
+static int v27_restart_words(uint32_t *w, int bit_rate)
+{
+    int32_t *iw = (int32_t *) (w + kV27Floats);
+    if (bit_rate != 4800  &&  bit_rate != 2400)
+        return -1;
+    iw[WI_BIT_RATE] = bit_rate;
+    zero_f(w, WF_RRC, kRrcLen);
+    put_f(w, WF_TRAIN_ERR, 0.0f);
+    iw[WI_RRC_STEP] = 0;
+    iw[WI_SCRAMBLE] = 0x3C;
+    iw[WI_PATTERN_COUNT] = 0;
+    iw[WI_STAGE] = V27_SYMBOL_ACQUISITION;
+    iw[WI_TRAINING_BC] = 0;
+    iw[WI_TRAIN_COUNT] = 0;
+    iw[WI_SIGNAL_PRESENT] = 0;
+    iw[WI_HIGH_SAMPLE] = 0;
+    iw[WI_LOW_SAMPLES] = 0;
+    iw[WI_DROP_PENDING] = 0;
+    memset(&iw[WI_DIFF_ANGLES], 0, 16*sizeof(int32_t));
+    iw[WI_CARRIER_PHASE] = 0;
+    put_f(w, WF_TRACK_I, 200000.0f);
+    put_f(w, WF_TRACK_P, 10000000.0f);
+    iw[WI_POWER] = 0;
+    iw[WI_CONSTEL] = 0;
+    iw[WI_PHASE_RATE] = (int32_t) (1800.0f*65536.0f*65536.0f/8000);
+    put_f(w, WF_AGC, (1.414f/1.000000f)/283.0f);
+    zero_f(w, WF_EQ_COEFF, 2*kV27EqLen);
+    put_f(w, WF_EQ_COEFF + 2*17, 1.414f);
+    zero_f(w, WF_EQ_BUF, 2*kV27EqLen);
+    put_f(w, WF_EQ_DELTA, 0.25f/kV27EqLen);
+    iw[WI_EQ_PUT_STEP] = (bit_rate == 4800)  ?  8*5/2  :  12*20/(3*2);
+    iw[WI_EQ_STEP] = 0;
+    iw[WI_EQ_SKIP] = 0;
+    iw[WI_LAST_SAMPLE] = 0;
+    iw[WI_GARDNER_INT] = 0;
+    iw[WI_TOTAL_CORR] = 0;
+    iw[WI_GARDNER_STEP] = 512;
+    iw[WI_BAUD_HALF] = 0;
+    return 0;
+}
+
+// v17_rx_restart(), v17rx.c:1399-1500
+static int v17_restart_words(uint32_t *w, int bit_rate, int short_train)
+{
+    int32_t *iw = (int32_t *) (w + kV17Floats);
+    switch (bit_rate)
+    {
+    case 14400: iw[XI_SPACE_MAP] = 0; iw[XI_BITS_PER_SYMBOL] = 6; break;
+    case 12000: iw[XI_SPACE_MAP] = 1; iw[XI_BITS_PER_SYMBOL] = 5; break;
+    case 9600: iw[XI_SPACE_MAP] = 2; iw[XI_BITS_PER_SYMBOL] = 4; break;
+    case 7200: iw[XI_SPACE_MAP] = 3; iw[XI_BITS_PER_SYMBOL] = 3; break;
+    case 4800: iw[XI_SPACE_MAP] = 0; iw[XI_BITS_PER_SYMBOL] = 2; break;
+    default: return -1;
+    }
+    iw[XI_BIT_RATE] = bit_rate;
+    zero_f(w, VF_RRC, kRrcLen);
+    put_f(w, VF_TRAIN_ERR, 0.0f);
+    iw[XI_RRC_STEP] = 0;
+    iw[XI_DIFF] = 1;
+    iw[XI_SCRAMBLE] = 0x2ECDD5;
+    iw[XI_STAGE] = V17_SYMBOL_ACQUISITION;
+    iw[XI_TRAIN_COUNT] = 0;
+    iw[XI_SIGNAL_PRESENT] = 0;
+    iw[XI_HIGH_SAMPLE] = 0;
+    iw[XI_LOW_SAMPLES] = 0;
+    iw[XI_DROP_PENDING] = 0;
+    if (short_train != 2)
+        iw[XI_SHORT_TRAIN] = short_train  ?  1  :  0;
+    iw[XI_LAST_ANGLES] = 0;
+    iw[XI_LAST_ANGLES + 1] = 0;
+    memset(&iw[XI_DIFF_ANGLES], 0, 16*sizeof(int32_t));
+    for (int k = 0;  k < 8;  k++)
+        put_f(w, XF_DIST + k, k  ?  99.0f*1.0f  :  0.0f);
+    memset(&iw[XI_FULL_PATH], 0, 256*sizeof(int32_t));
+    iw[XI_TRELLIS_PTR] = 14;
+    iw[XI_CARRIER_PHASE] = 0;
+    iw[XI_POWER] = 0;
+    zero_f(w, VF_EQ_BUF, 2*kEqLen);
+    iw[XI_EQ_PUT_STEP] = kV17Sets*10/(3*2) - 1;
+    iw[XI_EQ_STEP] = 0;
+    iw[XI_EQ_SKIP] = 0;
+    if (iw[XI_SHORT_TRAIN])
+    {
+        iw[XI_PHASE_RATE] = iw[XI_PHASE_RATE_SAVE];
+        memcpy(w + VF_EQ_COEFF, w + VF_EQ_SAVE, 2*kEqLen*sizeof(uint32_t));
+        put_f(w, VF_EQ_DELTA, 0.1f*(0.21f/kEqLen));
+        w[VF_AGC] = w[VF_AGC_SAVE];
+        put_f(w, VF_TRACK_I, 0.0f);
+        put_f(w, VF_TRACK_P, 40000.0f);
+    }
+    else
+    {
+        iw[XI_PHASE_RATE] = (int32_t) (1800.0f*65536.0f*65536.0f/8000);
+        zero_f(w, VF_EQ_COEFF, 2*kEqLen);
+        put_f(w, VF_EQ_COEFF + 2*16, 3.0f);
+        put_f(w, VF_EQ_DELTA, 0.21f/kEqLen);
+        put_f(w, VF_AGC_SAVE, 0.0f);
+        put_f(w, VF_AGC, (2.17f/1.000000f)/735.0f);
+        put_f(w, VF_TRACK_I, 5000.0f);
+        put_f(w, VF_TRACK_P, 40000.0f);
+    }
+    iw[XI_LAST_SAMPLE] = 0;
+    zero_f(w, VF_GLOW, 7);
+    iw[XI_TOTAL_CORR] = 0;
+    iw[XI_BAUD_HALF] = 0;
+    return 0;
+}
+
+static int fetch_words(spangpu_modem_t *m, int channel, uint32_t *w)
+{
+    V29_TRY(hipSetDevice(m->device));
+    V29_TRY(hipStreamSynchronize(m->stream));
+    V29_TRY(hipMemcpy2D(w, sizeof(uint32_t), m->state + channel, (size_t) m->n_ch*sizeof(uint32_t),
+                        sizeof(uint32_t), m->n_words, hipMemcpyDeviceToHost));
+    return SPANGPU_OK;
+}
+
+static int store_words(spangpu_modem_t *m, int channel, const uint32_t *w)
+{
+    V29_TRY(hipMemcpy2D(m->state + channel, (size_t) m->n_ch*sizeof(uint32_t), w, sizeof(uint32_t),
+                        sizeof(uint32_t), m->n_words, hipMemcpyHostToDevice));
+    return SPANGPU_OK;
+}
+
+extern "C" {
+
 // One channel's state as spangpu_modem_state_words() 32 bit words: the float words, then the int words
-// (order: "State word map" in v29_dev.hpp / v27ter_dev.hpp).
+// (order: "State word map" in v29_dev.hpp / v27ter_dev.hpp / v17_dev.hpp).
 int spangpu_modem_get_state(spangpu_modem_t *m, int channel, uint32_t *words)
+{
+    if (m == nullptr  ||  channel < 0  ||  channel >= m->n_ch  ||  words == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    const int rc = fetch_words(m, channel, words);
+    return (rc < 0)  ?  rc  :  m->n_words;
+}
+
+int spangpu_modem_set_state(spangpu_modem_t *m, int channel, const uint32_t *words)
 {
     if (m == nullptr  ||  channel < 0  ||  channel >= m->n_ch  ||  words == nullptr)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
     V29_TRY(hipSetDevice(m->device));
     V29_TRY(hipStreamSynchronize(m->stream));
-    V29_TRY(hipMemcpy2D(words, sizeof(uint32_t), m->state + channel, (size_t) m->n_ch*sizeof(uint32_t),
-                        sizeof(uint32_t), m->n_words, hipMemcpyDeviceToHost));
-    return m->n_words;
+    return store_words(m, channel, words);
 }
 
-// xxx_rx_restart(s, bit_rate, false) for one channel (v29rx.c:1019-1098, v27ter_rx.c:1091-1160)
+// v29_rx_restart(s, bit_rate, old_train) / v27ter_rx_restart(s, bit_rate, old_train) / v17_rx_restart(s, bit_rate,
+// short_train) for one channel.  A V.29 channel may change rate; V.27ter and V.17 banks run one rate (their tables
+// are per rate), so for them bit_rate must be the bank's.  Returns -1 for a rate the modem does not have, like the
+// reference.
+int spangpu_modem_restart_ex(spangpu_modem_t *m, int channel, int bit_rate, int train_flag)
+{
+    if (m == nullptr  ||  channel < 0  ||  channel >= m->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    uint32_t w[kMaxWords];
+    int rc = fetch_words(m, channel, w);
+    if (rc < 0)
+        return rc;
+    switch (m->kind)
+    {
+    case SPANGPU_V29:
+        rc = v29_restart_words(w, bit_rate, train_flag);
+        break;
+    case SPANGPU_V27TER:
+        rc = (bit_rate == m->bit_rate  ||  (bit_rate != 4800  &&  bit_rate != 2400))  ?  v27_restart_words(w, bit_rate)  :  -2;
+        break;
+    default:
+        rc = (bit_rate == m->bit_rate  ||  spg_v17_constellation_size(bit_rate) < 0)  ?  v17_restart_words(w, bit_rate, train_flag)  :  -2;
+        break;
+    }
+    if (rc == -2)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "this bank runs one bit rate; create another bank for a different rate");
+    if (rc < 0)
+        return -1;
+    return store_words(m, channel, w);
+}
+
+// xxx_rx_restart(s, current rate, false)
 int spangpu_modem_restart(spangpu_modem_t *m, int channel)
 {
     if (m == nullptr  ||  channel < 0  ||  channel >= m->n_ch)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
-    V29_TRY(hipSetDevice(m->device));
-    V29_TRY(hipStreamSynchronize(m->stream));
-    uint32_t w[kMaxWords];
-    uint32_t old[kMaxWords];
-    initial_words(m->kind, w, m->bit_rate);
-    V29_TRY(hipMemcpy2D(old, sizeof(uint32_t), m->state + channel, (size_t) m->n_ch*sizeof(uint32_t),
-                        sizeof(uint32_t), m->n_words, hipMemcpyDeviceToHost));
-    // what a restart keeps: the cutoff powers, the saved equaliser / carrier rate / AGC, and fields it never touches
-    const int nf = m->n_floats;
+    int rate = m->bit_rate;
     if (m->kind == SPANGPU_V29)
     {
-        static const int keep_i[] = {VI_ON_POWER, VI_OFF_POWER, VI_PHASE_RATE_SAVE, VI_LAST_ANGLES, VI_LAST_ANGLES + 1};
-        for (int k : keep_i)
-            w[nf + k] = old[nf + k];
-        for (int k = 0;  k < 2*kEqLen;  k++)
-            w[VF_EQ_SAVE + k] = old[VF_EQ_SAVE + k];
-        w[VF_TRAIN_ERR] = old[VF_TRAIN_ERR];
+        uint32_t w[kMaxWords];
+        const int rc = fetch_words(m, channel, w);
+        if (rc < 0)
+            return rc;
+        rate = (int) w[kV29Floats + VI_BIT_RATE];
+    }
+    return spangpu_modem_restart_ex(m, channel, rate, 0);
+}
+
+// xxx_rx_fillin(s, len): keep the carrier and symbol phase running over a gap (v29rx.c:967-996, v27ter_rx.c:1030-1067,
+// v17rx.c:1320-1358)
+int spangpu_modem_fillin(spangpu_modem_t *m, int channel, int len)
+{
+    if (m == nullptr  ||  channel < 0  ||  channel >= m->n_ch  ||  len < 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    uint32_t w[kMaxWords];
+    const int rc = fetch_words(m, channel, w);
+    if (rc < 0)
+        return rc;
+    int32_t *iw = (int32_t *) (w + m->n_floats);
+    int i_present, i_stage, i_phase, i_rate, i_put, sets, add, parked;
+    if (m->kind == SPANGPU_V29)
+    {
+        i_present = VI_SIGNAL_PRESENT; i_stage = VI_STAGE; i_phase = VI_CARRIER_PHASE; i_rate = VI_PHASE_RATE;
+        i_put = VI_EQ_PUT_STEP; sets = kRrcSets; add = kRrcSets*10/(3*2); parked = V29_PARKED;
     }
     else if (m->kind == SPANGPU_V17)
     {
-        // v17_rx_restart(s, bit_rate, false): a long-training restart
-        static const int keep_i[] = {XI_ON_POWER, XI_OFF_POWER, XI_PHASE_RATE_SAVE};
-        for (int k : keep_i)
-            w[nf + k] = old[nf + k];
-        for (int k = 0;  k < 2*kEqLen;  k++)
-            w[VF_EQ_SAVE + k] = old[VF_EQ_SAVE + k];
+        i_present = XI_SIGNAL_PRESENT; i_stage = XI_STAGE; i_phase = XI_CARRIER_PHASE; i_rate = XI_PHASE_RATE;
+        i_put = XI_EQ_PUT_STEP; sets = kV17Sets; add = kV17Sets*10/(3*2); parked = V17_PARKED;
     }
     else
     {
-        static const int keep_i[] = {WI_ON_POWER, WI_OFF_POWER, WI_PHASE_RATE_SAVE, WI_LAST_ANGLES, WI_LAST_ANGLES + 1};
-        for (int k : keep_i)
-            w[nf + k] = old[nf + k];
-        for (int k = 0;  k < 2*kV27EqLen;  k++)
-            w[WF_EQ_SAVE + k] = old[WF_EQ_SAVE + k];
-        w[WF_AGC_SAVE] = old[WF_AGC_SAVE];
+        i_present = WI_SIGNAL_PRESENT; i_stage = WI_STAGE; i_phase = WI_CARRIER_PHASE; i_rate = WI_PHASE_RATE;
+        i_put = WI_EQ_PUT_STEP; parked = V27_PARKED;
+        sets = (m->bit_rate == 4800)  ?  8  :  12;
+        add = (m->bit_rate == 4800)  ?  8*5/2  :  12*20/(3*2);
     }
-    V29_TRY(hipMemcpy2D(m->state + channel, (size_t) m->n_ch*sizeof(uint32_t), w, sizeof(uint32_t),
-                        sizeof(uint32_t), m->n_words, hipMemcpyHostToDevice));
-    return SPANGPU_OK;
+    if (iw[i_present] <= 0  ||  iw[i_stage] == parked)
+        return 0;
+    for (int i = 0;  i < len;  i++)
+    {
+        iw[i_phase] = (int32_t) ((uint32_t) iw[i_phase] + (uint32_t) iw[i_rate]);
+        if ((iw[i_put] -= sets) <= 0)
+            iw[i_put] += add;
+    }
+    return store_words(m, channel, w);
+}
+
+// xxx_rx_set_signal_cutoff(s, cutoff) (v29rx.c:163-169)
+int spangpu_modem_set_signal_cutoff(spangpu_modem_t *m, int channel, float cutoff_dbm0)
+{
+    if (m == nullptr  ||  channel < 0  ||  channel >= m->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    uint32_t w[kMaxWords];
+    const int rc = fetch_words(m, channel, w);
+    if (rc < 0)
+        return rc;
+    int32_t *iw = (int32_t *) (w + m->n_floats);
+    const int i_on = (m->kind == SPANGPU_V29)  ?  VI_ON_POWER  :  (m->kind == SPANGPU_V17)  ?  XI_ON_POWER  :  WI_ON_POWER;
+    iw[i_on] = (int32_t) (level_dbm0(cutoff_dbm0 + 2.5f)*0.4f);
+    iw[i_on + 1] = (int32_t) (level_dbm0(cutoff_dbm0 - 2.5f)*0.4f);
+    return store_words(m, channel, w);
 }
 
 // The constant tables this library builds (for tests).  which: 0 sine [2048], 1 sqrt (as float) [193],

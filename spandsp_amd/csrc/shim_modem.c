@@ -1,0 +1,417 @@
+/*
+ * shim_modem.c -- host side (plain C) of the spandsp-named modem receiver entry points declared in
+ * include/spangpu_spandsp.h: v29_rx*, v27ter_rx*, v17_rx*.  No signal processing happens here: samples
+ * go to a modem bank (include/spangpu.h, "Modem receiver banks"), the HIP kernel leaves each channel's
+ * put_bit / status stream in order, and this file replays it through the caller's callbacks exactly as
+ * the reference's report_status_change() / put_bit() would (src/v29rx.c:171-178, :365-397):
+ * negative entries go to the modem status handler if one is set, else to put_bit; bits go to put_bit.
+ * Without a GPU every init returns NULL: there is no CPU implementation.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "spangpu_spandsp.h"
+
+#define MAX_WORDS   1024
+
+struct spangpu_modem_group_s
+{
+    spangpu_modem_t *bank;
+    int kind;
+    int bit_rate;
+    int n_ch;
+    int max_samples;
+    int16_t *stage;
+    void **handles;
+    uint8_t *staged;
+    int n_attached;
+    int n_staged;
+    int tick_samples;
+};
+
+typedef struct
+{
+    int kind;
+    spangpu_modem_group_t *grp;
+    int channel;
+    int private_grp;
+    int bit_rate;
+    span_put_bit_func_t put_bit;
+    void *put_bit_user_data;
+    span_modem_status_func_t status_handler;
+    void *status_user_data;
+    uint32_t words[MAX_WORDS];              /* scratch for state reads (equalizer_state() hands out a view) */
+    int n_floats;
+} modem_obj_t;
+
+struct v29_rx_state_s { modem_obj_t o; };
+struct v27ter_rx_state_s { modem_obj_t o; };
+struct v17_rx_state_s { modem_obj_t o; };
+
+static int rate_ok(int kind, int bit_rate)
+{
+    switch (kind)
+    {
+    case SPANGPU_V29:
+        return bit_rate == 9600  ||  bit_rate == 7200  ||  bit_rate == 4800;
+    case SPANGPU_V27TER:
+        return bit_rate == 4800  ||  bit_rate == 2400;
+    case SPANGPU_V17:
+        return bit_rate == 14400  ||  bit_rate == 12000  ||  bit_rate == 9600  ||  bit_rate == 7200  ||  bit_rate == 4800;
+    }
+    return 0;
+}
+
+spangpu_modem_group_t *spangpu_modem_group_create(int device, int kind, int n_channels, int bit_rate, int max_samples)
+{
+    spangpu_modem_group_t *g;
+
+    if (n_channels <= 0  ||  max_samples <= 0  ||  !rate_ok(kind, bit_rate))
+        return NULL;
+    if ((g = (spangpu_modem_group_t *) calloc(1, sizeof(*g))) == NULL)
+        return NULL;
+    g->kind = kind;
+    g->bit_rate = bit_rate;
+    g->n_ch = n_channels;
+    g->max_samples = max_samples;
+    g->stage = (int16_t *) calloc((size_t) n_channels*max_samples, sizeof(int16_t));
+    g->handles = (void **) calloc(n_channels, sizeof(void *));
+    g->staged = (uint8_t *) calloc(n_channels, 1);
+    if (g->stage == NULL  ||  g->handles == NULL  ||  g->staged == NULL
+        ||  spangpu_modem_create(&g->bank, device, kind, n_channels, bit_rate) != SPANGPU_OK)
+    {
+        spangpu_modem_group_destroy(g);
+        return NULL;
+    }
+    return g;
+}
+
+int spangpu_modem_group_destroy(spangpu_modem_group_t *g)
+{
+    if (g == NULL)
+        return 0;
+    if (g->bank)
+        spangpu_modem_destroy(g->bank);
+    free(g->stage);
+    free(g->handles);
+    free(g->staged);
+    free(g);
+    return 0;
+}
+
+spangpu_modem_t *spangpu_modem_group_bank(spangpu_modem_group_t *g)
+{
+    return g  ?  g->bank  :  NULL;
+}
+
+static void deliver(modem_obj_t *o, const int8_t *ev, int n)
+{
+    int i;
+
+    for (i = 0;  i < n;  i++)
+    {
+        if (ev[i] < 0  &&  o->status_handler)
+            o->status_handler(o->status_user_data, ev[i]);
+        else if (o->put_bit)
+            o->put_bit(o->put_bit_user_data, ev[i]);
+    }
+}
+
+int spangpu_modem_group_flush(spangpu_modem_group_t *g)
+{
+    const int8_t *events;
+    const int32_t *counts;
+    int cap;
+    int c;
+    int rc;
+
+    if (g == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    if (g->n_staged == 0)
+        return 0;
+    if ((rc = spangpu_modem_rx(g->bank, g->stage, SPANGPU_MEM_HOST, g->tick_samples, g->max_samples)) < 0)
+        return rc;
+    if ((cap = spangpu_modem_events(g->bank, &events, &counts)) < 0)
+        return cap;
+    rc = g->n_staged;
+    for (c = 0;  c < g->n_ch;  c++)
+    {
+        /* a channel that staged nothing this tick was fed its previous (stale) frame; groups are meant to be
+           driven with every attached channel each tick, as the header says -- its events are still delivered */
+        if (g->handles[c])
+            deliver((modem_obj_t *) g->handles[c], events + (size_t) c*cap, (counts[c] < cap)  ?  counts[c]  :  cap);
+        g->staged[c] = 0;
+    }
+    g->n_staged = 0;
+    return rc;
+}
+
+static modem_obj_t *obj_new(size_t size, int kind, spangpu_modem_group_t *g, int channel, int private_grp, int bit_rate,
+                            span_put_bit_func_t put_bit, void *user_data)
+{
+    modem_obj_t *o;
+
+    if ((o = (modem_obj_t *) calloc(1, size)) == NULL)
+        return NULL;
+    o->kind = kind;
+    o->grp = g;
+    o->channel = channel;
+    o->private_grp = private_grp;
+    o->bit_rate = bit_rate;
+    o->put_bit = put_bit;
+    o->put_bit_user_data = user_data;
+    spangpu_modem_state_words(kind, &o->n_floats, NULL);
+    g->handles[channel] = o;
+    g->n_attached++;
+    return o;
+}
+
+static modem_obj_t *obj_init(size_t size, int kind, int bit_rate, span_put_bit_func_t put_bit, void *user_data)
+{
+    spangpu_modem_group_t *g;
+    modem_obj_t *o;
+
+    if (!rate_ok(kind, bit_rate))
+        return NULL;
+    /* a private object takes whatever one call hands it, in slices of at most 4096 samples */
+    if ((g = spangpu_modem_group_create(0, kind, 1, bit_rate, 4096)) == NULL)
+        return NULL;
+    if ((o = obj_new(size, kind, g, 0, 1, bit_rate, put_bit, user_data)) == NULL)
+        spangpu_modem_group_destroy(g);
+    return o;
+}
+
+static modem_obj_t *obj_attach(size_t size, int kind, spangpu_modem_group_t *g, int channel,
+                               span_put_bit_func_t put_bit, void *user_data)
+{
+    if (g == NULL  ||  g->kind != kind  ||  channel < 0  ||  channel >= g->n_ch  ||  g->handles[channel])
+        return NULL;
+    return obj_new(size, kind, g, channel, 0, g->bit_rate, put_bit, user_data);
+}
+
+static int obj_rx(modem_obj_t *o, const int16_t amp[], int len)
+{
+    spangpu_modem_group_t *g = o->grp;
+    int n;
+
+    if (o->private_grp)
+    {
+        while (len > 0)
+        {
+            n = (len > g->max_samples)  ?  g->max_samples  :  len;
+            memcpy(g->stage, amp, n*sizeof(int16_t));
+            g->staged[0] = 1;
+            g->n_staged = 1;
+            g->tick_samples = n;
+            spangpu_modem_group_flush(g);
+            amp += n;
+            len -= n;
+        }
+        return 0;
+    }
+    if (len > g->max_samples)
+        len = g->max_samples;
+    if (g->n_staged == 0)
+        g->tick_samples = len;
+    else if (len != g->tick_samples)
+        return 0;                           /* a group tick carries one frame length; a stray length is dropped */
+    memcpy(g->stage + (size_t) o->channel*g->max_samples, amp, len*sizeof(int16_t));
+    if (!g->staged[o->channel])
+    {
+        g->staged[o->channel] = 1;
+        g->n_staged++;
+    }
+    if (g->n_staged >= g->n_attached)
+        spangpu_modem_group_flush(g);
+    return 0;
+}
+
+static int obj_free(modem_obj_t *o)
+{
+    if (o == NULL)
+        return 0;
+    if (o->grp)
+    {
+        o->grp->handles[o->channel] = NULL;
+        o->grp->n_attached--;
+        if (o->private_grp)
+            spangpu_modem_group_destroy(o->grp);
+    }
+    free(o);
+    return 0;
+}
+
+/* A restart that changes the bit rate of a V.27ter / V.17 private object moves it to a bank of the new rate,
+   carrying the words the reference's restart keeps (they are all the words: restart edits in place). */
+static int obj_restart(modem_obj_t *o, int bit_rate, int flag)
+{
+    spangpu_modem_group_t *g = o->grp;
+    spangpu_modem_group_t *ng;
+    int words;
+
+    if (!rate_ok(o->kind, bit_rate))
+        return -1;
+    if (o->kind != SPANGPU_V29  &&  bit_rate != g->bit_rate)
+    {
+        if (!o->private_grp)
+            return -1;                      /* a shared bank runs one rate */
+        words = spangpu_modem_get_state(g->bank, 0, o->words);
+        if (words < 0  ||  (ng = spangpu_modem_group_create(0, o->kind, 1, bit_rate, g->max_samples)) == NULL)
+            return -1;
+        spangpu_modem_set_state(ng->bank, 0, o->words);
+        ng->handles[0] = o;
+        ng->n_attached = 1;
+        g->handles[0] = NULL;
+        spangpu_modem_group_destroy(g);
+        o->grp = g = ng;
+    }
+    o->bit_rate = bit_rate;
+    return (spangpu_modem_restart_ex(g->bank, o->channel, bit_rate, flag) < 0)  ?  -1  :  0;
+}
+
+static const uint32_t *obj_words(modem_obj_t *o)
+{
+    if (spangpu_modem_get_state(o->grp->bank, o->channel, o->words) < 0)
+        return NULL;
+    return o->words;
+}
+
+/* dds_frequencyf(), dds_float.c:2115-2118 */
+static float phase_rate_hz(int32_t rate)
+{
+    return (float) rate*8000.0f/(65536.0f*65536.0f);
+}
+
+/* power_meter_current_dbm0(), power_meter.c:114-121 (DBM0_MAX_POWER = 3.14 + 3.02) */
+static float reading_dbm0(int32_t reading)
+{
+    if (reading <= 0)
+        return -96.329f + (3.14f + 3.02f);
+    return 10.0f*log10f((float) reading/(32767.0f*32767.0f) + 1.0e-10f) + (3.14f + 3.02f);
+}
+
+/* State word positions the getters need (the "State word map" comments of v29_dev.hpp, v27ter_dev.hpp, v17_dev.hpp) */
+enum
+{
+    V29_F_EQ_COEFF = 40, V29_I_PHASE_RATE = 11, V29_I_POWER = 13, V29_I_TOTAL_CORR = 39,
+    V27_F_EQ_COEFF = 33, V27_I_PHASE_RATE = 15, V27_I_POWER = 17, V27_I_TOTAL_CORR = 26,
+    V17_F_EQ_COEFF = 40, V17_I_PHASE_RATE = 14, V17_I_POWER = 16, V17_I_TOTAL_CORR = 44
+};
+
+#define DEFINE_MODEM(pfx, T, KIND, EQ_F, EQ_LEN, I_RATE, I_POWER, POWER_ADJ)                                         \
+T *pfx##_init(T *s, int bit_rate, span_put_bit_func_t put_bit, void *user_data)                                      \
+{                                                                                                                    \
+    modem_obj_t *o;                                                                                                  \
+    if (s)                                                                                                           \
+    {                                                                                                                \
+        /* re-initialise in place (the reference memset()s the caller's struct) */                                   \
+        if (!rate_ok(KIND, bit_rate)  ||  !s->o.private_grp)                                                         \
+            return NULL;                                                                                             \
+        s->o.put_bit = put_bit;                                                                                      \
+        s->o.put_bit_user_data = user_data;                                                                          \
+        s->o.status_handler = NULL;                                                                                  \
+        if (obj_restart(&s->o, bit_rate, 0) < 0)                                                                     \
+            return NULL;                                                                                             \
+        spangpu_modem_set_signal_cutoff(s->o.grp->bank, 0, (KIND == SPANGPU_V29)  ?  -28.5f  :  -45.5f);             \
+        return s;                                                                                                    \
+    }                                                                                                                \
+    o = obj_init(sizeof(T), KIND, bit_rate, put_bit, user_data);                                                     \
+    return (T *) o;                                                                                                  \
+}                                                                                                                    \
+T *spangpu_##pfx##_attach(spangpu_modem_group_t *g, int channel, span_put_bit_func_t put_bit, void *user_data)       \
+{                                                                                                                    \
+    return (T *) obj_attach(sizeof(T), KIND, g, channel, put_bit, user_data);                                        \
+}                                                                                                                    \
+int pfx(T *s, const int16_t amp[], int len)                                                                          \
+{                                                                                                                    \
+    return obj_rx(&s->o, amp, len);                                                                                  \
+}                                                                                                                    \
+int pfx##_fillin(T *s, int len)                                                                                      \
+{                                                                                                                    \
+    spangpu_modem_fillin(s->o.grp->bank, s->o.channel, len);                                                         \
+    return 0;                                                                                                        \
+}                                                                                                                    \
+int pfx##_release(T *s)                                                                                              \
+{                                                                                                                    \
+    (void) s;                                                                                                        \
+    return 0;                                                                                                        \
+}                                                                                                                    \
+int pfx##_free(T *s)                                                                                                 \
+{                                                                                                                    \
+    return obj_free(s  ?  &s->o  :  NULL);                                                                           \
+}                                                                                                                    \
+void pfx##_set_put_bit(T *s, span_put_bit_func_t put_bit, void *user_data)                                           \
+{                                                                                                                    \
+    s->o.put_bit = put_bit;                                                                                          \
+    s->o.put_bit_user_data = user_data;                                                                              \
+}                                                                                                                    \
+void pfx##_set_modem_status_handler(T *s, span_modem_status_func_t handler, void *user_data)                         \
+{                                                                                                                    \
+    s->o.status_handler = handler;                                                                                   \
+    s->o.status_user_data = user_data;                                                                               \
+}                                                                                                                    \
+int pfx##_equalizer_state(T *s, complexf_t **coeffs)                                                                 \
+{                                                                                                                    \
+    const uint32_t *w = obj_words(&s->o);                                                                            \
+    *coeffs = w  ?  (complexf_t *) (s->o.words + EQ_F)  :  NULL;                                                     \
+    return w  ?  EQ_LEN  :  0;                                                                                       \
+}                                                                                                                    \
+float pfx##_carrier_frequency(T *s)                                                                                  \
+{                                                                                                                    \
+    const uint32_t *w = obj_words(&s->o);                                                                            \
+    return w  ?  phase_rate_hz((int32_t) w[s->o.n_floats + I_RATE])  :  0.0f;                                        \
+}                                                                                                                    \
+float pfx##_signal_power(T *s)                                                                                       \
+{                                                                                                                    \
+    const uint32_t *w = obj_words(&s->o);                                                                            \
+    return w  ?  reading_dbm0((int32_t) w[s->o.n_floats + I_POWER]) + POWER_ADJ  :  0.0f;                            \
+}                                                                                                                    \
+void pfx##_set_signal_cutoff(T *s, float cutoff)                                                                     \
+{                                                                                                                    \
+    spangpu_modem_set_signal_cutoff(s->o.grp->bank, s->o.channel, cutoff);                                           \
+}
+
+DEFINE_MODEM(v29_rx, v29_rx_state_t, SPANGPU_V29, V29_F_EQ_COEFF, 33, V29_I_PHASE_RATE, V29_I_POWER, 3.98f)
+DEFINE_MODEM(v27ter_rx, v27ter_rx_state_t, SPANGPU_V27TER, V27_F_EQ_COEFF, 32, V27_I_PHASE_RATE, V27_I_POWER, 3.98f)
+DEFINE_MODEM(v17_rx, v17_rx_state_t, SPANGPU_V17, V17_F_EQ_COEFF, 33, V17_I_PHASE_RATE, V17_I_POWER, 3.98f)
+
+int v29_rx_restart(v29_rx_state_t *s, int bit_rate, bool old_train)
+{
+    return obj_restart(&s->o, bit_rate, old_train);
+}
+
+int v27ter_rx_restart(v27ter_rx_state_t *s, int bit_rate, bool old_train)
+{
+    return obj_restart(&s->o, bit_rate, old_train);
+}
+
+int v17_rx_restart(v17_rx_state_t *s, int bit_rate, int short_train)
+{
+    return obj_restart(&s->o, bit_rate, short_train);
+}
+
+/* v29rx.c:153-156: total correction / (RX_PULSESHAPER_COEFF_SETS*10/3) */
+float v29_rx_symbol_timing_correction(v29_rx_state_t *s)
+{
+    const uint32_t *w = obj_words(&s->o);
+
+    return w  ?  (float) (int32_t) w[s->o.n_floats + V29_I_TOTAL_CORR]/((float) 48*10.0f/3.0f)  :  0.0f;
+}
+
+/* v27ter_rx.c:141-147 */
+float v27ter_rx_symbol_timing_correction(v27ter_rx_state_t *s)
+{
+    const uint32_t *w = obj_words(&s->o);
+    int steps_per_symbol = (s->o.bit_rate == 4800)  ?  8*5  :  12*20/3;
+
+    return w  ?  (float) (int32_t) w[s->o.n_floats + V27_I_TOTAL_CORR]/(float) steps_per_symbol  :  0.0f;
+}
+
+/* v17rx.c:171-174 */
+float v17_rx_symbol_timing_correction(v17_rx_state_t *s)
+{
+    const uint32_t *w = obj_words(&s->o);
+
+    return w  ?  (float) (int32_t) w[s->o.n_floats + V17_I_TOTAL_CORR]/((float) 192*10.0f/3.0f)  :  0.0f;
+}
