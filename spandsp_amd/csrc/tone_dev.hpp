@@ -61,6 +61,7 @@ struct ToneLaunch
     float threshold;
     float normal_twist;
     float reverse_twist;
+    long long *probe_ts;        // tools/probe.hip only: per-wave timestamps (kernels built with ABL & 32)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -615,6 +616,16 @@ void tone_bank_kernel(const ToneLaunch L)
     const int ch = live  ?  (ch0 + cl)  :  (L.n_ch - 1);        // shadow lanes follow the last channel, never store
     const bool store = live  &&  (sub == 0);
 
+    // probe-only (ABL & 32): per-wave timestamps into L.probe_ts, 16 slots per wave
+    long long *ts = nullptr;
+    if (ABL & 32)
+        ts = L.probe_ts + (size_t) (blockIdx.x*kWavesPerBlock + wv)*16;
+    auto stamp = [&](int k)
+    {
+        if ((ABL & 32)  &&  lane == 0  &&  k < 16)
+            ts[k] = (long long) __builtin_readcyclecounter();
+    };
+    stamp(0);
     const bool fast_loader = (L.layout == 0)  &&  L.aligned16  &&  (L.samples > 0);
     const int nseg = (L.samples + kSeg - 1)/kSeg;
     const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) char *) &lds[wv][0][0];
@@ -642,14 +653,12 @@ void tone_bank_kernel(const ToneLaunch L)
             g[j] = (const char *) L.amp + dma_row[j] + (size_t) (2*min(seg*kSeg + dma_col8[j], spad - 8));
         dma_issue<NDMA>(g, __builtin_amdgcn_readfirstlane(lds0 + buf*kBufBytes));
     };
-    // Both LDS buffers are free at kernel start: put the first TWO segments (a whole
-    // 160-sample frame) in flight before anything else, under the state loads.
+    // The first segment's DMA goes out ahead of the state loads.  hipcc's s_waitcnt bookkeeping does not see the
+    // DMA instructions: the wait it places before the first use of the state then covers exactly what the first sample
+    // needs (the older DMA and the state), and nothing younger is in flight to be waited for by accident.  The
+    // second segment is requested from inside the consume loop of the first.
     if (fast_loader  &&  !(ABL & 16))
-    {
         issue_dma(0, 0);
-        if (nseg > 1)
-            issue_dma(1, 1);
-    }
 
     // ---- load per-channel state (coalesced: SoA, lane == channel) -------------------
     Bank<NBL> bk;
@@ -696,6 +705,7 @@ void tone_bank_kernel(const ToneLaunch L)
     det.load_extra(L, ch);
     uint32_t w0 = (uint32_t) L.si[ch];
     int32_t w1 = L.si[(size_t) L.n_ch + ch];
+
     int cs = (int) (w0 & 0xFFFF);
     w0 &= 0xFFFF0000u;
     const int block = Det::block_len(L);
@@ -704,6 +714,7 @@ void tone_bank_kernel(const ToneLaunch L)
     // together, which the host slot allocator arranges.)
     const int cs_first = __builtin_amdgcn_readfirstlane(cs);
     const bool uniform = __all(cs == cs_first);
+    stamp(1);
 
     int nb = 0;                 // blocks completed by this lane in this call
     int take_acc = 0;           // samples since the last duration update (dtmf.c:202-204)
@@ -766,6 +777,8 @@ void tone_bank_kernel(const ToneLaunch L)
         if (fast_loader)
         {
             dma_wait_all();
+            if (seg == 0)
+                stamp(2);
         }
         else if (sub == 0)
         {
@@ -792,19 +805,26 @@ void tone_bank_kernel(const ToneLaunch L)
         {
             int cs_s = __builtin_amdgcn_readfirstlane(cs);
             const int nchunks = (seglen + 7) >> 3;
+            const int nfull = seglen >> 3;                  // chunks holding 8 samples
             int4 cur = rowv[0];
-            for (int q = 0;  q < nchunks;  q++)
+            int q = 0;
+            // Start the next segment's DMA from INSIDE the consume loop: hipcc drains vmcnt(0) in loop preheaders,
+            // which would serialise a DMA issued before the loop.
+            bool dma_due = fast_loader  &&  seg + 1 < nseg  &&  !(ABL & 16);
+            while (q < nchunks)
             {
-                const int4 nxt = rowv[(q + 1 < nchunks)  ?  (q + 1)  :  q];    // one chunk ahead
-                const int n = min(8, seglen - q*8);
-                // Start the next segment's DMA from INSIDE the chunk loop: hipcc drains vmcnt(0)
-                // in the loop preheader, which would serialise a DMA issued before the loop.
-                if (q == 0  &&  fast_loader  &&  seg >= 1  &&  seg + 1 < nseg  &&  !(ABL & 16))
-                    issue_dma(seg + 1, buf ^ 1);
-                if (ABL & 2)
-                    cur = make_int4(0x00010002, 0x00030004, 0x00050006, 0x00070008);
-                if (n == 8  &&  cs_s + 8 <= block)
+                // (1) a run of whole chunks that end before the block does: one tight loop, nothing else in it
+                const int nrun = min(nfull - q, (block - cs_s) >> 3);
+                for (int k = 0;  k < nrun;  k++)
                 {
+                    const int4 nxt = rowv[min(q + k + 1, nchunks - 1)];     // one chunk ahead
+                    if (dma_due)
+                    {
+                        issue_dma(seg + 1, buf ^ 1);
+                        dma_due = false;
+                    }
+                    if (ABL & 2)
+                        cur = make_int4(0x00010002, 0x00030004, 0x00050006, 0x00070008);
                     one_sample(s16_lo(cur.x));
                     one_sample(s16_hi(cur.x));
                     one_sample(s16_lo(cur.y));
@@ -813,17 +833,29 @@ void tone_bank_kernel(const ToneLaunch L)
                     one_sample(s16_hi(cur.z));
                     one_sample(s16_lo(cur.w));
                     one_sample(s16_hi(cur.w));
-                    cs_s += 8;
-                    take_acc += 8;
+                    cur = nxt;
+                }
+                if (nrun > 0)
+                {
+                    q += nrun;
+                    cs_s += 8*nrun;
+                    take_acc += 8*nrun;
                     if (cs_s == block)
                     {
                         end_block();
                         cs_s = 0;
                     }
+                    continue;
                 }
-                else
+                // (2) the chunk a block boundary (or the end of the call) falls in: sample by sample
                 {
-                    // a block boundary (or the end of the call) falls inside this chunk
+                    const int4 nxt = rowv[min(q + 1, nchunks - 1)];
+                    if (dma_due)
+                    {
+                        issue_dma(seg + 1, buf ^ 1);
+                        dma_due = false;
+                    }
+                    const int n = min(8, seglen - q*8);
                     for (int j = 0;  j < n;  j++)
                     {
                         const int w = (j < 2)  ?  cur.x  :  (j < 4)  ?  cur.y  :  (j < 6)  ?  cur.z  :  cur.w;
@@ -836,10 +868,12 @@ void tone_bank_kernel(const ToneLaunch L)
                             cs_s = 0;
                         }
                     }
+                    cur = nxt;
+                    q++;
                 }
-                cur = nxt;
             }
             cs = cs_s;
+            stamp(3 + seg);
         }
         else
         {
@@ -847,7 +881,7 @@ void tone_bank_kernel(const ToneLaunch L)
             // lanes of a channel share its phase, so they reach end_block() together.)
             for (int pos = 0;  pos < seglen;  pos++)
             {
-                if (pos == 0  &&  fast_loader  &&  seg >= 1  &&  seg + 1 < nseg)
+                if (pos == 0  &&  fast_loader  &&  seg + 1 < nseg)
                     issue_dma(seg + 1, buf ^ 1);
                 one_sample((float) row[pos]);
                 cs++;
@@ -895,6 +929,7 @@ void tone_bank_kernel(const ToneLaunch L)
         for (int b = nb;  b < L.maxb;  b++)
             L.rec[(size_t) b*L.n_ch + ch] = 0;         // slots without a completed block
     }
+    stamp(15);
 }
 
 }   // namespace spg

@@ -238,6 +238,13 @@ static void probe_tone(const char *name, int n_ch, int samples, int n_frames, in
     L.reverse_twist = 2.512f;
     const int waves = (n_ch + kWave/LPC - 1)/(kWave/LPC);
     const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
+    long long *d_ts = nullptr;
+    if (ABL & 32)
+    {
+        CK(hipMalloc(&d_ts, (size_t) blocks*kWavesPerBlock*16*sizeof(long long)));
+        CK(hipMemset(d_ts, 0, (size_t) blocks*kWavesPerBlock*16*sizeof(long long)));
+        L.probe_ts = d_ts;
+    }
     int f = 0;
     float ms = time_ms([&] {
         L.amp = amp + (size_t) (f % n_frames)*frame_elems;
@@ -248,6 +255,30 @@ static void probe_tone(const char *name, int n_ch, int samples, int n_frames, in
     const double rd = (double) n_ch*(samples*2 + 80);
     printf("%-10s abl=%2d lpc=%d ch=%8d samples=%5d %s: %9.2f us/launch  %8.1f Gsamples/s  alg-read %7.1f GB/s (%4.1f%% of 8 TB/s)\n",
            name, ABL, LPC, n_ch, samples, divergent  ?  "divergent"  :  "uniform  ", ms*1e3, smp/ms/1e6, rd/ms/1e6, rd/ms/1e6/80.0);
+    if (ABL & 32)
+    {
+        std::vector<long long> t((size_t) blocks*kWavesPerBlock*16);
+        CK(hipMemcpy(t.data(), d_ts, t.size()*sizeof(long long), hipMemcpyDeviceToHost));
+        long long tmin = t[0], tmax = 0;
+        for (int w = 0;  w < waves;  w++)
+        {
+            if (t[(size_t) w*16] < tmin) tmin = t[(size_t) w*16];
+            if (t[(size_t) w*16 + 15] > tmax) tmax = t[(size_t) w*16 + 15];
+        }
+        printf("   kernel span %lld ticks (ticks/us = %.1f from event time); mean over waves of (stamp - kernel start), in ticks:\n     ", tmax - tmin, (tmax - tmin)/(ms*1e3));
+        const int nst = 3 + (samples + kSeg - 1)/kSeg;
+        for (int k = 0;  k < 16;  k++)
+        {
+            if (k >= nst  &&  k != 15)
+                continue;
+            double acc = 0;
+            for (int w = 0;  w < waves;  w++)
+                acc += (double) (t[(size_t) w*16 + k] - tmin);
+            printf("s%d=%.0f ", k, acc/waves);
+        }
+        printf("\n");
+        CK(hipFree(d_ts));
+    }
     CK(hipFree(amp));
     CK(hipFree(L.sf));
     CK(hipFree(L.si));
@@ -278,10 +309,41 @@ int main(int argc, char **argv)
         probe_tone<DtmfDet<false>, 2, 31>("dtmf", 65536, 160, 64, 102, false);
         return 0;
     }
+    if (argc > 1  &&  strcmp(argv[1], "ts") == 0)
+    {
+        probe_tone<DtmfDet<false>, 1, 32>("dtmf", 65536, 160, 64, 102, false);
+        probe_tone<DtmfDet<false>, 2, 32>("dtmf", 65536, 160, 64, 102, false);
+        probe_tone<DtmfDet<false>, 1, 32>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1, 32>("dtmf", 1048576, 160, 8, 102, false);
+        return 0;
+    }
+    if (argc > 1  &&  strcmp(argv[1], "abl2") == 0)
+    {
+        probe_tone<DtmfDet<false>, 1, 0>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1, 1>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1, 2>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1, 4>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1, 8>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1, 16>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1, 7>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1, 23>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 2, 0>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 2, 1>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 2, 2>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 2, 4>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 2, 8>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 2, 16>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 2, 7>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 2, 23>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1, 0>("dtmf", 65536, 816, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1, 0>("dtmf", 65536, 800, 16, 80, false);
+        return 0;
+    }
     if (tone_only)
     {
         probe_tone<DtmfDet<false>, 2>("dtmf", 65536, 160, 64, 102, false);
         probe_tone<DtmfDet<false>, 2>("dtmf", 65536, 800, 16, 102, false);
+        probe_tone<DtmfDet<false>, 1>("dtmf", 65536, 800, 16, 102, false);
         return 0;
     }
     probe_valu();
