@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Secondary workloads of BASELINE.json (bench.py carries the headline DTMF line):
 
-    python tools/bench_paths.py --workload v29  [--channels 16384]      # configs[3]
-    python tools/bench_paths.py --workload echo [--channels 131072]     # configs[4], one GPU's shard
+    python tools/bench_paths.py --workload mixed  [--channels 131072]   # configs[2]: Bell MF + R2 MF + super-tone banks
+    python tools/bench_paths.py --workload v29    [--channels 16384]    # configs[3]
+    python tools/bench_paths.py --workload echo   [--channels 131072]   # configs[4], one GPU's shard of 1 048 576
+    python tools/bench_paths.py --workload v17 | v27ter                 # the other receivers of SURVEY 8(a)
 
 One JSON line per run, same fields as bench.py.  A step = one 160-sample frame of every channel, inputs resident
 in HBM.  Synthetic inputs: V.29 = the committed reference transmission (tests/golden/v29_9600.npz: training + PRBS data
@@ -25,8 +27,11 @@ FRAME = 160
 HBM_PEAK_GBPS = 8000.0
 
 
-def synth_v29(n_ch, n_frames, dev, seed):
-    g = np.load(os.path.join(ROOT, "tests", "golden", "v29_9600.npz"))
+MODEMS = {"v29": ("v29_9600.npz", 9600, 281), "v17": ("v17_14400.npz", 14400, 547), "v27ter": ("v27ter_4800.npz", 4800, 270)}
+
+
+def synth_v29(n_ch, n_frames, dev, seed, fixture="v29_9600.npz"):
+    g = np.load(os.path.join(ROOT, "tests", "golden", fixture))
     base = torch.tensor(g["amp"].astype(np.float32), device=dev)
     period = base.numel() + 270
     base = torch.cat([base, torch.zeros(270, device=dev)])
@@ -34,7 +39,7 @@ def synth_v29(n_ch, n_frames, dev, seed):
     gen.manual_seed(seed)
     delay = torch.randint(0, FRAME, (n_ch, 1), device=dev, generator=gen)
     gain = torch.pow(10.0, torch.empty(n_ch, 1, device=dev).uniform_(-14.0, 3.0, generator=gen)/20.0)
-    sigma = torch.empty(n_ch, 1, device=dev).uniform_(1.0, 40.0, generator=gen)
+    sigma = torch.empty(n_ch, 1, device=dev).uniform_(1.0, 12.0 if "v27" in fixture else 40.0, generator=gen)
     out = torch.empty(n_frames, n_ch, FRAME, dtype=torch.int16, device=dev)
     for f in range(n_frames):
         t = torch.arange(f*FRAME, (f + 1)*FRAME, device=dev).unsqueeze(0) - delay
@@ -44,53 +49,260 @@ def synth_v29(n_ch, n_frames, dev, seed):
     return out
 
 
-def cpu_v29(frames_host):
-    import oracle
-    from oracle import ref
-    assert oracle.have_ref(), "cpu baseline for the modem path needs oracle/_ref"
-    n_frames, n_ch, _ = frames_host.shape
+def run_threads(n_ch, work):
     cores = max(1, min(os.cpu_count() or 1, n_ch))
     bounds = np.linspace(0, n_ch, cores + 1).astype(int)
-    L = ref.lib()
-    L.glue_v29_rx_new_quiet.restype = ctypes.c_void_p
-    L.glue_v29_rx_new_quiet.argtypes = [ctypes.c_int]
-    L.glue_v29_rx_batch.restype = None
-    L.glue_v29_rx_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
-    arr = (ctypes.c_void_p*n_ch)(*[L.glue_v29_rx_new_quiet(9600) for _ in range(n_ch)])
-
-    def work(lo, hi):
-        base = ctypes.addressof(arr) + lo*ctypes.sizeof(ctypes.c_void_p)
-        for f in range(n_frames):
-            L.glue_v29_rx_batch(base, frames_host[f, lo:hi].ctypes.data, hi - lo, FRAME, FRAME)
     th = [threading.Thread(target=work, args=(int(bounds[i]), int(bounds[i + 1]))) for i in range(cores)]
     t0 = time.perf_counter()
     [t.start() for t in th]
     [t.join() for t in th]
-    dt = time.perf_counter() - t0
+    return cores, time.perf_counter() - t0
+
+
+def cpu_modem(kind, bit_rate, frames_host):
+    """The reference receiver (oracle/_ref) on the host cores over a bounded sample of the same frames."""
+    import oracle
+    from oracle import ref
+    assert oracle.have_ref(), "cpu baseline for the modem path needs oracle/_ref"
+    n_frames, n_ch, _ = frames_host.shape
+    L = ref.lib()
+    new = getattr(L, "glue_%s_rx_new_quiet" % kind)
+    batch = getattr(L, "glue_%s_rx_batch" % kind)
+    new.restype = ctypes.c_void_p
+    new.argtypes = [ctypes.c_int]
+    batch.restype = None
+    batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
+    arr = (ctypes.c_void_p*n_ch)(*[new(bit_rate) for _ in range(n_ch)])
+
+    def work(lo, hi):
+        base = ctypes.addressof(arr) + lo*ctypes.sizeof(ctypes.c_void_p)
+        for f in range(n_frames):
+            batch(base, frames_host[f, lo:hi].ctypes.data, hi - lo, FRAME, FRAME)
+    cores, dt = run_threads(n_ch, work)
     return {"value": n_frames*n_ch*FRAME/dt/1e6, "unit": "Msamples/s", "cores": cores, "kind": "reference",
-            "sample": "%d channels x %d frames of %d samples, reference v29_rx on %d host threads, %.1f s"
-                      % (n_ch, n_frames, FRAME, cores, dt)}
+            "sample": "%d channels x %d frames of %d samples, reference %s_rx on %d host threads, %.1f s"
+                      % (n_ch, n_frames, FRAME, kind, cores, dt)}
+
+
+# ---- echo canceller -----------------------------------------------------------------------------------
+ECHO_TAPS = 128
+ECHO_MODE = 0x01                        # ECHO_CAN_USE_ADAPTION (spandsp/echo.h:120-131), as SURVEY 8(d) config 5
+
+
+def synth_echo(n_ch, n_frames, dev, seed):
+    """tx = white noise at about -15 dBm0, rx = tx through one of 8 sparse echo paths (ERL 6..24 dB) + low noise;
+    every tenth channel carries near-end talk in part of the frames.  Frames are continuous in time."""
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    n = n_frames*FRAME
+    tx = torch.empty(n_frames, n_ch, FRAME, dtype=torch.int16, device=dev)
+    rx = torch.empty_like(tx)
+    paths = torch.zeros(8, 1, ECHO_TAPS, device=dev)
+    rng = np.random.default_rng(seed)
+    for k in range(8):
+        for d in rng.integers(2, 100, 5):
+            paths[k, 0, int(d)] = float(rng.normal(0.0, 0.3))
+    erl = torch.pow(10.0, -torch.empty(n_ch, device=dev).uniform_(6.0, 24.0, generator=gen)/20.0)
+    norm = torch.sqrt((paths**2).sum(dim=2)).clamp_min(1e-3).view(8)
+    chunk = 8192                                            # channels per synthesis chunk
+    for c0 in range(0, n_ch, chunk):
+        c1 = min(n_ch, c0 + chunk)
+        t = 4000.0*torch.randn(c1 - c0, n + ECHO_TAPS - 1, device=dev, generator=gen)
+        t = torch.clamp(torch.round(t), -32768, 32767)
+        idx = torch.arange(c0, c1, device=dev) % 8
+        r = torch.empty(c1 - c0, n, device=dev)
+        for k in range(8):
+            m = (idx == k).nonzero().squeeze(1)
+            if m.numel():
+                r[m] = torch.nn.functional.conv1d(t[m].unsqueeze(1), paths[k:k + 1].flip(2)).squeeze(1)/norm[k]
+        r = r*erl[c0:c1].unsqueeze(1) + 10.0*torch.randn(c1 - c0, n, device=dev, generator=gen)
+        talk = (torch.arange(c0, c1, device=dev) % 10 == 0).unsqueeze(1)
+        burst = ((torch.arange(n, device=dev)//4000) % 3 == 1).unsqueeze(0)
+        r = r + torch.where(talk & burst, 3000.0*torch.randn(c1 - c0, n, device=dev, generator=gen), torch.zeros((), device=dev))
+        tx[:, c0:c1] = t[:, ECHO_TAPS - 1:].to(torch.int16).view(c1 - c0, n_frames, FRAME).permute(1, 0, 2)
+        rx[:, c0:c1] = torch.clamp(torch.round(r), -32768, 32767).to(torch.int16).view(c1 - c0, n_frames, FRAME).permute(1, 0, 2)
+    return tx, rx
+
+
+def cpu_echo(tx_host, rx_host):
+    import oracle
+    from oracle import ref
+    assert oracle.have_ref(), "cpu baseline for the echo path needs oracle/_ref"
+    n_frames, n_ch, _ = tx_host.shape
+    L = ref.lib()
+    L.glue_echo_batch.restype = None
+    L.glue_echo_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                  ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+    cans = [ref.EchoCan(ECHO_TAPS, ECHO_MODE) for _ in range(n_ch)]
+    arr = (ctypes.c_void_p*n_ch)(*[c.p for c in cans])
+    clean = np.zeros((n_ch, FRAME), np.int16)
+
+    def work(lo, hi):
+        base = ctypes.addressof(arr) + lo*ctypes.sizeof(ctypes.c_void_p)
+        for f in range(n_frames):
+            L.glue_echo_batch(base, tx_host[f, lo:hi].ctypes.data, rx_host[f, lo:hi].ctypes.data, clean[lo:hi].ctypes.data,
+                              hi - lo, FRAME, FRAME, 0)
+    # One thread: on the hosts measured, this loop does not speed up with more threads or processes (1/4/16/64 threads
+    # gave 7.4/6.4/5.6/6.6 Msamples/s on the GPU box), so a many-thread figure would only be misleading.
+    t0 = time.perf_counter()
+    work(0, n_ch)
+    dt = time.perf_counter() - t0
+    return {"value": n_frames*n_ch*FRAME/dt/1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
+            "sample": "%d channels x %d frames of %d samples, reference echo_can_update (128 taps) on 1 host thread "
+                      "(does not scale with threads on this host), %.1f s" % (n_ch, n_frames, FRAME, dt)}
+
+
+def bench_echo(args, dev, stream):
+    from spandsp_amd import engine
+    n_ch = args.channels or 131072
+    nf = min(args.steps + args.warmup, 60)
+    tx, rx = synth_echo(n_ch, nf, dev, seed=0xEC40)
+    clean = torch.empty(n_ch, FRAME, dtype=torch.int16, device=dev)
+    bank = engine.EchoBank(n_ch, ECHO_TAPS, ECHO_MODE)
+    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    fb = n_ch*FRAME*2
+    power_rx = 0.0
+    power_clean = 0.0
+
+    def step(i):
+        k = i % nf
+        bank.update_device(ctypes.c_void_p(tx.data_ptr() + k*fb), ctypes.c_void_p(rx.data_ptr() + k*fb),
+                           ctypes.c_void_p(clean.data_ptr()), FRAME, FRAME)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record(stream)
+        step(args.warmup + i)
+        evs[i][1].record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k = (args.warmup + args.steps - 1) % nf
+    quiet = torch.arange(n_ch, device=dev) % 10 != 0
+    power_rx = float((rx[k][quiet].float()**2).mean())
+    power_clean = float((clean[quiet].float()**2).mean())
+    per = [a.elapsed_time(b) for a, b in evs]
+    avg_ms = sum(per)/len(per)
+    state_bytes = 48*4 + ECHO_TAPS*4 + 4*ECHO_TAPS*2 + ECHO_TAPS*2      # scalars + taps32 + taps16[4] + history
+    alg_read = n_ch*(2*FRAME*2 + state_bytes)
+    alg_write = n_ch*(FRAME*2 + state_bytes)
+    cpu = None
+    if not args.no_cpu_baseline:
+        nc = min(args.cpu_channels, n_ch, 4096)
+        nfc = min(nf, 60)
+        cpu = cpu_echo(tx[:nfc, :nc].contiguous().cpu().numpy(), rx[:nfc, :nc].contiguous().cpu().numpy())
+    value = args.steps*n_ch*FRAME/dt/1e6
+    return {
+        "metric": "Msamples/s of batched G.168 echo cancellation, 128 taps (8 kHz channels at real-time = value*1e6/8000)",
+        "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4] (one GPU's shard): echo_can_update 128 taps, %d channels x %d-sample "
+                               "frames, mode ECHO_CAN_USE_ADAPTION" % (n_ch, FRAME), "channels_per_gpu": n_ch,
+                   "erle_db_last_frame_single_talk_channels": 10.0*np.log10(max(power_rx, 1e-9)/max(power_clean, 1e-9))},
+        "roofline": {"bound": "hbm", "kernel": "echo_bank_kernel<128>", "achieved": alg_read/(avg_ms*1e-3)/1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
+                     "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
+                     "avg_launch_us": avg_ms*1e3,
+                     "note": "integer-VALU bound (2 x 128 MACs per sample per channel); the HBM figure is reported, not targeted"},
+        "cpu_baseline": cpu}
+
+
+# ---- mixed Goertzel banks ------------------------------------------------------------------------------
+def bench_mixed(args, dev, stream):
+    """BASELINE configs[2]: one third Bell MF, one third R2 MF (forward), one third super-tone (8 monitored
+    frequencies); a step = the three launches of one 20 ms tick."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    from spandsp_amd import engine
+    n_ch = args.channels or 131072
+    n_each = [n_ch//3, n_ch//3, n_ch - 2*(n_ch//3)]
+    nf = 50
+    n_src = 512                                             # distinct source channels per kind, tiled with a frame rotation
+    srcs = [synth.bell_mf_channels(n_src, nf*FRAME, 21)[0], synth.r2_mf_channels(n_src, nf*FRAME, 22, True)[0],
+            synth.call_progress_channels(n_src, nf*FRAME, 23)]
+    frames = []
+    for kind in range(3):
+        src = torch.tensor(srcs[kind], device=dev).view(n_src, nf, FRAME)
+        idx = torch.arange(n_each[kind], device=dev)
+        rot = (idx//n_src) % nf
+        fsel = (torch.arange(nf, device=dev).unsqueeze(0) + rot.unsqueeze(1)) % nf          # [ch, frame]
+        f = src[(idx % n_src).unsqueeze(1), fsel]                                            # [ch, frame, FRAME]
+        frames.append(f.permute(1, 0, 2).contiguous())
+    st_freqs = [350.0, 400.0, 440.0, 480.0, 620.0, 950.0, 1100.0, 1400.0]
+    fac = [engine.goertzel_fac(f) for f in st_freqs]
+    banks = [engine.ToneBank(engine.BELL_MF, n_each[0]), engine.ToneBank(engine.R2_MF, n_each[1], r2_fwd=True),
+             engine.ToneBank(engine.SUPER_TONE, n_each[2], bin_fac=fac)]
+    for b in banks:
+        b.set_stream(ctypes.c_void_p(stream.cuda_stream))
+
+    def step(i):
+        for kind in range(3):
+            banks[kind].rx_device(ctypes.c_void_p(frames[kind].data_ptr() + (i % nf)*n_each[kind]*FRAME*2), FRAME, FRAME)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record(stream)
+        step(args.warmup + i)
+        evs[i][1].record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = [a.elapsed_time(b) for a, b in evs]
+    avg_ms = sum(per)/len(per)
+    hits = [int((b.blocks()["hit"] != 0).sum()) for b in banks]
+    alg_read = n_each[0]*(320 + 64) + n_each[1]*(320 + 64) + n_each[2]*(320 + 8*8 + 160)       # SURVEY 8(d)
+    value = args.steps*n_ch*FRAME/dt/1e6
+    return {
+        "metric": "Msamples/s of mixed Bell MF + R2 MF + super-tone Goertzel banks (8 kHz channels at real-time = value*1e6/8000)",
+        "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[2]: %d Bell MF + %d R2 MF + %d super-tone (8 bins) channels x %d-sample "
+                               "frames, three launches per step" % (n_each[0], n_each[1], n_each[2], FRAME),
+                   "channels_per_gpu": n_ch, "blocks_with_a_hit_in_last_step": hits},
+        "roofline": {"bound": "hbm", "kernel": "tone_bank_kernel<BellMfDet | R2MfDet | MultiDet<8, true>> (3 launches)",
+                     "achieved": alg_read/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
+                     "alg_read_bytes_per_launch": alg_read, "avg_launch_us": avg_ms*1e3,
+                     "note": "avg_launch_us is the three launches of one step together"},
+        "cpu_baseline": None}
+
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["v29"], default="v29")
-    ap.add_argument("--channels", type=int, default=16384)
-    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed"], default="v29")
+    ap.add_argument("--channels", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-channels", type=int, default=2048)
+    ap.add_argument("--cpu-channels", type=int, default=16384)
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a HIP device; the engine has no CPU fallback")
+    if args.steps <= 0:
+        args.steps = 190 if args.workload == "v27ter" else 150
     dev = torch.device("cuda", 0)
     from spandsp_amd import engine
-    n_ch = args.channels
-    nf = args.steps + args.warmup
-    frames = synth_v29(n_ch, nf, dev, seed=0x29290000)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    bank = engine.V29Bank(n_ch, 9600)
+    if args.workload == "echo":
+        print(json.dumps(bench_echo(args, dev, stream)))
+        return
+    if args.workload == "mixed":
+        print(json.dumps(bench_mixed(args, dev, stream)))
+        return
+    fixture, bit_rate, n_words = MODEMS[args.workload]
+    kind = {"v29": engine.V29, "v17": engine.V17, "v27ter": engine.V27TER}[args.workload]
+    n_ch = args.channels or 16384
+    nf = args.steps + args.warmup
+    frames = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture)
+    bank = engine.ModemBank(kind, n_ch, bit_rate)
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
     frame_bytes = n_ch*FRAME*2
     torch.cuda.synchronize()
@@ -113,22 +325,23 @@ def main():
     for c in range(0, n_ch, max(1, n_ch//256)):
         _, w = bank.get_state(c)
         trained += int(w[6] == 0)
-    alg_read = n_ch*(FRAME*2 + 281*4)
-    alg_write = n_ch*(281*4 + 4 + 208)
+    alg_read = n_ch*(FRAME*2 + n_words*4)
+    alg_write = n_ch*(n_words*4 + 4 + 208)
     cpu = None
     if not args.no_cpu_baseline:
-        cpu = cpu_v29(frames[:, :min(args.cpu_channels, n_ch)].contiguous().cpu().numpy())
+        cpu = cpu_modem(args.workload, bit_rate, frames[:, :min(args.cpu_channels, n_ch)].contiguous().cpu().numpy())
     value = args.steps*n_ch*FRAME/dt/1e6
     print(json.dumps({
-        "metric": "Msamples/s of batched V.29 9600 bps receive (8 kHz channels at real-time = value*1e6/8000)",
+        "metric": "Msamples/s of batched %s %d bps receive (8 kHz channels at real-time = value*1e6/8000)" % (args.workload, bit_rate),
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3]: V.29 9600 bps RX, %d channels x %d-sample frames, AWGN line model"
-                               % (n_ch, FRAME), "channels_per_gpu": n_ch,
+        "config": {"workload": "%s %d bps RX, %d channels x %d-sample frames, AWGN line model%s"
+                               % (args.workload, bit_rate, n_ch, FRAME, " (BASELINE configs[3])" if args.workload == "v29" else ""),
+                   "channels_per_gpu": n_ch,
                    "sampled_channels_in_data_mode_at_end": "%d of %d" % (trained, len(range(0, n_ch, max(1, n_ch//256)))),
                    "events_in_last_frame": bits_last},
-        "roofline": {"bound": "hbm", "kernel": "v29_bank_kernel", "achieved": alg_read/(avg_ms*1e-3)/1e9,
+        "roofline": {"bound": "hbm", "kernel": "%s_bank_kernel" % args.workload, "achieved": alg_read/(avg_ms*1e-3)/1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS,
                      "traffic": None, "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
                      "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3, "max_launch_us": max(per)*1e3,
