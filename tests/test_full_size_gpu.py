@@ -1,0 +1,125 @@
+"""Parity at BASELINE.json's full sizes for the configurations whose oracle is too slow for every channel: channels
+are V distinct signals tiled over the bank; every replica must agree bit-for-bit with the first copy (a size-independent
+property that also exercises every workgroup, wave and lane position), and the first V channels are checked against
+the oracle.  (DTMF 65 536 channels: tests/test_tone_gpu.py::test_dtmf_full_size_replica_property.)"""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from test_oracle_pin import GOLDEN, bits, use_golden_modem_tables
+
+pytestmark = pytest.mark.gpu
+
+
+def test_v29_16384_channels(built):
+    """configs[3]: V.29 9600 bps, 16 384 channels."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    from test_v29_gpu import channel_signals
+    use_golden_modem_tables()
+    n_ch, V, n_frames = 16384, 64, 22                       # 22 frames = training + 1 500 samples of data
+    base = channel_signals(9600, V, seed=77)[:, :n_frames*160]
+    sig = np.tile(base, (n_ch//V, 1))
+    bank = engine.V29Bank(n_ch, 9600)
+    want = []
+    for c in range(V):
+        o = orc.V29(9600)
+        per = []
+        for k in range(n_frames):
+            o.sink.clear()
+            o.rx(base[c, k*160:(k + 1)*160])
+            per.append(o.sink.events()["a"].astype(np.int8))
+        want.append((per, o.snapshot()))
+    total = 0
+    for k in range(n_frames):
+        bank.rx_host(sig[:, k*160:(k + 1)*160])
+        ev = bank.events()
+        for c in range(n_ch):
+            assert np.array_equal(ev[c], want[c % V][0][k]), (k, c)
+        total += sum(len(e) for e in ev[:V])
+    assert total > 400*V//2
+    for c in (0, 63, 64, 8191, n_ch - 1):
+        f, w = bank.get_state(c)
+        of, ow = want[c % V][1]
+        assert np.array_equal(w, ow) and np.array_equal(bits(f), bits(of)), c
+    bank.close()
+
+
+def test_mixed_banks_131072_channels(built):
+    """configs[2]: Bell MF + R2 MF + super-tone, 131 072 channels in all."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    V, n_frames = 128, 12
+    n_each = [43690, 43690, 43692]
+    srcs = [synth.bell_mf_channels(V, n_frames*160, 31)[0], synth.r2_mf_channels(V, n_frames*160, 32, True)[0],
+            synth.call_progress_channels(V, n_frames*160, 33)]
+    st_freqs = [350.0, 400.0, 440.0, 480.0, 620.0, 950.0, 1100.0, 1400.0]
+    fac = [engine.goertzel_fac(f) for f in st_freqs]
+    banks = [engine.ToneBank(engine.BELL_MF, n_each[0]), engine.ToneBank(engine.R2_MF, n_each[1], r2_fwd=True),
+             engine.ToneBank(engine.SUPER_TONE, n_each[2], bin_fac=fac)]
+    hits = 0
+    for kind in range(3):
+        n = n_each[kind]
+        reps = -(-n//V)
+        sig = np.tile(srcs[kind], (reps, 1))[:n]
+        per_frame = []
+        for k in range(n_frames):
+            banks[kind].rx_host(sig[:, k*160:(k + 1)*160])
+            per_frame.append(banks[kind].blocks())
+        # replica property: channel c and channel c % V report the same blocks
+        for k, b in enumerate(per_frame):
+            first = b[b["channel"] < V]
+            key = {}
+            for r in first:
+                key.setdefault(int(r["channel"]), []).append((int(r["block"]), int(r["hit"]), int(r["code"]), int(r["flags"])))
+            nb = len(first)//V
+            assert len(b) == nb*n, (kind, k)
+            rr = b.reshape(n, nb)
+            ref_rows = np.stack([first[first["channel"] == c] for c in range(V)])
+            for name in ("block", "hit", "code", "flags"):
+                assert np.array_equal(rr[name], ref_rows[name][np.arange(n) % V]), (kind, k, name)
+            hits += int((first["hit"] != 0).sum())
+        # oracle on the first V channels: hit and code of every block, in order
+        for c in range(V):
+            if kind == 0:
+                o = orc.BellMf(0)
+            elif kind == 1:
+                o = orc.R2Mf(True, True)
+            else:
+                continue
+            blocks = []
+            for k in range(n_frames):
+                blocks.extend(o.rx(srcs[kind][c, k*160:(k + 1)*160]))
+            got = [(int(r["hit"]), int(r["code"])) for b in per_frame for r in b[b["channel"] == c]]
+            assert got == [(int(x["hit"]), int(x["aux"])) for x in blocks], (kind, c)
+            if kind == 0:
+                digits = "".join(chr(int(r["code"])) for b in per_frame for r in b[b["channel"] == c] if r["flags"] & engine.BLK_REPORT)
+                assert digits == o.get(), (c, digits)
+    assert hits > 100
+    for b in banks:
+        b.close()
+
+
+def test_echo_131072_channels(built):
+    """configs[4], one GPU's shard: 128-tap echo cancellers, 131 072 channels."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    from test_echo_gpu import make_channels
+    n_ch, V, n_frames = 131072, 64, 6
+    tx, rx = make_channels(V, 160*40, 128, seed=404)
+    tx, rx = tx[:, 160*30:160*(30 + n_frames)], rx[:, 160*30:160*(30 + n_frames)]        # a stretch with double talk in it
+    dets = [orc.EchoCan(128, 0x01) for _ in range(V)]
+    bank = engine.EchoBank(n_ch, 128, 0x01)
+    txb = np.tile(tx, (n_ch//V, 1))
+    rxb = np.tile(rx, (n_ch//V, 1))
+    for k in range(n_frames):
+        clean = bank.update_host(txb[:, k*160:(k + 1)*160], rxb[:, k*160:(k + 1)*160], True)
+        want = np.stack([d.run(tx[c, k*160:(k + 1)*160], rx[c, k*160:(k + 1)*160], True) for c, d in enumerate(dets)])
+        assert np.array_equal(clean.reshape(n_ch//V, V, 160), np.broadcast_to(want, (n_ch//V, V, 160))), k
+    for c in (0, 63, 64, 70000, n_ch - 1):
+        g = bank.get_state(c)
+        o = dets[c % V].snapshot()
+        assert np.array_equal(g["taps32"], o["taps32"]) and np.array_equal(g["history"], o["history"]), c
+    bank.close()
