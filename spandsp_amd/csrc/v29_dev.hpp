@@ -7,17 +7,22 @@
 // T/2 equaliser with LMS training, PI carrier loop, slicer, descrambler, training FSM); the
 // only regular arithmetic is three short inner products per T/2 instant with per-channel
 // operands and per-channel circular offsets -- nothing a matrix core can use.  So:
-//   * scalars and the 33 complex equaliser taps (always indexed by a compile-time i) live in
-//     VGPRs;
-//   * the two circular buffers (RRC delay line, equaliser delay line) live in a per-lane LDS
-//     row, stored twice back to back so x[(pos + i) mod n] is the contiguous x2[pos + i];
+//   * scalars, the 33 complex equaliser taps AND the equaliser delay line live in VGPRs: the
+//     delay line is kept in age order (a 66-register shift per T/2 instant), so every access
+//     has a compile-time index; the reference's circular position survives only as the
+//     per-lane split point of the summation and as the order in which state is stored;
+//   * the RRC delay line lives in a per-lane LDS column, stored twice back to back so
+//     x[(pos + i) mod n] is the contiguous x2[pos + i]; the frame's PCM is staged there too;
 //   * the polyphase RRC table (48 x 27 x {re, im}) and the sine table live once per
 //     workgroup in LDS and are gathered by per-lane row;
 //   * inner products keep the reference's exact summation tree: ascending coefficient
 //     index, the circular split summed separately and added last (a per-lane split point,
 //     handled by snapshotting the accumulator instead of branching).
-// Lanes diverge on the T/2 and baud instants and on the training stage; expect VALU/LDS
-// bound behaviour and a low HBM figure for this kernel.
+// Execution is BAUD ALIGNED: each lane consumes samples from its LDS tile until ITS next
+// T/2 instant, then all lanes run the half-baud phase together, and the baud phase runs on
+// alternate rounds -- instead of every lane stepping sample by sample, which made the wave
+// execute the half-baud and baud paths on nearly every sample with a fraction of its lanes.
+// Expect VALU-issue bound behaviour and a low HBM figure for this kernel.
 //
 // Numerics: fp32, every op rounded separately (-ffp-contract=off), float->int conversions
 // with the x86 out-of-range result the reference build has; the single libm dependency of
@@ -30,13 +35,16 @@
 
 namespace spg {
 
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
 constexpr int kV29Floats = 238;             // float words of state per channel (layout: V29 word map below)
 constexpr int kV29Ints = 43;
 constexpr int kV29Words = kV29Floats + kV29Ints;
 constexpr int kRrcSets = 48;
 constexpr int kRrcLen = 27;
 constexpr int kEqLen = 33;
-constexpr int kLanePitch = 2*kRrcLen + 4*kEqLen + 1;   // 187 floats per lane, odd => conflict-free same-index access
+constexpr int kLanePitch = 2*kRrcLen + 4*kEqLen + 1;   // (round 1 layout; kept for reference by the API's sizing notes)
+constexpr int kPcmTile = 80;                            // samples of PCM staged per lane at a time
 
 // State word map (identical to the reference-ordered snapshot the tests use):
 //   floats: 0 agc_scaling, 1 agc_scaling_save, 2 eq_delta, 3 training_error, 4 carrier_track_p,
@@ -198,8 +206,12 @@ void v29_bank_kernel(const V29Launch L)
     __shared__ float t_const[32];
     __shared__ uint16_t t_sqrt[194];
     __shared__ uint8_t t_map[400];
-    // per-lane delay lines, index-major [word][CPW]: lane l always uses bank (l mod 64) whatever its position
-    __shared__ float lanes[CPW*(kLanePitch - 1)];
+    // per-lane RRC delay line (doubled) and PCM tile, index-major [word][CPW]: lane l always uses bank (l mod 64)
+    // whatever its position
+    __shared__ float lanes[CPW*2*kRrcLen];
+    __shared__ uint32_t pcm[CPW*(kPcmTile/2)];
+    // equaliser taps {re, im}, [tap][lane]: always indexed by a compile-time tap number
+    __shared__ float2 taps[kEqLen*CPW];
 
     const int lane = threadIdx.x;
     const int ch = blockIdx.x*CPW + lane;
@@ -251,9 +263,7 @@ void v29_bank_kernel(const V29Launch L)
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV29Floats + w)*N + ch] = (uint32_t) v; };
 
     float *rrc2 = &lanes[lane];                         // [2*27] words, stride CPW
-    float *eqb2 = rrc2 + 2*kRrcLen*CPW;                 // [2*33][2] words, stride CPW
 #define RRC2(k)     rrc2[(k)*CPW]
-#define EQB2(k)     eqb2[(k)*CPW]
 
     float agc_scaling = ldf(VF_AGC);
     float agc_scaling_save = ldf(VF_AGC_SAVE);
@@ -274,22 +284,23 @@ void v29_bank_kernel(const V29Launch L)
         RRC2(i) = v;
         RRC2(kRrcLen + i) = v;
     }
-    float cre[kEqLen];
-    float cim[kEqLen];
+    float2 *ctap = &taps[lane];
+#define TAP(i)      ctap[(i)*CPW]
+    for (int i = 0;  i < kEqLen;  i++)
+        TAP(i) = make_float2(ldf(VF_EQ_COEFF + 2*i), ldf(VF_EQ_COEFF + 2*i + 1));
+    // equaliser delay line in age order: xre[i] = eq_buf[(eq_step + i) mod 33] (i = 0 oldest)
+    float xre[kEqLen];
+    float xim[kEqLen];
+    {
+        const int es = ldi(VI_EQ_STEP);
 #pragma unroll
-    for (int i = 0;  i < kEqLen;  i++)
-    {
-        cre[i] = ldf(VF_EQ_COEFF + 2*i);
-        cim[i] = ldf(VF_EQ_COEFF + 2*i + 1);
-    }
-    for (int i = 0;  i < kEqLen;  i++)
-    {
-        const float a = ldf(VF_EQ_BUF + 2*i);
-        const float b = ldf(VF_EQ_BUF + 2*i + 1);
-        EQB2(2*i) = a;
-        EQB2(2*i + 1) = b;
-        EQB2(2*(kEqLen + i)) = a;
-        EQB2(2*(kEqLen + i) + 1) = b;
+        for (int i = 0;  i < kEqLen;  i++)
+        {
+            int k = es + i;
+            k = (k >= kEqLen)  ?  (k - kEqLen)  :  k;
+            xre[i] = ldf(VF_EQ_BUF + 2*k);
+            xim[i] = ldf(VF_EQ_BUF + 2*k + 1);
+        }
     }
     const int bit_rate = ldi(VI_BIT_RATE);
     int rrc_step = ldi(VI_RRC_STEP);
@@ -352,15 +363,14 @@ void v29_bank_kernel(const V29Launch L)
         power_reading = 0;
         constellation_state = 0;
         carrier_phase_rate = v29_f2i(1700.0f*65536.0f*65536.0f/8000);
+        for (int i = 0;  i < kEqLen;  i++)
+            TAP(i) = make_float2((i == 16)  ?  3.0f  :  0.0f, 0.0f);       // V29_EQUALIZER_PRE_LEN
 #pragma unroll
         for (int i = 0;  i < kEqLen;  i++)
         {
-            cre[i] = 0.0f;
-            cim[i] = 0.0f;
+            xre[i] = 0.0f;
+            xim[i] = 0.0f;
         }
-        cre[16] = 3.0f;                                     // V29_EQUALIZER_PRE_LEN
-        for (int i = 0;  i < 4*kEqLen;  i++)
-            EQB2(i) = 0.0f;
         eq_put_step = kRrcSets*10/(3*2) - 1;
         eq_step = 0;
         agc_scaling_save = 0.0f;
@@ -381,6 +391,15 @@ void v29_bank_kernel(const V29Launch L)
         const float *y = table + row;
         const float *x = rrc2 + rrc_step*CPW;
         const int split = kRrcLen - rrc_step;
+        // all 54 LDS reads first (they do not depend on the running sum), so their latency overlaps
+        float xs[kRrcLen];
+        float ys[kRrcLen];
+#pragma unroll
+        for (int i = 0;  i < kRrcLen;  i++)
+        {
+            xs[i] = x[i*CPW];
+            ys[i] = y[i*kRrcSets];
+        }
         float a = 0.0f;
         float first = 0.0f;
 #pragma unroll
@@ -391,32 +410,33 @@ void v29_bank_kernel(const V29Launch L)
                 first = a;
                 a = 0.0f;
             }
-            a += x[i*CPW]*y[i*kRrcSets];
+            a += xs[i]*ys[i];
         }
         return first + a;
     };
 
-    auto track_carrier = [&](float zre, float zim, float tre, float tim)
+    // track_carrier() and tune_equalizer() (v29rx.c:281-331) are requested by the stage logic and carried out once,
+    // after it, with the loop gains as they were when the reference would have called them.
+    bool do_track = false;
+    bool do_tune = false;
+    bool do_save = false;
+    float tgt_re = 0.0f;
+    float tgt_im = 0.0f;
+    float use_track_i = 0.0f;
+    float use_track_p = 0.0f;
+    auto track_carrier = [&](float tre, float tim)
     {
-        // v29rx.c:297-331
-        const float error = zim*tre - zre*tim;
-        carrier_phase_rate += v29_f2i(carrier_track_i*error);
-        carrier_phase += (uint32_t) v29_f2i(carrier_track_p*error);
+        do_track = true;
+        tgt_re = tre;
+        tgt_im = tim;
+        use_track_i = carrier_track_i;
+        use_track_p = carrier_track_p;
     };
-    auto tune_equalizer = [&](float zre, float zim, float tre, float tim)
+    auto tune_equalizer = [&](float tre, float tim)
     {
-        // v29rx.c:281-291 + cvec_circular_lmsf (complex_vector_float.c:201-219)
-        const float ere = (tre - zre)*eq_delta;
-        const float eim = (tim - zim)*eq_delta;
-        const float *x = eqb2 + 2*eq_step*CPW;
-#pragma unroll
-        for (int i = 0;  i < kEqLen;  i++)
-        {
-            const float xr = x[2*i*CPW];
-            const float xi = x[(2*i + 1)*CPW];
-            cre[i] = cre[i]*0.9999f + (xi*eim + xr*ere);
-            cim[i] = cim[i]*0.9999f + (xr*eim - xi*ere);
-        }
+        do_tune = true;
+        tgt_re = tre;
+        tgt_im = tim;
     };
     auto put_bit = [&](int bit)
     {
@@ -469,11 +489,11 @@ void v29_bank_kernel(const V29Launch L)
         }
         const float tre = t_const[2*nearest];
         const float tim = t_const[2*nearest + 1];
-        track_carrier(zre, zim, tre, tim);
+        track_carrier(tre, tim);
         if (--eq_skip <= 0)
         {
             eq_skip = 10;
-            tune_equalizer(zre, zim, tre, tim);
+            tune_equalizer(tre, tim);
         }
         constellation_state = nearest;
     };
@@ -485,9 +505,61 @@ void v29_bank_kernel(const V29Launch L)
     };
 
     const int16_t *src = L.amp + (size_t) ch*L.stride;
-    for (int n = 0;  n < L.samples;  n++)
+    for (int tile = 0;  tile < L.samples;  tile += kPcmTile)
     {
-        const int amp = src[n];
+    const int tn = min(kPcmTile, L.samples - tile);
+    // ---- stage this lane's stretch of PCM: pcm[k][lane] = samples 2k, 2k+1 of the tile ----------------------
+    {
+        const int16_t *row = src + tile;
+        const bool wide = ((((uintptr_t) row) & 15) == 0)  &&  (tn == kPcmTile);
+        if (wide)
+        {
+#pragma unroll
+            for (int k = 0;  k < kPcmTile/8;  k++)
+            {
+                const int4 v = ((const int4 *) row)[k];
+                pcm[(4*k + 0)*CPW + lane] = (uint32_t) v.x;
+                pcm[(4*k + 1)*CPW + lane] = (uint32_t) v.y;
+                pcm[(4*k + 2)*CPW + lane] = (uint32_t) v.z;
+                pcm[(4*k + 3)*CPW + lane] = (uint32_t) v.w;
+            }
+        }
+        else
+        {
+            for (int k = 0;  k < (tn + 1)/2;  k++)
+            {
+                const uint32_t lo = (uint16_t) row[2*k];
+                const uint32_t hi = (2*k + 1 < tn)  ?  (uint16_t) row[2*k + 1]  :  0u;
+                pcm[k*CPW + lane] = lo | (hi << 16);
+            }
+        }
+    }
+    int pos = 0;
+    for (;;)
+    {
+    // One round = one BAUD of every lane: two T/2 instants (a lane that enters the round in the middle of its baud
+    // sits out the first), then the baud phase once, with all lanes in step.
+    bool any_ready = false;
+    bool baud_done = false;
+    float zre = 0.0f;
+    float zim = 0.0f;
+    for (int half = 0;  half < 2;  half++)
+    {
+    const bool take = (half == 1)  ||  (baud_half == 0);
+    // ---- phase A: every lane runs its own samples up to its next T/2 instant -------------------------------
+    bool ready = false;
+    int power = 0;
+    int step = 0;
+    float sre = 0.0f;
+    while (__any(take  &&  !ready  &&  pos < tn))
+    {
+    if (take  &&  !ready  &&  pos < tn)
+    {
+        const uint32_t pw = pcm[(pos >> 1)*CPW + lane];
+        const int amp = (int) (short) ((pos & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
+        pos++;
+        do
+        {
         // ---- v29_rx(), v29rx.c:885-961 --------------------------------------------------------
         RRC2(rrc_step) = (float) amp;
         RRC2(rrc_step + kRrcLen) = (float) amp;
@@ -495,7 +567,6 @@ void v29_bank_kernel(const V29Launch L)
             rrc_step = 0;
 
         // signal_detect(), v29rx.c:788-865 (with the IAXMODEM_STUFF this snapshot #defines)
-        int power;
         {
             const int x = amp >> 1;
             int diff = (int) (short) (x - last_sample);
@@ -549,15 +620,15 @@ void v29_bank_kernel(const V29Launch L)
             }
         }
         if (power == 0  ||  stage == V29_PARKED)
-            continue;
+            break;
 
         eq_put_step -= kRrcSets;
-        int step = -eq_put_step;
+        step = -eq_put_step;
         if (step < 0)
             step += kRrcSets;
         step = max(0, min(kRrcSets - 1, step));
         float v = rrc_dot(t_rrc_re, step);
-        const float sre = v*agc_scaling;
+        sre = v*agc_scaling;
         {
             // godard_ted_rx(), godard.c:144-162
             float t = glow0*g0 + glow1*g1 + sre;
@@ -568,7 +639,18 @@ void v29_bank_kernel(const V29Launch L)
             ghigh0 = t;
         }
         if (eq_put_step <= 0)
-        {
+            ready = true;
+        else
+            carrier_phase += (uint32_t) carrier_phase_rate;
+        }
+        while (0);
+    }
+    }
+    // ---- phase B: the T/2 instant, for all lanes that reached one ----------------------------------------------
+    if (ready)
+    {
+        any_ready = true;
+        float v;
             if (agc_scaling_save == 0.0f)
             {
                 // fixed_sqrt32(), math_fixed.c:158-169
@@ -594,15 +676,30 @@ void v29_bank_kernel(const V29Launch L)
             eq_put_step += kRrcSets*10/(3*2);
 
             // ---- process_half_baud(), v29rx.c:484-786 ----------------------------------------
-            EQB2(2*eq_step) = hre;
-            EQB2(2*eq_step + 1) = him;
-            EQB2(2*(eq_step + kEqLen)) = hre;
-            EQB2(2*(eq_step + kEqLen) + 1) = him;
+#pragma unroll
+            for (int i = 0;  i < kEqLen - 1;  i++)
+            {
+                xre[i] = xre[i + 1];
+                xim[i] = xim[i + 1];
+            }
+            xre[kEqLen - 1] = hre;
+            xim[kEqLen - 1] = him;
             if (++eq_step >= kEqLen)
                 eq_step = 0;
             baud_half ^= 1;
             if (baud_half == 0)
-            {
+                baud_done = true;
+        carrier_phase += (uint32_t) carrier_phase_rate;
+    }
+    }
+    if (!__any(any_ready))
+        break;
+    // ---- phase C: the baud, for every lane that completed one in this round ----------------------------------
+    // (the reference advances the carrier phase after process_half_baud(), with the rate the baud processing may just
+    // have changed; phase B already advanced it, so that advance is taken back here and redone at the end)
+    if (baud_done)
+    {
+        carrier_phase -= (uint32_t) carrier_phase_rate;
                 {
                     // godard_ted_per_baud(), godard.c:165-220
                     float cv = glow1*ghigh0*g2 - glow0*ghigh1*g5 + glow1*ghigh1*g6;
@@ -621,38 +718,39 @@ void v29_bank_kernel(const V29Launch L)
                     }
                 }
                 // equalizer_get(): cvec_circular_dot_prodf (complex_vector_float.c:137-196)
-                float zre;
-                float zim;
                 {
-                    const float *x = eqb2 + 2*eq_step*CPW;
                     const int split = kEqLen - eq_step;
-                    float are = 0.0f;
-                    float aim = 0.0f;
-                    float fre = 0.0f;
-                    float fim = 0.0f;
+                    float2 cs[kEqLen];
+#pragma unroll
+                    for (int i = 0;  i < kEqLen;  i++)
+                        cs[i] = TAP(i);
+                    f32x2v acc = f32x2v{0.0f, 0.0f};
+                    f32x2v fst = f32x2v{0.0f, 0.0f};
 #pragma unroll
                     for (int i = 0;  i < kEqLen;  i++)
                     {
                         if (i == split)
                         {
-                            fre = are;
-                            fim = aim;
-                            are = 0.0f;
-                            aim = 0.0f;
+                            fst = acc;
+                            acc = f32x2v{0.0f, 0.0f};
                         }
-                        const float xr = x[2*i*CPW];
-                        const float xi = x[(2*i + 1)*CPW];
-                        are += (xr*cre[i] - xi*cim[i]);
-                        aim += (xr*cim[i] + xi*cre[i]);
+                        // {xr*c.x - xi*c.y, xr*c.y + xi*c.x}: two packed products, a packed add with one negated half
+                        const f32x2v t1 = f32x2v{xre[i], xre[i]}*f32x2v{cs[i].x, cs[i].y};
+                        const f32x2v t2 = f32x2v{xim[i], xim[i]}*f32x2v{cs[i].y, cs[i].x};
+                        acc += t1 + f32x2v{-t2.x, t2.y};
                     }
-                    zre = fre + are;
-                    zim = fim + aim;
+                    zre = fst.x + acc.x;
+                    zim = fst.y + acc.y;
                 }
 
+                do_track = false;
+                do_tune = false;
+                do_save = false;
+                if (stage == V29_NORMAL  ||  stage == V29_TEST_ONES)
+                    decode_baud(zre, zim);
                 switch (stage)
                 {
                 case V29_NORMAL:
-                    decode_baud(zre, zim);
                     break;
                 case V29_SYMBOL_ACQUISITION:
                     if (++training_count >= 60)
@@ -700,16 +798,13 @@ void v29_bank_kernel(const V29Launch L)
                         const float p = ((uint32_t) angle)*2.0f*3.1415926f/(65536.0f*65536.0f);
                         const float zc = spg_sincosf(p, true);
                         const float zs = -spg_sincosf(p, false);
+#pragma unroll
                         for (int k = 0;  k < kEqLen;  k++)
                         {
-                            const float xr = EQB2(2*k);
-                            const float xi = EQB2(2*k + 1);
-                            const float nr = xr*zc - xi*zs;
-                            const float ni = xr*zs + xi*zc;
-                            EQB2(2*k) = nr;
-                            EQB2(2*k + 1) = ni;
-                            EQB2(2*(k + kEqLen)) = nr;
-                            EQB2(2*(k + kEqLen) + 1) = ni;
+                            const float xr = xre[k];
+                            const float xi = xim[k];
+                            xre[k] = xr*zc - xi*zs;
+                            xim[k] = xr*zs + xi*zc;
                         }
                         carrier_phase += (uint32_t) angle;
                         const int bit = scrambled_training_bit();
@@ -729,8 +824,8 @@ void v29_bank_kernel(const V29Launch L)
                     constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;
                     const float tre = t_const[2*constellation_state];
                     const float tim = t_const[2*constellation_state + 1];
-                    track_carrier(zre, zim, tre, tim);
-                    tune_equalizer(zre, zim, tre, tim);
+                    track_carrier(tre, tim);
+                    tune_equalizer(tre, tim);
                     if (++training_count >= 384 - 48)
                     {
                         stage = V29_TRAIN_ON_CDCD_AND_TEST;
@@ -746,8 +841,8 @@ void v29_bank_kernel(const V29Launch L)
                     constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;
                     const float tre = t_const[2*constellation_state];
                     const float tim = t_const[2*constellation_state + 1];
-                    track_carrier(zre, zim, tre, tim);
-                    tune_equalizer(zre, zim, tre, tim);
+                    track_carrier(tre, tim);
+                    tune_equalizer(tre, tim);
                     const float dre2 = zre - tre;
                     const float dim2 = zim - tim;
                     training_error += dre2*dre2 + dim2*dim2;
@@ -769,7 +864,6 @@ void v29_bank_kernel(const V29Launch L)
                 }
                 case V29_TEST_ONES:
                 {
-                    decode_baud(zre, zim);
                     const float tre = t_const[2*constellation_state];
                     const float tim = t_const[2*constellation_state + 1];
                     const float dre2 = zre - tre;
@@ -782,16 +876,7 @@ void v29_bank_kernel(const V29Launch L)
                             emit(-4);                       // SIG_STATUS_TRAINING_SUCCEEDED
                             signal_present = 60;
                             stage = V29_NORMAL;
-                            if (live)
-                            {
-#pragma unroll
-                                for (int k = 0;  k < kEqLen;  k++)
-                                {
-                                    stf(VF_EQ_SAVE + 2*k, cre[k]);
-                                    stf(VF_EQ_SAVE + 2*k + 1, cim[k]);
-                                }
-                            }
-                            carrier_phase_rate_save = carrier_phase_rate;
+                            do_save = true;                 // taps and carrier rate, once this baud's updates are in
                             agc_scaling_save = agc_scaling;
                         }
                         else
@@ -804,9 +889,41 @@ void v29_bank_kernel(const V29Launch L)
                 default:
                     break;
                 }
-            }
-        }
-        carrier_phase += (uint32_t) carrier_phase_rate;
+                if (do_track)
+                {
+                    const float error = zim*tgt_re - zre*tgt_im;
+                    carrier_phase_rate += v29_f2i(use_track_i*error);
+                    carrier_phase += (uint32_t) v29_f2i(use_track_p*error);
+                }
+                if (do_tune)
+                {
+                    // cvec_circular_lmsf (complex_vector_float.c:201-219)
+                    const float ere = (tgt_re - zre)*eq_delta;
+                    const float eim = (tgt_im - zim)*eq_delta;
+#pragma unroll
+                    for (int i = 0;  i < kEqLen;  i++)
+                    {
+                        const float2 c0 = TAP(i);
+                        // {xi*eim + xr*ere, xr*eim - xi*ere}
+                        const f32x2v u = f32x2v{xim[i], xre[i]}*f32x2v{eim, eim};
+                        const f32x2v w = f32x2v{xre[i], xim[i]}*f32x2v{ere, ere};
+                        const f32x2v c = f32x2v{c0.x, c0.y}*f32x2v{0.9999f, 0.9999f} + (u + f32x2v{w.x, -w.y});
+                        TAP(i) = make_float2(c.x, c.y);
+                    }
+                }
+                if (do_save)
+                {
+                    carrier_phase_rate_save = carrier_phase_rate;
+                    for (int k = 0;  k < kEqLen;  k++)
+                    {
+                        const float2 c = TAP(k);
+                        stf(VF_EQ_SAVE + 2*k, c.x);
+                        stf(VF_EQ_SAVE + 2*k + 1, c.y);
+                    }
+                }
+        carrier_phase += (uint32_t) carrier_phase_rate;     // dds_advancef() with the rate the baud left behind
+    }
+    }
     }
 
     // ---- write back -----------------------------------------------------------------------------
@@ -826,14 +943,20 @@ void v29_bank_kernel(const V29Launch L)
         stf(VF_BAUD_PHASE, baud_phase);
         for (int i = 0;  i < kRrcLen;  i++)
             stf(VF_RRC + i, RRC2(i));
+        for (int i = 0;  i < kEqLen;  i++)
+        {
+            const float2 c = TAP(i);
+            stf(VF_EQ_COEFF + 2*i, c.x);
+            stf(VF_EQ_COEFF + 2*i + 1, c.y);
+        }
 #pragma unroll
         for (int i = 0;  i < kEqLen;  i++)
         {
-            stf(VF_EQ_COEFF + 2*i, cre[i]);
-            stf(VF_EQ_COEFF + 2*i + 1, cim[i]);
+            int k = eq_step + i;
+            k = (k >= kEqLen)  ?  (k - kEqLen)  :  k;
+            stf(VF_EQ_BUF + 2*k, xre[i]);
+            stf(VF_EQ_BUF + 2*k + 1, xim[i]);
         }
-        for (int i = 0;  i < 2*kEqLen;  i++)
-            stf(VF_EQ_BUF + i, EQB2(i));
         sti(VI_RRC_STEP, rrc_step);
         sti(VI_SCRAMBLE, (int32_t) scramble_reg);
         sti(VI_TRAIN_SCRAMBLE, training_scramble_reg);
@@ -862,6 +985,6 @@ void v29_bank_kernel(const V29Launch L)
 }
 
 #undef RRC2
-#undef EQB2
+#undef TAP
 
 }   // namespace spg
