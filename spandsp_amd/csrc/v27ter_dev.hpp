@@ -80,7 +80,10 @@ void v27ter_bank_kernel(const V27Launch L)
     __shared__ float t_rrc_im[kV27MaxSets*kRrcLen];
     __shared__ float t_sine[2048];
     __shared__ uint16_t t_sqrt[194];
-    __shared__ float lanes[CPW*kV27LaneWords];
+    // per-lane RRC delay line (doubled) and PCM tile, index-major [word][CPW]; equaliser taps {re, im} [tap][lane]
+    __shared__ float lanes[CPW*2*kRrcLen];
+    __shared__ uint32_t pcm[CPW*(kPcmTile/2)];
+    __shared__ float2 taps[kV27EqLen*CPW];
 
     const int lane = threadIdx.x;
     const int ch = blockIdx.x*CPW + lane;
@@ -115,9 +118,9 @@ void v27ter_bank_kernel(const V27Launch L)
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV27Floats + w)*N + ch] = (uint32_t) v; };
 
     float *rrc2 = &lanes[lane];                         // [2*27] words, stride CPW
-    float *eqb2 = rrc2 + 2*kRrcLen*CPW;                 // [2*32][2] words, stride CPW
 #define RRC2(k)     rrc2[(k)*CPW]
-#define EQB2(k)     eqb2[(k)*CPW]
+    float2 *ctap = &taps[lane];
+#define TAP(i)      ctap[(i)*CPW]
     constexpr int EQN = kV27EqLen;
 
     float agc_scaling = ldf(WF_AGC);
@@ -132,19 +135,20 @@ void v27ter_bank_kernel(const V27Launch L)
         RRC2(i) = v;
         RRC2(kRrcLen + i) = v;
     }
-    float cre[EQN];
-    float cim[EQN];
-#pragma unroll
     for (int i = 0;  i < EQN;  i++)
+        TAP(i) = make_float2(ldf(WF_EQ_COEFF + 2*i), ldf(WF_EQ_COEFF + 2*i + 1));
+    // equaliser delay line in age order: xre[i] = eq_buf[(eq_step + i) mod 32] (i = 0 oldest)
+    float xre[EQN];
+    float xim[EQN];
     {
-        cre[i] = ldf(WF_EQ_COEFF + 2*i);
-        cim[i] = ldf(WF_EQ_COEFF + 2*i + 1);
-    }
-    for (int i = 0;  i < 2*EQN;  i++)
-    {
-        const float a = ldf(WF_EQ_BUF + i);
-        EQB2(i) = a;
-        EQB2(2*EQN + i) = a;
+        const int es = ldi(WI_EQ_STEP);
+#pragma unroll
+        for (int i = 0;  i < EQN;  i++)
+        {
+            const int k = (es + i) & (EQN - 1);
+            xre[i] = ldf(WF_EQ_BUF + 2*k);
+            xim[i] = ldf(WF_EQ_BUF + 2*k + 1);
+        }
     }
     int rrc_step = ldi(WI_RRC_STEP);
     uint32_t scramble_reg = (uint32_t) ldi(WI_SCRAMBLE);
@@ -210,15 +214,14 @@ void v27ter_bank_kernel(const V27Launch L)
         constellation_state = 0;
         carrier_phase_rate = v29_f2i(1800.0f*65536.0f*65536.0f/8000);
         agc_scaling = (1.414f/1.000000f)/283.0f;
+        for (int i = 0;  i < EQN;  i++)
+            TAP(i) = make_float2((i == 17)  ?  1.414f  :  0.0f, 0.0f);      // V27TER_EQUALIZER_PRE_LEN + 1
 #pragma unroll
         for (int i = 0;  i < EQN;  i++)
         {
-            cre[i] = 0.0f;
-            cim[i] = 0.0f;
+            xre[i] = 0.0f;
+            xim[i] = 0.0f;
         }
-        cre[17] = 1.414f;                                   // V27TER_EQUALIZER_PRE_LEN + 1
-        for (int i = 0;  i < 4*EQN;  i++)
-            EQB2(i) = 0.0f;
         eq_put_step = put_add;
         eq_step = 0;
         eq_skip = 0;
@@ -234,6 +237,14 @@ void v27ter_bank_kernel(const V27Launch L)
         const float *y = table + row;
         const float *x = rrc2 + rrc_step*CPW;
         const int split = kRrcLen - rrc_step;
+        float xs[kRrcLen];
+        float ys[kRrcLen];
+#pragma unroll
+        for (int i = 0;  i < kRrcLen;  i++)
+        {
+            xs[i] = x[i*CPW];
+            ys[i] = y[i*kV27MaxSets];
+        }
         float a = 0.0f;
         float first = 0.0f;
 #pragma unroll
@@ -244,29 +255,32 @@ void v27ter_bank_kernel(const V27Launch L)
                 first = a;
                 a = 0.0f;
             }
-            a += x[i*CPW]*y[i*kV27MaxSets];
+            a += xs[i]*ys[i];
         }
         return first + a;
     };
-    auto track_carrier = [&](float zre, float zim, float tre, float tim)
+    // track_carrier() and tune_equalizer() are requested by the stage logic and carried out once, after it, with the
+    // loop gains as they were when the reference would have called them (see v29_dev.hpp).
+    bool do_track = false;
+    bool do_tune = false;
+    bool do_save = false;
+    float tgt_re = 0.0f;
+    float tgt_im = 0.0f;
+    float use_track_i = 0.0f;
+    float use_track_p = 0.0f;
+    auto track_carrier = [&](float tre, float tim)
     {
-        const float error = zim*tre - zre*tim;
-        carrier_phase_rate += v29_f2i(carrier_track_i*error);
-        carrier_phase += (uint32_t) v29_f2i(carrier_track_p*error);
+        do_track = true;
+        tgt_re = tre;
+        tgt_im = tim;
+        use_track_i = carrier_track_i;
+        use_track_p = carrier_track_p;
     };
-    auto tune_equalizer = [&](float zre, float zim, float tre, float tim)
+    auto tune_equalizer = [&](float tre, float tim)
     {
-        const float ere = (tre - zre)*eq_delta;
-        const float eim = (tim - zim)*eq_delta;
-        const float *x = eqb2 + 2*eq_step*CPW;
-#pragma unroll
-        for (int i = 0;  i < EQN;  i++)
-        {
-            const float xr = x[2*i*CPW];
-            const float xi = x[(2*i + 1)*CPW];
-            cre[i] = cre[i]*0.9999f + (xi*eim + xr*ere);
-            cim[i] = cim[i]*0.9999f + (xr*eim - xi*ere);
-        }
+        do_tune = true;
+        tgt_re = tre;
+        tgt_im = tim;
     };
     // v27ter_rx.c:380-414
     auto descramble = [&](int in_bit)
@@ -354,11 +368,11 @@ void v27ter_bank_kernel(const V27Launch L)
         float tre;
         float tim;
         target_of(nearest, tre, tim);
-        track_carrier(zre, zim, tre, tim);
+        track_carrier(tre, tim);
         if (--eq_skip <= 0)
         {
             eq_skip = 100;
-            tune_equalizer(zre, zim, tre, tim);
+            tune_equalizer(tre, tim);
         }
     };
     auto park = [&]()
@@ -368,16 +382,64 @@ void v27ter_bank_kernel(const V27Launch L)
     };
 
     const int16_t *src = L.amp + (size_t) ch*L.stride;
-    for (int n = 0;  n < L.samples;  n++)
+    for (int tile = 0;  tile < L.samples;  tile += kPcmTile)
     {
-        const int amp = src[n];
+    const int tn = min(kPcmTile, L.samples - tile);
+    // ---- stage this lane's stretch of PCM: pcm[k][lane] = samples 2k, 2k+1 of the tile ----------------------
+    {
+        const int16_t *row = src + tile;
+        const bool wide = ((((uintptr_t) row) & 15) == 0)  &&  (tn == kPcmTile);
+        if (wide)
+        {
+#pragma unroll
+            for (int k = 0;  k < kPcmTile/8;  k++)
+            {
+                const int4 v = ((const int4 *) row)[k];
+                pcm[(4*k + 0)*CPW + lane] = (uint32_t) v.x;
+                pcm[(4*k + 1)*CPW + lane] = (uint32_t) v.y;
+                pcm[(4*k + 2)*CPW + lane] = (uint32_t) v.z;
+                pcm[(4*k + 3)*CPW + lane] = (uint32_t) v.w;
+            }
+        }
+        else
+        {
+            for (int k = 0;  k < (tn + 1)/2;  k++)
+            {
+                const uint32_t lo = (uint16_t) row[2*k];
+                const uint32_t hi = (2*k + 1 < tn)  ?  (uint16_t) row[2*k + 1]  :  0u;
+                pcm[k*CPW + lane] = lo | (hi << 16);
+            }
+        }
+    }
+    int pos = 0;
+    for (;;)
+    {
+    // One round = one baud of every lane (see v29_dev.hpp): two T/2 instants, then the baud phase with all lanes in step.
+    bool any_ready = false;
+    bool baud_done = false;
+    float zre = 0.0f;
+    float zim = 0.0f;
+    for (int half = 0;  half < 2;  half++)
+    {
+    const bool take = (half == 1)  ||  (baud_half == 0);
+    // ---- phase A: every lane runs its own samples up to its next T/2 instant (cheap here: no per-sample filter) ----
+    bool ready = false;
+    int power = 0;
+    while (__any(take  &&  !ready  &&  pos < tn))
+    {
+    if (take  &&  !ready  &&  pos < tn)
+    {
+        const uint32_t pw = pcm[(pos >> 1)*CPW + lane];
+        const int amp = (int) (short) ((pos & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
+        pos++;
+        do
+        {
         RRC2(rrc_step) = (float) amp;
         RRC2(rrc_step + kRrcLen) = (float) amp;
         if (++rrc_step >= kRrcLen)
             rrc_step = 0;
 
         // signal_detect(), v27ter_rx.c:779-861 (IAXMODEM_STUFF is #defined at v27ter_rx.c:1)
-        int power;
         {
             const int x = amp >> 1;
             int diff = (int) (short) (x - last_sample);
@@ -431,11 +493,21 @@ void v27ter_bank_kernel(const V27Launch L)
             }
         }
         if (power == 0  ||  stage == V27_PARKED)
-            continue;
+            break;
 
         eq_put_step -= sets;
         if (eq_put_step <= 0)
-        {
+            ready = true;
+        else
+            carrier_phase += (uint32_t) carrier_phase_rate;
+        }
+        while (0);
+    }
+    }
+    // ---- phase B: the T/2 instant, for all lanes that reached one ----------------------------------------------
+    if (ready)
+    {
+        any_ready = true;
             if (stage == V27_SYMBOL_ACQUISITION)
             {
                 int root_power;
@@ -462,24 +534,35 @@ void v27ter_bank_kernel(const V27Launch L)
             eq_put_step += put_add;
 
             // ---- process_half_baud(), v27ter_rx.c:531-777 ----
-            EQB2(2*eq_step) = hre;
-            EQB2(2*eq_step + 1) = him;
-            EQB2(2*(eq_step + EQN)) = hre;
-            EQB2(2*(eq_step + EQN) + 1) = him;
+#pragma unroll
+            for (int i = 0;  i < EQN - 1;  i++)
+            {
+                xre[i] = xre[i + 1];
+                xim[i] = xim[i + 1];
+            }
+            xre[EQN - 1] = hre;
+            xim[EQN - 1] = him;
             if (++eq_step >= EQN)
                 eq_step = 0;
             baud_half ^= 1;
             if (baud_half == 0)
-            {
+                baud_done = true;
+        carrier_phase += (uint32_t) carrier_phase_rate;
+    }
+    }
+    if (!__any(any_ready))
+        break;
+    // ---- phase C: the baud, for every lane that completed one in this round ----------------------------------
+    if (baud_done)
+    {
+        carrier_phase -= (uint32_t) carrier_phase_rate;
                 {
                     // symbol_sync(), v27ter_rx.c:486-528
-                    const int k3 = (eq_step - 3) & (EQN - 1);
-                    const int k2 = (eq_step - 2) & (EQN - 1);
-                    const int k1 = (eq_step - 1) & (EQN - 1);
-                    float p = EQB2(2*k3) - EQB2(2*k1);
-                    p *= EQB2(2*k2);
-                    float q = EQB2(2*k3 + 1) - EQB2(2*k1 + 1);
-                    q *= EQB2(2*k2 + 1);
+                    // eq_buf[(eq_step - 1, -2, -3) & 31] = the three newest entries of the delay line
+                    float p = xre[EQN - 3] - xre[EQN - 1];
+                    p *= xre[EQN - 2];
+                    float q = xim[EQN - 3] - xim[EQN - 1];
+                    q *= xim[EQN - 2];
                     gardner_integrate += (p + q > 0.0f)  ?  gardner_step  :  -gardner_step;
                     if (abs(gardner_integrate) >= 128)
                     {
@@ -488,38 +571,38 @@ void v27ter_bank_kernel(const V27Launch L)
                         gardner_integrate = 0;
                     }
                 }
-                float zre;
-                float zim;
                 {
-                    const float *x = eqb2 + 2*eq_step*CPW;
                     const int split = EQN - eq_step;
-                    float are = 0.0f;
-                    float aim = 0.0f;
-                    float fre = 0.0f;
-                    float fim = 0.0f;
+                    float2 cs[EQN];
+#pragma unroll
+                    for (int i = 0;  i < EQN;  i++)
+                        cs[i] = TAP(i);
+                    f32x2v acc = f32x2v{0.0f, 0.0f};
+                    f32x2v fst = f32x2v{0.0f, 0.0f};
 #pragma unroll
                     for (int i = 0;  i < EQN;  i++)
                     {
                         if (i == split)
                         {
-                            fre = are;
-                            fim = aim;
-                            are = 0.0f;
-                            aim = 0.0f;
+                            fst = acc;
+                            acc = f32x2v{0.0f, 0.0f};
                         }
-                        const float xr = x[2*i*CPW];
-                        const float xi = x[(2*i + 1)*CPW];
-                        are += (xr*cre[i] - xi*cim[i]);
-                        aim += (xr*cim[i] + xi*cre[i]);
+                        const f32x2v t1 = f32x2v{xre[i], xre[i]}*f32x2v{cs[i].x, cs[i].y};
+                        const f32x2v t2 = f32x2v{xim[i], xim[i]}*f32x2v{cs[i].y, cs[i].x};
+                        acc += t1 + f32x2v{-t2.x, t2.y};
                     }
-                    zre = fre + are;
-                    zim = fim + aim;
+                    zre = fst.x + acc.x;
+                    zim = fst.y + acc.y;
                 }
 
+                do_track = false;
+                do_tune = false;
+                do_save = false;
+                if (stage == V27_NORMAL  ||  stage == V27_TEST_ONES)
+                    decode_baud(zre, zim);
                 switch (stage)
                 {
                 case V27_NORMAL:
-                    decode_baud(zre, zim);
                     break;
                 case V27_SYMBOL_ACQUISITION:
                     if (++training_count >= 30)
@@ -569,16 +652,13 @@ void v27ter_bank_kernel(const V27Launch L)
                         const float p = ((uint32_t) angle)*2.0f*3.1415926f/(65536.0f*65536.0f);
                         const float zc = spg_sincosf(p, true);
                         const float zs = -spg_sincosf(p, false);
+#pragma unroll
                         for (int k = 0;  k < EQN;  k++)
                         {
-                            const float xr = EQB2(2*k);
-                            const float xi = EQB2(2*k + 1);
-                            const float nr = xr*zc - xi*zs;
-                            const float ni = xr*zs + xi*zc;
-                            EQB2(2*k) = nr;
-                            EQB2(2*k + 1) = ni;
-                            EQB2(2*(k + EQN)) = nr;
-                            EQB2(2*(k + EQN) + 1) = ni;
+                            const float xr = xre[k];
+                            const float xi = xim[k];
+                            xre[k] = xr*zc - xi*zs;
+                            xim[k] = xr*zs + xi*zc;
                         }
                         carrier_phase += (uint32_t) angle;
                         gardner_step = 2;
@@ -604,8 +684,8 @@ void v27ter_bank_kernel(const V27Launch L)
                     descramble(1);
                     constellation_state = training_bc  ?  4  :  0;
                     const float tre = training_bc  ?  -1.414f  :  1.414f;
-                    track_carrier(zre, zim, tre, 0.0f);
-                    tune_equalizer(zre, zim, tre, 0.0f);
+                    track_carrier(tre, 0.0f);
+                    tune_equalizer(tre, 0.0f);
                     carrier_track_i = 400.0f + (200000.0f - 400.0f)*(float) (1074 - training_count)/(float) 1074;
                     carrier_track_p = 1000000.0f + (10000000.0f - 1000000.0f)*(float) (1074 - training_count)/(float) 1074;
                     if (++training_count >= 1074)
@@ -618,7 +698,6 @@ void v27ter_bank_kernel(const V27Launch L)
                 }
                 case V27_TEST_ONES:
                 {
-                    decode_baud(zre, zim);
                     float tre;
                     float tim;
                     target_of(fast  ?  constellation_state  :  (constellation_state << 1), tre, tim);
@@ -632,13 +711,7 @@ void v27ter_bank_kernel(const V27Launch L)
                             emit(-4);                       // SIG_STATUS_TRAINING_SUCCEEDED
                             signal_present = fast  ?  90  :  120;
                             stage = V27_NORMAL;
-#pragma unroll
-                            for (int k = 0;  k < EQN;  k++)
-                            {
-                                stf(WF_EQ_SAVE + 2*k, cre[k]);
-                                stf(WF_EQ_SAVE + 2*k + 1, cim[k]);
-                            }
-                            carrier_phase_rate_save = carrier_phase_rate;
+                            do_save = true;                 // taps and carrier rate, once this baud's updates are in
                             agc_scaling_save = agc_scaling;
                         }
                         else
@@ -651,9 +724,39 @@ void v27ter_bank_kernel(const V27Launch L)
                 default:
                     break;
                 }
-            }
-        }
-        carrier_phase += (uint32_t) carrier_phase_rate;
+                if (do_track)
+                {
+                    const float error = zim*tgt_re - zre*tgt_im;
+                    carrier_phase_rate += v29_f2i(use_track_i*error);
+                    carrier_phase += (uint32_t) v29_f2i(use_track_p*error);
+                }
+                if (do_tune)
+                {
+                    const float ere = (tgt_re - zre)*eq_delta;
+                    const float eim = (tgt_im - zim)*eq_delta;
+#pragma unroll
+                    for (int i = 0;  i < EQN;  i++)
+                    {
+                        const float2 c0 = TAP(i);
+                        const f32x2v u = f32x2v{xim[i], xre[i]}*f32x2v{eim, eim};
+                        const f32x2v w = f32x2v{xre[i], xim[i]}*f32x2v{ere, ere};
+                        const f32x2v c = f32x2v{c0.x, c0.y}*f32x2v{0.9999f, 0.9999f} + (u + f32x2v{w.x, -w.y});
+                        TAP(i) = make_float2(c.x, c.y);
+                    }
+                }
+                if (do_save)
+                {
+                    carrier_phase_rate_save = carrier_phase_rate;
+                    for (int k = 0;  k < EQN;  k++)
+                    {
+                        const float2 c = TAP(k);
+                        stf(WF_EQ_SAVE + 2*k, c.x);
+                        stf(WF_EQ_SAVE + 2*k + 1, c.y);
+                    }
+                }
+        carrier_phase += (uint32_t) carrier_phase_rate;     // dds_advancef() with the rate the baud left behind
+    }
+    }
     }
 
     stf(WF_AGC, agc_scaling);
@@ -663,14 +766,19 @@ void v27ter_bank_kernel(const V27Launch L)
     stf(WF_TRACK_I, carrier_track_i);
     for (int i = 0;  i < kRrcLen;  i++)
         stf(WF_RRC + i, RRC2(i));
+    for (int i = 0;  i < EQN;  i++)
+    {
+        const float2 c = TAP(i);
+        stf(WF_EQ_COEFF + 2*i, c.x);
+        stf(WF_EQ_COEFF + 2*i + 1, c.y);
+    }
 #pragma unroll
     for (int i = 0;  i < EQN;  i++)
     {
-        stf(WF_EQ_COEFF + 2*i, cre[i]);
-        stf(WF_EQ_COEFF + 2*i + 1, cim[i]);
+        const int k = (eq_step + i) & (EQN - 1);
+        stf(WF_EQ_BUF + 2*k, xre[i]);
+        stf(WF_EQ_BUF + 2*k + 1, xim[i]);
     }
-    for (int i = 0;  i < 2*EQN;  i++)
-        stf(WF_EQ_BUF + i, EQB2(i));
     sti(WI_RRC_STEP, rrc_step);
     sti(WI_SCRAMBLE, (int32_t) scramble_reg);
     sti(WI_PATTERN_COUNT, pattern_count);
@@ -698,7 +806,7 @@ void v27ter_bank_kernel(const V27Launch L)
     sti(WI_LAST_ANGLES + 1, last_angle1);
     L.ev_count[ch] = n_ev;
 #undef RRC2
-#undef EQB2
+#undef TAP
 }
 
 }   // namespace spg
