@@ -90,7 +90,10 @@ void v17_bank_kernel(const V17Launch L)
     __shared__ float t_con[256];
     __shared__ uint32_t t_map[36*36*2];
     __shared__ uint16_t t_sqrt[194];
-    __shared__ float lanes[CPW*kV17LaneWords];
+    // per-lane RRC delay line (doubled) + survivor memory, PCM tile, equaliser taps: all index-major [word][CPW]
+    __shared__ float lanes[CPW*(2*kRrcLen + 16 + 32)];
+    __shared__ uint32_t pcm[CPW*(kPcmTile/2)];
+    __shared__ float2 taps[kEqLen*CPW];
 
     const int lane = threadIdx.x;
     const int ch = blockIdx.x*CPW + lane;
@@ -134,11 +137,11 @@ void v17_bank_kernel(const V17Launch L)
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV17Floats + w)*N + ch] = (uint32_t) v; };
 
     float *rrc2 = &lanes[lane];                         // [2*27] words, stride CPW
-    float *eqb2 = rrc2 + 2*kRrcLen*CPW;                 // [2*33][2]
-    uint32_t *past = (uint32_t *) (eqb2 + 4*kEqLen*CPW);   // [16]: 8 x 3 bit predecessor states per time step
+    uint32_t *past = (uint32_t *) (rrc2 + 2*kRrcLen*CPW);  // [16]: 8 x 3 bit predecessor states per time step
     uint32_t *full = past + 16*CPW;                     // [16][2]: 8 x 1 byte surviving points per time step
 #define RRC2(k)     rrc2[(k)*CPW]
-#define EQB2(k)     eqb2[(k)*CPW]
+    float2 *ctap = &taps[lane];
+#define TAP(i)      ctap[(i)*CPW]
 #define PAST(t)     past[(t)*CPW]
 #define FULL(t, h)  full[(2*(t) + (h))*CPW]
 
@@ -161,19 +164,21 @@ void v17_bank_kernel(const V17Launch L)
         RRC2(i) = v;
         RRC2(kRrcLen + i) = v;
     }
-    float cre[kEqLen];
-    float cim[kEqLen];
-#pragma unroll
     for (int i = 0;  i < kEqLen;  i++)
+        TAP(i) = make_float2(ldf(VF_EQ_COEFF + 2*i), ldf(VF_EQ_COEFF + 2*i + 1));
+    // equaliser delay line in age order: xre[i] = eq_buf[(eq_step + i) mod 33] (i = 0 oldest)
+    float xre[kEqLen];
+    float xim[kEqLen];
     {
-        cre[i] = ldf(VF_EQ_COEFF + 2*i);
-        cim[i] = ldf(VF_EQ_COEFF + 2*i + 1);
-    }
-    for (int i = 0;  i < 2*kEqLen;  i++)
-    {
-        const float a = ldf(VF_EQ_BUF + i);
-        EQB2(i) = a;
-        EQB2(2*kEqLen + i) = a;
+        const int es = ldi(XI_EQ_STEP);
+#pragma unroll
+        for (int i = 0;  i < kEqLen;  i++)
+        {
+            int k = es + i;
+            k = (k >= kEqLen)  ?  (k - kEqLen)  :  k;
+            xre[i] = ldf(VF_EQ_BUF + 2*k);
+            xim[i] = ldf(VF_EQ_BUF + 2*k + 1);
+        }
     }
     float sd[8];
 #pragma unroll
@@ -266,20 +271,20 @@ void v17_bank_kernel(const V17Launch L)
         trellis_ptr = 14;
         carrier_phase = 0;
         power_reading = 0;
-        for (int i = 0;  i < 4*kEqLen;  i++)
-            EQB2(i) = 0.0f;
+#pragma unroll
+        for (int i = 0;  i < kEqLen;  i++)
+        {
+            xre[i] = 0.0f;
+            xim[i] = 0.0f;
+        }
         eq_put_step = kV17Sets*10/(3*2) - 1;
         eq_step = 0;
         eq_skip = 0;
         if (short_train)
         {
             carrier_phase_rate = carrier_phase_rate_save;
-#pragma unroll
             for (int i = 0;  i < kEqLen;  i++)
-            {
-                cre[i] = ldf(VF_EQ_SAVE + 2*i);
-                cim[i] = ldf(VF_EQ_SAVE + 2*i + 1);
-            }
+                TAP(i) = make_float2(ldf(VF_EQ_SAVE + 2*i), ldf(VF_EQ_SAVE + 2*i + 1));
             eq_delta = 0.1f*(0.21f/kEqLen);
             agc_scaling = agc_scaling_save;
             carrier_track_i = 0.0f;
@@ -288,13 +293,8 @@ void v17_bank_kernel(const V17Launch L)
         else
         {
             carrier_phase_rate = v29_f2i(1800.0f*65536.0f*65536.0f/8000);
-#pragma unroll
             for (int i = 0;  i < kEqLen;  i++)
-            {
-                cre[i] = 0.0f;
-                cim[i] = 0.0f;
-            }
-            cre[16] = 3.0f;
+                TAP(i) = make_float2((i == 16)  ?  3.0f  :  0.0f, 0.0f);
             eq_delta = 0.21f/kEqLen;
             agc_scaling_save = 0.0f;
             agc_scaling = (2.17f/1.000000f)/735.0f;
@@ -313,6 +313,14 @@ void v17_bank_kernel(const V17Launch L)
         const float *y = table + row;
         const float *x = rrc2 + rrc_step*CPW;
         const int split = kRrcLen - rrc_step;
+        float xs[kRrcLen];
+        float ys[kRrcLen];
+#pragma unroll
+        for (int i = 0;  i < kRrcLen;  i++)
+        {
+            xs[i] = x[i*CPW];
+            ys[i] = y[i*kV17Sets];
+        }
         float a = 0.0f;
         float first = 0.0f;
 #pragma unroll
@@ -323,29 +331,34 @@ void v17_bank_kernel(const V17Launch L)
                 first = a;
                 a = 0.0f;
             }
-            a += x[i*CPW]*y[i*kV17Sets];
+            a += xs[i]*ys[i];
         }
         return first + a;
     };
-    auto track_carrier = [&](float zre, float zim, float tre, float tim)
+    // track_carrier() and tune_equalizer() are requested by the stage logic and carried out once, after it, with the
+    // loop gains and step size as they were when the reference would have called them (see v29_dev.hpp).
+    bool do_track = false;
+    bool do_tune = false;
+    bool do_save = false;
+    float tgt_re = 0.0f;
+    float tgt_im = 0.0f;
+    float use_track_i = 0.0f;
+    float use_track_p = 0.0f;
+    float use_delta = 0.0f;
+    auto track_carrier = [&](float tre, float tim)
     {
-        const float error = zim*tre - zre*tim;
-        carrier_phase_rate += v29_f2i(carrier_track_i*error);
-        carrier_phase += (uint32_t) v29_f2i(carrier_track_p*error);
+        do_track = true;
+        tgt_re = tre;
+        tgt_im = tim;
+        use_track_i = carrier_track_i;
+        use_track_p = carrier_track_p;
     };
-    auto tune_equalizer = [&](float zre, float zim, float tre, float tim)
+    auto tune_equalizer = [&](float tre, float tim)
     {
-        const float ere = (tre - zre)*eq_delta;
-        const float eim = (tim - zim)*eq_delta;
-        const float *x = eqb2 + 2*eq_step*CPW;
-#pragma unroll
-        for (int i = 0;  i < kEqLen;  i++)
-        {
-            const float xr = x[2*i*CPW];
-            const float xi = x[(2*i + 1)*CPW];
-            cre[i] = cre[i]*0.9999f + (xi*eim + xr*ere);
-            cim[i] = cim[i]*0.9999f + (xr*eim - xi*ere);
-        }
+        do_tune = true;
+        tgt_re = tre;
+        tgt_im = tim;
+        use_delta = eq_delta;
     };
     // v17rx.c:336-349 (scrambler_tap is 18 - 1: v17_rx_init never changes it)
     auto descramble = [&](int in_bit)
@@ -373,16 +386,13 @@ void v17_bank_kernel(const V17Launch L)
         const float p = phase_step*2.0f*3.1415926f/(65536.0f*65536.0f);
         const float zc = spg_sincosf(p, true);
         const float zs = -spg_sincosf(p, false);
+#pragma unroll
         for (int k = 0;  k < kEqLen;  k++)
         {
-            const float xr = EQB2(2*k);
-            const float xi = EQB2(2*k + 1);
-            const float nr = xr*zc - xi*zs;
-            const float ni = xr*zs + xi*zc;
-            EQB2(2*k) = nr;
-            EQB2(2*k + 1) = ni;
-            EQB2(2*(k + kEqLen)) = nr;
-            EQB2(2*(k + kEqLen) + 1) = ni;
+            const float xr = xre[k];
+            const float xi = xim[k];
+            xre[k] = xr*zc - xi*zs;
+            xim[k] = xr*zs + xi*zc;
         }
         carrier_phase += phase_step;
     };
@@ -437,7 +447,7 @@ void v17_bank_kernel(const V17Launch L)
                 cs = cell[i];
             }
         }
-        track_carrier(zre, zim, t_con[2*cs], t_con[2*cs + 1]);
+        track_carrier(t_con[2*cs], t_con[2*cs + 1]);
 
         if (++trellis_ptr >= 16)
             trellis_ptr = 0;
@@ -514,16 +524,66 @@ void v17_bank_kernel(const V17Launch L)
     };
 
     const int16_t *src = L.amp + (size_t) ch*L.stride;
-    for (int n = 0;  n < L.samples;  n++)
+    for (int tile = 0;  tile < L.samples;  tile += kPcmTile)
     {
-        const int amp = src[n];
+    const int tn = min(kPcmTile, L.samples - tile);
+    // ---- stage this lane's stretch of PCM: pcm[k][lane] = samples 2k, 2k+1 of the tile ----------------------
+    {
+        const int16_t *row = src + tile;
+        const bool wide = ((((uintptr_t) row) & 15) == 0)  &&  (tn == kPcmTile);
+        if (wide)
+        {
+#pragma unroll
+            for (int k = 0;  k < kPcmTile/8;  k++)
+            {
+                const int4 v = ((const int4 *) row)[k];
+                pcm[(4*k + 0)*CPW + lane] = (uint32_t) v.x;
+                pcm[(4*k + 1)*CPW + lane] = (uint32_t) v.y;
+                pcm[(4*k + 2)*CPW + lane] = (uint32_t) v.z;
+                pcm[(4*k + 3)*CPW + lane] = (uint32_t) v.w;
+            }
+        }
+        else
+        {
+            for (int k = 0;  k < (tn + 1)/2;  k++)
+            {
+                const uint32_t lo = (uint16_t) row[2*k];
+                const uint32_t hi = (2*k + 1 < tn)  ?  (uint16_t) row[2*k + 1]  :  0u;
+                pcm[k*CPW + lane] = lo | (hi << 16);
+            }
+        }
+    }
+    int pos = 0;
+    for (;;)
+    {
+    // One round = one baud of every lane (see v29_dev.hpp): two T/2 instants, then the baud phase with all lanes in step.
+    bool any_ready = false;
+    bool baud_done = false;
+    float zre = 0.0f;
+    float zim = 0.0f;
+    for (int half = 0;  half < 2;  half++)
+    {
+    const bool take = (half == 1)  ||  (baud_half == 0);
+    // ---- phase A: every lane runs its own samples up to its next T/2 instant -------------------------------
+    bool ready = false;
+    int power = 0;
+    int step = 0;
+    float sre = 0.0f;
+    while (__any(take  &&  !ready  &&  pos < tn))
+    {
+    if (take  &&  !ready  &&  pos < tn)
+    {
+        const uint32_t pw = pcm[(pos >> 1)*CPW + lane];
+        const int amp = (int) (short) ((pos & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
+        pos++;
+        do
+        {
         RRC2(rrc_step) = (float) amp;
         RRC2(rrc_step + kRrcLen) = (float) amp;
         if (++rrc_step >= kRrcLen)
             rrc_step = 0;
 
         // signal_detect(), v17rx.c:1133-1210 (IAXMODEM_STUFF is #defined at v17rx.c:1)
-        int power;
         {
             const int x = amp >> 1;
             int d = (int) (short) (x - last_sample);
@@ -577,15 +637,15 @@ void v17_bank_kernel(const V17Launch L)
             }
         }
         if (power == 0  ||  stage == V17_PARKED)
-            continue;
+            break;
 
         eq_put_step -= kV17Sets;
-        int step = -eq_put_step;
+        step = -eq_put_step;
         if (step < 0)
             step += kV17Sets;
         step = max(0, min(kV17Sets - 1, step));
         float v = rrc_dot(g_rrc_re, step);
-        const float sre = v*agc_scaling;
+        sre = v*agc_scaling;
         {
             float t = glow0*g0 + glow1*g1 + sre;
             glow1 = glow0;
@@ -595,7 +655,18 @@ void v17_bank_kernel(const V17Launch L)
             ghigh0 = t;
         }
         if (eq_put_step <= 0)
-        {
+            ready = true;
+        else
+            carrier_phase += (uint32_t) carrier_phase_rate;
+        }
+        while (0);
+    }
+    }
+    // ---- phase B: the T/2 instant, for all lanes that reached one ----------------------------------------------
+    if (ready)
+    {
+        any_ready = true;
+        float v;
             if (agc_scaling_save == 0.0f)
             {
                 int root_power;
@@ -619,15 +690,28 @@ void v17_bank_kernel(const V17Launch L)
             eq_put_step += kV17Sets*10/(3*2);
 
             // ---- process_half_baud(), v17rx.c:592-1130 ----
-            EQB2(2*eq_step) = hre;
-            EQB2(2*eq_step + 1) = him;
-            EQB2(2*(eq_step + kEqLen)) = hre;
-            EQB2(2*(eq_step + kEqLen) + 1) = him;
+#pragma unroll
+            for (int i = 0;  i < kEqLen - 1;  i++)
+            {
+                xre[i] = xre[i + 1];
+                xim[i] = xim[i + 1];
+            }
+            xre[kEqLen - 1] = hre;
+            xim[kEqLen - 1] = him;
             if (++eq_step >= kEqLen)
                 eq_step = 0;
             baud_half ^= 1;
             if (baud_half == 0)
-            {
+                baud_done = true;
+        carrier_phase += (uint32_t) carrier_phase_rate;
+    }
+    }
+    if (!__any(any_ready))
+        break;
+    // ---- phase C: the baud, for every lane that completed one in this round ----------------------------------
+    if (baud_done)
+    {
+        carrier_phase -= (uint32_t) carrier_phase_rate;
                 {
                     float cv = glow1*ghigh0*g2 - glow0*ghigh1*g5 + glow1*ghigh1*g6;
                     const float p = cv - gdc1;
@@ -644,40 +728,41 @@ void v17_bank_kernel(const V17Launch L)
                         eq_put_step += i;
                     }
                 }
-                float zre;
-                float zim;
                 {
-                    const float *x = eqb2 + 2*eq_step*CPW;
                     const int split = kEqLen - eq_step;
-                    float are = 0.0f;
-                    float aim = 0.0f;
-                    float fre = 0.0f;
-                    float fim = 0.0f;
+                    float2 cs_[kEqLen];
+#pragma unroll
+                    for (int i = 0;  i < kEqLen;  i++)
+                        cs_[i] = TAP(i);
+                    f32x2v acc = f32x2v{0.0f, 0.0f};
+                    f32x2v fst = f32x2v{0.0f, 0.0f};
 #pragma unroll
                     for (int i = 0;  i < kEqLen;  i++)
                     {
                         if (i == split)
                         {
-                            fre = are;
-                            fim = aim;
-                            are = 0.0f;
-                            aim = 0.0f;
+                            fst = acc;
+                            acc = f32x2v{0.0f, 0.0f};
                         }
-                        const float xr = x[2*i*CPW];
-                        const float xi = x[(2*i + 1)*CPW];
-                        are += (xr*cre[i] - xi*cim[i]);
-                        aim += (xr*cim[i] + xi*cre[i]);
+                        const f32x2v t1 = f32x2v{xre[i], xre[i]}*f32x2v{cs_[i].x, cs_[i].y};
+                        const f32x2v t2 = f32x2v{xim[i], xim[i]}*f32x2v{cs_[i].y, cs_[i].x};
+                        acc += t1 + f32x2v{-t2.x, t2.y};
                     }
-                    zre = fre + are;
-                    zim = fim + aim;
+                    zre = fst.x + acc.x;
+                    zim = fst.y + acc.y;
                 }
 
                 float tre;
                 float tim;
+                do_track = false;
+                do_tune = false;
+                do_save = false;
+                int cs = 0;
+                if (stage == V17_NORMAL  ||  stage == V17_TCM_WINDUP  ||  stage == V17_TEST_ONES)
+                    cs = decode_baud(zre, zim);
                 switch (stage)
                 {
                 case V17_NORMAL:
-                    decode_baud(zre, zim);
                     break;
                 case V17_SYMBOL_ACQUISITION:
                     if (++training_count >= 100)
@@ -761,8 +846,8 @@ void v17_bank_kernel(const V17Launch L)
                     int bit = descramble(1);
                     bit = (bit << 1) | descramble(1);
                     cdba(bit, tre, tim);
-                    track_carrier(zre, zim, tre, tim);
-                    tune_equalizer(zre, zim, tre, tim);
+                    track_carrier(tre, tim);
+                    tune_equalizer(tre, tim);
                     const float ere = zre - tre;
                     const float eim = zim - tim;
                     training_error = ere*ere + eim*eim;
@@ -779,8 +864,8 @@ void v17_bank_kernel(const V17Launch L)
                     int bit = descramble(1);
                     bit = (bit << 1) | descramble(1);
                     cdba(bit, tre, tim);
-                    track_carrier(zre, zim, tre, tim);
-                    tune_equalizer(zre, zim, tre, tim);
+                    track_carrier(tre, tim);
+                    tune_equalizer(tre, tim);
                     if (++training_count >= 2976 - 48)
                     {
                         training_error = 0.0f;
@@ -797,8 +882,8 @@ void v17_bank_kernel(const V17Launch L)
                     cdba(bit, tre, tim);
                     if (++training_count < 2976 - 20)
                     {
-                        track_carrier(zre, zim, tre, tim);
-                        tune_equalizer(zre, zim, tre, tim);
+                        track_carrier(tre, tim);
+                        tune_equalizer(tre, tim);
                         const float ere = zre - tre;
                         const float eim = zim - tim;
                         training_error += (ere*ere + eim*eim);
@@ -852,7 +937,7 @@ void v17_bank_kernel(const V17Launch L)
                     else
                     {
                         cdba((training_count & 1) + 2, tre, tim);
-                        track_carrier(zre, zim, tre, tim);
+                        track_carrier(tre, tim);
                         if (++training_count > 256)
                             park(false);
                     }
@@ -863,7 +948,7 @@ void v17_bank_kernel(const V17Launch L)
                     int bit = descramble(1);
                     bit = (bit << 1) | descramble(1);
                     cdba(bit, tre, tim);
-                    track_carrier(zre, zim, tre, tim);
+                    track_carrier(tre, tim);
                     if (training_count > 8)
                     {
                         const float ere = zre - tre;
@@ -898,7 +983,6 @@ void v17_bank_kernel(const V17Launch L)
                 }
                 case V17_TCM_WINDUP:
                 {
-                    const int cs = decode_baud(zre, zim);
                     const float ere = zre - t_con[2*cs];
                     const float eim = zim - t_con[2*cs + 1];
                     training_error += (ere*ere + eim*eim);
@@ -913,7 +997,6 @@ void v17_bank_kernel(const V17Launch L)
                 }
                 case V17_TEST_ONES:
                 {
-                    const int cs = decode_baud(zre, zim);
                     const float ere = zre - t_con[2*cs];
                     const float eim = zim - t_con[2*cs + 1];
                     training_error += (ere*ere + eim*eim);
@@ -923,13 +1006,7 @@ void v17_bank_kernel(const V17Launch L)
                         {
                             emit(-4);                       // SIG_STATUS_TRAINING_SUCCEEDED
                             signal_present = 60;
-#pragma unroll
-                            for (int k = 0;  k < kEqLen;  k++)
-                            {
-                                stf(VF_EQ_SAVE + 2*k, cre[k]);
-                                stf(VF_EQ_SAVE + 2*k + 1, cim[k]);
-                            }
-                            carrier_phase_rate_save = carrier_phase_rate;
+                            do_save = true;                 // taps and carrier rate, once this baud's updates are in
                             short_train = 1;
                             stage = V17_NORMAL;
                         }
@@ -943,9 +1020,39 @@ void v17_bank_kernel(const V17Launch L)
                 default:
                     break;
                 }
-            }
-        }
-        carrier_phase += (uint32_t) carrier_phase_rate;
+                if (do_track)
+                {
+                    const float error = zim*tgt_re - zre*tgt_im;
+                    carrier_phase_rate += v29_f2i(use_track_i*error);
+                    carrier_phase += (uint32_t) v29_f2i(use_track_p*error);
+                }
+                if (do_tune)
+                {
+                    const float ere = (tgt_re - zre)*use_delta;
+                    const float eim = (tgt_im - zim)*use_delta;
+#pragma unroll
+                    for (int i = 0;  i < kEqLen;  i++)
+                    {
+                        const float2 c0 = TAP(i);
+                        const f32x2v u = f32x2v{xim[i], xre[i]}*f32x2v{eim, eim};
+                        const f32x2v w = f32x2v{xre[i], xim[i]}*f32x2v{ere, ere};
+                        const f32x2v c = f32x2v{c0.x, c0.y}*f32x2v{0.9999f, 0.9999f} + (u + f32x2v{w.x, -w.y});
+                        TAP(i) = make_float2(c.x, c.y);
+                    }
+                }
+                if (do_save)
+                {
+                    carrier_phase_rate_save = carrier_phase_rate;
+                    for (int k = 0;  k < kEqLen;  k++)
+                    {
+                        const float2 c = TAP(k);
+                        stf(VF_EQ_SAVE + 2*k, c.x);
+                        stf(VF_EQ_SAVE + 2*k + 1, c.y);
+                    }
+                }
+        carrier_phase += (uint32_t) carrier_phase_rate;     // dds_advancef() with the rate the baud left behind
+    }
+    }
     }
 
     stf(VF_AGC, agc_scaling);
@@ -963,14 +1070,20 @@ void v17_bank_kernel(const V17Launch L)
     stf(VF_BAUD_PHASE, baud_phase);
     for (int i = 0;  i < kRrcLen;  i++)
         stf(VF_RRC + i, RRC2(i));
+    for (int i = 0;  i < kEqLen;  i++)
+    {
+        const float2 c = TAP(i);
+        stf(VF_EQ_COEFF + 2*i, c.x);
+        stf(VF_EQ_COEFF + 2*i + 1, c.y);
+    }
 #pragma unroll
     for (int i = 0;  i < kEqLen;  i++)
     {
-        stf(VF_EQ_COEFF + 2*i, cre[i]);
-        stf(VF_EQ_COEFF + 2*i + 1, cim[i]);
+        int k = eq_step + i;
+        k = (k >= kEqLen)  ?  (k - kEqLen)  :  k;
+        stf(VF_EQ_BUF + 2*k, xre[i]);
+        stf(VF_EQ_BUF + 2*k + 1, xim[i]);
     }
-    for (int i = 0;  i < 2*kEqLen;  i++)
-        stf(VF_EQ_BUF + i, EQB2(i));
 #pragma unroll
     for (int i = 0;  i < 8;  i++)
         stf(XF_DIST + i, sd[i]);
@@ -1010,7 +1123,7 @@ void v17_bank_kernel(const V17Launch L)
     sti(XI_TOTAL_CORR, total_corr);
     L.ev_count[ch] = n_ev;
 #undef RRC2
-#undef EQB2
+#undef TAP
 #undef PAST
 #undef FULL
 }
