@@ -1,6 +1,7 @@
 // v17_dev.hpp -- device side of the batched V.17 (and V.32bis 4800) receiver (reference: src/v17rx.c:214-1358;
-// primitives as in v29_dev.hpp).  Same mapping as the V.29 bank -- one channel per lane, delay lines index-major in
-// LDS, equaliser taps in VGPRs, reference summation order -- plus what V.17 adds:
+// primitives as in v29_dev.hpp).  Same mapping and baud-aligned execution as the V.29 bank -- one channel per lane,
+// RRC delay line / PCM tile / equaliser taps index-major in LDS, equaliser delay line in VGPRs in age order, reference
+// summation order -- plus what V.17 adds:
 //   * the 8-state trellis decoder (v17rx.c:396-589): accumulated path metrics in VGPRs, the 16-deep survivor memory
 //     packed in LDS per lane (3 bits per predecessor state, 1 byte per surviving point), traceback as 15 dependent
 //     LDS reads per baud;
@@ -21,7 +22,6 @@ constexpr int kV17Floats = 246;
 constexpr int kV17Ints = 301;
 constexpr int kV17Words = kV17Floats + kV17Ints;
 constexpr int kV17Sets = 192;
-constexpr int kV17LaneWords = 2*kRrcLen + 4*kEqLen + 16 + 32;      // delay lines + survivor memory = 234
 
 // State word map: floats 0-237 as the V.29 map (v29_dev.hpp), 238-245 trellis distances[8];
 //   ints: 0 bit_rate, 1 rrc_filter_step, 2 diff, 3 scramble_reg, 4 scrambler_tap, 5 short_train, 6 training_stage,

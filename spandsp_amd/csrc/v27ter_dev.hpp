@@ -1,6 +1,7 @@
 // v27ter_dev.hpp -- device side of the batched V.27ter receiver (reference: src/v27ter_rx.c:197-1028;
-// primitives as in v29_dev.hpp).  Same mapping as the V.29 bank: one channel per lane, per-lane
-// delay lines index-major in LDS, equaliser taps in VGPRs, the reference's summation order kept.
+// primitives as in v29_dev.hpp).  Same mapping and baud-aligned execution as the V.29 bank: one channel per lane,
+// RRC delay line, PCM tile and equaliser taps index-major in LDS, the equaliser delay line in VGPRs in age order, the
+// reference's summation order kept.
 // Differences from V.29 that shape the kernel: the pulse-shaping filter only runs at the T/2
 // instants (no per-sample timing-error filter; symbol timing is a Gardner detector on the
 // equaliser delay line), 32 taps, an 8-point PSK slicer, and a descrambler with the V.27ter
@@ -19,7 +20,6 @@ constexpr int kV27Ints = 45;
 constexpr int kV27Words = kV27Floats + kV27Ints;
 constexpr int kV27EqLen = 32;
 constexpr int kV27MaxSets = 12;
-constexpr int kV27LaneWords = 2*kRrcLen + 4*kV27EqLen;     // 182
 
 // State word map (reference-ordered snapshot used by the tests):
 //   floats: 0 agc_scaling, 1 agc_scaling_save, 2 eq_delta, 3 training_error, 4 carrier_track_p, 5 carrier_track_i,

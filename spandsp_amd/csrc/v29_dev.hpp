@@ -7,10 +7,11 @@
 // T/2 equaliser with LMS training, PI carrier loop, slicer, descrambler, training FSM); the
 // only regular arithmetic is three short inner products per T/2 instant with per-channel
 // operands and per-channel circular offsets -- nothing a matrix core can use.  So:
-//   * scalars, the 33 complex equaliser taps AND the equaliser delay line live in VGPRs: the
-//     delay line is kept in age order (a 66-register shift per T/2 instant), so every access
-//     has a compile-time index; the reference's circular position survives only as the
-//     per-lane split point of the summation and as the order in which state is stored;
+//   * scalars and the equaliser delay line live in VGPRs: the delay line is kept in age order
+//     (a 66-register shift per T/2 instant), so every access has a compile-time index; the
+//     reference's circular position survives only as the per-lane split point of the
+//     summation and as the order in which state is stored.  The 33 complex taps sit in LDS,
+//     [tap][lane], also always indexed by a compile-time tap number;
 //   * the RRC delay line lives in a per-lane LDS column, stored twice back to back so
 //     x[(pos + i) mod n] is the contiguous x2[pos + i]; the frame's PCM is staged there too;
 //   * the polyphase RRC table (48 x 27 x {re, im}) and the sine table live once per
@@ -18,10 +19,13 @@
 //   * inner products keep the reference's exact summation tree: ascending coefficient
 //     index, the circular split summed separately and added last (a per-lane split point,
 //     handled by snapshotting the accumulator instead of branching).
-// Execution is BAUD ALIGNED: each lane consumes samples from its LDS tile until ITS next
-// T/2 instant, then all lanes run the half-baud phase together, and the baud phase runs on
-// alternate rounds -- instead of every lane stepping sample by sample, which made the wave
-// execute the half-baud and baud paths on nearly every sample with a fraction of its lanes.
+// Execution is BAUD ALIGNED: a round of the main loop is one baud of every lane -- each lane
+// consumes samples from its LDS tile until ITS next T/2 instant, all lanes run the half-baud
+// phase together, twice, and then the baud phase (equaliser output, stage logic, carrier and
+// tap updates) runs once with all lanes in step; a lane that enters a round in the middle of
+// its baud sits out the first half.  Stepping all lanes sample by sample instead made the
+// wave execute the half-baud and baud paths on nearly every sample with a fraction of its
+// lanes (measured: 557 -> 450 us per 16 384 x 160 launch, V.27ter 890 -> 320, V.17 1480 -> 585).
 // Expect VALU-issue bound behaviour and a low HBM figure for this kernel.
 //
 // Numerics: fp32, every op rounded separately (-ffp-contract=off), float->int conversions
@@ -43,7 +47,6 @@ constexpr int kV29Words = kV29Floats + kV29Ints;
 constexpr int kRrcSets = 48;
 constexpr int kRrcLen = 27;
 constexpr int kEqLen = 33;
-constexpr int kLanePitch = 2*kRrcLen + 4*kEqLen + 1;   // (round 1 layout; kept for reference by the API's sizing notes)
 constexpr int kPcmTile = 80;                            // samples of PCM staged per lane at a time
 
 // State word map (identical to the reference-ordered snapshot the tests use):
@@ -215,7 +218,6 @@ void v29_bank_kernel(const V29Launch L)
 
     const int lane = threadIdx.x;
     const int ch = blockIdx.x*CPW + lane;
-    const bool live = true;
     const V29Tables &TB = *L.tab;
 
     // ---- tables -> LDS ----------------------------------------------------------------------
@@ -331,13 +333,13 @@ void v29_bank_kernel(const V29Launch L)
     int drop_pending = ldi(VI_DROP_PENDING);
     // diff_angles[16] is only touched during WAIT_FOR_CDCD: keep it in the state array in HBM
     auto diff_ld = [&](int k) { return ldi(VI_DIFF_ANGLES + (k & 0xF)); };
-    auto diff_st = [&](int k, int32_t v) { if (live) sti(VI_DIFF_ANGLES + (k & 0xF), v); };
+    auto diff_st = [&](int k, int32_t v) { sti(VI_DIFF_ANGLES + (k & 0xF), v); };
 
     int8_t *evp = L.events + (size_t) ch*L.ev_cap;
     int n_ev = 0;
     auto emit = [&](int v)
     {
-        if (live  &&  n_ev < L.ev_cap)
+        if (n_ev < L.ev_cap)
             evp[n_ev] = (int8_t) v;
         n_ev++;
     };
@@ -927,7 +929,6 @@ void v29_bank_kernel(const V29Launch L)
     }
 
     // ---- write back -----------------------------------------------------------------------------
-    if (live)
     {
         stf(VF_AGC, agc_scaling);
         stf(VF_AGC_SAVE, agc_scaling_save);
