@@ -130,6 +130,7 @@ SPANGPU_API int spangpu_bank_kind(const spangpu_bank_t *bank);
 SPANGPU_API int spangpu_bank_channels(const spangpu_bank_t *bank);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL = the bank's own stream. */
 SPANGPU_API int spangpu_bank_set_stream(spangpu_bank_t *bank, void *hip_stream);
+SPANGPU_API void *spangpu_bank_get_stream(spangpu_bank_t *bank);
 
 /* Advance every channel by `samples` samples.  `amp` is int16 PCM; for
    CHANNEL_MAJOR, channel c starts at amp + c*stride (stride in samples, must be a
@@ -138,6 +139,11 @@ SPANGPU_API int spangpu_bank_set_stream(spangpu_bank_t *bank, void *hip_stream);
    after the launch is queued on the bank stream.  Returns 0, like dtmf_rx(). */
 SPANGPU_API int spangpu_bank_rx(spangpu_bank_t *bank, const int16_t *amp, int mem, int layout,
                                 int samples, long long stride);
+/* Advance several banks (<= 4, same device and stream, device-resident channel-major frames) with ONE kernel launch:
+   a tick of a mixed population of small banks then pays the launch and ramp-up cost once.  DTMF (no dial-tone
+   filter), Bell MF, R2 MF and super-tone banks can share a launch.  strides may be NULL (= samples). */
+SPANGPU_API int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, int n_banks, int samples,
+                                 const long long *strides);
 /* Evaluate the current (partial) block of every channel now and restart it: what
    goertzel_result() called mid-block does (tone_detect.c:160-205).  The results are read
    with spangpu_bank_blocks() / spangpu_bank_trace() as after spangpu_bank_rx(). */

@@ -362,6 +362,12 @@ int spangpu_bank_set_stream(spangpu_bank_t *b, void *hip_stream)
     return SPANGPU_OK;
 }
 
+// The HIP stream the bank launches on (its own, unless spangpu_bank_set_stream() gave it another).
+void *spangpu_bank_get_stream(spangpu_bank_t *b)
+{
+    return b  ?  (void *) b->stream  :  nullptr;
+}
+
 int spangpu_bank_set_timing(spangpu_bank_t *b, int on)
 {
     if (b == nullptr)
@@ -370,9 +376,9 @@ int spangpu_bank_set_timing(spangpu_bank_t *b, int on)
     return SPANGPU_OK;
 }
 
-static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stride, int samples, int layout, int maxb, int force_end)
+static void fill_launch(ToneLaunch &L, spangpu_bank_t *b, const int16_t *d_amp, long long d_stride, int samples, int layout,
+                        int maxb, int force_end)
 {
-    ToneLaunch L;
     memset(&L, 0, sizeof(L));
     L.amp = d_amp;
     L.stride = d_stride;
@@ -399,6 +405,12 @@ static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stri
     L.threshold = b->threshold;
     L.normal_twist = b->normal_twist;
     L.reverse_twist = b->reverse_twist;
+}
+
+static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stride, int samples, int layout, int maxb, int force_end)
+{
+    ToneLaunch L;
+    fill_launch(L, b, d_amp, d_stride, samples, layout, maxb, force_end);
 
     if (b->timing)
         HIP_TRY(hipEventRecord(b->ev0, b->stream));
@@ -510,6 +522,73 @@ int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, 
         return rc;
     b->last_maxb = maxb;
     b->last_samples = samples;
+    return 0;
+}
+
+// Several banks, one launch (tone_multi_kernel): banks[k] is advanced by `samples` samples of amps[k].  All banks must
+// be on the same device and stream and hold device-resident, channel-major frames; kinds that can share a launch are
+// DTMF (without the dial-tone filter), Bell MF, R2 MF and super-tone.  Results are read per bank as after
+// spangpu_bank_rx().
+int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, int n_banks, int samples, const long long *strides)
+{
+    if (banks == nullptr  ||  amps == nullptr  ||  n_banks < 1  ||  n_banks > kMaxMulti  ||  samples < 0)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments (at most %d banks per launch)", kMaxMulti);
+    if (samples == 0)
+        return 0;
+    ToneMultiLaunch M;
+    memset(&M, 0, sizeof(M));
+    int total_ch = 0;
+    for (int k = 0;  k < n_banks;  k++)
+    {
+        spangpu_bank_t *b = banks[k];
+        if (b == nullptr  ||  amps[k] == nullptr)
+            return fail(SPANGPU_ERR_BAD_ARG, "null bank or frame");
+        if (b->device != banks[0]->device  ||  b->stream != banks[0]->stream)
+            return fail(SPANGPU_ERR_BAD_ARG, "banks of one launch must share a device and a stream (spangpu_bank_set_stream)");
+        total_ch += b->n_ch;
+    }
+    const int lpc = pick_lpc(total_ch);
+    const int cpw = kWave/lpc;
+    HIP_TRY(hipSetDevice(banks[0]->device));
+    int first = 0;
+    for (int k = 0;  k < n_banks;  k++)
+    {
+        spangpu_bank_t *b = banks[k];
+        switch (b->kind)
+        {
+        case SPANGPU_DTMF:
+            if (b->tp.filter_dialtone)
+                return fail(SPANGPU_ERR_UNSUPPORTED, "a DTMF bank with the dial-tone filter cannot share a launch");
+            M.kind[k] = TONE_K_DTMF;
+            break;
+        case SPANGPU_BELL_MF: M.kind[k] = TONE_K_BELL; break;
+        case SPANGPU_R2_MF: M.kind[k] = TONE_K_R2; break;
+        case SPANGPU_SUPER_TONE:
+            M.kind[k] = (b->nb == 4)  ?  TONE_K_ST4  :  (b->nb == 8)  ?  TONE_K_ST8  :  (b->nb == 12)  ?  TONE_K_ST12  :  TONE_K_ST16;
+            break;
+        default:
+            return fail(SPANGPU_ERR_UNSUPPORTED, "bank kind %d cannot share a launch", b->kind);
+        }
+        const long long stride = (strides  &&  strides[k] > 0)  ?  strides[k]  :  samples;
+        const int maxb = (samples + b->block_len - 1)/b->block_len;
+        const int rc = ensure_outputs(b, (maxb > 0)  ?  maxb  :  1);
+        if (rc != SPANGPU_OK)
+            return rc;
+        fill_launch(M.bank[k], b, amps[k], stride, samples, SPANGPU_LAYOUT_CHANNEL_MAJOR, maxb, 0);
+        M.first[k] = first;
+        const int waves = (b->n_ch + cpw - 1)/cpw;
+        first += (waves + kWavesPerBlock - 1)/kWavesPerBlock;
+        b->last_maxb = maxb;
+        b->last_samples = samples;
+    }
+    for (int k = n_banks;  k <= kMaxMulti;  k++)
+        M.first[k] = first;
+    M.n = n_banks;
+    if (lpc == 2)
+        hipLaunchKernelGGL(tone_multi_kernel<2>, dim3(first), dim3(kWave*kWavesPerBlock), 0, banks[0]->stream, M);
+    else
+        hipLaunchKernelGGL(tone_multi_kernel<1>, dim3(first), dim3(kWave*kWavesPerBlock), 0, banks[0]->stream, M);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

@@ -593,9 +593,18 @@ __device__ __forceinline__ void dma_wait_all()
 // ---------------------------------------------------------------------------------
 // ABL is a tuning-probe knob (tools/probe.hip) that removes one cost at a time; the
 // library only instantiates ABL = 0.
+// LDS bytes one workgroup of the bank kernel needs: two segment buffers per wave
+template <int LPC>
+struct ToneLds
+{
+    static constexpr int kBufBytes = (kWave/LPC)*kRowBytes;
+    static constexpr int kBytes = kWavesPerBlock*2*kBufBytes;
+};
+
+// The body of the bank kernel for workgroup `wg` of the bank described by L.  It is a device function so that one
+// launch can carry several banks (tone_multi_kernel below): a workgroup belongs to exactly one bank.
 template <class Det, int LPC, int ABL = 0>
-__global__ __launch_bounds__(kWave*kWavesPerBlock)
-void tone_bank_kernel(const ToneLaunch L)
+__device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg, char *lds_raw)
 {
     constexpr int NB = Det::NB;
     constexpr int NBH = (LPC == 1)  ?  NB  :  (NB + 1)/2;      // real bins per lane
@@ -603,11 +612,11 @@ void tone_bank_kernel(const ToneLaunch L)
     constexpr int CPW = kWave/LPC;                              // channels per wave
     constexpr int NDMA = CPW*kChunksPerRow/kWave;               // LDS-DMA instructions per segment
     constexpr int kBufBytes = CPW*kRowBytes;
-    __shared__ __attribute__((aligned(16))) char lds[kWavesPerBlock][2][kBufBytes];
+    char (*lds)[2][kBufBytes] = (char (*)[2][kBufBytes]) lds_raw;
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ch0 = (blockIdx.x*kWavesPerBlock + wv)*CPW;
+    const int ch0 = (wg*kWavesPerBlock + wv)*CPW;
     if (ch0 >= L.n_ch)
         return;                                     // whole wave idle (wave-uniform exit)
     const int cl = (LPC == 1)  ?  lane  :  (lane & (CPW - 1));  // channel within the wave
@@ -619,7 +628,7 @@ void tone_bank_kernel(const ToneLaunch L)
     // probe-only (ABL & 32): per-wave timestamps into L.probe_ts, 16 slots per wave
     long long *ts = nullptr;
     if (ABL & 32)
-        ts = L.probe_ts + (size_t) (blockIdx.x*kWavesPerBlock + wv)*16;
+        ts = L.probe_ts + (size_t) (wg*kWavesPerBlock + wv)*16;
     auto stamp = [&](int k)
     {
         if ((ABL & 32)  &&  lane == 0  &&  k < 16)
@@ -930,6 +939,54 @@ void tone_bank_kernel(const ToneLaunch L)
             L.rec[(size_t) b*L.n_ch + ch] = 0;         // slots without a completed block
     }
     stamp(15);
+}
+
+template <class Det, int LPC, int ABL = 0>
+__global__ __launch_bounds__(kWave*kWavesPerBlock)
+void tone_bank_kernel(const ToneLaunch L)
+{
+    __shared__ __attribute__((aligned(16))) char lds_raw[ToneLds<LPC>::kBytes];
+    tone_bank_body<Det, LPC, ABL>(L, (int) blockIdx.x, lds_raw);
+}
+
+// Several banks in ONE launch: workgroups [first[k], first[k + 1]) belong to bank k.  A 20 ms tick of a mixed
+// population (e.g. Bell MF + R2 MF + call-progress banks of ~43 k channels each) then pays launch overhead and the
+// ramp-up / drain of the chip once instead of once per bank.  kind[k] selects the detector policy per workgroup
+// (wave-uniform branch).
+constexpr int kMaxMulti = 4;
+enum
+{
+    TONE_K_DTMF = 0, TONE_K_BELL, TONE_K_R2, TONE_K_ST4, TONE_K_ST8, TONE_K_ST12, TONE_K_ST16
+};
+
+struct ToneMultiLaunch
+{
+    ToneLaunch bank[kMaxMulti];
+    int first[kMaxMulti + 1];
+    int kind[kMaxMulti];
+    int n;
+};
+
+template <int LPC>
+__global__ __launch_bounds__(kWave*kWavesPerBlock)
+void tone_multi_kernel(const ToneMultiLaunch M)
+{
+    __shared__ __attribute__((aligned(16))) char lds_raw[ToneLds<LPC>::kBytes];
+    int k = 0;
+    while (k + 1 < M.n  &&  (int) blockIdx.x >= M.first[k + 1])
+        k++;
+    const int block = (int) blockIdx.x - M.first[k];
+    const ToneLaunch &L = M.bank[k];
+    switch (M.kind[k])
+    {
+    case TONE_K_DTMF: tone_bank_body<DtmfDet<false>, LPC>(L, block, lds_raw); break;
+    case TONE_K_BELL: tone_bank_body<BellMfDet, LPC>(L, block, lds_raw); break;
+    case TONE_K_R2:   tone_bank_body<R2MfDet, LPC>(L, block, lds_raw); break;
+    case TONE_K_ST4:  tone_bank_body<MultiDet<4, true>, LPC>(L, block, lds_raw); break;
+    case TONE_K_ST8:  tone_bank_body<MultiDet<8, true>, LPC>(L, block, lds_raw); break;
+    case TONE_K_ST12: tone_bank_body<MultiDet<12, true>, LPC>(L, block, lds_raw); break;
+    default:          tone_bank_body<MultiDet<16, true>, LPC>(L, block, lds_raw); break;
+    }
 }
 
 }   // namespace spg

@@ -70,6 +70,8 @@ def lib():
             "spangpu_bank_set_timing": (ci, [vp, ci]),
             "spangpu_bank_bins": (ci, [vp]),
             "spangpu_bank_force_block": (ci, [vp]),
+            "spangpu_banks_rx": (ci, [vp, vp, ci, ci, vp]),
+            "spangpu_bank_get_stream": (vp, [vp]),
             "spangpu_modem_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
             "spangpu_modem_destroy": (ci, [vp]),
             "spangpu_modem_channels": (ci, [vp]),
@@ -159,6 +161,10 @@ class ToneBank:
     def set_stream(self, hip_stream):
         _check(lib().spangpu_bank_set_stream(self.h, hip_stream))
 
+    def share_stream(self, other):
+        """Launch on the same HIP stream as `other` (needed for banks that share a launch)."""
+        _check(lib().spangpu_bank_set_stream(self.h, lib().spangpu_bank_get_stream(other.h)))
+
     def set_timing(self, on=True):
         _check(lib().spangpu_bank_set_timing(self.h, int(on)))
 
@@ -221,6 +227,17 @@ ECHO_FIELDS = ["tx_power0", "tx_power1", "tx_power2", "tx_power3", "rx_power0", 
                "geigel_lag", "dtd_onset", "tap_set", "tap_rotate_counter", "latest_correction",
                "narrowband_count", "narrowband_score", "fir_curr_pos", "tx_hpf0", "tx_hpf1", "rx_hpf0",
                "rx_hpf1", "cng_level", "cng_rndnum", "cng_filter", "fir_set"]
+
+
+def banks_rx_device(banks, ptrs, samples, strides=None):
+    """Advance several ToneBanks (same stream) with one kernel launch; ptrs = device addresses of their frames."""
+    n = len(banks)
+    hb = (C.c_void_p*n)(*[b.h for b in banks])
+    pa = (C.c_void_p*n)(*[C.c_void_p(int(p)) for p in ptrs])
+    st = None
+    if strides is not None:
+        st = (C.c_longlong*n)(*strides)
+    _check(lib().spangpu_banks_rx(hb, pa, n, samples, st))
 
 
 class EchoBank:

@@ -358,3 +358,64 @@ def test_goertzel_bank(built):
         assert len(got[c]) == len(want), c
         for a, b in zip(got[c], want):
             assert np.array_equal(f32_bits(a), f32_bits(b)), c
+
+
+# --------------------------------------------------------------------------------------
+# several banks in one launch
+# --------------------------------------------------------------------------------------
+def test_multi_bank_launch_equals_separate_launches(built):
+    """spangpu_banks_rx(): DTMF + Bell MF + R2 MF + super-tone banks advanced by one kernel launch give exactly the
+    records and state that separate launches give (ragged channel counts, several frames)."""
+    import ctypes
+    from spandsp_amd import engine
+    # device buffers through the HIP runtime libspangpu already runs on (no second runtime in this process)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), a.nbytes) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0          # hipMemcpyHostToDevice
+        return p
+    n = [70, 131, 64, 33]
+    n_frames = 40
+    sigs = [synth.dtmf_channels(n[0], 160*n_frames, seed=41)[0], synth.bell_mf_channels(n[1], 160*n_frames, seed=42)[0],
+            synth.r2_mf_channels(n[2], 160*n_frames, seed=43, fwd=True)[0], synth.call_progress_channels(n[3], 160*n_frames, seed=44)]
+    fac = [engine.goertzel_fac(f) for f in (350.0, 400.0, 440.0, 480.0, 620.0, 950.0, 1100.0, 1400.0)]
+
+    def make():
+        return [engine.ToneBank(engine.DTMF, n[0]), engine.ToneBank(engine.BELL_MF, n[1]),
+                engine.ToneBank(engine.R2_MF, n[2], r2_fwd=True), engine.ToneBank(engine.SUPER_TONE, n[3], bin_fac=fac)]
+    sep = make()
+    fused = make()
+    for b in fused[1:]:
+        b.share_stream(fused[0])
+    total = 0
+    for k in range(n_frames):
+        for b, x in zip(sep, sigs):
+            b.rx_host(x[:, k*160:(k + 1)*160])
+        frames = [to_device(x[:, k*160:(k + 1)*160]) for x in sigs]
+        engine.banks_rx_device(fused, [f.value for f in frames], 160)
+        for b0, b1 in zip(sep, fused):
+            r0 = b0.blocks()
+            r1 = b1.blocks()
+            assert r0.tobytes() == r1.tobytes(), k
+            total += int((r0["hit"] != 0).sum())
+        for f in frames:
+            hip.hipFree(f)
+    for b0, b1, nn in zip(sep, fused, n):
+        for c in (0, nn//2, nn - 1):
+            f0, i0 = b0.get_state(c)
+            f1, i1 = b1.get_state(c)
+            assert np.array_equal(f32_bits(f0), f32_bits(f1)) and np.array_equal(i0, i1), c
+    assert total > 200
+    # kinds that cannot share a launch are refused, not silently run some other way
+    g = engine.ToneBank(engine.GOERTZEL, 8, bin_fac=fac[:4], block_len=100)
+    g.share_stream(fused[0])
+    buf = to_device(sigs[0][:, :160])
+    with pytest.raises(engine.SpanGpuError):
+        engine.banks_rx_device([fused[0], g], [buf.value, buf.value], 160)
+    hip.hipFree(buf)

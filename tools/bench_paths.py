@@ -238,7 +238,12 @@ def bench_mixed(args, dev, stream):
     for b in banks:
         b.set_stream(ctypes.c_void_p(stream.cuda_stream))
 
+    fused = not args.separate_launches
+
     def step(i):
+        if fused:
+            engine.banks_rx_device(banks, [frames[kind].data_ptr() + (i % nf)*n_each[kind]*FRAME*2 for kind in range(3)], FRAME)
+            return
         for kind in range(3):
             banks[kind].rx_device(ctypes.c_void_p(frames[kind].data_ptr() + (i % nf)*n_each[kind]*FRAME*2), FRAME, FRAME)
     for i in range(args.warmup):
@@ -263,13 +268,15 @@ def bench_mixed(args, dev, stream):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: %d Bell MF + %d R2 MF + %d super-tone (8 bins) channels x %d-sample "
-                               "frames, three launches per step" % (n_each[0], n_each[1], n_each[2], FRAME),
+                               "frames, %s" % (n_each[0], n_each[1], n_each[2], FRAME,
+                                                "one launch per step (spangpu_banks_rx)" if fused else "three launches per step"),
                    "channels_per_gpu": n_ch, "blocks_with_a_hit_in_last_step": hits},
-        "roofline": {"bound": "hbm", "kernel": "tone_bank_kernel<BellMfDet | R2MfDet | MultiDet<8, true>> (3 launches)",
+        "roofline": {"bound": "hbm", "kernel": "tone_multi_kernel<2> (Bell MF + R2 MF + super-tone workgroups in one launch)" if fused
+                               else "tone_bank_kernel<BellMfDet | R2MfDet | MultiDet<8, true>> (3 launches)",
                      "achieved": alg_read/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
                      "alg_read_bytes_per_launch": alg_read, "avg_launch_us": avg_ms*1e3,
-                     "note": "avg_launch_us is the three launches of one step together"},
+                     "note": "avg_launch_us is one whole step (all three banks)"},
         "cpu_baseline": None}
 
 
@@ -281,6 +288,7 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     args = ap.parse_args()
     if not torch.cuda.is_available():
