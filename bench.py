@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--channels", type=int, default=65536, help="channels per GPU (BASELINE config 2: 65536)")
     ap.add_argument("--distinct-frames", type=int, default=100, help="distinct 20 ms frames resident in HBM (cycled)")
+    ap.add_argument("--gather-every", type=int, default=5,
+                    help="multi-GPU: steps per RCCL gather of the block records (5 = one 100 ms report per collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     ap.add_argument("--cpu-frames", type=int, default=40)
@@ -161,9 +163,13 @@ def main():
         raise SystemExit("bench.py needs a HIP device; the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SPANGPU_BENCH_FORCE_GATHER=1 runs the RCCL record gather even with one rank (a self-test of the N > 1 path on a
+    # one-GPU box; launch through torch.distributed.run so that the rendezvous variables exist)
+    force_gather = world == 1 and os.environ.get("SPANGPU_BENCH_FORCE_GATHER") == "1"
+    if world > 1 or force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from spandsp_amd import engine
@@ -182,12 +188,14 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
-    gather = ResultGather(world, rank, n_ch, max_blocks=2, device=dev) if world > 1 else None
+    gather = ResultGather(world, rank, n_ch, max_blocks=2, device=dev, every=args.gather_every) if (world > 1 or force_gather) else None
     frame_bytes = n_ch*FRAME*2
     base_ptr = frames.data_ptr()
     nf = args.distinct_frames
 
     def step(i):
+        if gather is not None:
+            gather.aim(bank)                    # the kernel writes its records straight into the RCCL send buffer
         bank.rx_device(ctypes.c_void_p(base_ptr + (i % nf)*frame_bytes), FRAME, FRAME)
         if gather is not None:
             gather.submit(bank)
@@ -220,6 +228,8 @@ def main():
         dt = float(tmax.item())
     stream_ms = ev0.elapsed_time(ev1)
 
+    if gather is not None:
+        bank.set_records_buffer(None, 0)
     # ---- per-launch kernel duration with HIP events on the launch stream (roofline) ----
     roof = None
     if rank == 0:
@@ -282,13 +292,16 @@ def main():
                             "channel-major int16 resident in HBM, %d distinct frames cycled" % (n_ch, FRAME, nf),
                 "channels_per_gpu": n_ch,
                 "frame_samples": FRAME,
-                "parallelism": "channels sharded x%d, RCCL gather of block records" % world if world > 1 else "single GPU",
+                "parallelism": ("channels sharded x%d, RCCL gather of block records every %d steps" % (world, args.gather_every))
+                               if world > 1 else "single GPU",
             },
             "roofline": roof,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_gather:
+        if rank == 0 and gather is not None and gather.latest() is not None:
+            assert gather.latest().shape == (world, args.gather_every, 2*n_ch)
         dist.destroy_process_group()
 
 

@@ -157,6 +157,9 @@ SPANGPU_API int spangpu_bank_blocks(spangpu_bank_t *bank, spangpu_block_t *out, 
 /* Queue a device-to-device copy of the last call's raw record words ([blocks][channel] uint32,
    hit | code<<8 | flags<<16) into a caller-owned device buffer (e.g. the send buffer of an RCCL
    gather).  Returns the number of bytes, or a negative error. */
+/* Following launches write their block records directly into a caller-owned device buffer (e.g. an RCCL send
+   buffer); NULL restores the bank's own.  Size: ceil(samples/block) * n_channels words per frame to come. */
+SPANGPU_API int spangpu_bank_set_records_buffer(spangpu_bank_t *bank, void *device_buffer, size_t bytes);
 SPANGPU_API long long spangpu_bank_copy_records(spangpu_bank_t *bank, void *dst_device, size_t dst_bytes);
 /* Parity / diagnostics tap: per-block Goertzel energies of the last call, laid out
    [block][bin][channel] (bank created with trace=1).  Returns blocks-per-call. */

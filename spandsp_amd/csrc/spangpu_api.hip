@@ -60,6 +60,9 @@ struct spangpu_bank_s
     // per-call outputs (capacity = maxb_cap blocks)
     int maxb_cap;
     uint32_t *rec;
+    uint32_t *ext_rec;          // caller-owned record buffer for the next launches (spangpu_bank_set_records_buffer)
+    size_t ext_rec_bytes;
+    uint32_t *cur_rec;          // where the last launch wrote its records
     float *rec_energy;
     int32_t *rec_dur;
     float *trace;
@@ -391,7 +394,8 @@ static void fill_launch(ToneLaunch &L, spangpu_bank_t *b, const int16_t *d_amp, 
                    &&  d_stride >= ((samples + 7) & ~7))  ?  1  :  0;
     L.sf = b->sf;
     L.si = b->si;
-    L.rec = b->rec;
+    L.rec = b->ext_rec  ?  b->ext_rec  :  b->rec;
+    b->cur_rec = L.rec;
     L.rec_energy = b->rec_energy;
     L.rec_dur = b->rec_dur;
     L.trace = b->trace;
@@ -517,6 +521,8 @@ int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, 
         return fail(SPANGPU_ERR_BAD_ARG, "bad mem kind");
     }
 
+    if (b->ext_rec  &&  (size_t) maxb*b->n_ch*sizeof(uint32_t) > b->ext_rec_bytes)
+        return fail(SPANGPU_ERR_BAD_ARG, "records buffer too small for %d blocks", maxb);
     rc = launch_bank(b, d_amp, d_stride, samples, layout, maxb, 0);
     if (rc < 0)
         return rc;
@@ -636,7 +642,7 @@ int spangpu_bank_blocks(spangpu_bank_t *b, spangpu_block_t *out, int max)
         return 0;
     HIP_TRY(hipSetDevice(b->device));
     const size_t n = (size_t) b->last_maxb*b->n_ch;
-    HIP_TRY(hipMemcpyAsync(b->h_rec, b->rec, n*sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->h_rec, b->cur_rec  ?  b->cur_rec  :  b->rec, n*sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     if (b->rec_energy)
         HIP_TRY(hipMemcpyAsync(b->h_energy, b->rec_energy, n*sizeof(float), hipMemcpyDeviceToHost, b->stream));
     if (b->rec_dur)
@@ -670,6 +676,19 @@ int spangpu_bank_blocks(spangpu_bank_t *b, spangpu_block_t *out, int max)
     return count;
 }
 
+// Have the following launches write their block records straight into a caller-owned device buffer (for example the
+// send buffer of an RCCL gather: no copy between the kernel and the collective).  The buffer must hold
+// ceil(samples/block)*n_channels words for the frames to come (2*n_channels covers 160-sample frames of every
+// detector); NULL goes back to the bank's own buffer.  spangpu_bank_blocks() reads whichever was written last.
+int spangpu_bank_set_records_buffer(spangpu_bank_t *b, void *dev_ptr, size_t bytes)
+{
+    if (b == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "null bank");
+    b->ext_rec = (uint32_t *) dev_ptr;
+    b->ext_rec_bytes = dev_ptr  ?  bytes  :  0;
+    return SPANGPU_OK;
+}
+
 long long spangpu_bank_copy_records(spangpu_bank_t *b, void *dst_device, size_t dst_bytes)
 {
     if (b == nullptr  ||  dst_device == nullptr)
@@ -680,7 +699,7 @@ long long spangpu_bank_copy_records(spangpu_bank_t *b, void *dst_device, size_t 
     if (bytes == 0)
         return 0;
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipMemcpyAsync(dst_device, b->rec, bytes, hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(dst_device, b->cur_rec  ?  b->cur_rec  :  b->rec, bytes, hipMemcpyDeviceToDevice, b->stream));
     return (long long) bytes;
 }
 

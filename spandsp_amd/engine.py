@@ -71,6 +71,7 @@ def lib():
             "spangpu_bank_bins": (ci, [vp]),
             "spangpu_bank_force_block": (ci, [vp]),
             "spangpu_banks_rx": (ci, [vp, vp, ci, ci, vp]),
+            "spangpu_bank_set_records_buffer": (ci, [vp, vp, C.c_size_t]),
             "spangpu_bank_get_stream": (vp, [vp]),
             "spangpu_modem_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
             "spangpu_modem_destroy": (ci, [vp]),
@@ -193,6 +194,10 @@ class ToneBank:
         if n:
             _check(lib().spangpu_bank_blocks(self.h, out.ctypes.data, n))
         return out
+
+    def set_records_buffer(self, dev_ptr, nbytes):
+        """Later launches write their block records straight into this device buffer (None: the bank's own)."""
+        _check(lib().spangpu_bank_set_records_buffer(self.h, dev_ptr, nbytes))
 
     def copy_records(self, dst_ptr, dst_bytes):
         return _check(lib().spangpu_bank_copy_records(self.h, dst_ptr, dst_bytes))

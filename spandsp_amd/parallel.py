@@ -21,40 +21,67 @@ def shard_range(total_channels, world, rank):
 class ResultGather:
     """Double-buffered asynchronous gather of a bank's block-record words to rank 0.
 
-    submit(bank) queues a device-to-device copy of the bank's records into a send
-    buffer (spangpu_bank_copy_records) and starts a gather of it; the previous use of
-    that buffer is waited for first, so a step's gather overlaps the next step's kernel.
-    On rank 0, `latest()` returns the [world, max_blocks*n_ch] int32 words of the
-    most recently completed gather.
+    Zero-copy use: call `aim(bank)` BEFORE each step's launch -- the kernel then writes its records straight into the
+    next slice of the send buffer (spangpu_bank_set_records_buffer) -- and `submit(bank)` after it.  (Without `aim`,
+    submit() copies the bank's records device-to-device.)  Every `every` steps the filled buffer is gathered to rank 0
+    (one collective per reporting interval: `every` = 5 is a 100 ms report at 20 ms ticks).  The previous use of a buffer is waited for before it is refilled,
+    so a gather overlaps the kernels of the following interval.  On rank 0, `latest()` returns the
+    [world, every, max_blocks*n_ch] int32 words of the most recently completed gather.
     """
 
-    def __init__(self, world, rank, n_ch, max_blocks, device):
+    def __init__(self, world, rank, n_ch, max_blocks, device, every=1):
         self.world = world
         self.rank = rank
         self.n = max_blocks*n_ch
-        self.send = [torch.zeros(self.n, dtype=torch.int32, device=device) for _ in range(2)]
+        self.every = max(1, int(every))
+        size = self.n*self.every
+        self.send = [torch.zeros(size, dtype=torch.int32, device=device) for _ in range(2)]
         self.recv = None
         if rank == 0:
-            self.recv = [[torch.zeros(self.n, dtype=torch.int32, device=device) for _ in range(world)]
+            self.recv = [[torch.zeros(size, dtype=torch.int32, device=device) for _ in range(world)]
                          for _ in range(2)]
         self.handles = [None, None]
         self.count = 0
         self.done_slot = None
 
-    def submit(self, bank):
-        slot = self.count & 1
-        if self.handles[slot] is not None:
-            self.handles[slot].wait()
-            self.done_slot = slot
-        buf = self.send[slot]
-        bank.copy_records(buf.data_ptr(), buf.numel()*4)
-        self.handles[slot] = dist.gather(buf, gather_list=self.recv[slot] if self.rank == 0 else None,
+    def _start(self, slot):
+        self.handles[slot] = dist.gather(self.send[slot], gather_list=self.recv[slot] if self.rank == 0 else None,
                                          dst=0, async_op=True)
+
+    def _claim(self):
+        slot = (self.count//self.every) & 1
+        sub = self.count % self.every
+        if sub == 0 and self.handles[slot] is not None:
+            self.handles[slot].wait()
+            self.handles[slot] = None
+            self.done_slot = slot
+        return slot, sub
+
+    def aim(self, bank):
+        """Point the bank's next launch at this step's slice of the send buffer."""
+        slot, sub = self._claim()
+        bank.set_records_buffer(self.send[slot].data_ptr() + sub*self.n*4, self.n*4)
+        self.aimed = True
+
+    def submit(self, bank):
+        slot, sub = self._claim()
+        if not getattr(self, "aimed", False):
+            bank.copy_records(self.send[slot].data_ptr() + sub*self.n*4, self.n*4)
+        self.aimed = False
         self.count += 1
+        if sub == self.every - 1:
+            self._start(slot)
 
     def drain(self):
+        """Send a partly filled interval, wait for everything in flight."""
+        sub = self.count % self.every
+        if sub != 0:
+            slot = (self.count//self.every) & 1
+            self._start(slot)
+            self.count += self.every - sub
+        first = (self.count//self.every) & 1
         for k in range(2):
-            slot = (self.count + k) & 1
+            slot = (first + k) & 1
             if self.handles[slot] is not None:
                 self.handles[slot].wait()
                 self.handles[slot] = None
@@ -63,4 +90,4 @@ class ResultGather:
     def latest(self):
         if self.rank != 0 or self.done_slot is None:
             return None
-        return torch.stack(self.recv[self.done_slot])
+        return torch.stack(self.recv[self.done_slot]).view(self.world, self.every, self.n)

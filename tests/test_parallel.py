@@ -39,12 +39,12 @@ class FakeBank:
         return words.nbytes
 
 
-def _worker(rank, world, port, n_ch, steps, out):
+def _worker(rank, world, port, n_ch, steps, out, every=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from spandsp_amd.parallel import ResultGather
-    g = ResultGather(world, rank, n_ch, max_blocks=2, device=torch.device("cpu"))
+    g = ResultGather(world, rank, n_ch, max_blocks=2, device=torch.device("cpu"), every=every)
     bank = FakeBank(rank, 2*n_ch)
     ok = True
     for s in range(steps):
@@ -54,24 +54,31 @@ def _worker(rank, world, port, n_ch, steps, out):
             pass
     g.drain()
     if rank == 0:
-        got = g.latest().numpy()
+        got = g.latest().numpy()                    # [world, every, words]: the last (possibly partial) interval
         last = steps - 1
+        filled = (last % every) + 1
         for r in range(world):
-            want = (np.arange(2*n_ch, dtype=np.int64)*3 + r*1000003 + last*17).astype(np.int32)
-            ok = ok and np.array_equal(got[r], want)
+            for k in range(filled):
+                step = last - (filled - 1) + k
+                want = (np.arange(2*n_ch, dtype=np.int64)*3 + r*1000003 + step*17).astype(np.int32)
+                ok = ok and np.array_equal(got[r, k], want)
         out.put(bool(ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_result_gather_gloo_world2():
+import pytest
+
+
+@pytest.mark.parametrize("every,steps", [(1, 5), (5, 13), (4, 8)])
+def test_result_gather_gloo_world2(every, steps):
     sock = socket.socket()
     sock.bind(("127.0.0.1", 0))
     port = sock.getsockname()[1]
     sock.close()
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 257, 5, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 257, steps, out, every)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

@@ -419,3 +419,43 @@ def test_multi_bank_launch_equals_separate_launches(built):
     with pytest.raises(engine.SpanGpuError):
         engine.banks_rx_device([fused[0], g], [buf.value, buf.value], 160)
     hip.hipFree(buf)
+
+
+def test_records_straight_into_a_caller_buffer(built):
+    """spangpu_bank_set_records_buffer(): the kernel writes its block records into a caller-owned device buffer (the
+    zero-copy path of the multi-GPU gather); same records as the bank's own buffer gives."""
+    import ctypes
+    from spandsp_amd import engine
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    n_ch = 300
+    sig, _ = synth.dtmf_channels(n_ch, 160*30, seed=51)
+    a = engine.ToneBank(engine.DTMF, n_ch)
+    b = engine.ToneBank(engine.DTMF, n_ch)
+    buf = ctypes.c_void_p()
+    nbytes = 2*n_ch*4
+    assert hip.hipMalloc(ctypes.byref(buf), 3*nbytes) == 0
+    words = np.zeros(2*n_ch, np.uint32)
+    hits = 0
+    for k in range(30):
+        frame = sig[:, k*160:(k + 1)*160]
+        a.rx_host(frame)
+        b.set_records_buffer(ctypes.c_void_p(buf.value + (k % 3)*nbytes), nbytes)
+        b.rx_host(frame)
+        ra = a.blocks()
+        rb = b.blocks()
+        assert ra.tobytes() == rb.tobytes(), k
+        nb = len(ra)//n_ch
+        assert hip.hipMemcpy(words.ctypes.data, ctypes.c_void_p(buf.value + (k % 3)*nbytes), nbytes, 2) == 0
+        got = words[:nb*n_ch].reshape(nb, n_ch)
+        want = (ra["hit"].astype(np.uint32) | (ra["code"].astype(np.uint32) << 8) | (ra["flags"].astype(np.uint32) << 16)).reshape(n_ch, nb).T
+        assert np.array_equal(got, want), k
+        hits += int((ra["hit"] != 0).sum())
+    assert hits > 50
+    b.set_records_buffer(None, 0)
+    with pytest.raises(engine.SpanGpuError):
+        b.set_records_buffer(buf, 8)
+        b.rx_host(sig[:, :160])
+    hip.hipFree(buf)
