@@ -206,6 +206,12 @@ SPANGPU_API int spangpu_echo_sync(spangpu_echo_t *ec);
    tests/echo_tests.c:577-594).  Channel c's samples start at tx/rx/clean + c*stride. */
 SPANGPU_API int spangpu_echo_update(spangpu_echo_t *ec, const int16_t *tx, const int16_t *rx, int16_t *clean,
                                     int mem, int samples, long long stride, int use_hpf_tx);
+/* As spangpu_echo_update(); tx_out (may be NULL) receives the transmit samples after echo_can_hpf_tx(), i.e. what the
+   caller has to send to the line when ECHO_CAN_USE_TX_HPF is set (src/echo.c:663-669). */
+SPANGPU_API int spangpu_echo_update_tx(spangpu_echo_t *ec, const int16_t *tx, const int16_t *rx, int16_t *clean, int16_t *tx_out,
+                                       int mem, int samples, long long stride, int use_hpf_tx);
+/* echo_can_hpf_tx() on its own, for callers that filter tx before they have the matching rx (host buffers). */
+SPANGPU_API int spangpu_echo_hpf_tx(spangpu_echo_t *ec, const int16_t *tx, int16_t *out, int samples, long long stride);
 SPANGPU_API int spangpu_echo_adaption_mode(spangpu_echo_t *ec, int channel, int adaption_mode);
 SPANGPU_API int spangpu_echo_flush(spangpu_echo_t *ec, int channel);
 /* One channel's state in the reference's terms: control words (order: DESIGN.md), taps32[taps],

@@ -25,6 +25,8 @@
  *   r2_mf_rx_init/_rx/_get/_release/_free  src/spandsp/bell_r2_mf.h:236-266  src/bell_r2_mf.c:750-951
  *   super_tone_rx_* (descriptor + detector)  src/spandsp/super_tone_rx.h:76-164  src/super_tone_rx.c:81-568
  *   goertzel_*  / make_goertzel_descriptor src/spandsp/tone_detect.h:86-124  src/tone_detect.c:60-205
+ *   echo_can_init/_release/_free/_flush/_adaption_mode/_update/_hpf_tx
+ *                                          src/spandsp/echo.h:145-185     src/echo.c:254-380,421-669
  *   v29_rx_init/_restart/_release/_free/_set_put_bit/_set_modem_status_handler/_rx/_fillin/_equalizer_state/
  *     _carrier_frequency/_symbol_timing_correction/_signal_power/_set_signal_cutoff
  *                                          src/spandsp/v29rx.h:151-244    src/v29rx.c:139-196,867-1148
@@ -144,6 +146,35 @@ SPANGPU_API void v17_rx_set_signal_cutoff(v17_rx_state_t *s, float cutoff);
 SPANGPU_API int v29_rx_restart(v29_rx_state_t *s, int bit_rate, bool old_train);
 SPANGPU_API int v27ter_rx_restart(v27ter_rx_state_t *s, int bit_rate, bool old_train);
 SPANGPU_API int v17_rx_restart(v17_rx_state_t *s, int bit_rate, int short_train);
+
+/* ---- echo canceller ---------------------------------------------------------------------- */
+/* src/spandsp/echo.h:120-131 */
+enum
+{
+    ECHO_CAN_USE_ADAPTION = 0x01,
+    ECHO_CAN_USE_NLP = 0x02,
+    ECHO_CAN_USE_CNG = 0x04,
+    ECHO_CAN_USE_CLIP = 0x08,
+    ECHO_CAN_USE_SUPPRESSOR = 0x10,
+    ECHO_CAN_USE_TX_HPF = 0x20,
+    ECHO_CAN_USE_RX_HPF = 0x40,
+    ECHO_CAN_DISABLE = 0x80
+};
+
+typedef struct echo_can_state_s echo_can_state_t;
+
+/* len (taps) must be 32, 64, 128 or 256.  echo_can_update() is one kernel launch per sample: source compatibility only;
+   use spangpu_echo_can_update_block() (one object, n samples) or spangpu_echo_update() (N channels) for throughput. */
+SPANGPU_API echo_can_state_t *echo_can_init(int len, int adaption_mode);
+SPANGPU_API int echo_can_release(echo_can_state_t *ec);
+SPANGPU_API int echo_can_free(echo_can_state_t *ec);
+SPANGPU_API void echo_can_flush(echo_can_state_t *ec);
+SPANGPU_API void echo_can_adaption_mode(echo_can_state_t *ec, int adaption_mode);
+SPANGPU_API int16_t echo_can_update(echo_can_state_t *ec, int16_t tx, int16_t rx);
+SPANGPU_API int16_t echo_can_hpf_tx(echo_can_state_t *ec, int16_t tx);
+SPANGPU_API int spangpu_echo_can_update_block(echo_can_state_t *ec, const int16_t tx[], const int16_t rx[], int16_t clean[],
+                                              int16_t tx_out[], int n, int use_hpf_tx);
+SPANGPU_API spangpu_echo_t *spangpu_echo_can_bank(echo_can_state_t *ec);
 
 /* ---- channel groups: N spandsp objects on one GPU bank ----------------------------- */
 typedef struct spangpu_group_s spangpu_group_t;

@@ -175,6 +175,12 @@ int spangpu_echo_sync(spangpu_echo_t *e)
 int spangpu_echo_update(spangpu_echo_t *e, const int16_t *tx, const int16_t *rx, int16_t *clean,
                         int mem, int samples, long long stride, int use_hpf_tx)
 {
+    return spangpu_echo_update_tx(e, tx, rx, clean, nullptr, mem, samples, stride, use_hpf_tx);
+}
+
+int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *rx, int16_t *clean, int16_t *tx_out,
+                           int mem, int samples, long long stride, int use_hpf_tx)
+{
     if (e == nullptr  ||  tx == nullptr  ||  rx == nullptr  ||  clean == nullptr  ||  samples < 0)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
     if (samples == 0)
@@ -191,7 +197,7 @@ int spangpu_echo_update(spangpu_echo_t *e, const int16_t *tx, const int16_t *rx,
             if (e->d_io) (void) hipFree(e->d_io);
             e->d_io = nullptr;
             e->io_cap = 0;
-            ECHO_TRY(hipMalloc(&e->d_io, (size_t) 3*e->n_ch*samples*sizeof(int16_t)));
+            ECHO_TRY(hipMalloc(&e->d_io, (size_t) 4*e->n_ch*samples*sizeof(int16_t)));
             e->io_cap = samples;
         }
         int16_t *dtx = e->d_io;
@@ -204,6 +210,7 @@ int spangpu_echo_update(spangpu_echo_t *e, const int16_t *tx, const int16_t *rx,
         L.tx = dtx;
         L.rx = drx;
         L.clean = dcl;
+        L.tx_out = tx_out  ?  (e->d_io + (size_t) 3*e->n_ch*e->io_cap)  :  nullptr;
         L.stride = (long long) e->io_cap;
     }
     else if (mem == SPANGPU_MEM_DEVICE)
@@ -211,6 +218,7 @@ int spangpu_echo_update(spangpu_echo_t *e, const int16_t *tx, const int16_t *rx,
         L.tx = tx;
         L.rx = rx;
         L.clean = clean;
+        L.tx_out = tx_out;
         L.stride = stride;
     }
     else
@@ -238,8 +246,43 @@ int spangpu_echo_update(spangpu_echo_t *e, const int16_t *tx, const int16_t *rx,
     {
         ECHO_TRY(hipMemcpy2DAsync(clean, stride*sizeof(int16_t), L.clean, e->io_cap*sizeof(int16_t), samples*sizeof(int16_t),
                                   e->n_ch, hipMemcpyDeviceToHost, e->stream));
+        if (tx_out)
+            ECHO_TRY(hipMemcpy2DAsync(tx_out, stride*sizeof(int16_t), L.tx_out, e->io_cap*sizeof(int16_t), samples*sizeof(int16_t),
+                                      e->n_ch, hipMemcpyDeviceToHost, e->stream));
         ECHO_TRY(hipStreamSynchronize(e->stream));
     }
+    return 0;
+}
+
+// echo_can_hpf_tx() for every channel, separately from the update (the spandsp calling sequence: tx' = hpf_tx(tx), send
+// tx' to the line, later clean = update(tx', rx)).  Host buffers only; out may alias tx.
+int spangpu_echo_hpf_tx(spangpu_echo_t *e, const int16_t *tx, int16_t *out, int samples, long long stride)
+{
+    if (e == nullptr  ||  tx == nullptr  ||  out == nullptr  ||  samples < 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (samples == 0)
+        return 0;
+    if (stride <= 0)
+        stride = samples;
+    ECHO_TRY(hipSetDevice(e->device));
+    if ((size_t) samples > e->io_cap)
+    {
+        if (e->d_io) (void) hipFree(e->d_io);
+        e->d_io = nullptr;
+        e->io_cap = 0;
+        ECHO_TRY(hipMalloc(&e->d_io, (size_t) 4*e->n_ch*samples*sizeof(int16_t)));
+        e->io_cap = samples;
+    }
+    int16_t *dtx = e->d_io;
+    int16_t *dout = e->d_io + (size_t) 3*e->n_ch*e->io_cap;
+    ECHO_TRY(hipMemcpy2DAsync(dtx, e->io_cap*sizeof(int16_t), tx, stride*sizeof(int16_t), samples*sizeof(int16_t),
+                              e->n_ch, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(echo_hpf_tx_kernel, dim3((e->n_ch + 63)/64), dim3(64), 0, e->stream, dtx, dout, (long long) e->io_cap,
+                       samples, e->n_ch, e->scal);
+    ECHO_TRY(hipGetLastError());
+    ECHO_TRY(hipMemcpy2DAsync(out, stride*sizeof(int16_t), dout, e->io_cap*sizeof(int16_t), samples*sizeof(int16_t),
+                              e->n_ch, hipMemcpyDeviceToHost, e->stream));
+    ECHO_TRY(hipStreamSynchronize(e->stream));
     return 0;
 }
 

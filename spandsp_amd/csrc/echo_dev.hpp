@@ -69,6 +69,7 @@ struct EchoLaunch
     const int16_t *tx;          // [n_ch][stride]
     const int16_t *rx;
     int16_t *clean;
+    int16_t *tx_out;            // optional: the transmit samples after echo_can_hpf_tx() (what goes to the line)
     long long stride;
     int samples;
     int n_ch;
@@ -475,7 +476,7 @@ void echo_bank_kernel(const EchoLaunch L)
                 curr_pos = T;
             curr_pos--;
             if (j == 0)
-                io[wv][g][idx] = (int) (short) clean_rx;        // reuse the slot for the output
+                io[wv][g][idx] = ((int) (short) clean_rx & 0xFFFF) | (tx << 16);    // reuse the slot for the outputs
         };
 
         // ---- walk the pass: TPL samples per unrolled round (phases 0..TPL-1) ------------------
@@ -499,7 +500,12 @@ void echo_bank_kernel(const EchoLaunch L)
         if (live)
         {
             for (int i = j;  i < n;  i += kEchoGroup)
-                L.clean[(size_t) ch*L.stride + base + i] = (int16_t) io[wv][g][i];
+            {
+                const int word = io[wv][g][i];
+                L.clean[(size_t) ch*L.stride + base + i] = (int16_t) (word & 0xFFFF);
+                if (L.tx_out)
+                    L.tx_out[(size_t) ch*L.stride + base + i] = (int16_t) (word >> 16);
+            }
         }
     }
 
@@ -547,6 +553,29 @@ void echo_bank_kernel(const EchoLaunch L)
         sc[ES_VAD] = vad;
         sc[ES_LATEST_CORRECTION] = 0;
     }
+}
+
+// echo_can_hpf_tx() on its own (src/echo.c:663-669): one thread per channel filters `samples` transmit samples in place
+// of the fused path of echo_bank_kernel (callers that need the filtered sample before they have the matching rx sample).
+__global__ __launch_bounds__(64)
+void echo_hpf_tx_kernel(const int16_t *tx, int16_t *out, long long stride, int samples, int n_ch, int32_t *scal)
+{
+    const int ch = blockIdx.x*64 + threadIdx.x;
+    if (ch >= n_ch)
+        return;
+    int32_t *sc = scal + (size_t) ch*kEchoScalars;
+    const int mode = sc[ES_ADAPTION_MODE];
+    int32_t c0 = sc[ES_TX_HPF0];
+    int32_t c1 = sc[ES_TX_HPF1];
+    for (int i = 0;  i < samples;  i++)
+    {
+        int v = tx[(size_t) ch*stride + i];
+        if (mode & kModeTxHpf)
+            v = echo_hpf(c0, c1, v);
+        out[(size_t) ch*stride + i] = (int16_t) v;
+    }
+    sc[ES_TX_HPF0] = c0;
+    sc[ES_TX_HPF1] = c1;
 }
 
 }   // namespace spg
