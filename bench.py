@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--distinct-frames", type=int, default=100, help="distinct 20 ms frames resident in HBM (cycled)")
     ap.add_argument("--gather-every", type=int, default=5,
                     help="multi-GPU: steps per RCCL gather of the block records (5 = one 100 ms report per collective)")
+    ap.add_argument("--g711", choices=["none", "alaw", "ulaw"], default="none",
+                    help="feed the bank G.711 bytes (decoded on the device) instead of 16 bit linear PCM; not the "
+                         "BASELINE configuration -- a variant of it with the wire format of a trunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     ap.add_argument("--cpu-frames", type=int, default=40)
@@ -179,6 +182,17 @@ def main():
     lo, hi = shard_range(n_ch*world, world, rank)
     assert hi - lo == n_ch
     frames = synth_dtmf_frames(n_ch, args.distinct_frames, dev, seed=0x5EED0000 + rank)
+    law = {"none": 0, "alaw": 1, "ulaw": 2}[args.g711]
+    if law:
+        # encode to G.711 with the decode table of the reference (tests/golden/g711_decode.npz): nearest code
+        tab = np.load(os.path.join(ROOT, "tests", "golden", "g711_decode.npz"))[args.g711].astype(np.int32)
+        order = np.argsort(tab, kind="stable")
+        vals = torch.tensor(tab[order], device=dev, dtype=torch.int32)
+        codes_of = torch.tensor(order.astype(np.uint8), device=dev)
+        x = frames.to(torch.int32)
+        pos = torch.clamp(torch.searchsorted(vals, x.contiguous()), 1, 255)
+        lower = (x - vals[pos - 1]) <= (vals[pos] - x)
+        frames = codes_of[torch.where(lower, pos - 1, pos)].contiguous()
     torch.cuda.synchronize()
 
     bank = engine.ToneBank(engine.DTMF, n_ch, device=local_rank)
@@ -189,14 +203,17 @@ def main():
     assert stream.cuda_stream != 0
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
     gather = ResultGather(world, rank, n_ch, max_blocks=2, device=dev, every=args.gather_every) if (world > 1 or force_gather) else None
-    frame_bytes = n_ch*FRAME*2
+    frame_bytes = n_ch*FRAME*(1 if law else 2)
     base_ptr = frames.data_ptr()
     nf = args.distinct_frames
 
     def step(i):
         if gather is not None:
             gather.aim(bank)                    # the kernel writes its records straight into the RCCL send buffer
-        bank.rx_device(ctypes.c_void_p(base_ptr + (i % nf)*frame_bytes), FRAME, FRAME)
+        if law:
+            bank.rx_device_g711(ctypes.c_void_p(base_ptr + (i % nf)*frame_bytes), law, FRAME, FRAME)
+        else:
+            bank.rx_device(ctypes.c_void_p(base_ptr + (i % nf)*frame_bytes), FRAME, FRAME)
         if gather is not None:
             gather.submit(bank)
 
@@ -237,12 +254,16 @@ def main():
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
         for i in range(k):
             evs[i][0].record(stream)
-            bank.rx_device(ctypes.c_void_p(base_ptr + (i % nf)*frame_bytes), FRAME, FRAME)
+            if law:
+                bank.rx_device_g711(ctypes.c_void_p(base_ptr + (i % nf)*frame_bytes), law, FRAME, FRAME)
+            else:
+                bank.rx_device(ctypes.c_void_p(base_ptr + (i % nf)*frame_bytes), FRAME, FRAME)
             evs[i][1].record(stream)
         torch.cuda.synchronize()
         per = sorted(a.elapsed_time(b) for a, b in evs)
         avg_ms = sum(per)/len(per)
-        achieved = n_ch*ALG_READ_BYTES/(avg_ms*1e-3)/1e9
+        alg_read = ALG_READ_BYTES - (FRAME if law else 0)           # G.711: 160 B of codes instead of 320 B of PCM
+        achieved = n_ch*alg_read/(avg_ms*1e-3)/1e9
         roof = {
             "bound": "hbm",
             "kernel": "tone_bank_kernel<DtmfDet<false>>",
@@ -251,21 +272,21 @@ def main():
             "unit": "GB/s",
             "frac": achieved/HBM_PEAK_GBPS,
             "traffic": None,
-            "alg_read_bytes_per_launch": n_ch*ALG_READ_BYTES,
+            "alg_read_bytes_per_launch": n_ch*alg_read,
             "alg_write_bytes_per_launch": n_ch*ALG_WRITE_BYTES,
             "avg_launch_us": avg_ms*1e3,
             "median_launch_us": per[len(per)//2]*1e3,
             "stream_us_per_step_timed_region": stream_ms*1e3/args.steps,
         }
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
+        if os.path.exists(tfile) and not law:
             try:
                 roof["traffic"] = json.load(open(tfile)).get("dtmf_bytes_per_launch")
             except Exception:
                 pass
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not law:
         nc = min(args.cpu_channels, n_ch)
         host = frames[:min(args.cpu_frames, nf), :nc].contiguous().cpu().numpy()
         cpu = cpu_baseline(host, args.cpu_loops)
@@ -289,7 +310,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: batched DTMF Goertzel bank, %d channels/GPU x %d-sample frames, "
-                            "channel-major int16 resident in HBM, %d distinct frames cycled" % (n_ch, FRAME, nf),
+                            "channel-major %s resident in HBM, %d distinct frames cycled"
+                            % (n_ch, FRAME, ("G.711 %s bytes (decoded on the device)" % args.g711) if law else "int16", nf),
                 "channels_per_gpu": n_ch,
                 "frame_samples": FRAME,
                 "parallelism": ("channels sharded x%d, RCCL gather of block records every %d steps" % (world, args.gather_every))

@@ -139,6 +139,12 @@ SPANGPU_API void *spangpu_bank_get_stream(spangpu_bank_t *bank);
    after the launch is queued on the bank stream.  Returns 0, like dtmf_rx(). */
 SPANGPU_API int spangpu_bank_rx(spangpu_bank_t *bank, const int16_t *amp, int mem, int layout,
                                 int samples, long long stride);
+/* spangpu_bank_rx() for G.711 input: one A-law / u-law byte per sample, channel-major, decoded on the device
+   (alaw_to_linear / ulaw_to_linear, src/spandsp/g711.h:165-175,239-252).  stride in bytes (= samples). */
+#define SPANGPU_G711_ALAW           1
+#define SPANGPU_G711_ULAW           2
+SPANGPU_API int spangpu_bank_rx_g711(spangpu_bank_t *bank, const uint8_t *codes, int mem, int law, int samples, long long stride);
+
 /* Advance several banks (<= 4, same device and stream, device-resident channel-major frames) with ONE kernel launch:
    a tick of a mixed population of small banks then pays the launch and ramp-up cost once.  DTMF (no dial-tone
    filter), Bell MF, R2 MF and super-tone banks can share a launch.  strides may be NULL (= samples). */

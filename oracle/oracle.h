@@ -75,6 +75,8 @@ typedef struct
 
 /* ---- Goertzel primitive ---------------------------------------------------- */
 ORC_API float orc_goertzel_fac(float freq);
+ORC_API int16_t orc_ulaw_to_linear(uint8_t ulaw);
+ORC_API int16_t orc_alaw_to_linear(uint8_t alaw);
 typedef struct
 {
     float v2;

@@ -949,3 +949,29 @@ int orc_st_rx(orc_st_t *s, const int16_t amp[], int samples, orc_sink_t *sink, o
     }
     return nblocks;
 }
+
+
+/* ---- G.711 decode (spandsp/g711.h:165-175, :239-252): the front end the tone banks can fuse ---- */
+int16_t orc_ulaw_to_linear(uint8_t ulaw)
+{
+    int t;
+
+    ulaw = (uint8_t) ~ulaw;
+    t = (((ulaw & 0x0F) << 3) + 0x84) << (((int) ulaw & 0x70) >> 4);
+    return (int16_t) ((ulaw & 0x80)  ?  (0x84 - t)  :  (t - 0x84));
+}
+
+int16_t orc_alaw_to_linear(uint8_t alaw)
+{
+    int i;
+    int seg;
+
+    alaw ^= 0x55;
+    i = ((alaw & 0x0F) << 4);
+    seg = (((int) alaw & 0x70) >> 4);
+    if (seg)
+        i = (i + 0x108) << (seg - 1);
+    else
+        i += 8;
+    return (int16_t) ((alaw & 0x80)  ?  i  :  -i);
+}

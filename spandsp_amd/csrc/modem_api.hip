@@ -418,6 +418,7 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         }
         V29_TRY(hipMemcpy2DAsync(m->d_amp, m->amp_cap*sizeof(int16_t), amp, stride*sizeof(int16_t),
                                  samples*sizeof(int16_t), m->n_ch, hipMemcpyHostToDevice, m->stream));
+        V29_TRY(hipStreamSynchronize(m->stream));         // amp[] is only borrowed for the duration of the call
         d_amp = m->d_amp;
         d_stride = (long long) m->amp_cap;
     }

@@ -63,6 +63,7 @@ struct spangpu_bank_s
     uint32_t *ext_rec;          // caller-owned record buffer for the next launches (spangpu_bank_set_records_buffer)
     size_t ext_rec_bytes;
     uint32_t *cur_rec;          // where the last launch wrote its records
+    int next_fmt;               // sample format of the launch being prepared (0 linear, 1 A-law, 2 u-law)
     float *rec_energy;
     int32_t *rec_dur;
     float *trace;
@@ -100,7 +101,7 @@ static int pick_lpc(int n_ch)
 template <class Det>
 static void launch_tone(const ToneLaunch &L, hipStream_t st)
 {
-    if (pick_lpc(L.n_ch) == 2)
+    if (L.fmt != 0  ||  pick_lpc(L.n_ch) == 2)              // G.711 input: the LPC = 2 kernels hold the decode table
     {
         const int waves = (L.n_ch + 31)/32;
         const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
@@ -388,10 +389,14 @@ static void fill_launch(ToneLaunch &L, spangpu_bank_t *b, const int16_t *d_amp, 
     L.samples = samples;
     L.n_ch = b->n_ch;
     L.layout = layout;
-    L.aligned16 = (layout == SPANGPU_LAYOUT_CHANNEL_MAJOR
-                   &&  (((uintptr_t) d_amp) & 15) == 0
-                   &&  (d_stride & 7) == 0
-                   &&  d_stride >= ((samples + 7) & ~7))  ?  1  :  0;
+    L.fmt = b->next_fmt;
+    {
+        const int spc = L.fmt  ?  16  :  8;                 // samples per 16 bytes
+        L.aligned16 = (layout == SPANGPU_LAYOUT_CHANNEL_MAJOR
+                       &&  (((uintptr_t) d_amp) & 15) == 0
+                       &&  (d_stride & (spc - 1)) == 0
+                       &&  d_stride >= ((samples + spc - 1) & ~(spc - 1)))  ?  1  :  0;
+    }
     L.sf = b->sf;
     L.si = b->si;
     L.rec = b->ext_rec  ?  b->ext_rec  :  b->rec;
@@ -497,6 +502,7 @@ int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, 
             }
             HIP_TRY(hipMemcpy2DAsync(b->d_amp, padded*sizeof(int16_t), amp, stride*sizeof(int16_t),
                                      samples*sizeof(int16_t), b->n_ch, hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));       // amp[] is only borrowed for the duration of the call
             d_stride = padded;
         }
         else
@@ -512,6 +518,7 @@ int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, 
             }
             HIP_TRY(hipMemcpy2DAsync(b->d_amp, b->n_ch*sizeof(int16_t), amp, stride*sizeof(int16_t),
                                      b->n_ch*sizeof(int16_t), samples, hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
             d_stride = b->n_ch;
         }
         d_amp = b->d_amp;
@@ -524,6 +531,59 @@ int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, 
     if (b->ext_rec  &&  (size_t) maxb*b->n_ch*sizeof(uint32_t) > b->ext_rec_bytes)
         return fail(SPANGPU_ERR_BAD_ARG, "records buffer too small for %d blocks", maxb);
     rc = launch_bank(b, d_amp, d_stride, samples, layout, maxb, 0);
+    if (rc < 0)
+        return rc;
+    b->last_maxb = maxb;
+    b->last_samples = samples;
+    return 0;
+}
+
+// spangpu_bank_rx() for G.711 input: `codes` holds one A-law or u-law byte per sample, channel-major (the wire format
+// of a trunk); the kernel decodes through a 256-entry table in LDS (alaw_to_linear / ulaw_to_linear,
+// src/spandsp/g711.h:165-175,239-252), so the PCM read traffic of the detector is halved and no decode pass is needed.
+int spangpu_bank_rx_g711(spangpu_bank_t *b, const uint8_t *codes, int mem, int law, int samples, long long stride)
+{
+    if (b == nullptr  ||  codes == nullptr  ||  samples < 0)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (law != SPANGPU_G711_ALAW  &&  law != SPANGPU_G711_ULAW)
+        return fail(SPANGPU_ERR_BAD_ARG, "law must be SPANGPU_G711_ALAW or SPANGPU_G711_ULAW");
+    if (samples == 0)
+        return 0;
+    HIP_TRY(hipSetDevice(b->device));
+    if (stride <= 0)
+        stride = samples;
+    const int maxb = (samples + b->block_len - 1)/b->block_len;
+    int rc = ensure_outputs(b, (maxb > 0)  ?  maxb  :  1);
+    if (rc != SPANGPU_OK)
+        return rc;
+    const uint8_t *d_codes = codes;
+    long long d_stride = stride;
+    if (mem == SPANGPU_MEM_HOST)
+    {
+        const long long padded = (samples + 15) & ~15LL;
+        const size_t need = ((size_t) padded*b->n_ch + 16 + 1)/2;          // in int16 units of the staging buffer
+        if (need > b->d_amp_cap)
+        {
+            if (b->d_amp) (void) hipFree(b->d_amp);
+            b->d_amp = nullptr;
+            b->d_amp_cap = 0;
+            HIP_TRY(hipMalloc(&b->d_amp, need*sizeof(int16_t)));
+            b->d_amp_cap = need;
+        }
+        HIP_TRY(hipMemcpy2DAsync(b->d_amp, padded, codes, stride, samples, b->n_ch, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));           // codes[] is only borrowed for the duration of the call
+        d_codes = (const uint8_t *) b->d_amp;
+        d_stride = padded;
+    }
+    else if (mem != SPANGPU_MEM_DEVICE)
+    {
+        return fail(SPANGPU_ERR_BAD_ARG, "bad mem kind");
+    }
+    if (b->ext_rec  &&  (size_t) maxb*b->n_ch*sizeof(uint32_t) > b->ext_rec_bytes)
+        return fail(SPANGPU_ERR_BAD_ARG, "records buffer too small for %d blocks", maxb);
+    b->next_fmt = law;
+    rc = launch_bank(b, (const int16_t *) d_codes, d_stride, samples, SPANGPU_LAYOUT_CHANNEL_MAJOR, maxb, 0);
+    b->next_fmt = 0;
     if (rc < 0)
         return rc;
     b->last_maxb = maxb;

@@ -61,6 +61,7 @@ struct ToneLaunch
     float threshold;
     float normal_twist;
     float reverse_twist;
+    int fmt;                    // 0: int16 linear PCM, 1: G.711 A-law bytes, 2: G.711 u-law bytes (channel-major, LPC = 2 kernels)
     long long *probe_ts;        // tools/probe.hip only: per-wave timestamps (kernels built with ABL & 32)
 };
 
@@ -598,7 +599,10 @@ template <int LPC>
 struct ToneLds
 {
     static constexpr int kBufBytes = (kWave/LPC)*kRowBytes;
-    static constexpr int kBytes = kWavesPerBlock*2*kBufBytes;
+    // the LPC = 2 kernels also hold the 256-entry G.711 decode table (the LPC = 1 kernels use every byte of the CU's LDS
+    // for their two workgroups, and take linear PCM only)
+    static constexpr int kLutBytes = (LPC == 2)  ?  1024  :  0;
+    static constexpr int kBytes = kWavesPerBlock*2*kBufBytes + kLutBytes;
 };
 
 // The body of the bank kernel for workgroup `wg` of the bank described by L.  It is a device function so that one
@@ -613,6 +617,34 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
     constexpr int NDMA = CPW*kChunksPerRow/kWave;               // LDS-DMA instructions per segment
     constexpr int kBufBytes = CPW*kRowBytes;
     char (*lds)[2][kBufBytes] = (char (*)[2][kBufBytes]) lds_raw;
+    const float *lut = (const float *) (lds_raw + kWavesPerBlock*2*kBufBytes);
+
+    // G.711 input: the decode table, spandsp/g711.h:165-175 (u-law) and :239-252 (A-law), as floats
+    const int bps = (LPC == 2  &&  L.fmt != 0)  ?  1  :  2;     // bytes per sample
+    if (LPC == 2  &&  L.fmt != 0)
+    {
+        float *wl = (float *) (lds_raw + kWavesPerBlock*2*kBufBytes);
+        for (int code = threadIdx.x;  code < 256;  code += kWave*kWavesPerBlock)
+        {
+            int v;
+            if (L.fmt == 2)
+            {
+                const int u = ~code & 0xFF;
+                const int t = (((u & 0x0F) << 3) + 0x84) << ((u & 0x70) >> 4);
+                v = (u & 0x80)  ?  (0x84 - t)  :  (t - 0x84);
+            }
+            else
+            {
+                const int a = code ^ 0x55;
+                int i = (a & 0x0F) << 4;
+                const int sg = (a & 0x70) >> 4;
+                i = sg  ?  ((i + 0x108) << (sg - 1))  :  (i + 8);
+                v = (a & 0x80)  ?  i  :  -i;
+            }
+            wl[code] = (float) (short) v;
+        }
+        __syncthreads();
+    }
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -636,30 +668,32 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
     };
     stamp(0);
     const bool fast_loader = (L.layout == 0)  &&  L.aligned16  &&  (L.samples > 0);
-    const int nseg = (L.samples + kSeg - 1)/kSeg;
+    const int seg_samples = kRowBytes/bps;                      // a 160-byte row is 80 linear samples or 160 G.711 codes
+    const int spc = 16/bps;                                     // samples per 16-byte chunk
+    const int nseg = (L.samples + seg_samples - 1)/seg_samples;
     const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) char *) &lds[wv][0][0];
 
     // Per-lane DMA geometry, fixed for the launch: chunk c = j*64 + lane covers row c/10,
     // 16-byte column c%10 of a segment.  Rows outside the bank follow the last channel and
     // sample offsets past the (8-sample padded) frame re-read its last chunk; neither is
     // ever consumed.
-    const int spad = (L.samples + 7) & ~7;
+    const int spad = (L.samples + spc - 1) & ~(spc - 1);
     size_t dma_row[NDMA];
-    int dma_col8[NDMA];
+    int dma_col8[NDMA];                                          // first sample of the lane's chunk within a segment
 #pragma unroll
     for (int j = 0;  j < NDMA;  j++)
     {
         const int c = j*kWave + lane;
         const int r = c/kChunksPerRow;
-        dma_col8[j] = (c - r*kChunksPerRow)*8;
-        dma_row[j] = (size_t) min(ch0 + r, L.n_ch - 1)*(size_t) L.stride*2;
+        dma_col8[j] = (c - r*kChunksPerRow)*spc;
+        dma_row[j] = (size_t) min(ch0 + r, L.n_ch - 1)*(size_t) L.stride*bps;
     }
     auto issue_dma = [&](int seg, int buf)
     {
         const void *g[NDMA];
 #pragma unroll
         for (int j = 0;  j < NDMA;  j++)
-            g[j] = (const char *) L.amp + dma_row[j] + (size_t) (2*min(seg*kSeg + dma_col8[j], spad - 8));
+            g[j] = (const char *) L.amp + dma_row[j] + (size_t) (bps*min(seg*seg_samples + dma_col8[j], spad - spc));
         dma_issue<NDMA>(g, __builtin_amdgcn_readfirstlane(lds0 + buf*kBufBytes));
     };
     // The first segment's DMA goes out ahead of the state loads.  hipcc's s_waitcnt bookkeeping does not see the
@@ -778,8 +812,8 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
 
     for (int seg = 0;  seg < nseg;  seg++)
     {
-        const int seg_base = seg*kSeg;
-        const int seglen = min(kSeg, L.samples - seg_base);
+        const int seg_base = seg*seg_samples;
+        const int seglen = min(seg_samples, L.samples - seg_base);
         const int buf = seg & 1;
         char *mybuf = &lds[wv][buf][0];
         // ---- make this segment resident in LDS -------------------------------------------
@@ -792,7 +826,13 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
         else if (sub == 0)
         {
             short *wrow = (short *) (mybuf + cl*kRowBytes);
-            if (L.layout == 0)
+            if (bps == 1)
+            {
+                const uint8_t *src = (const uint8_t *) L.amp + (size_t) ch*L.stride + seg_base;
+                for (int j = 0;  j < seglen;  j++)
+                    ((uint8_t *) wrow)[j] = src[j];
+            }
+            else if (L.layout == 0)
             {
                 const int16_t *src = L.amp + (size_t) ch*L.stride + seg_base;
                 for (int j = 0;  j < seglen;  j++)
@@ -810,7 +850,77 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
         const short *row = (const short *) rowv;
 
         // ---- consume it ------------------------------------------------------------------
-        if (uniform)
+        if (uniform  &&  bps == 1)
+        {
+            // G.711 codes: 16 samples per 16-byte chunk, each through the decode table
+            int cs_s = __builtin_amdgcn_readfirstlane(cs);
+            const int nchunks = (seglen + 15) >> 4;
+            const int nfull = seglen >> 4;
+            int4 cur = rowv[0];
+            int q = 0;
+            bool dma_due = fast_loader  &&  seg + 1 < nseg  &&  !(ABL & 16);
+            while (q < nchunks)
+            {
+                const int nrun = min(nfull - q, (block - cs_s) >> 4);
+                for (int k = 0;  k < nrun;  k++)
+                {
+                    const int4 nxt = rowv[min(q + k + 1, nchunks - 1)];
+                    if (dma_due)
+                    {
+                        issue_dma(seg + 1, buf ^ 1);
+                        dma_due = false;
+                    }
+                    float xs[16];
+#pragma unroll
+                    for (int b = 0;  b < 16;  b++)
+                    {
+                        const int w = (b < 4)  ?  cur.x  :  (b < 8)  ?  cur.y  :  (b < 12)  ?  cur.z  :  cur.w;
+                        xs[b] = lut[(w >> (8*(b & 3))) & 0xFF];
+                    }
+#pragma unroll
+                    for (int b = 0;  b < 16;  b++)
+                        one_sample(xs[b]);
+                    cur = nxt;
+                }
+                if (nrun > 0)
+                {
+                    q += nrun;
+                    cs_s += 16*nrun;
+                    take_acc += 16*nrun;
+                    if (cs_s == block)
+                    {
+                        end_block();
+                        cs_s = 0;
+                    }
+                    continue;
+                }
+                {
+                    const int4 nxt = rowv[min(q + 1, nchunks - 1)];
+                    if (dma_due)
+                    {
+                        issue_dma(seg + 1, buf ^ 1);
+                        dma_due = false;
+                    }
+                    const int n = min(16, seglen - q*16);
+                    for (int j = 0;  j < n;  j++)
+                    {
+                        const int w = (j < 4)  ?  cur.x  :  (j < 8)  ?  cur.y  :  (j < 12)  ?  cur.z  :  cur.w;
+                        one_sample(lut[(w >> (8*(j & 3))) & 0xFF]);
+                        cs_s++;
+                        take_acc++;
+                        if (cs_s == block)
+                        {
+                            end_block();
+                            cs_s = 0;
+                        }
+                    }
+                    cur = nxt;
+                    q++;
+                }
+            }
+            cs = cs_s;
+        }
+        else if (uniform)
         {
             int cs_s = __builtin_amdgcn_readfirstlane(cs);
             const int nchunks = (seglen + 7) >> 3;
@@ -892,7 +1002,7 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
             {
                 if (pos == 0  &&  fast_loader  &&  seg + 1 < nseg)
                     issue_dma(seg + 1, buf ^ 1);
-                one_sample((float) row[pos]);
+                one_sample((bps == 1)  ?  lut[((const uint8_t *) row)[pos]]  :  (float) row[pos]);
                 cs++;
                 take_acc++;
                 if (cs >= block)

@@ -71,6 +71,7 @@ def lib():
             "spangpu_bank_bins": (ci, [vp]),
             "spangpu_bank_force_block": (ci, [vp]),
             "spangpu_banks_rx": (ci, [vp, vp, ci, ci, vp]),
+            "spangpu_bank_rx_g711": (ci, [vp, vp, ci, ci, ci, ll]),
             "spangpu_bank_set_records_buffer": (ci, [vp, vp, C.c_size_t]),
             "spangpu_bank_get_stream": (vp, [vp]),
             "spangpu_modem_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
@@ -184,6 +185,15 @@ class ToneBank:
 
     def rx_device(self, ptr, samples, stride=0, layout=CHANNEL_MAJOR):
         _check(lib().spangpu_bank_rx(self.h, ptr, MEM_DEVICE, layout, samples, stride))
+
+    def rx_host_g711(self, codes, law):
+        """codes: uint8 [n_channels, samples] of A-law (law = G711_ALAW) or u-law (G711_ULAW) bytes."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        assert codes.shape[0] == self.n
+        _check(lib().spangpu_bank_rx_g711(self.h, codes.ctypes.data, MEM_HOST, law, codes.shape[1], codes.shape[1]))
+
+    def rx_device_g711(self, ptr, law, samples, stride=0):
+        _check(lib().spangpu_bank_rx_g711(self.h, ptr, MEM_DEVICE, law, samples, stride))
 
     def sync(self):
         _check(lib().spangpu_bank_sync(self.h))
@@ -306,6 +316,8 @@ class EchoBank:
 V29 = 6
 V27TER = 7
 V17 = 8
+G711_ALAW = 1
+G711_ULAW = 2
 
 _TABLES = {"sine": 0, "sqrt_tab": 1, "rrc_re": 10, "rrc_im": 11, "godard": 12, "v27_4800_re": 20, "v27_4800_im": 21,
            "v27_2400_re": 22, "v27_2400_im": 23, "v17_re": 30, "v17_im": 31, "v17_godard": 32, "v17_constellation": 33}

@@ -93,6 +93,9 @@ def main():
              clean=clean, taps32=s["taps32"], taps16=s["taps16"], history=s["history"],
              fields=np.array(ref.ECHO_FIELDS), values=np.array([s[k] for k in ref.ECHO_FIELDS]))
 
+    codes = np.arange(256)
+    save("g711_decode", alaw=np.array([L.glue_alaw_to_linear(int(c)) for c in codes], np.int16),
+         ulaw=np.array([L.glue_ulaw_to_linear(int(c)) for c in codes], np.int16))
     save("modem_tables", **ref.modem_tables())
     for bit_rate, seed, noise in V29_CASES:
         x = v29_scenario(bit_rate, seed, noise)

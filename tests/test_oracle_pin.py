@@ -342,6 +342,26 @@ def test_v29_live(built, bit_rate, seed, noise, chunks):
     assert np.array_equal(f_r, f_o)
 
 
+def test_g711_decode(built):
+    """alaw_to_linear / ulaw_to_linear (spandsp/g711.h): restatement vs the frozen reference outputs, all 256 codes
+    (and vs the live reference when it is here)."""
+    import ctypes
+    from oracle import restated as orc
+    L = orc.lib()
+    L.orc_alaw_to_linear.restype = ctypes.c_int16
+    L.orc_ulaw_to_linear.restype = ctypes.c_int16
+    L.orc_alaw_to_linear.argtypes = [ctypes.c_uint8]
+    L.orc_ulaw_to_linear.argtypes = [ctypes.c_uint8]
+    g = np.load(os.path.join(GOLDEN, "g711_decode.npz"))
+    for c in range(256):
+        assert L.orc_alaw_to_linear(c) == int(g["alaw"][c]) and L.orc_ulaw_to_linear(c) == int(g["ulaw"][c]), c
+    if have_ref():
+        from oracle import ref
+        R = ref.lib()
+        for c in range(256):
+            assert R.glue_alaw_to_linear(c) == int(g["alaw"][c]) and R.glue_ulaw_to_linear(c) == int(g["ulaw"][c]), c
+
+
 def test_trig_restatement(built):
     """The cosf/sinf restatement (oracle/modem_common.h) against this machine's libm, on a sample of [0, 2*pi]
     (the exhaustive 1.09e9-value comparison is recorded in the header of modem_common.h)."""

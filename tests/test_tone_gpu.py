@@ -5,6 +5,7 @@ every decision BIT-EXACT (the tolerance north_star allows for energies, 1e-5
 relative, is not needed: the kernels evaluate the same unfused fp32 expression tree).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -459,3 +460,47 @@ def test_records_straight_into_a_caller_buffer(built):
         b.set_records_buffer(buf, 8)
         b.rx_host(sig[:, :160])
     hip.hipFree(buf)
+
+
+# --------------------------------------------------------------------------------------
+# G.711 front end
+# --------------------------------------------------------------------------------------
+def _g711_encode(x, table):
+    """Some G.711 code whose decoded value is nearest to x (test input only; the decode is what is under test)."""
+    order = np.argsort(table.astype(np.int32), kind="stable")
+    vals = table[order].astype(np.int32)
+    pos = np.clip(np.searchsorted(vals, x.astype(np.int32)), 1, 255)
+    lower = (x - vals[pos - 1]) <= (vals[pos] - x)
+    return order[np.where(lower, pos - 1, pos)].astype(np.uint8)
+
+
+@pytest.mark.parametrize("law", ["alaw", "ulaw"])
+def test_g711_input_equals_decoded_linear_input(built, law):
+    """A bank fed A-law / u-law bytes (decoded on the device) gives exactly the records, energies and state of a bank
+    fed the reference's decode of the same bytes; DTMF and Bell MF, aligned and ragged frame lengths."""
+    from spandsp_amd import engine
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g711_decode.npz"))
+    table = g[law]
+    code = engine.G711_ALAW if law == "alaw" else engine.G711_ULAW
+    for kind, make_sig, n_ch in ((engine.DTMF, synth.dtmf_channels, 150), (engine.BELL_MF, synth.bell_mf_channels, 70)):
+        sig, _ = make_sig(n_ch, 160*40, seed=61)
+        codes = _g711_encode(sig, table)
+        lin = table[codes]                                   # what the reference's decoder makes of those bytes
+        a = engine.ToneBank(kind, n_ch, trace=True)
+        b = engine.ToneBank(kind, n_ch, trace=True)
+        hits = 0
+        for pos, n in frames_of(sig.shape[1], [160, 160, 37, 240, 400]):
+            a.rx_host(lin[:, pos:pos + n])
+            b.rx_host_g711(codes[:, pos:pos + n], code)
+            ra = a.blocks()
+            rb = b.blocks()
+            assert ra.tobytes() == rb.tobytes(), (kind, pos)
+            ta = a.trace(4)
+            tb = b.trace(4)
+            assert np.array_equal(f32_bits(ta), f32_bits(tb)), (kind, pos)
+            hits += int((ra["hit"] != 0).sum())
+        for c in (0, n_ch//2, n_ch - 1):
+            fa, ia = a.get_state(c)
+            fb, ib = b.get_state(c)
+            assert np.array_equal(f32_bits(fa), f32_bits(fb)) and np.array_equal(ia, ib), (kind, c)
+        assert hits > 50
