@@ -115,3 +115,33 @@ def test_v29_restart(built):
     assert np.array_equal(first, g["events"])
     assert np.array_equal(np.concatenate(ev), g["events"])     # a restarted receiver trains again, identically
     bank.close()
+
+
+def test_modem_edge_cases(built):
+    """Empty calls, one-channel banks, one very long call, bad arguments."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    use_golden_modem_tables()
+    g = np.load(os.path.join(GOLDEN, "v29_7200.npz"))
+    x = g["amp"]
+    bank = engine.V29Bank(1, 7200)
+    bank.rx_host(np.zeros((1, 0), np.int16))                # nothing: no launch, no events yet
+    with pytest.raises(engine.SpanGpuError):
+        bank.events()
+    bank.rx_host(x[None, :])                                # the whole transmission in one call (6130 samples)
+    ev = bank.events()[0]
+    assert np.array_equal(ev, g["events"])
+    f, w = bank.get_state(0)
+    assert np.array_equal(w, g["iwords"]) and np.array_equal(bits(f), g["fwords"])
+    with pytest.raises(engine.SpanGpuError):
+        engine.V29Bank(4, 1234)                             # no such bit rate
+    with pytest.raises(engine.SpanGpuError):
+        engine.V29Bank(0, 9600)
+    with pytest.raises(engine.SpanGpuError):
+        bank.get_state(5)
+    bank.close()
+    # a V.17 bank refuses a restart at a rate its tables are not for; a V.29 channel may change rate
+    b17 = engine.V17Bank(2, 9600)
+    assert engine.lib().spangpu_modem_restart_ex(b17.h, 0, 14400, 0) < 0
+    assert engine.lib().spangpu_modem_restart_ex(b17.h, 0, 9600, 1) == 0
+    b17.close()
