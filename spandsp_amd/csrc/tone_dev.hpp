@@ -244,17 +244,18 @@ struct DtmfDet
                 bc = i;
             }
         }
-        bool ok = (er >= L.threshold)  &&  (ec >= L.threshold);
-        ok = ok  &&  (ec < er*L.reverse_twist)  &&  (ec*L.normal_twist > er);
-        bool peaky = true;
+        // All tests are side-effect free: evaluate every one and combine with non-short-circuit logic (no divergent
+        // branches at a block end, which every lane of the wave reaches together).
+        bool ok = (er >= L.threshold)  &  (ec >= L.threshold);
+        ok = ok  &  (ec < er*L.reverse_twist)  &  (ec*L.normal_twist > er);
+        bool off_peak = false;
 #pragma unroll
         for (int i = 0;  i < 4;  i++)
         {
             // dtmf.c:243-246; relative peak ratios are both 6.309f (dtmf.c:107-108)
-            if ((i != bc  &&  e[4 + i]*6.309f > ec)  ||  (i != br  &&  e[i]*6.309f > er))
-                peaky = false;
+            off_peak |= ((i != bc)  &  (e[4 + i]*6.309f > ec))  |  ((i != br)  &  (e[i]*6.309f > er));
         }
-        ok = ok  &&  peaky  &&  ((er + ec) > 83.868f*energy);     // dtmf.c:109,250-252
+        ok = ok  &  !off_peak  &  ((er + ec) > 83.868f*energy);  // dtmf.c:109,250-252
         constexpr uint64_t k0 = pack8("123A456B");
         constexpr uint64_t k1 = pack8("789C*0#D");
         const int raw = ok  ?  key_from(k0, k1, 0, 0, (br << 2) + bc)  :  0;
@@ -329,13 +330,10 @@ __device__ __forceinline__ int mf_pick_pair(const float (&e)[6], float threshold
             es = e[i];
         }
     }
-    bool ok = (eb >= threshold)  &&  (es >= threshold)  &&  (eb < es*twist)  &&  (eb*twist > es);
+    bool ok = (eb >= threshold)  &  (es >= threshold)  &  (eb < es*twist)  &  (eb*twist > es);
 #pragma unroll
     for (int i = 0;  i < 6;  i++)
-    {
-        if (i != best  &&  i != second  &&  e[i]*rel_peak >= es)
-            ok = false;
-    }
+        ok = ok  &  !((i != best)  &  (i != second)  &  (e[i]*rel_peak >= es));
     if (!ok)
         return -1;
     const int lo = (second < best)  ?  second  :  best;
