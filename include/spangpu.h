@@ -264,6 +264,70 @@ SPANGPU_API int spangpu_modem_set_signal_cutoff(spangpu_modem_t *modem, int chan
 SPANGPU_API int spangpu_modem_table(int which, float *out, int max);
 SPANGPU_API int spangpu_v17_rx_maps(uint8_t *maps, uint8_t *map_4800);
 
+/* ---- signal source banks ------------------------------
+ * N independent cadenced tone generators / digit senders, one per channel, state in HBM.
+ * One spangpu_txbank_tx() call writes one frame of every channel with one kernel launch, so a
+ * benchmark or a loop-back test can synthesise its input where the detector banks read it.
+ * Output is bit-exact with the reference's float build on x86-64 (lfastrintf() truncates there).
+ *   spangpu_txbank_create(SPANGPU_TX_TONE_GEN) + _tone()   tone_gen_descriptor_init()+tone_gen_init()
+ *                                                          src/tone_generate.c:60-120,232-262
+ *   spangpu_txbank_tx() on a tone_gen bank                 tone_gen() x N          src/tone_generate.c:128-229
+ *   SPANGPU_TX_DTMF: _create/_put/_set_level/_set_timing/_tx   dtmf_tx_init/_put/_set_level/_set_timing/dtmf_tx
+ *                                                          src/dtmf.c:551-660
+ *   SPANGPU_TX_BELL_MF: _create/_put/_tx                   bell_mf_tx_init/_put/bell_mf_tx   src/bell_r2_mf.c:306-381
+ *   SPANGPU_TX_R2_MF_FWD/_BACK: _create/_put/_tx           r2_mf_tx_init/_put/r2_mf_tx       src/bell_r2_mf.c:399-487
+ * Differences from the reference, both at the edge of a frame: samples past the returned length are
+ * zero-filled (the reference leaves them untouched), and digits_tx_callback_t (a host callback asked for
+ * more digits when the queue runs dry, dtmf.c:566-573) is not replayed -- refill with _put() between frames.
+ */
+#define SPANGPU_TX_TONE_GEN         1
+#define SPANGPU_TX_DTMF             2
+#define SPANGPU_TX_BELL_MF          3
+#define SPANGPU_TX_R2_MF_FWD        4
+#define SPANGPU_TX_R2_MF_BACK       5
+
+typedef struct spangpu_txbank_s spangpu_txbank_t;
+
+/* The arguments of tone_gen_descriptor_init() (src/spandsp/tone_generate.h): two tones in Hz with levels in
+   dBm0 (f2 < 0: tone 1 amplitude-modulated by |f2| at l2 percent), four cadence times in ms, repeat flag. */
+typedef struct
+{
+    int f1;
+    int l1;
+    int f2;
+    int l2;
+    int d1;
+    int d2;
+    int d3;
+    int d4;
+    int repeat;
+} spangpu_tone_desc_t;
+
+SPANGPU_API int spangpu_txbank_create(spangpu_txbank_t **bank, int device, int kind, int n_channels);
+SPANGPU_API void spangpu_txbank_destroy(spangpu_txbank_t *bank);
+SPANGPU_API int spangpu_txbank_channels(const spangpu_txbank_t *bank);
+SPANGPU_API int spangpu_txbank_set_stream(spangpu_txbank_t *bank, void *hip_stream);
+SPANGPU_API int spangpu_txbank_sync(spangpu_txbank_t *bank);
+/* tone_gen_init() of one descriptor on channels [first, first + n) of a SPANGPU_TX_TONE_GEN bank */
+SPANGPU_API int spangpu_txbank_tone(spangpu_txbank_t *bank, int first, int n, const spangpu_tone_desc_t *desc);
+/* dtmf_tx_set_level(level, twist) / dtmf_tx_set_timing(on_ms, off_ms) on channels [first, first + n) */
+SPANGPU_API int spangpu_txbank_set_level(spangpu_txbank_t *bank, int first, int n, int level, int twist);
+SPANGPU_API int spangpu_txbank_set_timing(spangpu_txbank_t *bank, int first, int n, int on_time, int off_time);
+/* dtmf_tx_put()/bell_mf_tx_put(digits, len) with the same digits on every channel of the range (len < 0: strlen);
+   r2_mf_tx_put(digits[0]) on an R2 bank.  Returns 0, or -- as the reference does per channel -- the number of
+   characters that did not fit (the largest over the range; channels without room queue nothing). */
+SPANGPU_API int spangpu_txbank_put(spangpu_txbank_t *bank, int first, int n, const char *digits, int len);
+/* Per-channel digits: channel first + i gets digits[i*stride .. i*stride + lens[i]); results[i] (may be NULL) is
+   that channel's xxx_tx_put() return value. */
+SPANGPU_API int spangpu_txbank_put_each(spangpu_txbank_t *bank, int first, int n, const char *digits, int stride,
+                                        const int *lens, int *results);
+/* One frame of every channel: pcm[channel*stride + i], i < samples; lens[channel] (may be NULL) = what the
+   reference's xxx_tx() would have returned.  pcm and lens live where mem_kind says. */
+SPANGPU_API int spangpu_txbank_tx(spangpu_txbank_t *bank, int mem_kind, int16_t *pcm, long long stride, int samples, int *lens);
+/* Test / checkpoint access to one channel's generator state (layout: txgen_dev.hpp) */
+SPANGPU_API int spangpu_txbank_state_words(void);
+SPANGPU_API int spangpu_txbank_get_state(spangpu_txbank_t *bank, int channel, int32_t *words);
+
 #if defined(__cplusplus)
 }
 #endif

@@ -460,6 +460,79 @@ ORC_API int orc_v27ter_init(orc_v27ter_t *s, int bit_rate);
 ORC_API int orc_v27ter_restart(orc_v27ter_t *s, int bit_rate, int old_train);
 ORC_API int orc_v27ter_rx(orc_v27ter_t *s, const int16_t amp[], int len, orc_sink_t *sink);
 
+/* ---- signal sources: tone_gen and the digit senders built on it (tonegen_oracle.c) ---- */
+typedef struct
+{
+    int32_t phase_rate;
+    float gain;
+} orc_tone_t;
+
+typedef struct
+{
+    orc_tone_t tone[4];
+    int32_t duration[4];
+    int32_t repeat;
+} orc_tone_desc_t;
+
+typedef struct
+{
+    orc_tone_t tone[4];
+    uint32_t phase[4];
+    int32_t duration[4];
+    int32_t repeat;
+    int32_t current_section;
+    int32_t current_position;
+} orc_tone_gen_t;
+
+#define ORC_TX_QUEUE    128
+
+typedef struct
+{
+    uint8_t data[ORC_TX_QUEUE];
+    int32_t rd;
+    int32_t count;
+} orc_digit_queue_t;
+
+typedef struct
+{
+    orc_tone_gen_t tones;
+    float low_level;
+    float high_level;
+    int32_t on_time;
+    int32_t off_time;
+    orc_digit_queue_t queue;
+} orc_dtmf_tx_t;
+
+typedef struct
+{
+    orc_tone_gen_t tones;
+    orc_digit_queue_t queue;
+} orc_bell_mf_tx_t;
+
+typedef struct
+{
+    orc_tone_gen_t tone;
+    int32_t fwd;
+    int32_t digit;
+} orc_r2_mf_tx_t;
+
+ORC_API void orc_tone_desc_init(orc_tone_desc_t *d, int f1, int l1, int f2, int l2, int d1, int d2, int d3, int d4,
+                                int repeat);
+ORC_API void orc_tone_gen_init(orc_tone_gen_t *g, const orc_tone_desc_t *d);
+ORC_API int orc_tone_gen(orc_tone_gen_t *g, int16_t amp[], int max_samples);
+ORC_API void orc_dtmf_tx_init(orc_dtmf_tx_t *s);
+ORC_API void orc_dtmf_tx_set_level(orc_dtmf_tx_t *s, int level, int twist);
+ORC_API void orc_dtmf_tx_set_timing(orc_dtmf_tx_t *s, int on_time, int off_time);
+ORC_API int orc_dtmf_tx_put(orc_dtmf_tx_t *s, const char *digits, int len);
+ORC_API int orc_dtmf_tx(orc_dtmf_tx_t *s, int16_t amp[], int max_samples);
+ORC_API long long orc_dtmf_tx_run_batch(orc_dtmf_tx_t *s, int n, int16_t *amp, long long stride, int samples, int frames);
+ORC_API void orc_bell_mf_tx_init(orc_bell_mf_tx_t *s);
+ORC_API int orc_bell_mf_tx_put(orc_bell_mf_tx_t *s, const char *digits, int len);
+ORC_API int orc_bell_mf_tx(orc_bell_mf_tx_t *s, int16_t amp[], int max_samples);
+ORC_API void orc_r2_mf_tx_init(orc_r2_mf_tx_t *s, int fwd);
+ORC_API int orc_r2_mf_tx_put(orc_r2_mf_tx_t *s, char digit);
+ORC_API int orc_r2_mf_tx(orc_r2_mf_tx_t *s, int16_t amp[], int samples);
+
 #if defined(__cplusplus)
 }
 #endif

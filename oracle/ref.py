@@ -376,6 +376,71 @@ def tone_pair(f1, l1, f2, l2, samples, d1=None):
     return buf
 
 
+
+class _RefSender:
+    """A live transmitter of the real reference: put() digits, tx(n) samples."""
+    _free = None
+
+    def __del__(self):
+        try:
+            getattr(lib(), self._free)(self.p)
+        except Exception:
+            pass
+
+    def tx(self, n):
+        buf = np.zeros(max(n, 1), np.int16)
+        got = getattr(lib(), self._tx)(self.p, buf.ctypes.data, n)
+        return buf[:got].copy()
+
+
+class DtmfTx(_RefSender):
+    _free, _tx = "dtmf_tx_free", "dtmf_tx"
+
+    def __init__(self):
+        self.p = lib().dtmf_tx_init(None, None, None)
+
+    def set_level(self, level, twist):
+        lib().dtmf_tx_set_level(self.p, level, twist)
+
+    def set_timing(self, on_ms, off_ms):
+        lib().dtmf_tx_set_timing(self.p, on_ms, off_ms)
+
+    def put(self, digits):
+        b = digits if isinstance(digits, bytes) else digits.encode()
+        return lib().dtmf_tx_put(self.p, b, len(b))
+
+
+class BellMfTx(_RefSender):
+    _free, _tx = "bell_mf_tx_free", "bell_mf_tx"
+
+    def __init__(self):
+        self.p = lib().bell_mf_tx_init(None)
+
+    def put(self, digits):
+        b = digits if isinstance(digits, bytes) else digits.encode()
+        return lib().bell_mf_tx_put(self.p, b, len(b))
+
+
+class R2MfTx(_RefSender):
+    _free, _tx = "r2_mf_tx_free", "r2_mf_tx"
+
+    def __init__(self, fwd=True):
+        self.p = lib().r2_mf_tx_init(None, int(fwd))
+
+    def put(self, digit):
+        b = digit if isinstance(digit, bytes) else digit.encode()
+        return lib().r2_mf_tx_put(self.p, b[:1] if b else b"\0")
+
+
+class ToneGen(_RefSender):
+    _free, _tx = "tone_gen_free", "tone_gen"
+
+    def __init__(self, f1, l1, f2, l2, d1, d2=0, d3=0, d4=0, repeat=False):
+        d = lib().tone_gen_descriptor_init(None, f1, l1, f2, l2, d1, d2, d3, d4, int(repeat))
+        self.p = lib().tone_gen_init(None, d)
+        lib().tone_gen_descriptor_free(d)
+
+
 def awgn(seed, level_dbm0, samples):
     L = lib()
     s = L.awgn_init_dbm0(None, seed, level_dbm0)

@@ -402,3 +402,101 @@ class V17:
         f = self.buf[:4*self.N_FLOATS].view(np.float32).copy()
         w = self.buf[4*self.N_FLOATS:4*(self.N_FLOATS + self.N_INTS)].view(np.int32).copy()
         return f, w
+
+
+# ---- signal sources (tonegen_oracle.c) ------------------------------------------
+class _Tone(C.Structure):
+    _fields_ = [("phase_rate", C.c_int32), ("gain", C.c_float)]
+
+
+class ToneDesc(C.Structure):
+    _fields_ = [("tone", _Tone*4), ("duration", C.c_int32*4), ("repeat", C.c_int32)]
+
+
+class ToneGenState(C.Structure):
+    _fields_ = [("tone", _Tone*4), ("phase", C.c_uint32*4), ("duration", C.c_int32*4), ("repeat", C.c_int32),
+                ("current_section", C.c_int32), ("current_position", C.c_int32)]
+
+
+class _DigitQueue(C.Structure):
+    _fields_ = [("data", C.c_uint8*128), ("rd", C.c_int32), ("count", C.c_int32)]
+
+
+class _DtmfTxState(C.Structure):
+    _fields_ = [("tones", ToneGenState), ("low_level", C.c_float), ("high_level", C.c_float),
+                ("on_time", C.c_int32), ("off_time", C.c_int32), ("queue", _DigitQueue)]
+
+
+class _BellMfTxState(C.Structure):
+    _fields_ = [("tones", ToneGenState), ("queue", _DigitQueue)]
+
+
+class _R2MfTxState(C.Structure):
+    _fields_ = [("tone", ToneGenState), ("fwd", C.c_int32), ("digit", C.c_int32)]
+
+
+def _tx_call(fn, state, n):
+    buf = np.zeros(max(n, 1), np.int16)
+    fn.restype = C.c_int
+    got = fn(C.byref(state), C.c_void_p(buf.ctypes.data), C.c_int(n))
+    return buf[:got].copy()
+
+
+def tone_desc(f1, l1, f2, l2, d1, d2=0, d3=0, d4=0, repeat=False):
+    d = ToneDesc()
+    lib().orc_tone_desc_init(C.byref(d), f1, l1, f2, l2, d1, d2, d3, d4, int(repeat))
+    return d
+
+
+class ToneGen:
+    def __init__(self, desc):
+        self.s = ToneGenState()
+        lib().orc_tone_gen_init(C.byref(self.s), C.byref(desc))
+
+    def tx(self, n):
+        return _tx_call(lib().orc_tone_gen, self.s, n)
+
+
+class DtmfTx:
+    def __init__(self):
+        self.s = _DtmfTxState()
+        lib().orc_dtmf_tx_init(C.byref(self.s))
+
+    def set_level(self, level, twist):
+        lib().orc_dtmf_tx_set_level(C.byref(self.s), level, twist)
+
+    def set_timing(self, on_ms, off_ms):
+        lib().orc_dtmf_tx_set_timing(C.byref(self.s), on_ms, off_ms)
+
+    def put(self, digits):
+        b = digits if isinstance(digits, bytes) else digits.encode()
+        return lib().orc_dtmf_tx_put(C.byref(self.s), b, len(b))
+
+    def tx(self, n):
+        return _tx_call(lib().orc_dtmf_tx, self.s, n)
+
+
+class BellMfTx:
+    def __init__(self):
+        self.s = _BellMfTxState()
+        lib().orc_bell_mf_tx_init(C.byref(self.s))
+
+    def put(self, digits):
+        b = digits if isinstance(digits, bytes) else digits.encode()
+        return lib().orc_bell_mf_tx_put(C.byref(self.s), b, len(b))
+
+    def tx(self, n):
+        return _tx_call(lib().orc_bell_mf_tx, self.s, n)
+
+
+class R2MfTx:
+    def __init__(self, fwd=True):
+        self.s = _R2MfTxState()
+        lib().orc_r2_mf_tx_init(C.byref(self.s), int(fwd))
+
+    def put(self, digit):
+        b = digit if isinstance(digit, bytes) else digit.encode()
+        return lib().orc_r2_mf_tx_put(C.byref(self.s), C.c_char(b[:1] if b else b"\0"))
+
+    def tx(self, n):
+        return _tx_call(lib().orc_r2_mf_tx, self.s, n)

@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "modem_tables.h"
 
@@ -414,4 +415,45 @@ void spg_make_v17_rx_maps(uint8_t maps[4*36*36*8], uint8_t map_4800[36*36])
             map_4800[re*36 + im] = (uint8_t) best;
         }
     }
+}
+
+
+/* ---- tone generator descriptors ---------------------------------------------------------------- */
+int32_t spg_dds_phase_ratef(float hz)
+{
+    /* dds_phase_ratef(), dds_float.c:2109-2112: binary32 throughout */
+    return (int32_t) (hz*65536.0f*65536.0f/8000);
+}
+
+float spg_dds_scaling_dbm0f(float level)
+{
+    /* dds_scaling_dbm0f(), dds_float.c:2121-2124; DBM0_MAX_SINE_POWER = 3.14f */
+    return powf(10.0f, (level - 3.14f)/20.0f)*32767.0f;
+}
+
+void spg_make_tone_descriptor(int32_t out[13], int f1, int l1, int f2, int l2, int d1, int d2, int d3, int d4, int repeat)
+{
+    float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int i;
+
+    for (i = 0;  i < 13;  i++)
+        out[i] = 0;
+    if (f1)
+    {
+        out[0] = spg_dds_phase_ratef((float) f1);
+        if (f2 < 0)
+            out[0] = -out[0];
+        g[0] = spg_dds_scaling_dbm0f((float) l1);
+    }
+    if (f2)
+    {
+        out[1] = spg_dds_phase_ratef((float) abs(f2));
+        g[1] = (f2 < 0)  ?  (float) l2/100.0f  :  spg_dds_scaling_dbm0f((float) l2);
+    }
+    memcpy(&out[4], g, sizeof(g));
+    out[8] = d1*8000/1000;
+    out[9] = d2*8000/1000;
+    out[10] = d3*8000/1000;
+    out[11] = d4*8000/1000;
+    out[12] = repeat;
 }

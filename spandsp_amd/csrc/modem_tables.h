@@ -23,6 +23,13 @@ int spg_v17_constellation_size(int bit_rate);
 int spg_make_v17_constellation(int bit_rate, int8_t out[][2]);
 void spg_make_v17_rx_maps(uint8_t maps[4*36*36*8], uint8_t map_4800[36*36]);
 
+/* Tone generator descriptors (tone_gen_descriptor_init(), tone_generate.c:60-120).  Called with run-time
+   arguments from another translation unit so that powf() is libm's, as it is in the reference. */
+int32_t spg_dds_phase_ratef(float hz);
+float spg_dds_scaling_dbm0f(float level);
+/* out: rate[4], gain[4] (as float bits), duration[4], repeat = 13 words */
+void spg_make_tone_descriptor(int32_t out[13], int f1, int l1, int f2, int l2, int d1, int d2, int d3, int d4, int repeat);
+
 #if defined(__cplusplus)
 }
 #endif

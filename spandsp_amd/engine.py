@@ -74,6 +74,19 @@ def lib():
             "spangpu_bank_rx_g711": (ci, [vp, vp, ci, ci, ci, ll]),
             "spangpu_bank_set_records_buffer": (ci, [vp, vp, C.c_size_t]),
             "spangpu_bank_get_stream": (vp, [vp]),
+            "spangpu_txbank_create": (ci, [C.POINTER(vp), ci, ci, ci]),
+            "spangpu_txbank_destroy": (None, [vp]),
+            "spangpu_txbank_channels": (ci, [vp]),
+            "spangpu_txbank_set_stream": (ci, [vp, vp]),
+            "spangpu_txbank_sync": (ci, [vp]),
+            "spangpu_txbank_tone": (ci, [vp, ci, ci, vp]),
+            "spangpu_txbank_set_level": (ci, [vp, ci, ci, ci, ci]),
+            "spangpu_txbank_set_timing": (ci, [vp, ci, ci, ci, ci]),
+            "spangpu_txbank_put": (ci, [vp, ci, ci, C.c_char_p, ci]),
+            "spangpu_txbank_put_each": (ci, [vp, ci, ci, vp, ci, vp, vp]),
+            "spangpu_txbank_tx": (ci, [vp, ci, vp, ll, ci, vp]),
+            "spangpu_txbank_state_words": (ci, []),
+            "spangpu_txbank_get_state": (ci, [vp, ci, vp]),
             "spangpu_modem_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
             "spangpu_modem_destroy": (ci, [vp]),
             "spangpu_modem_channels": (ci, [vp]),
@@ -413,3 +426,93 @@ class V27terBank(ModemBank):
 class V17Bank(ModemBank):
     def __init__(self, n_channels, bit_rate=14400, device=0):
         super().__init__(V17, n_channels, bit_rate, device)
+
+
+# ---- signal source banks (include/spangpu.h "signal source banks") --------------------
+TX_TONE_GEN, TX_DTMF, TX_BELL_MF, TX_R2_MF_FWD, TX_R2_MF_BACK = 1, 2, 3, 4, 5
+
+
+class ToneDesc(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("f1", "l1", "f2", "l2", "d1", "d2", "d3", "d4", "repeat")]
+
+
+class TxBank:
+    """N tone generators / digit senders (tone_gen, dtmf_tx, bell_mf_tx, r2_mf_tx), state in HBM."""
+
+    def __init__(self, kind, n_channels, device=0):
+        self.kind = kind
+        self.n = n_channels
+        self.h = C.c_void_p()
+        _check(lib().spangpu_txbank_create(C.byref(self.h), device, kind, n_channels))
+
+    def close(self):
+        if self.h:
+            lib().spangpu_txbank_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _range(self, first, n):
+        return first, (self.n - first) if n is None else n
+
+    def set_stream(self, hip_stream):
+        _check(lib().spangpu_txbank_set_stream(self.h, hip_stream))
+
+    def sync(self):
+        _check(lib().spangpu_txbank_sync(self.h))
+
+    def tone(self, f1, l1, f2, l2, d1, d2=0, d3=0, d4=0, repeat=False, first=0, n=None):
+        d = ToneDesc(f1, l1, f2, l2, d1, d2, d3, d4, int(repeat))
+        first, n = self._range(first, n)
+        _check(lib().spangpu_txbank_tone(self.h, first, n, C.byref(d)))
+
+    def set_level(self, level, twist, first=0, n=None):
+        first, n = self._range(first, n)
+        _check(lib().spangpu_txbank_set_level(self.h, first, n, level, twist))
+
+    def set_timing(self, on_ms, off_ms, first=0, n=None):
+        first, n = self._range(first, n)
+        _check(lib().spangpu_txbank_set_timing(self.h, first, n, on_ms, off_ms))
+
+    def put(self, digits, first=0, n=None):
+        """The same digits to every channel of the range; returns what xxx_tx_put() returns."""
+        b = digits if isinstance(digits, bytes) else digits.encode()
+        first, n = self._range(first, n)
+        rc = lib().spangpu_txbank_put(self.h, first, n, b, len(b))
+        if rc < 0:
+            _check(rc)
+        return rc
+
+    def put_each(self, digit_strings, first=0):
+        """One digit string per channel; returns the per-channel xxx_tx_put() results."""
+        bs = [d if isinstance(d, bytes) else d.encode() for d in digit_strings]
+        n = len(bs)
+        stride = max(1, max(len(b) for b in bs))
+        buf = np.zeros((n, stride), np.uint8)
+        lens = np.zeros(n, np.int32)
+        for i, b in enumerate(bs):
+            buf[i, :len(b)] = np.frombuffer(b, np.uint8)
+            lens[i] = len(b)
+        res = np.zeros(n, np.int32)
+        rc = lib().spangpu_txbank_put_each(self.h, first, n, buf.ctypes.data, stride, lens.ctypes.data, res.ctypes.data)
+        if rc < 0:
+            _check(rc)
+        return res
+
+    def tx_host(self, samples):
+        pcm = np.zeros((self.n, samples), np.int16)
+        lens = np.zeros(self.n, np.int32)
+        _check(lib().spangpu_txbank_tx(self.h, MEM_HOST, pcm.ctypes.data, samples, samples, lens.ctypes.data))
+        return pcm, lens
+
+    def tx_device(self, pcm_ptr, stride, samples, lens_ptr=None):
+        _check(lib().spangpu_txbank_tx(self.h, MEM_DEVICE, pcm_ptr, stride, samples, lens_ptr))
+
+    def get_state(self, channel):
+        w = np.zeros(lib().spangpu_txbank_state_words(), np.int32)
+        _check(lib().spangpu_txbank_get_state(self.h, channel, w.ctypes.data))
+        return w

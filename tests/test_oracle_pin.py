@@ -342,6 +342,76 @@ def test_v29_live(built, bit_rate, seed, noise, chunks):
     assert np.array_equal(f_r, f_o)
 
 
+
+# --------------------------------------------------------------------------------------
+# signal sources: tone_gen / dtmf_tx / bell_mf_tx / r2_mf_tx (tonegen_oracle.c)
+# --------------------------------------------------------------------------------------
+TX_TONES = [(350, -13, 440, -13, 100, 0, 0, 0, True), (480, -10, 620, -10, 500, 500, 0, 0, True),
+            (425, -10, 0, 0, 200, 200, 600, 1000, False), (400, -10, -17, 50, 300, 100, 0, 0, True),
+            (1000, 0, 2000, 0, 1, 0, 0, 0, True), (440, -20, 480, -20, 30, 40, 0, 0, False)]
+
+
+def tx_scenario(make, seed):
+    """One deterministic session over every sender kind.  make: dict of constructors (the reference's or the
+    restatement's).  Returns all samples produced, the per-call lengths and the put() return values."""
+    rng = np.random.default_rng(seed)
+    out, lens, puts = [], [], []
+
+    def run(s, sizes):
+        for n in sizes:
+            x = s.tx(int(n))
+            out.append(x)
+            lens.append(len(x))
+    for t in TX_TONES:
+        run(make["tone"](*t), rng.integers(1, 700, 30))
+    for trial in range(9):
+        s = make["dtmf"]()
+        if trial % 3 == 1:
+            s.set_level(-7, 3)
+            s.set_timing(40, 30)
+        if trial % 3 == 2:
+            s.set_timing(0, 13 if trial < 6 else 0)
+        for k in range(5):
+            puts.append(s.put("".join(rng.choice(list("0123456789ABCD*#xz"), int(rng.integers(0, 90))))))
+            run(s, rng.integers(1, 2000, int(rng.integers(1, 8))))
+    for trial in range(5):
+        s = make["bell"]()
+        for k in range(5):
+            puts.append(s.put("".join(rng.choice(list("0123456789ABC*#xz"), int(rng.integers(0, 90))))))
+            run(s, rng.integers(1, 2000, int(rng.integers(1, 8))))
+    for fwd in (True, False):
+        s = make["r2"](fwd)
+        for d in "1234567890BCDEF\0x5":
+            s.put(d)
+            run(s, rng.integers(1, 500, 3))
+    return np.concatenate(out), np.array(lens, np.int32), np.array(puts, np.int32)
+
+
+def restated_senders():
+    from oracle import restated as orc
+    return {"tone": lambda *a: orc.ToneGen(orc.tone_desc(*a)), "dtmf": orc.DtmfTx, "bell": orc.BellMfTx, "r2": orc.R2MfTx}
+
+
+@needs_ref
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_tx_sources_live(built, seed):
+    from oracle import ref
+    use_golden_modem_tables()
+    want = tx_scenario({"tone": ref.ToneGen, "dtmf": ref.DtmfTx, "bell": ref.BellMfTx, "r2": ref.R2MfTx}, seed)
+    got = tx_scenario(restated_senders(), seed)
+    assert len(want[0]) > 200000
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+
+
+def test_golden_tx_sources(built):
+    use_golden_modem_tables()
+    g = np.load(os.path.join(GOLDEN, "tx_sources.npz"))
+    amp, lens, puts = tx_scenario(restated_senders(), int(g["seed"]))
+    assert np.array_equal(lens, g["lens"]) and np.array_equal(puts, g["puts"])
+    assert np.array_equal(amp, g["amp"])
+
+
 def test_g711_decode(built):
     """alaw_to_linear / ulaw_to_linear (spandsp/g711.h): restatement vs the frozen reference outputs, all 256 codes
     (and vs the live reference when it is here)."""

@@ -280,10 +280,80 @@ def bench_mixed(args, dev, stream):
         "cpu_baseline": None}
 
 
+def bench_dtmf_tx(args, dev, stream):
+    """a DTMF sender bank (dtmf_tx x N) writing 160-sample frames into HBM, digits queued up front."""
+    from spandsp_amd import engine
+    n_ch = args.channels or 65536
+    rng = np.random.default_rng(5)
+    keys = np.frombuffer(b"0123456789ABCD*#", np.uint8)
+    digs = keys[rng.integers(0, 16, (n_ch, 128))]
+    bank = engine.TxBank(engine.TX_DTMF, n_ch)
+    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    lens = np.full(n_ch, 128, np.int32)
+    res = np.zeros(n_ch, np.int32)
+    assert engine.lib().spangpu_txbank_put_each(bank.h, 0, n_ch, digs.ctypes.data, 128, lens.ctypes.data, res.ctypes.data) == 0
+    out = torch.zeros(4, n_ch, FRAME, dtype=torch.int16, device=dev)
+    d_lens = torch.zeros(n_ch, dtype=torch.int32, device=dev)
+
+    def step(i):
+        bank.tx_device(ctypes.c_void_p(out[i % 4].data_ptr()), FRAME, FRAME, ctypes.c_void_p(d_lens.data_ptr()))
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record(stream)
+        step(args.warmup + i)
+        evs[i][1].record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = [a.elapsed_time(b) for a, b in evs]
+    avg_ms = sum(per)/len(per)
+    assert int(d_lens.min()) == FRAME                     # every sender still had digits queued
+    tone_frac = float((out != 0).float().mean())         # all senders share one cadence, so look at four frames
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import restated as orc
+        from test_oracle_pin import use_golden_modem_tables
+        use_golden_modem_tables()
+        n_cpu = min(args.cpu_channels, n_ch)
+        arr = (orc._DtmfTxState*n_cpu)()
+        for c in range(n_cpu):
+            orc.lib().orc_dtmf_tx_init(ctypes.byref(arr[c]))
+            orc.lib().orc_dtmf_tx_put(ctypes.byref(arr[c]), digs[c].tobytes(), 128)
+        buf = np.zeros((n_cpu, FRAME), np.int16)
+        fn = orc.lib().orc_dtmf_tx_run_batch
+        fn.restype = ctypes.c_longlong
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
+        frames_cpu = 400
+        item = ctypes.sizeof(orc._DtmfTxState)
+
+        def work(lo, hi):
+            fn(ctypes.addressof(arr) + lo*item, hi - lo, buf[lo:].ctypes.data, FRAME, FRAME, frames_cpu)
+        cores, t = run_threads(n_cpu, work)
+        cpu = {"value": n_cpu*frames_cpu*FRAME/t/1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+               "sample": "oracle/tonegen_oracle.c orc_dtmf_tx on %d channels x %d frames, %d threads" % (n_cpu, frames_cpu, cores)}
+    alg_write = n_ch*(FRAME*2 + 4)
+    alg_read = n_ch*26*4
+    value = args.steps*n_ch*FRAME/dt/1e6
+    return {
+        "metric": "Msamples/s of batched dtmf_tx (signal source bank)", "value": value, "unit": "Msamples/s",
+        "realtime_channels": value*1e6/8000.0, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt*1e3/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "dtmf_tx bank, %d channels x %d-sample frames, 128 random digits queued per channel" % (n_ch, FRAME),
+                   "channels_per_gpu": n_ch, "non_zero_sample_fraction_in_last_4_frames": tone_frac},
+        "roofline": {"bound": "hbm", "kernel": "tx_bank_kernel", "achieved": (alg_write + alg_read)/(avg_ms*1e-3)/1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (alg_write + alg_read)/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS,
+                     "traffic": None, "alg_write_bytes_per_launch": alg_write, "alg_read_bytes_per_launch": alg_read,
+                     "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3},
+        "cpu_baseline": cpu}
+
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed"], default="v29")
+    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx"], default="v29")
     ap.add_argument("--channels", type=int, default=0)
     ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
@@ -304,6 +374,10 @@ def main():
         return
     if args.workload == "mixed":
         print(json.dumps(bench_mixed(args, dev, stream)))
+        return
+    if args.workload == "dtmf_tx":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        print(json.dumps(bench_dtmf_tx(args, dev, stream)))
         return
     fixture, bit_rate, n_words = MODEMS[args.workload]
     kind = {"v29": engine.V29, "v17": engine.V17, "v27ter": engine.V27TER}[args.workload]
