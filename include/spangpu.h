@@ -328,6 +328,69 @@ SPANGPU_API int spangpu_txbank_tx(spangpu_txbank_t *bank, int mem_kind, int16_t 
 SPANGPU_API int spangpu_txbank_state_words(void);
 SPANGPU_API int spangpu_txbank_get_state(spangpu_txbank_t *bank, int channel, int32_t *words);
 
+/* ---- FSK receiver banks --------------------------------
+ * N independent non-coherent FSK receivers of one modem spec (V.21 channel 2 in synchronous mode is the
+ * HDLC control channel that runs beside V.17 / V.29 / V.27ter in a FAX front end,
+ * src/fax_modems.c:213-323).  Integer arithmetic throughout: results are bit-exact with the reference.
+ *   spangpu_fsk_preset()                 preset_fsk_specs[]                      src/fsk.c:60-155
+ *   spangpu_fsk_create()                 fsk_rx_init(NULL, spec, mode, put_bit, user)   src/fsk.c:723-742
+ *   spangpu_fsk_rx()                     fsk_rx(s, amp, len) x N                 src/fsk.c:393-622
+ *   spangpu_fsk_events()                 the put_bit stream: bits, SIG_STATUS_CARRIER_UP (-2) / _DOWN (-1), and in
+ *                                        framed mode the received characters    src/fsk.c:343-391
+ *   spangpu_fsk_restart()                fsk_rx_restart(s, spec, mode)           src/fsk.c:660-720
+ *   spangpu_fsk_set_signal_cutoff()      fsk_rx_set_signal_cutoff()              src/fsk.c:270-276
+ *   spangpu_fsk_set_frame_parameters()   fsk_rx_set_frame_parameters()           src/fsk.c:300-316
+ *   spangpu_fsk_fillin()                 fsk_rx_fillin()                         src/fsk.c:625-657
+ *   state words 26 / 27                  fsk_rx_get_parity_errors() / _framing_errors()   src/fsk.c:318-340
+ * A bank runs one spec (its correlation window length is a property of the baud rate); the framing mode and
+ * the frame parameters are per channel.
+ */
+#define SPANGPU_FSK_V21CH1          0
+#define SPANGPU_FSK_V21CH2          1
+#define SPANGPU_FSK_V23CH1          2
+#define SPANGPU_FSK_V23CH2          3
+#define SPANGPU_FSK_BELL103CH1      4
+#define SPANGPU_FSK_BELL103CH2      5
+#define SPANGPU_FSK_BELL202         6
+#define SPANGPU_FSK_WEITBRECHT_4545 7
+#define SPANGPU_FSK_WEITBRECHT_50   8
+#define SPANGPU_FSK_WEITBRECHT_476  9
+#define SPANGPU_FSK_V21CH1_110      10
+
+#define SPANGPU_FSK_FRAME_MODE_ASYNC    0
+#define SPANGPU_FSK_FRAME_MODE_SYNC     1
+#define SPANGPU_FSK_FRAME_MODE_FRAMED   2
+
+typedef struct spangpu_fsk_s spangpu_fsk_t;
+
+/* fsk_spec_t (src/spandsp/fsk.h:85-100) without the name */
+typedef struct
+{
+    int freq_zero;      /* Hz */
+    int freq_one;
+    int tx_level;       /* dBm0 (unused by the receiver) */
+    int min_level;      /* dBm0: the carrier detect cutoff */
+    int baud_rate;      /* baud x 100 */
+} spangpu_fsk_spec_t;
+
+SPANGPU_API int spangpu_fsk_preset(int which, spangpu_fsk_spec_t *spec);
+SPANGPU_API int spangpu_fsk_create(spangpu_fsk_t **fsk, int device, int n_channels, const spangpu_fsk_spec_t *spec,
+                                   int framing_mode);
+SPANGPU_API void spangpu_fsk_destroy(spangpu_fsk_t *fsk);
+SPANGPU_API int spangpu_fsk_channels(const spangpu_fsk_t *fsk);
+SPANGPU_API int spangpu_fsk_set_stream(spangpu_fsk_t *fsk, void *hip_stream);
+SPANGPU_API int spangpu_fsk_sync(spangpu_fsk_t *fsk);
+SPANGPU_API int spangpu_fsk_rx(spangpu_fsk_t *fsk, const int16_t *amp, int mem, int samples, long long stride);
+/* events[channel*cap + i], i < counts[channel]; returns cap.  Valid until the next call on this bank. */
+SPANGPU_API int spangpu_fsk_events(spangpu_fsk_t *fsk, const int16_t **events, const int32_t **counts);
+SPANGPU_API int spangpu_fsk_state_words(const spangpu_fsk_t *fsk);
+SPANGPU_API int spangpu_fsk_get_state(spangpu_fsk_t *fsk, int channel, int32_t *words);
+SPANGPU_API int spangpu_fsk_set_state(spangpu_fsk_t *fsk, int channel, const int32_t *words);
+SPANGPU_API int spangpu_fsk_restart(spangpu_fsk_t *fsk, int channel, int framing_mode);
+SPANGPU_API int spangpu_fsk_set_signal_cutoff(spangpu_fsk_t *fsk, int channel, float cutoff_dbm0);
+SPANGPU_API int spangpu_fsk_set_frame_parameters(spangpu_fsk_t *fsk, int channel, int data_bits, int parity, int stop_bits);
+SPANGPU_API int spangpu_fsk_fillin(spangpu_fsk_t *fsk, int channel, int len);
+
 #if defined(__cplusplus)
 }
 #endif

@@ -533,6 +533,48 @@ ORC_API void orc_r2_mf_tx_init(orc_r2_mf_tx_t *s, int fwd);
 ORC_API int orc_r2_mf_tx_put(orc_r2_mf_tx_t *s, char digit);
 ORC_API int orc_r2_mf_tx(orc_r2_mf_tx_t *s, int16_t amp[], int samples);
 
+/* ---- FSK receiver (fsk_oracle.c).  Field order = the snapshot word order of ref_glue_fsk.c and of the
+   device state (spandsp_amd/csrc/fsk_dev.hpp): 28 scalars then the window as [slot][tone][re, im]. ---- */
+#define ORC_FSK_MAX_WINDOW  128
+#define ORC_FSK_SCALARS     28
+
+typedef struct
+{
+    int32_t baud_rate;
+    int32_t framing_mode;       /* 0 async, 1 sync, 2 framed (fsk.h:124-129) */
+    int32_t data_bits;
+    int32_t parity;             /* 0 none, 1 even, 2 odd, 3 mark, 4 space (async.h:151-157) */
+    int32_t stop_bits;
+    int32_t total_data_bits;
+    int32_t carrier_on_power;
+    int32_t carrier_off_power;
+    int32_t power_reading;
+    int32_t last_sample;
+    int32_t signal_present;
+    int32_t phase_rate[2];
+    uint32_t phase_acc[2];
+    int32_t correlation_span;
+    int32_t dot[2][2];
+    int32_t buf_ptr;
+    int32_t frame_pos;
+    int32_t frame_in_progress;
+    int32_t baud_phase;
+    int32_t last_bit;
+    int32_t scaling_shift;
+    int32_t parity_errors;
+    int32_t framing_errors;
+    int32_t window[ORC_FSK_MAX_WINDOW][2][2];
+} orc_fsk_t;
+
+ORC_API int orc_fsk_sizeof(void);
+ORC_API int orc_fsk_preset(int which, int32_t out[5]);
+ORC_API int orc_fsk_init(orc_fsk_t *s, const int32_t spec[5], int framing_mode);
+ORC_API int orc_fsk_restart(orc_fsk_t *s, const int32_t spec[5], int framing_mode);
+ORC_API void orc_fsk_set_signal_cutoff(orc_fsk_t *s, float cutoff);
+ORC_API void orc_fsk_set_frame_parameters(orc_fsk_t *s, int data_bits, int parity, int stop_bits);
+ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *sink);
+ORC_API int orc_fsk_fillin(orc_fsk_t *s, int len);
+
 #if defined(__cplusplus)
 }
 #endif

@@ -96,6 +96,15 @@ def lib():
             "v27ter_tx": (ci, [vp, vp, ci]), "v27ter_tx_free": (ci, [vp]), "v27ter_tx_power": (None, [vp, cf]),
             "v17_rx": (ci, [vp, vp, ci]), "v17_rx_free": (ci, [vp]),
             "v17_tx": (ci, [vp, vp, ci]), "v17_tx_free": (ci, [vp]), "v17_tx_power": (None, [vp, cf]),
+            "glue_fn_prbs_get_bit": (vp, []), "glue_fn_put_bit": (vp, []),
+            "glue_fsk_preset": (ci, [ci, vp]), "glue_fsk_rx_new": (vp, [ci, ci, vp, vp]),
+            "glue_fsk_rx_restart": (ci, [vp, ci, ci]), "glue_fsk_tx_new": (vp, [ci, vp, vp]),
+            "glue_fsk_rx_snapshot": (ci, [vp, vp]),
+            "glue_fsk_rx_new_quiet": (vp, [ci, ci, vp]), "glue_fsk_rx_batch": (None, [vp, vp, ci, C.c_longlong, ci]),
+            "glue_fsk_rx_batch_frames": (None, [vp, vp, ci, C.c_longlong, C.c_longlong, ci, ci, ci]),
+            "fsk_rx": (ci, [vp, vp, ci]), "fsk_rx_free": (ci, [vp]), "fsk_rx_fillin": (ci, [vp, ci]),
+            "fsk_rx_set_signal_cutoff": (None, [vp, cf]), "fsk_rx_set_frame_parameters": (None, [vp, ci, ci, ci]),
+            "fsk_tx": (ci, [vp, vp, ci]), "fsk_tx_free": (ci, [vp]), "fsk_tx_power": (None, [vp, cf]),
             "vec_dot_prodf": (cf, [vp, vp, ci]), "vec_circular_dot_prodf": (cf, [vp, vp, ci, ci]),
             "vec_lmsf": (None, [vp, vp, ci, cf]), "vec_circular_lmsf": (None, [vp, vp, ci, ci, cf]),
         }
@@ -642,3 +651,75 @@ def v29_tx(bit_rate, n_samples, seed=1, tep=False, level_dbm0=None):
     n = L.v29_tx(tx, buf.ctypes.data, n_samples)
     L.v29_tx_free(tx)
     return buf[:n]
+
+
+# ---- FSK (src/fsk.c) ---------------------------------------------------------------------
+FSK_PRESETS = ["V21CH1", "V21CH2", "V23CH1", "V23CH2", "BELL103CH1", "BELL103CH2", "BELL202", "WEITBRECHT_4545",
+               "WEITBRECHT_50", "WEITBRECHT_476", "V21CH1_110"]
+
+
+def fsk_preset(which):
+    out = np.zeros(5, np.int32)
+    assert lib().glue_fsk_preset(which, out.ctypes.data) == 0
+    return out
+
+
+class FskRx:
+    """fsk_rx_init(NULL, &preset_fsk_specs[which], framing_mode, put_bit, sink) of the real reference."""
+
+    def __init__(self, which, framing_mode):
+        self.sink = Sink()
+        self.p = lib().glue_fsk_rx_new(which, framing_mode, lib().glue_fn_put_bit(), self.sink.p)
+
+    def __del__(self):
+        try:
+            lib().fsk_rx_free(self.p)
+        except Exception:
+            pass
+
+    def restart(self, which, framing_mode):
+        return lib().glue_fsk_rx_restart(self.p, which, framing_mode)
+
+    def set_signal_cutoff(self, cutoff):
+        lib().fsk_rx_set_signal_cutoff(self.p, cutoff)
+
+    def set_frame_parameters(self, data_bits, parity, stop_bits):
+        lib().fsk_rx_set_frame_parameters(self.p, data_bits, parity, stop_bits)
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().fsk_rx(self.p, amp.ctypes.data, len(amp))
+
+    def fillin(self, n):
+        return lib().fsk_rx_fillin(self.p, n)
+
+    def snapshot(self):
+        out = np.zeros(28 + 4*128, np.int32)
+        n = lib().glue_fsk_rx_snapshot(self.p, out.ctypes.data)
+        return out[:n].copy()
+
+
+def fsk_tx(which, n_samples, seed=1, level_dbm0=None, bits=None):
+    """fsk_tx() fed by the glue's PRBS (or by the 0/1 array `bits`, then idle marks)."""
+    L = lib()
+    if bits is None:
+        st = (C.c_uint32*1)(seed & 0x7FFF or 1)
+        tx = L.glue_fsk_tx_new(which, L.glue_fn_prbs_get_bit(), C.cast(st, C.c_void_p))
+        keep = st
+    else:
+        seq = [int(b) for b in bits]
+        pos = [0]
+        GET = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+        def get_bit(_):
+            pos[0] += 1
+            return seq[pos[0] - 1] if pos[0] <= len(seq) else 1
+        keep = GET(get_bit)
+        tx = L.glue_fsk_tx_new(which, C.cast(keep, C.c_void_p), None)
+    if level_dbm0 is not None:
+        L.fsk_tx_power(tx, level_dbm0)
+    out = np.zeros(n_samples, np.int16)
+    got = L.fsk_tx(tx, out.ctypes.data, n_samples)
+    L.fsk_tx_free(tx)
+    del keep
+    return out[:got]

@@ -68,6 +68,14 @@ def lib():
             "orc_v27ter_init": (ci, [vp, ci]),
             "orc_v27ter_restart": (ci, [vp, ci, ci]),
             "orc_v27ter_rx": (ci, [vp, vp, ci, vp]),
+            "orc_fsk_sizeof": (ci, []),
+            "orc_fsk_preset": (ci, [ci, vp]),
+            "orc_fsk_init": (ci, [vp, vp, ci]),
+            "orc_fsk_restart": (ci, [vp, vp, ci]),
+            "orc_fsk_set_signal_cutoff": (None, [vp, cf]),
+            "orc_fsk_set_frame_parameters": (None, [vp, ci, ci, ci]),
+            "orc_fsk_rx": (ci, [vp, vp, ci, vp]),
+            "orc_fsk_fillin": (ci, [vp, ci]),
             "orc_echo_sizeof": (ci, []),
             "orc_echo_init": (ci, [vp, ci, ci]),
             "orc_echo_adaption_mode": (None, [vp, ci]),
@@ -500,3 +508,42 @@ class R2MfTx:
 
     def tx(self, n):
         return _tx_call(lib().orc_r2_mf_tx, self.s, n)
+
+
+# ---- FSK receiver (fsk_oracle.c) --------------------------------------------------------
+def fsk_preset(which):
+    out = np.zeros(5, np.int32)
+    assert lib().orc_fsk_preset(which, out.ctypes.data) == 0
+    return out
+
+
+class Fsk:
+    SCALARS = 28
+
+    def __init__(self, which, framing_mode):
+        self.buf = np.zeros(lib().orc_fsk_sizeof()//4, np.int32)
+        self.p = self.buf.ctypes.data
+        self.sink = Sink()
+        self.spec = fsk_preset(which)
+        assert lib().orc_fsk_init(self.p, self.spec.ctypes.data, framing_mode) == 0
+
+    def restart(self, which, framing_mode):
+        self.spec = fsk_preset(which)
+        return lib().orc_fsk_restart(self.p, self.spec.ctypes.data, framing_mode)
+
+    def set_signal_cutoff(self, cutoff):
+        lib().orc_fsk_set_signal_cutoff(self.p, cutoff)
+
+    def set_frame_parameters(self, data_bits, parity, stop_bits):
+        lib().orc_fsk_set_frame_parameters(self.p, data_bits, parity, stop_bits)
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().orc_fsk_rx(self.p, amp.ctypes.data, len(amp), self.sink.p)
+
+    def fillin(self, n):
+        return lib().orc_fsk_fillin(self.p, n)
+
+    def snapshot(self):
+        span = int(self.buf[15])
+        return self.buf[:self.SCALARS + 4*span].copy()

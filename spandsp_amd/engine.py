@@ -74,6 +74,21 @@ def lib():
             "spangpu_bank_rx_g711": (ci, [vp, vp, ci, ci, ci, ll]),
             "spangpu_bank_set_records_buffer": (ci, [vp, vp, C.c_size_t]),
             "spangpu_bank_get_stream": (vp, [vp]),
+            "spangpu_fsk_preset": (ci, [ci, vp]),
+            "spangpu_fsk_create": (ci, [C.POINTER(vp), ci, ci, vp, ci]),
+            "spangpu_fsk_destroy": (None, [vp]),
+            "spangpu_fsk_channels": (ci, [vp]),
+            "spangpu_fsk_set_stream": (ci, [vp, vp]),
+            "spangpu_fsk_sync": (ci, [vp]),
+            "spangpu_fsk_rx": (ci, [vp, vp, ci, ci, ll]),
+            "spangpu_fsk_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_fsk_state_words": (ci, [vp]),
+            "spangpu_fsk_get_state": (ci, [vp, ci, vp]),
+            "spangpu_fsk_set_state": (ci, [vp, ci, vp]),
+            "spangpu_fsk_restart": (ci, [vp, ci, ci]),
+            "spangpu_fsk_set_signal_cutoff": (ci, [vp, ci, cf]),
+            "spangpu_fsk_set_frame_parameters": (ci, [vp, ci, ci, ci, ci]),
+            "spangpu_fsk_fillin": (ci, [vp, ci, ci]),
             "spangpu_txbank_create": (ci, [C.POINTER(vp), ci, ci, ci]),
             "spangpu_txbank_destroy": (None, [vp]),
             "spangpu_txbank_channels": (ci, [vp]),
@@ -516,3 +531,87 @@ class TxBank:
         w = np.zeros(lib().spangpu_txbank_state_words(), np.int32)
         _check(lib().spangpu_txbank_get_state(self.h, channel, w.ctypes.data))
         return w
+
+
+# ---- FSK receiver banks (include/spangpu.h "FSK receiver banks") ------------------------
+(FSK_V21CH1, FSK_V21CH2, FSK_V23CH1, FSK_V23CH2, FSK_BELL103CH1, FSK_BELL103CH2, FSK_BELL202, FSK_WEITBRECHT_4545,
+ FSK_WEITBRECHT_50, FSK_WEITBRECHT_476, FSK_V21CH1_110) = range(11)
+FSK_FRAME_MODE_ASYNC, FSK_FRAME_MODE_SYNC, FSK_FRAME_MODE_FRAMED = 0, 1, 2
+
+
+class FskSpec(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("freq_zero", "freq_one", "tx_level", "min_level", "baud_rate")]
+
+
+def fsk_preset(which):
+    sp = FskSpec()
+    _check(lib().spangpu_fsk_preset(which, C.byref(sp)))
+    return sp
+
+
+class FskBank:
+    """N FSK receivers of one spec (fsk_rx), state in HBM."""
+
+    def __init__(self, spec, n_channels, framing_mode=FSK_FRAME_MODE_SYNC, device=0):
+        self.spec = fsk_preset(spec) if isinstance(spec, int) else spec
+        self.n = n_channels
+        self.h = C.c_void_p()
+        _check(lib().spangpu_fsk_create(C.byref(self.h), device, n_channels, C.byref(self.spec), framing_mode))
+        self.words = lib().spangpu_fsk_state_words(self.h)
+
+    def close(self):
+        if self.h:
+            lib().spangpu_fsk_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(lib().spangpu_fsk_set_stream(self.h, hip_stream))
+
+    def sync(self):
+        _check(lib().spangpu_fsk_sync(self.h))
+
+    def rx_host(self, amp):
+        amp = np.ascontiguousarray(amp, np.int16)
+        assert amp.shape[0] == self.n
+        _check(lib().spangpu_fsk_rx(self.h, amp.ctypes.data, MEM_HOST, amp.shape[1], amp.shape[1]))
+
+    def rx_device(self, ptr, samples, stride=0):
+        _check(lib().spangpu_fsk_rx(self.h, ptr, MEM_DEVICE, samples, stride))
+
+    def events(self):
+        """Per channel: the int16 put_bit() values of the last frame, in order."""
+        ev = C.c_void_p()
+        cnt = C.c_void_p()
+        cap = _check(lib().spangpu_fsk_events(self.h, C.byref(ev), C.byref(cnt)))
+        counts = np.ctypeslib.as_array(C.cast(cnt, C.POINTER(C.c_int32)), (self.n,)).copy()
+        assert counts.max(initial=0) <= cap
+        flat = np.ctypeslib.as_array(C.cast(ev, C.POINTER(C.c_int16)), (self.n*cap,)).reshape(self.n, cap)
+        return [flat[c, :counts[c]].copy() for c in range(self.n)]
+
+    def get_state(self, channel):
+        w = np.zeros(self.words, np.int32)
+        _check(lib().spangpu_fsk_get_state(self.h, channel, w.ctypes.data))
+        return w
+
+    def set_state(self, channel, w):
+        w = np.ascontiguousarray(w, np.int32)
+        assert len(w) == self.words
+        _check(lib().spangpu_fsk_set_state(self.h, channel, w.ctypes.data))
+
+    def restart(self, channel, framing_mode):
+        _check(lib().spangpu_fsk_restart(self.h, channel, framing_mode))
+
+    def set_signal_cutoff(self, channel, cutoff_dbm0):
+        _check(lib().spangpu_fsk_set_signal_cutoff(self.h, channel, cutoff_dbm0))
+
+    def set_frame_parameters(self, channel, data_bits, parity, stop_bits):
+        _check(lib().spangpu_fsk_set_frame_parameters(self.h, channel, data_bits, parity, stop_bits))
+
+    def fillin(self, channel, n):
+        _check(lib().spangpu_fsk_fillin(self.h, channel, n))

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
 from oracle import ref  # noqa: E402
-from test_oracle_pin import (ALL_FREQS, ECHO_CASES, V17_CASES, V27_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
+from test_oracle_pin import (ALL_FREQS, FSK_CASES, fsk_run, fsk_scenario, ECHO_CASES, V17_CASES, V27_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
                              tx_scenario, v17_scenario, v27ter_scenario, v29_run, v29_scenario)
 
 
@@ -112,6 +112,11 @@ def main():
         ev, f, w = v29_run(ref.V17Rx(bit_rate), x, (160,))
         assert np.count_nonzero(ev == -4) == 2 and -1 in ev
         save("v17_%d" % bit_rate, amp=x, events=ev.astype(np.int8), fwords=f, iwords=w)
+    for which, mode in FSK_CASES:
+        x = fsk_scenario(which, mode)
+        ev, snaps = fsk_run(ref.FskRx(which, mode), x, (160,))
+        assert -2 in ev and -1 in ev
+        save("fsk_%d_%d" % (which, mode), amp=x, events=ev, snapshots=snaps)
     amp, lens, puts = tx_scenario({"tone": ref.ToneGen, "dtmf": ref.DtmfTx, "bell": ref.BellMfTx, "r2": ref.R2MfTx}, 5)
     save("tx_sources", seed=5, amp=amp, lens=lens, puts=puts)
 

@@ -104,3 +104,46 @@ def call_progress_channels(n_ch, n_samples, seed):
         x = x + rng.normal(0.0, dbm0_to_amp(rng.uniform(-60.0, -40.0))/np.sqrt(2.0), size=n_samples)
         out[c] = _finish(x)
     return out
+
+
+def fsk_channels(n_ch, n_samples, seed, freq_zero, freq_one, baud_x100, framed=False, data_bits=8, parity=0):
+    """Phase-continuous FSK test signals (not the reference's modulator: any input serves a parity test).
+    Each channel: silence, a burst of random bits (or of start/data/parity/stop characters when framed=True) at a
+    random level with a little noise, silence again, sometimes a second burst.  parity: 0 none, 1 even, 2 odd."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n_ch, n_samples), np.float64)
+    spb = 800000.0/baud_x100
+    for c in range(n_ch):
+        pos = int(rng.integers(0, n_samples//6))
+        while pos < n_samples - 200:
+            length = int(rng.integers(n_samples//4, n_samples//2))
+            nbits = int(length/spb) + 2
+            if framed:
+                bits = []
+                while len(bits) < nbits:
+                    ch = int(rng.integers(0, 1 << data_bits))
+                    data = [(ch >> k) & 1 for k in range(data_bits)]
+                    word = [0] + data
+                    if parity:
+                        p = sum(data) & 1
+                        if rng.random() < 0.1:
+                            p ^= 1                      # a parity error now and then
+                        word.append(p if parity == 1 else p ^ 1)
+                    word += [1]*int(rng.integers(1, 4))
+                    if rng.random() < 0.05:
+                        word[-1] = 0                    # and a framing error
+                    bits += word
+                bits = np.array(bits[:nbits])
+            else:
+                bits = rng.integers(0, 2, nbits)
+            t = np.arange(length)
+            f = np.where(bits[np.minimum((t/spb).astype(int), nbits - 1)] == 1, freq_one, freq_zero)
+            ph = 2*np.pi*np.cumsum(f)/8000.0 + rng.uniform(0, 2*np.pi)
+            amp = dbm0_to_amp(rng.uniform(-28.0, -6.0))
+            end = min(n_samples, pos + length)
+            out[c, pos:end] += amp*np.sin(ph[:end - pos])
+            pos = end + int(rng.integers(300, n_samples//3))
+        out[c] += rng.normal(0.0, rng.uniform(1.0, 40.0), n_samples)
+        if c % 7 == 3:
+            out[c] += 300.0                             # a DC offset: the power meter sits behind a DC blocker
+    return _finish(out)

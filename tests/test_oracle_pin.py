@@ -412,6 +412,97 @@ def test_golden_tx_sources(built):
     assert np.array_equal(amp, g["amp"])
 
 
+
+# --------------------------------------------------------------------------------------
+# FSK receiver (fsk_oracle.c)
+# --------------------------------------------------------------------------------------
+FSK_CASES = [(1, 1), (1, 0), (1, 2), (0, 1), (2, 0), (3, 2), (6, 1), (7, 2), (10, 0)]       # (preset, framing mode)
+
+
+def fsk_scenario(which, mode, seed=0):
+    """Input for one FSK pin case, from the reference's own modulator: silence, a transmission (PRBS bits, or
+    start/data/stop characters for the framed mode), silence; light noise."""
+    from oracle import ref
+    rng = np.random.default_rng(1000 + which*10 + mode + seed)
+    n = 24000 if which not in (3, 7, 8, 9, 10) else 60000
+    if mode == 2:
+        bits = []
+        for ch in rng.integers(0, 256, 60):
+            bits += [0] + [(int(ch) >> k) & 1 for k in range(8)] + [1] + [1]*int(rng.integers(0, 3))
+        x = ref.fsk_tx(which, n, bits=bits)
+    else:
+        x = ref.fsk_tx(which, n, seed=which*7 + mode + 1 + seed)
+    x = x.astype(np.int32)
+    x[:500] = 0
+    x[n - 3000:] = 0
+    return np.clip(x + rng.normal(0, 30, n), -32768, 32767).astype(np.int16)
+
+
+def fsk_run(rx, x, chunks):
+    pos = 0
+    k = 0
+    snaps = []
+    while pos < len(x):
+        m = chunks[k % len(chunks)]
+        rx.rx(x[pos:pos + m])
+        pos += m
+        k += 1
+        if k % 16 == 0:
+            snaps.append(rx.snapshot())
+    snaps.append(rx.snapshot())
+    ev = np.array([e["a"] for e in rx.sink.events() if e["kind"] == 3], np.int32)
+    return ev, np.stack(snaps)
+
+
+@needs_ref
+@pytest.mark.parametrize("which,mode", FSK_CASES + [(4, 1), (5, 0), (8, 0), (9, 1)])
+@pytest.mark.parametrize("chunks", [(160,), (1, 7, 333, 64)])
+def test_fsk_live(built, which, mode, chunks):
+    from oracle import ref, restated as orc
+    x = fsk_scenario(which, mode)
+    ev_r, s_r = fsk_run(ref.FskRx(which, mode), x, chunks)
+    ev_o, s_o = fsk_run(orc.Fsk(which, mode), x, chunks)
+    assert -2 in ev_r and -1 in ev_r and len(ev_r) > 25
+    assert np.array_equal(ev_r, ev_o)
+    assert np.array_equal(s_r, s_o)
+
+
+@needs_ref
+def test_fsk_live_controls(built):
+    """set_frame_parameters (parity), set_signal_cutoff, fillin and restart, live against the reference."""
+    from oracle import ref, restated as orc
+    for parity in (1, 2, 3, 4):
+        a, b = ref.FskRx(1, 2), orc.Fsk(1, 2)
+        for s in (a, b):
+            s.set_frame_parameters(7, parity, 1)
+            s.set_signal_cutoff(-40.0)
+        x = fsk_scenario(1, 2, seed=parity)
+        for k in range(0, len(x), 160):
+            a.rx(x[k:k + 160])
+            b.rx(x[k:k + 160])
+            if k == 160*40:
+                a.fillin(160)
+                b.fillin(160)
+            if k == 160*90:
+                a.restart(1, 0)
+                b.restart(1, 0)
+            assert np.array_equal(a.snapshot(), b.snapshot()), (parity, k)
+        ea = [e["a"] for e in a.sink.events()]
+        eb = [e["a"] for e in b.sink.events()]
+        assert ea == eb and len(ea) > 20
+    for which in range(11):
+        assert np.array_equal(ref.fsk_preset(which), orc.fsk_preset(which))
+
+
+@pytest.mark.parametrize("which,mode", FSK_CASES)
+def test_golden_fsk(built, which, mode):
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, "fsk_%d_%d.npz" % (which, mode)))
+    ev, snaps = fsk_run(orc.Fsk(which, mode), g["amp"], (160,))
+    assert np.array_equal(ev, g["events"])
+    assert np.array_equal(snaps, g["snapshots"])
+
+
 def test_g711_decode(built):
     """alaw_to_linear / ulaw_to_linear (spandsp/g711.h): restatement vs the frozen reference outputs, all 256 codes
     (and vs the live reference when it is here)."""
