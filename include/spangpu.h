@@ -22,6 +22,8 @@
  *                                                                     cadence matcher :164-228,:364-448 in the host shim)
  *   spangpu_bank_create(SPANGPU_GOERTZEL)   goertzel_init() x bins    src/tone_detect.c:71-92
  *   spangpu_bank_rx() on a Goertzel bank    goertzel_update()/goertzel_result() x N x bins   src/tone_detect.c:123-205
+ *                                           plus the block's total energy: the tone front ends of src/v18.c:1546-1600 and
+ *                                           src/ademco_contactid.c:890-935 are this bank + a few comparisons on the host
  *   spangpu_bank_reset_channel()            xxx_rx_init() on a live object / dtmf_rx_fillin()  src/dtmf.c:363-379
  *
  * Threading: a bank is single-submitter (like a spandsp state object); distinct

@@ -285,7 +285,7 @@ int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_chann
             return fail(SPANGPU_ERR_BAD_ARG, "n_bins %d out of range", m);
         }
         b->nb = (m <= 4)  ?  4  :  (m <= 8)  ?  8  :  (m <= 12)  ?  12  :  16;
-        b->nsf = 2*b->nb + ((kind == SPANGPU_SUPER_TONE)  ?  1  :  0);
+        b->nsf = 2*b->nb + 1;
         b->block_len = (kind == SPANGPU_SUPER_TONE)  ?  128  :  b->tp.block_len;
         if (b->block_len <= 0  ||  b->block_len > 65535)
         {

@@ -432,9 +432,11 @@ template <int NBINS, bool SUPER>
 struct MultiDet
 {
     static constexpr int NB = NBINS;
-    static constexpr bool kEnergy = SUPER;
+    // the generic bank keeps the block's total energy too: the Goertzel users outside tone_detect.c gate their
+    // decisions on it (v18.c:1559,1597, ademco_contactid.c:903,920)
+    static constexpr bool kEnergy = true;
     static constexpr bool kDuration = false;
-    static constexpr int NSF = 2*NB + (SUPER  ?  1  :  0);
+    static constexpr int NSF = 2*NB + 1;
     __device__ static __forceinline__ int block_len(const ToneLaunch &L) { return SUPER  ?  128  :  L.block_len; }
     __device__ __forceinline__ void load_extra(const ToneLaunch &, int) {}
     __device__ __forceinline__ void store_extra(const ToneLaunch &, int) {}
@@ -519,11 +521,17 @@ struct MultiDet
             }
             energy = 0.0f;
         }
-        else if (store)
+        else
         {
-            L.rec[(size_t) nb*L.n_ch + ch] = make_rec(0, 0, kBlkValid);
-            if (L.trace)
-                write_trace<NB>(L, ein, 0.0f, ch, nb);
+            if (store)
+            {
+                if (L.rec_energy)
+                    L.rec_energy[(size_t) nb*L.n_ch + ch] = energy;
+                L.rec[(size_t) nb*L.n_ch + ch] = make_rec(0, 0, kBlkValid);
+                if (L.trace)
+                    write_trace<NB>(L, ein, energy, ch, nb);
+            }
+            energy = 0.0f;
         }
         w0 = 0;
     }

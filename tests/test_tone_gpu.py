@@ -361,6 +361,75 @@ def test_goertzel_bank(built):
             assert np.array_equal(f32_bits(a), f32_bits(b)), c
 
 
+@pytest.mark.parametrize("name,freqs,block", [
+    ("v18", [390.0, 980.0, 1180.0, 1270.0, 1300.0, 1400.0, 1650.0, 1800.0, 2225.0], 102),     # v18.c:177,200-211
+    ("ademco", [1400.0, 2300.0], 55)])                                                        # ademco_contactid.c:446,467-468
+def test_goertzel_bank_serves_the_other_goertzel_users(built, name, freqs, block):
+    """the tone front ends of v18.c (:1546-1600) and ademco_contactid.c (:890-935) are a Goertzel tone
+    set + the block's total energy + a few comparisons.  The generic bank delivers the energies and the total energy
+    bit-exact; the comparisons (a host functor here) then give the reference's raw block decision."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 130
+    rng = np.random.default_rng(5)
+    n = block*60
+    sig = np.zeros((n_ch, n))
+    t = np.arange(n)
+    for c in range(n_ch):
+        for k in range(0, n, 1500):
+            f = freqs[int(rng.integers(0, len(freqs)))]*float(rng.uniform(0.985, 1.015))
+            on = int(rng.integers(300, 1400))
+            sig[c, k:k + on] += synth.dbm0_to_amp(rng.uniform(-35.0, -8.0))*np.sin(2*np.pi*f*t[k:k + on]/8000.0 + rng.uniform(0, 6.28))
+        sig[c] += rng.normal(0.0, rng.uniform(2.0, 60.0), n)
+    sig = synth._finish(sig)
+    bank = engine.ToneBank(engine.GOERTZEL, n_ch, bin_fac=[engine.goertzel_fac(f) for f in freqs], block_len=block)
+    got = [[] for _ in range(n_ch)]
+    for pos, m in frames_of(n, [160]):
+        bank.rx_host(sig[:, pos:pos + m])
+        blk = bank.blocks()
+        if blk.size:
+            tr = bank.trace()
+            for r in blk:
+                # trace rows: the compiled bins (bank.nbins >= len(freqs)), then the block's total energy
+                row = tr[r["block"], :, r["channel"]]
+                got[r["channel"]].append(np.concatenate([row[:len(freqs)], row[bank.nbins:bank.nbins + 1]]))
+    # the literal constants of the float builds: ademco_contactid.c:461-462, v18.c:192 (its threshold is per object)
+    threshold = np.float32(49728296.6) if name == "ademco" else np.float32(10.0**((-42.0 - 3.14)/10.0)*(block*32768.0*32768.0/2.0))
+    fraction = np.float32(45.2233) if name == "ademco" else np.float32(83.868)
+
+    def decide(e, total):
+        if name == "ademco":
+            # ademco_contactid.c:918-935
+            if e[0] > threshold or e[1] > threshold:
+                if e[0] > e[1]:
+                    return 1 if e[0] > fraction*total else 0
+                return 2 if e[1] > fraction*total else 0
+            return 0
+        # v18.c:1580-1600: strict > scan from zero, then the level and fraction-of-total tests
+        best, at = np.float32(0.0), 0
+        for i in range(len(e)):
+            if e[i] > best:
+                best, at = e[i], i
+        return 0 if (best < threshold or best <= fraction*total) else at
+    hits = 0
+    for c in range(n_ch):
+        gs = [orc.Goertzel(f, block) for f in freqs]
+        for b in range(n//block):
+            seg = sig[c, b*block:(b + 1)*block]
+            for gz in gs:
+                gz.update(seg)
+            e = np.array([gz.result() for gz in gs], np.float32)
+            total = np.float32(0.0)
+            for v in seg.astype(np.float32):
+                total = np.float32(total + v*v)
+            assert np.array_equal(f32_bits(got[c][b][:len(freqs)]), f32_bits(e)), (c, b)
+            assert f32_bits(got[c][b][len(freqs):])[0] == f32_bits(np.array([total]))[0], (c, b)
+            d = decide(got[c][b][:len(freqs)], got[c][b][len(freqs)])
+            assert d == decide(e, total)
+            hits += int(d != 0)
+    assert hits > n_ch
+
+
 # --------------------------------------------------------------------------------------
 # several banks in one launch
 # --------------------------------------------------------------------------------------
