@@ -393,6 +393,42 @@ SPANGPU_API int spangpu_fsk_set_signal_cutoff(spangpu_fsk_t *fsk, int channel, f
 SPANGPU_API int spangpu_fsk_set_frame_parameters(spangpu_fsk_t *fsk, int channel, int data_bits, int parity, int stop_bits);
 SPANGPU_API int spangpu_fsk_fillin(spangpu_fsk_t *fsk, int channel, int len);
 
+/* ---- modem connect tone banks ---------------------------
+ * N detectors of one tone type: FAX CNG (1100 Hz), CED / ANS (2100 Hz) with its phase-reversal and 15 Hz AM
+ * variants, Bell answer tone (2225 Hz), calling tone (1300 Hz), and the V.21 FAX preamble (HDLC flags on the
+ * V.21 channel 2 bit stream), as run at the head of a FAX or data call beside the receivers above.
+ *   spangpu_mct_create()     modem_connect_tones_rx_init(NULL, tone_type, callback, user)   src/modem_connect_tones.c:799-857
+ *   spangpu_mct_rx()         modem_connect_tones_rx(s, amp, len) x N                       src/modem_connect_tones.c:521-785
+ *   spangpu_mct_events()     the span_tone_report_func_t calls (tone, level, 0)             src/modem_connect_tones.c:416-435
+ *   spangpu_mct_get()        modem_connect_tones_rx_get()                                   src/modem_connect_tones.c:793-797
+ * tone_type takes the MODEM_CONNECT_TONES_* codes of src/spandsp/modem_connect_tones.h:57-90 (below).
+ * use_callback = 0 replays the no-callback behaviour (reports latch `hit`, read with spangpu_mct_get()).
+ */
+#define SPANGPU_MCT_NONE                    0
+#define SPANGPU_MCT_FAX_CNG                 1
+#define SPANGPU_MCT_ANS                     2
+#define SPANGPU_MCT_ANS_PR                  3
+#define SPANGPU_MCT_ANSAM                   4
+#define SPANGPU_MCT_ANSAM_PR                5
+#define SPANGPU_MCT_FAX_PREAMBLE            6
+#define SPANGPU_MCT_FAX_CED_OR_PREAMBLE     7
+#define SPANGPU_MCT_BELL_ANS                8
+#define SPANGPU_MCT_CALLING_TONE            9
+
+typedef struct spangpu_mct_s spangpu_mct_t;
+
+SPANGPU_API int spangpu_mct_create(spangpu_mct_t **mct, int device, int tone_type, int n_channels, int use_callback);
+SPANGPU_API void spangpu_mct_destroy(spangpu_mct_t *mct);
+SPANGPU_API int spangpu_mct_channels(const spangpu_mct_t *mct);
+SPANGPU_API int spangpu_mct_set_stream(spangpu_mct_t *mct, void *hip_stream);
+SPANGPU_API int spangpu_mct_sync(spangpu_mct_t *mct);
+SPANGPU_API int spangpu_mct_rx(spangpu_mct_t *mct, const int16_t *amp, int mem, int samples, long long stride);
+/* events[(channel*cap + i)*2 + {0: tone, 1: level}], i < counts[channel]; returns cap.  Valid until the next call. */
+SPANGPU_API int spangpu_mct_events(spangpu_mct_t *mct, const int32_t **events, const int32_t **counts);
+SPANGPU_API int spangpu_mct_get(spangpu_mct_t *mct, int channel);
+SPANGPU_API int spangpu_mct_state_words(const spangpu_mct_t *mct);
+SPANGPU_API int spangpu_mct_get_state(spangpu_mct_t *mct, int channel, int32_t *words);
+
 #if defined(__cplusplus)
 }
 #endif

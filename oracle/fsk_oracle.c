@@ -126,7 +126,7 @@ ORC_API int orc_fsk_init(orc_fsk_t *s, const int32_t spec[5], int framing_mode)
     return orc_fsk_restart(s, spec, framing_mode);
 }
 
-static void deliver_frame(orc_fsk_t *s, uint32_t frame, orc_sink_t *sink)
+static void deliver_frame(orc_fsk_t *s, uint32_t frame, orc_put_bit_t put, void *user)
 {
     /* put_frame(), fsk.c:352-391; frame is the 16 bit shift register */
     if (s->parity != 0)
@@ -147,17 +147,17 @@ static void deliver_frame(orc_fsk_t *s, uint32_t frame, orc_sink_t *sink)
         default: want = 0; break;           /* ASYNC_PARITY_SPACE */
         }
         if (sent == want)
-            orc_sink_push(sink, 3, (int) frame, 0, 0);
+            put(user, (int) frame);
         else
             s->parity_errors++;
     }
     else
     {
-        orc_sink_push(sink, 3, (int) (frame >> (16 - s->total_data_bits)), 0, 0);
+        put(user, (int) (frame >> (16 - s->total_data_bits)));
     }
 }
 
-ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *sink)
+ORC_API int orc_fsk_rx_cb(orc_fsk_t *s, const int16_t amp[], int len, orc_put_bit_t put, void *user)
 {
     int ptr = s->buf_ptr;
 
@@ -201,7 +201,7 @@ ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *s
             {
                 if (--s->signal_present <= 0)
                 {
-                    orc_sink_push(sink, 3, -1, 0, 0);       /* SIG_STATUS_CARRIER_DOWN */
+                    put(user, -1);                          /* SIG_STATUS_CARRIER_DOWN */
                     s->baud_phase = 0;
                     continue;                               /* note: the window slot is not advanced */
                 }
@@ -224,7 +224,7 @@ ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *s
             s->frame_pos = -2;
             s->frame_in_progress = 0;
             s->last_bit = 0;
-            orc_sink_push(sink, 3, -2, 0, 0);               /* SIG_STATUS_CARRIER_UP */
+            put(user, -2);                                  /* SIG_STATUS_CARRIER_UP */
         }
         state = (sum[0] < sum[1]);
         if (s->framing_mode == 1)
@@ -241,7 +241,7 @@ ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *s
             if ((s->baud_phase += s->baud_rate) >= RATE_X100)
             {
                 s->baud_phase -= RATE_X100;
-                orc_sink_push(sink, 3, state, 0, 0);
+                put(user, state);
             }
         }
         else if (s->framing_mode == 0)
@@ -255,7 +255,7 @@ ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *s
             if ((s->baud_phase += s->baud_rate) >= RATE_X100)
             {
                 s->baud_phase -= RATE_X100;
-                orc_sink_push(sink, 3, state, 0, 0);
+                put(user, state);
             }
         }
         else if (s->frame_pos == -2)
@@ -295,7 +295,7 @@ ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *s
                 if (s->frame_pos++ > s->total_data_bits)
                 {
                     if (state == 1)
-                        deliver_frame(s, (uint32_t) s->frame_in_progress, sink);
+                        deliver_frame(s, (uint32_t) s->frame_in_progress, put, user);
                     else
                         s->framing_errors++;
                     s->frame_pos = -2;
@@ -313,6 +313,16 @@ ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *s
     }
     s->buf_ptr = ptr;
     return 0;
+}
+
+static void sink_put_bit(void *user, int bit)
+{
+    orc_sink_push((orc_sink_t *) user, 3, bit, 0, 0);
+}
+
+ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *sink)
+{
+    return orc_fsk_rx_cb(s, amp, len, sink_put_bit, sink);
 }
 
 ORC_API int orc_fsk_fillin(orc_fsk_t *s, int len)

@@ -572,8 +572,53 @@ ORC_API int orc_fsk_init(orc_fsk_t *s, const int32_t spec[5], int framing_mode);
 ORC_API int orc_fsk_restart(orc_fsk_t *s, const int32_t spec[5], int framing_mode);
 ORC_API void orc_fsk_set_signal_cutoff(orc_fsk_t *s, float cutoff);
 ORC_API void orc_fsk_set_frame_parameters(orc_fsk_t *s, int data_bits, int parity, int stop_bits);
+typedef void (*orc_put_bit_t)(void *user, int bit);
 ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *sink);
+ORC_API int orc_fsk_rx_cb(orc_fsk_t *s, const int16_t amp[], int len, orc_put_bit_t put, void *user);
 ORC_API int orc_fsk_fillin(orc_fsk_t *s, int len);
+
+/* ---- modem connect tones (mct_oracle.c) ---- */
+#define ORC_MCT_FAX_CNG             1
+#define ORC_MCT_ANS                 2
+#define ORC_MCT_ANS_PR              3
+#define ORC_MCT_ANSAM               4
+#define ORC_MCT_ANSAM_PR            5
+#define ORC_MCT_FAX_PREAMBLE        6
+#define ORC_MCT_FAX_CED_OR_PREAMBLE 7
+#define ORC_MCT_BELL_ANS            8
+#define ORC_MCT_CALLING_TONE        9
+
+/* The first 18 words are the detector's own state in the order of the device layout (mct_dev.hpp). */
+typedef struct
+{
+    int32_t tone_type;
+    float znotch_1;
+    float znotch_2;
+    float z15hz_1;
+    float z15hz_2;
+    int32_t notch_level;
+    int32_t channel_level;
+    int32_t am_level;
+    int32_t tone_present;
+    int32_t tone_on;
+    int32_t tone_cycle_duration;
+    int32_t good_cycles;
+    int32_t hit;
+    uint32_t raw_bit_stream;
+    int32_t num_bits;
+    int32_t flags_seen;
+    int32_t framing_ok_announced;
+    int32_t pad;
+    orc_fsk_t v21;
+    orc_sink_t *sink;
+} orc_mct_t;
+
+#define ORC_MCT_WORDS   18
+
+ORC_API int orc_mct_sizeof(void);
+ORC_API void orc_mct_init(orc_mct_t *s, int tone_type, orc_sink_t *sink);
+ORC_API int orc_mct_rx(orc_mct_t *s, const int16_t amp[], int len);
+ORC_API int orc_mct_get(orc_mct_t *s);
 
 #if defined(__cplusplus)
 }

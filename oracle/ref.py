@@ -96,7 +96,12 @@ def lib():
             "v27ter_tx": (ci, [vp, vp, ci]), "v27ter_tx_free": (ci, [vp]), "v27ter_tx_power": (None, [vp, cf]),
             "v17_rx": (ci, [vp, vp, ci]), "v17_rx_free": (ci, [vp]),
             "v17_tx": (ci, [vp, vp, ci]), "v17_tx_free": (ci, [vp]), "v17_tx_power": (None, [vp, cf]),
-            "glue_fn_prbs_get_bit": (vp, []), "glue_fn_put_bit": (vp, []),
+            "glue_fn_prbs_get_bit": (vp, []), "glue_fn_put_bit": (vp, []), "glue_fn_tone_report": (vp, []),
+            "modem_connect_tones_rx_init": (vp, [vp, ci, vp, vp]), "modem_connect_tones_rx": (ci, [vp, vp, ci]),
+            "modem_connect_tones_rx_get": (ci, [vp]), "modem_connect_tones_rx_free": (ci, [vp]),
+            "modem_connect_tones_tx_init": (vp, [vp, ci]), "modem_connect_tones_tx": (ci, [vp, vp, ci]),
+            "modem_connect_tones_tx_free": (ci, [vp]), "glue_mct_rx_snapshot": (ci, [vp, vp]),
+            "glue_mct_rx_batch_frames": (None, [vp, vp, ci, C.c_longlong, C.c_longlong, ci, ci, ci]),
             "glue_fsk_preset": (ci, [ci, vp]), "glue_fsk_rx_new": (vp, [ci, ci, vp, vp]),
             "glue_fsk_rx_restart": (ci, [vp, ci, ci]), "glue_fsk_tx_new": (vp, [ci, vp, vp]),
             "glue_fsk_rx_snapshot": (ci, [vp, vp]),
@@ -722,4 +727,41 @@ def fsk_tx(which, n_samples, seed=1, level_dbm0=None, bits=None):
     got = L.fsk_tx(tx, out.ctypes.data, n_samples)
     L.fsk_tx_free(tx)
     del keep
+    return out[:got]
+
+
+# ---- modem connect tones (src/modem_connect_tones.c) --------------------------------------
+class MctRx:
+    """modem_connect_tones_rx_init(NULL, tone_type, callback, sink); use_callback=False leaves the hit latch."""
+
+    def __init__(self, tone_type, use_callback=True):
+        self.sink = Sink()
+        self.p = lib().modem_connect_tones_rx_init(None, tone_type, lib().glue_fn_tone_report() if use_callback else None,
+                                                   self.sink.p if use_callback else None)
+
+    def __del__(self):
+        try:
+            lib().modem_connect_tones_rx_free(self.p)
+        except Exception:
+            pass
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().modem_connect_tones_rx(self.p, amp.ctypes.data, len(amp))
+
+    def get(self):
+        return lib().modem_connect_tones_rx_get(self.p)
+
+    def snapshot(self):
+        out = np.zeros(18 + 28 + 4*128, np.int32)
+        n = lib().glue_mct_rx_snapshot(self.p, out.ctypes.data)
+        return out[:n].copy()
+
+
+def modem_connect_tones_tx(tone_type, n_samples):
+    L = lib()
+    tx = L.modem_connect_tones_tx_init(None, tone_type)
+    out = np.zeros(n_samples, np.int16)
+    got = L.modem_connect_tones_tx(tx, out.ctypes.data, n_samples)
+    L.modem_connect_tones_tx_free(tx)
     return out[:got]

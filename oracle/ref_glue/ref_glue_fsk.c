@@ -132,3 +132,57 @@ GLUE void glue_fsk_rx_batch_frames(fsk_rx_state_t **s, const int16_t *amp, int n
         }
     }
 }
+
+/* ---- modem connect tones (src/modem_connect_tones.c) ---- */
+#include "spandsp/tone_detect.h"
+#include "spandsp/super_tone_rx.h"
+#include "spandsp/tone_generate.h"
+#include "spandsp/modem_connect_tones.h"
+#include "spandsp/private/tone_generate.h"
+#include "spandsp/private/modem_connect_tones.h"
+
+/* 18 words of the detector proper (floats as their bits), then the V.21 receiver's snapshot when it is in use */
+GLUE int glue_mct_rx_snapshot(const modem_connect_tones_rx_state_t *s, int32_t *out)
+{
+    int n = 0;
+
+    out[n++] = s->tone_type;
+    memcpy(&out[n++], &s->znotch_1, 4);
+    memcpy(&out[n++], &s->znotch_2, 4);
+    memcpy(&out[n++], &s->z15hz_1, 4);
+    memcpy(&out[n++], &s->z15hz_2, 4);
+    out[n++] = s->notch_level;
+    out[n++] = s->channel_level;
+    out[n++] = s->am_level;
+    out[n++] = s->tone_present;
+    out[n++] = s->tone_on;
+    out[n++] = s->tone_cycle_duration;
+    out[n++] = s->good_cycles;
+    out[n++] = s->hit;
+    out[n++] = (int32_t) s->raw_bit_stream;
+    out[n++] = s->num_bits;
+    out[n++] = s->flags_seen;
+    out[n++] = s->framing_ok_announced;
+    out[n++] = 0;
+    if (s->tone_type == MODEM_CONNECT_TONES_FAX_PREAMBLE  ||  s->tone_type == MODEM_CONNECT_TONES_FAX_CED_OR_PREAMBLE)
+        n += glue_fsk_rx_snapshot(&s->v21rx, out + n);
+    return n;
+}
+
+/* CPU baseline helper: `frames` consecutive frames, `loops` times, on n detectors (no callback: hits latch) */
+GLUE void glue_mct_rx_batch_frames(modem_connect_tones_rx_state_t **s, const int16_t *amp, int n, long long stride,
+                                   long long frame_stride, int samples, int frames, int loops)
+{
+    int c;
+    int f;
+    int l;
+
+    for (l = 0;  l < loops;  l++)
+    {
+        for (f = 0;  f < frames;  f++)
+        {
+            for (c = 0;  c < n;  c++)
+                modem_connect_tones_rx(s[c], amp + f*frame_stride + c*stride, samples);
+        }
+    }
+}

@@ -76,6 +76,10 @@ def lib():
             "orc_fsk_set_frame_parameters": (None, [vp, ci, ci, ci]),
             "orc_fsk_rx": (ci, [vp, vp, ci, vp]),
             "orc_fsk_fillin": (ci, [vp, ci]),
+            "orc_mct_sizeof": (ci, []),
+            "orc_mct_init": (None, [vp, ci, vp]),
+            "orc_mct_rx": (ci, [vp, vp, ci]),
+            "orc_mct_get": (ci, [vp]),
             "orc_echo_sizeof": (ci, []),
             "orc_echo_init": (ci, [vp, ci, ci]),
             "orc_echo_adaption_mode": (None, [vp, ci]),
@@ -547,3 +551,28 @@ class Fsk:
     def snapshot(self):
         span = int(self.buf[15])
         return self.buf[:self.SCALARS + 4*span].copy()
+
+
+# ---- modem connect tones (mct_oracle.c) ---------------------------------------------------
+class Mct:
+    WORDS = 18
+
+    def __init__(self, tone_type, use_callback=True):
+        self.buf = np.zeros(lib().orc_mct_sizeof()//4 + 2, np.int32)
+        self.p = self.buf.ctypes.data
+        self.sink = Sink()
+        lib().orc_mct_init(self.p, tone_type, self.sink.p if use_callback else None)
+
+    def rx(self, amp):
+        amp = _i16(amp)
+        return lib().orc_mct_rx(self.p, amp.ctypes.data, len(amp))
+
+    def get(self):
+        return lib().orc_mct_get(self.p)
+
+    def snapshot(self):
+        w = self.buf[:self.WORDS].copy()
+        if int(w[0]) in (6, 7):
+            span = int(self.buf[self.WORDS + 15])
+            return np.concatenate([w, self.buf[self.WORDS:self.WORDS + 28 + 4*span]])
+        return w

@@ -29,6 +29,63 @@ extern "C" int spangpu_set_error(int code, const char *msg);
     }                                                                                       \
     while (0)
 
+namespace spg
+{
+
+__global__ __launch_bounds__(64) void fsk_bank_kernel(const FskLaunch L)
+{
+    extern __shared__ int32_t win[];        // [4*span][64]
+    __shared__ int16_t quarter[260];        // [257]; a separate object, so that table reads can move across window writes
+    const int lane = threadIdx.x;
+    const int ch = blockIdx.x*64 + lane;
+    const bool live = ch < L.n_ch;
+    const size_t n = (size_t) L.n_ch;
+    const int span = L.span;
+
+    for (int i = lane;  i < 257;  i += 64)
+        quarter[i] = L.quarter[i];
+    // (a lane past the end of the bank reads channel 0's words and stops after the barrier)
+    int32_t *st = L.st + (live  ?  ch  :  0);
+    fsk_load_window(win, st + (size_t) kFskScalars*n, n, span, lane);
+    __syncthreads();
+    if (!live)
+        return;
+
+    FskRegs r;
+    fsk_load_regs(r, st, n);
+    int16_t *ev = L.events + (size_t) ch*L.ev_cap;
+    const int ev_cap = L.ev_cap;
+    auto emit = [&](int v)
+    {
+        if (r.n_ev < ev_cap)
+            ev[r.n_ev] = (int16_t) v;
+        r.n_ev++;
+    };
+    const int16_t *row = L.pcm + (size_t) ch*L.stride;
+    for (int base = 0;  base < L.samples;  base += 8)
+    {
+        const int todo = (L.samples - base < 8)  ?  (L.samples - base)  :  8;
+        int32_t a[8];
+        int32_t c0[8];
+        int32_t q0[8];
+        int32_t c1[8];
+        int32_t q1[8];
+        fsk_block_samples(row, base, todo, L.vec != 0, a);
+        fsk_block_lookups(r, quarter, todo, c0, q0, c1, q1);
+#pragma unroll
+        for (int k = 0;  k < 8;  k++)
+        {
+            if (k < todo)
+                fsk_step(r, win, lane, span, a[k], c0[k], q0[k], c1[k], q1[k], emit);
+        }
+    }
+    fsk_store_regs(r, st, n);
+    fsk_store_window(win, st + (size_t) kFskScalars*n, n, span, lane);
+    L.ev_count[ch] = r.n_ev;
+}
+
+}   // namespace spg
+
 struct spangpu_fsk_s
 {
     int device;

@@ -85,39 +85,18 @@ struct FskRegs
     int32_t n_ev;
 };
 
-__global__ __launch_bounds__(64) void fsk_bank_kernel(const FskLaunch L)
+// dds_lookup(), dds_int.c: one quadrant of a sine, mirrored and negated
+__device__ __forceinline__ int32_t fsk_lookup(const int16_t *quarter, uint32_t phase)
 {
-    extern __shared__ int32_t win[];        // [4*span][64]
-    __shared__ int16_t quarter[260];        // [257]; a separate object, so that table reads can move across window writes
-    const int lane = threadIdx.x;
-    const int ch = blockIdx.x*64 + lane;
-    const bool live = ch < L.n_ch;
-    const size_t n = (size_t) L.n_ch;
-    const int span = L.span;
+    const uint32_t p = phase >> 22;
+    uint32_t step = p & 255u;
+    step = (p & 256u)  ?  (256u - step)  :  step;
+    const int32_t amp = quarter[step];
+    return (p & 512u)  ?  -amp  :  amp;
+}
 
-    for (int i = lane;  i < 257;  i += 64)
-        quarter[i] = L.quarter[i];
-    // (a lane past the end of the bank reads channel 0's words and stops after the barrier)
-    int32_t *st = L.st + (live  ?  ch  :  0);
-    // the window comes in sixteen words at a time, all sixteen loads in flight before the first LDS write
-    for (int w0 = 0;  w0 < 4*span;  w0 += 16)
-    {
-        int32_t t[16];
-#pragma unroll
-        for (int k = 0;  k < 16;  k++)
-            t[k] = st[(size_t) (kFskScalars + ((w0 + k < 4*span)  ?  (w0 + k)  :  0))*n];
-#pragma unroll
-        for (int k = 0;  k < 16;  k++)
-        {
-            if (w0 + k < 4*span)
-                win[(w0 + k)*64 + lane] = t[k];
-        }
-    }
-    __syncthreads();
-    if (!live)
-        return;
-
-    FskRegs r;
+__device__ __forceinline__ void fsk_load_regs(FskRegs &r, const int32_t *st, size_t n)
+{
     r.baud_rate = st[FS_BAUD_RATE*n];
     r.framing = st[FS_FRAMING*n];
     r.parity = st[FS_PARITY*n];
@@ -144,236 +123,10 @@ __global__ __launch_bounds__(64) void fsk_bank_kernel(const FskLaunch L)
     r.parity_err = st[FS_PARITY_ERR*n];
     r.framing_err = st[FS_FRAMING_ERR*n];
     r.n_ev = 0;
+}
 
-    int16_t *ev = L.events + (size_t) ch*L.ev_cap;
-    const int ev_cap = L.ev_cap;
-    auto emit = [&](int v)
-    {
-        if (r.n_ev < ev_cap)
-            ev[r.n_ev] = (int16_t) v;
-        r.n_ev++;
-    };
-    auto lookup = [&](uint32_t phase) -> int32_t
-    {
-        // dds_lookup(), dds_int.c
-        const uint32_t p = phase >> 22;
-        uint32_t step = p & 255u;
-        step = (p & 256u)  ?  (256u - step)  :  step;
-        const int32_t amp = quarter[step];
-        return (p & 512u)  ?  -amp  :  amp;
-    };
-    // One sample of fsk_rx(), fsk.c:408-618.  Returns without advancing the window slot where the
-    // reference `continue`s.
-    auto step = [&](int32_t a, int32_t c0, int32_t q0, int32_t c1, int32_t q1)
-    {
-        int32_t *slot = win + (r.ptr*4)*64 + lane;
-        int32_t sum0;
-        int32_t sum1;
-        {
-            const int32_t c = c0;
-            const int32_t q = q0;
-            const int32_t nre = __mul24(c, a) >> r.shift;        // 16 bit x 16 bit
-            const int32_t nim = __mul24(q, a) >> r.shift;
-            r.dot0re += nre - slot[0];
-            r.dot0im += nim - slot[64];
-            slot[0] = nre;
-            slot[64] = nim;
-            const int32_t dr = r.dot0re >> 15;
-            const int32_t di = r.dot0im >> 15;
-            sum0 = __mul24(dr, dr) + __mul24(di, di);       // |dot| < 2^30 (span values of < 2^30/2^shift), so 24 bit multiplies are exact
-        }
-        {
-            const int32_t c = c1;
-            const int32_t q = q1;
-            const int32_t nre = __mul24(c, a) >> r.shift;        // 16 bit x 16 bit
-            const int32_t nim = __mul24(q, a) >> r.shift;
-            r.dot1re += nre - slot[128];
-            r.dot1im += nim - slot[192];
-            slot[128] = nre;
-            slot[192] = nim;
-            const int32_t dr = r.dot1re >> 15;
-            const int32_t di = r.dot1im >> 15;
-            sum1 = __mul24(dr, dr) + __mul24(di, di);
-        }
-        // power behind a one-tap DC blocker, fsk.c:425-431
-        const int32_t x = a >> 1;
-        const int32_t diff = (int32_t) (int16_t) (x - r.last_sample);
-        r.power += (__mul24(diff, diff) - r.power) >> 4;
-        r.last_sample = x;
-        // Carrier detect, fsk.c:433-475, as selects (the branches are data dependent per lane and nearly all of
-        // them just move a counter).  drop / quiet / counting are the three places the reference `continue`s.
-        const bool present = (r.signal_present != 0);
-        const bool low_off = (r.power < r.off_power);
-        const bool low_on = (r.power < r.on_power);
-        const bool dec = present  &&  low_off;
-        const int32_t sp1 = r.signal_present - 1;
-        const bool drop = dec  &&  (sp1 <= 0);
-        const bool quiet = !present  &&  low_on;
-        const bool counting = !present  &&  !low_on  &&  (r.baud_phase < (span >> 1) - 30);
-        const bool rise = !present  &&  !low_on  &&  !counting;
-        r.signal_present = dec  ?  sp1  :  (rise  ?  1  :  r.signal_present);
-        r.baud_phase = (drop  ||  quiet  ||  rise)  ?  0  :  (counting  ?  (r.baud_phase + 1)  :  r.baud_phase);
-        r.frame_pos = rise  ?  -2  :  r.frame_pos;
-        r.frame = rise  ?  0  :  r.frame;
-        r.last_bit = rise  ?  0  :  r.last_bit;
-        if (drop)
-            emit(-1);                               // SIG_STATUS_CARRIER_DOWN
-        if (rise)
-            emit(-2);                               // SIG_STATUS_CARRIER_UP
-        if (drop  ||  quiet  ||  counting)
-            return;
-        const int state = (sum0 < sum1)  ?  1  :  0;
-        if (r.framing != 2)
-        {
-            // synchronous (fsk.c:489-512): a transition nudges the baud phase towards the middle of the baud;
-            // asynchronous (fsk.c:513-537): a transition sets it there.  Then one bit per baud.
-            const bool change = (r.last_bit != state);
-            const int32_t eighth = r.baud_rate >> 3;
-            const int32_t nudged = r.baud_phase + ((r.baud_phase < kFskRateX100/2)  ?  eighth  :  -eighth);
-            const int32_t moved = (r.framing == 1)  ?  nudged  :  (kFskRateX100/2);
-            r.last_bit = state;
-            const int32_t bp = (change  ?  moved  :  r.baud_phase) + r.baud_rate;
-            const bool fire = (bp >= kFskRateX100);
-            r.baud_phase = fire  ?  (bp - kFskRateX100)  :  bp;
-            if (fire)
-                emit(state);
-        }
-        else if (r.frame_pos == -2)
-        {
-            // framed, fsk.c:538-614: hunting for a start bit
-            if (state == 0)
-            {
-                r.baud_phase = 8000*(100 - 40)/2;
-                r.frame_pos = -1;
-                r.frame = 0;
-                r.last_bit = -1;
-            }
-        }
-        else if (r.frame_pos == -1)
-        {
-            if (state != 0)
-            {
-                r.frame_pos = -2;
-            }
-            else
-            {
-                r.baud_phase += r.baud_rate;
-                if (r.baud_phase >= kFskRateX100)
-                {
-                    r.frame_pos = 0;
-                    r.last_bit = state;
-                }
-            }
-        }
-        else
-        {
-            r.baud_phase += r.baud_rate;
-            if (r.baud_phase >= 8000*(100 - 40))
-            {
-                if (r.last_bit < 0)
-                    r.last_bit = state;
-                if (r.last_bit != state)
-                {
-                    r.frame_pos = -2;
-                    r.framing_err++;
-                }
-                else if (r.baud_phase >= kFskRateX100)
-                {
-                    if (r.frame_pos++ > r.total_bits)
-                    {
-                        if (state == 1)
-                        {
-                            // put_frame(), fsk.c:352-391
-                            uint32_t frame = (uint32_t) r.frame & 0xFFFFu;
-                            if (r.parity != 0)
-                            {
-                                const uint32_t sent = (frame >> 15) & 1u;
-                                frame = (frame & 0x7FFFu) >> (16 - r.total_bits);
-                                uint32_t x8 = frame & 0xFFu;
-                                x8 = (x8 ^ (x8 >> 4)) & 0x0Fu;
-                                x8 = (0x6996u >> x8) & 1u;
-                                uint32_t want = 0u;                 // ASYNC_PARITY_SPACE
-                                want = (r.parity == 2)  ?  (x8 ^ 1u)  :  want;
-                                want = (r.parity == 1)  ?  x8  :  want;
-                                want = (r.parity == 3)  ?  1u  :  want;
-                                if (sent == want)
-                                    emit((int) frame);
-                                else
-                                    r.parity_err++;
-                            }
-                            else
-                            {
-                                emit((int) (frame >> (16 - r.total_bits)));
-                            }
-                        }
-                        else
-                        {
-                            r.framing_err++;
-                        }
-                        r.frame_pos = -2;
-                    }
-                    else
-                    {
-                        r.frame = ((r.frame >> 1) | (state << 15)) & 0xFFFF;
-                    }
-                    r.baud_phase -= kFskRateX100;
-                    r.last_bit = -1;
-                }
-            }
-        }
-        r.ptr = (r.ptr + 1 >= span)  ?  0  :  (r.ptr + 1);
-    };
-
-    // The two oscillators run on whatever the receiver does with a sample (dds_complexi() is called before any
-    // of the early outs), so the table look-ups of a block of eight samples are issued together, ahead of
-    // the sample-serial part.
-    const int16_t *row = L.pcm + (size_t) ch*L.stride;
-    for (int base = 0;  base < L.samples;  base += 8)
-    {
-        const int todo = (L.samples - base < 8)  ?  (L.samples - base)  :  8;
-        int32_t a[8];
-        if (L.vec  &&  todo == 8)
-        {
-            const uint4 q = *reinterpret_cast<const uint4 *>(row + base);
-            a[0] = (int32_t) (int16_t) (q.x & 0xFFFFu);
-            a[1] = (int32_t) q.x >> 16;
-            a[2] = (int32_t) (int16_t) (q.y & 0xFFFFu);
-            a[3] = (int32_t) q.y >> 16;
-            a[4] = (int32_t) (int16_t) (q.z & 0xFFFFu);
-            a[5] = (int32_t) q.z >> 16;
-            a[6] = (int32_t) (int16_t) (q.w & 0xFFFFu);
-            a[7] = (int32_t) q.w >> 16;
-        }
-        else
-        {
-#pragma unroll
-            for (int k = 0;  k < 8;  k++)
-                a[k] = (k < todo)  ?  (int32_t) row[base + k]  :  0;
-        }
-        int32_t c0[8];
-        int32_t q0[8];
-        int32_t c1[8];
-        int32_t q1[8];
-#pragma unroll
-        for (int k = 0;  k < 8;  k++)
-        {
-            const uint32_t p0 = r.acc0 + (uint32_t) k*(uint32_t) r.rate0;
-            const uint32_t p1 = r.acc1 + (uint32_t) k*(uint32_t) r.rate1;
-            c0[k] = lookup(p0 + (1u << 30));
-            q0[k] = lookup(p0);
-            c1[k] = lookup(p1 + (1u << 30));
-            q1[k] = lookup(p1);
-        }
-        r.acc0 += (uint32_t) todo*(uint32_t) r.rate0;
-        r.acc1 += (uint32_t) todo*(uint32_t) r.rate1;
-#pragma unroll
-        for (int k = 0;  k < 8;  k++)
-        {
-            if (k < todo)
-                step(a[k], c0[k], q0[k], c1[k], q1[k]);
-        }
-    }
-
+__device__ __forceinline__ void fsk_store_regs(const FskRegs &r, int32_t *st, size_t n)
+{
     st[FS_POWER*n] = r.power;
     st[FS_LAST_SAMPLE*n] = r.last_sample;
     st[FS_SIGNAL_PRESENT*n] = r.signal_present;
@@ -390,9 +143,238 @@ __global__ __launch_bounds__(64) void fsk_bank_kernel(const FskLaunch L)
     st[FS_LAST_BIT*n] = r.last_bit;
     st[FS_PARITY_ERR*n] = r.parity_err;
     st[FS_FRAMING_ERR*n] = r.framing_err;
+}
+
+// The correlation windows of a wave's 64 channels, HBM <-> LDS ([word][lane]); sixteen words at a time, all
+// sixteen loads in flight before the first LDS write.
+__device__ __forceinline__ void fsk_load_window(int32_t *win, const int32_t *st_win, size_t n, int span, int lane)
+{
+    for (int w0 = 0;  w0 < 4*span;  w0 += 16)
+    {
+        int32_t t[16];
+#pragma unroll
+        for (int k = 0;  k < 16;  k++)
+            t[k] = st_win[(size_t) ((w0 + k < 4*span)  ?  (w0 + k)  :  0)*n];
+#pragma unroll
+        for (int k = 0;  k < 16;  k++)
+        {
+            if (w0 + k < 4*span)
+                win[(w0 + k)*64 + lane] = t[k];
+        }
+    }
+}
+
+__device__ __forceinline__ void fsk_store_window(const int32_t *win, int32_t *st_win, size_t n, int span, int lane)
+{
     for (int w = 0;  w < 4*span;  w++)
-        st[(size_t) (kFskScalars + w)*n] = win[w*64 + lane];
-    L.ev_count[ch] = r.n_ev;
+        st_win[(size_t) w*n] = win[w*64 + lane];
+}
+
+// One sample of fsk_rx(), fsk.c:408-618; (c0, q0) and (c1, q1) are the two oscillators' cos / sin for this
+// sample.  emit(v) stands for put_bit(v).  Returns without advancing the window slot where the reference
+// `continue`s.
+template <class Emit>
+__device__ __forceinline__ void fsk_step(FskRegs &r, int32_t *win, int lane, int span, int32_t a, int32_t c0, int32_t q0,
+                                         int32_t c1, int32_t q1, Emit &&emit)
+{
+    int32_t *slot = win + (r.ptr*4)*64 + lane;
+    int32_t sum0;
+    int32_t sum1;
+    {
+        const int32_t c = c0;
+        const int32_t q = q0;
+        const int32_t nre = __mul24(c, a) >> r.shift;        // 16 bit x 16 bit
+        const int32_t nim = __mul24(q, a) >> r.shift;
+        r.dot0re += nre - slot[0];
+        r.dot0im += nim - slot[64];
+        slot[0] = nre;
+        slot[64] = nim;
+        const int32_t dr = r.dot0re >> 15;
+        const int32_t di = r.dot0im >> 15;
+        sum0 = __mul24(dr, dr) + __mul24(di, di);       // |dot| < 2^30 (span values of < 2^30/2^shift), so 24 bit multiplies are exact
+    }
+    {
+        const int32_t c = c1;
+        const int32_t q = q1;
+        const int32_t nre = __mul24(c, a) >> r.shift;        // 16 bit x 16 bit
+        const int32_t nim = __mul24(q, a) >> r.shift;
+        r.dot1re += nre - slot[128];
+        r.dot1im += nim - slot[192];
+        slot[128] = nre;
+        slot[192] = nim;
+        const int32_t dr = r.dot1re >> 15;
+        const int32_t di = r.dot1im >> 15;
+        sum1 = __mul24(dr, dr) + __mul24(di, di);
+    }
+    // power behind a one-tap DC blocker, fsk.c:425-431
+    const int32_t x = a >> 1;
+    const int32_t diff = (int32_t) (int16_t) (x - r.last_sample);
+    r.power += (__mul24(diff, diff) - r.power) >> 4;
+    r.last_sample = x;
+    // Carrier detect, fsk.c:433-475, as selects (the branches are data dependent per lane and nearly all of
+    // them just move a counter).  drop / quiet / counting are the three places the reference `continue`s.
+    const bool present = (r.signal_present != 0);
+    const bool low_off = (r.power < r.off_power);
+    const bool low_on = (r.power < r.on_power);
+    const bool dec = present  &&  low_off;
+    const int32_t sp1 = r.signal_present - 1;
+    const bool drop = dec  &&  (sp1 <= 0);
+    const bool quiet = !present  &&  low_on;
+    const bool counting = !present  &&  !low_on  &&  (r.baud_phase < (span >> 1) - 30);
+    const bool rise = !present  &&  !low_on  &&  !counting;
+    r.signal_present = dec  ?  sp1  :  (rise  ?  1  :  r.signal_present);
+    r.baud_phase = (drop  ||  quiet  ||  rise)  ?  0  :  (counting  ?  (r.baud_phase + 1)  :  r.baud_phase);
+    r.frame_pos = rise  ?  -2  :  r.frame_pos;
+    r.frame = rise  ?  0  :  r.frame;
+    r.last_bit = rise  ?  0  :  r.last_bit;
+    if (drop)
+        emit(-1);                               // SIG_STATUS_CARRIER_DOWN
+    if (rise)
+        emit(-2);                               // SIG_STATUS_CARRIER_UP
+    if (drop  ||  quiet  ||  counting)
+        return;
+    const int state = (sum0 < sum1)  ?  1  :  0;
+    if (r.framing != 2)
+    {
+        // synchronous (fsk.c:489-512): a transition nudges the baud phase towards the middle of the baud;
+        // asynchronous (fsk.c:513-537): a transition sets it there.  Then one bit per baud.
+        const bool change = (r.last_bit != state);
+        const int32_t eighth = r.baud_rate >> 3;
+        const int32_t nudged = r.baud_phase + ((r.baud_phase < kFskRateX100/2)  ?  eighth  :  -eighth);
+        const int32_t moved = (r.framing == 1)  ?  nudged  :  (kFskRateX100/2);
+        r.last_bit = state;
+        const int32_t bp = (change  ?  moved  :  r.baud_phase) + r.baud_rate;
+        const bool fire = (bp >= kFskRateX100);
+        r.baud_phase = fire  ?  (bp - kFskRateX100)  :  bp;
+        if (fire)
+            emit(state);
+    }
+    else if (r.frame_pos == -2)
+    {
+        // framed, fsk.c:538-614: hunting for a start bit
+        if (state == 0)
+        {
+            r.baud_phase = 8000*(100 - 40)/2;
+            r.frame_pos = -1;
+            r.frame = 0;
+            r.last_bit = -1;
+        }
+    }
+    else if (r.frame_pos == -1)
+    {
+        if (state != 0)
+        {
+            r.frame_pos = -2;
+        }
+        else
+        {
+            r.baud_phase += r.baud_rate;
+            if (r.baud_phase >= kFskRateX100)
+            {
+                r.frame_pos = 0;
+                r.last_bit = state;
+            }
+        }
+    }
+    else
+    {
+        r.baud_phase += r.baud_rate;
+        if (r.baud_phase >= 8000*(100 - 40))
+        {
+            if (r.last_bit < 0)
+                r.last_bit = state;
+            if (r.last_bit != state)
+            {
+                r.frame_pos = -2;
+                r.framing_err++;
+            }
+            else if (r.baud_phase >= kFskRateX100)
+            {
+                if (r.frame_pos++ > r.total_bits)
+                {
+                    if (state == 1)
+                    {
+                        // put_frame(), fsk.c:352-391
+                        uint32_t frame = (uint32_t) r.frame & 0xFFFFu;
+                        if (r.parity != 0)
+                        {
+                            const uint32_t sent = (frame >> 15) & 1u;
+                            frame = (frame & 0x7FFFu) >> (16 - r.total_bits);
+                            uint32_t x8 = frame & 0xFFu;
+                            x8 = (x8 ^ (x8 >> 4)) & 0x0Fu;
+                            x8 = (0x6996u >> x8) & 1u;
+                            uint32_t want = 0u;                 // ASYNC_PARITY_SPACE
+                            want = (r.parity == 2)  ?  (x8 ^ 1u)  :  want;
+                            want = (r.parity == 1)  ?  x8  :  want;
+                            want = (r.parity == 3)  ?  1u  :  want;
+                            if (sent == want)
+                                emit((int) frame);
+                            else
+                                r.parity_err++;
+                        }
+                        else
+                        {
+                            emit((int) (frame >> (16 - r.total_bits)));
+                        }
+                    }
+                    else
+                    {
+                        r.framing_err++;
+                    }
+                    r.frame_pos = -2;
+                }
+                else
+                {
+                    r.frame = ((r.frame >> 1) | (state << 15)) & 0xFFFF;
+                }
+                r.baud_phase -= kFskRateX100;
+                r.last_bit = -1;
+            }
+        }
+    }
+    r.ptr = (r.ptr + 1 >= span)  ?  0  :  (r.ptr + 1);
+}
+
+// The look-ups of a block of up to eight samples, issued together ahead of the sample-serial part: the two
+// oscillators run on whatever the receiver does with a sample (dds_complexi() comes before any early out).
+__device__ __forceinline__ void fsk_block_lookups(FskRegs &r, const int16_t *quarter, int todo, int32_t (&c0)[8], int32_t (&q0)[8],
+                                                  int32_t (&c1)[8], int32_t (&q1)[8])
+{
+#pragma unroll
+    for (int k = 0;  k < 8;  k++)
+    {
+        const uint32_t p0 = r.acc0 + (uint32_t) k*(uint32_t) r.rate0;
+        const uint32_t p1 = r.acc1 + (uint32_t) k*(uint32_t) r.rate1;
+        c0[k] = fsk_lookup(quarter, p0 + (1u << 30));
+        q0[k] = fsk_lookup(quarter, p0);
+        c1[k] = fsk_lookup(quarter, p1 + (1u << 30));
+        q1[k] = fsk_lookup(quarter, p1);
+    }
+    r.acc0 += (uint32_t) todo*(uint32_t) r.rate0;
+    r.acc1 += (uint32_t) todo*(uint32_t) r.rate1;
+}
+
+// Eight samples of a lane's row (fewer at the end of a frame; the rest read as 0 and are not used)
+__device__ __forceinline__ void fsk_block_samples(const int16_t *row, int base, int todo, bool vec, int32_t (&a)[8])
+{
+    if (vec  &&  todo == 8)
+    {
+        const uint4 q = *reinterpret_cast<const uint4 *>(row + base);
+        a[0] = (int32_t) (int16_t) (q.x & 0xFFFFu);
+        a[1] = (int32_t) q.x >> 16;
+        a[2] = (int32_t) (int16_t) (q.y & 0xFFFFu);
+        a[3] = (int32_t) q.y >> 16;
+        a[4] = (int32_t) (int16_t) (q.z & 0xFFFFu);
+        a[5] = (int32_t) q.z >> 16;
+        a[6] = (int32_t) (int16_t) (q.w & 0xFFFFu);
+        a[7] = (int32_t) q.w >> 16;
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0;  k < 8;  k++)
+            a[k] = (k < todo)  ?  (int32_t) row[base + k]  :  0;
+    }
 }
 
 }   // namespace spg

@@ -74,6 +74,16 @@ def lib():
             "spangpu_bank_rx_g711": (ci, [vp, vp, ci, ci, ci, ll]),
             "spangpu_bank_set_records_buffer": (ci, [vp, vp, C.c_size_t]),
             "spangpu_bank_get_stream": (vp, [vp]),
+            "spangpu_mct_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
+            "spangpu_mct_destroy": (None, [vp]),
+            "spangpu_mct_channels": (ci, [vp]),
+            "spangpu_mct_set_stream": (ci, [vp, vp]),
+            "spangpu_mct_sync": (ci, [vp]),
+            "spangpu_mct_rx": (ci, [vp, vp, ci, ci, ll]),
+            "spangpu_mct_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_mct_get": (ci, [vp, ci]),
+            "spangpu_mct_state_words": (ci, [vp]),
+            "spangpu_mct_get_state": (ci, [vp, ci, vp]),
             "spangpu_fsk_preset": (ci, [ci, vp]),
             "spangpu_fsk_create": (ci, [C.POINTER(vp), ci, ci, vp, ci]),
             "spangpu_fsk_destroy": (None, [vp]),
@@ -615,3 +625,61 @@ class FskBank:
 
     def fillin(self, channel, n):
         _check(lib().spangpu_fsk_fillin(self.h, channel, n))
+
+
+# ---- modem connect tone banks (include/spangpu.h "modem connect tone banks") -------------
+(MCT_NONE, MCT_FAX_CNG, MCT_ANS, MCT_ANS_PR, MCT_ANSAM, MCT_ANSAM_PR, MCT_FAX_PREAMBLE, MCT_FAX_CED_OR_PREAMBLE,
+ MCT_BELL_ANS, MCT_CALLING_TONE) = range(10)
+
+
+class MctBank:
+    """N modem connect tone detectors of one tone type (modem_connect_tones_rx), state in HBM."""
+
+    def __init__(self, tone_type, n_channels, use_callback=True, device=0):
+        self.n = n_channels
+        self.h = C.c_void_p()
+        _check(lib().spangpu_mct_create(C.byref(self.h), device, tone_type, n_channels, int(use_callback)))
+        self.words = lib().spangpu_mct_state_words(self.h)
+
+    def close(self):
+        if self.h:
+            lib().spangpu_mct_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(lib().spangpu_mct_set_stream(self.h, hip_stream))
+
+    def sync(self):
+        _check(lib().spangpu_mct_sync(self.h))
+
+    def rx_host(self, amp):
+        amp = np.ascontiguousarray(amp, np.int16)
+        assert amp.shape[0] == self.n
+        _check(lib().spangpu_mct_rx(self.h, amp.ctypes.data, MEM_HOST, amp.shape[1], amp.shape[1]))
+
+    def rx_device(self, ptr, samples, stride=0):
+        _check(lib().spangpu_mct_rx(self.h, ptr, MEM_DEVICE, samples, stride))
+
+    def events(self):
+        """Per channel: [k, 2] int32 (tone, level) reports of the last frame, in order."""
+        ev = C.c_void_p()
+        cnt = C.c_void_p()
+        cap = _check(lib().spangpu_mct_events(self.h, C.byref(ev), C.byref(cnt)))
+        counts = np.ctypeslib.as_array(C.cast(cnt, C.POINTER(C.c_int32)), (self.n,)).copy()
+        assert counts.max(initial=0) <= cap
+        flat = np.ctypeslib.as_array(C.cast(ev, C.POINTER(C.c_int32)), (self.n*cap*2,)).reshape(self.n, cap, 2)
+        return [flat[c, :counts[c]].copy() for c in range(self.n)]
+
+    def get(self, channel):
+        return _check(lib().spangpu_mct_get(self.h, channel))
+
+    def get_state(self, channel):
+        w = np.zeros(self.words, np.int32)
+        _check(lib().spangpu_mct_get_state(self.h, channel, w.ctypes.data))
+        return w

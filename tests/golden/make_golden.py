@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
 from oracle import ref  # noqa: E402
-from test_oracle_pin import (ALL_FREQS, FSK_CASES, fsk_run, fsk_scenario, ECHO_CASES, V17_CASES, V27_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
+from test_oracle_pin import (ALL_FREQS, FSK_CASES, fsk_run, fsk_scenario, mct_run, mct_scenario, ECHO_CASES, V17_CASES, V27_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
                              tx_scenario, v17_scenario, v27ter_scenario, v29_run, v29_scenario)
 
 
@@ -117,6 +117,11 @@ def main():
         ev, snaps = fsk_run(ref.FskRx(which, mode), x, (160,))
         assert -2 in ev and -1 in ev
         save("fsk_%d_%d" % (which, mode), amp=x, events=ev, snapshots=snaps)
+    for rx_type, tx_kind in [(1, 1), (2, 3), (2, 4), (7, "preamble"), (7, 5), (9, 9)]:
+        x = mct_scenario(rx_type, tx_kind)
+        ev, snaps, _ = mct_run(ref.MctRx(rx_type), x)
+        assert len(ev) >= 2
+        save("mct_%d_%s" % (rx_type, tx_kind), amp=x, events=ev, snapshots=snaps)
     amp, lens, puts = tx_scenario({"tone": ref.ToneGen, "dtmf": ref.DtmfTx, "bell": ref.BellMfTx, "r2": ref.R2MfTx}, 5)
     save("tx_sources", seed=5, amp=amp, lens=lens, puts=puts)
 

@@ -147,3 +147,47 @@ def fsk_channels(n_ch, n_samples, seed, freq_zero, freq_one, baud_x100, framed=F
         if c % 7 == 3:
             out[c] += 300.0                             # a DC offset: the power meter sits behind a DC blocker
     return _finish(out)
+
+
+def connect_tone_channels(n_ch, n_samples, seed, kind):
+    """Test signals for the modem connect tone detectors.  kind: 'cng' (1100 Hz, 0.5 s on / 3 s off), 'calling'
+    (1300 Hz, 0.6 s / 1.75 s), 'ans' (2100 Hz), 'ans_pr' (2100 Hz with a phase reversal every 450 ms), 'ansam' /
+    'ansam_pr' (the same with 20 % AM at 15 Hz), 'bell' (2225 Hz), 'preamble' (V.21 channel 2 carrying HDLC flags, then
+    random bits), 'mix' (a different one of the above per channel).  Frequencies, levels, start times and noise vary per
+    channel; some channels get a tone that is off frequency or too short to count."""
+    rng = np.random.default_rng(seed)
+    kinds = ["cng", "calling", "ans", "ans_pr", "ansam", "ansam_pr", "bell", "preamble"]
+    out = np.zeros((n_ch, n_samples), np.float64)
+    t = np.arange(n_samples)
+    for c in range(n_ch):
+        k = kinds[c % len(kinds)] if kind == "mix" else kind
+        amp = dbm0_to_amp(rng.uniform(-30.0, -8.0))
+        start = int(rng.integers(200, 4000))
+        wrong = (c % 11 == 5)
+        if k == "preamble":
+            flags = int(rng.integers(2, 60)) if not wrong else 3
+            bits = np.array([0, 1, 1, 1, 1, 1, 1, 0]*flags + list(rng.integers(0, 2, 400)))
+            spb = 8000.0/300.0
+            length = min(n_samples - start, int(len(bits)*spb))
+            f = np.where(bits[np.minimum((np.arange(length)/spb).astype(int), len(bits) - 1)] == 1, 1650.0, 1850.0)
+            out[c, start:start + length] = amp*np.sin(2*np.pi*np.cumsum(f)/8000.0)
+        else:
+            f0 = {"cng": 1100.0, "calling": 1300.0, "bell": 2225.0}.get(k, 2100.0)
+            f0 *= (1.06 if wrong else float(rng.uniform(0.997, 1.003)))
+            ph = 2*np.pi*f0*t/8000.0
+            env = np.zeros(n_samples)
+            if k in ("cng", "calling"):
+                on, off = (4000, 24000) if k == "cng" else (4800, 14000)
+                pos = start
+                while pos < n_samples:
+                    env[pos:pos + on] = 1.0
+                    pos += on + off
+            else:
+                env[start:start + int(rng.integers(8000, 30000))] = 1.0
+            if k in ("ans_pr", "ansam_pr"):
+                ph = ph + np.pi*(((t - start)//3600) % 2)
+            if k in ("ansam", "ansam_pr"):
+                env = env*(1.0 + 0.2*np.sin(2*np.pi*15.0*t/8000.0))
+            out[c] = amp*env*np.sin(ph)
+        out[c] += rng.normal(0.0, rng.uniform(1.0, 30.0), n_samples)
+    return _finish(out)

@@ -503,6 +503,72 @@ def test_golden_fsk(built, which, mode):
     assert np.array_equal(snaps, g["snapshots"])
 
 
+
+# --------------------------------------------------------------------------------------
+# modem connect tones (mct_oracle.c)
+# --------------------------------------------------------------------------------------
+# (detector tone type, what is transmitted: a modem_connect_tones_tx type or "preamble")
+MCT_CASES = [(1, 1), (2, 2), (2, 3), (2, 4), (2, 5), (3, 3), (7, 2), (7, 5), (7, "preamble"), (6, "preamble"), (8, 8), (9, 9),
+             (1, 9), (2, 8)]
+
+
+def mct_scenario(rx_type, tx_kind):
+    """The reference's own generators: modem_connect_tones_tx for the tones, fsk_tx carrying HDLC flags for the
+    preamble (a long run that must be declared, then a run too short to count)."""
+    from oracle import ref
+    rng = np.random.default_rng(2000 + rx_type*16 + (0 if tx_kind == "preamble" else tx_kind))
+
+    def preamble(n, flags):
+        bits = [0, 1, 1, 1, 1, 1, 1, 0]*flags + list(rng.integers(0, 2, 300))
+        return ref.fsk_tx(1, n, bits=bits, level_dbm0=-15.0)
+    if tx_kind == "preamble":
+        x = np.concatenate([np.zeros(2000, np.int16), preamble(20000, 40), np.zeros(4000, np.int16), preamble(12000, 3),
+                            np.zeros(3000, np.int16)])
+    else:
+        x = np.concatenate([np.zeros(1500, np.int16), ref.modem_connect_tones_tx(tx_kind, 8000*6), np.zeros(4000, np.int16)])
+    return np.clip(x.astype(np.int32) + rng.normal(0, 20, len(x)), -32768, 32767).astype(np.int16)
+
+
+def mct_run(rx, x, chunk=160, use_callback=True):
+    snaps = []
+    hits = []
+    for k in range(0, len(x), chunk):
+        rx.rx(x[k:k + chunk])
+        if (k//chunk) % 10 == 9:
+            snaps.append(rx.snapshot())
+            if not use_callback:
+                hits.append(rx.get())
+    snaps.append(rx.snapshot())
+    ev = np.array([(e["a"], e["b"], e["c"]) for e in rx.sink.events() if e["kind"] == 1], np.int32).reshape(-1, 3)
+    return ev, np.stack(snaps), np.array(hits, np.int32)
+
+
+@needs_ref
+@pytest.mark.parametrize("rx_type,tx_kind", MCT_CASES)
+@pytest.mark.parametrize("use_callback", [True, False])
+def test_mct_live(built, rx_type, tx_kind, use_callback):
+    from oracle import ref, restated as orc
+    x = mct_scenario(rx_type, tx_kind)
+    ev_r, s_r, h_r = mct_run(ref.MctRx(rx_type, use_callback), x, 160, use_callback)
+    ev_o, s_o, h_o = mct_run(orc.Mct(rx_type, use_callback), x, 160, use_callback)
+    assert np.array_equal(ev_r, ev_o)
+    assert np.array_equal(s_r, s_o)
+    assert np.array_equal(h_r, h_o)
+    if (rx_type, tx_kind) not in ((1, 9), (2, 8)):
+        assert (len(ev_r) >= 2) if use_callback else h_r.any()       # declared and withdrawn / latched
+    else:
+        assert len(ev_r) == 0 and not h_r.any()                       # the wrong tone is not reported
+
+
+@pytest.mark.parametrize("rx_type,tx_kind", [(1, 1), (2, 3), (2, 4), (7, "preamble"), (7, 5), (9, 9)])
+def test_golden_mct(built, rx_type, tx_kind):
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, "mct_%d_%s.npz" % (rx_type, tx_kind)))
+    ev, snaps, _ = mct_run(orc.Mct(rx_type), g["amp"])
+    assert np.array_equal(ev, g["events"])
+    assert np.array_equal(snaps, g["snapshots"])
+
+
 def test_g711_decode(built):
     """alaw_to_linear / ulaw_to_linear (spandsp/g711.h): restatement vs the frozen reference outputs, all 256 codes
     (and vs the live reference when it is here)."""

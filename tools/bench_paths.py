@@ -351,6 +351,77 @@ def bench_fsk(args, dev, stream):
         "cpu_baseline": cpu}
 
 
+def bench_mct(args, dev, stream):
+    """modem connect tone detectors, type FAX_CED_OR_PREAMBLE (the V.21 preamble hunter + the 2100 Hz
+    detector), the one a FAX terminal runs at the head of a call."""
+    import synth
+    from spandsp_amd import engine
+    n_ch = args.channels or 65536
+    nf = 50
+    n_src = 256
+    src = torch.tensor(synth.connect_tone_channels(n_src, nf*FRAME, 78, "mix"), device=dev).view(n_src, nf, FRAME)
+    idx = torch.arange(n_ch, device=dev)
+    fsel = (torch.arange(nf, device=dev).unsqueeze(0) + ((idx//n_src) % nf).unsqueeze(1)) % nf
+    frames = src[(idx % n_src).unsqueeze(1), fsel].permute(1, 0, 2).contiguous()
+    bank = engine.MctBank(engine.MCT_FAX_CED_OR_PREAMBLE, n_ch)
+    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    frame_bytes = n_ch*FRAME*2
+
+    def step(i):
+        bank.rx_device(ctypes.c_void_p(frames.data_ptr() + (i % nf)*frame_bytes), FRAME, FRAME)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record(stream)
+        step(args.warmup + i)
+        evs[i][1].record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = [a.elapsed_time(b) for a, b in evs]
+    avg_ms = sum(per)/len(per)
+    reports = 0
+    for i in range(nf):                                  # one more pass over the signal, untimed, counting reports
+        step(args.warmup + args.steps + i)
+        reports += int(sum(len(e) for e in bank.events()))
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import ref
+        L = ref.lib()
+        n_cpu = min(args.cpu_channels, n_ch)
+        objs = (ctypes.c_void_p*n_cpu)(*[L.modem_connect_tones_rx_init(None, 7, None, None) for _ in range(n_cpu)])
+        host = frames[:, :n_cpu].contiguous().cpu().numpy()
+        loops = 20
+
+        def work(lo, hi):
+            L.glue_mct_rx_batch_frames(ctypes.addressof(objs) + lo*8, host[0, lo:].ctypes.data, hi - lo, FRAME, n_cpu*FRAME,
+                                       FRAME, nf, loops)
+        cores, t = run_threads(n_cpu, work)
+        cpu = {"value": n_cpu*nf*loops*FRAME/t/1e6, "unit": "Msamples/s", "cores": cores, "kind": "reference",
+               "sample": "modem_connect_tones_rx() of oracle/_ref on %d channels x %d frames, %d threads" % (n_cpu, nf*loops, cores)}
+        for o in objs:
+            L.modem_connect_tones_rx_free(o)
+    words = bank.words
+    alg_read = n_ch*(FRAME*2 + words*4)
+    alg_write = n_ch*((words - 12)*4 + 4)
+    value = args.steps*n_ch*FRAME/dt/1e6
+    return {
+        "metric": "Msamples/s of batched modem connect tone detection (8 kHz channels at real-time = value*1e6/8000)",
+        "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32+int32", "data": "synthetic",
+        "config": {"workload": "modem_connect_tones_rx FAX_CED_OR_PREAMBLE, %d channels x %d-sample frames" % (n_ch, FRAME),
+                   "channels_per_gpu": n_ch, "tone_reports_in_one_more_second_of_signal": reports},
+        "roofline": {"bound": "hbm", "kernel": "mct_bank_kernel<7>", "achieved": (alg_read + alg_write)/(avg_ms*1e-3)/1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (alg_read + alg_write)/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS,
+                     "traffic": None, "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
+                     "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3,
+                     "note": "sample-serial state machines (V.21 receiver + biquads), latency bound at one wave per SIMD"},
+        "cpu_baseline": cpu}
+
+
 def bench_dtmf_tx(args, dev, stream):
     """a DTMF sender bank (dtmf_tx x N) writing 160-sample frames into HBM, digits queued up front."""
     from spandsp_amd import engine
@@ -424,7 +495,7 @@ def bench_dtmf_tx(args, dev, stream):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk"], default="v29")
+    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct"], default="v29")
     ap.add_argument("--channels", type=int, default=0)
     ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
@@ -445,6 +516,10 @@ def main():
         return
     if args.workload == "mixed":
         print(json.dumps(bench_mixed(args, dev, stream)))
+        return
+    if args.workload == "mct":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        print(json.dumps(bench_mct(args, dev, stream)))
         return
     if args.workload == "fsk":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
