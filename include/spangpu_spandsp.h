@@ -249,6 +249,120 @@ SPANGPU_API void goertzel_reset(goertzel_state_t *s);
 SPANGPU_API int goertzel_update(goertzel_state_t *s, const int16_t amp[], int samples);
 SPANGPU_API float goertzel_result(goertzel_state_t *s);
 
+/* ---- FSK receiver, modem connect tones, DTMF sender (csrc/shim_fsk.c) ---------------------------------
+ * Reference declarations being replaced:
+ *   fsk_rx_init/_restart/_rx/_fillin/_release/_free/_set_put_bit/_set_modem_status_handler/_set_signal_cutoff/
+ *     _set_frame_parameters/_signal_power/_get_parity_errors/_get_framing_errors, fsk_spec_t, preset_fsk_specs[]
+ *                                          src/spandsp/fsk.h:85-260      src/fsk.c:60-155,270-742
+ *   modem_connect_tones_rx_init/_rx/_fillin/_get/_release/_free, modem_connect_tone_to_str
+ *                                          src/spandsp/modem_connect_tones.h:57-200  src/modem_connect_tones.c:84-112,521-871
+ *   dtmf_tx_init/_put/dtmf_tx/_set_level/_set_timing/_release/_free
+ *                                          src/spandsp/dtmf.h:112-148    src/dtmf.c:551-676
+ * As with the other families: xxx_init(NULL, ...) makes a private one-channel bank; a spangpu_line_group_t puts N
+ * receivers on one bank and one launch per tick.  Storage supplied by the caller (s != NULL) cannot be used --
+ * the state lives in HBM -- so such a call returns NULL.  fsk_rx_restart() accepts the spec the object was made
+ * with (a bank runs one baud rate); a dtmf_tx digits callback is not replayed (init with one returns NULL).
+ */
+typedef struct
+{
+    const char *name;
+    int freq_zero;
+    int freq_one;
+    int tx_level;
+    int min_level;
+    int baud_rate;
+} fsk_spec_t;
+
+enum
+{
+    FSK_V21CH1 = 0, FSK_V21CH2, FSK_V23CH1, FSK_V23CH2, FSK_BELL103CH1, FSK_BELL103CH2, FSK_BELL202, FSK_WEITBRECHT_4545,
+    FSK_WEITBRECHT_50, FSK_WEITBRECHT_476, FSK_V21CH1_110
+};
+
+enum
+{
+    FSK_FRAME_MODE_ASYNC = 0,
+    FSK_FRAME_MODE_SYNC = 1,
+    FSK_FRAME_MODE_FRAMED = 2
+};
+
+enum
+{
+    ASYNC_PARITY_NONE = 0,
+    ASYNC_PARITY_EVEN,
+    ASYNC_PARITY_ODD,
+    ASYNC_PARITY_MARK,
+    ASYNC_PARITY_SPACE
+};
+
+enum
+{
+    MODEM_CONNECT_TONES_NONE = 0,
+    MODEM_CONNECT_TONES_FAX_CNG = 1,
+    MODEM_CONNECT_TONES_ANS = 2,
+    MODEM_CONNECT_TONES_ANS_PR = 3,
+    MODEM_CONNECT_TONES_ANSAM = 4,
+    MODEM_CONNECT_TONES_ANSAM_PR = 5,
+    MODEM_CONNECT_TONES_FAX_PREAMBLE = 6,
+    MODEM_CONNECT_TONES_FAX_CED_OR_PREAMBLE = 7,
+    MODEM_CONNECT_TONES_BELL_ANS = 8,
+    MODEM_CONNECT_TONES_CALLING_TONE = 9,
+    MODEM_CONNECT_TONES_REAL_TIME_REPORTS = 0x1000
+};
+#define MODEM_CONNECT_TONES_FAX_CED MODEM_CONNECT_TONES_ANS
+
+typedef void (*digits_tx_callback_t)(void *user_data);
+
+typedef struct fsk_rx_state_s fsk_rx_state_t;
+typedef struct modem_connect_tones_rx_state_s modem_connect_tones_rx_state_t;
+typedef struct dtmf_tx_state_s dtmf_tx_state_t;
+typedef struct spangpu_line_group_s spangpu_line_group_t;
+
+SPANGPU_API extern const fsk_spec_t preset_fsk_specs[];
+
+SPANGPU_API spangpu_line_group_t *spangpu_fsk_group_create(int device, const fsk_spec_t *spec, int framing_mode, int n_channels,
+                                                           int max_samples);
+SPANGPU_API spangpu_line_group_t *spangpu_modem_connect_tones_group_create(int device, int tone_type, int use_callbacks,
+                                                                           int n_channels, int max_samples);
+SPANGPU_API int spangpu_line_group_destroy(spangpu_line_group_t *g);
+SPANGPU_API int spangpu_line_group_flush(spangpu_line_group_t *g);
+
+SPANGPU_API fsk_rx_state_t *fsk_rx_init(fsk_rx_state_t *s, const fsk_spec_t *spec, int framing_mode, span_put_bit_func_t put_bit,
+                                        void *user_data);
+SPANGPU_API fsk_rx_state_t *spangpu_fsk_rx_attach(spangpu_line_group_t *g, int channel, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API int fsk_rx_restart(fsk_rx_state_t *s, const fsk_spec_t *spec, int framing_mode);
+SPANGPU_API int fsk_rx(fsk_rx_state_t *s, const int16_t *amp, int len);
+SPANGPU_API int fsk_rx_fillin(fsk_rx_state_t *s, int len);
+SPANGPU_API int fsk_rx_release(fsk_rx_state_t *s);
+SPANGPU_API int fsk_rx_free(fsk_rx_state_t *s);
+SPANGPU_API void fsk_rx_set_put_bit(fsk_rx_state_t *s, span_put_bit_func_t put_bit, void *user_data);
+SPANGPU_API void fsk_rx_set_modem_status_handler(fsk_rx_state_t *s, span_modem_status_func_t handler, void *user_data);
+SPANGPU_API void fsk_rx_set_signal_cutoff(fsk_rx_state_t *s, float cutoff);
+SPANGPU_API void fsk_rx_set_frame_parameters(fsk_rx_state_t *s, int data_bits, int parity, int stop_bits);
+SPANGPU_API float fsk_rx_signal_power(fsk_rx_state_t *s);
+SPANGPU_API int fsk_rx_get_parity_errors(fsk_rx_state_t *s, bool reset);
+SPANGPU_API int fsk_rx_get_framing_errors(fsk_rx_state_t *s, bool reset);
+
+SPANGPU_API modem_connect_tones_rx_state_t *modem_connect_tones_rx_init(modem_connect_tones_rx_state_t *s, int tone_type,
+                                                                        span_tone_report_func_t tone_callback, void *user_data);
+SPANGPU_API modem_connect_tones_rx_state_t *spangpu_modem_connect_tones_rx_attach(spangpu_line_group_t *g, int channel,
+                                                                                  span_tone_report_func_t tone_callback,
+                                                                                  void *user_data);
+SPANGPU_API int modem_connect_tones_rx(modem_connect_tones_rx_state_t *s, const int16_t amp[], int len);
+SPANGPU_API int modem_connect_tones_rx_fillin(modem_connect_tones_rx_state_t *s, int len);
+SPANGPU_API int modem_connect_tones_rx_get(modem_connect_tones_rx_state_t *s);
+SPANGPU_API int modem_connect_tones_rx_release(modem_connect_tones_rx_state_t *s);
+SPANGPU_API int modem_connect_tones_rx_free(modem_connect_tones_rx_state_t *s);
+SPANGPU_API const char *modem_connect_tone_to_str(int tone);
+
+SPANGPU_API dtmf_tx_state_t *dtmf_tx_init(dtmf_tx_state_t *s, digits_tx_callback_t callback, void *user_data);
+SPANGPU_API int dtmf_tx_release(dtmf_tx_state_t *s);
+SPANGPU_API int dtmf_tx_free(dtmf_tx_state_t *s);
+SPANGPU_API void dtmf_tx_set_level(dtmf_tx_state_t *s, int level, int twist);
+SPANGPU_API void dtmf_tx_set_timing(dtmf_tx_state_t *s, int on_time, int off_time);
+SPANGPU_API int dtmf_tx_put(dtmf_tx_state_t *s, const char *digits, int len);
+SPANGPU_API int dtmf_tx(dtmf_tx_state_t *s, int16_t amp[], int max_samples);
+
 #if defined(__cplusplus)
 }
 #endif

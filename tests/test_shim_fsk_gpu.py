@@ -1,0 +1,184 @@
+"""GPU tests of the spandsp-named entry points of spandsp_amd/csrc/shim_fsk.c (include/spangpu_spandsp.h): what a
+caller of fsk_rx() / modem_connect_tones_rx() / dtmf_tx() observes through its callbacks and return values must equal
+what the reference delivers -- the committed reference outputs (tests/golden/fsk_*.npz, mct_*.npz, tx_sources via the
+oracle) for private objects, and the oracle for grouped objects."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from test_oracle_pin import GOLDEN, use_golden_modem_tables
+
+pytestmark = pytest.mark.gpu
+
+PUT_BIT = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+STATUS = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+REPORT = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int, C.c_int)
+
+
+class FskSpec(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("freq_zero", C.c_int), ("freq_one", C.c_int), ("tx_level", C.c_int),
+                ("min_level", C.c_int), ("baud_rate", C.c_int)]
+
+
+@pytest.fixture(scope="module")
+def L(built):
+    from spandsp_amd import engine
+    lib = C.CDLL(engine.LIB_PATH)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    sig = {
+        "fsk_rx_init": (vp, [vp, vp, ci, PUT_BIT, vp]), "spangpu_fsk_rx_attach": (vp, [vp, ci, PUT_BIT, vp]),
+        "fsk_rx": (ci, [vp, vp, ci]), "fsk_rx_restart": (ci, [vp, vp, ci]), "fsk_rx_fillin": (ci, [vp, ci]),
+        "fsk_rx_free": (ci, [vp]), "fsk_rx_set_put_bit": (None, [vp, PUT_BIT, vp]),
+        "fsk_rx_set_modem_status_handler": (None, [vp, STATUS, vp]), "fsk_rx_set_signal_cutoff": (None, [vp, cf]),
+        "fsk_rx_set_frame_parameters": (None, [vp, ci, ci, ci]), "fsk_rx_signal_power": (cf, [vp]),
+        "fsk_rx_get_parity_errors": (ci, [vp, C.c_bool]), "fsk_rx_get_framing_errors": (ci, [vp, C.c_bool]),
+        "spangpu_fsk_group_create": (vp, [ci, vp, ci, ci, ci]),
+        "spangpu_modem_connect_tones_group_create": (vp, [ci, ci, ci, ci, ci]),
+        "spangpu_line_group_destroy": (ci, [vp]), "spangpu_line_group_flush": (ci, [vp]),
+        "modem_connect_tones_rx_init": (vp, [vp, ci, REPORT, vp]),
+        "spangpu_modem_connect_tones_rx_attach": (vp, [vp, ci, REPORT, vp]),
+        "modem_connect_tones_rx": (ci, [vp, vp, ci]), "modem_connect_tones_rx_get": (ci, [vp]),
+        "modem_connect_tones_rx_free": (ci, [vp]), "modem_connect_tone_to_str": (C.c_char_p, [ci]),
+        "dtmf_tx_init": (vp, [vp, vp, vp]), "dtmf_tx_put": (ci, [vp, C.c_char_p, ci]), "dtmf_tx": (ci, [vp, vp, ci]),
+        "dtmf_tx_set_level": (None, [vp, ci, ci]), "dtmf_tx_set_timing": (None, [vp, ci, ci]), "dtmf_tx_free": (ci, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        getattr(lib, name).restype = res
+        getattr(lib, name).argtypes = args
+    return lib
+
+
+def spec_ptr(L, which):
+    arr = (FskSpec*11).in_dll(L, "preset_fsk_specs")
+    return C.addressof(arr) + which*C.sizeof(FskSpec)
+
+
+def feed(fn, s, x, chunk):
+    x = np.ascontiguousarray(x, np.int16)
+    for k in range(0, len(x), chunk):
+        blk = x[k:k + chunk]
+        assert fn(s, blk.ctypes.data, len(blk)) == 0
+
+
+@pytest.mark.parametrize("which,mode", [(1, 1), (1, 0), (1, 2), (2, 0), (7, 2)])
+def test_fsk_private_object_replays_reference_stream(L, which, mode):
+    g = np.load(os.path.join(GOLDEN, "fsk_%d_%d.npz" % (which, mode)))
+    ev = []
+    put_bit = PUT_BIT(lambda u, b: ev.append(b))
+    arr = (FskSpec*11).in_dll(L, "preset_fsk_specs")
+    assert arr[1].name == b"V21 ch 2" and arr[1].freq_zero == 1850 and arr[10].baud_rate == 11000
+    s = L.fsk_rx_init(None, spec_ptr(L, which), mode, put_bit, None)
+    assert s
+    feed(L.fsk_rx, s, g["amp"], 517)
+    assert np.array_equal(np.array(ev, np.int32), g["events"])
+    assert L.fsk_rx_signal_power(s) < -30.0                # the transmission has ended
+    assert L.fsk_rx_get_framing_errors(s, True) >= 0 and L.fsk_rx_get_framing_errors(s, False) == 0
+    # with a status handler the carrier reports leave the bit stream (fsk.c:343-349)
+    ev2, st2 = [], []
+    pb2 = PUT_BIT(lambda u, b: ev2.append(b))
+    sh2 = STATUS(lambda u, v: st2.append(v))
+    assert L.fsk_rx_restart(s, spec_ptr(L, which), mode) == 0
+    assert L.fsk_rx_restart(s, spec_ptr(L, (which + 1) % 11), mode) == -1         # another spec needs another object
+    L.fsk_rx_set_put_bit(s, pb2, None)
+    L.fsk_rx_set_modem_status_handler(s, sh2, None)
+    feed(L.fsk_rx, s, g["amp"], 160)
+    want = g["events"]
+    assert st2 == [int(v) for v in want if v in (-1, -2)]
+    assert len(ev2) > 10 and all(v >= 0 for v in ev2)
+    L.fsk_rx_free(s)
+    assert L.fsk_rx_init(C.c_void_p(1), spec_ptr(L, which), mode, put_bit, None) is None
+
+
+def test_fsk_group_equals_oracle(L):
+    from oracle import restated as orc
+    n, frames = 40, 60
+    sig = synth.fsk_channels(n, 160*frames, 901, 1850, 1650, 30000)
+    grp = L.spangpu_fsk_group_create(0, spec_ptr(L, 1), 1, n, 160)
+    assert grp
+    taps = [[] for _ in range(n)]
+    cbs = [PUT_BIT(lambda u, b, t=taps[c]: t.append(b)) for c in range(n)]
+    objs = [L.spangpu_fsk_rx_attach(grp, c, cbs[c], None) for c in range(n)]
+    assert all(objs) and L.spangpu_fsk_rx_attach(grp, 0, cbs[0], None) is None
+    for k in range(frames):
+        for c in range(n):
+            blk = np.ascontiguousarray(sig[c, k*160:(k + 1)*160])
+            L.fsk_rx(objs[c], blk.ctypes.data, 160)
+    for c in range(n):
+        o = orc.Fsk(1, 1)
+        o.rx(sig[c])
+        assert taps[c] == [int(e["a"]) for e in o.sink.events()], c
+    for o in objs:
+        L.fsk_rx_free(o)
+    L.spangpu_line_group_destroy(grp)
+
+
+@pytest.mark.parametrize("rx_type,tx_kind", [(1, 1), (2, 3), (2, 4), (7, "preamble"), (7, 5), (9, 9)])
+def test_mct_private_object_replays_reference_reports(L, rx_type, tx_kind):
+    g = np.load(os.path.join(GOLDEN, "mct_%d_%s.npz" % (rx_type, tx_kind)))
+    rep = []
+    cb = REPORT(lambda u, tone, level, delay: rep.append((tone, level, delay)))
+    s = L.modem_connect_tones_rx_init(None, rx_type, cb, None)
+    assert s
+    feed(L.modem_connect_tones_rx, s, g["amp"], 160)       # the committed reports were made with 160-sample calls
+    assert rep == [tuple(int(v) for v in e) for e in g["events"]]
+    L.modem_connect_tones_rx_free(s)
+    # no callback: the hit latch
+    s = L.modem_connect_tones_rx_init(None, rx_type, C.cast(None, REPORT), None)
+    feed(L.modem_connect_tones_rx, s, g["amp"], 160)
+    tones = [int(e[0]) for e in g["events"] if e[0] != 0]
+    assert L.modem_connect_tones_rx_get(s) == tones[-1]
+    assert L.modem_connect_tones_rx_get(s) == 0
+    L.modem_connect_tones_rx_free(s)
+    assert L.modem_connect_tone_to_str(7) == b"FAX CED or preamble" and L.modem_connect_tone_to_str(99) == b"???"
+
+
+def test_mct_group_equals_oracle(L):
+    from oracle import restated as orc
+    n, frames = 32, 200
+    sig = synth.connect_tone_channels(n, 160*frames, 902, "mix")
+    grp = L.spangpu_modem_connect_tones_group_create(0, 7, 1, n, 160)
+    assert grp
+    taps = [[] for _ in range(n)]
+    cbs = [REPORT(lambda u, tone, level, delay, t=taps[c]: t.append((tone, level))) for c in range(n)]
+    objs = [L.spangpu_modem_connect_tones_rx_attach(grp, c, cbs[c], None) for c in range(n)]
+    assert all(objs)
+    for k in range(frames):
+        for c in range(n):
+            blk = np.ascontiguousarray(sig[c, k*160:(k + 1)*160])
+            L.modem_connect_tones_rx(objs[c], blk.ctypes.data, 160)
+    total = 0
+    for c in range(n):
+        o = orc.Mct(7)
+        for k in range(frames):
+            o.rx(sig[c, k*160:(k + 1)*160])
+        want = [(int(e["a"]), int(e["b"])) for e in o.sink.events()]
+        assert taps[c] == want, c
+        total += len(want)
+    assert total > n
+    for o in objs:
+        L.modem_connect_tones_rx_free(o)
+    L.spangpu_line_group_destroy(grp)
+
+
+def test_dtmf_tx_object_equals_oracle(L):
+    from oracle import restated as orc
+    use_golden_modem_tables()
+    s = L.dtmf_tx_init(None, None, None)
+    assert s
+    o = orc.DtmfTx()
+    L.dtmf_tx_set_level(s, -7, 3)
+    o.set_level(-7, 3)
+    L.dtmf_tx_set_timing(s, 40, 30)
+    o.set_timing(40, 30)
+    assert L.dtmf_tx_put(s, b"159D*0#x", -1) == o.put("159D*0#x")
+    big = b"1"*125
+    assert L.dtmf_tx_put(s, big, len(big)) == o.put(big)       # does not fit: the shortfall comes back, nothing is queued
+    buf = np.zeros(1000, np.int16)
+    for n in (160, 1, 333, 1000, 1000, 1000, 1000, 1000):
+        got = L.dtmf_tx(s, buf.ctypes.data, n)
+        want = o.tx(n)
+        assert got == len(want) and np.array_equal(buf[:got], want)
+    L.dtmf_tx_free(s)
