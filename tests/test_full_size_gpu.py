@@ -123,3 +123,72 @@ def test_echo_131072_channels(built):
         o = dets[c % V].snapshot()
         assert np.array_equal(g["taps32"], o["taps32"]) and np.array_equal(g["history"], o["history"]), c
     bank.close()
+
+
+def test_fsk_and_connect_tones_65536_channels(built):
+    """The widened receivers at bank sizes that fill the chip: V distinct signals tiled over 65 536 channels; every
+    replica's events and final state must equal the first copy's, and the first V channels equal the oracle."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch, V = 65536, 64
+    for what in ("fsk", "mct"):
+        n_frames = 40 if what == "fsk" else 110         # a connect tone needs 0.4 - 0.55 s before it is declared
+        if what == "fsk":
+            base = synth.fsk_channels(V, 160*n_frames, 811, 1850, 1650, 30000)
+            bank = engine.FskBank(engine.FSK_V21CH2, n_ch)
+            orcs = [orc.Fsk(1, 1) for _ in range(V)]
+        else:
+            base = synth.connect_tone_channels(V, 160*n_frames, 812, "mix")
+            bank = engine.MctBank(engine.MCT_FAX_CED_OR_PREAMBLE, n_ch)
+            orcs = [orc.Mct(7) for _ in range(V)]
+        sig = np.tile(base, (n_ch//V, 1))
+        total = 0
+        for k in range(n_frames):
+            bank.rx_host(sig[:, k*160:(k + 1)*160])
+            ev = bank.events()
+            want = []
+            for c in range(V):
+                orcs[c].sink.clear()
+                orcs[c].rx(base[c, k*160:(k + 1)*160])
+                e = orcs[c].sink.events()
+                want.append(e["a"].astype(np.int64) if what == "fsk" else np.stack([e["a"], e["b"]], 1).astype(np.int64).reshape(-1, 2))
+            for c in range(n_ch):
+                assert np.array_equal(ev[c].astype(np.int64), want[c % V]), (what, k, c)
+            total += sum(len(w) for w in want)
+        assert total > V//2
+        for c in list(range(V)) + list(range(n_ch - V, n_ch)) + list(range(0, n_ch, 4099)):
+            assert np.array_equal(bank.get_state(c), orcs[c % V].snapshot()), (what, c)
+        bank.close()
+
+
+def test_dtmf_sender_feeds_detector_65536_channels(built):
+    """dtmf_tx bank -> HBM -> dtmf_rx bank at BASELINE configs[1]'s size without the samples leaving the device:
+    every channel's detector reports exactly the digits its sender was given (a round trip that holds at any size)."""
+    import ctypes
+    from spandsp_amd import engine
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    n, samples = 65536, 160
+    rng = np.random.default_rng(13)
+    keys = np.frombuffer(b"0123456789ABCD*#", np.uint8)
+    ndig = rng.integers(1, 9, n)
+    digs = keys[rng.integers(0, 16, (n, 8))]
+    want = [bytes(digs[c, :ndig[c]]).decode() for c in range(n)]
+    tx = engine.TxBank(engine.TX_DTMF, n)
+    rx = engine.ToneBank(engine.DTMF, n)
+    tx.set_stream(engine.lib().spangpu_bank_get_stream(rx.h))
+    assert not tx.put_each(want).any()
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), n*samples*2) == 0
+    got = [[] for _ in range(n)]
+    for _ in range(8*840//samples + 4):
+        tx.tx_device(buf, samples, samples)
+        rx.rx_device(buf.value, samples)
+        blk = rx.blocks()
+        sel = blk[((blk["flags"] & engine.BLK_CHANGE) != 0) & (blk["code"] != 0)]
+        for ch, code in zip(sel["channel"], sel["code"]):
+            got[ch].append(chr(code))
+    hip.hipFree(buf)
+    bad = [c for c in range(n) if "".join(got[c]) != want[c]]
+    assert not bad, (len(bad), bad[:5])
