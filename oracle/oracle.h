@@ -577,6 +577,36 @@ ORC_API int orc_fsk_rx(orc_fsk_t *s, const int16_t amp[], int len, orc_sink_t *s
 ORC_API int orc_fsk_rx_cb(orc_fsk_t *s, const int16_t amp[], int len, orc_put_bit_t put, void *user);
 ORC_API int orc_fsk_fillin(orc_fsk_t *s, int len);
 
+/* ---- V.29 transmitter (v29tx_oracle.c); field order = glue_v29_tx_snapshot() = the device state ---- */
+typedef struct
+{
+    int32_t bit_rate;
+    float base_gain;
+    float gain;
+    float rrc_re[9];
+    float rrc_im[9];
+    int32_t rrc_step;
+    uint32_t scramble_reg;
+    uint32_t training_scramble_reg;
+    int32_t in_training;
+    int32_t training_step;
+    int32_t training_offset;
+    uint32_t carrier_phase;
+    int32_t carrier_phase_rate;
+    int32_t baud_phase;
+    int32_t constellation_state;
+    uint32_t prbs;              /* the data source: x^15 + x^14 + 1 */
+} orc_v29_tx_t;
+
+#define ORC_V29_TX_WORDS    32
+
+ORC_API int orc_v29_tx_sizeof(void);
+ORC_API void orc_v29_tx_set_table(const float table[90]);
+ORC_API int orc_v29_tx_init(orc_v29_tx_t *s, int bit_rate, int tep, uint32_t prbs_seed);
+ORC_API int orc_v29_tx_restart(orc_v29_tx_t *s, int bit_rate, int tep);
+ORC_API void orc_v29_tx_power(orc_v29_tx_t *s, float power);
+ORC_API int orc_v29_tx(orc_v29_tx_t *s, int16_t amp[], int len);
+
 /* ---- modem connect tones (mct_oracle.c) ---- */
 #define ORC_MCT_FAX_CNG             1
 #define ORC_MCT_ANS                 2

@@ -76,6 +76,12 @@ def lib():
             "orc_fsk_set_frame_parameters": (None, [vp, ci, ci, ci]),
             "orc_fsk_rx": (ci, [vp, vp, ci, vp]),
             "orc_fsk_fillin": (ci, [vp, ci]),
+            "orc_v29_tx_sizeof": (ci, []),
+            "orc_v29_tx_set_table": (None, [vp]),
+            "orc_v29_tx_init": (ci, [vp, ci, ci, C.c_uint32]),
+            "orc_v29_tx_restart": (ci, [vp, ci, ci]),
+            "orc_v29_tx_power": (None, [vp, cf]),
+            "orc_v29_tx": (ci, [vp, vp, ci]),
             "orc_mct_sizeof": (ci, []),
             "orc_mct_init": (None, [vp, ci, vp]),
             "orc_mct_rx": (ci, [vp, vp, ci]),
@@ -576,3 +582,34 @@ class Mct:
             span = int(self.buf[self.WORDS + 15])
             return np.concatenate([w, self.buf[self.WORDS:self.WORDS + 28 + 4*span]])
         return w
+
+
+# ---- V.29 transmitter (v29tx_oracle.c) ----------------------------------------------------------
+def set_v29_tx_table(table):
+    t = np.ascontiguousarray(table, np.float32)
+    assert t.size == 90
+    lib().orc_v29_tx_set_table(t.ctypes.data)
+
+
+class V29Tx:
+    WORDS = 32
+
+    def __init__(self, bit_rate, tep=False, seed=1):
+        self.buf = np.zeros(self.WORDS, np.uint32)
+        self.p = self.buf.ctypes.data
+        assert lib().orc_v29_tx_sizeof() == 4*self.WORDS
+        assert lib().orc_v29_tx_init(self.p, bit_rate, int(tep), seed & 0x7FFF) == 0
+
+    def power(self, level_dbm0):
+        lib().orc_v29_tx_power(self.p, level_dbm0)
+
+    def restart(self, bit_rate, tep):
+        return lib().orc_v29_tx_restart(self.p, bit_rate, int(tep))
+
+    def tx(self, n):
+        out = np.zeros(max(n, 1), np.int16)
+        got = lib().orc_v29_tx(self.p, out.ctypes.data, n)
+        return out[:got].copy()
+
+    def snapshot(self):
+        return self.buf.copy()

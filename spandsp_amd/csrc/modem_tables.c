@@ -418,11 +418,46 @@ void spg_make_v17_rx_maps(uint8_t maps[4*36*36*8], uint8_t map_4800[36*36])
 }
 
 
+/* The transmit pulse shaper of make_modem_filter.c:52-152 (make_tx_filter): a root raised cosine at baseband,
+   coeff_sets interpolation phases of coeffs_per_filter taps, unity DC gain, printed with ten decimals. */
+int spg_make_tx_pulseshaper(int coeff_sets, int coeffs_per_filter, double excess_bandwidth, float *out)
+{
+    double *coeffs;
+    double gain;
+    int total;
+    int i;
+    int j;
+
+    total = coeff_sets*coeffs_per_filter + 1;
+    if ((coeffs = (double *) malloc(sizeof(double)*total)) == NULL)
+        return -1;
+    /* alpha = baud_rate/(2*coeff_sets*baud_rate) */
+    root_raised_cosine(coeffs, total, 1.0/(2.0*(double) coeff_sets), excess_bandwidth);
+    gain = 0.0;
+    for (i = coeff_sets/2;  i < total;  i += coeff_sets)
+        gain += coeffs[i];
+    for (i = 0;  i < total;  i++)
+        coeffs[i] /= gain;
+    for (j = 0;  j < coeff_sets;  j++)
+    {
+        for (i = 0;  i < coeffs_per_filter;  i++)
+            out[j*coeffs_per_filter + i] = via_text(coeffs[i*coeff_sets + j], 10);
+    }
+    free(coeffs);
+    return 0;
+}
+
 /* ---- tone generator descriptors ---------------------------------------------------------------- */
 int32_t spg_dds_phase_ratef(float hz)
 {
     /* dds_phase_ratef(), dds_float.c:2109-2112: binary32 throughout */
     return (int32_t) (hz*65536.0f*65536.0f/8000);
+}
+
+float spg_db_to_amplitude_ratio(float db)
+{
+    /* db_to_amplitude_ratio(), telephony.h:141 */
+    return powf(10.0f, db/20.0f);
 }
 
 float spg_dds_scaling_dbm0f(float level)

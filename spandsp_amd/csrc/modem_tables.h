@@ -17,6 +17,9 @@ void spg_make_sqrt_table(uint16_t out[193]);
 int spg_make_rx_pulseshaper(int coeff_sets, int coeffs_per_filter, double carrier_hz, double baud_rate,
                             double excess_bandwidth, float *re, float *im);
 
+/* out: [coeff_sets][coeffs_per_filter] */
+int spg_make_tx_pulseshaper(int coeff_sets, int coeffs_per_filter, double excess_bandwidth, float *out);
+
 void spg_make_godard(double carrier, double baud_rate, double alpha, float out[7]);
 void spg_make_v29_space_map(uint8_t out[400]);
 int spg_v17_constellation_size(int bit_rate);
@@ -27,6 +30,7 @@ void spg_make_v17_rx_maps(uint8_t maps[4*36*36*8], uint8_t map_4800[36*36]);
    arguments from another translation unit so that powf() is libm's, as it is in the reference. */
 int32_t spg_dds_phase_ratef(float hz);
 float spg_dds_scaling_dbm0f(float level);
+float spg_db_to_amplitude_ratio(float db);
 /* out: rate[4], gain[4] (as float bits), duration[4], repeat = 13 words */
 void spg_make_tone_descriptor(int32_t out[13], int f1, int l1, int f2, int l2, int d1, int d2, int d3, int d4, int repeat);
 

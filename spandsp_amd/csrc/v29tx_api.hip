@@ -1,0 +1,320 @@
+// v29tx_api.hip -- C ABI of the V.29 transmitter banks (include/spangpu.h, "V.29 transmitter banks"): batched
+// v29_tx() as a device-side signal source.  Device code: v29tx_dev.hpp.  No CPU implementation exists behind
+// these entry points.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/spangpu.h"
+#include "modem_tables.h"
+#include "v29tx_dev.hpp"
+
+using namespace spg;
+
+extern "C" int spangpu_set_error(int code, const char *msg);
+
+#define VT_TRY(expr)                                                                        \
+    do                                                                                      \
+    {                                                                                       \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+        {                                                                                   \
+            char m_[256];                                                                   \
+            snprintf(m_, sizeof(m_), "%s failed: %s", #expr, hipGetErrorString(e_));        \
+            return spangpu_set_error(SPANGPU_ERR_HIP, m_);                                  \
+        }                                                                                   \
+    }                                                                                       \
+    while (0)
+
+struct spangpu_v29tx_s
+{
+    int device;
+    int n_ch;
+    hipStream_t stream;
+    bool own_stream;
+    int32_t *st;
+    float *sine;
+    float *shaper;
+    int16_t *d_pcm;
+    size_t pcm_cap;
+};
+
+static void put_f(int32_t *w, int idx, float v)
+{
+    memcpy(w + idx, &v, sizeof(float));
+}
+
+static float get_f(const int32_t *w, int idx)
+{
+    float v;
+    memcpy(&v, w + idx, sizeof(float));
+    return v;
+}
+
+static void gain_words(int32_t *w)
+{
+    // set_working_gain(), v29tx.c:286-320
+    const float base = get_f(w, VT_BASE_GAIN);
+    switch (w[VT_BIT_RATE])
+    {
+    case 9600: put_f(w, VT_GAIN, 0.387f*base); break;
+    case 7200: put_f(w, VT_GAIN, 0.605f*base); break;
+    case 4800: put_f(w, VT_GAIN, 0.470f*base); break;
+    }
+}
+
+static void power_words(int32_t *w, float power)
+{
+    // v29_tx_power(), v29tx.c:322-338; TX_PULSESHAPER_GAIN = 1.0f in the float build
+    put_f(w, VT_BASE_GAIN, spg_db_to_amplitude_ratio(power - 3.14f)*32768.0f/1.000000f);
+    gain_words(w);
+}
+
+static int restart_words(int32_t *w, int bit_rate, int tep)
+{
+    // v29_tx_restart(), v29tx.c:365-404
+    w[VT_BIT_RATE] = bit_rate;
+    gain_words(w);
+    switch (bit_rate)
+    {
+    case 9600: w[VT_TRAINING_OFFSET] = 0; break;
+    case 7200: w[VT_TRAINING_OFFSET] = 2; break;
+    case 4800: w[VT_TRAINING_OFFSET] = 4; break;
+    default: return -1;
+    }
+    for (int i = 0;  i < 18;  i++)
+        w[VT_RRC_RE + i] = 0;
+    w[VT_RRC_STEP] = 0;
+    w[VT_SCRAMBLE] = 0;
+    w[VT_TRAIN_SCRAMBLE] = 0x2A;
+    w[VT_IN_TRAINING] = 1;
+    w[VT_TRAINING_STEP] = tep  ?  0  :  kVtSeg1;
+    w[VT_CARRIER_PHASE] = 0;
+    w[VT_BAUD_PHASE] = 0;
+    w[VT_CONSTELLATION] = 0;
+    return 0;
+}
+
+static int rw_words(spangpu_v29tx_s *t, int ch, int32_t *w, bool write)
+{
+    VT_TRY(hipSetDevice(t->device));
+    if (write)
+        VT_TRY(hipMemcpy2DAsync(t->st + ch, (size_t) t->n_ch*sizeof(int32_t), w, sizeof(int32_t), sizeof(int32_t), kV29TxWords,
+                                hipMemcpyHostToDevice, t->stream));
+    else
+        VT_TRY(hipMemcpy2DAsync(w, sizeof(int32_t), t->st + ch, (size_t) t->n_ch*sizeof(int32_t), sizeof(int32_t), kV29TxWords,
+                                hipMemcpyDeviceToHost, t->stream));
+    VT_TRY(hipStreamSynchronize(t->stream));
+    return SPANGPU_OK;
+}
+
+extern "C" {
+
+int spangpu_v29tx_create(spangpu_v29tx_t **out, int device, int n_channels, int bit_rate, int tep, const uint32_t *seeds)
+{
+    if (out == NULL  ||  n_channels <= 0  ||  (bit_rate != 9600  &&  bit_rate != 7200  &&  bit_rate != 4800))
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments (bit rate 9600, 7200 or 4800)");
+    *out = NULL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess  ||  count <= 0)
+        return spangpu_set_error(SPANGPU_ERR_NO_DEVICE, "no HIP device: libspangpu has no CPU fallback");
+    if (device < 0  ||  device >= count)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "device out of range");
+    VT_TRY(hipSetDevice(device));
+    spangpu_v29tx_s *t = (spangpu_v29tx_s *) calloc(1, sizeof(*t));
+    if (t == NULL)
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "calloc");
+    t->device = device;
+    t->n_ch = n_channels;
+    if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+        free(t);
+        return spangpu_set_error(SPANGPU_ERR_HIP, "hipStreamCreate failed");
+    }
+    t->own_stream = true;
+    const size_t words = (size_t) kV29TxWords*n_channels;
+    if (hipMalloc(&t->st, words*sizeof(int32_t)) != hipSuccess
+        ||  hipMalloc(&t->sine, 2048*sizeof(float)) != hipSuccess
+        ||  hipMalloc(&t->shaper, 90*sizeof(float)) != hipSuccess)
+    {
+        spangpu_v29tx_destroy(t);
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "allocation of the V.29 transmitter bank failed");
+    }
+    float sine[2048];
+    float shaper[90];
+    spg_make_sine_table(sine);
+    // make_modem_filter -m V.29 -t: 10 phases x 9 taps, excess bandwidth 0.25 (make_modem_filter.c:401-412)
+    if (spg_make_tx_pulseshaper(10, 9, 0.25, shaper) != 0)
+    {
+        spangpu_v29tx_destroy(t);
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "table scratch");
+    }
+    // v29_tx_init(), v29tx.c:406-434
+    int32_t one[kV29TxWords];
+    memset(one, 0, sizeof(one));
+    one[VT_BIT_RATE] = bit_rate;
+    one[VT_CARRIER_RATE] = spg_dds_phase_ratef(1700.0f);
+    power_words(one, -14.0f);
+    restart_words(one, bit_rate, tep);
+    int32_t *host = (int32_t *) malloc(words*sizeof(int32_t));
+    if (host == NULL)
+    {
+        spangpu_v29tx_destroy(t);
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "malloc");
+    }
+    for (int k = 0;  k < kV29TxWords;  k++)
+    {
+        for (int c = 0;  c < n_channels;  c++)
+            host[(size_t) k*n_channels + c] = one[k];
+    }
+    for (int c = 0;  c < n_channels;  c++)
+        host[(size_t) VT_PRBS*n_channels + c] = (int32_t) ((seeds  ?  seeds[c]  :  (uint32_t) (c*2654435761u + 1u)) & 0x7FFFu);
+    hipError_t e = hipMemcpy(t->st, host, words*sizeof(int32_t), hipMemcpyHostToDevice);
+    free(host);
+    if (e == hipSuccess)
+        e = hipMemcpy(t->sine, sine, sizeof(sine), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(t->shaper, shaper, sizeof(shaper), hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+        spangpu_v29tx_destroy(t);
+        return spangpu_set_error(SPANGPU_ERR_HIP, "state upload failed");
+    }
+    *out = t;
+    return SPANGPU_OK;
+}
+
+void spangpu_v29tx_destroy(spangpu_v29tx_t *t)
+{
+    if (t == NULL)
+        return;
+    (void) hipSetDevice(t->device);
+    if (t->stream)
+        (void) hipStreamSynchronize(t->stream);
+    (void) hipFree(t->st);
+    (void) hipFree(t->sine);
+    (void) hipFree(t->shaper);
+    (void) hipFree(t->d_pcm);
+    if (t->own_stream  &&  t->stream)
+        (void) hipStreamDestroy(t->stream);
+    free(t);
+}
+
+int spangpu_v29tx_channels(const spangpu_v29tx_t *t) { return t  ?  t->n_ch  :  SPANGPU_ERR_BAD_ARG; }
+int spangpu_v29tx_state_words(void) { return kV29TxWords; }
+
+int spangpu_v29tx_set_stream(spangpu_v29tx_t *t, void *stream)
+{
+    if (t == NULL)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null bank");
+    VT_TRY(hipSetDevice(t->device));
+    VT_TRY(hipStreamSynchronize(t->stream));
+    if (t->own_stream)
+        (void) hipStreamDestroy(t->stream);
+    t->stream = (hipStream_t) stream;
+    t->own_stream = false;
+    return SPANGPU_OK;
+}
+
+int spangpu_v29tx_sync(spangpu_v29tx_t *t)
+{
+    if (t == NULL)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null bank");
+    VT_TRY(hipSetDevice(t->device));
+    VT_TRY(hipStreamSynchronize(t->stream));
+    return SPANGPU_OK;
+}
+
+int spangpu_v29tx_power(spangpu_v29tx_t *t, int channel, float power_dbm0)
+{
+    if (t == NULL  ||  channel < 0  ||  channel >= t->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    int32_t w[kV29TxWords];
+    int rc = rw_words(t, channel, w, false);
+    if (rc != SPANGPU_OK)
+        return rc;
+    power_words(w, power_dbm0);
+    return rw_words(t, channel, w, true);
+}
+
+int spangpu_v29tx_restart(spangpu_v29tx_t *t, int channel, int bit_rate, int tep)
+{
+    if (t == NULL  ||  channel < 0  ||  channel >= t->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    int32_t w[kV29TxWords];
+    int rc = rw_words(t, channel, w, false);
+    if (rc != SPANGPU_OK)
+        return rc;
+    if (restart_words(w, bit_rate, tep) != 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bit rate 9600, 7200 or 4800");
+    return rw_words(t, channel, w, true);
+}
+
+int spangpu_v29tx_get_state(spangpu_v29tx_t *t, int channel, int32_t *words)
+{
+    if (t == NULL  ||  words == NULL  ||  channel < 0  ||  channel >= t->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    return rw_words(t, channel, words, false);
+}
+
+int spangpu_v29tx_tx(spangpu_v29tx_t *t, int mem_kind, int16_t *pcm, long long stride, int samples)
+{
+    if (t == NULL  ||  pcm == NULL  ||  samples < 0  ||  stride < samples)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (mem_kind != SPANGPU_MEM_HOST  &&  mem_kind != SPANGPU_MEM_DEVICE)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad mem kind");
+    if (samples == 0)
+        return 0;
+    VT_TRY(hipSetDevice(t->device));
+    V29TxLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.st = t->st;
+    L.sine = t->sine;
+    L.shaper = t->shaper;
+    L.n_ch = t->n_ch;
+    L.samples = samples;
+    if (mem_kind == SPANGPU_MEM_HOST)
+    {
+        const size_t need = (size_t) ((samples + 7) & ~7);
+        if (need > t->pcm_cap)
+        {
+            VT_TRY(hipStreamSynchronize(t->stream));
+            (void) hipFree(t->d_pcm);
+            t->d_pcm = NULL;
+            t->pcm_cap = 0;
+            if (hipMalloc(&t->d_pcm, need*t->n_ch*sizeof(int16_t)) != hipSuccess)
+                return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "pcm staging");
+            t->pcm_cap = need;
+        }
+        L.pcm = t->d_pcm;
+        L.stride = (long long) t->pcm_cap;
+    }
+    else
+    {
+        L.pcm = pcm;
+        L.stride = stride;
+    }
+    L.vec = ((L.stride & 7) == 0  &&  (reinterpret_cast<uintptr_t>(L.pcm) & 15) == 0)  ?  1  :  0;
+    hipLaunchKernelGGL(v29tx_bank_kernel, dim3((t->n_ch + 63)/64), dim3(64), 0, t->stream, L);
+    VT_TRY(hipGetLastError());
+    if (mem_kind == SPANGPU_MEM_HOST)
+    {
+        VT_TRY(hipMemcpy2DAsync(pcm, (size_t) stride*sizeof(int16_t), t->d_pcm, t->pcm_cap*sizeof(int16_t),
+                                (size_t) samples*sizeof(int16_t), t->n_ch, hipMemcpyDeviceToHost, t->stream));
+        VT_TRY(hipStreamSynchronize(t->stream));
+    }
+    return samples;
+}
+
+// The pulse shaper table this library builds (for tests): [10][9]
+int spangpu_v29tx_table(float *out, int max)
+{
+    if (out == NULL  ||  max < 90)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "need room for 90 floats");
+    return (spg_make_tx_pulseshaper(10, 9, 0.25, out) == 0)  ?  90  :  spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "table scratch");
+}
+
+}   // extern "C"

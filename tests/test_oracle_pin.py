@@ -569,6 +569,65 @@ def test_golden_mct(built, rx_type, tx_kind):
     assert np.array_equal(snaps, g["snapshots"])
 
 
+
+# --------------------------------------------------------------------------------------
+# V.29 transmitter (v29tx_oracle.c)
+# --------------------------------------------------------------------------------------
+V29TX_CASES = [(9600, False, 0x1234), (9600, True, 0x0001), (7200, False, 0x7FFF), (7200, True, 0x2B2B), (4800, False, 0x0F0F),
+               (4800, True, 0x5555)]
+
+
+def v29tx_run(tx, seed):
+    """One session of a transmitter object: odd call sizes, a power change, a restart at another rate."""
+    rng = np.random.default_rng(seed)
+    out = []
+    snaps = []
+    for k in range(150):
+        out.append(tx.tx(int(rng.integers(1, 400))))
+        if k % 10 == 9:
+            snaps.append(tx.snapshot())
+        if k == 60:
+            tx.power(-9.5)
+        if k == 110:
+            tx.restart(7200 if int(snaps[0][0]) != 7200 else 9600, True)
+    return np.concatenate(out), np.stack(snaps)
+
+
+def use_v29_tx_table(built):
+    """The pulse shaper the oracle runs on: the library's own builder's (host code), accepted only if it equals the
+    reference's generated table, a copy of which is committed in tests/golden/v29tx.npz."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    t = engine.v29_tx_table()
+    g = np.load(os.path.join(GOLDEN, "v29tx.npz"))
+    assert np.array_equal(t.view(np.uint32), g["table"].view(np.uint32))
+    use_golden_modem_tables()
+    orc.set_v29_tx_table(t)
+
+
+@needs_ref
+@pytest.mark.parametrize("bit_rate,tep,seed", V29TX_CASES)
+def test_v29_tx_live(built, bit_rate, tep, seed):
+    from oracle import ref, restated as orc
+    use_v29_tx_table(built)
+    assert np.array_equal(ref.v29_tx_table().view(np.uint32), np.load(os.path.join(GOLDEN, "v29tx.npz"))["table"].view(np.uint32))
+    a_amp, a_snaps = v29tx_run(ref.V29Tx(bit_rate, tep, seed), seed)
+    b_amp, b_snaps = v29tx_run(orc.V29Tx(bit_rate, tep, seed), seed)
+    assert len(a_amp) > 20000
+    assert np.array_equal(a_amp, b_amp)
+    assert np.array_equal(a_snaps, b_snaps)
+
+
+def test_golden_v29_tx(built):
+    from oracle import restated as orc
+    use_v29_tx_table(built)
+    g = np.load(os.path.join(GOLDEN, "v29tx.npz"))
+    for i, (bit_rate, tep, seed) in enumerate(V29TX_CASES):
+        amp, snaps = v29tx_run(orc.V29Tx(bit_rate, tep, seed), seed)
+        assert np.array_equal(amp, g["amp_%d" % i]), i
+        assert np.array_equal(snaps, g["snaps_%d" % i]), i
+
+
 def test_g711_decode(built):
     """alaw_to_linear / ulaw_to_linear (spandsp/g711.h): restatement vs the frozen reference outputs, all 256 codes
     (and vs the live reference when it is here)."""

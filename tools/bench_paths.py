@@ -49,6 +49,69 @@ def synth_v29(n_ch, n_frames, dev, seed, fixture="v29_9600.npz"):
     return out
 
 
+def synth_v29_on_device(n_ch, n_frames, dev, stream, seed):
+    """V.29 9600 bps input made where it is consumed: a V29TxBank (the reference's modulator, bit-exact, on the
+    device) writes every channel's own transmission (its own data bits and level) frame by frame into HBM; AWGN is
+    added with torch.  Returns int16 [n_frames, n_ch, FRAME]."""
+    from spandsp_amd import engine
+    rng = np.random.default_rng(seed)
+    tx = engine.V29TxBank(n_ch, 9600, False, rng.integers(1, 0x7FFF, n_ch).astype(np.uint32))
+    tx.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    for c in range(0, n_ch, 4):                             # a spread of levels (every 4th channel moved off -14 dBm0)
+        tx.power(c, float(rng.uniform(-26.0, -10.0)))
+    out = torch.empty(n_frames, n_ch, FRAME, dtype=torch.int16, device=dev)
+    for f in range(n_frames):
+        tx.tx_device(ctypes.c_void_p(out[f].data_ptr()), FRAME, FRAME)
+    tx.sync()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    sigma = torch.empty(1, n_ch, 1, device=dev).uniform_(1.0, 30.0, generator=gen)
+    for f0 in range(0, n_frames, 16):
+        blk = out[f0:f0 + 16].float()
+        blk = blk + sigma*torch.randn(blk.shape, device=dev, generator=gen)
+        out[f0:f0 + 16] = torch.clamp(torch.round(blk), -32768, 32767).to(torch.int16)
+    return out
+
+
+def bench_v29_tx(args, dev, stream):
+    """the V.29 transmitter bank writing 160-sample frames into HBM."""
+    from spandsp_amd import engine
+    n_ch = args.channels or 65536
+    tx = engine.V29TxBank(n_ch, 9600)
+    tx.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    out = torch.zeros(4, n_ch, FRAME, dtype=torch.int16, device=dev)
+
+    def step(i):
+        tx.tx_device(ctypes.c_void_p(out[i % 4].data_ptr()), FRAME, FRAME)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record(stream)
+        step(args.warmup + i)
+        evs[i][1].record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = [a.elapsed_time(b) for a, b in evs]
+    avg_ms = sum(per)/len(per)
+    rms = float(out.float().pow(2).mean().sqrt())
+    alg = n_ch*(FRAME*2 + 2*32*4)
+    value = args.steps*n_ch*FRAME/dt/1e6
+    return {
+        "metric": "Msamples/s of batched V.29 9600 bps transmit (signal source bank)", "value": value, "unit": "Msamples/s",
+        "realtime_channels": value*1e6/8000.0, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt*1e3/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic", "config": {"workload": "v29_tx bank, %d channels x %d-sample frames" % (n_ch, FRAME),
+                                        "channels_per_gpu": n_ch, "rms_of_last_frames": rms},
+        "roofline": {"bound": "hbm", "kernel": "v29tx_bank_kernel", "achieved": alg/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": alg/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None, "alg_bytes_per_launch": alg,
+                     "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3,
+                     "note": "sample-serial modulator, one channel per lane: latency bound at one wave per SIMD"},
+        "cpu_baseline": None}
+
+
 def run_threads(n_ch, work):
     cores = max(1, min(os.cpu_count() or 1, n_ch))
     bounds = np.linspace(0, n_ch, cores + 1).astype(int)
@@ -495,13 +558,15 @@ def bench_dtmf_tx(args, dev, stream):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct"], default="v29")
+    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct", "v29_tx"], default="v29")
     ap.add_argument("--channels", type=int, default=0)
     ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
     ap.add_argument("--cpu-channels", type=int, default=16384)
+    ap.add_argument("--replay-fixture", action="store_true",
+                    help="v29: replay the committed reference transmission instead of running the V.29 transmitter bank")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a HIP device; the engine has no CPU fallback")
@@ -516,6 +581,9 @@ def main():
         return
     if args.workload == "mixed":
         print(json.dumps(bench_mixed(args, dev, stream)))
+        return
+    if args.workload == "v29_tx":
+        print(json.dumps(bench_v29_tx(args, dev, stream)))
         return
     if args.workload == "mct":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -533,7 +601,10 @@ def main():
     kind = {"v29": engine.V29, "v17": engine.V17, "v27ter": engine.V27TER}[args.workload]
     n_ch = args.channels or 16384
     nf = args.steps + args.warmup
-    frames = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture)
+    if args.workload == "v29" and not args.replay_fixture:
+        frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929)
+    else:
+        frames = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture)
     bank = engine.ModemBank(kind, n_ch, bit_rate)
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
     frame_bytes = n_ch*FRAME*2
@@ -568,7 +639,7 @@ def main():
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s %d bps RX, %d channels x %d-sample frames, AWGN line model%s"
+        "config": {"workload": "%s %d bps RX, %d channels x %d-sample frames, AWGN%s"
                                % (args.workload, bit_rate, n_ch, FRAME, " (BASELINE configs[3])" if args.workload == "v29" else ""),
                    "channels_per_gpu": n_ch,
                    "sampled_channels_in_data_mode_at_end": "%d of %d" % (trained, len(range(0, n_ch, max(1, n_ch//256)))),
