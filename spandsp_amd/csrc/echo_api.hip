@@ -33,6 +33,7 @@ struct spangpu_echo_s
     int n_ch;
     int taps;
     int tpl;
+    int group;              // lanes per channel: 16 or 8
     hipStream_t stream;
     bool own_stream;
     int32_t *scal;
@@ -64,7 +65,18 @@ static void init_scalars(int32_t *s, int taps, int mode)
     s[ES_ADAPTION_MODE] = mode;
 }
 
+static int g_echo_group = 0;
+
 extern "C" {
+
+// Tuning / A-B testing: lanes per channel of banks created from now on (0 = choose by length, 8, 16).
+int spangpu_tune_echo_lanes_per_channel(int lanes)
+{
+    if (lanes != 0  &&  lanes != 8  &&  lanes != 16)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "lanes per channel must be 0 (auto), 8 or 16");
+    g_echo_group = lanes;
+    return SPANGPU_OK;
+}
 
 int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int taps, int adaption_mode)
 {
@@ -84,7 +96,13 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     e->device = device;
     e->n_ch = n_channels;
     e->taps = taps;
-    e->tpl = taps/kEchoGroup;
+    // Sixteen lanes per channel by default.  Eight (spangpu_tune_echo_lanes_per_channel) put twice the channels
+    // behind the replicated control code, but the 16-tap slices then need ~250 VGPRs and the two come out even
+    // (1.16 ms against 1.13 ms for 131072 x 128 taps), so it stays an option for A-B tests.
+    e->group = (g_echo_group != 0)  ?  g_echo_group  :  16;
+    if (taps/e->group < 2  ||  taps/e->group > 16)
+        e->group = 16;
+    e->tpl = taps/e->group;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
     {
         free(e);
@@ -232,14 +250,27 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
     L.taps32 = e->taps32;
     L.taps16 = e->taps16;
     L.hist = e->hist;
-    const int waves = (e->n_ch + kEchoChPerWave - 1)/kEchoChPerWave;
+    const int per_wave = 64/e->group;
+    const int waves = (e->n_ch + per_wave - 1)/per_wave;
     const int blocks = (waves + 3)/4;
-    switch (e->tpl)
+    if (e->group == 8)
     {
-    case 2:  hipLaunchKernelGGL(echo_bank_kernel<2>, dim3(blocks), dim3(256), 0, e->stream, L);  break;
-    case 4:  hipLaunchKernelGGL(echo_bank_kernel<4>, dim3(blocks), dim3(256), 0, e->stream, L);  break;
-    case 8:  hipLaunchKernelGGL(echo_bank_kernel<8>, dim3(blocks), dim3(256), 0, e->stream, L);  break;
-    default: hipLaunchKernelGGL(echo_bank_kernel<16>, dim3(blocks), dim3(256), 0, e->stream, L); break;
+        switch (e->tpl)
+        {
+        case 4:  hipLaunchKernelGGL((echo_bank_kernel<4, 8>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
+        case 8:  hipLaunchKernelGGL((echo_bank_kernel<8, 8>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
+        default: hipLaunchKernelGGL((echo_bank_kernel<16, 8>), dim3(blocks), dim3(256), 0, e->stream, L); break;
+        }
+    }
+    else
+    {
+        switch (e->tpl)
+        {
+        case 2:  hipLaunchKernelGGL((echo_bank_kernel<2, 16>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
+        case 4:  hipLaunchKernelGGL((echo_bank_kernel<4, 16>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
+        case 8:  hipLaunchKernelGGL((echo_bank_kernel<8, 16>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
+        default: hipLaunchKernelGGL((echo_bank_kernel<16, 16>), dim3(blocks), dim3(256), 0, e->stream, L); break;
+        }
     }
     ECHO_TRY(hipGetLastError());
     if (mem == SPANGPU_MEM_HOST)

@@ -1,8 +1,12 @@
 // echo_dev.hpp -- device side of the batched G.168 line echo canceller
 // (reference: src/echo.c:120-661, src/spandsp/fir.h:121-183).
 //
-// Mapping: SIXTEEN LANES PER CHANNEL, four channels per wavefront.  A 16-lane group is
-// exactly one DPP row.  Lane j of a group owns taps [j*TPL, (j+1)*TPL) of its channel for
+// Mapping: G = SIXTEEN OR EIGHT LANES PER CHANNEL, 64/G channels per wavefront (a 16-lane group is
+// exactly one DPP row, an 8-lane group half of one).  The scalar control below is replicated in the
+// lanes of a group, so it costs one instruction stream per WAVE whatever G is: eight lanes per
+// channel put twice the channels behind every control instruction, but need 16-tap slices for a
+// 128 tap canceller and with them ~250 VGPRs; measured, the two mappings come out even, and the
+// library uses G = 16 unless told otherwise.  Lane j of a group owns taps [j*TPL, (j+1)*TPL) of its channel for
 // the whole frame, in registers: the 32-bit LMS taps, the 16-bit FIR coefficients of the
 // active tap set, and the matching slice of the FIR history.  The history is held in
 // "window order" (w[0] = newest sample), so tap i always meets w[i]; advancing a sample
@@ -42,8 +46,6 @@ __device__ __forceinline__ void for_each_phase(F &f, int idx)
 }
 
 constexpr int kEchoScalars = 48;        // int32 words per channel (layout below)
-constexpr int kEchoGroup = 16;          // lanes per channel
-constexpr int kEchoChPerWave = 4;
 
 // Scalar word indices (the control fields of echo_can_state_t, src/spandsp/private/echo.h, in order)
 enum
@@ -105,10 +107,30 @@ __device__ __forceinline__ int32_t f2i_x86(float v)
     return (int32_t) v;
 }
 
+// d = a*b + c through the 24 bit multiplier (operands sign-extended from bit 23, low 32 bits of the result:
+// exact for the 16 bit x <= 24 bit products here).  Written as the instruction: given __mul24() on operands
+// whose ranges it cannot see, hipcc emits v_bfe_i32 + the quarter-rate v_mul_lo_u32 instead.
+__device__ __forceinline__ int mad24(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 template <int CTRL>
 __device__ __forceinline__ int dpp_mov(int old, int src)
 {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xF, 0xF, false);
+}
+
+// Sum over the 8 lanes of half a DPP row, result in every lane: the two quad butterflies, then the mirror
+// within the half row (after the butterflies a quad is uniform, so the mirror brings in the other quad's sum).
+__device__ __forceinline__ int row_sum8(int v)
+{
+    v += dpp_mov<0xB1>(0, v);       // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(0, v);       // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(0, v);      // row_half_mirror
+    return v;
 }
 
 // Sum over the 16 lanes of a DPP row, result in every lane (wrap-around add).
@@ -121,21 +143,23 @@ __device__ __forceinline__ int row_sum16(int v)
     return v;
 }
 
-template <int TPL>
+template <int TPL, int G>
 __global__ __launch_bounds__(256)
 void echo_bank_kernel(const EchoLaunch L)
 {
-    constexpr int T = TPL*kEchoGroup;
-    constexpr int kMaxFrame = 320;                  // samples staged per pass
-    __shared__ int io[4][kEchoChPerWave][kMaxFrame];        // tx | rx<<16 per sample, then the clean output
-    __shared__ int bounce[4][kEchoChPerWave][T];            // tap-set / history gathers at set events
-    __shared__ float acfbuf[4][kEchoChPerWave][48];         // narrowband_detect scratch
+    static_assert(G == 16  ||  G == 8, "a channel's lanes are one DPP row or half of one");
+    constexpr int T = TPL*G;
+    constexpr int kChPerWave = 64/G;
+    constexpr int kMaxFrame = (G == 16)  ?  320  :  128;    // samples staged per pass
+    __shared__ int io[4][kChPerWave][kMaxFrame];            // tx | rx<<16 per sample, then the clean output
+    __shared__ int bounce[4][kChPerWave][T];                // tap-set / history gathers at set events
+    __shared__ float acfbuf[4][kChPerWave][48];             // narrowband_detect scratch
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int g = lane >> 4;
-    const int j = lane & 15;
-    const int ch_raw = ((blockIdx.x*4 + wv)*kEchoChPerWave) + g;
+    const int g = lane/G;
+    const int j = lane%G;
+    const int ch_raw = ((blockIdx.x*4 + wv)*kChPerWave) + g;
     const bool live = ch_raw < L.n_ch;
     const int ch = live  ?  ch_raw  :  (L.n_ch - 1);
     const bool leader = live  &&  (j == 0);
@@ -172,6 +196,7 @@ void echo_bank_kernel(const EchoLaunch L)
     int fir_set = sc[ES_FIR_SET];
     int vad = sc[ES_VAD];
     int my_acf = (j < 9)  ?  sc[ES_LAST_ACF + j]  :  0;         // lane k holds last_acf[k]
+    int my_acf8 = (G == 8  &&  j == 0)  ?  sc[ES_LAST_ACF + 8]  :  0;     // eight lanes: lane 0 also holds last_acf[8]
 
     // ---- per-lane tap slices ------------------------------------------------------------------
     int t32[TPL];               // fir_taps32
@@ -207,7 +232,7 @@ void echo_bank_kernel(const EchoLaunch L)
     {
         const int n = min(kMaxFrame, L.samples - base);
         // ---- stage tx/rx of this pass into LDS (each group copies its own channel) ----------
-        for (int i = j;  i < n;  i += kEchoGroup)
+        for (int i = j;  i < n;  i += G)
         {
             const int a = (uint16_t) L.tx[(size_t) ch*L.stride + base + i];
             const int b = (uint16_t) L.rx[(size_t) ch*L.stride + base + i];
@@ -233,12 +258,20 @@ void echo_bank_kernel(const EchoLaunch L)
             // oldest sample; lane 0 of the group receives tx.
             constexpr int NEWP = (TPL - 1 - PH + 8*TPL)%TPL;     // physical reg of logical slot TPL-1 before the shift
             w[NEWP] = dpp_mov<0x111>(tx, w[NEWP]);              // row_shr:1, lane 0 keeps `old` = tx
+            if (G == 8)
+                w[NEWP] = (j == 0)  ?  tx  :  w[NEWP];          // the second channel of the row starts at lane 8
             // after the shift the phase is PH + 1: logical k -> w[(k - PH - 1) mod TPL]
+            // two accumulators: integer addition wraps and associates, so the order is free
             int y = 0;
+            int y1 = 0;
 #pragma unroll
-            for (int k = 0;  k < TPL;  k++)
-                y += __mul24(f16[k], w[(k - PH - 1 + 8*TPL)%TPL]);
-            y = row_sum16(y);
+            for (int k = 0;  k < TPL;  k += 2)
+            {
+                y = mad24(f16[k], w[(k - PH - 1 + 8*TPL)%TPL], y);
+                y1 = mad24(f16[k + 1], w[(k + 1 - PH - 1 + 8*TPL)%TPL], y1);
+            }
+            y += y1;
+            y = (G == 16)  ?  row_sum16(y)  :  row_sum8(y);
             const int echo_value = (int) (short) (y >> 15);
             int clean_rx = rx - echo_value;                     // echo.c:452
             if (nonupdate_dwell > 0)
@@ -274,23 +307,40 @@ void echo_bank_kernel(const EchoLaunch L)
                                 }
                             }
                             float temp = 0.0f;
+                            float temp8 = 0.0f;
                             if (j < 9)
                             {
                                 for (int i = j;  i < 32;  i++)
                                     temp += acfbuf[wv][g][i]*acfbuf[wv][g][i - j];
                                 acfbuf[wv][g][32 + j] = temp;
                             }
+                            if (G == 8  &&  j == 0)
+                            {
+                                for (int i = 8;  i < 32;  i++)
+                                    temp8 += acfbuf[wv][g][i]*acfbuf[wv][g][i - 8];
+                            }
                             const float scale = (float) 0x1FFFFFFF/acfbuf[wv][g][32];
+                            auto similar = [](int before, int now) -> bool
+                            {
+                                // echo.c:150-168: within a factor of two of the previous value, same sign
+                                if (before >= 0  &&  now >= 0)
+                                    return ((before >> 1) < now)  &&  (now < (int) ((uint32_t) before << 1));
+                                if (before < 0  &&  now < 0)
+                                    return ((before >> 1) > now)  &&  (now > (int) ((uint32_t) before << 1));
+                                return false;
+                            };
                             const int acf = f2i_x86(temp*scale);
-                            bool hit = false;
-                            if (my_acf >= 0  &&  acf >= 0)
-                                hit = ((my_acf >> 1) < acf)  &&  (acf < (int) ((uint32_t) my_acf << 1));
-                            else if (my_acf < 0  &&  acf < 0)
-                                hit = ((my_acf >> 1) > acf)  &&  (acf > (int) ((uint32_t) my_acf << 1));
+                            const int acf8 = f2i_x86(temp8*scale);
+                            const bool hit = similar(my_acf, acf);
+                            const bool hit8 = (G == 8  &&  j == 0)  &&  similar(my_acf8, acf8);
                             const unsigned long long bal = __ballot(hit  &&  j < 9);
-                            const int score = __popcll((bal >> (g*16)) & 0x1FFull);
+                            const unsigned long long bal8 = __ballot(hit8);
+                            const int score = (G == 16)  ?  __popcll((bal >> (g*16)) & 0x1FFull)
+                                                         :  (__popcll((bal >> (g*8)) & 0xFFull) + (int) ((bal8 >> (g*8)) & 1ull));
                             if (j < 9)
                                 my_acf = acf;
+                            if (G == 8  &&  j == 0)
+                                my_acf8 = acf8;
                             if (score > 6)
                             {
                                 if (narrowband_score == 0)
@@ -373,7 +423,7 @@ void echo_bank_kernel(const EchoLaunch L)
 #pragma unroll
                             for (int k = 0;  k < TPL;  k++)
                             {
-                                t32[k] += __mul24(w[(k - PH - 1 + 8*TPL)%TPL], factor);
+                                t32[k] = mad24(w[(k - PH - 1 + 8*TPL)%TPL], factor, t32[k]);
                                 t16[k] = (int) (short) (t32[k] >> 15);
                                 if (same)
                                     f16[k] = t16[k];
@@ -499,7 +549,7 @@ void echo_bank_kernel(const EchoLaunch L)
         // ---- clean samples out (each group writes its own channel) ---------------------------
         if (live)
         {
-            for (int i = j;  i < n;  i += kEchoGroup)
+            for (int i = j;  i < n;  i += G)
             {
                 const int word = io[wv][g][i];
                 L.clean[(size_t) ch*L.stride + base + i] = (int16_t) (word & 0xFFFF);
@@ -521,6 +571,8 @@ void echo_bank_kernel(const EchoLaunch L)
         }
         if (j < 9)
             sc[ES_LAST_ACF + j] = my_acf;
+        if (G == 8  &&  j == 0)
+            sc[ES_LAST_ACF + 8] = my_acf8;
     }
     if (leader)
     {

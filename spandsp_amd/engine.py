@@ -110,6 +110,7 @@ def lib():
             "spangpu_fsk_set_signal_cutoff": (ci, [vp, ci, cf]),
             "spangpu_fsk_set_frame_parameters": (ci, [vp, ci, ci, ci, ci]),
             "spangpu_fsk_fillin": (ci, [vp, ci, ci]),
+            "spangpu_tune_echo_lanes_per_channel": (ci, [ci]),
             "spangpu_txbank_create": (ci, [C.POINTER(vp), ci, ci, ci]),
             "spangpu_txbank_destroy": (None, [vp]),
             "spangpu_txbank_channels": (ci, [vp]),

@@ -59,21 +59,29 @@ def compare_state(bank, dets, what):
         assert np.array_equal(g["history"], o["history"]), (what, c, "history")
 
 
-@pytest.mark.parametrize("taps,mode,sizes", [
-    (128, 0x01, [160]),
-    (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160]),
-    (128, 0x01 | 0x02, [1, 7, 160, 333, 64, 5]),
-    (256, 0x01 | 0x20 | 0x40, [160]),
-    (64, 0x01 | 0x02 | 0x04, [80, 240]),
-    (32, 0x01, [160]),
+@pytest.mark.parametrize("taps,mode,sizes,lanes", [
+    (128, 0x01, [160], 0),
+    (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160], 0),
+    (128, 0x01 | 0x02, [1, 7, 160, 333, 64, 5], 0),
+    (256, 0x01 | 0x20 | 0x40, [160], 0),
+    (64, 0x01 | 0x02 | 0x04, [80, 240], 0),
+    (32, 0x01, [160], 0),
+    # the eight-lanes-per-channel mapping (spangpu_tune_echo_lanes_per_channel): identical results
+    (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 8),
+    (64, 0x01 | 0x02, [160], 8),
+    (32, 0x01, [160], 8),
 ])
-def test_echo_bank_parity(built, taps, mode, sizes):
+def test_echo_bank_parity(built, taps, mode, sizes, lanes):
     from oracle import restated as orc
     from spandsp_amd import engine
     n_ch = 37                               # ragged: 9 full wavefronts + one with a single channel
     n = 160*150
     tx, rx = make_channels(n_ch, n, taps, seed=taps + mode)
-    bank = engine.EchoBank(n_ch, taps, mode)
+    assert engine.lib().spangpu_tune_echo_lanes_per_channel(lanes) == 0
+    try:
+        bank = engine.EchoBank(n_ch, taps, mode)
+    finally:
+        engine.lib().spangpu_tune_echo_lanes_per_channel(0)
     dets = [orc.EchoCan(taps, mode) for _ in range(n_ch)]
     events = {"rot": 0, "dtd": 0, "nb": 0}
     for fi, (pos, m) in enumerate(frames_of(n, sizes)):
