@@ -431,31 +431,34 @@ SPANGPU_API int spangpu_mct_get(spangpu_mct_t *mct, int channel);
 SPANGPU_API int spangpu_mct_state_words(const spangpu_mct_t *mct);
 SPANGPU_API int spangpu_mct_get_state(spangpu_mct_t *mct, int channel, int32_t *words);
 
-/* ---- V.29 transmitter banks ------------------------------
- * N V.29 modulators as a device-side signal source for the receiver banks: training (optionally with the
- * talker echo protection tone), then scrambled data.  Bit-exact with the reference's float build on x86-64.
- *   spangpu_v29tx_create()    v29_tx_init(NULL, bit_rate, tep, get_bit, user)    src/v29tx.c:406-434
- *   spangpu_v29tx_tx()        v29_tx(s, amp, len) x N                          src/v29tx.c:226-284
- *   spangpu_v29tx_power()     v29_tx_power()                                   src/v29tx.c:322-338
- *   spangpu_v29tx_restart()   v29_tx_restart()                                 src/v29tx.c:365-404
+/* ---- modem transmitter banks ---------------------------
+ * N V.29 or V.27ter modulators as device-side signal sources for the receiver banks: training (optionally with
+ * the talker echo protection tone), then scrambled data.  Bit-exact with the reference's float build on x86-64.
+ *   spangpu_modemtx_create(SPANGPU_V29)      v29_tx_init(NULL, bit_rate, tep, get_bit, user)      src/v29tx.c:406-434
+ *   spangpu_modemtx_create(SPANGPU_V27TER)   v27ter_tx_init(NULL, bit_rate, tep, get_bit, user)   src/v27ter_tx.c:411-437
+ *   spangpu_modemtx_tx()                     v29_tx() / v27ter_tx() x N        src/v29tx.c:226-284, src/v27ter_tx.c:246-350
+ *   spangpu_modemtx_power()                  v29_tx_power() / v27ter_tx_power()     src/v29tx.c:322-338, src/v27ter_tx.c:352-364
+ *   spangpu_modemtx_restart()                v29_tx_restart() / v27ter_tx_restart() src/v29tx.c:365-404, src/v27ter_tx.c:384-409
  * The data bits of channel c come from a 15 bit LFSR (x^15 + x^14 + 1) seeded with seeds[c] (NULL: a seed per
  * channel is derived from its index); a get_bit() callback, and with it the end-of-data shutdown sequence, is
  * not replayed.
  */
-typedef struct spangpu_v29tx_s spangpu_v29tx_t;
+typedef struct spangpu_modemtx_s spangpu_modemtx_t;
 
-SPANGPU_API int spangpu_v29tx_create(spangpu_v29tx_t **tx, int device, int n_channels, int bit_rate, int tep, const uint32_t *seeds);
-SPANGPU_API void spangpu_v29tx_destroy(spangpu_v29tx_t *tx);
-SPANGPU_API int spangpu_v29tx_channels(const spangpu_v29tx_t *tx);
-SPANGPU_API int spangpu_v29tx_set_stream(spangpu_v29tx_t *tx, void *hip_stream);
-SPANGPU_API int spangpu_v29tx_sync(spangpu_v29tx_t *tx);
-SPANGPU_API int spangpu_v29tx_power(spangpu_v29tx_t *tx, int channel, float power_dbm0);
-SPANGPU_API int spangpu_v29tx_restart(spangpu_v29tx_t *tx, int channel, int bit_rate, int tep);
+SPANGPU_API int spangpu_modemtx_create(spangpu_modemtx_t **tx, int device, int modem, int n_channels, int bit_rate, int tep,
+                                       const uint32_t *seeds);
+SPANGPU_API void spangpu_modemtx_destroy(spangpu_modemtx_t *tx);
+SPANGPU_API int spangpu_modemtx_channels(const spangpu_modemtx_t *tx);
+SPANGPU_API int spangpu_modemtx_set_stream(spangpu_modemtx_t *tx, void *hip_stream);
+SPANGPU_API int spangpu_modemtx_sync(spangpu_modemtx_t *tx);
+SPANGPU_API int spangpu_modemtx_power(spangpu_modemtx_t *tx, int channel, float power_dbm0);
+SPANGPU_API int spangpu_modemtx_restart(spangpu_modemtx_t *tx, int channel, int bit_rate, int tep);
 /* pcm[channel*stride + i], i < samples, where mem says; returns samples */
-SPANGPU_API int spangpu_v29tx_tx(spangpu_v29tx_t *tx, int mem, int16_t *pcm, long long stride, int samples);
-SPANGPU_API int spangpu_v29tx_state_words(void);
-SPANGPU_API int spangpu_v29tx_get_state(spangpu_v29tx_t *tx, int channel, int32_t *words);
-SPANGPU_API int spangpu_v29tx_table(float *out, int max);
+SPANGPU_API int spangpu_modemtx_tx(spangpu_modemtx_t *tx, int mem, int16_t *pcm, long long stride, int samples);
+SPANGPU_API int spangpu_modemtx_state_words(void);
+SPANGPU_API int spangpu_modemtx_get_state(spangpu_modemtx_t *tx, int channel, int32_t *words);
+/* The pulse shaper tables as built by this library (host code): which = 0 V.29, 1 V.27ter 4800 bps, 2 V.27ter 2400 bps */
+SPANGPU_API int spangpu_modemtx_table(int which, float *out, int max);
 
 #if defined(__cplusplus)
 }

@@ -607,6 +607,34 @@ ORC_API int orc_v29_tx_restart(orc_v29_tx_t *s, int bit_rate, int tep);
 ORC_API void orc_v29_tx_power(orc_v29_tx_t *s, float power);
 ORC_API int orc_v29_tx(orc_v29_tx_t *s, int16_t amp[], int len);
 
+/* ---- V.27ter transmitter (v27tertx_oracle.c); same word positions as the V.29 one ---- */
+typedef struct
+{
+    int32_t bit_rate;
+    float gain_2400;
+    float gain_4800;
+    float rrc_re[9];
+    float rrc_im[9];
+    int32_t rrc_step;
+    uint32_t scramble_reg;
+    int32_t scrambler_pattern_count;
+    int32_t in_training;
+    int32_t training_step;
+    int32_t unused;
+    uint32_t carrier_phase;
+    int32_t carrier_phase_rate;
+    int32_t baud_phase;
+    int32_t constellation_state;
+    uint32_t prbs;
+} orc_v27ter_tx_t;
+
+ORC_API int orc_v27ter_tx_sizeof(void);
+ORC_API void orc_v27ter_tx_set_tables(const float t4800[45], const float t2400[180]);
+ORC_API int orc_v27ter_tx_init(orc_v27ter_tx_t *s, int bit_rate, int tep, uint32_t prbs_seed);
+ORC_API int orc_v27ter_tx_restart(orc_v27ter_tx_t *s, int bit_rate, int tep);
+ORC_API void orc_v27ter_tx_power(orc_v27ter_tx_t *s, float power);
+ORC_API int orc_v27ter_tx(orc_v27ter_tx_t *s, int16_t amp[], int len);
+
 /* ---- modem connect tones (mct_oracle.c) ---- */
 #define ORC_MCT_FAX_CNG             1
 #define ORC_MCT_ANS                 2

@@ -76,6 +76,12 @@ def lib():
             "orc_fsk_set_frame_parameters": (None, [vp, ci, ci, ci]),
             "orc_fsk_rx": (ci, [vp, vp, ci, vp]),
             "orc_fsk_fillin": (ci, [vp, ci]),
+            "orc_v27ter_tx_sizeof": (ci, []),
+            "orc_v27ter_tx_set_tables": (None, [vp, vp]),
+            "orc_v27ter_tx_init": (ci, [vp, ci, ci, C.c_uint32]),
+            "orc_v27ter_tx_restart": (ci, [vp, ci, ci]),
+            "orc_v27ter_tx_power": (None, [vp, cf]),
+            "orc_v27ter_tx": (ci, [vp, vp, ci]),
             "orc_v29_tx_sizeof": (ci, []),
             "orc_v29_tx_set_table": (None, [vp]),
             "orc_v29_tx_init": (ci, [vp, ci, ci, C.c_uint32]),
@@ -613,3 +619,29 @@ class V29Tx:
 
     def snapshot(self):
         return self.buf.copy()
+
+
+def set_v27ter_tx_tables(t4800, t2400):
+    a = np.ascontiguousarray(t4800, np.float32)
+    b = np.ascontiguousarray(t2400, np.float32)
+    assert a.size == 45 and b.size == 180
+    lib().orc_v27ter_tx_set_tables(a.ctypes.data, b.ctypes.data)
+
+
+class V27terTx(V29Tx):
+    def __init__(self, bit_rate, tep=False, seed=1):
+        self.buf = np.zeros(self.WORDS, np.uint32)
+        self.p = self.buf.ctypes.data
+        assert lib().orc_v27ter_tx_sizeof() == 4*self.WORDS
+        assert lib().orc_v27ter_tx_init(self.p, bit_rate, int(tep), seed & 0x7FFF) == 0
+
+    def power(self, level_dbm0):
+        lib().orc_v27ter_tx_power(self.p, level_dbm0)
+
+    def restart(self, bit_rate, tep):
+        return lib().orc_v27ter_tx_restart(self.p, bit_rate, int(tep))
+
+    def tx(self, n):
+        out = np.zeros(max(n, 1), np.int16)
+        got = lib().orc_v27ter_tx(self.p, out.ctypes.data, n)
+        return out[:got].copy()

@@ -1,5 +1,5 @@
-// v29tx_api.hip -- C ABI of the V.29 transmitter banks (include/spangpu.h, "V.29 transmitter banks"): batched
-// v29_tx() as a device-side signal source.  Device code: v29tx_dev.hpp.  No CPU implementation exists behind
+// modemtx_api.hip -- C ABI of the modem transmitter banks (include/spangpu.h, "modem transmitter banks"): batched
+// v29_tx() / v27ter_tx() as device-side signal sources.  Device code: modemtx_dev.hpp.  No CPU implementation exists behind
 // these entry points.
 
 #include <hip/hip_runtime.h>
@@ -10,7 +10,7 @@
 
 #include "../../include/spangpu.h"
 #include "modem_tables.h"
-#include "v29tx_dev.hpp"
+#include "modemtx_dev.hpp"
 
 using namespace spg;
 
@@ -29,9 +29,10 @@ extern "C" int spangpu_set_error(int code, const char *msg);
     }                                                                                       \
     while (0)
 
-struct spangpu_v29tx_s
+struct spangpu_modemtx_s
 {
     int device;
+    int kind;               // kTxV29 or kTxV27ter
     int n_ch;
     hipStream_t stream;
     bool own_stream;
@@ -54,8 +55,10 @@ static float get_f(const int32_t *w, int idx)
     return v;
 }
 
-static void gain_words(int32_t *w)
+static void gain_words(int32_t *w, int kind)
 {
+    if (kind != kTxV29)
+        return;             // V.27ter keeps one gain per rate, both set by v27ter_tx_power()
     // set_working_gain(), v29tx.c:286-320
     const float base = get_f(w, VT_BASE_GAIN);
     switch (w[VT_BIT_RATE])
@@ -66,18 +69,46 @@ static void gain_words(int32_t *w)
     }
 }
 
-static void power_words(int32_t *w, float power)
+static void power_words(int32_t *w, int kind, float power)
 {
-    // v29_tx_power(), v29tx.c:322-338; TX_PULSESHAPER_GAIN = 1.0f in the float build
-    put_f(w, VT_BASE_GAIN, spg_db_to_amplitude_ratio(power - 3.14f)*32768.0f/1.000000f);
-    gain_words(w);
+    if (kind == kTxV29)
+    {
+        // v29_tx_power(), v29tx.c:322-338; TX_PULSESHAPER_GAIN = 1.0f in the float build
+        put_f(w, VT_BASE_GAIN, spg_db_to_amplitude_ratio(power - 3.14f)*32768.0f/1.000000f);
+        gain_words(w, kind);
+        return;
+    }
+    // v27ter_tx_power(), v27ter_tx.c:352-364: gain_2400 (word 1) and gain_4800 (word 2), both shaper gains 1.0f
+    const float gain = spg_db_to_amplitude_ratio(power - 3.14f)*32768.0f;
+    put_f(w, VT_BASE_GAIN, gain/1.000000f);
+    put_f(w, VT_GAIN, gain/1.000000f);
 }
 
-static int restart_words(int32_t *w, int bit_rate, int tep)
+static int restart_words(int32_t *w, int kind, int bit_rate, int tep)
 {
+    if (kind == kTxV27ter)
+    {
+        // v27ter_tx_restart(), v27ter_tx.c:384-409
+        if (bit_rate != 4800  &&  bit_rate != 2400)
+            return -1;
+        w[VT_BIT_RATE] = bit_rate;
+        for (int i = 0;  i < 18;  i++)
+            w[VT_RRC_RE + i] = 0;
+        w[VT_RRC_STEP] = 0;
+        w[VT_SCRAMBLE] = 0x3C;
+        w[VT_TRAIN_SCRAMBLE] = 0;               // scrambler_pattern_count
+        w[VT_IN_TRAINING] = 1;
+        w[VT_TRAINING_STEP] = tep  ?  0  :  kV27Seg2;
+        w[VT_CARRIER_PHASE] = 0;
+        w[VT_BAUD_PHASE] = 0;
+        w[VT_CONSTELLATION] = 0;
+        return 0;
+    }
     // v29_tx_restart(), v29tx.c:365-404
+    if (bit_rate != 9600  &&  bit_rate != 7200  &&  bit_rate != 4800)
+        return -1;
     w[VT_BIT_RATE] = bit_rate;
-    gain_words(w);
+    gain_words(w, kind);
     switch (bit_rate)
     {
     case 9600: w[VT_TRAINING_OFFSET] = 0; break;
@@ -98,7 +129,7 @@ static int restart_words(int32_t *w, int bit_rate, int tep)
     return 0;
 }
 
-static int rw_words(spangpu_v29tx_s *t, int ch, int32_t *w, bool write)
+static int rw_words(spangpu_modemtx_s *t, int ch, int32_t *w, bool write)
 {
     VT_TRY(hipSetDevice(t->device));
     if (write)
@@ -113,10 +144,15 @@ static int rw_words(spangpu_v29tx_s *t, int ch, int32_t *w, bool write)
 
 extern "C" {
 
-int spangpu_v29tx_create(spangpu_v29tx_t **out, int device, int n_channels, int bit_rate, int tep, const uint32_t *seeds)
+int spangpu_modemtx_create(spangpu_modemtx_t **out, int device, int modem, int n_channels, int bit_rate, int tep, const uint32_t *seeds)
 {
-    if (out == NULL  ||  n_channels <= 0  ||  (bit_rate != 9600  &&  bit_rate != 7200  &&  bit_rate != 4800))
-        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments (bit rate 9600, 7200 or 4800)");
+    if (out == NULL  ||  n_channels <= 0  ||  (modem != SPANGPU_V29  &&  modem != SPANGPU_V27TER))
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments (modem SPANGPU_V29 or SPANGPU_V27TER)");
+    const int kind = (modem == SPANGPU_V29)  ?  kTxV29  :  kTxV27ter;
+    int32_t probe[kV29TxWords];
+    memset(probe, 0, sizeof(probe));
+    if (restart_words(probe, kind, bit_rate, tep) != 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bit rate not valid for this modem (V.29: 9600/7200/4800, V.27ter: 4800/2400)");
     *out = NULL;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess  ||  count <= 0)
@@ -124,10 +160,11 @@ int spangpu_v29tx_create(spangpu_v29tx_t **out, int device, int n_channels, int 
     if (device < 0  ||  device >= count)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "device out of range");
     VT_TRY(hipSetDevice(device));
-    spangpu_v29tx_s *t = (spangpu_v29tx_s *) calloc(1, sizeof(*t));
+    spangpu_modemtx_s *t = (spangpu_modemtx_s *) calloc(1, sizeof(*t));
     if (t == NULL)
         return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "calloc");
     t->device = device;
+    t->kind = kind;
     t->n_ch = n_channels;
     if (hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking) != hipSuccess)
     {
@@ -138,31 +175,34 @@ int spangpu_v29tx_create(spangpu_v29tx_t **out, int device, int n_channels, int 
     const size_t words = (size_t) kV29TxWords*n_channels;
     if (hipMalloc(&t->st, words*sizeof(int32_t)) != hipSuccess
         ||  hipMalloc(&t->sine, 2048*sizeof(float)) != hipSuccess
-        ||  hipMalloc(&t->shaper, 90*sizeof(float)) != hipSuccess)
+        ||  hipMalloc(&t->shaper, 225*sizeof(float)) != hipSuccess)
     {
-        spangpu_v29tx_destroy(t);
+        spangpu_modemtx_destroy(t);
         return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "allocation of the V.29 transmitter bank failed");
     }
     float sine[2048];
-    float shaper[90];
+    float shaper[225];
+    memset(shaper, 0, sizeof(shaper));
     spg_make_sine_table(sine);
-    // make_modem_filter -m V.29 -t: 10 phases x 9 taps, excess bandwidth 0.25 (make_modem_filter.c:401-412)
-    if (spg_make_tx_pulseshaper(10, 9, 0.25, shaper) != 0)
+    // make_modem_filter -t: V.29 10 phases x 9 taps, excess bandwidth 0.25; V.27ter 4800 bps 5 x 9 and 2400 bps
+    // 20 x 9, excess bandwidth 0.5 (make_modem_filter.c:375-412)
+    if (((kind == kTxV29)  ?  spg_make_tx_pulseshaper(10, 9, 0.25, shaper)
+                           :  (spg_make_tx_pulseshaper(5, 9, 0.5, shaper) | spg_make_tx_pulseshaper(20, 9, 0.5, shaper + 45))) != 0)
     {
-        spangpu_v29tx_destroy(t);
+        spangpu_modemtx_destroy(t);
         return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "table scratch");
     }
-    // v29_tx_init(), v29tx.c:406-434
+    // v29_tx_init(), v29tx.c:406-434 / v27ter_tx_init(), v27ter_tx.c:411-437
     int32_t one[kV29TxWords];
     memset(one, 0, sizeof(one));
     one[VT_BIT_RATE] = bit_rate;
-    one[VT_CARRIER_RATE] = spg_dds_phase_ratef(1700.0f);
-    power_words(one, -14.0f);
-    restart_words(one, bit_rate, tep);
+    one[VT_CARRIER_RATE] = spg_dds_phase_ratef((kind == kTxV29)  ?  1700.0f  :  1800.0f);
+    power_words(one, kind, -14.0f);
+    restart_words(one, kind, bit_rate, tep);
     int32_t *host = (int32_t *) malloc(words*sizeof(int32_t));
     if (host == NULL)
     {
-        spangpu_v29tx_destroy(t);
+        spangpu_modemtx_destroy(t);
         return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "malloc");
     }
     for (int k = 0;  k < kV29TxWords;  k++)
@@ -180,14 +220,14 @@ int spangpu_v29tx_create(spangpu_v29tx_t **out, int device, int n_channels, int 
         e = hipMemcpy(t->shaper, shaper, sizeof(shaper), hipMemcpyHostToDevice);
     if (e != hipSuccess)
     {
-        spangpu_v29tx_destroy(t);
+        spangpu_modemtx_destroy(t);
         return spangpu_set_error(SPANGPU_ERR_HIP, "state upload failed");
     }
     *out = t;
     return SPANGPU_OK;
 }
 
-void spangpu_v29tx_destroy(spangpu_v29tx_t *t)
+void spangpu_modemtx_destroy(spangpu_modemtx_t *t)
 {
     if (t == NULL)
         return;
@@ -203,10 +243,10 @@ void spangpu_v29tx_destroy(spangpu_v29tx_t *t)
     free(t);
 }
 
-int spangpu_v29tx_channels(const spangpu_v29tx_t *t) { return t  ?  t->n_ch  :  SPANGPU_ERR_BAD_ARG; }
-int spangpu_v29tx_state_words(void) { return kV29TxWords; }
+int spangpu_modemtx_channels(const spangpu_modemtx_t *t) { return t  ?  t->n_ch  :  SPANGPU_ERR_BAD_ARG; }
+int spangpu_modemtx_state_words(void) { return kV29TxWords; }
 
-int spangpu_v29tx_set_stream(spangpu_v29tx_t *t, void *stream)
+int spangpu_modemtx_set_stream(spangpu_modemtx_t *t, void *stream)
 {
     if (t == NULL)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null bank");
@@ -219,7 +259,7 @@ int spangpu_v29tx_set_stream(spangpu_v29tx_t *t, void *stream)
     return SPANGPU_OK;
 }
 
-int spangpu_v29tx_sync(spangpu_v29tx_t *t)
+int spangpu_modemtx_sync(spangpu_modemtx_t *t)
 {
     if (t == NULL)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null bank");
@@ -228,7 +268,7 @@ int spangpu_v29tx_sync(spangpu_v29tx_t *t)
     return SPANGPU_OK;
 }
 
-int spangpu_v29tx_power(spangpu_v29tx_t *t, int channel, float power_dbm0)
+int spangpu_modemtx_power(spangpu_modemtx_t *t, int channel, float power_dbm0)
 {
     if (t == NULL  ||  channel < 0  ||  channel >= t->n_ch)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
@@ -236,11 +276,11 @@ int spangpu_v29tx_power(spangpu_v29tx_t *t, int channel, float power_dbm0)
     int rc = rw_words(t, channel, w, false);
     if (rc != SPANGPU_OK)
         return rc;
-    power_words(w, power_dbm0);
+    power_words(w, t->kind, power_dbm0);
     return rw_words(t, channel, w, true);
 }
 
-int spangpu_v29tx_restart(spangpu_v29tx_t *t, int channel, int bit_rate, int tep)
+int spangpu_modemtx_restart(spangpu_modemtx_t *t, int channel, int bit_rate, int tep)
 {
     if (t == NULL  ||  channel < 0  ||  channel >= t->n_ch)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
@@ -248,19 +288,19 @@ int spangpu_v29tx_restart(spangpu_v29tx_t *t, int channel, int bit_rate, int tep
     int rc = rw_words(t, channel, w, false);
     if (rc != SPANGPU_OK)
         return rc;
-    if (restart_words(w, bit_rate, tep) != 0)
-        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bit rate 9600, 7200 or 4800");
+    if (restart_words(w, t->kind, bit_rate, tep) != 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bit rate not valid for this modem");
     return rw_words(t, channel, w, true);
 }
 
-int spangpu_v29tx_get_state(spangpu_v29tx_t *t, int channel, int32_t *words)
+int spangpu_modemtx_get_state(spangpu_modemtx_t *t, int channel, int32_t *words)
 {
     if (t == NULL  ||  words == NULL  ||  channel < 0  ||  channel >= t->n_ch)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
     return rw_words(t, channel, words, false);
 }
 
-int spangpu_v29tx_tx(spangpu_v29tx_t *t, int mem_kind, int16_t *pcm, long long stride, int samples)
+int spangpu_modemtx_tx(spangpu_modemtx_t *t, int mem_kind, int16_t *pcm, long long stride, int samples)
 {
     if (t == NULL  ||  pcm == NULL  ||  samples < 0  ||  stride < samples)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
@@ -298,7 +338,10 @@ int spangpu_v29tx_tx(spangpu_v29tx_t *t, int mem_kind, int16_t *pcm, long long s
         L.stride = stride;
     }
     L.vec = ((L.stride & 7) == 0  &&  (reinterpret_cast<uintptr_t>(L.pcm) & 15) == 0)  ?  1  :  0;
-    hipLaunchKernelGGL(v29tx_bank_kernel, dim3((t->n_ch + 63)/64), dim3(64), 0, t->stream, L);
+    if (t->kind == kTxV29)
+        hipLaunchKernelGGL(modemtx_bank_kernel<kTxV29>, dim3((t->n_ch + 63)/64), dim3(64), 0, t->stream, L);
+    else
+        hipLaunchKernelGGL(modemtx_bank_kernel<kTxV27ter>, dim3((t->n_ch + 63)/64), dim3(64), 0, t->stream, L);
     VT_TRY(hipGetLastError());
     if (mem_kind == SPANGPU_MEM_HOST)
     {
@@ -309,12 +352,17 @@ int spangpu_v29tx_tx(spangpu_v29tx_t *t, int mem_kind, int16_t *pcm, long long s
     return samples;
 }
 
-// The pulse shaper table this library builds (for tests): [10][9]
-int spangpu_v29tx_table(float *out, int max)
+// The pulse shaper tables this library builds (for tests).  which: 0 V.29 [10][9], 1 V.27ter 4800 bps [5][9],
+// 2 V.27ter 2400 bps [20][9].  Returns the number of floats.
+int spangpu_modemtx_table(int which, float *out, int max)
 {
-    if (out == NULL  ||  max < 90)
-        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "need room for 90 floats");
-    return (spg_make_tx_pulseshaper(10, 9, 0.25, out) == 0)  ?  90  :  spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "table scratch");
+    static const int sets[3] = {10, 5, 20};
+    static const double excess[3] = {0.25, 0.5, 0.5};
+    if (out == NULL  ||  which < 0  ||  which > 2  ||  max < sets[which]*9)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad table request");
+    if (spg_make_tx_pulseshaper(sets[which], 9, excess[which], out) != 0)
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "table scratch");
+    return sets[which]*9;
 }
 
 }   // extern "C"

@@ -74,17 +74,17 @@ def lib():
             "spangpu_bank_rx_g711": (ci, [vp, vp, ci, ci, ci, ll]),
             "spangpu_bank_set_records_buffer": (ci, [vp, vp, C.c_size_t]),
             "spangpu_bank_get_stream": (vp, [vp]),
-            "spangpu_v29tx_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, vp]),
-            "spangpu_v29tx_destroy": (None, [vp]),
-            "spangpu_v29tx_channels": (ci, [vp]),
-            "spangpu_v29tx_set_stream": (ci, [vp, vp]),
-            "spangpu_v29tx_sync": (ci, [vp]),
-            "spangpu_v29tx_power": (ci, [vp, ci, cf]),
-            "spangpu_v29tx_restart": (ci, [vp, ci, ci, ci]),
-            "spangpu_v29tx_tx": (ci, [vp, ci, vp, ll, ci]),
-            "spangpu_v29tx_state_words": (ci, []),
-            "spangpu_v29tx_get_state": (ci, [vp, ci, vp]),
-            "spangpu_v29tx_table": (ci, [vp, ci]),
+            "spangpu_modemtx_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, vp]),
+            "spangpu_modemtx_destroy": (None, [vp]),
+            "spangpu_modemtx_channels": (ci, [vp]),
+            "spangpu_modemtx_set_stream": (ci, [vp, vp]),
+            "spangpu_modemtx_sync": (ci, [vp]),
+            "spangpu_modemtx_power": (ci, [vp, ci, cf]),
+            "spangpu_modemtx_restart": (ci, [vp, ci, ci, ci]),
+            "spangpu_modemtx_tx": (ci, [vp, ci, vp, ll, ci]),
+            "spangpu_modemtx_state_words": (ci, []),
+            "spangpu_modemtx_get_state": (ci, [vp, ci, vp]),
+            "spangpu_modemtx_table": (ci, [ci, vp, ci]),
             "spangpu_mct_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
             "spangpu_mct_destroy": (None, [vp]),
             "spangpu_mct_channels": (ci, [vp]),
@@ -697,17 +697,22 @@ class MctBank:
         return w
 
 
-# ---- V.29 transmitter banks (include/spangpu.h "V.29 transmitter banks") -----------------
+# ---- modem transmitter banks (include/spangpu.h "modem transmitter banks") -----------------
+def modem_tx_table(which):
+    """which: 0 V.29 [10, 9], 1 V.27ter 4800 bps [5, 9], 2 V.27ter 2400 bps [20, 9] -- flat float32."""
+    out = np.zeros(180, np.float32)
+    n = _check(lib().spangpu_modemtx_table(which, out.ctypes.data, 180))
+    return out[:n].copy()
+
+
 def v29_tx_table():
-    out = np.zeros(90, np.float32)
-    _check(lib().spangpu_v29tx_table(out.ctypes.data, 90))
-    return out
+    return modem_tx_table(0)
 
 
-class V29TxBank:
-    """N V.29 modulators (v29_tx), state in HBM; data bits from a per-channel LFSR."""
+class ModemTxBank:
+    """N V.29 / V.27ter modulators (v29_tx, v27ter_tx), state in HBM; data bits from a per-channel LFSR."""
 
-    def __init__(self, n_channels, bit_rate=9600, tep=False, seeds=None, device=0):
+    def __init__(self, modem, n_channels, bit_rate, tep=False, seeds=None, device=0):
         self.n = n_channels
         self.h = C.c_void_p()
         sp = None
@@ -715,11 +720,11 @@ class V29TxBank:
             seeds = np.ascontiguousarray(seeds, np.uint32)
             assert len(seeds) == n_channels
             sp = seeds.ctypes.data
-        _check(lib().spangpu_v29tx_create(C.byref(self.h), device, n_channels, bit_rate, int(tep), sp))
+        _check(lib().spangpu_modemtx_create(C.byref(self.h), device, modem, n_channels, bit_rate, int(tep), sp))
 
     def close(self):
         if self.h:
-            lib().spangpu_v29tx_destroy(self.h)
+            lib().spangpu_modemtx_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
@@ -729,26 +734,36 @@ class V29TxBank:
             pass
 
     def set_stream(self, hip_stream):
-        _check(lib().spangpu_v29tx_set_stream(self.h, hip_stream))
+        _check(lib().spangpu_modemtx_set_stream(self.h, hip_stream))
 
     def sync(self):
-        _check(lib().spangpu_v29tx_sync(self.h))
+        _check(lib().spangpu_modemtx_sync(self.h))
 
     def power(self, channel, level_dbm0):
-        _check(lib().spangpu_v29tx_power(self.h, channel, level_dbm0))
+        _check(lib().spangpu_modemtx_power(self.h, channel, level_dbm0))
 
     def restart(self, channel, bit_rate, tep):
-        _check(lib().spangpu_v29tx_restart(self.h, channel, bit_rate, int(tep)))
+        _check(lib().spangpu_modemtx_restart(self.h, channel, bit_rate, int(tep)))
 
     def tx_host(self, samples):
         pcm = np.zeros((self.n, samples), np.int16)
-        _check(lib().spangpu_v29tx_tx(self.h, MEM_HOST, pcm.ctypes.data, samples, samples))
+        _check(lib().spangpu_modemtx_tx(self.h, MEM_HOST, pcm.ctypes.data, samples, samples))
         return pcm
 
     def tx_device(self, pcm_ptr, stride, samples):
-        _check(lib().spangpu_v29tx_tx(self.h, MEM_DEVICE, pcm_ptr, stride, samples))
+        _check(lib().spangpu_modemtx_tx(self.h, MEM_DEVICE, pcm_ptr, stride, samples))
 
     def get_state(self, channel):
-        w = np.zeros(lib().spangpu_v29tx_state_words(), np.uint32)
-        _check(lib().spangpu_v29tx_get_state(self.h, channel, w.ctypes.data))
+        w = np.zeros(lib().spangpu_modemtx_state_words(), np.uint32)
+        _check(lib().spangpu_modemtx_get_state(self.h, channel, w.ctypes.data))
         return w
+
+
+class V29TxBank(ModemTxBank):
+    def __init__(self, n_channels, bit_rate=9600, tep=False, seeds=None, device=0):
+        super().__init__(V29, n_channels, bit_rate, tep, seeds, device)
+
+
+class V27terTxBank(ModemTxBank):
+    def __init__(self, n_channels, bit_rate=4800, tep=False, seeds=None, device=0):
+        super().__init__(V27TER, n_channels, bit_rate, tep, seeds, device)

@@ -1,8 +1,8 @@
-"""V.29 transmitter banks against the oracle: v29_tx.
+"""Modem transmitter banks against the oracle: v29_tx and v27ter_tx.
 
 Bar: bit-exact int16 samples and state words (float words as bits).  The oracle (oracle/v29tx_oracle.c) is pinned to
-the real reference in test_oracle_pin.py; its pulse shaper table is this library's own builder's, which
-test_modem_tables.py pins to the reference's generated table.
+the real reference in test_oracle_pin.py; the pulse shaper tables are this library's own builder's, which
+test_oracle_pin.py pins to the reference's generated tables.
 """
 import ctypes
 
@@ -20,23 +20,33 @@ def setup_oracle():
     from oracle import restated as orc
     from spandsp_amd import engine
     use_golden_modem_tables()
-    orc.set_v29_tx_table(engine.v29_tx_table())
+    orc.set_v29_tx_table(engine.modem_tx_table(0))
+    orc.set_v27ter_tx_tables(engine.modem_tx_table(1), engine.modem_tx_table(2))
     return orc, engine
 
 
-@pytest.mark.parametrize("bit_rate,tep", [(9600, False), (7200, True), (4800, False), (9600, True)])
-def test_v29_tx_bank(built, bit_rate, tep):
+@pytest.mark.parametrize("modem,bit_rate,tep", [("v29", 9600, False), ("v29", 7200, True), ("v29", 4800, False), ("v29", 9600, True),
+                                                ("v27ter", 4800, False), ("v27ter", 2400, True), ("v27ter", 2400, False)])
+def test_modem_tx_bank(built, modem, bit_rate, tep):
     orc, engine = setup_oracle()
     n = 150
     seeds = (np.arange(n)*7919 + 13) & 0x7FFF
     seeds[5] = 0                                     # an all-zero register sends a constant bit: still the reference's behaviour
-    bank = engine.V29TxBank(n, bit_rate, tep, seeds)
-    tx = [orc.V29Tx(bit_rate, tep, int(s)) for s in seeds]
+    if modem == "v29":
+        bank = engine.V29TxBank(n, bit_rate, tep, seeds)
+        tx = [orc.V29Tx(bit_rate, tep, int(s)) for s in seeds]
+        other = 7200 if bit_rate != 7200 else 9600
+        train = (480 if tep else 0) + 48 + 128 + 384 + 48
+    else:
+        bank = engine.V27terTxBank(n, bit_rate, tep, seeds)
+        tx = [orc.V27terTx(bit_rate, tep, int(s)) for s in seeds]
+        other = 2400 if bit_rate == 4800 else 4800
+        train = ((320 if tep else 0) + 32 + 50 + 1074 + 8)*(5 if bit_rate == 4800 else 7)
     for c in range(0, n, 9):
         bank.power(c, -20.0 + (c % 13))
         tx[c].power(-20.0 + (c % 13))
     total = 0
-    for k, m in enumerate(FRAMES*3):
+    for k, m in enumerate(FRAMES*(3 if modem == "v29" else 6)):
         pcm = bank.tx_host(m)
         for c in range(n):
             want = tx[c].tx(m)
@@ -44,13 +54,12 @@ def test_v29_tx_bank(built, bit_rate, tep):
         total += m
         if k == 12:
             for c in range(3, n, 17):
-                nr = 7200 if bit_rate != 7200 else 9600
-                bank.restart(c, nr, not tep)
-                tx[c].restart(nr, not tep)
+                bank.restart(c, other, not tep)
+                tx[c].restart(other, not tep)
         if k % 5 == 4:
             for c in range(0, n, 11):
                 assert np.array_equal(bank.get_state(c), tx[c].snapshot()), (k, c)
-    assert total > (480 if tep else 0) + 48 + 128 + 384 + 48 + 1000       # well into the data
+    assert total > train + 1000                                              # well into the data
     assert bank.get_state(0)[24] == 0                                        # in_training is off
 
 
@@ -89,6 +98,43 @@ def test_v29_tx_feeds_v29_rx_on_device(built):
         want = np.array(want)
         assert len(data) > 1000
         # the receiver starts delivering somewhere in the stream: find the alignment once, then demand equality
+        hit = [k for k in range(200) if np.array_equal(want[k:k + 64], data[:64])]
+        assert hit, c
+        assert np.array_equal(want[hit[0]:hit[0] + len(data)], data), c
+
+
+def test_v27ter_tx_feeds_v27ter_rx_on_device(built):
+    """The same loop for V.27ter at 4800 bps: v27ter_tx bank -> HBM -> v27ter_rx bank."""
+    orc, engine = setup_oracle()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    n, samples, frames = 256, 160, 70
+    seeds = ((np.arange(n)*2654435761 + 777) & 0x7FFF) | 1
+    tx = engine.V27terTxBank(n, 4800, False, seeds)
+    rx = engine.V27terBank(n, 4800)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), n*samples*2) == 0
+    bits = [[] for _ in range(n)]
+    for _ in range(frames):
+        tx.tx_device(buf, samples, samples)
+        tx.sync()
+        rx.rx_device(buf, samples, samples)
+        for c, e in enumerate(rx.events()):
+            bits[c].extend(int(v) for v in e)
+    hip.hipFree(buf)
+    for c in range(n):
+        ev = bits[c]
+        assert -4 in ev, c
+        data = np.array([b for b in ev[ev.index(-4) + 1:] if b >= 0])
+        st = int(seeds[c])
+        want = []
+        for _ in range(len(data) + 200):
+            b = ((st >> 14) ^ (st >> 13)) & 1
+            st = ((st << 1) | b) & 0x7FFF
+            want.append(b)
+        want = np.array(want)
+        assert len(data) > 500
         hit = [k for k in range(200) if np.array_equal(want[k:k + 64], data[:64])]
         assert hit, c
         assert np.array_equal(want[hit[0]:hit[0] + len(data)], data), c

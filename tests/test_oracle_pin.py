@@ -577,7 +577,7 @@ V29TX_CASES = [(9600, False, 0x1234), (9600, True, 0x0001), (7200, False, 0x7FFF
                (4800, True, 0x5555)]
 
 
-def v29tx_run(tx, seed):
+def v29tx_run(tx, seed, other_rate=None):
     """One session of a transmitter object: odd call sizes, a power change, a restart at another rate."""
     rng = np.random.default_rng(seed)
     out = []
@@ -589,7 +589,7 @@ def v29tx_run(tx, seed):
         if k == 60:
             tx.power(-9.5)
         if k == 110:
-            tx.restart(7200 if int(snaps[0][0]) != 7200 else 9600, True)
+            tx.restart(other_rate if other_rate else (7200 if int(snaps[0][0]) != 7200 else 9600), True)
     return np.concatenate(out), np.stack(snaps)
 
 
@@ -598,11 +598,16 @@ def use_v29_tx_table(built):
     reference's generated table, a copy of which is committed in tests/golden/v29tx.npz."""
     from oracle import restated as orc
     from spandsp_amd import engine
-    t = engine.v29_tx_table()
+    t = engine.modem_tx_table(0)
     g = np.load(os.path.join(GOLDEN, "v29tx.npz"))
     assert np.array_equal(t.view(np.uint32), g["table"].view(np.uint32))
+    g27 = np.load(os.path.join(GOLDEN, "v27tertx.npz"))
+    t48, t24 = engine.modem_tx_table(1), engine.modem_tx_table(2)
+    assert np.array_equal(t48.view(np.uint32), g27["table_4800"].view(np.uint32))
+    assert np.array_equal(t24.view(np.uint32), g27["table_2400"].view(np.uint32))
     use_golden_modem_tables()
     orc.set_v29_tx_table(t)
+    orc.set_v27ter_tx_tables(t48, t24)
 
 
 @needs_ref
@@ -616,6 +621,36 @@ def test_v29_tx_live(built, bit_rate, tep, seed):
     assert len(a_amp) > 20000
     assert np.array_equal(a_amp, b_amp)
     assert np.array_equal(a_snaps, b_snaps)
+
+
+V27TX_CASES = [(4800, False, 0x1234), (4800, True, 0x0001), (2400, False, 0x7FFF), (2400, True, 0x2B2B)]
+
+
+@needs_ref
+@pytest.mark.parametrize("bit_rate,tep,seed", V27TX_CASES)
+def test_v27ter_tx_live(built, bit_rate, tep, seed):
+    from oracle import ref, restated as orc
+    use_v29_tx_table(built)
+    g = np.load(os.path.join(GOLDEN, "v27tertx.npz"))
+    a, b = ref.v27ter_tx_tables()
+    assert np.array_equal(a.view(np.uint32), g["table_4800"].view(np.uint32))
+    assert np.array_equal(b.view(np.uint32), g["table_2400"].view(np.uint32))
+    other = 2400 if bit_rate == 4800 else 4800
+    a_amp, a_snaps = v29tx_run(ref.V27terTx(bit_rate, tep, seed), seed, other)
+    b_amp, b_snaps = v29tx_run(orc.V27terTx(bit_rate, tep, seed), seed, other)
+    assert len(a_amp) > 20000
+    assert np.array_equal(a_amp, b_amp)
+    assert np.array_equal(a_snaps, b_snaps)
+
+
+def test_golden_v27ter_tx(built):
+    from oracle import restated as orc
+    use_v29_tx_table(built)
+    g = np.load(os.path.join(GOLDEN, "v27tertx.npz"))
+    for i, (bit_rate, tep, seed) in enumerate(V27TX_CASES):
+        amp, snaps = v29tx_run(orc.V27terTx(bit_rate, tep, seed), seed, 2400 if bit_rate == 4800 else 4800)
+        assert np.array_equal(amp, g["amp_%d" % i]), i
+        assert np.array_equal(snaps, g["snaps_%d" % i]), i
 
 
 def test_golden_v29_tx(built):

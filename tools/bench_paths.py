@@ -49,13 +49,14 @@ def synth_v29(n_ch, n_frames, dev, seed, fixture="v29_9600.npz"):
     return out
 
 
-def synth_v29_on_device(n_ch, n_frames, dev, stream, seed):
-    """V.29 9600 bps input made where it is consumed: a V29TxBank (the reference's modulator, bit-exact, on the
-    device) writes every channel's own transmission (its own data bits and level) frame by frame into HBM; AWGN is
-    added with torch.  Returns int16 [n_frames, n_ch, FRAME]."""
+def synth_v29_on_device(n_ch, n_frames, dev, stream, seed, modem="v29"):
+    """V.29 9600 bps / V.27ter 4800 bps input made where it is consumed: a transmitter bank (the reference's
+    modulator, bit-exact, on the device) writes every channel's own transmission (its own data bits and level) frame
+    by frame into HBM; AWGN is added with torch.  Returns int16 [n_frames, n_ch, FRAME]."""
     from spandsp_amd import engine
     rng = np.random.default_rng(seed)
-    tx = engine.V29TxBank(n_ch, 9600, False, rng.integers(1, 0x7FFF, n_ch).astype(np.uint32))
+    seeds = rng.integers(1, 0x7FFF, n_ch).astype(np.uint32)
+    tx = engine.V29TxBank(n_ch, 9600, False, seeds) if modem == "v29" else engine.V27terTxBank(n_ch, 4800, False, seeds)
     tx.set_stream(ctypes.c_void_p(stream.cuda_stream))
     for c in range(0, n_ch, 4):                             # a spread of levels (every 4th channel moved off -14 dBm0)
         tx.power(c, float(rng.uniform(-26.0, -10.0)))
@@ -65,7 +66,7 @@ def synth_v29_on_device(n_ch, n_frames, dev, stream, seed):
     tx.sync()
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
-    sigma = torch.empty(1, n_ch, 1, device=dev).uniform_(1.0, 30.0, generator=gen)
+    sigma = torch.empty(1, n_ch, 1, device=dev).uniform_(1.0, 30.0 if modem == "v29" else 12.0, generator=gen)
     for f0 in range(0, n_frames, 16):
         blk = out[f0:f0 + 16].float()
         blk = blk + sigma*torch.randn(blk.shape, device=dev, generator=gen)
@@ -105,7 +106,7 @@ def bench_v29_tx(args, dev, stream):
         "ms_per_step": dt*1e3/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic", "config": {"workload": "v29_tx bank, %d channels x %d-sample frames" % (n_ch, FRAME),
                                         "channels_per_gpu": n_ch, "rms_of_last_frames": rms},
-        "roofline": {"bound": "hbm", "kernel": "v29tx_bank_kernel", "achieved": alg/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS,
+        "roofline": {"bound": "hbm", "kernel": "modemtx_bank_kernel<V.29>", "achieved": alg/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": alg/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None, "alg_bytes_per_launch": alg,
                      "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3,
                      "note": "sample-serial modulator, one channel per lane: latency bound at one wave per SIMD"},
@@ -566,7 +567,7 @@ def main():
     ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     ap.add_argument("--replay-fixture", action="store_true",
-                    help="v29: replay the committed reference transmission instead of running the V.29 transmitter bank")
+                    help="v29 / v27ter: replay the committed reference transmission instead of running the transmitter bank")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a HIP device; the engine has no CPU fallback")
@@ -601,8 +602,8 @@ def main():
     kind = {"v29": engine.V29, "v17": engine.V17, "v27ter": engine.V27TER}[args.workload]
     n_ch = args.channels or 16384
     nf = args.steps + args.warmup
-    if args.workload == "v29" and not args.replay_fixture:
-        frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929)
+    if args.workload in ("v29", "v27ter") and not args.replay_fixture:
+        frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem=args.workload)
     else:
         frames = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture)
     bank = engine.ModemBank(kind, n_ch, bit_rate)
