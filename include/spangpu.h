@@ -432,13 +432,16 @@ SPANGPU_API int spangpu_mct_state_words(const spangpu_mct_t *mct);
 SPANGPU_API int spangpu_mct_get_state(spangpu_mct_t *mct, int channel, int32_t *words);
 
 /* ---- modem transmitter banks ---------------------------
- * N V.29 or V.27ter modulators as device-side signal sources for the receiver banks: training (optionally with
+ * N V.29, V.27ter or V.17 modulators as device-side signal sources for the receiver banks: training (optionally with
  * the talker echo protection tone), then scrambled data.  Bit-exact with the reference's float build on x86-64.
  *   spangpu_modemtx_create(SPANGPU_V29)      v29_tx_init(NULL, bit_rate, tep, get_bit, user)      src/v29tx.c:406-434
  *   spangpu_modemtx_create(SPANGPU_V27TER)   v27ter_tx_init(NULL, bit_rate, tep, get_bit, user)   src/v27ter_tx.c:411-437
- *   spangpu_modemtx_tx()                     v29_tx() / v27ter_tx() x N        src/v29tx.c:226-284, src/v27ter_tx.c:246-350
+ *   spangpu_modemtx_create(SPANGPU_V17)      v17_tx_init(NULL, bit_rate, tep, get_bit, user)      src/v17tx.c:452-483
+ *   spangpu_modemtx_tx()                     v29_tx() / v27ter_tx() / v17_tx() x N   src/v29tx.c:226-284, src/v27ter_tx.c:246-350,
+ *                                                                                     src/v17tx.c:295-369
  *   spangpu_modemtx_power()                  v29_tx_power() / v27ter_tx_power()     src/v29tx.c:322-338, src/v27ter_tx.c:352-364
  *   spangpu_modemtx_restart()                v29_tx_restart() / v27ter_tx_restart() src/v29tx.c:365-404, src/v27ter_tx.c:384-409
+ *   spangpu_modemtx_restart_ex()             v17_tx_restart(s, rate, tep, short_train)  src/v17tx.c:397-450 (and _power: :371-383)
  * The data bits of channel c come from a 15 bit LFSR (x^15 + x^14 + 1) seeded with seeds[c] (NULL: a seed per
  * channel is derived from its index); a get_bit() callback, and with it the end-of-data shutdown sequence, is
  * not replayed.
@@ -453,6 +456,7 @@ SPANGPU_API int spangpu_modemtx_set_stream(spangpu_modemtx_t *tx, void *hip_stre
 SPANGPU_API int spangpu_modemtx_sync(spangpu_modemtx_t *tx);
 SPANGPU_API int spangpu_modemtx_power(spangpu_modemtx_t *tx, int channel, float power_dbm0);
 SPANGPU_API int spangpu_modemtx_restart(spangpu_modemtx_t *tx, int channel, int bit_rate, int tep);
+SPANGPU_API int spangpu_modemtx_restart_ex(spangpu_modemtx_t *tx, int channel, int bit_rate, int tep, int short_train);
 /* pcm[channel*stride + i], i < samples, where mem says; returns samples */
 SPANGPU_API int spangpu_modemtx_tx(spangpu_modemtx_t *tx, int mem, int16_t *pcm, long long stride, int samples);
 SPANGPU_API int spangpu_modemtx_state_words(void);

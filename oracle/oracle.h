@@ -635,6 +635,33 @@ ORC_API int orc_v27ter_tx_restart(orc_v27ter_tx_t *s, int bit_rate, int tep);
 ORC_API void orc_v27ter_tx_power(orc_v27ter_tx_t *s, float power);
 ORC_API int orc_v27ter_tx(orc_v27ter_tx_t *s, int16_t amp[], int len);
 
+/* ---- V.17 transmitter (v17tx_oracle.c) ---- */
+typedef struct
+{
+    int32_t bit_rate;
+    float gain;
+    int32_t diff;
+    float rrc_re[9];
+    float rrc_im[9];
+    int32_t rrc_step;
+    uint32_t scramble_reg;
+    int32_t convolution;
+    int32_t in_training;
+    int32_t training_step;
+    int32_t short_train;
+    uint32_t carrier_phase;
+    int32_t carrier_phase_rate;
+    int32_t baud_phase;
+    int32_t constellation_state;
+    uint32_t prbs;
+} orc_v17_tx_t;
+
+ORC_API int orc_v17_tx_sizeof(void);
+ORC_API int orc_v17_tx_init(orc_v17_tx_t *s, int bit_rate, int tep, uint32_t prbs_seed);
+ORC_API int orc_v17_tx_restart(orc_v17_tx_t *s, int bit_rate, int tep, int short_train);
+ORC_API void orc_v17_tx_power(orc_v17_tx_t *s, float power);
+ORC_API int orc_v17_tx(orc_v17_tx_t *s, int16_t amp[], int len);
+
 /* ---- modem connect tones (mct_oracle.c) ---- */
 #define ORC_MCT_FAX_CNG             1
 #define ORC_MCT_ANS                 2

@@ -102,6 +102,7 @@ def lib():
             "modem_connect_tones_tx_init": (vp, [vp, ci]), "modem_connect_tones_tx": (ci, [vp, vp, ci]),
             "modem_connect_tones_tx_free": (ci, [vp]), "glue_mct_rx_snapshot": (ci, [vp, vp]),
             "glue_v27ter_tx_tables": (None, [vp, vp]), "glue_v27ter_tx_snapshot": (ci, [vp, vp]), "v27ter_tx_restart": (ci, [vp, ci, ci]),
+            "glue_v17_tx_table": (None, [vp]), "glue_v17_tx_snapshot": (ci, [vp, vp]),
             "glue_v29_tx_table": (None, [vp]), "glue_v29_tx_snapshot": (ci, [vp, vp]), "v29_tx_restart": (ci, [vp, ci, ci]),
             "glue_mct_rx_batch_frames": (None, [vp, vp, ci, C.c_longlong, C.c_longlong, ci, ci, ci]),
             "glue_fsk_preset": (ci, [ci, vp]), "glue_fsk_rx_new": (vp, [ci, ci, vp, vp]),
@@ -841,5 +842,42 @@ class V27terTx(V29Tx):
     def snapshot(self):
         out = np.zeros(32, np.uint32)
         n = lib().glue_v27ter_tx_snapshot(self.p, out.ctypes.data)
+        out[n] = self.st[0]
+        return out[:n + 1].copy()
+
+
+def v17_tx_table():
+    out = np.zeros(90, np.float32)
+    lib().glue_v17_tx_table(out.ctypes.data)
+    return out
+
+
+class V17Tx(V29Tx):
+    """v17_tx_init(NULL, bit_rate, tep, prbs_get_bit, &state) of the real reference."""
+
+    def __init__(self, bit_rate, tep=False, seed=1):
+        self.st = (C.c_uint32*1)(seed & 0x7FFF)
+        self.p = lib().glue_v17_tx_new(bit_rate, int(tep), C.cast(self.st, C.c_void_p))
+
+    def __del__(self):
+        try:
+            lib().v17_tx_free(self.p)
+        except Exception:
+            pass
+
+    def power(self, level_dbm0):
+        lib().v17_tx_power(self.p, level_dbm0)
+
+    def restart(self, bit_rate, tep, short_train=False):
+        return lib().v17_tx_restart(self.p, bit_rate, int(tep), int(short_train))
+
+    def tx(self, n):
+        out = np.zeros(max(n, 1), np.int16)
+        got = lib().v17_tx(self.p, out.ctypes.data, n)
+        return out[:got].copy()
+
+    def snapshot(self):
+        out = np.zeros(32, np.uint32)
+        n = lib().glue_v17_tx_snapshot(self.p, out.ctypes.data)
         out[n] = self.st[0]
         return out[:n + 1].copy()

@@ -141,3 +141,45 @@ GLUE void glue_v17_rx_snapshot(v17_rx_state_t *s, float f[246], int32_t w[301])
     for (i = 0;  i < 16*8;  i++)
         w[n++] = s->past_state_locations[i >> 3][i & 7];
 }
+
+/* ---- V.17 transmitter: its pulse shaper table and a state snapshot (word order of oracle/v17tx_oracle.c) ---- */
+#include "spandsp/v17tx.h"
+#include "spandsp/private/v17tx.h"
+#include "v17_v32bis_tx_rrc.h"
+
+GLUE void glue_v17_tx_table(float out[10*9])
+{
+    int i;
+    int j;
+
+    for (j = 0;  j < 10;  j++)
+    {
+        for (i = 0;  i < 9;  i++)
+            out[j*9 + i] = tx_pulseshaper[j][i];
+    }
+}
+
+GLUE int glue_v17_tx_snapshot(const v17_tx_state_t *s, uint32_t *out)
+{
+    int n = 0;
+    int i;
+
+    out[n++] = (uint32_t) s->bit_rate;
+    memcpy(&out[n++], &s->gain, 4);
+    out[n++] = (uint32_t) s->diff;
+    for (i = 0;  i < V17_TX_FILTER_STEPS;  i++)
+        memcpy(&out[n++], &s->rrc_filter_re[i], 4);
+    for (i = 0;  i < V17_TX_FILTER_STEPS;  i++)
+        memcpy(&out[n++], &s->rrc_filter_im[i], 4);
+    out[n++] = (uint32_t) s->rrc_filter_step;
+    out[n++] = s->scramble_reg;
+    out[n++] = (uint32_t) s->convolution;
+    out[n++] = (uint32_t) s->in_training;
+    out[n++] = (uint32_t) s->training_step;
+    out[n++] = (uint32_t) s->short_train;
+    out[n++] = s->carrier_phase;
+    out[n++] = (uint32_t) s->carrier_phase_rate;
+    out[n++] = (uint32_t) s->baud_phase;
+    out[n++] = (uint32_t) s->constellation_state;
+    return n;
+}

@@ -82,6 +82,11 @@ def lib():
             "orc_v27ter_tx_restart": (ci, [vp, ci, ci]),
             "orc_v27ter_tx_power": (None, [vp, cf]),
             "orc_v27ter_tx": (ci, [vp, vp, ci]),
+            "orc_v17_tx_sizeof": (ci, []),
+            "orc_v17_tx_init": (ci, [vp, ci, ci, C.c_uint32]),
+            "orc_v17_tx_restart": (ci, [vp, ci, ci, ci]),
+            "orc_v17_tx_power": (None, [vp, cf]),
+            "orc_v17_tx": (ci, [vp, vp, ci]),
             "orc_v29_tx_sizeof": (ci, []),
             "orc_v29_tx_set_table": (None, [vp]),
             "orc_v29_tx_init": (ci, [vp, ci, ci, C.c_uint32]),
@@ -644,4 +649,25 @@ class V27terTx(V29Tx):
     def tx(self, n):
         out = np.zeros(max(n, 1), np.int16)
         got = lib().orc_v27ter_tx(self.p, out.ctypes.data, n)
+        return out[:got].copy()
+
+
+class V17Tx(V29Tx):
+    """Needs set_modem_tables() (constellations, sine) and set_v29_tx_table() (the shared 10 x 9 pulse shaper)."""
+
+    def __init__(self, bit_rate, tep=False, seed=1):
+        self.buf = np.zeros(self.WORDS, np.uint32)
+        self.p = self.buf.ctypes.data
+        assert lib().orc_v17_tx_sizeof() == 4*self.WORDS
+        assert lib().orc_v17_tx_init(self.p, bit_rate, int(tep), seed & 0x7FFF) == 0
+
+    def power(self, level_dbm0):
+        lib().orc_v17_tx_power(self.p, level_dbm0)
+
+    def restart(self, bit_rate, tep, short_train=False):
+        return lib().orc_v17_tx_restart(self.p, bit_rate, int(tep), int(short_train))
+
+    def tx(self, n):
+        out = np.zeros(max(n, 1), np.int16)
+        got = lib().orc_v17_tx(self.p, out.ctypes.data, n)
         return out[:got].copy()

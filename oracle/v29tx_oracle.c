@@ -35,6 +35,12 @@ ORC_API void orc_v29_tx_set_table(const float table[90])
     memcpy(tx_shaper, table, sizeof(tx_shaper));
 }
 
+/* the V.17 transmitter shapes with the same table (v17tx_oracle.c) */
+const float *orc_v29_tx_shaper(void)
+{
+    return &tx_shaper[0][0];
+}
+
 /* The 16 point constellation: index = amplitude bit << 3 | phase octant (v29tx_constellation_maps.h) */
 static void point(int idx, float z[2])
 {

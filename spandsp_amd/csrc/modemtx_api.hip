@@ -32,7 +32,8 @@ extern "C" int spangpu_set_error(int code, const char *msg);
 struct spangpu_modemtx_s
 {
     int device;
-    int kind;               // kTxV29 or kTxV27ter
+    int kind;               // kTxV29, kTxV27ter or kTxV17
+    float *constel;         // V.17: the constellations of every rate + the ABCD training points
     int n_ch;
     hipStream_t stream;
     bool own_stream;
@@ -58,7 +59,7 @@ static float get_f(const int32_t *w, int idx)
 static void gain_words(int32_t *w, int kind)
 {
     if (kind != kTxV29)
-        return;             // V.27ter keeps one gain per rate, both set by v27ter_tx_power()
+        return;             // V.27ter keeps one gain per rate, V.17 one gain; both are set by xxx_tx_power()
     // set_working_gain(), v29tx.c:286-320
     const float base = get_f(w, VT_BASE_GAIN);
     switch (w[VT_BIT_RATE])
@@ -78,14 +79,40 @@ static void power_words(int32_t *w, int kind, float power)
         gain_words(w, kind);
         return;
     }
+    if (kind == kTxV17)
+    {
+        // v17_tx_power(), v17tx.c:371-383
+        put_f(w, VT_BASE_GAIN, 0.223f*spg_db_to_amplitude_ratio(power - 3.14f)*32768.0f/1.000000f);
+        return;
+    }
     // v27ter_tx_power(), v27ter_tx.c:352-364: gain_2400 (word 1) and gain_4800 (word 2), both shaper gains 1.0f
     const float gain = spg_db_to_amplitude_ratio(power - 3.14f)*32768.0f;
     put_f(w, VT_BASE_GAIN, gain/1.000000f);
     put_f(w, VT_GAIN, gain/1.000000f);
 }
 
-static int restart_words(int32_t *w, int kind, int bit_rate, int tep)
+static int restart_words(int32_t *w, int kind, int bit_rate, int tep, int short_train = 0)
 {
+    if (kind == kTxV17)
+    {
+        // v17_tx_restart(), v17tx.c:397-450
+        if (bit_rate != 14400  &&  bit_rate != 12000  &&  bit_rate != 9600  &&  bit_rate != 7200  &&  bit_rate != 4800)
+            return -1;
+        w[VT_BIT_RATE] = bit_rate;
+        w[VT_GAIN] = short_train  ?  0  :  1;          // diff
+        for (int i = 0;  i < 18;  i++)
+            w[VT_RRC_RE + i] = 0;
+        w[VT_RRC_STEP] = 0;
+        w[VT_TRAIN_SCRAMBLE] = 0;                       // convolution
+        w[VT_SCRAMBLE] = 0x2ECDD5;
+        w[VT_IN_TRAINING] = 1;
+        w[VT_TRAINING_OFFSET] = short_train  ?  1  :  0;
+        w[VT_TRAINING_STEP] = tep  ?  0  :  kV17Seg1;
+        w[VT_CARRIER_PHASE] = 0;
+        w[VT_BAUD_PHASE] = 0;
+        w[VT_CONSTELLATION] = 0;
+        return 0;
+    }
     if (kind == kTxV27ter)
     {
         // v27ter_tx_restart(), v27ter_tx.c:384-409
@@ -146,13 +173,13 @@ extern "C" {
 
 int spangpu_modemtx_create(spangpu_modemtx_t **out, int device, int modem, int n_channels, int bit_rate, int tep, const uint32_t *seeds)
 {
-    if (out == NULL  ||  n_channels <= 0  ||  (modem != SPANGPU_V29  &&  modem != SPANGPU_V27TER))
-        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments (modem SPANGPU_V29 or SPANGPU_V27TER)");
-    const int kind = (modem == SPANGPU_V29)  ?  kTxV29  :  kTxV27ter;
+    if (out == NULL  ||  n_channels <= 0  ||  (modem != SPANGPU_V29  &&  modem != SPANGPU_V27TER  &&  modem != SPANGPU_V17))
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments (modem SPANGPU_V29, SPANGPU_V27TER or SPANGPU_V17)");
+    const int kind = (modem == SPANGPU_V29)  ?  kTxV29  :  ((modem == SPANGPU_V27TER)  ?  kTxV27ter  :  kTxV17);
     int32_t probe[kV29TxWords];
     memset(probe, 0, sizeof(probe));
     if (restart_words(probe, kind, bit_rate, tep) != 0)
-        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bit rate not valid for this modem (V.29: 9600/7200/4800, V.27ter: 4800/2400)");
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bit rate not valid for this modem (V.29: 9600/7200/4800, V.27ter: 4800/2400, V.17: 14400/12000/9600/7200/4800)");
     *out = NULL;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess  ||  count <= 0)
@@ -175,7 +202,8 @@ int spangpu_modemtx_create(spangpu_modemtx_t **out, int device, int modem, int n
     const size_t words = (size_t) kV29TxWords*n_channels;
     if (hipMalloc(&t->st, words*sizeof(int32_t)) != hipSuccess
         ||  hipMalloc(&t->sine, 2048*sizeof(float)) != hipSuccess
-        ||  hipMalloc(&t->shaper, 225*sizeof(float)) != hipSuccess)
+        ||  hipMalloc(&t->shaper, 225*sizeof(float)) != hipSuccess
+        ||  hipMalloc(&t->constel, 496*sizeof(float)) != hipSuccess)
     {
         spangpu_modemtx_destroy(t);
         return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "allocation of the V.29 transmitter bank failed");
@@ -186,7 +214,8 @@ int spangpu_modemtx_create(spangpu_modemtx_t **out, int device, int modem, int n
     spg_make_sine_table(sine);
     // make_modem_filter -t: V.29 10 phases x 9 taps, excess bandwidth 0.25; V.27ter 4800 bps 5 x 9 and 2400 bps
     // 20 x 9, excess bandwidth 0.5 (make_modem_filter.c:375-412)
-    if (((kind == kTxV29)  ?  spg_make_tx_pulseshaper(10, 9, 0.25, shaper)
+    // V.17 shapes with the V.29 parameters (make_modem_filter.c:319-331)
+    if (((kind != kTxV27ter)  ?  spg_make_tx_pulseshaper(10, 9, 0.25, shaper)
                            :  (spg_make_tx_pulseshaper(5, 9, 0.5, shaper) | spg_make_tx_pulseshaper(20, 9, 0.5, shaper + 45))) != 0)
     {
         spangpu_modemtx_destroy(t);
@@ -197,6 +226,26 @@ int spangpu_modemtx_create(spangpu_modemtx_t **out, int device, int modem, int n
     memset(one, 0, sizeof(one));
     one[VT_BIT_RATE] = bit_rate;
     one[VT_CARRIER_RATE] = spg_dds_phase_ratef((kind == kTxV29)  ?  1700.0f  :  1800.0f);
+    // the V.17 constellations (v17_v32bis_tx_constellation_maps.h) and the ABCD training points (:314-323)
+    float constel[496];
+    memset(constel, 0, sizeof(constel));
+    {
+        static const int rates[5] = {14400, 12000, 9600, 7200, 4800};
+        static const float abcd[8] = {-6.0f, -2.0f, 2.0f, -6.0f, 6.0f, 2.0f, -2.0f, 6.0f};
+        int at = 0;
+        for (int r = 0;  r < 5;  r++)
+        {
+            int8_t pts[128][2];
+            const int np = spg_make_v17_constellation(rates[r], pts);
+            for (int i = 0;  i < np;  i++)
+            {
+                constel[2*(at + i)] = (float) pts[i][0];
+                constel[2*(at + i) + 1] = (float) pts[i][1];
+            }
+            at += np;
+        }
+        memcpy(constel + 2*at, abcd, sizeof(abcd));
+    }
     power_words(one, kind, -14.0f);
     restart_words(one, kind, bit_rate, tep);
     int32_t *host = (int32_t *) malloc(words*sizeof(int32_t));
@@ -218,6 +267,8 @@ int spangpu_modemtx_create(spangpu_modemtx_t **out, int device, int modem, int n
         e = hipMemcpy(t->sine, sine, sizeof(sine), hipMemcpyHostToDevice);
     if (e == hipSuccess)
         e = hipMemcpy(t->shaper, shaper, sizeof(shaper), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(t->constel, constel, sizeof(constel), hipMemcpyHostToDevice);
     if (e != hipSuccess)
     {
         spangpu_modemtx_destroy(t);
@@ -237,6 +288,7 @@ void spangpu_modemtx_destroy(spangpu_modemtx_t *t)
     (void) hipFree(t->st);
     (void) hipFree(t->sine);
     (void) hipFree(t->shaper);
+    (void) hipFree(t->constel);
     (void) hipFree(t->d_pcm);
     if (t->own_stream  &&  t->stream)
         (void) hipStreamDestroy(t->stream);
@@ -282,13 +334,18 @@ int spangpu_modemtx_power(spangpu_modemtx_t *t, int channel, float power_dbm0)
 
 int spangpu_modemtx_restart(spangpu_modemtx_t *t, int channel, int bit_rate, int tep)
 {
+    return spangpu_modemtx_restart_ex(t, channel, bit_rate, tep, 0);
+}
+
+int spangpu_modemtx_restart_ex(spangpu_modemtx_t *t, int channel, int bit_rate, int tep, int short_train)
+{
     if (t == NULL  ||  channel < 0  ||  channel >= t->n_ch)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
     int32_t w[kV29TxWords];
     int rc = rw_words(t, channel, w, false);
     if (rc != SPANGPU_OK)
         return rc;
-    if (restart_words(w, t->kind, bit_rate, tep) != 0)
+    if (restart_words(w, t->kind, bit_rate, tep, short_train) != 0)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bit rate not valid for this modem");
     return rw_words(t, channel, w, true);
 }
@@ -314,6 +371,7 @@ int spangpu_modemtx_tx(spangpu_modemtx_t *t, int mem_kind, int16_t *pcm, long lo
     L.st = t->st;
     L.sine = t->sine;
     L.shaper = t->shaper;
+    L.constel = t->constel;
     L.n_ch = t->n_ch;
     L.samples = samples;
     if (mem_kind == SPANGPU_MEM_HOST)
@@ -340,6 +398,8 @@ int spangpu_modemtx_tx(spangpu_modemtx_t *t, int mem_kind, int16_t *pcm, long lo
     L.vec = ((L.stride & 7) == 0  &&  (reinterpret_cast<uintptr_t>(L.pcm) & 15) == 0)  ?  1  :  0;
     if (t->kind == kTxV29)
         hipLaunchKernelGGL(modemtx_bank_kernel<kTxV29>, dim3((t->n_ch + 63)/64), dim3(64), 0, t->stream, L);
+    else if (t->kind == kTxV17)
+        hipLaunchKernelGGL(modemtx_bank_kernel<kTxV17>, dim3((t->n_ch + 63)/64), dim3(64), 0, t->stream, L);
     else
         hipLaunchKernelGGL(modemtx_bank_kernel<kTxV27ter>, dim3((t->n_ch + 63)/64), dim3(64), 0, t->stream, L);
     VT_TRY(hipGetLastError());

@@ -1,11 +1,14 @@
-// modemtx_dev.hpp -- device side of the modem transmitter banks: N V.29 or V.27ter
-// modulators, one channel per lane, as the signal sources of the receiver banks.
+// modemtx_dev.hpp -- device side of the modem transmitter banks: N V.29, V.27ter or
+// V.17 modulators, one channel per lane, as the signal sources of the receiver banks.
 //
 // What is restated (paths relative to the reference tree; float build, x86-64):
 //   v29_tx()                   src/v29tx.c:226-284
 //   getbaud(), get_scrambled_bit()   src/v29tx.c:103-224   (training segments, data scrambler, differential phase map)
 //   v27ter_tx()                src/v27ter_tx.c:246-350   (1600 baud at 4800 bps, 1200 baud at 2400 bps)
 //   getbaud(), scramble()      src/v27ter_tx.c:103-244   (the scrambler with its guard against repeating patterns)
+//   v17_tx()                   src/v17tx.c:295-369
+//   training_get(), diff_and_convolutional_encode(), getbaud()   src/v17tx.c:106-293   (long / short training, the
+//                              bridge, differential + convolutional encoding into the 4 .. 128 point constellations)
 //   vec_circular_dot_prodf()   src/vector_float.c (scalar path): two partial sums, split where the ring wraps
 //   dds_complexf()             src/dds_float.c:2184-2191
 //   lfastrintf()               a truncating cast on x86-64 (spandsp/fast_convert.h:184-197)
@@ -28,16 +31,16 @@ namespace spg
 enum
 {
     VT_BIT_RATE = 0,
-    VT_BASE_GAIN = 1,       // float (V.27ter: gain_2400)
-    VT_GAIN = 2,            // float (V.27ter: gain_4800)
+    VT_BASE_GAIN = 1,       // float (V.27ter: gain_2400; V.17: gain)
+    VT_GAIN = 2,            // float (V.27ter: gain_4800; V.17: int diff)
     VT_RRC_RE = 3,          // 9 floats, ring order (as the reference keeps them)
     VT_RRC_IM = 12,         // 9 floats
     VT_RRC_STEP = 21,
     VT_SCRAMBLE = 22,
-    VT_TRAIN_SCRAMBLE = 23, // V.27ter: scrambler_pattern_count
+    VT_TRAIN_SCRAMBLE = 23, // V.27ter: scrambler_pattern_count; V.17: convolution
     VT_IN_TRAINING = 24,
     VT_TRAINING_STEP = 25,
-    VT_TRAINING_OFFSET = 26,
+    VT_TRAINING_OFFSET = 26,    // V.17: short_train
     VT_CARRIER_PHASE = 27,
     VT_CARRIER_RATE = 28,
     VT_BAUD_PHASE = 29,
@@ -55,6 +58,17 @@ constexpr int kVtShutdownEnd = kVtEnd + 32;
 
 constexpr int kTxV29 = 0;
 constexpr int kTxV27ter = 1;
+constexpr int kTxV17 = 2;
+
+// V.17 training, in symbols (v17tx.c:86-103)
+constexpr int kV17TepB = 480;
+constexpr int kV17Seg1 = kV17TepB + 48;
+constexpr int kV17Seg2 = kV17Seg1 + 256;
+constexpr int kV17Seg3 = kV17Seg2 + 2976;
+constexpr int kV17Seg4 = kV17Seg3 + 64;
+constexpr int kV17ShortSeg4 = kV17Seg2 + 38;
+constexpr int kV17End = kV17Seg4 + 48;
+constexpr int kV17ShutdownEnd = kV17End + 32 + 48;
 
 // V.27ter training, in symbols (v27ter_tx.c:82-96)
 constexpr int kV27Seg2 = 320;
@@ -68,7 +82,8 @@ struct V29TxLaunch
 {
     int32_t *st;                // [kV29TxWords][n_ch]
     const float *sine;          // [2048]
-    const float *shaper;        // V.29: [10][9]; V.27ter: [5][9] (4800 bps) then [20][9] (2400 bps)
+    const float *shaper;        // V.29, V.17: [10][9]; V.27ter: [5][9] (4800 bps) then [20][9] (2400 bps)
+    const float *constel;       // V.17: [128 + 64 + 32 + 16 + 4][2] (14400 .. 4800 bps) then the ABCD points [4][2]
     int16_t *pcm;               // [n_ch][stride]
     long long stride;
     int n_ch;
@@ -105,13 +120,19 @@ __global__ __launch_bounds__(64) void modemtx_bank_kernel(const V29TxLaunch L)
 {
     __shared__ float sine[2048];
     __shared__ float shaper[25][9];
+    __shared__ float constel[(KIND == kTxV17)  ?  248  :  1][2];
     const int lane = threadIdx.x;
     const int ch = blockIdx.x*64 + lane;
 
     for (int i = lane;  i < 2048;  i += 64)
         sine[i] = L.sine[i];
-    for (int i = lane;  i < ((KIND == kTxV29)  ?  90  :  225);  i += 64)
+    for (int i = lane;  i < ((KIND == kTxV27ter)  ?  225  :  90);  i += 64)
         (&shaper[0][0])[i] = L.shaper[i];
+    if (KIND == kTxV17)
+    {
+        for (int i = lane;  i < 496;  i += 64)
+            (&constel[0][0])[i] = L.constel[i];
+    }
     __syncthreads();
     if (ch >= L.n_ch)
         return;
@@ -120,7 +141,8 @@ __global__ __launch_bounds__(64) void modemtx_bank_kernel(const V29TxLaunch L)
     const size_t n = (size_t) L.n_ch;
     const int bit_rate = st[VT_BIT_RATE*n];
     // V.27ter keeps one gain per rate: word 1 for 2400 bps, word 2 for 4800 bps
-    const float gain = __int_as_float(st[((KIND == kTxV27ter  &&  bit_rate == 2400)  ?  VT_BASE_GAIN  :  VT_GAIN)*n]);
+    const float gain = __int_as_float(st[(((KIND == kTxV27ter  &&  bit_rate == 2400)  ||  KIND == kTxV17)  ?  VT_BASE_GAIN  :  VT_GAIN)*n]);
+    int diff = (KIND == kTxV17)  ?  st[VT_GAIN*n]  :  0;
     int rrc_step = st[VT_RRC_STEP*n];
     uint32_t scramble = (uint32_t) st[VT_SCRAMBLE*n];
     uint32_t train_scramble = (uint32_t) st[VT_TRAIN_SCRAMBLE*n];
@@ -178,8 +200,18 @@ __global__ __launch_bounds__(64) void modemtx_bank_kernel(const V29TxLaunch L)
         return (int) out;
     };
 
+    // scramble(), v17tx.c:106-116 (scrambler_tap = 17)
+    auto scramble17 = [&](int in_bit) -> int
+    {
+        const int out = (int) (((uint32_t) in_bit ^ (scramble >> 17) ^ (scramble >> 22)) & 1u);
+        scramble = (scramble << 1) | (uint32_t) out;
+        return out;
+    };
+    // the constellation of this lane's rate inside `constel`
+    const int pts_at = (bit_rate == 14400)  ?  0  :  ((bit_rate == 12000)  ?  128  :  ((bit_rate == 9600)  ?  192  :  ((bit_rate == 7200)  ?  224  :  240)));
+
     int16_t *row = L.pcm + (size_t) ch*L.stride;
-    const bool silent = (training_step >= ((KIND == kTxV29)  ?  kVtShutdownEnd  :  kV27ShutdownEnd));    // nothing more is sent
+    const bool silent = (training_step >= ((KIND == kTxV29)  ?  kVtShutdownEnd  :  ((KIND == kTxV27ter)  ?  kV27ShutdownEnd  :  kV17ShutdownEnd)));
     for (int base = 0;  base < L.samples;  base += 8)
     {
         uint32_t pk[4] = {0u, 0u, 0u, 0u};
@@ -191,7 +223,7 @@ __global__ __launch_bounds__(64) void modemtx_bank_kernel(const V29TxLaunch L)
             if (j < todo  &&  !silent)
             {
                 bool fresh;
-                if (KIND == kTxV29)
+                if (KIND == kTxV29  ||  KIND == kTxV17)
                 {
                     baud_phase += 3;
                     fresh = (baud_phase >= 10);
@@ -274,6 +306,91 @@ __global__ __launch_bounds__(64) void modemtx_bank_kernel(const V29TxLaunch L)
                             v29tx_point(amp | constellation, vre, vim);
                         }
                     }
+                    else if (KIND == kTxV17)
+                    {
+                        // getbaud() / training_get(), v17tx.c:118-293; training_offset holds short_train, train_scramble
+                        // the convolutional encoder state
+                        bool have = false;
+                        if (in_training  &&  training_step <= kV17End)
+                        {
+                            if (training_step < kV17Seg4)
+                            {
+                                have = true;
+                                training_step++;
+                                int k;
+                                if (training_step <= kV17Seg2)
+                                {
+                                    // TEP carrier (A), silence, then ABAB
+                                    k = (training_step <= kV17TepB)  ?  0  :  ((training_step & 1) ^ 1);
+                                    if (training_step > kV17TepB  &&  training_step <= kV17Seg1)
+                                        k = -1;
+                                }
+                                else if (training_step <= kV17Seg3)
+                                {
+                                    // CDBA through the scrambler
+                                    int bits = scramble17(1);
+                                    bits = (bits << 1) | scramble17(1);
+                                    constellation = (0x0132 >> (bits*4)) & 3;                   // {2, 3, 1, 0}
+                                    if (training_offset  &&  training_step == kV17ShortSeg4)
+                                        training_step = kV17Seg4;
+                                    k = constellation;
+                                }
+                                else
+                                {
+                                    // the bridge, carrying 0x8880
+                                    const int shift = ((training_step - kV17Seg3 - 1) & 7) << 1;
+                                    int bits = scramble17((0x8880 >> shift) & 1);
+                                    bits = (bits << 1) | scramble17((0x8880 >> (shift + 1)) & 1);
+                                    constellation = (constellation + ((0x3201 >> (bits*4)) & 3)) & 3;  // {1, 0, 2, 3}
+                                    k = constellation;
+                                }
+                                vre = (k < 0)  ?  0.0f  :  constel[244 + ((k < 0)  ?  0  :  k)][0];
+                                vim = (k < 0)  ?  0.0f  :  constel[244 + ((k < 0)  ?  0  :  k)][1];
+                            }
+                            else
+                            {
+                                training_step++;
+                                if (training_step > kV17End)
+                                    in_training = 0;
+                            }
+                        }
+                        if (!have)
+                        {
+                            const int nbits = (bit_rate == 14400)  ?  6  :  ((bit_rate == 12000)  ?  5  :  ((bit_rate == 9600)  ?  4  :  ((bit_rate == 7200)  ?  3  :  2)));
+                            int q = 0;
+                            for (int i = 0;  i < nbits;  i++)
+                            {
+                                int bit = 1;
+                                if (!in_training)
+                                {
+                                    bit = (int) (((prbs >> 14) ^ (prbs >> 13)) & 1u);
+                                    prbs = ((prbs << 1) | (uint32_t) bit) & 0x7FFFu;
+                                }
+                                q |= scramble17(bit) << i;
+                            }
+                            // diff_and_convolutional_encode(), v17tx.c:170-222
+                            int idx = 0;
+                            if (bit_rate != 4800)
+                            {
+                                diff = (diff + (q & 3)) & 3;        // v17_differential_encoder: addition mod 4
+                                // v17_convolutional_encoder[8][4], one byte per row, two bits... kept as a table of nibbles
+                                const uint32_t row4 = (train_scramble == 0)  ?  0x1320u  :  (train_scramble == 1)  ?  0x6574u  :  (train_scramble == 2)  ?  0x0231u
+                                                      :  (train_scramble == 3)  ?  0x5647u  :  (train_scramble == 4)  ?  0x3102u  :  (train_scramble == 5)  ?  0x4756u
+                                                      :  (train_scramble == 6)  ?  0x2013u  :  0x7465u;
+                                train_scramble = (row4 >> (diff*4)) & 7u;
+                                idx = ((q << 1) & 0x78) | (diff << 1) | (int) ((train_scramble >> 2) & 1u);
+                            }
+                            else
+                            {
+                                // v32bis_4800_differential_encoder[diff][q]: {2,3,0,1},{0,2,1,3},{3,1,2,0},{1,0,3,2}
+                                const uint32_t d4 = (diff == 0)  ?  0x1032u  :  (diff == 1)  ?  0x3120u  :  (diff == 2)  ?  0x0213u  :  0x2301u;
+                                diff = (int) ((d4 >> ((q & 3)*4)) & 3u);
+                                idx = diff;
+                            }
+                            vre = constel[pts_at + idx][0];
+                            vim = constel[pts_at + idx][1];
+                        }
+                    }
                     else
                     {
                         // getbaud(), v27ter_tx.c:148-244
@@ -343,7 +460,7 @@ __global__ __launch_bounds__(64) void modemtx_bank_kernel(const V29TxLaunch L)
                 }
                 // vec_circular_dot_prodf(ring, shaper[9 - baud_phase], 9, rrc_step): the first partial sum runs over the
                 // 9 - rrc_step oldest entries, the second over the rest; each from 0.0f, then added
-                const float *coef = (KIND == kTxV29)  ?  shaper[9 - baud_phase]
+                const float *coef = (KIND != kTxV27ter)  ?  shaper[9 - baud_phase]
                                                       :  ((bit_rate == 4800)  ?  shaper[4 - baud_phase]  :  shaper[5 + 19 - baud_phase]);
                 const int split = 9 - rrc_step;
                 float zre = 0.0f;
@@ -393,6 +510,8 @@ __global__ __launch_bounds__(64) void modemtx_bank_kernel(const V29TxLaunch L)
         st[(size_t) (VT_RRC_IM + at)*n] = __float_as_int(aim[i]);
     }
     st[VT_RRC_STEP*n] = rrc_step;
+    if (KIND == kTxV17)
+        st[VT_GAIN*n] = diff;
     st[VT_SCRAMBLE*n] = (int32_t) scramble;
     st[VT_TRAIN_SCRAMBLE*n] = (int32_t) train_scramble;
     st[VT_IN_TRAINING*n] = in_training;

@@ -81,6 +81,7 @@ def lib():
             "spangpu_modemtx_sync": (ci, [vp]),
             "spangpu_modemtx_power": (ci, [vp, ci, cf]),
             "spangpu_modemtx_restart": (ci, [vp, ci, ci, ci]),
+            "spangpu_modemtx_restart_ex": (ci, [vp, ci, ci, ci, ci]),
             "spangpu_modemtx_tx": (ci, [vp, ci, vp, ll, ci]),
             "spangpu_modemtx_state_words": (ci, []),
             "spangpu_modemtx_get_state": (ci, [vp, ci, vp]),
@@ -742,8 +743,8 @@ class ModemTxBank:
     def power(self, channel, level_dbm0):
         _check(lib().spangpu_modemtx_power(self.h, channel, level_dbm0))
 
-    def restart(self, channel, bit_rate, tep):
-        _check(lib().spangpu_modemtx_restart(self.h, channel, bit_rate, int(tep)))
+    def restart(self, channel, bit_rate, tep, short_train=False):
+        _check(lib().spangpu_modemtx_restart_ex(self.h, channel, bit_rate, int(tep), int(short_train)))
 
     def tx_host(self, samples):
         pcm = np.zeros((self.n, samples), np.int16)
@@ -767,3 +768,8 @@ class V29TxBank(ModemTxBank):
 class V27terTxBank(ModemTxBank):
     def __init__(self, n_channels, bit_rate=4800, tep=False, seeds=None, device=0):
         super().__init__(V27TER, n_channels, bit_rate, tep, seeds, device)
+
+
+class V17TxBank(ModemTxBank):
+    def __init__(self, n_channels, bit_rate=14400, tep=False, seeds=None, device=0):
+        super().__init__(V17, n_channels, bit_rate, tep, seeds, device)

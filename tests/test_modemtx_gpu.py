@@ -1,4 +1,4 @@
-"""Modem transmitter banks against the oracle: v29_tx and v27ter_tx.
+"""Modem transmitter banks against the oracle: v29_tx, v27ter_tx and v17_tx.
 
 Bar: bit-exact int16 samples and state words (float words as bits).  The oracle (oracle/v29tx_oracle.c) is pinned to
 the real reference in test_oracle_pin.py; the pulse shaper tables are this library's own builder's, which
@@ -26,7 +26,9 @@ def setup_oracle():
 
 
 @pytest.mark.parametrize("modem,bit_rate,tep", [("v29", 9600, False), ("v29", 7200, True), ("v29", 4800, False), ("v29", 9600, True),
-                                                ("v27ter", 4800, False), ("v27ter", 2400, True), ("v27ter", 2400, False)])
+                                                ("v27ter", 4800, False), ("v27ter", 2400, True), ("v27ter", 2400, False),
+                                                ("v17", 14400, False), ("v17", 12000, True), ("v17", 9600, False), ("v17", 7200, False),
+                                                ("v17", 4800, True)])
 def test_modem_tx_bank(built, modem, bit_rate, tep):
     orc, engine = setup_oracle()
     n = 150
@@ -37,6 +39,13 @@ def test_modem_tx_bank(built, modem, bit_rate, tep):
         tx = [orc.V29Tx(bit_rate, tep, int(s)) for s in seeds]
         other = 7200 if bit_rate != 7200 else 9600
         train = (480 if tep else 0) + 48 + 128 + 384 + 48
+    elif modem == "v17":
+        n = 80
+        seeds = seeds[:n]
+        bank = engine.V17TxBank(n, bit_rate, tep, seeds)
+        tx = [orc.V17Tx(bit_rate, tep, int(s)) for s in seeds]
+        other = 9600 if bit_rate != 9600 else 14400
+        train = ((528 if tep else 0) + 256 + 2976 + 64 + 48)*10//3 + 10
     else:
         bank = engine.V27terTxBank(n, bit_rate, tep, seeds)
         tx = [orc.V27terTx(bit_rate, tep, int(s)) for s in seeds]
@@ -46,7 +55,7 @@ def test_modem_tx_bank(built, modem, bit_rate, tep):
         bank.power(c, -20.0 + (c % 13))
         tx[c].power(-20.0 + (c % 13))
     total = 0
-    for k, m in enumerate(FRAMES*(3 if modem == "v29" else 6)):
+    for k, m in enumerate(FRAMES*{"v29": 3, "v27ter": 6, "v17": 8}[modem]):
         pcm = bank.tx_host(m)
         for c in range(n):
             want = tx[c].tx(m)
@@ -54,8 +63,12 @@ def test_modem_tx_bank(built, modem, bit_rate, tep):
         total += m
         if k == 12:
             for c in range(3, n, 17):
-                bank.restart(c, other, not tep)
-                tx[c].restart(other, not tep)
+                if modem == "v17":
+                    bank.restart(c, other, not tep, short_train=True)       # v17_tx_restart(s, rate, tep, short_train)
+                    tx[c].restart(other, not tep, True)
+                else:
+                    bank.restart(c, other, not tep)
+                    tx[c].restart(other, not tep)
         if k % 5 == 4:
             for c in range(0, n, 11):
                 assert np.array_equal(bank.get_state(c), tx[c].snapshot()), (k, c)
@@ -136,5 +149,42 @@ def test_v27ter_tx_feeds_v27ter_rx_on_device(built):
         want = np.array(want)
         assert len(data) > 500
         hit = [k for k in range(200) if np.array_equal(want[k:k + 64], data[:64])]
+        assert hit, c
+        assert np.array_equal(want[hit[0]:hit[0] + len(data)], data), c
+
+
+def test_v17_tx_feeds_v17_rx_on_device(built):
+    """And for V.17 at 14400 bps, long training: v17_tx bank -> HBM -> v17_rx bank (trellis decoder and all)."""
+    orc, engine = setup_oracle()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    n, samples, frames = 128, 160, 95
+    seeds = ((np.arange(n)*2654435761 + 4242) & 0x7FFF) | 1
+    tx = engine.V17TxBank(n, 14400, False, seeds)
+    rx = engine.V17Bank(n, 14400)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), n*samples*2) == 0
+    bits = [[] for _ in range(n)]
+    for _ in range(frames):
+        tx.tx_device(buf, samples, samples)
+        tx.sync()
+        rx.rx_device(buf, samples, samples)
+        for c, e in enumerate(rx.events()):
+            bits[c].extend(int(v) for v in e)
+    hip.hipFree(buf)
+    for c in range(n):
+        ev = bits[c]
+        assert -4 in ev, c
+        data = np.array([b for b in ev[ev.index(-4) + 1:] if b >= 0])
+        st = int(seeds[c])
+        want = []
+        for _ in range(len(data) + 400):
+            b = ((st >> 14) ^ (st >> 13)) & 1
+            st = ((st << 1) | b) & 0x7FFF
+            want.append(b)
+        want = np.array(want)
+        assert len(data) > 1000
+        hit = [k for k in range(400) if np.array_equal(want[k:k + 64], data[:64])]
         assert hit, c
         assert np.array_equal(want[hit[0]:hit[0] + len(data)], data), c

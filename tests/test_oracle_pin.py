@@ -577,19 +577,23 @@ V29TX_CASES = [(9600, False, 0x1234), (9600, True, 0x0001), (7200, False, 0x7FFF
                (4800, True, 0x5555)]
 
 
-def v29tx_run(tx, seed, other_rate=None):
+def v29tx_run(tx, seed, other_rate=None, n_calls=150, short_train=None):
     """One session of a transmitter object: odd call sizes, a power change, a restart at another rate."""
     rng = np.random.default_rng(seed)
     out = []
     snaps = []
-    for k in range(150):
+    for k in range(n_calls):
         out.append(tx.tx(int(rng.integers(1, 400))))
         if k % 10 == 9:
             snaps.append(tx.snapshot())
         if k == 60:
             tx.power(-9.5)
         if k == 110:
-            tx.restart(other_rate if other_rate else (7200 if int(snaps[0][0]) != 7200 else 9600), True)
+            nr = other_rate if other_rate else (7200 if int(snaps[0][0]) != 7200 else 9600)
+            if short_train is None:
+                tx.restart(nr, True)
+            else:
+                tx.restart(nr, True, short_train)
     return np.concatenate(out), np.stack(snaps)
 
 
@@ -649,6 +653,44 @@ def test_golden_v27ter_tx(built):
     g = np.load(os.path.join(GOLDEN, "v27tertx.npz"))
     for i, (bit_rate, tep, seed) in enumerate(V27TX_CASES):
         amp, snaps = v29tx_run(orc.V27terTx(bit_rate, tep, seed), seed, 2400 if bit_rate == 4800 else 4800)
+        assert np.array_equal(amp, g["amp_%d" % i]), i
+        assert np.array_equal(snaps, g["snaps_%d" % i]), i
+
+
+V17TX_CASES = [(14400, False, 0x1234), (12000, True, 0x0001), (9600, False, 0x7FFF), (7200, True, 0x2B2B), (4800, False, 0x0F0F)]
+
+
+def use_v17_tx_tables(built):
+    """The V.17 transmitter's tables: constellations = the receiver's (v17_signal_space(), CRC-pinned), pulse shaper =
+    the V.29 transmitter's table (make_modem_filter gives both modems the same parameters)."""
+    from oracle import restated as orc
+    use_v29_tx_table(built)
+    g = np.load(os.path.join(GOLDEN, "modem_tables.npz"))
+    t = {k: g[k] for k in g.files}
+    t.update(v17_signal_space())
+    orc.set_modem_tables(t)
+
+
+@needs_ref
+@pytest.mark.parametrize("bit_rate,tep,seed", V17TX_CASES)
+def test_v17_tx_live(built, bit_rate, tep, seed):
+    from oracle import ref, restated as orc
+    use_v17_tx_tables(built)
+    assert np.array_equal(ref.v17_tx_table().view(np.uint32), ref.v29_tx_table().view(np.uint32))
+    other = 9600 if bit_rate != 9600 else 14400
+    a_amp, a_snaps = v29tx_run(ref.V17Tx(bit_rate, tep, seed), seed, other, 260, True)
+    b_amp, b_snaps = v29tx_run(orc.V17Tx(bit_rate, tep, seed), seed, other, 260, True)
+    assert len(a_amp) > 40000
+    assert np.array_equal(a_amp, b_amp)
+    assert np.array_equal(a_snaps, b_snaps)
+
+
+def test_golden_v17_tx(built):
+    from oracle import restated as orc
+    use_v17_tx_tables(built)
+    g = np.load(os.path.join(GOLDEN, "v17tx.npz"))
+    for i, (bit_rate, tep, seed) in enumerate(V17TX_CASES):
+        amp, snaps = v29tx_run(orc.V17Tx(bit_rate, tep, seed), seed, 9600 if bit_rate != 9600 else 14400, 260, True)
         assert np.array_equal(amp, g["amp_%d" % i]), i
         assert np.array_equal(snaps, g["snaps_%d" % i]), i
 

@@ -50,13 +50,14 @@ def synth_v29(n_ch, n_frames, dev, seed, fixture="v29_9600.npz"):
 
 
 def synth_v29_on_device(n_ch, n_frames, dev, stream, seed, modem="v29"):
-    """V.29 9600 bps / V.27ter 4800 bps input made where it is consumed: a transmitter bank (the reference's
+    """V.29 9600 bps / V.27ter 4800 bps / V.17 14400 bps input made where it is consumed: a transmitter bank (the reference's
     modulator, bit-exact, on the device) writes every channel's own transmission (its own data bits and level) frame
     by frame into HBM; AWGN is added with torch.  Returns int16 [n_frames, n_ch, FRAME]."""
     from spandsp_amd import engine
     rng = np.random.default_rng(seed)
     seeds = rng.integers(1, 0x7FFF, n_ch).astype(np.uint32)
-    tx = engine.V29TxBank(n_ch, 9600, False, seeds) if modem == "v29" else engine.V27terTxBank(n_ch, 4800, False, seeds)
+    tx = {"v29": lambda: engine.V29TxBank(n_ch, 9600, False, seeds), "v27ter": lambda: engine.V27terTxBank(n_ch, 4800, False, seeds),
+          "v17": lambda: engine.V17TxBank(n_ch, 14400, False, seeds)}[modem]()
     tx.set_stream(ctypes.c_void_p(stream.cuda_stream))
     for c in range(0, n_ch, 4):                             # a spread of levels (every 4th channel moved off -14 dBm0)
         tx.power(c, float(rng.uniform(-26.0, -10.0)))
@@ -66,7 +67,7 @@ def synth_v29_on_device(n_ch, n_frames, dev, stream, seed, modem="v29"):
     tx.sync()
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
-    sigma = torch.empty(1, n_ch, 1, device=dev).uniform_(1.0, 30.0 if modem == "v29" else 12.0, generator=gen)
+    sigma = torch.empty(1, n_ch, 1, device=dev).uniform_(1.0, {"v29": 30.0, "v27ter": 12.0, "v17": 10.0}[modem], generator=gen)
     for f0 in range(0, n_frames, 16):
         blk = out[f0:f0 + 16].float()
         blk = blk + sigma*torch.randn(blk.shape, device=dev, generator=gen)
@@ -567,7 +568,7 @@ def main():
     ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     ap.add_argument("--replay-fixture", action="store_true",
-                    help="v29 / v27ter: replay the committed reference transmission instead of running the transmitter bank")
+                    help="v29 / v27ter / v17: replay the committed reference transmission instead of running the transmitter bank")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs a HIP device; the engine has no CPU fallback")
@@ -602,7 +603,7 @@ def main():
     kind = {"v29": engine.V29, "v17": engine.V17, "v27ter": engine.V27TER}[args.workload]
     n_ch = args.channels or 16384
     nf = args.steps + args.warmup
-    if args.workload in ("v29", "v27ter") and not args.replay_fixture:
+    if args.workload in ("v29", "v27ter", "v17") and not args.replay_fixture:
         frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem=args.workload)
     else:
         frames = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture)
