@@ -36,9 +36,28 @@ def test_no_cpu_fallback(built):
     from spandsp_amd import engine
     if engine.device_count() > 0:
         pytest.skip("a GPU is visible")
-    with pytest.raises(engine.SpanGpuError) as ei:
-        engine.ToneBank(engine.DTMF, 64)
-    assert ei.value.code == -1          # SPANGPU_ERR_NO_DEVICE
+    makers = [lambda: engine.ToneBank(engine.DTMF, 64), lambda: engine.V29Bank(64, 9600), lambda: engine.V27terBank(64, 4800),
+              lambda: engine.V17Bank(64, 14400), lambda: engine.EchoBank(64, 128, 1), lambda: engine.FskBank(engine.FSK_V21CH2, 64),
+              lambda: engine.MctBank(engine.MCT_FAX_CED_OR_PREAMBLE, 64), lambda: engine.TxBank(engine.TX_DTMF, 64),
+              lambda: engine.V29TxBank(64), lambda: engine.V27terTxBank(64), lambda: engine.V17TxBank(64)]
+    for make in makers:
+        with pytest.raises(engine.SpanGpuError) as ei:
+            make()
+        assert ei.value.code == -1      # SPANGPU_ERR_NO_DEVICE
+
+
+def test_bad_arguments_are_refused_before_any_device_work(built):
+    """Argument validation does not need a GPU: every create call names its mistake with SPANGPU_ERR_BAD_ARG (-2)
+    or SPANGPU_ERR_UNSUPPORTED (-6)."""
+    from spandsp_amd import engine
+    bad = [lambda: engine.V29Bank(64, 1234), lambda: engine.V27terBank(64, 9600), lambda: engine.V17Bank(64, 2400),
+           lambda: engine.EchoBank(64, 100, 1), lambda: engine.FskBank(engine.FSK_V21CH2, 0), lambda: engine.FskBank(99, 64),
+           lambda: engine.MctBank(42, 64), lambda: engine.TxBank(99, 64), lambda: engine.V29TxBank(64, 2400),
+           lambda: engine.V27terTxBank(64, 9600), lambda: engine.V17TxBank(64, 2400), lambda: engine.ToneBank(engine.DTMF, 0)]
+    for make in bad:
+        with pytest.raises(engine.SpanGpuError) as ei:
+            make()
+        assert ei.value.code in (-2, -6), ei.value
 
 
 def test_goertzel_fac_matches_oracle(built):
