@@ -98,7 +98,7 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     e->taps = taps;
     // Sixteen lanes per channel by default.  Eight (spangpu_tune_echo_lanes_per_channel) put twice the channels
     // behind the replicated control code, but the 16-tap slices then need ~250 VGPRs and the two come out even
-    // (1.16 ms against 1.13 ms for 131072 x 128 taps), so it stays an option for A-B tests.
+    // (1.14 ms against 0.98 ms for 131072 x 128 taps), so it stays an option for A-B tests.
     e->group = (g_echo_group != 0)  ?  g_echo_group  :  16;
     if (taps/e->group < 2  ||  taps/e->group > 16)
         e->group = 16;
