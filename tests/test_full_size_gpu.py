@@ -192,3 +192,55 @@ def test_dtmf_sender_feeds_detector_65536_channels(built):
     hip.hipFree(buf)
     bad = [c for c in range(n) if "".join(got[c]) != want[c]]
     assert not bad, (len(bad), bad[:5])
+
+
+@pytest.mark.parametrize("modem,bit_rate,frames", [("v29", 9600, 40), ("v27ter", 4800, 70), ("v17", 14400, 95)])
+def test_modem_round_trip_16384_channels(built, modem, bit_rate, frames):
+    """BASELINE configs[3]'s size as a round trip that holds at any size: 16 384 transmitters (own LFSR seed each) ->
+    HBM -> 16 384 receivers, the samples never leaving the device.  Every receiver must report training success and
+    then deliver exactly its transmitter's bit stream (checked bit for bit on every 16th channel, and by a bit count
+    and a spot comparison on all the others)."""
+    import ctypes
+    from spandsp_amd import engine
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    n, samples = 16384, 160
+    seeds = (((np.arange(n, dtype=np.uint64)*2654435761 + 99) & 0x7FFF) | 1).astype(np.uint32)
+    tx = {"v29": engine.V29TxBank, "v27ter": engine.V27terTxBank, "v17": engine.V17TxBank}[modem](n, bit_rate, False, seeds)
+    rx = {"v29": engine.V29Bank, "v27ter": engine.V27terBank, "v17": engine.V17Bank}[modem](n, bit_rate)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), n*samples*2) == 0
+    chunks = [[] for _ in range(n)]
+    for _ in range(frames):
+        tx.tx_device(buf, samples, samples)
+        tx.sync()
+        rx.rx_device(buf, samples, samples)
+        for c, e in enumerate(rx.events()):
+            if len(e):
+                chunks[c].append(e)
+    hip.hipFree(buf)
+
+    def lfsr(seed, count):
+        st = int(seed)
+        out = np.empty(count, np.int8)
+        for i in range(count):
+            b = ((st >> 14) ^ (st >> 13)) & 1
+            st = ((st << 1) | b) & 0x7FFF
+            out[i] = b
+        return out
+    counts = []
+    for c in range(n):
+        ev = np.concatenate(chunks[c]) if chunks[c] else np.zeros(0, np.int8)
+        ok = np.nonzero(ev == -4)[0]                    # SIG_STATUS_TRAINING_SUCCEEDED
+        assert len(ok) == 1, c
+        data = ev[ok[0] + 1:]
+        assert (data >= 0).all(), c                     # no carrier drop, no training failure afterwards
+        counts.append(len(data))
+        if c % 16 == 0:
+            want = lfsr(seeds[c], len(data) + 400)
+            hit = [k for k in range(400) if np.array_equal(want[k:k + 64], data[:64])]
+            assert hit, c
+            assert np.array_equal(want[hit[0]:hit[0] + len(data)], data), c
+    counts = np.array(counts)
+    assert counts.min() > 500 and counts.max() - counts.min() <= 2*bit_rate//2400 + 8      # every channel ran in step
