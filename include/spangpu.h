@@ -464,6 +464,35 @@ SPANGPU_API int spangpu_modemtx_get_state(spangpu_modemtx_t *tx, int channel, in
 /* The pulse shaper tables as built by this library (host code): which = 0 V.29, 1 V.27ter 4800 bps, 2 V.27ter 2400 bps */
 SPANGPU_API int spangpu_modemtx_table(int which, float *out, int max);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Noise source banks: batched awgn() -- one independent Gaussian noise generator per channel (Numerical Recipes
+ * ran1 + polar Box-Muller in binary64, as the reference), written to, or mixed with saturation into, a
+ * [channel][stride] int16 buffer.
+ *   spangpu_awgn_create() / _reinit()   awgn_init_dbm0(NULL, idum, level)      src/awgn.c:127-152 (ran_init :82-105)
+ *   spangpu_awgn_tx()                   awgn(s) x samples x N                  src/awgn.c:168-195
+ * Exactness: the uniform generator, the accept / reject sequence and all arithmetic but one call are IEEE
+ * binary64 operations identical to the reference's; the one call is libm's log(), which the reference takes from
+ * the host's C library (glibc picks an FMA or non-FMA variant per CPU) and this library takes from the device
+ * maths library.  Both are within 1 ulp, which cannot move a scaled sample by more than 2^-34, so the int16
+ * output differs from the reference's only for a sample that lies within that distance of a rounding tie.  The
+ * kernel counts every sample within 2^-30 of a tie: spangpu_awgn_uncertain() == 0 proves the output identical.
+ */
+typedef struct spangpu_awgn_s spangpu_awgn_t;
+
+SPANGPU_API int spangpu_awgn_create(spangpu_awgn_t **bank, int device, int n_channels, const int32_t seeds[],
+                                    const float levels_dbm0[]);
+SPANGPU_API void spangpu_awgn_destroy(spangpu_awgn_t *bank);
+SPANGPU_API int spangpu_awgn_channels(const spangpu_awgn_t *bank);
+SPANGPU_API int spangpu_awgn_set_stream(spangpu_awgn_t *bank, void *hip_stream);
+SPANGPU_API int spangpu_awgn_sync(spangpu_awgn_t *bank);
+SPANGPU_API int spangpu_awgn_reinit(spangpu_awgn_t *bank, int channel, int seed, float level_dbm0);
+/* mix = 0: pcm[channel*stride + i] = awgn();  mix = 1: pcm[...] = saturate16(pcm[...] + awgn());  returns samples */
+SPANGPU_API int spangpu_awgn_tx(spangpu_awgn_t *bank, int mem, int16_t *pcm, long long stride, int samples, int mix);
+/* samples, since creation, that fell within 2^-30 of a rounding tie (see above); synchronises the bank's stream */
+SPANGPU_API int spangpu_awgn_uncertain(spangpu_awgn_t *bank, long long *count);
+SPANGPU_API int spangpu_awgn_state_words(const spangpu_awgn_t *bank);
+SPANGPU_API int spangpu_awgn_get_state(spangpu_awgn_t *bank, int channel, int32_t *words);
+
 #if defined(__cplusplus)
 }
 #endif

@@ -662,6 +662,23 @@ ORC_API int orc_v17_tx_restart(orc_v17_tx_t *s, int bit_rate, int tep, int short
 ORC_API void orc_v17_tx_power(orc_v17_tx_t *s, float power);
 ORC_API int orc_v17_tx(orc_v17_tx_t *s, int16_t amp[], int len);
 
+/* ---- AWGN (awgn_oracle.c); field order = the device state (doubles as two words, low first) ---- */
+typedef struct
+{
+    double rms;
+    double amp2;
+    int32_t odd;
+    int32_t ix1;
+    int32_t ix2;
+    int32_t ix3;
+    double r[97];
+} orc_awgn_t;
+
+ORC_API int orc_awgn_sizeof(void);
+ORC_API void orc_awgn_init_dbm0(orc_awgn_t *s, int idum, float level);
+ORC_API int16_t orc_awgn(orc_awgn_t *s);
+ORC_API void orc_awgn_block(orc_awgn_t *s, int16_t out[], int n);
+
 /* ---- modem connect tones (mct_oracle.c) ---- */
 #define ORC_MCT_FAX_CNG             1
 #define ORC_MCT_ANS                 2

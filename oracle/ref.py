@@ -85,6 +85,7 @@ def lib():
             "tone_gen_descriptor_free": (None, [vp]),
             "tone_gen_init": (vp, [vp, vp]), "tone_gen": (ci, [vp, vp, ci]), "tone_gen_free": (ci, [vp]),
             "awgn_init_dbm0": (vp, [vp, ci, cf]), "awgn": (C.c_int16, [vp]), "awgn_free": (ci, [vp]),
+            "glue_awgn_run": (ci, [ci, cf, vp, ci, vp]),
             "echo_can_init": (vp, [ci, ci]), "echo_can_free": (ci, [vp]), "echo_can_flush": (None, [vp]),
             "echo_can_adaption_mode": (None, [vp, ci]),
             "echo_can_update": (C.c_int16, [vp, C.c_int16, C.c_int16]),
@@ -458,12 +459,20 @@ class ToneGen(_RefSender):
         lib().tone_gen_descriptor_free(d)
 
 
+def _awgn_run(seed, level_dbm0, samples):
+    out = np.zeros(max(samples, 1), np.int16)
+    words = np.zeros(202, np.uint32)
+    assert lib().glue_awgn_run(seed, level_dbm0, out.ctypes.data, samples, words.ctypes.data) == 202
+    return out[:samples], words
+
+
 def awgn(seed, level_dbm0, samples):
-    L = lib()
-    s = L.awgn_init_dbm0(None, seed, level_dbm0)
-    out = np.array([L.awgn(s) for _ in range(samples)], dtype=np.int16)
-    L.awgn_free(s)
-    return out
+    return _awgn_run(seed, level_dbm0, samples)[0]
+
+
+def awgn_state_words(seed, level_dbm0, samples):
+    """The generator's state after `samples` calls, in the oracle / device word layout."""
+    return _awgn_run(seed, level_dbm0, samples)[1]
 
 
 def saturated_add(a, b):

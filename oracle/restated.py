@@ -87,6 +87,9 @@ def lib():
             "orc_v17_tx_restart": (ci, [vp, ci, ci, ci]),
             "orc_v17_tx_power": (None, [vp, cf]),
             "orc_v17_tx": (ci, [vp, vp, ci]),
+            "orc_awgn_sizeof": (ci, []),
+            "orc_awgn_init_dbm0": (None, [vp, ci, cf]),
+            "orc_awgn_block": (None, [vp, vp, ci]),
             "orc_v29_tx_sizeof": (ci, []),
             "orc_v29_tx_set_table": (None, [vp]),
             "orc_v29_tx_init": (ci, [vp, ci, ci, C.c_uint32]),
@@ -671,3 +674,22 @@ class V17Tx(V29Tx):
         out = np.zeros(max(n, 1), np.int16)
         got = lib().orc_v17_tx(self.p, out.ctypes.data, n)
         return out[:got].copy()
+
+
+# ---- AWGN (awgn_oracle.c) ---------------------------------------------------------------------
+class Awgn:
+    WORDS = 2*(2 + 97) + 4
+
+    def __init__(self, seed, level_dbm0):
+        assert lib().orc_awgn_sizeof() == 4*self.WORDS
+        self.buf = np.zeros(self.WORDS, np.uint32)
+        self.p = self.buf.ctypes.data
+        lib().orc_awgn_init_dbm0(self.p, seed, level_dbm0)
+
+    def gen(self, n):
+        out = np.zeros(n, np.int16)
+        lib().orc_awgn_block(self.p, out.ctypes.data, n)
+        return out
+
+    def snapshot(self):
+        return self.buf.copy()

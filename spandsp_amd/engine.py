@@ -86,6 +86,16 @@ def lib():
             "spangpu_modemtx_state_words": (ci, []),
             "spangpu_modemtx_get_state": (ci, [vp, ci, vp]),
             "spangpu_modemtx_table": (ci, [ci, vp, ci]),
+            "spangpu_awgn_create": (ci, [C.POINTER(vp), ci, ci, vp, vp]),
+            "spangpu_awgn_destroy": (None, [vp]),
+            "spangpu_awgn_channels": (ci, [vp]),
+            "spangpu_awgn_set_stream": (ci, [vp, vp]),
+            "spangpu_awgn_sync": (ci, [vp]),
+            "spangpu_awgn_reinit": (ci, [vp, ci, ci, cf]),
+            "spangpu_awgn_tx": (ci, [vp, ci, vp, ll, ci, ci]),
+            "spangpu_awgn_uncertain": (ci, [vp, C.POINTER(ll)]),
+            "spangpu_awgn_state_words": (ci, [vp]),
+            "spangpu_awgn_get_state": (ci, [vp, ci, vp]),
             "spangpu_mct_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
             "spangpu_mct_destroy": (None, [vp]),
             "spangpu_mct_channels": (ci, [vp]),
@@ -773,3 +783,57 @@ class V27terTxBank(ModemTxBank):
 class V17TxBank(ModemTxBank):
     def __init__(self, n_channels, bit_rate=14400, tep=False, seeds=None, device=0):
         super().__init__(V17, n_channels, bit_rate, tep, seeds, device)
+
+
+class AwgnBank:
+    """N Gaussian noise generators (awgn_init_dbm0 / awgn), state in HBM."""
+
+    def __init__(self, seeds, levels_dbm0, device=0):
+        seeds = np.ascontiguousarray(seeds, np.int32)
+        levels = np.ascontiguousarray(levels_dbm0, np.float32)
+        assert len(seeds) == len(levels)
+        self.n = len(seeds)
+        self.h = C.c_void_p()
+        _check(lib().spangpu_awgn_create(C.byref(self.h), device, self.n, seeds.ctypes.data, levels.ctypes.data))
+
+    def close(self):
+        if self.h:
+            lib().spangpu_awgn_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(lib().spangpu_awgn_set_stream(self.h, hip_stream))
+
+    def sync(self):
+        _check(lib().spangpu_awgn_sync(self.h))
+
+    def reinit(self, channel, seed, level_dbm0):
+        _check(lib().spangpu_awgn_reinit(self.h, channel, seed, level_dbm0))
+
+    def tx_host(self, samples, mix_into=None):
+        if mix_into is None:
+            pcm = np.zeros((self.n, samples), np.int16)
+        else:
+            pcm = np.ascontiguousarray(mix_into, np.int16).copy()
+            assert pcm.shape == (self.n, samples)
+        _check(lib().spangpu_awgn_tx(self.h, MEM_HOST, pcm.ctypes.data, samples, samples, int(mix_into is not None)))
+        return pcm
+
+    def tx_device(self, pcm_ptr, stride, samples, mix=False):
+        _check(lib().spangpu_awgn_tx(self.h, MEM_DEVICE, pcm_ptr, stride, samples, int(mix)))
+
+    def uncertain(self):
+        v = C.c_longlong(0)
+        _check(lib().spangpu_awgn_uncertain(self.h, C.byref(v)))
+        return v.value
+
+    def get_state(self, channel):
+        w = np.zeros(lib().spangpu_awgn_state_words(self.h), np.uint32)
+        _check(lib().spangpu_awgn_get_state(self.h, channel, w.ctypes.data))
+        return w

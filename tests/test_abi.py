@@ -39,7 +39,8 @@ def test_no_cpu_fallback(built):
     makers = [lambda: engine.ToneBank(engine.DTMF, 64), lambda: engine.V29Bank(64, 9600), lambda: engine.V27terBank(64, 4800),
               lambda: engine.V17Bank(64, 14400), lambda: engine.EchoBank(64, 128, 1), lambda: engine.FskBank(engine.FSK_V21CH2, 64),
               lambda: engine.MctBank(engine.MCT_FAX_CED_OR_PREAMBLE, 64), lambda: engine.TxBank(engine.TX_DTMF, 64),
-              lambda: engine.V29TxBank(64), lambda: engine.V27terTxBank(64), lambda: engine.V17TxBank(64)]
+              lambda: engine.V29TxBank(64), lambda: engine.V27terTxBank(64), lambda: engine.V17TxBank(64),
+              lambda: engine.AwgnBank([1]*64, [-30.0]*64)]
     for make in makers:
         with pytest.raises(engine.SpanGpuError) as ei:
             make()
@@ -53,7 +54,8 @@ def test_bad_arguments_are_refused_before_any_device_work(built):
     bad = [lambda: engine.V29Bank(64, 1234), lambda: engine.V27terBank(64, 9600), lambda: engine.V17Bank(64, 2400),
            lambda: engine.EchoBank(64, 100, 1), lambda: engine.FskBank(engine.FSK_V21CH2, 0), lambda: engine.FskBank(99, 64),
            lambda: engine.MctBank(42, 64), lambda: engine.TxBank(99, 64), lambda: engine.V29TxBank(64, 2400),
-           lambda: engine.V27terTxBank(64, 9600), lambda: engine.V17TxBank(64, 2400), lambda: engine.ToneBank(engine.DTMF, 0)]
+           lambda: engine.V27terTxBank(64, 9600), lambda: engine.V17TxBank(64, 2400), lambda: engine.ToneBank(engine.DTMF, 0),
+           lambda: engine.AwgnBank([], [])]
     for make in bad:
         with pytest.raises(engine.SpanGpuError) as ei:
             make()

@@ -244,3 +244,36 @@ def test_modem_round_trip_16384_channels(built, modem, bit_rate, frames):
             assert np.array_equal(want[hit[0]:hit[0] + len(data)], data), c
     counts = np.array(counts)
     assert counts.min() > 500 and counts.max() - counts.min() <= 2*bit_rate//2400 + 8      # every channel ran in step
+
+
+def test_awgn_65536_channels(built):
+    """The noise source bank at full size: a spread of channels against the oracle, and every channel against the
+    properties the domain offers (its own level, zero mean, channels with different seeds uncorrelated, channels
+    with the same seed identical)."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n = 65536
+    rng = np.random.default_rng(77)
+    seeds = rng.integers(1, 250000, n).astype(np.int32)
+    seeds[n//2:] = seeds[:n//2]                      # every generator has a twin
+    levels = rng.uniform(-40.0, -15.0, n//2).astype(np.float32)
+    levels = np.concatenate([levels, levels])
+    bank = engine.AwgnBank(seeds, levels)
+    frames = 12
+    out = np.concatenate([bank.tx_host(160) for _ in range(frames)], axis=1)
+    unsure = bank.uncertain()
+    picks = list(range(0, n, 997)) + [n - 1]
+    for c in picks:
+        want = orc.Awgn(int(seeds[c]), float(levels[c])).gen(160*frames)
+        bad = np.count_nonzero(out[c] != want)
+        assert bad <= unsure and (bad == 0 or np.abs(out[c].astype(np.int32) - want).max() == 1), (c, bad, unsure)
+    assert np.array_equal(out[:n//2], out[n//2:])
+    x = out[:n//2].astype(np.float64)
+    dbm0 = 10.0*np.log10(np.mean(x*x, axis=1)/32768.0**2) + 3.14 + 3.02
+    assert np.max(np.abs(dbm0 - levels[:n//2])) < 1.0          # 1920 samples: sigma of the estimate ~0.14 dB
+    assert abs(np.mean(x/np.std(x, axis=1, keepdims=True))) < 0.01
+    u = x/np.linalg.norm(x, axis=1, keepdims=True)
+    distinct = np.unique(seeds[:n//2], return_index=True)[1][:2048]
+    g = u[distinct] @ u[distinct].T
+    np.fill_diagonal(g, 0.0)
+    assert np.abs(g).max() < 0.2                               # 1/sqrt(1920) = 0.023 per pair, 4M pairs

@@ -695,6 +695,31 @@ def test_golden_v17_tx(built):
         assert np.array_equal(snaps, g["snaps_%d" % i]), i
 
 
+# ---- AWGN ---------------------------------------------------------------------------------------
+AWGN_CASES = [(1234567, -30.0), (1, -10.5), (-77, -50.0), (99999, 0.0), (0, 6.0), (424242, -90.0), (7, -35.25)]
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,level", AWGN_CASES)
+def test_awgn_live(built, seed, level):
+    from oracle import ref, restated as orc
+    o = orc.Awgn(seed, level)
+    assert np.array_equal(o.snapshot(), ref.awgn_state_words(seed, level, 0))
+    a = ref.awgn(seed, level, 30001)
+    b = np.concatenate([o.gen(1), o.gen(160), o.gen(29840)])
+    assert np.array_equal(a, b)
+    assert np.array_equal(o.snapshot(), ref.awgn_state_words(seed, level, 30001))
+
+
+def test_golden_awgn(built):
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, "awgn.npz"))
+    for i, (seed, level) in enumerate(AWGN_CASES):
+        o = orc.Awgn(seed, level)
+        assert np.array_equal(o.gen(30001), g["amp_%d" % i]), i
+        assert np.array_equal(o.snapshot(), g["state_%d" % i]), i
+
+
 def test_golden_v29_tx(built):
     from oracle import restated as orc
     use_v29_tx_table(built)

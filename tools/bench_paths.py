@@ -52,7 +52,7 @@ def synth_v29(n_ch, n_frames, dev, seed, fixture="v29_9600.npz"):
 def synth_v29_on_device(n_ch, n_frames, dev, stream, seed, modem="v29"):
     """V.29 9600 bps / V.27ter 4800 bps / V.17 14400 bps input made where it is consumed: a transmitter bank (the reference's
     modulator, bit-exact, on the device) writes every channel's own transmission (its own data bits and level) frame
-    by frame into HBM; AWGN is added with torch.  Returns int16 [n_frames, n_ch, FRAME]."""
+    by frame into HBM, and a noise source bank (the reference's awgn()) mixes line noise into it.  Returns int16 [n_frames, n_ch, FRAME]."""
     from spandsp_amd import engine
     rng = np.random.default_rng(seed)
     seeds = rng.integers(1, 0x7FFF, n_ch).astype(np.uint32)
@@ -65,13 +65,14 @@ def synth_v29_on_device(n_ch, n_frames, dev, stream, seed, modem="v29"):
     for f in range(n_frames):
         tx.tx_device(ctypes.c_void_p(out[f].data_ptr()), FRAME, FRAME)
     tx.sync()
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(seed)
-    sigma = torch.empty(1, n_ch, 1, device=dev).uniform_(1.0, {"v29": 30.0, "v27ter": 12.0, "v17": 10.0}[modem], generator=gen)
-    for f0 in range(0, n_frames, 16):
-        blk = out[f0:f0 + 16].float()
-        blk = blk + sigma*torch.randn(blk.shape, device=dev, generator=gen)
-        out[f0:f0 + 16] = torch.clamp(torch.round(blk), -32768, 32767).to(torch.int16)
+    # line noise from the noise source bank (the reference's awgn(), on the device), 1 .. top LSB rms per channel
+    top = {"v29": 30.0, "v27ter": 12.0, "v17": 10.0}[modem]
+    sigma = rng.uniform(1.0, top, n_ch)
+    noise = engine.AwgnBank(rng.integers(1, 2_000_000, n_ch), 20.0*np.log10(sigma/32768.0) + 3.14 + 3.02)
+    noise.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    for f in range(n_frames):
+        noise.tx_device(ctypes.c_void_p(out[f].data_ptr()), FRAME, FRAME, mix=True)
+    noise.sync()
     return out
 
 
@@ -112,6 +113,56 @@ def bench_v29_tx(args, dev, stream):
                      "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3,
                      "note": "sample-serial modulator, one channel per lane: latency bound at one wave per SIMD"},
         "cpu_baseline": None}
+
+
+def bench_awgn(args, dev, stream):
+    """the noise source bank (awgn x N) writing 160-sample frames into HBM."""
+    from spandsp_amd import engine
+    n_ch = args.channels or 65536
+    rng = np.random.default_rng(3)
+    bank = engine.AwgnBank(rng.integers(1, 2_000_000, n_ch), rng.uniform(-50.0, -10.0, n_ch))
+    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    out = torch.zeros(4, n_ch, FRAME, dtype=torch.int16, device=dev)
+
+    def step(i):
+        bank.tx_device(ctypes.c_void_p(out[i % 4].data_ptr()), FRAME, FRAME)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record(stream)
+        step(args.warmup + i)
+        evs[i][1].record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = [a.elapsed_time(b) for a, b in evs]
+    avg_ms = sum(per)/len(per)
+    rms = float(out.float().pow(2).mean().sqrt())
+    alg = n_ch*(FRAME*2 + 2*202*4)
+    value = args.steps*n_ch*FRAME/dt/1e6
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import ref
+        t1 = time.perf_counter()
+        n_cpu = 0
+        while time.perf_counter() - t1 < 5.0:
+            ref.awgn(12345 + n_cpu, -30.0, 400000)
+            n_cpu += 400000
+        cpu = {"value": n_cpu/(time.perf_counter() - t1)/1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
+               "sample": "oracle/_ref awgn(), 400000-sample runs for 5 s on one thread"}
+    return {
+        "metric": "Msamples/s of batched awgn (noise source bank)", "value": value, "unit": "Msamples/s",
+        "realtime_channels": value*1e6/8000.0, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt*1e3/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "config": {"workload": "awgn bank, %d channels x %d-sample frames" % (n_ch, FRAME),
+                                        "channels_per_gpu": n_ch, "rms_of_last_frames": rms, "uncertain_samples": bank.uncertain()},
+        "roofline": {"bound": "hbm", "kernel": "awgn_bank_kernel", "achieved": alg/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": alg/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None, "alg_bytes_per_launch": alg,
+                     "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3,
+                     "note": "binary64 Box-Muller (log, sqrt, divide per pair) behind a data-dependent LDS shuffle table"},
+        "cpu_baseline": cpu}
 
 
 def run_threads(n_ch, work):
@@ -560,7 +611,7 @@ def bench_dtmf_tx(args, dev, stream):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct", "v29_tx"], default="v29")
+    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct", "v29_tx", "awgn"], default="v29")
     ap.add_argument("--channels", type=int, default=0)
     ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
@@ -586,6 +637,9 @@ def main():
         return
     if args.workload == "v29_tx":
         print(json.dumps(bench_v29_tx(args, dev, stream)))
+        return
+    if args.workload == "awgn":
+        print(json.dumps(bench_awgn(args, dev, stream)))
         return
     if args.workload == "mct":
         sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -10,7 +10,7 @@ timeout 300 python $GRAFT_REPO_ROOT/bench.py > $R/bench.json 2> $R/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench_stats -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 30 --no-cpu-baseline > $R/bench_stats.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/bench_fetch -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $R/bench_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/bench_write -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $R/bench_write.log 2>&1
-for w in mixed v29 v17 v27ter echo dtmf_tx fsk mct v29_tx; do
+for w in mixed v29 v17 v27ter echo dtmf_tx fsk mct v29_tx awgn; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/${w}_stats -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --no-cpu-baseline > $R/${w}_stats.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
