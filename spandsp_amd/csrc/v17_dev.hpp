@@ -91,8 +91,12 @@ void v17_bank_kernel(const V17Launch L)
     __shared__ uint32_t t_map[36*36*2];
     __shared__ uint16_t t_sqrt[194];
     // per-lane RRC delay line (doubled) + survivor memory, PCM tile, equaliser taps: all index-major [word][CPW]
-    __shared__ float lanes[CPW*(2*kRrcLen + 16 + 32)];
-    __shared__ uint32_t pcm[CPW*(kPcmTile/2)];
+    // (the RRC delay line as zero padded pairs, see v29_dev.hpp)
+    __shared__ float2 lanes[CPW*2*kRrcLen];
+    __shared__ uint32_t surv[CPW*(16 + 32)];
+    // (a full wave's LDS must stay under half a CU's 160 KB so that two waves share a CU: shorter PCM tile there)
+    constexpr int kTile = (CPW == 64)  ?  32  :  kPcmTile;
+    __shared__ uint32_t pcm[CPW*(kTile/2)];
     __shared__ float2 taps[kEqLen*CPW];
 
     const int lane = threadIdx.x;
@@ -136,8 +140,8 @@ void v17_bank_kernel(const V17Launch L)
     auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV17Floats + w)*N + ch] = (uint32_t) v; };
 
-    float *rrc2 = &lanes[lane];                         // [2*27] words, stride CPW
-    uint32_t *past = (uint32_t *) (rrc2 + 2*kRrcLen*CPW);  // [16]: 8 x 3 bit predecessor states per time step
+    float2 *rrc2 = &lanes[lane];                        // [2*27] pairs, stride CPW
+    uint32_t *past = &surv[lane];                        // [16]: 8 x 3 bit predecessor states per time step
     uint32_t *full = past + 16*CPW;                     // [16][2]: 8 x 1 byte surviving points per time step
 #define RRC2(k)     rrc2[(k)*CPW]
     float2 *ctap = &taps[lane];
@@ -161,8 +165,8 @@ void v17_bank_kernel(const V17Launch L)
     for (int i = 0;  i < kRrcLen;  i++)
     {
         const float v = ldf(VF_RRC + i);
-        RRC2(i) = v;
-        RRC2(kRrcLen + i) = v;
+        RRC2(i) = make_float2(v, 0.0f);
+        RRC2(kRrcLen + i) = make_float2(0.0f, v);
     }
     for (int i = 0;  i < kEqLen;  i++)
         TAP(i) = make_float2(ldf(VF_EQ_COEFF + 2*i), ldf(VF_EQ_COEFF + 2*i + 1));
@@ -243,7 +247,7 @@ void v17_bank_kernel(const V17Launch L)
     auto restart = [&]()
     {
         for (int i = 0;  i < 2*kRrcLen;  i++)
-            RRC2(i) = 0.0f;
+            RRC2(i) = make_float2(0.0f, 0.0f);
         training_error = 0.0f;
         rrc_step = 0;
         diff = 1;
@@ -308,32 +312,25 @@ void v17_bank_kernel(const V17Launch L)
         baud_half = 0;
     };
 
+    // vec_circular_dot_prodf() with its two partial sums kept in the halves of a packed pair (see v29_dev.hpp)
     auto rrc_dot = [&](const float *table, int row)
     {
         const float *y = table + row;
-        const float *x = rrc2 + rrc_step*CPW;
-        const int split = kRrcLen - rrc_step;
-        float xs[kRrcLen];
+        const float2 *x = rrc2 + rrc_step*CPW;
+        f32x2v xs[kRrcLen];
         float ys[kRrcLen];
 #pragma unroll
         for (int i = 0;  i < kRrcLen;  i++)
         {
-            xs[i] = x[i*CPW];
+            const float2 w = x[i*CPW];
+            xs[i] = (f32x2v) {w.x, w.y};
             ys[i] = y[i*kV17Sets];
         }
-        float a = 0.0f;
-        float first = 0.0f;
+        f32x2v a = {0.0f, 0.0f};
 #pragma unroll
         for (int i = 0;  i < kRrcLen;  i++)
-        {
-            if (i == split)
-            {
-                first = a;
-                a = 0.0f;
-            }
-            a += xs[i]*ys[i];
-        }
-        return first + a;
+            a += xs[i]*(f32x2v) {ys[i], ys[i]};
+        return a.x + a.y;
     };
     // track_carrier() and tune_equalizer() are requested by the stage logic and carried out once, after it, with the
     // loop gains and step size as they were when the reference would have called them (see v29_dev.hpp).
@@ -524,17 +521,17 @@ void v17_bank_kernel(const V17Launch L)
     };
 
     const int16_t *src = L.amp + (size_t) ch*L.stride;
-    for (int tile = 0;  tile < L.samples;  tile += kPcmTile)
+    for (int tile = 0;  tile < L.samples;  tile += kTile)
     {
-    const int tn = min(kPcmTile, L.samples - tile);
+    const int tn = min(kTile, L.samples - tile);
     // ---- stage this lane's stretch of PCM: pcm[k][lane] = samples 2k, 2k+1 of the tile ----------------------
     {
         const int16_t *row = src + tile;
-        const bool wide = ((((uintptr_t) row) & 15) == 0)  &&  (tn == kPcmTile);
+        const bool wide = ((((uintptr_t) row) & 15) == 0)  &&  (tn == kTile);
         if (wide)
         {
 #pragma unroll
-            for (int k = 0;  k < kPcmTile/8;  k++)
+            for (int k = 0;  k < kTile/8;  k++)
             {
                 const int4 v = ((const int4 *) row)[k];
                 pcm[(4*k + 0)*CPW + lane] = (uint32_t) v.x;
@@ -578,8 +575,8 @@ void v17_bank_kernel(const V17Launch L)
         pos++;
         do
         {
-        RRC2(rrc_step) = (float) amp;
-        RRC2(rrc_step + kRrcLen) = (float) amp;
+        RRC2(rrc_step).x = (float) amp;
+        RRC2(rrc_step + kRrcLen).y = (float) amp;
         if (++rrc_step >= kRrcLen)
             rrc_step = 0;
 
@@ -1069,7 +1066,7 @@ void v17_bank_kernel(const V17Launch L)
     stf(VF_GDC + 1, gdc1);
     stf(VF_BAUD_PHASE, baud_phase);
     for (int i = 0;  i < kRrcLen;  i++)
-        stf(VF_RRC + i, RRC2(i));
+        stf(VF_RRC + i, RRC2(i).x);
     for (int i = 0;  i < kEqLen;  i++)
     {
         const float2 c = TAP(i);

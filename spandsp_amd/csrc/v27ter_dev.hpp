@@ -81,7 +81,8 @@ void v27ter_bank_kernel(const V27Launch L)
     __shared__ float t_sine[2048];
     __shared__ uint16_t t_sqrt[194];
     // per-lane RRC delay line (doubled) and PCM tile, index-major [word][CPW]; equaliser taps {re, im} [tap][lane]
-    __shared__ float lanes[CPW*2*kRrcLen];
+    // RRC delay line as zero padded pairs, see v29_dev.hpp
+    __shared__ float2 lanes[CPW*2*kRrcLen];
     __shared__ uint32_t pcm[CPW*(kPcmTile/2)];
     __shared__ float2 taps[kV27EqLen*CPW];
 
@@ -117,7 +118,7 @@ void v27ter_bank_kernel(const V27Launch L)
     auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV27Floats + w)*N + ch] = (uint32_t) v; };
 
-    float *rrc2 = &lanes[lane];                         // [2*27] words, stride CPW
+    float2 *rrc2 = &lanes[lane];                        // [2*27] pairs, stride CPW
 #define RRC2(k)     rrc2[(k)*CPW]
     float2 *ctap = &taps[lane];
 #define TAP(i)      ctap[(i)*CPW]
@@ -132,8 +133,8 @@ void v27ter_bank_kernel(const V27Launch L)
     for (int i = 0;  i < kRrcLen;  i++)
     {
         const float v = ldf(WF_RRC + i);
-        RRC2(i) = v;
-        RRC2(kRrcLen + i) = v;
+        RRC2(i) = make_float2(v, 0.0f);
+        RRC2(kRrcLen + i) = make_float2(0.0f, v);
     }
     for (int i = 0;  i < EQN;  i++)
         TAP(i) = make_float2(ldf(WF_EQ_COEFF + 2*i), ldf(WF_EQ_COEFF + 2*i + 1));
@@ -193,7 +194,7 @@ void v27ter_bank_kernel(const V27Launch L)
     auto restart = [&]()
     {
         for (int i = 0;  i < 2*kRrcLen;  i++)
-            RRC2(i) = 0.0f;
+            RRC2(i) = make_float2(0.0f, 0.0f);
         training_error = 0.0f;
         rrc_step = 0;
         scramble_reg = 0x3C;
@@ -232,32 +233,25 @@ void v27ter_bank_kernel(const V27Launch L)
         baud_half = 0;
     };
 
+    // vec_circular_dot_prodf() with its two partial sums kept in the halves of a packed pair (see v29_dev.hpp)
     auto rrc_dot = [&](const float *table, int row)
     {
         const float *y = table + row;
-        const float *x = rrc2 + rrc_step*CPW;
-        const int split = kRrcLen - rrc_step;
-        float xs[kRrcLen];
+        const float2 *x = rrc2 + rrc_step*CPW;
+        f32x2v xs[kRrcLen];
         float ys[kRrcLen];
 #pragma unroll
         for (int i = 0;  i < kRrcLen;  i++)
         {
-            xs[i] = x[i*CPW];
+            const float2 w = x[i*CPW];
+            xs[i] = (f32x2v) {w.x, w.y};
             ys[i] = y[i*kV27MaxSets];
         }
-        float a = 0.0f;
-        float first = 0.0f;
+        f32x2v a = {0.0f, 0.0f};
 #pragma unroll
         for (int i = 0;  i < kRrcLen;  i++)
-        {
-            if (i == split)
-            {
-                first = a;
-                a = 0.0f;
-            }
-            a += xs[i]*ys[i];
-        }
-        return first + a;
+            a += xs[i]*(f32x2v) {ys[i], ys[i]};
+        return a.x + a.y;
     };
     // track_carrier() and tune_equalizer() are requested by the stage logic and carried out once, after it, with the
     // loop gains as they were when the reference would have called them (see v29_dev.hpp).
@@ -434,8 +428,8 @@ void v27ter_bank_kernel(const V27Launch L)
         pos++;
         do
         {
-        RRC2(rrc_step) = (float) amp;
-        RRC2(rrc_step + kRrcLen) = (float) amp;
+        RRC2(rrc_step).x = (float) amp;
+        RRC2(rrc_step + kRrcLen).y = (float) amp;
         if (++rrc_step >= kRrcLen)
             rrc_step = 0;
 
@@ -765,7 +759,7 @@ void v27ter_bank_kernel(const V27Launch L)
     stf(WF_TRACK_P, carrier_track_p);
     stf(WF_TRACK_I, carrier_track_i);
     for (int i = 0;  i < kRrcLen;  i++)
-        stf(WF_RRC + i, RRC2(i));
+        stf(WF_RRC + i, RRC2(i).x);
     for (int i = 0;  i < EQN;  i++)
     {
         const float2 c = TAP(i);

@@ -13,12 +13,15 @@
 //     summation and as the order in which state is stored.  The 33 complex taps sit in LDS,
 //     [tap][lane], also always indexed by a compile-time tap number;
 //   * the RRC delay line lives in a per-lane LDS column, stored twice back to back so
-//     x[(pos + i) mod n] is the contiguous x2[pos + i]; the frame's PCM is staged there too;
+//     x[(pos + i) mod n] is the contiguous x2[pos + i], as zero padded pairs ({x, 0} then {0, x}) so that
+//     one packed multiply-add per tap forms both partial sums of the circular inner product; the frame's
+//     PCM is staged in LDS too;
 //   * the polyphase RRC table (48 x 27 x {re, im}) and the sine table live once per
 //     workgroup in LDS and are gathered by per-lane row;
 //   * inner products keep the reference's exact summation tree: ascending coefficient
 //     index, the circular split summed separately and added last (a per-lane split point,
-//     handled by snapshotting the accumulator instead of branching).
+//     handled by the zero padding above for the RRC filter and by snapshotting the accumulator,
+//     instead of branching, for the equaliser).
 // Execution is BAUD ALIGNED: a round of the main loop is one baud of every lane -- each lane
 // consumes samples from its LDS tile until ITS next T/2 instant, all lanes run the half-baud
 // phase together, twice, and then the baud phase (equaliser output, stage logic, carrier and
@@ -209,9 +212,11 @@ void v29_bank_kernel(const V29Launch L)
     __shared__ float t_const[32];
     __shared__ uint16_t t_sqrt[194];
     __shared__ uint8_t t_map[400];
-    // per-lane RRC delay line (doubled) and PCM tile, index-major [word][CPW]: lane l always uses bank (l mod 64)
-    // whatever its position
-    __shared__ float lanes[CPW*2*kRrcLen];
+    // per-lane RRC delay line and PCM tile, index-major [word][CPW]: lane l always uses the banks of (l mod 32)
+    // whatever its position.  The delay line is stored as 2*27 pairs: pair k < 27 is {x[k], 0}, pair 27 + k is
+    // {0, x[k]} -- the window of 27 pairs starting at the circular position then holds, in .x, the head part of
+    // vec_circular_dot_prodf()'s sum padded with zeros and, in .y, zeros followed by its wrapped part.
+    __shared__ float2 lanes[CPW*2*kRrcLen];
     __shared__ uint32_t pcm[CPW*(kPcmTile/2)];
     // equaliser taps {re, im}, [tap][lane]: always indexed by a compile-time tap number
     __shared__ float2 taps[kEqLen*CPW];
@@ -264,7 +269,7 @@ void v29_bank_kernel(const V29Launch L)
     auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV29Floats + w)*N + ch] = (uint32_t) v; };
 
-    float *rrc2 = &lanes[lane];                         // [2*27] words, stride CPW
+    float2 *rrc2 = &lanes[lane];                        // [2*27] pairs, stride CPW
 #define RRC2(k)     rrc2[(k)*CPW]
 
     float agc_scaling = ldf(VF_AGC);
@@ -283,8 +288,8 @@ void v29_bank_kernel(const V29Launch L)
     for (int i = 0;  i < kRrcLen;  i++)
     {
         const float v = ldf(VF_RRC + i);
-        RRC2(i) = v;
-        RRC2(kRrcLen + i) = v;
+        RRC2(i) = make_float2(v, 0.0f);
+        RRC2(kRrcLen + i) = make_float2(0.0f, v);
     }
     float2 *ctap = &taps[lane];
 #define TAP(i)      ctap[(i)*CPW]
@@ -348,7 +353,7 @@ void v29_bank_kernel(const V29Launch L)
     auto restart = [&]()
     {
         for (int i = 0;  i < 2*kRrcLen;  i++)
-            RRC2(i) = 0.0f;
+            RRC2(i) = make_float2(0.0f, 0.0f);
         rrc_step = 0;
         scramble_reg = 0;
         training_scramble_reg = 0x2A;
@@ -391,30 +396,24 @@ void v29_bank_kernel(const V29Launch L)
     auto rrc_dot = [&](const float *table, int row)
     {
         const float *y = table + row;
-        const float *x = rrc2 + rrc_step*CPW;
-        const int split = kRrcLen - rrc_step;
-        // all 54 LDS reads first (they do not depend on the running sum), so their latency overlaps
-        float xs[kRrcLen];
+        const float2 *x = rrc2 + rrc_step*CPW;
+        // all 54 LDS reads first (they do not depend on the running sums), so their latency overlaps
+        f32x2v xs[kRrcLen];
         float ys[kRrcLen];
 #pragma unroll
         for (int i = 0;  i < kRrcLen;  i++)
         {
-            xs[i] = x[i*CPW];
+            const float2 w = x[i*CPW];
+            xs[i] = (f32x2v) {w.x, w.y};
             ys[i] = y[i*kRrcSets];
         }
-        float a = 0.0f;
-        float first = 0.0f;
+        // .x: x[pos..n) . y[0..n-pos) then + 0*y (exact: a running sum that starts at +0 is never -0);
+        // .y: 0*y then x[0..pos) . y[n-pos..n) -- the reference's two partial sums, each in its own order
+        f32x2v a = {0.0f, 0.0f};
 #pragma unroll
         for (int i = 0;  i < kRrcLen;  i++)
-        {
-            if (i == split)
-            {
-                first = a;
-                a = 0.0f;
-            }
-            a += xs[i]*ys[i];
-        }
-        return first + a;
+            a += xs[i]*(f32x2v) {ys[i], ys[i]};
+        return a.x + a.y;
     };
 
     // track_carrier() and tune_equalizer() (v29rx.c:281-331) are requested by the stage logic and carried out once,
@@ -563,8 +562,8 @@ void v29_bank_kernel(const V29Launch L)
         do
         {
         // ---- v29_rx(), v29rx.c:885-961 --------------------------------------------------------
-        RRC2(rrc_step) = (float) amp;
-        RRC2(rrc_step + kRrcLen) = (float) amp;
+        RRC2(rrc_step).x = (float) amp;
+        RRC2(rrc_step + kRrcLen).y = (float) amp;
         if (++rrc_step >= kRrcLen)
             rrc_step = 0;
 
@@ -943,7 +942,7 @@ void v29_bank_kernel(const V29Launch L)
         stf(VF_GDC + 1, gdc1);
         stf(VF_BAUD_PHASE, baud_phase);
         for (int i = 0;  i < kRrcLen;  i++)
-            stf(VF_RRC + i, RRC2(i));
+            stf(VF_RRC + i, RRC2(i).x);
         for (int i = 0;  i < kEqLen;  i++)
         {
             const float2 c = TAP(i);
