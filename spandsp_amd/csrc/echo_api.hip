@@ -72,8 +72,8 @@ extern "C" {
 // Tuning / A-B testing: lanes per channel of banks created from now on (0 = choose by length, 8, 16).
 int spangpu_tune_echo_lanes_per_channel(int lanes)
 {
-    if (lanes != 0  &&  lanes != 8  &&  lanes != 16)
-        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "lanes per channel must be 0 (auto), 8 or 16");
+    if (lanes != 0  &&  lanes != 4  &&  lanes != 8  &&  lanes != 16)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "lanes per channel must be 0 (auto), 4, 8 or 16");
     g_echo_group = lanes;
     return SPANGPU_OK;
 }
@@ -100,7 +100,7 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     // behind the replicated control code, but the 16-tap slices then need ~250 VGPRs and the two come out even
     // (1.14 ms against 0.98 ms for 131072 x 128 taps), so it stays an option for A-B tests.
     e->group = (g_echo_group != 0)  ?  g_echo_group  :  16;
-    if (taps/e->group < 2  ||  taps/e->group > 16)
+    if (taps/e->group < 2  ||  taps/e->group > ((e->group == 4)  ?  32  :  16))
         e->group = 16;
     e->tpl = taps/e->group;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
@@ -253,7 +253,16 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
     const int per_wave = 64/e->group;
     const int waves = (e->n_ch + per_wave - 1)/per_wave;
     const int blocks = (waves + 3)/4;
-    if (e->group == 8)
+    if (e->group == 4)
+    {
+        switch (e->tpl)
+        {
+        case 8:  hipLaunchKernelGGL((echo_bank_kernel<8, 4>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
+        case 16: hipLaunchKernelGGL((echo_bank_kernel<16, 4>), dim3(blocks), dim3(256), 0, e->stream, L); break;
+        default: hipLaunchKernelGGL((echo_bank_kernel<32, 4>), dim3(blocks), dim3(256), 0, e->stream, L); break;
+        }
+    }
+    else if (e->group == 8)
     {
         switch (e->tpl)
         {

@@ -1,12 +1,11 @@
 // echo_dev.hpp -- device side of the batched G.168 line echo canceller
 // (reference: src/echo.c:120-661, src/spandsp/fir.h:121-183).
 //
-// Mapping: G = SIXTEEN OR EIGHT LANES PER CHANNEL, 64/G channels per wavefront (a 16-lane group is
-// exactly one DPP row, an 8-lane group half of one).  The scalar control below is replicated in the
-// lanes of a group, so it costs one instruction stream per WAVE whatever G is: eight lanes per
-// channel put twice the channels behind every control instruction, but need 16-tap slices for a
-// 128 tap canceller and with them ~250 VGPRs; measured, the two mappings come out even, and the
-// library uses G = 16 unless told otherwise.  Lane j of a group owns taps [j*TPL, (j+1)*TPL) of its channel for
+// Mapping: G = SIXTEEN, EIGHT OR FOUR LANES PER CHANNEL, 64/G channels per wavefront (a 16-lane group is
+// exactly one DPP row, an 8-lane group half of one, a 4-lane group a quad).  The scalar control below is
+// replicated in the lanes of a group, so it costs one instruction stream per WAVE whatever G is: fewer
+// lanes per channel put more channels behind every control instruction, at the price of longer tap slices
+// per lane (see DESIGN.md 4.2 for the measured trade).  Lane j of a group owns taps [j*TPL, (j+1)*TPL) of its channel for
 // the whole frame, in registers: the 32-bit LMS taps, the 16-bit FIR coefficients of the
 // active tap set, and the matching slice of the FIR history.  The history is held in
 // "window order" (w[0] = newest sample), so tap i always meets w[i]; advancing a sample
@@ -143,18 +142,108 @@ __device__ __forceinline__ int row_sum16(int v)
     return v;
 }
 
-// Register budget: the compiler's own choice (148 VGPRs at TPL = 8) leaves three waves per SIMD, too few to hide the
-// long dependent control chain of a sample; asking for five (96 VGPRs, a few spills to scratch) measured 13 % faster.
+// Bring the window registers from phase PH order (logical slot k in w[(k - PH) mod TPL]) back to phase 0 order.
+template <int PH, int TPL>
+__device__ __forceinline__ void echo_rotate_window(int (&w)[TPL])
+{
+    if constexpr ((PH%TPL) != 0)
+    {
+        int tmp[TPL];
+#pragma unroll
+        for (int k = 0;  k < TPL;  k++)
+            tmp[k] = w[(k - PH + 8*TPL)%TPL];
+#pragma unroll
+        for (int k = 0;  k < TPL;  k++)
+            w[k] = tmp[k];
+    }
+}
+
+// Run the common-sample body for phases PH .. U-1 of a round of U samples.  Returns the number of samples completed,
+// with the window registers back in phase 0 order: after a whole round (a no-op when U == TPL, a physical rotation by
+// U registers otherwise -- TPL moves per U samples, the price of unrolling only U times so that the loop stays inside
+// the instruction cache), or when a phase declines its sample (a set event).
+template <int PH, int U, int TPL, class F>
+__device__ __forceinline__ int echo_fast_round(F &fast, int (&w)[TPL], int idx)
+{
+    if constexpr (PH == U)
+    {
+        echo_rotate_window<U, TPL>(w);
+        return U;
+    }
+    else
+    {
+        if (!fast(idx + PH, std::integral_constant<int, PH>{}))
+        {
+            echo_rotate_window<PH, TPL>(w);
+            return PH;
+        }
+        return echo_fast_round<PH + 1, U, TPL>(fast, w, idx);
+    }
+}
+
+// Sum over the 4 lanes of a quad, result in every lane.
+__device__ __forceinline__ int row_sum4(int v)
+{
+    v += dpp_mov<0xB1>(0, v);       // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(0, v);       // quad_perm [2,3,0,1]
+    return v;
+}
+
+template <int G>
+__device__ __forceinline__ int group_sum(int v)
+{
+    return (G == 16)  ?  row_sum16(v)  :  (G == 8)  ?  row_sum8(v)  :  row_sum4(v);
+}
+
+// The history window moves one lane up inside a group; lane 0 of the group takes the new sample.
+template <int G>
+__device__ __forceinline__ int group_shift_in(int tx, int v, int j)
+{
+    if (G == 16)
+        return dpp_mov<0x111>(tx, v);                   // row_shr:1, lane 0 of the row keeps `old` = tx
+    if (G == 8)
+    {
+        v = dpp_mov<0x111>(tx, v);
+        return (j == 0)  ?  tx  :  v;                   // the second channel of the row starts at lane 8
+    }
+    v = dpp_mov<0x90>(tx, v);                           // quad_perm [0,0,1,2]
+    return (j == 0)  ?  tx  :  v;
+}
+
+// Structure of a pass.  A sample is one of two kinds.  COMMON samples run the straight-line `fast` body: history shift,
+// FIR, the power meters and, when the canceller is adapting, the LMS update; that body exists once per rotation phase of
+// the history registers (a round is U unrolled samples, within which the shift of the window inside a lane is
+// register renaming; a round ends with a physical rotation by U registers when U < TPL).
+// A sample on which any channel of the wave meets a SET EVENT (narrow-band test every 160 adapted samples, tap set
+// rotation every 1600, double-talk revert, divergence zap) -- all of which read or rewrite whole tap slices -- is
+// recognised from values the fast body has computed but not yet committed; the fast round is abandoned with the
+// registers brought back to phase 0 and the `slow` body, the complete per-sample algorithm, runs that one sample.
+// Keeping the set events out of the unrolled bodies is what lets eight or four lanes per channel pay off: with them
+// inline, a fifth of the instructions were register moves at their merge points.
+// The FIR runs on the active tap set's registers; while fir_set != tap_set (after echo_can_flush(), until the next
+// rotation) every sample of the wave takes the slow body, which then reads its FIR coefficients from HBM, where the
+// inactive sets are always current.
+// Register budget by tap slice length: 96 VGPRs (five waves per SIMD) up to 8 taps per lane, 168 (three) at 16,
+// 256 (two) at 32 -- at 32 taps per lane three waves' worth of registers put spills into the common-sample body.
+constexpr int echo_waves_per_simd(int tpl)
+{
+    return (tpl <= 8)  ?  5  :  3;
+}
+
 template <int TPL, int G>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((TPL <= 8)  ?  5  :  3, (TPL <= 8)  ?  5  :  3)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(echo_waves_per_simd(TPL), echo_waves_per_simd(TPL))))
 void echo_bank_kernel(const EchoLaunch L)
 {
-    static_assert(G == 16  ||  G == 8, "a channel's lanes are one DPP row or half of one");
+    static_assert(G == 16  ||  G == 8  ||  G == 4, "a channel's lanes are a DPP row, half of one, or a quad");
     constexpr int T = TPL*G;
     constexpr int kChPerWave = 64/G;
-    constexpr int kMaxFrame = (G == 16)  ?  160  :  128;    // samples staged per pass
-    __shared__ int io[4][kChPerWave][kMaxFrame];            // tx | rx<<16 per sample, then the clean output
-    __shared__ int bounce[4][kChPerWave][T];                // tap-set / history gathers at set events
+    constexpr int kMaxFrame = (G == 16)  ?  160  :  (G == 8)  ?  128  :  64;    // samples staged per pass
+    // samples per unrolled round: all TPL phases (measured at TPL = 32: 636 us against 679 us with rounds of 8, although
+    // the fully unrolled loop is larger than the instruction cache)
+    constexpr int U = TPL;
+    constexpr int NL = (9 + G - 1)/G;                       // autocorrelation lags per lane: lag = j + m*G < 9
+    __shared__ int io[4][kChPerWave][kMaxFrame + 1];        // tx | rx<<16 per sample, then the clean output (+1: read-ahead)
+    __shared__ short bounce[4][kChPerWave][T];              // tap-set / history gathers at set events
     __shared__ float acfbuf[4][kChPerWave][48];             // narrowband_detect scratch
 
     const int lane = threadIdx.x & 63;
@@ -171,7 +260,7 @@ void echo_bank_kernel(const EchoLaunch L)
     int16_t *g16 = L.taps16 + (size_t) ch*4*T + j*TPL;     // + set*T
     int16_t *gh = L.hist + (size_t) ch*T + j*TPL;
 
-    // ---- scalars (replicated in the 16 lanes of the group) --------------------------------
+    // ---- scalars (replicated in the lanes of the group) -----------------------------------
     int tx_power0 = sc[ES_TX_POWER0];
     int tx_power1 = sc[ES_TX_POWER1];
     int tx_power2 = sc[ES_TX_POWER2];
@@ -197,20 +286,20 @@ void echo_bank_kernel(const EchoLaunch L)
     int cng_filter = sc[ES_CNG_FILTER];
     int fir_set = sc[ES_FIR_SET];
     int vad = sc[ES_VAD];
-    int my_acf = (j < 9)  ?  sc[ES_LAST_ACF + j]  :  0;         // lane k holds last_acf[k]
-    int my_acf8 = (G == 8  &&  j == 0)  ?  sc[ES_LAST_ACF + 8]  :  0;     // eight lanes: lane 0 also holds last_acf[8]
+    int my_acf[NL];                                             // lane j holds last_acf[j + m*G]
+#pragma unroll
+    for (int m = 0;  m < NL;  m++)
+        my_acf[m] = (j + m*G < 9)  ?  sc[ES_LAST_ACF + j + m*G]  :  0;
 
     // ---- per-lane tap slices ------------------------------------------------------------------
     int t32[TPL];               // fir_taps32
     int t16[TPL];               // fir_taps16[tap_set], sign-extended
-    int f16[TPL];               // fir_taps16[fir_set] (== t16 unless a flush left them apart)
     int w[TPL];                 // history window slice, physical register order (see `phase`)
 #pragma unroll
     for (int k = 0;  k < TPL;  k++)
     {
         t32[k] = g32[k];
         t16[k] = g16[tap_set*T + k];
-        f16[k] = g16[fir_set*T + k];
         w[k] = gh[k];
     }
 
@@ -229,6 +318,45 @@ void echo_bank_kernel(const EchoLaunch L)
                 g16[set*T + k] = (int16_t) src[k];
         }
     };
+    // echo.c:613-651: the non-linear processor and comfort noise, then the position update and the output slot
+    auto finish_sample = [&](int idx, int tx, int clean_rx)
+    {
+        if (mode & kModeNlp)
+        {
+            if (rx_power1 < 30000000)
+            {
+                if (!cng)
+                {
+                    cng_level = clean_rx_power;
+                    cng = 1;
+                }
+                if (mode & kModeCng)
+                {
+                    cng_rndnum = (int) (1664525U*(uint32_t) cng_rndnum + 1013904223U);
+                    cng_filter = ((cng_rndnum & 0xFFFF) - 32768 + 5*cng_filter) >> 3;
+                    clean_rx = (int) ((uint32_t) cng_filter*(uint32_t) cng_level) >> 17;
+                }
+                else
+                {
+                    clean_rx = 0;
+                }
+            }
+            else
+            {
+                cng = 0;
+            }
+        }
+        else
+        {
+            cng = 0;
+        }
+        // echo.c:655-658
+        if (curr_pos <= 0)
+            curr_pos = T;
+        curr_pos--;
+        if (j == 0)
+            io[wv][g][idx] = ((int) (short) clean_rx & 0xFFFF) | (tx << 16);    // reuse the slot for the outputs
+    };
 
     for (int base = 0;  base < L.samples;  base += kMaxFrame)
     {
@@ -242,26 +370,30 @@ void echo_bank_kernel(const EchoLaunch L)
         }
         // (one wave per io/bounce/acfbuf slice; LDS ops of a wave complete in order)
 
-        // One sample.  PH is the compile-time rotation phase of the history registers:
-        // logical window slot k of this lane lives in w[(k - PH) mod TPL].
-        auto sample = [&](int idx, auto ph_tag)
+        // ---- a common sample.  PH is the compile-time rotation phase of the history registers: logical window
+        // slot k of this lane lives in w[(k - PH) mod TPL].  Returns false, with nothing changed, when some
+        // channel of the wave meets a set event on this sample.
+        int ahead = 0;
+        auto fast = [&](int idx, auto ph_tag) -> bool
         {
             constexpr int PH = decltype(ph_tag)::value;
-            const int word = io[wv][g][idx];
+            const int word = ahead;
+            ahead = io[wv][g][idx + 1];                         // the next sample's input, a whole sample early
             int tx = (int) (short) (word & 0xFFFF);
             int rx = (int) (short) (word >> 16);
+            int32_t n_txh0 = tx_hpf0;
+            int32_t n_txh1 = tx_hpf1;
+            int32_t n_rxh0 = rx_hpf0;
+            int32_t n_rxh1 = rx_hpf1;
             if (L.use_hpf_tx  &&  (mode & kModeTxHpf))
-                tx = echo_hpf(tx_hpf0, tx_hpf1, tx);            // echo.c:663-669
+                tx = echo_hpf(n_txh0, n_txh1, tx);              // echo.c:663-669
             if (mode & kModeRxHpf)
-                rx = echo_hpf(rx_hpf0, rx_hpf1, rx);            // echo.c:430
-
-            // fir16(): history[curr_pos] = tx, i.e. the window shifts by one (fir.h:168-183).
-            // The register that held this lane's oldest slot receives the previous lane's
-            // oldest sample; lane 0 of the group receives tx.
-            constexpr int NEWP = (TPL - 1 - PH + 8*TPL)%TPL;     // physical reg of logical slot TPL-1 before the shift
-            w[NEWP] = dpp_mov<0x111>(tx, w[NEWP]);              // row_shr:1, lane 0 keeps `old` = tx
-            if (G == 8)
-                w[NEWP] = (j == 0)  ?  tx  :  w[NEWP];          // the second channel of the row starts at lane 8
+                rx = echo_hpf(n_rxh0, n_rxh1, rx);              // echo.c:430
+            // fir16(): history[curr_pos] = tx, i.e. the window shifts by one (fir.h:168-183).  The register that
+            // held this lane's oldest slot receives the previous lane's oldest sample; lane 0 receives tx.
+            constexpr int NEWP = (TPL - 1 - PH + 8*TPL)%TPL;
+            const int w_old = w[NEWP];
+            w[NEWP] = group_shift_in<G>(tx, w_old, j);
             // after the shift the phase is PH + 1: logical k -> w[(k - PH - 1) mod TPL]
             // two accumulators: integer addition wraps and associates, so the order is free
             int y = 0;
@@ -269,11 +401,108 @@ void echo_bank_kernel(const EchoLaunch L)
 #pragma unroll
             for (int k = 0;  k < TPL;  k += 2)
             {
-                y = mad24(f16[k], w[(k - PH - 1 + 8*TPL)%TPL], y);
-                y1 = mad24(f16[k + 1], w[(k + 1 - PH - 1 + 8*TPL)%TPL], y1);
+                y = mad24(t16[k], w[(k - PH - 1 + 8*TPL)%TPL], y);
+                y1 = mad24(t16[k + 1], w[(k + 1 - PH - 1 + 8*TPL)%TPL], y1);
             }
-            y += y1;
-            y = (G == 16)  ?  row_sum16(y)  :  row_sum8(y);
+            y = group_sum<G>(y + y1);
+            const int echo_value = (int) (short) (y >> 15);
+            const int clean_rx = rx - echo_value;                // echo.c:452
+            const int n_dwell = nonupdate_dwell - ((nonupdate_dwell > 0)  ?  1  :  0);
+            // echo.c:463-469
+            const int n_tp3 = tx_power3 + ((abs(tx) - tx_power3) >> 5);
+            const int n_tp2 = tx_power2 + ((tx*tx - tx_power2) >> 8);
+            const int n_tp1 = tx_power1 + ((tx*tx - tx_power1) >> 5);
+            const int n_tp0 = tx_power0 + ((tx*tx - tx_power0) >> 3);
+            const int n_rp1 = rx_power1 + ((rx*rx - rx_power1) >> 6);
+            const int n_rp0 = rx_power0 + ((rx*rx - rx_power0) >> 3);
+            const int n_crp = clean_rx_power + (((int) ((uint32_t) clean_rx*(uint32_t) clean_rx) - clean_rx_power) >> 6);
+            // the set events (plain bit logic: with && and || hipcc builds these from exec-masked branches).  Testing the
+            // ones that do not need the FIR's result before it runs was tried: the values kept alive across the FIR cost
+            // more in spills than the abandoned work saves.
+            const bool loud = n_tp0 > 64*64;                     // MIN_TX_POWER_FOR_ADAPTION
+            const bool single = n_tp1 > n_rp0;
+            const bool adapting = loud & single & (n_dwell == 0);
+            const bool doubletalk = loud & !single;
+            const bool event = (adapting & ((narrowband_count >= 159) | (tap_rotate_counter <= 1)))
+                               | (doubletalk & (dtd_onset == 0))
+                               | ((n_rp1 > 2048*2048) & (n_crp > 4*n_rp1));
+            if (__any(event))
+            {
+                w[NEWP] = w_old;
+                return false;
+            }
+            tx_hpf0 = n_txh0;
+            tx_hpf1 = n_txh1;
+            rx_hpf0 = n_rxh0;
+            rx_hpf1 = n_rxh1;
+            nonupdate_dwell = n_dwell;
+            tx_power3 = n_tp3;
+            tx_power2 = n_tp2;
+            tx_power1 = n_tp1;
+            tx_power0 = n_tp0;
+            rx_power1 = n_rp1;
+            rx_power0 = n_rp0;
+            clean_rx_power = n_crp;
+            if (adapting)
+            {
+                narrowband_count++;
+                dtd_onset = 0;
+                tap_rotate_counter--;
+                if ((mode & kModeAdaption)  &&  narrowband_score == 0)
+                {
+                    // echo.c:530-553 + lms_adapt(), echo.c:232-249
+                    int factor = clean_rx;
+                    int sh;
+                    if (tx > 4*tx_power3)
+                        sh = top_bit_u32((uint32_t) tx) - 8;
+                    else
+                        sh = top_bit_u32((uint32_t) tx_power3) - 8;
+                    if (sh > 0)
+                        factor >>= sh;
+#pragma unroll
+                    for (int k = 0;  k < TPL;  k++)
+                    {
+                        t32[k] = mad24(w[(k - PH - 1 + 8*TPL)%TPL], factor, t32[k]);
+                        t16[k] = __builtin_amdgcn_sbfe(t32[k], 15, 16);
+                    }
+                }
+            }
+            nonupdate_dwell = doubletalk  ?  600  :  nonupdate_dwell;      // NONUPDATE_DWELL_TIME
+            finish_sample(idx, tx, clean_rx);
+            return true;
+        };
+
+        // ---- any sample, registers in phase 0: the whole of echo_can_update() ------------------------------------
+        auto slow = [&](int idx)
+        {
+            const int word = io[wv][g][idx];
+            int tx = (int) (short) (word & 0xFFFF);
+            int rx = (int) (short) (word >> 16);
+            if (L.use_hpf_tx  &&  (mode & kModeTxHpf))
+                tx = echo_hpf(tx_hpf0, tx_hpf1, tx);            // echo.c:663-669
+            if (mode & kModeRxHpf)
+                rx = echo_hpf(rx_hpf0, rx_hpf1, rx);            // echo.c:430
+            w[TPL - 1] = group_shift_in<G>(tx, w[TPL - 1], j);
+            // now logical k -> w[(k - 1) mod TPL]
+            int y = 0;
+            if (__all(fir_set == tap_set))
+            {
+#pragma unroll
+                for (int k = 0;  k < TPL;  k++)
+                    y = mad24(t16[k], w[(k - 1 + TPL)%TPL], y);
+            }
+            else
+            {
+                // the inactive sets are current in HBM (every set event stores what it changes)
+                const bool own = (fir_set == tap_set);
+#pragma unroll
+                for (int k = 0;  k < TPL;  k++)
+                {
+                    const int c = own  ?  t16[k]  :  (int) g16[fir_set*T + k];
+                    y = mad24(c, w[(k - 1 + TPL)%TPL], y);
+                }
+            }
+            y = group_sum<G>(y);
             const int echo_value = (int) (short) (y >> 15);
             int clean_rx = rx - echo_value;                     // echo.c:452
             if (nonupdate_dwell > 0)
@@ -287,6 +516,17 @@ void echo_bank_kernel(const EchoLaunch L)
             rx_power0 += ((rx*rx - rx_power0) >> 3);
             clean_rx_power += ((int) ((uint32_t) clean_rx*(uint32_t) clean_rx) - clean_rx_power) >> 6;
 
+            // fir_taps16[-1] is the FIR history (see the header): history[p] <- set[p]
+            auto set_over_history = [&]()
+            {
+#pragma unroll
+                for (int k = 0;  k < TPL;  k++)
+                    bounce[wv][g][j*TPL + k] = (short) t16[k];
+#pragma unroll
+                for (int k = 0;  k < TPL;  k++)
+                    w[(k - 1 + TPL)%TPL] = bounce[wv][g][(j*TPL + k + curr_pos)%T];
+            };
+
             if (tx_power0 > 64*64)                              // MIN_TX_POWER_FOR_ADAPTION
             {
                 if (tx_power1 > rx_power0)
@@ -297,7 +537,7 @@ void echo_bank_kernel(const EchoLaunch L)
                         {
                             narrowband_count = 0;
                             // ---- narrowband_detect(), echo.c:120-175 ---------------------------
-                            // window samples 0..31 -> LDS, then lanes 0..8 each own one lag
+                            // window samples 0..31 -> LDS, then every lag 0..8 has its lane (lane j: lags j, j + G, ...)
 #pragma unroll
                             for (int k = 0;  k < TPL;  k++)
                             {
@@ -305,21 +545,22 @@ void echo_bank_kernel(const EchoLaunch L)
                                 if (i < 32)
                                 {
                                     const bool inside = (T == 256)  ||  (curr_pos + i < T);
-                                    acfbuf[wv][g][i] = inside  ?  (float) w[(k - PH - 1 + 8*TPL)%TPL]  :  0.0f;
+                                    acfbuf[wv][g][i] = inside  ?  (float) w[(k - 1 + TPL)%TPL]  :  0.0f;
                                 }
                             }
-                            float temp = 0.0f;
-                            float temp8 = 0.0f;
-                            if (j < 9)
+                            float temp[NL];
+#pragma unroll
+                            for (int m = 0;  m < NL;  m++)
                             {
-                                for (int i = j;  i < 32;  i++)
-                                    temp += acfbuf[wv][g][i]*acfbuf[wv][g][i - j];
-                                acfbuf[wv][g][32 + j] = temp;
-                            }
-                            if (G == 8  &&  j == 0)
-                            {
-                                for (int i = 8;  i < 32;  i++)
-                                    temp8 += acfbuf[wv][g][i]*acfbuf[wv][g][i - 8];
+                                const int lag = j + m*G;
+                                temp[m] = 0.0f;
+                                if (lag < 9)
+                                {
+                                    for (int i = lag;  i < 32;  i++)
+                                        temp[m] += acfbuf[wv][g][i]*acfbuf[wv][g][i - lag];
+                                    if (lag == 0)
+                                        acfbuf[wv][g][32] = temp[m];
+                                }
                             }
                             const float scale = (float) 0x1FFFFFFF/acfbuf[wv][g][32];
                             auto similar = [](int before, int now) -> bool
@@ -331,18 +572,17 @@ void echo_bank_kernel(const EchoLaunch L)
                                     return ((before >> 1) > now)  &&  (now > (int) ((uint32_t) before << 1));
                                 return false;
                             };
-                            const int acf = f2i_x86(temp*scale);
-                            const int acf8 = f2i_x86(temp8*scale);
-                            const bool hit = similar(my_acf, acf);
-                            const bool hit8 = (G == 8  &&  j == 0)  &&  similar(my_acf8, acf8);
-                            const unsigned long long bal = __ballot(hit  &&  j < 9);
-                            const unsigned long long bal8 = __ballot(hit8);
-                            const int score = (G == 16)  ?  __popcll((bal >> (g*16)) & 0x1FFull)
-                                                         :  (__popcll((bal >> (g*8)) & 0xFFull) + (int) ((bal8 >> (g*8)) & 1ull));
-                            if (j < 9)
-                                my_acf = acf;
-                            if (G == 8  &&  j == 0)
-                                my_acf8 = acf8;
+                            int score = 0;
+#pragma unroll
+                            for (int m = 0;  m < NL;  m++)
+                            {
+                                const bool mine = (j + m*G < 9);
+                                const int acf = f2i_x86(temp[m]*scale);
+                                const unsigned long long bal = __ballot(mine  &&  similar(my_acf[m], acf));
+                                score += __popcll((bal >> (g*G)) & ((1ull << G) - 1ull));
+                                if (mine)
+                                    my_acf[m] = acf;
+                            }
                             if (score > 6)
                             {
                                 if (narrowband_score == 0)
@@ -351,8 +591,6 @@ void echo_bank_kernel(const EchoLaunch L)
                                     int tmp[TPL];
                                     load_set((tap_set + 1)%3, tmp);
                                     store_set(3, tmp);
-                                    if (fir_set == 3)
-                                        load_set(3, f16);
                                 }
                                 narrowband_score += score;
                             }
@@ -364,32 +602,12 @@ void echo_bank_kernel(const EchoLaunch L)
                                     load_set(3, t16);
                                     const int d2 = (tap_set - 1)%3;
                                     if (d2 >= 0)
-                                    {
                                         store_set(d2, t16);
-                                    }
                                     else
-                                    {
-                                        // fir_taps16[-1] is the FIR history: history[p] <- set[p]
-#pragma unroll
-                                        for (int k = 0;  k < TPL;  k++)
-                                            bounce[wv][g][j*TPL + k] = t16[k];
-#pragma unroll
-                                        for (int k = 0;  k < TPL;  k++)
-                                            w[(k - PH - 1 + 8*TPL)%TPL] = bounce[wv][g][(j*TPL + k + curr_pos)%T];
-                                    }
+                                        set_over_history();
 #pragma unroll
                                     for (int k = 0;  k < TPL;  k++)
                                         t32[k] = (int) ((uint32_t) t16[k] << 15);
-                                    if (fir_set == tap_set)
-                                    {
-#pragma unroll
-                                        for (int k = 0;  k < TPL;  k++)
-                                            f16[k] = t16[k];
-                                    }
-                                    else if (fir_set == d2)
-                                    {
-                                        load_set(fir_set, f16);
-                                    }
                                     tap_rotate_counter = 1600;
                                 }
                                 narrowband_score = 0;
@@ -406,9 +624,6 @@ void echo_bank_kernel(const EchoLaunch L)
                                 tap_set = 0;
                             fir_set = tap_set;
                             load_set(tap_set, t16);
-#pragma unroll
-                            for (int k = 0;  k < TPL;  k++)
-                                f16[k] = t16[k];
                         }
                         if ((mode & kModeAdaption)  &&  narrowband_score == 0)
                         {
@@ -421,14 +636,11 @@ void echo_bank_kernel(const EchoLaunch L)
                                 sh = top_bit_u32((uint32_t) tx_power3) - 8;
                             if (sh > 0)
                                 factor >>= sh;
-                            const bool same = (fir_set == tap_set);
 #pragma unroll
                             for (int k = 0;  k < TPL;  k++)
                             {
-                                t32[k] = mad24(w[(k - PH - 1 + 8*TPL)%TPL], factor, t32[k]);
+                                t32[k] = mad24(w[(k - 1 + TPL)%TPL], factor, t32[k]);
                                 t16[k] = (int) (short) (t32[k] >> 15);
-                                if (same)
-                                    f16[k] = t16[k];
                             }
                         }
                     }
@@ -442,31 +654,12 @@ void echo_bank_kernel(const EchoLaunch L)
                         const int d2 = (tap_set - 1)%3;
                         load_set(src, t16);
                         if (d2 >= 0)
-                        {
                             store_set(d2, t16);
-                        }
                         else
-                        {
-#pragma unroll
-                            for (int k = 0;  k < TPL;  k++)
-                                bounce[wv][g][j*TPL + k] = t16[k];
-#pragma unroll
-                            for (int k = 0;  k < TPL;  k++)
-                                w[(k - PH - 1 + 8*TPL)%TPL] = bounce[wv][g][(j*TPL + k + curr_pos)%T];
-                        }
+                            set_over_history();
 #pragma unroll
                         for (int k = 0;  k < TPL;  k++)
                             t32[k] = (int) ((uint32_t) t16[k] << 15);
-                        if (fir_set == tap_set)
-                        {
-#pragma unroll
-                            for (int k = 0;  k < TPL;  k++)
-                                f16[k] = t16[k];
-                        }
-                        else if (fir_set == d2)
-                        {
-                            load_set(fir_set, f16);
-                        }
                         tap_rotate_counter = 1600;
                         dtd_onset = 1;
                     }
@@ -485,67 +678,35 @@ void echo_bank_kernel(const EchoLaunch L)
                 {
                     t32[k] = 0;
                     t16[k] = 0;
-                    f16[k] = 0;
                 }
                 store_set(0, t16);
                 store_set(1, t16);
                 store_set(2, t16);
                 store_set(3, t16);
             }
-
-            // echo.c:613-651
-            if (mode & kModeNlp)
-            {
-                if (rx_power1 < 30000000)
-                {
-                    if (!cng)
-                    {
-                        cng_level = clean_rx_power;
-                        cng = 1;
-                    }
-                    if (mode & kModeCng)
-                    {
-                        cng_rndnum = (int) (1664525U*(uint32_t) cng_rndnum + 1013904223U);
-                        cng_filter = ((cng_rndnum & 0xFFFF) - 32768 + 5*cng_filter) >> 3;
-                        clean_rx = (int) ((uint32_t) cng_filter*(uint32_t) cng_level) >> 17;
-                    }
-                    else
-                    {
-                        clean_rx = 0;
-                    }
-                }
-                else
-                {
-                    cng = 0;
-                }
-            }
-            else
-            {
-                cng = 0;
-            }
-            // echo.c:655-658
-            if (curr_pos <= 0)
-                curr_pos = T;
-            curr_pos--;
-            if (j == 0)
-                io[wv][g][idx] = ((int) (short) clean_rx & 0xFFFF) | (tx << 16);    // reuse the slot for the outputs
-        };
-
-        // ---- walk the pass: TPL samples per unrolled round (phases 0..TPL-1) ------------------
-        int idx = 0;
-        for (  ;  idx + TPL <= n;  idx += TPL)
-        {
-            for_each_phase<0, TPL>(sample, idx);
-        }
-        // tail (frame length not a multiple of TPL): phase 0, then rotate the registers once
-        for (  ;  idx < n;  idx++)
-        {
-            sample(idx, std::integral_constant<int, 0>{});
+            finish_sample(idx, tx, clean_rx);
+            // back to phase 0: rotate the window registers once
             const int last = w[TPL - 1];
 #pragma unroll
             for (int k = TPL - 1;  k > 0;  k--)
                 w[k] = w[k - 1];
             w[0] = last;
+        };
+
+        // ---- walk the pass ---------------------------------------------------------------------------------------
+        int idx = 0;
+        while (idx < n)
+        {
+            if (idx + U <= n  &&  __all(fir_set == tap_set))
+            {
+                ahead = io[wv][g][idx];
+                const int done = echo_fast_round<0, U, TPL>(fast, w, idx);
+                idx += done;
+                if (done == U)
+                    continue;
+            }
+            slow(idx);
+            idx++;
         }
 
         // ---- clean samples out (each group writes its own channel) ---------------------------
@@ -571,10 +732,12 @@ void echo_bank_kernel(const EchoLaunch L)
             g16[tap_set*T + k] = (int16_t) t16[k];
             gh[k] = (int16_t) w[k];
         }
-        if (j < 9)
-            sc[ES_LAST_ACF + j] = my_acf;
-        if (G == 8  &&  j == 0)
-            sc[ES_LAST_ACF + 8] = my_acf8;
+#pragma unroll
+        for (int m = 0;  m < NL;  m++)
+        {
+            if (j + m*G < 9)
+                sc[ES_LAST_ACF + j + m*G] = my_acf[m];
+        }
     }
     if (leader)
     {

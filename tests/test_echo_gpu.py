@@ -70,6 +70,11 @@ def compare_state(bank, dets, what):
     (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 8),
     (64, 0x01 | 0x02, [160], 8),
     (32, 0x01, [160], 8),
+    # four lanes per channel (a DPP quad)
+    (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 4),
+    (128, 0x01, [160], 4),
+    (64, 0x01 | 0x02, [160, 1, 31], 4),
+    (32, 0x01 | 0x20 | 0x40, [160], 4),
 ])
 def test_echo_bank_parity(built, taps, mode, sizes, lanes):
     from oracle import restated as orc
