@@ -219,7 +219,7 @@ SPANGPU_API int spangpu_echo_update(spangpu_echo_t *ec, const int16_t *tx, const
 SPANGPU_API int spangpu_echo_update_tx(spangpu_echo_t *ec, const int16_t *tx, const int16_t *rx, int16_t *clean, int16_t *tx_out,
                                        int mem, int samples, long long stride, int use_hpf_tx);
 /* echo_can_hpf_tx() on its own, for callers that filter tx before they have the matching rx (host buffers). */
-/* Tuning / A-B testing: lanes per channel of echo banks created from now on (0 = by length, 8 or 16); results are identical. */
+/* Tuning / A-B testing: lanes per channel of echo banks created from now on (0 = by length, 4, 8 or 16); results are identical. */
 SPANGPU_API int spangpu_tune_echo_lanes_per_channel(int lanes);
 SPANGPU_API int spangpu_echo_hpf_tx(spangpu_echo_t *ec, const int16_t *tx, int16_t *out, int samples, long long stride);
 SPANGPU_API int spangpu_echo_adaption_mode(spangpu_echo_t *ec, int channel, int adaption_mode);

@@ -33,7 +33,7 @@ struct spangpu_echo_s
     int n_ch;
     int taps;
     int tpl;
-    int group;              // lanes per channel: 16 or 8
+    int group;              // lanes per channel: 16, 8 or 4
     hipStream_t stream;
     bool own_stream;
     int32_t *scal;
@@ -96,10 +96,11 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     e->device = device;
     e->n_ch = n_channels;
     e->taps = taps;
-    // Sixteen lanes per channel by default.  Eight (spangpu_tune_echo_lanes_per_channel) put twice the channels
-    // behind the replicated control code, but the 16-tap slices then need ~250 VGPRs and the two come out even
-    // (1.14 ms against 0.98 ms for 131072 x 128 taps), so it stays an option for A-B tests.
-    e->group = (g_echo_group != 0)  ?  g_echo_group  :  16;
+    // Four lanes per channel by default (32 / 64 / 128 taps: slices of 8 / 16 / 32 taps per lane; sixteen lanes for 256
+    // taps): the scalar control of echo_can_update() is replicated in a channel's lanes, so the fewer lanes a channel
+    // has the more channels share each control instruction (measured on 131072 x 128 taps: 0.98 / 0.75 / 0.63 ms
+    // with 16 / 8 / 4 lanes).  spangpu_tune_echo_lanes_per_channel() overrides for A-B tests.
+    e->group = (g_echo_group != 0)  ?  g_echo_group  :  4;
     if (taps/e->group < 2  ||  taps/e->group > ((e->group == 4)  ?  32  :  16))
         e->group = 16;
     e->tpl = taps/e->group;

@@ -395,16 +395,28 @@ void echo_bank_kernel(const EchoLaunch L)
             const int w_old = w[NEWP];
             w[NEWP] = group_shift_in<G>(tx, w_old, j);
             // after the shift the phase is PH + 1: logical k -> w[(k - PH - 1) mod TPL]
-            // two accumulators: integer addition wraps and associates, so the order is free
+            // four accumulators: integer addition wraps and associates, so the order is free, and no multiply-add
+            // waits on the one issued just before it
             int y = 0;
-            int y1 = 0;
-#pragma unroll
-            for (int k = 0;  k < TPL;  k += 2)
+            if constexpr (TPL >= 4)
             {
-                y = mad24(t16[k], w[(k - PH - 1 + 8*TPL)%TPL], y);
-                y1 = mad24(t16[k + 1], w[(k + 1 - PH - 1 + 8*TPL)%TPL], y1);
+                int ya[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0;  k < TPL;  k += 4)
+                {
+#pragma unroll
+                    for (int q = 0;  q < 4;  q++)
+                        ya[q] = mad24(t16[k + q], w[(k + q - PH - 1 + 8*TPL)%TPL], ya[q]);
+                }
+                y = (ya[0] + ya[1]) + (ya[2] + ya[3]);
             }
-            y = group_sum<G>(y + y1);
+            else
+            {
+#pragma unroll
+                for (int k = 0;  k < TPL;  k++)
+                    y = mad24(t16[k], w[(k - PH - 1 + 8*TPL)%TPL], y);
+            }
+            y = group_sum<G>(y);
             const int echo_value = (int) (short) (y >> 15);
             const int clean_rx = rx - echo_value;                // echo.c:452
             const int n_dwell = nonupdate_dwell - ((nonupdate_dwell > 0)  ?  1  :  0);

@@ -66,11 +66,14 @@ def compare_state(bank, dets, what):
     (256, 0x01 | 0x20 | 0x40, [160], 0),
     (64, 0x01 | 0x02 | 0x04, [80, 240], 0),
     (32, 0x01, [160], 0),
-    # the eight-lanes-per-channel mapping (spangpu_tune_echo_lanes_per_channel): identical results
+    # the other lane mappings (spangpu_tune_echo_lanes_per_channel): identical results.  Eight lanes (half a DPP row)
     (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 8),
     (64, 0x01 | 0x02, [160], 8),
     (32, 0x01, [160], 8),
-    # four lanes per channel (a DPP quad)
+    # sixteen lanes per channel (a DPP row)
+    (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 16),
+    (64, 0x01 | 0x02, [160], 16),
+    # four lanes per channel (a DPP quad; the default up to 128 taps)
     (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 4),
     (128, 0x01, [160], 4),
     (64, 0x01 | 0x02, [160, 1, 31], 4),

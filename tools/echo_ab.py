@@ -1,4 +1,4 @@
-"""A-B timing of the echo kernel's two lane mappings: python tools/echo_ab.py 16|8 (prints ms per step, launch us)."""
+"""A-B timing of the echo kernel lane mappings: python tools/echo_ab.py 16|8|4 (prints ms per step, launch us)."""
 import ctypes
 import runpy
 import sys
