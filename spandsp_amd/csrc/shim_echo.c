@@ -78,6 +78,8 @@ int16_t echo_can_hpf_tx(echo_can_state_t *ec, int16_t tx)
 int spangpu_echo_can_update_block(echo_can_state_t *ec, const int16_t tx[], const int16_t rx[], int16_t clean[], int16_t tx_out[],
                                   int n, int use_hpf_tx)
 {
+    if (n <= 0)
+        return 0;
     return spangpu_echo_update_tx(ec->bank, tx, rx, clean, tx_out, SPANGPU_MEM_HOST, n, n, use_hpf_tx);
 }
 

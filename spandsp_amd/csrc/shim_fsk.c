@@ -212,6 +212,8 @@ static int line_rx(spangpu_line_group_t *g, int channel, int private_grp, const 
 {
     int n;
 
+    if (len <= 0)
+        return 0;                           /* as the reference: nothing to do (fsk.c:330 loops over len) */
     if (private_grp)
     {
         while (len > 0)

@@ -195,6 +195,8 @@ static int obj_rx(modem_obj_t *o, const int16_t amp[], int len)
     spangpu_modem_group_t *g = o->grp;
     int n;
 
+    if (len <= 0)
+        return 0;                           /* as the reference: nothing to do (v29rx.c:867-965 loops over len) */
     if (o->private_grp)
     {
         while (len > 0)

@@ -58,6 +58,7 @@ def spec_ptr(L, which):
 
 def feed(fn, s, x, chunk):
     x = np.ascontiguousarray(x, np.int16)
+    assert fn(s, x.ctypes.data, 0) == 0                     # empty input: nothing happens
     for k in range(0, len(x), chunk):
         blk = x[k:k + chunk]
         assert fn(s, blk.ctypes.data, len(blk)) == 0

@@ -56,6 +56,7 @@ class Tap:
 
 def feed(L, pfx, s, x, chunk=160):
     x = np.ascontiguousarray(x, np.int16)
+    assert getattr(L, pfx)(s, x.ctypes.data, 0) == 0                            # empty input: nothing happens
     for k in range(0, len(x), chunk):
         blk = x[k:k + chunk]
         assert getattr(L, pfx)(s, blk.ctypes.data, len(blk)) == 0
@@ -167,6 +168,8 @@ def test_group_of_receivers(L):
     for k in range(0, len(xs), 160):
         for c in range(n):
             blk = np.ascontiguousarray(xs[k:k + 160] if c % 2 == 0 else np.zeros(160, np.int16))
+            if k == 320:
+                assert L.v27ter_rx(objs[c], blk.ctypes.data, 0) == 0          # an empty block is no block (and no tick)
             L.v27ter_rx(objs[c], blk.ctypes.data, 160)
     for c in range(n):
         if c % 2 == 0:
