@@ -49,6 +49,7 @@ typedef struct
     char *text;
     int ntext;
     int captext;
+    int want_qam;           /* modem receivers: also record the qam_report_handler_t calls (kinds 6 and 7) */
 } orc_sink_t;
 
 ORC_API orc_sink_t *orc_sink_new(void);
@@ -59,6 +60,10 @@ ORC_API const orc_event_t *orc_sink_events(const orc_sink_t *k);
 ORC_API int orc_sink_ntext(const orc_sink_t *k);
 ORC_API const char *orc_sink_text(const orc_sink_t *k);
 void orc_sink_push(orc_sink_t *k, int kind, int a, int b, int c);
+/* The modems' qam_report(user, constel, target, symbol) call (v29rx.c:769-783): two events, kind 6 = {symbol, bits of
+   constel.re, constel.im} and kind 7 = {1 if the pointers were NULL, bits of target.re, target.im}; only when wanted. */
+ORC_API void orc_sink_want_qam(orc_sink_t *k, int on);
+void orc_sink_qam(orc_sink_t *k, const float *constel, const float *target, int symbol);
 void orc_sink_text_append(orc_sink_t *k, const char *s, int len);
 
 /* Per-block trace record for the tone detectors (what the GPU kernels also

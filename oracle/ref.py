@@ -49,6 +49,7 @@ def lib():
             "glue_echo_run": (None, [vp, vp, vp, vp, ci, ci]),
             "glue_echo_taps": (ci, [vp]),
             "glue_echo_snapshot": (None, [vp, vp, vp, vp, vp]),
+            "glue_v29_rx_tap_qam": (None, [vp, vp]), "glue_v27ter_rx_tap_qam": (None, [vp, vp]), "glue_v17_rx_tap_qam": (None, [vp, vp]),
             "glue_v29_rx_new": (vp, [ci, vp]), "glue_v27ter_rx_new": (vp, [ci, vp]), "glue_v17_rx_new": (vp, [ci, vp]),
             "glue_v29_tx_new": (vp, [ci, ci, vp]), "glue_v27ter_tx_new": (vp, [ci, ci, vp]), "glue_v17_tx_new": (vp, [ci, ci, vp]),
             "glue_sizeof": (ci, [C.c_char_p]),
@@ -571,6 +572,9 @@ class V29Rx:
         except Exception:
             pass
 
+    def tap_qam(self):
+        lib().glue_v29_rx_tap_qam(self.p, self.sink.p)
+
     def rx(self, amp):
         amp = _i16(amp)
         return lib().v29_rx(self.p, amp.ctypes.data, len(amp))
@@ -592,6 +596,9 @@ class V27terRx:
             lib().v27ter_rx_free(self.p)
         except Exception:
             pass
+
+    def tap_qam(self):
+        lib().glue_v27ter_rx_tap_qam(self.p, self.sink.p)
 
     def rx(self, amp):
         amp = _i16(amp)
@@ -617,6 +624,9 @@ class V17Rx:
 
     def restart(self, bit_rate, short_train):
         return lib().v17_rx_restart(self.p, bit_rate, int(short_train))
+
+    def tap_qam(self):
+        lib().glue_v17_rx_tap_qam(self.p, self.sink.p)
 
     def rx(self, amp):
         amp = _i16(amp)

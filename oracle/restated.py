@@ -26,6 +26,7 @@ def lib():
             "orc_sink_new": (vp, []),
             "orc_sink_free": (None, [vp]),
             "orc_sink_clear": (None, [vp]),
+            "orc_sink_want_qam": (None, [vp, ci]),
             "orc_sink_count": (ci, [vp]),
             "orc_sink_events": (vp, [vp]),
             "orc_sink_ntext": (ci, [vp]),
@@ -145,6 +146,25 @@ class Sink:
 
     def text(self):
         return lib().orc_sink_text(self.p).decode("latin1")
+
+    def want_qam(self, on=True):
+        lib().orc_sink_want_qam(self.p, int(on))
+
+
+def qam_stream(events):
+    """The qam_report_handler_t calls among a modem's events as uint32 [n, 7]: events (put_bit calls) before the report,
+    1 if its pointers were NULL, symbol, constel re / im and target re / im as bits -- the device's record layout."""
+    out = []
+    pos = 0
+    pend = None
+    for e in events:
+        if e["kind"] == 3:
+            pos += 1
+        elif e["kind"] == 6:
+            pend = (pos, int(e["a"]), int(e["b"]), int(e["c"]))
+        elif e["kind"] == 7:
+            out.append((pend[0], int(e["a"]), pend[1], pend[2], pend[3], int(e["b"]), int(e["c"])))
+    return np.array(out, np.int64).astype(np.uint32).reshape(-1, 7)
 
 
 class _Detector:
@@ -383,6 +403,9 @@ class V29:
         self.sink = Sink()
         assert lib().orc_v29_init(self.p, bit_rate) == 0
 
+    def tap_qam(self):
+        self.sink.want_qam(True)
+
     def rx(self, amp):
         amp = _i16(amp)
         return lib().orc_v29_rx(self.p, amp.ctypes.data, len(amp), self.sink.p)
@@ -402,6 +425,9 @@ class V27ter:
         self.p = self.buf.ctypes.data
         self.sink = Sink()
         assert lib().orc_v27ter_init(self.p, bit_rate) == 0
+
+    def tap_qam(self):
+        self.sink.want_qam(True)
 
     def rx(self, amp):
         amp = _i16(amp)
@@ -425,6 +451,9 @@ class V17:
 
     def restart(self, bit_rate, short_train):
         return lib().orc_v17_restart(self.p, bit_rate, int(short_train))
+
+    def tap_qam(self):
+        self.sink.want_qam(True)
 
     def rx(self, amp):
         amp = _i16(amp)

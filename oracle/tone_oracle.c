@@ -57,6 +57,28 @@ const orc_event_t *orc_sink_events(const orc_sink_t *k) { return k->ev; }
 int orc_sink_ntext(const orc_sink_t *k) { return k->ntext; }
 const char *orc_sink_text(const orc_sink_t *k) { return k->text; }
 
+void orc_sink_want_qam(orc_sink_t *k, int on)
+{
+    k->want_qam = on;
+}
+
+void orc_sink_qam(orc_sink_t *k, const float *constel, const float *target, int symbol)
+{
+    int32_t w[4] = {0, 0, 0, 0};
+
+    if (k == NULL  ||  !k->want_qam)
+        return;
+    if (constel)
+    {
+        memcpy(&w[0], &constel[0], 4);
+        memcpy(&w[1], &constel[1], 4);
+        memcpy(&w[2], &target[0], 4);
+        memcpy(&w[3], &target[1], 4);
+    }
+    orc_sink_push(k, 6, symbol, w[0], w[1]);
+    orc_sink_push(k, 7, (constel == NULL), w[2], w[3]);
+}
+
 void orc_sink_push(orc_sink_t *k, int kind, int a, int b, int c)
 {
     if (k == NULL)

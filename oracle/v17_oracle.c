@@ -417,7 +417,9 @@ static void process_half_baud(orc_v17_t *s, orc_sink_t *sink, const float sample
     const float (*con)[2] = constellation(s);
     float z[2];
     float zz[2];
+    static const float zero[2] = {0.0f, 0.0f};
     const float *target;
+    int symbol = 0;                 /* the reference's local constellation_state, what qam_report() is given */
     int bit;
     int i;
     int j;
@@ -438,9 +440,11 @@ static void process_half_baud(orc_v17_t *s, orc_sink_t *sink, const float sample
     switch (s->training_stage)
     {
     case ST_NORMAL:
-        decode_baud(s, sink, z);
+        symbol = decode_baud(s, sink, z);
+        target = con[symbol];
         break;
     case ST_SYMBOL_ACQUISITION:
+        target = zero;
         if (++s->training_count >= 100)
         {
             s->training_stage = ST_LOG_PHASE;
@@ -451,6 +455,7 @@ static void process_half_baud(orc_v17_t *s, orc_sink_t *sink, const float sample
         }
         break;
     case ST_LOG_PHASE:
+        target = zero;
         angle = arctan2_i(z[1], z[0]);
         s->training_count = 1;
         if (s->short_train)
@@ -478,6 +483,7 @@ static void process_half_baud(orc_v17_t *s, orc_sink_t *sink, const float sample
         }
         break;
     case ST_WAIT_FOR_CDBA:
+        target = zero;
         angle = arctan2_i(z[1], z[0]);
         i = s->training_count + 1;
         ang = (int32_t) ((uint32_t) angle - (uint32_t) s->last_angles[i & 1]);
@@ -503,6 +509,7 @@ static void process_half_baud(orc_v17_t *s, orc_sink_t *sink, const float sample
             spin(s, phase_step);
             bit = descramble(s, 1);
             bit = (bit << 1) | descramble(s, 1);
+            target = CDBA[bit];
             s->training_count = 1;
             s->training_stage = ST_COARSE_TRAIN_ON_CDBA;
             report_status(sink, -3);                            /* SIG_STATUS_TRAINING_IN_PROGRESS */
@@ -570,6 +577,7 @@ static void process_half_baud(orc_v17_t *s, orc_sink_t *sink, const float sample
     case ST_BRIDGE:
         descramble(s, BRIDGE_WORD >> ((s->training_count & 0x7) << 1));
         descramble(s, BRIDGE_WORD >> (((s->training_count & 0x7) << 1) + 1));
+        target = z;
         if (++s->training_count >= SEG_3_LEN)
         {
             s->training_error = 0.0f;
@@ -592,6 +600,7 @@ static void process_half_baud(orc_v17_t *s, orc_sink_t *sink, const float sample
         {
             bit = descramble(s, 1);
             bit = (bit << 1) | descramble(s, 1);
+            target = CDBA[bit];
             s->training_error = 0.0f;
             s->training_count = 1;
             s->training_stage = ST_SHORT_TRAIN_ON_CDBA_AND_TEST;
@@ -642,6 +651,8 @@ static void process_half_baud(orc_v17_t *s, orc_sink_t *sink, const float sample
         break;
     case ST_TCM_WINDUP:
         cs = decode_baud(s, sink, z);
+        symbol = cs;
+        target = con[cs];
         zz[0] = z[0] - con[cs][0];
         zz[1] = z[1] - con[cs][1];
         s->training_error += (zz[0]*zz[0] + zz[1]*zz[1]);
@@ -655,6 +666,8 @@ static void process_half_baud(orc_v17_t *s, orc_sink_t *sink, const float sample
         break;
     case ST_TEST_ONES:
         cs = decode_baud(s, sink, z);
+        symbol = cs;
+        target = con[cs];
         zz[0] = z[0] - con[cs][0];
         zz[1] = z[1] - con[cs][1];
         s->training_error += (zz[0]*zz[0] + zz[1]*zz[1]);
@@ -676,8 +689,10 @@ static void process_half_baud(orc_v17_t *s, orc_sink_t *sink, const float sample
         }
         break;
     default:
+        target = zero;
         break;
     }
+    orc_sink_qam(sink, z, target, symbol);                      /* v17rx.c:1117-1131 */
 }
 
 /* v17rx.c:1133-1210 */

@@ -258,7 +258,7 @@ static void decode_baud(orc_v27ter_t *s, orc_sink_t *sink, const float z[2])
 }
 
 /* v27ter_rx.c:486-528 */
-static void symbol_sync(orc_v27ter_t *s)
+static void symbol_sync(orc_v27ter_t *s, orc_sink_t *sink)
 {
     float p;
     float q;
@@ -272,6 +272,7 @@ static void symbol_sync(orc_v27ter_t *s)
     {
         s->eq_put_step += (s->gardner_integrate/128);
         s->total_baud_timing_correction += (s->gardner_integrate/128);
+        orc_sink_qam(sink, NULL, NULL, s->gardner_integrate);       /* v27ter_rx.c:517-518 */
         s->gardner_integrate = 0;
     }
 }
@@ -280,6 +281,8 @@ static void symbol_sync(orc_v27ter_t *s)
 static void process_half_baud(orc_v27ter_t *s, orc_sink_t *sink, const float sample[2])
 {
     static const int abab_pos[2] = {0, 4};
+    static const float zero[2] = {0.0f, 0.0f};
+    const float *target;
     float z[2];
     float zz[2];
     float p;
@@ -296,15 +299,18 @@ static void process_half_baud(orc_v27ter_t *s, orc_sink_t *sink, const float sam
         s->eq_step = 0;
     if ((s->baud_half ^= 1))
         return;
-    symbol_sync(s);
+    symbol_sync(s, sink);
     ccircular_dot((const float (*)[2]) s->eq_buf, (const float (*)[2]) s->eq_coeff, EQ_LEN, s->eq_step, z);
 
     switch (s->training_stage)
     {
     case ST_NORMAL:
         decode_baud(s, sink, z);
+        cs = (s->bit_rate == 4800)  ?  s->constellation_state  :  (s->constellation_state << 1);
+        target = CONSTEL[cs];
         break;
     case ST_SYMBOL_ACQUISITION:
+        target = zero;
         if (++s->training_count >= 30)
         {
             s->gardner_step = 32;
@@ -314,11 +320,13 @@ static void process_half_baud(orc_v27ter_t *s, orc_sink_t *sink, const float sam
         }
         break;
     case ST_LOG_PHASE:
+        target = zero;
         s->last_angles[1] = arctan2_i(z[1], z[0]);
         s->training_count = 1;
         s->training_stage = ST_WAIT_FOR_HOP;
         break;
     case ST_WAIT_FOR_HOP:
+        target = zero;
         angle = arctan2_i(z[1], z[0]);
         i = s->training_count + 1;
         ang = (int32_t) ((uint32_t) angle - (uint32_t) s->last_angles[i & 1]);
@@ -361,6 +369,7 @@ static void process_half_baud(orc_v27ter_t *s, orc_sink_t *sink, const float sam
             descramble(s, 1);
             descramble(s, 1);
             s->constellation_state = abab_pos[s->training_bc];
+            target = CONSTEL[s->constellation_state];
             s->training_count = 1;
             s->training_stage = ST_TRAIN_ON_ABAB;
             report_status(sink, -3);                        /* SIG_STATUS_TRAINING_IN_PROGRESS */
@@ -376,8 +385,9 @@ static void process_half_baud(orc_v27ter_t *s, orc_sink_t *sink, const float sam
         descramble(s, 1);
         descramble(s, 1);
         s->constellation_state = abab_pos[s->training_bc];
-        track_carrier(s, z, CONSTEL[s->constellation_state]);
-        tune_equalizer(s, z, CONSTEL[s->constellation_state]);
+        target = CONSTEL[s->constellation_state];
+        track_carrier(s, z, target);
+        tune_equalizer(s, z, target);
         s->carrier_track_i = 400.0f + (200000.0f - 400.0f)*(float) (SEG_5_LEN - s->training_count)/(float) SEG_5_LEN;
         s->carrier_track_p = 1000000.0f + (10000000.0f - 1000000.0f)*(float) (SEG_5_LEN - s->training_count)/(float) SEG_5_LEN;
         if (++s->training_count >= SEG_5_LEN)
@@ -390,6 +400,7 @@ static void process_half_baud(orc_v27ter_t *s, orc_sink_t *sink, const float sam
     case ST_TEST_ONES:
         decode_baud(s, sink, z);
         cs = (s->bit_rate == 4800)  ?  s->constellation_state  :  (s->constellation_state << 1);
+        target = CONSTEL[cs];
         zz[0] = z[0] - CONSTEL[cs][0];
         zz[1] = z[1] - CONSTEL[cs][1];
         s->training_error += (zz[0]*zz[0] + zz[1]*zz[1]);
@@ -414,8 +425,10 @@ static void process_half_baud(orc_v27ter_t *s, orc_sink_t *sink, const float sam
         }
         break;
     default:
+        target = zero;
         break;
     }
+    orc_sink_qam(sink, z, target, s->constellation_state);      /* v27ter_rx.c:765-777 */
 }
 
 /* v27ter_rx.c:779-861 */

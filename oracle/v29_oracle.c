@@ -368,6 +368,7 @@ static void park(orc_v29_t *s, orc_sink_t *sink)
 static void process_half_baud(orc_v29_t *s, orc_sink_t *sink, const float sample[2])
 {
     static const int cdcd_pos[6] = {0, 11, 0, 3, 0, 2};
+    static const float zero[2] = {0.0f, 0.0f};
     float z[2];
     float zz[2];
     float p;
@@ -394,8 +395,10 @@ static void process_half_baud(orc_v29_t *s, orc_sink_t *sink, const float sample
     {
     case ST_NORMAL:
         decode_baud(s, sink, z);
+        target = CONSTEL[s->constellation_state];
         break;
     case ST_SYMBOL_ACQUISITION:
+        target = zero;
         if (++s->training_count >= 60)
         {
             s->training_stage = ST_LOG_PHASE;
@@ -406,11 +409,13 @@ static void process_half_baud(orc_v29_t *s, orc_sink_t *sink, const float sample
         }
         break;
     case ST_LOG_PHASE:
+        target = zero;
         s->last_angles[1] = arctan2_i(z[1], z[0]);
         s->training_count = 1;
         s->training_stage = ST_WAIT_FOR_CDCD;
         break;
     case ST_WAIT_FOR_CDCD:
+        target = zero;
         angle = arctan2_i(z[1], z[0]);
         i = s->training_count + 1;
         ang = (int32_t) ((uint32_t) angle - (uint32_t) s->last_angles[i & 1]);
@@ -448,6 +453,7 @@ static void process_half_baud(orc_v29_t *s, orc_sink_t *sink, const float sample
             s->carrier_phase += (uint32_t) angle;
             bit = scrambled_training_bit(s);
             s->constellation_state = cdcd_pos[s->training_cd + bit];
+            target = CONSTEL[s->constellation_state];
             s->training_count = 1;
             s->training_stage = ST_TRAIN_ON_CDCD;
             report_status(sink, -3);                /* SIG_STATUS_TRAINING_IN_PROGRESS */
@@ -519,8 +525,10 @@ static void process_half_baud(orc_v29_t *s, orc_sink_t *sink, const float sample
         break;
     case ST_PARKED:
     default:
+        target = zero;
         break;
     }
+    orc_sink_qam(sink, z, target, s->constellation_state);      /* v29rx.c:769-783 */
 }
 
 /* v29rx.c:788-865.  Returns the power, 0 meaning "skip this sample". */

@@ -291,6 +291,21 @@ def v29_run(rx, x, chunks):
     return ev["a"].astype(np.int32), bits(f), w
 
 
+def qam_run(rx, x, chunks):
+    """As v29_run, with the receiver's qam_report tap on: the put_bit stream and the report stream."""
+    from oracle import restated as orc
+    rx.tap_qam()
+    k = 0
+    i = 0
+    while k < len(x):
+        n = chunks[i % len(chunks)]
+        rx.rx(x[k:k + n])
+        k += n
+        i += 1
+    ev = rx.sink.events()
+    return ev["a"][ev["kind"] == 3].astype(np.int32), orc.qam_stream(ev)
+
+
 V17_MAPS_CRC = 0x99A92B10           # CRC-32 of the reference's constel_maps[4][36][36][8]
 V17_MAP_4800_CRC = 0xD5E4365B       # ... of constel_map_4800[36][36]
 V17_CONSTEL_CRC = 0x784A4EC3        # ... of the 244 constellation points as int8 {re, im} pairs
@@ -341,6 +356,19 @@ def test_v29_live(built, bit_rate, seed, noise, chunks):
     assert np.array_equal(w_r, w_o)
     assert np.array_equal(f_r, f_o)
 
+
+@needs_ref
+@pytest.mark.parametrize("bit_rate,seed,noise", V29_CASES[:2] + [(9600, 22, -60.0)])
+def test_v29_qam_reports_live(built, bit_rate, seed, noise):
+    """The per-baud qam_report_handler_t calls (v29rx.c:769-783): constellation point, target and symbol, in place."""
+    from oracle import ref, restated as orc
+    use_golden_modem_tables()
+    x = v29_scenario(bit_rate, seed, noise)
+    ev_r, q_r = qam_run(ref.V29Rx(bit_rate), x, (160, 1, 77))
+    ev_o, q_o = qam_run(orc.V29(bit_rate), x, (160, 1, 77))
+    assert np.array_equal(ev_r, ev_o)
+    assert len(q_r) > 1000 and np.any(q_r[:, 5] != 0)      # training and data bauds, with real targets
+    assert np.array_equal(q_r, q_o)
 
 
 # --------------------------------------------------------------------------------------
@@ -800,6 +828,21 @@ def test_v27ter_live(built, bit_rate, seed, noise, chunks):
     assert np.array_equal(f_r, f_o)
 
 
+@needs_ref
+@pytest.mark.parametrize("bit_rate,seed,noise", V27_CASES[:2] + [(2400, 42, -60.0)])
+def test_v27ter_qam_reports_live(built, bit_rate, seed, noise):
+    """qam_report_handler_t calls of v27ter_rx: one per baud (v27ter_rx.c:765-777) and the (NULL, NULL, step) reports of
+    the symbol synchroniser (:517-518)."""
+    from oracle import ref, restated as orc
+    use_golden_modem_tables()
+    x = v27ter_scenario(bit_rate, seed, noise)
+    ev_r, q_r = qam_run(ref.V27terRx(bit_rate), x, (160, 1, 77))
+    ev_o, q_o = qam_run(orc.V27ter(bit_rate), x, (160, 1, 77))
+    assert np.array_equal(ev_r, ev_o)
+    assert len(q_r) > 500 and np.any(q_r[:, 1] == 1) and np.any(q_r[:, 5] != 0)
+    assert np.array_equal(q_r, q_o)
+
+
 # ---------------------------------------------------------------------------------
 # V.17 receiver
 # ---------------------------------------------------------------------------------
@@ -832,6 +875,22 @@ def test_v17_live(built, bit_rate, seed, noise, chunks):
     assert np.array_equal(ev_r, ev_o)
     assert np.array_equal(w_r, w_o)
     assert np.array_equal(f_r, f_o)
+
+
+@needs_ref
+@pytest.mark.parametrize("bit_rate,seed,noise", V17_CASES[:3] + [(9600, 62, -36.0)])
+def test_v17_qam_reports_live(built, bit_rate, seed, noise):
+    """qam_report_handler_t calls of v17_rx (v17rx.c:1117-1131): long and short training, the bridge (target = the point
+    itself), trellis wind-up and data."""
+    from oracle import ref, restated as orc
+    use_golden_modem_tables()
+    x = v17_scenario(bit_rate, seed, noise)
+    ev_r, q_r = qam_run(ref.V17Rx(bit_rate), x, (160, 1, 77))
+    ev_o, q_o = qam_run(orc.V17(bit_rate), x, (160, 1, 77))
+    assert np.array_equal(ev_r, ev_o)
+    assert len(q_r) > 1000 and np.any(q_r[:, 2] != 0)
+    assert np.array_equal(q_r, q_o)
+
 
 
 # ---------------------------------------------------------------------------------
