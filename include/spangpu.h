@@ -255,6 +255,13 @@ SPANGPU_API int spangpu_modem_set_stream(spangpu_modem_t *modem, void *hip_strea
 SPANGPU_API int spangpu_modem_sync(spangpu_modem_t *modem);
 SPANGPU_API int spangpu_modem_rx(spangpu_modem_t *modem, const int16_t *amp, int mem, int samples, long long stride);
 SPANGPU_API int spangpu_modem_events(spangpu_modem_t *modem, const int8_t **events, const int32_t **counts);
+/* xxx_rx_set_qam_report_handler() (src/v29rx.c:1149, v27ter_rx.c:1204, v17rx.c:1535): with the tap on, every channel's
+   qam_report(user, constel, target, symbol) calls (v29rx.c:769-783, v27ter_rx.c:517,765-777, v17rx.c:1117-1131) of an rx
+   call are recorded: counts[c] records of seven words at records + c*cap*7 = {put_bit / status calls before it in
+   this rx call, 1 if constel and target were NULL, symbol, constel re, im, target re, im as binary32 bits}.
+   spangpu_modem_qam_reports() returns cap.  Bit-exact with the reference's float build. */
+SPANGPU_API int spangpu_modem_qam_tap(spangpu_modem_t *modem, int enable);
+SPANGPU_API int spangpu_modem_qam_reports(spangpu_modem_t *modem, const uint32_t **records, const int32_t **counts);
 SPANGPU_API int spangpu_modem_state_words(int kind, int *n_floats, int *n_ints);
 SPANGPU_API int spangpu_modem_get_state(spangpu_modem_t *modem, int channel, uint32_t *words);
 SPANGPU_API int spangpu_modem_set_state(spangpu_modem_t *modem, int channel, const uint32_t *words);

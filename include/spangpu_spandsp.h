@@ -27,7 +27,7 @@
  *   goertzel_*  / make_goertzel_descriptor src/spandsp/tone_detect.h:86-124  src/tone_detect.c:60-205
  *   echo_can_init/_release/_free/_flush/_adaption_mode/_update/_hpf_tx
  *                                          src/spandsp/echo.h:145-185     src/echo.c:254-380,421-669
- *   v29_rx_init/_restart/_release/_free/_set_put_bit/_set_modem_status_handler/_rx/_fillin/_equalizer_state/
+ *   v29_rx_init/_restart/_release/_free/_set_put_bit/_set_modem_status_handler/_set_qam_report_handler/_rx/_fillin/_equalizer_state/
  *     _carrier_frequency/_symbol_timing_correction/_signal_power/_set_signal_cutoff
  *                                          src/spandsp/v29rx.h:151-244    src/v29rx.c:139-196,867-1148
  *   v27ter_rx_* (same set)                 src/spandsp/v27ter_rx.h:71-165 src/v27ter_rx.c:136-170,863-1210
@@ -79,6 +79,9 @@ typedef struct
     float im;
 } complexf_t;
 
+/* spandsp/v29rx.h:130: the per-baud constellation tap (constel and target are NULL for V.27ter's timing hop report) */
+typedef void (*qam_report_handler_t)(void *user_data, const complexf_t *constel, const complexf_t *target, int symbol);
+
 /* spandsp/async.h:66-103: the status codes a receiver passes through put_bit / the status handler */
 enum
 {
@@ -109,6 +112,7 @@ SPANGPU_API int v29_rx_release(v29_rx_state_t *s);
 SPANGPU_API int v29_rx_free(v29_rx_state_t *s);
 SPANGPU_API void v29_rx_set_put_bit(v29_rx_state_t *s, span_put_bit_func_t put_bit, void *user_data);
 SPANGPU_API void v29_rx_set_modem_status_handler(v29_rx_state_t *s, span_modem_status_func_t handler, void *user_data);
+SPANGPU_API void v29_rx_set_qam_report_handler(v29_rx_state_t *s, qam_report_handler_t handler, void *user_data);
 SPANGPU_API int v29_rx_equalizer_state(v29_rx_state_t *s, complexf_t **coeffs);
 SPANGPU_API float v29_rx_carrier_frequency(v29_rx_state_t *s);
 SPANGPU_API float v29_rx_symbol_timing_correction(v29_rx_state_t *s);
@@ -123,6 +127,7 @@ SPANGPU_API int v27ter_rx_release(v27ter_rx_state_t *s);
 SPANGPU_API int v27ter_rx_free(v27ter_rx_state_t *s);
 SPANGPU_API void v27ter_rx_set_put_bit(v27ter_rx_state_t *s, span_put_bit_func_t put_bit, void *user_data);
 SPANGPU_API void v27ter_rx_set_modem_status_handler(v27ter_rx_state_t *s, span_modem_status_func_t handler, void *user_data);
+SPANGPU_API void v27ter_rx_set_qam_report_handler(v27ter_rx_state_t *s, qam_report_handler_t handler, void *user_data);
 SPANGPU_API int v27ter_rx_equalizer_state(v27ter_rx_state_t *s, complexf_t **coeffs);
 SPANGPU_API float v27ter_rx_carrier_frequency(v27ter_rx_state_t *s);
 SPANGPU_API float v27ter_rx_symbol_timing_correction(v27ter_rx_state_t *s);
@@ -137,6 +142,7 @@ SPANGPU_API int v17_rx_release(v17_rx_state_t *s);
 SPANGPU_API int v17_rx_free(v17_rx_state_t *s);
 SPANGPU_API void v17_rx_set_put_bit(v17_rx_state_t *s, span_put_bit_func_t put_bit, void *user_data);
 SPANGPU_API void v17_rx_set_modem_status_handler(v17_rx_state_t *s, span_modem_status_func_t handler, void *user_data);
+SPANGPU_API void v17_rx_set_qam_report_handler(v17_rx_state_t *s, qam_report_handler_t handler, void *user_data);
 SPANGPU_API int v17_rx_equalizer_state(v17_rx_state_t *s, complexf_t **coeffs);
 SPANGPU_API float v17_rx_carrier_frequency(v17_rx_state_t *s);
 SPANGPU_API float v17_rx_symbol_timing_correction(v17_rx_state_t *s);

@@ -51,6 +51,13 @@ struct spangpu_modem_s
     int8_t *h_events;
     int32_t *h_count;
     int last_cap;
+    bool qam_tap;               // spangpu_modem_qam_tap(): run the kernel variant that records the qam_report calls
+    uint32_t *qam;              // [n_ch][qam_cap][7]
+    int32_t *qam_count;
+    int qam_cap;
+    uint32_t *h_qam;
+    int32_t *h_qam_count;
+    int last_qam_cap;
 };
 
 // power_meter_level_dbm0(), power_meter.c:82-92
@@ -346,6 +353,10 @@ int spangpu_modem_destroy(spangpu_modem_t *m)
     if (m->ev_count) (void) hipFree(m->ev_count);
     if (m->h_events) (void) hipHostFree(m->h_events);
     if (m->h_count) (void) hipHostFree(m->h_count);
+    if (m->qam) (void) hipFree(m->qam);
+    if (m->qam_count) (void) hipFree(m->qam_count);
+    if (m->h_qam) (void) hipHostFree(m->h_qam);
+    if (m->h_qam_count) (void) hipHostFree(m->h_qam_count);
     if (m->own_stream  &&  m->stream)
         (void) hipStreamDestroy(m->stream);
     free(m);
@@ -404,6 +415,27 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         V29_TRY(hipHostMalloc(&m->h_events, (size_t) m->n_ch*cap));
         m->ev_cap = cap;
     }
+    if (m->qam_tap)
+    {
+        // one report per baud (at most 2400 per second) and, V.27ter, one per timing hop (at most one per baud)
+        const int qcap = 2*((samples*3 + 9)/10 + 2);
+        if (qcap > m->qam_cap)
+        {
+            if (m->qam) (void) hipFree(m->qam);
+            if (m->h_qam) (void) hipHostFree(m->h_qam);
+            m->qam = nullptr;
+            m->h_qam = nullptr;
+            m->qam_cap = 0;
+            V29_TRY(hipMalloc(&m->qam, (size_t) m->n_ch*qcap*7*sizeof(uint32_t)));
+            V29_TRY(hipHostMalloc(&m->h_qam, (size_t) m->n_ch*qcap*7*sizeof(uint32_t)));
+            m->qam_cap = qcap;
+        }
+        if (m->qam_count == nullptr)
+        {
+            V29_TRY(hipMalloc(&m->qam_count, (size_t) m->n_ch*sizeof(int32_t)));
+            V29_TRY(hipHostMalloc(&m->h_qam_count, (size_t) m->n_ch*sizeof(int32_t)));
+        }
+    }
     const int16_t *d_amp = amp;
     long long d_stride = stride;
     if (mem == SPANGPU_MEM_HOST)
@@ -442,7 +474,12 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         L.ev_count = m->ev_count;
         L.ev_cap = m->ev_cap;
         L.tab = (const V29Tables *) m->tab;
-        if (cpw == 64)
+        L.qam = m->qam;
+        L.qam_count = m->qam_count;
+        L.qam_cap = m->qam_cap;
+        if (m->qam_tap)
+            hipLaunchKernelGGL((v29_bank_kernel<16, true>), dim3((m->n_ch + 15)/16), dim3(64), 0, m->stream, L);
+        else if (cpw == 64)
             hipLaunchKernelGGL(v29_bank_kernel<64>, grid, dim3(64), 0, m->stream, L);
         else if (cpw == 32)
             hipLaunchKernelGGL(v29_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
@@ -463,7 +500,12 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         L.ev_count = m->ev_count;
         L.ev_cap = m->ev_cap;
         L.tab = (const V17Tables *) m->tab;
-        if (cpw == 64)
+        L.qam = m->qam;
+        L.qam_count = m->qam_count;
+        L.qam_cap = m->qam_cap;
+        if (m->qam_tap)
+            hipLaunchKernelGGL((v17_bank_kernel<16, true>), dim3((m->n_ch + 15)/16), dim3(64), 0, m->stream, L);
+        else if (cpw == 64)
             hipLaunchKernelGGL(v17_bank_kernel<64>, grid, dim3(64), 0, m->stream, L);
         else if (cpw == 32)
             hipLaunchKernelGGL(v17_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
@@ -484,7 +526,12 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         L.ev_count = m->ev_count;
         L.ev_cap = m->ev_cap;
         L.tab = (const V27Tables *) m->tab;
-        if (cpw == 64)
+        L.qam = m->qam;
+        L.qam_count = m->qam_count;
+        L.qam_cap = m->qam_cap;
+        if (m->qam_tap)
+            hipLaunchKernelGGL((v27ter_bank_kernel<16, true>), dim3((m->n_ch + 15)/16), dim3(64), 0, m->stream, L);
+        else if (cpw == 64)
             hipLaunchKernelGGL(v27ter_bank_kernel<64>, grid, dim3(64), 0, m->stream, L);
         else if (cpw == 32)
             hipLaunchKernelGGL(v27ter_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
@@ -493,9 +540,38 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
     }
     V29_TRY(hipGetLastError());
     m->last_cap = m->ev_cap;
+    m->last_qam_cap = m->qam_tap  ?  m->qam_cap  :  0;
     if (mem == SPANGPU_MEM_HOST)
         V29_TRY(hipStreamSynchronize(m->stream));
     return 0;
+}
+
+// The tap behind xxx_rx_set_qam_report_handler(): from the next spangpu_modem_rx() on, every channel's
+// qam_report(user, constel, target, symbol) calls are recorded beside its put_bit stream.
+int spangpu_modem_qam_tap(spangpu_modem_t *m, int enable)
+{
+    if (m == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null modem bank");
+    m->qam_tap = (enable != 0);
+    return 0;
+}
+
+// The qam_report calls of the last spangpu_modem_rx(): for channel c, counts[c] records of seven words at
+// records + c*cap*7 -- {put_bit / status calls that came before it in this rx call, 1 if constel and target were NULL
+// (V.27ter's timing hop report, v27ter_rx.c:517), symbol, constel re, im, target re, im (binary32 bits)}.  Returns cap.
+int spangpu_modem_qam_reports(spangpu_modem_t *m, const uint32_t **records, const int32_t **counts)
+{
+    if (m == nullptr  ||  records == nullptr  ||  counts == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (m->last_qam_cap <= 0)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "no spangpu_modem_rx() with the tap on yet");
+    V29_TRY(hipSetDevice(m->device));
+    V29_TRY(hipMemcpyAsync(m->h_qam, m->qam, (size_t) m->n_ch*m->last_qam_cap*7*sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
+    V29_TRY(hipMemcpyAsync(m->h_qam_count, m->qam_count, (size_t) m->n_ch*sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+    V29_TRY(hipStreamSynchronize(m->stream));
+    *records = m->h_qam;
+    *counts = m->h_qam_count;
+    return m->last_qam_cap;
 }
 
 // The put_bit stream of the last spangpu_modem_rx() call: for channel c, counts[c] entries at

@@ -28,6 +28,7 @@ struct spangpu_modem_group_s
     int n_attached;
     int n_staged;
     int tick_samples;
+    int qam_tap;                /* some object of the group has a qam report handler: the bank records the reports */
 };
 
 typedef struct
@@ -41,6 +42,8 @@ typedef struct
     void *put_bit_user_data;
     span_modem_status_func_t status_handler;
     void *status_user_data;
+    qam_report_handler_t qam_report;
+    void *qam_user_data;
     uint32_t words[MAX_WORDS];              /* scratch for state reads (equalizer_state() hands out a view) */
     int n_floats;
 } modem_obj_t;
@@ -105,16 +108,47 @@ spangpu_modem_t *spangpu_modem_group_bank(spangpu_modem_group_t *g)
     return g  ?  g->bank  :  NULL;
 }
 
-static void deliver(modem_obj_t *o, const int8_t *ev, int n)
+/* One qam_report() call from its record (include/spangpu.h: spangpu_modem_qam_reports()) */
+static void deliver_qam(modem_obj_t *o, const uint32_t *r)
+{
+    complexf_t constel;
+    complexf_t target;
+
+    if (r[1])
+    {
+        o->qam_report(o->qam_user_data, NULL, NULL, (int) r[2]);
+        return;
+    }
+    memcpy(&constel.re, &r[3], 4);
+    memcpy(&constel.im, &r[4], 4);
+    memcpy(&target.re, &r[5], 4);
+    memcpy(&target.im, &r[6], 4);
+    o->qam_report(o->qam_user_data, &constel, &target, (int) r[2]);
+}
+
+/* The callbacks of one rx call, in the order the reference makes them: record q comes after q[0] put_bit / status calls */
+static void deliver(modem_obj_t *o, const int8_t *ev, int n, const uint32_t *qam, int nq)
 {
     int i;
+    int q = 0;
 
     for (i = 0;  i < n;  i++)
     {
+        while (q < nq  &&  (int) qam[7*q] <= i)
+        {
+            if (o->qam_report)
+                deliver_qam(o, &qam[7*q]);
+            q++;
+        }
         if (ev[i] < 0  &&  o->status_handler)
             o->status_handler(o->status_user_data, ev[i]);
         else if (o->put_bit)
             o->put_bit(o->put_bit_user_data, ev[i]);
+    }
+    for (  ;  q < nq;  q++)
+    {
+        if (o->qam_report)
+            deliver_qam(o, &qam[7*q]);
     }
 }
 
@@ -122,7 +156,10 @@ int spangpu_modem_group_flush(spangpu_modem_group_t *g)
 {
     const int8_t *events;
     const int32_t *counts;
+    const uint32_t *qam = NULL;
+    const int32_t *qcounts = NULL;
     int cap;
+    int qcap = 0;
     int c;
     int rc;
 
@@ -134,13 +171,18 @@ int spangpu_modem_group_flush(spangpu_modem_group_t *g)
         return rc;
     if ((cap = spangpu_modem_events(g->bank, &events, &counts)) < 0)
         return cap;
+    if (g->qam_tap  &&  (qcap = spangpu_modem_qam_reports(g->bank, &qam, &qcounts)) < 0)
+        return qcap;
     rc = g->n_staged;
     for (c = 0;  c < g->n_ch;  c++)
     {
         /* a channel that staged nothing this tick was fed its previous (stale) frame; groups are meant to be
            driven with every attached channel each tick, as the header says -- its events are still delivered */
         if (g->handles[c])
-            deliver((modem_obj_t *) g->handles[c], events + (size_t) c*cap, (counts[c] < cap)  ?  counts[c]  :  cap);
+        {
+            deliver((modem_obj_t *) g->handles[c], events + (size_t) c*cap, (counts[c] < cap)  ?  counts[c]  :  cap,
+                    qam  ?  qam + (size_t) c*qcap*7  :  NULL, qam  ?  ((qcounts[c] < qcap)  ?  qcounts[c]  :  qcap)  :  0);
+        }
         g->staged[c] = 0;
     }
     g->n_staged = 0;
@@ -190,6 +232,28 @@ static modem_obj_t *obj_attach(size_t size, int kind, spangpu_modem_group_t *g, 
     return obj_new(size, kind, g, channel, 0, g->bit_rate, put_bit, user_data);
 }
 
+/* The bank records the reports as long as any object of the group wants them (the tap changes the kernel variant, not
+   the results) */
+static void obj_set_qam(modem_obj_t *o, qam_report_handler_t handler, void *user_data)
+{
+    spangpu_modem_group_t *g = o->grp;
+    int c;
+    int any = 0;
+
+    o->qam_report = handler;
+    o->qam_user_data = user_data;
+    for (c = 0;  c < g->n_ch;  c++)
+    {
+        if (g->handles[c]  &&  ((modem_obj_t *) g->handles[c])->qam_report)
+            any = 1;
+    }
+    if (any != g->qam_tap)
+    {
+        g->qam_tap = any;
+        spangpu_modem_qam_tap(g->bank, any);
+    }
+}
+
 static int obj_rx(modem_obj_t *o, const int16_t amp[], int len)
 {
     spangpu_modem_group_t *g = o->grp;
@@ -233,6 +297,8 @@ static int obj_free(modem_obj_t *o)
 {
     if (o == NULL)
         return 0;
+    if (o->grp  &&  o->qam_report)
+        obj_set_qam(o, NULL, NULL);
     if (o->grp)
     {
         o->grp->handles[o->channel] = NULL;
@@ -352,6 +418,10 @@ void pfx##_set_modem_status_handler(T *s, span_modem_status_func_t handler, void
 {                                                                                                                    \
     s->o.status_handler = handler;                                                                                   \
     s->o.status_user_data = user_data;                                                                               \
+}                                                                                                                    \
+void pfx##_set_qam_report_handler(T *s, qam_report_handler_t handler, void *user_data)                               \
+{                                                                                                                    \
+    obj_set_qam(&s->o, handler, user_data);                                                                          \
 }                                                                                                                    \
 int pfx##_equalizer_state(T *s, complexf_t **coeffs)                                                                 \
 {                                                                                                                    \

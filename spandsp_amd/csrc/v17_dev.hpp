@@ -76,13 +76,16 @@ struct V17Launch
     int8_t *events;
     int32_t *ev_count;
     int ev_cap;
+    uint32_t *qam;              // QAM variant: [n_ch][qam_cap][7] qam_report records (include/spangpu.h), else unused
+    int32_t *qam_count;         // [n_ch]
+    int qam_cap;
     const V17Tables *tab;
 };
 
 // DDS_PHASE(), spandsp/dds.h:32 (float arithmetic)
 #define V17_DDS_PHASE(deg)  ((int32_t) ((uint32_t) ((((deg) < 0.0f)  ?  (360.0f + (deg))  :  (deg))*65536.0f*65536.0f/360.0f)))
 
-template <int CPW>
+template <int CPW, bool QAM = false>
 __global__ __launch_bounds__(64)
 void v17_bank_kernel(const V17Launch L)
 {
@@ -241,6 +244,28 @@ void v17_bank_kernel(const V17Launch L)
         if (n_ev < L.ev_cap)
             evp[n_ev] = (int8_t) v;
         n_ev++;
+    };
+
+    // qam_report(user, constel, target, symbol) calls, for the kernel variant a caller's tap asks for: one record per
+    // call = {events emitted before it in this launch, 1 if the pointers were NULL, symbol, constel re / im, target re / im}
+    int n_q = 0;
+    auto qam_report = [&](uint32_t null_ptrs, int symbol, float cre, float cim, float tre, float tim)
+    {
+        if constexpr (QAM)
+        {
+            if (n_q < L.qam_cap)
+            {
+                uint32_t *r = L.qam + ((size_t) ch*L.qam_cap + n_q)*7;
+                r[0] = (uint32_t) n_ev;
+                r[1] = null_ptrs;
+                r[2] = (uint32_t) symbol;
+                r[3] = __float_as_uint(cre);
+                r[4] = __float_as_uint(cim);
+                r[5] = __float_as_uint(tre);
+                r[6] = __float_as_uint(tim);
+            }
+            n_q++;
+        }
     };
 
     // v17_rx_restart(s, s->bit_rate, s->short_train), v17rx.c:1399-1500
@@ -755,8 +780,17 @@ void v17_bank_kernel(const V17Launch L)
                 do_tune = false;
                 do_save = false;
                 int cs = 0;
+                float rep_re = 0.0f;                        // `target` of process_half_baud(), for the qam report
+                float rep_im = 0.0f;
                 if (stage == V17_NORMAL  ||  stage == V17_TCM_WINDUP  ||  stage == V17_TEST_ONES)
+                {
                     cs = decode_baud(zre, zim);
+                    if constexpr (QAM)
+                    {
+                        rep_re = t_con[2*cs];
+                        rep_im = t_con[2*cs + 1];
+                    }
+                }
                 switch (stage)
                 {
                 case V17_NORMAL:
@@ -827,8 +861,12 @@ void v17_bank_kernel(const V17Launch L)
                             break;
                         }
                         spin((uint32_t) angle - (uint32_t) V17_DDS_PHASE(18.433f));
-                        descramble(1);
-                        descramble(1);
+                        {
+                            int skipped = descramble(1);
+                            skipped = (skipped << 1) | descramble(1);
+                            if constexpr (QAM)
+                                cdba(skipped, rep_re, rep_im);
+                        }
                         training_count = 1;
                         stage = V17_COARSE_TRAIN_ON_CDBA;
                         emit(-3);                           // SIG_STATUS_TRAINING_IN_PROGRESS
@@ -843,6 +881,8 @@ void v17_bank_kernel(const V17Launch L)
                     int bit = descramble(1);
                     bit = (bit << 1) | descramble(1);
                     cdba(bit, tre, tim);
+                    rep_re = tre;
+                    rep_im = tim;
                     track_carrier(tre, tim);
                     tune_equalizer(tre, tim);
                     const float ere = zre - tre;
@@ -861,6 +901,8 @@ void v17_bank_kernel(const V17Launch L)
                     int bit = descramble(1);
                     bit = (bit << 1) | descramble(1);
                     cdba(bit, tre, tim);
+                    rep_re = tre;
+                    rep_im = tim;
                     track_carrier(tre, tim);
                     tune_equalizer(tre, tim);
                     if (++training_count >= 2976 - 48)
@@ -877,6 +919,8 @@ void v17_bank_kernel(const V17Launch L)
                     int bit = descramble(1);
                     bit = (bit << 1) | descramble(1);
                     cdba(bit, tre, tim);
+                    rep_re = tre;
+                    rep_im = tim;
                     if (++training_count < 2976 - 20)
                     {
                         track_carrier(tre, tim);
@@ -903,6 +947,8 @@ void v17_bank_kernel(const V17Launch L)
                 case V17_BRIDGE:
                     descramble(0x8880 >> ((training_count & 0x7) << 1));
                     descramble(0x8880 >> (((training_count & 0x7) << 1) + 1));
+                    rep_re = zre;                           // target = &z (v17rx.c:914)
+                    rep_im = zim;
                     if (++training_count >= 64)
                     {
                         training_error = 0.0f;
@@ -925,8 +971,12 @@ void v17_bank_kernel(const V17Launch L)
                     const int32_t ang = (int32_t) ((uint32_t) angle - (uint32_t) prev);
                     if (ang > V17_DDS_PHASE(90.0f)  ||  ang < V17_DDS_PHASE(-90.0f))
                     {
-                        descramble(1);
-                        descramble(1);
+                        {
+                            int skipped = descramble(1);
+                            skipped = (skipped << 1) | descramble(1);
+                            if constexpr (QAM)
+                                cdba(skipped, rep_re, rep_im);
+                        }
                         training_error = 0.0f;
                         training_count = 1;
                         stage = V17_SHORT_TRAIN_ON_CDBA_AND_TEST;
@@ -934,6 +984,8 @@ void v17_bank_kernel(const V17Launch L)
                     else
                     {
                         cdba((training_count & 1) + 2, tre, tim);
+                        rep_re = tre;
+                        rep_im = tim;
                         track_carrier(tre, tim);
                         if (++training_count > 256)
                             park(false);
@@ -945,6 +997,8 @@ void v17_bank_kernel(const V17Launch L)
                     int bit = descramble(1);
                     bit = (bit << 1) | descramble(1);
                     cdba(bit, tre, tim);
+                    rep_re = tre;
+                    rep_im = tim;
                     track_carrier(tre, tim);
                     if (training_count > 8)
                     {
@@ -1017,6 +1071,7 @@ void v17_bank_kernel(const V17Launch L)
                 default:
                     break;
                 }
+                qam_report(0, cs, zre, zim, rep_re, rep_im);                        // v17rx.c:1117-1131
                 if (do_track)
                 {
                     const float error = zim*tgt_re - zre*tgt_im;
@@ -1119,6 +1174,8 @@ void v17_bank_kernel(const V17Launch L)
     sti(XI_TRELLIS_PTR, trellis_ptr);
     sti(XI_TOTAL_CORR, total_corr);
     L.ev_count[ch] = n_ev;
+    if constexpr (QAM)
+        L.qam_count[ch] = n_q;
 #undef RRC2
 #undef TAP
 #undef PAST

@@ -69,10 +69,13 @@ struct V27Launch
     int8_t *events;
     int32_t *ev_count;
     int ev_cap;
+    uint32_t *qam;              // QAM variant: [n_ch][qam_cap][7] qam_report records (include/spangpu.h), else unused
+    int32_t *qam_count;         // [n_ch]
+    int qam_cap;
     const V27Tables *tab;
 };
 
-template <int CPW>
+template <int CPW, bool QAM = false>
 __global__ __launch_bounds__(64)
 void v27ter_bank_kernel(const V27Launch L)
 {
@@ -188,6 +191,28 @@ void v27ter_bank_kernel(const V27Launch L)
         if (n_ev < L.ev_cap)
             evp[n_ev] = (int8_t) v;
         n_ev++;
+    };
+
+    // qam_report(user, constel, target, symbol) calls, for the kernel variant a caller's tap asks for: one record per
+    // call = {events emitted before it in this launch, 1 if the pointers were NULL, symbol, constel re / im, target re / im}
+    int n_q = 0;
+    auto qam_report = [&](uint32_t null_ptrs, int symbol, float cre, float cim, float tre, float tim)
+    {
+        if constexpr (QAM)
+        {
+            if (n_q < L.qam_cap)
+            {
+                uint32_t *r = L.qam + ((size_t) ch*L.qam_cap + n_q)*7;
+                r[0] = (uint32_t) n_ev;
+                r[1] = null_ptrs;
+                r[2] = (uint32_t) symbol;
+                r[3] = __float_as_uint(cre);
+                r[4] = __float_as_uint(cim);
+                r[5] = __float_as_uint(tre);
+                r[6] = __float_as_uint(tim);
+            }
+            n_q++;
+        }
     };
 
     // v27ter_rx_restart() as the receive path reaches it (v27ter_rx.c:1091-1160; s->old_train is never set)
@@ -562,6 +587,7 @@ void v27ter_bank_kernel(const V27Launch L)
                     {
                         eq_put_step += gardner_integrate/128;
                         total_corr += gardner_integrate/128;
+                        qam_report(1, gardner_integrate, 0.0f, 0.0f, 0.0f, 0.0f);      // v27ter_rx.c:517-518
                         gardner_integrate = 0;
                     }
                 }
@@ -592,11 +618,15 @@ void v27ter_bank_kernel(const V27Launch L)
                 do_track = false;
                 do_tune = false;
                 do_save = false;
+                float rep_re = 0.0f;                        // `target` of process_half_baud(), for the qam report
+                float rep_im = 0.0f;
                 if (stage == V27_NORMAL  ||  stage == V27_TEST_ONES)
                     decode_baud(zre, zim);
                 switch (stage)
                 {
                 case V27_NORMAL:
+                    if constexpr (QAM)
+                        target_of(fast  ?  constellation_state  :  (constellation_state << 1), rep_re, rep_im);
                     break;
                 case V27_SYMBOL_ACQUISITION:
                     if (++training_count >= 30)
@@ -661,6 +691,7 @@ void v27ter_bank_kernel(const V27Launch L)
                         descramble(1);
                         descramble(1);
                         constellation_state = training_bc  ?  4  :  0;
+                        rep_re = training_bc  ?  -1.414f  :  1.414f;
                         training_count = 1;
                         stage = V27_TRAIN_ON_ABAB;
                         emit(-3);                           // SIG_STATUS_TRAINING_IN_PROGRESS
@@ -678,6 +709,7 @@ void v27ter_bank_kernel(const V27Launch L)
                     descramble(1);
                     constellation_state = training_bc  ?  4  :  0;
                     const float tre = training_bc  ?  -1.414f  :  1.414f;
+                    rep_re = tre;
                     track_carrier(tre, 0.0f);
                     tune_equalizer(tre, 0.0f);
                     carrier_track_i = 400.0f + (200000.0f - 400.0f)*(float) (1074 - training_count)/(float) 1074;
@@ -695,6 +727,8 @@ void v27ter_bank_kernel(const V27Launch L)
                     float tre;
                     float tim;
                     target_of(fast  ?  constellation_state  :  (constellation_state << 1), tre, tim);
+                    rep_re = tre;
+                    rep_im = tim;
                     const float dre2 = zre - tre;
                     const float dim2 = zim - tim;
                     training_error += (dre2*dre2 + dim2*dim2);
@@ -718,6 +752,7 @@ void v27ter_bank_kernel(const V27Launch L)
                 default:
                     break;
                 }
+                qam_report(0, constellation_state, zre, zim, rep_re, rep_im);      // v27ter_rx.c:765-777
                 if (do_track)
                 {
                     const float error = zim*tgt_re - zre*tgt_im;
@@ -799,6 +834,8 @@ void v27ter_bank_kernel(const V27Launch L)
     sti(WI_LAST_ANGLES, last_angle0);
     sti(WI_LAST_ANGLES + 1, last_angle1);
     L.ev_count[ch] = n_ev;
+    if constexpr (QAM)
+        L.qam_count[ch] = n_q;
 #undef RRC2
 #undef TAP
 }

@@ -108,6 +108,9 @@ struct V29Launch
     int8_t *events;             // [n_ch][ev_cap]: 0/1 bits and negative SIG_STATUS_* codes, in order
     int32_t *ev_count;          // [n_ch]
     int ev_cap;
+    uint32_t *qam;              // QAM variant: [n_ch][qam_cap][7] qam_report records (include/spangpu.h), else unused
+    int32_t *qam_count;         // [n_ch]
+    int qam_cap;
     const V29Tables *tab;
 };
 
@@ -201,7 +204,7 @@ __device__ __forceinline__ int32_t v29_arctan2(float y, float x)
 
 // CPW = channels per workgroup (one wavefront): 64 when the bank is big enough to fill every SIMD of the chip with
 // full waves, fewer (idle upper lanes) for small banks so that the channels still spread over all 1024 SIMDs.
-template <int CPW>
+template <int CPW, bool QAM = false>
 __global__ __launch_bounds__(64)
 void v29_bank_kernel(const V29Launch L)
 {
@@ -347,6 +350,28 @@ void v29_bank_kernel(const V29Launch L)
         if (n_ev < L.ev_cap)
             evp[n_ev] = (int8_t) v;
         n_ev++;
+    };
+
+    // qam_report(user, constel, target, symbol) calls, for the kernel variant a caller's tap asks for: one record per
+    // call = {events emitted before it in this launch, 1 if the pointers were NULL, symbol, constel re / im, target re / im}
+    int n_q = 0;
+    auto qam_report = [&](uint32_t null_ptrs, int symbol, float cre, float cim, float tre, float tim)
+    {
+        if constexpr (QAM)
+        {
+            if (n_q < L.qam_cap)
+            {
+                uint32_t *r = L.qam + ((size_t) ch*L.qam_cap + n_q)*7;
+                r[0] = (uint32_t) n_ev;
+                r[1] = null_ptrs;
+                r[2] = (uint32_t) symbol;
+                r[3] = __float_as_uint(cre);
+                r[4] = __float_as_uint(cim);
+                r[5] = __float_as_uint(tre);
+                r[6] = __float_as_uint(tim);
+            }
+            n_q++;
+        }
     };
 
     // v29rx.c:1019-1098 (old_train == false, the only way the receive path calls it)
@@ -747,11 +772,18 @@ void v29_bank_kernel(const V29Launch L)
                 do_track = false;
                 do_tune = false;
                 do_save = false;
+                float rep_re = 0.0f;                        // `target` of process_half_baud(), for the qam report
+                float rep_im = 0.0f;
                 if (stage == V29_NORMAL  ||  stage == V29_TEST_ONES)
                     decode_baud(zre, zim);
                 switch (stage)
                 {
                 case V29_NORMAL:
+                    if constexpr (QAM)
+                    {
+                        rep_re = t_const[2*constellation_state];
+                        rep_im = t_const[2*constellation_state + 1];
+                    }
                     break;
                 case V29_SYMBOL_ACQUISITION:
                     if (++training_count >= 60)
@@ -810,6 +842,11 @@ void v29_bank_kernel(const V29Launch L)
                         carrier_phase += (uint32_t) angle;
                         const int bit = scrambled_training_bit();
                         constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;   // cdcd_pos = {0,11,0,3,0,2}
+                        if constexpr (QAM)
+                        {
+                            rep_re = t_const[2*constellation_state];
+                            rep_im = t_const[2*constellation_state + 1];
+                        }
                         training_count = 1;
                         stage = V29_TRAIN_ON_CDCD;
                         emit(-3);                           // SIG_STATUS_TRAINING_IN_PROGRESS
@@ -825,6 +862,8 @@ void v29_bank_kernel(const V29Launch L)
                     constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;
                     const float tre = t_const[2*constellation_state];
                     const float tim = t_const[2*constellation_state + 1];
+                    rep_re = tre;
+                    rep_im = tim;
                     track_carrier(tre, tim);
                     tune_equalizer(tre, tim);
                     if (++training_count >= 384 - 48)
@@ -842,6 +881,8 @@ void v29_bank_kernel(const V29Launch L)
                     constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;
                     const float tre = t_const[2*constellation_state];
                     const float tim = t_const[2*constellation_state + 1];
+                    rep_re = tre;
+                    rep_im = tim;
                     track_carrier(tre, tim);
                     tune_equalizer(tre, tim);
                     const float dre2 = zre - tre;
@@ -867,6 +908,8 @@ void v29_bank_kernel(const V29Launch L)
                 {
                     const float tre = t_const[2*constellation_state];
                     const float tim = t_const[2*constellation_state + 1];
+                    rep_re = tre;
+                    rep_im = tim;
                     const float dre2 = zre - tre;
                     const float dim2 = zim - tim;
                     training_error += dre2*dre2 + dim2*dim2;
@@ -890,6 +933,7 @@ void v29_bank_kernel(const V29Launch L)
                 default:
                     break;
                 }
+                qam_report(0, constellation_state, zre, zim, rep_re, rep_im);      // v29rx.c:769-783
                 if (do_track)
                 {
                     const float error = zim*tgt_re - zre*tgt_im;
@@ -981,6 +1025,8 @@ void v29_bank_kernel(const V29Launch L)
         sti(VI_LOW_SAMPLES, low_samples);
         sti(VI_DROP_PENDING, drop_pending);
         L.ev_count[ch] = n_ev;
+        if constexpr (QAM)
+            L.qam_count[ch] = n_q;
     }
 }
 

@@ -142,6 +142,8 @@ def lib():
             "spangpu_modem_sync": (ci, [vp]),
             "spangpu_modem_rx": (ci, [vp, vp, ci, ci, ll]),
             "spangpu_modem_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_modem_qam_tap": (ci, [vp, ci]),
+            "spangpu_modem_qam_reports": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
             "spangpu_modem_state_words": (ci, [ci, C.POINTER(ci), C.POINTER(ci)]),
             "spangpu_modem_get_state": (ci, [vp, ci, vp]),
             "spangpu_modem_restart": (ci, [vp, ci]),
@@ -450,6 +452,20 @@ class ModemBank:
         counts = np.frombuffer((C.c_char*(4*self.n)).from_address(cnt.value), dtype=np.int32).copy()
         raw = np.frombuffer((C.c_char*(cap*self.n)).from_address(ev.value), dtype=np.int8).reshape(self.n, cap)
         assert counts.max(initial=0) <= cap, "event buffer overflow"
+        return [raw[c, :counts[c]].copy() for c in range(self.n)]
+
+    def qam_tap(self, on=True):
+        """Record the qam_report_handler_t calls of the following rx calls (xxx_rx_set_qam_report_handler)."""
+        _check(lib().spangpu_modem_qam_tap(self.h, int(on)))
+
+    def qam_reports(self):
+        """List (per channel) of uint32 [n, 7]: events before the report, NULL flag, symbol, constel re / im, target re / im."""
+        rec = C.c_void_p()
+        cnt = C.c_void_p()
+        cap = _check(lib().spangpu_modem_qam_reports(self.h, C.byref(rec), C.byref(cnt)))
+        counts = np.frombuffer((C.c_char*(4*self.n)).from_address(cnt.value), dtype=np.int32).copy()
+        raw = np.frombuffer((C.c_char*(28*cap*self.n)).from_address(rec.value), dtype=np.uint32).reshape(self.n, cap, 7)
+        assert counts.max(initial=0) <= cap, "report buffer overflow"
         return [raw[c, :counts[c]].copy() for c in range(self.n)]
 
     def get_state(self, channel):

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
 from oracle import ref  # noqa: E402
-from test_oracle_pin import (ALL_FREQS, AWGN_CASES, V29TX_CASES, V27TX_CASES, V17TX_CASES, v29tx_run, FSK_CASES, fsk_run, fsk_scenario, mct_run, mct_scenario, ECHO_CASES, V17_CASES, V27_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
+from test_oracle_pin import (ALL_FREQS, AWGN_CASES, QAM_GOLDEN_CASES, qam_golden_run, V29TX_CASES, V27TX_CASES, V17TX_CASES, v29tx_run, FSK_CASES, fsk_run, fsk_scenario, mct_run, mct_scenario, ECHO_CASES, V17_CASES, V27_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
                              tx_scenario, v17_scenario, v27ter_scenario, v29_run, v29_scenario)
 
 
@@ -135,6 +135,10 @@ def main():
     for i, (bit_rate, tep, seed) in enumerate(V17TX_CASES):
         kw["amp_%d" % i], kw["snaps_%d" % i] = v29tx_run(ref.V17Tx(bit_rate, tep, seed), seed, 9600 if bit_rate != 9600 else 14400, 260, True)
     save("v17tx", **kw)
+    kw = {}
+    for name, bit_rate, seed, noise in QAM_GOLDEN_CASES:
+        kw["%s_%d" % (name, bit_rate)] = qam_golden_run({"v29": ref.V29Rx, "v27ter": ref.V27terRx, "v17": ref.V17Rx}[name], name, bit_rate, seed, noise)
+    save("modem_qam", **kw)
     kw = {}
     for i, (seed, level) in enumerate(AWGN_CASES):
         kw["amp_%d" % i] = ref.awgn(seed, level, 30001)

@@ -1006,3 +1006,21 @@ def test_golden_v17(built, bit_rate):
     assert np.array_equal(ev, g["events"].astype(np.int32))
     assert np.array_equal(f, g["fwords"])
     assert np.array_equal(w, g["iwords"])
+
+
+QAM_GOLDEN_CASES = [("v29", 9600, 11, -45.0), ("v27ter", 4800, 31, -50.0), ("v17", 14400, 51, -50.0)]
+
+
+def qam_golden_run(make, name, bit_rate, seed, noise):
+    x = {"v29": v29_scenario, "v27ter": v27ter_scenario, "v17": v17_scenario}[name](bit_rate, seed, noise)
+    return qam_run(make(bit_rate), x, (160,))[1]
+
+
+def test_golden_modem_qam(built):
+    """The reference's qam_report streams (committed) against the oracle, where the reference itself is not present."""
+    from oracle import restated as orc
+    use_golden_modem_tables()
+    g = np.load(os.path.join(GOLDEN, "modem_qam.npz"))
+    for name, bit_rate, seed, noise in QAM_GOLDEN_CASES:
+        q = qam_golden_run({"v29": orc.V29, "v27ter": orc.V27ter, "v17": orc.V17}[name], name, bit_rate, seed, noise)
+        assert np.array_equal(q, g["%s_%d" % (name, bit_rate)]), (name, bit_rate)
