@@ -369,6 +369,21 @@ SPANGPU_API void dtmf_tx_set_timing(dtmf_tx_state_t *s, int on_time, int off_tim
 SPANGPU_API int dtmf_tx_put(dtmf_tx_state_t *s, const char *digits, int len);
 SPANGPU_API int dtmf_tx(dtmf_tx_state_t *s, int16_t amp[], int max_samples);
 
+/* Bell MF and MFC/R2 senders (src/spandsp/bell_r2_mf.h:137-191, src/bell_r2_mf.c:281-372,386-462): a private one-channel
+   signal source bank each; caller-supplied storage (s != NULL) is not supported (state lives in HBM) */
+typedef struct bell_mf_tx_state_s bell_mf_tx_state_t;
+typedef struct r2_mf_tx_state_s r2_mf_tx_state_t;
+SPANGPU_API bell_mf_tx_state_t *bell_mf_tx_init(bell_mf_tx_state_t *s);
+SPANGPU_API int bell_mf_tx_release(bell_mf_tx_state_t *s);
+SPANGPU_API int bell_mf_tx_free(bell_mf_tx_state_t *s);
+SPANGPU_API int bell_mf_tx_put(bell_mf_tx_state_t *s, const char *digits, int len);
+SPANGPU_API int bell_mf_tx(bell_mf_tx_state_t *s, int16_t amp[], int max_samples);
+SPANGPU_API r2_mf_tx_state_t *r2_mf_tx_init(r2_mf_tx_state_t *s, bool fwd);
+SPANGPU_API int r2_mf_tx_release(r2_mf_tx_state_t *s);
+SPANGPU_API int r2_mf_tx_free(r2_mf_tx_state_t *s);
+SPANGPU_API int r2_mf_tx_put(r2_mf_tx_state_t *s, char digit);
+SPANGPU_API int r2_mf_tx(r2_mf_tx_state_t *s, int16_t amp[], int samples);
+
 #if defined(__cplusplus)
 }
 #endif

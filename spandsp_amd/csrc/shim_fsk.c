@@ -531,3 +531,102 @@ int dtmf_tx(dtmf_tx_state_t *s, int16_t amp[], int max_samples)
         return 0;
     return len;
 }
+
+/* ---- bell_mf_tx / r2_mf_tx: one private sender per object (src/bell_r2_mf.c:281-372, 386-462) ----------------- */
+struct bell_mf_tx_state_s
+{
+    spangpu_txbank_t *bank;
+};
+
+struct r2_mf_tx_state_s
+{
+    spangpu_txbank_t *bank;
+};
+
+bell_mf_tx_state_t *bell_mf_tx_init(bell_mf_tx_state_t *s)
+{
+    if (s != NULL  ||  (s = (bell_mf_tx_state_t *) calloc(1, sizeof(*s))) == NULL)
+        return NULL;
+    if (spangpu_txbank_create(&s->bank, 0, SPANGPU_TX_BELL_MF, 1) != SPANGPU_OK)
+    {
+        free(s);
+        return NULL;
+    }
+    return s;
+}
+
+int bell_mf_tx_release(bell_mf_tx_state_t *s)
+{
+    (void) s;
+    return 0;
+}
+
+int bell_mf_tx_free(bell_mf_tx_state_t *s)
+{
+    if (s)
+    {
+        spangpu_txbank_destroy(s->bank);
+        free(s);
+    }
+    return 0;
+}
+
+int bell_mf_tx_put(bell_mf_tx_state_t *s, const char *digits, int len)
+{
+    const int rc = spangpu_txbank_put(s->bank, 0, 1, digits, len);
+
+    return (rc < 0)  ?  -1  :  rc;
+}
+
+int bell_mf_tx(bell_mf_tx_state_t *s, int16_t amp[], int max_samples)
+{
+    int len = 0;
+
+    if (max_samples <= 0  ||  spangpu_txbank_tx(s->bank, SPANGPU_MEM_HOST, amp, max_samples, max_samples, &len) < 0)
+        return 0;
+    return len;
+}
+
+r2_mf_tx_state_t *r2_mf_tx_init(r2_mf_tx_state_t *s, bool fwd)
+{
+    if (s != NULL  ||  (s = (r2_mf_tx_state_t *) calloc(1, sizeof(*s))) == NULL)
+        return NULL;
+    if (spangpu_txbank_create(&s->bank, 0, fwd  ?  SPANGPU_TX_R2_MF_FWD  :  SPANGPU_TX_R2_MF_BACK, 1) != SPANGPU_OK)
+    {
+        free(s);
+        return NULL;
+    }
+    return s;
+}
+
+int r2_mf_tx_release(r2_mf_tx_state_t *s)
+{
+    (void) s;
+    return 0;
+}
+
+int r2_mf_tx_free(r2_mf_tx_state_t *s)
+{
+    if (s)
+    {
+        spangpu_txbank_destroy(s->bank);
+        free(s);
+    }
+    return 0;
+}
+
+int r2_mf_tx_put(r2_mf_tx_state_t *s, char digit)
+{
+    /* one signal at a time: the tone of `digit` until the next put, 0 switches it off (bell_r2_mf.c:414-434) */
+    (void) spangpu_txbank_put(s->bank, 0, 1, &digit, 1);
+    return 0;
+}
+
+int r2_mf_tx(r2_mf_tx_state_t *s, int16_t amp[], int samples)
+{
+    int len = 0;
+
+    if (samples <= 0  ||  spangpu_txbank_tx(s->bank, SPANGPU_MEM_HOST, amp, samples, samples, &len) < 0)
+        return 0;
+    return len;
+}

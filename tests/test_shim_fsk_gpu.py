@@ -183,3 +183,33 @@ def test_dtmf_tx_object_equals_oracle(L):
         want = o.tx(n)
         assert got == len(want) and np.array_equal(buf[:got], want)
     L.dtmf_tx_free(s)
+
+
+def test_bell_and_r2_tx_objects_equal_oracle(L):
+    from oracle import restated as orc
+    vp, ci = C.c_void_p, C.c_int
+    for name, res, args in [("bell_mf_tx_init", vp, [vp]), ("bell_mf_tx_put", ci, [vp, C.c_char_p, ci]), ("bell_mf_tx", ci, [vp, vp, ci]),
+                            ("bell_mf_tx_free", ci, [vp]), ("r2_mf_tx_init", vp, [vp, C.c_bool]), ("r2_mf_tx_put", ci, [vp, C.c_char]),
+                            ("r2_mf_tx", ci, [vp, vp, ci]), ("r2_mf_tx_free", ci, [vp])]:
+        getattr(L, name).restype = res
+        getattr(L, name).argtypes = args
+    buf = np.zeros(2000, np.int16)
+    s = L.bell_mf_tx_init(None)
+    assert s and L.bell_mf_tx_init(C.c_void_p(1)) is None
+    o = orc.BellMfTx()
+    assert L.bell_mf_tx_put(s, b"K1234567890S", -1) == o.put("K1234567890S")
+    for n in (160, 1, 777, 2000, 2000, 2000, 2000, 2000, 2000):
+        got = L.bell_mf_tx(s, buf.ctypes.data, n)
+        want = o.tx(n)
+        assert got == len(want) and np.array_equal(buf[:got], want)
+    L.bell_mf_tx_free(s)
+    for fwd in (True, False):
+        s = L.r2_mf_tx_init(None, fwd)
+        assert s
+        o = orc.R2MfTx(fwd)
+        for digit, n in ((b"5", 400), (b"F", 161), (b"\0", 80), (b"x", 40), (b"1", 333)):
+            assert L.r2_mf_tx_put(s, digit) == o.put(digit) == 0
+            got = L.r2_mf_tx(s, buf.ctypes.data, n)
+            want = o.tx(n)
+            assert got == len(want) and np.array_equal(buf[:got], want), (fwd, digit)
+        L.r2_mf_tx_free(s)
