@@ -176,6 +176,8 @@ void v17_bank_kernel(const V17Launch L)
     // equaliser delay line in age order: xre[i] = eq_buf[(eq_step + i) mod 33] (i = 0 oldest)
     float xre[kEqLen];
     float xim[kEqLen];
+    bool eq_clear_pending = false;
+    bool restart_pending = false;
     {
         const int es = ldi(XI_EQ_STEP);
 #pragma unroll
@@ -300,12 +302,8 @@ void v17_bank_kernel(const V17Launch L)
         trellis_ptr = 14;
         carrier_phase = 0;
         power_reading = 0;
-#pragma unroll
-        for (int i = 0;  i < kEqLen;  i++)
-        {
-            xre[i] = 0.0f;
-            xim[i] = 0.0f;
-        }
+        // (the equaliser delay line is register state: it is cleared where it is next looked at, see v29_dev.hpp)
+        eq_clear_pending = true;
         eq_put_step = kV17Sets*10/(3*2) - 1;
         eq_step = 0;
         eq_skip = 0;
@@ -580,6 +578,7 @@ void v17_bank_kernel(const V17Launch L)
     {
     // One round = one baud of every lane (see v29_dev.hpp): two T/2 instants, then the baud phase with all lanes in step.
     bool any_ready = false;
+    bool restarted = false;
     bool baud_done = false;
     float zre = 0.0f;
     float zim = 0.0f;
@@ -591,9 +590,9 @@ void v17_bank_kernel(const V17Launch L)
     int power = 0;
     int step = 0;
     float sre = 0.0f;
-    while (__any(take  &&  !ready  &&  pos < tn))
+    while (__any(take  &&  !ready  &&  !restart_pending  &&  pos < tn))
     {
-    if (take  &&  !ready  &&  pos < tn)
+    if (take  &&  !ready  &&  !restart_pending  &&  pos < tn)
     {
         const uint32_t pw = pcm[(pos >> 1)*CPW + lane];
         const int amp = (int) (short) ((pos & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
@@ -634,9 +633,11 @@ void v17_bank_kernel(const V17Launch L)
                 {
                     if (--signal_present <= 0)
                     {
-                        restart();
+                        // v17_rx_restart(): carried out right after this loop (see v29_dev.hpp)
+                        restart_pending = true;
                         emit(-1);                           // SIG_STATUS_CARRIER_DOWN
                         power = 0;
+                        break;
                     }
                     else
                     {
@@ -685,6 +686,29 @@ void v17_bank_kernel(const V17Launch L)
     }
     }
     // ---- phase B: the T/2 instant, for all lanes that reached one ----------------------------------------------
+    if (__any(restart_pending))
+    {
+        if (restart_pending)
+        {
+            restart();
+            restart_pending = false;
+            restarted = true;
+        }
+    }
+    // (and the restart leaves the clearing of the equaliser delay line to here)
+    if (__any(eq_clear_pending))
+    {
+        if (eq_clear_pending)
+        {
+#pragma unroll
+            for (int i = 0;  i < kEqLen;  i++)
+            {
+                xre[i] = 0.0f;
+                xim[i] = 0.0f;
+            }
+            eq_clear_pending = false;
+        }
+    }
     if (ready)
     {
         any_ready = true;
@@ -728,7 +752,7 @@ void v17_bank_kernel(const V17Launch L)
         carrier_phase += (uint32_t) carrier_phase_rate;
     }
     }
-    if (!__any(any_ready))
+    if (!__any(any_ready  ||  restarted))
         break;
     // ---- phase C: the baud, for every lane that completed one in this round ----------------------------------
     if (baud_done)
@@ -1127,6 +1151,19 @@ void v17_bank_kernel(const V17Launch L)
         const float2 c = TAP(i);
         stf(VF_EQ_COEFF + 2*i, c.x);
         stf(VF_EQ_COEFF + 2*i + 1, c.y);
+    }
+    if (__any(eq_clear_pending))
+    {
+        if (eq_clear_pending)
+        {
+#pragma unroll
+            for (int i = 0;  i < kEqLen;  i++)
+            {
+                xre[i] = 0.0f;
+                xim[i] = 0.0f;
+            }
+            eq_clear_pending = false;
+        }
     }
 #pragma unroll
     for (int i = 0;  i < kEqLen;  i++)

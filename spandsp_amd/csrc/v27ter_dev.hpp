@@ -144,6 +144,8 @@ void v27ter_bank_kernel(const V27Launch L)
     // equaliser delay line in age order: xre[i] = eq_buf[(eq_step + i) mod 32] (i = 0 oldest)
     float xre[EQN];
     float xim[EQN];
+    bool eq_clear_pending = false;
+    bool restart_pending = false;
     {
         const int es = ldi(WI_EQ_STEP);
 #pragma unroll
@@ -242,12 +244,8 @@ void v27ter_bank_kernel(const V27Launch L)
         agc_scaling = (1.414f/1.000000f)/283.0f;
         for (int i = 0;  i < EQN;  i++)
             TAP(i) = make_float2((i == 17)  ?  1.414f  :  0.0f, 0.0f);      // V27TER_EQUALIZER_PRE_LEN + 1
-#pragma unroll
-        for (int i = 0;  i < EQN;  i++)
-        {
-            xre[i] = 0.0f;
-            xim[i] = 0.0f;
-        }
+        // (the equaliser delay line is register state: it is cleared where it is next looked at, see v29_dev.hpp)
+        eq_clear_pending = true;
         eq_put_step = put_add;
         eq_step = 0;
         eq_skip = 0;
@@ -435,6 +433,7 @@ void v27ter_bank_kernel(const V27Launch L)
     {
     // One round = one baud of every lane (see v29_dev.hpp): two T/2 instants, then the baud phase with all lanes in step.
     bool any_ready = false;
+    bool restarted = false;
     bool baud_done = false;
     float zre = 0.0f;
     float zim = 0.0f;
@@ -444,9 +443,9 @@ void v27ter_bank_kernel(const V27Launch L)
     // ---- phase A: every lane runs its own samples up to its next T/2 instant (cheap here: no per-sample filter) ----
     bool ready = false;
     int power = 0;
-    while (__any(take  &&  !ready  &&  pos < tn))
+    while (__any(take  &&  !ready  &&  !restart_pending  &&  pos < tn))
     {
-    if (take  &&  !ready  &&  pos < tn)
+    if (take  &&  !ready  &&  !restart_pending  &&  pos < tn)
     {
         const uint32_t pw = pcm[(pos >> 1)*CPW + lane];
         const int amp = (int) (short) ((pos & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
@@ -487,9 +486,11 @@ void v27ter_bank_kernel(const V27Launch L)
                 {
                     if (--signal_present <= 0)
                     {
-                        restart();
+                        // v27ter_rx_restart(): carried out right after this loop (see v29_dev.hpp)
+                        restart_pending = true;
                         emit(-1);                           // SIG_STATUS_CARRIER_DOWN
                         power = 0;
+                        break;
                     }
                     else
                     {
@@ -524,6 +525,29 @@ void v27ter_bank_kernel(const V27Launch L)
     }
     }
     // ---- phase B: the T/2 instant, for all lanes that reached one ----------------------------------------------
+    if (__any(restart_pending))
+    {
+        if (restart_pending)
+        {
+            restart();
+            restart_pending = false;
+            restarted = true;
+        }
+    }
+    // (and the restart leaves the clearing of the equaliser delay line to here)
+    if (__any(eq_clear_pending))
+    {
+        if (eq_clear_pending)
+        {
+#pragma unroll
+            for (int i = 0;  i < EQN;  i++)
+            {
+                xre[i] = 0.0f;
+                xim[i] = 0.0f;
+            }
+            eq_clear_pending = false;
+        }
+    }
     if (ready)
     {
         any_ready = true;
@@ -569,7 +593,7 @@ void v27ter_bank_kernel(const V27Launch L)
         carrier_phase += (uint32_t) carrier_phase_rate;
     }
     }
-    if (!__any(any_ready))
+    if (!__any(any_ready  ||  restarted))
         break;
     // ---- phase C: the baud, for every lane that completed one in this round ----------------------------------
     if (baud_done)
@@ -800,6 +824,19 @@ void v27ter_bank_kernel(const V27Launch L)
         const float2 c = TAP(i);
         stf(WF_EQ_COEFF + 2*i, c.x);
         stf(WF_EQ_COEFF + 2*i + 1, c.y);
+    }
+    if (__any(eq_clear_pending))
+    {
+        if (eq_clear_pending)
+        {
+#pragma unroll
+            for (int i = 0;  i < EQN;  i++)
+            {
+                xre[i] = 0.0f;
+                xim[i] = 0.0f;
+            }
+            eq_clear_pending = false;
+        }
     }
 #pragma unroll
     for (int i = 0;  i < EQN;  i++)

@@ -301,6 +301,8 @@ void v29_bank_kernel(const V29Launch L)
     // equaliser delay line in age order: xre[i] = eq_buf[(eq_step + i) mod 33] (i = 0 oldest)
     float xre[kEqLen];
     float xim[kEqLen];
+    bool eq_clear_pending = false;
+    bool restart_pending = false;
     {
         const int es = ldi(VI_EQ_STEP);
 #pragma unroll
@@ -397,12 +399,10 @@ void v29_bank_kernel(const V29Launch L)
         carrier_phase_rate = v29_f2i(1700.0f*65536.0f*65536.0f/8000);
         for (int i = 0;  i < kEqLen;  i++)
             TAP(i) = make_float2((i == 16)  ?  3.0f  :  0.0f, 0.0f);       // V29_EQUALIZER_PRE_LEN
-#pragma unroll
-        for (int i = 0;  i < kEqLen;  i++)
-        {
-            xre[i] = 0.0f;
-            xim[i] = 0.0f;
-        }
+        // The equaliser delay line is register state, and this path is rare: clearing it here, inside the sample loop,
+        // made every iteration of that loop pay ~450 register moves at the merge points.  It is cleared where it is
+        // next looked at instead (start of the T/2 phase, write-back).
+        eq_clear_pending = true;
         eq_put_step = kRrcSets*10/(3*2) - 1;
         eq_step = 0;
         agc_scaling_save = 0.0f;
@@ -422,22 +422,27 @@ void v29_bank_kernel(const V29Launch L)
     {
         const float *y = table + row;
         const float2 *x = rrc2 + rrc_step*CPW;
-        // all 54 LDS reads first (they do not depend on the running sums), so their latency overlaps
-        f32x2v xs[kRrcLen];
-        float ys[kRrcLen];
-#pragma unroll
-        for (int i = 0;  i < kRrcLen;  i++)
-        {
-            const float2 w = x[i*CPW];
-            xs[i] = (f32x2v) {w.x, w.y};
-            ys[i] = y[i*kRrcSets];
-        }
-        // .x: x[pos..n) . y[0..n-pos) then + 0*y (exact: a running sum that starts at +0 is never -0);
-        // .y: 0*y then x[0..pos) . y[n-pos..n) -- the reference's two partial sums, each in its own order
+        // the LDS reads go out nine taps at a time, ahead of that group's part of the summation chain: all 54 at once
+        // kept 81 registers live across a kernel that already overflows into AGPRs
         f32x2v a = {0.0f, 0.0f};
 #pragma unroll
-        for (int i = 0;  i < kRrcLen;  i++)
-            a += xs[i]*(f32x2v) {ys[i], ys[i]};
+        for (int i0 = 0;  i0 < kRrcLen;  i0 += 9)
+        {
+            f32x2v xs[9];
+            float ys[9];
+#pragma unroll
+            for (int i = 0;  i < 9;  i++)
+            {
+                const float2 w = x[(i0 + i)*CPW];
+                xs[i] = (f32x2v) {w.x, w.y};
+                ys[i] = y[(i0 + i)*kRrcSets];
+            }
+            // .x: x[pos..n) . y[0..n-pos) then + 0*y (exact: a running sum that starts at +0 is never -0);
+            // .y: 0*y then x[0..pos) . y[n-pos..n) -- the reference's two partial sums, each in its own order
+#pragma unroll
+            for (int i = 0;  i < 9;  i++)
+                a += xs[i]*(f32x2v) {ys[i], ys[i]};
+        }
         return a.x + a.y;
     };
 
@@ -566,6 +571,7 @@ void v29_bank_kernel(const V29Launch L)
     // One round = one BAUD of every lane: two T/2 instants (a lane that enters the round in the middle of its baud
     // sits out the first), then the baud phase once, with all lanes in step.
     bool any_ready = false;
+    bool restarted = false;
     bool baud_done = false;
     float zre = 0.0f;
     float zim = 0.0f;
@@ -577,9 +583,9 @@ void v29_bank_kernel(const V29Launch L)
     int power = 0;
     int step = 0;
     float sre = 0.0f;
-    while (__any(take  &&  !ready  &&  pos < tn))
+    while (__any(take  &&  !ready  &&  !restart_pending  &&  pos < tn))
     {
-    if (take  &&  !ready  &&  pos < tn)
+    if (take  &&  !ready  &&  !restart_pending  &&  pos < tn)
     {
         const uint32_t pw = pcm[(pos >> 1)*CPW + lane];
         const int amp = (int) (short) ((pos & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
@@ -621,9 +627,13 @@ void v29_bank_kernel(const V29Launch L)
                 {
                     if (--signal_present <= 0)
                     {
-                        restart();
+                        // v29_rx_restart() rewrites some forty state variables: done right after this loop (the lane
+                        // takes no further sample until then), because with it inline every iteration of the loop
+                        // paid for the register copies at its merge points
+                        restart_pending = true;
                         emit(-1);                           // SIG_STATUS_CARRIER_DOWN
                         power = 0;
+                        break;
                     }
                     else
                     {
@@ -673,6 +683,29 @@ void v29_bank_kernel(const V29Launch L)
     }
     }
     // ---- phase B: the T/2 instant, for all lanes that reached one ----------------------------------------------
+    if (__any(restart_pending))
+    {
+        if (restart_pending)
+        {
+            restart();
+            restart_pending = false;
+            restarted = true;
+        }
+    }
+    // (and the restart leaves the clearing of the equaliser delay line to here)
+    if (__any(eq_clear_pending))
+    {
+        if (eq_clear_pending)
+        {
+#pragma unroll
+            for (int i = 0;  i < kEqLen;  i++)
+            {
+                xre[i] = 0.0f;
+                xim[i] = 0.0f;
+            }
+            eq_clear_pending = false;
+        }
+    }
     if (ready)
     {
         any_ready = true;
@@ -718,7 +751,7 @@ void v29_bank_kernel(const V29Launch L)
         carrier_phase += (uint32_t) carrier_phase_rate;
     }
     }
-    if (!__any(any_ready))
+    if (!__any(any_ready  ||  restarted))
         break;
     // ---- phase C: the baud, for every lane that completed one in this round ----------------------------------
     // (the reference advances the carrier phase after process_half_baud(), with the rate the baud processing may just
@@ -992,6 +1025,19 @@ void v29_bank_kernel(const V29Launch L)
             const float2 c = TAP(i);
             stf(VF_EQ_COEFF + 2*i, c.x);
             stf(VF_EQ_COEFF + 2*i + 1, c.y);
+        }
+        if (__any(eq_clear_pending))
+        {
+            if (eq_clear_pending)
+            {
+#pragma unroll
+                for (int i = 0;  i < kEqLen;  i++)
+                {
+                    xre[i] = 0.0f;
+                    xim[i] = 0.0f;
+                }
+                eq_clear_pending = false;
+            }
         }
 #pragma unroll
         for (int i = 0;  i < kEqLen;  i++)
