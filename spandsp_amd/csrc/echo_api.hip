@@ -96,12 +96,17 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     e->device = device;
     e->n_ch = n_channels;
     e->taps = taps;
-    // Four lanes per channel by default (32 / 64 / 128 taps: slices of 8 / 16 / 32 taps per lane; sixteen lanes for 256
-    // taps): the scalar control of echo_can_update() is replicated in a channel's lanes, so the fewer lanes a channel
-    // has the more channels share each control instruction (measured on 131072 x 128 taps: 0.98 / 0.75 / 0.63 ms
-    // with 16 / 8 / 4 lanes).  spangpu_tune_echo_lanes_per_channel() overrides for A-B tests.
-    e->group = (g_echo_group != 0)  ?  g_echo_group  :  4;
-    if (taps/e->group < 2  ||  taps/e->group > ((e->group == 4)  ?  32  :  16))
+    // Lanes per channel.  The scalar control of echo_can_update() is replicated in a channel's lanes, so the fewer lanes a
+    // channel has the more channels share each control instruction; a small bank wants the opposite -- more,
+    // narrower-sliced waves, so that every SIMD has some.  Measured, 128 taps, kernel time in us for 16 / 8 / 4 lanes:
+    // 4096 channels 100 / 118 / 104, 8192: 131 / 122 / 122, 16384: 182 / 153 / 183, 32768: 300 / 247 / 303,
+    // 65536: - / 418 / 540 (4096 four-lane waves are one and a third rounds of three per SIMD), 131072: 977 / 747 / 633.
+    // Slices are at most 32 taps (four lanes) or 16 taps per lane.
+    // spangpu_tune_echo_lanes_per_channel() overrides for A-B tests.
+    e->group = (g_echo_group != 0)  ?  g_echo_group  :  (n_channels >= 131072)  ?  4  :  (n_channels >= 8192)  ?  8  :  16;
+    if (e->group == 4  &&  (taps/4 < 2  ||  taps/4 > 32))
+        e->group = 8;
+    if (e->group == 8  &&  (taps/8 < 2  ||  taps/8 > 16))
         e->group = 16;
     e->tpl = taps/e->group;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
