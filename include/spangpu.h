@@ -123,6 +123,11 @@ SPANGPU_API float spangpu_goertzel_fac(float freq_hz);
    identical): 1 = one channel per lane, 2 = a channel's bins split over two lanes (more
    wavefronts for small banks), 0 = choose from the bank size (default). */
 SPANGPU_API int spangpu_tune_lanes_per_channel(int lpc);
+/* Tuning knob for the tone banks: which kernel family serves spangpu_bank_rx() (results are identical):
+   0 = choose per call (a streaming kernel for channel-major frames with 16-byte aligned rows -- with a loader wave
+   per workgroup for banks of up to 393 216 channels, without for larger ones -- and the general kernel otherwise),
+   1 = always the general kernel, 2 = streaming with loader waves where eligible, 3 = streaming without. */
+SPANGPU_API int spangpu_tune_tone_kernel(int variant);
 
 /* ---- banks ------------------------------------------------------------------------ */
 SPANGPU_API int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_channels,

@@ -14,6 +14,7 @@
 
 #include "../../include/spangpu.h"
 #include "tone_dev.hpp"
+#include "tone_fast.hpp"
 
 using namespace spg;
 
@@ -86,21 +87,80 @@ struct spangpu_bank_s
 // on every SIMD (1024 SIMDs x 64 lanes x 4), else 1.  SPANGPU_LPC=1|2 overrides (tuning).
 static int g_forced_lpc = -1;
 
-static int pick_lpc(int n_ch)
+static int forced_lpc(void)
 {
     if (g_forced_lpc < 0)
     {
         const char *e = getenv("SPANGPU_LPC");
         g_forced_lpc = (e  &&  (e[0] == '1'  ||  e[0] == '2'))  ?  (e[0] - '0')  :  0;
     }
-    if (g_forced_lpc)
+    return g_forced_lpc;
+}
+
+// the general kernel's mapping
+static int pick_lpc(int n_ch)
+{
+    if (forced_lpc())
         return g_forced_lpc;
     return (n_ch < 262144)  ?  2  :  1;
+}
+
+// Which kernel family serves a launch: the streaming kernels (tone_fast.hpp) whenever the frame is channel-major with
+// 16-byte aligned rows, else the general one (tone_dev.hpp: sample-major / unaligned frames, zero-length calls).  Of the
+// streaming kernels, banks up to kLoaderMaxChannels take the one with a loader wave per workgroup (the consumer waves
+// of a small bank are alone on their SIMDs: nothing covers a wave that stands in the memory pipeline's queue), larger
+// banks the one in which every wave fetches for itself (there the other waves of the SIMD cover it, and a loader wave
+// would only take a wave slot).  Crossover measured in profiles/r2_probe.log.  spangpu_tune_tone_kernel() forces one
+// family (A-B measurements, parity tests of all of them).
+static int g_tone_variant = 0;          // 0 auto, 1 general, 2 streaming with loader waves, 3 streaming without
+constexpr int kLoaderMaxChannels = 393216;
+
+static bool fast_eligible(const ToneLaunch &L)
+{
+    return g_tone_variant != 1  &&  L.layout == 0  &&  L.aligned16  &&  L.samples > 0
+           &&  (unsigned long long) L.stride*2ull*256ull < 0xFFFFFFFFull  &&  L.n_ch <= (1 << 29);
+}
+
+static bool use_loader(int n_ch)
+{
+    if (g_tone_variant == 2)
+        return true;
+    if (g_tone_variant == 3)
+        return false;
+    return n_ch <= kLoaderMaxChannels;
+}
+
+constexpr int kFastWPB = 4;
+constexpr int kRingLoader = 2;          // segment slots per consumer wave, kernels with a loader wave
+constexpr int kRingSelf = 3;            // ... kernels whose waves fetch for themselves
+
+template <class Det, int LPC, bool G711>
+static void launch_fast(const ToneLaunch &L, hipStream_t st, bool loader)
+{
+    const int waves = (L.n_ch + kWave/LPC - 1)/(kWave/LPC);
+    const int blocks = (waves + kFastWPB - 1)/kFastWPB;
+    if (loader  &&  LPC == 1)
+        launch_tone_fast<Det, 1, kRingLoader, G711, false, kFastWPB, 0, true>(L, blocks, st);
+    else
+        launch_tone_fast<Det, LPC, kRingSelf, G711, false, kFastWPB, 0, false>(L, blocks, st);
 }
 
 template <class Det>
 static void launch_tone(const ToneLaunch &L, hipStream_t st)
 {
+    // Lanes per channel: the streaming kernels run one channel per lane unless two are asked for (the split mapping
+    // only ever paid on the general kernel, for banks too small to give every SIMD two waves).
+    if (fast_eligible(L)  &&  !(L.fmt != 0  &&  forced_lpc() == 2))
+    {
+        const bool loader = use_loader(L.n_ch);
+        if (L.fmt != 0)
+            launch_fast<Det, 1, true>(L, st, loader);
+        else if (g_forced_lpc == 2)
+            launch_fast<Det, 2, false>(L, st, false);
+        else
+            launch_fast<Det, 1, false>(L, st, loader);
+        return;
+    }
     if (L.fmt != 0  ||  pick_lpc(L.n_ch) == 2)              // G.711 input: the LPC = 2 kernels hold the decode table
     {
         const int waves = (L.n_ch + 31)/32;
@@ -127,6 +187,14 @@ int spangpu_tune_lanes_per_channel(int lpc)
     if (lpc != 0  &&  lpc != 1  &&  lpc != 2)
         return fail(SPANGPU_ERR_BAD_ARG, "lanes per channel must be 0 (auto), 1 or 2");
     g_forced_lpc = lpc;
+    return SPANGPU_OK;
+}
+
+int spangpu_tune_tone_kernel(int variant)
+{
+    if (variant < 0  ||  variant > 3)
+        return fail(SPANGPU_ERR_BAD_ARG, "variant must be 0 (auto), 1 (general), 2 (streaming, loader waves) or 3 (streaming)");
+    g_tone_variant = variant;
     return SPANGPU_OK;
 }
 
@@ -613,10 +681,8 @@ int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, i
             return fail(SPANGPU_ERR_BAD_ARG, "banks of one launch must share a device and a stream (spangpu_bank_set_stream)");
         total_ch += b->n_ch;
     }
-    const int lpc = pick_lpc(total_ch);
-    const int cpw = kWave/lpc;
     HIP_TRY(hipSetDevice(banks[0]->device));
-    int first = 0;
+    bool all_fast = true;
     for (int k = 0;  k < n_banks;  k++)
     {
         spangpu_bank_t *b = banks[k];
@@ -640,17 +706,34 @@ int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, i
         const int rc = ensure_outputs(b, (maxb > 0)  ?  maxb  :  1);
         if (rc != SPANGPU_OK)
             return rc;
+        if (b->ext_rec  &&  (size_t) maxb*b->n_ch*sizeof(uint32_t) > b->ext_rec_bytes)
+            return fail(SPANGPU_ERR_BAD_ARG, "records buffer of bank %d too small for %d blocks", k, maxb);
         fill_launch(M.bank[k], b, amps[k], stride, samples, SPANGPU_LAYOUT_CHANNEL_MAJOR, maxb, 0);
-        M.first[k] = first;
-        const int waves = (b->n_ch + cpw - 1)/cpw;
-        first += (waves + kWavesPerBlock - 1)/kWavesPerBlock;
+        all_fast = all_fast  &&  fast_eligible(M.bank[k]);
         b->last_maxb = maxb;
         b->last_samples = samples;
+    }
+    // lanes per channel: the streaming kernels run one channel per lane unless two are asked for
+    const int lpc = all_fast  ?  ((forced_lpc() == 2)  ?  2  :  1)  :  pick_lpc(total_ch);
+    const int cpw = kWave/lpc;
+    int first = 0;
+    for (int k = 0;  k < n_banks;  k++)
+    {
+        M.first[k] = first;
+        const int waves = (banks[k]->n_ch + cpw - 1)/cpw;
+        first += (waves + kWavesPerBlock - 1)/kWavesPerBlock;
     }
     for (int k = n_banks;  k <= kMaxMulti;  k++)
         M.first[k] = first;
     M.n = n_banks;
-    if (lpc == 2)
+    static_assert(kFastWPB == kWavesPerBlock, "the workgroup ranges above serve both kernel families");
+    if (all_fast  &&  lpc == 1  &&  use_loader(total_ch))
+        hipLaunchKernelGGL((tone_multi_fast_kernel<1, kRingLoader, true>), dim3(first), dim3(kWave*(kWavesPerBlock + 1)), 0, banks[0]->stream, M);
+    else if (all_fast  &&  lpc == 1)
+        hipLaunchKernelGGL((tone_multi_fast_kernel<1, kRingSelf, false>), dim3(first), dim3(kWave*kWavesPerBlock), 0, banks[0]->stream, M);
+    else if (all_fast)
+        hipLaunchKernelGGL((tone_multi_fast_kernel<2, kRingSelf, false>), dim3(first), dim3(kWave*kWavesPerBlock), 0, banks[0]->stream, M);
+    else if (lpc == 2)
         hipLaunchKernelGGL(tone_multi_kernel<2>, dim3(first), dim3(kWave*kWavesPerBlock), 0, banks[0]->stream, M);
     else
         hipLaunchKernelGGL(tone_multi_kernel<1>, dim3(first), dim3(kWave*kWavesPerBlock), 0, banks[0]->stream, M);

@@ -108,6 +108,139 @@ struct Bank
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    // Two consecutive samples held in one register pair (x01.x first, then x01.y): same arithmetic as two step()
+    // calls, written as one asm block per group of up to four bin pairs, in place:
+    //     sample 0:  a <- (fac*b - a) + x.lo      (a held v2 and becomes the new v3; b is now v2)
+    //     sample 1:  b <- (fac*a - b) + x.hi      (b becomes the new v3; a is v2 again)
+    // so (a, b) are (v2, v3) again after the pair and nothing is renamed.  Why asm: hipcc re-orders inside a phase and
+    // then pads adjacent dependent packed ops with s_nop, and it copies the high sample into a fresh register pair
+    // instead of naming it through op_sel; a lone wave per SIMD (a 65 536-channel bank) pays a full issue slot for
+    // each of those.  FACS: the coefficients are wave-uniform (SGPR pairs).
+    template <bool FACS>
+    __device__ __forceinline__ void step2(const f32x2 (&fac)[NP], const f32x2 x01)
+    {
+        chain2<FACS, 0, (NP > 4)  ?  4  :  NP>(fac, x01);
+        if constexpr (NP > 4)
+            chain2<FACS, 4, NP - 4>(fac, x01);
+    }
+
+    // One sample, in place: a <- (fac*b - a) + x, then the roles are put right again by exchanging a and b.  For the odd
+    // sample before or after a block end that does not fall on a pair boundary (same arithmetic as step()).
+    template <bool FACS>
+    __device__ __forceinline__ void step1(const f32x2 (&fac)[NP], const float x)
+    {
+        const f32x2 xx = {x, x};
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
+        {
+            f32x2 t;
+            if constexpr (FACS)
+                asm("v_pk_mul_f32 %0, %2, %3\n\ts_nop 0\n\tv_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\t"
+                    "v_pk_add_f32 %1, %0, %4 op_sel_hi:[1,0]"
+                    : "=&v"(t), "+v"(a[i]) : "s"(fac[i]), "v"(b[i]), "v"(xx));
+            else
+                asm("v_pk_mul_f32 %0, %2, %3\n\ts_nop 0\n\tv_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\t"
+                    "v_pk_add_f32 %1, %0, %4 op_sel_hi:[1,0]"
+                    : "=&v"(t), "+v"(a[i]) : "v"(fac[i]), "v"(b[i]), "v"(xx));
+            const f32x2 v3 = a[i];
+            a[i] = b[i];
+            b[i] = v3;
+        }
+    }
+
+#define SPG_C_MUL(t, f, s)      "v_pk_mul_f32 %" #t ", %" #f ", %" #s "\n\t"
+#define SPG_C_SUB(t, s)         "v_pk_add_f32 %" #t ", %" #t ", %" #s " neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define SPG_C_ADDL(d, t, x)     "v_pk_add_f32 %" #d ", %" #t ", %" #x " op_sel_hi:[1,0]\n\t"
+#define SPG_C_ADDH(d, t, x)     "v_pk_add_f32 %" #d ", %" #t ", %" #x " op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+#define SPG_C_GAP               "s_nop 0\n\t"
+    // G bin pairs starting at pair O.  Dependent packed ops are G instructions apart; for G = 1 they are adjacent
+    // and need the one wait state hipcc would put there.
+    template <bool FACS, int O, int G>
+    __device__ __forceinline__ void chain2(const f32x2 (&fac)[NP], const f32x2 x)
+    {
+        static_assert(G >= 1  &&  G <= 4  &&  O + G <= NP, "groups of one to four pairs");
+        f32x2 t0;
+        f32x2 t1;
+        f32x2 t2;
+        f32x2 t3;
+        if constexpr (G == 1)
+        {
+            if constexpr (FACS)
+                asm(SPG_C_MUL(2, 3, 1) SPG_C_GAP SPG_C_SUB(2, 0) SPG_C_GAP SPG_C_ADDL(0, 2, 4) SPG_C_GAP
+                    SPG_C_MUL(2, 3, 0) SPG_C_GAP SPG_C_SUB(2, 1) SPG_C_GAP SPG_C_ADDH(1, 2, 4)
+                    : "+v"(a[O]), "+v"(b[O]), "=&v"(t0) : "s"(fac[O]), "v"(x));
+            else
+                asm(SPG_C_MUL(2, 3, 1) SPG_C_GAP SPG_C_SUB(2, 0) SPG_C_GAP SPG_C_ADDL(0, 2, 4) SPG_C_GAP
+                    SPG_C_MUL(2, 3, 0) SPG_C_GAP SPG_C_SUB(2, 1) SPG_C_GAP SPG_C_ADDH(1, 2, 4)
+                    : "+v"(a[O]), "+v"(b[O]), "=&v"(t0) : "v"(fac[O]), "v"(x));
+        }
+        else if constexpr (G == 2)
+        {
+            constexpr int P = O;
+            if constexpr (FACS)
+                asm(SPG_C_MUL(4, 6, 2) SPG_C_MUL(5, 7, 3) SPG_C_SUB(4, 0) SPG_C_SUB(5, 1) SPG_C_ADDL(0, 4, 8) SPG_C_ADDL(1, 5, 8)
+                    SPG_C_MUL(4, 6, 0) SPG_C_MUL(5, 7, 1) SPG_C_SUB(4, 2) SPG_C_SUB(5, 3) SPG_C_ADDH(2, 4, 8) SPG_C_ADDH(3, 5, 8)
+                    : "+v"(a[P]), "+v"(a[P + 1]), "+v"(b[P]), "+v"(b[P + 1]), "=&v"(t0), "=&v"(t1)
+                    : "s"(fac[P]), "s"(fac[P + 1]), "v"(x));
+            else
+                asm(SPG_C_MUL(4, 6, 2) SPG_C_MUL(5, 7, 3) SPG_C_SUB(4, 0) SPG_C_SUB(5, 1) SPG_C_ADDL(0, 4, 8) SPG_C_ADDL(1, 5, 8)
+                    SPG_C_MUL(4, 6, 0) SPG_C_MUL(5, 7, 1) SPG_C_SUB(4, 2) SPG_C_SUB(5, 3) SPG_C_ADDH(2, 4, 8) SPG_C_ADDH(3, 5, 8)
+                    : "+v"(a[P]), "+v"(a[P + 1]), "+v"(b[P]), "+v"(b[P + 1]), "=&v"(t0), "=&v"(t1)
+                    : "v"(fac[P]), "v"(fac[P + 1]), "v"(x));
+        }
+        else if constexpr (G == 3)
+        {
+            constexpr int P = O;
+            if constexpr (FACS)
+                asm(SPG_C_MUL(6, 9, 3) SPG_C_MUL(7, 10, 4) SPG_C_MUL(8, 11, 5) SPG_C_SUB(6, 0) SPG_C_SUB(7, 1) SPG_C_SUB(8, 2)
+                    SPG_C_ADDL(0, 6, 12) SPG_C_ADDL(1, 7, 12) SPG_C_ADDL(2, 8, 12)
+                    SPG_C_MUL(6, 9, 0) SPG_C_MUL(7, 10, 1) SPG_C_MUL(8, 11, 2) SPG_C_SUB(6, 3) SPG_C_SUB(7, 4) SPG_C_SUB(8, 5)
+                    SPG_C_ADDH(3, 6, 12) SPG_C_ADDH(4, 7, 12) SPG_C_ADDH(5, 8, 12)
+                    : "+v"(a[P]), "+v"(a[P + 1]), "+v"(a[P + 2]), "+v"(b[P]), "+v"(b[P + 1]), "+v"(b[P + 2]),
+                      "=&v"(t0), "=&v"(t1), "=&v"(t2)
+                    : "s"(fac[P]), "s"(fac[P + 1]), "s"(fac[P + 2]), "v"(x));
+            else
+                asm(SPG_C_MUL(6, 9, 3) SPG_C_MUL(7, 10, 4) SPG_C_MUL(8, 11, 5) SPG_C_SUB(6, 0) SPG_C_SUB(7, 1) SPG_C_SUB(8, 2)
+                    SPG_C_ADDL(0, 6, 12) SPG_C_ADDL(1, 7, 12) SPG_C_ADDL(2, 8, 12)
+                    SPG_C_MUL(6, 9, 0) SPG_C_MUL(7, 10, 1) SPG_C_MUL(8, 11, 2) SPG_C_SUB(6, 3) SPG_C_SUB(7, 4) SPG_C_SUB(8, 5)
+                    SPG_C_ADDH(3, 6, 12) SPG_C_ADDH(4, 7, 12) SPG_C_ADDH(5, 8, 12)
+                    : "+v"(a[P]), "+v"(a[P + 1]), "+v"(a[P + 2]), "+v"(b[P]), "+v"(b[P + 1]), "+v"(b[P + 2]),
+                      "=&v"(t0), "=&v"(t1), "=&v"(t2)
+                    : "v"(fac[P]), "v"(fac[P + 1]), "v"(fac[P + 2]), "v"(x));
+        }
+        else
+        {
+            constexpr int P = O;
+            if constexpr (FACS)
+                asm(SPG_C_MUL(8, 12, 4) SPG_C_MUL(9, 13, 5) SPG_C_MUL(10, 14, 6) SPG_C_MUL(11, 15, 7)
+                    SPG_C_SUB(8, 0) SPG_C_SUB(9, 1) SPG_C_SUB(10, 2) SPG_C_SUB(11, 3)
+                    SPG_C_ADDL(0, 8, 16) SPG_C_ADDL(1, 9, 16) SPG_C_ADDL(2, 10, 16) SPG_C_ADDL(3, 11, 16)
+                    SPG_C_MUL(8, 12, 0) SPG_C_MUL(9, 13, 1) SPG_C_MUL(10, 14, 2) SPG_C_MUL(11, 15, 3)
+                    SPG_C_SUB(8, 4) SPG_C_SUB(9, 5) SPG_C_SUB(10, 6) SPG_C_SUB(11, 7)
+                    SPG_C_ADDH(4, 8, 16) SPG_C_ADDH(5, 9, 16) SPG_C_ADDH(6, 10, 16) SPG_C_ADDH(7, 11, 16)
+                    : "+v"(a[P]), "+v"(a[P + 1]), "+v"(a[P + 2]), "+v"(a[P + 3]),
+                      "+v"(b[P]), "+v"(b[P + 1]), "+v"(b[P + 2]), "+v"(b[P + 3]),
+                      "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                    : "s"(fac[P]), "s"(fac[P + 1]), "s"(fac[P + 2]), "s"(fac[P + 3]), "v"(x));
+            else
+                asm(SPG_C_MUL(8, 12, 4) SPG_C_MUL(9, 13, 5) SPG_C_MUL(10, 14, 6) SPG_C_MUL(11, 15, 7)
+                    SPG_C_SUB(8, 0) SPG_C_SUB(9, 1) SPG_C_SUB(10, 2) SPG_C_SUB(11, 3)
+                    SPG_C_ADDL(0, 8, 16) SPG_C_ADDL(1, 9, 16) SPG_C_ADDL(2, 10, 16) SPG_C_ADDL(3, 11, 16)
+                    SPG_C_MUL(8, 12, 0) SPG_C_MUL(9, 13, 1) SPG_C_MUL(10, 14, 2) SPG_C_MUL(11, 15, 3)
+                    SPG_C_SUB(8, 4) SPG_C_SUB(9, 5) SPG_C_SUB(10, 6) SPG_C_SUB(11, 7)
+                    SPG_C_ADDH(4, 8, 16) SPG_C_ADDH(5, 9, 16) SPG_C_ADDH(6, 10, 16) SPG_C_ADDH(7, 11, 16)
+                    : "+v"(a[P]), "+v"(a[P + 1]), "+v"(a[P + 2]), "+v"(a[P + 3]),
+                      "+v"(b[P]), "+v"(b[P + 1]), "+v"(b[P + 2]), "+v"(b[P + 3]),
+                      "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                    : "v"(fac[P]), "v"(fac[P + 1]), "v"(fac[P + 2]), "v"(fac[P + 3]), "v"(x));
+        }
+    }
+#undef SPG_C_MUL
+#undef SPG_C_SUB
+#undef SPG_C_ADDL
+#undef SPG_C_ADDH
+#undef SPG_C_GAP
+
     // goertzel_result() for every bin: one zero sample, energy, reset (tone_detect.c:160-205)
     __device__ __forceinline__ void finish(const f32x2 (&fac)[NP], float (&e)[NBL])
     {
@@ -177,6 +310,7 @@ struct DtmfDet
     static constexpr int NB = 8;
     static constexpr bool kEnergy = true;
     static constexpr bool kDuration = true;
+    static constexpr bool kFilter = FILTER;
     static constexpr int NSF = 2*NB + 1 + 4;                // v2, v3, energy, z350[2], z440[2]
     __device__ static __forceinline__ int block_len(const ToneLaunch &) { return 102; }    // dtmf.c:71
 
@@ -221,8 +355,8 @@ struct DtmfDet
 
     // Decision (dtmf.c:209-258) and debounce (dtmf.c:304-347).
     // w0 = cs | last_hit<<16 | in_digit<<24 ; w1 = duration.
-    __device__ __forceinline__ void decide(const ToneLaunch &L, const float (&e)[NB], float &energy,
-                                           uint32_t &w0, int32_t &w1, int ch, int nb, bool store)
+    __device__ __forceinline__ uint32_t decide(const ToneLaunch &L, const float (&e)[NB], float &energy,
+                                               uint32_t &w0, int32_t &w1, int ch, int nb, bool store)
     {
         if (L.trace  &&  store)
             write_trace<NB>(L, e, energy, ch, nb);
@@ -285,14 +419,11 @@ struct DtmfDet
             code = hit;
         }
         last_hit = hit;
-        if (store)
-        {
-            if (L.rec_energy)
-                L.rec_energy[(size_t) nb*L.n_ch + ch] = energy;
-            L.rec[(size_t) nb*L.n_ch + ch] = make_rec(raw, code, flags);
-        }
+        if (store  &&  L.rec_energy)
+            L.rec_energy[(size_t) nb*L.n_ch + ch] = energy;
         energy = 0.0f;
         w0 = ((uint32_t) last_hit << 16) | ((uint32_t) in_digit << 24);       // cs = 0
+        return make_rec(raw, code, flags);
     }
 };
 
@@ -346,6 +477,7 @@ struct BellMfDet
     static constexpr int NB = 6;
     static constexpr bool kEnergy = false;
     static constexpr bool kDuration = false;
+    static constexpr bool kFilter = false;
     static constexpr int NSF = 2*NB;
     __device__ static __forceinline__ int block_len(const ToneLaunch &) { return 120; }    // bell_r2_mf.c:204
     __device__ __forceinline__ void load_extra(const ToneLaunch &, int) {}
@@ -353,8 +485,8 @@ struct BellMfDet
     __device__ __forceinline__ float prefilter(float x) { return x; }
 
     // w0 = cs | hits[0]<<16 | hits[1]<<24 ; w1 = hits[2] | hits[3]<<8 | hits[4]<<16
-    __device__ __forceinline__ void decide(const ToneLaunch &L, const float (&e)[NB], float &,
-                                           uint32_t &w0, int32_t &w1, int ch, int nb, bool store)
+    __device__ __forceinline__ uint32_t decide(const ToneLaunch &L, const float (&e)[NB], float &,
+                                               uint32_t &w0, int32_t &w1, int ch, int nb, bool store)
     {
         if (L.trace  &&  store)
             write_trace<NB>(L, e, 0.0f, ch, nb);
@@ -384,11 +516,10 @@ struct BellMfDet
             flags |= kBlkReport;
             code = hit;
         }
-        if (store)
-            L.rec[(size_t) nb*L.n_ch + ch] = make_rec(hit, code, flags);
         // bell_r2_mf.c:657-661: shift the hit history
         w0 = ((uint32_t) h1 << 16) | ((uint32_t) h2 << 24);
         w1 = (int32_t) ((uint32_t) h3 | ((uint32_t) h4 << 8) | ((uint32_t) hit << 16));
+        return make_rec(hit, code, flags);
     }
 };
 
@@ -397,6 +528,7 @@ struct R2MfDet
     static constexpr int NB = 6;
     static constexpr bool kEnergy = false;
     static constexpr bool kDuration = false;
+    static constexpr bool kFilter = false;
     static constexpr int NSF = 2*NB;
     __device__ static __forceinline__ int block_len(const ToneLaunch &) { return 133; }    // bell_r2_mf.c:206
     __device__ __forceinline__ void load_extra(const ToneLaunch &, int) {}
@@ -404,8 +536,8 @@ struct R2MfDet
     __device__ __forceinline__ float prefilter(float x) { return x; }
 
     // w0 = cs | current_digit<<16
-    __device__ __forceinline__ void decide(const ToneLaunch &L, const float (&e)[NB], float &,
-                                           uint32_t &w0, int32_t &, int ch, int nb, bool store)
+    __device__ __forceinline__ uint32_t decide(const ToneLaunch &L, const float (&e)[NB], float &,
+                                               uint32_t &w0, int32_t &, int ch, int nb, bool store)
     {
         if (L.trace  &&  store)
             write_trace<NB>(L, e, 0.0f, ch, nb);
@@ -420,9 +552,8 @@ struct R2MfDet
         int flags = kBlkValid;
         if (current != digit)
             flags |= kBlkReport;                                    // bell_r2_mf.c:869-875
-        if (store)
-            L.rec[(size_t) nb*L.n_ch + ch] = make_rec(digit, digit, flags);
         w0 = (uint32_t) digit << 16;
+        return make_rec(digit, digit, flags);
     }
 };
 
@@ -436,16 +567,18 @@ struct MultiDet
     // decisions on it (v18.c:1559,1597, ademco_contactid.c:903,920)
     static constexpr bool kEnergy = true;
     static constexpr bool kDuration = false;
+    static constexpr bool kFilter = false;
     static constexpr int NSF = 2*NB + 1;
     __device__ static __forceinline__ int block_len(const ToneLaunch &L) { return SUPER  ?  128  :  L.block_len; }
     __device__ __forceinline__ void load_extra(const ToneLaunch &, int) {}
     __device__ __forceinline__ void store_extra(const ToneLaunch &, int) {}
     __device__ __forceinline__ float prefilter(float x) { return x; }
 
-    __device__ __forceinline__ void decide(const ToneLaunch &L, const float (&ein)[NB], float &energy,
-                                           uint32_t &w0, int32_t &, int ch, int nb, bool store)
+    __device__ __forceinline__ uint32_t decide(const ToneLaunch &L, const float (&ein)[NB], float &energy,
+                                               uint32_t &w0, int32_t &, int ch, int nb, bool store)
     {
         const int m = L.nbins;
+        uint32_t recw;
         if (SUPER)
         {
             int k1 = -1;
@@ -515,10 +648,10 @@ struct MultiDet
             {
                 if (L.rec_energy)
                     L.rec_energy[(size_t) nb*L.n_ch + ch] = energy;
-                L.rec[(size_t) nb*L.n_ch + ch] = make_rec(k1 + 1, k2 + 1, kBlkValid);
                 if (L.trace)
                     write_trace<NB>(L, e, energy, ch, nb);
             }
+            recw = make_rec(k1 + 1, k2 + 1, kBlkValid);
             energy = 0.0f;
         }
         else
@@ -527,13 +660,14 @@ struct MultiDet
             {
                 if (L.rec_energy)
                     L.rec_energy[(size_t) nb*L.n_ch + ch] = energy;
-                L.rec[(size_t) nb*L.n_ch + ch] = make_rec(0, 0, kBlkValid);
                 if (L.trace)
                     write_trace<NB>(L, ein, energy, ch, nb);
             }
+            recw = make_rec(0, 0, kBlkValid);
             energy = 0.0f;
         }
         w0 = 0;
+        return recw;
     }
 };
 
@@ -812,7 +946,9 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
                     e[NBH + i] = sub  ?  el[i]  :  other;
             }
         }
-        det.decide(L, e, energy, w0, w1, ch, nb, store);
+        const uint32_t recw = det.decide(L, e, energy, w0, w1, ch, nb, store);
+        if (store)
+            L.rec[(size_t) nb*L.n_ch + ch] = recw;
         nb++;
     };
 

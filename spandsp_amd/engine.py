@@ -53,6 +53,7 @@ def lib():
             "spangpu_version": (C.c_char_p, []),
             "spangpu_goertzel_fac": (cf, [cf]),
             "spangpu_tune_lanes_per_channel": (ci, [ci]),
+            "spangpu_tune_tone_kernel": (ci, [ci]),
             "spangpu_bank_create": (ci, [C.POINTER(vp), ci, ci, ci, vp, C.c_size_t]),
             "spangpu_bank_destroy": (ci, [vp]),
             "spangpu_bank_kind": (ci, [vp]),
@@ -181,6 +182,11 @@ def device_count():
 
 def tune_lanes_per_channel(lpc):
     _check(lib().spangpu_tune_lanes_per_channel(lpc))
+
+
+def tune_tone_kernel(variant):
+    """0 = per-call choice, 1 = always the general kernel, 2 = streaming with loader waves, 3 = streaming without."""
+    _check(lib().spangpu_tune_tone_kernel(variant))
 
 
 def goertzel_fac(freq):

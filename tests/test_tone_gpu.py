@@ -19,13 +19,22 @@ _libm.log10f.restype = C.c_float
 _libm.log10f.argtypes = [C.c_float]
 
 
-@pytest.fixture(params=[1, 2], autouse=True)
+# (lanes per channel, kernel family): the general kernel (tone_dev.hpp) under both lane mappings, the streaming kernels
+# (tone_fast.hpp) with a loader wave per workgroup and without, the latter also with two lanes per channel.
+_KERNELS = [(1, 1), (2, 1), (1, 2), (1, 3), (2, 3)]
+_FAMILY = {1: "general", 2: "loader", 3: "stream"}
+
+
+@pytest.fixture(params=_KERNELS, ids=lambda p: "lpc%d-%s" % (p[0], _FAMILY[p[1]]), autouse=True)
 def lanes_per_channel(request, built):
-    """Every parity test runs under both kernel mappings (1 and 2 lanes per channel)."""
+    """Every parity test runs under every kernel family and lane mapping the library can pick."""
     from spandsp_amd import engine
-    engine.tune_lanes_per_channel(request.param)
-    yield request.param
+    lpc, variant = request.param
+    engine.tune_lanes_per_channel(lpc)
+    engine.tune_tone_kernel(variant)
+    yield lpc
     engine.tune_lanes_per_channel(0)
+    engine.tune_tone_kernel(0)
 
 
 def f32_bits(a):

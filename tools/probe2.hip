@@ -1,0 +1,316 @@
+// tools/probe2.hip -- round-2 on-GPU probes for the streaming Goertzel bank kernel (tone_fast.hpp): launch time over
+// lane mappings, ring depths, workgroup sizes and cache policy, against the round-1 kernel on the same frames, with an
+// A-B check that both leave identical state and records; knock-outs (no recurrence / no DMA) and per-wave timestamps.
+// Not part of the product.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/probe2.hip -o tools/probe2
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+#include "../spandsp_amd/csrc/tone_fast.hpp"
+
+using namespace spg;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct Rig
+{
+    ToneLaunch L;
+    int16_t *amp;
+    size_t frame_elems;
+    int n_frames;
+    int nsf;
+    long long *d_ts;
+};
+
+template <class Det>
+static Rig make_rig(int n_ch, int samples, int n_frames, int block_len, bool divergent)
+{
+    Rig r;
+    memset(&r, 0, sizeof(r));
+    ToneLaunch &L = r.L;
+    r.frame_elems = (size_t) n_ch*samples;
+    r.n_frames = n_frames;
+    r.nsf = Det::NSF;
+    CK(hipMalloc(&r.amp, r.frame_elems*n_frames*sizeof(int16_t)));
+    std::vector<int16_t> h(r.frame_elems);
+    unsigned s = 12345;
+    for (int f = 0;  f < n_frames;  f++)
+    {
+        for (size_t i = 0;  i < r.frame_elems;  i++)
+        {
+            s = s*1664525u + 1013904223u;
+            h[i] = (int16_t) ((int) (s >> 16) % 8000 - 4000);
+        }
+        CK(hipMemcpy(r.amp + f*r.frame_elems, h.data(), r.frame_elems*sizeof(int16_t), hipMemcpyHostToDevice));
+    }
+    const int maxb = (samples + block_len - 1)/block_len;
+    CK(hipMalloc(&L.sf, (size_t) Det::NSF*n_ch*sizeof(float)));
+    CK(hipMalloc(&L.si, (size_t) 2*n_ch*sizeof(int32_t)));
+    CK(hipMalloc(&L.rec, (size_t) maxb*n_ch*sizeof(uint32_t)));
+    L.stride = samples;
+    L.samples = samples;
+    L.n_ch = n_ch;
+    L.layout = 0;
+    L.aligned16 = 1;
+    L.maxb = maxb;
+    L.nbins = Det::NB;
+    L.block_len = block_len;
+    for (int i = 0;  i < kMaxBins;  i++)
+        L.fac[i] = 1.0f + 0.05f*i;
+    L.threshold = 171029200.0f;
+    L.normal_twist = 6.309f;
+    L.reverse_twist = 2.512f;
+    CK(hipMalloc(&r.d_ts, (size_t) (n_ch/8 + 64)*16*sizeof(long long)));
+    L.probe_ts = r.d_ts;
+    (void) divergent;
+    return r;
+}
+
+static void reset_rig(Rig &r, bool divergent, int block_len)
+{
+    CK(hipMemset(r.L.sf, 0, (size_t) r.nsf*r.L.n_ch*sizeof(float)));
+    std::vector<int32_t> si(2*(size_t) r.L.n_ch, 0);
+    if (divergent)
+    {
+        for (int c = 0;  c < r.L.n_ch;  c++)
+            si[c] = (c*37) % block_len;
+    }
+    CK(hipMemcpy(r.L.si, si.data(), si.size()*sizeof(int32_t), hipMemcpyHostToDevice));
+    CK(hipMemset(r.d_ts, 0, (size_t) (r.L.n_ch/8 + 64)*16*sizeof(long long)));
+    CK(hipDeviceSynchronize());
+}
+
+static void free_rig(Rig &r)
+{
+    CK(hipFree(r.amp));
+    CK(hipFree(r.L.sf));
+    CK(hipFree(r.L.si));
+    CK(hipFree(r.L.rec));
+    CK(hipFree(r.d_ts));
+}
+
+static bool g_graph = false;
+static hipStream_t g_stream = 0;
+
+template <class F>
+static float time_ms(F launch, int reps)
+{
+    if (g_graph)
+    {
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a));
+        CK(hipEventCreate(&b));
+        launch();
+        CK(hipStreamSynchronize(g_stream));
+        CK(hipStreamBeginCapture(g_stream, hipStreamCaptureModeGlobal));
+        for (int i = 0;  i < reps;  i++)
+            launch();
+        CK(hipStreamEndCapture(g_stream, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CK(hipGraphLaunch(ge, g_stream));
+        CK(hipStreamSynchronize(g_stream));
+        CK(hipEventRecord(a, g_stream));
+        CK(hipGraphLaunch(ge, g_stream));
+        CK(hipEventRecord(b, g_stream));
+        CK(hipEventSynchronize(b));
+        float ms = 0.0f;
+        CK(hipEventElapsedTime(&ms, a, b));
+        CK(hipGraphExecDestroy(ge));
+        CK(hipGraphDestroy(g));
+        return ms/reps;
+    }
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    launch();
+    launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a, g_stream));
+    for (int i = 0;  i < reps;  i++)
+        launch();
+    CK(hipEventRecord(b, g_stream));
+    CK(hipEventSynchronize(b));
+    float ms = 0.0f;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventDestroy(a));
+    CK(hipEventDestroy(b));
+    return ms/reps;
+}
+
+static unsigned long long digest(const Rig &r)
+{
+    const size_t nf = (size_t) r.nsf*r.L.n_ch;
+    std::vector<uint32_t> a(nf + 2*(size_t) r.L.n_ch + (size_t) r.L.maxb*r.L.n_ch);
+    CK(hipMemcpy(a.data(), r.L.sf, nf*4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(a.data() + nf, r.L.si, 2*(size_t) r.L.n_ch*4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(a.data() + nf + 2*(size_t) r.L.n_ch, r.L.rec, (size_t) r.L.maxb*r.L.n_ch*4, hipMemcpyDeviceToHost));
+    unsigned long long h = 1469598103934665603ull;
+    for (size_t i = 0;  i < a.size();  i++)
+    {
+        h ^= a[i];
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+static void report(const char *name, const Rig &r, float ms, int waves, bool ts, unsigned long long dg)
+{
+    const double smp = (double) r.L.n_ch*r.L.samples;
+    const double rd = (double) r.L.n_ch*(r.L.samples*2 + 80);
+    printf("%-34s ch=%8d n=%4d : %8.2f us  %7.1f Gsmp/s  alg-read %6.1f GB/s (%4.1f%%)  digest %016llx\n",
+           name, r.L.n_ch, r.L.samples, ms*1e3, smp/ms/1e6, rd/ms/1e6, rd/ms/1e6/80.0, dg);
+    if (ts)
+    {
+        std::vector<long long> t((size_t) waves*16);
+        CK(hipMemcpy(t.data(), r.d_ts, t.size()*sizeof(long long), hipMemcpyDeviceToHost));
+        long long tmin = 0x7fffffffffffffffll, tmax = 0;
+        for (int w = 0;  w < waves;  w++)
+        {
+            if (t[(size_t) w*16]) tmin = std::min(tmin, t[(size_t) w*16]);
+            tmax = std::max(tmax, t[(size_t) w*16 + 15]);
+        }
+        printf("     last launch: first wave start -> last wave end %lld ticks = %.2f of the event time per launch if 2.4 ticks/ns; per stamp min/mean/max over waves, ticks after the first start:\n", tmax - tmin, (tmax - tmin)/2400.0/(ms*1e3));
+        for (int k = 0;  k < 16;  k++)
+        {
+            double acc = 0;
+            long long mx = 0, mn = 0x7fffffffffffffffll;
+            int cnt = 0;
+            for (int w = 0;  w < waves;  w++)
+            {
+                const long long v = t[(size_t) w*16 + k];
+                if (v == 0)
+                    continue;
+                const long long d = v - t[(size_t) w*16];        // ticks since this wave's own start (counters differ between XCDs)
+                acc += (double) d;
+                mx = std::max(mx, d);
+                mn = std::min(mn, d);
+                cnt++;
+            }
+            if (cnt)
+                printf("       s%-2d %7lld %9.0f %7lld\n", k, mn, acc/cnt, mx);
+        }
+        // loader waves (if any): stamps at slot waves + 8 + wg
+        std::vector<long long> tl((size_t) 1024*16);
+        const int nwg = std::min(1024, (waves + 3)/4);
+        CK(hipMemcpy(tl.data(), r.d_ts + ((size_t) waves + 8)*16, (size_t) nwg*16*sizeof(long long), hipMemcpyDeviceToHost));
+        if (tl[0])
+        {
+            printf("     loader waves, ticks after their own start (mean over %d workgroups):", nwg);
+            for (int k = 0;  k < 16;  k++)
+            {
+                double acc = 0;
+                int cnt = 0;
+                for (int w = 0;  w < nwg;  w++)
+                {
+                    if (tl[(size_t) w*16 + k] == 0)
+                        continue;
+                    acc += (double) (tl[(size_t) w*16 + k] - tl[(size_t) w*16]);
+                    cnt++;
+                }
+                if (cnt)
+                    printf(" l%d=%.0f", k, acc/cnt);
+            }
+            printf("\n");
+        }
+    }
+}
+
+// One frame through the kernel from a fresh state (for the A-B digest), then the timing loop over the frame ring.
+template <class Det, int LPC, int ABL>
+static unsigned long long run_old(const char *name, Rig &r, int block_len, bool divergent, int reps)
+{
+    const int waves = (r.L.n_ch + kWave/LPC - 1)/(kWave/LPC);
+    const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
+    reset_rig(r, divergent, block_len);
+    int f = 0;
+    auto go = [&] {
+        r.L.amp = r.amp + (size_t) (f % r.n_frames)*r.frame_elems;
+        f++;
+        hipLaunchKernelGGL((tone_bank_kernel<Det, LPC, ABL>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, g_stream, r.L);
+    };
+    go(); go(); go();
+    CK(hipDeviceSynchronize());
+    const unsigned long long dg = digest(r);
+    const float ms = time_ms(go, reps);
+    CK(hipDeviceSynchronize());
+    report(name, r, ms, waves, (ABL & 32) != 0, dg);
+    return dg;
+}
+
+template <class Det, int LPC, int R, bool NT, int WPB, int ABL, bool LDR = false>
+static unsigned long long run_new(const char *name, Rig &r, int block_len, bool divergent, int reps)
+{
+    const int waves = (r.L.n_ch + kWave/LPC - 1)/(kWave/LPC);
+    const int blocks = (waves + WPB - 1)/WPB;
+    reset_rig(r, divergent, block_len);
+    int f = 0;
+    auto go = [&] {
+        r.L.amp = r.amp + (size_t) (f % r.n_frames)*r.frame_elems;
+        f++;
+        launch_tone_fast<Det, LPC, R, false, NT, WPB, ABL, LDR>(r.L, blocks, g_stream);
+    };
+    go(); go(); go();
+    CK(hipDeviceSynchronize());
+    const unsigned long long dg = digest(r);
+    const float ms = time_ms(go, reps);
+    report(name, r, ms, waves, (ABL & 32) != 0, dg);
+    return dg;
+}
+
+#define OLD(LPC, ABL) run_old<D, LPC, ABL>("r1 lpc" #LPC " abl" #ABL, r, 102, false, reps)
+#define NEWL(LPC, R, NT, ABL) run_new<D, LPC, R, NT, 4, ABL, true>("ring+loader lpc" #LPC " R" #R " nt" #NT " abl" #ABL, r, 102, false, reps)
+#define NEW(LPC, R, NT, WPB, ABL) run_new<D, LPC, R, NT, WPB, ABL>("ring lpc" #LPC " R" #R " nt" #NT " wpb" #WPB " abl" #ABL, r, 102, false, reps)
+
+static void sweep(int n_ch, int samples, int n_frames, int reps, bool full)
+{
+    typedef DtmfDet<false> D;
+    Rig r = make_rig<D>(n_ch, samples, n_frames, 102, false);
+    printf("---- DTMF, %d channels x %d samples, %d distinct frames ----\n", n_ch, samples, n_frames);
+    const unsigned long long want = OLD(1, 0);
+    unsigned long long got[16];
+    int k = 0;
+    got[k++] = NEWL(1, 2, false, 0);
+    got[k++] = NEWL(1, 3, false, 0);
+    got[k++] = NEW(1, 2, false, 4, 0);
+    got[k++] = NEW(1, 2, false, 1, 0);
+    got[k++] = NEW(1, 3, false, 4, 0);
+    got[k++] = NEW(1, 2, true, 4, 0);
+    for (int i = 0;  i < k;  i++)
+    {
+        if (got[i] != want)
+            printf("   !!! variant %d differs from the round-1 kernel\n", i);
+    }
+    if (full)
+    {
+        NEWL(1, 3, false, 128);
+        NEWL(1, 3, false, 256);
+        NEWL(1, 3, false, 272);
+        NEWL(1, 3, false, 24);
+        NEWL(1, 3, false, 32);
+    }
+    free_rig(r);
+}
+
+int main(int argc, char **argv)
+{
+    hipDeviceProp_t p;
+    CK(hipGetDeviceProperties(&p, 0));
+    printf("device: %s  CUs=%d  clock=%d MHz\n", p.name, p.multiProcessorCount, p.clockRate/1000);
+    const bool quick = (argc > 1  &&  strcmp(argv[1], "quick") == 0);
+    CK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    if (argc > 2  &&  strcmp(argv[2], "graph") == 0)
+        g_graph = true;
+    sweep(65536, 160, 64, 200, true);
+    if (quick)
+        return 0;
+    sweep(1048576, 160, 6, 20, false);
+    sweep(131072, 160, 32, 100, false);
+    sweep(262144, 160, 16, 50, false);
+    sweep(524288, 160, 8, 30, false);
+    return 0;
+}
