@@ -80,26 +80,52 @@ struct r2_mf_rx_state_s
     int current_digit;
 };
 
+/* Super tone.  A descriptor is two things: a BOOK of every frequency the caller has named, each with the answer
+   super_tone_rx_add_element() gives for it (the bin that monitors it), plus the coefficient of every bin; and a list of
+   TONES, each a cadence of elements (a bin pair and a duration window).  A detector keeps the last ten confirmed runs
+   of a (k1, k2) bin pair in a ring, newest at `head`, plus the pair seen in the last block while it is still unconfirmed. */
+typedef struct
+{
+    int hz;                 /* the frequency as named */
+    int answer;             /* what naming it again returns */
+} st_name_t;
+
+typedef struct
+{
+    int f1;                 /* bin pair, -1 = none */
+    int f2;
+    long long lo;           /* duration window, in samples */
+    long long hi;
+} st_elem_t;
+
+typedef struct
+{
+    st_elem_t *elem;
+    int n;
+    int cap;
+} st_tone_t;
+
+struct super_tone_rx_descriptor_s
+{
+    st_name_t *book;
+    int n_names;
+    int cap_names;
+    float fac[SPANGPU_MAX_BINS];
+    int n_bins;             /* may run past SPANGPU_MAX_BINS: such a descriptor cannot be given to a detector */
+    st_tone_t *tone;
+    int n_tones;
+    int cap_tones;
+    int owned;
+};
+
+#define ST_HISTORY          10
+
 typedef struct
 {
     int f1;
     int f2;
-    int recognition_duration;
-    int min_duration;
-    int max_duration;
-} st_segment_t;
-
-struct super_tone_rx_descriptor_s
-{
-    int used_frequencies;
-    int monitored_frequencies;
-    int pitches[SUPER_TONE_BINS/2][2];
-    int tones;
-    st_segment_t **tone_list;
-    int *tone_segs;
-    float fac[SUPER_TONE_BINS/2];
-    int owned;
-};
+    long long blocks;       /* length so far, in 128-sample blocks */
+} st_run_t;
 
 struct super_tone_rx_state_s
 {
@@ -107,12 +133,15 @@ struct super_tone_rx_state_s
     int channel;
     int private_grp;
     super_tone_rx_descriptor_t *desc;
-    int detected_tone;
-    int rotation;
+    int tone;               /* cadence being followed, -1 = none */
+    int turn;               /* elements of it completed since it was recognised */
     span_tone_report_func_t tone_callback;
     tone_segment_func_t segment_callback;
     void *callback_data;
-    st_segment_t segments[11];
+    st_run_t run[ST_HISTORY];
+    int head;               /* index of the current run */
+    int seen_f1;            /* the pair of the last block */
+    int seen_f2;
 };
 
 struct goertzel_state_s
@@ -798,14 +827,10 @@ int r2_mf_rx_get(r2_mf_rx_state_t *s)
 /* ------------------------------------------------------------------------------------ */
 super_tone_rx_descriptor_t *super_tone_rx_make_descriptor(super_tone_rx_descriptor_t *desc)
 {
-    int owned = 0;
+    const int owned = (desc == NULL);
 
-    if (desc == NULL)
-    {
-        if ((desc = (super_tone_rx_descriptor_t *) malloc(sizeof(*desc))) == NULL)
-            return NULL;
-        owned = 1;
-    }
+    if (owned  &&  (desc = (super_tone_rx_descriptor_t *) malloc(sizeof(*desc))) == NULL)
+        return NULL;
     memset(desc, 0, sizeof(*desc));
     desc->owned = owned;
     return desc;
@@ -813,181 +838,218 @@ super_tone_rx_descriptor_t *super_tone_rx_make_descriptor(super_tone_rx_descript
 
 int super_tone_rx_free_descriptor(super_tone_rx_descriptor_t *desc)
 {
-    int i;
+    int t;
 
-    if (desc)
-    {
-        for (i = 0;  i < desc->tones;  i++)
-            free(desc->tone_list[i]);
-        free(desc->tone_list);
-        free(desc->tone_segs);
-        if (desc->owned)
-            free(desc);
-    }
+    if (desc == NULL)
+        return 0;
+    for (t = 0;  t < desc->n_tones;  t++)
+        free(desc->tone[t].elem);
+    free(desc->tone);
+    free(desc->book);
+    if (desc->owned)
+        free(desc);
     return 0;
 }
 
-/* super_tone_rx.c:81-123 (including its habit of storing the pitch index, not the bin
-   number, for a merged entry) */
-static int st_add_freq(super_tone_rx_descriptor_t *desc, int freq)
+/* Room for one more item in a growing array (doubling). */
+static int st_room(void **arr, int *cap, int n, size_t item)
+{
+    void *p;
+    int want;
+
+    if (n < *cap)
+        return 0;
+    want = (*cap)  ?  2*(*cap)  :  8;
+    if ((p = realloc(*arr, (size_t) want*item)) == NULL)
+        return -1;
+    *arr = p;
+    *cap = want;
+    return 0;
+}
+
+static void st_tune_bin(super_tone_rx_descriptor_t *desc, int bin, float hz)
+{
+    if (bin >= 0  &&  bin < SPANGPU_MAX_BINS)
+        desc->fac[bin] = spangpu_goertzel_fac(hz);
+}
+
+/* The bin that monitors `hz`, entering it in the book if it is new.  Observable behaviour of the reference's
+   resolver (super_tone_rx.c:81-123), which a caller's element numbering depends on:
+     - a frequency named before gets the answer recorded for it;
+     - one within 10 Hz of an earlier NAME (searched in naming order) shares that name's answer as its bin, the bin is
+       re-tuned to the mean of the two, and the new name is recorded with the POSITION of the earlier name in the book as
+       its answer -- not the bin; naming it a second time returns that position (a quirk of the reference that is kept);
+     - anything else opens a new bin.
+   0 Hz means "no tone" (-1). */
+static int st_bin_for(super_tone_rx_descriptor_t *desc, int hz)
 {
     int i;
+    int near = -1;
+    st_name_t *e;
 
-    if (freq == 0)
+    if (hz == 0)
         return -1;
-    for (i = 0;  i < desc->used_frequencies;  i++)
+    for (i = 0;  i < desc->n_names;  i++)
     {
-        if (desc->pitches[i][0] == freq)
-            return desc->pitches[i][1];
+        if (desc->book[i].hz == hz)
+            return desc->book[i].answer;
+        if (near < 0  &&  abs(desc->book[i].hz - hz) <= 10)
+            near = i;
     }
-    for (i = 0;  i < desc->used_frequencies;  i++)
+    if (st_room((void **) &desc->book, &desc->cap_names, desc->n_names, sizeof(st_name_t)) < 0)
+        return -1;
+    e = &desc->book[desc->n_names++];
+    e->hz = hz;
+    if (near >= 0)
     {
-        if ((desc->pitches[i][0] - 10) <= freq  &&  freq <= (desc->pitches[i][0] + 10))
-        {
-            desc->pitches[desc->used_frequencies][0] = freq;
-            desc->pitches[desc->used_frequencies][1] = i;
-            desc->fac[desc->pitches[i][1]] = spangpu_goertzel_fac((float) (freq + desc->pitches[i][0])/2);
-            desc->used_frequencies++;
-            return desc->pitches[i][1];
-        }
+        const int bin = desc->book[near].answer;
+
+        e->answer = near;
+        st_tune_bin(desc, bin, (float) (hz + desc->book[near].hz)/2);
+        return bin;
     }
-    desc->pitches[i][0] = freq;
-    desc->pitches[i][1] = desc->monitored_frequencies;
-    desc->fac[desc->monitored_frequencies++] = spangpu_goertzel_fac((float) freq);
-    desc->used_frequencies++;
-    return desc->pitches[i][1];
+    e->answer = desc->n_bins;
+    st_tune_bin(desc, desc->n_bins, (float) hz);
+    return desc->n_bins++;
 }
 
 int super_tone_rx_add_tone(super_tone_rx_descriptor_t *desc)
 {
-    if (desc->tones%5 == 0)
-    {
-        desc->tone_list = (st_segment_t **) realloc(desc->tone_list, (desc->tones + 5)*sizeof(st_segment_t *));
-        desc->tone_segs = (int *) realloc(desc->tone_segs, (desc->tones + 5)*sizeof(int));
-    }
-    desc->tone_list[desc->tones] = NULL;
-    desc->tone_segs[desc->tones] = 0;
-    desc->tones++;
-    return desc->tones - 1;
+    if (st_room((void **) &desc->tone, &desc->cap_tones, desc->n_tones, sizeof(st_tone_t)) < 0)
+        return -1;
+    memset(&desc->tone[desc->n_tones], 0, sizeof(st_tone_t));
+    return desc->n_tones++;
 }
 
+/* min / max in milliseconds (max 0 = no upper limit), kept in samples like the reference (super_tone_rx.c:157-158). */
 int super_tone_rx_add_element(super_tone_rx_descriptor_t *desc, int tone, int f1, int f2, int min, int max)
 {
-    int step = desc->tone_segs[tone];
+    st_tone_t *t;
+    st_elem_t *e;
 
-    if (step%5 == 0)
-        desc->tone_list[tone] = (st_segment_t *) realloc(desc->tone_list[tone], (step + 5)*sizeof(st_segment_t));
-    desc->tone_list[tone][step].f1 = st_add_freq(desc, f1);
-    desc->tone_list[tone][step].f2 = st_add_freq(desc, f2);
-    desc->tone_list[tone][step].min_duration = min*8;
-    desc->tone_list[tone][step].max_duration = (max == 0)  ?  0x7FFFFFFF  :  max*8;
-    desc->tone_segs[tone]++;
-    return step;
+    if (tone < 0  ||  tone >= desc->n_tones)
+        return -1;
+    t = &desc->tone[tone];
+    if (st_room((void **) &t->elem, &t->cap, t->n, sizeof(st_elem_t)) < 0)
+        return -1;
+    e = &t->elem[t->n];
+    e->f1 = st_bin_for(desc, f1);           /* in this order: the bins are numbered as they are first named */
+    e->f2 = st_bin_for(desc, f2);
+    e->lo = 8LL*min;
+    e->hi = (max == 0)  ?  0x7FFFFFFFLL  :  8LL*max;
+    return t->n++;
 }
 
-/* super_tone_rx.c:164-228 */
-static int st_test_cadence(const st_segment_t *pattern, int steps, const st_segment_t *test, int rotation)
+/* ---- cadence matching (the decisions of super_tone_rx.c:164-228 and :364-448 on the run history) ---- */
+
+/* The run `back` places before the current one (0 = current). */
+static const st_run_t *st_past(const super_tone_rx_state_t *s, int back)
+{
+    return &s->run[(s->head + ST_HISTORY - back)%ST_HISTORY];
+}
+
+static int st_same_pair(const st_elem_t *e, const st_run_t *r)
+{
+    return e->f1 == r->f1  &&  e->f2 == r->f2;
+}
+
+static long long st_samples(const st_run_t *r)
+{
+    return r->blocks*SUPER_TONE_BINS;
+}
+
+/* A finished run fits an element when the pair is right and the length lies in the window. */
+static int st_fits(const st_elem_t *e, const st_run_t *r)
+{
+    return st_same_pair(e, r)  &&  e->lo <= st_samples(r)  &&  st_samples(r) <= e->hi;
+}
+
+/* Does the newest history spell out the whole cadence, the current run being its last element? */
+static int st_spells(const super_tone_rx_state_t *s, const st_tone_t *t)
 {
     int i;
-    int j;
 
-    if (rotation >= 0)
+    if (t->n > ST_HISTORY)
+        return 0;
+    for (i = 0;  i < t->n;  i++)
     {
-        j = 0;
-        if (steps < 0)
-        {
-            steps = -steps;
-            j = (rotation + steps - 2)%steps;
-            if (pattern[j].f1 != test[8].f1  ||  pattern[j].f2 != test[8].f2)
-                return 0;
-            if (pattern[j].min_duration > test[8].min_duration*SUPER_TONE_BINS
-                ||  pattern[j].max_duration < test[8].min_duration*SUPER_TONE_BINS)
-            {
-                return 0;
-            }
-        }
-        if (steps)
-            j = (rotation + steps - 1)%steps;
-        if (pattern[j].f1 != test[9].f1  ||  pattern[j].f2 != test[9].f2)
+        if (!st_fits(&t->elem[i], st_past(s, t->n - 1 - i)))
             return 0;
-        if (pattern[j].max_duration < test[9].min_duration*SUPER_TONE_BINS)
-            return 0;
-    }
-    else
-    {
-        for (i = 0;  i < steps;  i++)
-        {
-            j = i + 10 - steps;
-            if (pattern[i].f1 != test[j].f1  ||  pattern[i].f2 != test[j].f2)
-                return 0;
-            if (pattern[i].min_duration > test[j].min_duration*SUPER_TONE_BINS
-                ||  pattern[i].max_duration < test[j].min_duration*SUPER_TONE_BINS)
-            {
-                return 0;
-            }
-        }
     }
     return 1;
 }
 
-/* One 128-sample block decided on the device as (k1, k2): super_tone_rx.c:364-448 */
+/* Is the cadence being followed still alive?  `turn` elements of it have gone by since it was recognised (it was
+   recognised on its last element), so the current run must be element (turn - 1) mod n and not yet too long; when a run
+   has just ended (`run_ended`) the one before it must in addition have been a proper element (turn - 2) mod n. */
+static int st_alive(const super_tone_rx_state_t *s, const st_tone_t *t, int turn, int run_ended)
+{
+    const st_elem_t *e;
+
+    if (t->n <= 0)
+        return 0;
+    if (run_ended  &&  !st_fits(&t->elem[(turn + t->n - 2)%t->n], st_past(s, 1)))
+        return 0;
+    e = &t->elem[(turn + t->n - 1)%t->n];
+    return st_same_pair(e, st_past(s, 0))  &&  st_samples(st_past(s, 0)) <= e->hi;
+}
+
+static void st_lose_tone(super_tone_rx_state_t *s)
+{
+    s->tone = -1;
+    s->tone_callback(s->callback_data, -1, -10, 0);
+}
+
+/* One 128-sample block, decided on the device as the bin pair (k1, k2). */
 static void st_block(super_tone_rx_state_t *s, int k1, int k2)
 {
-    super_tone_rx_descriptor_t *d = s->desc;
-    int j;
+    const super_tone_rx_descriptor_t *d = s->desc;
+    st_run_t *cur = &s->run[s->head];
+    const int repeat = (k1 == s->seen_f1  &&  k2 == s->seen_f2);
+    int t;
 
-    if (k1 != s->segments[10].f1  ||  k2 != s->segments[10].f2)
+    s->seen_f1 = k1;
+    s->seen_f2 = k2;
+    if (!repeat)
     {
-        s->segments[10].f1 = k1;
-        s->segments[10].f2 = k2;
-        s->segments[9].min_duration++;
+        /* a pair seen for the first time may be a glitch: it still counts towards the current run */
+        cur->blocks++;
+    }
+    else if (k1 != cur->f1  ||  k2 != cur->f2)
+    {
+        /* seen twice in a row, and not what the current run is made of: that run is over */
+        if (s->tone >= 0)
+        {
+            const int turn = s->turn++;
+
+            if (!st_alive(s, &d->tone[s->tone], turn, 1))
+                st_lose_tone(s);
+        }
+        if (s->segment_callback)
+            s->segment_callback(s->callback_data, cur->f1, cur->f2, (int) (st_samples(cur)/8));
+        s->head = (s->head + 1)%ST_HISTORY;
+        cur = &s->run[s->head];
+        cur->f1 = k1;
+        cur->f2 = k2;
+        cur->blocks = 1;
     }
     else
     {
-        if (k1 != s->segments[9].f1  ||  k2 != s->segments[9].f2)
-        {
-            if (s->detected_tone >= 0)
-            {
-                if (!st_test_cadence(d->tone_list[s->detected_tone], -d->tone_segs[s->detected_tone], s->segments, s->rotation++))
-                {
-                    s->detected_tone = -1;
-                    s->tone_callback(s->callback_data, s->detected_tone, -10, 0);
-                }
-            }
-            if (s->segment_callback)
-            {
-                s->segment_callback(s->callback_data, s->segments[9].f1, s->segments[9].f2,
-                                    s->segments[9].min_duration*SUPER_TONE_BINS/8);
-            }
-            memmove(&s->segments[0], &s->segments[1], 9*sizeof(s->segments[0]));
-            s->segments[9].f1 = k1;
-            s->segments[9].f2 = k2;
-            s->segments[9].min_duration = 1;
-        }
-        else
-        {
-            if (s->detected_tone >= 0)
-            {
-                if (!st_test_cadence(d->tone_list[s->detected_tone], d->tone_segs[s->detected_tone], s->segments, s->rotation))
-                {
-                    s->detected_tone = -1;
-                    s->tone_callback(s->callback_data, s->detected_tone, -10, 0);
-                }
-            }
-            s->segments[9].min_duration++;
-        }
+        /* more of the same (tested before this block is counted, as the reference does) */
+        if (s->tone >= 0  &&  !st_alive(s, &d->tone[s->tone], s->turn, 0))
+            st_lose_tone(s);
+        cur->blocks++;
     }
-    if (s->detected_tone < 0)
+    if (s->tone >= 0)
+        return;
+    for (t = 0;  t < d->n_tones;  t++)
     {
-        for (j = 0;  j < d->tones;  j++)
+        if (st_spells(s, &d->tone[t]))
         {
-            if (st_test_cadence(d->tone_list[j], d->tone_segs[j], s->segments, -1))
-            {
-                s->detected_tone = j;
-                s->rotation = 0;
-                s->tone_callback(s->callback_data, s->detected_tone, -10, 0);
-                break;
-            }
+            s->tone = t;
+            s->turn = 0;
+            s->tone_callback(s->callback_data, t, -10, 0);
+            break;
         }
     }
 }
@@ -1004,18 +1066,21 @@ static void st_reset(super_tone_rx_state_t *s, super_tone_rx_descriptor_t *desc,
 {
     int i;
 
-    for (i = 0;  i < 11;  i++)
+    for (i = 0;  i < ST_HISTORY;  i++)
     {
-        s->segments[i].f1 = -1;
-        s->segments[i].f2 = -1;
-        s->segments[i].min_duration = 0;
+        s->run[i].f1 = -1;
+        s->run[i].f2 = -1;
+        s->run[i].blocks = 0;
     }
+    s->head = ST_HISTORY - 1;
+    s->seen_f1 = -1;
+    s->seen_f2 = -1;
     s->segment_callback = NULL;
     s->tone_callback = callback;
     s->callback_data = user_data;
     s->desc = desc;
-    s->detected_tone = -1;
-    s->rotation = 0;
+    s->tone = -1;
+    s->turn = 0;
 }
 
 static void st_params(const super_tone_rx_descriptor_t *desc, spangpu_tone_params_t *p)
@@ -1023,8 +1088,8 @@ static void st_params(const super_tone_rx_descriptor_t *desc, spangpu_tone_param
     int i;
 
     memset(p, 0, sizeof(*p));
-    p->n_bins = desc->monitored_frequencies;
-    for (i = 0;  i < desc->monitored_frequencies  &&  i < SPANGPU_MAX_BINS;  i++)
+    p->n_bins = desc->n_bins;
+    for (i = 0;  i < desc->n_bins  &&  i < SPANGPU_MAX_BINS;  i++)
         p->bin_fac[i] = desc->fac[i];
 }
 
@@ -1035,7 +1100,7 @@ super_tone_rx_state_t *super_tone_rx_init(super_tone_rx_state_t *s, super_tone_r
 
     if (desc == NULL  ||  callback == NULL)
         return NULL;                                        /* super_tone_rx.c:514-519 */
-    if (desc->monitored_frequencies < 2  ||  desc->monitored_frequencies > SPANGPU_MAX_BINS)
+    if (desc->n_bins < 2  ||  desc->n_bins > SPANGPU_MAX_BINS)
         return NULL;
     if (spangpu_device_count() <= 0)
         return NULL;
@@ -1084,7 +1149,7 @@ super_tone_rx_state_t *spangpu_super_tone_rx_attach(spangpu_group_t *g, int chan
 /* Bank parameters for a group whose channels all use `desc` (one descriptor per bank). */
 int spangpu_super_tone_params(const super_tone_rx_descriptor_t *desc, spangpu_tone_params_t *params)
 {
-    if (desc == NULL  ||  params == NULL  ||  desc->monitored_frequencies < 2  ||  desc->monitored_frequencies > SPANGPU_MAX_BINS)
+    if (desc == NULL  ||  params == NULL  ||  desc->n_bins < 2  ||  desc->n_bins > SPANGPU_MAX_BINS)
         return SPANGPU_ERR_BAD_ARG;
     st_params(desc, params);
     return SPANGPU_OK;

@@ -175,6 +175,19 @@ static void launch_tone(const ToneLaunch &L, hipStream_t st)
     }
 }
 
+// Banks of more than 16 bins per channel: always two lanes per channel (16 bins = 8 packed pairs per lane is what one
+// lane's registers hold), linear PCM only; the streaming kernel without loader waves where the frame allows it.
+template <class Det>
+static void launch_tone_wide(const ToneLaunch &L, hipStream_t st)
+{
+    const int waves = (L.n_ch + 31)/32;
+    const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
+    if (fast_eligible(L)  &&  L.fmt == 0)
+        launch_tone_fast<Det, 2, kRingSelf, false, false, kFastWPB, 0, false>(L, blocks, st);
+    else
+        hipLaunchKernelGGL((tone_bank_kernel<Det, 2>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
+}
+
 extern "C" int spangpu_set_error(int code, const char *msg)
 {
     return fail(code, "%s", msg);
@@ -352,7 +365,7 @@ int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_chann
             free(b);
             return fail(SPANGPU_ERR_BAD_ARG, "n_bins %d out of range", m);
         }
-        b->nb = (m <= 4)  ?  4  :  (m <= 8)  ?  8  :  (m <= 12)  ?  12  :  16;
+        b->nb = (m <= 4)  ?  4  :  (m <= 8)  ?  8  :  (m <= 12)  ?  12  :  (m <= 16)  ?  16  :  (m <= 24)  ?  24  :  32;
         b->nsf = 2*b->nb + 1;
         b->block_len = (kind == SPANGPU_SUPER_TONE)  ?  128  :  b->tp.block_len;
         if (b->block_len <= 0  ||  b->block_len > 65535)
@@ -511,7 +524,9 @@ static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stri
         case 4:  launch_tone<MultiDet<4, true>>(L, b->stream);  break;
         case 8:  launch_tone<MultiDet<8, true>>(L, b->stream);  break;
         case 12: launch_tone<MultiDet<12, true>>(L, b->stream); break;
-        default: launch_tone<MultiDet<16, true>>(L, b->stream); break;
+        case 16: launch_tone<MultiDet<16, true>>(L, b->stream); break;
+        case 24: launch_tone_wide<MultiDet<24, true>>(L, b->stream); break;
+        default: launch_tone_wide<MultiDet<32, true>>(L, b->stream); break;
         }
         break;
     case SPANGPU_GOERTZEL:
@@ -520,7 +535,9 @@ static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stri
         case 4:  launch_tone<MultiDet<4, false>>(L, b->stream);  break;
         case 8:  launch_tone<MultiDet<8, false>>(L, b->stream);  break;
         case 12: launch_tone<MultiDet<12, false>>(L, b->stream); break;
-        default: launch_tone<MultiDet<16, false>>(L, b->stream); break;
+        case 16: launch_tone<MultiDet<16, false>>(L, b->stream); break;
+        case 24: launch_tone_wide<MultiDet<24, false>>(L, b->stream); break;
+        default: launch_tone_wide<MultiDet<32, false>>(L, b->stream); break;
         }
         break;
     default:
@@ -696,6 +713,8 @@ int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, i
         case SPANGPU_BELL_MF: M.kind[k] = TONE_K_BELL; break;
         case SPANGPU_R2_MF: M.kind[k] = TONE_K_R2; break;
         case SPANGPU_SUPER_TONE:
+            if (b->nb > 16)
+                return fail(SPANGPU_ERR_UNSUPPORTED, "a super-tone bank of more than 16 bins cannot share a launch");
             M.kind[k] = (b->nb == 4)  ?  TONE_K_ST4  :  (b->nb == 8)  ?  TONE_K_ST8  :  (b->nb == 12)  ?  TONE_K_ST12  :  TONE_K_ST16;
             break;
         default:
@@ -906,9 +925,9 @@ int spangpu_bank_reset_channel(spangpu_bank_t *b, int channel, int fillin_only)
 {
     if (b == nullptr  ||  channel < 0  ||  channel >= b->n_ch)
         return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
-    float f[64];
+    float f[2*kMaxBins + 8];
     int32_t w[4];
-    int rc = spangpu_bank_get_state(b, channel, f, 64, w, 4);
+    int rc = spangpu_bank_get_state(b, channel, f, 2*kMaxBins + 8, w, 4);
     if (rc < 0)
         return rc;
     // Goertzel states, block energy and block position always restart (dtmf.c:363-379);

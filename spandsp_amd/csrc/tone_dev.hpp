@@ -35,7 +35,7 @@ namespace spg {
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
-constexpr int kMaxBins = 16;
+constexpr int kMaxBins = 32;            // banks of more than 16 bins run two lanes per channel (16 bins per lane)
 
 // Kernel argument block (passed by value; lives in SGPRs / kernarg segment).
 struct ToneLaunch

@@ -720,7 +720,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
 // wave, and the state loads and the first DMA can be addressed without waiting for a scalar load of the kernarg
 // segment first.
 template <class Det, int LPC, int R, bool G711, bool NT, int WPB, int ABL = 0, bool LDR = false>
-__global__ __launch_bounds__(kWave*(WPB + (LDR  ?  1  :  0))) __attribute__((amdgpu_waves_per_eu(LDR  ?  2  :  4)))
+__global__ __launch_bounds__(kWave*(WPB + (LDR  ?  1  :  0))) __attribute__((amdgpu_waves_per_eu(LDR  ?  2  :  3)))
 void tone_fast_kernel(const int16_t *amp, long long stride, int samples, int n_ch, int layout, int aligned16,
                       float *sf, int32_t *si, uint32_t *rec, const ToneLaunch L0)
 {
@@ -749,7 +749,7 @@ static inline void launch_tone_fast(const ToneLaunch &L, int blocks, hipStream_t
 // Several banks in ONE launch (see tone_multi_kernel in tone_dev.hpp): workgroups [first[k], first[k + 1]) belong to
 // bank k, the detector policy is chosen per workgroup.
 template <int LPC, int R, bool LDR>
-__global__ __launch_bounds__(kWave*(4 + (LDR  ?  1  :  0))) __attribute__((amdgpu_waves_per_eu(LDR  ?  2  :  4)))
+__global__ __launch_bounds__(kWave*(4 + (LDR  ?  1  :  0))) __attribute__((amdgpu_waves_per_eu(LDR  ?  2  :  3)))
 void tone_multi_fast_kernel(const ToneMultiLaunch M)
 {
     __shared__ __attribute__((aligned(1024))) char lds_raw[FastLds<LPC, R, false, 4>::kBytes];

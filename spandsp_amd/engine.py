@@ -16,7 +16,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 CHANNEL_MAJOR, SAMPLE_MAJOR = 0, 1
 REPORT_DIGITS, REPORT_REALTIME = 0, 2
 BLK_VALID, BLK_CHANGE, BLK_REPORT, BLK_TONE_OFF = 1, 2, 4, 8
-MAX_BINS = 16
+MAX_BINS = 32
 
 BLOCK_DTYPE = np.dtype([("channel", "<i4"), ("block", "<i4"), ("hit", "<i4"), ("code", "<i4"),
                         ("flags", "<i4"), ("duration", "<i4"), ("energy", "<f4")])

@@ -216,6 +216,45 @@ def test_super_tone_live(built):
     assert len(er) > 0
 
 
+def build_wide_st_desc(D):
+    """22 monitored frequencies and the resolver's naming quirks: a near frequency (shares and re-tunes a bin), the
+    same near frequency named again (answered with the earlier name's position), a second merge."""
+    d = D()
+    ids = []
+    base = [350, 440, 480, 620, 950, 1100, 1400, 1800, 400, 425, 450, 500, 540, 660, 700, 770, 852, 941, 1004, 1209, 1336, 1477]
+    for k in range(0, len(base), 2):
+        t = d.add_tone()
+        ids.append(d.add_element(t, base[k], base[k + 1], 300, 0))
+        ids.append(d.add_element(t, 0, 0, 200, 0))
+    t = d.add_tone()
+    ids.append(d.add_element(t, 355, 0, 400, 0))
+    ids.append(d.add_element(t, 355, 445, 400, 0))
+    t = d.add_tone()
+    ids.append(d.add_element(t, 1100, 0, 400, 600))
+    ids.append(d.add_element(t, 0, 0, 2800, 3200))
+    return d, ids
+
+
+def test_super_tone_wide_descriptor_live(built):
+    """The descriptor the > 16-bin GPU tests use: oracle == reference on bins, element numbering and every report."""
+    from oracle import ref, restated as orc
+    (dr, ir), (do, io) = build_wide_st_desc(ref.SuperToneDesc), build_wide_st_desc(orc.SuperToneDesc)
+    assert ir == io
+    assert len(dr.fac) == 20 and np.array_equal(bits(dr.fac), bits(do.fac))    # 450 merges with 440, 941 with 950
+    n_ev = 0
+    for c in range(4):
+        x = synth.call_progress_channels(4, 160*220, seed=58)[c]
+        r = ref.SuperToneRx(dr, True)
+        o = orc.SuperTone(do, True)
+        for k in range(0, len(x), 160):
+            r.rx(x[k:k + 160])
+            o.rx(x[k:k + 160])
+        er, eo = r.sink.events(), o.sink.events()
+        assert er.tobytes() == eo.tobytes()
+        n_ev += len(er)
+    assert n_ev > 0
+
+
 def echo_scenario(taps, seed, n=160*150):
     """tx noise with a tone stretch, echo through a sparse path, double talk, a gain > 1 stretch."""
     rng = np.random.default_rng(seed)

@@ -266,6 +266,50 @@ def test_super_tone_private_and_group(L):
     L.super_tone_rx_free_descriptor(desc)
 
 
+def _build_wide_desc(add_tone, add_element):
+    """22 monitored frequencies plus the resolver's naming quirks (see test_tone_gpu._st_desc_wide)."""
+    base = [350, 440, 480, 620, 950, 1100, 1400, 1800, 400, 425, 450, 500, 540, 660, 700, 770, 852, 941, 1004, 1209, 1336, 1477]
+    ids = []
+    for k in range(0, len(base), 2):
+        t = add_tone()
+        ids.append(add_element(t, base[k], base[k + 1], 300, 0))
+        ids.append(add_element(t, 0, 0, 200, 0))
+    t = add_tone()
+    ids.append(add_element(t, 355, 0, 400, 0))
+    ids.append(add_element(t, 355, 445, 400, 0))
+    t = add_tone()
+    ids.append(add_element(t, 1100, 0, 400, 600))
+    ids.append(add_element(t, 0, 0, 2800, 3200))
+    return ids
+
+
+def test_super_tone_descriptor_of_more_than_16_frequencies(L):
+    """A descriptor the reference accepts (up to 64 pitches) with more monitored frequencies than one lane's 16 bins:
+    element numbering, tone reports and segment reports equal the oracle's."""
+    from oracle import restated as orc
+    desc = L.super_tone_rx_make_descriptor(None)
+    ids = _build_wide_desc(lambda: L.super_tone_rx_add_tone(desc), lambda *a: L.super_tone_rx_add_element(desc, *a))
+    od = orc.SuperToneDesc()
+    oids = _build_wide_desc(od.add_tone, od.add_element)
+    assert ids == oids
+    assert len(od.fac) > 16
+    sig = synth.call_progress_channels(6, 160*220, seed=58)
+    for c in range(6):
+        rec = Rec()
+        s = L.super_tone_rx_init(None, desc, rec.tone_cb, None)
+        assert s
+        L.super_tone_rx_segment_callback(s, rec.seg_cb)
+        o = orc.SuperTone(od, True)
+        for pos in range(0, sig.shape[1], 160):
+            fr = i16(sig[c, pos:pos + 160])
+            assert L.super_tone_rx(s, fr.ctypes.data, 160) == 160
+            o.rx(fr)
+        assert rec.events == orc_events(o), c
+        assert len(rec.events) > 0
+        L.super_tone_rx_free(s)
+    L.super_tone_rx_free_descriptor(desc)
+
+
 def test_goertzel_object(L):
     """goertzel_update() clamps to the block; goertzel_result() works at a block end and mid-block."""
     from oracle import restated as orc

@@ -340,6 +340,44 @@ def test_super_tone_bank(built):
     assert sum(1 for c in range(n_ch) for b in g[c] if b[0] >= 0) > n_ch
 
 
+def _st_desc_wide(D):
+    """A call-progress plan of 22 monitored frequencies (more than one lane's 16 bins), with the naming quirks of
+    the reference's resolver in it: a frequency within 10 Hz of an earlier one (shares and re-tunes its bin), and
+    the same near frequency named twice (the second time it gets the earlier NAME's position, not the bin)."""
+    d = D()
+    base = [350, 440, 480, 620, 950, 1100, 1400, 1800, 400, 425, 450, 500, 540, 660, 700, 770, 852, 941, 1004, 1209, 1336, 1477]
+    for k in range(0, len(base), 2):
+        t = d.add_tone()
+        d.add_element(t, base[k], base[k + 1], 300, 0)
+        d.add_element(t, 0, 0, 200, 0)
+    t = d.add_tone()
+    d.add_element(t, 355, 0, 400, 0)        # within 10 Hz of 350: merged into its bin
+    d.add_element(t, 355, 445, 400, 0)      # 355 named again; 445 merges with 440
+    t = d.add_tone()
+    d.add_element(t, 1100, 0, 400, 600)
+    d.add_element(t, 0, 0, 2800, 3200)
+    return d
+
+
+def test_super_tone_bank_of_more_than_16_bins(built):
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 70
+    sig = synth.call_progress_channels(n_ch, 160*100, seed=33)
+    desc = _st_desc_wide(orc.SuperToneDesc)
+    fac = list(desc.fac)
+    assert 16 < len(fac) <= engine.MAX_BINS
+    bank = engine.ToneBank(engine.SUPER_TONE, n_ch, bin_fac=fac, trace=True)
+    g = run_gpu(bank, sig, [160, 96, 256])
+    dets = [orc.SuperTone(desc) for _ in range(n_ch)]
+    o = [[] for _ in dets]
+    for pos, n in frames_of(sig.shape[1], [160, 96, 256]):
+        for c, d in enumerate(dets):
+            o[c].extend(list(d.rx(sig[c, pos:pos + n])))
+    check_blocks(g, o, len(fac), "super-tone, %d bins" % len(fac))
+    assert sum(1 for c in range(n_ch) for b in g[c] if b[0] >= 0) > n_ch
+
+
 def test_goertzel_bank(built):
     from oracle import restated as orc
     from spandsp_amd import engine
