@@ -79,45 +79,59 @@ def synth_dtmf_frames(n_ch, n_frames, device, seed):
     return out
 
 
-def cpu_baseline(frames_host, loops):
+def cpu_baseline(frames_host, target_s):
     """Time the CPU path on the host cores over a bounded sample of the same workload.
 
-    Uses the real reference (oracle/_ref/libspandsp_ref.so, dtmf_rx() per channel)
-    when that build is present, else our C restatement (oracle/liboracle.so).  One
-    Python thread per core, each driving a static slice of channels through a C batch
-    loop (ctypes releases the GIL)."""
+    With the real reference present (oracle/_ref/libspandsp_ref.so -- it travels with the snapshot) dtmf_rx() is
+    driven by the pthread driver of oracle/ref_glue/ref_glue_mt.c: one C call per measurement, every thread looping
+    over its static slice of channel objects, frames and repetitions inside C.  Two figures: all host cores (the
+    headline `value`) and one core.  Without it, the C restatement (oracle/liboracle.so) is driven from one Python
+    thread per core (ctypes releases the GIL), one call per frame."""
     import oracle
     from oracle import ref, restated
     n_frames, n_ch, _ = frames_host.shape
     cores = os.cpu_count() or 1
+    if oracle.have_ref():
+        L = ref.lib()
+        per_loop = float(frames_host.size)
+
+        def measure(ch, threads, seconds):
+            states = [L.glue_dtmf_rx_new(None, 0, 0) for _ in range(ch)]
+            sub = np.ascontiguousarray(frames_host[:, :ch])
+            rate, loops, dt = ref.timed_baseline(lambda l: ref.mt_rx(ref.MT_DTMF, states, sub, l, threads), float(sub.size), seconds)
+            return rate, loops, dt
+
+        usable, cores_note = ref.usable_cores()
+        threads = max(1, min(usable, n_ch))
+        all_rate, all_loops, all_dt = measure(n_ch, threads, target_s)
+        one_ch = min(n_ch, 256)
+        one_rate, one_loops, one_dt = measure(one_ch, 1, min(target_s, 2.0))
+        return {
+            "value": all_rate/1e6,
+            "unit": "Msamples/s",
+            "cores": threads,
+            "kind": "reference",
+            "single_core": one_rate/1e6,
+            "host_cores": cores_note,
+            "sample": "reference (oracle/_ref) dtmf_rx(), pthread driver: all usable cores = %d channels x %d distinct frames x %d "
+                      "passes on %d threads in %.2f s; one core = %d channels x %d frames x %d passes in %.2f s"
+                      % (n_ch, n_frames, all_loops, threads, all_dt, one_ch, n_frames, one_loops, one_dt),
+        }
     cores = max(1, min(cores, n_ch))
     bounds = np.linspace(0, n_ch, cores + 1).astype(int)
-    kind = "reference" if oracle.have_ref() else "port"
-    if kind == "reference":
-        L = ref.lib()
-        L.glue_dtmf_rx_batch.restype = None
-        L.glue_dtmf_rx_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
-        states = [L.glue_dtmf_rx_new(None, 0, 0) for _ in range(n_ch)]
-        arr = (ctypes.c_void_p*n_ch)(*states)
+    L = restated.lib()
+    L.orc_dtmf_rx_batch.restype = None
+    L.orc_dtmf_rx_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
+    sz = L.orc_dtmf_sizeof()
+    blob = np.zeros(n_ch*sz, np.uint8)
+    for c in range(n_ch):
+        L.orc_dtmf_init(blob.ctypes.data + c*sz, 0)
+    loops = 10
 
-        def work(lo, hi):
-            base = ctypes.addressof(arr) + lo*ctypes.sizeof(ctypes.c_void_p)
-            for _ in range(loops):
-                for f in range(n_frames):
-                    L.glue_dtmf_rx_batch(base, frames_host[f, lo:hi].ctypes.data, hi - lo, FRAME, FRAME)
-    else:
-        L = restated.lib()
-        L.orc_dtmf_rx_batch.restype = None
-        L.orc_dtmf_rx_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
-        sz = L.orc_dtmf_sizeof()
-        blob = np.zeros(n_ch*sz, np.uint8)
-        for c in range(n_ch):
-            L.orc_dtmf_init(blob.ctypes.data + c*sz, 0)
-
-        def work(lo, hi):
-            for _ in range(loops):
-                for f in range(n_frames):
-                    L.orc_dtmf_rx_batch(blob.ctypes.data + lo*sz, frames_host[f, lo:hi].ctypes.data, hi - lo, FRAME, FRAME)
+    def work(lo, hi):
+        for _ in range(loops):
+            for f in range(n_frames):
+                L.orc_dtmf_rx_batch(blob.ctypes.data + lo*sz, frames_host[f, lo:hi].ctypes.data, hi - lo, FRAME, FRAME)
     threads = [threading.Thread(target=work, args=(int(bounds[i]), int(bounds[i + 1]))) for i in range(cores)]
     t0 = time.perf_counter()
     for th in threads:
@@ -130,10 +144,36 @@ def cpu_baseline(frames_host, loops):
         "value": samples/dt/1e6,
         "unit": "Msamples/s",
         "cores": cores,
-        "kind": kind,
-        "sample": "%d channels x %d frames of %d samples (%d distinct frames cycled %dx), %s dtmf_rx on %d host threads, %.1f s"
-                  % (n_ch, n_frames*loops, FRAME, n_frames, loops,
-                     "reference (oracle/_ref)" if kind == "reference" else "C restatement (oracle/)", cores, dt),
+        "kind": "port",
+        "sample": "%d channels x %d frames of %d samples (%d distinct frames cycled %dx), C restatement (oracle/) dtmf_rx on %d "
+                  "Python-driven host threads, %.1f s" % (n_ch, n_frames*loops, FRAME, n_frames, loops, cores, dt),
+    }
+
+
+def end_to_end(engine, n_ch, frames_dev, device_index, steps):
+    """SURVEY 8(d)'s second number: a tick as a caller with HOST buffers sees it -- H2D of the PCM frame (pinned host
+    memory), the kernel, D2H of the block records and their decode into per-channel block structs on the host."""
+    bank = engine.ToneBank(engine.DTMF, n_ch, device=device_index)
+    nf = min(frames_dev.shape[0], 8)
+    host = frames_dev[:nf].cpu().pin_memory()
+    views = [host[f].numpy() for f in range(nf)]
+    for f in range(2):
+        bank.rx_host(views[f % nf])
+        bank.blocks()
+    t0 = time.perf_counter()
+    n_blocks = 0
+    for i in range(steps):
+        bank.rx_host(views[i % nf])
+        n_blocks += len(bank.blocks())
+    dt = time.perf_counter() - t0
+    return {
+        "ms_per_step": dt*1e3/steps,
+        "value": float(steps)*n_ch*FRAME/dt/1e6,
+        "unit": "Msamples/s",
+        "steps": steps,
+        "includes": "per step: H2D copy of the %d x %d int16 frame from pinned host memory (%.1f MB), the kernel, D2H of the "
+                    "block records, their decode into spangpu_block_t on the host (%d blocks in all)"
+                    % (n_ch, FRAME, n_ch*FRAME*2/1e6, n_blocks),
     }
 
 
@@ -152,7 +192,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     ap.add_argument("--cpu-frames", type=int, default=40)
-    ap.add_argument("--cpu-loops", type=int, default=15)
+    ap.add_argument("--cpu-seconds", type=float, default=1.5, help="wall time of the all-core reference measurement")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0,
+                    help="the timed region is repeated (whole multiples of --steps) until it lasts at least this long")
+    ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -222,6 +265,25 @@ def main():
     if gather is not None:
         gather.drain()
     torch.cuda.synchronize()
+    # A region of --steps launches of this kernel lasts a fraction of a millisecond: repeat it (whole multiples of
+    # --steps, `reps` of them) until the timed region is at least --min-timed-ms long.  Estimated on an untimed probe.
+    ev_a = torch.cuda.Event(enable_timing=True)
+    ev_b = torch.cuda.Event(enable_timing=True)
+    ev_a.record(stream)
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev_b.record(stream)
+    torch.cuda.synchronize()
+    probe_ms = max(ev_a.elapsed_time(ev_b), 1e-3)
+    reps = max(1, int(np.ceil(args.min_timed_ms/probe_ms)))
+    if world > 1:
+        r = torch.tensor([reps], device=dev, dtype=torch.int64)
+        dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        reps = int(r.item())
+    timed_steps = args.steps*reps
+    if gather is not None:
+        gather.drain()
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -229,7 +291,7 @@ def main():
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    for i in range(args.steps):
+    for i in range(timed_steps):
         step(args.warmup + i)
     if gather is not None:
         gather.drain()
@@ -265,12 +327,12 @@ def main():
         torch.cuda.synchronize()
         per = sorted(a.elapsed_time(b) for a, b in evs)
         pair_avg_ms = sum(per)/len(per)
-        avg_ms = stream_ms/args.steps
+        avg_ms = stream_ms/timed_steps
         alg_read = ALG_READ_BYTES - (FRAME if law else 0)           # G.711: 160 B of codes instead of 320 B of PCM
         achieved = n_ch*alg_read/(avg_ms*1e-3)/1e9
         roof = {
             "bound": "hbm",
-            "kernel": "tone_bank_kernel<DtmfDet<false>>",
+            "kernel": "tone_fast_kernel<DtmfDet<false>, 1 channel per lane, 2-slot ring, loader wave>",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -293,10 +355,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not law:
         nc = min(args.cpu_channels, n_ch)
         host = frames[:min(args.cpu_frames, nf), :nc].contiguous().cpu().numpy()
-        cpu = cpu_baseline(host, args.cpu_loops)
+        cpu = cpu_baseline(host, args.cpu_seconds)
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e and not law:
+        e2e = end_to_end(engine, n_ch, frames, local_rank, 30)
 
     if rank == 0:
-        total_samples = float(args.steps)*n_ch*world*FRAME
+        total_samples = float(timed_steps)*n_ch*world*FRAME
         value = total_samples/dt/1e6
         line = {
             "metric": "Msamples/s of batched DTMF Goertzel detect (8 kHz channels at real-time = value*1e6/8000)",
@@ -306,7 +371,9 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt*1e3/args.steps,
+            "timed_steps": timed_steps,
+            "timed_region_ms": dt*1e3,
+            "ms_per_step": dt*1e3/timed_steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -323,6 +390,7 @@ def main():
             },
             "roofline": roof,
             "cpu_baseline": cpu,
+            "e2e": e2e,
         }
         print(json.dumps(line))
     if world > 1 or force_gather:

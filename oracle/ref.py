@@ -53,6 +53,8 @@ def lib():
             "glue_v29_rx_new": (vp, [ci, vp]), "glue_v27ter_rx_new": (vp, [ci, vp]), "glue_v17_rx_new": (vp, [ci, vp]),
             "glue_v29_tx_new": (vp, [ci, ci, vp]), "glue_v27ter_tx_new": (vp, [ci, ci, vp]), "glue_v17_tx_new": (vp, [ci, ci, vp]),
             "glue_sizeof": (ci, [C.c_char_p]),
+            "glue_mt_rx": (C.c_double, [ci, vp, vp, ci, ci, ci, C.c_longlong, C.c_longlong, ci, ci]),
+            "glue_mt_echo": (C.c_double, [vp, vp, vp, vp, ci, ci, ci, C.c_longlong, C.c_longlong, ci, ci]),
             "glue_modem_tables": (None, [vp, vp, vp, vp, vp, vp]),
             "glue_v29_rx_snapshot": (None, [vp, vp, vp]),
             "glue_v27ter_rx_snapshot": (None, [vp, vp, vp]),
@@ -900,3 +902,77 @@ class V17Tx(V29Tx):
         n = lib().glue_v17_tx_snapshot(self.p, out.ctypes.data)
         out[n] = self.st[0]
         return out[:n + 1].copy()
+
+
+# ---- the pthread driver of the cpu_baseline legs (ref_glue/ref_glue_mt.c) ---------------------------------------
+MT_DTMF, MT_BELL_MF, MT_R2_MF, MT_SUPER_TONE, MT_V29, MT_V27TER, MT_V17, MT_FSK, MT_MCT = range(9)
+
+
+def mt_rx(kind, states, frames, loops, threads):
+    """Runs `loops` passes over frames (int16 [n_frames, n_ch, samples], C order) through the reference receiver
+    objects `states` (list of pointers, one per channel) of `kind` on `threads` host threads, all inside C.
+    Returns the elapsed seconds."""
+    frames = np.ascontiguousarray(frames, np.int16)
+    n_frames, n_ch, samples = frames.shape
+    assert len(states) == n_ch
+    arr = (C.c_void_p*n_ch)(*states)
+    return lib().glue_mt_rx(kind, C.addressof(arr), frames.ctypes.data, n_ch, n_frames, samples, samples, n_ch*samples,
+                            loops, threads)
+
+
+def mt_echo(states, tx, rx, loops, threads):
+    """The same for echo_can_update(): tx / rx int16 [n_frames, n_ch, samples].  Returns (seconds, clean samples of
+    the last frame [n_ch, samples])."""
+    tx = np.ascontiguousarray(tx, np.int16)
+    rx = np.ascontiguousarray(rx, np.int16)
+    n_frames, n_ch, samples = tx.shape
+    assert rx.shape == tx.shape and len(states) == n_ch
+    arr = (C.c_void_p*n_ch)(*states)
+    out = np.zeros((n_ch, samples), np.int16)
+    dt = lib().glue_mt_echo(C.addressof(arr), tx.ctypes.data, rx.ctypes.data, out.ctypes.data, n_ch, n_frames, samples,
+                            samples, n_ch*samples, loops, threads)
+    return dt, out
+
+
+def timed_baseline(run, samples_per_loop, target_s):
+    """run(loops) -> seconds.  Calibrates on a short run, then runs enough loops for about target_s seconds.
+    Returns (samples per second, loops, seconds)."""
+    loops = 1
+    dt = run(loops)
+    while dt < 0.05 and loops < (1 << 20):
+        loops *= 4
+        dt = run(loops)
+    want = max(1, int(loops*target_s/max(dt, 1e-9)))
+    if want > loops:
+        loops = want
+        dt = run(loops)
+    return samples_per_loop*loops/dt, loops, dt
+
+
+def usable_cores():
+    """Host cores this process can actually run on at once: the smaller of its CPU affinity and the cgroup CPU quota
+    (the GPU boxes show 256 CPUs but cap the container at 16 cores' worth of time: cpu.max = "1600000 100000";
+    measured in tools/cpu_scaling.py -- the reference scales linearly to 16 threads and not beyond).  Returns
+    (cores, description)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    note = "%d CPUs visible" % n
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q)/float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q/per
+        except Exception:
+            pass
+    if quota is not None:
+        note += ", cgroup CPU quota %.1f cores" % quota
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, note

@@ -324,6 +324,25 @@ def banks_rx_device(banks, ptrs, samples, strides=None):
     _check(lib().spangpu_banks_rx(hb, pa, n, samples, st))
 
 
+class BanksPlan:
+    """banks_rx_device() with the argument arrays built once: plan = BanksPlan(banks); plan.frame(ptrs) -> a handle
+    for one set of frame addresses; plan.rx(handle, samples) queues the launch (no Python-side allocation per tick)."""
+
+    def __init__(self, banks, strides=None):
+        self.n = len(banks)
+        self.hb = (C.c_void_p*self.n)(*[b.h for b in banks])
+        self.st = (C.c_longlong*self.n)(*strides) if strides is not None else None
+        self.fn = lib().spangpu_banks_rx
+
+    def frame(self, ptrs):
+        return (C.c_void_p*self.n)(*[C.c_void_p(int(p)) for p in ptrs])
+
+    def rx(self, frame, samples):
+        rc = self.fn(self.hb, frame, self.n, samples, self.st)
+        if rc < 0:
+            _check(rc)
+
+
 class EchoBank:
     """N G.168 line echo cancellers, state resident in HBM."""
 

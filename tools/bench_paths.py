@@ -175,29 +175,44 @@ def run_threads(n_ch, work):
     return cores, time.perf_counter() - t0
 
 
-def cpu_modem(kind, bit_rate, frames_host):
-    """The reference receiver (oracle/_ref) on the host cores over a bounded sample of the same frames."""
+def ref_baseline(what, kind_id, new_state, free_state, frames_host, seconds=1.0):
+    """The reference receiver on the host over a bounded sample of the same frames, driven by the pthread driver of
+    oracle/ref_glue/ref_glue_mt.c (every thread loops over its slice of channel objects, frames and passes inside C):
+    all usable cores (the headline value) and one core."""
     import oracle
     from oracle import ref
-    assert oracle.have_ref(), "cpu baseline for the modem path needs oracle/_ref"
+    assert oracle.have_ref(), "the cpu baseline of this path needs oracle/_ref"
     n_frames, n_ch, _ = frames_host.shape
+    usable, note = ref.usable_cores()
+    threads = max(1, min(usable, n_ch))
+
+    def measure(ch, th, secs):
+        states = [new_state(c) for c in range(ch)]
+        sub = np.ascontiguousarray(frames_host[:, :ch])
+        rate, loops, dt = ref.timed_baseline(lambda l: ref.mt_rx(kind_id, states, sub, l, th), float(sub.size), secs)
+        if free_state is not None:
+            for st in states:
+                free_state(st)
+        return rate, loops, dt
+    all_rate, all_loops, all_dt = measure(n_ch, threads, seconds)
+    one_ch = min(n_ch, 64)
+    one_rate, one_loops, one_dt = measure(one_ch, 1, seconds)
+    return {"value": all_rate/1e6, "unit": "Msamples/s", "cores": threads, "kind": "reference", "single_core": one_rate/1e6,
+            "host_cores": note,
+            "sample": "reference (oracle/_ref) %s, pthread driver: %d channels x %d frames x %d passes on %d threads in %.2f s; "
+                      "one core: %d channels x %d passes in %.2f s" % (what, n_ch, n_frames, all_loops, threads, all_dt,
+                                                                        one_ch, one_loops, one_dt)}
+
+
+def cpu_modem(kind, bit_rate, frames_host):
+    """The reference receiver (oracle/_ref) on the host cores over a bounded sample of the same frames."""
+    from oracle import ref
     L = ref.lib()
     new = getattr(L, "glue_%s_rx_new_quiet" % kind)
-    batch = getattr(L, "glue_%s_rx_batch" % kind)
     new.restype = ctypes.c_void_p
     new.argtypes = [ctypes.c_int]
-    batch.restype = None
-    batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
-    arr = (ctypes.c_void_p*n_ch)(*[new(bit_rate) for _ in range(n_ch)])
-
-    def work(lo, hi):
-        base = ctypes.addressof(arr) + lo*ctypes.sizeof(ctypes.c_void_p)
-        for f in range(n_frames):
-            batch(base, frames_host[f, lo:hi].ctypes.data, hi - lo, FRAME, FRAME)
-    cores, dt = run_threads(n_ch, work)
-    return {"value": n_frames*n_ch*FRAME/dt/1e6, "unit": "Msamples/s", "cores": cores, "kind": "reference",
-            "sample": "%d channels x %d frames of %d samples, reference %s_rx on %d host threads, %.1f s"
-                      % (n_ch, n_frames, FRAME, kind, cores, dt)}
+    kind_id = {"v29": ref.MT_V29, "v27ter": ref.MT_V27TER, "v17": ref.MT_V17}[kind]
+    return ref_baseline("%s_rx()" % kind, kind_id, lambda c: new(bit_rate), None, frames_host)
 
 
 # ---- echo canceller -----------------------------------------------------------------------------------
@@ -240,32 +255,29 @@ def synth_echo(n_ch, n_frames, dev, seed):
     return tx, rx
 
 
-def cpu_echo(tx_host, rx_host):
+def cpu_echo(tx_host, rx_host, seconds=1.0):
+    """echo_can_update() of the reference (oracle/_ref) on the host: all usable cores and one core (pthread driver)."""
     import oracle
     from oracle import ref
     assert oracle.have_ref(), "cpu baseline for the echo path needs oracle/_ref"
     n_frames, n_ch, _ = tx_host.shape
-    L = ref.lib()
-    L.glue_echo_batch.restype = None
-    L.glue_echo_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                  ctypes.c_longlong, ctypes.c_int, ctypes.c_int]
-    cans = [ref.EchoCan(ECHO_TAPS, ECHO_MODE) for _ in range(n_ch)]
-    arr = (ctypes.c_void_p*n_ch)(*[c.p for c in cans])
-    clean = np.zeros((n_ch, FRAME), np.int16)
+    usable, note = ref.usable_cores()
+    threads = max(1, min(usable, n_ch))
 
-    def work(lo, hi):
-        base = ctypes.addressof(arr) + lo*ctypes.sizeof(ctypes.c_void_p)
-        for f in range(n_frames):
-            L.glue_echo_batch(base, tx_host[f, lo:hi].ctypes.data, rx_host[f, lo:hi].ctypes.data, clean[lo:hi].ctypes.data,
-                              hi - lo, FRAME, FRAME, 0)
-    # One thread: on the hosts measured, this loop does not speed up with more threads or processes (1/4/16/64 threads
-    # gave 7.4/6.4/5.6/6.6 Msamples/s on the GPU box), so a many-thread figure would only be misleading.
-    t0 = time.perf_counter()
-    work(0, n_ch)
-    dt = time.perf_counter() - t0
-    return {"value": n_frames*n_ch*FRAME/dt/1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
-            "sample": "%d channels x %d frames of %d samples, reference echo_can_update (128 taps) on 1 host thread "
-                      "(does not scale with threads on this host), %.1f s" % (n_ch, n_frames, FRAME, dt)}
+    def measure(ch, th, secs):
+        cans = [ref.EchoCan(ECHO_TAPS, ECHO_MODE) for _ in range(ch)]
+        tx = np.ascontiguousarray(tx_host[:, :ch])
+        rx = np.ascontiguousarray(rx_host[:, :ch])
+        rate, loops, dt = ref.timed_baseline(lambda l: ref.mt_echo([c.p for c in cans], tx, rx, l, th)[0], float(tx.size), secs)
+        return rate, loops, dt
+    all_rate, all_loops, all_dt = measure(n_ch, threads, seconds)
+    one_ch = min(n_ch, 32)
+    one_rate, one_loops, one_dt = measure(one_ch, 1, seconds)
+    return {"value": all_rate/1e6, "unit": "Msamples/s", "cores": threads, "kind": "reference", "single_core": one_rate/1e6,
+            "host_cores": note,
+            "sample": "reference (oracle/_ref) echo_can_update() 128 taps, pthread driver: %d channels x %d frames x %d passes on "
+                      "%d threads in %.2f s; one core: %d channels x %d passes in %.2f s"
+                      % (n_ch, n_frames, all_loops, threads, all_dt, one_ch, one_loops, one_dt)}
 
 
 def bench_echo(args, dev, stream):
@@ -355,29 +367,57 @@ def bench_mixed(args, dev, stream):
         b.set_stream(ctypes.c_void_p(stream.cuda_stream))
 
     fused = not args.separate_launches
+    plan = engine.BanksPlan(banks)
+    handles = [plan.frame([frames[kind].data_ptr() + f*n_each[kind]*FRAME*2 for kind in range(3)]) for f in range(nf)]
+    addr = [[ctypes.c_void_p(frames[kind].data_ptr() + f*n_each[kind]*FRAME*2) for kind in range(3)] for f in range(nf)]
 
     def step(i):
         if fused:
-            engine.banks_rx_device(banks, [frames[kind].data_ptr() + (i % nf)*n_each[kind]*FRAME*2 for kind in range(3)], FRAME)
+            plan.rx(handles[i % nf], FRAME)
             return
         for kind in range(3):
-            banks[kind].rx_device(ctypes.c_void_p(frames[kind].data_ptr() + (i % nf)*n_each[kind]*FRAME*2), FRAME, FRAME)
+            banks[kind].rx_device(addr[i % nf][kind], FRAME, FRAME)
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # the launch duration: HIP events on the launch stream around the whole timed region / launches in it
+    reps = max(1, int(np.ceil(2000/args.steps)))
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        evs[i][0].record(stream)
+    ev0.record(stream)
+    for i in range(args.steps*reps):
         step(args.warmup + i)
-        evs[i][1].record(stream)
+    ev1.record(stream)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    per = [a.elapsed_time(b) for a, b in evs]
-    avg_ms = sum(per)/len(per)
+    dt = (time.perf_counter() - t0)/reps
+    avg_ms = ev0.elapsed_time(ev1)/(args.steps*reps)
     hits = [int((b.blocks()["hit"] != 0).sum()) for b in banks]
     alg_read = n_each[0]*(320 + 64) + n_each[1]*(320 + 64) + n_each[2]*(320 + 8*8 + 160)
     value = args.steps*n_ch*FRAME/dt/1e6
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the reference on the host, the three detector kinds one after the other on a third of the sample each
+        from oracle import ref
+        L = ref.lib()
+        n_cpu = min(args.cpu_channels, n_ch)//3
+        desc = ref.SuperToneDesc()
+        for f in st_freqs:
+            t = desc.add_tone()
+            desc.add_element(t, int(f), 0, 300, 0)
+        parts = [
+            ref_baseline("bell_mf_rx()", ref.MT_BELL_MF, lambda c: L.glue_bell_mf_rx_new(None, 0), None,
+                         frames[0][:, :n_cpu].contiguous().cpu().numpy(), 0.7),
+            ref_baseline("r2_mf_rx()", ref.MT_R2_MF, lambda c: L.glue_r2_mf_rx_new(None, 1, 0), None,
+                         frames[1][:, :n_cpu].contiguous().cpu().numpy(), 0.7),
+            ref_baseline("super_tone_rx()", ref.MT_SUPER_TONE, lambda c: L.glue_super_tone_rx_new(desc.p, L.glue_sink_new(), 0), None,
+                         frames[2][:, :n_cpu].contiguous().cpu().numpy(), 0.7),
+        ]
+        w = [n_each[k]/float(n_ch) for k in range(3)]
+        cpu = {"value": 1.0/sum(w[k]/parts[k]["value"] for k in range(3)), "unit": "Msamples/s", "cores": parts[0]["cores"],
+               "kind": "reference", "single_core": 1.0/sum(w[k]/parts[k]["single_core"] for k in range(3)),
+               "host_cores": parts[0]["host_cores"],
+               "sample": "channel-weighted harmonic mean of: " + " | ".join(p["sample"] for p in parts)}
     return {
         "metric": "Msamples/s of mixed Bell MF + R2 MF + super-tone Goertzel banks (8 kHz channels at real-time = value*1e6/8000)",
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
@@ -387,13 +427,13 @@ def bench_mixed(args, dev, stream):
                                "frames, %s" % (n_each[0], n_each[1], n_each[2], FRAME,
                                                 "one launch per step (spangpu_banks_rx)" if fused else "three launches per step"),
                    "channels_per_gpu": n_ch, "blocks_with_a_hit_in_last_step": hits},
-        "roofline": {"bound": "hbm", "kernel": "tone_multi_kernel<2> (Bell MF + R2 MF + super-tone workgroups in one launch)" if fused
-                               else "tone_bank_kernel<BellMfDet | R2MfDet | MultiDet<8, true>> (3 launches)",
+        "roofline": {"bound": "hbm", "kernel": "tone_multi_fast_kernel (Bell MF + R2 MF + super-tone workgroups in one launch)" if fused
+                               else "tone_fast_kernel<BellMfDet | R2MfDet | MultiDet<8, true>> (3 launches)",
                      "achieved": alg_read/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
                      "alg_read_bytes_per_launch": alg_read, "avg_launch_us": avg_ms*1e3,
-                     "note": "avg_launch_us is one whole step (all three banks)"},
-        "cpu_baseline": None}
+                     "note": "avg_launch_us is one whole step (all three banks): events around the timed region / steps in it"},
+        "cpu_baseline": cpu}
 
 
 def bench_fsk(args, dev, stream):
@@ -436,18 +476,9 @@ def bench_fsk(args, dev, stream):
         L = ref.lib()
         n_cpu = min(args.cpu_channels, n_ch)
         counters = np.zeros(n_cpu*8, np.int64)              # one per receiver, a cache line apart
-        objs = (ctypes.c_void_p*n_cpu)(*[L.glue_fsk_rx_new_quiet(which, 1, counters.ctypes.data + c*64) for c in range(n_cpu)])
-        host = frames[:, :n_cpu].contiguous().cpu().numpy()
-        loops = 40
-
-        def work(lo, hi):
-            L.glue_fsk_rx_batch_frames(ctypes.addressof(objs) + lo*8, host[0, lo:].ctypes.data, hi - lo, FRAME, n_cpu*FRAME,
-                                       FRAME, nf, loops)
-        cores, t = run_threads(n_cpu, work)
-        cpu = {"value": n_cpu*nf*loops*FRAME/t/1e6, "unit": "Msamples/s", "cores": cores, "kind": "reference",
-               "sample": "fsk_rx() of oracle/_ref on %d channels x %d frames, %d threads" % (n_cpu, nf*loops, cores)}
-        for o in objs:
-            L.fsk_rx_free(o)
+        cpu = ref_baseline("fsk_rx() V.21 ch 2 sync", ref.MT_FSK,
+                           lambda c: L.glue_fsk_rx_new_quiet(which, 1, counters.ctypes.data + c*64), L.fsk_rx_free,
+                           frames[:, :n_cpu].contiguous().cpu().numpy())
     words = bank.words
     alg_read = n_ch*(FRAME*2 + words*4)
     alg_write = n_ch*((words - 12)*4 + 4)
@@ -507,18 +538,9 @@ def bench_mct(args, dev, stream):
         from oracle import ref
         L = ref.lib()
         n_cpu = min(args.cpu_channels, n_ch)
-        objs = (ctypes.c_void_p*n_cpu)(*[L.modem_connect_tones_rx_init(None, 7, None, None) for _ in range(n_cpu)])
-        host = frames[:, :n_cpu].contiguous().cpu().numpy()
-        loops = 20
-
-        def work(lo, hi):
-            L.glue_mct_rx_batch_frames(ctypes.addressof(objs) + lo*8, host[0, lo:].ctypes.data, hi - lo, FRAME, n_cpu*FRAME,
-                                       FRAME, nf, loops)
-        cores, t = run_threads(n_cpu, work)
-        cpu = {"value": n_cpu*nf*loops*FRAME/t/1e6, "unit": "Msamples/s", "cores": cores, "kind": "reference",
-               "sample": "modem_connect_tones_rx() of oracle/_ref on %d channels x %d frames, %d threads" % (n_cpu, nf*loops, cores)}
-        for o in objs:
-            L.modem_connect_tones_rx_free(o)
+        cpu = ref_baseline("modem_connect_tones_rx() FAX_CED_OR_PREAMBLE", ref.MT_MCT,
+                           lambda c: L.modem_connect_tones_rx_init(None, 7, None, None), L.modem_connect_tones_rx_free,
+                           frames[:, :n_cpu].contiguous().cpu().numpy())
     words = bank.words
     alg_read = n_ch*(FRAME*2 + words*4)
     alg_write = n_ch*((words - 12)*4 + 4)
