@@ -177,6 +177,124 @@ def end_to_end(engine, n_ch, frames_dev, device_index, steps):
     }
 
 
+def run_echo(args, engine, dev, local_rank, rank, world):
+    """BASELINE configs[4]: the G.168 canceller (echo.c, 128 taps, ECHO_CAN_USE_ADAPTION) on 131 072 channels per GPU,
+    channels sharded over the ranks with no data-path collective; once per second of signal (50 steps) every rank turns
+    its per-channel energy sums into ERLE (spangpu_echo_erle, written into the RCCL send buffer) and the floats are
+    gathered to rank 0.  A step = one 160-sample frame of every channel of the rank."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_paths as bp
+    from spandsp_amd.parallel import FloatGather
+    n_ch = args.channels if args.channels != 65536 else 131072
+    nf = 50
+    tx, rx = bp.synth_echo(n_ch, nf, dev, seed=0xEC40 + rank)
+    clean = torch.empty(n_ch, FRAME, dtype=torch.int16, device=dev)
+    bank = engine.EchoBank(n_ch, bp.ECHO_TAPS, bp.ECHO_MODE, device=local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    bank.stats(True)
+    gather = FloatGather(world, rank, n_ch, dev) if world > 1 else None
+    erle_dev = gather.send if gather is not None else torch.zeros(n_ch, dtype=torch.float32, device=dev)
+    fb = n_ch*FRAME*2
+    report_every = 50
+
+    def step(i):
+        k = i % nf
+        bank.update_device(ctypes.c_void_p(tx.data_ptr() + k*fb), ctypes.c_void_p(rx.data_ptr() + k*fb),
+                           ctypes.c_void_p(clean.data_ptr()), FRAME, FRAME)
+        if (i + 1) % report_every == 0:
+            bank.erle_device(ctypes.c_void_p(erle_dev.data_ptr()))
+            if gather is not None:
+                gather.result()                     # the previous report has arrived
+                gather.gather()
+            bank.stats_reset(sums=True, crc=False)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    ev_a = torch.cuda.Event(enable_timing=True)
+    ev_b = torch.cuda.Event(enable_timing=True)
+    ev_a.record(stream)
+    for i in range(args.steps):
+        step(args.warmup + i)
+    ev_b.record(stream)
+    torch.cuda.synchronize()
+    reps = max(1, int(np.ceil(args.min_timed_ms/max(ev_a.elapsed_time(ev_b), 1e-3))))
+    if world > 1:
+        r = torch.tensor([reps], device=dev, dtype=torch.int64)
+        dist.all_reduce(r, op=dist.ReduceOp.MAX)
+        reps = int(r.item())
+    timed_steps = args.steps*reps
+    first = args.warmup + args.steps
+    if gather is not None:
+        gather.result()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for i in range(timed_steps):
+        step(first + i)
+    if gather is not None:
+        gather.result()
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    stream_ms = ev0.elapsed_time(ev1)
+    # a final report over everything since the last reset, for the JSON line
+    bank.erle_device(ctypes.c_void_p(erle_dev.data_ptr()))
+    if gather is not None:
+        gather.gather()
+        allr = gather.result()
+    else:
+        torch.cuda.synchronize()
+        allr = erle_dev.unsqueeze(0)
+    if rank != 0:
+        return
+    quiet = (torch.arange(n_ch, device=dev) % 10 != 0)
+    erle_single = allr[:, quiet].float()
+    state_bytes = 48*4 + bp.ECHO_TAPS*4 + 4*bp.ECHO_TAPS*2 + bp.ECHO_TAPS*2
+    alg_read = n_ch*(2*FRAME*2 + state_bytes)
+    avg_ms = stream_ms/timed_steps
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        nc = min(4096, n_ch)
+        cpu = bp.cpu_echo(tx[:, :nc].contiguous().cpu().numpy(), rx[:, :nc].contiguous().cpu().numpy())
+    value = float(timed_steps)*n_ch*world*FRAME/dt/1e6
+    print(json.dumps({
+        "metric": "Msamples/s of batched G.168 echo cancellation, 128 taps (8 kHz channels at real-time = value*1e6/8000)",
+        "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "timed_steps": timed_steps, "timed_region_ms": dt*1e3,
+        "ms_per_step": dt*1e3/timed_steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4]: echo_can_update 128 taps, ECHO_CAN_USE_ADAPTION, %d channels/GPU x %d-sample "
+                               "frames, per-channel ERLE gathered to rank 0 every %d steps" % (n_ch, FRAME, report_every),
+                   "channels_per_gpu": n_ch, "frame_samples": FRAME,
+                   "parallelism": ("channels sharded x%d, RCCL gather of one ERLE float per channel per second of signal" % world)
+                                  if world > 1 else "single GPU",
+                   "erle_db_single_talk_channels": {"median": float(erle_single.median()), "p10": float(erle_single.quantile(0.1)),
+                                                    "ranks": int(allr.shape[0])}},
+        "roofline": {"bound": "hbm", "kernel": "echo_bank_kernel<32 taps per lane, 4 lanes per channel>",
+                     "achieved": alg_read/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None, "alg_read_bytes_per_launch": alg_read,
+                     "avg_launch_us": avg_ms*1e3,
+                     "note": "integer-VALU bound (2 x 128 MACs per sample per channel); the HBM figure is reported, not targeted; "
+                             "avg_launch_us is a whole step (update + statistics kernels)"},
+        "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +307,10 @@ def main():
     ap.add_argument("--g711", choices=["none", "alaw", "ulaw"], default="none",
                     help="feed the bank G.711 bytes (decoded on the device) instead of 16 bit linear PCM; not the "
                          "BASELINE configuration -- a variant of it with the wire format of a trunk")
+    ap.add_argument("--workload", choices=["dtmf", "echo"], default="dtmf",
+                    help="dtmf: BASELINE configs[1] (the headline); echo: BASELINE configs[4], one GPU's shard per rank "
+                         "(131072 channels of the 128-tap echo canceller), ERLE of every channel gathered to rank 0 "
+                         "once per second of signal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     ap.add_argument("--cpu-frames", type=int, default=40)
@@ -220,6 +342,12 @@ def main():
 
     from spandsp_amd import engine
     from spandsp_amd.parallel import ResultGather, shard_range
+
+    if args.workload == "echo":
+        run_echo(args, engine, dev, local_rank, rank, world)
+        if world > 1 or force_gather:
+            dist.destroy_process_group()
+        return
 
     n_ch = args.channels
     lo, hi = shard_range(n_ch*world, world, rank)

@@ -229,6 +229,25 @@ SPANGPU_API int spangpu_tune_echo_lanes_per_channel(int lanes);
 SPANGPU_API int spangpu_echo_hpf_tx(spangpu_echo_t *ec, const int16_t *tx, int16_t *out, int samples, long long stride);
 SPANGPU_API int spangpu_echo_adaption_mode(spangpu_echo_t *ec, int channel, int adaption_mode);
 SPANGPU_API int spangpu_echo_flush(spangpu_echo_t *ec, int channel);
+/* Per-channel line statistics (the result a multi-GPU echo run gathers: SURVEY 8(d)-5).  Once enabled, every update
+   also accumulates, per channel, the energy of the received signal and of the cleaned signal -- ERLE = 10 log10 of their
+   ratio, what level_measurements_update() of tests/echo_tests.c:577-594 watches -- and the CRC-32 (zlib) of the clean
+   stream as int16 little-endian bytes, for exactness checks against the CPU path. */
+typedef struct
+{
+    uint64_t sum_rx2;           /* sum of rx[i]^2 since the sums were last reset        */
+    uint64_t sum_clean2;        /* sum of clean[i]^2                                    */
+    uint32_t crc;               /* CRC-32 of every clean sample since the CRC was reset */
+    uint32_t samples;           /* samples in the sums                                  */
+} spangpu_echo_stats_t;
+#define SPANGPU_ECHO_STATS_SUMS     1
+#define SPANGPU_ECHO_STATS_CRC      2
+SPANGPU_API int spangpu_echo_stats(spangpu_echo_t *ec, int enable);
+SPANGPU_API int spangpu_echo_stats_reset(spangpu_echo_t *ec, int what);    /* SPANGPU_ECHO_STATS_SUMS | _CRC */
+SPANGPU_API int spangpu_echo_stats_get(spangpu_echo_t *ec, int first_channel, int n, spangpu_echo_stats_t *out);
+/* ERLE in dB of every channel from the sums, into erle_db[n_channels] (host or device memory: a device buffer can be the
+   send buffer of an RCCL gather).  0 while nothing was measured, 120 when the residue is exactly zero. */
+SPANGPU_API int spangpu_echo_erle(spangpu_echo_t *ec, float *erle_db, int mem);
 /* One channel's state in the reference's terms: control words (order: DESIGN.md), taps32[taps],
    taps16[4][taps], FIR history[taps] in its physical circular order.  Any pointer may be NULL. */
 SPANGPU_API int spangpu_echo_get_state(spangpu_echo_t *ec, int channel, int32_t *scalars, int32_t *taps32,

@@ -42,6 +42,9 @@ struct spangpu_echo_s
     int16_t *hist;
     int16_t *d_io;          // staging for host-resident tx / rx / clean: [3][n_ch][cap]
     size_t io_cap;          // samples per channel
+    EchoStats *stats;       // per-channel line statistics, allocated by spangpu_echo_stats(ec, 1)
+    bool stats_on;
+    float *d_erle;          // scratch for spangpu_echo_erle() with a host destination
 };
 
 __global__ void echo_set_scalar_kernel(int32_t *scal, int lo, int hi, int idx, int value)
@@ -159,6 +162,8 @@ int spangpu_echo_destroy(spangpu_echo_t *e)
     if (e->taps16) (void) hipFree(e->taps16);
     if (e->hist) (void) hipFree(e->hist);
     if (e->d_io) (void) hipFree(e->d_io);
+    if (e->stats) (void) hipFree(e->stats);
+    if (e->d_erle) (void) hipFree(e->d_erle);
     if (e->own_stream  &&  e->stream)
         (void) hipStreamDestroy(e->stream);
     free(e);
@@ -288,6 +293,12 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
         }
     }
     ECHO_TRY(hipGetLastError());
+    if (e->stats_on)
+    {
+        hipLaunchKernelGGL(echo_stats_kernel, dim3((e->n_ch + 255)/256), dim3(256), 0, e->stream,
+                           L.rx, (const int16_t *) L.clean, L.stride, samples, e->n_ch, e->stats);
+        ECHO_TRY(hipGetLastError());
+    }
     if (mem == SPANGPU_MEM_HOST)
     {
         ECHO_TRY(hipMemcpy2DAsync(clean, stride*sizeof(int16_t), L.clean, e->io_cap*sizeof(int16_t), samples*sizeof(int16_t),
@@ -384,6 +395,83 @@ int spangpu_echo_set_state(spangpu_echo_t *e, int channel, const int32_t *scal, 
 }
 
 // echo_can_adaption_mode(), echo.c:324-328 (channel < 0: every channel)
+// ---- per-channel line statistics ----------------------------------------------------------------------------------
+int spangpu_echo_stats(spangpu_echo_t *e, int enable)
+{
+    if (e == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null bank");
+    ECHO_TRY(hipSetDevice(e->device));
+    if (enable  &&  e->stats == nullptr)
+    {
+        ECHO_TRY(hipMalloc(&e->stats, (size_t) e->n_ch*sizeof(EchoStats)));
+        ECHO_TRY(hipMemsetAsync(e->stats, 0, (size_t) e->n_ch*sizeof(EchoStats), e->stream));
+    }
+    e->stats_on = (enable != 0);
+    return SPANGPU_OK;
+}
+
+__global__ void echo_stats_reset_kernel(EchoStats *st, int n_ch, int what)
+{
+    const int ch = blockIdx.x*256 + threadIdx.x;
+    if (ch >= n_ch)
+        return;
+    if (what & SPANGPU_ECHO_STATS_SUMS)
+    {
+        st[ch].sum_rx2 = 0;
+        st[ch].sum_clean2 = 0;
+        st[ch].samples = 0;
+    }
+    if (what & SPANGPU_ECHO_STATS_CRC)
+        st[ch].crc = 0;
+}
+
+int spangpu_echo_stats_reset(spangpu_echo_t *e, int what)
+{
+    if (e == nullptr  ||  e->stats == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "statistics are not enabled on this bank");
+    ECHO_TRY(hipSetDevice(e->device));
+    hipLaunchKernelGGL(echo_stats_reset_kernel, dim3((e->n_ch + 255)/256), dim3(256), 0, e->stream, e->stats, e->n_ch, what);
+    ECHO_TRY(hipGetLastError());
+    return SPANGPU_OK;
+}
+
+int spangpu_echo_stats_get(spangpu_echo_t *e, int first, int n, spangpu_echo_stats_t *out)
+{
+    if (e == nullptr  ||  e->stats == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "statistics are not enabled on this bank");
+    if (out == nullptr  ||  first < 0  ||  n < 0  ||  first + n > e->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    static_assert(sizeof(spangpu_echo_stats_t) == sizeof(EchoStats), "ABI struct and device struct are the same record");
+    ECHO_TRY(hipSetDevice(e->device));
+    ECHO_TRY(hipMemcpyAsync(out, e->stats + first, (size_t) n*sizeof(EchoStats), hipMemcpyDeviceToHost, e->stream));
+    ECHO_TRY(hipStreamSynchronize(e->stream));
+    return SPANGPU_OK;
+}
+
+int spangpu_echo_erle(spangpu_echo_t *e, float *erle_db, int mem)
+{
+    if (e == nullptr  ||  e->stats == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "statistics are not enabled on this bank");
+    if (erle_db == nullptr  ||  (mem != SPANGPU_MEM_HOST  &&  mem != SPANGPU_MEM_DEVICE))
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    ECHO_TRY(hipSetDevice(e->device));
+    float *dst = erle_db;
+    if (mem == SPANGPU_MEM_HOST)
+    {
+        if (e->d_erle == nullptr)
+            ECHO_TRY(hipMalloc(&e->d_erle, (size_t) e->n_ch*sizeof(float)));
+        dst = e->d_erle;
+    }
+    hipLaunchKernelGGL(echo_erle_kernel, dim3((e->n_ch + 255)/256), dim3(256), 0, e->stream, (const EchoStats *) e->stats, dst, e->n_ch);
+    ECHO_TRY(hipGetLastError());
+    if (mem == SPANGPU_MEM_HOST)
+    {
+        ECHO_TRY(hipMemcpyAsync(erle_db, dst, (size_t) e->n_ch*sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        ECHO_TRY(hipStreamSynchronize(e->stream));
+    }
+    return SPANGPU_OK;
+}
+
 int spangpu_echo_adaption_mode(spangpu_echo_t *e, int channel, int adaption_mode)
 {
     if (e == nullptr  ||  channel >= e->n_ch)

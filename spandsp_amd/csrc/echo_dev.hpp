@@ -807,4 +807,82 @@ void echo_hpf_tx_kernel(const int16_t *tx, int16_t *out, long long stride, int s
     sc[ES_TX_HPF1] = c1;
 }
 
+// ---- per-channel line statistics (the result a multi-GPU echo run reports) -----------------------------
+// After an update, one lane per channel walks that channel's received (rx) and cleaned samples of the frame and
+// accumulates sum rx^2 and sum clean^2 (exact, 64 bit) -- ERLE = 10 log10(sum rx^2 / sum clean^2) as the reference's
+// level_measurements do (tests/echo_tests.c:577-594) -- and carries on the CRC-32 (zlib polynomial, the bytes of the
+// int16 little-endian stream) of everything the canceller has put out, for bit-exactness checks against the CPU path.
+// The frame was written a moment ago by echo_bank_kernel and is read from L2; the CRC table sits in LDS.
+struct EchoStats
+{
+    unsigned long long sum_rx2;
+    unsigned long long sum_clean2;
+    uint32_t crc;               // running CRC-32 of the clean stream (pre- and post-conditioned as zlib's)
+    uint32_t samples;           // samples in the sums
+};
+
+__global__ __launch_bounds__(256)
+void echo_stats_kernel(const int16_t *rx, const int16_t *clean, long long stride, int samples, int n_ch, EchoStats *st)
+{
+    __shared__ uint32_t table[256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0;  k < 8;  k++)
+            c = (c & 1u)  ?  (0xEDB88320u ^ (c >> 1))  :  (c >> 1);
+        table[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const int ch = blockIdx.x*256 + threadIdx.x;
+    if (ch >= n_ch)
+        return;
+    EchoStats s = st[ch];
+    uint32_t crc = ~s.crc;
+    const int16_t *r = rx + (size_t) ch*stride;
+    const int16_t *c = clean + (size_t) ch*stride;
+    auto one = [&](int a, int b)
+    {
+        s.sum_rx2 += (unsigned long long) (a*a);
+        s.sum_clean2 += (unsigned long long) (b*b);
+        crc = table[(crc ^ (uint32_t) b) & 0xFF] ^ (crc >> 8);
+        crc = table[(crc ^ ((uint32_t) b >> 8)) & 0xFF] ^ (crc >> 8);
+    };
+    int i = 0;
+    if ((((uintptr_t) r | (uintptr_t) c) & 15) == 0)
+    {
+        // rows on 16-byte boundaries: eight samples per load
+        for (  ;  i + 8 <= samples;  i += 8)
+        {
+            const int4 ra = *(const int4 *) (r + i);
+            const int4 ca = *(const int4 *) (c + i);
+            const int rw[4] = {ra.x, ra.y, ra.z, ra.w};
+            const int cw[4] = {ca.x, ca.y, ca.z, ca.w};
+#pragma unroll
+            for (int k = 0;  k < 4;  k++)
+            {
+                one((int) (short) (rw[k] & 0xFFFF), (int) (short) (cw[k] & 0xFFFF));
+                one(rw[k] >> 16, cw[k] >> 16);
+            }
+        }
+    }
+    for (  ;  i < samples;  i++)
+        one(r[i], c[i]);
+    s.crc = ~crc;
+    s.samples += (uint32_t) samples;
+    st[ch] = s;
+}
+
+// ERLE in dB per channel from the sums (0 dB while nothing has been measured; capped at 120 dB when the residue is zero).
+__global__ __launch_bounds__(256)
+void echo_erle_kernel(const EchoStats *st, float *erle_db, int n_ch)
+{
+    const int ch = blockIdx.x*256 + threadIdx.x;
+    if (ch >= n_ch)
+        return;
+    const EchoStats s = st[ch];
+    float v = 0.0f;
+    if (s.sum_rx2 != 0)
+        v = (s.sum_clean2 == 0)  ?  120.0f  :  10.0f*log10f((float) ((double) s.sum_rx2/(double) s.sum_clean2));
+    erle_db[ch] = v;
+}
+
 }   // namespace spg

@@ -123,6 +123,10 @@ def lib():
             "spangpu_fsk_set_frame_parameters": (ci, [vp, ci, ci, ci, ci]),
             "spangpu_fsk_fillin": (ci, [vp, ci, ci]),
             "spangpu_tune_echo_lanes_per_channel": (ci, [ci]),
+            "spangpu_echo_stats": (ci, [vp, ci]),
+            "spangpu_echo_stats_reset": (ci, [vp, ci]),
+            "spangpu_echo_stats_get": (ci, [vp, ci, ci, vp]),
+            "spangpu_echo_erle": (ci, [vp, vp, ci]),
             "spangpu_txbank_create": (ci, [C.POINTER(vp), ci, ci, ci]),
             "spangpu_txbank_destroy": (None, [vp]),
             "spangpu_txbank_channels": (ci, [vp]),
@@ -343,6 +347,9 @@ class BanksPlan:
             _check(rc)
 
 
+ECHO_STATS_DTYPE = np.dtype([("sum_rx2", "<u8"), ("sum_clean2", "<u8"), ("crc", "<u4"), ("samples", "<u4")])
+
+
 class EchoBank:
     """N G.168 line echo cancellers, state resident in HBM."""
 
@@ -383,6 +390,27 @@ class EchoBank:
 
     def adaption_mode(self, mode, channel=-1):
         _check(lib().spangpu_echo_adaption_mode(self.h, channel, mode))
+
+    # per-channel line statistics: energy of rx and of the clean signal, CRC-32 of the clean stream
+    def stats(self, enable=True):
+        _check(lib().spangpu_echo_stats(self.h, int(enable)))
+
+    def stats_reset(self, sums=True, crc=False):
+        _check(lib().spangpu_echo_stats_reset(self.h, (1 if sums else 0) | (2 if crc else 0)))
+
+    def stats_get(self, first=0, n=None):
+        n = self.n - first if n is None else n
+        out = np.zeros(n, ECHO_STATS_DTYPE)
+        _check(lib().spangpu_echo_stats_get(self.h, first, n, out.ctypes.data))
+        return out
+
+    def erle_host(self):
+        out = np.zeros(self.n, np.float32)
+        _check(lib().spangpu_echo_erle(self.h, out.ctypes.data, MEM_HOST))
+        return out
+
+    def erle_device(self, dev_ptr):
+        _check(lib().spangpu_echo_erle(self.h, dev_ptr, MEM_DEVICE))
 
     def flush(self, channel):
         _check(lib().spangpu_echo_flush(self.h, channel))

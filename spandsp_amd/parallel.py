@@ -91,3 +91,31 @@ class ResultGather:
         if self.rank != 0 or self.done_slot is None:
             return None
         return torch.stack(self.recv[self.done_slot]).view(self.world, self.every, self.n)
+
+
+class FloatGather:
+    """Gather of one float per channel (e.g. the ERLE of every echo canceller, spangpu_echo_erle()) from every rank
+    to rank 0: the fixed-size per-channel result of a reporting interval, the only exchange of the multi-GPU echo
+    configuration (BASELINE configs[4]).  `send` is the device buffer the producer writes (for the echo bank:
+    bank.erle_device(g.send.data_ptr())); gather() starts the collective on the current stream and returns the
+    handle, result() waits for it and returns [world, n_ch] on rank 0."""
+
+    def __init__(self, world, rank, n_ch, device):
+        self.world = world
+        self.rank = rank
+        self.n = n_ch
+        self.send = torch.zeros(n_ch, dtype=torch.float32, device=device)
+        self.recv = [torch.zeros(n_ch, dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
+        self.handle = None
+
+    def gather(self):
+        self.handle = dist.gather(self.send, gather_list=self.recv, dst=0, async_op=True)
+        return self.handle
+
+    def result(self):
+        if self.handle is not None:
+            self.handle.wait()
+            self.handle = None
+        if self.rank != 0:
+            return None
+        return torch.stack(self.recv)

@@ -128,3 +128,44 @@ def test_echo_flush_and_mode_change(built):
             want = d.run(tx[c, pos:pos + 160], rx[c, pos:pos + 160], False)
             assert np.array_equal(got[c], want), (fi, c)
     compare_state(bank, dets, "flush")
+
+
+def test_echo_line_statistics(built):
+    """The per-channel result of a multi-GPU echo run: energy of rx and of the cleaned signal over the
+    last second (exact 64-bit sums; ERLE from them) and the CRC-32 of the whole clean stream, against the oracle."""
+    import zlib
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch, taps, mode = 70, 128, 0x01
+    n = 160*120
+    tx, rx = make_channels(n_ch, n, taps, seed=4242)
+    bank = engine.EchoBank(n_ch, taps, mode)
+    bank.stats(True)
+    dets = [orc.EchoCan(taps, mode) for _ in range(n_ch)]
+    clean_o = np.zeros((n_ch, n), np.int16)
+    last_second = n - 8000
+    for pos in range(0, n, 160):
+        if pos == last_second:
+            bank.stats_reset(sums=True, crc=False)
+        got = bank.update_host(tx[:, pos:pos + 160], rx[:, pos:pos + 160], use_hpf_tx=False)
+        for c, d in enumerate(dets):
+            clean_o[c, pos:pos + 160] = d.run(tx[c, pos:pos + 160], rx[c, pos:pos + 160], False)
+        assert np.array_equal(got, clean_o[:, pos:pos + 160])
+    st = bank.stats_get()
+    r = rx[:, last_second:].astype(np.int64)
+    c = clean_o[:, last_second:].astype(np.int64)
+    assert np.array_equal(st["sum_rx2"], (r*r).sum(axis=1).astype(np.uint64))
+    assert np.array_equal(st["sum_clean2"], (c*c).sum(axis=1).astype(np.uint64))
+    assert np.all(st["samples"] == 8000)
+    want_crc = np.array([zlib.crc32(clean_o[k].astype("<i2").tobytes()) for k in range(n_ch)], np.uint32)
+    assert np.array_equal(st["crc"], want_crc)
+    erle = bank.erle_host()
+    want = 10.0*np.log10((r*r).sum(axis=1)/np.maximum((c*c).sum(axis=1), 1))
+    assert np.allclose(erle, want, rtol=1e-5, atol=1e-4)
+    assert np.max(erle) > 20.0 and np.sum(erle > 10.0) >= n_ch//4       # the single-talk lines did converge
+    # a sub-range, and a second reset
+    part = bank.stats_get(5, 9)
+    assert np.array_equal(part["crc"], want_crc[5:14])
+    bank.stats_reset(sums=True, crc=True)
+    z = bank.stats_get()
+    assert not z["sum_rx2"].any() and not z["crc"].any() and not z["samples"].any()

@@ -1,6 +1,8 @@
-"""CPU (gloo, world_size 2) test of the multi-GPU plumbing in spandsp_amd/parallel.py:
-channel sharding and the double-buffered gather of result records to rank 0.  The bank is
-faked (records are a known function of rank / step / channel) -- no GPU compute here."""
+"""CPU (gloo, world_size 2) tests of the multi-GPU plumbing in spandsp_amd/parallel.py: channel sharding, the
+double-buffered gather of result records to rank 0 -- through copy_records() and through the zero-copy aim() /
+set_records_buffer() path bench.py --gpus N uses -- and the gather of per-channel floats (the ERLE result of the echo
+configuration).  Only the kernel is stood in for (there is no GPU here, and the library has no CPU path): the stand-in
+bank writes the record words a launch would write, to wherever the gather aimed it."""
 import ctypes
 import os
 import socket
@@ -79,6 +81,121 @@ def test_result_gather_gloo_world2(every, steps):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, 257, steps, out, every)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=10) is True
+
+
+class AimedBank:
+    """Stands in for a ToneBank on the zero-copy path: set_records_buffer() is what ResultGather.aim() calls, and
+    launch() does what a kernel launch does with it -- writes this step's record words straight to that address."""
+
+    def __init__(self, rank, n):
+        self.rank = rank
+        self.n = n
+        self.step = 0
+        self.dst = None
+        self.dst_bytes = 0
+        self.copies = 0
+
+    def set_records_buffer(self, ptr, nbytes):
+        self.dst = ptr
+        self.dst_bytes = nbytes
+
+    def copy_records(self, dst_ptr, dst_bytes):
+        self.copies += 1
+        raise AssertionError("the aimed path must not copy records")
+
+    def launch(self):
+        words = (np.arange(self.n, dtype=np.int64)*5 + self.rank*7777 + self.step*31).astype(np.int32)
+        assert self.dst is not None and self.dst_bytes >= words.nbytes
+        ctypes.memmove(self.dst, words.ctypes.data, words.nbytes)
+        self.step += 1
+
+
+def _aimed_worker(rank, world, port, total_ch, steps, every, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spandsp_amd.parallel import ResultGather, shard_range
+    lo, hi = shard_range(total_ch, world, rank)
+    n_ch = hi - lo
+    assert n_ch == total_ch//world                    # equal shards (what bench.py runs)
+    g = ResultGather(world, rank, n_ch, max_blocks=2, device=torch.device("cpu"), every=every)
+    bank = AimedBank(rank, 2*n_ch)
+    for s in range(steps):
+        g.aim(bank)
+        bank.launch()
+        g.submit(bank)
+    g.drain()
+    ok = True
+    if rank == 0:
+        got = g.latest().numpy()
+        last = steps - 1
+        filled = (last % every) + 1
+        for r in range(world):
+            for k in range(filled):
+                step = last - (filled - 1) + k
+                want = (np.arange(2*n_ch, dtype=np.int64)*5 + r*7777 + step*31).astype(np.int32)
+                ok = ok and np.array_equal(got[r, k], want)
+        out.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("every,steps", [(1, 4), (5, 12)])
+def test_result_gather_aimed_path_gloo_world2(every, steps):
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_aimed_worker, args=(r, 2, port, 2*193, steps, every, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=10) is True
+
+
+def _float_worker(rank, world, port, n_ch, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spandsp_amd.parallel import FloatGather
+    g = FloatGather(world, rank, n_ch, torch.device("cpu"))
+    ok = True
+    for round_ in range(3):
+        # what spangpu_echo_erle(bank, send, SPANGPU_MEM_DEVICE) does: writes one float per channel into the send buffer
+        vals = (np.arange(n_ch, dtype=np.float32)*0.25 + rank*100.0 + round_).astype(np.float32)
+        ctypes.memmove(g.send.data_ptr(), vals.ctypes.data, vals.nbytes)
+        g.gather()
+        res = g.result()
+        if rank == 0:
+            for r in range(world):
+                want = (np.arange(n_ch, dtype=np.float32)*0.25 + r*100.0 + round_).astype(np.float32)
+                ok = ok and np.array_equal(res[r].numpy(), want)
+        else:
+            ok = ok and res is None
+    if rank == 0:
+        out.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_float_gather_gloo_world2():
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_float_worker, args=(r, 2, port, 1031, out)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
