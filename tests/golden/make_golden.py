@@ -28,9 +28,35 @@ def save(name, **kw):
     print("wrote", name, {k: getattr(v, "shape", v) for k, v in kw.items()})
 
 
+def mitel_side1():
+    """BASELINE configs[0]: Tests 2-7 of tests/dtmf_rx_tests.c on the real reference (signals from its tone_gen / awgn,
+    answers from its dtmf_rx / dtmf_rx_get): every answer, a CRC of every signal, and the summary figures."""
+    import mitel
+
+    def burst(f1, l1, f2, l2, on_ms, off_ms):
+        return ref.ToneGen(f1, l1, f2, l2, on_ms, off_ms, 0, 0, False).tx(1000)
+
+    class Noise:
+        def __init__(self, seed, level):
+            self.cache = ref.awgn(seed, level, 1000*1000)
+            self.pos = 0
+
+        def gen(self, n):
+            out = self.cache[self.pos:self.pos + n]
+            self.pos += n
+            return out
+    run = mitel.Run(burst, Noise, ref.DtmfRx(0))
+    res = run.run()
+    save("mitel_side1", answers=np.frombuffer("|".join(run.log).encode("latin1"), np.uint8), calls=run.calls,
+         signal_crc=np.uint32(run.crc), decode_ok=int(res["decode_ok"]), bandwidth=res["bandwidth"], twist=res["twist"],
+         dynamic_range=res["dynamic_range"], guard_time_ms=res["guard_time_ms"], guard_responses=res["guard_responses"],
+         snr_levels=res["snr_levels"], acceptable_snr_db=res["acceptable_snr_db"])
+
+
 def main():
     assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
     L = ref.lib()
+    mitel_side1()
     save("goertzel_fac", freq=np.array(ALL_FREQS, np.float32),
          fac_bits=np.array([bits([L.glue_goertzel_fac(f, 102)])[0] for f in ALL_FREQS], np.uint32))
 

@@ -1,0 +1,105 @@
+"""BASELINE configs[0]: dtmf_rx() on the Mitel CM7291 side-1 test sequence, exactly as the reference's own test program
+drives it (tests/dtmf_rx_tests.c:357-655, restated in tests/mitel.py).  The golden file holds what the REAL reference
+answered to every one of the 4173 dtmf_rx() calls (tests/golden/make_golden.py: mitel_side1, from oracle/_ref) and the
+CRC of every signal it was given.  Here the signals are regenerated with the restated tone generator and noise source
+(the CRC proves they are the reference's), and
+
+  * on the CPU the restated oracle must give the reference's answers (one more pin of oracle/tone_oracle.c), and
+  * on the GPU the dtmf_rx() / dtmf_rx_get() shim over the HIP engine (a private one-channel object, the plumbing
+    configuration) must give them too, call for call,
+
+plus the summary figures BASELINE.md section 2 records for the reference: twist 8.0 / 8.5 / 8.3 / 8.6 dB (reverse
+4.0 / 4.4 / 4.5 / 4.6), dynamic range 39 dB, guard time 27 ms, acceptable S/N 9 dB."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import mitel
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mitel_side1.npz")
+
+
+def _burst(f1, l1, f2, l2, on_ms, off_ms):
+    from oracle import restated as orc
+    return orc.ToneGen(orc.tone_desc(f1, l1, f2, l2, on_ms, off_ms, 0, 0, False)).tx(1000)
+
+
+def _noise(seed, level):
+    from oracle import restated as orc
+    return orc.Awgn(seed, level)
+
+
+def _check(run, res):
+    g = np.load(GOLDEN)
+    assert run.calls == int(g["calls"])
+    assert np.uint32(run.crc) == g["signal_crc"], "the regenerated test signals differ from the reference's"
+    assert "|".join(run.log) == bytes(g["answers"]).decode("latin1")
+    assert res["decode_ok"] and int(g["decode_ok"]) == 1
+    assert np.array_equal(res["bandwidth"], g["bandwidth"])
+    assert np.array_equal(res["twist"], g["twist"])
+    assert res["dynamic_range"] == int(g["dynamic_range"])
+    assert res["guard_time_ms"] == int(g["guard_time_ms"]) and res["guard_responses"] == int(g["guard_responses"])
+    assert np.array_equal(res["snr_levels"], g["snr_levels"])
+    assert res["acceptable_snr_db"] == int(g["acceptable_snr_db"])
+    # the known answers of BASELINE.md section 2 (the reference's own program, run unmodified in the survey container)
+    assert [t[0] for t in res["twist"].tolist()] == [80, 85, 83, 86]
+    assert [t[1] for t in res["twist"].tolist()] == [40, 44, 45, 46]
+    assert res["dynamic_range"] == 39
+    assert res["guard_time_ms"] == 27
+    assert res["acceptable_snr_db"] == 9
+    # and the pass limits the reference's program applies (dtmf_rx_tests.c:463,529,546,579,650)
+    for nplus, nminus in res["bandwidth"].tolist():
+        rrb = (nplus + nminus)/10.0
+        rcfo = (nplus - nminus)/10.0
+        assert 3.0 + rcfo <= rrb < 15.0 + rcfo
+
+
+def test_mitel_side1_oracle(built):
+    from oracle import restated as orc
+    from test_oracle_pin import use_golden_modem_tables
+    use_golden_modem_tables()               # the restated tone generator's sine table
+    run = mitel.Run(_burst, _noise, orc.Dtmf(0))
+    _check(run, run.run())
+
+
+class _ShimRx:
+    def __init__(self, lib):
+        self.L = lib
+        self.s = lib.dtmf_rx_init(None, None, None)
+        assert self.s
+
+    def rx(self, amp):
+        assert self.L.dtmf_rx(self.s, amp.ctypes.data, len(amp)) == 0
+
+    def get(self):
+        buf = C.create_string_buffer(129)
+        n = self.L.dtmf_rx_get(self.s, buf, 128)
+        assert n == len(buf.value)
+        return buf.value.decode("latin1")
+
+    def close(self):
+        self.L.dtmf_rx_free(self.s)
+
+
+@pytest.mark.gpu
+def test_mitel_side1_dtmf_rx_shim(built):
+    from spandsp_amd import engine
+    lib = C.CDLL(engine.LIB_PATH)
+    vp, ci = C.c_void_p, C.c_int
+    lib.dtmf_rx_init.restype = vp
+    lib.dtmf_rx_init.argtypes = [vp, vp, vp]
+    lib.dtmf_rx.restype = ci
+    lib.dtmf_rx.argtypes = [vp, vp, ci]
+    lib.dtmf_rx_get.restype = C.c_size_t
+    lib.dtmf_rx_get.argtypes = [vp, C.c_char_p, ci]
+    lib.dtmf_rx_free.restype = ci
+    lib.dtmf_rx_free.argtypes = [vp]
+    from test_oracle_pin import use_golden_modem_tables
+    use_golden_modem_tables()
+    rx = _ShimRx(lib)
+    run = mitel.Run(_burst, _noise, rx)
+    res = run.run()
+    rx.close()
+    _check(run, res)
