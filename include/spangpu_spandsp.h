@@ -34,8 +34,11 @@
  *   v17_rx_* (same set)                    src/spandsp/v17rx.h:236-333    src/v17rx.c:165-212,1212-1541
  * Callback types: digits_rx_callback_t (dtmf.h:76), span_tone_report_func_t and
  * tone_segment_func_t (super_tone_rx.h:56-58), span_put_bit_func_t and span_modem_status_func_t
- * (async.h:123,131).  Not provided: xxx_rx_set_qam_report_handler (the per-symbol constellation
- * tap stays on the device) and xxx_rx_get_logging_state.
+ * (async.h:123,131), qam_report_handler_t (v29rx.h:130).  xxx_rx_get_logging_state() hands out a
+ * logging_state_t with the layout spandsp's span_log_*() functions work on (private/logging.h:32-42).
+ *   filter_create/_delete/_step, cfilter_create/_delete/_step
+ *                                          src/spandsp/complex_filters.h:62-68   src/complex_filters.c:39-118
+ *   echo_can_snapshot                      src/spandsp/echo.h:185          src/echo.c:376-379
  */
 #if !defined(SPANGPU_SPANDSP_H)
 #define SPANGPU_SPANDSP_H
@@ -49,6 +52,21 @@
 #if defined(__cplusplus)
 extern "C" {
 #endif
+
+/* The logging descriptor the reference's receivers carry (src/spandsp/private/logging.h:32-42): same fields in the same
+   order, so that a caller that links spandsp's logging.c can hand the pointer xxx_rx_get_logging_state() returns to
+   span_log_set_level() / span_log_set_tag() as it does today.  The engine itself never writes log text. */
+typedef void (*message_handler_func_t)(void *user_data, int level, const char *text);
+typedef struct logging_state_s
+{
+    int level;
+    int samples_per_second;
+    int64_t elapsed_samples;
+    const char *tag;
+    const char *protocol;
+    message_handler_func_t span_message;
+    void *user_data;
+} logging_state_t;
 
 typedef void (*digits_rx_callback_t)(void *user_data, const char *digits, int len);
 typedef void (*span_tone_report_func_t)(void *user_data, int code, int level, int delay);
@@ -117,6 +135,7 @@ SPANGPU_API int v29_rx_equalizer_state(v29_rx_state_t *s, complexf_t **coeffs);
 SPANGPU_API float v29_rx_carrier_frequency(v29_rx_state_t *s);
 SPANGPU_API float v29_rx_symbol_timing_correction(v29_rx_state_t *s);
 SPANGPU_API float v29_rx_signal_power(v29_rx_state_t *s);
+SPANGPU_API logging_state_t *v29_rx_get_logging_state(v29_rx_state_t *s);          /* src/spandsp/v29rx.h:177 */
 SPANGPU_API void v29_rx_set_signal_cutoff(v29_rx_state_t *s, float cutoff);
 
 SPANGPU_API v27ter_rx_state_t *v27ter_rx_init(v27ter_rx_state_t *s, int bit_rate, span_put_bit_func_t put_bit, void *user_data);
@@ -132,6 +151,7 @@ SPANGPU_API int v27ter_rx_equalizer_state(v27ter_rx_state_t *s, complexf_t **coe
 SPANGPU_API float v27ter_rx_carrier_frequency(v27ter_rx_state_t *s);
 SPANGPU_API float v27ter_rx_symbol_timing_correction(v27ter_rx_state_t *s);
 SPANGPU_API float v27ter_rx_signal_power(v27ter_rx_state_t *s);
+SPANGPU_API logging_state_t *v27ter_rx_get_logging_state(v27ter_rx_state_t *s);
 SPANGPU_API void v27ter_rx_set_signal_cutoff(v27ter_rx_state_t *s, float cutoff);
 
 SPANGPU_API v17_rx_state_t *v17_rx_init(v17_rx_state_t *s, int bit_rate, span_put_bit_func_t put_bit, void *user_data);
@@ -147,6 +167,7 @@ SPANGPU_API int v17_rx_equalizer_state(v17_rx_state_t *s, complexf_t **coeffs);
 SPANGPU_API float v17_rx_carrier_frequency(v17_rx_state_t *s);
 SPANGPU_API float v17_rx_symbol_timing_correction(v17_rx_state_t *s);
 SPANGPU_API float v17_rx_signal_power(v17_rx_state_t *s);
+SPANGPU_API logging_state_t *v17_rx_get_logging_state(v17_rx_state_t *s);
 SPANGPU_API void v17_rx_set_signal_cutoff(v17_rx_state_t *s, float cutoff);
 
 SPANGPU_API int v29_rx_restart(v29_rx_state_t *s, int bit_rate, bool old_train);
@@ -175,6 +196,10 @@ SPANGPU_API echo_can_state_t *echo_can_init(int len, int adaption_mode);
 SPANGPU_API int echo_can_release(echo_can_state_t *ec);
 SPANGPU_API int echo_can_free(echo_can_state_t *ec);
 SPANGPU_API void echo_can_flush(echo_can_state_t *ec);
+/* echo_can_snapshot(): keep a copy of tap set 0 as it is now (src/echo.c:376-379; the reference keeps it in a private
+   field).  spangpu_echo_can_snapshot_taps() hands the copy out: taps int16 values, returns the count. */
+SPANGPU_API void echo_can_snapshot(echo_can_state_t *ec);
+SPANGPU_API int spangpu_echo_can_snapshot_taps(echo_can_state_t *ec, int16_t *out, int max);
 SPANGPU_API void echo_can_adaption_mode(echo_can_state_t *ec, int adaption_mode);
 SPANGPU_API int16_t echo_can_update(echo_can_state_t *ec, int16_t tx, int16_t rx);
 SPANGPU_API int16_t echo_can_hpf_tx(echo_can_state_t *ec, int16_t tx);
@@ -218,6 +243,7 @@ SPANGPU_API int dtmf_rx(dtmf_rx_state_t *s, const int16_t amp[], int samples);
 SPANGPU_API int dtmf_rx_fillin(dtmf_rx_state_t *s, int samples);
 SPANGPU_API int dtmf_rx_status(dtmf_rx_state_t *s);
 SPANGPU_API size_t dtmf_rx_get(dtmf_rx_state_t *s, char *digits, int max);
+SPANGPU_API logging_state_t *dtmf_rx_get_logging_state(dtmf_rx_state_t *s);        /* src/spandsp/dtmf.h:206 */
 
 /* ---- Bell MF / R2 MF (src/spandsp/bell_r2_mf.h) ------------------------------------------ */
 SPANGPU_API bell_mf_rx_state_t *bell_mf_rx_init(bell_mf_rx_state_t *s, digits_rx_callback_t callback, void *user_data);
@@ -251,6 +277,35 @@ SPANGPU_API void make_goertzel_descriptor(goertzel_descriptor_t *t, float freq, 
 SPANGPU_API goertzel_state_t *goertzel_init(goertzel_state_t *s, goertzel_descriptor_t *t);
 SPANGPU_API int goertzel_release(goertzel_state_t *s);
 SPANGPU_API int goertzel_free(goertzel_state_t *s);
+
+/* ---- complex_filters.h: a filter instance around a caller-supplied step function (src/complex_filters.c:39-118).  The
+   arithmetic of a filter is its fspec_t's fsf callback; these entry points only own the state it works on.  Host side only. */
+typedef struct filter_s filter_t;
+typedef float (*filter_step_func_t)(filter_t *fi, float x);
+typedef struct
+{
+    int nz;
+    int np;
+    filter_step_func_t fsf;
+} fspec_t;
+struct filter_s
+{
+    fspec_t *fs;
+    float sum;
+    int ptr;                    /* only for moving average filters */
+    float v[];
+};
+typedef struct
+{
+    filter_t *ref;
+    filter_t *imf;
+} cfilter_t;
+SPANGPU_API filter_t *filter_create(fspec_t *fs);
+SPANGPU_API void filter_delete(filter_t *fi);
+SPANGPU_API float filter_step(filter_t *fi, float x);
+SPANGPU_API cfilter_t *cfilter_create(fspec_t *fs);
+SPANGPU_API void cfilter_delete(cfilter_t *cfi);
+SPANGPU_API complexf_t cfilter_step(cfilter_t *cfi, const complexf_t *z);
 SPANGPU_API void goertzel_reset(goertzel_state_t *s);
 SPANGPU_API int goertzel_update(goertzel_state_t *s, const int16_t amp[], int samples);
 SPANGPU_API float goertzel_result(goertzel_state_t *s);

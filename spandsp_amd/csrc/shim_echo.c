@@ -14,6 +14,7 @@ struct echo_can_state_s
 {
     spangpu_echo_t *bank;
     int taps;
+    int16_t *snapshot;          /* tap set 0 as echo_can_snapshot() last saw it */
 };
 
 echo_can_state_t *echo_can_init(int len, int adaption_mode)
@@ -23,8 +24,11 @@ echo_can_state_t *echo_can_init(int len, int adaption_mode)
     if ((ec = (echo_can_state_t *) calloc(1, sizeof(*ec))) == NULL)
         return NULL;
     ec->taps = len;
-    if (spangpu_echo_create(&ec->bank, 0, 1, len, adaption_mode) != SPANGPU_OK)
+    if ((ec->snapshot = (int16_t *) calloc((size_t) (len > 0  ?  len  :  1), sizeof(int16_t))) == NULL
+        ||
+        spangpu_echo_create(&ec->bank, 0, 1, len, adaption_mode) != SPANGPU_OK)
     {
+        free(ec->snapshot);
         free(ec);
         return NULL;
     }
@@ -42,6 +46,7 @@ int echo_can_free(echo_can_state_t *ec)
     if (ec)
     {
         spangpu_echo_destroy(ec->bank);
+        free(ec->snapshot);
         free(ec);
     }
     return 0;
@@ -55,6 +60,30 @@ void echo_can_flush(echo_can_state_t *ec)
 void echo_can_adaption_mode(echo_can_state_t *ec, int adaption_mode)
 {
     spangpu_echo_adaption_mode(ec->bank, 0, adaption_mode);
+}
+
+/* src/echo.c:376-379: the working tap set (set 0) is copied aside.  The copy lives on the host: the four 16 bit sets of
+   the one channel come back in one transfer and the first is kept. */
+void echo_can_snapshot(echo_can_state_t *ec)
+{
+    int16_t *sets;
+
+    if ((sets = (int16_t *) malloc((size_t) 4*ec->taps*sizeof(int16_t))) == NULL)
+        return;
+    if (spangpu_echo_get_state(ec->bank, 0, NULL, NULL, sets, NULL) == SPANGPU_OK)
+        memcpy(ec->snapshot, sets, (size_t) ec->taps*sizeof(int16_t));
+    free(sets);
+}
+
+int spangpu_echo_can_snapshot_taps(echo_can_state_t *ec, int16_t *out, int max)
+{
+    int n;
+
+    if (ec == NULL  ||  out == NULL  ||  max < 0)
+        return -1;
+    n = (max < ec->taps)  ?  max  :  ec->taps;
+    memcpy(out, ec->snapshot, (size_t) n*sizeof(int16_t));
+    return n;
 }
 
 int16_t echo_can_update(echo_can_state_t *ec, int16_t tx, int16_t rx)

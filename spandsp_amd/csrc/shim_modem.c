@@ -44,6 +44,7 @@ typedef struct
     void *status_user_data;
     qam_report_handler_t qam_report;
     void *qam_user_data;
+    logging_state_t logging;
     uint32_t words[MAX_WORDS];              /* scratch for state reads (equalizer_state() hands out a view) */
     int n_floats;
 } modem_obj_t;
@@ -167,6 +168,8 @@ int spangpu_modem_group_flush(spangpu_modem_group_t *g)
         return SPANGPU_ERR_BAD_ARG;
     if (g->n_staged == 0)
         return 0;
+    if (g->n_staged != g->n_attached)
+        return SPANGPU_ERR_STATE;           /* a receiver that has not been given its frame must not advance */
     if ((rc = spangpu_modem_rx(g->bank, g->stage, SPANGPU_MEM_HOST, g->tick_samples, g->max_samples)) < 0)
         return rc;
     if ((cap = spangpu_modem_events(g->bank, &events, &counts)) < 0)
@@ -176,8 +179,6 @@ int spangpu_modem_group_flush(spangpu_modem_group_t *g)
     rc = g->n_staged;
     for (c = 0;  c < g->n_ch;  c++)
     {
-        /* a channel that staged nothing this tick was fed its previous (stale) frame; groups are meant to be
-           driven with every attached channel each tick, as the header says -- its events are still delivered */
         if (g->handles[c])
         {
             deliver((modem_obj_t *) g->handles[c], events + (size_t) c*cap, (counts[c] < cap)  ?  counts[c]  :  cap,
@@ -203,6 +204,10 @@ static modem_obj_t *obj_new(size_t size, int kind, spangpu_modem_group_t *g, int
     o->bit_rate = bit_rate;
     o->put_bit = put_bit;
     o->put_bit_user_data = user_data;
+    /* what span_log_init(.., SPAN_LOG_NONE, NULL) + span_log_set_protocol() leave behind (v29rx.c:1120-1121 and twins) */
+    memset(&o->logging, 0, sizeof(o->logging));
+    o->logging.samples_per_second = 8000;
+    o->logging.protocol = (kind == SPANGPU_V29)  ?  "V.29 RX"  :  (kind == SPANGPU_V27TER)  ?  "V.27ter RX"  :  "V.17 RX";
     spangpu_modem_state_words(kind, &o->n_floats, NULL);
     g->handles[channel] = o;
     g->n_attached++;
@@ -276,20 +281,22 @@ static int obj_rx(modem_obj_t *o, const int16_t amp[], int len)
         }
         return 0;
     }
+    /* A shared bank advances in ticks of one frame per attached receiver.  Nothing is ever dropped silently: a frame
+       longer than the group was made for, of another length than the tick's, or a second frame for a channel before the
+       tick has run is refused with -1 (the tone groups do the same). */
     if (len > g->max_samples)
-        len = g->max_samples;
+        return -1;
+    if (g->staged[o->channel])
+        return -1;
     if (g->n_staged == 0)
         g->tick_samples = len;
     else if (len != g->tick_samples)
-        return 0;                           /* a group tick carries one frame length; a stray length is dropped */
+        return -1;
     memcpy(g->stage + (size_t) o->channel*g->max_samples, amp, len*sizeof(int16_t));
-    if (!g->staged[o->channel])
-    {
-        g->staged[o->channel] = 1;
-        g->n_staged++;
-    }
-    if (g->n_staged >= g->n_attached)
-        spangpu_modem_group_flush(g);
+    g->staged[o->channel] = 1;
+    g->n_staged++;
+    if (g->n_staged == g->n_attached)
+        return (spangpu_modem_group_flush(g) < 0)  ?  -1  :  0;
     return 0;
 }
 
@@ -301,10 +308,20 @@ static int obj_free(modem_obj_t *o)
         obj_set_qam(o, NULL, NULL);
     if (o->grp)
     {
-        o->grp->handles[o->channel] = NULL;
-        o->grp->n_attached--;
+        spangpu_modem_group_t *g = o->grp;
+
+        g->handles[o->channel] = NULL;
+        g->n_attached--;
+        if (g->staged[o->channel])
+        {
+            /* its frame of the tick in progress goes with it */
+            g->staged[o->channel] = 0;
+            g->n_staged--;
+        }
         if (o->private_grp)
-            spangpu_modem_group_destroy(o->grp);
+            spangpu_modem_group_destroy(g);
+        else if (g->n_staged > 0  &&  g->n_staged == g->n_attached)
+            spangpu_modem_group_flush(g);   /* it was the one the others were waiting for */
     }
     free(o);
     return 0;
@@ -442,6 +459,10 @@ float pfx##_signal_power(T *s)                                                  
 void pfx##_set_signal_cutoff(T *s, float cutoff)                                                                     \
 {                                                                                                                    \
     spangpu_modem_set_signal_cutoff(s->o.grp->bank, s->o.channel, cutoff);                                           \
+}                                                                                                                    \
+logging_state_t *pfx##_get_logging_state(T *s)                                                                       \
+{                                                                                                                    \
+    return &s->o.logging;                                                                                            \
 }
 
 DEFINE_MODEM(v29_rx, v29_rx_state_t, SPANGPU_V29, V29_F_EQ_COEFF, 33, V29_I_PHASE_RATE, V29_I_POWER, 3.98f)

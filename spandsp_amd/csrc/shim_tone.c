@@ -55,6 +55,7 @@ struct dtmf_rx_state_s
     /* bank parameters of a private object (applied when its bank is (re)built) */
     spangpu_tone_params_t params;
     int dirty;
+    logging_state_t logging;
 };
 
 struct bell_mf_rx_state_s
@@ -398,6 +399,15 @@ static int dtmf_private_rebuild(dtmf_rx_state_t *s, int max_samples)
     return 0;
 }
 
+/* What span_log_init(&s->logging, SPAN_LOG_NONE, NULL) + span_log_set_protocol() leave behind (dtmf.c:468-469,
+   logging.c:264-281): logging off, 8 kHz time base, no tag.  The message handler stays NULL: the engine writes no text. */
+static void st_logging_init(logging_state_t *lg, const char *protocol)
+{
+    memset(lg, 0, sizeof(*lg));
+    lg->samples_per_second = 8000;
+    lg->protocol = protocol;
+}
+
 dtmf_rx_state_t *dtmf_rx_init(dtmf_rx_state_t *s, digits_rx_callback_t callback, void *user_data)
 {
     int fresh = (s == NULL);
@@ -430,6 +440,7 @@ dtmf_rx_state_t *dtmf_rx_init(dtmf_rx_state_t *s, digits_rx_callback_t callback,
     s->digits_callback = callback;
     s->digits_callback_data = user_data;
     s->dirty = 1;
+    st_logging_init(&s->logging, "DTMF");
     if (s->private_grp  &&  dtmf_private_rebuild(s, 160) < 0)
     {
         if (fresh)
@@ -456,7 +467,13 @@ dtmf_rx_state_t *spangpu_dtmf_rx_attach(spangpu_group_t *g, int channel, digits_
     s->channel = channel;
     s->digits_callback = callback;
     s->digits_callback_data = user_data;
+    st_logging_init(&s->logging, "DTMF");
     return s;
+}
+
+logging_state_t *dtmf_rx_get_logging_state(dtmf_rx_state_t *s)
+{
+    return &s->logging;
 }
 
 int dtmf_rx_release(dtmf_rx_state_t *s)

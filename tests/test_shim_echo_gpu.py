@@ -28,6 +28,9 @@ def L(built):
     lib.echo_can_hpf_tx.restype = i16
     lib.echo_can_hpf_tx.argtypes = [vp, i16]
     lib.spangpu_echo_can_update_block.argtypes = [vp, vp, vp, vp, vp, ci, ci]
+    lib.echo_can_snapshot.restype = None
+    lib.echo_can_snapshot.argtypes = [vp]
+    lib.spangpu_echo_can_snapshot_taps.argtypes = [vp, vp, ci]
     return lib
 
 
@@ -64,6 +67,34 @@ def test_sample_by_sample_sequence(L):
     assert not np.array_equal(tx_out, t2) and abs(int(tx_out[-200:].astype(np.int64).mean())) < 60     # DC removed from what goes to the line
     L.echo_can_free(ec)
     assert not L.echo_can_init(100, MODE)               # unsupported length: NULL, like an allocation failure
+
+
+def test_snapshot_keeps_the_working_tap_set(L):
+    """echo_can_snapshot() (src/echo.c:376-379): a copy of tap set 0 as it stands, unchanged by what follows."""
+    from oracle import restated as orc
+    tx, rx = make_channels(3, 160*20, 128, seed=12)
+    tx, rx = np.ascontiguousarray(tx[1]), np.ascontiguousarray(rx[1])
+    ec = L.echo_can_init(128, MODE)
+    o = orc.EchoCan(128, MODE)
+    got = np.zeros(128, np.int16)
+    assert L.spangpu_echo_can_snapshot_taps(ec, got.ctypes.data, 128) == 128 and not got.any()      # nothing taken yet
+    n = 160*12
+    clean = np.zeros(n, np.int16)
+    assert L.spangpu_echo_can_update_block(ec, tx.ctypes.data, rx.ctypes.data, clean.ctypes.data, None, n, 0) == 0
+    o.run(tx[:n], rx[:n], False)
+    L.echo_can_snapshot(ec)
+    want = o.snapshot()["taps16"][0]
+    assert want.any()
+    m = 160*8
+    clean2 = np.zeros(m, np.int16)
+    assert L.spangpu_echo_can_update_block(ec, tx[n:].ctypes.data, rx[n:].ctypes.data, clean2.ctypes.data, None, m, 0) == 0
+    o.run(tx[n:], rx[n:], False)
+    assert not np.array_equal(o.snapshot()["taps16"][0], want)          # the canceller went on adapting
+    assert L.spangpu_echo_can_snapshot_taps(ec, got.ctypes.data, 128) == 128
+    assert np.array_equal(got, want)
+    short = np.zeros(40, np.int16)
+    assert L.spangpu_echo_can_snapshot_taps(ec, short.ctypes.data, 40) == 40 and np.array_equal(short, want[:40])
+    L.echo_can_free(ec)
 
 
 def test_tx_out_equals_separate_hpf(built):

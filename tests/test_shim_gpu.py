@@ -39,6 +39,7 @@ def L(built):
         "dtmf_rx_fillin": (ci, [vp, ci]),
         "dtmf_rx_status": (ci, [vp]),
         "dtmf_rx_get": (C.c_size_t, [vp, C.c_char_p, ci]),
+        "dtmf_rx_get_logging_state": (vp, [vp]),
         "bell_mf_rx_init": (vp, [vp, DIGITS_CB, vp]),
         "bell_mf_rx_free": (ci, [vp]),
         "bell_mf_rx": (ci, [vp, vp, ci]),
@@ -152,6 +153,13 @@ def test_dtmf_private_parms_and_fillin(L):
         L.dtmf_rx_get(s, buf, 128)
         assert buf.value.decode() == o.get()
         L.dtmf_rx_free(s)
+
+
+def test_dtmf_logging_descriptor(L):
+    from test_shim_modem_gpu import LoggingState, check_logging_state
+    s = L.dtmf_rx_init(None, DIGITS_CB(0), None)
+    check_logging_state(C.cast(L.dtmf_rx_get_logging_state(s), C.POINTER(LoggingState)), b"DTMF")
+    L.dtmf_rx_free(s)
 
 
 def test_dtmf_group_of_channels(L):

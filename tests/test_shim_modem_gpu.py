@@ -15,6 +15,31 @@ PUT_BIT = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
 STATUS = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
 
 
+class LoggingState(C.Structure):
+    """src/spandsp/private/logging.h:32-42"""
+    _fields_ = [("level", C.c_int), ("samples_per_second", C.c_int), ("elapsed_samples", C.c_int64), ("tag", C.c_char_p),
+                ("protocol", C.c_char_p), ("span_message", C.c_void_p), ("user_data", C.c_void_p)]
+
+
+def check_logging_state(lg, protocol):
+    """The descriptor a receiver hands out starts as span_log_init(.., SPAN_LOG_NONE, NULL) + set_protocol leaves it, and
+    the reference's own logging functions (when oracle/_ref is built) can work on it: the layout is theirs."""
+    assert lg
+    c = lg.contents
+    assert (c.level, c.samples_per_second, c.elapsed_samples, c.tag, c.protocol) == (0, 8000, 0, None, protocol)
+    from oracle import ref
+    if ref.available():
+        R = C.CDLL(ref.REF_SO)
+        R.span_log_set_level.argtypes = [C.c_void_p, C.c_int]
+        R.span_log_set_tag.argtypes = [C.c_void_p, C.c_char_p]
+        R.span_log_test.argtypes = [C.c_void_p, C.c_int]
+        R.span_log_test.restype = C.c_bool
+        R.span_log_set_level(lg, 5 | 0x100)
+        R.span_log_set_tag(lg, b"trunk 7")
+        assert lg.contents.level == 5 | 0x100 and lg.contents.tag == b"trunk 7" and lg.contents.protocol == protocol
+        assert R.span_log_test(lg, 4) and not R.span_log_test(lg, 6)
+
+
 @pytest.fixture(scope="module")
 def L(built):
     from spandsp_amd import engine
@@ -35,6 +60,7 @@ def L(built):
             pfx + "_symbol_timing_correction": (cf, [vp]),
             pfx + "_signal_power": (cf, [vp]),
             pfx + "_set_signal_cutoff": (None, [vp, cf]),
+            pfx + "_get_logging_state": (C.POINTER(LoggingState), [vp]),
         }
         for name, (res, args) in sig.items():
             getattr(lib, name).restype = res
@@ -148,6 +174,15 @@ def test_v29_old_train_restart_and_fillin(L):
     o.rx(y[3160:])
     assert np.array_equal(np.array(t.ev, np.int32), o.sink.events()["a"].astype(np.int32))
     L.v29_rx_free(s)
+
+
+def test_logging_descriptors(L):
+    for pfx, rate, proto in (("v29_rx", 9600, b"V.29 RX"), ("v27ter_rx", 4800, b"V.27ter RX"), ("v17_rx", 14400, b"V.17 RX")):
+        tap = Tap()
+        s = getattr(L, pfx + "_init")(None, rate, tap.put_bit, None)
+        assert s
+        check_logging_state(getattr(L, pfx + "_get_logging_state")(s), proto)
+        getattr(L, pfx + "_free")(s)
 
 
 def test_group_of_receivers(L):
