@@ -93,7 +93,14 @@ typedef struct
                                    make_goertzel_descriptor() computes it (tone_detect.c:60-68);
                                    spangpu_goertzel_fac() below reproduces it on the host             */
     int32_t trace;              /* 1 = also write per-block Goertzel energies (parity / diagnostics)   */
+    int32_t set_mask;           /* DTMF: SPANGPU_TP_* -- which of twist_db / reverse_twist_db / threshold_dbm0 are
+                                   meant as given, 0 dB and 0 dBm0 included, under dtmf_rx_parms()'s own tests
+                                   (twists >= 0, threshold > -99).  0 = the rules in the field comments above.   */
 } spangpu_tone_params_t;
+
+#define SPANGPU_TP_TWIST            0x01
+#define SPANGPU_TP_REVERSE_TWIST    0x02
+#define SPANGPU_TP_THRESHOLD        0x04
 
 /* One completed detection block of one channel, decoded from the device records. */
 typedef struct
@@ -151,6 +158,15 @@ SPANGPU_API int spangpu_bank_rx(spangpu_bank_t *bank, const int16_t *amp, int me
 #define SPANGPU_G711_ALAW           1
 #define SPANGPU_G711_ULAW           2
 SPANGPU_API int spangpu_bank_rx_g711(spangpu_bank_t *bank, const uint8_t *codes, int mem, int law, int samples, long long stride);
+/* A tick in which not every channel has a frame (or frames differ in length): channel c takes part with lens[c]
+   samples of row c of amp[n_channels][stride]; 0 = the channel sits the call out, its detector exactly as it was (what
+   the reference does for a channel whose xxx_rx() is not called).  lens[] is host memory; amp as `mem` says. */
+SPANGPU_API int spangpu_bank_rx_var(spangpu_bank_t *bank, const int16_t *amp, int mem, const int32_t *lens, int max_samples,
+                                    long long stride);
+/* dtmf_rx_parms() (src/dtmf.c:421-445) for ONE channel of a DTMF bank: filter_dialtone (< 0 = leave), twist_db,
+   reverse_twist_db, threshold_dbm0 under set_mask; the other fields of params are ignored. */
+SPANGPU_API int spangpu_bank_set_channel_params(spangpu_bank_t *bank, int channel, const spangpu_tone_params_t *params,
+                                                size_t params_size);
 
 /* Advance several banks (<= 4, same device and stream, device-resident channel-major frames) with ONE kernel launch:
    a tick of a mixed population of small banks then pays the launch and ramp-up cost once.  DTMF (no dial-tone
@@ -278,6 +294,10 @@ SPANGPU_API int spangpu_modem_channels(const spangpu_modem_t *modem);
 SPANGPU_API int spangpu_modem_set_stream(spangpu_modem_t *modem, void *hip_stream);
 SPANGPU_API int spangpu_modem_sync(spangpu_modem_t *modem);
 SPANGPU_API int spangpu_modem_rx(spangpu_modem_t *modem, const int16_t *amp, int mem, int samples, long long stride);
+/* A tick in which not every receiver has a frame (or frames differ in length): channel c takes lens[c] samples of row c;
+   0 = it sits the call out, untouched.  lens[] is host memory. */
+SPANGPU_API int spangpu_modem_rx_var(spangpu_modem_t *modem, const int16_t *amp, int mem, const int32_t *lens, int max_samples,
+                                     long long stride);
 SPANGPU_API int spangpu_modem_events(spangpu_modem_t *modem, const int8_t **events, const int32_t **counts);
 /* xxx_rx_set_qam_report_handler() (src/v29rx.c:1149, v27ter_rx.c:1204, v17rx.c:1535): with the tap on, every channel's
    qam_report(user, constel, target, symbol) calls (v29rx.c:769-783, v27ter_rx.c:517,765-777, v17rx.c:1117-1131) of an rx
@@ -501,12 +521,11 @@ SPANGPU_API int spangpu_modemtx_table(int which, float *out, int max);
  * [channel][stride] int16 buffer.
  *   spangpu_awgn_create() / _reinit()   awgn_init_dbm0(NULL, idum, level)      src/awgn.c:127-152 (ran_init :82-105)
  *   spangpu_awgn_tx()                   awgn(s) x samples x N                  src/awgn.c:168-195
- * Exactness: the uniform generator, the accept / reject sequence and all arithmetic but one call are IEEE
- * binary64 operations identical to the reference's; the one call is libm's log(), which the reference takes from
- * the host's C library (glibc picks an FMA or non-FMA variant per CPU) and this library takes from the device
- * maths library.  Both are within 1 ulp, which cannot move a scaled sample by more than 2^-34, so the int16
- * output differs from the reference's only for a sample that lies within that distance of a rounding tie.  The
- * kernel counts every sample within 2^-30 of a tie: spangpu_awgn_uncertain() == 0 proves the output identical.
+ * Exactness: every int16 and the carried half pair equal the reference's.  The generator, the accept / reject sequence
+ * and the arithmetic are IEEE binary64 operations rounded as the reference's compiled code rounds them; the one library
+ * call of the path, log(), is GNU libc's table-driven routine (not correctly rounded: its bits are part of the
+ * reference's output) restated on the device operation by operation, as the x86-64 FMA build of glibc computes it
+ * (csrc/glibc_log_dev.hpp).
  */
 typedef struct spangpu_awgn_s spangpu_awgn_t;
 
@@ -519,8 +538,6 @@ SPANGPU_API int spangpu_awgn_sync(spangpu_awgn_t *bank);
 SPANGPU_API int spangpu_awgn_reinit(spangpu_awgn_t *bank, int channel, int seed, float level_dbm0);
 /* mix = 0: pcm[channel*stride + i] = awgn();  mix = 1: pcm[...] = saturate16(pcm[...] + awgn());  returns samples */
 SPANGPU_API int spangpu_awgn_tx(spangpu_awgn_t *bank, int mem, int16_t *pcm, long long stride, int samples, int mix);
-/* samples, since creation, that fell within 2^-30 of a rounding tie (see above); synchronises the bank's stream */
-SPANGPU_API int spangpu_awgn_uncertain(spangpu_awgn_t *bank, long long *count);
 SPANGPU_API int spangpu_awgn_state_words(const spangpu_awgn_t *bank);
 SPANGPU_API int spangpu_awgn_get_state(spangpu_awgn_t *bank, int channel, int32_t *words);
 

@@ -8,7 +8,9 @@
  *   awgn (polar Box-Muller, one pair per two calls)                                    src/awgn.c:168-195
  *   fsaturate                                                                          src/spandsp/saturated.h:152-159
  *
- * Uses libm's pow(), log() and sqrt(), as the reference does.
+ * pow() (once, at init) and sqrt() (correctly rounded everywhere) are libm's, as in the reference; log() is the
+ * restatement of GNU libc's routine in glibc_log.c, so that the result does not depend on which build of log() the
+ * host's C library selects.
  */
 #include <math.h>
 #include <string.h>
@@ -88,7 +90,7 @@ ORC_API int16_t orc_awgn(orc_awgn_t *s)
             r = v1*v1 + v2*v2;
         }
         while (r >= 1.0);
-        r = sqrt(-2.0*log(r)/r);
+        r = sqrt(-2.0*orc_glibc_log(r)/r);
         s->amp2 = v1*r;
         amp = v2*r;
     }

@@ -680,6 +680,9 @@ typedef struct
 } orc_awgn_t;
 
 ORC_API int orc_awgn_sizeof(void);
+/* GNU libc's binary64 log() as the x86-64 FMA build computes it (glibc_log.c) -- what awgn() calls */
+ORC_API double orc_glibc_log(double x);
+ORC_API void orc_glibc_log_block(const double x[], double y[], int n);
 ORC_API void orc_awgn_init_dbm0(orc_awgn_t *s, int idum, float level);
 ORC_API int16_t orc_awgn(orc_awgn_t *s);
 ORC_API void orc_awgn_block(orc_awgn_t *s, int16_t out[], int n);

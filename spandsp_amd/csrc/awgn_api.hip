@@ -35,7 +35,6 @@ struct spangpu_awgn_s
     hipStream_t stream;
     bool own_stream;
     int32_t *st;
-    int32_t *uncertain;
     int16_t *d_amp;
     size_t amp_cap;
 };
@@ -97,8 +96,7 @@ int spangpu_awgn_create(spangpu_awgn_t **out, int device, int n_channels, const 
     const size_t words = (size_t) kAwgnWords*n_channels;
     int32_t *host = (int32_t *) malloc(words*sizeof(int32_t));
     if (host == NULL
-        ||  hipMalloc(&b->st, words*sizeof(int32_t)) != hipSuccess
-        ||  hipMalloc(&b->uncertain, sizeof(int32_t)) != hipSuccess)
+        ||  hipMalloc(&b->st, words*sizeof(int32_t)) != hipSuccess)
     {
         free(host);
         spangpu_awgn_destroy(b);
@@ -113,8 +111,6 @@ int spangpu_awgn_create(spangpu_awgn_t **out, int device, int n_channels, const 
     }
     hipError_t e = hipMemcpy(b->st, host, words*sizeof(int32_t), hipMemcpyHostToDevice);
     free(host);
-    if (e == hipSuccess)
-        e = hipMemset(b->uncertain, 0, sizeof(int32_t));
     if (e != hipSuccess)
     {
         spangpu_awgn_destroy(b);
@@ -132,7 +128,6 @@ void spangpu_awgn_destroy(spangpu_awgn_t *b)
     if (b->stream)
         (void) hipStreamSynchronize(b->stream);
     (void) hipFree(b->st);
-    (void) hipFree(b->uncertain);
     (void) hipFree(b->d_amp);
     if (b->own_stream  &&  b->stream)
         (void) hipStreamDestroy(b->stream);
@@ -191,7 +186,6 @@ int spangpu_awgn_tx(spangpu_awgn_t *b, int mem_kind, int16_t *amp, long long str
     AwgnLaunch L;
     memset(&L, 0, sizeof(L));
     L.st = b->st;
-    L.uncertain = b->uncertain;
     L.n_ch = b->n_ch;
     L.samples = samples;
     L.mix = mix  ?  1  :  0;
@@ -217,7 +211,7 @@ int spangpu_awgn_tx(spangpu_awgn_t *b, int mem_kind, int16_t *amp, long long str
         L.amp = amp;
     }
     L.stride = stride;
-    hipLaunchKernelGGL(awgn_bank_kernel, dim3((b->n_ch + 63)/64), dim3(64), 97*64*sizeof(double), b->stream, L);
+    hipLaunchKernelGGL(awgn_bank_kernel, dim3((b->n_ch + 63)/64), dim3(64), (97*64 + 2*kLogTab)*sizeof(double), b->stream, L);
     AWGN_TRY(hipGetLastError());
     if (mem_kind == SPANGPU_MEM_HOST)
     {
@@ -226,18 +220,6 @@ int spangpu_awgn_tx(spangpu_awgn_t *b, int mem_kind, int16_t *amp, long long str
         AWGN_TRY(hipStreamSynchronize(b->stream));
     }
     return samples;
-}
-
-int spangpu_awgn_uncertain(spangpu_awgn_t *b, long long *count)
-{
-    if (b == NULL  ||  count == NULL)
-        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
-    AWGN_TRY(hipSetDevice(b->device));
-    int32_t v = 0;
-    AWGN_TRY(hipMemcpyAsync(&v, b->uncertain, sizeof(v), hipMemcpyDeviceToHost, b->stream));
-    AWGN_TRY(hipStreamSynchronize(b->stream));
-    *count = v;
-    return SPANGPU_OK;
 }
 
 int spangpu_awgn_get_state(spangpu_awgn_t *b, int channel, int32_t *words)

@@ -33,6 +33,9 @@ extern "C" int spangpu_set_error(int code, const char *msg);
 
 struct spangpu_modem_s
 {
+    const int32_t *next_lens;   // per-channel lengths of the call being prepared (device), or nullptr
+    int32_t *d_lens;            // [n_ch], device
+    int32_t *h_lens;            // [n_ch], pinned
     int kind;
     int n_words;
     int n_floats;
@@ -349,6 +352,8 @@ int spangpu_modem_destroy(spangpu_modem_t *m)
     if (m->state) (void) hipFree(m->state);
     if (m->tab) (void) hipFree(m->tab);
     if (m->d_amp) (void) hipFree(m->d_amp);
+    if (m->d_lens) (void) hipFree(m->d_lens);
+    if (m->h_lens) (void) hipHostFree(m->h_lens);
     if (m->events) (void) hipFree(m->events);
     if (m->ev_count) (void) hipFree(m->ev_count);
     if (m->h_events) (void) hipHostFree(m->h_events);
@@ -468,6 +473,7 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         L.amp = d_amp;
         L.stride = d_stride;
         L.samples = samples;
+        L.lens = m->next_lens;
         L.n_ch = m->n_ch;
         L.state = m->state;
         L.events = m->events;
@@ -493,6 +499,7 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         L.amp = d_amp;
         L.stride = d_stride;
         L.samples = samples;
+        L.lens = m->next_lens;
         L.n_ch = m->n_ch;
         L.bit_rate = m->bit_rate;
         L.state = m->state;
@@ -519,6 +526,7 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         L.amp = d_amp;
         L.stride = d_stride;
         L.samples = samples;
+        L.lens = m->next_lens;
         L.n_ch = m->n_ch;
         L.bit_rate = m->bit_rate;
         L.state = m->state;
@@ -544,6 +552,44 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
     if (mem == SPANGPU_MEM_HOST)
         V29_TRY(hipStreamSynchronize(m->stream));
     return 0;
+}
+
+// spangpu_modem_rx() for a tick in which not every receiver has a frame, or frames differ in length: channel c takes
+// lens[c] samples of its row (0: it sits the call out, its state as it was, no events).  lens[] is host memory.
+int spangpu_modem_rx_var(spangpu_modem_t *m, const int16_t *amp, int mem, const int32_t *lens, int max_samples, long long stride)
+{
+    if (m == nullptr  ||  amp == nullptr  ||  lens == nullptr  ||  max_samples < 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    int longest = 0;
+    bool all = true;
+    for (int c = 0;  c < m->n_ch;  c++)
+    {
+        if (lens[c] < 0  ||  lens[c] > max_samples)
+            return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "a channel's length is outside 0..max_samples");
+        if (lens[c] > longest)
+            longest = lens[c];
+    }
+    if (longest == 0)
+        return 0;
+    for (int c = 0;  c < m->n_ch;  c++)
+        all &= (lens[c] == longest);
+    if (stride <= 0)
+        stride = max_samples;
+    if (all)
+        return spangpu_modem_rx(m, amp, mem, longest, stride);
+    V29_TRY(hipSetDevice(m->device));
+    if (m->d_lens == nullptr)
+    {
+        V29_TRY(hipMalloc(&m->d_lens, (size_t) m->n_ch*sizeof(int32_t)));
+        V29_TRY(hipHostMalloc(&m->h_lens, (size_t) m->n_ch*sizeof(int32_t)));
+    }
+    V29_TRY(hipStreamSynchronize(m->stream));
+    memcpy(m->h_lens, lens, (size_t) m->n_ch*sizeof(int32_t));
+    V29_TRY(hipMemcpyAsync(m->d_lens, m->h_lens, (size_t) m->n_ch*sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    m->next_lens = m->d_lens;
+    const int rc = spangpu_modem_rx(m, amp, mem, longest, stride);
+    m->next_lens = nullptr;
+    return rc;
 }
 
 // The tap behind xxx_rx_set_qam_report_handler(): from the next spangpu_modem_rx() on, every channel's

@@ -8,6 +8,7 @@
  * Without a GPU every init returns NULL: there is no CPU implementation.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -24,10 +25,10 @@ struct spangpu_modem_group_s
     int max_samples;
     int16_t *stage;
     void **handles;
-    uint8_t *staged;
+    int32_t *lens;              /* per channel: samples staged for the tick being collected (0 = none) */
     int n_attached;
     int n_staged;
-    int tick_samples;
+    pthread_mutex_t lock;       /* staging, attach / detach and the tick itself (recursive: callbacks may call back in) */
     int qam_tap;                /* some object of the group has a qam report handler: the bank records the reports */
 };
 
@@ -81,8 +82,16 @@ spangpu_modem_group_t *spangpu_modem_group_create(int device, int kind, int n_ch
     g->max_samples = max_samples;
     g->stage = (int16_t *) calloc((size_t) n_channels*max_samples, sizeof(int16_t));
     g->handles = (void **) calloc(n_channels, sizeof(void *));
-    g->staged = (uint8_t *) calloc(n_channels, 1);
-    if (g->stage == NULL  ||  g->handles == NULL  ||  g->staged == NULL
+    g->lens = (int32_t *) calloc(n_channels, sizeof(int32_t));
+    {
+        pthread_mutexattr_t at;
+
+        pthread_mutexattr_init(&at);
+        pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
+        pthread_mutex_init(&g->lock, &at);
+        pthread_mutexattr_destroy(&at);
+    }
+    if (g->stage == NULL  ||  g->handles == NULL  ||  g->lens == NULL
         ||  spangpu_modem_create(&g->bank, device, kind, n_channels, bit_rate) != SPANGPU_OK)
     {
         spangpu_modem_group_destroy(g);
@@ -99,7 +108,8 @@ int spangpu_modem_group_destroy(spangpu_modem_group_t *g)
         spangpu_modem_destroy(g->bank);
     free(g->stage);
     free(g->handles);
-    free(g->staged);
+    free(g->lens);
+    pthread_mutex_destroy(&g->lock);
     free(g);
     return 0;
 }
@@ -153,7 +163,9 @@ static void deliver(modem_obj_t *o, const int8_t *ev, int n, const uint32_t *qam
     }
 }
 
-int spangpu_modem_group_flush(spangpu_modem_group_t *g)
+/* Run the tick with the receivers that have staged a frame; the others sit it out, untouched (as the reference's are
+   when their xxx_rx() is not called), and may stage for the next one.  Returns how many took part. */
+static int group_flush_locked(spangpu_modem_group_t *g)
 {
     const int8_t *events;
     const int32_t *counts;
@@ -164,13 +176,9 @@ int spangpu_modem_group_flush(spangpu_modem_group_t *g)
     int c;
     int rc;
 
-    if (g == NULL)
-        return SPANGPU_ERR_BAD_ARG;
     if (g->n_staged == 0)
         return 0;
-    if (g->n_staged != g->n_attached)
-        return SPANGPU_ERR_STATE;           /* a receiver that has not been given its frame must not advance */
-    if ((rc = spangpu_modem_rx(g->bank, g->stage, SPANGPU_MEM_HOST, g->tick_samples, g->max_samples)) < 0)
+    if ((rc = spangpu_modem_rx_var(g->bank, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples)) < 0)
         return rc;
     if ((cap = spangpu_modem_events(g->bank, &events, &counts)) < 0)
         return cap;
@@ -179,14 +187,26 @@ int spangpu_modem_group_flush(spangpu_modem_group_t *g)
     rc = g->n_staged;
     for (c = 0;  c < g->n_ch;  c++)
     {
-        if (g->handles[c])
+        if (g->handles[c]  &&  g->lens[c] > 0)
         {
             deliver((modem_obj_t *) g->handles[c], events + (size_t) c*cap, (counts[c] < cap)  ?  counts[c]  :  cap,
                     qam  ?  qam + (size_t) c*qcap*7  :  NULL, qam  ?  ((qcounts[c] < qcap)  ?  qcounts[c]  :  qcap)  :  0);
         }
-        g->staged[c] = 0;
+        g->lens[c] = 0;
     }
     g->n_staged = 0;
+    return rc;
+}
+
+int spangpu_modem_group_flush(spangpu_modem_group_t *g)
+{
+    int rc;
+
+    if (g == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    pthread_mutex_lock(&g->lock);
+    rc = group_flush_locked(g);
+    pthread_mutex_unlock(&g->lock);
     return rc;
 }
 
@@ -209,8 +229,10 @@ static modem_obj_t *obj_new(size_t size, int kind, spangpu_modem_group_t *g, int
     o->logging.samples_per_second = 8000;
     o->logging.protocol = (kind == SPANGPU_V29)  ?  "V.29 RX"  :  (kind == SPANGPU_V27TER)  ?  "V.27ter RX"  :  "V.17 RX";
     spangpu_modem_state_words(kind, &o->n_floats, NULL);
+    pthread_mutex_lock(&g->lock);
     g->handles[channel] = o;
     g->n_attached++;
+    pthread_mutex_unlock(&g->lock);
     return o;
 }
 
@@ -263,6 +285,7 @@ static int obj_rx(modem_obj_t *o, const int16_t amp[], int len)
 {
     spangpu_modem_group_t *g = o->grp;
     int n;
+    int rc;
 
     if (len <= 0)
         return 0;                           /* as the reference: nothing to do (v29rx.c:867-965 loops over len) */
@@ -272,32 +295,34 @@ static int obj_rx(modem_obj_t *o, const int16_t amp[], int len)
         {
             n = (len > g->max_samples)  ?  g->max_samples  :  len;
             memcpy(g->stage, amp, n*sizeof(int16_t));
-            g->staged[0] = 1;
+            g->lens[0] = n;
             g->n_staged = 1;
-            g->tick_samples = n;
             spangpu_modem_group_flush(g);
             amp += n;
             len -= n;
         }
         return 0;
     }
-    /* A shared bank advances in ticks of one frame per attached receiver.  Nothing is ever dropped silently: a frame
-       longer than the group was made for, of another length than the tick's, or a second frame for a channel before the
-       tick has run is refused with -1 (the tone groups do the same). */
+    /* A shared bank advances in ticks: a frame per receiver that has one (any thread may stage; one submitter per
+       receiver, as for a spandsp object).  The tick runs when every attached receiver has staged, or when its owner calls
+       spangpu_modem_group_flush() at the deadline.  Nothing is dropped silently: a frame longer than the group was made
+       for, or a second frame for a receiver before the tick has run, is refused with -1. */
     if (len > g->max_samples)
         return -1;
-    if (g->staged[o->channel])
+    pthread_mutex_lock(&g->lock);
+    if (g->lens[o->channel])
+    {
+        pthread_mutex_unlock(&g->lock);
         return -1;
-    if (g->n_staged == 0)
-        g->tick_samples = len;
-    else if (len != g->tick_samples)
-        return -1;
+    }
+    pthread_mutex_unlock(&g->lock);
     memcpy(g->stage + (size_t) o->channel*g->max_samples, amp, len*sizeof(int16_t));
-    g->staged[o->channel] = 1;
+    pthread_mutex_lock(&g->lock);
+    g->lens[o->channel] = len;
     g->n_staged++;
-    if (g->n_staged == g->n_attached)
-        return (spangpu_modem_group_flush(g) < 0)  ?  -1  :  0;
-    return 0;
+    rc = (g->n_staged >= g->n_attached)  ?  group_flush_locked(g)  :  0;
+    pthread_mutex_unlock(&g->lock);
+    return (rc < 0)  ?  -1  :  0;
 }
 
 static int obj_free(modem_obj_t *o)
@@ -310,18 +335,20 @@ static int obj_free(modem_obj_t *o)
     {
         spangpu_modem_group_t *g = o->grp;
 
+        pthread_mutex_lock(&g->lock);
         g->handles[o->channel] = NULL;
         g->n_attached--;
-        if (g->staged[o->channel])
+        if (g->lens[o->channel])
         {
             /* its frame of the tick in progress goes with it */
-            g->staged[o->channel] = 0;
+            g->lens[o->channel] = 0;
             g->n_staged--;
         }
+        if (!o->private_grp  &&  g->n_staged > 0  &&  g->n_staged >= g->n_attached)
+            group_flush_locked(g);          /* it was the one the others were waiting for */
+        pthread_mutex_unlock(&g->lock);
         if (o->private_grp)
             spangpu_modem_group_destroy(g);
-        else if (g->n_staged > 0  &&  g->n_staged == g->n_attached)
-            spangpu_modem_group_flush(g);   /* it was the one the others were waiting for */
     }
     free(o);
     return 0;

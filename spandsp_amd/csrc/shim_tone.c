@@ -11,6 +11,7 @@
  */
 #include <limits.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -29,10 +30,10 @@ struct spangpu_group_s
     int max_samples;
     int16_t *stage;             /* [n_ch][max_samples] */
     void **handles;             /* per channel: the attached state object or NULL */
-    uint8_t *staged;
+    int32_t *lens;              /* per channel: samples staged for the tick being collected (0 = none) */
     int n_attached;
     int n_staged;
-    int tick_samples;
+    pthread_mutex_t lock;       /* staging, attach / detach and the tick itself (recursive: callbacks may call back in) */
     spangpu_block_t *blocks;
     int blocks_cap;
     spangpu_tone_params_t params;
@@ -180,8 +181,16 @@ spangpu_group_t *spangpu_group_create(int device, int kind, int n_channels, int 
     }
     g->stage = (int16_t *) calloc((size_t) n_channels*max_samples, sizeof(int16_t));
     g->handles = (void **) calloc(n_channels, sizeof(void *));
-    g->staged = (uint8_t *) calloc(n_channels, 1);
-    if (g->stage == NULL  ||  g->handles == NULL  ||  g->staged == NULL)
+    g->lens = (int32_t *) calloc(n_channels, sizeof(int32_t));
+    {
+        pthread_mutexattr_t at;
+
+        pthread_mutexattr_init(&at);
+        pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
+        pthread_mutex_init(&g->lock, &at);
+        pthread_mutexattr_destroy(&at);
+    }
+    if (g->stage == NULL  ||  g->handles == NULL  ||  g->lens == NULL)
     {
         spangpu_group_destroy(g);
         return NULL;
@@ -196,8 +205,9 @@ int spangpu_group_destroy(spangpu_group_t *g)
     spangpu_bank_destroy(g->bank);
     free(g->stage);
     free(g->handles);
-    free(g->staged);
+    free(g->lens);
     free(g->blocks);
+    pthread_mutex_destroy(&g->lock);
     free(g);
     return SPANGPU_OK;
 }
@@ -207,7 +217,10 @@ spangpu_bank_t *spangpu_group_bank(spangpu_group_t *g)
     return (g)  ?  g->bank  :  NULL;
 }
 
-int spangpu_group_flush(spangpu_group_t *g)
+/* Run the tick with the channels that have staged a frame.  The others sit it out -- their detectors are exactly as they
+   were, as the reference's are for a channel whose xxx_rx() was not called -- and may stage for the next one.  Returns
+   the number of channels that took part. */
+static int group_flush_locked(spangpu_group_t *g)
 {
     int rc;
     int n;
@@ -215,13 +228,9 @@ int spangpu_group_flush(spangpu_group_t *g)
     int start;
     int ch;
 
-    if (g == NULL)
-        return SPANGPU_ERR_BAD_ARG;
     if (g->n_staged == 0)
         return 0;
-    if (g->n_staged != g->n_attached)
-        return SPANGPU_ERR_STATE;       /* a channel that has not called xxx_rx() must not advance */
-    rc = spangpu_bank_rx(g->bank, g->stage, SPANGPU_MEM_HOST, SPANGPU_LAYOUT_CHANNEL_MAJOR, g->tick_samples, g->max_samples);
+    rc = spangpu_bank_rx_var(g->bank, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples);
     if (rc < 0)
         return rc;
     n = spangpu_bank_blocks(g->bank, NULL, 0);
@@ -246,7 +255,7 @@ int spangpu_group_flush(spangpu_group_t *g)
         i = start;
         while (i < n  &&  g->blocks[i].channel == ch)
             i++;
-        if (g->handles[ch])
+        if (g->handles[ch]  &&  g->lens[ch] > 0)
         {
             replay(g, ch, &g->blocks[start], i - start);
             end_of_call(g, ch);
@@ -254,55 +263,86 @@ int spangpu_group_flush(spangpu_group_t *g)
         start = i;
     }
     n = g->n_staged;
-    memset(g->staged, 0, g->n_ch);
+    memset(g->lens, 0, sizeof(int32_t)*g->n_ch);
     g->n_staged = 0;
-    g->tick_samples = 0;
     return n;
 }
 
-/* Stage one channel's frame; run the tick when every attached channel has staged. */
+int spangpu_group_flush(spangpu_group_t *g)
+{
+    int rc;
+
+    if (g == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    pthread_mutex_lock(&g->lock);
+    rc = group_flush_locked(g);
+    pthread_mutex_unlock(&g->lock);
+    return rc;
+}
+
+/* Stage one channel's frame (any thread); the tick runs when every attached channel has staged, or when the owner of
+   the tick calls spangpu_group_flush() at its deadline.  The frame is copied outside the lock: a channel has one
+   submitter, as a spandsp object has. */
 static int group_stage(spangpu_group_t *g, int channel, const int16_t amp[], int samples)
 {
+    int rc;
+
     if (samples <= 0)
         return 0;
     if (samples > g->max_samples)
         return SPANGPU_ERR_BAD_ARG;
-    if (g->staged[channel])
+    pthread_mutex_lock(&g->lock);
+    if (g->lens[channel])
+    {
+        pthread_mutex_unlock(&g->lock);
         return SPANGPU_ERR_STATE;       /* second frame before the tick ran */
-    if (g->n_staged == 0)
-        g->tick_samples = samples;
-    else if (samples != g->tick_samples)
-        return SPANGPU_ERR_BAD_ARG;     /* all channels of a tick carry the same frame length */
+    }
+    pthread_mutex_unlock(&g->lock);
     memcpy(g->stage + (size_t) channel*g->max_samples, amp, sizeof(int16_t)*samples);
-    g->staged[channel] = 1;
+    pthread_mutex_lock(&g->lock);
+    g->lens[channel] = samples;
     g->n_staged++;
-    if (g->n_staged == g->n_attached)
-        return spangpu_group_flush(g);
-    return 0;
+    rc = (g->n_staged >= g->n_attached)  ?  group_flush_locked(g)  :  0;
+    pthread_mutex_unlock(&g->lock);
+    return rc;
 }
 
 static int group_attach(spangpu_group_t *g, int channel, void *handle)
 {
-    if (g == NULL  ||  channel < 0  ||  channel >= g->n_ch  ||  g->handles[channel])
+    if (g == NULL  ||  channel < 0  ||  channel >= g->n_ch)
         return -1;
+    pthread_mutex_lock(&g->lock);
+    if (g->handles[channel])
+    {
+        pthread_mutex_unlock(&g->lock);
+        return -1;
+    }
     g->handles[channel] = handle;
     g->n_attached++;
     spangpu_bank_reset_channel(g->bank, channel, 0);
+    pthread_mutex_unlock(&g->lock);
     return 0;
 }
 
 static void group_detach(spangpu_group_t *g, int channel)
 {
-    if (g  &&  g->handles[channel])
+    if (g == NULL)
+        return;
+    pthread_mutex_lock(&g->lock);
+    if (g->handles[channel])
     {
         g->handles[channel] = NULL;
         g->n_attached--;
-        if (g->staged[channel])
+        if (g->lens[channel])
         {
-            g->staged[channel] = 0;
+            g->lens[channel] = 0;
             g->n_staged--;
         }
+        /* the channels that remain may all have been waiting for this one */
+        if (g->n_staged > 0  &&  g->n_staged >= g->n_attached)
+            group_flush_locked(g);
     }
+    pthread_mutex_unlock(&g->lock);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -523,7 +563,21 @@ void dtmf_rx_parms(dtmf_rx_state_t *s, int filter_dialtone, float twist, float r
     int nf;
 
     if (!s->private_grp)
-        return;                 /* shared banks take their parameters at spangpu_group_create() */
+    {
+        /* one channel of a shared bank: the bank keeps thresholds, twists and the filter switch per channel */
+        spangpu_tone_params_t p;
+
+        memset(&p, 0, sizeof(p));
+        p.filter_dialtone = (filter_dialtone >= 0)  ?  (filter_dialtone != 0)  :  -1;
+        p.twist_db = twist;
+        p.reverse_twist_db = reverse_twist;
+        p.threshold_dbm0 = threshold;
+        p.set_mask = SPANGPU_TP_TWIST | SPANGPU_TP_REVERSE_TWIST | SPANGPU_TP_THRESHOLD;    /* the bank applies dtmf.c:436-444's tests */
+        pthread_mutex_lock(&s->grp->lock);
+        spangpu_bank_set_channel_params(s->grp->bank, s->channel, &p, sizeof(p));
+        pthread_mutex_unlock(&s->grp->lock);
+        return;
+    }
     if (filter_dialtone >= 0)
     {
         /* dtmf.c:428-434: the notch states restart */
@@ -535,11 +589,20 @@ void dtmf_rx_parms(dtmf_rx_state_t *s, int filter_dialtone, float twist, float r
         s->params.filter_dialtone = filter_dialtone;
     }
     if (twist >= 0.0f)
+    {
         s->params.twist_db = twist;
+        s->params.set_mask |= SPANGPU_TP_TWIST;
+    }
     if (reverse_twist >= 0.0f)
+    {
         s->params.reverse_twist_db = reverse_twist;
+        s->params.set_mask |= SPANGPU_TP_REVERSE_TWIST;
+    }
     if (threshold > -99.0f)
+    {
         s->params.threshold_dbm0 = threshold;
+        s->params.set_mask |= SPANGPU_TP_THRESHOLD;
+    }
     s->dirty = 1;
     dtmf_private_rebuild(s, 160);
 }

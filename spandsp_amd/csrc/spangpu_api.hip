@@ -65,6 +65,13 @@ struct spangpu_bank_s
     size_t ext_rec_bytes;
     uint32_t *cur_rec;          // where the last launch wrote its records
     int next_fmt;               // sample format of the launch being prepared (0 linear, 1 A-law, 2 u-law)
+    const int32_t *next_lens;   // per-channel lengths of the launch being prepared (device), or nullptr
+    bool next_ragged;           // ... some of them are neither 0 nor the longest
+    int32_t *d_lens;            // [n_ch], device
+    int32_t *h_lens;            // [n_ch], pinned
+    float *chan_parms;          // DTMF, once a channel was given parameters of its own: [4][n_ch] on the device
+    float *h_chan_parms;        // ... and its host mirror
+    int n_filter_on;            // channels whose dial tone filter is on
     float *rec_energy;
     int32_t *rec_dur;
     float *trace;
@@ -117,7 +124,7 @@ constexpr int kLoaderMaxChannels = 393216;
 
 static bool fast_eligible(const ToneLaunch &L)
 {
-    return g_tone_variant != 1  &&  L.layout == 0  &&  L.aligned16  &&  L.samples > 0
+    return g_tone_variant != 1  &&  L.layout == 0  &&  L.aligned16  &&  L.samples > 0  &&  !L.lens_ragged
            &&  (unsigned long long) L.stride*2ull*256ull < 0xFFFFFFFFull  &&  L.n_ch <= (1 << 29);
 }
 
@@ -186,6 +193,25 @@ static void launch_tone_wide(const ToneLaunch &L, hipStream_t st)
         launch_tone_fast<Det, 2, kRingSelf, false, false, kFastWPB, 0, false>(L, blocks, st);
     else
         hipLaunchKernelGGL((tone_bank_kernel<Det, 2>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
+}
+
+// dtmf_rx_parms(), dtmf.c:421-445, on top of the defaults of dtmf_rx_init() (dtmf.c:470-476).  A field takes effect when
+// its bit of set_mask is set and the reference's own test passes (twists >= 0 dB, threshold > -99 dBm0); without
+// set_mask (a zeroed struct, or one from a caller built before the mask existed) a positive twist and a non-zero
+// threshold do.
+static void dtmf_levels(const spangpu_tone_params_t &tp, float &threshold, float &normal_twist, float &reverse_twist)
+{
+    threshold = 171029200.0f;
+    normal_twist = 6.309f;
+    reverse_twist = 2.512f;
+    const bool m = (tp.set_mask != 0);
+    if (m  ?  ((tp.set_mask & SPANGPU_TP_TWIST)  &&  tp.twist_db >= 0.0f)  :  (tp.twist_db > 0.0f))
+        normal_twist = powf(10.0f, tp.twist_db/10.0f);
+    if (m  ?  ((tp.set_mask & SPANGPU_TP_REVERSE_TWIST)  &&  tp.reverse_twist_db >= 0.0f)  :  (tp.reverse_twist_db > 0.0f))
+        reverse_twist = powf(10.0f, tp.reverse_twist_db/10.0f);
+    if (m  ?  ((tp.set_mask & SPANGPU_TP_THRESHOLD)  &&  tp.threshold_dbm0 > -99.0f)
+           :  (tp.threshold_dbm0 > -99.0f  &&  tp.threshold_dbm0 != 0.0f))
+        threshold = (float) ((102*102*32768.0f*32768.0f/2.0f)*powf(10.0f, (tp.threshold_dbm0 - 3.14f)/10.0f));
 }
 
 extern "C" int spangpu_set_error(int code, const char *msg)
@@ -320,19 +346,7 @@ int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_chann
         b->block_len = 102;
         for (int i = 0;  i < 8;  i++)
             b->fac[i] = spangpu_goertzel_fac(freqs[i]);
-        b->threshold = 171029200.0f;
-        b->normal_twist = 6.309f;
-        b->reverse_twist = 2.512f;
-        // dtmf_rx_parms(), dtmf.c:421-445.  A zeroed params struct keeps the defaults.
-        if (params)
-        {
-            if (b->tp.twist_db > 0.0f)
-                b->normal_twist = powf(10.0f, b->tp.twist_db/10.0f);
-            if (b->tp.reverse_twist_db > 0.0f)
-                b->reverse_twist = powf(10.0f, b->tp.reverse_twist_db/10.0f);
-            if (b->tp.threshold_dbm0 > -99.0f  &&  b->tp.threshold_dbm0 != 0.0f)
-                b->threshold = (float) ((102*102*32768.0f*32768.0f/2.0f)*powf(10.0f, (b->tp.threshold_dbm0 - 3.14f)/10.0f));
-        }
+        dtmf_levels(b->tp, b->threshold, b->normal_twist, b->reverse_twist);
         break;
     }
     case SPANGPU_BELL_MF:
@@ -416,6 +430,10 @@ int spangpu_bank_destroy(spangpu_bank_t *b)
     if (b->sf) (void) hipFree(b->sf);
     if (b->si) (void) hipFree(b->si);
     if (b->d_amp) (void) hipFree(b->d_amp);
+    if (b->d_lens) (void) hipFree(b->d_lens);
+    if (b->h_lens) (void) hipHostFree(b->h_lens);
+    if (b->chan_parms) (void) hipFree(b->chan_parms);
+    free(b->h_chan_parms);
     if (b->ev0) (void) hipEventDestroy(b->ev0);
     if (b->ev1) (void) hipEventDestroy(b->ev1);
     if (b->own_stream  &&  b->stream)
@@ -471,6 +489,9 @@ static void fill_launch(ToneLaunch &L, spangpu_bank_t *b, const int16_t *d_amp, 
     L.n_ch = b->n_ch;
     L.layout = layout;
     L.fmt = b->next_fmt;
+    L.lens = b->next_lens;
+    L.lens_ragged = (b->next_lens  &&  b->next_ragged)  ?  1  :  0;
+    L.chan_parms = b->chan_parms;
     {
         const int spc = L.fmt  ?  16  :  8;                 // samples per 16 bytes
         L.aligned16 = (layout == SPANGPU_LAYOUT_CHANNEL_MAJOR
@@ -507,7 +528,7 @@ static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stri
     switch (b->kind)
     {
     case SPANGPU_DTMF:
-        if (b->tp.filter_dialtone)
+        if (b->chan_parms  ?  (b->n_filter_on > 0)  :  (b->tp.filter_dialtone != 0))
             launch_tone<DtmfDet<true>>(L, b->stream);
         else
             launch_tone<DtmfDet<false>>(L, b->stream);
@@ -621,6 +642,118 @@ int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, 
     b->last_maxb = maxb;
     b->last_samples = samples;
     return 0;
+}
+
+// spangpu_bank_rx() for a tick in which not every channel has a frame, or not all frames are of one length: channel c
+// takes part with lens[c] samples of its row (0: it sits the call out -- its filters, block phase and debounce state are
+// exactly as they were, and it reports no block).  lens[] is host memory whatever `mem` says; frames are channel-major.
+int spangpu_bank_rx_var(spangpu_bank_t *b, const int16_t *amp, int mem, const int32_t *lens, int max_samples, long long stride)
+{
+    if (b == nullptr  ||  amp == nullptr  ||  lens == nullptr  ||  max_samples < 0)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    int longest = 0;
+    for (int c = 0;  c < b->n_ch;  c++)
+    {
+        if (lens[c] < 0  ||  lens[c] > max_samples)
+            return fail(SPANGPU_ERR_BAD_ARG, "channel %d: %d samples, outside 0..%d", c, lens[c], max_samples);
+        if (lens[c] > longest)
+            longest = lens[c];
+    }
+    if (longest == 0)
+        return 0;
+    if (stride <= 0)
+        stride = max_samples;
+    bool ragged = false;
+    bool all = true;
+    for (int c = 0;  c < b->n_ch;  c++)
+    {
+        ragged |= (lens[c] != 0  &&  lens[c] != longest);
+        all &= (lens[c] == longest);
+    }
+    if (all)
+        return spangpu_bank_rx(b, amp, mem, SPANGPU_LAYOUT_CHANNEL_MAJOR, longest, stride);
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->d_lens == nullptr)
+    {
+        HIP_TRY(hipMalloc(&b->d_lens, (size_t) b->n_ch*sizeof(int32_t)));
+        HIP_TRY(hipHostMalloc(&b->h_lens, (size_t) b->n_ch*sizeof(int32_t), hipHostMallocDefault));
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));               // the previous call's copy out of h_lens is done
+    memcpy(b->h_lens, lens, (size_t) b->n_ch*sizeof(int32_t));
+    HIP_TRY(hipMemcpyAsync(b->d_lens, b->h_lens, (size_t) b->n_ch*sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    b->next_lens = b->d_lens;
+    b->next_ragged = ragged;
+    const int rc = spangpu_bank_rx(b, amp, mem, SPANGPU_LAYOUT_CHANNEL_MAJOR, longest, stride);
+    b->next_lens = nullptr;
+    b->next_ragged = false;
+    return rc;
+}
+
+// Parameters of ONE channel of a DTMF bank: what dtmf_rx_parms() (dtmf.c:421-445) does to one detector.  The fields of
+// `params` that count are filter_dialtone (< 0: leave as it is; else the notch states of the channel restart, as in
+// dtmf.c:428-434), twist_db, reverse_twist_db and threshold_dbm0 under set_mask.  From the first such call on the bank
+// carries its thresholds per channel (three loads per channel and block end more); channels never named keep the
+// bank's values.
+int spangpu_bank_set_channel_params(spangpu_bank_t *b, int channel, const spangpu_tone_params_t *params, size_t params_size)
+{
+    if (b == nullptr  ||  params == nullptr  ||  channel < 0  ||  channel >= b->n_ch)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (b->kind != SPANGPU_DTMF)
+        return fail(SPANGPU_ERR_UNSUPPORTED, "per-channel parameters exist for DTMF banks only");
+    spangpu_tone_params_t tp;
+    memset(&tp, 0, sizeof(tp));
+    memcpy(&tp, params, (params_size < sizeof(tp))  ?  params_size  :  sizeof(tp));
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const size_t n = (size_t) b->n_ch;
+    if (b->chan_parms == nullptr)
+    {
+        if ((b->h_chan_parms = (float *) malloc(4*n*sizeof(float))) == nullptr)
+            return fail(SPANGPU_ERR_NO_MEMORY, "malloc");
+        for (size_t c = 0;  c < n;  c++)
+        {
+            b->h_chan_parms[c] = b->threshold;
+            b->h_chan_parms[n + c] = b->normal_twist;
+            b->h_chan_parms[2*n + c] = b->reverse_twist;
+            b->h_chan_parms[3*n + c] = b->tp.filter_dialtone  ?  1.0f  :  0.0f;
+        }
+        b->n_filter_on = b->tp.filter_dialtone  ?  b->n_ch  :  0;
+        float *d = nullptr;
+        if (hipMalloc(&d, 4*n*sizeof(float)) != hipSuccess)
+        {
+            free(b->h_chan_parms);
+            b->h_chan_parms = nullptr;
+            return fail(SPANGPU_ERR_NO_MEMORY, "hipMalloc of per-channel parameters failed");
+        }
+        HIP_TRY(hipMemcpy(d, b->h_chan_parms, 4*n*sizeof(float), hipMemcpyHostToDevice));
+        b->chan_parms = d;
+    }
+    float *h = b->h_chan_parms;
+    // the channel's present values stand where the call leaves a field alone
+    spangpu_tone_params_t q = tp;
+    if (q.set_mask == 0)
+        q.set_mask = ((q.twist_db > 0.0f)  ?  SPANGPU_TP_TWIST  :  0)  |  ((q.reverse_twist_db > 0.0f)  ?  SPANGPU_TP_REVERSE_TWIST  :  0)
+                     |  ((q.threshold_dbm0 > -99.0f  &&  q.threshold_dbm0 != 0.0f)  ?  SPANGPU_TP_THRESHOLD  :  0)  |  0x40000000;
+    float thr, nt, rt;
+    dtmf_levels(q, thr, nt, rt);
+    if ((q.set_mask & SPANGPU_TP_THRESHOLD)  &&  q.threshold_dbm0 > -99.0f)
+        h[channel] = thr;
+    if ((q.set_mask & SPANGPU_TP_TWIST)  &&  q.twist_db >= 0.0f)
+        h[n + channel] = nt;
+    if ((q.set_mask & SPANGPU_TP_REVERSE_TWIST)  &&  q.reverse_twist_db >= 0.0f)
+        h[2*n + channel] = rt;
+    if (tp.filter_dialtone >= 0)
+    {
+        const float on = tp.filter_dialtone  ?  1.0f  :  0.0f;
+        b->n_filter_on += (int) on - (int) h[3*n + channel];
+        h[3*n + channel] = on;
+        for (int i = 0;  i < 4;  i++)
+            HIP_TRY(hipMemsetAsync(b->sf + (size_t) (17 + i)*n + channel, 0, sizeof(float), b->stream));
+    }
+    for (int i = 0;  i < 4;  i++)
+        HIP_TRY(hipMemcpyAsync(b->chan_parms + (size_t) i*n + channel, &h[(size_t) i*n + channel], sizeof(float), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return SPANGPU_OK;
 }
 
 // spangpu_bank_rx() for G.711 input: `codes` holds one A-law or u-law byte per sample, channel-major (the wire format

@@ -63,6 +63,11 @@ struct ToneLaunch
     float reverse_twist;
     int fmt;                    // 0: int16 linear PCM, 1: G.711 A-law bytes, 2: G.711 u-law bytes (channel-major, LPC = 2 kernels)
     long long *probe_ts;        // tools/probe.hip only: per-wave timestamps (kernels built with ABL & 32)
+    const int32_t *lens;        // nullptr: every channel has `samples`; else samples per channel in this call (0 = the
+                                // channel sits this call out: its state and block phase are not touched)
+    int lens_ragged;            // host side only: lengths other than 0 and `samples` occur (the general kernel takes the call)
+    const float *chan_parms;    // nullptr: threshold / twists / dial tone filter as set for the bank; else DTMF
+                                // per channel, [4][n_ch]: threshold, normal twist, reverse twist, filter on (0 / 1)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -315,14 +320,18 @@ struct DtmfDet
     __device__ static __forceinline__ int block_len(const ToneLaunch &) { return 102; }    // dtmf.c:71
 
     float z[FILTER  ?  4  :  1];
+    bool filt;                  // this channel's dial tone filter is on (dtmf.c:421-445 sets it per detector)
 
     __device__ __forceinline__ void load_extra(const ToneLaunch &L, int ch)
     {
+        filt = FILTER;
         if (FILTER)
         {
 #pragma unroll
             for (int i = 0;  i < 4;  i++)
                 z[i] = L.sf[(size_t) (2*NB + 1 + i)*L.n_ch + ch];
+            if (L.chan_parms)
+                filt = (L.chan_parms[(size_t) 3*L.n_ch + ch] != 0.0f);
         }
     }
     __device__ __forceinline__ void store_extra(const ToneLaunch &L, int ch)
@@ -342,13 +351,14 @@ struct DtmfDet
         {
             float v1 = 0.98356f*x + 1.8954426f*z[0] - 0.9691396f*z[1];
             float f = v1 - 1.9251480f*z[0] + z[1];
-            z[1] = z[0];
-            z[0] = v1;
-            v1 = 0.98456f*f + 1.8529543f*z[2] - 0.9691396f*z[3];
-            f = v1 - 1.8819938f*z[2] + z[3];
-            z[3] = z[2];
-            z[2] = v1;
-            return f;
+            const float v2 = 0.98456f*f + 1.8529543f*z[2] - 0.9691396f*z[3];
+            const float g = v2 - 1.8819938f*z[2] + z[3];
+            // a channel whose filter is off keeps its (zero) filter state and sees the raw sample
+            z[1] = filt  ?  z[0]  :  z[1];
+            z[0] = filt  ?  v1  :  z[0];
+            z[3] = filt  ?  z[2]  :  z[3];
+            z[2] = filt  ?  v2  :  z[2];
+            return filt  ?  g  :  x;
         }
         return x;
     }
@@ -380,8 +390,17 @@ struct DtmfDet
         }
         // All tests are side-effect free: evaluate every one and combine with non-short-circuit logic (no divergent
         // branches at a block end, which every lane of the wave reaches together).
-        bool ok = (er >= L.threshold)  &  (ec >= L.threshold);
-        ok = ok  &  (ec < er*L.reverse_twist)  &  (ec*L.normal_twist > er);
+        float threshold = L.threshold;
+        float normal_twist = L.normal_twist;
+        float reverse_twist = L.reverse_twist;
+        if (L.chan_parms)
+        {
+            threshold = L.chan_parms[ch];
+            normal_twist = L.chan_parms[(size_t) L.n_ch + ch];
+            reverse_twist = L.chan_parms[(size_t) 2*L.n_ch + ch];
+        }
+        bool ok = (er >= threshold)  &  (ec >= threshold);
+        ok = ok  &  (ec < er*reverse_twist)  &  (ec*normal_twist > er);
         bool off_peak = false;
 #pragma unroll
         for (int i = 0;  i < 4;  i++)
@@ -793,8 +812,23 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
         return;                                     // whole wave idle (wave-uniform exit)
     const int cl = (LPC == 1)  ?  lane  :  (lane & (CPW - 1));  // channel within the wave
     const int sub = (LPC == 1)  ?  0  :  (lane >> 5);           // which half of the bins
-    const bool live = (ch0 + cl) < L.n_ch;
-    const int ch = live  ?  (ch0 + cl)  :  (L.n_ch - 1);        // shadow lanes follow the last channel, never store
+    const bool in_bank = (ch0 + cl) < L.n_ch;
+    const int ch = in_bank  ?  (ch0 + cl)  :  (L.n_ch - 1);     // shadow lanes follow the last channel, never store
+    // A call with per-channel lengths: a channel with no samples in it rides along as a shadow lane too (nothing of
+    // it is stored but empty record slots), and a wave with no channel taking part leaves at once.
+    int mylen = L.samples;
+    if (L.lens)
+    {
+        mylen = min(max(L.lens[ch], 0), L.samples);
+        if (in_bank  &&  sub == 0  &&  mylen == 0)
+        {
+            for (int b = 0;  b < L.maxb;  b++)
+                L.rec[(size_t) b*L.n_ch + ch] = 0;
+        }
+        if (!__any(in_bank  &&  mylen > 0))
+            return;
+    }
+    const bool live = in_bank  &&  (!L.lens  ||  mylen > 0);    // (a forced block end is a call of no samples)
     const bool store = live  &&  (sub == 0);
 
     // probe-only (ABL & 32): per-wave timestamps into L.probe_ts, 16 slots per wave
@@ -895,8 +929,17 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
 
     // Wave-uniform block phase?  (true whenever the wave's channels were started
     // together, which the host slot allocator arranges.)
-    const int cs_first = __builtin_amdgcn_readfirstlane(cs);
-    const bool uniform = __all(cs == cs_first);
+    int cs_first = __builtin_amdgcn_readfirstlane(cs);
+    bool uniform = __all(cs == cs_first);
+    if (L.lens)
+    {
+        // the phase the channels taking part share, if they do; the others adopt it for the ride
+        const unsigned long long act = __ballot(live);
+        cs_first = __builtin_amdgcn_readlane(cs, (int) __ffsll(act) - 1);
+        uniform = __all(!live  ||  (cs == cs_first  &&  mylen == L.samples));
+        if (uniform)
+            cs = cs_first;
+    }
     stamp(1);
 
     int nb = 0;                 // blocks completed by this lane in this call
@@ -1144,13 +1187,16 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
             {
                 if (pos == 0  &&  fast_loader  &&  seg + 1 < nseg)
                     issue_dma(seg + 1, buf ^ 1);
-                one_sample((bps == 1)  ?  lut[((const uint8_t *) row)[pos]]  :  (float) row[pos]);
-                cs++;
-                take_acc++;
-                if (cs >= block)
+                if (seg_base + pos < mylen)
                 {
-                    end_block();
-                    cs = 0;
+                    one_sample((bps == 1)  ?  lut[((const uint8_t *) row)[pos]]  :  (float) row[pos]);
+                    cs++;
+                    take_acc++;
+                    if (cs >= block)
+                    {
+                        end_block();
+                        cs = 0;
+                    }
                 }
             }
         }

@@ -255,10 +255,33 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
     }
     const unsigned cl = (LPC == 1)  ?  lane  :  (lane & (CPW - 1));     // channel within the wave
     const int sub = (LPC == 1)  ?  0  :  (int) (lane >> 5);             // which half of the bins
-    const bool live = (ch0 + (int) cl) < L.n_ch;
-    const unsigned ch = live  ?  (unsigned) ch0 + cl  :  (unsigned) (L.n_ch - 1);   // shadow lanes follow the last channel, never store
-    const bool store = live  &&  (sub == 0);
+    const bool in_bank = (ch0 + (int) cl) < L.n_ch;
+    const unsigned ch = in_bank  ?  (unsigned) ch0 + cl  :  (unsigned) (L.n_ch - 1);   // shadow lanes follow the last channel, never store
     const unsigned nch = (unsigned) L.n_ch;
+    // A call with an active mask (L.lens holds 0 or `samples` per channel; other lengths go to the general kernel): a
+    // channel sitting the call out rides along as a shadow lane -- nothing of it is stored but empty record slots --
+    // and a wave with no channel taking part only keeps the workgroup's barriers.
+    bool live = in_bank;
+    if (L.lens)
+    {
+        live = in_bank  &&  (L.lens[ch] > 0);
+        if (in_bank  &&  !live  &&  sub == 0)
+        {
+            for (int b = 0;  b < L.maxb;  b++)
+                L.rec[(size_t) b*nch + ch] = 0;
+        }
+        if (!__any(live))
+        {
+            if (LDR)
+            {
+                const int nseg_idle = (int) (((unsigned) L.samples*BPS + kPiece - 1)/kPiece);
+                for (int seg = 0;  seg < nseg_idle;  seg++)
+                    seg_barrier();
+            }
+            return;
+        }
+    }
+    const bool store = live  &&  (sub == 0);
 
     long long *ts = nullptr;
     if (ABL & 32)
@@ -359,8 +382,17 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
     int cs = (int) (w0 & 0xFFFF);
     w0 &= 0xFFFF0000u;
     const int block = Det::block_len(L);
-    const int cs_first = __builtin_amdgcn_readfirstlane(cs);
-    const bool uniform = __all(cs == cs_first);     // true whenever the wave's channels were started together
+    int cs_first = __builtin_amdgcn_readfirstlane(cs);
+    bool uniform = __all(cs == cs_first);           // true whenever the wave's channels were started together
+    if (L.lens)
+    {
+        // the phase the channels taking part share, if they do; the others adopt it for the ride
+        const unsigned long long act = __ballot(live);
+        cs_first = __builtin_amdgcn_readlane(cs, (int) __ffsll(act) - 1);
+        uniform = __all(!live  ||  cs == cs_first);
+        if (uniform)
+            cs = cs_first;
+    }
     stamp(1);
 
     int nb = 0;                 // blocks completed by this lane in this call

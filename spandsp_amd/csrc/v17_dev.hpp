@@ -70,6 +70,7 @@ struct V17Launch
     const int16_t *amp;
     long long stride;
     int samples;
+    const int32_t *lens;        // nullptr, or samples per channel in this call (<= samples; 0 = the channel sits it out)
     int n_ch;
     int bit_rate;
     uint32_t *state;            // [kV17Words][n_ch]
@@ -138,6 +139,7 @@ void v17_bank_kernel(const V17Launch L)
     const float spacing = (space_map == 0)  ?  1.414f  :  (space_map == 1)  ?  2.0f  :  (space_map == 2)  ?  2.828f  :  4.0f;
 
     const size_t N = (size_t) L.n_ch;
+    const int mylen = L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;
     auto ldf = [&](int w) { return __uint_as_float(L.state[(size_t) w*N + ch]); };
     auto ldi = [&](int w) { return (int32_t) L.state[(size_t) (kV17Floats + w)*N + ch]; };
     auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
@@ -546,7 +548,7 @@ void v17_bank_kernel(const V17Launch L)
     const int16_t *src = L.amp + (size_t) ch*L.stride;
     for (int tile = 0;  tile < L.samples;  tile += kTile)
     {
-    const int tn = min(kTile, L.samples - tile);
+    const int tn = max(0, min(kTile, mylen - tile));         // per lane when the call carries per-channel lengths
     // ---- stage this lane's stretch of PCM: pcm[k][lane] = samples 2k, 2k+1 of the tile ----------------------
     {
         const int16_t *row = src + tile;

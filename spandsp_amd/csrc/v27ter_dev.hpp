@@ -63,6 +63,7 @@ struct V27Launch
     const int16_t *amp;
     long long stride;
     int samples;
+    const int32_t *lens;        // nullptr, or samples per channel in this call (<= samples; 0 = the channel sits it out)
     int n_ch;
     int bit_rate;               // bank-wide: 4800 or 2400
     uint32_t *state;            // [kV27Words][n_ch]
@@ -116,6 +117,7 @@ void v27ter_bank_kernel(const V27Launch L)
         return;
 
     const size_t N = (size_t) L.n_ch;
+    const int mylen = L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;
     auto ldf = [&](int w) { return __uint_as_float(L.state[(size_t) w*N + ch]); };
     auto ldi = [&](int w) { return (int32_t) L.state[(size_t) (kV27Floats + w)*N + ch]; };
     auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
@@ -401,7 +403,7 @@ void v27ter_bank_kernel(const V27Launch L)
     const int16_t *src = L.amp + (size_t) ch*L.stride;
     for (int tile = 0;  tile < L.samples;  tile += kPcmTile)
     {
-    const int tn = min(kPcmTile, L.samples - tile);
+    const int tn = max(0, min(kPcmTile, mylen - tile));         // per lane when the call carries per-channel lengths
     // ---- stage this lane's stretch of PCM: pcm[k][lane] = samples 2k, 2k+1 of the tile ----------------------
     {
         const int16_t *row = src + tile;

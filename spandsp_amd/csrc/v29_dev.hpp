@@ -103,6 +103,7 @@ struct V29Launch
     const int16_t *amp;
     long long stride;
     int samples;
+    const int32_t *lens;        // nullptr, or samples per channel in this call (<= samples; 0 = the channel sits it out)
     int n_ch;
     uint32_t *state;            // [kV29Words][n_ch]
     int8_t *events;             // [n_ch][ev_cap]: 0/1 bits and negative SIG_STATUS_* codes, in order
@@ -267,6 +268,7 @@ void v29_bank_kernel(const V29Launch L)
 
     // ---- state -> registers / LDS ---------------------------------------------------------------
     const size_t N = (size_t) L.n_ch;
+    const int mylen = L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;
     auto ldf = [&](int w) { return __uint_as_float(L.state[(size_t) w*N + ch]); };
     auto ldi = [&](int w) { return (int32_t) L.state[(size_t) (kV29Floats + w)*N + ch]; };
     auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
@@ -538,7 +540,7 @@ void v29_bank_kernel(const V29Launch L)
     const int16_t *src = L.amp + (size_t) ch*L.stride;
     for (int tile = 0;  tile < L.samples;  tile += kPcmTile)
     {
-    const int tn = min(kPcmTile, L.samples - tile);
+    const int tn = max(0, min(kPcmTile, mylen - tile));         // per lane when the call carries per-channel lengths
     // ---- stage this lane's stretch of PCM: pcm[k][lane] = samples 2k, 2k+1 of the tile ----------------------
     {
         const int16_t *row = src + tile;

@@ -26,7 +26,10 @@ class ToneParams(C.Structure):
     _fields_ = [("report_mode", C.c_int32), ("filter_dialtone", C.c_int32),
                 ("twist_db", C.c_float), ("reverse_twist_db", C.c_float), ("threshold_dbm0", C.c_float),
                 ("r2_fwd", C.c_int32), ("n_bins", C.c_int32), ("block_len", C.c_int32),
-                ("bin_fac", C.c_float*MAX_BINS), ("trace", C.c_int32)]
+                ("bin_fac", C.c_float*MAX_BINS), ("trace", C.c_int32), ("set_mask", C.c_int32)]
+
+
+TP_TWIST, TP_REVERSE_TWIST, TP_THRESHOLD = 1, 2, 4
 
 
 class SpanGpuError(RuntimeError):
@@ -60,6 +63,8 @@ def lib():
             "spangpu_bank_channels": (ci, [vp]),
             "spangpu_bank_set_stream": (ci, [vp, vp]),
             "spangpu_bank_rx": (ci, [vp, vp, ci, ci, ci, ll]),
+            "spangpu_bank_rx_var": (ci, [vp, vp, ci, vp, ci, ll]),
+            "spangpu_bank_set_channel_params": (ci, [vp, ci, vp, C.c_size_t]),
             "spangpu_bank_sync": (ci, [vp]),
             "spangpu_bank_blocks": (ci, [vp, vp, ci]),
             "spangpu_bank_trace": (ci, [vp, vp, C.c_size_t]),
@@ -94,7 +99,6 @@ def lib():
             "spangpu_awgn_sync": (ci, [vp]),
             "spangpu_awgn_reinit": (ci, [vp, ci, ci, cf]),
             "spangpu_awgn_tx": (ci, [vp, ci, vp, ll, ci, ci]),
-            "spangpu_awgn_uncertain": (ci, [vp, C.POINTER(ll)]),
             "spangpu_awgn_state_words": (ci, [vp]),
             "spangpu_awgn_get_state": (ci, [vp, ci, vp]),
             "spangpu_mct_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
@@ -146,6 +150,7 @@ def lib():
             "spangpu_modem_set_stream": (ci, [vp, vp]),
             "spangpu_modem_sync": (ci, [vp]),
             "spangpu_modem_rx": (ci, [vp, vp, ci, ci, ll]),
+            "spangpu_modem_rx_var": (ci, [vp, vp, ci, vp, ci, ll]),
             "spangpu_modem_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
             "spangpu_modem_qam_tap": (ci, [vp, ci]),
             "spangpu_modem_qam_reports": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
@@ -202,8 +207,9 @@ class ToneBank:
 
     def __init__(self, kind, n_channels, device=0, report_mode=REPORT_DIGITS, filter_dialtone=False,
                  twist_db=0.0, reverse_twist_db=0.0, threshold_dbm0=0.0, r2_fwd=True,
-                 bin_fac=None, block_len=0, trace=False):
+                 bin_fac=None, block_len=0, trace=False, set_mask=0):
         p = ToneParams()
+        p.set_mask = set_mask
         p.report_mode = report_mode
         p.filter_dialtone = int(filter_dialtone)
         p.twist_db = twist_db
@@ -258,6 +264,27 @@ class ToneBank:
 
     def rx_device(self, ptr, samples, stride=0, layout=CHANNEL_MAJOR):
         _check(lib().spangpu_bank_rx(self.h, ptr, MEM_DEVICE, layout, samples, stride))
+
+    def rx_host_var(self, frames, lens):
+        """A tick with per-channel frame lengths: frames int16 [n_channels, max_samples], lens[c] samples of row c count
+        (0 = channel c sits the tick out, untouched)."""
+        frames = np.ascontiguousarray(frames, dtype=np.int16)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        assert frames.shape[0] == self.n and lens.shape == (self.n,)
+        _check(lib().spangpu_bank_rx_var(self.h, frames.ctypes.data, MEM_HOST, lens.ctypes.data, frames.shape[1], frames.shape[1]))
+        self.sync()
+
+    def rx_device_var(self, ptr, lens, max_samples, stride):
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        _check(lib().spangpu_bank_rx_var(self.h, ptr, MEM_DEVICE, lens.ctypes.data, max_samples, stride))
+
+    def set_channel_params(self, channel, filter_dialtone=-1, twist_db=-1.0, reverse_twist_db=-1.0, threshold_dbm0=-99.0):
+        """dtmf_rx_parms() for one channel of a DTMF bank, with its argument conventions (negative = leave alone)."""
+        p = ToneParams()
+        p.filter_dialtone = int(filter_dialtone)
+        p.twist_db, p.reverse_twist_db, p.threshold_dbm0 = twist_db, reverse_twist_db, threshold_dbm0
+        p.set_mask = TP_TWIST | TP_REVERSE_TWIST | TP_THRESHOLD
+        _check(lib().spangpu_bank_set_channel_params(self.h, channel, C.byref(p), C.sizeof(p)))
 
     def rx_host_g711(self, codes, law):
         """codes: uint8 [n_channels, samples] of A-law (law = G711_ALAW) or u-law (G711_ULAW) bytes."""
@@ -496,6 +523,13 @@ class ModemBank:
 
     def rx_device(self, ptr, samples, stride):
         _check(lib().spangpu_modem_rx(self.h, ptr, MEM_DEVICE, samples, stride))
+
+    def rx_host_var(self, frames, lens):
+        """A tick with per-channel frame lengths (0 = the receiver sits it out, untouched)."""
+        frames = np.ascontiguousarray(frames, np.int16)
+        lens = np.ascontiguousarray(lens, np.int32)
+        assert frames.shape[0] == self.n and lens.shape == (self.n,)
+        _check(lib().spangpu_modem_rx_var(self.h, frames.ctypes.data, MEM_HOST, lens.ctypes.data, frames.shape[1], frames.shape[1]))
 
     def events(self):
         """List (per channel) of int8 arrays: 0/1 bits and negative SIG_STATUS codes, in order."""
@@ -896,11 +930,6 @@ class AwgnBank:
 
     def tx_device(self, pcm_ptr, stride, samples, mix=False):
         _check(lib().spangpu_awgn_tx(self.h, MEM_DEVICE, pcm_ptr, stride, samples, int(mix)))
-
-    def uncertain(self):
-        v = C.c_longlong(0)
-        _check(lib().spangpu_awgn_uncertain(self.h, C.byref(v)))
-        return v.value
 
     def get_state(self, channel):
         w = np.zeros(lib().spangpu_awgn_state_words(self.h), np.uint32)

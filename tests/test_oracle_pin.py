@@ -778,6 +778,33 @@ def test_awgn_live(built, seed, level):
     assert np.array_equal(o.snapshot(), ref.awgn_state_words(seed, level, 30001))
 
 
+def test_restated_log_is_the_c_librarys(built):
+    """oracle/glibc_log.c against the log() the reference links on this host (GNU libc; on x86-64 with FMA3 + AVX2 the
+    library runs its FMA build, the one restated): bit for bit over the noise source's domain (0, 1), around 1 where the
+    routine changes polynomial, over the whole exponent range, on subnormals and at the special values."""
+    import ctypes as C
+    import oracle
+    flags = open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split()
+    if "fma" not in flags or "avx2" not in flags:
+        pytest.skip("this host's C library runs another build of log()")
+    L = C.CDLL(oracle.ORACLE_SO)
+    L.orc_glibc_log_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    libm = C.CDLL("libm.so.6")
+    libm.log.restype = C.c_double
+    libm.log.argtypes = [C.c_double]
+    rng = np.random.default_rng(2)
+    sets = [rng.random(300000), 1.0 + (rng.random(100000) - 0.5)*0.14, np.exp(rng.uniform(-708.0, 709.0, 50000)),
+            rng.random(20000)*2.0e-308,
+            np.array([1.0, 0.5, 2.0, 1.0 - 2.0**-4, 1.0 + float.fromhex("0x1.09p-4"), np.nextafter(1.0, 0.0), np.nextafter(1.0, 2.0),
+                      np.nextafter(1.0 - 2.0**-4, 0.0), 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 0.0, np.inf])]
+    for x in sets:
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.zeros_like(x)
+        L.orc_glibc_log_block(x.ctypes.data, y.ctypes.data, len(x))
+        want = np.array([libm.log(float(v)) for v in x])
+        assert np.array_equal(y.view(np.uint64), want.view(np.uint64)), np.nonzero(y.view(np.uint64) != want.view(np.uint64))[0][:5]
+
+
 def test_golden_awgn(built):
     from oracle import restated as orc
     g = np.load(os.path.join(GOLDEN, "awgn.npz"))

@@ -188,6 +188,104 @@ def test_dtmf_group_of_channels(L):
     L.spangpu_group_destroy(g)
 
 
+def test_dtmf_group_tick_with_late_and_silent_channels(L):
+    """A tick runs with the channels that staged when its owner calls spangpu_group_flush(): a late or silent channel
+    stalls nobody and is itself untouched; frames of different lengths share a tick; dtmf_rx_parms() on an attached
+    object is that channel's own."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 70
+    sig, _ = synth.dtmf_channels(n_ch, 160*60, seed=57)
+    t = np.arange(sig.shape[1])
+    dial = 3000.0*np.sin(2*np.pi*350.0*t/8000.0) + 3000.0*np.sin(2*np.pi*440.0*t/8000.0)
+    sig[:8] = np.clip(sig[:8].astype(np.float64) + dial, -32768, 32767).astype(np.int16)
+    g = L.spangpu_group_create(0, engine.DTMF, n_ch, 160, None)
+    recs = [Rec() for _ in range(n_ch)]
+    hs = [L.spangpu_dtmf_rx_attach(g, c, recs[c].digits_cb, None) for c in range(n_ch)]
+    dets = [orc.Dtmf(1) for _ in range(n_ch)]
+    for c in range(0, 8, 2):
+        L.dtmf_rx_parms(hs[c], 1, 0.0, -1.0, -40.0)
+        dets[c].parms(1, 0.0, -1.0, -40.0)
+    rng = np.random.default_rng(3)
+    pos = np.zeros(n_ch, np.int64)
+    for tick in range(75):
+        r = rng.random(n_ch)
+        lens = np.where(r < 0.25, 0, np.where(r < 0.35, 80, 160))
+        lens = np.minimum(lens, sig.shape[1] - pos)
+        if tick == 40:
+            lens[:] = 160
+            lens = np.minimum(lens, sig.shape[1] - pos)
+        staged = 0
+        for c in range(n_ch):
+            if lens[c]:
+                fr = i16(sig[c, pos[c]:pos[c] + lens[c]])
+                assert L.dtmf_rx(hs[c], fr.ctypes.data, int(lens[c])) == 0
+                dets[c].rx(fr)
+                staged += 1
+        if staged and staged < n_ch:
+            c = int(np.flatnonzero(lens)[0])
+            fr = i16(sig[c, :160])
+            assert L.dtmf_rx(hs[c], fr.ctypes.data, 160) == -1         # a second frame before the tick ran is refused
+        want = 0 if staged == n_ch else staged                           # a full house ran by itself
+        assert L.spangpu_group_flush(g) == want
+        assert L.spangpu_group_flush(g) == 0
+        pos += lens
+        for c in range(n_ch):
+            assert recs[c].events == orc_events(dets[c]), (c, tick)
+    assert sum(len(r.text) for r in recs) > n_ch//2
+    for c in range(n_ch):
+        assert recs[c].text == dets[c].sink.text()
+        L.dtmf_rx_free(hs[c])
+    L.spangpu_group_destroy(g)
+
+
+def test_dtmf_group_staged_from_many_threads(L):
+    """Staging is safe from many threads (one submitter per channel, as for a spandsp object): 8 threads feed 12 channels
+    each; whichever completes the tick runs it and replays everybody's callbacks."""
+    import threading
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_thr, per = 8, 12
+    n_ch = n_thr*per
+    n_ticks = 50
+    sig, _ = synth.dtmf_channels(n_ch, 160*n_ticks, seed=58)
+    g = L.spangpu_group_create(0, engine.DTMF, n_ch, 160, None)
+    recs = [Rec() for _ in range(n_ch)]
+    hs = [L.spangpu_dtmf_rx_attach(g, c, recs[c].digits_cb, None) for c in range(n_ch)]
+    frames = [[i16(sig[c, k*160:(k + 1)*160]) for k in range(n_ticks)] for c in range(n_ch)]
+    gate = threading.Barrier(n_thr)
+    errors = []
+
+    def worker(w):
+        try:
+            for k in range(n_ticks):
+                for c in range(w*per, (w + 1)*per):
+                    if L.dtmf_rx(hs[c], frames[c][k].ctypes.data, 160) != 0:
+                        errors.append((c, k))
+                gate.wait()             # the tick is over (its last stager ran it) before anybody stages the next
+        except Exception as e:          # pragma: no cover
+            errors.append(repr(e))
+            gate.abort()
+
+    th = [threading.Thread(target=worker, args=(w,)) for w in range(n_thr)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert errors == []
+    n_digits = 0
+    for c in range(n_ch):
+        d = orc.Dtmf(1)
+        for k in range(n_ticks):
+            d.rx(frames[c][k])
+        assert recs[c].events == orc_events(d), c
+        assert recs[c].text == d.sink.text()
+        n_digits += len(recs[c].text)
+        L.dtmf_rx_free(hs[c])
+    assert n_digits > n_ch
+    L.spangpu_group_destroy(g)
+
+
 def test_bell_and_r2_private_objects(L):
     from oracle import restated as orc
     sig, _ = synth.bell_mf_channels(4, 160*100, seed=54)

@@ -201,6 +201,120 @@ def test_dtmf_divergent_block_phase_and_fillin(built):
     _dtmf_state_check(bank, dets, "dtmf-divergent")
 
 
+def _var_ticks(n_ch, n_ticks, seed, ragged):
+    """lens[tick][channel]: most channels bring a whole 160-sample frame, some none, and (ragged) some a short one."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for t in range(n_ticks):
+        r = rng.random(n_ch)
+        lens = np.where(r < 0.2, 0, 160).astype(np.int32)
+        if ragged and t % 3 == 1:
+            short = rng.random(n_ch) < 0.15
+            lens[short] = rng.integers(1, 160, int(short.sum()))
+        if t % 7 == 3:
+            lens[64:128] = 0                # a whole wavefront of one-lane-per-channel kernels sits the tick out
+        if t % 11 == 5:
+            lens[:] = 0
+            lens[rng.integers(0, n_ch)] = 160
+        out.append(lens)
+    return out
+
+
+@pytest.mark.parametrize("ragged", [False, True], ids=["mask", "ragged"])
+def test_dtmf_tick_with_missing_and_short_channels(built, ragged):
+    """spangpu_bank_rx_var(): a channel without a frame in a tick is untouched by it (filters, block phase, debounce,
+    duration), one with a short frame advances by just that; every channel equals an oracle detector fed its own samples
+    only.  Frames of 0 / 160 keep the streaming kernels (active mask), other lengths take the general one."""
+    from spandsp_amd import engine
+    from oracle import restated as orc
+    n_ch = 200
+    n_ticks = 70
+    sig, _ = synth.dtmf_channels(n_ch, 160*n_ticks, seed=21)
+    bank = engine.ToneBank(engine.DTMF, n_ch, trace=True)
+    dets = [orc.Dtmf(0) for _ in range(n_ch)]
+    pos = np.zeros(n_ch, np.int64)
+    rng = np.random.default_rng(99)
+    g = [[] for _ in range(n_ch)]
+    o = [[] for _ in range(n_ch)]
+    for lens in _var_ticks(n_ch, n_ticks, 5, ragged):
+        frames = rng.integers(-20000, 20000, (n_ch, 160)).astype(np.int16)     # what a row holds beyond lens[c] is never read
+        for c in range(n_ch):
+            frames[c, :lens[c]] = sig[c, pos[c]:pos[c] + lens[c]]
+        bank.rx_host_var(frames, lens)
+        blk = bank.blocks()
+        tr = bank.trace(max_blocks=4) if blk.size else None
+        for r in blk:
+            assert lens[r["channel"]] > 0
+            g[r["channel"]].append((int(r["hit"]), int(r["code"]), int(r["flags"]), int(r["duration"]), np.float32(r["energy"]),
+                                    tr[r["block"], :, r["channel"]].copy()))
+        for c in range(n_ch):
+            if lens[c]:
+                o[c].extend(list(dets[c].rx(sig[c, pos[c]:pos[c] + lens[c]])))
+        pos += lens
+    check_blocks(g, o, 8, "dtmf-var")
+    _dtmf_state_check(bank, dets, "dtmf-var")
+    assert sum(len(x) for x in g) > 50*n_ch
+    # wrong lengths are refused before anything runs
+    bad = np.full(n_ch, 160, np.int32)
+    bad[7] = 161
+    with pytest.raises(engine.SpanGpuError):
+        bank.rx_host_var(np.zeros((n_ch, 160), np.int16), bad)
+    bank.rx_host_var(np.zeros((n_ch, 160), np.int16), np.zeros(n_ch, np.int32))        # an empty tick is no tick
+    _dtmf_state_check(bank, dets, "dtmf-var-empty")
+
+
+def test_dtmf_parameters_per_channel(built):
+    """spangpu_bank_set_channel_params() = dtmf_rx_parms() on one detector of the bank (dtmf.c:421-445): dial tone filter,
+    twists (0 dB included) and threshold differ between channels of one launch, and change in mid-call."""
+    from spandsp_amd import engine
+    n_ch = 150
+    sig, _ = synth.dtmf_channels(n_ch, 160*50, seed=23)
+    t = np.arange(sig.shape[1])
+    dial = 3000.0*np.sin(2*np.pi*350.0*t/8000.0) + 3000.0*np.sin(2*np.pi*440.0*t/8000.0)
+    sig = np.clip(sig.astype(np.float64) + dial, -32768, 32767).astype(np.int16)
+    at_start = {c: dict(filter_dialtone=1) for c in range(0, n_ch, 3)}
+    at_start.update({c: dict(filter_dialtone=1, twist=0.0, reverse_twist=0.0, threshold=-30.0) for c in range(1, n_ch, 7)})
+    at_start.update({c: dict(twist=12.0, threshold=0.0) for c in range(2, n_ch, 11)})
+    later = {20: {c: dict(filter_dialtone=0) for c in range(0, n_ch, 6)}, 31: {5: dict(filter_dialtone=1, twist=3.0), 149: dict(threshold=-50.0)}}
+    gp = lambda d: dict(filter_dialtone=d.get("filter_dialtone", -1), twist_db=d.get("twist", -1.0),
+                        reverse_twist_db=d.get("reverse_twist", -1.0), threshold_dbm0=d.get("threshold", -99.0))
+
+    def ghook(fi, bank):
+        for c, d in (at_start if fi == 0 else later.get(fi, {})).items():
+            bank.set_channel_params(c, **gp(d))
+
+    def ohook(fi, dets):
+        for c, d in (at_start if fi == 0 else later.get(fi, {})).items():
+            dets[c].parms(**d)
+
+    bank = engine.ToneBank(engine.DTMF, n_ch, trace=True)
+    g = run_gpu(bank, sig, [160], hook=ghook)
+    dets, o = _dtmf_oracle(sig, [160], hook=ohook)
+    check_blocks(g, o, 8, "dtmf-chan-parms")
+    _dtmf_state_check(bank, dets, "dtmf-chan-parms")
+    for c, d in enumerate(dets):
+        f, i = bank.get_state(c)
+        sn = d.snapshot()
+        assert np.array_equal(f32_bits(f[17:19]), f32_bits(sn["z350"])) and np.array_equal(f32_bits(f[19:21]), f32_bits(sn["z440"])), c
+    n_diff = sum(1 for c in range(n_ch) if [b[1] for b in g[c]] != [b[1] for b in g[(c + 3) % n_ch]])
+    assert n_diff > 0
+    with pytest.raises(engine.SpanGpuError):
+        engine.ToneBank(engine.BELL_MF, 8).set_channel_params(0, twist_db=3.0)
+
+
+def test_dtmf_zero_db_parameters_through_set_mask(built):
+    """A 0 dB twist or 0 dBm0 threshold is a value, not "unset", once set_mask names the field."""
+    from spandsp_amd import engine
+    n_ch = 64
+    sig, _ = synth.dtmf_channels(n_ch, 160*30, seed=24)
+    bank = engine.ToneBank(engine.DTMF, n_ch, twist_db=0.0, reverse_twist_db=6.0, threshold_dbm0=0.0, trace=True,
+                           set_mask=engine.TP_TWIST | engine.TP_REVERSE_TWIST)
+    g = run_gpu(bank, sig, [160])
+    dets, o = _dtmf_oracle(sig, [160], parms=dict(twist=0.0, reverse_twist=6.0))
+    check_blocks(g, o, 8, "dtmf-mask")
+    assert dets[0].snapshot()["normal_twist"] == 1.0
+
+
 def test_dtmf_sample_major_layout(built):
     from spandsp_amd import engine
     n_ch = 70

@@ -157,7 +157,7 @@ def bench_awgn(args, dev, stream):
         "realtime_channels": value*1e6/8000.0, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt*1e3/args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic", "config": {"workload": "awgn bank, %d channels x %d-sample frames" % (n_ch, FRAME),
-                                        "channels_per_gpu": n_ch, "rms_of_last_frames": rms, "uncertain_samples": bank.uncertain()},
+                                        "channels_per_gpu": n_ch, "rms_of_last_frames": rms},
         "roofline": {"bound": "hbm", "kernel": "awgn_bank_kernel", "achieved": alg/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": alg/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None, "alg_bytes_per_launch": alg,
                      "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3,
