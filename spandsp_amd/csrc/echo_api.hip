@@ -9,6 +9,7 @@
 
 #include "../../include/spangpu.h"
 #include "echo_dev.hpp"
+#include "echo_pair.hpp"
 
 using namespace spg;
 
@@ -75,8 +76,8 @@ extern "C" {
 // Tuning / A-B testing: lanes per channel of banks created from now on (0 = choose by length, 8, 16).
 int spangpu_tune_echo_lanes_per_channel(int lanes)
 {
-    if (lanes != 0  &&  lanes != 4  &&  lanes != 8  &&  lanes != 16)
-        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "lanes per channel must be 0 (auto), 4, 8 or 16");
+    if (lanes != 0  &&  lanes != 2  &&  lanes != 4  &&  lanes != 8  &&  lanes != 16)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "lanes per channel must be 0 (auto), 2, 4, 8 or 16");
     g_echo_group = lanes;
     return SPANGPU_OK;
 }
@@ -101,12 +102,17 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     e->taps = taps;
     // Lanes per channel.  The scalar control of echo_can_update() is replicated in a channel's lanes, so the fewer lanes a
     // channel has the more channels share each control instruction; a small bank wants the opposite -- more,
-    // narrower-sliced waves, so that every SIMD has some.  Measured, 128 taps, kernel time in us for 16 / 8 / 4 lanes:
-    // 4096 channels 100 / 118 / 104, 8192: 131 / 122 / 122, 16384: 182 / 153 / 183, 32768: 300 / 247 / 303,
-    // 65536: - / 418 / 540 (4096 four-lane waves are one and a third rounds of three per SIMD), 131072: 977 / 747 / 633.
-    // Slices are at most 32 taps (four lanes) or 16 taps per lane.
+    // narrower-sliced waves, so that every SIMD has some.  Measured, 128 taps, kernel time in us per 160-sample frame for
+    // 16 / 8 / 4 / 2 lanes (tools/echo_ab.py; two lanes = echo_pair.hpp, the 16-bit quantities packed in pairs):
+    // 4096 channels 100 / 118 / 104 / -, 8192: 131 / 122 / 122 / -, 16384: 182 / 153 / 183 / -, 32768: 300 / 218 / 303 / 210,
+    // 65536: - / 386 / 540 / 298, 131072: 977 / 747 / 599 / 596.  VALU instructions per channel and sample (SQ_INSTS_VALU,
+    // profiles/r2_echo_pmc.txt): 23.1 at eight lanes, 15.6 at four, 10.7 at two; the two-lane kernel holds 256 registers,
+    // so two waves per SIMD, and keeps the VALU 64 % busy where the others reach ~100 % -- its remaining distance.
+    // Slices are at most 32 taps (four lanes) or 16 taps per lane; two lanes take 32, 64 or 128 taps.
     // spangpu_tune_echo_lanes_per_channel() overrides for A-B tests.
-    e->group = (g_echo_group != 0)  ?  g_echo_group  :  (n_channels >= 131072)  ?  4  :  (n_channels >= 8192)  ?  8  :  16;
+    e->group = (g_echo_group != 0)  ?  g_echo_group  :  (n_channels >= 32768)  ?  2  :  (n_channels >= 8192)  ?  8  :  16;
+    if (e->group == 2  &&  taps != 128  &&  taps != 64  &&  taps != 32)
+        e->group = (g_echo_group != 0  ||  n_channels >= 131072)  ?  4  :  8;
     if (e->group == 4  &&  (taps/4 < 2  ||  taps/4 > 32))
         e->group = 8;
     if (e->group == 8  &&  (taps/8 < 2  ||  taps/8 > 16))
@@ -264,7 +270,16 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
     const int per_wave = 64/e->group;
     const int waves = (e->n_ch + per_wave - 1)/per_wave;
     const int blocks = (waves + 3)/4;
-    if (e->group == 4)
+    if (e->group == 2)
+    {
+        switch (e->tpl)
+        {
+        case 16: hipLaunchKernelGGL(echo_pair_kernel<16>, dim3(blocks), dim3(256), 0, e->stream, L); break;
+        case 32: hipLaunchKernelGGL(echo_pair_kernel<32>, dim3(blocks), dim3(256), 0, e->stream, L); break;
+        default: hipLaunchKernelGGL(echo_pair_kernel<64>, dim3(blocks), dim3(256), 0, e->stream, L); break;
+        }
+    }
+    else if (e->group == 4)
     {
         switch (e->tpl)
         {

@@ -189,6 +189,13 @@ __device__ __forceinline__ int row_sum4(int v)
     return v;
 }
 
+// Sum over a pair of lanes, result in both (echo_pair.hpp).
+__device__ __forceinline__ int row_sum2(int v)
+{
+    v += dpp_mov<0xB1>(0, v);       // quad_perm [1,0,3,2]
+    return v;
+}
+
 template <int G>
 __device__ __forceinline__ int group_sum(int v)
 {

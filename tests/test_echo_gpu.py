@@ -78,6 +78,11 @@ def compare_state(bank, dets, what):
     (128, 0x01, [160], 4),
     (64, 0x01 | 0x02, [160, 1, 31], 4),
     (32, 0x01 | 0x20 | 0x40, [160], 4),
+    # two lanes per channel, 16-bit quantities packed in pairs (echo_pair.hpp; the default for big banks)
+    (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 2),
+    (128, 0x01, [160, 1, 31], 2),
+    (64, 0x01 | 0x02 | 0x04, [160], 2),
+    (32, 0x01 | 0x20 | 0x40, [160, 3], 2),
 ])
 def test_echo_bank_parity(built, taps, mode, sizes, lanes):
     from oracle import restated as orc
