@@ -96,7 +96,18 @@ typedef struct
     int32_t set_mask;           /* DTMF: SPANGPU_TP_* -- which of twist_db / reverse_twist_db / threshold_dbm0 are
                                    meant as given, 0 dB and 0 dBm0 included, under dtmf_rx_parms()'s own tests
                                    (twists >= 0, threshold > -99).  0 = the rules in the field comments above.   */
+    int32_t functor;            /* GOERTZEL: SPANGPU_FUNCTOR_* -- which raw block decision goes into a block's `hit`     */
+    float functor_threshold;    /* GOERTZEL, SPANGPU_FUNCTOR_V18: the object's level threshold (v18_state_t.threshold)     */
 } spangpu_tone_params_t;
+
+/* Raw block decisions of the reference's Goertzel users outside tone_detect.c, made on the device from a generic bank's
+   bin energies and block energy (the caller's debounce / protocol logic stays on the host, fed by spangpu_block_t.hit):
+     SPANGPU_FUNCTOR_V18     src/v18.c:1580-1600 (and :1721-1741): bins = the nine tone set frequencies, block_len 102;
+                             hit = index of the tone seen, 0 = none (and tone 0: the reference does not tell them apart)
+     SPANGPU_FUNCTOR_ADEMCO  src/ademco_contactid.c:915-935: bins = 1400 Hz, 2300 Hz, block_len 55; hit = 1, 2 or 0 */
+#define SPANGPU_FUNCTOR_NONE        0
+#define SPANGPU_FUNCTOR_V18         1
+#define SPANGPU_FUNCTOR_ADEMCO      2
 
 #define SPANGPU_TP_TWIST            0x01
 #define SPANGPU_TP_REVERSE_TWIST    0x02

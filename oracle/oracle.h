@@ -679,6 +679,11 @@ typedef struct
     double r[97];
 } orc_awgn_t;
 
+/* raw block decisions of the Goertzel users outside tone_detect.c (tone_oracle.c) */
+ORC_API int orc_v18_tone_decide(const float e[], int n, float total, float threshold);
+ORC_API int orc_ademco_tone_decide(float e1400, float e2300, float total);
+ORC_API void orc_tone_functor_blocks(int kind, const float freqs[], int n_freqs, int block_len, float threshold,
+                                     const int16_t amp[], int n_blocks, int32_t decisions[]);
 ORC_API int orc_awgn_sizeof(void);
 /* GNU libc's binary64 log() as the x86-64 FMA build computes it (glibc_log.c) -- what awgn() calls */
 ORC_API double orc_glibc_log(double x);

@@ -687,6 +687,29 @@ FSK_PRESETS = ["V21CH1", "V21CH2", "V23CH1", "V23CH2", "BELL103CH1", "BELL103CH2
                "WEITBRECHT_50", "WEITBRECHT_476", "V21CH1_110"]
 
 
+def v18_tone_blocks(amp):
+    """in_tone after every 102-sample block of amp through v18_rx() (caller_tone_scan), and the object's threshold."""
+    amp = _i16(amp)
+    nb = len(amp)//102
+    out = np.zeros(nb, np.int32)
+    lib().glue_v18_tone_blocks.restype = C.c_float
+    lib().glue_v18_tone_blocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    with quiet_stdout():
+        thr = lib().glue_v18_tone_blocks(amp.ctypes.data, nb, out.ctypes.data)
+    return out, float(thr)
+
+
+def ademco_tone_blocks(amp):
+    """last_hit after every 55-sample block of amp through ademco_contactid_sender_rx()."""
+    amp = _i16(amp)
+    nb = len(amp)//55
+    out = np.zeros(nb, np.int32)
+    lib().glue_ademco_tone_blocks.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    with quiet_stdout():
+        assert lib().glue_ademco_tone_blocks(amp.ctypes.data, nb, out.ctypes.data) == 0
+    return out
+
+
 def fsk_preset(which):
     out = np.zeros(5, np.int32)
     assert lib().glue_fsk_preset(which, out.ctypes.data) == 0

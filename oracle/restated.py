@@ -304,6 +304,24 @@ def goertzel_fac(freq):
     return lib().orc_goertzel_fac(freq)
 
 
+V18_TONE_SET = [390.0, 980.0, 1180.0, 1270.0, 1300.0, 1400.0, 1650.0, 1800.0, 2225.0]      # v18.c:200-211
+ADEMCO_TONE_SET = [1400.0, 2300.0]                                                           # ademco_contactid.c:1179-1180
+
+
+def tone_functor_blocks(kind, amp, threshold=0.0):
+    """Raw block decisions of the v18.c (kind 1, 102-sample blocks) or ademco_contactid.c (kind 2, 55) tone scan over the
+    whole blocks of amp."""
+    freqs = np.array(V18_TONE_SET if kind == 1 else ADEMCO_TONE_SET, np.float32)
+    block = 102 if kind == 1 else 55
+    amp = _i16(amp)
+    nb = len(amp)//block
+    out = np.zeros(nb, np.int32)
+    L = lib()
+    L.orc_tone_functor_blocks.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_tone_functor_blocks(kind, freqs.ctypes.data, len(freqs), block, threshold, amp.ctypes.data, nb, out.ctypes.data)
+    return out
+
+
 ECHO_FIELDS = ["tx_power0", "tx_power1", "tx_power2", "tx_power3", "rx_power0", "rx_power1", "rx_power2",
                "clean_rx_power", "rx_power_threshold", "nonupdate_dwell", "curr_pos", "taps", "tap_mask",
                "adaption_mode", "supp_test1", "supp_test2", "supp1", "supp2", "vad", "cng", "geigel_max",

@@ -997,3 +997,75 @@ int16_t orc_alaw_to_linear(uint8_t alaw)
         i += 8;
     return (int16_t) ((alaw & 0x80)  ?  i  :  -i);
 }
+
+/* ---- the Goertzel users outside tone_detect.c: raw block decisions ---------------------------- */
+
+/* src/v18.c:1580-1600 (caller_tone_scan; answerer_tone_scan :1721-1741 is the same): the strongest of the n tone set
+   energies by a strict > scan from zero, then the level test against the object's threshold (never assigned in this
+   snapshot: 0) and the fraction-of-total-energy test (tone_to_total_energy = 83.868, :192).  0 stands for "no tone" and
+   for tone set entry 0 alike, as in the reference. */
+ORC_API int orc_v18_tone_decide(const float e[], int n, float total, float threshold)
+{
+    float best = 0.0f;
+    int at = 0;
+
+    for (int i = 0;  i < n;  i++)
+    {
+        if (e[i] > best)
+        {
+            best = e[i];
+            at = i;
+        }
+    }
+    if (best < threshold  ||  best <= 83.868f*total)
+        at = 0;
+    return at;
+}
+
+/* src/ademco_contactid.c:915-935: 1 = 1400 Hz, 2 = 2300 Hz, 0 = neither (detection_threshold :461, tone_to_total_energy :462) */
+ORC_API int orc_ademco_tone_decide(float e1400, float e2300, float total)
+{
+    int hit = 0;
+
+    if (e1400 > 49728296.6f  ||  e2300 > 49728296.6f)
+    {
+        if (e1400 > e2300)
+        {
+            if (e1400 > 45.2233f*total)
+                hit = 1;
+        }
+        else
+        {
+            if (e2300 > 45.2233f*total)
+                hit = 2;
+        }
+    }
+    return hit;
+}
+
+/* One detector of either kind over whole blocks: decisions[b] for n_blocks blocks of block_len samples */
+ORC_API void orc_tone_functor_blocks(int kind, const float freqs[], int n_freqs, int block_len, float threshold,
+                                     const int16_t amp[], int n_blocks, int32_t decisions[])
+{
+    orc_goertzel_t g[16];
+    float e[16];
+
+    for (int i = 0;  i < n_freqs;  i++)
+        orc_goertzel_init(&g[i], freqs[i], block_len);
+    for (int b = 0;  b < n_blocks;  b++)
+    {
+        float total = 0.0f;
+        for (int j = 0;  j < block_len;  j++)
+        {
+            const float x = amp[b*block_len + j];
+            total += x*x;
+        }
+        for (int i = 0;  i < n_freqs;  i++)
+        {
+            orc_goertzel_update(&g[i], amp + b*block_len, block_len);
+            e[i] = orc_goertzel_result(&g[i]);
+            orc_goertzel_init(&g[i], freqs[i], block_len);
+        }
+        decisions[b] = (kind == 1)  ?  orc_v18_tone_decide(e, n_freqs, total, threshold)  :  orc_ademco_tone_decide(e[0], e[1], total);
+    }
+}

@@ -407,8 +407,11 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
     if (stride <= 0)
         stride = samples;
     V29_TRY(hipSetDevice(m->device));
-    // at most 4 (V.17: 6) bits per baud, a baud every 8000/2400 samples, plus a handful of status events
-    const int cap = ((samples*3*((m->kind == SPANGPU_V17)  ?  6  :  4) + 9)/10 + 8 + 15) & ~15;
+    // at most 4 (V.17: 6) bits per baud and nominally a baud every 8000/2400 samples; symbol timing recovery can run the
+    // baud clock fast by up to 5/160 of a baud per baud, so 1/16 more bauds than nominal are provided for, plus room
+    // for every status report a call can make.  spangpu_modem_events() refuses to hand out a stream that did not fit.
+    const int bauds = (samples*3 + 9)/10;
+    const int cap = ((bauds + bauds/16 + 2)*((m->kind == SPANGPU_V17)  ?  6  :  4) + 16 + 15) & ~15;
     if (cap > m->ev_cap)
     {
         if (m->events) (void) hipFree(m->events);
@@ -633,6 +636,11 @@ int spangpu_modem_events(spangpu_modem_t *m, const int8_t **events, const int32_
     V29_TRY(hipMemcpyAsync(m->h_events, m->events, (size_t) m->n_ch*m->last_cap, hipMemcpyDeviceToHost, m->stream));
     V29_TRY(hipMemcpyAsync(m->h_count, m->ev_count, (size_t) m->n_ch*sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
     V29_TRY(hipStreamSynchronize(m->stream));
+    for (int c = 0;  c < m->n_ch;  c++)
+    {
+        if (m->h_count[c] > m->last_cap)
+            return spangpu_set_error(SPANGPU_ERR_STATE, "modem event buffer overflow: a channel produced more events than the call's frame length allows");
+    }
     *events = m->h_events;
     *counts = m->h_count;
     return m->last_cap;

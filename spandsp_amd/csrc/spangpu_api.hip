@@ -387,6 +387,12 @@ int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_chann
             free(b);
             return fail(SPANGPU_ERR_BAD_ARG, "block_len %d out of range", b->block_len);
         }
+        if (kind == SPANGPU_GOERTZEL  &&  (b->tp.functor < 0  ||  b->tp.functor > SPANGPU_FUNCTOR_ADEMCO
+                                           ||  (b->tp.functor == SPANGPU_FUNCTOR_ADEMCO  &&  m != 2)))
+        {
+            free(b);
+            return fail(SPANGPU_ERR_BAD_ARG, "functor %d does not fit a bank of %d bins", b->tp.functor, m);
+        }
         for (int i = 0;  i < m;  i++)
             b->fac[i] = b->tp.bin_fac[i];
         break;
@@ -492,6 +498,8 @@ static void fill_launch(ToneLaunch &L, spangpu_bank_t *b, const int16_t *d_amp, 
     L.lens = b->next_lens;
     L.lens_ragged = (b->next_lens  &&  b->next_ragged)  ?  1  :  0;
     L.chan_parms = b->chan_parms;
+    L.functor = (b->kind == SPANGPU_GOERTZEL)  ?  b->tp.functor  :  0;
+    L.functor_threshold = b->tp.functor_threshold;
     {
         const int spc = L.fmt  ?  16  :  8;                 // samples per 16 bytes
         L.aligned16 = (layout == SPANGPU_LAYOUT_CHANNEL_MAJOR

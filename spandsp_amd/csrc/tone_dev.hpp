@@ -65,6 +65,8 @@ struct ToneLaunch
     long long *probe_ts;        // tools/probe.hip only: per-wave timestamps (kernels built with ABL & 32)
     const int32_t *lens;        // nullptr: every channel has `samples`; else samples per channel in this call (0 = the
                                 // channel sits this call out: its state and block phase are not touched)
+    int functor;                // generic bank: 0 none, 1 v18.c's raw block decision, 2 ademco_contactid.c's (include/spangpu.h)
+    float functor_threshold;
     int lens_ragged;            // host side only: lengths other than 0 and `samples` occur (the general kernel takes the call)
     const float *chan_parms;    // nullptr: threshold / twists / dial tone filter as set for the bank; else DTMF
                                 // per channel, [4][n_ch]: threshold, normal twist, reverse twist, filter on (0 / 1)
@@ -682,7 +684,37 @@ struct MultiDet
                 if (L.trace)
                     write_trace<NB>(L, ein, energy, ch, nb);
             }
-            recw = make_rec(0, 0, kBlkValid);
+            int hit = 0;
+            if (L.functor == 1)
+            {
+                // v18.c:1580-1600: strongest bin by a strict > scan from zero, level test, fraction-of-total test
+                float best = 0.0f;
+#pragma unroll
+                for (int i = 0;  i < NB;  i++)
+                {
+                    if (i < m  &&  ein[i] > best)
+                    {
+                        best = ein[i];
+                        hit = i;
+                    }
+                }
+                if (best < L.functor_threshold  ||  best <= 83.868f*energy)     // v18.c:192
+                    hit = 0;
+            }
+            else if (L.functor == 2)
+            {
+                // ademco_contactid.c:915-935 (constants :461-462)
+                const float e1400 = ein[0];
+                const float e2300 = ein[(NB > 1)  ?  1  :  0];
+                if (e1400 > 49728296.6f  ||  e2300 > 49728296.6f)
+                {
+                    if (e1400 > e2300)
+                        hit = (e1400 > 45.2233f*energy)  ?  1  :  0;
+                    else
+                        hit = (e2300 > 45.2233f*energy)  ?  2  :  0;
+                }
+            }
+            recw = make_rec(hit, 0, kBlkValid);
             energy = 0.0f;
         }
         w0 = 0;

@@ -26,10 +26,12 @@ class ToneParams(C.Structure):
     _fields_ = [("report_mode", C.c_int32), ("filter_dialtone", C.c_int32),
                 ("twist_db", C.c_float), ("reverse_twist_db", C.c_float), ("threshold_dbm0", C.c_float),
                 ("r2_fwd", C.c_int32), ("n_bins", C.c_int32), ("block_len", C.c_int32),
-                ("bin_fac", C.c_float*MAX_BINS), ("trace", C.c_int32), ("set_mask", C.c_int32)]
+                ("bin_fac", C.c_float*MAX_BINS), ("trace", C.c_int32), ("set_mask", C.c_int32),
+                ("functor", C.c_int32), ("functor_threshold", C.c_float)]
 
 
 TP_TWIST, TP_REVERSE_TWIST, TP_THRESHOLD = 1, 2, 4
+FUNCTOR_NONE, FUNCTOR_V18, FUNCTOR_ADEMCO = 0, 1, 2
 
 
 class SpanGpuError(RuntimeError):
@@ -207,9 +209,11 @@ class ToneBank:
 
     def __init__(self, kind, n_channels, device=0, report_mode=REPORT_DIGITS, filter_dialtone=False,
                  twist_db=0.0, reverse_twist_db=0.0, threshold_dbm0=0.0, r2_fwd=True,
-                 bin_fac=None, block_len=0, trace=False, set_mask=0):
+                 bin_fac=None, block_len=0, trace=False, set_mask=0, functor=FUNCTOR_NONE, functor_threshold=0.0):
         p = ToneParams()
         p.set_mask = set_mask
+        p.functor = functor
+        p.functor_threshold = functor_threshold
         p.report_mode = report_mode
         p.filter_dialtone = int(filter_dialtone)
         p.twist_db = twist_db

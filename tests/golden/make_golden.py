@@ -170,6 +170,13 @@ def main():
         kw["amp_%d" % i] = ref.awgn(seed, level, 30001)
         kw["state_%d" % i] = ref.awgn_state_words(seed, level, 30001)
     save("awgn", **kw)
+    from test_oracle_pin import FUNCTOR_CASES, functor_signal, zlib_crc
+    kw = {}
+    for i, (kind, n_blocks, seed) in enumerate(FUNCTOR_CASES):
+        x = functor_signal(kind, seed, n_blocks)
+        kw["crc_%d" % i] = np.uint32(zlib_crc(x))
+        kw["hits_%d" % i] = ref.v18_tone_blocks(x)[0] if kind == 1 else ref.ademco_tone_blocks(x)
+    save("tone_functors", **kw)
     amp, lens, puts = tx_scenario({"tone": ref.ToneGen, "dtmf": ref.DtmfTx, "bell": ref.BellMfTx, "r2": ref.R2MfTx}, 5)
     save("tx_sources", seed=5, amp=amp, lens=lens, puts=puts)
 

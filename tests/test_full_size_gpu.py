@@ -55,8 +55,15 @@ def test_mixed_banks_131072_channels(built):
     n_each = [43690, 43690, 43692]
     srcs = [synth.bell_mf_channels(V, n_frames*160, 31)[0], synth.r2_mf_channels(V, n_frames*160, 32, True)[0],
             synth.call_progress_channels(V, n_frames*160, 33)]
-    st_freqs = [350.0, 400.0, 440.0, 480.0, 620.0, 950.0, 1100.0, 1400.0]
-    fac = [engine.goertzel_fac(f) for f in st_freqs]
+    # the call-progress plan of the third bank as a super-tone descriptor: 8 monitored frequencies
+    desc = orc.SuperToneDesc()
+    for tone in ([(400, 0, 700, 0)], [(1100, 0, 400, 600), (0, 0, 2800, 3200)], [(350, 440, 400, 0)],
+                 [(480, 620, 450, 550), (0, 0, 450, 550)], [(950, 0, 300, 0)], [(1400, 0, 300, 0)]):
+        t = desc.add_tone()
+        for f1, f2, lo, hi in tone:
+            desc.add_element(t, f1, f2, lo, hi)
+    fac = [float(f) for f in desc.fac]
+    assert len(fac) == 8
     banks = [engine.ToneBank(engine.BELL_MF, n_each[0]), engine.ToneBank(engine.R2_MF, n_each[1], r2_fwd=True),
              engine.ToneBank(engine.SUPER_TONE, n_each[2], bin_fac=fac)]
     hits = 0
@@ -88,7 +95,7 @@ def test_mixed_banks_131072_channels(built):
             elif kind == 1:
                 o = orc.R2Mf(True, True)
             else:
-                continue
+                o = orc.SuperTone(desc)
             blocks = []
             for k in range(n_frames):
                 blocks.extend(o.rx(srcs[kind][c, k*160:(k + 1)*160]))

@@ -762,6 +762,56 @@ def test_golden_v17_tx(built):
         assert np.array_equal(snaps, g["snaps_%d" % i]), i
 
 
+# ---- the Goertzel users outside tone_detect.c -----------------------------------
+def zlib_crc(a):
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def functor_signal(kind, seed, n_blocks):
+    """Bursts of the kind's tones (+-1.5 % off frequency, -45 .. -8 dBm0) in noise: whole blocks of 102 (v18) / 55 (ademco)."""
+    from oracle import restated as orc
+    freqs, block = (orc.V18_TONE_SET, 102) if kind == 1 else (orc.ADEMCO_TONE_SET, 55)
+    rng = np.random.default_rng(seed)
+    n = block*n_blocks
+    t = np.arange(n)
+    x = np.zeros(n)
+    for k in range(0, n, 1500):
+        f = freqs[int(rng.integers(0, len(freqs)))]*float(rng.uniform(0.985, 1.015))
+        on = int(rng.integers(300, 1400))
+        x[k:k + on] += synth.dbm0_to_amp(rng.uniform(-45.0, -8.0))*np.sin(2*np.pi*f*t[k:k + on]/8000.0 + rng.uniform(0, 6.28))
+    x += rng.normal(0.0, rng.uniform(2.0, 60.0), n)
+    return np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+
+
+FUNCTOR_CASES = [(1, 300, s) for s in range(6)] + [(2, 500, 100 + s) for s in range(6)]
+
+
+@needs_ref
+@pytest.mark.parametrize("kind,n_blocks,seed", FUNCTOR_CASES)
+def test_tone_functors_live(built, kind, n_blocks, seed):
+    """The raw block decision of v18.c's caller tone scan (in_tone after every block of v18_rx()) and of the Ademco sender's
+    handshake detector (last_hit after every block of ademco_contactid_sender_rx()), from the reference itself."""
+    from oracle import ref, restated as orc
+    x = functor_signal(kind, seed, n_blocks)
+    if kind == 1:
+        want, threshold = ref.v18_tone_blocks(x)
+        assert threshold == 0.0                 # v18_state_t.threshold is never assigned in this snapshot
+    else:
+        want, threshold = ref.ademco_tone_blocks(x), 0.0
+    assert np.array_equal(orc.tone_functor_blocks(kind, x, threshold), want)
+    assert np.count_nonzero(want) > n_blocks//8
+
+
+def test_golden_tone_functors(built):
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, "tone_functors.npz"))
+    for i, (kind, n_blocks, seed) in enumerate(FUNCTOR_CASES):
+        x = functor_signal(kind, seed, n_blocks)
+        assert int(g["crc_%d" % i]) == zlib_crc(x)
+        assert np.array_equal(orc.tone_functor_blocks(kind, x, 0.0), g["hits_%d" % i]), i
+
+
 # ---- AWGN ---------------------------------------------------------------------------------------
 AWGN_CASES = [(1234567, -30.0), (1, -10.5), (-77, -50.0), (99999, 0.0), (0, 6.0), (424242, -90.0), (7, -35.25)]
 

@@ -591,6 +591,34 @@ def test_goertzel_bank_serves_the_other_goertzel_users(built, name, freqs, block
     assert hits > n_ch
 
 
+@pytest.mark.parametrize("kind", [1, 2], ids=["v18", "ademco"])
+def test_goertzel_bank_functors(built, kind):
+    """The raw block decisions of v18.c's tone scan and of the Ademco sender's handshake detector made on the device
+    (spangpu_tone_params_t.functor): a block's `hit` equals the oracle's decision (oracle/tone_oracle.c, held to the
+    reference's own in_tone / last_hit in test_oracle_pin.py), across frames that cut the blocks anywhere."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    from test_oracle_pin import functor_signal
+    freqs, block = (orc.V18_TONE_SET, 102) if kind == 1 else (orc.ADEMCO_TONE_SET, 55)
+    n_ch, n_blocks = 100, 160
+    sig = np.stack([functor_signal(kind, 1000*kind + c, n_blocks) for c in range(n_ch)])
+    bank = engine.ToneBank(engine.GOERTZEL, n_ch, bin_fac=[engine.goertzel_fac(f) for f in freqs], block_len=block,
+                           functor=kind, functor_threshold=0.0)
+    got = [[] for _ in range(n_ch)]
+    for pos, m in frames_of(sig.shape[1], [160, 33, 160, 401]):
+        bank.rx_host(sig[:, pos:pos + m])
+        for r in bank.blocks():
+            got[r["channel"]].append(int(r["hit"]))
+    hits = 0
+    for c in range(n_ch):
+        want = orc.tone_functor_blocks(kind, sig[c], 0.0)
+        assert np.array_equal(np.array(got[c], np.int32), want), (c, np.nonzero(np.array(got[c]) != want)[0][:5])
+        hits += int(np.count_nonzero(want))
+    assert hits > 10*n_ch
+    with pytest.raises(engine.SpanGpuError):
+        engine.ToneBank(engine.GOERTZEL, 4, bin_fac=[1.0, 1.1, 1.2], block_len=55, functor=engine.FUNCTOR_ADEMCO)
+
+
 # --------------------------------------------------------------------------------------
 # several banks in one launch
 # --------------------------------------------------------------------------------------
