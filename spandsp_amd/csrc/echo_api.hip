@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "../../include/spangpu.h"
+#include "../../include/spangpu_refstate.h"
 #include "echo_dev.hpp"
 #include "echo_pair.hpp"
 
@@ -406,6 +407,140 @@ int spangpu_echo_set_state(spangpu_echo_t *e, int channel, const int32_t *scal, 
             w[i] = history[(i + scal[ES_CURR_POS] + 1)%T];
         ECHO_TRY(hipMemcpy(e->hist + (size_t) channel*T, w, T*sizeof(int16_t), hipMemcpyHostToDevice));
     }
+    return SPANGPU_OK;
+}
+
+// ---- a channel's state in the reference's own struct layout (include/spangpu_refstate.h) ----------------------------
+static void echo_words_from_ref(const spangpu_ref_echo_can_t *ec, int32_t *s)
+{
+    memset(s, 0, kEchoScalars*sizeof(int32_t));
+    for (int i = 0;  i < 4;  i++)
+        s[ES_TX_POWER0 + i] = ec->tx_power[i];
+    for (int i = 0;  i < 3;  i++)
+        s[ES_RX_POWER0 + i] = ec->rx_power[i];
+    s[ES_CLEAN_RX_POWER] = ec->clean_rx_power;
+    s[ES_RX_POWER_THRESHOLD] = ec->rx_power_threshold;
+    s[ES_NONUPDATE_DWELL] = ec->nonupdate_dwell;
+    s[ES_CURR_POS] = ec->curr_pos;
+    s[ES_TAPS] = ec->taps;
+    s[ES_TAP_MASK] = ec->tap_mask;
+    s[ES_ADAPTION_MODE] = ec->adaption_mode;
+    s[ES_SUPP_TEST1] = ec->supp_test1;
+    s[ES_SUPP_TEST2] = ec->supp_test2;
+    s[ES_SUPP1] = ec->supp1;
+    s[ES_SUPP2] = ec->supp2;
+    s[ES_VAD] = ec->vad;
+    s[ES_CNG] = ec->cng;
+    s[ES_GEIGEL_MAX] = ec->geigel_max;
+    s[ES_GEIGEL_LAG] = ec->geigel_lag;
+    s[ES_DTD_ONSET] = ec->dtd_onset;
+    s[ES_TAP_SET] = ec->tap_set;
+    s[ES_TAP_ROTATE_COUNTER] = ec->tap_rotate_counter;
+    s[ES_LATEST_CORRECTION] = ec->latest_correction;
+    s[ES_NARROWBAND_COUNT] = ec->narrowband_count;
+    s[ES_NARROWBAND_SCORE] = ec->narrowband_score;
+    s[ES_FIR_CURR_POS] = ec->fir_state.curr_pos;
+    s[ES_TX_HPF0] = ec->tx_hpf[0];
+    s[ES_TX_HPF1] = ec->tx_hpf[1];
+    s[ES_RX_HPF0] = ec->rx_hpf[0];
+    s[ES_RX_HPF1] = ec->rx_hpf[1];
+    s[ES_CNG_LEVEL] = ec->cng_level;
+    s[ES_CNG_RNDNUM] = ec->cng_rndnum;
+    s[ES_CNG_FILTER] = ec->cng_filter;
+    s[ES_FIR_SET] = ec->tap_set;
+    for (int i = 0;  i < 4;  i++)
+    {
+        if (ec->fir_state.coeffs == ec->fir_taps16[i])
+            s[ES_FIR_SET] = i;
+    }
+    for (int i = 0;  i < 9;  i++)
+        s[ES_LAST_ACF + i] = ec->last_acf[i];
+}
+
+int spangpu_echo_import_state(spangpu_echo_t *e, int channel, const spangpu_ref_echo_can_t *ec)
+{
+    if (e == nullptr  ||  ec == nullptr  ||  channel < 0  ||  channel >= e->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (ec->taps != e->taps  ||  ec->fir_taps32 == nullptr  ||  ec->fir_state.history == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "the canceller is of another length than the bank, or has no arrays");
+    const int T = e->taps;
+    int32_t s[kEchoScalars];
+    echo_words_from_ref(ec, s);
+    int16_t *sets = (int16_t *) malloc((size_t) 4*T*sizeof(int16_t));
+    if (sets == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "malloc");
+    for (int i = 0;  i < 4;  i++)
+    {
+        if (ec->fir_taps16[i])
+            memcpy(sets + (size_t) i*T, ec->fir_taps16[i], T*sizeof(int16_t));
+        else
+            memset(sets + (size_t) i*T, 0, T*sizeof(int16_t));
+    }
+    const int rc = spangpu_echo_set_state(e, channel, s, ec->fir_taps32, sets, ec->fir_state.history);
+    free(sets);
+    return rc;
+}
+
+int spangpu_echo_export_state(spangpu_echo_t *e, int channel, spangpu_ref_echo_can_t *ec)
+{
+    if (e == nullptr  ||  ec == nullptr  ||  channel < 0  ||  channel >= e->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (ec->taps != e->taps  ||  ec->fir_taps32 == nullptr  ||  ec->fir_state.history == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "the canceller is of another length than the bank, or has no arrays");
+    const int T = e->taps;
+    int32_t s[kEchoScalars];
+    int16_t *sets = (int16_t *) malloc((size_t) 4*T*sizeof(int16_t));
+    if (sets == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "malloc");
+    const int rc = spangpu_echo_get_state(e, channel, s, ec->fir_taps32, sets, ec->fir_state.history);
+    if (rc != SPANGPU_OK)
+    {
+        free(sets);
+        return rc;
+    }
+    for (int i = 0;  i < 4;  i++)
+    {
+        if (ec->fir_taps16[i])
+            memcpy(ec->fir_taps16[i], sets + (size_t) i*T, T*sizeof(int16_t));
+    }
+    free(sets);
+    for (int i = 0;  i < 4;  i++)
+        ec->tx_power[i] = s[ES_TX_POWER0 + i];
+    for (int i = 0;  i < 3;  i++)
+        ec->rx_power[i] = s[ES_RX_POWER0 + i];
+    ec->clean_rx_power = s[ES_CLEAN_RX_POWER];
+    ec->rx_power_threshold = s[ES_RX_POWER_THRESHOLD];
+    ec->nonupdate_dwell = s[ES_NONUPDATE_DWELL];
+    ec->curr_pos = s[ES_CURR_POS];
+    ec->tap_mask = s[ES_TAP_MASK];
+    ec->adaption_mode = s[ES_ADAPTION_MODE];
+    ec->supp_test1 = s[ES_SUPP_TEST1];
+    ec->supp_test2 = s[ES_SUPP_TEST2];
+    ec->supp1 = s[ES_SUPP1];
+    ec->supp2 = s[ES_SUPP2];
+    ec->vad = s[ES_VAD];
+    ec->cng = s[ES_CNG];
+    ec->geigel_max = (int16_t) s[ES_GEIGEL_MAX];
+    ec->geigel_lag = s[ES_GEIGEL_LAG];
+    ec->dtd_onset = s[ES_DTD_ONSET];
+    ec->tap_set = s[ES_TAP_SET];
+    ec->tap_rotate_counter = s[ES_TAP_ROTATE_COUNTER];
+    ec->latest_correction = s[ES_LATEST_CORRECTION];
+    ec->narrowband_count = s[ES_NARROWBAND_COUNT];
+    ec->narrowband_score = s[ES_NARROWBAND_SCORE];
+    ec->fir_state.curr_pos = s[ES_FIR_CURR_POS];
+    ec->fir_state.taps = T;
+    if (s[ES_FIR_SET] >= 0  &&  s[ES_FIR_SET] < 4  &&  ec->fir_taps16[s[ES_FIR_SET]])
+        ec->fir_state.coeffs = ec->fir_taps16[s[ES_FIR_SET]];
+    ec->tx_hpf[0] = s[ES_TX_HPF0];
+    ec->tx_hpf[1] = s[ES_TX_HPF1];
+    ec->rx_hpf[0] = s[ES_RX_HPF0];
+    ec->rx_hpf[1] = s[ES_RX_HPF1];
+    ec->cng_level = s[ES_CNG_LEVEL];
+    ec->cng_rndnum = s[ES_CNG_RNDNUM];
+    ec->cng_filter = s[ES_CNG_FILTER];
+    for (int i = 0;  i < 9;  i++)
+        ec->last_acf[i] = s[ES_LAST_ACF + i];
     return SPANGPU_OK;
 }
 

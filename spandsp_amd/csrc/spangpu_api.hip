@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include "../../include/spangpu.h"
+#include "../../include/spangpu_refstate.h"
 #include "tone_dev.hpp"
 #include "tone_fast.hpp"
 
@@ -697,6 +698,34 @@ int spangpu_bank_rx_var(spangpu_bank_t *b, const int16_t *amp, int mem, const in
     return rc;
 }
 
+// The per-channel parameter table of a DTMF bank, made on first use with the bank's values in every channel
+static int ensure_chan_parms(spangpu_bank_t *b)
+{
+    const size_t n = (size_t) b->n_ch;
+    if (b->chan_parms)
+        return SPANGPU_OK;
+    if ((b->h_chan_parms = (float *) malloc(4*n*sizeof(float))) == nullptr)
+        return fail(SPANGPU_ERR_NO_MEMORY, "malloc");
+    for (size_t c = 0;  c < n;  c++)
+    {
+        b->h_chan_parms[c] = b->threshold;
+        b->h_chan_parms[n + c] = b->normal_twist;
+        b->h_chan_parms[2*n + c] = b->reverse_twist;
+        b->h_chan_parms[3*n + c] = b->tp.filter_dialtone  ?  1.0f  :  0.0f;
+    }
+    b->n_filter_on = b->tp.filter_dialtone  ?  b->n_ch  :  0;
+    float *d = nullptr;
+    if (hipMalloc(&d, 4*n*sizeof(float)) != hipSuccess)
+    {
+        free(b->h_chan_parms);
+        b->h_chan_parms = nullptr;
+        return fail(SPANGPU_ERR_NO_MEMORY, "hipMalloc of per-channel parameters failed");
+    }
+    HIP_TRY(hipMemcpy(d, b->h_chan_parms, 4*n*sizeof(float), hipMemcpyHostToDevice));
+    b->chan_parms = d;
+    return SPANGPU_OK;
+}
+
 // Parameters of ONE channel of a DTMF bank: what dtmf_rx_parms() (dtmf.c:421-445) does to one detector.  The fields of
 // `params` that count are filter_dialtone (< 0: leave as it is; else the notch states of the channel restart, as in
 // dtmf.c:428-434), twist_db, reverse_twist_db and threshold_dbm0 under set_mask.  From the first such call on the bank
@@ -714,28 +743,9 @@ int spangpu_bank_set_channel_params(spangpu_bank_t *b, int channel, const spangp
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     const size_t n = (size_t) b->n_ch;
-    if (b->chan_parms == nullptr)
-    {
-        if ((b->h_chan_parms = (float *) malloc(4*n*sizeof(float))) == nullptr)
-            return fail(SPANGPU_ERR_NO_MEMORY, "malloc");
-        for (size_t c = 0;  c < n;  c++)
-        {
-            b->h_chan_parms[c] = b->threshold;
-            b->h_chan_parms[n + c] = b->normal_twist;
-            b->h_chan_parms[2*n + c] = b->reverse_twist;
-            b->h_chan_parms[3*n + c] = b->tp.filter_dialtone  ?  1.0f  :  0.0f;
-        }
-        b->n_filter_on = b->tp.filter_dialtone  ?  b->n_ch  :  0;
-        float *d = nullptr;
-        if (hipMalloc(&d, 4*n*sizeof(float)) != hipSuccess)
-        {
-            free(b->h_chan_parms);
-            b->h_chan_parms = nullptr;
-            return fail(SPANGPU_ERR_NO_MEMORY, "hipMalloc of per-channel parameters failed");
-        }
-        HIP_TRY(hipMemcpy(d, b->h_chan_parms, 4*n*sizeof(float), hipMemcpyHostToDevice));
-        b->chan_parms = d;
-    }
+    const int rc0 = ensure_chan_parms(b);
+    if (rc0 != SPANGPU_OK)
+        return rc0;
     float *h = b->h_chan_parms;
     // the channel's present values stand where the call leaves a field alone
     spangpu_tone_params_t q = tp;
@@ -1059,6 +1069,102 @@ int spangpu_bank_set_state(spangpu_bank_t *b, int channel, const float *fstate, 
     w[1] = istate[3];
     HIP_TRY(hipMemcpy2D(b->si + channel, (size_t) b->n_ch*sizeof(int32_t), w, sizeof(int32_t),
                         sizeof(int32_t), 2, hipMemcpyHostToDevice));
+    return SPANGPU_OK;
+}
+
+// ---- one DTMF channel in the reference's struct layout (include/spangpu_refstate.h; src/spandsp/private/dtmf.h:54-117) --
+int spangpu_dtmf_import_state(spangpu_bank_t *b, int channel, const spangpu_ref_dtmf_rx_t *s)
+{
+    if (b == nullptr  ||  s == nullptr  ||  channel < 0  ||  channel >= b->n_ch  ||  b->kind != SPANGPU_DTMF)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    float f[21];
+    int32_t w[4];
+    for (int i = 0;  i < 4;  i++)
+    {
+        f[i] = s->row_out[i].v2;
+        f[4 + i] = s->col_out[i].v2;
+        f[8 + i] = s->row_out[i].v3;
+        f[12 + i] = s->col_out[i].v3;
+    }
+    f[16] = s->energy;
+    f[17] = s->z350[0];
+    f[18] = s->z350[1];
+    f[19] = s->z440[0];
+    f[20] = s->z440[1];
+    w[0] = s->current_sample;
+    w[1] = s->last_hit;
+    w[2] = s->in_digit;
+    w[3] = s->duration;
+    int rc = spangpu_bank_set_state(b, channel, f, 21, w, 4);
+    if (rc != SPANGPU_OK)
+        return rc;
+    // the detector's own thresholds: the bank's table takes them as they stand
+    const size_t n = (size_t) b->n_ch;
+    const bool differs = s->threshold != b->threshold  ||  s->normal_twist != b->normal_twist  ||  s->reverse_twist != b->reverse_twist
+                         ||  (s->filter_dialtone  ?  1  :  0) != (b->tp.filter_dialtone  ?  1  :  0);
+    if (b->chan_parms == nullptr  &&  !differs)
+        return SPANGPU_OK;
+    if ((rc = ensure_chan_parms(b)) != SPANGPU_OK)
+        return rc;
+    float *h = b->h_chan_parms;
+    const float on = s->filter_dialtone  ?  1.0f  :  0.0f;
+    b->n_filter_on += (int) on - (int) h[3*n + channel];
+    h[channel] = s->threshold;
+    h[n + channel] = s->normal_twist;
+    h[2*n + channel] = s->reverse_twist;
+    h[3*n + channel] = on;
+    for (int i = 0;  i < 4;  i++)
+        HIP_TRY(hipMemcpy(b->chan_parms + (size_t) i*n + channel, &h[(size_t) i*n + channel], sizeof(float), hipMemcpyHostToDevice));
+    return SPANGPU_OK;
+}
+
+int spangpu_dtmf_export_state(spangpu_bank_t *b, int channel, spangpu_ref_dtmf_rx_t *s)
+{
+    if (b == nullptr  ||  s == nullptr  ||  channel < 0  ||  channel >= b->n_ch  ||  b->kind != SPANGPU_DTMF)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    float f[2*kMaxBins + 8];
+    int32_t w[4];
+    const int rc = spangpu_bank_get_state(b, channel, f, 2*kMaxBins + 8, w, 4);
+    if (rc < 0)
+        return rc;
+    const size_t n = (size_t) b->n_ch;
+    for (int i = 0;  i < 4;  i++)
+    {
+        // dtmf_rx() drives its Goertzels through goertzel_samplex(): their own sample counters stay where
+        // goertzel_init() left them (tone_detect.c:96-106), the block phase is the detector's current_sample
+        s->row_out[i].v2 = f[i];
+        s->col_out[i].v2 = f[4 + i];
+        s->row_out[i].v3 = f[8 + i];
+        s->col_out[i].v3 = f[12 + i];
+        s->row_out[i].fac = b->fac[i];
+        s->col_out[i].fac = b->fac[4 + i];
+        s->row_out[i].samples = s->col_out[i].samples = 102;
+        s->row_out[i].current_sample = s->col_out[i].current_sample = 0;
+    }
+    s->energy = f[16];
+    s->z350[0] = f[17];
+    s->z350[1] = f[18];
+    s->z440[0] = f[19];
+    s->z440[1] = f[20];
+    s->current_sample = w[0];
+    s->last_hit = (uint8_t) w[1];
+    s->in_digit = (uint8_t) w[2];
+    s->duration = w[3];
+    if (b->chan_parms)
+    {
+        const float *h = b->h_chan_parms;
+        s->threshold = h[channel];
+        s->normal_twist = h[n + channel];
+        s->reverse_twist = h[2*n + channel];
+        s->filter_dialtone = (h[3*n + channel] != 0.0f);
+    }
+    else
+    {
+        s->threshold = b->threshold;
+        s->normal_twist = b->normal_twist;
+        s->reverse_twist = b->reverse_twist;
+        s->filter_dialtone = (b->tp.filter_dialtone != 0);
+    }
     return SPANGPU_OK;
 }
 

@@ -1,0 +1,165 @@
+"""A live call changes sides: state in the reference's own struct layout (include/spangpu_refstate.h).  A detector /
+canceller made and run by the REAL reference (oracle/_ref/libspandsp_ref.so) is imported into a bank channel in
+mid-stream and both go on -- what the bank reports must be what the reference reports; and the other way: a bank
+channel is exported into a fresh reference object, which then carries on.  The reference struct is never described to
+Python: its pointer is handed to the library as it is, so the layout in the header is what is under test."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+DIGITS_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_int)
+
+
+@pytest.fixture(scope="module")
+def libs(built):
+    from oracle import ref
+    from spandsp_amd import engine
+    if not ref.available():
+        pytest.skip("oracle/_ref not built")
+    R = C.CDLL(ref.REF_SO)
+    vp, ci = C.c_void_p, C.c_int
+    R.dtmf_rx_init.restype = vp
+    R.dtmf_rx_init.argtypes = [vp, vp, vp]
+    R.dtmf_rx.argtypes = [vp, vp, ci]
+    R.dtmf_rx_get.restype = C.c_size_t
+    R.dtmf_rx_get.argtypes = [vp, C.c_char_p, ci]
+    R.dtmf_rx_parms.argtypes = [vp, ci, C.c_float, C.c_float, C.c_float]
+    R.dtmf_rx_free.argtypes = [vp]
+    R.echo_can_init.restype = vp
+    R.echo_can_init.argtypes = [ci, ci]
+    R.echo_can_update.restype = C.c_int16
+    R.echo_can_update.argtypes = [vp, C.c_int16, C.c_int16]
+    R.echo_can_free.argtypes = [vp]
+    L = engine.lib()
+    L.spangpu_dtmf_import_state.argtypes = [vp, ci, vp]
+    L.spangpu_dtmf_export_state.argtypes = [vp, ci, vp]
+    L.spangpu_echo_import_state.argtypes = [vp, ci, vp]
+    L.spangpu_echo_export_state.argtypes = [vp, ci, vp]
+    return R, L
+
+
+def ref_digits(R, s, x):
+    """The digits the reference collects over x, fed in 160-sample frames."""
+    out = ""
+    buf = C.create_string_buffer(200)
+    for k in range(0, len(x), 160):
+        fr = np.ascontiguousarray(x[k:k + 160])
+        R.dtmf_rx(s, fr.ctypes.data, len(fr))
+        n = R.dtmf_rx_get(s, buf, 128)
+        out += buf.raw[:n].decode("latin1")
+    return out
+
+
+def bank_digits(bank, ch, x, n_ch):
+    from spandsp_amd import engine
+    out = ""
+    for k in range(0, len(x), 160):
+        fr = np.zeros((n_ch, 160), np.int16)
+        m = min(160, len(x) - k)
+        lens = np.zeros(n_ch, np.int32)
+        fr[ch, :m] = x[k:k + m]
+        lens[ch] = m
+        bank.rx_host_var(fr, lens)
+        for r in bank.blocks():
+            if r["channel"] == ch and (r["flags"] & engine.BLK_CHANGE) and r["code"]:
+                out += chr(int(r["code"]))
+    return out
+
+
+@pytest.mark.parametrize("parms", [None, (1, 5.0, 3.0, -35.0)], ids=["defaults", "own-parms"])
+def test_dtmf_call_changes_sides(libs, parms):
+    from spandsp_amd import engine
+    R, L = libs
+    sig, _ = synth.dtmf_channels(4, 160*120, seed=71)
+    t = np.arange(sig.shape[1])
+    dial = 2500.0*np.sin(2*np.pi*350.0*t/8000.0) + 2500.0*np.sin(2*np.pi*440.0*t/8000.0)
+    n_ch, ch = 5, 3
+    total = 0
+    for c in range(4):
+        x = np.clip(sig[c].astype(np.float64) + (dial if parms else 0.0), -32768, 32767).astype(np.int16)
+        cut = 160*47 + 61                       # in the middle of a frame and of a 102-sample block
+        # the whole call on the reference
+        whole = R.dtmf_rx_init(None, None, None)
+        if parms:
+            R.dtmf_rx_parms(whole, *parms)
+        want = ref_digits(R, whole, x[:cut]) + ref_digits(R, whole, x[cut:])
+        total += len(want)
+        # reference -> bank
+        a = R.dtmf_rx_init(None, None, None)
+        if parms:
+            R.dtmf_rx_parms(a, *parms)
+        first = ref_digits(R, a, x[:cut])
+        bank = engine.ToneBank(engine.DTMF, n_ch)
+        assert L.spangpu_dtmf_import_state(bank.h, ch, a) == 0
+        assert first + bank_digits(bank, ch, x[cut:], n_ch) == want, c
+        # bank -> reference
+        bank2 = engine.ToneBank(engine.DTMF, n_ch)
+        if parms:
+            bank2.set_channel_params(ch, filter_dialtone=parms[0], twist_db=parms[1], reverse_twist_db=parms[2], threshold_dbm0=parms[3])
+        first2 = bank_digits(bank2, ch, x[:cut], n_ch)
+        b = R.dtmf_rx_init(None, None, None)
+        assert L.spangpu_dtmf_export_state(bank2.h, ch, b) == 0
+        assert first2 + ref_digits(R, b, x[cut:]) == want, c
+        # and the exported struct is, byte for byte in its signal-processing part, the one the reference built itself
+        probe = R.dtmf_rx_init(None, None, None)
+        assert L.spangpu_dtmf_export_state(bank.h, ch, probe) == 0
+        R.dtmf_rx(a, np.ascontiguousarray(x[cut:]).ctypes.data, len(x) - cut)      # `a` catches up with the bank
+        lo, hi = 4*C.sizeof(C.c_void_p), 4*C.sizeof(C.c_void_p) + 4 + 4*8 + 8*20 + 4 + 8       # filter_dialtone .. duration
+        assert C.string_at(probe + lo, hi - lo) == C.string_at(a + lo, hi - lo), c
+        for s in (whole, a, b, probe):
+            R.dtmf_rx_free(s)
+        bank.close()
+        bank2.close()
+    assert total > 15                           # (some of the synthetic channels are too poor to yield a digit: part of the test)
+
+
+def test_echo_call_changes_sides(libs):
+    from spandsp_amd import engine
+    from test_echo_gpu import make_channels
+    R, L = libs
+    taps, mode = 128, 0x01 | 0x02 | 0x04 | 0x40
+    tx, rx = make_channels(3, 160*40, taps, seed=73)
+    tx, rx = tx[2, 160*14:160*30], rx[2, 160*14:160*30]
+    cut = 160*9 + 77
+    n_ch, ch = 4, 2
+
+    def ref_run(ec, a, b):
+        return np.array([R.echo_can_update(ec, int(t), int(r)) for t, r in zip(a, b)], np.int16)
+
+    def bank_run(bank, a, b):
+        out = []
+        for k in range(0, len(a), 160):
+            m = min(160, len(a) - k)
+            t2 = np.zeros((n_ch, m), np.int16)
+            r2 = np.zeros((n_ch, m), np.int16)
+            t2[ch], r2[ch] = a[k:k + m], b[k:k + m]
+            out.append(bank.update_host(t2, r2, False)[ch])
+        return np.concatenate(out)
+
+    whole = R.echo_can_init(taps, mode)
+    want = ref_run(whole, tx, rx)
+    assert np.any(want[cut:] != rx[cut:])
+    # reference -> bank
+    a = R.echo_can_init(taps, mode)
+    ref_run(a, tx[:cut], rx[:cut])
+    bank = engine.EchoBank(n_ch, taps, mode)
+    assert L.spangpu_echo_import_state(bank.h, ch, a) == 0
+    assert np.array_equal(bank_run(bank, tx[cut:], rx[cut:]), want[cut:])
+    # bank -> reference
+    bank2 = engine.EchoBank(n_ch, taps, mode)
+    first = bank_run(bank2, tx[:cut], rx[:cut])
+    assert np.array_equal(first, want[:cut])
+    b = R.echo_can_init(taps, mode)
+    assert L.spangpu_echo_export_state(bank2.h, ch, b) == 0
+    assert np.array_equal(ref_run(b, tx[cut:], rx[cut:]), want[cut:])
+    other = R.echo_can_init(64, mode)
+    assert L.spangpu_echo_import_state(bank.h, ch, other) != 0             # another length: refused
+    for ec in (whole, a, b, other):
+        R.echo_can_free(ec)
+    bank.close()
+    bank2.close()
