@@ -239,6 +239,7 @@ SPANGPU_API int spangpu_echo_create(spangpu_echo_t **ec, int device, int n_chann
 SPANGPU_API int spangpu_echo_destroy(spangpu_echo_t *ec);
 SPANGPU_API int spangpu_echo_channels(const spangpu_echo_t *ec);
 SPANGPU_API int spangpu_echo_taps(const spangpu_echo_t *ec);
+SPANGPU_API int spangpu_echo_lanes_per_channel(const spangpu_echo_t *ec);     /* the kernel mapping the bank runs: 16, 8, 4 or 2 */
 SPANGPU_API int spangpu_echo_set_stream(spangpu_echo_t *ec, void *hip_stream);
 SPANGPU_API int spangpu_echo_sync(spangpu_echo_t *ec);
 /* Run `samples` samples of every channel: clean[c][i] = echo_can_update(ec_c, tx'[c][i], rx[c][i])

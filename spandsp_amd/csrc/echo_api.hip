@@ -104,14 +104,19 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     // Lanes per channel.  The scalar control of echo_can_update() is replicated in a channel's lanes, so the fewer lanes a
     // channel has the more channels share each control instruction; a small bank wants the opposite -- more,
     // narrower-sliced waves, so that every SIMD has some.  Measured, 128 taps, kernel time in us per 160-sample frame for
-    // 16 / 8 / 4 / 2 lanes (tools/echo_ab.py; two lanes = echo_pair.hpp, the 16-bit quantities packed in pairs):
-    // 4096 channels 100 / 118 / 104 / -, 8192: 131 / 122 / 122 / -, 16384: 182 / 153 / 183 / -, 32768: 300 / 218 / 303 / 210,
-    // 65536: - / 386 / 540 / 298, 131072: 977 / 747 / 599 / 596.  VALU instructions per channel and sample (SQ_INSTS_VALU,
-    // profiles/r2_echo_pmc.txt): 23.1 at eight lanes, 15.6 at four, 10.7 at two; the two-lane kernel holds 256 registers,
-    // so two waves per SIMD, and keeps the VALU 64 % busy where the others reach ~100 % -- its remaining distance.
+    // 16 / 8 / 4 / 2 lanes (two lanes = echo_pair.hpp, the 16-bit quantities packed in pairs):
+    //   every channel adapting in step (tools/echo_ab.py): 4096 channels 100 / 118 / 104 / -, 8192: 131 / 122 / 122 / -,
+    //     16384: 182 / 153 / 183 / -, 32768: - / 215 / 193 / 207, 65536: - / 384 / 347 / 293, 131072: 977 / 723 / 597 / 594
+    //   mixed lines -- single talk, double talk, silence, DC offsets, so that set events fall on different samples in
+    //     different channels (tools/bench_paths.py --workload echo --echo-lanes G): 32768: - / 232 / 218 / 265,
+    //     65536: - / 400 / 370 / 361, 131072: - / 737 / 624 / 660
+    // The two-lane kernel executes 10.7 VALU instructions per channel and sample against 15.6 at four lanes and 23.1 at
+    // eight (profiles/r2_echo_pmc.txt), but a sample on which ANY of a wave's channels meets a set event takes the whole
+    // wave through the complete routine, and its waves hold 32 channels: on mixed lines that eats the gain.  So four
+    // lanes from 24576 channels, eight from 8192, sixteen below; two lanes on request
+    // (spangpu_tune_echo_lanes_per_channel()), for banks whose channels run in step.
     // Slices are at most 32 taps (four lanes) or 16 taps per lane; two lanes take 32, 64 or 128 taps.
-    // spangpu_tune_echo_lanes_per_channel() overrides for A-B tests.
-    e->group = (g_echo_group != 0)  ?  g_echo_group  :  (n_channels >= 32768)  ?  2  :  (n_channels >= 8192)  ?  8  :  16;
+    e->group = (g_echo_group != 0)  ?  g_echo_group  :  (n_channels >= 24576)  ?  4  :  (n_channels >= 8192)  ?  8  :  16;
     if (e->group == 2  &&  taps != 128  &&  taps != 64  &&  taps != 32)
         e->group = (g_echo_group != 0  ||  n_channels >= 131072)  ?  4  :  8;
     if (e->group == 4  &&  (taps/4 < 2  ||  taps/4 > 32))
@@ -179,6 +184,7 @@ int spangpu_echo_destroy(spangpu_echo_t *e)
 
 int spangpu_echo_channels(const spangpu_echo_t *e) { return e  ?  e->n_ch  :  SPANGPU_ERR_BAD_ARG; }
 int spangpu_echo_taps(const spangpu_echo_t *e) { return e  ?  e->taps  :  SPANGPU_ERR_BAD_ARG; }
+int spangpu_echo_lanes_per_channel(const spangpu_echo_t *e) { return e  ?  e->group  :  SPANGPU_ERR_BAD_ARG; }
 
 int spangpu_echo_set_stream(spangpu_echo_t *e, void *hip_stream)
 {

@@ -140,7 +140,7 @@ static bool use_loader(int n_ch)
 
 constexpr int kFastWPB = 4;
 constexpr int kRingLoader = 2;          // segment slots per consumer wave, kernels with a loader wave
-constexpr int kRingSelf = 3;            // ... kernels whose waves fetch for themselves
+constexpr int kRingSelf = 2;            // ... kernels whose waves fetch for themselves (three slots measured slower: r2_probe.log)
 
 template <class Det, int LPC, bool G711>
 static void launch_fast(const ToneLaunch &L, hipStream_t st, bool loader)

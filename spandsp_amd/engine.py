@@ -129,6 +129,7 @@ def lib():
             "spangpu_fsk_set_frame_parameters": (ci, [vp, ci, ci, ci, ci]),
             "spangpu_fsk_fillin": (ci, [vp, ci, ci]),
             "spangpu_tune_echo_lanes_per_channel": (ci, [ci]),
+            "spangpu_echo_lanes_per_channel": (ci, [vp]),
             "spangpu_echo_stats": (ci, [vp, ci]),
             "spangpu_echo_stats_reset": (ci, [vp, ci]),
             "spangpu_echo_stats_get": (ci, [vp, ci, ci, vp]),

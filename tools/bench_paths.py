@@ -112,7 +112,26 @@ def bench_v29_tx(args, dev, stream):
                      "unit": "GB/s", "frac": alg/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None, "alg_bytes_per_launch": alg,
                      "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3,
                      "note": "sample-serial modulator, one channel per lane: latency bound at one wave per SIMD"},
-        "cpu_baseline": None}
+        "cpu_baseline": cpu_v29_tx(args)}
+
+
+def cpu_v29_tx(args):
+    """The reference's own v29_tx() (oracle/_ref) carrying a PRBS, on one host core (a modulator is a serial loop)."""
+    if args.no_cpu_baseline:
+        return None
+    import oracle
+    from oracle import ref
+    if not oracle.have_ref():
+        return None
+    with ref.quiet_stdout():
+        ref.v29_tx(9600, 200000, seed=3)
+        t1 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t1 < 3.0:
+            n += len(ref.v29_tx(9600, 400000, seed=5 + n))
+        dt = time.perf_counter() - t1
+    return {"value": n/dt/1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
+            "sample": "oracle/_ref v29_tx() 9600 bps, 400000-sample runs for %.1f s on one core" % dt}
 
 
 def bench_awgn(args, dev, stream):
@@ -166,7 +185,13 @@ def bench_awgn(args, dev, stream):
 
 
 def run_threads(n_ch, work):
-    cores = max(1, min(os.cpu_count() or 1, n_ch))
+    """Python threads over a C batch function that releases the GIL: as many as the container may really run."""
+    try:
+        from oracle import ref
+        usable = ref.usable_cores()[0]
+    except Exception:
+        usable = os.cpu_count() or 1
+    cores = max(1, min(usable, n_ch))
     bounds = np.linspace(0, n_ch, cores + 1).astype(int)
     th = [threading.Thread(target=work, args=(int(bounds[i]), int(bounds[i + 1]))) for i in range(cores)]
     t0 = time.perf_counter()
@@ -286,7 +311,10 @@ def bench_echo(args, dev, stream):
     nf = min(args.steps + args.warmup, 60)
     tx, rx = synth_echo(n_ch, nf, dev, seed=0xEC40)
     clean = torch.empty(n_ch, FRAME, dtype=torch.int16, device=dev)
+    if args.echo_lanes:
+        engine.lib().spangpu_tune_echo_lanes_per_channel(args.echo_lanes)
     bank = engine.EchoBank(n_ch, ECHO_TAPS, ECHO_MODE)
+    engine.lib().spangpu_tune_echo_lanes_per_channel(0)
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
     fb = n_ch*FRAME*2
     power_rx = 0.0
@@ -330,7 +358,7 @@ def bench_echo(args, dev, stream):
         "config": {"workload": "BASELINE configs[4] (one GPU's shard): echo_can_update 128 taps, %d channels x %d-sample "
                                "frames, mode ECHO_CAN_USE_ADAPTION" % (n_ch, FRAME), "channels_per_gpu": n_ch,
                    "erle_db_last_frame_single_talk_channels": 10.0*np.log10(max(power_rx, 1e-9)/max(power_clean, 1e-9))},
-        "roofline": {"bound": "hbm", "kernel": "echo_bank_kernel<128>", "achieved": alg_read/(avg_ms*1e-3)/1e9,
+        "roofline": {"bound": "hbm", "kernel": "echo canceller kernel, %d lanes per channel, 128 taps" % engine.lib().spangpu_echo_lanes_per_channel(bank.h), "achieved": alg_read/(avg_ms*1e-3)/1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
                      "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
                      "avg_launch_us": avg_ms*1e3,
@@ -638,6 +666,7 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--echo-lanes", type=int, default=0, help="echo: lanes per channel (0 = the library's choice; 2, 4, 8, 16 for A-B runs)")
     ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     ap.add_argument("--replay-fixture", action="store_true",
