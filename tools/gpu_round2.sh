@@ -6,6 +6,8 @@ cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT/gpurun_out/r2
 mkdir -p $R
 export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
+timeout 900 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log
 cd /tmp
 timeout 400 python $GRAFT_REPO_ROOT/bench.py > $R/bench.json 2> $R/bench.err
 timeout 400 python $GRAFT_REPO_ROOT/bench.py --workload echo > $R/bench_echo.json 2> $R/bench_echo.err
@@ -29,9 +31,10 @@ cd $GRAFT_REPO_ROOT
   echo "### tools/probe2 (tone kernels: variants, sizes; eager)"; timeout 200 ./tools/probe2
   echo "### tools/probe2 quick graph (same launches from a hipGraph)"; timeout 100 ./tools/probe2 quick graph
   echo "### tools/probe5 (launch boundary)"; timeout 100 ./tools/probe5
-  echo "### tools/probe6 (integer instruction issue, echo kernels)"; timeout 100 ./tools/probe6
+  echo "### tools/probe6 (integer instruction issue, echo kernels)"; timeout 100 ./tools/probe6; echo "(rc=$?)"
   echo "### tools/probe3 x (Goertzel step2 block issue)"; timeout 100 ./tools/probe3 x
-  echo "### tools/echo_ab.py"; for n in 32768 65536 131072; do python tools/echo_ab.py $n 8 4 2 2>&1 | grep lanes; done
+  echo "### tools/echo_ab.py (every channel adapting in step)"; for n in 32768 65536 131072; do python tools/echo_ab.py $n 8 4 2 2>&1 | grep lanes; done
+  echo "### tools/echo_wl.sh (mixed lines: tools/bench_paths.py --workload echo --echo-lanes G)"; bash tools/echo_wl.sh 2>&1 | grep channels
 } > $R/probe.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections, json
