@@ -296,12 +296,36 @@ static void sweep(int n_ch, int samples, int n_frames, int reps, bool full)
     free_rig(r);
 }
 
+// Where a big bank's time goes: the self-fetching kernel at 1 M channels with parts switched off, and per-wave stamps
+static void sweep_big(int n_ch)
+{
+    typedef DtmfDet<false> D;
+    const int reps = 20;
+    Rig r = make_rig<D>(n_ch, 160, 6, 102, false);
+    printf("---- DTMF, %d channels x 160 samples: ablations of the self-fetching kernel ----\n", n_ch);
+    NEW(1, 2, false, 4, 0);
+    NEW(1, 2, false, 4, 8);         // no recurrence
+    NEW(1, 2, false, 4, 16);        // no DMA (pieces not fetched)
+    NEW(1, 2, false, 4, 24);        // neither
+    NEW(1, 2, false, 4, 256);       // state only
+    NEW(1, 2, false, 4, 32);        // stamps
+    NEWL(1, 2, false, 0);
+    NEWL(1, 2, false, 32);
+    free_rig(r);
+}
+
 int main(int argc, char **argv)
 {
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
     printf("device: %s  CUs=%d  clock=%d MHz\n", p.name, p.multiProcessorCount, p.clockRate/1000);
     const bool quick = (argc > 1  &&  strcmp(argv[1], "quick") == 0);
+    if (argc > 1  &&  strcmp(argv[1], "big") == 0)
+    {
+        CK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        sweep_big((argc > 2)  ?  atoi(argv[2])  :  1048576);
+        return 0;
+    }
     CK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
     if (argc > 2  &&  strcmp(argv[2], "graph") == 0)
         g_graph = true;
