@@ -448,6 +448,8 @@ SPANGPU_API int spangpu_fsk_channels(const spangpu_fsk_t *fsk);
 SPANGPU_API int spangpu_fsk_set_stream(spangpu_fsk_t *fsk, void *hip_stream);
 SPANGPU_API int spangpu_fsk_sync(spangpu_fsk_t *fsk);
 SPANGPU_API int spangpu_fsk_rx(spangpu_fsk_t *fsk, const int16_t *amp, int mem, int samples, long long stride);
+/* a tick in which channels are missing or bring short frames: lens[c] samples of row c; 0 = untouched (host array) */
+SPANGPU_API int spangpu_fsk_rx_var(spangpu_fsk_t *fsk, const int16_t *amp, int mem, const int32_t *lens, int max_samples, long long stride);
 /* events[channel*cap + i], i < counts[channel]; returns cap.  Valid until the next call on this bank. */
 SPANGPU_API int spangpu_fsk_events(spangpu_fsk_t *fsk, const int16_t **events, const int32_t **counts);
 SPANGPU_API int spangpu_fsk_state_words(const spangpu_fsk_t *fsk);
@@ -488,6 +490,7 @@ SPANGPU_API int spangpu_mct_channels(const spangpu_mct_t *mct);
 SPANGPU_API int spangpu_mct_set_stream(spangpu_mct_t *mct, void *hip_stream);
 SPANGPU_API int spangpu_mct_sync(spangpu_mct_t *mct);
 SPANGPU_API int spangpu_mct_rx(spangpu_mct_t *mct, const int16_t *amp, int mem, int samples, long long stride);
+SPANGPU_API int spangpu_mct_rx_var(spangpu_mct_t *mct, const int16_t *amp, int mem, const int32_t *lens, int max_samples, long long stride);
 /* events[(channel*cap + i)*2 + {0: tone, 1: level}], i < counts[channel]; returns cap.  Valid until the next call. */
 SPANGPU_API int spangpu_mct_events(spangpu_mct_t *mct, const int32_t **events, const int32_t **counts);
 SPANGPU_API int spangpu_mct_get(spangpu_mct_t *mct, int channel);

@@ -62,9 +62,10 @@ __global__ __launch_bounds__(64) void fsk_bank_kernel(const FskLaunch L)
         r.n_ev++;
     };
     const int16_t *row = L.pcm + (size_t) ch*L.stride;
+    const int mylen = L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;
     for (int base = 0;  base < L.samples;  base += 8)
     {
-        const int todo = (L.samples - base < 8)  ?  (L.samples - base)  :  8;
+        const int todo = max(0, min(8, mylen - base));          // per lane when the call carries per-channel lengths
         int32_t a[8];
         int32_t c0[8];
         int32_t q0[8];
@@ -88,6 +89,9 @@ __global__ __launch_bounds__(64) void fsk_bank_kernel(const FskLaunch L)
 
 struct spangpu_fsk_s
 {
+    const int32_t *next_lens;   // per-channel lengths of the call being prepared (device), or NULL
+    int32_t *d_lens;            // [n_ch], device
+    int32_t *h_lens;            // [n_ch], pinned
     int device;
     int n_ch;
     int span;
@@ -290,6 +294,8 @@ void spangpu_fsk_destroy(spangpu_fsk_t *f)
     (void) hipFree(f->st);
     (void) hipFree(f->quarter);
     (void) hipFree(f->d_pcm);
+    (void) hipFree(f->d_lens);
+    if (f->h_lens) (void) hipHostFree(f->h_lens);
     (void) hipFree(f->events);
     (void) hipFree(f->ev_count);
     free(f->h_events);
@@ -355,6 +361,7 @@ int spangpu_fsk_rx(spangpu_fsk_t *f, const int16_t *amp, int mem_kind, int sampl
     L.ev_count = f->ev_count;
     L.n_ch = f->n_ch;
     L.samples = samples;
+    L.lens = f->next_lens;
     L.span = f->span;
     L.ev_cap = f->ev_cap;
     if (mem_kind == SPANGPU_MEM_HOST)
@@ -388,6 +395,44 @@ int spangpu_fsk_rx(spangpu_fsk_t *f, const int16_t *amp, int mem_kind, int sampl
     FSK_TRY(hipGetLastError());
     f->last_cap = f->ev_cap;
     return SPANGPU_OK;
+}
+
+// spangpu_fsk_rx() for a tick in which not every channel has a frame, or frames differ in length: channel c takes lens[c] samples
+// of its row (0: it sits the call out, its state as it was, no events).  lens[] is host memory.
+int spangpu_fsk_rx_var(spangpu_fsk_t *f, const int16_t *amp, int mem_kind, const int32_t *lens, int max_samples, long long stride)
+{
+    if (f == NULL  ||  amp == NULL  ||  lens == NULL  ||  max_samples <= 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    int longest = 0;
+    bool all = true;
+    for (int c = 0;  c < f->n_ch;  c++)
+    {
+        if (lens[c] < 0  ||  lens[c] > max_samples)
+            return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "a channel's length is outside 0..max_samples");
+        if (lens[c] > longest)
+            longest = lens[c];
+    }
+    if (longest == 0)
+        return SPANGPU_OK;
+    for (int c = 0;  c < f->n_ch;  c++)
+        all &= (lens[c] == longest);
+    if (stride <= 0)
+        stride = max_samples;
+    if (all)
+        return spangpu_fsk_rx(f, amp, mem_kind, longest, stride);
+    FSK_TRY(hipSetDevice(f->device));
+    if (f->d_lens == NULL)
+    {
+        FSK_TRY(hipMalloc(&f->d_lens, (size_t) f->n_ch*sizeof(int32_t)));
+        FSK_TRY(hipHostMalloc(&f->h_lens, (size_t) f->n_ch*sizeof(int32_t)));
+    }
+    FSK_TRY(hipStreamSynchronize(f->stream));
+    memcpy(f->h_lens, lens, (size_t) f->n_ch*sizeof(int32_t));
+    FSK_TRY(hipMemcpyAsync(f->d_lens, f->h_lens, (size_t) f->n_ch*sizeof(int32_t), hipMemcpyHostToDevice, f->stream));
+    f->next_lens = f->d_lens;
+    const int rc = spangpu_fsk_rx(f, amp, mem_kind, longest, stride);
+    f->next_lens = NULL;
+    return rc;
 }
 
 int spangpu_fsk_events(spangpu_fsk_t *f, const int16_t **events, const int32_t **counts)

@@ -69,6 +69,7 @@ struct FskLaunch
     long long stride;
     int n_ch;
     int samples;
+    const int32_t *lens;        // nullptr, or samples per channel in this call (<= samples; 0 = the channel sits it out)
     int span;
     int ev_cap;
     int vec;                    // rows are 16 B aligned: eight samples per load

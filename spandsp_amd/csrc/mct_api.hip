@@ -30,6 +30,9 @@ extern "C" int spangpu_set_error(int code, const char *msg);
 
 struct spangpu_mct_s
 {
+    const int32_t *next_lens;   // per-channel lengths of the call being prepared (device), or NULL
+    int32_t *d_lens;            // [n_ch], device
+    int32_t *h_lens;            // [n_ch], pinned
     int device;
     int n_ch;
     int tone_type;              // after modem_connect_tones_rx_init()'s folding of the ANS variants
@@ -186,6 +189,8 @@ void spangpu_mct_destroy(spangpu_mct_t *m)
     (void) hipFree(m->st);
     (void) hipFree(m->quarter);
     (void) hipFree(m->d_pcm);
+    (void) hipFree(m->d_lens);
+    if (m->h_lens) (void) hipHostFree(m->h_lens);
     (void) hipFree(m->events);
     (void) hipFree(m->ev_count);
     free(m->h_events);
@@ -252,6 +257,7 @@ int spangpu_mct_rx(spangpu_mct_t *m, const int16_t *amp, int mem_kind, int sampl
     L.ev_count = m->ev_count;
     L.n_ch = m->n_ch;
     L.samples = samples;
+    L.lens = m->next_lens;
     L.ev_cap = m->ev_cap;
     L.latch = m->latch;
     if (mem_kind == SPANGPU_MEM_HOST)
@@ -291,6 +297,44 @@ int spangpu_mct_rx(spangpu_mct_t *m, const int16_t *amp, int mem_kind, int sampl
     MCT_TRY(hipGetLastError());
     m->last_cap = m->ev_cap;
     return SPANGPU_OK;
+}
+
+// spangpu_mct_rx() for a tick in which not every channel has a frame, or frames differ in length: channel c takes lens[c] samples
+// of its row (0: it sits the call out, its state as it was, no events).  lens[] is host memory.
+int spangpu_mct_rx_var(spangpu_mct_t *m, const int16_t *amp, int mem_kind, const int32_t *lens, int max_samples, long long stride)
+{
+    if (m == NULL  ||  amp == NULL  ||  lens == NULL  ||  max_samples <= 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    int longest = 0;
+    bool all = true;
+    for (int c = 0;  c < m->n_ch;  c++)
+    {
+        if (lens[c] < 0  ||  lens[c] > max_samples)
+            return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "a channel's length is outside 0..max_samples");
+        if (lens[c] > longest)
+            longest = lens[c];
+    }
+    if (longest == 0)
+        return SPANGPU_OK;
+    for (int c = 0;  c < m->n_ch;  c++)
+        all &= (lens[c] == longest);
+    if (stride <= 0)
+        stride = max_samples;
+    if (all)
+        return spangpu_mct_rx(m, amp, mem_kind, longest, stride);
+    MCT_TRY(hipSetDevice(m->device));
+    if (m->d_lens == NULL)
+    {
+        MCT_TRY(hipMalloc(&m->d_lens, (size_t) m->n_ch*sizeof(int32_t)));
+        MCT_TRY(hipHostMalloc(&m->h_lens, (size_t) m->n_ch*sizeof(int32_t)));
+    }
+    MCT_TRY(hipStreamSynchronize(m->stream));
+    memcpy(m->h_lens, lens, (size_t) m->n_ch*sizeof(int32_t));
+    MCT_TRY(hipMemcpyAsync(m->d_lens, m->h_lens, (size_t) m->n_ch*sizeof(int32_t), hipMemcpyHostToDevice, m->stream));
+    m->next_lens = m->d_lens;
+    const int rc = spangpu_mct_rx(m, amp, mem_kind, longest, stride);
+    m->next_lens = NULL;
+    return rc;
 }
 
 int spangpu_mct_events(spangpu_mct_t *m, const int32_t **events, const int32_t **counts)

@@ -67,6 +67,7 @@ struct MctLaunch
     long long stride;
     int n_ch;
     int samples;
+    const int32_t *lens;        // nullptr, or samples per channel in this call (<= samples; 0 = the channel sits it out)
     int ev_cap;
     int vec;
     int latch;                  // no callback installed: reports also set `hit` (modem_connect_tones.c:426-429)
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(64) void mct_bank_kernel(const MctLaunch L)
     }
     if (!live)
         return;
+    const int mylen = L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;       // per lane with per-channel lengths
 
     MctRegs m;
     m.znotch_1 = __int_as_float(st[MC_ZNOTCH_1*n]);
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(64) void mct_bank_kernel(const MctLaunch L)
         };
         for (int base = 0;  base < L.samples;  base += 8)
         {
-            const int todo = (L.samples - base < 8)  ?  (L.samples - base)  :  8;
+            const int todo = max(0, min(8, mylen - base));
             int32_t a[8];
             int32_t c0[8];
             int32_t q0[8];
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(64) void mct_bank_kernel(const MctLaunch L)
         }
         for (int base = 0;  base < L.samples;  base += 8)
         {
-            const int todo = (L.samples - base < 8)  ?  (L.samples - base)  :  8;
+            const int todo = max(0, min(8, mylen - base));
             int32_t a[8];
             fsk_block_samples(row, base, todo, L.vec != 0, a);
 #pragma unroll

@@ -7,6 +7,7 @@
  * Without a GPU every init returns NULL: there is no CPU implementation.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -40,10 +41,10 @@ struct spangpu_line_group_s
     int max_samples;
     int16_t *stage;
     void **handles;
-    uint8_t *staged;
+    int32_t *lens;              /* per channel: samples staged for the tick being collected (0 = none) */
     int n_attached;
     int n_staged;
-    int tick_samples;
+    pthread_mutex_t lock;       /* staging, attach / detach and the tick itself (recursive: callbacks may call back in) */
 };
 
 struct fsk_rx_state_s
@@ -76,8 +77,16 @@ static spangpu_line_group_t *group_new(int n_channels, int max_samples)
     g->max_samples = max_samples;
     g->stage = (int16_t *) calloc((size_t) n_channels*max_samples, sizeof(int16_t));
     g->handles = (void **) calloc(n_channels, sizeof(void *));
-    g->staged = (uint8_t *) calloc(n_channels, 1);
-    if (g->stage == NULL  ||  g->handles == NULL  ||  g->staged == NULL)
+    g->lens = (int32_t *) calloc(n_channels, sizeof(int32_t));
+    {
+        pthread_mutexattr_t at;
+
+        pthread_mutexattr_init(&at);
+        pthread_mutexattr_settype(&at, PTHREAD_MUTEX_RECURSIVE);
+        pthread_mutex_init(&g->lock, &at);
+        pthread_mutexattr_destroy(&at);
+    }
+    if (g->stage == NULL  ||  g->handles == NULL  ||  g->lens == NULL)
     {
         spangpu_line_group_destroy(g);
         return NULL;
@@ -131,12 +140,15 @@ int spangpu_line_group_destroy(spangpu_line_group_t *g)
         spangpu_mct_destroy(g->mct);
     free(g->stage);
     free(g->handles);
-    free(g->staged);
+    free(g->lens);
+    pthread_mutex_destroy(&g->lock);
     free(g);
     return 0;
 }
 
-int spangpu_line_group_flush(spangpu_line_group_t *g)
+/* Run the tick with the receivers that have staged a frame; the others sit it out, untouched (as the reference's are when
+   their xxx_rx() is not called), and may stage for the next one.  Returns how many took part. */
+static int line_flush_locked(spangpu_line_group_t *g)
 {
     int cap;
     int c;
@@ -144,8 +156,6 @@ int spangpu_line_group_flush(spangpu_line_group_t *g)
     int n;
     int rc;
 
-    if (g == NULL)
-        return SPANGPU_ERR_BAD_ARG;
     if (g->n_staged == 0)
         return 0;
     if (g->is_mct)
@@ -153,7 +163,7 @@ int spangpu_line_group_flush(spangpu_line_group_t *g)
         const int32_t *events;
         const int32_t *counts;
 
-        if ((rc = spangpu_mct_rx(g->mct, g->stage, SPANGPU_MEM_HOST, g->tick_samples, g->max_samples)) < 0)
+        if ((rc = spangpu_mct_rx_var(g->mct, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples)) < 0)
             return rc;
         if ((cap = spangpu_mct_events(g->mct, &events, &counts)) < 0)
             return cap;
@@ -162,13 +172,12 @@ int spangpu_line_group_flush(spangpu_line_group_t *g)
             modem_connect_tones_rx_state_t *s = (modem_connect_tones_rx_state_t *) g->handles[c];
 
             n = (counts[c] < cap)  ?  counts[c]  :  cap;
-            if (s  &&  s->tone_callback)
+            if (s  &&  s->tone_callback  &&  g->lens[c] > 0)
             {
                 /* report_tone_state(), modem_connect_tones.c:420-423 */
                 for (i = 0;  i < n;  i++)
                     s->tone_callback(s->callback_data, events[((size_t) c*cap + i)*2], events[((size_t) c*cap + i)*2 + 1], 0);
             }
-            g->staged[c] = 0;
         }
     }
     else
@@ -176,7 +185,7 @@ int spangpu_line_group_flush(spangpu_line_group_t *g)
         const int16_t *events;
         const int32_t *counts;
 
-        if ((rc = spangpu_fsk_rx(g->fsk, g->stage, SPANGPU_MEM_HOST, g->tick_samples, g->max_samples)) < 0)
+        if ((rc = spangpu_fsk_rx_var(g->fsk, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples)) < 0)
             return rc;
         if ((cap = spangpu_fsk_events(g->fsk, &events, &counts)) < 0)
             return cap;
@@ -185,7 +194,7 @@ int spangpu_line_group_flush(spangpu_line_group_t *g)
             fsk_rx_state_t *s = (fsk_rx_state_t *) g->handles[c];
 
             n = (counts[c] < cap)  ?  counts[c]  :  cap;
-            if (s)
+            if (s  &&  g->lens[c] > 0)
             {
                 for (i = 0;  i < n;  i++)
                 {
@@ -198,19 +207,34 @@ int spangpu_line_group_flush(spangpu_line_group_t *g)
                         s->put_bit(s->put_bit_user_data, v);
                 }
             }
-            g->staged[c] = 0;
         }
     }
     rc = g->n_staged;
+    memset(g->lens, 0, sizeof(int32_t)*g->n_ch);
     g->n_staged = 0;
     return rc;
 }
 
-/* One object's frame: a private bank runs it now (in slices), a shared one stages it and launches when the
-   last attached channel of the tick has staged. */
+int spangpu_line_group_flush(spangpu_line_group_t *g)
+{
+    int rc;
+
+    if (g == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    pthread_mutex_lock(&g->lock);
+    rc = line_flush_locked(g);
+    pthread_mutex_unlock(&g->lock);
+    return rc;
+}
+
+/* One object's frame: a private bank runs it now (in slices); a shared one stages it (any thread; one submitter per
+   receiver) and the tick runs when every attached receiver has staged, or when its owner calls
+   spangpu_line_group_flush() at the deadline.  A frame longer than the group was made for, or a second frame for a
+   receiver before the tick has run, is refused with -1: nothing is dropped silently. */
 static int line_rx(spangpu_line_group_t *g, int channel, int private_grp, const int16_t amp[], int len)
 {
     int n;
+    int rc;
 
     if (len <= 0)
         return 0;                           /* as the reference: nothing to do (fsk.c:330 loops over len) */
@@ -220,9 +244,8 @@ static int line_rx(spangpu_line_group_t *g, int channel, int private_grp, const 
         {
             n = (len > g->max_samples)  ?  g->max_samples  :  len;
             memcpy(g->stage, amp, n*sizeof(int16_t));
-            g->staged[0] = 1;
+            g->lens[0] = n;
             g->n_staged = 1;
-            g->tick_samples = n;
             spangpu_line_group_flush(g);
             amp += n;
             len -= n;
@@ -230,20 +253,39 @@ static int line_rx(spangpu_line_group_t *g, int channel, int private_grp, const 
         return 0;
     }
     if (len > g->max_samples)
-        len = g->max_samples;
-    if (g->n_staged == 0)
-        g->tick_samples = len;
-    else if (len != g->tick_samples)
-        return 0;                           /* a group tick carries one frame length; a stray length is dropped */
-    memcpy(g->stage + (size_t) channel*g->max_samples, amp, len*sizeof(int16_t));
-    if (!g->staged[channel])
+        return -1;
+    pthread_mutex_lock(&g->lock);
+    if (g->lens[channel])
     {
-        g->staged[channel] = 1;
-        g->n_staged++;
+        pthread_mutex_unlock(&g->lock);
+        return -1;
     }
-    if (g->n_staged >= g->n_attached)
-        spangpu_line_group_flush(g);
-    return 0;
+    pthread_mutex_unlock(&g->lock);
+    memcpy(g->stage + (size_t) channel*g->max_samples, amp, len*sizeof(int16_t));
+    pthread_mutex_lock(&g->lock);
+    g->lens[channel] = len;
+    g->n_staged++;
+    rc = (g->n_staged >= g->n_attached)  ?  line_flush_locked(g)  :  0;
+    pthread_mutex_unlock(&g->lock);
+    return (rc < 0)  ?  -1  :  0;
+}
+
+static void line_detach(spangpu_line_group_t *g, int channel, int private_grp)
+{
+    pthread_mutex_lock(&g->lock);
+    g->handles[channel] = NULL;
+    g->n_attached--;
+    if (g->lens[channel])
+    {
+        /* its frame of the tick in progress goes with it */
+        g->lens[channel] = 0;
+        g->n_staged--;
+    }
+    if (!private_grp  &&  g->n_staged > 0  &&  g->n_staged >= g->n_attached)
+        line_flush_locked(g);               /* it was the one the others were waiting for */
+    pthread_mutex_unlock(&g->lock);
+    if (private_grp)
+        spangpu_line_group_destroy(g);
 }
 
 /* ---- fsk_rx -------------------------------------------------------------------------------------------- */
@@ -258,8 +300,10 @@ static fsk_rx_state_t *fsk_obj(spangpu_line_group_t *g, int channel, int private
     s->private_grp = private_grp;
     s->put_bit = put_bit;
     s->put_bit_user_data = user_data;
+    pthread_mutex_lock(&g->lock);
     g->handles[channel] = s;
     g->n_attached++;
+    pthread_mutex_unlock(&g->lock);
     return s;
 }
 
@@ -314,10 +358,7 @@ int fsk_rx_free(fsk_rx_state_t *s)
 {
     if (s == NULL)
         return 0;
-    s->grp->handles[s->channel] = NULL;
-    s->grp->n_attached--;
-    if (s->private_grp)
-        spangpu_line_group_destroy(s->grp);
+    line_detach(s->grp, s->channel, s->private_grp);
     free(s);
     return 0;
 }
@@ -394,8 +435,10 @@ static modem_connect_tones_rx_state_t *mct_obj(spangpu_line_group_t *g, int chan
     s->private_grp = private_grp;
     s->tone_callback = tone_callback;
     s->callback_data = user_data;
+    pthread_mutex_lock(&g->lock);
     g->handles[channel] = s;
     g->n_attached++;
+    pthread_mutex_unlock(&g->lock);
     return s;
 }
 
@@ -451,10 +494,7 @@ int modem_connect_tones_rx_free(modem_connect_tones_rx_state_t *s)
 {
     if (s == NULL)
         return 0;
-    s->grp->handles[s->channel] = NULL;
-    s->grp->n_attached--;
-    if (s->private_grp)
-        spangpu_line_group_destroy(s->grp);
+    line_detach(s->grp, s->channel, s->private_grp);
     free(s);
     return 0;
 }

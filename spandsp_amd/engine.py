@@ -109,6 +109,7 @@ def lib():
             "spangpu_mct_set_stream": (ci, [vp, vp]),
             "spangpu_mct_sync": (ci, [vp]),
             "spangpu_mct_rx": (ci, [vp, vp, ci, ci, ll]),
+            "spangpu_mct_rx_var": (ci, [vp, vp, ci, vp, ci, ll]),
             "spangpu_mct_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
             "spangpu_mct_get": (ci, [vp, ci]),
             "spangpu_mct_state_words": (ci, [vp]),
@@ -120,6 +121,7 @@ def lib():
             "spangpu_fsk_set_stream": (ci, [vp, vp]),
             "spangpu_fsk_sync": (ci, [vp]),
             "spangpu_fsk_rx": (ci, [vp, vp, ci, ci, ll]),
+            "spangpu_fsk_rx_var": (ci, [vp, vp, ci, vp, ci, ll]),
             "spangpu_fsk_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
             "spangpu_fsk_state_words": (ci, [vp]),
             "spangpu_fsk_get_state": (ci, [vp, ci, vp]),
@@ -725,6 +727,12 @@ class FskBank:
     def rx_device(self, ptr, samples, stride=0):
         _check(lib().spangpu_fsk_rx(self.h, ptr, MEM_DEVICE, samples, stride))
 
+    def rx_host_var(self, amp, lens):
+        """A tick with per-channel frame lengths (0 = the receiver sits it out, untouched)."""
+        amp = np.ascontiguousarray(amp, np.int16)
+        lens = np.ascontiguousarray(lens, np.int32)
+        _check(lib().spangpu_fsk_rx_var(self.h, amp.ctypes.data, MEM_HOST, lens.ctypes.data, amp.shape[1], amp.shape[1]))
+
     def events(self):
         """Per channel: the int16 put_bit() values of the last frame, in order."""
         ev = C.c_void_p()
@@ -796,6 +804,12 @@ class MctBank:
 
     def rx_device(self, ptr, samples, stride=0):
         _check(lib().spangpu_mct_rx(self.h, ptr, MEM_DEVICE, samples, stride))
+
+    def rx_host_var(self, amp, lens):
+        """A tick with per-channel frame lengths (0 = the detector sits it out, untouched)."""
+        amp = np.ascontiguousarray(amp, np.int16)
+        lens = np.ascontiguousarray(lens, np.int32)
+        _check(lib().spangpu_mct_rx_var(self.h, amp.ctypes.data, MEM_HOST, lens.ctypes.data, amp.shape[1], amp.shape[1]))
 
     def events(self):
         """Per channel: [k, 2] int32 (tone, level) reports of the last frame, in order."""
