@@ -11,10 +11,12 @@
  *     on the GPU and replays callbacks before it returns -- same observable behaviour, per
  *     call, as the reference (this is the plumbing configuration);
  *   - spangpu_group_create() + spangpu_xxx_rx_attach() put N objects on ONE bank: each
- *     xxx_rx() stages its frame, and when the last attached channel of the tick has staged
- *     (or on spangpu_group_flush()) a single kernel launch advances all N channels and the
- *     callbacks of every channel are replayed in channel order, each channel's events in
- *     sample order.  This is the production configuration (thousands of channels / launch).
+ *     xxx_rx() stages its frame (from any thread; one submitter per object), and when every
+ *     attached channel has staged -- or when the tick's owner calls spangpu_group_flush() at
+ *     its deadline, with whoever staged: a silent or late channel stalls nobody and is itself
+ *     untouched -- a single kernel launch advances the channels that take part and their
+ *     callbacks are replayed in channel order, each channel's events in sample order.  This
+ *     is the production configuration (thousands of channels / launch).
  *
  * Reference declarations being replaced (relative to the reference tree):
  *   dtmf_rx_init/_release/_free            src/spandsp/dtmf.h:216-228     src/dtmf.c:447-519
