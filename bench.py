@@ -303,8 +303,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--channels", type=int, default=65536, help="channels per GPU (BASELINE config 2: 65536)")
     ap.add_argument("--distinct-frames", type=int, default=100, help="distinct 20 ms frames resident in HBM (cycled)")
-    ap.add_argument("--gather-every", type=int, default=5,
-                    help="multi-GPU: steps per RCCL gather of the block records (5 = one 100 ms report per collective)")
+    ap.add_argument("--gather", choices=["digits", "records"], default="digits",
+                    help="multi-GPU: what rank 0 collects per step -- one byte per block and channel (the digit delivered, 0 = "
+                         "none; default) or the 32-bit record word of every block; either is written by the detector kernel "
+                         "straight into the RCCL send buffer")
+    ap.add_argument("--gather-every", type=int, default=25,
+                    help="multi-GPU: steps per RCCL gather (25 = one report to rank 0 per 0.5 s of signal; every digit of every "
+                         "step travels, a report only batches them: measured on one rank, a collective per 5 steps costs "
+                         "3.1 us per step, per 25 steps 1.3 us)")
     ap.add_argument("--g711", choices=["none", "alaw", "ulaw"], default="none",
                     help="feed the bank G.711 bytes (decoded on the device) instead of 16 bit linear PCM; not the "
                          "BASELINE configuration -- a variant of it with the wire format of a trunk")
@@ -342,7 +348,7 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from spandsp_amd import engine
-    from spandsp_amd.parallel import ResultGather, shard_range
+    from spandsp_amd.parallel import DigitGather, ResultGather, shard_range
 
     if args.workload == "echo":
         run_echo(args, engine, dev, local_rank, rank, world)
@@ -374,14 +380,19 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
-    gather = ResultGather(world, rank, n_ch, max_blocks=2, device=dev, every=args.gather_every) if (world > 1 or force_gather) else None
+    gather = None
+    if world > 1 or force_gather:
+        if args.gather == "digits":
+            gather = DigitGather(world, rank, n_ch, 2, dev, every=args.gather_every)
+        else:
+            gather = ResultGather(world, rank, n_ch, max_blocks=2, device=dev, every=args.gather_every)
     frame_bytes = n_ch*FRAME*(1 if law else 2)
     base_ptr = frames.data_ptr()
     nf = args.distinct_frames
 
     def step(i):
         if gather is not None:
-            gather.aim(bank)                    # the kernel writes its records straight into the RCCL send buffer
+            gather.aim(bank)                    # the kernel writes its digit list / records straight into the RCCL send buffer
         if law:
             bank.rx_device_g711(ctypes.c_void_p(base_ptr + (i % nf)*frame_bytes), law, FRAME, FRAME)
         else:
@@ -438,6 +449,7 @@ def main():
 
     if gather is not None:
         bank.set_records_buffer(None, 0)
+        bank.set_digits_buffer(None, 0)
     # ---- roofline: the kernel's average launch duration = HIP events on the launch stream around the timed
     # region / launches in it (back-to-back launches of the one kernel; agrees with the rocprofv3 kernel average
     # in profiles/).  A second pass with an event pair around every launch gives the spread; each pair adds the
@@ -514,7 +526,9 @@ def main():
                             % (n_ch, FRAME, ("G.711 %s bytes (decoded on the device)" % args.g711) if law else "int16", nf),
                 "channels_per_gpu": n_ch,
                 "frame_samples": FRAME,
-                "parallelism": ("channels sharded x%d, RCCL gather of block records every %d steps" % (world, args.gather_every))
+                "parallelism": ("channels sharded x%d, RCCL gather of %s every %d steps"
+                                % (world, "one digit byte per block and channel" if args.gather == "digits"
+                                   else "all block records", args.gather_every))
                                if world > 1 else "single GPU",
             },
             "roofline": roof,
@@ -524,7 +538,10 @@ def main():
         print(json.dumps(line))
     if world > 1 or force_gather:
         if rank == 0 and gather is not None and gather.latest() is not None:
-            assert gather.latest().shape == (world, args.gather_every, 2*n_ch)
+            assert gather.latest().shape == (world, args.gather_every, gather.n)
+            if args.gather == "digits":
+                dg = gather.digits()
+                assert dg.shape == (world, args.gather_every, 2, n_ch) and int((dg != 0).sum()) > 0, "no rank reported a digit"
         dist.destroy_process_group()
 
 

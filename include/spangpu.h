@@ -201,6 +201,18 @@ SPANGPU_API int spangpu_bank_blocks(spangpu_bank_t *bank, spangpu_block_t *out, 
    buffer); NULL restores the bank's own.  Size: ceil(samples/block) * n_channels words per frame to come. */
 SPANGPU_API int spangpu_bank_set_records_buffer(spangpu_bank_t *bank, void *device_buffer, size_t bytes);
 SPANGPU_API long long spangpu_bank_copy_records(spangpu_bank_t *bank, void *dst_device, size_t dst_bytes);
+/* The digits of the last spangpu_bank_rx() as a compact device-resident list, written on the bank's stream: dst[0] = how
+   many blocks accepted a digit (SPANGPU_BLK_CHANGE with a non-zero code), dst[1 + i] = channel | code << 20 | block << 28
+   for the first cap_entries of them, in no particular order (dst holds 1 + cap_entries words; a count above cap_entries
+   says the list was cut).  A separate small kernel over the records of the last launch (two stream operations). */
+SPANGPU_API int spangpu_bank_digit_events(spangpu_bank_t *bank, uint32_t *dst_device, int cap_entries);
+/* One byte per block and channel, written by the detector kernel itself beside its records (no extra launch): launches
+   from now on fill dev_ptr as digits[block][channel] = the digit the block delivered, 0 = none (DTMF: digit accepted; Bell
+   MF / R2 MF: the digit of a report).  What a multi-GPU run gathers: a quarter of the record words.  NULL turns it off. */
+SPANGPU_API int spangpu_bank_set_digits_buffer(spangpu_bank_t *bank, void *dev_ptr, size_t bytes);
+/* ... into n_slices slices of slice_bytes, successive launches filling successive slices round and round: one call sets up
+   a reporting interval of n_slices steps. */
+SPANGPU_API int spangpu_bank_set_digits_ring(spangpu_bank_t *bank, void *dev_ptr, size_t slice_bytes, int n_slices);
 /* Parity / diagnostics tap: per-block Goertzel energies of the last call, laid out
    [block][bin][channel] (bank created with trace=1).  Returns blocks-per-call. */
 SPANGPU_API int spangpu_bank_trace(spangpu_bank_t *bank, float *energies, size_t max_floats);

@@ -64,6 +64,10 @@ struct spangpu_bank_s
     uint32_t *rec;
     uint32_t *ext_rec;          // caller-owned record buffer for the next launches (spangpu_bank_set_records_buffer)
     size_t ext_rec_bytes;
+    uint8_t *ext_digits;        // caller-owned digit bytes of the next launches (spangpu_bank_set_digits_buffer / _ring):
+    size_t ext_digits_bytes;    // ... bytes per slice, slices, and which slice the next launch fills
+    int ext_digits_slices;
+    int ext_digits_next;
     uint32_t *cur_rec;          // where the last launch wrote its records
     int next_fmt;               // sample format of the launch being prepared (0 linear, 1 A-law, 2 u-law)
     const int32_t *next_lens;   // per-channel lengths of the launch being prepared (device), or nullptr
@@ -213,6 +217,29 @@ static void dtmf_levels(const spangpu_tone_params_t &tp, float &threshold, float
     if (m  ?  ((tp.set_mask & SPANGPU_TP_THRESHOLD)  &&  tp.threshold_dbm0 > -99.0f)
            :  (tp.threshold_dbm0 > -99.0f  &&  tp.threshold_dbm0 != 0.0f))
         threshold = (float) ((102*102*32768.0f*32768.0f/2.0f)*powf(10.0f, (tp.threshold_dbm0 - 3.14f)/10.0f));
+}
+
+// The digits of the last launch as a compact list, for reports that leave the GPU (an RCCL gather to another rank, a
+// small D2H copy): out[0] = number of blocks in which the debouncer accepted a digit (SPANGPU_BLK_CHANGE with a non-zero
+// code: dtmf.c:318-340, Bell MF :629-655), out[1 + i] = channel | code << 20 | block << 28, in no particular order.
+// A 65536-channel DTMF tick has 131072 record words and, on live lines, a few thousand such blocks.
+__global__ __launch_bounds__(256) void digit_events_kernel(const uint32_t *rec, int n_ch, int maxb, uint32_t *out, int cap)
+{
+    const int ch = (int) (blockIdx.x*256 + threadIdx.x);
+    if (ch >= n_ch)
+        return;
+    for (int b = 0;  b < maxb;  b++)
+    {
+        const uint32_t w = rec[(size_t) b*n_ch + ch];
+        const uint32_t flags = (w >> 16) & 0xFF;
+        const uint32_t code = (w >> 8) & 0xFF;
+        if ((flags & kBlkValid)  &&  (flags & kBlkChange)  &&  code)
+        {
+            const uint32_t at = atomicAdd(out, 1u);
+            if (at < (uint32_t) cap)
+                out[1 + at] = (uint32_t) ch | (code << 20) | ((uint32_t) b << 28);
+        }
+    }
 }
 
 extern "C" int spangpu_set_error(int code, const char *msg)
@@ -499,6 +526,12 @@ static void fill_launch(ToneLaunch &L, spangpu_bank_t *b, const int16_t *d_amp, 
     L.lens = b->next_lens;
     L.lens_ragged = (b->next_lens  &&  b->next_ragged)  ?  1  :  0;
     L.chan_parms = b->chan_parms;
+    L.digits = nullptr;
+    if (b->ext_digits  &&  (size_t) maxb*b->n_ch <= b->ext_digits_bytes)
+    {
+        L.digits = b->ext_digits + (size_t) b->ext_digits_next*b->ext_digits_bytes;
+        b->ext_digits_next = (b->ext_digits_next + 1 < b->ext_digits_slices)  ?  (b->ext_digits_next + 1)  :  0;
+    }
     L.functor = (b->kind == SPANGPU_GOERTZEL)  ?  b->tp.functor  :  0;
     L.functor_threshold = b->tp.functor_threshold;
     {
@@ -1014,6 +1047,47 @@ long long spangpu_bank_copy_records(spangpu_bank_t *b, void *dst_device, size_t 
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipMemcpyAsync(dst_device, b->cur_rec  ?  b->cur_rec  :  b->rec, bytes, hipMemcpyDeviceToDevice, b->stream));
     return (long long) bytes;
+}
+
+// The launches from now on also write one byte per block and channel into a caller-owned device buffer (e.g. a slice of
+// an RCCL send buffer): digits[block][channel] = the digit the block delivered, 0 = none (DTMF: the debouncer accepted a
+// digit; Bell MF / R2 MF: the digit of a report), blocks a channel did not complete in the call = 0.  A quarter of the
+// record words' bytes, no extra launch, no atomics.  A launch whose blocks do not fit `bytes` leaves the buffer alone.
+// _ring: the buffer is n_slices slices of slice_bytes; successive launches fill successive slices, round and round (a
+// reporting interval of n steps is then set up with one call instead of one per step).
+int spangpu_bank_set_digits_ring(spangpu_bank_t *b, void *dev_ptr, size_t slice_bytes, int n_slices)
+{
+    if (b == nullptr  ||  (dev_ptr  &&  n_slices <= 0))
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (dev_ptr  &&  b->kind != SPANGPU_DTMF  &&  b->kind != SPANGPU_BELL_MF  &&  b->kind != SPANGPU_R2_MF)
+        return fail(SPANGPU_ERR_UNSUPPORTED, "digit bytes exist for DTMF / Bell MF / R2 MF banks");
+    b->ext_digits = (uint8_t *) dev_ptr;
+    b->ext_digits_bytes = dev_ptr  ?  slice_bytes  :  0;
+    b->ext_digits_slices = dev_ptr  ?  n_slices  :  0;
+    b->ext_digits_next = 0;
+    return SPANGPU_OK;
+}
+
+int spangpu_bank_set_digits_buffer(spangpu_bank_t *b, void *dev_ptr, size_t bytes)
+{
+    return spangpu_bank_set_digits_ring(b, dev_ptr, bytes, 1);
+}
+
+int spangpu_bank_digit_events(spangpu_bank_t *b, uint32_t *dst_device, int cap_entries)
+{
+    if (b == nullptr  ||  dst_device == nullptr  ||  cap_entries < 0)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (b->n_ch > (1 << 20)  ||  b->last_maxb > 16)
+        return fail(SPANGPU_ERR_UNSUPPORTED, "digit events pack the channel in 20 bits and the block in 4");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemsetAsync(dst_device, 0, sizeof(uint32_t), b->stream));
+    if (b->last_maxb > 0)
+    {
+        hipLaunchKernelGGL(digit_events_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, b->stream,
+                           (const uint32_t *) (b->cur_rec  ?  b->cur_rec  :  b->rec), b->n_ch, b->last_maxb, dst_device, cap_entries);
+        HIP_TRY(hipGetLastError());
+    }
+    return SPANGPU_OK;
 }
 
 int spangpu_bank_trace(spangpu_bank_t *b, float *energies, size_t max_floats)

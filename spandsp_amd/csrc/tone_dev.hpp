@@ -65,6 +65,8 @@ struct ToneLaunch
     long long *probe_ts;        // tools/probe.hip only: per-wave timestamps (kernels built with ABL & 32)
     const int32_t *lens;        // nullptr: every channel has `samples`; else samples per channel in this call (0 = the
                                 // channel sits this call out: its state and block phase are not touched)
+    uint8_t *digits;            // nullptr, or [maxb][n_ch]: per block the digit it delivered (0 = none) -- the one-byte
+                                // report a multi-GPU run gathers instead of the record words
     int functor;                // generic bank: 0 none, 1 v18.c's raw block decision, 2 ademco_contactid.c's (include/spangpu.h)
     float functor_threshold;
     int lens_ragged;            // host side only: lengths other than 0 and `samples` occur (the general kernel takes the call)
@@ -308,6 +310,17 @@ __device__ __forceinline__ void write_trace(const ToneLaunch &L, const float (&e
     for (int i = 0;  i < NB;  i++)
         L.trace[((size_t) nb*(NB + 1) + i)*L.n_ch + ch] = e[i];
     L.trace[((size_t) nb*(NB + 1) + NB)*L.n_ch + ch] = total;
+}
+
+// The digit a block delivered, as one byte (0 = none): DTMF = the debouncer accepted a digit (dtmf.c:318-340: a change to
+// a non-zero code), the MF detectors = the digit of a report (Bell MF: accepted, R2 MF: changed).
+template <bool DTMF>
+__device__ __forceinline__ uint8_t tone_digit_byte(uint32_t recw)
+{
+    const uint32_t flags = (recw >> 16) & 0xFF;
+    const uint32_t code = (recw >> 8) & 0xFF;
+    const bool ev = DTMF  ?  ((flags & kBlkChange)  &&  code != 0)  :  ((flags & kBlkReport) != 0);
+    return (uint8_t) (ev  ?  code  :  0u);
 }
 
 // ---- DTMF (src/dtmf.c:132-361) ------------------------------------------------------
@@ -855,7 +868,11 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
         if (in_bank  &&  sub == 0  &&  mylen == 0)
         {
             for (int b = 0;  b < L.maxb;  b++)
+            {
                 L.rec[(size_t) b*L.n_ch + ch] = 0;
+                if (L.digits)
+                    L.digits[(size_t) b*L.n_ch + ch] = 0;
+            }
         }
         if (!__any(in_bank  &&  mylen > 0))
             return;
@@ -1024,6 +1041,8 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
         const uint32_t recw = det.decide(L, e, energy, w0, w1, ch, nb, store);
         if (store)
             L.rec[(size_t) nb*L.n_ch + ch] = recw;
+        if (L.digits  &&  store)
+            L.digits[(size_t) nb*L.n_ch + ch] = tone_digit_byte<Det::kDuration>(recw);
         nb++;
     };
 
@@ -1266,7 +1285,11 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
         L.si[ch] = (int32_t) (w0 | (uint32_t) cs);
         L.si[(size_t) L.n_ch + ch] = w1;
         for (int b = nb;  b < L.maxb;  b++)
+        {
             L.rec[(size_t) b*L.n_ch + ch] = 0;         // slots without a completed block
+            if (L.digits)
+                L.digits[(size_t) b*L.n_ch + ch] = 0;
+        }
     }
     stamp(15);
 }

@@ -268,7 +268,11 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         if (in_bank  &&  !live  &&  sub == 0)
         {
             for (int b = 0;  b < L.maxb;  b++)
+            {
                 L.rec[(size_t) b*nch + ch] = 0;
+                if (L.digits)
+                    L.digits[(size_t) b*nch + ch] = 0;
+            }
         }
         if (!__any(live))
         {
@@ -516,6 +520,8 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
             rec1 = recw;
         else if (store)
             *(uint32_t *) ((char *) (L.rec + (size_t) nb*nch) + ch4) = recw;
+        if (L.digits  &&  store)
+            L.digits[(size_t) nb*nch + ch] = tone_digit_byte<Det::kDuration>(recw);
         nb++;
     };
     auto chunk_at = [&](uint32_t a) -> int4
@@ -743,6 +749,11 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
             sti((int32_t *) L.rec + (size_t) nch, (int32_t) rec1);
         for (int b = max(nb, 2);  b < L.maxb;  b++)
             sti((int32_t *) L.rec + (size_t) b*nch, 0);    // slots without a completed block
+        if (L.digits)
+        {
+            for (int b = nb;  b < L.maxb;  b++)
+                L.digits[(size_t) b*nch + ch] = 0;
+        }
     }
     stamp(15);
 }

@@ -71,6 +71,9 @@ def lib():
             "spangpu_bank_blocks": (ci, [vp, vp, ci]),
             "spangpu_bank_trace": (ci, [vp, vp, C.c_size_t]),
             "spangpu_bank_copy_records": (ll, [vp, vp, C.c_size_t]),
+            "spangpu_bank_digit_events": (ci, [vp, vp, ci]),
+            "spangpu_bank_set_digits_buffer": (ci, [vp, vp, C.c_size_t]),
+            "spangpu_bank_set_digits_ring": (ci, [vp, vp, C.c_size_t, ci]),
             "spangpu_bank_reset_channel": (ci, [vp, ci, ci]),
             "spangpu_bank_get_state": (ci, [vp, ci, vp, ci, vp, ci]),
             "spangpu_bank_set_state": (ci, [vp, ci, vp, ci, vp, ci]),
@@ -318,6 +321,18 @@ class ToneBank:
 
     def copy_records(self, dst_ptr, dst_bytes):
         return _check(lib().spangpu_bank_copy_records(self.h, dst_ptr, dst_bytes))
+
+    def set_digits_buffer(self, dev_ptr, nbytes):
+        """From now on the detector kernel also writes digits[block][channel] bytes (0 = none) at dev_ptr; None: off."""
+        _check(lib().spangpu_bank_set_digits_buffer(self.h, dev_ptr, nbytes))
+
+    def set_digits_ring(self, dev_ptr, slice_bytes, n_slices):
+        """... successive launches fill successive slices of dev_ptr (n_slices of slice_bytes), round and round."""
+        _check(lib().spangpu_bank_set_digits_ring(self.h, dev_ptr, slice_bytes, n_slices))
+
+    def digit_events_device(self, dst_ptr, cap_entries):
+        """The digits of the last launch as a compact list at dst_ptr (1 + cap_entries uint32 words of device memory)."""
+        _check(lib().spangpu_bank_digit_events(self.h, dst_ptr, cap_entries))
 
     def trace(self, max_blocks=8):
         buf = np.zeros(max_blocks*(self.nbins + 1)*self.n, np.float32)

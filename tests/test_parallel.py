@@ -202,3 +202,77 @@ def test_float_gather_gloo_world2():
         p.join(120)
         assert p.exitcode == 0
     assert out.get(timeout=10) is True
+
+
+class FakeDigitBank:
+    """Stands in for engine.ToneBank with a digits buffer set: a launch writes one byte per block and channel to where it
+    was aimed."""
+
+    def __init__(self, rank, n_ch):
+        self.rank = rank
+        self.n_ch = n_ch
+        self.step = 0
+
+    @staticmethod
+    def expected(rank, step, n_ch):
+        rng = np.random.default_rng(1000*rank + step)
+        d = np.where(rng.random((2, n_ch)) < 0.1, rng.integers(48, 58, (2, n_ch)), 0).astype(np.uint8)
+        return d
+
+    def set_digits_ring(self, dst_ptr, slice_bytes, n_slices):
+        self.ring = (dst_ptr, slice_bytes, n_slices)
+        self.next = 0
+
+    def launch(self):
+        dst_ptr, slice_bytes, n_slices = self.ring
+        d = self.expected(self.rank, self.step, self.n_ch)
+        assert d.nbytes <= slice_bytes
+        ctypes.memmove(dst_ptr + self.next*slice_bytes, d.ctypes.data, d.nbytes)
+        self.next = (self.next + 1) % n_slices
+        self.step += 1
+
+
+def _digit_worker(rank, world, port, steps, every, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spandsp_amd.parallel import DigitGather
+    n_ch = 1031                                 # 2 x 1031 bytes: not a whole number of words
+    g = DigitGather(world, rank, n_ch, 2, torch.device("cpu"), every=every)
+    bank = FakeDigitBank(rank, n_ch)
+    for s in range(steps):
+        g.aim(bank)
+        bank.launch()
+        g.submit(bank)
+    g.drain()
+    ok = True
+    if rank == 0:
+        dg = g.digits().numpy()
+        ok = dg.shape == (world, every, 2, n_ch)
+        last_interval = ((steps - 1)//every)*every
+        for r in range(world):
+            for k in range(every):
+                step = last_interval + k
+                if step < steps:
+                    ok = ok and np.array_equal(dg[r, k], FakeDigitBank.expected(r, step, n_ch))
+        out.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("every,steps", [(1, 4), (5, 10), (5, 13)])
+def test_digit_gather_gloo_world2(every, steps):
+    """bench.py --gpus N (--gather digits): each rank's digit bytes of every step, gathered to rank 0 once per interval."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_digit_worker, args=(r, 2, port, steps, every, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=10) is True

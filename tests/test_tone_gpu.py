@@ -315,6 +315,63 @@ def test_dtmf_zero_db_parameters_through_set_mask(built):
     assert dets[0].snapshot()["normal_twist"] == 1.0
 
 
+def test_digit_events_are_the_digits_of_the_records(built):
+    """spangpu_bank_digit_events() (a compact list made by a small kernel over the last launch's records) and
+    spangpu_bank_set_digits_buffer() (one byte per block and channel written by the detector kernel itself: what a
+    multi-GPU run gathers) hold exactly the digits the full records report; a list cut by its capacity still says how many."""
+    import ctypes
+    from spandsp_amd import engine
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    n_ch = 1000
+    sig, _ = synth.dtmf_channels(n_ch, 160*40, seed=31)
+    bank = engine.ToneBank(engine.DTMF, n_ch)
+    cap = n_ch
+    dev = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dev), 4*(1 + cap)) == 0
+    dev2 = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dev2), 4*(1 + cap)) == 0
+    total = 0
+    armed = False
+    for pos in range(0, sig.shape[1], 160):
+        bank.rx_host(sig[:, pos:pos + 160])
+        blk = bank.blocks()
+        want = sorted((int(r["channel"]), int(r["code"]), int(r["block"])) for r in blk
+                      if (r["flags"] & engine.BLK_CHANGE) and r["code"])
+        small = 3 if pos == 160*20 else cap
+        bank.digit_events_device(dev, small)
+        bank.sync()
+        out = np.zeros(1 + cap, np.uint32)
+        assert hip.hipMemcpy(out.ctypes.data, dev, 4*(1 + small), 2) == 0
+        assert int(out[0]) == len(want), (pos, int(out[0]), len(want))
+        w = out[1:1 + min(small, len(want))].astype(np.int64)
+        got = sorted(zip((w & 0xFFFFF).tolist(), ((w >> 20) & 0xFF).tolist(), ((w >> 28) & 0xF).tolist()))
+        if small == cap:
+            assert got == want, pos
+        else:
+            assert set(got) <= set(want) and len(got) == min(small, len(want))
+        # the one-byte-per-block report written by the detector kernel itself (this launch wrote into dev2)
+        if armed:
+            nb_max = 2
+            dg = np.zeros((nb_max, n_ch), np.uint8)
+            assert hip.hipMemcpy(dg.ctypes.data, dev2, dg.nbytes, 2) == 0
+            exp = np.zeros((nb_max, n_ch), np.uint8)
+            for c, code, b in want:
+                exp[b, c] = code
+            assert np.array_equal(dg, exp), pos
+        fill = np.full((2, n_ch), 0xEE, np.uint8)                       # stale bytes must be overwritten, zeros included
+        assert hip.hipMemcpy(dev2, fill.ctypes.data, fill.nbytes, 1) == 0
+        bank.set_digits_buffer(dev2, 2*n_ch)
+        armed = True
+        total += len(want)
+    assert total > n_ch
+    bank.set_digits_buffer(None, 0)
+    hip.hipFree(dev)
+    hip.hipFree(dev2)
+
+
 def test_dtmf_sample_major_layout(built):
     from spandsp_amd import engine
     n_ch = 70
