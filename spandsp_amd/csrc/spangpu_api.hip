@@ -151,10 +151,38 @@ static void launch_fast(const ToneLaunch &L, hipStream_t st, bool loader)
 {
     const int waves = (L.n_ch + kWave/LPC - 1)/(kWave/LPC);
     const int blocks = (waves + kFastWPB - 1)/kFastWPB;
+    if constexpr (Det::kDigits)
+    {
+        // a launch that also reports one digit byte per block runs the variant with those stores compiled in
+        if (L.digits)
+        {
+            if (loader  &&  LPC == 1)
+                launch_tone_fast<Det, 1, kRingLoader, G711, false, kFastWPB, kToneDigits, true>(L, blocks, st);
+            else
+                launch_tone_fast<Det, LPC, kRingSelf, G711, false, kFastWPB, kToneDigits, false>(L, blocks, st);
+            return;
+        }
+    }
     if (loader  &&  LPC == 1)
         launch_tone_fast<Det, 1, kRingLoader, G711, false, kFastWPB, 0, true>(L, blocks, st);
     else
         launch_tone_fast<Det, LPC, kRingSelf, G711, false, kFastWPB, 0, false>(L, blocks, st);
+}
+
+template <class Det, int LPC>
+static void launch_general(const ToneLaunch &L, hipStream_t st)
+{
+    const int waves = (L.n_ch + kWave/LPC - 1)/(kWave/LPC);
+    const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
+    if constexpr (Det::kDigits)
+    {
+        if (L.digits)
+        {
+            hipLaunchKernelGGL((tone_bank_kernel<Det, LPC, kToneDigits>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((tone_bank_kernel<Det, LPC>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
 }
 
 template <class Det>
@@ -174,17 +202,9 @@ static void launch_tone(const ToneLaunch &L, hipStream_t st)
         return;
     }
     if (L.fmt != 0  ||  pick_lpc(L.n_ch) == 2)              // G.711 input: the LPC = 2 kernels hold the decode table
-    {
-        const int waves = (L.n_ch + 31)/32;
-        const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
-        hipLaunchKernelGGL((tone_bank_kernel<Det, 2>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
-    }
+        launch_general<Det, 2>(L, st);
     else
-    {
-        const int waves = (L.n_ch + kWave - 1)/kWave;
-        const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
-        hipLaunchKernelGGL((tone_bank_kernel<Det, 1>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
-    }
+        launch_general<Det, 1>(L, st);
 }
 
 // Banks of more than 16 bins per channel: always two lanes per channel (16 bins = 8 packed pairs per lane is what one

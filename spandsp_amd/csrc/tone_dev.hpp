@@ -314,6 +314,9 @@ __device__ __forceinline__ void write_trace(const ToneLaunch &L, const float (&e
 
 // The digit a block delivered, as one byte (0 = none): DTMF = the debouncer accepted a digit (dtmf.c:318-340: a change to
 // a non-zero code), the MF detectors = the digit of a report (Bell MF: accepted, R2 MF: changed).
+constexpr int kToneDigits = 4096;       // ABL bit: the digit-byte stores are compiled in (a variant of its own: with the
+                                        // stores merely switched by a pointer test the plain kernel ran 4 % slower)
+
 template <bool DTMF>
 __device__ __forceinline__ uint8_t tone_digit_byte(uint32_t recw)
 {
@@ -331,6 +334,7 @@ struct DtmfDet
     static constexpr bool kEnergy = true;
     static constexpr bool kDuration = true;
     static constexpr bool kFilter = FILTER;
+    static constexpr bool kDigits = true;             // the kernels can also write one digit byte per block (ABL bit kToneDigits)
     static constexpr int NSF = 2*NB + 1 + 4;                // v2, v3, energy, z350[2], z440[2]
     __device__ static __forceinline__ int block_len(const ToneLaunch &) { return 102; }    // dtmf.c:71
 
@@ -512,6 +516,7 @@ struct BellMfDet
     static constexpr bool kEnergy = false;
     static constexpr bool kDuration = false;
     static constexpr bool kFilter = false;
+    static constexpr bool kDigits = true;
     static constexpr int NSF = 2*NB;
     __device__ static __forceinline__ int block_len(const ToneLaunch &) { return 120; }    // bell_r2_mf.c:204
     __device__ __forceinline__ void load_extra(const ToneLaunch &, int) {}
@@ -563,6 +568,7 @@ struct R2MfDet
     static constexpr bool kEnergy = false;
     static constexpr bool kDuration = false;
     static constexpr bool kFilter = false;
+    static constexpr bool kDigits = true;
     static constexpr int NSF = 2*NB;
     __device__ static __forceinline__ int block_len(const ToneLaunch &) { return 133; }    // bell_r2_mf.c:206
     __device__ __forceinline__ void load_extra(const ToneLaunch &, int) {}
@@ -602,6 +608,7 @@ struct MultiDet
     static constexpr bool kEnergy = true;
     static constexpr bool kDuration = false;
     static constexpr bool kFilter = false;
+    static constexpr bool kDigits = false;
     static constexpr int NSF = 2*NB + 1;
     __device__ static __forceinline__ int block_len(const ToneLaunch &L) { return SUPER  ?  128  :  L.block_len; }
     __device__ __forceinline__ void load_extra(const ToneLaunch &, int) {}
@@ -870,7 +877,7 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
             for (int b = 0;  b < L.maxb;  b++)
             {
                 L.rec[(size_t) b*L.n_ch + ch] = 0;
-                if (L.digits)
+                if ((ABL & kToneDigits)  &&  L.digits)
                     L.digits[(size_t) b*L.n_ch + ch] = 0;
             }
         }
@@ -1041,7 +1048,7 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
         const uint32_t recw = det.decide(L, e, energy, w0, w1, ch, nb, store);
         if (store)
             L.rec[(size_t) nb*L.n_ch + ch] = recw;
-        if (L.digits  &&  store)
+        if ((ABL & kToneDigits)  &&  L.digits  &&  store)
             L.digits[(size_t) nb*L.n_ch + ch] = tone_digit_byte<Det::kDuration>(recw);
         nb++;
     };
@@ -1287,7 +1294,7 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
         for (int b = nb;  b < L.maxb;  b++)
         {
             L.rec[(size_t) b*L.n_ch + ch] = 0;         // slots without a completed block
-            if (L.digits)
+            if ((ABL & kToneDigits)  &&  L.digits)
                 L.digits[(size_t) b*L.n_ch + ch] = 0;
         }
     }

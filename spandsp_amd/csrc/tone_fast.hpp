@@ -270,7 +270,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
             for (int b = 0;  b < L.maxb;  b++)
             {
                 L.rec[(size_t) b*nch + ch] = 0;
-                if (L.digits)
+                if ((ABL & kToneDigits)  &&  L.digits)
                     L.digits[(size_t) b*nch + ch] = 0;
             }
         }
@@ -520,7 +520,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
             rec1 = recw;
         else if (store)
             *(uint32_t *) ((char *) (L.rec + (size_t) nb*nch) + ch4) = recw;
-        if (L.digits  &&  store)
+        if ((ABL & kToneDigits)  &&  L.digits  &&  store)
             L.digits[(size_t) nb*nch + ch] = tone_digit_byte<Det::kDuration>(recw);
         nb++;
     };
@@ -749,7 +749,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
             sti((int32_t *) L.rec + (size_t) nch, (int32_t) rec1);
         for (int b = max(nb, 2);  b < L.maxb;  b++)
             sti((int32_t *) L.rec + (size_t) b*nch, 0);    // slots without a completed block
-        if (L.digits)
+        if ((ABL & kToneDigits)  &&  L.digits)
         {
             for (int b = nb;  b < L.maxb;  b++)
                 L.digits[(size_t) b*nch + ch] = 0;
