@@ -308,6 +308,9 @@ static void sweep_big(int n_ch)
     NEW(1, 2, false, 4, 16);        // no DMA (pieces not fetched)
     NEW(1, 2, false, 4, 24);        // neither
     NEW(1, 2, false, 4, 256);       // state only
+    NEW(1, 2, false, 4, 1040);      // no DMA, no state traffic: the compute side alone (recurrence, LDS reads, block ends)
+    NEW(1, 2, false, 4, 1024);      // no state traffic: frame stream + compute
+    NEW(1, 2, false, 4, 1032);      // no state traffic, no recurrence: the frame stream alone
     NEW(1, 2, false, 4, 32);        // stamps
     NEWL(1, 2, false, 0);
     NEWL(1, 2, false, 32);
