@@ -509,6 +509,75 @@ SPANGPU_API int spangpu_mct_get(spangpu_mct_t *mct, int channel);
 SPANGPU_API int spangpu_mct_state_words(const spangpu_mct_t *mct);
 SPANGPU_API int spangpu_mct_get_state(spangpu_mct_t *mct, int channel, int32_t *words);
 
+/* ---- signalling tone banks (sig_tone.c) -----------------
+ * N in-band signalling tone receivers, or senders, of one tone type: 2280 Hz (AC15 and relatives), 2600 Hz, or
+ * 2400 Hz / 2600 Hz (SS5).  A receiver detects the tone(s) -- notch filters as guard filters, a sharp detector that
+ * turns into a flat one on sustained tone, persistence checks -- and rewrites the frame in place: muted, passed, or
+ * passed with the tone notched out.  A sender mutes or passes the frame and adds the tone(s), high level first.
+ *   spangpu_sigtone_rx_create()    sig_tone_rx_init(NULL, tone_type, callback, user)    src/sig_tone.c:672-723
+ *   spangpu_sigtone_rx_set_mode()  sig_tone_rx_set_mode(s, mode, duration)              src/sig_tone.c:666-669
+ *   spangpu_sigtone_rx()           sig_tone_rx(s, amp, len) x N                         src/sig_tone.c:402-663
+ *   spangpu_sigtone_rx_events()    the span_tone_report_func_t calls (signalling_state, 0, duration), :627-635
+ *   spangpu_sigtone_tx_create()    sig_tone_tx_init(NULL, tone_type, callback, user)    src/sig_tone.c:348-382
+ *   spangpu_sigtone_tx_set_mode()  sig_tone_tx_set_mode(s, mode, duration)              src/sig_tone.c:326-345
+ *   spangpu_sigtone_tx()           sig_tone_tx(s, amp, len) x N                         src/sig_tone.c:246-323
+ * tone_type and the mode bits are those of src/spandsp/sig_tone.h:57-88 (below).
+ *
+ * The reference's sender calls back from inside sig_tone_tx() when a mode's duration runs out
+ * (SIG_TONE_TX_UPDATE_REQUEST), and the caller sets the next mode in that callback.  A bank stops each such channel at
+ * that sample: spangpu_sigtone_tx() returns the number of channels whose callback is due, spangpu_sigtone_tx_requests()
+ * says which, the caller sets their next modes and calls spangpu_sigtone_tx_continue() on the same frame until 0 comes
+ * back.  (A caller that never sets a duration never sees a request.)
+ */
+#define SPANGPU_SIG_TONE_2280HZ             1
+#define SPANGPU_SIG_TONE_2600HZ             2
+#define SPANGPU_SIG_TONE_2400HZ_2600HZ      3
+
+#define SPANGPU_SIG_TONE_1_PRESENT          0x001
+#define SPANGPU_SIG_TONE_1_CHANGE           0x002
+#define SPANGPU_SIG_TONE_2_PRESENT          0x004
+#define SPANGPU_SIG_TONE_2_CHANGE           0x008
+#define SPANGPU_SIG_TONE_TX_PASSTHROUGH     0x010
+#define SPANGPU_SIG_TONE_RX_PASSTHROUGH     0x040
+#define SPANGPU_SIG_TONE_RX_FILTER_TONE     0x080
+#define SPANGPU_SIG_TONE_TX_UPDATE_REQUEST  0x100
+
+typedef struct spangpu_sigtone_rx_s spangpu_sigtone_rx_t;
+typedef struct spangpu_sigtone_tx_s spangpu_sigtone_tx_t;
+
+SPANGPU_API int spangpu_sigtone_rx_create(spangpu_sigtone_rx_t **bank, int device, int tone_type, int n_channels);
+SPANGPU_API void spangpu_sigtone_rx_destroy(spangpu_sigtone_rx_t *bank);
+SPANGPU_API int spangpu_sigtone_rx_channels(const spangpu_sigtone_rx_t *bank);
+SPANGPU_API int spangpu_sigtone_rx_set_stream(spangpu_sigtone_rx_t *bank, void *hip_stream);
+SPANGPU_API int spangpu_sigtone_rx_sync(spangpu_sigtone_rx_t *bank);
+/* channel < 0: every channel */
+SPANGPU_API int spangpu_sigtone_rx_set_mode(spangpu_sigtone_rx_t *bank, int channel, int mode);
+/* amp is read AND written: [n_channels] rows of `samples`, `stride` apart */
+SPANGPU_API int spangpu_sigtone_rx(spangpu_sigtone_rx_t *bank, int16_t *amp, int mem, int samples, long long stride);
+SPANGPU_API int spangpu_sigtone_rx_var(spangpu_sigtone_rx_t *bank, int16_t *amp, int mem, const int32_t *lens, int max_samples, long long stride);
+/* events[(channel*cap + i)*3 + {0: sample of the call, 1: signalling_state, 2: duration}], i < counts[channel];
+   returns cap.  Valid until the next call. */
+SPANGPU_API int spangpu_sigtone_rx_events(spangpu_sigtone_rx_t *bank, const int32_t **events, const int32_t **counts);
+SPANGPU_API int spangpu_sigtone_rx_state_words(const spangpu_sigtone_rx_t *bank);
+SPANGPU_API int spangpu_sigtone_rx_get_state(spangpu_sigtone_rx_t *bank, int channel, int32_t *words);
+/* flat_detection_threshold, sharp_detection_threshold, detection_ratio as sig_tone_rx_init() computes them */
+SPANGPU_API int spangpu_sigtone_rx_thresholds(const spangpu_sigtone_rx_t *bank, int32_t out[3]);
+
+SPANGPU_API int spangpu_sigtone_tx_create(spangpu_sigtone_tx_t **bank, int device, int tone_type, int n_channels);
+SPANGPU_API void spangpu_sigtone_tx_destroy(spangpu_sigtone_tx_t *bank);
+SPANGPU_API int spangpu_sigtone_tx_channels(const spangpu_sigtone_tx_t *bank);
+SPANGPU_API int spangpu_sigtone_tx_set_stream(spangpu_sigtone_tx_t *bank, void *hip_stream);
+/* channel < 0: every channel */
+SPANGPU_API int spangpu_sigtone_tx_set_mode(spangpu_sigtone_tx_t *bank, int channel, int mode, int duration);
+/* host arrays of n_channels entries; channels whose modes[] entry is negative keep theirs */
+SPANGPU_API int spangpu_sigtone_tx_set_modes(spangpu_sigtone_tx_t *bank, const int32_t *modes, const int32_t *durations);
+/* both return the number of channels stopped at an update request (0: the frame is done), or a negative error */
+SPANGPU_API int spangpu_sigtone_tx(spangpu_sigtone_tx_t *bank, int16_t *amp, int mem, int samples, long long stride);
+SPANGPU_API int spangpu_sigtone_tx_continue(spangpu_sigtone_tx_t *bank, int16_t *amp, int mem, long long stride);
+SPANGPU_API int spangpu_sigtone_tx_requests(spangpu_sigtone_tx_t *bank, const int32_t **request, const int32_t **stopped);
+SPANGPU_API int spangpu_sigtone_tx_state_words(const spangpu_sigtone_tx_t *bank);
+SPANGPU_API int spangpu_sigtone_tx_get_state(spangpu_sigtone_tx_t *bank, int channel, int32_t *words);
+
 /* ---- modem transmitter banks ---------------------------
  * N V.29, V.27ter or V.17 modulators as device-side signal sources for the receiver banks: training (optionally with
  * the talker echo protection tone), then scrambled data.  Bit-exact with the reference's float build on x86-64.

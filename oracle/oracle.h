@@ -735,6 +735,70 @@ ORC_API void orc_mct_init(orc_mct_t *s, int tone_type, orc_sink_t *sink);
 ORC_API int orc_mct_rx(orc_mct_t *s, const int16_t amp[], int len);
 ORC_API int orc_mct_get(orc_mct_t *s);
 
+/* ---- in-band signalling tones (sigtone_oracle.c) ---- */
+#define ORC_SIG_TONE_2280HZ         1
+#define ORC_SIG_TONE_2600HZ         2
+#define ORC_SIG_TONE_2400HZ_2600HZ  3
+
+/* The first 27 words are the receiver's own state in the order of the device layout (sigtone_dev.hpp). */
+typedef struct
+{
+    struct
+    {
+        float z1[2];
+        float z2[2];
+        int32_t power;
+    } tone[3];
+    float flat_z[2];
+    int32_t flat_power;
+    int32_t tone_persistence_timeout;
+    int32_t last_sample_tone_present;
+    int32_t flat_mode;
+    int32_t flat_mode_timeout;
+    int32_t notch_insertion_timeout;
+    int32_t signalling_state;
+    int32_t signalling_state_duration;
+    int32_t current_notch_filter;
+    int32_t current_rx_tone;
+    int32_t tone_type;
+    int32_t flat_detection_threshold;
+    int32_t sharp_detection_threshold;
+    int32_t detection_ratio;
+    orc_sink_t *sink;
+} orc_sigtone_rx_t;
+
+#define ORC_SIGTONE_RX_WORDS    27
+
+ORC_API int orc_sigtone_rx_sizeof(void);
+ORC_API int orc_sigtone_rx_init(orc_sigtone_rx_t *s, int tone_type, orc_sink_t *sink);
+ORC_API void orc_sigtone_rx_set_mode(orc_sigtone_rx_t *s, int mode);
+ORC_API void orc_sigtone_rx_thresholds(int tone_type, int32_t out[3]);
+ORC_API int orc_sigtone_rx(orc_sigtone_rx_t *s, int16_t amp[], int len);
+
+/* The first 5 words are the sender's own state in the order of the device layout. */
+typedef struct
+{
+    uint32_t phase_acc[2];
+    int32_t high_low_timer;
+    int32_t current_tx_tone;
+    int32_t current_tx_timeout;
+    int32_t phase_rate[2];
+    int16_t tone_scaling[2][2];
+    int32_t tone_type;
+    const int32_t *script;      /* (mode, duration) pairs, one consumed per update request */
+    int32_t script_len;
+    int32_t script_pos;
+    orc_sink_t *sink;
+} orc_sigtone_tx_t;
+
+#define ORC_SIGTONE_TX_WORDS    5
+
+ORC_API int orc_sigtone_tx_sizeof(void);
+ORC_API int orc_sigtone_tx_init(orc_sigtone_tx_t *s, int tone_type, orc_sink_t *sink);
+ORC_API void orc_sigtone_tx_set_mode(orc_sigtone_tx_t *s, int mode, int duration);
+ORC_API void orc_sigtone_tx_script(orc_sigtone_tx_t *s, const int32_t *script, int n_pairs);
+ORC_API int orc_sigtone_tx(orc_sigtone_tx_t *s, int16_t amp[], int len);
+
 #if defined(__cplusplus)
 }
 #endif

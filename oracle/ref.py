@@ -109,6 +109,14 @@ def lib():
             "glue_v17_tx_table": (None, [vp]), "glue_v17_tx_snapshot": (ci, [vp, vp]),
             "glue_v29_tx_table": (None, [vp]), "glue_v29_tx_snapshot": (ci, [vp, vp]), "v29_tx_restart": (ci, [vp, ci, ci]),
             "glue_mct_rx_batch_frames": (None, [vp, vp, ci, C.c_longlong, C.c_longlong, ci, ci, ci]),
+            "sig_tone_rx_init": (vp, [vp, ci, vp, vp]), "sig_tone_rx": (ci, [vp, vp, ci]),
+            "sig_tone_rx_set_mode": (None, [vp, ci, ci]), "sig_tone_rx_free": (ci, [vp]),
+            "glue_sigtone_rx_snapshot": (ci, [vp, vp]), "glue_sigtone_rx_thresholds": (None, [vp, vp]),
+            "glue_sigtone_rx_new_quiet": (vp, [ci, ci, vp]),
+            "glue_sigtone_rx_batch_frames": (None, [vp, vp, ci, C.c_longlong, C.c_longlong, ci, ci, ci]),
+            "glue_sigtone_tx_new": (vp, [ci, vp, ci]), "glue_sigtone_tx_free": (None, [vp]),
+            "glue_sigtone_tx_set_mode": (None, [vp, ci, ci]), "glue_sigtone_tx": (ci, [vp, vp, ci]),
+            "glue_sigtone_tx_requests": (ci, [vp]), "glue_sigtone_tx_snapshot": (ci, [vp, vp]),
             "glue_fsk_preset": (ci, [ci, vp]), "glue_fsk_rx_new": (vp, [ci, ci, vp, vp]),
             "glue_fsk_rx_restart": (ci, [vp, ci, ci]), "glue_fsk_tx_new": (vp, [ci, vp, vp]),
             "glue_fsk_rx_snapshot": (ci, [vp, vp]),
@@ -802,6 +810,74 @@ class MctRx:
     def snapshot(self):
         out = np.zeros(18 + 28 + 4*128, np.int32)
         n = lib().glue_mct_rx_snapshot(self.p, out.ctypes.data)
+        return out[:n].copy()
+
+
+# ---- in-band signalling tones (src/sig_tone.c) ---------------------------------------------
+class SigToneRx:
+    """sig_tone_rx_init(NULL, tone_type, callback, sink); rx() returns the frame as the receiver left it."""
+
+    def __init__(self, tone_type, mode=0):
+        self.sink = Sink()
+        self.p = lib().sig_tone_rx_init(None, tone_type, lib().glue_fn_tone_report(), self.sink.p)
+        if not self.p:
+            raise ValueError("sig_tone_rx_init refused tone type %d" % tone_type)
+        self.set_mode(mode)
+
+    def __del__(self):
+        try:
+            lib().sig_tone_rx_free(self.p)
+        except Exception:
+            pass
+
+    def set_mode(self, mode):
+        lib().sig_tone_rx_set_mode(self.p, mode, 0)
+
+    def rx(self, amp):
+        buf = _i16(amp).copy()
+        lib().sig_tone_rx(self.p, buf.ctypes.data, len(buf))
+        return buf
+
+    def snapshot(self):
+        out = np.zeros(27, np.int32)
+        n = lib().glue_sigtone_rx_snapshot(self.p, out.ctypes.data)
+        return out[:n].copy()
+
+    def thresholds(self):
+        out = np.zeros(3, np.int32)
+        lib().glue_sigtone_rx_thresholds(self.p, out.ctypes.data)
+        return out
+
+
+class SigToneTx:
+    """sig_tone_tx_init(NULL, tone_type, callback, ...) with a callback that sets the next (mode, duration) of `script`."""
+
+    def __init__(self, tone_type, script=()):
+        self.script = np.ascontiguousarray(np.asarray(script, np.int32).reshape(-1, 2))
+        self.p = lib().glue_sigtone_tx_new(tone_type, self.script.ctypes.data, len(self.script))
+        if not self.p:
+            raise ValueError("sig_tone_tx_init refused tone type %d" % tone_type)
+
+    def __del__(self):
+        try:
+            lib().glue_sigtone_tx_free(self.p)
+        except Exception:
+            pass
+
+    def set_mode(self, mode, duration):
+        lib().glue_sigtone_tx_set_mode(self.p, mode, duration)
+
+    def tx(self, amp):
+        buf = _i16(amp).copy()
+        lib().glue_sigtone_tx(self.p, buf.ctypes.data, len(buf))
+        return buf
+
+    def requests(self):
+        return lib().glue_sigtone_tx_requests(self.p)
+
+    def snapshot(self):
+        out = np.zeros(11, np.int32)
+        n = lib().glue_sigtone_tx_snapshot(self.p, out.ctypes.data)
         return out[:n].copy()
 
 

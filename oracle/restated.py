@@ -101,6 +101,12 @@ def lib():
             "orc_mct_init": (None, [vp, ci, vp]),
             "orc_mct_rx": (ci, [vp, vp, ci]),
             "orc_mct_get": (ci, [vp]),
+            "orc_sigtone_rx_sizeof": (ci, []), "orc_sigtone_rx_init": (ci, [vp, ci, vp]),
+            "orc_sigtone_rx_set_mode": (None, [vp, ci]), "orc_sigtone_rx_thresholds": (None, [ci, vp]),
+            "orc_sigtone_rx": (ci, [vp, vp, ci]),
+            "orc_sigtone_tx_sizeof": (ci, []), "orc_sigtone_tx_init": (ci, [vp, ci, vp]),
+            "orc_sigtone_tx_set_mode": (None, [vp, ci, ci]), "orc_sigtone_tx_script": (None, [vp, vp, ci]),
+            "orc_sigtone_tx": (ci, [vp, vp, ci]),
             "orc_echo_sizeof": (ci, []),
             "orc_echo_init": (ci, [vp, ci, ci]),
             "orc_echo_adaption_mode": (None, [vp, ci]),
@@ -643,6 +649,69 @@ class Mct:
             span = int(self.buf[self.WORDS + 15])
             return np.concatenate([w, self.buf[self.WORDS:self.WORDS + 28 + 4*span]])
         return w
+
+
+# ---- in-band signalling tones (sigtone_oracle.c) ------------------------------------------
+class SigToneRx:
+    WORDS = 27
+
+    def __init__(self, tone_type, mode=0):
+        self.buf = np.zeros(lib().orc_sigtone_rx_sizeof()//4 + 2, np.int32)
+        self.p = self.buf.ctypes.data
+        self.sink = Sink()
+        if lib().orc_sigtone_rx_init(self.p, tone_type, self.sink.p) != 0:
+            raise ValueError("not a signalling tone type: %d" % tone_type)
+        self.set_mode(mode)
+
+    def set_mode(self, mode):
+        lib().orc_sigtone_rx_set_mode(self.p, mode)
+
+    def rx(self, amp):
+        buf = _i16(amp).copy()
+        lib().orc_sigtone_rx(self.p, buf.ctypes.data, len(buf))
+        return buf
+
+    def snapshot(self):
+        return self.buf[:self.WORDS].copy()
+
+    def thresholds(self):
+        return self.buf[self.WORDS + 1:self.WORDS + 4].copy()
+
+
+def sigtone_rx_thresholds(tone_type):
+    out = np.zeros(3, np.int32)
+    lib().orc_sigtone_rx_thresholds(tone_type, out.ctypes.data)
+    return out
+
+
+class SigToneTx:
+    WORDS = 5
+
+    def __init__(self, tone_type, script=()):
+        self.buf = np.zeros(lib().orc_sigtone_tx_sizeof()//4 + 2, np.int32)
+        self.p = self.buf.ctypes.data
+        self.sink = Sink()
+        if lib().orc_sigtone_tx_init(self.p, tone_type, self.sink.p) != 0:
+            raise ValueError("not a signalling tone type: %d" % tone_type)
+        self.script = np.ascontiguousarray(np.asarray(script, np.int32).reshape(-1, 2))
+        lib().orc_sigtone_tx_script(self.p, self.script.ctypes.data, len(self.script))
+
+    def set_mode(self, mode, duration):
+        lib().orc_sigtone_tx_set_mode(self.p, mode, duration)
+
+    def tx(self, amp):
+        buf = _i16(amp).copy()
+        lib().orc_sigtone_tx(self.p, buf.ctypes.data, len(buf))
+        return buf
+
+    def requests(self):
+        return len(self.sink.events())
+
+    def snapshot(self):
+        """phase_acc[2], high_low_timer, current_tx_tone, current_tx_timeout, phase_rate[2], the four scalings"""
+        w = self.buf[:7].copy()
+        sc = self.buf[7:9].view(np.int16).astype(np.int32)
+        return np.concatenate([w, sc])
 
 
 # ---- V.29 transmitter (v29tx_oracle.c) ----------------------------------------------------------

@@ -117,6 +117,29 @@ def lib():
             "spangpu_mct_get": (ci, [vp, ci]),
             "spangpu_mct_state_words": (ci, [vp]),
             "spangpu_mct_get_state": (ci, [vp, ci, vp]),
+            "spangpu_sigtone_rx_create": (ci, [C.POINTER(vp), ci, ci, ci]),
+            "spangpu_sigtone_rx_destroy": (None, [vp]),
+            "spangpu_sigtone_rx_channels": (ci, [vp]),
+            "spangpu_sigtone_rx_set_stream": (ci, [vp, vp]),
+            "spangpu_sigtone_rx_sync": (ci, [vp]),
+            "spangpu_sigtone_rx_set_mode": (ci, [vp, ci, ci]),
+            "spangpu_sigtone_rx": (ci, [vp, vp, ci, ci, ll]),
+            "spangpu_sigtone_rx_var": (ci, [vp, vp, ci, vp, ci, ll]),
+            "spangpu_sigtone_rx_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_sigtone_rx_state_words": (ci, [vp]),
+            "spangpu_sigtone_rx_get_state": (ci, [vp, ci, vp]),
+            "spangpu_sigtone_rx_thresholds": (ci, [vp, vp]),
+            "spangpu_sigtone_tx_create": (ci, [C.POINTER(vp), ci, ci, ci]),
+            "spangpu_sigtone_tx_destroy": (None, [vp]),
+            "spangpu_sigtone_tx_channels": (ci, [vp]),
+            "spangpu_sigtone_tx_set_stream": (ci, [vp, vp]),
+            "spangpu_sigtone_tx_set_mode": (ci, [vp, ci, ci, ci]),
+            "spangpu_sigtone_tx_set_modes": (ci, [vp, vp, vp]),
+            "spangpu_sigtone_tx": (ci, [vp, vp, ci, ci, ll]),
+            "spangpu_sigtone_tx_continue": (ci, [vp, vp, ci, ll]),
+            "spangpu_sigtone_tx_requests": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_sigtone_tx_state_words": (ci, [vp]),
+            "spangpu_sigtone_tx_get_state": (ci, [vp, ci, vp]),
             "spangpu_fsk_preset": (ci, [ci, vp]),
             "spangpu_fsk_create": (ci, [C.POINTER(vp), ci, ci, vp, ci]),
             "spangpu_fsk_destroy": (None, [vp]),
@@ -842,6 +865,144 @@ class MctBank:
     def get_state(self, channel):
         w = np.zeros(self.words, np.int32)
         _check(lib().spangpu_mct_get_state(self.h, channel, w.ctypes.data))
+        return w
+
+
+# ---- signalling tone banks (include/spangpu.h "signalling tone banks") ---------------------
+(SIG_TONE_2280HZ, SIG_TONE_2600HZ, SIG_TONE_2400HZ_2600HZ) = (1, 2, 3)
+SIG_TONE_1_PRESENT, SIG_TONE_1_CHANGE, SIG_TONE_2_PRESENT, SIG_TONE_2_CHANGE = 0x001, 0x002, 0x004, 0x008
+SIG_TONE_TX_PASSTHROUGH, SIG_TONE_RX_PASSTHROUGH, SIG_TONE_RX_FILTER_TONE = 0x010, 0x040, 0x080
+SIG_TONE_TX_UPDATE_REQUEST = 0x100
+
+
+class SigToneRxBank:
+    """N in-band signalling tone receivers of one tone type (sig_tone_rx), state in HBM; frames are rewritten in place."""
+
+    def __init__(self, tone_type, n_channels, device=0):
+        self.n = n_channels
+        self.h = C.c_void_p()
+        _check(lib().spangpu_sigtone_rx_create(C.byref(self.h), device, tone_type, n_channels))
+        self.words = lib().spangpu_sigtone_rx_state_words(self.h)
+
+    def close(self):
+        if self.h:
+            lib().spangpu_sigtone_rx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        _check(lib().spangpu_sigtone_rx_set_stream(self.h, hip_stream))
+
+    def sync(self):
+        _check(lib().spangpu_sigtone_rx_sync(self.h))
+
+    def set_mode(self, mode, channel=-1):
+        _check(lib().spangpu_sigtone_rx_set_mode(self.h, channel, mode))
+
+    def rx_host(self, amp):
+        """Returns the frames as the receivers left them."""
+        buf = np.array(amp, np.int16, order="C", copy=True)
+        assert buf.shape[0] == self.n
+        _check(lib().spangpu_sigtone_rx(self.h, buf.ctypes.data, MEM_HOST, buf.shape[1], buf.shape[1]))
+        return buf
+
+    def rx_device(self, ptr, samples, stride=0):
+        _check(lib().spangpu_sigtone_rx(self.h, ptr, MEM_DEVICE, samples, stride))
+
+    def rx_host_var(self, amp, lens):
+        """A tick with per-channel frame lengths (0 = the receiver sits it out, state and row untouched)."""
+        buf = np.array(amp, np.int16, order="C", copy=True)
+        lens = np.ascontiguousarray(lens, np.int32)
+        _check(lib().spangpu_sigtone_rx_var(self.h, buf.ctypes.data, MEM_HOST, lens.ctypes.data, buf.shape[1], buf.shape[1]))
+        return buf
+
+    def events(self):
+        """Per channel: [k, 3] int32 (sample of the call, signalling_state, duration) reports of the last call, in order."""
+        ev = C.c_void_p()
+        cnt = C.c_void_p()
+        cap = _check(lib().spangpu_sigtone_rx_events(self.h, C.byref(ev), C.byref(cnt)))
+        counts = np.ctypeslib.as_array(C.cast(cnt, C.POINTER(C.c_int32)), (self.n,)).copy()
+        flat = np.ctypeslib.as_array(C.cast(ev, C.POINTER(C.c_int32)), (self.n*cap*3,)).reshape(self.n, cap, 3)
+        return [flat[c, :counts[c]].copy() for c in range(self.n)]
+
+    def get_state(self, channel):
+        w = np.zeros(self.words, np.int32)
+        _check(lib().spangpu_sigtone_rx_get_state(self.h, channel, w.ctypes.data))
+        return w
+
+    def thresholds(self):
+        out = np.zeros(3, np.int32)
+        _check(lib().spangpu_sigtone_rx_thresholds(self.h, out.ctypes.data))
+        return out
+
+
+class SigToneTxBank:
+    """N in-band signalling tone senders of one tone type (sig_tone_tx), state in HBM; frames are rewritten in place."""
+
+    def __init__(self, tone_type, n_channels, device=0):
+        self.n = n_channels
+        self.h = C.c_void_p()
+        _check(lib().spangpu_sigtone_tx_create(C.byref(self.h), device, tone_type, n_channels))
+        self.words = lib().spangpu_sigtone_tx_state_words(self.h)
+
+    def close(self):
+        if self.h:
+            lib().spangpu_sigtone_tx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_mode(self, mode, duration, channel=-1):
+        _check(lib().spangpu_sigtone_tx_set_mode(self.h, channel, mode, duration))
+
+    def set_modes(self, modes, durations):
+        modes = np.ascontiguousarray(modes, np.int32)
+        durations = np.ascontiguousarray(durations, np.int32)
+        assert len(modes) == self.n and len(durations) == self.n
+        _check(lib().spangpu_sigtone_tx_set_modes(self.h, modes.ctypes.data, durations.ctypes.data))
+
+    def tx_host(self, amp, on_request=None):
+        """One frame for every channel.  on_request(channels) -> (modes, durations) arrays for those channels is what the
+        reference's update-request callback does; without it a request is simply acknowledged."""
+        buf = np.array(amp, np.int16, order="C", copy=True)
+        assert buf.shape[0] == self.n
+        pending = _check(lib().spangpu_sigtone_tx(self.h, buf.ctypes.data, MEM_HOST, buf.shape[1], buf.shape[1]))
+        rounds = 0
+        while pending > 0:
+            req, _ = self.requests()
+            who = np.nonzero(req)[0]
+            if on_request is not None:
+                modes = np.full(self.n, -1, np.int32)
+                durs = np.zeros(self.n, np.int32)
+                m, d = on_request(who)
+                modes[who] = m
+                durs[who] = d
+                self.set_modes(modes, durs)
+            pending = _check(lib().spangpu_sigtone_tx_continue(self.h, buf.ctypes.data, MEM_HOST, buf.shape[1]))
+            rounds += 1
+            assert rounds <= buf.shape[1] + 1
+        return buf
+
+    def requests(self):
+        req = C.c_void_p()
+        stop = C.c_void_p()
+        _check(lib().spangpu_sigtone_tx_requests(self.h, C.byref(req), C.byref(stop)))
+        r = np.ctypeslib.as_array(C.cast(req, C.POINTER(C.c_int32)), (self.n,)).copy()
+        s = np.ctypeslib.as_array(C.cast(stop, C.POINTER(C.c_int32)), (self.n,)).copy()
+        return r, s
+
+    def get_state(self, channel):
+        w = np.zeros(self.words, np.int32)
+        _check(lib().spangpu_sigtone_tx_get_state(self.h, channel, w.ctypes.data))
         return w
 
 

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import synth  # noqa: E402
 from oracle import ref  # noqa: E402
-from test_oracle_pin import (ALL_FREQS, AWGN_CASES, QAM_GOLDEN_CASES, qam_golden_run, V29TX_CASES, V27TX_CASES, V17TX_CASES, v29tx_run, FSK_CASES, fsk_run, fsk_scenario, mct_run, mct_scenario, ECHO_CASES, V17_CASES, V27_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
+from test_oracle_pin import (SIGTONE_TX_CASES, sigtone_rx_run, sigtone_tx_run, sigtone_tx_script, ALL_FREQS, AWGN_CASES, QAM_GOLDEN_CASES, qam_golden_run, V29TX_CASES, V27TX_CASES, V17TX_CASES, v29tx_run, FSK_CASES, fsk_run, fsk_scenario, mct_run, mct_scenario, ECHO_CASES, V17_CASES, V27_CASES, V29_CASES, bits, build_st_desc, echo_scenario, st_signal,  # noqa: E402
                              tx_scenario, v17_scenario, v27ter_scenario, v29_run, v29_scenario)
 
 
@@ -51,6 +51,21 @@ def mitel_side1():
          signal_crc=np.uint32(run.crc), decode_ok=int(res["decode_ok"]), bandwidth=res["bandwidth"], twist=res["twist"],
          dynamic_range=res["dynamic_range"], guard_time_ms=res["guard_time_ms"], guard_responses=res["guard_responses"],
          snr_levels=res["snr_levels"], acceptable_snr_db=res["acceptable_snr_db"])
+
+
+def sigtone_goldens():
+    """sig_tone_rx / sig_tone_tx of the real reference (oracle/ref.py: SigToneRx, SigToneTx)"""
+    from test_oracle_pin import zlib_crc
+    for tone_type, mode, seed in [(1, 0x40, 12), (2, 0xC0, 15), (3, 0x40, 17)]:
+        x = synth.sig_tone_channels(4, 8000*5, seed, tone_type)[seed % 3]
+        out, ev, snaps = sigtone_rx_run(ref.SigToneRx(tone_type, mode), x)
+        assert len(ev) >= 4
+        save("sigtone_rx_%d_%02x" % (tone_type, mode), amp=x, out=out, events=ev, snapshots=snaps)
+    for tone_type, seed in SIGTONE_TX_CASES:
+        script = np.array(sigtone_tx_script(seed), np.int32)
+        out, snaps, n = sigtone_tx_run(ref.SigToneTx(tone_type, script), seed)
+        save("sigtone_tx_%d" % tone_type, script=script, out_crc=np.uint32(zlib_crc(out)), out_len=np.int64(len(out)),
+             out_head=out[:4000], snapshots=snaps, requests=np.int32(n))
 
 
 def main():
@@ -148,6 +163,7 @@ def main():
         ev, snaps, _ = mct_run(ref.MctRx(rx_type), x)
         assert len(ev) >= 2
         save("mct_%d_%s" % (rx_type, tx_kind), amp=x, events=ev, snapshots=snaps)
+    sigtone_goldens()
     kw = {"table": ref.v29_tx_table()}
     for i, (bit_rate, tep, seed) in enumerate(V29TX_CASES):
         kw["amp_%d" % i], kw["snaps_%d" % i] = v29tx_run(ref.V29Tx(bit_rate, tep, seed), seed)
@@ -182,4 +198,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["sigtone"]:
+        assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+        sigtone_goldens()
+    else:
+        main()

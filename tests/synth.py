@@ -191,3 +191,34 @@ def connect_tone_channels(n_ch, n_samples, seed, kind):
             out[c] = amp*env*np.sin(ph)
         out[c] += rng.normal(0.0, rng.uniform(1.0, 30.0), n_samples)
     return _finish(out)
+
+
+def sig_tone_channels(n_ch, n_samples, seed, tone_type):
+    """Test signals for the in-band signalling tone receivers (sig_tone.c): bursts of the type's tone(s) -- 2280 Hz,
+    2600 Hz, or 2400 / 2600 Hz alone and together -- from 2 ms to 1.2 s long with pauses of the same range, over
+    speech-like noise whose level varies per channel (so that some channels never qualify and some chatter); level,
+    exact frequency and start differ per channel, every seventh channel carries a tone the type does not listen for,
+    every ninth noise only."""
+    rng = np.random.default_rng(seed)
+    freqs = {1: [(2280.0,)], 2: [(2600.0,)], 3: [(2400.0,), (2600.0,), (2400.0, 2600.0)]}[tone_type]
+    out = np.zeros((n_ch, n_samples), np.float64)
+    t = np.arange(n_samples)
+    for c in range(n_ch):
+        out[c] = rng.normal(0.0, dbm0_to_amp(rng.uniform(-60.0, -22.0)), n_samples)
+        if c % 9 == 8:
+            continue
+        amp = dbm0_to_amp(rng.uniform(-24.0, -6.0))
+        pos = int(rng.integers(0, 3000))
+        while pos < n_samples:
+            on = int(rng.choice([16, 40, 200, 700, 2500, 9600], p=[0.1, 0.1, 0.2, 0.25, 0.25, 0.1]))
+            off = int(rng.choice([16, 80, 400, 1600, 4000], p=[0.1, 0.2, 0.3, 0.3, 0.1]))
+            fs = freqs[int(rng.integers(0, len(freqs)))]
+            if c % 7 == 6:
+                fs = (1900.0,)
+            seg = np.zeros(min(on, n_samples - pos))
+            for f in fs:
+                f = f*float(rng.uniform(0.998, 1.002))
+                seg += amp*np.sin(2*np.pi*f*t[:len(seg)]/8000.0 + rng.uniform(0, 6.28))
+            out[c, pos:pos + len(seg)] += seg
+            pos += on + off
+    return _finish(out)

@@ -638,6 +638,120 @@ def test_golden_mct(built, rx_type, tx_kind):
 
 
 # --------------------------------------------------------------------------------------
+# in-band signalling tones (sigtone_oracle.c)
+# --------------------------------------------------------------------------------------
+# (tone type, receiver mode, seed)
+SIGTONE_RX_CASES = [(1, 0x00, 11), (1, 0x40, 12), (1, 0xC0, 13), (2, 0x40, 14), (2, 0xC0, 15), (3, 0x00, 16), (3, 0x40, 17),
+                    (3, 0xC0, 18)]
+SIGTONE_TX_CASES = [(1, 21), (2, 22), (3, 23)]
+
+
+def sigtone_rx_run(rx, x, chunks=(160,)):
+    """frames as the receiver leaves them, reports (state, level, duration), state snapshots every tenth call"""
+    out = []
+    snaps = []
+    k = 0
+    i = 0
+    while k < len(x):
+        m = chunks[i % len(chunks)]
+        out.append(rx.rx(x[k:k + m]))
+        k += m
+        i += 1
+        if i % 10 == 0:
+            snaps.append(rx.snapshot())
+    snaps.append(rx.snapshot())
+    ev = np.array([(e["a"], e["b"], e["c"]) for e in rx.sink.events() if e["kind"] == 1], np.int32).reshape(-1, 3)
+    return np.concatenate(out), ev, np.stack(snaps)
+
+
+def sigtone_tx_script(seed):
+    rng = np.random.default_rng(seed)
+    modes = [0x00, 0x01, 0x04, 0x05, 0x10, 0x11, 0x14, 0x15]
+    script = [(int(rng.choice(modes)), int(rng.choice([1, 37, 160, 161, 400, 801, 2400, 3333]))) for _ in range(60)]
+    script.append((0x11, 0))
+    return script
+
+
+def sigtone_tx_run(tx, seed, frames=200):
+    rng = np.random.default_rng(seed + 1000)
+    tx.set_mode(0x11, 120)
+    out = []
+    snaps = []
+    for f in range(frames):
+        x = rng.integers(-25000, 25000, [160, 80, 333][f % 3]).astype(np.int16)
+        out.append(tx.tx(x))
+        if f % 10 == 9:
+            snaps.append(tx.snapshot())
+    return np.concatenate(out), np.stack(snaps), tx.requests()
+
+
+@needs_ref
+@pytest.mark.parametrize("tone_type,mode,seed", SIGTONE_RX_CASES)
+@pytest.mark.parametrize("chunks", [(160,), (1, 7, 333, 160)])
+def test_sigtone_rx_live(built, tone_type, mode, seed, chunks):
+    from oracle import ref, restated as orc
+    x = synth.sig_tone_channels(4, 8000*5, seed, tone_type)[seed % 3]
+    a, ev_r, s_r = sigtone_rx_run(ref.SigToneRx(tone_type, mode), x, chunks)
+    b, ev_o, s_o = sigtone_rx_run(orc.SigToneRx(tone_type, mode), x, chunks)
+    assert np.array_equal(a, b)
+    assert np.array_equal(ev_r, ev_o)
+    assert np.array_equal(s_r, s_o)
+    assert len(ev_r) >= 4
+    assert np.array_equal(ref.SigToneRx(tone_type).thresholds(), orc.sigtone_rx_thresholds(tone_type))
+    if mode == 0:
+        assert not a.any()                    # the media path is muted
+    elif mode == 0xC0:
+        assert not np.array_equal(a, x)       # the notch is always in
+
+
+@needs_ref
+def test_sigtone_init_refusals_live(built):
+    from oracle import ref, restated as orc
+    for t in (0, 4):
+        with pytest.raises(ValueError):
+            ref.SigToneRx(t)
+        with pytest.raises(ValueError):
+            orc.SigToneRx(t)
+        with pytest.raises(ValueError):
+            ref.SigToneTx(t)
+        with pytest.raises(ValueError):
+            orc.SigToneTx(t)
+
+
+@needs_ref
+@pytest.mark.parametrize("tone_type,seed", SIGTONE_TX_CASES)
+def test_sigtone_tx_live(built, tone_type, seed):
+    from oracle import ref, restated as orc
+    script = sigtone_tx_script(seed)
+    a, s_r, n_r = sigtone_tx_run(ref.SigToneTx(tone_type, script), seed)
+    b, s_o, n_o = sigtone_tx_run(orc.SigToneTx(tone_type, script), seed)
+    assert np.array_equal(a, b)
+    assert np.array_equal(s_r, s_o)
+    assert n_r == n_o and n_r > 20
+
+
+@pytest.mark.parametrize("tone_type,mode,seed", [(1, 0x40, 12), (2, 0xC0, 15), (3, 0x40, 17)])
+def test_golden_sigtone_rx(built, tone_type, mode, seed):
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, "sigtone_rx_%d_%02x.npz" % (tone_type, mode)))
+    out, ev, snaps = sigtone_rx_run(orc.SigToneRx(tone_type, mode), g["amp"])
+    assert np.array_equal(out, g["out"])
+    assert np.array_equal(ev, g["events"])
+    assert np.array_equal(snaps, g["snapshots"])
+
+
+@pytest.mark.parametrize("tone_type,seed", SIGTONE_TX_CASES)
+def test_golden_sigtone_tx(built, tone_type, seed):
+    from oracle import restated as orc
+    g = np.load(os.path.join(GOLDEN, "sigtone_tx_%d.npz" % tone_type))
+    out, snaps, n = sigtone_tx_run(orc.SigToneTx(tone_type, g["script"]), seed)
+    assert zlib_crc(out) == int(g["out_crc"]) and len(out) == int(g["out_len"])
+    assert np.array_equal(out[:4000], g["out_head"])
+    assert np.array_equal(snaps, g["snapshots"])
+    assert n == int(g["requests"])
+
+
+# --------------------------------------------------------------------------------------
 # V.29 transmitter (v29tx_oracle.c)
 # --------------------------------------------------------------------------------------
 V29TX_CASES = [(9600, False, 0x1234), (9600, True, 0x0001), (7200, False, 0x7FFF), (7200, True, 0x2B2B), (4800, False, 0x0F0F),
