@@ -560,6 +560,7 @@ SPANGPU_API int spangpu_sigtone_rx_var(spangpu_sigtone_rx_t *bank, int16_t *amp,
 SPANGPU_API int spangpu_sigtone_rx_events(spangpu_sigtone_rx_t *bank, const int32_t **events, const int32_t **counts);
 SPANGPU_API int spangpu_sigtone_rx_state_words(const spangpu_sigtone_rx_t *bank);
 SPANGPU_API int spangpu_sigtone_rx_get_state(spangpu_sigtone_rx_t *bank, int channel, int32_t *words);
+SPANGPU_API int spangpu_sigtone_rx_set_state(spangpu_sigtone_rx_t *bank, int channel, const int32_t *words);
 /* flat_detection_threshold, sharp_detection_threshold, detection_ratio as sig_tone_rx_init() computes them */
 SPANGPU_API int spangpu_sigtone_rx_thresholds(const spangpu_sigtone_rx_t *bank, int32_t out[3]);
 

@@ -418,6 +418,31 @@ SPANGPU_API int modem_connect_tones_rx_release(modem_connect_tones_rx_state_t *s
 SPANGPU_API int modem_connect_tones_rx_free(modem_connect_tones_rx_state_t *s);
 SPANGPU_API const char *modem_connect_tone_to_str(int tone);
 
+/* ---- in-band signalling tones (csrc/shim_sigtone.c) ------------------------------------------------------
+ * Reference declarations being replaced:
+ *   sig_tone_rx_init/_rx/_set_mode/_release/_free, sig_tone_tx_init/_tx/_set_mode/_release/_free
+ *                                          src/spandsp/sig_tone.h:57-176   src/sig_tone.c:246-738
+ * Tone types SIG_TONE_2280HZ .. SIG_TONE_2400HZ_2600HZ (1..3) and the mode / report bits are the SPANGPU_SIG_TONE_*
+ * values of spangpu.h.  An object is a private one-channel bank (N channels per launch: spangpu_sigtone_rx_create()
+ * etc.); as everywhere, caller storage (s != NULL) returns NULL.  Callbacks arrive from inside the call, in order, and a
+ * mode set in one applies to the rest of the same frame, as in the reference.
+ */
+typedef struct sig_tone_rx_state_s sig_tone_rx_state_t;
+typedef struct sig_tone_tx_state_s sig_tone_tx_state_t;
+
+SPANGPU_API sig_tone_rx_state_t *sig_tone_rx_init(sig_tone_rx_state_t *s, int tone_type, span_tone_report_func_t sig_update,
+                                                  void *user_data);
+SPANGPU_API int sig_tone_rx(sig_tone_rx_state_t *s, int16_t amp[], int len);
+SPANGPU_API void sig_tone_rx_set_mode(sig_tone_rx_state_t *s, int mode, int duration);
+SPANGPU_API int sig_tone_rx_release(sig_tone_rx_state_t *s);
+SPANGPU_API int sig_tone_rx_free(sig_tone_rx_state_t *s);
+SPANGPU_API sig_tone_tx_state_t *sig_tone_tx_init(sig_tone_tx_state_t *s, int tone_type, span_tone_report_func_t sig_update,
+                                                  void *user_data);
+SPANGPU_API int sig_tone_tx(sig_tone_tx_state_t *s, int16_t amp[], int len);
+SPANGPU_API void sig_tone_tx_set_mode(sig_tone_tx_state_t *s, int mode, int duration);
+SPANGPU_API int sig_tone_tx_release(sig_tone_tx_state_t *s);
+SPANGPU_API int sig_tone_tx_free(sig_tone_tx_state_t *s);
+
 SPANGPU_API dtmf_tx_state_t *dtmf_tx_init(dtmf_tx_state_t *s, digits_tx_callback_t callback, void *user_data);
 SPANGPU_API int dtmf_tx_release(dtmf_tx_state_t *s);
 SPANGPU_API int dtmf_tx_free(dtmf_tx_state_t *s);

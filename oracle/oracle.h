@@ -765,6 +765,9 @@ typedef struct
     int32_t sharp_detection_threshold;
     int32_t detection_ratio;
     orc_sink_t *sink;
+    const int32_t *script;      /* modes, one set from inside each report (what a caller's callback may do) */
+    int32_t script_len;
+    int32_t script_pos;
 } orc_sigtone_rx_t;
 
 #define ORC_SIGTONE_RX_WORDS    27
@@ -772,6 +775,7 @@ typedef struct
 ORC_API int orc_sigtone_rx_sizeof(void);
 ORC_API int orc_sigtone_rx_init(orc_sigtone_rx_t *s, int tone_type, orc_sink_t *sink);
 ORC_API void orc_sigtone_rx_set_mode(orc_sigtone_rx_t *s, int mode);
+ORC_API void orc_sigtone_rx_script(orc_sigtone_rx_t *s, const int32_t *modes, int n);
 ORC_API void orc_sigtone_rx_thresholds(int tone_type, int32_t out[3]);
 ORC_API int orc_sigtone_rx(orc_sigtone_rx_t *s, int16_t amp[], int len);
 

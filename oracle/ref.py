@@ -114,6 +114,9 @@ def lib():
             "glue_sigtone_rx_snapshot": (ci, [vp, vp]), "glue_sigtone_rx_thresholds": (None, [vp, vp]),
             "glue_sigtone_rx_new_quiet": (vp, [ci, ci, vp]),
             "glue_sigtone_rx_batch_frames": (None, [vp, vp, ci, C.c_longlong, C.c_longlong, ci, ci, ci]),
+            "glue_sigtone_rx_scripted_new": (vp, [ci, ci, vp, ci]), "glue_sigtone_rx_scripted_free": (None, [vp]),
+            "glue_sigtone_rx_scripted": (ci, [vp, vp, ci]), "glue_sigtone_rx_scripted_reports": (ci, [vp, C.POINTER(vp)]),
+            "glue_sigtone_rx_scripted_state": (vp, [vp]),
             "glue_sigtone_tx_new": (vp, [ci, vp, ci]), "glue_sigtone_tx_free": (None, [vp]),
             "glue_sigtone_tx_set_mode": (None, [vp, ci, ci]), "glue_sigtone_tx": (ci, [vp, vp, ci]),
             "glue_sigtone_tx_requests": (ci, [vp]), "glue_sigtone_tx_snapshot": (ci, [vp, vp]),
@@ -846,6 +849,37 @@ class SigToneRx:
     def thresholds(self):
         out = np.zeros(3, np.int32)
         lib().glue_sigtone_rx_thresholds(self.p, out.ctypes.data)
+        return out
+
+
+class SigToneRxScripted:
+    """A receiver whose callback sets the next mode of `script` at every report (sig_tone_rx_set_mode from inside it)."""
+
+    def __init__(self, tone_type, mode, script):
+        self.script = np.ascontiguousarray(script, np.int32)
+        self.p = lib().glue_sigtone_rx_scripted_new(tone_type, mode, self.script.ctypes.data, len(self.script))
+
+    def __del__(self):
+        try:
+            lib().glue_sigtone_rx_scripted_free(self.p)
+        except Exception:
+            pass
+
+    def rx(self, amp):
+        buf = _i16(amp).copy()
+        lib().glue_sigtone_rx_scripted(self.p, buf.ctypes.data, len(buf))
+        return buf
+
+    def reports(self):
+        ptr = C.c_void_p()
+        n = lib().glue_sigtone_rx_scripted_reports(self.p, C.byref(ptr))
+        if n == 0:
+            return np.zeros((0, 3), np.int32)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), (n*3,)).reshape(n, 3).copy()
+
+    def snapshot(self):
+        out = np.zeros(27, np.int32)
+        lib().glue_sigtone_rx_snapshot(lib().glue_sigtone_rx_scripted_state(self.p), out.ctypes.data)
         return out
 
 

@@ -93,6 +93,78 @@ GLUE void glue_sigtone_rx_batch_frames(sig_tone_rx_state_t **s, int16_t *amp, in
     }
 }
 
+/* A receiver whose callback records the report and sets the next mode of a script */
+typedef struct
+{
+    sig_tone_rx_state_t *rx;
+    const int32_t *script;
+    int script_len;
+    int script_pos;
+    int32_t *reports;           /* (state, level, duration) triples */
+    int n_reports;
+    int cap_reports;
+} glue_sigtone_rx_t;
+
+static void rx_update(void *user_data, int what, int level, int duration)
+{
+    glue_sigtone_rx_t *g = (glue_sigtone_rx_t *) user_data;
+
+    if (g->n_reports == g->cap_reports)
+    {
+        g->cap_reports = g->cap_reports  ?  2*g->cap_reports  :  64;
+        g->reports = (int32_t *) realloc(g->reports, sizeof(int32_t)*3*g->cap_reports);
+    }
+    g->reports[3*g->n_reports] = what;
+    g->reports[3*g->n_reports + 1] = level;
+    g->reports[3*g->n_reports + 2] = duration;
+    g->n_reports++;
+    if (g->script_pos < g->script_len)
+        sig_tone_rx_set_mode(g->rx, g->script[g->script_pos++], 0);
+}
+
+GLUE glue_sigtone_rx_t *glue_sigtone_rx_scripted_new(int tone_type, int mode, const int32_t *script, int n)
+{
+    glue_sigtone_rx_t *g = (glue_sigtone_rx_t *) calloc(1, sizeof(*g));
+
+    if (g == NULL)
+        return NULL;
+    if ((g->rx = sig_tone_rx_init(NULL, tone_type, rx_update, g)) == NULL)
+    {
+        free(g);
+        return NULL;
+    }
+    sig_tone_rx_set_mode(g->rx, mode, 0);
+    g->script = script;
+    g->script_len = n;
+    return g;
+}
+
+GLUE void glue_sigtone_rx_scripted_free(glue_sigtone_rx_t *g)
+{
+    if (g)
+    {
+        sig_tone_rx_free(g->rx);
+        free(g->reports);
+        free(g);
+    }
+}
+
+GLUE int glue_sigtone_rx_scripted(glue_sigtone_rx_t *g, int16_t amp[], int len)
+{
+    return sig_tone_rx(g->rx, amp, len);
+}
+
+GLUE int glue_sigtone_rx_scripted_reports(const glue_sigtone_rx_t *g, const int32_t **reports)
+{
+    *reports = g->reports;
+    return g->n_reports;
+}
+
+GLUE const sig_tone_rx_state_t *glue_sigtone_rx_scripted_state(const glue_sigtone_rx_t *g)
+{
+    return g->rx;
+}
+
 typedef struct
 {
     sig_tone_tx_state_t *tx;

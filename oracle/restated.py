@@ -102,7 +102,7 @@ def lib():
             "orc_mct_rx": (ci, [vp, vp, ci]),
             "orc_mct_get": (ci, [vp]),
             "orc_sigtone_rx_sizeof": (ci, []), "orc_sigtone_rx_init": (ci, [vp, ci, vp]),
-            "orc_sigtone_rx_set_mode": (None, [vp, ci]), "orc_sigtone_rx_thresholds": (None, [ci, vp]),
+            "orc_sigtone_rx_set_mode": (None, [vp, ci]), "orc_sigtone_rx_script": (None, [vp, vp, ci]), "orc_sigtone_rx_thresholds": (None, [ci, vp]),
             "orc_sigtone_rx": (ci, [vp, vp, ci]),
             "orc_sigtone_tx_sizeof": (ci, []), "orc_sigtone_tx_init": (ci, [vp, ci, vp]),
             "orc_sigtone_tx_set_mode": (None, [vp, ci, ci]), "orc_sigtone_tx_script": (None, [vp, vp, ci]),
@@ -665,6 +665,11 @@ class SigToneRx:
 
     def set_mode(self, mode):
         lib().orc_sigtone_rx_set_mode(self.p, mode)
+
+    def script(self, modes):
+        """modes set from inside the reports, one each, as a caller's callback might"""
+        self._script = np.ascontiguousarray(modes, np.int32)
+        lib().orc_sigtone_rx_script(self.p, self._script.ctypes.data, len(self._script))
 
     def rx(self, amp):
         buf = _i16(amp).copy()

@@ -144,6 +144,13 @@ void orc_sigtone_rx_set_mode(orc_sigtone_rx_t *s, int mode)
     s->current_rx_tone = mode;          /* sig_tone.c:666-669 */
 }
 
+void orc_sigtone_rx_script(orc_sigtone_rx_t *s, const int32_t *modes, int n)
+{
+    s->script = modes;
+    s->script_len = n;
+    s->script_pos = 0;
+}
+
 void orc_sigtone_rx_thresholds(int tone_type, int32_t out[3])
 {
     orc_sigtone_rx_t t;
@@ -295,6 +302,9 @@ int orc_sigtone_rx(orc_sigtone_rx_t *s, int16_t amp[], int len)
         {
             if (s->sink)
                 orc_sink_push(s->sink, 1, s->signalling_state, 0, s->signalling_state_duration);
+            /* inside the callback: a caller may set the mode, which the media path of this very sample then uses */
+            if (s->script_pos < s->script_len)
+                s->current_rx_tone = s->script[s->script_pos++];
             s->signalling_state &= ~(0x002 | 0x008);
             s->signalling_state_duration = 0;
         }

@@ -381,6 +381,18 @@ int spangpu_sigtone_rx_get_state(spangpu_sigtone_rx_t *b, int channel, int32_t *
     return SPANGPU_OK;
 }
 
+// The reverse of spangpu_sigtone_rx_get_state(): a channel's 27 words as a caller holds them (a snapshot taken earlier).
+int spangpu_sigtone_rx_set_state(spangpu_sigtone_rx_t *b, int channel, const int32_t *words)
+{
+    if (b == NULL  ||  words == NULL  ||  channel < 0  ||  channel >= b->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    SIG_TRY(hipSetDevice(b->device));
+    SIG_TRY(hipMemcpy2DAsync(b->st + channel, (size_t) b->n_ch*sizeof(int32_t), words, sizeof(int32_t), sizeof(int32_t), kSigRxWords,
+                             hipMemcpyHostToDevice, b->stream));
+    SIG_TRY(hipStreamSynchronize(b->stream));
+    return SPANGPU_OK;
+}
+
 int spangpu_sigtone_rx_thresholds(const spangpu_sigtone_rx_t *b, int32_t out[3])
 {
     if (b == NULL  ||  out == NULL)

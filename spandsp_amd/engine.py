@@ -128,6 +128,7 @@ def lib():
             "spangpu_sigtone_rx_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
             "spangpu_sigtone_rx_state_words": (ci, [vp]),
             "spangpu_sigtone_rx_get_state": (ci, [vp, ci, vp]),
+            "spangpu_sigtone_rx_set_state": (ci, [vp, ci, vp]),
             "spangpu_sigtone_rx_thresholds": (ci, [vp, vp]),
             "spangpu_sigtone_tx_create": (ci, [C.POINTER(vp), ci, ci, ci]),
             "spangpu_sigtone_tx_destroy": (None, [vp]),
@@ -934,6 +935,11 @@ class SigToneRxBank:
         w = np.zeros(self.words, np.int32)
         _check(lib().spangpu_sigtone_rx_get_state(self.h, channel, w.ctypes.data))
         return w
+
+    def set_state(self, channel, words):
+        w = np.ascontiguousarray(words, np.int32)
+        assert len(w) == self.words
+        _check(lib().spangpu_sigtone_rx_set_state(self.h, channel, w.ctypes.data))
 
     def thresholds(self):
         out = np.zeros(3, np.int32)

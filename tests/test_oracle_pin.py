@@ -705,6 +705,23 @@ def test_sigtone_rx_live(built, tone_type, mode, seed, chunks):
 
 
 @needs_ref
+@pytest.mark.parametrize("tone_type", [1, 2, 3])
+def test_sigtone_rx_mode_set_in_callback_live(built, tone_type):
+    """sig_tone_rx_set_mode() called from inside the report: the media path of that very sample already uses the mode"""
+    from oracle import ref, restated as orc
+    x = synth.sig_tone_channels(4, 8000*5, 30 + tone_type, tone_type)[1]
+    script = [0x40, 0x00, 0xC0, 0x40, 0x00, 0xC0]*10
+    a = ref.SigToneRxScripted(tone_type, 0x40, script)
+    b = orc.SigToneRx(tone_type, 0x40)
+    b.script(script)
+    for k in range(0, len(x), 160):
+        assert np.array_equal(a.rx(x[k:k + 160]), b.rx(x[k:k + 160])), k
+    ev = np.array([(e["a"], e["b"], e["c"]) for e in b.sink.events()], np.int32).reshape(-1, 3)
+    assert np.array_equal(a.reports(), ev) and len(ev) >= 10
+    assert np.array_equal(a.snapshot(), b.snapshot())
+
+
+@needs_ref
 def test_sigtone_init_refusals_live(built):
     from oracle import ref, restated as orc
     for t in (0, 4):
