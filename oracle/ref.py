@@ -1038,7 +1038,7 @@ class V17Tx(V29Tx):
 
 
 # ---- the pthread driver of the cpu_baseline legs (ref_glue/ref_glue_mt.c) ---------------------------------------
-MT_DTMF, MT_BELL_MF, MT_R2_MF, MT_SUPER_TONE, MT_V29, MT_V27TER, MT_V17, MT_FSK, MT_MCT = range(9)
+MT_DTMF, MT_BELL_MF, MT_R2_MF, MT_SUPER_TONE, MT_V29, MT_V27TER, MT_V17, MT_FSK, MT_MCT, MT_SIGTONE = range(10)
 
 
 def mt_rx(kind, states, frames, loops, threads):

@@ -38,6 +38,7 @@
 #include "spandsp/godard.h"
 #include "spandsp/fsk.h"
 #include "spandsp/modem_connect_tones.h"
+#include "spandsp/sig_tone.h"
 #include "spandsp/v29rx.h"
 #include "spandsp/v27ter_rx.h"
 #include "spandsp/v17rx.h"
@@ -47,7 +48,7 @@
 enum
 {
     GLUE_MT_DTMF = 0, GLUE_MT_BELL_MF, GLUE_MT_R2_MF, GLUE_MT_SUPER_TONE, GLUE_MT_V29, GLUE_MT_V27TER, GLUE_MT_V17,
-    GLUE_MT_FSK, GLUE_MT_MCT
+    GLUE_MT_FSK, GLUE_MT_MCT, GLUE_MT_SIGTONE
 };
 
 typedef struct
@@ -80,6 +81,16 @@ static void rx_one(int kind, void *s, const int16_t *amp, int n)
     case GLUE_MT_V17:           v17_rx((v17_rx_state_t *) s, amp, n); break;
     case GLUE_MT_FSK:           fsk_rx((fsk_rx_state_t *) s, amp, n); break;
     case GLUE_MT_MCT:           modem_connect_tones_rx((modem_connect_tones_rx_state_t *) s, amp, n); break;
+    case GLUE_MT_SIGTONE:
+        {
+            /* the receiver rewrites its frame: it gets a copy, so that every pass sees the same signal */
+            int16_t scratch[1024];
+            const int m = (n > 1024)  ?  1024  :  n;
+
+            memcpy(scratch, amp, sizeof(int16_t)*m);
+            sig_tone_rx((sig_tone_rx_state_t *) s, scratch, m);
+        }
+        break;
     }
 }
 

@@ -201,13 +201,21 @@ __global__ __launch_bounds__(64) void sigtone_rx_kernel(const SigRxLaunch L)
     int16_t *row = L.pcm + (size_t) ch*L.stride;
     const bool vec = (L.vec != 0);
 
+    // The frame goes through the lane in chunks of eight samples (one 16-byte access each way); the next chunk is requested
+    // before the current one is worked on.  The per-sample logic is written as selects, not branches: the lanes of a wave
+    // are different lines in different signalling states, and a branch taken by any of them is paid by all.
+    int4 q_next = {0, 0, 0, 0};
+    if (vec  &&  mylen >= 8)
+        q_next = *(const int4 *) row;
     for (int base = 0;  base < mylen;  base += 8)
     {
         const int todo = min(8, mylen - base);
         int32_t a[8];
         if (vec  &&  todo == 8)
         {
-            const int4 q = *(const int4 *) (row + base);
+            const int4 q = q_next;
+            if (base + 16 <= mylen)
+                q_next = *(const int4 *) (row + base + 8);
             a[0] = (int16_t) q.x;  a[1] = q.x >> 16;
             a[2] = (int16_t) q.y;  a[3] = q.y >> 16;
             a[4] = (int16_t) q.z;  a[5] = q.z >> 16;
@@ -225,115 +233,73 @@ __global__ __launch_bounds__(64) void sigtone_rx_kernel(const SigRxLaunch L)
             if (k >= todo)
                 continue;
             const float famp = (float) a[k];
-            if (duration < INT_MAX)
-                duration++;
+            duration += (duration < INT_MAX)  ?  1  :  0;
             // ---- the notch filters and their power meters, sig_tone.c:437-487 ----
-            float notched[3] = {0.0f, 0.0f, 0.0f};
-            int32_t notch_power[3] = {0, INT_MAX, INT_MAX};
-            notched[0] = sig_notch_step(c0, t[0], famp);
-            notch_power[0] = sig_meter(t[0].power, sig_to_i16(notched[0]));
+            float notched1 = 0.0f;
+            float notched2 = 0.0f;
+            int32_t np1 = INT_MAX;
+            int32_t np2 = INT_MAX;
+            const float notched0 = sig_notch_step(c0, t[0], famp);
+            const int32_t np0 = sig_meter(t[0].power, sig_to_i16(notched0));
             if constexpr (NT == 3)
             {
-                notched[1] = sig_notch_step(c1, t[1], famp);
-                notch_power[1] = sig_meter(t[1].power, sig_to_i16(notched[1]));
-                notched[2] = sig_notch_step(c0, t[2], notched[1]);
-                notch_power[2] = sig_meter(t[2].power, sig_to_i16(notched[2]));
+                notched1 = sig_notch_step(c1, t[1], famp);
+                np1 = sig_meter(t[1].power, sig_to_i16(notched1));
+                notched2 = sig_notch_step(c0, t[2], notched1);
+                np2 = sig_meter(t[2].power, sig_to_i16(notched2));
             }
             // ---- sharp or flat, sig_tone.c:488-499 ----
             const bool present = (state & (SIG_1_PRESENT | SIG_2_PRESENT)) != 0;
-            if (present)
+            bool flat = false;
+            float band = famp;
+            if constexpr (kFlat)
             {
-                if (flat_timeout  &&  --flat_timeout == 0)
-                    flat_mode = 1;
+                const bool tick = present  &&  (flat_timeout != 0);
+                const int32_t ft = flat_timeout - (tick  ?  1  :  0);
+                flat_mode = present  ?  ((tick  &&  ft == 0)  ?  1  :  flat_mode)  :  0;
+                flat_timeout = present  ?  ft  :  kSharpFlat;
+                flat = (flat_mode != 0);
+                // the flat mode bi-quad, sig_tone.c:507-528: it only runs (its state only moves) in flat mode
+                float v = famp*0.393676f + flat_z0*-0.261778f + flat_z1*-0.359985f;
+                const float x = v;
+                v += flat_z0*-0.5f + flat_z1*-0.5f;
+                band = v;
+                flat_z1 = flat  ?  flat_z0  :  flat_z1;
+                flat_z0 = flat  ?  x  :  flat_z0;
             }
-            else
+            const int32_t fp = sig_meter(flat_power, flat  ?  sig_to_i16(band)  :  a[k]);
+            // ---- flat mode, sig_tone.c:530-561: a plain power threshold ----
+            int32_t st_flat = state;
+            int32_t nt_flat = notch_timeout;
+            if constexpr (kFlat)
             {
-                flat_timeout = kSharpFlat;
-                flat_mode = 0;
+                st_flat = present  ?  ((fp < L.flat_threshold)  ?  ((state & ~SIG_1_PRESENT) | SIG_1_CHANGE)  :  state)
+                                   :  ((fp > L.flat_threshold)  ?  (state | SIG_1_PRESENT | SIG_1_CHANGE)  :  state);
+                nt_flat = (st_flat & (SIG_1_PRESENT | SIG_2_PRESENT))  ?  kNotchLag  :  (notch_timeout - ((notch_timeout != 0)  ?  1  :  0));
             }
-            int immediate = -1;
-            if (flat_mode)
-            {
-                // flat mode, sig_tone.c:503-561
-                float band = famp;
-                if (kFlat)
-                {
-                    float v = famp*0.393676f + flat_z0*-0.261778f + flat_z1*-0.359985f;
-                    const float x = v;
-                    v += flat_z0*-0.5f + flat_z1*-0.5f;
-                    flat_z1 = flat_z0;
-                    flat_z0 = x;
-                    band = v;
-                }
-                const int32_t fp = sig_meter(flat_power, sig_to_i16(band));
-                if (present)
-                {
-                    if (fp < L.flat_threshold)
-                    {
-                        state &= ~SIG_1_PRESENT;
-                        state |= SIG_1_CHANGE;
-                    }
-                }
-                else
-                {
-                    if (fp > L.flat_threshold)
-                        state |= (SIG_1_PRESENT | SIG_1_CHANGE);
-                }
-                if ((state & (SIG_1_PRESENT | SIG_2_PRESENT)))
-                    notch_timeout = kNotchLag;
-                else if (notch_timeout)
-                    notch_timeout--;
-            }
-            else
-            {
-                // sharp mode, sig_tone.c:563-625
-                const int32_t fp = sig_meter(flat_power, a[k]);
-                if (fp >= L.sharp_threshold)
-                {
-                    const int m = (notch_power[0] < notch_power[1])  ?  0  :  1;
-                    const int32_t npm = m  ?  notch_power[1]  :  notch_power[0];
-                    if ((npm >> 6)*L.detection_ratio < (fp >> 6))
-                        immediate = m;
-                    else if ((notch_power[2] >> 6)*L.detection_ratio < (fp >> 7))
-                        immediate = 2;
-                }
-                if (present)
-                {
-                    if (immediate != notch_filter)
-                    {
-                        if (--persistence == 0)
-                        {
-                            persistence = kOnCheck;
-                            state |= ((state & (SIG_1_PRESENT | SIG_2_PRESENT)) << 1);
-                            state &= ~(SIG_1_PRESENT | SIG_2_PRESENT);
-                        }
-                    }
-                    else
-                    {
-                        persistence = kOffCheck;
-                    }
-                }
-                else
-                {
-                    if (notch_timeout)
-                        notch_timeout--;
-                    if (immediate >= 0  &&  immediate == last_present)
-                    {
-                        if (--persistence == 0)
-                        {
-                            persistence = kOffCheck;
-                            notch_timeout = kNotchLag;
-                            const int bits = (immediate == 0)  ?  SIG_1_PRESENT  :  (immediate == 1)  ?  SIG_2_PRESENT  :  (SIG_1_PRESENT | SIG_2_PRESENT);
-                            state |= (bits | (bits << 1));
-                            notch_filter = immediate;
-                        }
-                    }
-                    else
-                    {
-                        persistence = kOnCheck;
-                    }
-                }
-            }
+            // ---- sharp mode, sig_tone.c:563-625: notched against total power, then the persistence checks ----
+            const int m = (np0 < np1)  ?  0  :  1;
+            const int32_t npm = m  ?  np1  :  np0;
+            const bool t1 = (npm >> 6)*L.detection_ratio < (fp >> 6);
+            const bool t2 = (np2 >> 6)*L.detection_ratio < (fp >> 7);
+            const int imm = (fp >= L.sharp_threshold)  ?  (t1  ?  m  :  (t2  ?  2  :  -1))  :  -1;
+            const int32_t p_dec = persistence - 1;
+            const bool miss = (imm != notch_filter);
+            const bool hit = (imm >= 0)  &&  (imm == last_present);
+            const bool off_confirmed = present  &&  miss  &&  (p_dec == 0);
+            const bool on_confirmed = !present  &&  hit  &&  (p_dec == 0);
+            const int32_t pers_sharp = present  ?  (miss  ?  ((p_dec == 0)  ?  kOnCheck  :  p_dec)  :  kOffCheck)
+                                                :  (hit  ?  ((p_dec == 0)  ?  kOffCheck  :  p_dec)  :  kOnCheck);
+            const int bits = (imm == 0)  ?  SIG_1_PRESENT  :  (imm == 1)  ?  SIG_2_PRESENT  :  (SIG_1_PRESENT | SIG_2_PRESENT);
+            int32_t st_sharp = off_confirmed  ?  ((state | ((state & (SIG_1_PRESENT | SIG_2_PRESENT)) << 1)) & ~(SIG_1_PRESENT | SIG_2_PRESENT))  :  state;
+            st_sharp = on_confirmed  ?  (state | bits | (bits << 1))  :  st_sharp;
+            int32_t nt_sharp = present  ?  notch_timeout  :  (notch_timeout - ((notch_timeout != 0)  ?  1  :  0));
+            nt_sharp = on_confirmed  ?  kNotchLag  :  nt_sharp;
+            state = flat  ?  st_flat  :  st_sharp;
+            notch_timeout = flat  ?  nt_flat  :  nt_sharp;
+            persistence = flat  ?  persistence  :  pers_sharp;
+            notch_filter = (!flat  &&  on_confirmed)  ?  imm  :  notch_filter;
+            const int immediate = flat  ?  -1  :  imm;
             // ---- the report, sig_tone.c:627-635 ----
             if ((state & (SIG_1_CHANGE | SIG_2_CHANGE)))
             {
@@ -348,19 +314,11 @@ __global__ __launch_bounds__(64) void sigtone_rx_kernel(const SigRxLaunch L)
                 duration = 0;
             }
             // ---- the media path, sig_tone.c:637-653 ----
-            if ((rx_tone & SIG_RX_PASSTHROUGH))
-            {
-                if ((rx_tone & SIG_RX_FILTER_TONE)  ||  notch_timeout)
-                {
-                    const float pick = (NT == 1)  ?  ((notch_filter == 0)  ?  notched[0]  :  0.0f)
-                                                  :  ((notch_filter == 0)  ?  notched[0]  :  (notch_filter == 1)  ?  notched[1]  :  notched[2]);
-                    a[k] = sig_fsat(pick);
-                }
-            }
-            else
-            {
-                a[k] = 0;
-            }
+            const float pick = (NT == 1)  ?  ((notch_filter == 0)  ?  notched0  :  0.0f)
+                                          :  ((notch_filter == 0)  ?  notched0  :  (notch_filter == 1)  ?  notched1  :  notched2);
+            const bool pass = (rx_tone & SIG_RX_PASSTHROUGH) != 0;
+            const bool filter = (rx_tone & SIG_RX_FILTER_TONE)  ||  notch_timeout;
+            a[k] = pass  ?  (filter  ?  sig_fsat(pick)  :  a[k])  :  0;
             last_present = immediate;
         }
         if (vec  &&  todo == 8)

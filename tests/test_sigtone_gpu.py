@@ -235,3 +235,36 @@ def test_sigtone_tx_then_rx_loop(built):
             assert [(int(s), int(d)) for _, s, d in ev[c]] == [(int(e["a"]), int(e["c"])) for e in new]
             seen.update(int(s) for _, s, _ in ev[c])
     assert {0x3, 0x2} <= seen
+
+
+def test_sigtone_rx_full_size_bank(built):
+    """65 536 receivers on one launch per frame: 128 distinct lines, each carried by 512 channels spread over the bank.
+    Every replica must leave the same frames, reports and state as the oracle's run of its line."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_src, n = 128, 65536
+    frames = 30
+    sig = synth.sig_tone_channels(n_src, 160*frames, 321, 3)
+    pick = (np.arange(n)*37) % n_src
+    bank = engine.SigToneRxBank(3, n)
+    bank.set_mode(0x40)
+    orcs = [orc.SigToneRx(3, 0x40) for _ in range(n_src)]
+    total = 0
+    for f in range(frames):
+        src = sig[:, f*160:(f + 1)*160]
+        out = bank.rx_host(src[pick])
+        ev = bank.events()
+        want = []
+        want_ev = []
+        for c, o in enumerate(orcs):
+            before = len(o.sink.events())
+            want.append(o.rx(src[c]))
+            want_ev.append([(int(e["a"]), int(e["c"])) for e in o.sink.events()[before:]])
+        want = np.stack(want)
+        assert np.array_equal(out, want[pick]), f
+        for c in range(0, n, 97):
+            assert [(int(s), int(d)) for _, s, d in ev[c]] == want_ev[pick[c]], (c, f)
+        total += sum(len(e) for e in want_ev)
+    assert total > 100
+    for c in list(range(0, n, 1021)) + [n - 1]:
+        assert np.array_equal(bank.get_state(c), orcs[pick[c]].snapshot()), c

@@ -588,6 +588,76 @@ def bench_mct(args, dev, stream):
         "cpu_baseline": cpu}
 
 
+def bench_sigtone(args, dev, stream):
+    """a bank of 2280 Hz signalling tone receivers (sig_tone_rx) in pass-through mode with the notch switched
+    in while a tone is about -- every frame is read, filtered and written back."""
+    import synth
+    from spandsp_amd import engine
+    n_ch = args.channels or 65536
+    nf = 50
+    n_src = 256
+    src = torch.tensor(synth.sig_tone_channels(n_src, nf*FRAME, 79, 1), device=dev).view(n_src, nf, FRAME)
+    idx = torch.arange(n_ch, device=dev)
+    fsel = (torch.arange(nf, device=dev).unsqueeze(0) + ((idx//n_src) % nf).unsqueeze(1)) % nf
+    frames = src[(idx % n_src).unsqueeze(1), fsel].permute(1, 0, 2).contiguous()
+    work = frames.clone()
+    bank = engine.SigToneRxBank(engine.SIG_TONE_2280HZ, n_ch)
+    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    bank.set_mode(engine.SIG_TONE_RX_PASSTHROUGH)
+    frame_bytes = n_ch*FRAME*2
+
+    def step(i):
+        bank.rx_device(ctypes.c_void_p(work.data_ptr() + (i % nf)*frame_bytes), FRAME, FRAME)
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    work.copy_(frames)                                   # the receivers rewrite their frames: a fresh copy for the timed pass
+    torch.cuda.synchronize()
+    steps = min(args.steps, nf)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        evs[i][0].record(stream)
+        step(i)
+        evs[i][1].record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = [a.elapsed_time(b) for a, b in evs]
+    avg_ms = sum(per)/len(per)
+    work.copy_(frames)
+    reports = 0
+    for i in range(nf):                                  # one more pass over the signal, untimed, counting reports
+        step(i)
+        reports += int(sum(len(e) for e in bank.events()))
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import ref
+        L = ref.lib()
+        n_cpu = min(args.cpu_channels, n_ch)
+        counters = np.zeros(n_cpu*8, np.int64)
+        cpu = ref_baseline("sig_tone_rx() 2280 Hz, pass-through", ref.MT_SIGTONE,
+                           lambda c: L.glue_sigtone_rx_new_quiet(1, 0x40, counters.ctypes.data + c*64), L.sig_tone_rx_free,
+                           frames[:, :n_cpu].contiguous().cpu().numpy())
+    words = 27
+    used = 5 + 3 + 9                                     # one notch, the flat filter and its meter, the counters and flags
+    alg_read = n_ch*(FRAME*2 + used*4)
+    alg_write = n_ch*(FRAME*2 + (used - 1)*4)
+    value = steps*n_ch*FRAME/dt/1e6
+    return {
+        "metric": "Msamples/s of batched in-band signalling tone receive (8 kHz channels at real-time = value*1e6/8000)",
+        "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1, "steps": steps,
+        "warmup": args.warmup, "ms_per_step": dt*1e3/steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32+int32", "data": "synthetic",
+        "config": {"workload": "sig_tone_rx 2280 Hz, pass-through with notch insertion, %d channels x %d-sample frames" % (n_ch, FRAME),
+                   "channels_per_gpu": n_ch, "state_words": words, "reports_in_one_more_second_of_signal": reports},
+        "roofline": {"bound": "hbm", "kernel": "sigtone_rx_kernel<1>", "achieved": (alg_read + alg_write)/(avg_ms*1e-3)/1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (alg_read + alg_write)/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS,
+                     "traffic": None, "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
+                     "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3,
+                     "note": "sample-serial bi-quads and integer logic per channel; frames read and written in place"},
+        "cpu_baseline": cpu}
+
+
 def bench_dtmf_tx(args, dev, stream):
     """a DTMF sender bank (dtmf_tx x N) writing 160-sample frames into HBM, digits queued up front."""
     from spandsp_amd import engine
@@ -661,7 +731,7 @@ def bench_dtmf_tx(args, dev, stream):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct", "v29_tx", "awgn"], default="v29")
+    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct", "sigtone", "v29_tx", "awgn"], default="v29")
     ap.add_argument("--channels", type=int, default=0)
     ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
@@ -695,6 +765,10 @@ def main():
     if args.workload == "mct":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         print(json.dumps(bench_mct(args, dev, stream)))
+        return
+    if args.workload == "sigtone":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        print(json.dumps(bench_sigtone(args, dev, stream)))
         return
     if args.workload == "fsk":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
