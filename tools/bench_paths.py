@@ -658,6 +658,54 @@ def bench_sigtone(args, dev, stream):
         "cpu_baseline": cpu}
 
 
+def bench_fax_rx(args, dev, stream):
+    """The receive front end of N FAX terminals: a V.29 receiver bank and a V.21 receiver bank fed the same frames, each on
+    its own stream (what fax_modems_v29_v21_rx() does per channel, src/fax_modems.c:290-308): the step time of the pair
+    against each bank on its own."""
+    from spandsp_amd import engine
+    n_ch = args.channels or 16384
+    nf = args.steps + args.warmup
+    frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem="v29")
+    frame_bytes = n_ch*FRAME*2
+    s2 = torch.cuda.Stream(device=dev)
+
+    def run(use_fast, use_slow):
+        fast = engine.ModemBank(engine.V29, n_ch, 9600) if use_fast else None
+        slow = engine.FskBank(engine.FSK_V21CH2, n_ch, engine.FSK_FRAME_MODE_SYNC) if use_slow else None
+        if fast:
+            fast.set_stream(ctypes.c_void_p(stream.cuda_stream))
+        if slow:
+            slow.set_stream(ctypes.c_void_p(s2.cuda_stream))
+
+        def step(i):
+            ptr = ctypes.c_void_p(frames.data_ptr() + i*frame_bytes)
+            if fast:
+                fast.rx_device(ptr, FRAME, FRAME)
+            if slow:
+                slow.rx_device(ptr, FRAME, FRAME)
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0)/args.steps
+    t_fast = run(True, False)
+    t_slow = run(False, True)
+    t_pair = run(True, True)
+    value = n_ch*FRAME/t_pair/1e6
+    return {
+        "metric": "Msamples/s of a batched FAX receive front end, V.29 + V.21 on the same frames (8 kHz channels at real-time = value*1e6/8000)",
+        "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": t_pair*1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32+int32", "data": "synthetic",
+        "config": {"workload": "v29_rx 9600 bps + fsk_rx V.21 ch 2 on the same %d channels x %d-sample frames, one stream per bank" % (n_ch, FRAME),
+                   "channels_per_gpu": n_ch, "ms_per_step_v29_alone": t_fast*1e3, "ms_per_step_v21_alone": t_slow*1e3,
+                   "ms_per_step_pair": t_pair*1e3},
+        "roofline": None, "cpu_baseline": None}
+
+
 def bench_dtmf_tx(args, dev, stream):
     """a DTMF sender bank (dtmf_tx x N) writing 160-sample frames into HBM, digits queued up front."""
     from spandsp_amd import engine
@@ -731,7 +779,7 @@ def bench_dtmf_tx(args, dev, stream):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct", "sigtone", "v29_tx", "awgn"], default="v29")
+    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct", "sigtone", "fax_rx", "v29_tx", "awgn"], default="v29")
     ap.add_argument("--channels", type=int, default=0)
     ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
@@ -765,6 +813,9 @@ def main():
     if args.workload == "mct":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         print(json.dumps(bench_mct(args, dev, stream)))
+        return
+    if args.workload == "fax_rx":
+        print(json.dumps(bench_fax_rx(args, dev, stream)))
         return
     if args.workload == "sigtone":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
