@@ -71,7 +71,8 @@ void sig_tone_rx_set_mode(sig_tone_rx_state_t *s, int mode, int duration)
     (void) spangpu_sigtone_rx_set_mode(s->bank, 0, mode);
 }
 
-int sig_tone_rx(sig_tone_rx_state_t *s, int16_t amp[], int len)
+/* at most 1024 samples: two reports are 24 samples apart at the least, so 64 slots hold what one call can report */
+static int rx_slice(sig_tone_rx_state_t *s, int16_t amp[], int len)
 {
     int32_t before[RX_WORDS];
     const int32_t *ev;
@@ -153,6 +154,24 @@ int sig_tone_rx(sig_tone_rx_state_t *s, int16_t amp[], int len)
         pos++;
     }
     return len;
+}
+
+int sig_tone_rx(sig_tone_rx_state_t *s, int16_t amp[], int len)
+{
+    int done = 0;
+
+    if (s == NULL  ||  amp == NULL  ||  len <= 0)
+        return 0;
+    while (done < len)
+    {
+        const int m = (len - done > 1024)  ?  1024  :  (len - done);
+        const int got = rx_slice(s, amp + done, m);
+
+        done += got;
+        if (got < m)
+            break;
+    }
+    return done;
 }
 
 int sig_tone_rx_release(sig_tone_rx_state_t *s)

@@ -34,8 +34,9 @@ def L(built):
     return lib
 
 
+@pytest.mark.parametrize("chunk", [160, 4000])
 @pytest.mark.parametrize("tone_type,mode", [(1, 0x40), (2, 0xC0), (3, 0x40)])
-def test_sig_tone_rx_against_the_reference_outputs(L, tone_type, mode):
+def test_sig_tone_rx_against_the_reference_outputs(L, tone_type, mode, chunk):
     g = np.load(os.path.join(GOLDEN, "sigtone_rx_%d_%02x.npz" % (tone_type, mode)))
     got = []
     cb = REPORT(lambda user, what, level, dur: got.append((what, level, dur)))
@@ -44,8 +45,8 @@ def test_sig_tone_rx_against_the_reference_outputs(L, tone_type, mode):
     L.sig_tone_rx_set_mode(s, mode, 0)
     x = g["amp"]
     out = []
-    for k in range(0, len(x), 160):
-        buf = x[k:k + 160].copy()
+    for k in range(0, len(x), chunk):
+        buf = x[k:k + chunk].copy()
         assert L.sig_tone_rx(s, buf.ctypes.data, len(buf)) == len(buf)
         out.append(buf)
     assert np.array_equal(np.concatenate(out), g["out"])
