@@ -296,6 +296,25 @@ static void sweep(int n_ch, int samples, int n_frames, int reps, bool full)
     free_rig(r);
 }
 
+// What the block ends cost: the generic 8-bin bank (same arithmetic as DTMF up to the decision) with 102-sample blocks and
+// with blocks so long that none ends
+static void sweep_blocks(int n_ch)
+{
+    typedef MultiDet<8, false> D;
+    const int reps = (n_ch > 200000)  ?  20  :  200;
+    for (int bl = 0;  bl < 2;  bl++)
+    {
+        const int block_len = bl  ?  30000  :  102;
+        Rig r = make_rig<D>(n_ch, 160, (n_ch > 200000)  ?  6  :  64, block_len, false);
+        r.L.block_len = block_len;
+        printf("---- generic 8-bin bank, %d channels x 160 samples, %d-sample blocks ----\n", n_ch, block_len);
+        if (n_ch <= 393216)
+            run_new<D, 1, 2, false, 4, 0, true>("ring+loader", r, block_len, false, reps);
+        run_new<D, 1, 2, false, 4, 0, false>("ring", r, block_len, false, reps);
+        free_rig(r);
+    }
+}
+
 // Where a big bank's time goes: the self-fetching kernel at 1 M channels with parts switched off, and per-wave stamps
 static void sweep_big(int n_ch)
 {
@@ -323,6 +342,13 @@ int main(int argc, char **argv)
     CK(hipGetDeviceProperties(&p, 0));
     printf("device: %s  CUs=%d  clock=%d MHz\n", p.name, p.multiProcessorCount, p.clockRate/1000);
     const bool quick = (argc > 1  &&  strcmp(argv[1], "quick") == 0);
+    if (argc > 1  &&  strcmp(argv[1], "blocks") == 0)
+    {
+        CK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        sweep_blocks(65536);
+        sweep_blocks(1048576);
+        return 0;
+    }
     if (argc > 1  &&  strcmp(argv[1], "big") == 0)
     {
         CK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
