@@ -268,3 +268,37 @@ def test_sigtone_rx_full_size_bank(built):
     assert total > 100
     for c in list(range(0, n, 1021)) + [n - 1]:
         assert np.array_equal(bank.get_state(c), orcs[pick[c]].snapshot()), c
+
+
+def test_sigtone_tx_device_frames_with_stride(built):
+    """Sender frames resident on the device, rows a stride apart: only the rows' samples are touched."""
+    import ctypes
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    n, samples, stride = 70, 160, 168
+    bank = engine.SigToneTxBank(3, n)
+    orcs = [orc.SigToneTx(3) for _ in range(n)]
+    rng = np.random.default_rng(77)
+    modes = rng.choice([0x00, 0x01, 0x04, 0x05, 0x11, 0x15], n).astype(np.int32)
+    bank.set_modes(modes, np.zeros(n, np.int32))
+    for c in range(n):
+        orcs[c].set_mode(int(modes[c]), 0)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), n*stride*2) == 0
+    L = engine.lib()
+    for f in range(12):
+        frame = rng.integers(-20000, 20000, (n, stride)).astype(np.int16)
+        assert hip.hipMemcpy(buf, frame.ctypes.data, frame.nbytes, 1) == 0
+        assert L.spangpu_sigtone_tx(bank.h, buf, engine.MEM_DEVICE, samples, stride) == 0     # no durations set: no requests
+        out = np.zeros_like(frame)
+        assert hip.hipMemcpy(out.ctypes.data, buf, out.nbytes, 2) == 0
+        for c, o in enumerate(orcs):
+            assert np.array_equal(out[c, :samples], o.tx(frame[c, :samples])), (c, f)
+        assert np.array_equal(out[:, samples:], frame[:, samples:])
+    hip.hipFree(buf)
+    for c in range(n):
+        assert np.array_equal(bank.get_state(c), orcs[c].snapshot()[:5]), c
