@@ -7,7 +7,8 @@
  *   spangpu_ref_dtmf_rx_t       struct dtmf_rx_state_s      src/spandsp/private/dtmf.h:54-117
  *   spangpu_ref_fir16_t         fir16_state_t               src/spandsp/fir.h:64-70
  *   spangpu_ref_echo_can_t      struct echo_can_state_s     src/spandsp/private/echo.h:37-89
- * so a pointer to a detector made by the reference (dtmf_rx_init(), echo_can_init()) can be passed as it is.  An import
+ *   spangpu_ref_v29_rx_t        struct v29_rx_state_s       src/spandsp/private/v29rx.h:56-226
+ * so a pointer to a detector made by the reference (dtmf_rx_init(), echo_can_init(), v29_rx_init()) can be passed as it is.  An import
  * takes the signal-processing fields; an export writes them and leaves the fields that belong to the caller's side of
  * the object alone (callbacks and their data, the collected digits, the logging descriptor, the pointers of the echo
  * canceller's arrays -- through which the arrays themselves are written).  tests/test_refstate_gpu.py checks sizes and
@@ -113,6 +114,92 @@ SPANGPU_API int spangpu_dtmf_export_state(spangpu_bank_t *bank, int channel, spa
    written, and fir_state.coeffs is set to the struct's own fir_taps16[] entry. */
 SPANGPU_API int spangpu_echo_import_state(spangpu_echo_t *bank, int channel, const spangpu_ref_echo_can_t *ec);
 SPANGPU_API int spangpu_echo_export_state(spangpu_echo_t *bank, int channel, spangpu_ref_echo_can_t *ec);
+
+/* ---- V.29 receiver ---------------------------------------------------------------------------------------- */
+typedef struct
+{
+    float low_band_edge_coeff[3];
+    float high_band_edge_coeff[3];
+    float mixed_band_edges_coeff_3;
+    float coarse_trigger;
+    float fine_trigger;
+    int coarse_step;
+    int fine_step;
+} spangpu_ref_godard_descriptor_t;          /* godard_ted_descriptor_t, src/spandsp/godard.h:30-66 */
+
+typedef struct
+{
+    spangpu_ref_godard_descriptor_t desc;
+    float low_band_edge[2];
+    float high_band_edge[2];
+    float dc_filter[2];
+    float baud_phase;
+    int total_baud_timing_correction;
+} spangpu_ref_godard_t;                     /* struct godard_ted_state_s, src/spandsp/private/godard.h:28-55 */
+
+typedef struct
+{
+    int shift;
+    int32_t reading;
+} spangpu_ref_power_meter_t;                /* struct power_meter_s, src/spandsp/private/power_meter.h:33-40 */
+
+typedef struct
+{
+    int bit_rate;
+    span_put_bit_func_t put_bit;
+    void *put_bit_user_data;
+    span_modem_status_func_t status_handler;
+    void *status_user_data;
+    qam_report_handler_t qam_report;
+    void *qam_user_data;
+    float agc_scaling;
+    float agc_scaling_save;
+    float eq_delta;
+    complexf_t eq_coeff[33];
+    complexf_t eq_coeff_save[33];
+    complexf_t eq_buf[33];
+    float training_error;
+    float carrier_track_p;
+    float carrier_track_i;
+    float rrc_filter[27];
+    spangpu_ref_godard_t godard;
+    int rrc_filter_step;
+    uint32_t scramble_reg;
+    uint8_t training_scramble_reg;
+    int training_cd;
+    bool old_train;
+    int training_stage;
+    int training_count;
+    int16_t last_sample;
+    int signal_present;
+    int carrier_drop_pending;
+    int low_samples;
+    int16_t high_sample;
+    uint32_t carrier_phase;
+    int32_t carrier_phase_rate;
+    int32_t carrier_phase_rate_save;
+    spangpu_ref_power_meter_t power;
+    int32_t carrier_on_power;
+    int32_t carrier_off_power;
+    int eq_step;
+    int eq_put_step;
+    int eq_skip;
+    int baud_half;
+    int32_t last_angles[2];
+    int32_t diff_angles[16];
+    int constellation_state;
+    logging_state_t logging;
+} spangpu_ref_v29_rx_t;                     /* struct v29_rx_state_s (float build), src/spandsp/private/v29rx.h:56-226 */
+
+/* A V.29 receiver -- trained equaliser, carrier and timing loops, scrambler, training stage and all -- in or out of a
+   channel of a bank made with spangpu_modem_create(SPANGPU_V29, ...).  The callbacks, the logging descriptor and the
+   Godard descriptor (a constant of the modem) are not taken on import and are left alone on export. */
+SPANGPU_API int spangpu_v29_import_state(spangpu_modem_t *bank, int channel, const spangpu_ref_v29_rx_t *s);
+SPANGPU_API int spangpu_v29_export_state(spangpu_modem_t *bank, int channel, spangpu_ref_v29_rx_t *s);
+
+/* sizeof() of the mirror of the reference struct of that name ("dtmf_rx_state_t", "goertzel_state_t",
+   "echo_can_state_t", "v29_rx_state_t"), -1 for any other: what the tests hold against the reference build's own sizeof */
+SPANGPU_API int spangpu_refstate_sizeof(const char *what);
 
 #if defined(__cplusplus)
 }

@@ -1,0 +1,196 @@
+/*
+ * refstate_modem.c -- a V.29 receiver's state in the reference's own struct layout (include/spangpu_refstate.h) in and
+ * out of a bank channel.  Host code over the bank's word-level state access: the 238 float and 43 integer words of a
+ * channel are, in this order, the fields listed below (the order of the bank's get_state / set_state, which the parity
+ * tests compare word for word with the reference's struct).
+ */
+#include <string.h>
+
+#include "spangpu.h"
+#include "spangpu_refstate.h"
+
+#define NF  238
+#define NI  43
+
+static uint32_t fbits(float v)
+{
+    uint32_t u;
+
+    memcpy(&u, &v, 4);
+    return u;
+}
+
+static float bitsf(uint32_t u)
+{
+    float v;
+
+    memcpy(&v, &u, 4);
+    return v;
+}
+
+int spangpu_v29_import_state(spangpu_modem_t *bank, int channel, const spangpu_ref_v29_rx_t *s)
+{
+    uint32_t w[NF + NI + 512];
+    uint32_t *f = w;
+    uint32_t *iw = w + NF;
+    int n = 0;
+    int i;
+
+    if (bank == NULL  ||  s == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    /* what is there says how many words this bank keeps per channel: only a V.29 bank keeps 281 */
+    if (spangpu_modem_get_state(bank, channel, w) != NF + NI)
+        return SPANGPU_ERR_BAD_ARG;
+    f[n++] = fbits(s->agc_scaling);
+    f[n++] = fbits(s->agc_scaling_save);
+    f[n++] = fbits(s->eq_delta);
+    f[n++] = fbits(s->training_error);
+    f[n++] = fbits(s->carrier_track_p);
+    f[n++] = fbits(s->carrier_track_i);
+    f[n++] = fbits(s->godard.low_band_edge[0]);
+    f[n++] = fbits(s->godard.low_band_edge[1]);
+    f[n++] = fbits(s->godard.high_band_edge[0]);
+    f[n++] = fbits(s->godard.high_band_edge[1]);
+    f[n++] = fbits(s->godard.dc_filter[0]);
+    f[n++] = fbits(s->godard.dc_filter[1]);
+    f[n++] = fbits(s->godard.baud_phase);
+    for (i = 0;  i < 27;  i++)
+        f[n++] = fbits(s->rrc_filter[i]);
+    for (i = 0;  i < 33;  i++)
+    {
+        f[n++] = fbits(s->eq_coeff[i].re);
+        f[n++] = fbits(s->eq_coeff[i].im);
+    }
+    for (i = 0;  i < 33;  i++)
+    {
+        f[n++] = fbits(s->eq_coeff_save[i].re);
+        f[n++] = fbits(s->eq_coeff_save[i].im);
+    }
+    for (i = 0;  i < 33;  i++)
+    {
+        f[n++] = fbits(s->eq_buf[i].re);
+        f[n++] = fbits(s->eq_buf[i].im);
+    }
+    n = 0;
+    iw[n++] = (uint32_t) s->bit_rate;
+    iw[n++] = (uint32_t) s->rrc_filter_step;
+    iw[n++] = s->scramble_reg;
+    iw[n++] = s->training_scramble_reg;
+    iw[n++] = (uint32_t) s->training_cd;
+    iw[n++] = s->old_train  ?  1  :  0;
+    iw[n++] = (uint32_t) s->training_stage;
+    iw[n++] = (uint32_t) s->training_count;
+    iw[n++] = (uint32_t) (int32_t) s->last_sample;
+    iw[n++] = (uint32_t) s->signal_present;
+    iw[n++] = s->carrier_phase;
+    iw[n++] = (uint32_t) s->carrier_phase_rate;
+    iw[n++] = (uint32_t) s->carrier_phase_rate_save;
+    iw[n++] = (uint32_t) s->power.reading;
+    iw[n++] = (uint32_t) s->carrier_on_power;
+    iw[n++] = (uint32_t) s->carrier_off_power;
+    iw[n++] = (uint32_t) s->eq_step;
+    iw[n++] = (uint32_t) s->eq_put_step;
+    iw[n++] = (uint32_t) s->eq_skip;
+    iw[n++] = (uint32_t) s->baud_half;
+    iw[n++] = (uint32_t) s->last_angles[0];
+    iw[n++] = (uint32_t) s->last_angles[1];
+    for (i = 0;  i < 16;  i++)
+        iw[n++] = (uint32_t) s->diff_angles[i];
+    iw[n++] = (uint32_t) s->constellation_state;
+    iw[n++] = (uint32_t) s->godard.total_baud_timing_correction;
+    iw[n++] = (uint32_t) (int32_t) s->high_sample;
+    iw[n++] = (uint32_t) s->low_samples;
+    iw[n++] = (uint32_t) s->carrier_drop_pending;
+    return spangpu_modem_set_state(bank, channel, w);
+}
+
+int spangpu_v29_export_state(spangpu_modem_t *bank, int channel, spangpu_ref_v29_rx_t *s)
+{
+    uint32_t w[NF + NI + 512];
+    const uint32_t *f = w;
+    const uint32_t *iw = w + NF;
+    int n = 0;
+    int i;
+
+    if (bank == NULL  ||  s == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    if (spangpu_modem_get_state(bank, channel, w) != NF + NI)
+        return SPANGPU_ERR_BAD_ARG;
+    s->agc_scaling = bitsf(f[n++]);
+    s->agc_scaling_save = bitsf(f[n++]);
+    s->eq_delta = bitsf(f[n++]);
+    s->training_error = bitsf(f[n++]);
+    s->carrier_track_p = bitsf(f[n++]);
+    s->carrier_track_i = bitsf(f[n++]);
+    s->godard.low_band_edge[0] = bitsf(f[n++]);
+    s->godard.low_band_edge[1] = bitsf(f[n++]);
+    s->godard.high_band_edge[0] = bitsf(f[n++]);
+    s->godard.high_band_edge[1] = bitsf(f[n++]);
+    s->godard.dc_filter[0] = bitsf(f[n++]);
+    s->godard.dc_filter[1] = bitsf(f[n++]);
+    s->godard.baud_phase = bitsf(f[n++]);
+    for (i = 0;  i < 27;  i++)
+        s->rrc_filter[i] = bitsf(f[n++]);
+    for (i = 0;  i < 33;  i++)
+    {
+        s->eq_coeff[i].re = bitsf(f[n++]);
+        s->eq_coeff[i].im = bitsf(f[n++]);
+    }
+    for (i = 0;  i < 33;  i++)
+    {
+        s->eq_coeff_save[i].re = bitsf(f[n++]);
+        s->eq_coeff_save[i].im = bitsf(f[n++]);
+    }
+    for (i = 0;  i < 33;  i++)
+    {
+        s->eq_buf[i].re = bitsf(f[n++]);
+        s->eq_buf[i].im = bitsf(f[n++]);
+    }
+    n = 0;
+    s->bit_rate = (int) iw[n++];
+    s->rrc_filter_step = (int) iw[n++];
+    s->scramble_reg = iw[n++];
+    s->training_scramble_reg = (uint8_t) iw[n++];
+    s->training_cd = (int) iw[n++];
+    s->old_train = (iw[n++] != 0);
+    s->training_stage = (int) iw[n++];
+    s->training_count = (int) iw[n++];
+    s->last_sample = (int16_t) iw[n++];
+    s->signal_present = (int) iw[n++];
+    s->carrier_phase = iw[n++];
+    s->carrier_phase_rate = (int32_t) iw[n++];
+    s->carrier_phase_rate_save = (int32_t) iw[n++];
+    s->power.reading = (int32_t) iw[n++];
+    s->carrier_on_power = (int32_t) iw[n++];
+    s->carrier_off_power = (int32_t) iw[n++];
+    s->eq_step = (int) iw[n++];
+    s->eq_put_step = (int) iw[n++];
+    s->eq_skip = (int) iw[n++];
+    s->baud_half = (int) iw[n++];
+    s->last_angles[0] = (int32_t) iw[n++];
+    s->last_angles[1] = (int32_t) iw[n++];
+    for (i = 0;  i < 16;  i++)
+        s->diff_angles[i] = (int32_t) iw[n++];
+    s->constellation_state = (int) iw[n++];
+    s->godard.total_baud_timing_correction = (int) iw[n++];
+    s->high_sample = (int16_t) iw[n++];
+    s->low_samples = (int) iw[n++];
+    s->carrier_drop_pending = (int) iw[n++];
+    return SPANGPU_OK;
+}
+
+/* sizeof() of the mirrors above and in spangpu_refstate.h, for the tests to hold against the reference build's own */
+int spangpu_refstate_sizeof(const char *what)
+{
+    if (what == NULL)
+        return -1;
+    if (strcmp(what, "dtmf_rx_state_t") == 0)
+        return (int) sizeof(spangpu_ref_dtmf_rx_t);
+    if (strcmp(what, "goertzel_state_t") == 0)
+        return (int) sizeof(spangpu_ref_goertzel_t);
+    if (strcmp(what, "echo_can_state_t") == 0)
+        return (int) sizeof(spangpu_ref_echo_can_t);
+    if (strcmp(what, "v29_rx_state_t") == 0)
+        return (int) sizeof(spangpu_ref_v29_rx_t);
+    return -1;
+}

@@ -637,6 +637,22 @@ def test_golden_mct(built, rx_type, tx_kind):
 
 
 
+@needs_ref
+def test_refstate_mirrors_have_the_reference_sizes(built):
+    """include/spangpu_refstate.h against the reference build: sizeof of every mirrored struct (the run of a call across
+    the boundary, which is what checks the offsets, is tests/test_refstate_gpu.py)"""
+    import ctypes as C
+    from oracle import ref
+    from spandsp_amd import engine
+    L = C.CDLL(engine.LIB_PATH)
+    L.spangpu_refstate_sizeof.argtypes = [C.c_char_p]
+    R = ref.lib()
+    R.glue_sizeof.argtypes = [C.c_char_p]
+    for what in (b"dtmf_rx_state_t", b"goertzel_state_t", b"echo_can_state_t", b"v29_rx_state_t"):
+        assert L.spangpu_refstate_sizeof(what) == R.glue_sizeof(what) > 0, what
+    assert L.spangpu_refstate_sizeof(b"something_else") == -1
+
+
 # --------------------------------------------------------------------------------------
 # in-band signalling tones (sigtone_oracle.c)
 # --------------------------------------------------------------------------------------

@@ -163,3 +163,63 @@ def test_echo_call_changes_sides(libs):
         R.echo_can_free(ec)
     bank.close()
     bank2.close()
+
+
+@pytest.mark.parametrize("cut", [160*7 + 5, 160*30 + 77], ids=["in-training", "in-data"])
+def test_v29_call_changes_sides(libs, cut):
+    """A V.29 receiver handed over in mid-call, trained equaliser, loops, scrambler and all: reference -> bank channel and
+    bank channel -> reference; the bits and status events delivered across the change are those of one receiver that ran
+    the whole call."""
+    import os
+    from oracle import ref
+    from spandsp_amd import engine
+    from test_oracle_pin import GOLDEN
+    R, L = libs
+    vp, ci = C.c_void_p, C.c_int
+    L.spangpu_v29_import_state.argtypes = [vp, ci, vp]
+    L.spangpu_v29_export_state.argtypes = [vp, ci, vp]
+    x = np.load(os.path.join(GOLDEN, "v29_9600.npz"))["amp"][:160*60]
+    n_ch, ch = 3, 1
+
+    def ref_bits(rx, seg):
+        rx.sink.clear()
+        for k in range(0, len(seg), 160):
+            rx.rx(seg[k:k + 160])
+        return [int(e["a"]) for e in rx.sink.events()]
+
+    def bank_bits(bank, seg):
+        out = []
+        for k in range(0, len(seg), 160):
+            m = min(160, len(seg) - k)
+            fr = np.zeros((n_ch, 160), np.int16)
+            lens = np.zeros(n_ch, np.int32)
+            fr[ch, :m] = seg[k:k + m]
+            lens[ch] = m
+            bank.rx_host_var(fr, lens)
+            out.extend(int(b) for b in bank.events()[ch])
+        return out
+
+    whole = ref.V29Rx(9600)
+    want = ref_bits(whole, x[:cut]) + ref_bits(whole, x[cut:])
+    assert -4 in want and sum(1 for b in want if b >= 0) > 2000          # trained, and data came through
+    # reference -> bank
+    a = ref.V29Rx(9600)
+    first = ref_bits(a, x[:cut])
+    bank = engine.V29Bank(n_ch, 9600)
+    assert L.spangpu_v29_import_state(bank.h, ch, a.p) == 0
+    assert first + bank_bits(bank, x[cut:]) == want
+    # bank -> reference
+    bank2 = engine.V29Bank(n_ch, 9600)
+    first2 = bank_bits(bank2, x[:cut])
+    b = ref.V29Rx(9600)
+    assert L.spangpu_v29_export_state(bank2.h, ch, b.p) == 0
+    assert first2 + ref_bits(b, x[cut:]) == want
+    # and what the bank exports after the whole call is, word for word, the state of the receiver that ran it all
+    probe = ref.V29Rx(9600)
+    assert L.spangpu_v29_export_state(bank.h, ch, probe.p) == 0
+    fw, iw = whole.snapshot()
+    fp, ip = probe.snapshot()
+    assert np.array_equal(fw.view(np.uint32), fp.view(np.uint32)) and np.array_equal(iw, ip)
+    # a bank of another modem refuses
+    other = engine.V27terBank(n_ch, 4800)
+    assert L.spangpu_v29_import_state(other.h, ch, a.p) < 0
