@@ -165,9 +165,17 @@ def test_echo_call_changes_sides(libs):
     bank2.close()
 
 
-@pytest.mark.parametrize("cut", [160*7 + 5, 160*30 + 77], ids=["in-training", "in-data"])
-def test_v29_call_changes_sides(libs, cut):
-    """A V.29 receiver handed over in mid-call, trained equaliser, loops, scrambler and all: reference -> bank channel and
+MODEMS = {"v29": ("v29_9600.npz", 9600, "V29Rx", "V29Bank", "V27terBank", 4800),
+          "v27ter": ("v27ter_4800.npz", 4800, "V27terRx", "V27terBank", "V29Bank", 9600)}
+
+
+DATA_CUT = {"v29": 160*20 + 77, "v27ter": 160*45 + 77}          # well after each modem's training
+
+
+@pytest.mark.parametrize("where", ["in-training", "in-data"])
+@pytest.mark.parametrize("modem", ["v29", "v27ter"])
+def test_modem_call_changes_sides(libs, modem, where):
+    """A modem receiver handed over in mid-call, trained equaliser, loops, scrambler and all: reference -> bank channel and
     bank channel -> reference; the bits and status events delivered across the change are those of one receiver that ran
     the whole call."""
     import os
@@ -175,11 +183,18 @@ def test_v29_call_changes_sides(libs, cut):
     from spandsp_amd import engine
     from test_oracle_pin import GOLDEN
     R, L = libs
+    fixture, rate, ref_cls, bank_cls, other_cls, other_rate = MODEMS[modem]
     vp, ci = C.c_void_p, C.c_int
-    L.spangpu_v29_import_state.argtypes = [vp, ci, vp]
-    L.spangpu_v29_export_state.argtypes = [vp, ci, vp]
-    x = np.load(os.path.join(GOLDEN, "v29_9600.npz"))["amp"][:160*60]
+    imp = getattr(L, "spangpu_%s_import_state" % modem)
+    exp = getattr(L, "spangpu_%s_export_state" % modem)
+    imp.argtypes = [vp, ci, vp]
+    exp.argtypes = [vp, ci, vp]
+    x = np.load(os.path.join(GOLDEN, fixture))["amp"]
+    cut = DATA_CUT[modem] if where == "in-data" else 160*7 + 5
+    assert cut + 1000 < len(x)
     n_ch, ch = 3, 1
+    make_ref = getattr(ref, ref_cls)
+    make_bank = getattr(engine, bank_cls)
 
     def ref_bits(rx, seg):
         rx.sink.clear()
@@ -199,27 +214,32 @@ def test_v29_call_changes_sides(libs, cut):
             out.extend(int(b) for b in bank.events()[ch])
         return out
 
-    whole = ref.V29Rx(9600)
+    whole = make_ref(rate)
     want = ref_bits(whole, x[:cut]) + ref_bits(whole, x[cut:])
     assert -4 in want and sum(1 for b in want if b >= 0) > 2000          # trained, and data came through
     # reference -> bank
-    a = ref.V29Rx(9600)
+    a = make_ref(rate)
     first = ref_bits(a, x[:cut])
-    bank = engine.V29Bank(n_ch, 9600)
-    assert L.spangpu_v29_import_state(bank.h, ch, a.p) == 0
+    assert (-4 in first) == (where == "in-data")
+    bank = make_bank(n_ch, rate)
+    assert imp(bank.h, ch, a.p) == 0
     assert first + bank_bits(bank, x[cut:]) == want
     # bank -> reference
-    bank2 = engine.V29Bank(n_ch, 9600)
+    bank2 = make_bank(n_ch, rate)
     first2 = bank_bits(bank2, x[:cut])
-    b = ref.V29Rx(9600)
-    assert L.spangpu_v29_export_state(bank2.h, ch, b.p) == 0
+    b = make_ref(rate)
+    assert exp(bank2.h, ch, b.p) == 0
     assert first2 + ref_bits(b, x[cut:]) == want
     # and what the bank exports after the whole call is, word for word, the state of the receiver that ran it all
-    probe = ref.V29Rx(9600)
-    assert L.spangpu_v29_export_state(bank.h, ch, probe.p) == 0
+    probe = make_ref(rate)
+    assert exp(bank.h, ch, probe.p) == 0
     fw, iw = whole.snapshot()
     fp, ip = probe.snapshot()
     assert np.array_equal(fw.view(np.uint32), fp.view(np.uint32)) and np.array_equal(iw, ip)
     # a bank of another modem refuses
-    other = engine.V27terBank(n_ch, 4800)
-    assert L.spangpu_v29_import_state(other.h, ch, a.p) < 0
+    other = getattr(engine, other_cls)(n_ch, other_rate)
+    assert imp(other.h, ch, a.p) < 0
+    if modem == "v27ter":
+        # and so does a V.27ter bank of the other rate (its tables are per rate)
+        slow = engine.V27terBank(n_ch, 2400)
+        assert imp(slow.h, ch, a.p) < 0
