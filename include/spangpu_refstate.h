@@ -9,6 +9,7 @@
  *   spangpu_ref_echo_can_t      struct echo_can_state_s     src/spandsp/private/echo.h:37-89
  *   spangpu_ref_v29_rx_t        struct v29_rx_state_s       src/spandsp/private/v29rx.h:56-226
  *   spangpu_ref_v27ter_rx_t     struct v27ter_rx_state_s    src/spandsp/private/v27ter_rx.h:57-210
+ *   spangpu_ref_v17_rx_t        struct v17_rx_state_s       src/spandsp/private/v17rx.h:64-254
  * so a pointer to a detector made by the reference (dtmf_rx_init(), echo_can_init(), v29_rx_init()) can be passed as it is.  An import
  * takes the signal-processing fields; an export writes them and leaves the fields that belong to the caller's side of
  * the object alone (callbacks and their data, the collected digits, the logging descriptor, the pointers of the echo
@@ -254,8 +255,68 @@ typedef struct
 SPANGPU_API int spangpu_v27ter_import_state(spangpu_modem_t *bank, int channel, const spangpu_ref_v27ter_rx_t *s);
 SPANGPU_API int spangpu_v27ter_export_state(spangpu_modem_t *bank, int channel, spangpu_ref_v27ter_rx_t *s);
 
+/* ---- V.17 receiver ---------------------------------------------------------------------------------------- */
+typedef struct
+{
+    int bit_rate;
+    span_put_bit_func_t put_bit;
+    void *put_bit_user_data;
+    span_modem_status_func_t status_handler;
+    void *status_user_data;
+    qam_report_handler_t qam_report;
+    void *qam_user_data;
+    float agc_scaling;
+    float agc_scaling_save;
+    float eq_delta;
+    complexf_t eq_coeff[33];
+    complexf_t eq_coeff_save[33];
+    complexf_t eq_buf[33];
+    float training_error;
+    float carrier_track_p;
+    float carrier_track_i;
+    float rrc_filter[27];
+    const complexf_t *constellation;        /* into the reference library's own tables: never read, never written here */
+    spangpu_ref_godard_t godard;
+    int rrc_filter_step;
+    int diff;
+    uint32_t scramble_reg;
+    int scrambler_tap;
+    bool short_train;
+    int training_stage;
+    int training_count;
+    int16_t last_sample;
+    int signal_present;
+    int carrier_drop_pending;
+    int low_samples;
+    int16_t high_sample;
+    uint32_t carrier_phase;
+    int32_t carrier_phase_rate;
+    int32_t carrier_phase_rate_save;
+    spangpu_ref_power_meter_t power;
+    int32_t carrier_on_power;
+    int32_t carrier_off_power;
+    int eq_step;
+    int eq_put_step;
+    int eq_skip;
+    int baud_half;
+    int32_t last_angles[2];
+    int32_t diff_angles[16];
+    int space_map;
+    int bits_per_symbol;
+    int trellis_ptr;
+    int full_path_to_past_state_locations[16][8];
+    int past_state_locations[16][8];
+    float distances[8];
+    logging_state_t logging;
+} spangpu_ref_v17_rx_t;                     /* struct v17_rx_state_s (float build), src/spandsp/private/v17rx.h:64-254 */
+
+/* As for V.27ter, on a bank made with spangpu_modem_create(SPANGPU_V17, ...): one bit rate per bank, a receiver of
+   another rate is refused.  The trellis decoder's survivor memory and path metrics travel with the rest. */
+SPANGPU_API int spangpu_v17_import_state(spangpu_modem_t *bank, int channel, const spangpu_ref_v17_rx_t *s);
+SPANGPU_API int spangpu_v17_export_state(spangpu_modem_t *bank, int channel, spangpu_ref_v17_rx_t *s);
+
 /* sizeof() of the mirror of the reference struct of that name ("dtmf_rx_state_t", "goertzel_state_t",
-   "echo_can_state_t", "v29_rx_state_t", "v27ter_rx_state_t"), -1 for any other: what the tests hold against the reference build's own sizeof */
+   "echo_can_state_t", "v29_rx_state_t", "v27ter_rx_state_t", "v17_rx_state_t"), -1 for any other: what the tests hold against the reference build's own sizeof */
 SPANGPU_API int spangpu_refstate_sizeof(const char *what);
 
 #if defined(__cplusplus)

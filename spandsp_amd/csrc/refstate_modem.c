@@ -1,5 +1,5 @@
 /*
- * refstate_modem.c -- a V.29 or V.27ter receiver's state in the reference's own struct layout (include/spangpu_refstate.h) in and
+ * refstate_modem.c -- a V.29, V.27ter or V.17 receiver's state in the reference's own struct layout (include/spangpu_refstate.h) in and
  * out of a bank channel.  Host code over the bank's word-level state access: the 238 float and 43 integer words of a
  * channel are, in this order, the fields listed below (the order of the bank's get_state / set_state, which the parity
  * tests compare word for word with the reference's struct).
@@ -325,6 +325,179 @@ int spangpu_v27ter_export_state(spangpu_modem_t *bank, int channel, spangpu_ref_
     return SPANGPU_OK;
 }
 
+/* ---- V.17: 246 float words and 301 integer words ------------------------------------------------------------ */
+#define NF17    246
+#define NI17    301
+
+int spangpu_v17_import_state(spangpu_modem_t *bank, int channel, const spangpu_ref_v17_rx_t *s)
+{
+    uint32_t w[NF17 + NI17 + 64];
+    uint32_t *f = w;
+    uint32_t *iw = w + NF17;
+    int n = 0;
+    int i;
+
+    if (bank == NULL  ||  s == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    if (spangpu_modem_get_state(bank, channel, w) != NF17 + NI17)
+        return SPANGPU_ERR_BAD_ARG;
+    if ((int) iw[0] != s->bit_rate)
+        return SPANGPU_ERR_BAD_ARG;             /* the bank's constellation and space map are those of its own rate */
+    f[n++] = fbits(s->agc_scaling);
+    f[n++] = fbits(s->agc_scaling_save);
+    f[n++] = fbits(s->eq_delta);
+    f[n++] = fbits(s->training_error);
+    f[n++] = fbits(s->carrier_track_p);
+    f[n++] = fbits(s->carrier_track_i);
+    f[n++] = fbits(s->godard.low_band_edge[0]);
+    f[n++] = fbits(s->godard.low_band_edge[1]);
+    f[n++] = fbits(s->godard.high_band_edge[0]);
+    f[n++] = fbits(s->godard.high_band_edge[1]);
+    f[n++] = fbits(s->godard.dc_filter[0]);
+    f[n++] = fbits(s->godard.dc_filter[1]);
+    f[n++] = fbits(s->godard.baud_phase);
+    for (i = 0;  i < 27;  i++)
+        f[n++] = fbits(s->rrc_filter[i]);
+    for (i = 0;  i < 33;  i++)
+    {
+        f[n++] = fbits(s->eq_coeff[i].re);
+        f[n++] = fbits(s->eq_coeff[i].im);
+    }
+    for (i = 0;  i < 33;  i++)
+    {
+        f[n++] = fbits(s->eq_coeff_save[i].re);
+        f[n++] = fbits(s->eq_coeff_save[i].im);
+    }
+    for (i = 0;  i < 33;  i++)
+    {
+        f[n++] = fbits(s->eq_buf[i].re);
+        f[n++] = fbits(s->eq_buf[i].im);
+    }
+    for (i = 0;  i < 8;  i++)
+        f[n++] = fbits(s->distances[i]);
+    n = 0;
+    iw[n++] = (uint32_t) s->bit_rate;
+    iw[n++] = (uint32_t) s->rrc_filter_step;
+    iw[n++] = (uint32_t) s->diff;
+    iw[n++] = s->scramble_reg;
+    iw[n++] = (uint32_t) s->scrambler_tap;
+    iw[n++] = s->short_train  ?  1  :  0;
+    iw[n++] = (uint32_t) s->training_stage;
+    iw[n++] = (uint32_t) s->training_count;
+    iw[n++] = (uint32_t) (int32_t) s->last_sample;
+    iw[n++] = (uint32_t) s->signal_present;
+    iw[n++] = (uint32_t) s->carrier_drop_pending;
+    iw[n++] = (uint32_t) s->low_samples;
+    iw[n++] = (uint32_t) (int32_t) s->high_sample;
+    iw[n++] = s->carrier_phase;
+    iw[n++] = (uint32_t) s->carrier_phase_rate;
+    iw[n++] = (uint32_t) s->carrier_phase_rate_save;
+    iw[n++] = (uint32_t) s->power.reading;
+    iw[n++] = (uint32_t) s->carrier_on_power;
+    iw[n++] = (uint32_t) s->carrier_off_power;
+    iw[n++] = (uint32_t) s->eq_step;
+    iw[n++] = (uint32_t) s->eq_put_step;
+    iw[n++] = (uint32_t) s->eq_skip;
+    iw[n++] = (uint32_t) s->baud_half;
+    iw[n++] = (uint32_t) s->last_angles[0];
+    iw[n++] = (uint32_t) s->last_angles[1];
+    for (i = 0;  i < 16;  i++)
+        iw[n++] = (uint32_t) s->diff_angles[i];
+    iw[n++] = (uint32_t) s->space_map;
+    iw[n++] = (uint32_t) s->bits_per_symbol;
+    iw[n++] = (uint32_t) s->trellis_ptr;
+    iw[n++] = (uint32_t) s->godard.total_baud_timing_correction;
+    for (i = 0;  i < 16*8;  i++)
+        iw[n++] = (uint32_t) s->full_path_to_past_state_locations[i >> 3][i & 7];
+    for (i = 0;  i < 16*8;  i++)
+        iw[n++] = (uint32_t) s->past_state_locations[i >> 3][i & 7];
+    return spangpu_modem_set_state(bank, channel, w);
+}
+
+int spangpu_v17_export_state(spangpu_modem_t *bank, int channel, spangpu_ref_v17_rx_t *s)
+{
+    uint32_t w[NF17 + NI17 + 64];
+    const uint32_t *f = w;
+    const uint32_t *iw = w + NF17;
+    int n = 0;
+    int i;
+
+    if (bank == NULL  ||  s == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    if (spangpu_modem_get_state(bank, channel, w) != NF17 + NI17)
+        return SPANGPU_ERR_BAD_ARG;
+    if ((int) iw[0] != s->bit_rate)
+        return SPANGPU_ERR_BAD_ARG;             /* (the struct's constellation pointer is the one of its own rate) */
+    s->agc_scaling = bitsf(f[n++]);
+    s->agc_scaling_save = bitsf(f[n++]);
+    s->eq_delta = bitsf(f[n++]);
+    s->training_error = bitsf(f[n++]);
+    s->carrier_track_p = bitsf(f[n++]);
+    s->carrier_track_i = bitsf(f[n++]);
+    s->godard.low_band_edge[0] = bitsf(f[n++]);
+    s->godard.low_band_edge[1] = bitsf(f[n++]);
+    s->godard.high_band_edge[0] = bitsf(f[n++]);
+    s->godard.high_band_edge[1] = bitsf(f[n++]);
+    s->godard.dc_filter[0] = bitsf(f[n++]);
+    s->godard.dc_filter[1] = bitsf(f[n++]);
+    s->godard.baud_phase = bitsf(f[n++]);
+    for (i = 0;  i < 27;  i++)
+        s->rrc_filter[i] = bitsf(f[n++]);
+    for (i = 0;  i < 33;  i++)
+    {
+        s->eq_coeff[i].re = bitsf(f[n++]);
+        s->eq_coeff[i].im = bitsf(f[n++]);
+    }
+    for (i = 0;  i < 33;  i++)
+    {
+        s->eq_coeff_save[i].re = bitsf(f[n++]);
+        s->eq_coeff_save[i].im = bitsf(f[n++]);
+    }
+    for (i = 0;  i < 33;  i++)
+    {
+        s->eq_buf[i].re = bitsf(f[n++]);
+        s->eq_buf[i].im = bitsf(f[n++]);
+    }
+    for (i = 0;  i < 8;  i++)
+        s->distances[i] = bitsf(f[n++]);
+    n = 1;                                      /* (bit_rate: checked above, as it is) */
+    s->rrc_filter_step = (int) iw[n++];
+    s->diff = (int) iw[n++];
+    s->scramble_reg = iw[n++];
+    s->scrambler_tap = (int) iw[n++];
+    s->short_train = (iw[n++] != 0);
+    s->training_stage = (int) iw[n++];
+    s->training_count = (int) iw[n++];
+    s->last_sample = (int16_t) iw[n++];
+    s->signal_present = (int) iw[n++];
+    s->carrier_drop_pending = (int) iw[n++];
+    s->low_samples = (int) iw[n++];
+    s->high_sample = (int16_t) iw[n++];
+    s->carrier_phase = iw[n++];
+    s->carrier_phase_rate = (int32_t) iw[n++];
+    s->carrier_phase_rate_save = (int32_t) iw[n++];
+    s->power.reading = (int32_t) iw[n++];
+    s->carrier_on_power = (int32_t) iw[n++];
+    s->carrier_off_power = (int32_t) iw[n++];
+    s->eq_step = (int) iw[n++];
+    s->eq_put_step = (int) iw[n++];
+    s->eq_skip = (int) iw[n++];
+    s->baud_half = (int) iw[n++];
+    s->last_angles[0] = (int32_t) iw[n++];
+    s->last_angles[1] = (int32_t) iw[n++];
+    for (i = 0;  i < 16;  i++)
+        s->diff_angles[i] = (int32_t) iw[n++];
+    s->space_map = (int) iw[n++];
+    s->bits_per_symbol = (int) iw[n++];
+    s->trellis_ptr = (int) iw[n++];
+    s->godard.total_baud_timing_correction = (int) iw[n++];
+    for (i = 0;  i < 16*8;  i++)
+        s->full_path_to_past_state_locations[i >> 3][i & 7] = (int) iw[n++];
+    for (i = 0;  i < 16*8;  i++)
+        s->past_state_locations[i >> 3][i & 7] = (int) iw[n++];
+    return SPANGPU_OK;
+}
+
 /* sizeof() of the mirrors above and in spangpu_refstate.h, for the tests to hold against the reference build's own */
 int spangpu_refstate_sizeof(const char *what)
 {
@@ -340,5 +513,7 @@ int spangpu_refstate_sizeof(const char *what)
         return (int) sizeof(spangpu_ref_v29_rx_t);
     if (strcmp(what, "v27ter_rx_state_t") == 0)
         return (int) sizeof(spangpu_ref_v27ter_rx_t);
+    if (strcmp(what, "v17_rx_state_t") == 0)
+        return (int) sizeof(spangpu_ref_v17_rx_t);
     return -1;
 }

@@ -166,14 +166,15 @@ def test_echo_call_changes_sides(libs):
 
 
 MODEMS = {"v29": ("v29_9600.npz", 9600, "V29Rx", "V29Bank", "V27terBank", 4800),
-          "v27ter": ("v27ter_4800.npz", 4800, "V27terRx", "V27terBank", "V29Bank", 9600)}
+          "v27ter": ("v27ter_4800.npz", 4800, "V27terRx", "V27terBank", "V29Bank", 9600),
+          "v17": ("v17_14400.npz", 14400, "V17Rx", "V17Bank", "V29Bank", 9600)}
 
 
-DATA_CUT = {"v29": 160*20 + 77, "v27ter": 160*45 + 77}          # well after each modem's training
+DATA_CUT = {"v29": 160*20 + 77, "v27ter": 160*45 + 77, "v17": 160*85 + 77}          # well after each modem's training
 
 
 @pytest.mark.parametrize("where", ["in-training", "in-data"])
-@pytest.mark.parametrize("modem", ["v29", "v27ter"])
+@pytest.mark.parametrize("modem", ["v29", "v27ter", "v17"])
 def test_modem_call_changes_sides(libs, modem, where):
     """A modem receiver handed over in mid-call, trained equaliser, loops, scrambler and all: reference -> bank channel and
     bank channel -> reference; the bits and status events delivered across the change are those of one receiver that ran
@@ -239,7 +240,7 @@ def test_modem_call_changes_sides(libs, modem, where):
     # a bank of another modem refuses
     other = getattr(engine, other_cls)(n_ch, other_rate)
     assert imp(other.h, ch, a.p) < 0
-    if modem == "v27ter":
-        # and so does a V.27ter bank of the other rate (its tables are per rate)
-        slow = engine.V27terBank(n_ch, 2400)
+    if modem != "v29":
+        # and so does a bank of the same modem at another rate (tables, constellation and space map are per rate)
+        slow = make_bank(n_ch, 2400 if modem == "v27ter" else 9600)
         assert imp(slow.h, ch, a.p) < 0
