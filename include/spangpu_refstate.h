@@ -7,6 +7,8 @@
  *   spangpu_ref_dtmf_rx_t       struct dtmf_rx_state_s      src/spandsp/private/dtmf.h:54-117
  *   spangpu_ref_fir16_t         fir16_state_t               src/spandsp/fir.h:64-70
  *   spangpu_ref_echo_can_t      struct echo_can_state_s     src/spandsp/private/echo.h:37-89
+ *   spangpu_ref_bell_mf_rx_t    struct bell_mf_rx_state_s   src/spandsp/private/bell_r2_mf.h:62-84
+ *   spangpu_ref_r2_mf_rx_t      struct r2_mf_rx_state_s     src/spandsp/private/bell_r2_mf.h:102-116
  *   spangpu_ref_v29_rx_t        struct v29_rx_state_s       src/spandsp/private/v29rx.h:56-226
  *   spangpu_ref_v27ter_rx_t     struct v27ter_rx_state_s    src/spandsp/private/v27ter_rx.h:57-210
  *   spangpu_ref_v17_rx_t        struct v17_rx_state_s       src/spandsp/private/v17rx.h:64-254
@@ -116,6 +118,36 @@ SPANGPU_API int spangpu_dtmf_export_state(spangpu_bank_t *bank, int channel, spa
    written, and fir_state.coeffs is set to the struct's own fir_taps16[] entry. */
 SPANGPU_API int spangpu_echo_import_state(spangpu_echo_t *bank, int channel, const spangpu_ref_echo_can_t *ec);
 SPANGPU_API int spangpu_echo_export_state(spangpu_echo_t *bank, int channel, spangpu_ref_echo_can_t *ec);
+
+/* ---- Bell MF and MFC/R2 detectors ------------------------------------------------------------------------ */
+typedef struct
+{
+    digits_rx_callback_t digits_callback;
+    void *digits_callback_data;
+    spangpu_ref_goertzel_t out[6];
+    uint8_t hits[5];
+    int current_sample;
+    int lost_digits;
+    int current_digits;
+    char digits[MAX_BELL_MF_DIGITS + 1];
+} spangpu_ref_bell_mf_rx_t;                 /* struct bell_mf_rx_state_s, src/spandsp/private/bell_r2_mf.h:62-84 */
+
+typedef struct
+{
+    span_tone_report_func_t callback;
+    void *callback_data;
+    bool fwd;
+    spangpu_ref_goertzel_t out[6];
+    int current_sample;
+    int current_digit;
+} spangpu_ref_r2_mf_rx_t;                   /* struct r2_mf_rx_state_s, src/spandsp/private/bell_r2_mf.h:102-116 */
+
+/* On banks of kind SPANGPU_BELL_MF / SPANGPU_R2_MF.  What moves: the six Goertzel states, the block position, and
+   the hit history (Bell MF) or the digit being reported (R2); an R2 detector must be of the bank's direction (fwd). */
+SPANGPU_API int spangpu_bell_mf_import_state(spangpu_bank_t *bank, int channel, const spangpu_ref_bell_mf_rx_t *s);
+SPANGPU_API int spangpu_bell_mf_export_state(spangpu_bank_t *bank, int channel, spangpu_ref_bell_mf_rx_t *s);
+SPANGPU_API int spangpu_r2_mf_import_state(spangpu_bank_t *bank, int channel, const spangpu_ref_r2_mf_rx_t *s);
+SPANGPU_API int spangpu_r2_mf_export_state(spangpu_bank_t *bank, int channel, spangpu_ref_r2_mf_rx_t *s);
 
 /* ---- V.29 receiver ---------------------------------------------------------------------------------------- */
 typedef struct
@@ -316,7 +348,7 @@ SPANGPU_API int spangpu_v17_import_state(spangpu_modem_t *bank, int channel, con
 SPANGPU_API int spangpu_v17_export_state(spangpu_modem_t *bank, int channel, spangpu_ref_v17_rx_t *s);
 
 /* sizeof() of the mirror of the reference struct of that name ("dtmf_rx_state_t", "goertzel_state_t",
-   "echo_can_state_t", "v29_rx_state_t", "v27ter_rx_state_t", "v17_rx_state_t"), -1 for any other: what the tests hold against the reference build's own sizeof */
+   "echo_can_state_t", "bell_mf_rx_state_t", "r2_mf_rx_state_t", "v29_rx_state_t", "v27ter_rx_state_t", "v17_rx_state_t"), -1 for any other: what the tests hold against the reference build's own sizeof */
 SPANGPU_API int spangpu_refstate_sizeof(const char *what);
 
 #if defined(__cplusplus)

@@ -509,6 +509,10 @@ int spangpu_refstate_sizeof(const char *what)
         return (int) sizeof(spangpu_ref_goertzel_t);
     if (strcmp(what, "echo_can_state_t") == 0)
         return (int) sizeof(spangpu_ref_echo_can_t);
+    if (strcmp(what, "bell_mf_rx_state_t") == 0)
+        return (int) sizeof(spangpu_ref_bell_mf_rx_t);
+    if (strcmp(what, "r2_mf_rx_state_t") == 0)
+        return (int) sizeof(spangpu_ref_r2_mf_rx_t);
     if (strcmp(what, "v29_rx_state_t") == 0)
         return (int) sizeof(spangpu_ref_v29_rx_t);
     if (strcmp(what, "v27ter_rx_state_t") == 0)

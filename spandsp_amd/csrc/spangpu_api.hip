@@ -1262,6 +1262,98 @@ int spangpu_dtmf_export_state(spangpu_bank_t *b, int channel, spangpu_ref_dtmf_r
     return SPANGPU_OK;
 }
 
+// ---- Bell MF and MFC/R2 detectors in the reference's struct layout (src/spandsp/private/bell_r2_mf.h:62-116).  Both
+// drive their six Goertzels through goertzel_samplex(), like dtmf_rx(): the block position is the detector's own
+// current_sample, the Goertzels' counters stay where goertzel_init() left them.
+int spangpu_bell_mf_import_state(spangpu_bank_t *b, int channel, const spangpu_ref_bell_mf_rx_t *s)
+{
+    if (b == nullptr  ||  s == nullptr  ||  channel < 0  ||  channel >= b->n_ch  ||  b->kind != SPANGPU_BELL_MF)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    float f[12];
+    int32_t w[4];
+    for (int i = 0;  i < 6;  i++)
+    {
+        f[i] = s->out[i].v2;
+        f[6 + i] = s->out[i].v3;
+    }
+    // bell_r2_mf.c:629-661: hits[0] is the oldest of the five block results kept
+    w[0] = s->current_sample;
+    w[1] = s->hits[0];
+    w[2] = s->hits[1];
+    w[3] = (int32_t) ((uint32_t) s->hits[2] | ((uint32_t) s->hits[3] << 8) | ((uint32_t) s->hits[4] << 16));
+    return spangpu_bank_set_state(b, channel, f, 12, w, 4);
+}
+
+int spangpu_bell_mf_export_state(spangpu_bank_t *b, int channel, spangpu_ref_bell_mf_rx_t *s)
+{
+    if (b == nullptr  ||  s == nullptr  ||  channel < 0  ||  channel >= b->n_ch  ||  b->kind != SPANGPU_BELL_MF)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    float f[2*kMaxBins + 8];
+    int32_t w[4];
+    const int rc = spangpu_bank_get_state(b, channel, f, 2*kMaxBins + 8, w, 4);
+    if (rc < 0)
+        return rc;
+    for (int i = 0;  i < 6;  i++)
+    {
+        s->out[i].v2 = f[i];
+        s->out[i].v3 = f[6 + i];
+        s->out[i].fac = b->fac[i];
+        s->out[i].samples = 120;
+        s->out[i].current_sample = 0;
+    }
+    s->current_sample = w[0];
+    s->hits[0] = (uint8_t) w[1];
+    s->hits[1] = (uint8_t) w[2];
+    s->hits[2] = (uint8_t) (w[3] & 0xFF);
+    s->hits[3] = (uint8_t) ((w[3] >> 8) & 0xFF);
+    s->hits[4] = (uint8_t) ((w[3] >> 16) & 0xFF);
+    return SPANGPU_OK;
+}
+
+int spangpu_r2_mf_import_state(spangpu_bank_t *b, int channel, const spangpu_ref_r2_mf_rx_t *s)
+{
+    if (b == nullptr  ||  s == nullptr  ||  channel < 0  ||  channel >= b->n_ch  ||  b->kind != SPANGPU_R2_MF)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if ((s->fwd  ?  1  :  0) != (b->tp.r2_fwd  ?  1  :  0))
+        return fail(SPANGPU_ERR_BAD_ARG, "the detector listens for the other direction's tones");
+    float f[12];
+    int32_t w[4];
+    for (int i = 0;  i < 6;  i++)
+    {
+        f[i] = s->out[i].v2;
+        f[6 + i] = s->out[i].v3;
+    }
+    w[0] = s->current_sample;
+    w[1] = s->current_digit & 0xFF;
+    w[2] = 0;
+    w[3] = 0;
+    return spangpu_bank_set_state(b, channel, f, 12, w, 4);
+}
+
+int spangpu_r2_mf_export_state(spangpu_bank_t *b, int channel, spangpu_ref_r2_mf_rx_t *s)
+{
+    if (b == nullptr  ||  s == nullptr  ||  channel < 0  ||  channel >= b->n_ch  ||  b->kind != SPANGPU_R2_MF)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if ((s->fwd  ?  1  :  0) != (b->tp.r2_fwd  ?  1  :  0))
+        return fail(SPANGPU_ERR_BAD_ARG, "the detector listens for the other direction's tones");
+    float f[2*kMaxBins + 8];
+    int32_t w[4];
+    const int rc = spangpu_bank_get_state(b, channel, f, 2*kMaxBins + 8, w, 4);
+    if (rc < 0)
+        return rc;
+    for (int i = 0;  i < 6;  i++)
+    {
+        s->out[i].v2 = f[i];
+        s->out[i].v3 = f[6 + i];
+        s->out[i].fac = b->fac[i];
+        s->out[i].samples = 133;
+        s->out[i].current_sample = 0;
+    }
+    s->current_sample = w[0];
+    s->current_digit = w[1];
+    return SPANGPU_OK;
+}
+
 int spangpu_bank_reset_channel(spangpu_bank_t *b, int channel, int fillin_only)
 {
     if (b == nullptr  ||  channel < 0  ||  channel >= b->n_ch)

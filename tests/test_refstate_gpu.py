@@ -244,3 +244,91 @@ def test_modem_call_changes_sides(libs, modem, where):
         # and so does a bank of the same modem at another rate (tables, constellation and space map are per rate)
         slow = make_bank(n_ch, 2400 if modem == "v27ter" else 9600)
         assert imp(slow.h, ch, a.p) < 0
+
+
+def test_bell_mf_and_r2_mf_calls_change_sides(libs):
+    """The two MF detectors: six Goertzel states, the block position, and the hit history (Bell MF) or the digit being
+    reported (R2) move between the real reference and a bank channel in the middle of a block."""
+    from oracle import ref
+    from spandsp_amd import engine
+    R, L = libs
+    vp, ci = C.c_void_p, C.c_int
+    Rl = ref.lib()
+    for name in ("spangpu_bell_mf_import_state", "spangpu_bell_mf_export_state", "spangpu_r2_mf_import_state", "spangpu_r2_mf_export_state"):
+        getattr(L, name).argtypes = [vp, ci, vp]
+    n_ch, ch = 4, 2
+    cut = 160*23 + 71
+
+    def bank_hits(bank, seg):
+        """(block digit, flags) of every block that reports something, in order"""
+        out = []
+        for k in range(0, len(seg), 160):
+            m = min(160, len(seg) - k)
+            fr = np.zeros((n_ch, 160), np.int16)
+            lens = np.zeros(n_ch, np.int32)
+            fr[ch, :m] = seg[k:k + m]
+            lens[ch] = m
+            bank.rx_host_var(fr, lens)
+            for r in bank.blocks():
+                if r["channel"] == ch and (r["flags"] & engine.BLK_REPORT):
+                    out.append(int(r["code"]))
+        return out
+
+    # ---- Bell MF: the digits collected ----
+    sig, _ = synth.bell_mf_channels(3, 160*60, seed=81)
+    for x in sig:
+        def ref_digits(rx, seg):
+            out = ""
+            for k in range(0, len(seg), 160):
+                rx.rx(seg[k:k + 160])
+                out += rx.get()
+            return out
+        whole = ref.BellMfRx(0)
+        want = ref_digits(whole, x[:cut]) + ref_digits(whole, x[cut:])
+        assert len(want) >= 3
+        a = ref.BellMfRx(0)
+        first = ref_digits(a, x[:cut])
+        bank = engine.ToneBank(engine.BELL_MF, n_ch)
+        assert L.spangpu_bell_mf_import_state(bank.h, ch, a.p) == 0
+        assert first + "".join(chr(c) for c in bank_hits(bank, x[cut:])) == want
+        bank2 = engine.ToneBank(engine.BELL_MF, n_ch)
+        first2 = "".join(chr(c) for c in bank_hits(bank2, x[:cut]))
+        b = ref.BellMfRx(0)
+        assert L.spangpu_bell_mf_export_state(bank2.h, ch, b.p) == 0
+        assert first2 + ref_digits(b, x[cut:]) == want
+        # the exported detector is, in what moved, the one the reference built itself
+        probe = ref.BellMfRx(0)
+        assert L.spangpu_bell_mf_export_state(bank.h, ch, probe.p) == 0
+        sw, sp = whole.snapshot(), probe.snapshot()
+        for key in ("v2", "v3", "fac", "hits"):
+            assert np.array_equal(np.asarray(sw[key]).view(np.uint32), np.asarray(sp[key]).view(np.uint32)), key
+        assert sw["current_sample"] == sp["current_sample"]
+        assert L.spangpu_bell_mf_import_state(engine.ToneBank(engine.DTMF, n_ch).h, ch, a.p) < 0
+    # ---- R2: the changes of the digit present ----
+    for fwd in (True, False):
+        sig, _ = synth.r2_mf_channels(4, 160*60, seed=83, fwd=fwd)
+        moved = 0
+        for x in sig:
+            def ref_changes(rx, seg):
+                rx.sink.clear()
+                for k in range(0, len(seg), 160):
+                    rx.rx(seg[k:k + 160])
+                return [int(e["a"]) for e in rx.sink.events() if e["kind"] == 1]
+            whole = ref.R2MfRx(fwd, use_callback=True)
+            want = ref_changes(whole, x[:cut]) + ref_changes(whole, x[cut:])
+            if len(want) < 4:
+                continue                    # (some of the synthetic channels are too poor to yield a digit)
+            moved += 1
+            a = ref.R2MfRx(fwd, use_callback=True)
+            first = ref_changes(a, x[:cut])
+            bank = engine.ToneBank(engine.R2_MF, n_ch, r2_fwd=fwd)
+            assert L.spangpu_r2_mf_import_state(bank.h, ch, a.p) == 0
+            assert first + bank_hits(bank, x[cut:]) == want
+            bank2 = engine.ToneBank(engine.R2_MF, n_ch, r2_fwd=fwd)
+            first2 = bank_hits(bank2, x[:cut])
+            b = ref.R2MfRx(fwd, use_callback=True)
+            assert L.spangpu_r2_mf_export_state(bank2.h, ch, b.p) == 0
+            assert first2 + ref_changes(b, x[cut:]) == want
+            wrong = engine.ToneBank(engine.R2_MF, n_ch, r2_fwd=not fwd)
+            assert L.spangpu_r2_mf_import_state(wrong.h, ch, a.p) < 0
+        assert moved >= 2
