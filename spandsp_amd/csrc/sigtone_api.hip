@@ -601,9 +601,29 @@ int spangpu_sigtone_tx_set_mode(spangpu_sigtone_tx_t *b, int channel, int mode, 
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
     SIG_TRY(hipSetDevice(b->device));
     SIG_TRY(hipStreamSynchronize(b->stream));
+    if (channel >= 0)
+    {
+        // one channel: its five words through the host (sig_tone_tx_set_mode(), sig_tone.c:326-345), not two arrays of
+        // n_channels entries through a kernel
+        int32_t w[kSigTxWords];
+        const size_t pitch = (size_t) b->n_ch*sizeof(int32_t);
+        SIG_TRY(hipMemcpy2D(w, sizeof(int32_t), b->st + channel, pitch, sizeof(int32_t), kSigTxWords, hipMemcpyDeviceToHost));
+        const int old_tones = w[SX_TONE] & (SIG_1_PRESENT | SIG_2_PRESENT);
+        const int new_tones = mode & (SIG_1_PRESENT | SIG_2_PRESENT);
+        if (new_tones  &&  old_tones != new_tones)
+            w[SX_HIGH_LOW] = kDesc[b->tone_type - 1].high_low_timeout;
+        if ((mode & SIG_1_PRESENT)  &&  !(w[SX_TONE] & SIG_1_PRESENT))
+            w[SX_PHASE0] = 0;
+        if ((mode & SIG_2_PRESENT)  &&  !(w[SX_TONE] & SIG_2_PRESENT))
+            w[SX_PHASE1] = 0;
+        w[SX_TONE] = mode;
+        w[SX_TIMEOUT] = duration;
+        SIG_TRY(hipMemcpy2D(b->st + channel, pitch, w, sizeof(int32_t), sizeof(int32_t), kSigTxWords, hipMemcpyHostToDevice));
+        return SPANGPU_OK;
+    }
     for (int c = 0;  c < b->n_ch;  c++)
     {
-        b->h_modes[c] = (channel < 0  ||  c == channel)  ?  mode  :  -1;
+        b->h_modes[c] = mode;
         b->h_modes[b->n_ch + c] = duration;
     }
     SIG_TRY(hipMemcpyAsync(b->d_modes, b->h_modes, 2*(size_t) b->n_ch*sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
