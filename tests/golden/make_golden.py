@@ -78,6 +78,32 @@ def bell_mf_side1():
          guard_time_ms=res["guard_time_ms"], snr_levels=res["snr_levels"], acceptable_snr_db=res["acceptable_snr_db"])
 
 
+def r2_mf_side1():
+    """Tests 2-7 of tests/r2_mf_rx_tests.c on the real reference, forward and backward tone sets"""
+    import mf_side1
+
+    def burst(f1, l1, f2, l2, on_ms, off_ms):
+        return ref.ToneGen(f1, l1, f2, l2, on_ms, off_ms, 0, 0, False).tx(9999)
+
+    class Noise:
+        def __init__(self, seed, level):
+            self.cache = ref.awgn(seed, level, 400000)
+            self.pos = 0
+
+        def gen(self, n):
+            out = self.cache[self.pos:self.pos + n]
+            self.pos += n
+            assert len(out) == n
+            return out
+    for fwd in (True, False):
+        run = mf_side1.R2Run(burst, Noise, ref.R2MfRx(fwd, use_callback=False), fwd)
+        res = run.run()
+        save("r2_mf_side1_%s" % ("fwd" if fwd else "back"), answers=np.array(run.log, np.uint8), calls=run.calls,
+             signal_crc=np.uint32(run.crc), decode_ok=int(res["decode_ok"]), bandwidth=res["bandwidth"], twist=res["twist"],
+             dynamic_rounds=res["dynamic_rounds"], dynamic_range=res["dynamic_range"], guard_rounds=res["guard_rounds"],
+             guard_time_ms=res["guard_time_ms"], snr_levels=res["snr_levels"], acceptable_snr_db=res["acceptable_snr_db"])
+
+
 def sigtone_goldens():
     """sig_tone_rx / sig_tone_tx of the real reference (oracle/ref.py: SigToneRx, SigToneTx)"""
     from test_oracle_pin import zlib_crc
@@ -98,6 +124,7 @@ def main():
     L = ref.lib()
     mitel_side1()
     bell_mf_side1()
+    r2_mf_side1()
     save("goertzel_fac", freq=np.array(ALL_FREQS, np.float32),
          fac_bits=np.array([bits([L.glue_goertzel_fac(f, 102)])[0] for f in ALL_FREQS], np.uint32))
 
@@ -227,6 +254,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["sigtone"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         sigtone_goldens()
+    elif sys.argv[1:] == ["r2_mf_side1"]:
+        assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+        r2_mf_side1()
     elif sys.argv[1:] == ["bell_mf_side1"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         bell_mf_side1()

@@ -140,3 +140,131 @@ class Run:
         res["snr_levels"] = np.array(per_level, np.int32)
         res["acceptable_snr_db"] = -3 - i
         return res
+
+
+# ---- MFC/R2 (tests/r2_mf_rx_tests.c:100-145, 246-587): the same procedure, one continuous pulse per call ------------
+R2_FWD = [(1380.0, 1500.0), (1380.0, 1620.0), (1500.0, 1620.0), (1380.0, 1740.0), (1500.0, 1740.0), (1620.0, 1740.0),
+          (1380.0, 1860.0), (1500.0, 1860.0), (1620.0, 1860.0), (1740.0, 1860.0), (1380.0, 1980.0), (1500.0, 1980.0),
+          (1620.0, 1980.0), (1740.0, 1980.0), (1860.0, 1980.0)]
+R2_BACK = [(1140.0, 1020.0), (1140.0, 900.0), (1020.0, 900.0), (1140.0, 780.0), (1020.0, 780.0), (900.0, 780.0),
+           (1140.0, 660.0), (1020.0, 660.0), (900.0, 660.0), (780.0, 660.0), (1140.0, 540.0), (1020.0, 540.0),
+           (900.0, 540.0), (780.0, 540.0), (660.0, 540.0)]
+R2_CODES = "1234567890BCDEF"
+
+
+class R2Run:
+    """rx: an object with rx(amp) and get() -> the digit present (r2_mf_rx / r2_mf_rx_get); noise(seed, level) as above"""
+
+    def __init__(self, burst, noise, rx, fwd):
+        self.burst = burst
+        self.noise = noise
+        self.rx = rx
+        self.tones = R2_FWD if fwd else R2_BACK
+        self.log = []               # what r2_mf_rx_get() returned after every r2_mf_rx() call
+        self.crc = 0
+        self.calls = 0
+
+    def _send(self, d, low_fudge, low_level, high_fudge, high_level, duration, add=None):
+        f1, f2 = self.tones[R2_CODES.index(d)]
+        a = int(np.float64(np.float32(f1))*(1.0 + np.float64(np.float32(low_fudge))))
+        b = int(np.float64(np.float32(f2))*(1.0 + np.float64(np.float32(high_fudge))))
+        amp = np.ascontiguousarray(self.burst(a, low_level, b, high_level, duration, 0), np.int16)
+        if add is not None:
+            n = add.gen(len(amp))
+            amp = np.clip(amp.astype(np.int32) + n.astype(np.int32), -32768, 32767).astype(np.int16)
+        self.crc = zlib.crc32(amp.tobytes(), self.crc)
+        self.rx.rx(amp)
+        got = int(self.rx.get())
+        self.log.append(got)
+        self.calls += 1
+        return got
+
+    def run(self):
+        res = {}
+        # Test 2 (:259-283)
+        ok = True
+        for d in R2_CODES:
+            for _ in range(10):
+                ok = ok and (self._send(d, 0.0, -3, 0.0, -3, 68) == ord(d))
+        res["decode_ok"] = ok
+        # Test 3 (:313-396)
+        bw = []
+        for d in R2_CODES:
+            for which in (0, 1):
+                counts = []
+                for sweep in (range(1, 61), range(-1, -61, -1)):
+                    n = 0
+                    for i in sweep:
+                        fu = np.float32(np.float64(np.float32(i))/1000.0)
+                        n += (self._send(d, fu if which == 0 else 0.0, -17, 0.0 if which == 0 else fu, -17, 68) == ord(d))
+                    counts.append(n)
+                bw.append(tuple(counts))
+        res["bandwidth"] = np.array(bw, np.int32)
+        # Test 4 (:403-448)
+        tw = []
+        for d in R2_CODES:
+            nplus = sum(self._send(d, 0.0, -5, 0.0, int(i/10), 68) == ord(d) for i in range(-50, -251, -1))
+            nminus = sum(self._send(d, 0.0, int(i/10), 0.0, -5, 68) == ord(d) for i in range(-50, -251, -1))
+            tw.append((nplus, nminus))
+        res["twist"] = np.array(tw, np.int32)
+        # Test 5 (:455-500): per level, digit after digit a hundred times each until one is missed
+        nplus = nminus = -1000
+        rounds = []
+        for i in range(-50, 4):
+            j = 0
+            for d in R2_CODES:
+                j = 0
+                while j < 100:
+                    if self._send(d, 0.0, i, 0.0, i, 68) != ord(d):
+                        break
+                    j += 1
+                if j < 100:
+                    break
+            rounds.append(j)
+            if j == 100:
+                if nplus == -1000:
+                    nplus = i
+            elif nplus != -1000 and nminus == -1000:
+                nminus = i
+        res["dynamic_rounds"] = np.array(rounds, np.int32)
+        res["dynamic_range"] = np.array([nplus, nminus - 1], np.int32)
+        # Test 6 (:506-542)
+        rounds = []
+        i = 30
+        while i < 62:
+            j = 0
+            for d in R2_CODES:
+                j = 0
+                while j < 500:
+                    if self._send(d, 0.0, -5, 0.0, -3, i) != ord(d):
+                        break
+                    j += 1
+                if j < 500:
+                    break
+            rounds.append(j)
+            if j == 500:
+                break
+            i += 1
+        res["guard_rounds"] = np.array(rounds, np.int32)
+        res["guard_time_ms"] = i
+        # Test 7 (:548-587): a fresh noise source (same seed) for every digit of every level
+        per_level = []
+        i = -3
+        while i > -50:
+            j = 0
+            for d in R2_CODES:
+                src = self.noise(1234567, float(i))
+                j = 0
+                while j < 500:
+                    if self._send(d, 0.0, -3, 0.0, -3, 68, add=src) != ord(d):
+                        break
+                    j += 1
+                if j < 500:
+                    break
+            per_level.append((i, j))
+            if j == 500:
+                break
+            i -= 1
+        res["snr_levels"] = np.array(per_level, np.int32)
+        res["acceptable_snr_db"] = -3 - i
+        return res
