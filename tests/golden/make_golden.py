@@ -53,6 +53,31 @@ def mitel_side1():
          snr_levels=res["snr_levels"], acceptable_snr_db=res["acceptable_snr_db"])
 
 
+def dial_tone_tolerance():
+    """dial_tone_tolerance_tests() of tests/dtmf_rx_tests.c on the real reference, dial tone filter off and on"""
+    import mitel
+
+    def burst(f1, l1, f2, l2, on_ms, off_ms):
+        return ref.ToneGen(f1, l1, f2, l2, on_ms, off_ms, 0, 0, False).tx(1000)
+
+    class Dial:
+        def __init__(self, level):
+            self.g = ref.ToneGen(350, level, 440, level, 1, 0, 0, 0, True)
+
+        def gen(self, n):
+            return self.g.tx(n)
+    kw = {}
+    for filt in (0, 1):
+        run = mitel.DialToneRun(burst, Dial, ref.DtmfRx(0), bool(filt))
+        res = run.run()
+        kw["answers_%d" % filt] = np.frombuffer("|".join(run.log).encode("latin1"), np.uint8)
+        kw["calls_%d" % filt] = run.calls
+        kw["signal_crc_%d" % filt] = np.uint32(run.crc)
+        kw["rounds_%d" % filt] = res["rounds"]
+        kw["ratio_%d" % filt] = res["signal_to_dial_tone_db"]
+    save("dtmf_dial_tone", **kw)
+
+
 def bell_mf_side1():
     """Tests 2-7 of tests/bell_mf_rx_tests.c on the real reference: every answer, a CRC of every signal, the summary figures"""
     import mf_side1
@@ -123,6 +148,7 @@ def main():
     assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
     L = ref.lib()
     mitel_side1()
+    dial_tone_tolerance()
     bell_mf_side1()
     r2_mf_side1()
     save("goertzel_fac", freq=np.array(ALL_FREQS, np.float32),
@@ -254,6 +280,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["sigtone"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         sigtone_goldens()
+    elif sys.argv[1:] == ["dial_tone"]:
+        assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+        dial_tone_tolerance()
     elif sys.argv[1:] == ["r2_mf_side1"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         r2_mf_side1()

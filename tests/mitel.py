@@ -126,3 +126,48 @@ class Run:
 def c_int_div(a, b):
     """C integer division (truncation toward zero)."""
     return int(a/b)
+
+
+class DialToneRun:
+    """dial_tone_tolerance_tests() of the same program (dtmf_rx_tests.c:744-800): all sixteen digits at -15 dBm0 per tone,
+    50 ms on / 50 ms off, over a continuous 350 Hz + 440 Hz dial tone whose level rises from -30 dBm0 per tone until a
+    round of ten is no longer received whole -- with the receiver's dial tone filter off (the program's default) or on.
+
+        burst(f1, l1, f2, l2, on_ms, off_ms) as above;  dial(level) -> an object whose gen(n) returns the next n samples
+        of the dial tone (tone_gen_descriptor_init(350, level, 440, level, 1, 0, 0, 0, true));  rx with rx(amp), get() and
+        parms(filter_dialtone, twist, reverse_twist, threshold) = dtmf_rx_parms()"""
+
+    def __init__(self, burst, dial, rx, use_filter):
+        self.burst = burst
+        self.dial = dial
+        self.rx = rx
+        self.use_filter = use_filter
+        self.log = []
+        self.crc = 0
+        self.calls = 0
+
+    def run(self):
+        if self.use_filter:
+            self.rx.parms(1, -1.0, -1.0, -99.0)            # (:756-757)
+        digits = np.concatenate([self.burst(*tone_freqs(d, 0.0, 0.0)[:1], -15, tone_freqs(d, 0.0, 0.0)[1], -15, 50, 50)
+                                 for d in POSITIONS])
+        rounds = []
+        j = -30
+        while j < -3:
+            tone = self.dial(j)
+            i = 0
+            while i < 10:
+                amp = np.clip(digits.astype(np.int32) + tone.gen(len(digits)).astype(np.int32), -32768, 32767).astype(np.int16)
+                self.crc = zlib.crc32(amp.tobytes(), self.crc)
+                self.rx.rx(amp)
+                got = self.rx.get()
+                self.log.append(got)
+                self.calls += 1
+                if len(got) != len(POSITIONS):
+                    break
+                i += 1
+            rounds.append(i)
+            if i != 10:
+                break
+            j += 1
+        return {"rounds": np.array(rounds, np.int32), "signal_to_dial_tone_db": -15 - j}

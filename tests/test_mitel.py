@@ -103,3 +103,64 @@ def test_mitel_side1_dtmf_rx_shim(built):
     res = run.run()
     rx.close()
     _check(run, res)
+
+
+# ---- dial_tone_tolerance_tests() of the same program (dtmf_rx_tests.c:744-800), dial tone filter off and on --------
+DIAL_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dtmf_dial_tone.npz")
+
+
+class _Dial:
+    def __init__(self, level):
+        from oracle import restated as orc
+        self.g = orc.ToneGen(orc.tone_desc(350, level, 440, level, 1, 0, 0, 0, True))
+
+    def gen(self, n):
+        return self.g.tx(n)
+
+
+def _check_dial(run, res, filt):
+    g = np.load(DIAL_GOLDEN)
+    k = int(filt)
+    assert run.calls == int(g["calls_%d" % k])
+    assert np.uint32(run.crc) == g["signal_crc_%d" % k], "the regenerated test signals differ from the reference's"
+    assert "|".join(run.log) == bytes(g["answers_%d" % k]).decode("latin1")
+    assert np.array_equal(res["rounds"], g["rounds_%d" % k])
+    assert res["signal_to_dial_tone_db"] == int(g["ratio_%d" % k])
+    # the reference's answers, and its pass limits (dtmf_rx_tests.c:790-791)
+    assert res["signal_to_dial_tone_db"] == (-12 if filt else 9)
+    assert not (res["signal_to_dial_tone_db"] > (-12 if filt else 10))
+
+
+@pytest.mark.parametrize("filt", [False, True], ids=["filter-off", "filter-on"])
+def test_dial_tone_tolerance_oracle(built, filt):
+    from oracle import restated as orc
+    from test_oracle_pin import use_golden_modem_tables
+    use_golden_modem_tables()
+    run = mitel.DialToneRun(_burst, _Dial, orc.Dtmf(0), filt)
+    _check_dial(run, run.run(), filt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("filt", [False, True], ids=["filter-off", "filter-on"])
+def test_dial_tone_tolerance_dtmf_rx_shim(built, filt):
+    from spandsp_amd import engine
+    lib = C.CDLL(engine.LIB_PATH)
+    vp, ci = C.c_void_p, C.c_int
+    lib.dtmf_rx_init.restype = vp
+    lib.dtmf_rx_init.argtypes = [vp, vp, vp]
+    lib.dtmf_rx.restype = ci
+    lib.dtmf_rx.argtypes = [vp, vp, ci]
+    lib.dtmf_rx_get.restype = C.c_size_t
+    lib.dtmf_rx_get.argtypes = [vp, C.c_char_p, ci]
+    lib.dtmf_rx_parms.restype = None
+    lib.dtmf_rx_parms.argtypes = [vp, ci, C.c_float, C.c_float, C.c_float]
+    lib.dtmf_rx_free.restype = ci
+    lib.dtmf_rx_free.argtypes = [vp]
+    from test_oracle_pin import use_golden_modem_tables
+    use_golden_modem_tables()
+    rx = _ShimRx(lib)
+    rx.parms = lambda f, t, r, th: lib.dtmf_rx_parms(rx.s, f, t, r, th)
+    run = mitel.DialToneRun(_burst, _Dial, rx, filt)
+    res = run.run()
+    rx.close()
+    _check_dial(run, res, filt)
