@@ -78,6 +78,21 @@ def dial_tone_tolerance():
     save("dtmf_dial_tone", **kw)
 
 
+def super_tone_range():
+    """detection_range_tests() of tests/super_tone_rx_tests.c on the real reference: every callback, a CRC of the signal"""
+    import zlib
+    import st_range
+    rx = ref.SuperToneRx(st_range.fill_descriptor(ref.SuperToneDesc()), True)
+    crc = 0
+    for level, frames in st_range.sweep():
+        crc = zlib.crc32(frames.tobytes(), crc)
+        for fr in frames:
+            rx.rx(fr)
+    ev = rx.sink.events()
+    save("super_tone_range", events=np.array([tuple(int(x) for x in e) for e in ev], np.int32).reshape(-1, 4),
+         signal_crc=np.uint32(crc))
+
+
 def bell_mf_side1():
     """Tests 2-7 of tests/bell_mf_rx_tests.c on the real reference: every answer, a CRC of every signal, the summary figures"""
     import mf_side1
@@ -149,6 +164,7 @@ def main():
     L = ref.lib()
     mitel_side1()
     dial_tone_tolerance()
+    super_tone_range()
     bell_mf_side1()
     r2_mf_side1()
     save("goertzel_fac", freq=np.array(ALL_FREQS, np.float32),
@@ -280,6 +296,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["sigtone"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         sigtone_goldens()
+    elif sys.argv[1:] == ["super_tone_range"]:
+        assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+        super_tone_range()
     elif sys.argv[1:] == ["dial_tone"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         dial_tone_tolerance()
