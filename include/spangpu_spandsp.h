@@ -424,7 +424,7 @@ SPANGPU_API const char *modem_connect_tone_to_str(int tone);
  *                                          src/spandsp/sig_tone.h:57-176   src/sig_tone.c:246-738
  * Tone types SIG_TONE_2280HZ .. SIG_TONE_2400HZ_2600HZ (1..3) and the mode / report bits are the SPANGPU_SIG_TONE_*
  * values of spangpu.h.  An object is a private one-channel bank (N channels per launch: spangpu_sigtone_rx_create()
- * etc.); as everywhere, caller storage (s != NULL) returns NULL.  Callbacks arrive from inside the call, in order, and a
+ * etc.); caller storage (s != NULL) returns NULL, an object made by these functions is re-initialised in place.  Callbacks arrive from inside the call, in order, and a
  * mode set in one applies to the rest of the same frame, as in the reference.
  */
 typedef struct sig_tone_rx_state_s sig_tone_rx_state_t;

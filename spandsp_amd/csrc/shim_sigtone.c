@@ -20,8 +20,12 @@
 
 #define RX_WORDS    27
 
+#define RX_MAGIC    0x53475258u     /* an object this file made (and may therefore re-initialise in place) */
+#define TX_MAGIC    0x53475458u
+
 struct sig_tone_rx_state_s
 {
+    uint32_t magic;
     spangpu_sigtone_rx_t *bank;
     span_tone_report_func_t sig_update;
     void *user_data;
@@ -34,6 +38,7 @@ struct sig_tone_rx_state_s
 
 struct sig_tone_tx_state_s
 {
+    uint32_t magic;
     spangpu_sigtone_tx_t *bank;
     span_tone_report_func_t sig_update;
     void *user_data;
@@ -43,16 +48,31 @@ struct sig_tone_tx_state_s
 
 sig_tone_rx_state_t *sig_tone_rx_init(sig_tone_rx_state_t *s, int tone_type, span_tone_report_func_t sig_update, void *user_data)
 {
-    /* sig_tone.c:679-680: no callback or no such tone type -> NULL; caller storage cannot hold state that lives in HBM */
-    if (s != NULL  ||  sig_update == NULL  ||  tone_type < 1  ||  tone_type > 3)
+    const int fresh = (s == NULL);
+
+    /* sig_tone.c:679-680: no callback or no such tone type -> NULL.  Caller storage cannot hold state that lives in HBM;
+       an object made here is re-initialised in place, as the reference re-initialises whatever it is handed. */
+    if (sig_update == NULL  ||  tone_type < 1  ||  tone_type > 3)
         return NULL;
-    if ((s = (sig_tone_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
-        return NULL;
-    if (spangpu_sigtone_rx_create(&s->bank, 0, tone_type, 1) != SPANGPU_OK)
+    if (!fresh)
     {
-        free(s);
+        if (s->magic != RX_MAGIC)
+            return NULL;
+        spangpu_sigtone_rx_destroy(s->bank);
+        free(s->keep);
+        memset(s, 0, sizeof(*s));
+    }
+    else if ((s = (sig_tone_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+    {
         return NULL;
     }
+    if (spangpu_sigtone_rx_create(&s->bank, 0, tone_type, 1) != SPANGPU_OK)
+    {
+        if (fresh)
+            free(s);
+        return NULL;
+    }
+    s->magic = RX_MAGIC;
     s->sig_update = sig_update;
     s->user_data = user_data;
     return s;
@@ -186,6 +206,7 @@ int sig_tone_rx_free(sig_tone_rx_state_t *s)
     {
         spangpu_sigtone_rx_destroy(s->bank);
         free(s->keep);
+        s->magic = 0;
         free(s);
     }
     return 0;
@@ -195,16 +216,29 @@ int sig_tone_rx_free(sig_tone_rx_state_t *s)
 
 sig_tone_tx_state_t *sig_tone_tx_init(sig_tone_tx_state_t *s, int tone_type, span_tone_report_func_t sig_update, void *user_data)
 {
+    const int fresh = (s == NULL);
+
     /* sig_tone.c:352-353 */
-    if (s != NULL  ||  sig_update == NULL  ||  tone_type < 1  ||  tone_type > 3)
+    if (sig_update == NULL  ||  tone_type < 1  ||  tone_type > 3)
         return NULL;
-    if ((s = (sig_tone_tx_state_t *) calloc(1, sizeof(*s))) == NULL)
-        return NULL;
-    if (spangpu_sigtone_tx_create(&s->bank, 0, tone_type, 1) != SPANGPU_OK)
+    if (!fresh)
     {
-        free(s);
+        if (s->magic != TX_MAGIC)
+            return NULL;
+        spangpu_sigtone_tx_destroy(s->bank);
+        memset(s, 0, sizeof(*s));
+    }
+    else if ((s = (sig_tone_tx_state_t *) calloc(1, sizeof(*s))) == NULL)
+    {
         return NULL;
     }
+    if (spangpu_sigtone_tx_create(&s->bank, 0, tone_type, 1) != SPANGPU_OK)
+    {
+        if (fresh)
+            free(s);
+        return NULL;
+    }
+    s->magic = TX_MAGIC;
     s->sig_update = sig_update;
     s->user_data = user_data;
     return s;
@@ -244,6 +278,7 @@ int sig_tone_tx_free(sig_tone_tx_state_t *s)
     if (s)
     {
         spangpu_sigtone_tx_destroy(s->bank);
+        s->magic = 0;
         free(s);
     }
     return 0;

@@ -130,3 +130,9 @@ def test_sig_tone_init_refusals(L):
         assert not init(storage, 1, cb, None)           # caller storage cannot hold state that lives in HBM
     L.sig_tone_rx_free(None)
     L.sig_tone_tx_free(None)
+    # an object the library made is re-initialised in place, as the reference re-initialises what it is handed
+    for init, free in ((L.sig_tone_rx_init, L.sig_tone_rx_free), (L.sig_tone_tx_init, L.sig_tone_tx_free)):
+        s = init(None, 1, cb, None)
+        assert s and init(s, 3, cb, None) == s
+        assert not init(s, 9, cb, None)
+        free(s)
