@@ -78,6 +78,47 @@ def dial_tone_tolerance():
     save("dtmf_dial_tone", **kw)
 
 
+def flatten_callback_log(log):
+    """CallbackRun's log as arrays: per dtmf_rx() call its position (or -1), then its callbacks, then its digits"""
+    rows = []
+    text = []
+    for entry in log:
+        at, (ev, t) = entry if isinstance(entry[0], int) else (-1, entry)
+        rows.append((9, at, len(ev), len(t)))
+        rows.extend(ev)
+        text.append(t)
+    return np.array(rows, np.int32).reshape(-1, 4), np.frombuffer("".join(text).encode("latin1"), np.uint8)
+
+
+def dtmf_callbacks():
+    """callback_function_tests() of tests/dtmf_rx_tests.c on the real reference: every callback of every call"""
+    import mitel
+
+    def burst(f1, l1, f2, l2, on_ms, off_ms):
+        return ref.ToneGen(f1, l1, f2, l2, on_ms, off_ms, 0, 0, False).tx(1000)
+
+    class Rx:
+        def __init__(self, mode):
+            self.d = ref.DtmfRx(mode)
+            self.n = 0
+            self.t = 0
+
+        def rx(self, amp):
+            self.d.rx(amp)
+
+        def drain(self):
+            ev = self.d.sink.events()
+            txt = self.d.sink.text()
+            new = [tuple(int(x) for x in e) for e in ev[self.n:]]
+            t = txt[self.t:]
+            self.n = len(ev)
+            self.t = len(txt)
+            return new, t
+    run = mitel.CallbackRun(burst, Rx)
+    rows, text = flatten_callback_log(run.run())
+    save("dtmf_callbacks", rows=rows, text=text, signal_crc=np.uint32(run.crc))
+
+
 def super_tone_range():
     """detection_range_tests() of tests/super_tone_rx_tests.c on the real reference: every callback, a CRC of the signal"""
     import zlib
@@ -164,6 +205,7 @@ def main():
     L = ref.lib()
     mitel_side1()
     dial_tone_tolerance()
+    dtmf_callbacks()
     super_tone_range()
     bell_mf_side1()
     r2_mf_side1()
@@ -296,6 +338,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["sigtone"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         sigtone_goldens()
+    elif sys.argv[1:] == ["dtmf_callbacks"]:
+        assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+        dtmf_callbacks()
     elif sys.argv[1:] == ["super_tone_range"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         super_tone_range()

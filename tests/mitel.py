@@ -171,3 +171,39 @@ class DialToneRun:
                 break
             j += 1
         return {"rounds": np.array(rounds, np.int32), "signal_to_dial_tone_db": -15 - j}
+
+
+class CallbackRun:
+    """callback_function_tests() of the same program (dtmf_rx_tests.c:805-893): one to nine rounds of all sixteen digits
+    (-10 dBm0 per tone, 50 ms on / 50 ms off) handed to a receiver with a digits callback in ONE dtmf_rx() call per
+    round count -- up to 115 200 samples a call -- and then to a receiver with a realtime callback in 160-sample chunks.
+
+        make_rx(mode) -> an object with rx(amp) and drain() -> (the callback calls since the last drain as tuples
+                         (kind, a, b, c): kind 2 = digits callback (a = len), kind 1 = realtime callback (a = code,
+                         b = level, c = delay); the digits delivered since the last drain as a string)
+    The log is, per dtmf_rx() call, what drain() returned."""
+
+    def __init__(self, burst, make_rx):
+        self.burst = burst
+        self.make_rx = make_rx
+        self.log = []
+        self.crc = 0
+
+    def run(self):
+        one = np.concatenate([self.burst(*tone_freqs(d, 0.0, 0.0)[:1], -10, tone_freqs(d, 0.0, 0.0)[1], -10, 50, 50)
+                              for d in POSITIONS])
+        rx = self.make_rx(1)
+        for i in range(1, 10):
+            amp = np.ascontiguousarray(np.tile(one, i))
+            self.crc = zlib.crc32(amp.tobytes(), self.crc)
+            rx.rx(amp)
+            self.log.append(rx.drain())
+        rx = self.make_rx(2)
+        for i in range(1, 10):
+            amp = np.ascontiguousarray(np.tile(one, i))
+            for k in range(0, len(amp), 160):
+                rx.rx(amp[k:k + 160])
+                ev = rx.drain()
+                if ev[0]:
+                    self.log.append((k, ev))
+        return self.log

@@ -164,3 +164,113 @@ def test_dial_tone_tolerance_dtmf_rx_shim(built, filt):
     res = run.run()
     rx.close()
     _check_dial(run, res, filt)
+
+
+# ---- callback_function_tests() of the same program (dtmf_rx_tests.c:805-893): digits and realtime callbacks --------
+CB_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dtmf_callbacks.npz")
+
+
+def _flatten(log):
+    rows = []
+    text = []
+    for entry in log:
+        at, (ev, t) = entry if isinstance(entry[0], int) else (-1, entry)
+        rows.append((9, at, len(ev), len(t)))
+        rows.extend(ev)
+        text.append(t)
+    return np.array(rows, np.int32).reshape(-1, 4), np.frombuffer("".join(text).encode("latin1"), np.uint8)
+
+
+def _check_callbacks(run, log):
+    g = np.load(CB_GOLDEN)
+    assert np.uint32(run.crc) == g["signal_crc"], "the regenerated test signals differ from the reference's"
+    rows, text = _flatten(log)
+    assert np.array_equal(rows, g["rows"]) and np.array_equal(text, g["text"])
+    # what the reference's program checks (:219-318): the digits arrive in order, round after round; the realtime reports
+    # alternate digit / off with the sender's level (-10 dBm0 per tone) to within 1 dB
+    assert bytes(text).decode("latin1") == mitel.POSITIONS*45
+    reports = [e for entry in log if isinstance(entry[0], int) for e in entry[1][0]]
+    assert len(reports) == 2*16*45
+    assert all(r[1] == (ord(mitel.POSITIONS[(k//2) % 16]) if k % 2 == 0 else 0) for k, r in enumerate(reports))
+    assert all(-11 <= r[2] <= -9 for r in reports[::2])
+
+
+def test_dtmf_callback_modes_oracle(built):
+    from oracle import restated as orc
+    from test_oracle_pin import use_golden_modem_tables
+    use_golden_modem_tables()
+
+    class Rx:
+        def __init__(self, mode):
+            self.d = orc.Dtmf(mode)
+            self.n = 0
+            self.t = 0
+
+        def rx(self, amp):
+            self.d.rx(amp)
+
+        def drain(self):
+            ev = self.d.sink.events()
+            txt = self.d.sink.text()
+            new = [tuple(int(x) for x in e) for e in ev[self.n:]]
+            t = txt[self.t:]
+            self.n = len(ev)
+            self.t = len(txt)
+            return new, t
+    run = mitel.CallbackRun(_burst, Rx)
+    _check_callbacks(run, run.run())
+
+
+@pytest.mark.gpu
+def test_dtmf_callback_modes_dtmf_rx_shim(built):
+    """The digits callback inside single dtmf_rx() calls of up to 115 200 samples, and the realtime callback over
+    160-sample chunks, on private shim objects."""
+    from spandsp_amd import engine
+    lib = C.CDLL(engine.LIB_PATH)
+    vp, ci = C.c_void_p, C.c_int
+    DIGITS_CB = C.CFUNCTYPE(None, vp, C.c_char_p, ci)
+    TONE_CB = C.CFUNCTYPE(None, vp, ci, ci, ci)
+    lib.dtmf_rx_init.restype = vp
+    lib.dtmf_rx_init.argtypes = [vp, DIGITS_CB, vp]
+    lib.dtmf_rx_set_realtime_callback.restype = None
+    lib.dtmf_rx_set_realtime_callback.argtypes = [vp, TONE_CB, vp]
+    lib.dtmf_rx.restype = ci
+    lib.dtmf_rx.argtypes = [vp, vp, ci]
+    lib.dtmf_rx_free.restype = ci
+    lib.dtmf_rx_free.argtypes = [vp]
+    from test_oracle_pin import use_golden_modem_tables
+    use_golden_modem_tables()
+    made = []
+
+    class Rx:
+        def __init__(self, mode):
+            self.ev = []
+            self.text = ""
+            self.dcb = DIGITS_CB(self._digits)
+            self.tcb = TONE_CB(lambda ud, code, level, delay: self.ev.append((1, code, level, delay)))
+            if mode == 1:
+                self.s = lib.dtmf_rx_init(None, self.dcb, None)
+            else:
+                self.s = lib.dtmf_rx_init(None, C.cast(None, DIGITS_CB), None)
+                lib.dtmf_rx_set_realtime_callback(self.s, self.tcb, None)
+            assert self.s
+            made.append(self)
+
+        def _digits(self, ud, digits, n):
+            self.text += digits[:n].decode("latin1")
+            self.ev.append((2, n, 0, 0))
+
+        def rx(self, amp):
+            amp = np.ascontiguousarray(amp)
+            assert lib.dtmf_rx(self.s, amp.ctypes.data, len(amp)) == 0
+
+        def drain(self):
+            out = (self.ev, self.text)
+            self.ev = []
+            self.text = ""
+            return out
+    run = mitel.CallbackRun(_burst, Rx)
+    log = run.run()
+    for r in made:
+        lib.dtmf_rx_free(r.s)
+    _check_callbacks(run, log)
