@@ -12,6 +12,7 @@
  *   spangpu_ref_v29_rx_t        struct v29_rx_state_s       src/spandsp/private/v29rx.h:56-226
  *   spangpu_ref_v27ter_rx_t     struct v27ter_rx_state_s    src/spandsp/private/v27ter_rx.h:57-210
  *   spangpu_ref_v17_rx_t        struct v17_rx_state_s       src/spandsp/private/v17rx.h:64-254
+ *   spangpu_ref_fsk_rx_t        struct fsk_rx_state_s       src/spandsp/private/fsk.h:58-115
  * so a pointer to a detector made by the reference (dtmf_rx_init(), echo_can_init(), v29_rx_init()) can be passed as it is.  An import
  * takes the signal-processing fields; an export writes them and leaves the fields that belong to the caller's side of
  * the object alone (callbacks and their data, the collected digits, the logging descriptor, the pointers of the echo
@@ -347,8 +348,52 @@ typedef struct
 SPANGPU_API int spangpu_v17_import_state(spangpu_modem_t *bank, int channel, const spangpu_ref_v17_rx_t *s);
 SPANGPU_API int spangpu_v17_export_state(spangpu_modem_t *bank, int channel, spangpu_ref_v17_rx_t *s);
 
+/* ---- FSK receiver ----------------------------------------------------------------------------------------- */
+typedef struct
+{
+    int32_t re;
+    int32_t im;
+} spangpu_ref_complexi32_t;                 /* complexi32_t, src/spandsp/complex.h:99-105 */
+
+typedef struct
+{
+    int baud_rate;
+    int framing_mode;
+    int data_bits;
+    int parity;
+    int stop_bits;
+    int total_data_bits;
+    span_put_bit_func_t put_bit;
+    void *put_bit_user_data;
+    span_modem_status_func_t status_handler;
+    void *status_user_data;
+    int32_t carrier_on_power;
+    int32_t carrier_off_power;
+    spangpu_ref_power_meter_t power;
+    int16_t last_sample;
+    int signal_present;
+    int32_t phase_rate[2];
+    uint32_t phase_acc[2];
+    int correlation_span;
+    spangpu_ref_complexi32_t window[2][128];
+    spangpu_ref_complexi32_t dot[2];
+    int buf_ptr;
+    int frame_pos;
+    uint16_t frame_in_progress;
+    int baud_phase;
+    int last_bit;
+    int scaling_shift;
+    int parity_errors;
+    int framing_errors;
+} spangpu_ref_fsk_rx_t;                     /* struct fsk_rx_state_s, src/spandsp/private/fsk.h:58-115 */
+
+/* On a bank made with spangpu_fsk_create(): the receiver must be of the bank's spec (baud rate and the two
+   frequencies); framing mode, frame parameters and the power cutoffs travel with the receiver. */
+SPANGPU_API int spangpu_fsk_import_state(spangpu_fsk_t *bank, int channel, const spangpu_ref_fsk_rx_t *s);
+SPANGPU_API int spangpu_fsk_export_state(spangpu_fsk_t *bank, int channel, spangpu_ref_fsk_rx_t *s);
+
 /* sizeof() of the mirror of the reference struct of that name ("dtmf_rx_state_t", "goertzel_state_t",
-   "echo_can_state_t", "bell_mf_rx_state_t", "r2_mf_rx_state_t", "v29_rx_state_t", "v27ter_rx_state_t", "v17_rx_state_t"), -1 for any other: what the tests hold against the reference build's own sizeof */
+   "echo_can_state_t", "bell_mf_rx_state_t", "r2_mf_rx_state_t", "v29_rx_state_t", "v27ter_rx_state_t", "v17_rx_state_t", "fsk_rx_state_t"), -1 for any other: what the tests hold against the reference build's own sizeof */
 SPANGPU_API int spangpu_refstate_sizeof(const char *what);
 
 #if defined(__cplusplus)

@@ -94,6 +94,11 @@ GLUE int glue_fsk_rx_snapshot(const fsk_rx_state_t *s, int32_t *out)
     return n;
 }
 
+GLUE int glue_sizeof_fsk_rx(void)
+{
+    return (int) sizeof(fsk_rx_state_t);
+}
+
 /* ---- CPU baseline helpers: receivers whose put_bit() only counts, run a frame at a time ---- */
 static void count_put_bit(void *user_data, int bit)
 {

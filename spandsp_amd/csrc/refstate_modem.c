@@ -1,5 +1,5 @@
 /*
- * refstate_modem.c -- a V.29, V.27ter or V.17 receiver's state in the reference's own struct layout (include/spangpu_refstate.h) in and
+ * refstate_modem.c -- a V.29, V.27ter, V.17 or FSK receiver's state in the reference's own struct layout (include/spangpu_refstate.h) in and
  * out of a bank channel.  Host code over the bank's word-level state access: the 238 float and 43 integer words of a
  * channel are, in this order, the fields listed below (the order of the bank's get_state / set_state, which the parity
  * tests compare word for word with the reference's struct).
@@ -498,6 +498,114 @@ int spangpu_v17_export_state(spangpu_modem_t *bank, int channel, spangpu_ref_v17
     return SPANGPU_OK;
 }
 
+/* ---- FSK: 28 scalar words, then the correlation window (4 words per position) ---------------------------------- */
+#define FSK_SCALARS 28
+
+int spangpu_fsk_import_state(spangpu_fsk_t *bank, int channel, const spangpu_ref_fsk_rx_t *s)
+{
+    int32_t w[FSK_SCALARS + 4*128];
+    int n = 0;
+    int i;
+    int j;
+
+    if (bank == NULL  ||  s == NULL  ||  s->correlation_span < 1  ||  s->correlation_span > 128)
+        return SPANGPU_ERR_BAD_ARG;
+    if (spangpu_fsk_get_state(bank, channel, w) != SPANGPU_OK)
+        return SPANGPU_ERR_BAD_ARG;
+    /* a bank runs one baud rate and one pair of frequencies: the window length and the oscillators say which */
+    if (w[0] != s->baud_rate  ||  w[11] != s->phase_rate[0]  ||  w[12] != s->phase_rate[1]  ||  w[15] != s->correlation_span)
+        return SPANGPU_ERR_BAD_ARG;
+    w[n++] = s->baud_rate;
+    w[n++] = s->framing_mode;
+    w[n++] = s->data_bits;
+    w[n++] = s->parity;
+    w[n++] = s->stop_bits;
+    w[n++] = s->total_data_bits;
+    w[n++] = s->carrier_on_power;
+    w[n++] = s->carrier_off_power;
+    w[n++] = s->power.reading;
+    w[n++] = s->last_sample;
+    w[n++] = s->signal_present;
+    w[n++] = s->phase_rate[0];
+    w[n++] = s->phase_rate[1];
+    w[n++] = (int32_t) s->phase_acc[0];
+    w[n++] = (int32_t) s->phase_acc[1];
+    w[n++] = s->correlation_span;
+    w[n++] = s->dot[0].re;
+    w[n++] = s->dot[0].im;
+    w[n++] = s->dot[1].re;
+    w[n++] = s->dot[1].im;
+    w[n++] = s->buf_ptr;
+    w[n++] = s->frame_pos;
+    w[n++] = s->frame_in_progress;
+    w[n++] = s->baud_phase;
+    w[n++] = s->last_bit;
+    w[n++] = s->scaling_shift;
+    w[n++] = s->parity_errors;
+    w[n++] = s->framing_errors;
+    for (i = 0;  i < s->correlation_span;  i++)
+    {
+        for (j = 0;  j < 2;  j++)
+        {
+            w[n++] = s->window[j][i].re;
+            w[n++] = s->window[j][i].im;
+        }
+    }
+    return spangpu_fsk_set_state(bank, channel, w);
+}
+
+int spangpu_fsk_export_state(spangpu_fsk_t *bank, int channel, spangpu_ref_fsk_rx_t *s)
+{
+    int32_t w[FSK_SCALARS + 4*128];
+    int n = 0;
+    int i;
+    int j;
+
+    if (bank == NULL  ||  s == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    if (spangpu_fsk_get_state(bank, channel, w) != SPANGPU_OK)
+        return SPANGPU_ERR_BAD_ARG;
+    if (w[15] < 1  ||  w[15] > 128)
+        return SPANGPU_ERR_STATE;
+    s->baud_rate = w[n++];
+    s->framing_mode = w[n++];
+    s->data_bits = w[n++];
+    s->parity = w[n++];
+    s->stop_bits = w[n++];
+    s->total_data_bits = w[n++];
+    s->carrier_on_power = w[n++];
+    s->carrier_off_power = w[n++];
+    s->power.reading = w[n++];
+    s->last_sample = (int16_t) w[n++];
+    s->signal_present = w[n++];
+    s->phase_rate[0] = w[n++];
+    s->phase_rate[1] = w[n++];
+    s->phase_acc[0] = (uint32_t) w[n++];
+    s->phase_acc[1] = (uint32_t) w[n++];
+    s->correlation_span = w[n++];
+    s->dot[0].re = w[n++];
+    s->dot[0].im = w[n++];
+    s->dot[1].re = w[n++];
+    s->dot[1].im = w[n++];
+    s->buf_ptr = w[n++];
+    s->frame_pos = w[n++];
+    s->frame_in_progress = (uint16_t) w[n++];
+    s->baud_phase = w[n++];
+    s->last_bit = w[n++];
+    s->scaling_shift = w[n++];
+    s->parity_errors = w[n++];
+    s->framing_errors = w[n++];
+    for (i = 0;  i < s->correlation_span;  i++)
+    {
+        for (j = 0;  j < 2;  j++)
+        {
+            s->window[j][i].re = w[n++];
+            s->window[j][i].im = w[n++];
+        }
+    }
+    return SPANGPU_OK;
+}
+
 /* sizeof() of the mirrors above and in spangpu_refstate.h, for the tests to hold against the reference build's own */
 int spangpu_refstate_sizeof(const char *what)
 {
@@ -519,5 +627,7 @@ int spangpu_refstate_sizeof(const char *what)
         return (int) sizeof(spangpu_ref_v27ter_rx_t);
     if (strcmp(what, "v17_rx_state_t") == 0)
         return (int) sizeof(spangpu_ref_v17_rx_t);
+    if (strcmp(what, "fsk_rx_state_t") == 0)
+        return (int) sizeof(spangpu_ref_fsk_rx_t);
     return -1;
 }

@@ -332,3 +332,57 @@ def test_bell_mf_and_r2_mf_calls_change_sides(libs):
             wrong = engine.ToneBank(engine.R2_MF, n_ch, r2_fwd=not fwd)
             assert L.spangpu_r2_mf_import_state(wrong.h, ch, a.p) < 0
         assert moved >= 2
+
+
+@pytest.mark.parametrize("which,mode", [(1, 1), (1, 0), (1, 2)], ids=["v21ch2-sync", "v21ch2-async", "v21ch2-framed"])
+def test_fsk_call_changes_sides(libs, which, mode):
+    """An FSK receiver handed over in the middle of a transmission, correlation window, oscillators, baud phase and
+    framing state included: reference -> bank channel and bank channel -> reference."""
+    from oracle import ref
+    from spandsp_amd import engine
+    from test_oracle_pin import fsk_scenario
+    R, L = libs
+    vp, ci = C.c_void_p, C.c_int
+    L.spangpu_fsk_import_state.argtypes = [vp, ci, vp]
+    L.spangpu_fsk_export_state.argtypes = [vp, ci, vp]
+    x = fsk_scenario(which, mode)
+    cut = 160*31 + 53
+    assert cut + 2000 < len(x)
+    n_ch, ch = 3, 2
+
+    def ref_bits(rx, seg):
+        rx.sink.clear()
+        for k in range(0, len(seg), 160):
+            rx.rx(seg[k:k + 160])
+        return [int(e["a"]) for e in rx.sink.events()]
+
+    def bank_bits(bank, seg):
+        out = []
+        for k in range(0, len(seg), 160):
+            m = min(160, len(seg) - k)
+            fr = np.zeros((n_ch, 160), np.int16)
+            lens = np.zeros(n_ch, np.int32)
+            fr[ch, :m] = seg[k:k + m]
+            lens[ch] = m
+            bank.rx_host_var(fr, lens)
+            out.extend(int(b) for b in bank.events()[ch])
+        return out
+
+    whole = ref.FskRx(which, mode)
+    want = ref_bits(whole, x[:cut]) + ref_bits(whole, x[cut:])
+    assert len(want) > 40
+    a = ref.FskRx(which, mode)
+    first = ref_bits(a, x[:cut])
+    bank = engine.FskBank(which, n_ch, mode)
+    assert L.spangpu_fsk_import_state(bank.h, ch, a.p) == 0
+    assert first + bank_bits(bank, x[cut:]) == want
+    bank2 = engine.FskBank(which, n_ch, mode)
+    first2 = bank_bits(bank2, x[:cut])
+    b = ref.FskRx(which, mode)
+    assert L.spangpu_fsk_export_state(bank2.h, ch, b.p) == 0
+    assert first2 + ref_bits(b, x[cut:]) == want
+    probe = ref.FskRx(which, mode)
+    assert L.spangpu_fsk_export_state(bank.h, ch, probe.p) == 0
+    assert np.array_equal(whole.snapshot(), probe.snapshot())
+    other = engine.FskBank(0 if which else 1, n_ch, mode)           # another spec: refused
+    assert L.spangpu_fsk_import_state(other.h, ch, a.p) < 0
