@@ -508,6 +508,7 @@ SPANGPU_API int spangpu_mct_events(spangpu_mct_t *mct, const int32_t **events, c
 SPANGPU_API int spangpu_mct_get(spangpu_mct_t *mct, int channel);
 SPANGPU_API int spangpu_mct_state_words(const spangpu_mct_t *mct);
 SPANGPU_API int spangpu_mct_get_state(spangpu_mct_t *mct, int channel, int32_t *words);
+SPANGPU_API int spangpu_mct_set_state(spangpu_mct_t *mct, int channel, const int32_t *words);
 
 /* ---- signalling tone banks (sig_tone.c) -----------------
  * N in-band signalling tone receivers, or senders, of one tone type: 2280 Hz (AC15 and relatives), 2600 Hz, or

@@ -13,6 +13,8 @@
  *   spangpu_ref_v27ter_rx_t     struct v27ter_rx_state_s    src/spandsp/private/v27ter_rx.h:57-210
  *   spangpu_ref_v17_rx_t        struct v17_rx_state_s       src/spandsp/private/v17rx.h:64-254
  *   spangpu_ref_fsk_rx_t        struct fsk_rx_state_s       src/spandsp/private/fsk.h:58-115
+ *   spangpu_ref_mct_rx_t        struct modem_connect_tones_rx_state_s   src/spandsp/private/modem_connect_tones.h:58-112
+ *   spangpu_ref_sig_tone_rx_t   struct sig_tone_rx_state_s  src/spandsp/private/sig_tone.h:163-236
  * so a pointer to a detector made by the reference (dtmf_rx_init(), echo_can_init(), v29_rx_init()) can be passed as it is.  An import
  * takes the signal-processing fields; an export writes them and leaves the fields that belong to the caller's side of
  * the object alone (callbacks and their data, the collected digits, the logging descriptor, the pointers of the echo
@@ -392,8 +394,73 @@ typedef struct
 SPANGPU_API int spangpu_fsk_import_state(spangpu_fsk_t *bank, int channel, const spangpu_ref_fsk_rx_t *s);
 SPANGPU_API int spangpu_fsk_export_state(spangpu_fsk_t *bank, int channel, spangpu_ref_fsk_rx_t *s);
 
+/* ---- modem connect tone detector and signalling tone receiver ------------------------------------------------ */
+typedef struct
+{
+    int tone_type;
+    bool real_time_reports;
+    span_tone_report_func_t tone_callback;
+    void *callback_data;
+    float znotch_1;
+    float znotch_2;
+    float z15hz_1;
+    float z15hz_2;
+    int32_t notch_level;
+    int32_t channel_level;
+    int32_t am_level;
+    int chunk_remainder;
+    int tone_present;
+    int tone_on;
+    int tone_cycle_duration;
+    int good_cycles;
+    int hit;
+    spangpu_ref_fsk_rx_t v21rx;
+    unsigned int raw_bit_stream;
+    int num_bits;
+    int flags_seen;
+    bool framing_ok_announced;
+} spangpu_ref_mct_rx_t;                     /* struct modem_connect_tones_rx_state_s, src/spandsp/private/modem_connect_tones.h:58-112 */
+
+typedef struct
+{
+    span_tone_report_func_t sig_update;
+    void *user_data;
+    const void *desc;                       /* into the reference library's own tables: never read, never written here */
+    int current_rx_tone;
+    int high_low_timer;
+    int current_notch_filter;
+    struct
+    {
+        float notch_z1[2];
+        float notch_z2[2];
+        spangpu_ref_power_meter_t power;
+    } tone[3];
+    float flat_z[2];
+    spangpu_ref_power_meter_t flat_power;
+    int tone_persistence_timeout;
+    int last_sample_tone_present;
+    int32_t flat_detection_threshold;
+    int32_t sharp_detection_threshold;
+    int32_t detection_ratio;
+    bool flat_mode;
+    bool notch_enabled;
+    int flat_mode_timeout;
+    int notch_insertion_timeout;
+    int signalling_state;
+    int signalling_state_duration;
+} spangpu_ref_sig_tone_rx_t;                /* struct sig_tone_rx_state_s (float build), src/spandsp/private/sig_tone.h:163-236 */
+
+/* The detector must be of the bank's tone type (after modem_connect_tones_rx_init()'s folding of the ANS variants);
+   the V.21 receiver of the preamble hunting types travels inside it. */
+SPANGPU_API int spangpu_mct_import_state(spangpu_mct_t *bank, int channel, const spangpu_ref_mct_rx_t *s);
+SPANGPU_API int spangpu_mct_export_state(spangpu_mct_t *bank, int channel, spangpu_ref_mct_rx_t *s);
+/* The receiver must have the bank's thresholds (that is: its tone type); its mode travels with it. */
+SPANGPU_API int spangpu_sig_tone_rx_import_state(spangpu_sigtone_rx_t *bank, int channel, const spangpu_ref_sig_tone_rx_t *s);
+SPANGPU_API int spangpu_sig_tone_rx_export_state(spangpu_sigtone_rx_t *bank, int channel, spangpu_ref_sig_tone_rx_t *s);
+
 /* sizeof() of the mirror of the reference struct of that name ("dtmf_rx_state_t", "goertzel_state_t",
-   "echo_can_state_t", "bell_mf_rx_state_t", "r2_mf_rx_state_t", "v29_rx_state_t", "v27ter_rx_state_t", "v17_rx_state_t", "fsk_rx_state_t"), -1 for any other: what the tests hold against the reference build's own sizeof */
+   "echo_can_state_t", "bell_mf_rx_state_t", "r2_mf_rx_state_t", "v29_rx_state_t", "v27ter_rx_state_t", "v17_rx_state_t", "fsk_rx_state_t", "modem_connect_tones_rx_state_t",
+   "sig_tone_rx_state_t"), -1 for any other: what the tests hold against the reference build's own sizeof */
 SPANGPU_API int spangpu_refstate_sizeof(const char *what);
 
 #if defined(__cplusplus)

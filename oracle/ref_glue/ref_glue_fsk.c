@@ -174,6 +174,11 @@ GLUE int glue_mct_rx_snapshot(const modem_connect_tones_rx_state_t *s, int32_t *
     return n;
 }
 
+GLUE int glue_sizeof_mct_rx(void)
+{
+    return (int) sizeof(modem_connect_tones_rx_state_t);
+}
+
 /* CPU baseline helper: `frames` consecutive frames, `loops` times, on n detectors (no callback: hits latch) */
 GLUE void glue_mct_rx_batch_frames(modem_connect_tones_rx_state_t **s, const int16_t *amp, int n, long long stride,
                                    long long frame_stride, int samples, int frames, int loops)

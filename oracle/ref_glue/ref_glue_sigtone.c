@@ -58,6 +58,11 @@ GLUE void glue_sigtone_rx_thresholds(const sig_tone_rx_state_t *s, int32_t out[3
     out[2] = s->detection_ratio;
 }
 
+GLUE int glue_sizeof_sig_tone_rx(void)
+{
+    return (int) sizeof(sig_tone_rx_state_t);
+}
+
 static void quiet_report(void *user_data, int code, int level, int delay)
 {
     (void) code;

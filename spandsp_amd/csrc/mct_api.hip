@@ -394,4 +394,17 @@ int spangpu_mct_get_state(spangpu_mct_t *m, int channel, int32_t *words)
     return SPANGPU_OK;
 }
 
+// The reverse of spangpu_mct_get_state(): a channel's words as a caller holds them.
+int spangpu_mct_set_state(spangpu_mct_t *m, int channel, const int32_t *words)
+{
+    if (m == NULL  ||  words == NULL  ||  channel < 0  ||  channel >= m->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    MCT_TRY(hipSetDevice(m->device));
+    MCT_TRY(hipStreamSynchronize(m->stream));
+    MCT_TRY(hipMemcpy2DAsync(m->st + channel, (size_t) m->n_ch*sizeof(int32_t), words, sizeof(int32_t), sizeof(int32_t), m->words,
+                             hipMemcpyHostToDevice, m->stream));
+    MCT_TRY(hipStreamSynchronize(m->stream));
+    return SPANGPU_OK;
+}
+
 }   // extern "C"

@@ -1,5 +1,5 @@
 /*
- * refstate_modem.c -- a V.29, V.27ter, V.17 or FSK receiver's state in the reference's own struct layout (include/spangpu_refstate.h) in and
+ * refstate_modem.c -- a modem, FSK, connect tone or signalling tone receiver's state in the reference's own struct layout (include/spangpu_refstate.h) in and
  * out of a bank channel.  Host code over the bank's word-level state access: the 238 float and 43 integer words of a
  * channel are, in this order, the fields listed below (the order of the bank's get_state / set_state, which the parity
  * tests compare word for word with the reference's struct).
@@ -501,20 +501,12 @@ int spangpu_v17_export_state(spangpu_modem_t *bank, int channel, spangpu_ref_v17
 /* ---- FSK: 28 scalar words, then the correlation window (4 words per position) ---------------------------------- */
 #define FSK_SCALARS 28
 
-int spangpu_fsk_import_state(spangpu_fsk_t *bank, int channel, const spangpu_ref_fsk_rx_t *s)
+static int fsk_to_words(const spangpu_ref_fsk_rx_t *s, int32_t *w)
 {
-    int32_t w[FSK_SCALARS + 4*128];
     int n = 0;
     int i;
     int j;
 
-    if (bank == NULL  ||  s == NULL  ||  s->correlation_span < 1  ||  s->correlation_span > 128)
-        return SPANGPU_ERR_BAD_ARG;
-    if (spangpu_fsk_get_state(bank, channel, w) != SPANGPU_OK)
-        return SPANGPU_ERR_BAD_ARG;
-    /* a bank runs one baud rate and one pair of frequencies: the window length and the oscillators say which */
-    if (w[0] != s->baud_rate  ||  w[11] != s->phase_rate[0]  ||  w[12] != s->phase_rate[1]  ||  w[15] != s->correlation_span)
-        return SPANGPU_ERR_BAD_ARG;
     w[n++] = s->baud_rate;
     w[n++] = s->framing_mode;
     w[n++] = s->data_bits;
@@ -551,22 +543,15 @@ int spangpu_fsk_import_state(spangpu_fsk_t *bank, int channel, const spangpu_ref
             w[n++] = s->window[j][i].im;
         }
     }
-    return spangpu_fsk_set_state(bank, channel, w);
+    return n;
 }
 
-int spangpu_fsk_export_state(spangpu_fsk_t *bank, int channel, spangpu_ref_fsk_rx_t *s)
+static int fsk_from_words(spangpu_ref_fsk_rx_t *s, const int32_t *w)
 {
-    int32_t w[FSK_SCALARS + 4*128];
     int n = 0;
     int i;
     int j;
 
-    if (bank == NULL  ||  s == NULL)
-        return SPANGPU_ERR_BAD_ARG;
-    if (spangpu_fsk_get_state(bank, channel, w) != SPANGPU_OK)
-        return SPANGPU_ERR_BAD_ARG;
-    if (w[15] < 1  ||  w[15] > 128)
-        return SPANGPU_ERR_STATE;
     s->baud_rate = w[n++];
     s->framing_mode = w[n++];
     s->data_bits = w[n++];
@@ -603,6 +588,198 @@ int spangpu_fsk_export_state(spangpu_fsk_t *bank, int channel, spangpu_ref_fsk_r
             s->window[j][i].im = w[n++];
         }
     }
+    return n;
+}
+
+int spangpu_fsk_import_state(spangpu_fsk_t *bank, int channel, const spangpu_ref_fsk_rx_t *s)
+{
+    int32_t w[FSK_SCALARS + 4*128];
+
+    if (bank == NULL  ||  s == NULL  ||  s->correlation_span < 1  ||  s->correlation_span > 128)
+        return SPANGPU_ERR_BAD_ARG;
+    if (spangpu_fsk_get_state(bank, channel, w) != SPANGPU_OK)
+        return SPANGPU_ERR_BAD_ARG;
+    /* a bank runs one baud rate and one pair of frequencies: the window length and the oscillators say which */
+    if (w[0] != s->baud_rate  ||  w[11] != s->phase_rate[0]  ||  w[12] != s->phase_rate[1]  ||  w[15] != s->correlation_span)
+        return SPANGPU_ERR_BAD_ARG;
+    (void) fsk_to_words(s, w);
+    return spangpu_fsk_set_state(bank, channel, w);
+}
+
+int spangpu_fsk_export_state(spangpu_fsk_t *bank, int channel, spangpu_ref_fsk_rx_t *s)
+{
+    int32_t w[FSK_SCALARS + 4*128];
+
+    if (bank == NULL  ||  s == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    if (spangpu_fsk_get_state(bank, channel, w) != SPANGPU_OK)
+        return SPANGPU_ERR_BAD_ARG;
+    if (w[15] < 1  ||  w[15] > 128)
+        return SPANGPU_ERR_STATE;
+    (void) fsk_from_words(s, w);
+    return SPANGPU_OK;
+}
+
+/* ---- modem connect tones: 18 words of the detector, then the V.21 receiver's words where it runs ------------------ */
+#define MCT_WORDS   18
+
+int spangpu_mct_import_state(spangpu_mct_t *bank, int channel, const spangpu_ref_mct_rx_t *s)
+{
+    int32_t w[MCT_WORDS + FSK_SCALARS + 4*128];
+    int words;
+    int n = 0;
+
+    if (bank == NULL  ||  s == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    words = spangpu_mct_state_words(bank);
+    if (words < MCT_WORDS  ||  words > MCT_WORDS + FSK_SCALARS + 4*128  ||  spangpu_mct_get_state(bank, channel, w) != SPANGPU_OK)
+        return SPANGPU_ERR_BAD_ARG;
+    if (w[0] != s->tone_type)
+        return SPANGPU_ERR_BAD_ARG;
+    if (words > MCT_WORDS  &&  (s->v21rx.correlation_span != w[MCT_WORDS + 15]  ||  s->v21rx.baud_rate != w[MCT_WORDS]))
+        return SPANGPU_ERR_BAD_ARG;
+    w[n++] = s->tone_type;
+    w[n++] = (int32_t) fbits(s->znotch_1);
+    w[n++] = (int32_t) fbits(s->znotch_2);
+    w[n++] = (int32_t) fbits(s->z15hz_1);
+    w[n++] = (int32_t) fbits(s->z15hz_2);
+    w[n++] = s->notch_level;
+    w[n++] = s->channel_level;
+    w[n++] = s->am_level;
+    w[n++] = s->tone_present;
+    w[n++] = s->tone_on;
+    w[n++] = s->tone_cycle_duration;
+    w[n++] = s->good_cycles;
+    w[n++] = s->hit;
+    w[n++] = (int32_t) s->raw_bit_stream;
+    w[n++] = s->num_bits;
+    w[n++] = s->flags_seen;
+    w[n++] = s->framing_ok_announced  ?  1  :  0;
+    w[n++] = 0;
+    if (words > MCT_WORDS)
+        (void) fsk_to_words(&s->v21rx, w + MCT_WORDS);
+    return spangpu_mct_set_state(bank, channel, w);
+}
+
+int spangpu_mct_export_state(spangpu_mct_t *bank, int channel, spangpu_ref_mct_rx_t *s)
+{
+    int32_t w[MCT_WORDS + FSK_SCALARS + 4*128];
+    int words;
+    int n = 1;
+
+    if (bank == NULL  ||  s == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    words = spangpu_mct_state_words(bank);
+    if (words < MCT_WORDS  ||  words > MCT_WORDS + FSK_SCALARS + 4*128  ||  spangpu_mct_get_state(bank, channel, w) != SPANGPU_OK)
+        return SPANGPU_ERR_BAD_ARG;
+    if (w[0] != s->tone_type)
+        return SPANGPU_ERR_BAD_ARG;             /* (the struct must have been initialised for the same tone type) */
+    s->znotch_1 = bitsf((uint32_t) w[n++]);
+    s->znotch_2 = bitsf((uint32_t) w[n++]);
+    s->z15hz_1 = bitsf((uint32_t) w[n++]);
+    s->z15hz_2 = bitsf((uint32_t) w[n++]);
+    s->notch_level = w[n++];
+    s->channel_level = w[n++];
+    s->am_level = w[n++];
+    s->tone_present = w[n++];
+    s->tone_on = w[n++];
+    s->tone_cycle_duration = w[n++];
+    s->good_cycles = w[n++];
+    s->hit = w[n++];
+    s->raw_bit_stream = (unsigned int) w[n++];
+    s->num_bits = w[n++];
+    s->flags_seen = w[n++];
+    s->framing_ok_announced = (w[n++] != 0);
+    if (words > MCT_WORDS)
+    {
+        /* the V.21 receiver's callbacks point into the detector that owns it: they stay */
+        span_put_bit_func_t put_bit = s->v21rx.put_bit;
+        void *put_bit_user_data = s->v21rx.put_bit_user_data;
+        span_modem_status_func_t status_handler = s->v21rx.status_handler;
+        void *status_user_data = s->v21rx.status_user_data;
+
+        (void) fsk_from_words(&s->v21rx, w + MCT_WORDS);
+        s->v21rx.put_bit = put_bit;
+        s->v21rx.put_bit_user_data = put_bit_user_data;
+        s->v21rx.status_handler = status_handler;
+        s->v21rx.status_user_data = status_user_data;
+    }
+    return SPANGPU_OK;
+}
+
+/* ---- signalling tone receiver: 27 words ----------------------------------------------------------------------------- */
+#define SIG_WORDS   27
+
+int spangpu_sig_tone_rx_import_state(spangpu_sigtone_rx_t *bank, int channel, const spangpu_ref_sig_tone_rx_t *s)
+{
+    int32_t w[SIG_WORDS];
+    int32_t thr[3];
+    int n = 0;
+    int j;
+
+    if (bank == NULL  ||  s == NULL  ||  spangpu_sigtone_rx_thresholds(bank, thr) != SPANGPU_OK)
+        return SPANGPU_ERR_BAD_ARG;
+    /* a bank runs one tone type; what tells the types apart in the receiver's own fields is the detection ratio
+       (2280 Hz against the 2600 Hz types) and, between those two, which tones a report may name -- the caller says which
+       bank by handing the channel over; the thresholds are checked */
+    if (thr[0] != s->flat_detection_threshold  ||  thr[1] != s->sharp_detection_threshold  ||  thr[2] != s->detection_ratio)
+        return SPANGPU_ERR_BAD_ARG;
+    for (j = 0;  j < 3;  j++)
+    {
+        w[n++] = (int32_t) fbits(s->tone[j].notch_z1[0]);
+        w[n++] = (int32_t) fbits(s->tone[j].notch_z1[1]);
+        w[n++] = (int32_t) fbits(s->tone[j].notch_z2[0]);
+        w[n++] = (int32_t) fbits(s->tone[j].notch_z2[1]);
+        w[n++] = s->tone[j].power.reading;
+    }
+    w[n++] = (int32_t) fbits(s->flat_z[0]);
+    w[n++] = (int32_t) fbits(s->flat_z[1]);
+    w[n++] = s->flat_power.reading;
+    w[n++] = s->tone_persistence_timeout;
+    w[n++] = s->last_sample_tone_present;
+    w[n++] = s->flat_mode  ?  1  :  0;
+    w[n++] = s->flat_mode_timeout;
+    w[n++] = s->notch_insertion_timeout;
+    w[n++] = s->signalling_state;
+    w[n++] = s->signalling_state_duration;
+    w[n++] = s->current_notch_filter;
+    w[n++] = s->current_rx_tone;
+    return spangpu_sigtone_rx_set_state(bank, channel, w);
+}
+
+int spangpu_sig_tone_rx_export_state(spangpu_sigtone_rx_t *bank, int channel, spangpu_ref_sig_tone_rx_t *s)
+{
+    int32_t w[SIG_WORDS];
+    int32_t thr[3];
+    int n = 0;
+    int j;
+
+    if (bank == NULL  ||  s == NULL  ||  spangpu_sigtone_rx_thresholds(bank, thr) != SPANGPU_OK)
+        return SPANGPU_ERR_BAD_ARG;
+    if (thr[0] != s->flat_detection_threshold  ||  thr[1] != s->sharp_detection_threshold  ||  thr[2] != s->detection_ratio)
+        return SPANGPU_ERR_BAD_ARG;             /* (the struct must have been initialised for the bank's tone type) */
+    if (spangpu_sigtone_rx_get_state(bank, channel, w) != SPANGPU_OK)
+        return SPANGPU_ERR_BAD_ARG;
+    for (j = 0;  j < 3;  j++)
+    {
+        s->tone[j].notch_z1[0] = bitsf((uint32_t) w[n++]);
+        s->tone[j].notch_z1[1] = bitsf((uint32_t) w[n++]);
+        s->tone[j].notch_z2[0] = bitsf((uint32_t) w[n++]);
+        s->tone[j].notch_z2[1] = bitsf((uint32_t) w[n++]);
+        s->tone[j].power.reading = w[n++];
+    }
+    s->flat_z[0] = bitsf((uint32_t) w[n++]);
+    s->flat_z[1] = bitsf((uint32_t) w[n++]);
+    s->flat_power.reading = w[n++];
+    s->tone_persistence_timeout = w[n++];
+    s->last_sample_tone_present = w[n++];
+    s->flat_mode = (w[n++] != 0);
+    s->flat_mode_timeout = w[n++];
+    s->notch_insertion_timeout = w[n++];
+    s->signalling_state = w[n++];
+    s->signalling_state_duration = w[n++];
+    s->current_notch_filter = w[n++];
+    s->current_rx_tone = w[n++];
     return SPANGPU_OK;
 }
 
@@ -629,5 +806,9 @@ int spangpu_refstate_sizeof(const char *what)
         return (int) sizeof(spangpu_ref_v17_rx_t);
     if (strcmp(what, "fsk_rx_state_t") == 0)
         return (int) sizeof(spangpu_ref_fsk_rx_t);
+    if (strcmp(what, "modem_connect_tones_rx_state_t") == 0)
+        return (int) sizeof(spangpu_ref_mct_rx_t);
+    if (strcmp(what, "sig_tone_rx_state_t") == 0)
+        return (int) sizeof(spangpu_ref_sig_tone_rx_t);
     return -1;
 }

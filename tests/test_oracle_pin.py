@@ -651,6 +651,8 @@ def test_refstate_mirrors_have_the_reference_sizes(built):
     for what in (b"dtmf_rx_state_t", b"goertzel_state_t", b"echo_can_state_t", b"bell_mf_rx_state_t", b"r2_mf_rx_state_t", b"v29_rx_state_t", b"v27ter_rx_state_t", b"v17_rx_state_t"):
         assert L.spangpu_refstate_sizeof(what) == R.glue_sizeof(what) > 0, what
     assert L.spangpu_refstate_sizeof(b"fsk_rx_state_t") == R.glue_sizeof_fsk_rx() > 0
+    assert L.spangpu_refstate_sizeof(b"modem_connect_tones_rx_state_t") == R.glue_sizeof_mct_rx() > 0
+    assert L.spangpu_refstate_sizeof(b"sig_tone_rx_state_t") == R.glue_sizeof_sig_tone_rx() > 0
     assert L.spangpu_refstate_sizeof(b"something_else") == -1
 
 

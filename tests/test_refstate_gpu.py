@@ -386,3 +386,112 @@ def test_fsk_call_changes_sides(libs, which, mode):
     assert np.array_equal(whole.snapshot(), probe.snapshot())
     other = engine.FskBank(0 if which else 1, n_ch, mode)           # another spec: refused
     assert L.spangpu_fsk_import_state(other.h, ch, a.p) < 0
+
+
+@pytest.mark.parametrize("rx_type,tx_kind", [(2, 4), (7, "preamble"), (7, 5), (1, 1)])
+def test_connect_tone_call_changes_sides(libs, rx_type, tx_kind):
+    """A modem connect tone detector -- its V.21 receiver inside it where it hunts for the FAX preamble -- handed over in
+    mid-signal, both ways."""
+    from oracle import ref
+    from spandsp_amd import engine
+    from test_oracle_pin import mct_scenario
+    R, L = libs
+    vp, ci = C.c_void_p, C.c_int
+    L.spangpu_mct_import_state.argtypes = [vp, ci, vp]
+    L.spangpu_mct_export_state.argtypes = [vp, ci, vp]
+    x = mct_scenario(rx_type, tx_kind)
+    n_ch, ch = 3, 0
+    for cut in (160*20 + 9, 160*60 + 101):
+        def ref_reports(rx, seg):
+            rx.sink.clear()
+            for k in range(0, len(seg), 160):
+                rx.rx(seg[k:k + 160])
+            return [(int(e["a"]), int(e["b"])) for e in rx.sink.events() if e["kind"] == 1]
+
+        def bank_reports(bank, seg):
+            out = []
+            for k in range(0, len(seg), 160):
+                m = min(160, len(seg) - k)
+                fr = np.zeros((n_ch, 160), np.int16)
+                lens = np.zeros(n_ch, np.int32)
+                fr[ch, :m] = seg[k:k + m]
+                lens[ch] = m
+                bank.rx_host_var(fr, lens)
+                out.extend((int(t), int(lv)) for t, lv in bank.events()[ch])
+            return out
+        whole = ref.MctRx(rx_type)
+        want = ref_reports(whole, x[:cut]) + ref_reports(whole, x[cut:])
+        assert len(want) >= 2
+        a = ref.MctRx(rx_type)
+        first = ref_reports(a, x[:cut])
+        bank = engine.MctBank(rx_type, n_ch)
+        assert L.spangpu_mct_import_state(bank.h, ch, a.p) == 0
+        assert first + bank_reports(bank, x[cut:]) == want
+        bank2 = engine.MctBank(rx_type, n_ch)
+        first2 = bank_reports(bank2, x[:cut])
+        b = ref.MctRx(rx_type)
+        assert L.spangpu_mct_export_state(bank2.h, ch, b.p) == 0
+        assert first2 + ref_reports(b, x[cut:]) == want
+        probe = ref.MctRx(rx_type)
+        assert L.spangpu_mct_export_state(bank.h, ch, probe.p) == 0
+        assert np.array_equal(whole.snapshot(), probe.snapshot())
+        assert L.spangpu_mct_import_state(engine.MctBank(8, n_ch).h, ch, a.p) < 0        # another tone type: refused
+
+
+@pytest.mark.parametrize("tone_type,mode", [(1, 0x40), (2, 0xC0), (3, 0x40)])
+def test_sig_tone_call_changes_sides(libs, tone_type, mode):
+    """A signalling tone receiver handed over in mid-frame with a tone present: filter states, meters, timers, mode."""
+    from oracle import ref
+    from spandsp_amd import engine
+    R, L = libs
+    vp, ci = C.c_void_p, C.c_int
+    L.spangpu_sig_tone_rx_import_state.argtypes = [vp, ci, vp]
+    L.spangpu_sig_tone_rx_export_state.argtypes = [vp, ci, vp]
+    sig = synth.sig_tone_channels(4, 8000*4, 140 + tone_type, tone_type)
+    n_ch, ch = 3, 1
+    moved = 0
+    for x in sig:
+        def ref_run(rx, seg):
+            rx.sink.clear()
+            out = [rx.rx(seg[k:k + 160]) for k in range(0, len(seg), 160)]
+            return np.concatenate(out), [(int(e["a"]), int(e["c"])) for e in rx.sink.events()]
+
+        def bank_run(bank, seg):
+            out = []
+            ev = []
+            for k in range(0, len(seg), 160):
+                m = min(160, len(seg) - k)
+                fr = np.zeros((n_ch, 160), np.int16)
+                lens = np.zeros(n_ch, np.int32)
+                fr[ch, :m] = seg[k:k + m]
+                lens[ch] = m
+                got = bank.rx_host_var(fr, lens)
+                out.append(got[ch, :m])
+                ev.extend((int(s), int(d)) for _, s, d in bank.events()[ch])
+            return np.concatenate(out), ev
+        whole = ref.SigToneRx(tone_type, mode)
+        probe_run = ref_run(whole, x)
+        if len(probe_run[1]) < 4:
+            continue
+        moved += 1
+        cut = 160*41 + 37
+        want_out, want_ev = probe_run
+        a = ref.SigToneRx(tone_type, mode)
+        o1, e1 = ref_run(a, x[:cut])
+        bank = engine.SigToneRxBank(tone_type, n_ch)
+        assert L.spangpu_sig_tone_rx_import_state(bank.h, ch, a.p) == 0
+        o2, e2 = bank_run(bank, x[cut:])
+        assert np.array_equal(np.concatenate([o1, o2]), want_out) and e1 + e2 == want_ev
+        bank2 = engine.SigToneRxBank(tone_type, n_ch)
+        bank2.set_mode(mode)
+        o1, e1 = bank_run(bank2, x[:cut])
+        b = ref.SigToneRx(tone_type, 0)
+        assert L.spangpu_sig_tone_rx_export_state(bank2.h, ch, b.p) == 0
+        o2, e2 = ref_run(b, x[cut:])
+        assert np.array_equal(np.concatenate([o1, o2]), want_out) and e1 + e2 == want_ev
+        probe = ref.SigToneRx(tone_type, 0)
+        assert L.spangpu_sig_tone_rx_export_state(bank.h, ch, probe.p) == 0
+        assert np.array_equal(whole.snapshot(), probe.snapshot())
+        other = engine.SigToneRxBank(1 if tone_type != 1 else 2, n_ch)
+        assert L.spangpu_sig_tone_rx_import_state(other.h, ch, a.p) < 0
+    assert moved >= 1
