@@ -12,6 +12,7 @@
  *   spangpu_ref_v29_rx_t        struct v29_rx_state_s       src/spandsp/private/v29rx.h:56-226
  *   spangpu_ref_v27ter_rx_t     struct v27ter_rx_state_s    src/spandsp/private/v27ter_rx.h:57-210
  *   spangpu_ref_v17_rx_t        struct v17_rx_state_s       src/spandsp/private/v17rx.h:64-254
+ *   spangpu_ref_super_tone_rx_t struct super_tone_rx_state_s src/spandsp/private/super_tone_rx.h:50-62
  *   spangpu_ref_fsk_rx_t        struct fsk_rx_state_s       src/spandsp/private/fsk.h:58-115
  *   spangpu_ref_mct_rx_t        struct modem_connect_tones_rx_state_s   src/spandsp/private/modem_connect_tones.h:58-112
  *   spangpu_ref_sig_tone_rx_t   struct sig_tone_rx_state_s  src/spandsp/private/sig_tone.h:163-236
@@ -457,6 +458,36 @@ SPANGPU_API int spangpu_mct_export_state(spangpu_mct_t *bank, int channel, spang
 /* The receiver must have the bank's thresholds (that is: its tone type); its mode travels with it. */
 SPANGPU_API int spangpu_sig_tone_rx_import_state(spangpu_sigtone_rx_t *bank, int channel, const spangpu_ref_sig_tone_rx_t *s);
 SPANGPU_API int spangpu_sig_tone_rx_export_state(spangpu_sigtone_rx_t *bank, int channel, spangpu_ref_sig_tone_rx_t *s);
+
+/* ---- super-tone receiver -------------------------------------------------------------------------------------- */
+typedef struct
+{
+    int f1;
+    int f2;
+    int recognition_duration;
+    int min_duration;
+    int max_duration;
+} spangpu_ref_super_tone_rx_segment_t;      /* struct super_tone_rx_segment_s, src/spandsp/private/super_tone_rx.h:29-36 */
+
+typedef struct
+{
+    const void *desc;                       /* the reference's own descriptor: only its bin count is looked at */
+    float energy;
+    int detected_tone;
+    int rotation;
+    span_tone_report_func_t tone_callback;
+    tone_segment_func_t segment_callback;
+    void *callback_data;
+    spangpu_ref_super_tone_rx_segment_t segments[11];
+    spangpu_ref_goertzel_t state[];
+} spangpu_ref_super_tone_rx_t;              /* struct super_tone_rx_state_s, src/spandsp/private/super_tone_rx.h:50-62 */
+
+/* Between a receiver of the reference and a receiver made by this library's super_tone_rx_init() (or attached to a
+   group) on a descriptor built by the same sequence of add_tone / add_element calls: the Goertzel states and the
+   block's energy and position move to / from the channel in HBM, the cadence bookkeeping (the last ten runs, the pair
+   seen last, the tone being followed) to / from the host object. */
+SPANGPU_API int spangpu_super_tone_rx_import_state(super_tone_rx_state_t *s, const spangpu_ref_super_tone_rx_t *ref);
+SPANGPU_API int spangpu_super_tone_rx_export_state(super_tone_rx_state_t *s, spangpu_ref_super_tone_rx_t *ref);
 
 /* sizeof() of the mirror of the reference struct of that name ("dtmf_rx_state_t", "goertzel_state_t",
    "echo_can_state_t", "bell_mf_rx_state_t", "r2_mf_rx_state_t", "v29_rx_state_t", "v27ter_rx_state_t", "v17_rx_state_t", "fsk_rx_state_t", "modem_connect_tones_rx_state_t",

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include "spangpu_spandsp.h"
+#include "spangpu_refstate.h"
 
 #define SUPER_TONE_BINS     128             /* src/spandsp/private/super_tone_rx.h:29 */
 
@@ -1269,6 +1270,107 @@ int super_tone_rx(super_tone_rx_state_t *s, const int16_t amp[], int samples)
     if (stage_any(s->grp, s->private_grp, s->channel, amp, samples) < 0)
         return -1;
     return samples;                                         /* super_tone_rx.c:489 */
+}
+
+/* ---- a super-tone receiver in the reference's struct layout (include/spangpu_refstate.h).  The reference keeps the
+   current run in segments[9], the nine before it in [8] .. [0], and in [10] the pair seen in the last block
+   (super_tone_rx.c:369-409); its Goertzels are driven by goertzel_update(), so their own counters are the block position. */
+static int st_ref_bins(const spangpu_ref_super_tone_rx_t *ref)
+{
+    /* struct super_tone_rx_descriptor_s begins {int used_frequencies; int monitored_frequencies; ...} */
+    return (ref->desc)  ?  ((const int *) ref->desc)[1]  :  -1;
+}
+
+int spangpu_super_tone_rx_import_state(super_tone_rx_state_t *s, const spangpu_ref_super_tone_rx_t *ref)
+{
+    float f[2*SPANGPU_MAX_BINS + 8];
+    int32_t w[4] = {0, 0, 0, 0};
+    int m;
+    int nb;
+    int nsf;
+    int i;
+    int rc;
+
+    if (s == NULL  ||  ref == NULL  ||  s->desc == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    m = s->desc->n_bins;
+    if (m < 2  ||  m > SPANGPU_MAX_BINS  ||  st_ref_bins(ref) != m)
+        return SPANGPU_ERR_BAD_ARG;
+    if ((rc = spangpu_group_flush(s->grp)) < 0)
+        return rc;
+    /* the bank keeps nb >= m bins per channel (the kernel's bin count): v2[nb], v3[nb], energy */
+    if ((nsf = spangpu_bank_get_state(s->grp->bank, s->channel, f, 2*SPANGPU_MAX_BINS + 8, w, 4)) < 0)
+        return nsf;
+    nb = (nsf - 1)/2;
+    if (nb < m)
+        return SPANGPU_ERR_STATE;
+    for (i = 0;  i < m;  i++)
+    {
+        f[i] = ref->state[i].v2;
+        f[nb + i] = ref->state[i].v3;
+    }
+    f[2*nb] = ref->energy;
+    w[0] = ref->state[0].current_sample;
+    w[1] = w[2] = w[3] = 0;
+    if ((rc = spangpu_bank_set_state(s->grp->bank, s->channel, f, nsf, w, 4)) != SPANGPU_OK)
+        return rc;
+    s->head = ST_HISTORY - 1;
+    for (i = 0;  i < ST_HISTORY;  i++)
+    {
+        s->run[i].f1 = ref->segments[i].f1;
+        s->run[i].f2 = ref->segments[i].f2;
+        s->run[i].blocks = ref->segments[i].min_duration;
+    }
+    s->seen_f1 = ref->segments[10].f1;
+    s->seen_f2 = ref->segments[10].f2;
+    s->tone = ref->detected_tone;
+    s->turn = ref->rotation;
+    return SPANGPU_OK;
+}
+
+int spangpu_super_tone_rx_export_state(super_tone_rx_state_t *s, spangpu_ref_super_tone_rx_t *ref)
+{
+    float f[2*SPANGPU_MAX_BINS + 8];
+    int32_t w[4];
+    int m;
+    int nb;
+    int i;
+    int rc;
+
+    if (s == NULL  ||  ref == NULL  ||  s->desc == NULL)
+        return SPANGPU_ERR_BAD_ARG;
+    m = s->desc->n_bins;
+    if (m < 2  ||  m > SPANGPU_MAX_BINS  ||  st_ref_bins(ref) != m)
+        return SPANGPU_ERR_BAD_ARG;
+    if ((rc = spangpu_group_flush(s->grp)) < 0)
+        return rc;
+    if ((rc = spangpu_bank_get_state(s->grp->bank, s->channel, f, 2*SPANGPU_MAX_BINS + 8, w, 4)) < 0)
+        return rc;
+    nb = (rc - 1)/2;
+    if (nb < m)
+        return SPANGPU_ERR_STATE;
+    for (i = 0;  i < m;  i++)
+    {
+        ref->state[i].v2 = f[i];
+        ref->state[i].v3 = f[nb + i];
+        ref->state[i].fac = s->desc->fac[i];
+        ref->state[i].samples = SUPER_TONE_BINS;
+        ref->state[i].current_sample = w[0];
+    }
+    ref->energy = f[2*nb];
+    for (i = 0;  i < ST_HISTORY;  i++)
+    {
+        const st_run_t *r = st_past(s, ST_HISTORY - 1 - i);
+
+        ref->segments[i].f1 = r->f1;
+        ref->segments[i].f2 = r->f2;
+        ref->segments[i].min_duration = (int) r->blocks;
+    }
+    ref->segments[10].f1 = s->seen_f1;
+    ref->segments[10].f2 = s->seen_f2;
+    ref->detected_tone = s->tone;
+    ref->rotation = s->turn;
+    return SPANGPU_OK;
 }
 
 int super_tone_rx_fillin(super_tone_rx_state_t *s, int samples)

@@ -495,3 +495,83 @@ def test_sig_tone_call_changes_sides(libs, tone_type, mode):
         other = engine.SigToneRxBank(1 if tone_type != 1 else 2, n_ch)
         assert L.spangpu_sig_tone_rx_import_state(other.h, ch, a.p) < 0
     assert moved >= 1
+
+
+def test_super_tone_call_changes_sides(libs):
+    """A super-tone receiver: the Goertzel states, the block's energy and position (device side) and the cadence bookkeeping
+    (host side) move between a receiver of the real reference and one made by this library on an equal descriptor."""
+    from oracle import ref
+    from spandsp_amd import engine
+    from test_oracle_pin import build_st_desc, st_signal
+    R, L0 = libs
+    L = C.CDLL(engine.LIB_PATH)
+    vp, ci = C.c_void_p, C.c_int
+    TONE_CB = C.CFUNCTYPE(None, vp, ci, ci, ci)
+    SEG_CB = C.CFUNCTYPE(None, vp, ci, ci, ci)
+    for name, (res, args) in {"super_tone_rx_make_descriptor": (vp, [vp]), "super_tone_rx_free_descriptor": (ci, [vp]),
+                              "super_tone_rx_add_tone": (ci, [vp]), "super_tone_rx_add_element": (ci, [vp, ci, ci, ci, ci, ci]),
+                              "super_tone_rx_init": (vp, [vp, vp, TONE_CB, vp]), "super_tone_rx_free": (ci, [vp]),
+                              "super_tone_rx_segment_callback": (None, [vp, SEG_CB]), "super_tone_rx": (ci, [vp, vp, ci]),
+                              "spangpu_super_tone_rx_import_state": (ci, [vp, vp]),
+                              "spangpu_super_tone_rx_export_state": (ci, [vp, vp])}.items():
+        getattr(L, name).restype = res
+        getattr(L, name).argtypes = args
+    desc = L.super_tone_rx_make_descriptor(None)
+
+    class D:
+        def add_tone(self):
+            return L.super_tone_rx_add_tone(desc)
+
+        def add_element(self, *a):
+            return L.super_tone_rx_add_element(desc, *a)
+    build_st_desc(D)
+    rdesc = build_st_desc(ref.SuperToneDesc)
+    x = st_signal()
+
+    def ref_events(rx, seg):
+        rx.sink.clear()
+        for k in range(0, len(seg), 160):
+            rx.rx(seg[k:k + 160])
+        return [tuple(int(v) for v in e) for e in rx.sink.events()]
+
+    class Shim:
+        def __init__(self):
+            self.ev = []
+            self.tcb = TONE_CB(lambda ud, code, level, delay: self.ev.append((1, code, level, delay)))
+            self.scb = SEG_CB(lambda ud, f1, f2, dur: self.ev.append((4, f1, f2, dur)))
+            self.s = L.super_tone_rx_init(None, desc, self.tcb, None)
+            assert self.s
+            L.super_tone_rx_segment_callback(self.s, self.scb)
+
+        def run(self, seg):
+            self.ev = []
+            for k in range(0, len(seg), 160):
+                fr = np.ascontiguousarray(seg[k:k + 160])
+                assert L.super_tone_rx(self.s, fr.ctypes.data, len(fr)) == len(fr)
+            return list(self.ev)
+    whole = ref.SuperToneRx(rdesc, True)
+    want = ref_events(whole, x)
+    assert len(want) >= 20
+    for cut in (160*61 + 45, 160*300 + 3, 160*520 + 127):
+        assert cut + 1000 < len(x)
+        a = ref.SuperToneRx(rdesc, True)
+        first = ref_events(a, x[:cut])
+        sh = Shim()
+        assert L.spangpu_super_tone_rx_import_state(sh.s, a.p) == 0
+        assert first + sh.run(x[cut:]) == want, cut
+        sh2 = Shim()
+        first2 = sh2.run(x[:cut])
+        b = ref.SuperToneRx(rdesc, True)
+        assert L.spangpu_super_tone_rx_export_state(sh2.s, b.p) == 0
+        assert first2 + ref_events(b, x[cut:]) == want, cut
+        L.super_tone_rx_free(sh.s)
+        L.super_tone_rx_free(sh2.s)
+    # a receiver on another descriptor (another number of monitored frequencies) is refused
+    small = ref.SuperToneDesc()
+    t = small.add_tone()
+    small.add_element(t, 400, 0, 700, 0)
+    small.add_element(t, 620, 0, 700, 0)
+    other = ref.SuperToneRx(small, True)
+    sh = Shim()
+    assert L.spangpu_super_tone_rx_import_state(sh.s, other.p) < 0
+    L.super_tone_rx_free(sh.s)
