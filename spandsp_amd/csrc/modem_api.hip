@@ -489,7 +489,12 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         if (m->qam_tap)
             hipLaunchKernelGGL((v29_bank_kernel<16, true>), dim3((m->n_ch + 15)/16), dim3(64), 0, m->stream, L);
         else if (cpw == 64)
-            hipLaunchKernelGGL(v29_bank_kernel<64>, grid, dim3(64), 0, m->stream, L);
+        {
+            // full waves: four to a workgroup, sharing the tables, the RRC delay line as packed int16 pairs -- 150 KB of
+            // LDS per workgroup, one workgroup per CU, a wave on every SIMD (v29_dev.hpp)
+            const int waves = (m->n_ch + 63)/64;
+            hipLaunchKernelGGL((v29_bank_kernel<64, false, 4, 16, true>), dim3((waves + 3)/4), dim3(256), 0, m->stream, L);
+        }
         else if (cpw == 32)
             hipLaunchKernelGGL(v29_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
         else
@@ -543,7 +548,10 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         if (m->qam_tap)
             hipLaunchKernelGGL((v27ter_bank_kernel<16, true>), dim3((m->n_ch + 15)/16), dim3(64), 0, m->stream, L);
         else if (cpw == 64)
-            hipLaunchKernelGGL(v27ter_bank_kernel<64>, grid, dim3(64), 0, m->stream, L);
+        {
+            const int waves = (m->n_ch + 63)/64;
+            hipLaunchKernelGGL((v27ter_bank_kernel<64, false, 4, 16, true>), dim3((waves + 3)/4), dim3(256), 0, m->stream, L);
+        }
         else if (cpw == 32)
             hipLaunchKernelGGL(v27ter_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
         else

@@ -142,7 +142,10 @@ void v17_bank_kernel(const V17Launch L)
     const int mylen = L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;
     auto ldf = [&](int w) { return __uint_as_float(L.state[(size_t) w*N + ch]); };
     auto ldi = [&](int w) { return (int32_t) L.state[(size_t) (kV17Floats + w)*N + ch]; };
-    auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
+    // A float word goes back as its bits -- except a NaN (a receiver whose equaliser has run away is full of them), which
+    // goes back as x86's: there an invalid operation makes the negative quiet NaN and arithmetic hands an operand's NaN on
+    // sign and all, while here the negated operand of a subtraction flips it.  Nothing ever depends on a NaN's sign.
+    auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = (v != v)  ?  0xFFC00000u  :  __float_as_uint(v); };
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV17Floats + w)*N + ch] = (uint32_t) v; };
 
     float2 *rrc2 = &lanes[lane];                        // [2*27] pairs, stride CPW

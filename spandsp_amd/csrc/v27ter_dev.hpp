@@ -76,22 +76,30 @@ struct V27Launch
     const V27Tables *tab;
 };
 
-template <int CPW, bool QAM = false>
-__global__ __launch_bounds__(64)
+// WPB, TILE, PK16: several waves per workgroup sharing the tables, a short PCM tile and the RRC delay line as packed
+// int16 pairs, for banks of full waves -- see v29_bank_kernel.
+template <int CPW, bool QAM = false, int WPB = 1, int TILE = kPcmTile, bool PK16 = false>
+__global__ __launch_bounds__(64*WPB)
 void v27ter_bank_kernel(const V27Launch L)
 {
+    static_assert(WPB == 1  ||  CPW == 64, "several waves per workgroup: full waves only");
+    static_assert(TILE%8 == 0  &&  TILE >= 8, "the PCM tile is staged in 16-byte pieces");
     __shared__ float t_rrc_re[kV27MaxSets*kRrcLen];     // [tap][set]
     __shared__ float t_rrc_im[kV27MaxSets*kRrcLen];
     __shared__ float t_sine[2048];
     __shared__ uint16_t t_sqrt[194];
     // per-lane RRC delay line (doubled) and PCM tile, index-major [word][CPW]; equaliser taps {re, im} [tap][lane]
     // RRC delay line as zero padded pairs, see v29_dev.hpp
-    __shared__ float2 lanes[CPW*2*kRrcLen];
-    __shared__ uint32_t pcm[CPW*(kPcmTile/2)];
-    __shared__ float2 taps[kV27EqLen*CPW];
+    __shared__ float2 lanes[PK16  ?  1  :  WPB*CPW*2*kRrcLen];
+    __shared__ uint32_t lanes16[PK16  ?  WPB*CPW*2*kRrcLen  :  1];
+    __shared__ uint32_t pcm[WPB*CPW*(TILE/2)];
+    __shared__ float2 taps[WPB*kV27EqLen*CPW];
 
-    const int lane = threadIdx.x;
-    const int ch = blockIdx.x*CPW + lane;
+    const int lane = threadIdx.x & 63;
+    const int wv = (WPB == 1)  ?  0  :  (int) (threadIdx.x >> 6);
+    const int ch = (blockIdx.x*WPB + wv)*CPW + lane;
+    constexpr int kThreads = 64*WPB;
+    const int tid = threadIdx.x;
     const V27Tables &TB = *L.tab;
     const bool fast = (L.bit_rate == 4800);
     const int sets = fast  ?  8  :  12;
@@ -100,7 +108,7 @@ void v27ter_bank_kernel(const V27Launch L)
     {
         const float *sre = fast  ?  TB.re4800  :  TB.re2400;
         const float *sim = fast  ?  TB.im4800  :  TB.im2400;
-        for (int i = lane;  i < sets*kRrcLen;  i += 64)
+        for (int i = tid;  i < sets*kRrcLen;  i += kThreads)
         {
             const int set = i/kRrcLen;
             const int tap = i - set*kRrcLen;
@@ -108,9 +116,9 @@ void v27ter_bank_kernel(const V27Launch L)
             t_rrc_im[tap*kV27MaxSets + set] = sim[i];
         }
     }
-    for (int i = lane;  i < 2048;  i += 64)
+    for (int i = tid;  i < 2048;  i += kThreads)
         t_sine[i] = TB.sine[i];
-    for (int i = lane;  i < 194;  i += 64)
+    for (int i = tid;  i < 194;  i += kThreads)
         t_sqrt[i] = TB.sqrt_tab[i];
     __syncthreads();
     if (lane >= CPW  ||  ch >= L.n_ch)
@@ -120,12 +128,36 @@ void v27ter_bank_kernel(const V27Launch L)
     const int mylen = L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;
     auto ldf = [&](int w) { return __uint_as_float(L.state[(size_t) w*N + ch]); };
     auto ldi = [&](int w) { return (int32_t) L.state[(size_t) (kV27Floats + w)*N + ch]; };
-    auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
+    // A float word goes back as its bits -- except a NaN (a receiver whose equaliser has run away is full of them), which
+    // goes back as x86's: there an invalid operation makes the negative quiet NaN and arithmetic hands an operand's NaN on
+    // sign and all, while here the negated operand of a subtraction flips it.  Nothing ever depends on a NaN's sign.
+    auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = (v != v)  ?  0xFFC00000u  :  __float_as_uint(v); };
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV27Floats + w)*N + ch] = (uint32_t) v; };
 
-    float2 *rrc2 = &lanes[lane];                        // [2*27] pairs, stride CPW
-#define RRC2(k)     rrc2[(k)*CPW]
-    float2 *ctap = &taps[lane];
+    float2 *rrc2 = &lanes[PK16  ?  0  :  (wv*CPW*2*kRrcLen + lane)];           // [2*27] pairs, stride CPW
+    uint32_t *rrc16 = &lanes16[PK16  ?  (wv*CPW*2*kRrcLen + lane)  :  0];
+    uint32_t *pcmw = &pcm[wv*CPW*(TILE/2)];
+    auto rrc_put = [&](int k, float v)
+    {
+        if (PK16)
+        {
+            const uint32_t h = (uint32_t) (int) v & 0xFFFFu;
+            rrc16[k*CPW] = h;
+            rrc16[(kRrcLen + k)*CPW] = h << 16;
+        }
+        else
+        {
+            rrc2[k*CPW].x = v;
+            rrc2[(kRrcLen + k)*CPW].y = v;
+        }
+    };
+    auto rrc_at = [&](int k) -> float
+    {
+        if (PK16)
+            return (float) (int) (short) (rrc16[k*CPW] & 0xFFFFu);
+        return rrc2[k*CPW].x;
+    };
+    float2 *ctap = &taps[wv*kV27EqLen*CPW + lane];
 #define TAP(i)      ctap[(i)*CPW]
     constexpr int EQN = kV27EqLen;
 
@@ -138,8 +170,12 @@ void v27ter_bank_kernel(const V27Launch L)
     for (int i = 0;  i < kRrcLen;  i++)
     {
         const float v = ldf(WF_RRC + i);
-        RRC2(i) = make_float2(v, 0.0f);
-        RRC2(kRrcLen + i) = make_float2(0.0f, v);
+        if (!PK16)
+        {
+            rrc2[i*CPW] = make_float2(v, 0.0f);
+            rrc2[(kRrcLen + i)*CPW] = make_float2(0.0f, v);
+        }
+        rrc_put(i, v);
     }
     for (int i = 0;  i < EQN;  i++)
         TAP(i) = make_float2(ldf(WF_EQ_COEFF + 2*i), ldf(WF_EQ_COEFF + 2*i + 1));
@@ -223,7 +259,12 @@ void v27ter_bank_kernel(const V27Launch L)
     auto restart = [&]()
     {
         for (int i = 0;  i < 2*kRrcLen;  i++)
-            RRC2(i) = make_float2(0.0f, 0.0f);
+        {
+            if (PK16)
+                rrc16[i*CPW] = 0;
+            else
+                rrc2[i*CPW] = make_float2(0.0f, 0.0f);
+        }
         training_error = 0.0f;
         rrc_step = 0;
         scramble_reg = 0x3C;
@@ -263,13 +304,22 @@ void v27ter_bank_kernel(const V27Launch L)
     {
         const float *y = table + row;
         const float2 *x = rrc2 + rrc_step*CPW;
+        const uint32_t *xq = rrc16 + rrc_step*CPW;
         f32x2v xs[kRrcLen];
         float ys[kRrcLen];
 #pragma unroll
         for (int i = 0;  i < kRrcLen;  i++)
         {
-            const float2 w = x[i*CPW];
-            xs[i] = (f32x2v) {w.x, w.y};
+            if (PK16)
+            {
+                const uint32_t q = xq[i*CPW];
+                xs[i] = (f32x2v) {(float) (int) (short) (q & 0xFFFFu), (float) ((int) q >> 16)};
+            }
+            else
+            {
+                const float2 w = x[i*CPW];
+                xs[i] = (f32x2v) {w.x, w.y};
+            }
             ys[i] = y[i*kV27MaxSets];
         }
         f32x2v a = {0.0f, 0.0f};
@@ -401,23 +451,23 @@ void v27ter_bank_kernel(const V27Launch L)
     };
 
     const int16_t *src = L.amp + (size_t) ch*L.stride;
-    for (int tile = 0;  tile < L.samples;  tile += kPcmTile)
+    for (int tile = 0;  tile < L.samples;  tile += TILE)
     {
-    const int tn = max(0, min(kPcmTile, mylen - tile));         // per lane when the call carries per-channel lengths
+    const int tn = max(0, min(TILE, mylen - tile));         // per lane when the call carries per-channel lengths
     // ---- stage this lane's stretch of PCM: pcm[k][lane] = samples 2k, 2k+1 of the tile ----------------------
     {
         const int16_t *row = src + tile;
-        const bool wide = ((((uintptr_t) row) & 15) == 0)  &&  (tn == kPcmTile);
+        const bool wide = ((((uintptr_t) row) & 15) == 0)  &&  (tn == TILE);
         if (wide)
         {
 #pragma unroll
-            for (int k = 0;  k < kPcmTile/8;  k++)
+            for (int k = 0;  k < TILE/8;  k++)
             {
                 const int4 v = ((const int4 *) row)[k];
-                pcm[(4*k + 0)*CPW + lane] = (uint32_t) v.x;
-                pcm[(4*k + 1)*CPW + lane] = (uint32_t) v.y;
-                pcm[(4*k + 2)*CPW + lane] = (uint32_t) v.z;
-                pcm[(4*k + 3)*CPW + lane] = (uint32_t) v.w;
+                pcmw[(4*k + 0)*CPW + lane] = (uint32_t) v.x;
+                pcmw[(4*k + 1)*CPW + lane] = (uint32_t) v.y;
+                pcmw[(4*k + 2)*CPW + lane] = (uint32_t) v.z;
+                pcmw[(4*k + 3)*CPW + lane] = (uint32_t) v.w;
             }
         }
         else
@@ -426,7 +476,7 @@ void v27ter_bank_kernel(const V27Launch L)
             {
                 const uint32_t lo = (uint16_t) row[2*k];
                 const uint32_t hi = (2*k + 1 < tn)  ?  (uint16_t) row[2*k + 1]  :  0u;
-                pcm[k*CPW + lane] = lo | (hi << 16);
+                pcmw[k*CPW + lane] = lo | (hi << 16);
             }
         }
     }
@@ -449,13 +499,12 @@ void v27ter_bank_kernel(const V27Launch L)
     {
     if (take  &&  !ready  &&  !restart_pending  &&  pos < tn)
     {
-        const uint32_t pw = pcm[(pos >> 1)*CPW + lane];
+        const uint32_t pw = pcmw[(pos >> 1)*CPW + lane];
         const int amp = (int) (short) ((pos & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
         pos++;
         do
         {
-        RRC2(rrc_step).x = (float) amp;
-        RRC2(rrc_step + kRrcLen).y = (float) amp;
+        rrc_put(rrc_step, (float) amp);
         if (++rrc_step >= kRrcLen)
             rrc_step = 0;
 
@@ -820,7 +869,7 @@ void v27ter_bank_kernel(const V27Launch L)
     stf(WF_TRACK_P, carrier_track_p);
     stf(WF_TRACK_I, carrier_track_i);
     for (int i = 0;  i < kRrcLen;  i++)
-        stf(WF_RRC + i, RRC2(i).x);
+        stf(WF_RRC + i, rrc_at(i));
     for (int i = 0;  i < EQN;  i++)
     {
         const float2 c = TAP(i);

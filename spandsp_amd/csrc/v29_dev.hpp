@@ -205,10 +205,17 @@ __device__ __forceinline__ int32_t v29_arctan2(float y, float x)
 
 // CPW = channels per workgroup (one wavefront): 64 when the bank is big enough to fill every SIMD of the chip with
 // full waves, fewer (idle upper lanes) for small banks so that the channels still spread over all 1024 SIMDs.
-template <int CPW, bool QAM = false>
-__global__ __launch_bounds__(64)
+// WPB waves per workgroup share the tables (WPB > 1 goes with CPW = 64); TILE = samples of PCM staged per lane at a
+// time; PK16: the RRC delay line -- raw 16 bit samples -- is kept as packed pairs of int16 and converted on the way to
+// the multipliers.  A full wave's per-lane LDS is then 13.8 KB (delay line) + 16.9 KB (equaliser taps) + the PCM tile
+// instead of 27.6 + 16.9 + 10 KB: with four waves sharing 19.5 KB of tables a CU holds four waves, one per SIMD, where
+// the one-wave workgroups of 74 KB left two SIMDs of every CU empty on banks of 64 K channels and more.
+template <int CPW, bool QAM = false, int WPB = 1, int TILE = kPcmTile, bool PK16 = false>
+__global__ __launch_bounds__(64*WPB)
 void v29_bank_kernel(const V29Launch L)
 {
+    static_assert(WPB == 1  ||  CPW == 64, "several waves per workgroup: full waves only");
+    static_assert(TILE%8 == 0  &&  TILE >= 8, "the PCM tile is staged in 16-byte pieces");
     // coefficient tables transposed to [tap][set]: lanes on different polyphase sets hit different banks
     __shared__ float t_rrc_re[kRrcSets*kRrcLen];
     __shared__ float t_rrc_im[kRrcSets*kRrcLen];
@@ -220,36 +227,40 @@ void v29_bank_kernel(const V29Launch L)
     // whatever its position.  The delay line is stored as 2*27 pairs: pair k < 27 is {x[k], 0}, pair 27 + k is
     // {0, x[k]} -- the window of 27 pairs starting at the circular position then holds, in .x, the head part of
     // vec_circular_dot_prodf()'s sum padded with zeros and, in .y, zeros followed by its wrapped part.
-    __shared__ float2 lanes[CPW*2*kRrcLen];
-    __shared__ uint32_t pcm[CPW*(kPcmTile/2)];
+    __shared__ float2 lanes[PK16  ?  1  :  WPB*CPW*2*kRrcLen];
+    __shared__ uint32_t lanes16[PK16  ?  WPB*CPW*2*kRrcLen  :  1];     // PK16: pair k = x[k] | 0 << 16, pair 27 + k = 0 | x[k] << 16
+    __shared__ uint32_t pcm[WPB*CPW*(TILE/2)];
     // equaliser taps {re, im}, [tap][lane]: always indexed by a compile-time tap number
-    __shared__ float2 taps[kEqLen*CPW];
+    __shared__ float2 taps[WPB*kEqLen*CPW];
 
-    const int lane = threadIdx.x;
-    const int ch = blockIdx.x*CPW + lane;
+    const int lane = threadIdx.x & 63;
+    const int wv = (WPB == 1)  ?  0  :  (int) (threadIdx.x >> 6);
+    const int ch = (blockIdx.x*WPB + wv)*CPW + lane;
     const V29Tables &TB = *L.tab;
+    constexpr int kThreads = 64*WPB;
+    const int tid = threadIdx.x;
 
     // ---- tables -> LDS ----------------------------------------------------------------------
-    for (int i = lane;  i < kRrcSets*kRrcLen;  i += 64)
+    for (int i = tid;  i < kRrcSets*kRrcLen;  i += kThreads)
     {
         const int set = i/kRrcLen;
         const int tap = i - set*kRrcLen;
         t_rrc_re[tap*kRrcSets + set] = TB.rrc_re[i];
         t_rrc_im[tap*kRrcSets + set] = TB.rrc_im[i];
     }
-    for (int i = lane;  i < 2048;  i += 64)
+    for (int i = tid;  i < 2048;  i += kThreads)
         t_sine[i] = TB.sine[i];
-    for (int i = lane;  i < 194;  i += 64)
+    for (int i = tid;  i < 194;  i += kThreads)
         t_sqrt[i] = TB.sqrt_tab[i];
-    for (int i = lane;  i < 400;  i += 64)
+    for (int i = tid;  i < 400;  i += kThreads)
         t_map[i] = TB.space_map[i];
-    if (lane < 16)
+    if (tid < 16)
     {
         // v29tx_constellation_maps.h:58-77
         const float re[16] = {3, 1, 0, -1, -3, -1, 0, 1, 5, 3, 0, -3, -5, -3, 0, 3};
         const float im[16] = {0, 1, 3, 1, 0, -1, -3, -1, 0, 3, 5, 3, 0, -3, -5, -3};
-        t_const[2*lane] = re[lane];
-        t_const[2*lane + 1] = im[lane];
+        t_const[2*tid] = re[tid];
+        t_const[2*tid + 1] = im[tid];
     }
     const float g0 = TB.godard[0];
     const float g1 = TB.godard[1];
@@ -271,11 +282,36 @@ void v29_bank_kernel(const V29Launch L)
     const int mylen = L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;
     auto ldf = [&](int w) { return __uint_as_float(L.state[(size_t) w*N + ch]); };
     auto ldi = [&](int w) { return (int32_t) L.state[(size_t) (kV29Floats + w)*N + ch]; };
-    auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = __float_as_uint(v); };
+    // A float word goes back as its bits -- except a NaN (a receiver whose equaliser has run away is full of them), which
+    // goes back as x86's: there an invalid operation makes the negative quiet NaN and arithmetic hands an operand's NaN on
+    // sign and all, while here the negated operand of a subtraction flips it.  Nothing ever depends on a NaN's sign.
+    auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = (v != v)  ?  0xFFC00000u  :  __float_as_uint(v); };
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV29Floats + w)*N + ch] = (uint32_t) v; };
 
-    float2 *rrc2 = &lanes[lane];                        // [2*27] pairs, stride CPW
-#define RRC2(k)     rrc2[(k)*CPW]
+    float2 *rrc2 = &lanes[PK16  ?  0  :  (wv*CPW*2*kRrcLen + lane)];           // [2*27] pairs, stride CPW
+    uint32_t *rrc16 = &lanes16[PK16  ?  (wv*CPW*2*kRrcLen + lane)  :  0];
+    uint32_t *pcmw = &pcm[wv*CPW*(TILE/2)];
+    // delay line element k <- v (both of its pairs); the element back as a float
+    auto rrc_put = [&](int k, float v)
+    {
+        if (PK16)
+        {
+            const uint32_t h = (uint32_t) (int) v & 0xFFFFu;
+            rrc16[k*CPW] = h;
+            rrc16[(kRrcLen + k)*CPW] = h << 16;
+        }
+        else
+        {
+            rrc2[k*CPW].x = v;
+            rrc2[(kRrcLen + k)*CPW].y = v;
+        }
+    };
+    auto rrc_at = [&](int k) -> float
+    {
+        if (PK16)
+            return (float) (int) (short) (rrc16[k*CPW] & 0xFFFFu);
+        return rrc2[k*CPW].x;
+    };
 
     float agc_scaling = ldf(VF_AGC);
     float agc_scaling_save = ldf(VF_AGC_SAVE);
@@ -293,10 +329,14 @@ void v29_bank_kernel(const V29Launch L)
     for (int i = 0;  i < kRrcLen;  i++)
     {
         const float v = ldf(VF_RRC + i);
-        RRC2(i) = make_float2(v, 0.0f);
-        RRC2(kRrcLen + i) = make_float2(0.0f, v);
+        if (!PK16)
+        {
+            rrc2[i*CPW] = make_float2(v, 0.0f);
+            rrc2[(kRrcLen + i)*CPW] = make_float2(0.0f, v);
+        }
+        rrc_put(i, v);
     }
-    float2 *ctap = &taps[lane];
+    float2 *ctap = &taps[wv*kEqLen*CPW + lane];
 #define TAP(i)      ctap[(i)*CPW]
     for (int i = 0;  i < kEqLen;  i++)
         TAP(i) = make_float2(ldf(VF_EQ_COEFF + 2*i), ldf(VF_EQ_COEFF + 2*i + 1));
@@ -382,7 +422,12 @@ void v29_bank_kernel(const V29Launch L)
     auto restart = [&]()
     {
         for (int i = 0;  i < 2*kRrcLen;  i++)
-            RRC2(i) = make_float2(0.0f, 0.0f);
+        {
+            if (PK16)
+                rrc16[i*CPW] = 0;
+            else
+                rrc2[i*CPW] = make_float2(0.0f, 0.0f);
+        }
         rrc_step = 0;
         scramble_reg = 0;
         training_scramble_reg = 0x2A;
@@ -424,6 +469,7 @@ void v29_bank_kernel(const V29Launch L)
     {
         const float *y = table + row;
         const float2 *x = rrc2 + rrc_step*CPW;
+        const uint32_t *xq = rrc16 + rrc_step*CPW;
         // the LDS reads go out nine taps at a time, ahead of that group's part of the summation chain: all 54 at once
         // kept 81 registers live across a kernel that already overflows into AGPRs
         f32x2v a = {0.0f, 0.0f};
@@ -435,8 +481,16 @@ void v29_bank_kernel(const V29Launch L)
 #pragma unroll
             for (int i = 0;  i < 9;  i++)
             {
-                const float2 w = x[(i0 + i)*CPW];
-                xs[i] = (f32x2v) {w.x, w.y};
+                if (PK16)
+                {
+                    const uint32_t q = xq[(i0 + i)*CPW];
+                    xs[i] = (f32x2v) {(float) (int) (short) (q & 0xFFFFu), (float) ((int) q >> 16)};
+                }
+                else
+                {
+                    const float2 w = x[(i0 + i)*CPW];
+                    xs[i] = (f32x2v) {w.x, w.y};
+                }
                 ys[i] = y[(i0 + i)*kRrcSets];
             }
             // .x: x[pos..n) . y[0..n-pos) then + 0*y (exact: a running sum that starts at +0 is never -0);
@@ -538,23 +592,23 @@ void v29_bank_kernel(const V29Launch L)
     };
 
     const int16_t *src = L.amp + (size_t) ch*L.stride;
-    for (int tile = 0;  tile < L.samples;  tile += kPcmTile)
+    for (int tile = 0;  tile < L.samples;  tile += TILE)
     {
-    const int tn = max(0, min(kPcmTile, mylen - tile));         // per lane when the call carries per-channel lengths
+    const int tn = max(0, min(TILE, mylen - tile));         // per lane when the call carries per-channel lengths
     // ---- stage this lane's stretch of PCM: pcm[k][lane] = samples 2k, 2k+1 of the tile ----------------------
     {
         const int16_t *row = src + tile;
-        const bool wide = ((((uintptr_t) row) & 15) == 0)  &&  (tn == kPcmTile);
+        const bool wide = ((((uintptr_t) row) & 15) == 0)  &&  (tn == TILE);
         if (wide)
         {
 #pragma unroll
-            for (int k = 0;  k < kPcmTile/8;  k++)
+            for (int k = 0;  k < TILE/8;  k++)
             {
                 const int4 v = ((const int4 *) row)[k];
-                pcm[(4*k + 0)*CPW + lane] = (uint32_t) v.x;
-                pcm[(4*k + 1)*CPW + lane] = (uint32_t) v.y;
-                pcm[(4*k + 2)*CPW + lane] = (uint32_t) v.z;
-                pcm[(4*k + 3)*CPW + lane] = (uint32_t) v.w;
+                pcmw[(4*k + 0)*CPW + lane] = (uint32_t) v.x;
+                pcmw[(4*k + 1)*CPW + lane] = (uint32_t) v.y;
+                pcmw[(4*k + 2)*CPW + lane] = (uint32_t) v.z;
+                pcmw[(4*k + 3)*CPW + lane] = (uint32_t) v.w;
             }
         }
         else
@@ -563,7 +617,7 @@ void v29_bank_kernel(const V29Launch L)
             {
                 const uint32_t lo = (uint16_t) row[2*k];
                 const uint32_t hi = (2*k + 1 < tn)  ?  (uint16_t) row[2*k + 1]  :  0u;
-                pcm[k*CPW + lane] = lo | (hi << 16);
+                pcmw[k*CPW + lane] = lo | (hi << 16);
             }
         }
     }
@@ -589,14 +643,13 @@ void v29_bank_kernel(const V29Launch L)
     {
     if (take  &&  !ready  &&  !restart_pending  &&  pos < tn)
     {
-        const uint32_t pw = pcm[(pos >> 1)*CPW + lane];
+        const uint32_t pw = pcmw[(pos >> 1)*CPW + lane];
         const int amp = (int) (short) ((pos & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
         pos++;
         do
         {
         // ---- v29_rx(), v29rx.c:885-961 --------------------------------------------------------
-        RRC2(rrc_step).x = (float) amp;
-        RRC2(rrc_step + kRrcLen).y = (float) amp;
+        rrc_put(rrc_step, (float) amp);
         if (++rrc_step >= kRrcLen)
             rrc_step = 0;
 
@@ -1021,7 +1074,7 @@ void v29_bank_kernel(const V29Launch L)
         stf(VF_GDC + 1, gdc1);
         stf(VF_BAUD_PHASE, baud_phase);
         for (int i = 0;  i < kRrcLen;  i++)
-            stf(VF_RRC + i, RRC2(i).x);
+            stf(VF_RRC + i, rrc_at(i));
         for (int i = 0;  i < kEqLen;  i++)
         {
             const float2 c = TAP(i);

@@ -47,6 +47,80 @@ def test_v29_16384_channels(built):
     bank.close()
 
 
+def test_v29_full_wave_kernel_65797_channels(built):
+    """Banks of 64 K channels and more run the full-wave kernel (four waves per workgroup sharing the tables, the RRC delay
+    line as packed int16 pairs): a bank that does not fill its last workgroup nor its last wave, every channel against
+    the oracle's run of its line, events of every frame and the state at the end."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    from test_v29_gpu import channel_signals
+    use_golden_modem_tables()
+    n_ch, V, n_frames = 65536 + 64*4 + 5, 61, 24
+    base = channel_signals(9600, V, seed=78)[:, :n_frames*160]
+    pick = (np.arange(n_ch)*7) % V
+    sig = base[pick]
+    bank = engine.V29Bank(n_ch, 9600)
+    want = []
+    for c in range(V):
+        o = orc.V29(9600)
+        per = []
+        for k in range(n_frames):
+            o.sink.clear()
+            o.rx(base[c, k*160:(k + 1)*160])
+            per.append(o.sink.events()["a"].astype(np.int8))
+        want.append((per, o.snapshot()))
+    total = 0
+    for k in range(n_frames):
+        bank.rx_host(sig[:, k*160:(k + 1)*160])
+        ev = bank.events()
+        for c in range(n_ch):
+            assert np.array_equal(ev[c], want[pick[c]][0][k]), (k, c)
+        total += sum(len(e) for e in ev[:V])
+    assert total > 100*V
+    for c in list(range(0, n_ch, 509)) + [65535, 65536, n_ch - 6, n_ch - 1]:
+        f, w = bank.get_state(c)
+        fo, wo = want[pick[c]][1]
+        assert np.array_equal(w, wo), c
+        assert np.array_equal(bits(f), bits(fo)), c
+
+
+@pytest.mark.parametrize("bit_rate", [4800, 2400])
+def test_v27ter_full_wave_kernel_65700_channels(built, bit_rate):
+    """The same for V.27ter (both rates: their pulse shaping tables differ in size): the full-wave kernel on a bank that
+    fills neither its last workgroup nor its last wave."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    from test_v27ter_gpu import channel_signals
+    use_golden_modem_tables()
+    n_ch, V, n_frames = 65536 + 64*2 + 36, 47, (48 if bit_rate == 4800 else 58)      # the training (0.7 s / 0.94 s) and some data
+    base = channel_signals(bit_rate, V, seed=79)[:, :n_frames*160]
+    pick = (np.arange(n_ch)*5) % V
+    sig = base[pick]
+    bank = engine.V27terBank(n_ch, bit_rate)
+    want = []
+    for c in range(V):
+        o = orc.V27ter(bit_rate)
+        per = []
+        for k in range(n_frames):
+            o.sink.clear()
+            o.rx(base[c, k*160:(k + 1)*160])
+            per.append(o.sink.events()["a"].astype(np.int8))
+        want.append((per, o.snapshot()))
+    total = 0
+    for k in range(n_frames):
+        bank.rx_host(sig[:, k*160:(k + 1)*160])
+        ev = bank.events()
+        for c in range(n_ch):
+            assert np.array_equal(ev[c], want[pick[c]][0][k]), (k, c)
+        total += sum(len(e) for e in ev[:V])
+    assert total > 30*V
+    for c in list(range(0, n_ch, 997)) + [65535, 65536, n_ch - 37, n_ch - 1]:
+        f, w = bank.get_state(c)
+        fo, wo = want[pick[c]][1]
+        assert np.array_equal(w, wo), c
+        assert np.array_equal(bits(f), bits(fo)), c
+
+
 def test_mixed_banks_131072_channels(built):
     """configs[2]: Bell MF + R2 MF + super-tone, 131 072 channels in all."""
     from oracle import restated as orc
