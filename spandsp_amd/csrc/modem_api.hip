@@ -521,7 +521,10 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         if (m->qam_tap)
             hipLaunchKernelGGL((v17_bank_kernel<16, true>), dim3((m->n_ch + 15)/16), dim3(64), 0, m->stream, L);
         else if (cpw == 64)
-            hipLaunchKernelGGL(v17_bank_kernel<64>, grid, dim3(64), 0, m->stream, L);
+        {
+            const int waves = (m->n_ch + 63)/64;
+            hipLaunchKernelGGL((v17_bank_kernel<64, false, 3, 16, true>), dim3((waves + 2)/3), dim3(192), 0, m->stream, L);
+        }
         else if (cpw == 32)
             hipLaunchKernelGGL(v17_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
         else

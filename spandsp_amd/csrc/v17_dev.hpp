@@ -86,36 +86,45 @@ struct V17Launch
 // DDS_PHASE(), spandsp/dds.h:32 (float arithmetic)
 #define V17_DDS_PHASE(deg)  ((int32_t) ((uint32_t) ((((deg) < 0.0f)  ?  (360.0f + (deg))  :  (deg))*65536.0f*65536.0f/360.0f)))
 
-template <int CPW, bool QAM = false>
-__global__ __launch_bounds__(64)
+// WPB, TILE, PK16: several waves per workgroup sharing the tables, a short PCM tile and the RRC delay line as packed
+// int16 pairs, for banks of full waves -- see v29_bank_kernel.  With the survivor memory a V.17 wave needs 45 KB of its
+// own: three of them and the 20 KB of tables fill a CU (155 KB), where the one-wave workgroups of 81 KB put two on it.
+template <int CPW, bool QAM = false, int WPB = 1, int TILE = 0, bool PK16 = false>
+__global__ __launch_bounds__(64*WPB)
 void v17_bank_kernel(const V17Launch L)
 {
+    static_assert(WPB == 1  ||  CPW == 64, "several waves per workgroup: full waves only");
     __shared__ float t_sine[2048];
     __shared__ float t_con[256];
     __shared__ uint32_t t_map[36*36*2];
     __shared__ uint16_t t_sqrt[194];
     // per-lane RRC delay line (doubled) + survivor memory, PCM tile, equaliser taps: all index-major [word][CPW]
     // (the RRC delay line as zero padded pairs, see v29_dev.hpp)
-    __shared__ float2 lanes[CPW*2*kRrcLen];
-    __shared__ uint32_t surv[CPW*(16 + 32)];
+    __shared__ float2 lanes[PK16  ?  1  :  WPB*CPW*2*kRrcLen];
+    __shared__ uint32_t lanes16[PK16  ?  WPB*CPW*2*kRrcLen  :  1];
+    __shared__ uint32_t surv[WPB*CPW*(16 + 32)];
     // (a full wave's LDS must stay under half a CU's 160 KB so that two waves share a CU: shorter PCM tile there)
-    constexpr int kTile = (CPW == 64)  ?  32  :  kPcmTile;
-    __shared__ uint32_t pcm[CPW*(kTile/2)];
-    __shared__ float2 taps[kEqLen*CPW];
+    constexpr int kTile = (TILE > 0)  ?  TILE  :  (CPW == 64)  ?  32  :  kPcmTile;
+    static_assert(kTile%8 == 0, "the PCM tile is staged in 16-byte pieces");
+    __shared__ uint32_t pcm[WPB*CPW*(kTile/2)];
+    __shared__ float2 taps[WPB*kEqLen*CPW];
 
-    const int lane = threadIdx.x;
-    const int ch = blockIdx.x*CPW + lane;
+    const int lane = threadIdx.x & 63;
+    const int wv = (WPB == 1)  ?  0  :  (int) (threadIdx.x >> 6);
+    const int ch = (blockIdx.x*WPB + wv)*CPW + lane;
+    constexpr int kThreads = 64*WPB;
+    const int tid = threadIdx.x;
     const V17Tables &TB = *L.tab;
     const float *g_rrc_re = TB.rrc_re;
     const float *g_rrc_im = TB.rrc_im;
 
-    for (int i = lane;  i < 2048;  i += 64)
+    for (int i = tid;  i < 2048;  i += kThreads)
         t_sine[i] = TB.sine[i];
-    for (int i = lane;  i < 256;  i += 64)
+    for (int i = tid;  i < 256;  i += kThreads)
         t_con[i] = TB.con[i];
-    for (int i = lane;  i < 36*36*2;  i += 64)
+    for (int i = tid;  i < 36*36*2;  i += kThreads)
         t_map[i] = TB.map[i];
-    for (int i = lane;  i < 194;  i += 64)
+    for (int i = tid;  i < 194;  i += kThreads)
         t_sqrt[i] = TB.sqrt_tab[i];
     const float g0 = TB.godard[0];
     const float g1 = TB.godard[1];
@@ -148,11 +157,32 @@ void v17_bank_kernel(const V17Launch L)
     auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = (v != v)  ?  0xFFC00000u  :  __float_as_uint(v); };
     auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV17Floats + w)*N + ch] = (uint32_t) v; };
 
-    float2 *rrc2 = &lanes[lane];                        // [2*27] pairs, stride CPW
-    uint32_t *past = &surv[lane];                        // [16]: 8 x 3 bit predecessor states per time step
+    float2 *rrc2 = &lanes[PK16  ?  0  :  (wv*CPW*2*kRrcLen + lane)];           // [2*27] pairs, stride CPW
+    uint32_t *rrc16 = &lanes16[PK16  ?  (wv*CPW*2*kRrcLen + lane)  :  0];
+    uint32_t *pcmw = &pcm[wv*CPW*(kTile/2)];
+    auto rrc_put = [&](int k, float v)
+    {
+        if (PK16)
+        {
+            const uint32_t h = (uint32_t) (int) v & 0xFFFFu;
+            rrc16[k*CPW] = h;
+            rrc16[(kRrcLen + k)*CPW] = h << 16;
+        }
+        else
+        {
+            rrc2[k*CPW].x = v;
+            rrc2[(kRrcLen + k)*CPW].y = v;
+        }
+    };
+    auto rrc_at = [&](int k) -> float
+    {
+        if (PK16)
+            return (float) (int) (short) (rrc16[k*CPW] & 0xFFFFu);
+        return rrc2[k*CPW].x;
+    };
+    uint32_t *past = &surv[wv*CPW*(16 + 32) + lane];    // [16]: 8 x 3 bit predecessor states per time step
     uint32_t *full = past + 16*CPW;                     // [16][2]: 8 x 1 byte surviving points per time step
-#define RRC2(k)     rrc2[(k)*CPW]
-    float2 *ctap = &taps[lane];
+    float2 *ctap = &taps[wv*kEqLen*CPW + lane];
 #define TAP(i)      ctap[(i)*CPW]
 #define PAST(t)     past[(t)*CPW]
 #define FULL(t, h)  full[(2*(t) + (h))*CPW]
@@ -173,8 +203,12 @@ void v17_bank_kernel(const V17Launch L)
     for (int i = 0;  i < kRrcLen;  i++)
     {
         const float v = ldf(VF_RRC + i);
-        RRC2(i) = make_float2(v, 0.0f);
-        RRC2(kRrcLen + i) = make_float2(0.0f, v);
+        if (!PK16)
+        {
+            rrc2[i*CPW] = make_float2(v, 0.0f);
+            rrc2[(kRrcLen + i)*CPW] = make_float2(0.0f, v);
+        }
+        rrc_put(i, v);
     }
     for (int i = 0;  i < kEqLen;  i++)
         TAP(i) = make_float2(ldf(VF_EQ_COEFF + 2*i), ldf(VF_EQ_COEFF + 2*i + 1));
@@ -279,7 +313,12 @@ void v17_bank_kernel(const V17Launch L)
     auto restart = [&]()
     {
         for (int i = 0;  i < 2*kRrcLen;  i++)
-            RRC2(i) = make_float2(0.0f, 0.0f);
+        {
+            if (PK16)
+                rrc16[i*CPW] = 0;
+            else
+                rrc2[i*CPW] = make_float2(0.0f, 0.0f);
+        }
         training_error = 0.0f;
         rrc_step = 0;
         diff = 1;
@@ -345,13 +384,22 @@ void v17_bank_kernel(const V17Launch L)
     {
         const float *y = table + row;
         const float2 *x = rrc2 + rrc_step*CPW;
+        const uint32_t *xq = rrc16 + rrc_step*CPW;
         f32x2v xs[kRrcLen];
         float ys[kRrcLen];
 #pragma unroll
         for (int i = 0;  i < kRrcLen;  i++)
         {
-            const float2 w = x[i*CPW];
-            xs[i] = (f32x2v) {w.x, w.y};
+            if (PK16)
+            {
+                const uint32_t q = xq[i*CPW];
+                xs[i] = (f32x2v) {(float) (int) (short) (q & 0xFFFFu), (float) ((int) q >> 16)};
+            }
+            else
+            {
+                const float2 w = x[i*CPW];
+                xs[i] = (f32x2v) {w.x, w.y};
+            }
             ys[i] = y[i*kV17Sets];
         }
         f32x2v a = {0.0f, 0.0f};
@@ -562,10 +610,10 @@ void v17_bank_kernel(const V17Launch L)
             for (int k = 0;  k < kTile/8;  k++)
             {
                 const int4 v = ((const int4 *) row)[k];
-                pcm[(4*k + 0)*CPW + lane] = (uint32_t) v.x;
-                pcm[(4*k + 1)*CPW + lane] = (uint32_t) v.y;
-                pcm[(4*k + 2)*CPW + lane] = (uint32_t) v.z;
-                pcm[(4*k + 3)*CPW + lane] = (uint32_t) v.w;
+                pcmw[(4*k + 0)*CPW + lane] = (uint32_t) v.x;
+                pcmw[(4*k + 1)*CPW + lane] = (uint32_t) v.y;
+                pcmw[(4*k + 2)*CPW + lane] = (uint32_t) v.z;
+                pcmw[(4*k + 3)*CPW + lane] = (uint32_t) v.w;
             }
         }
         else
@@ -574,7 +622,7 @@ void v17_bank_kernel(const V17Launch L)
             {
                 const uint32_t lo = (uint16_t) row[2*k];
                 const uint32_t hi = (2*k + 1 < tn)  ?  (uint16_t) row[2*k + 1]  :  0u;
-                pcm[k*CPW + lane] = lo | (hi << 16);
+                pcmw[k*CPW + lane] = lo | (hi << 16);
             }
         }
     }
@@ -599,13 +647,12 @@ void v17_bank_kernel(const V17Launch L)
     {
     if (take  &&  !ready  &&  !restart_pending  &&  pos < tn)
     {
-        const uint32_t pw = pcm[(pos >> 1)*CPW + lane];
+        const uint32_t pw = pcmw[(pos >> 1)*CPW + lane];
         const int amp = (int) (short) ((pos & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
         pos++;
         do
         {
-        RRC2(rrc_step).x = (float) amp;
-        RRC2(rrc_step + kRrcLen).y = (float) amp;
+        rrc_put(rrc_step, (float) amp);
         if (++rrc_step >= kRrcLen)
             rrc_step = 0;
 
@@ -1150,7 +1197,7 @@ void v17_bank_kernel(const V17Launch L)
     stf(VF_GDC + 1, gdc1);
     stf(VF_BAUD_PHASE, baud_phase);
     for (int i = 0;  i < kRrcLen;  i++)
-        stf(VF_RRC + i, RRC2(i).x);
+        stf(VF_RRC + i, rrc_at(i));
     for (int i = 0;  i < kEqLen;  i++)
     {
         const float2 c = TAP(i);

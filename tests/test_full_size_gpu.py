@@ -119,6 +119,41 @@ def test_v27ter_full_wave_kernel_65700_channels(built, bit_rate):
         assert np.array_equal(bits(f), bits(fo)), c
 
 
+def test_v17_full_wave_kernel_65650_channels(built):
+    """And for V.17 (trellis survivor memory in LDS, three waves per workgroup): 14 400 bps through its long training
+    into data, on a bank that fills neither its last workgroup nor its last wave."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    from test_v17_gpu import channel_signals
+    use_golden_modem_tables()
+    n_ch, V, n_frames = 65536 + 64 + 50, 37, 84              # 84 frames: the 1.4 s of training and some data
+    base = channel_signals(14400, V, seed=80)[:, :n_frames*160]
+    pick = (np.arange(n_ch)*11) % V
+    bank = engine.V17Bank(n_ch, 14400)
+    want = []
+    for c in range(V):
+        o = orc.V17(14400)
+        per = []
+        for k in range(n_frames):
+            o.sink.clear()
+            o.rx(base[c, k*160:(k + 1)*160])
+            per.append(o.sink.events()["a"].astype(np.int8))
+        want.append((per, o.snapshot()))
+    total = 0
+    for k in range(n_frames):
+        bank.rx_host(base[pick, k*160:(k + 1)*160])
+        ev = bank.events()
+        for c in range(n_ch):
+            assert np.array_equal(ev[c], want[pick[c]][0][k]), (k, c)
+        total += sum(len(e) for e in ev[:V])
+    assert total > 100*V
+    for c in list(range(0, n_ch, 1499)) + [65535, 65536, 65599, 65600, n_ch - 1]:
+        f, w = bank.get_state(c)
+        fo, wo = want[pick[c]][1]
+        assert np.array_equal(w, wo), c
+        assert np.array_equal(bits(f), bits(fo)), c
+
+
 def test_mixed_banks_131072_channels(built):
     """configs[2]: Bell MF + R2 MF + super-tone, 131 072 channels in all."""
     from oracle import restated as orc
