@@ -213,6 +213,50 @@ SPANGPU_API int spangpu_bank_set_digits_buffer(spangpu_bank_t *bank, void *dev_p
 /* ... into n_slices slices of slice_bytes, successive launches filling successive slices round and round: one call sets up
    a reporting interval of n_slices steps. */
 SPANGPU_API int spangpu_bank_set_digits_ring(spangpu_bank_t *bank, void *dev_ptr, size_t slice_bytes, int n_slices);
+/* Super-tone banks: the cadence matching of super_tone_rx() (src/super_tone_rx.c:164-228 test_cadence() and :364-448, the
+   tail of super_tone_chunk()) on the device, for callers that want tone reports and not block records.  The descriptor is
+   given as super_tone_rx_add_tone() / _add_element() build it (src/super_tone_rx.c:125-162): tone_elems[t] = how many
+   elements tone t has, elems = all of them in order, f1 / f2 = the BIN numbers the frequencies resolved to (-1 = none, the
+   numbering of the bank's bin_fac[]), min_ms / max_ms in milliseconds (max 0 = no upper limit); up to 255 tones of 1024
+   elements in all (the table is staged in LDS).  Giving cadences again
+   replaces the tones and keeps every channel's run history.  Events of one launch, per channel in the order the reference
+   would call back, two words each at events[(slot*n_channels + channel)*2], counts[channel] of them:
+     word 0 = kind | (f1 + 1) << 8 | (f2 + 1) << 16 | block << 24, word 1 = tone (kind 1) or milliseconds (kind 3)
+     SPANGPU_CADENCE_TONE_ON   tone_callback(user, tone, -10, 0): the newest runs spell out a tone
+     SPANGPU_CADENCE_TONE_OFF  tone_callback(user, -1, -10, 0): the cadence followed broke
+     SPANGPU_CADENCE_SEGMENT   segment_callback(user, f1, f2, ms): a run ended (only with want_segments)
+   spangpu_bank_cadence_run() queues the matcher over the records of the last spangpu_bank_rx*() on the bank's stream (once
+   per launch; every launch must be followed by it or by _events(), else its blocks are not counted) and returns the slots
+   per channel; spangpu_bank_cadence_events() does that if it was not done, waits and hands out pinned host copies;
+   spangpu_bank_cadence_device() the device buffers themselves (for a gather). */
+#define SPANGPU_CADENCE_TONE_ON     1
+#define SPANGPU_CADENCE_TONE_OFF    2
+#define SPANGPU_CADENCE_SEGMENT     3
+typedef struct
+{
+    int32_t f1;
+    int32_t f2;
+    int32_t min_ms;
+    int32_t max_ms;
+} spangpu_cadence_elem_t;
+SPANGPU_API int spangpu_bank_set_cadences(spangpu_bank_t *bank, const int32_t *tone_elems, int n_tones,
+                                          const spangpu_cadence_elem_t *elems, int want_segments);
+SPANGPU_API int spangpu_bank_cadence_run(spangpu_bank_t *bank);
+SPANGPU_API int spangpu_bank_cadence_events(spangpu_bank_t *bank, const uint32_t **events, const int32_t **counts);
+SPANGPU_API int spangpu_bank_cadence_device(spangpu_bank_t *bank, const uint32_t **events_dev, const int32_t **counts_dev);
+/* The same events as one compact list (what a host consumer of a large bank wants: a tick of 65 536 lines has a few hundred
+   to a few thousand reports, the slot arrays are 3 MB): returns how many, *list = that many (channel, word 0, word 1) triples
+   in pinned host memory; a channel's events are together and in order, the channels in no particular order.  Runs the
+   matcher if that was not done, waits. */
+SPANGPU_API int spangpu_bank_cadence_list(spangpu_bank_t *bank, const uint32_t **list);
+/* One channel's history back to that of a new detector (channel -1: all of them). */
+SPANGPU_API int spangpu_bank_cadence_reset(spangpu_bank_t *bank, int channel);
+/* A channel's matcher state as words: 0-1 the pair of the last block, 2 tone followed (-1 none), 3 turn (elements gone by
+   since it was recognised), 4-13 the pairs of the ten newest runs (f1 & 0xFFFF | f2 << 16), the current one first, 14-23
+   their lengths in blocks. */
+SPANGPU_API int spangpu_bank_cadence_state_words(void);
+SPANGPU_API int spangpu_bank_cadence_get_state(spangpu_bank_t *bank, int channel, int32_t *words);
+SPANGPU_API int spangpu_bank_cadence_set_state(spangpu_bank_t *bank, int channel, const int32_t *words);
 /* Parity / diagnostics tap: per-block Goertzel energies of the last call, laid out
    [block][bin][channel] (bank created with trace=1).  Returns blocks-per-call. */
 SPANGPU_API int spangpu_bank_trace(spangpu_bank_t *bank, float *energies, size_t max_floats);

@@ -234,6 +234,8 @@ SPANGPU_API super_tone_rx_state_t *spangpu_super_tone_rx_attach(spangpu_group_t 
 
 /* Bank parameters (bin count and taps) for a super-tone group whose channels all use `desc`. */
 SPANGPU_API int spangpu_super_tone_params(const super_tone_rx_descriptor_t *desc, spangpu_tone_params_t *params);
+/* ... and its cadences, for spangpu_bank_cadence_events() (matched on the device; include/spangpu.h) */
+SPANGPU_API int spangpu_super_tone_cadences(const super_tone_rx_descriptor_t *desc, spangpu_bank_t *bank, int want_segments);
 
 /* ---- DTMF (src/spandsp/dtmf.h) -------------------------------------------------------- */
 SPANGPU_API dtmf_rx_state_t *dtmf_rx_init(dtmf_rx_state_t *s, digits_rx_callback_t callback, void *user_data);

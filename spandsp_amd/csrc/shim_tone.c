@@ -1236,6 +1236,49 @@ int spangpu_super_tone_params(const super_tone_rx_descriptor_t *desc, spangpu_to
     return SPANGPU_OK;
 }
 
+/* Give a bank the descriptor's cadences, to be matched on the device (spangpu_bank_set_cadences): for callers that run a
+   super-tone bank themselves and want tone reports instead of block records. */
+int spangpu_super_tone_cadences(const super_tone_rx_descriptor_t *desc, spangpu_bank_t *bank, int want_segments)
+{
+    int32_t *counts;
+    spangpu_cadence_elem_t *el;
+    int t;
+    int i;
+    int n = 0;
+    int rc;
+
+    if (desc == NULL  ||  bank == NULL  ||  desc->n_bins < 2  ||  desc->n_bins > SPANGPU_MAX_BINS)
+        return SPANGPU_ERR_BAD_ARG;
+    for (t = 0;  t < desc->n_tones;  t++)
+        n += desc->tone[t].n;
+    counts = (int32_t *) malloc(sizeof(int32_t)*(size_t) (desc->n_tones + 1));
+    el = (spangpu_cadence_elem_t *) malloc(sizeof(*el)*(size_t) (n + 1));
+    if (counts == NULL  ||  el == NULL)
+    {
+        free(counts);
+        free(el);
+        return SPANGPU_ERR_NO_MEMORY;
+    }
+    n = 0;
+    for (t = 0;  t < desc->n_tones;  t++)
+    {
+        counts[t] = desc->tone[t].n;
+        for (i = 0;  i < desc->tone[t].n;  i++, n++)
+        {
+            const st_elem_t *e = &desc->tone[t].elem[i];
+
+            el[n].f1 = e->f1;
+            el[n].f2 = e->f2;
+            el[n].min_ms = (int32_t) (e->lo/8);
+            el[n].max_ms = (e->hi >= 0x7FFFFFFFLL)  ?  0  :  (int32_t) (e->hi/8);
+        }
+    }
+    rc = spangpu_bank_set_cadences(bank, counts, desc->n_tones, el, want_segments);
+    free(counts);
+    free(el);
+    return rc;
+}
+
 int super_tone_rx_release(super_tone_rx_state_t *s)
 {
     (void) s;

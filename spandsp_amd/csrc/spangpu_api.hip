@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #include "../../include/spangpu.h"
 #include "../../include/spangpu_refstate.h"
@@ -90,6 +91,8 @@ struct spangpu_bank_s
     // last call
     int last_maxb;
     int last_samples;
+    unsigned launch_serial;     // counts launches (the cadence matcher takes each launch's records once)
+    struct Cadence *cad;        // super-tone: the cadence matcher on the device (spangpu_bank_set_cadences)
     hipEvent_t ev0;
     hipEvent_t ev1;
     bool ev_valid;
@@ -260,6 +263,280 @@ __global__ __launch_bounds__(256) void digit_events_kernel(const uint32_t *rec, 
                 out[1 + at] = (uint32_t) ch | (code << 20) | ((uint32_t) b << 28);
         }
     }
+}
+
+
+// ---- super-tone cadences on the device --------------------------------------------------------------------------------
+// What super_tone_rx.c:164-228 and :364-448 decide from the stream of per-block bin pairs (k1, k2): which run of equal
+// pairs is current, when it ended (the pair seen twice in a row differs from it), whether the cadence being followed is
+// still alive, and whether the newest runs spell out one of the descriptor's tones.  One lane per channel walks the
+// records of the last launch (one or two blocks of a 160-sample frame).  The history of the ten newest runs is kept newest
+// first, so that "the run j places back" is register j: it is read in one go (24 coalesced words in flight together),
+// shifted down when a run ends (a few times a second) and only what changed is written back.  Window limits are kept in
+// blocks (lo <= 128 b  <=>  b >= ceil(lo/128)), which makes every test a 32-bit compare.
+//   state words: 0 seen f1, 1 seen f2, 2 tone followed (-1 none), 3 turn, 4..13 run pair (f1 & 0xFFFF | f2 << 16), newest
+//   first, 14..23 run length in blocks.
+// Events, in the order the reference calls back: two words each at ev[(slot*n_ch + ch)*2]:
+//   word 0 = kind | (f1 + 1) << 8 | (f2 + 1) << 16 | block << 24, word 1 = tone number (kind 1) or milliseconds (kind 3);
+//   kind 1 = tone recognised (tone_callback(user, tone, -10, 0)), 2 = tone lost (tone_callback(user, -1, -10, 0)),
+//   3 = a segment ended (segment_callback(user, f1, f2, ms)).
+static constexpr int kCadHistory = 10;
+static constexpr int kCadWords = 4 + 2*kCadHistory;
+static constexpr int kCadSlotsPerBlock = 3;
+
+struct Cadence
+{
+    int n_tones;
+    int n_elems;
+    int32_t *d_first;       // [n_tones + 1]
+    int4 *d_elem;           // (pair, least blocks, most blocks, 0)
+    int32_t *d_state;       // [kCadWords][n_ch]
+    uint32_t *d_ev;         // [slots][n_ch][2]
+    int32_t *d_count;       // [n_ch]
+    uint32_t *h_ev;         // pinned
+    int32_t *h_count;
+    uint32_t *d_list;       // [2 + 3*slots_cap*n_ch]: two counters used in turn (a launch clears the next one's), then
+                            // (channel, word 0, word 1) per event, a channel's together
+    int which;              // the counter of the last launch
+    uint32_t *h_list;       // pinned
+    int slots_cap;
+    int segments;
+    unsigned done_serial;   // the launch whose records were matched last
+    int last_slots;
+};
+
+__host__ __device__ static inline int32_t cad_pair(int f1, int f2)
+{
+    return (int32_t) (((uint32_t) f1 & 0xFFFFu) | ((uint32_t) f2 << 16));
+}
+
+__global__ __launch_bounds__(256) void cadence_init_kernel(int32_t *st, int n_ch, int first, int n)
+{
+    const int i = (int) (blockIdx.x*256 + threadIdx.x);
+    if (i >= n)
+        return;
+    const int ch = first + i;
+    for (int w = 0;  w < kCadWords;  w++)
+        st[(size_t) w*n_ch + ch] = (w == 3  ||  w >= 4 + kCadHistory)  ?  0  :  -1;
+}
+
+static constexpr int kCadMaxTones = 255;
+static constexpr int kCadMaxElems = 1024;
+
+// The descriptor (a few dozen elements as a rule) is copied to LDS first: the walk over it is a chain of dependent reads,
+// and from global memory each link costs a trip to the L2.
+__global__ __launch_bounds__(256) void cadence_kernel(const uint32_t *__restrict__ rec, int n_ch, int maxb, const int32_t *__restrict__ g_first,
+                                                      const int4 *__restrict__ g_elem, int n_tones, int n_elems, int32_t *__restrict__ st,
+                                                      uint32_t *__restrict__ ev, int32_t *__restrict__ count, int segments, uint32_t *list,
+                                                      uint32_t list_cap, int which)
+{
+    extern __shared__ int4 cad_lds[];
+    int4 *elem = cad_lds;
+    int32_t *first = (int32_t *) (cad_lds + n_elems);
+    for (int i = (int) threadIdx.x;  i < n_elems;  i += 256)
+        elem[i] = g_elem[i];
+    for (int i = (int) threadIdx.x;  i <= n_tones;  i += 256)
+        first[i] = g_first[i];
+    __shared__ uint32_t wg_events;
+    __shared__ uint32_t wg_at;
+    __shared__ uint32_t wg_ev[2*kCadSlotsPerBlock][2][256];     // the events of a 160-sample frame, for the compact list
+    if (threadIdx.x == 0)
+        wg_events = 0;
+    __syncthreads();
+    // lanes past the end of the bank walk the last channel again and write nothing (they have barriers to keep)
+    const bool active = ((int) (blockIdx.x*256 + threadIdx.x) < n_ch);
+    const int ch = active  ?  (int) (blockIdx.x*256 + threadIdx.x)  :  n_ch - 1;
+    int32_t pf[kCadHistory];
+    int32_t bl[kCadHistory];
+    int32_t w0[4];
+#pragma unroll
+    for (int i = 0;  i < 4;  i++)
+        w0[i] = st[(size_t) i*n_ch + ch];
+#pragma unroll
+    for (int i = 0;  i < kCadHistory;  i++)
+    {
+        pf[i] = st[(size_t) (4 + i)*n_ch + ch];
+        bl[i] = st[(size_t) (4 + kCadHistory + i)*n_ch + ch];
+    }
+    // the records of a 160-sample frame (one or two blocks) are asked for along with the state: one trip to memory in all
+    const uint32_t rec0 = (maxb > 0)  ?  rec[ch]  :  0;
+    const uint32_t rec1 = (maxb > 1)  ?  rec[(size_t) n_ch + ch]  :  0;
+    int seen1 = w0[0];
+    int seen2 = w0[1];
+    int tone = w0[2];
+    int turn = w0[3];
+    bool shifted = false;
+    bool touched = false;
+    int n_ev = 0;
+    int blk = 0;
+    auto emit = [&](uint32_t kind, int32_t pair, int32_t v)
+    {
+        if (!active)
+            return;
+        uint32_t *e = ev + ((size_t) n_ev*n_ch + ch)*2;
+        const int f1 = (int) (int16_t) (pair & 0xFFFF);
+        const int f2 = pair >> 16;
+        e[0] = kind | ((uint32_t) ((f1 + 1) & 0xFF) << 8) | ((uint32_t) ((f2 + 1) & 0xFF) << 16) | ((uint32_t) blk << 24);
+        e[1] = (uint32_t) v;
+        if (n_ev < 2*kCadSlotsPerBlock)
+        {
+            wg_ev[n_ev][0][threadIdx.x] = e[0];
+            wg_ev[n_ev][1][threadIdx.x] = (uint32_t) v;
+        }
+        n_ev++;
+    };
+    auto fits = [&](const int4 &e, int32_t pair, int32_t blocks) { return e.x == pair  &&  e.y <= blocks  &&  blocks <= e.z; };
+    // Is the cadence followed still alive?  `turn` elements of it have gone by since it was recognised (on its last element),
+    // so the current run must be element (turn - 1) mod n and not yet too long; when a run has just ended, the one before
+    // it must in addition have been a proper element (turn - 2) mod n.
+    auto alive = [&](int t, int turn_now, bool run_ended)
+    {
+        const int e0 = first[t];
+        const int n = first[t + 1] - e0;
+        if (n <= 0)
+            return false;
+        if (run_ended  &&  !fits(elem[e0 + (turn_now + n - 2)%n], pf[1], bl[1]))
+            return false;
+        const int4 e = elem[e0 + (turn_now + n - 1)%n];
+        return e.x == pf[0]  &&  bl[0] <= e.z;
+    };
+    for (blk = 0;  blk < maxb;  blk++)
+    {
+        const uint32_t w = (blk == 0)  ?  rec0  :  (blk == 1)  ?  rec1  :  rec[(size_t) blk*n_ch + ch];
+        if (!((w >> 16) & kBlkValid))
+            continue;
+        touched = true;
+        const int k1 = (int) (w & 0xFF) - 1;
+        const int k2 = (int) ((w >> 8) & 0xFF) - 1;
+        const int32_t pair = cad_pair(k1, k2);
+        const bool repeat = (k1 == seen1  &&  k2 == seen2);
+        seen1 = k1;
+        seen2 = k2;
+        if (!repeat)
+        {
+            // a pair seen for the first time may be a glitch: the block still counts towards the current run
+            bl[0]++;
+        }
+        else if (pair != pf[0])
+        {
+            // seen twice in a row and not what the current run is made of: that run is over
+            if (tone >= 0)
+            {
+                const int t_now = turn++;
+                if (!alive(tone, t_now, true))
+                {
+                    tone = -1;
+                    emit(2, -1, -1);
+                }
+            }
+            if (segments)
+                emit(3, pf[0], (int32_t) ((uint32_t) bl[0]*16u));
+#pragma unroll
+            for (int i = kCadHistory - 1;  i > 0;  i--)
+            {
+                pf[i] = pf[i - 1];
+                bl[i] = bl[i - 1];
+            }
+            pf[0] = pair;
+            bl[0] = 1;
+            shifted = true;
+        }
+        else
+        {
+            // more of the same (tested before this block is counted, as the reference does)
+            if (tone >= 0  &&  !alive(tone, turn, false))
+            {
+                tone = -1;
+                emit(2, -1, -1);
+            }
+            bl[0]++;
+        }
+        if (tone >= 0)
+            continue;
+        // do the newest runs spell out a whole cadence, the current run being its last element?
+        for (int t = 0;  t < n_tones;  t++)
+        {
+            const int e0 = first[t];
+            const int n = first[t + 1] - e0;
+            if (n > kCadHistory)
+                continue;
+            bool ok = true;
+#pragma unroll
+            for (int j = 0;  j < kCadHistory;  j++)
+            {
+                if (j < n)
+                    ok = ok  &&  fits(elem[e0 + n - 1 - j], pf[j], bl[j]);
+            }
+            if (ok)
+            {
+                tone = t;
+                turn = 0;
+                emit(1, -1, t);
+                break;
+            }
+        }
+    }
+    if (active)
+        count[ch] = n_ev;
+    // the compact list: the workgroup takes room for all its events with one atomic on the list's counter (thousands of lanes
+    // adding to one address cost more than the rest of the kernel), each channel a piece of that, so that a channel's events
+    // stay together and in order
+    const uint32_t mine = (n_ev > 0)  ?  atomicAdd(&wg_events, (uint32_t) n_ev)  :  0;
+    __syncthreads();
+    if (threadIdx.x == 0  &&  wg_events > 0)
+        wg_at = atomicAdd(list + which, wg_events);
+    if (blockIdx.x == 0  &&  threadIdx.x == 0)
+        list[which ^ 1] = 0;                    // the next launch's counter (it starts when this one is over)
+    __syncthreads();
+    if (n_ev > 0)
+    {
+        const uint32_t at = wg_at + mine;
+        for (int k = 0;  k < n_ev;  k++)
+        {
+            if (at + k < list_cap)
+            {
+                const uint32_t *e = ev + ((size_t) k*n_ch + ch)*2;
+                uint32_t *o = list + 2 + (size_t) (at + k)*3;
+                const bool staged = (k < 2*kCadSlotsPerBlock);
+                o[0] = (uint32_t) ch;
+                o[1] = staged  ?  wg_ev[staged  ?  k  :  0][0][threadIdx.x]  :  e[0];
+                o[2] = staged  ?  wg_ev[staged  ?  k  :  0][1][threadIdx.x]  :  e[1];
+            }
+        }
+    }
+    if (!touched  ||  !active)
+        return;
+    st[(size_t) 0*n_ch + ch] = seen1;
+    st[(size_t) 1*n_ch + ch] = seen2;
+    st[(size_t) 2*n_ch + ch] = tone;
+    st[(size_t) 3*n_ch + ch] = turn;
+    st[(size_t) 4*n_ch + ch] = pf[0];
+    st[(size_t) (4 + kCadHistory)*n_ch + ch] = bl[0];
+    if (shifted)
+    {
+#pragma unroll
+        for (int i = 1;  i < kCadHistory;  i++)
+        {
+            st[(size_t) (4 + i)*n_ch + ch] = pf[i];
+            st[(size_t) (4 + kCadHistory + i)*n_ch + ch] = bl[i];
+        }
+    }
+}
+
+static void cadence_free(Cadence *c)
+{
+    if (c == nullptr)
+        return;
+    if (c->d_first) (void) hipFree(c->d_first);
+    if (c->d_elem) (void) hipFree(c->d_elem);
+    if (c->d_state) (void) hipFree(c->d_state);
+    if (c->d_ev) (void) hipFree(c->d_ev);
+    if (c->d_count) (void) hipFree(c->d_count);
+    if (c->h_ev) (void) hipHostFree(c->h_ev);
+    if (c->h_count) (void) hipHostFree(c->h_count);
+    if (c->d_list) (void) hipFree(c->d_list);
+    if (c->h_list) (void) hipHostFree(c->h_list);
+    free(c);
 }
 
 extern "C" int spangpu_set_error(int code, const char *msg)
@@ -481,6 +758,7 @@ int spangpu_bank_destroy(spangpu_bank_t *b)
     if (b->stream)
         (void) hipStreamSynchronize(b->stream);
     free_outputs(b);
+    cadence_free(b->cad);
     if (b->sf) (void) hipFree(b->sf);
     if (b->si) (void) hipFree(b->si);
     if (b->d_amp) (void) hipFree(b->d_amp);
@@ -702,6 +980,7 @@ int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, 
     if (rc < 0)
         return rc;
     b->last_maxb = maxb;
+    b->launch_serial++;
     b->last_samples = samples;
     return 0;
 }
@@ -876,6 +1155,7 @@ int spangpu_bank_rx_g711(spangpu_bank_t *b, const uint8_t *codes, int mem, int l
     if (rc < 0)
         return rc;
     b->last_maxb = maxb;
+    b->launch_serial++;
     b->last_samples = samples;
     return 0;
 }
@@ -934,6 +1214,7 @@ int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, i
         fill_launch(M.bank[k], b, amps[k], stride, samples, SPANGPU_LAYOUT_CHANNEL_MAJOR, maxb, 0);
         all_fast = all_fast  &&  fast_eligible(M.bank[k]);
         b->last_maxb = maxb;
+    b->launch_serial++;
         b->last_samples = samples;
     }
     // lanes per channel: the streaming kernels run one channel per lane unless two are asked for
@@ -976,6 +1257,7 @@ int spangpu_bank_force_block(spangpu_bank_t *b)
     if (rc < 0)
         return rc;
     b->last_maxb = 1;
+    b->launch_serial++;
     b->last_samples = 0;
     return SPANGPU_OK;
 }
@@ -1372,6 +1654,220 @@ int spangpu_bank_reset_channel(spangpu_bank_t *b, int channel, int fillin_only)
     if (!fillin_only)
         w[1] = w[2] = w[3] = 0;
     return spangpu_bank_set_state(b, channel, f, b->nsf, w, 4);
+}
+
+// ---- super-tone cadences (src/super_tone_rx.c:164-228, :364-448) on the device ------------------------------------------
+int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int n_tones, const spangpu_cadence_elem_t *elems,
+                              int want_segments)
+{
+    if (b == nullptr  ||  n_tones < 0  ||  (n_tones > 0  &&  (tone_elems == nullptr  ||  elems == nullptr)))
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (b->kind != SPANGPU_SUPER_TONE)
+        return fail(SPANGPU_ERR_UNSUPPORTED, "cadences belong to a super-tone bank");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    std::vector<int32_t> first(n_tones + 1, 0);
+    for (int t = 0;  t < n_tones;  t++)
+    {
+        if (tone_elems[t] < 0)
+            return fail(SPANGPU_ERR_BAD_ARG, "tone %d has a negative element count", t);
+        first[t + 1] = first[t] + tone_elems[t];
+    }
+    const int n_elems = first[n_tones];
+    if (n_tones > kCadMaxTones  ||  n_elems > kCadMaxElems)
+        return fail(SPANGPU_ERR_UNSUPPORTED, "a bank matches up to %d tones of %d elements in all", kCadMaxTones, kCadMaxElems);
+    std::vector<int4> el(n_elems > 0  ?  n_elems  :  1);
+    for (int i = 0;  i < n_elems;  i++)
+    {
+        if (elems[i].f1 < -1  ||  elems[i].f1 >= 255  ||  elems[i].f2 < -1  ||  elems[i].f2 >= 255  ||  elems[i].min_ms < 0
+            ||  elems[i].max_ms < 0  ||  elems[i].min_ms > 0x7FFFFFFF/8)
+            return fail(SPANGPU_ERR_BAD_ARG, "element %d: bins are -1..254, times are milliseconds >= 0", i);
+        // milliseconds are kept in samples, 0 = no upper limit (super_tone_rx.c:157-158); a run of b blocks is 128 b samples
+        // long, so the window in blocks is ceil(lo/128) .. floor(hi/128)
+        const long long lo = 8LL*elems[i].min_ms;
+        const long long hi = (elems[i].max_ms == 0)  ?  0x7FFFFFFFLL  :  8LL*elems[i].max_ms;
+        el[i] = make_int4(cad_pair(elems[i].f1, elems[i].f2), (int) ((lo + 127)/128), (int) ((hi > 0x7FFFFFFFLL  ?  0x7FFFFFFFLL  :  hi)/128), 0);
+    }
+    Cadence *c = b->cad;
+    const bool fresh = (c == nullptr);
+    if (fresh)
+    {
+        if ((c = (Cadence *) calloc(1, sizeof(Cadence))) == nullptr)
+            return fail(SPANGPU_ERR_NO_MEMORY, "out of memory");
+        if (hipMalloc(&c->d_state, (size_t) kCadWords*b->n_ch*sizeof(int32_t)) != hipSuccess
+            ||  hipMalloc(&c->d_count, (size_t) b->n_ch*sizeof(int32_t)) != hipSuccess
+            ||  hipHostMalloc(&c->h_count, (size_t) b->n_ch*sizeof(int32_t)) != hipSuccess)
+        {
+            cadence_free(c);
+            return fail(SPANGPU_ERR_NO_MEMORY, "out of device memory for the cadence state");
+        }
+        hipLaunchKernelGGL(cadence_init_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, b->stream, c->d_state, b->n_ch, 0, b->n_ch);
+        c->done_serial = b->launch_serial;      // what was received before now is not matched
+        b->cad = c;
+    }
+    if (c->d_first) (void) hipFree(c->d_first);
+    if (c->d_elem) (void) hipFree(c->d_elem);
+    c->d_first = nullptr;
+    c->d_elem = nullptr;
+    HIP_TRY(hipMalloc(&c->d_first, first.size()*sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->d_elem, el.size()*sizeof(int4)));
+    HIP_TRY(hipMemcpy(c->d_first, first.data(), first.size()*sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_elem, el.data(), el.size()*sizeof(int4), hipMemcpyHostToDevice));
+    c->n_tones = n_tones;
+    c->n_elems = n_elems;
+    c->segments = want_segments  ?  1  :  0;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return SPANGPU_OK;
+}
+
+int spangpu_bank_cadence_run(spangpu_bank_t *b)
+{
+    if (b == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "null bank");
+    Cadence *c = b->cad;
+    if (c == nullptr)
+        return fail(SPANGPU_ERR_STATE, "no cadences were given to this bank (spangpu_bank_set_cadences)");
+    if (c->done_serial == b->launch_serial)
+        return c->last_slots;
+    HIP_TRY(hipSetDevice(b->device));
+    const int slots = kCadSlotsPerBlock*b->last_maxb;
+    if (slots > c->slots_cap)
+    {
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        if (c->d_ev) (void) hipFree(c->d_ev);
+        if (c->h_ev) (void) hipHostFree(c->h_ev);
+        c->d_ev = nullptr;
+        c->h_ev = nullptr;
+        c->slots_cap = 0;
+        if (c->d_list) (void) hipFree(c->d_list);
+        if (c->h_list) (void) hipHostFree(c->h_list);
+        c->d_list = nullptr;
+        c->h_list = nullptr;
+        HIP_TRY(hipMalloc(&c->d_ev, (size_t) slots*b->n_ch*2*sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc(&c->h_ev, (size_t) slots*b->n_ch*2*sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_list, ((size_t) slots*b->n_ch*3 + 2)*sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc(&c->h_list, ((size_t) slots*b->n_ch*3 + 2)*sizeof(uint32_t)));
+        HIP_TRY(hipMemset(c->d_list, 0, 2*sizeof(uint32_t)));
+        c->which = 0;
+        c->slots_cap = slots;
+    }
+    if (b->last_maxb > 0)
+    {
+        c->which ^= 1;
+        hipLaunchKernelGGL(cadence_kernel, dim3((b->n_ch + 255)/256), dim3(256), (size_t) c->n_elems*sizeof(int4) + (c->n_tones + 1)*sizeof(int32_t),
+                           b->stream, (const uint32_t *) (b->cur_rec  ?  b->cur_rec  :  b->rec), b->n_ch, b->last_maxb,
+                           (const int32_t *) c->d_first, (const int4 *) c->d_elem, c->n_tones, c->n_elems, c->d_state, c->d_ev, c->d_count,
+                           c->segments, c->d_list, (uint32_t) ((size_t) c->slots_cap*b->n_ch), c->which);
+        HIP_TRY(hipGetLastError());
+    }
+    else
+    {
+        HIP_TRY(hipMemsetAsync(c->d_count, 0, (size_t) b->n_ch*sizeof(int32_t), b->stream));
+    }
+    c->done_serial = b->launch_serial;
+    c->last_slots = slots;
+    return slots;
+}
+
+int spangpu_bank_cadence_events(spangpu_bank_t *b, const uint32_t **events, const int32_t **counts)
+{
+    const int slots = spangpu_bank_cadence_run(b);
+    if (slots < 0)
+        return slots;
+    Cadence *c = b->cad;
+    HIP_TRY(hipMemcpyAsync(c->h_count, c->d_count, (size_t) b->n_ch*sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    if (slots > 0)
+        HIP_TRY(hipMemcpyAsync(c->h_ev, c->d_ev, (size_t) slots*b->n_ch*2*sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (events)
+        *events = c->h_ev;
+    if (counts)
+        *counts = c->h_count;
+    return slots;
+}
+
+int spangpu_bank_cadence_list(spangpu_bank_t *b, const uint32_t **list)
+{
+    const int slots = spangpu_bank_cadence_run(b);
+    if (slots < 0)
+        return slots;
+    Cadence *c = b->cad;
+    if (slots == 0  ||  c->d_list == nullptr  ||  b->last_maxb <= 0)
+        return 0;
+    // as a rule a tick has few reports: one small copy brings the counters and the first of them
+    const size_t cap = (size_t) c->slots_cap*b->n_ch;
+    const size_t first = (cap < 4096)  ?  cap  :  4096;
+    HIP_TRY(hipMemcpyAsync(c->h_list, c->d_list, (2 + 3*first)*sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    const size_t n = c->h_list[c->which];
+    if (n > cap)
+        return fail(SPANGPU_ERR_STATE, "cadence event list overran its buffer");
+    if (n > first)
+    {
+        HIP_TRY(hipMemcpyAsync(c->h_list + 2 + 3*first, c->d_list + 2 + 3*first, 3*(n - first)*sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    if (list)
+        *list = c->h_list + 2;
+    return (int) n;
+}
+
+int spangpu_bank_cadence_device(spangpu_bank_t *b, const uint32_t **events_dev, const int32_t **counts_dev)
+{
+    if (b == nullptr  ||  b->cad == nullptr)
+        return fail(SPANGPU_ERR_STATE, "no cadences were given to this bank");
+    if (events_dev)
+        *events_dev = b->cad->d_ev;
+    if (counts_dev)
+        *counts_dev = b->cad->d_count;
+    return b->cad->last_slots;
+}
+
+int spangpu_bank_cadence_reset(spangpu_bank_t *b, int channel)
+{
+    if (b == nullptr  ||  b->cad == nullptr)
+        return fail(SPANGPU_ERR_STATE, "no cadences were given to this bank");
+    if (channel < -1  ||  channel >= b->n_ch)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad channel");
+    HIP_TRY(hipSetDevice(b->device));
+    const int first = (channel < 0)  ?  0  :  channel;
+    const int n = (channel < 0)  ?  b->n_ch  :  1;
+    hipLaunchKernelGGL(cadence_init_kernel, dim3((n + 255)/256), dim3(256), 0, b->stream, b->cad->d_state, b->n_ch, first, n);
+    HIP_TRY(hipGetLastError());
+    return SPANGPU_OK;
+}
+
+int spangpu_bank_cadence_state_words(void)
+{
+    return kCadWords;
+}
+
+int spangpu_bank_cadence_get_state(spangpu_bank_t *b, int channel, int32_t *words)
+{
+    if (b == nullptr  ||  b->cad == nullptr)
+        return fail(SPANGPU_ERR_STATE, "no cadences were given to this bank");
+    if (channel < 0  ||  channel >= b->n_ch  ||  words == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy2D(words, sizeof(int32_t), b->cad->d_state + channel, (size_t) b->n_ch*sizeof(int32_t), sizeof(int32_t), kCadWords,
+                        hipMemcpyDeviceToHost));
+    return kCadWords;
+}
+
+int spangpu_bank_cadence_set_state(spangpu_bank_t *b, int channel, const int32_t *words)
+{
+    if (b == nullptr  ||  b->cad == nullptr)
+        return fail(SPANGPU_ERR_STATE, "no cadences were given to this bank");
+    if (channel < 0  ||  channel >= b->n_ch  ||  words == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (words[2] < -1  ||  words[2] >= b->cad->n_tones)
+        return fail(SPANGPU_ERR_BAD_ARG, "state words out of range");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy2D(b->cad->d_state + channel, (size_t) b->n_ch*sizeof(int32_t), words, sizeof(int32_t), sizeof(int32_t), kCadWords,
+                        hipMemcpyHostToDevice));
+    return SPANGPU_OK;
 }
 
 }   // extern "C"

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(HERE, "libspangpu.so")
 
 # include/spangpu.h
 DTMF, BELL_MF, R2_MF, SUPER_TONE, GOERTZEL, V29, V27TER, V17, ECHO = range(1, 10)
+CADENCE_TONE_ON, CADENCE_TONE_OFF, CADENCE_SEGMENT = 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 CHANNEL_MAJOR, SAMPLE_MAJOR = 0, 1
 REPORT_DIGITS, REPORT_REALTIME = 0, 2
@@ -72,6 +73,15 @@ def lib():
             "spangpu_bank_trace": (ci, [vp, vp, C.c_size_t]),
             "spangpu_bank_copy_records": (ll, [vp, vp, C.c_size_t]),
             "spangpu_bank_digit_events": (ci, [vp, vp, ci]),
+            "spangpu_bank_set_cadences": (ci, [vp, vp, ci, vp, ci]),
+            "spangpu_bank_cadence_run": (ci, [vp]),
+            "spangpu_bank_cadence_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_bank_cadence_device": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_bank_cadence_list": (ci, [vp, C.POINTER(vp)]),
+            "spangpu_bank_cadence_reset": (ci, [vp, ci]),
+            "spangpu_bank_cadence_state_words": (ci, []),
+            "spangpu_bank_cadence_get_state": (ci, [vp, ci, vp]),
+            "spangpu_bank_cadence_set_state": (ci, [vp, ci, vp]),
             "spangpu_bank_set_digits_buffer": (ci, [vp, vp, C.c_size_t]),
             "spangpu_bank_set_digits_ring": (ci, [vp, vp, C.c_size_t, ci]),
             "spangpu_bank_reset_channel": (ci, [vp, ci, ci]),
@@ -357,6 +367,62 @@ class ToneBank:
     def digit_events_device(self, dst_ptr, cap_entries):
         """The digits of the last launch as a compact list at dst_ptr (1 + cap_entries uint32 words of device memory)."""
         _check(lib().spangpu_bank_digit_events(self.h, dst_ptr, cap_entries))
+
+    # ---- super-tone cadences matched on the device ----
+    def set_cadences(self, tones, want_segments=False):
+        """tones = [[(f1_bin, f2_bin, min_ms, max_ms), ...], ...] as super_tone_rx_add_element() resolved them."""
+        counts = np.array([len(t) for t in tones], np.int32)
+        el = np.array([e for t in tones for e in t], np.int32).reshape(-1, 4)
+        _check(lib().spangpu_bank_set_cadences(self.h, counts.ctypes.data, len(tones), el.ctypes.data if len(el) else None,
+                                               int(want_segments)))
+
+    def cadence_run(self):
+        return _check(lib().spangpu_bank_cadence_run(self.h))
+
+    def cadence_events(self):
+        """Per channel, the callbacks super_tone_rx() would have made over the last launch, in the oracle's event format:
+        (1, tone, -10, 0) for tone reports (tone -1 = lost), (4, f1, f2, ms) for segments."""
+        ev = C.c_void_p()
+        cnt = C.c_void_p()
+        slots = _check(lib().spangpu_bank_cadence_events(self.h, C.byref(ev), C.byref(cnt)))
+        counts = np.ctypeslib.as_array(C.cast(cnt, C.POINTER(C.c_int32)), (self.n,))
+        out = [[] for _ in range(self.n)]
+        if slots == 0 or not counts.any():
+            return out
+        words = np.ctypeslib.as_array(C.cast(ev, C.POINTER(C.c_uint32)), (slots, self.n, 2))
+        for c in np.nonzero(counts)[0]:
+            for k in range(int(counts[c])):
+                w0 = int(words[k, c, 0])
+                w1 = int(np.int32(words[k, c, 1]))
+                kind = w0 & 0xFF
+                if kind == CADENCE_TONE_ON:
+                    out[c].append((1, w1, -10, 0))
+                elif kind == CADENCE_TONE_OFF:
+                    out[c].append((1, -1, -10, 0))
+                else:
+                    out[c].append((4, ((w0 >> 8) & 0xFF) - 1, ((w0 >> 16) & 0xFF) - 1, w1))
+        return out
+
+    def cadence_list(self):
+        """The events of the last launch as an [n, 3] array of (channel, word 0, word 1), a channel's events together and in
+        order (a view of the library's pinned buffer: good until the next call)."""
+        p = C.c_void_p()
+        n = _check(lib().spangpu_bank_cadence_list(self.h, C.byref(p)))
+        if n == 0:
+            return np.zeros((0, 3), np.uint32)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), (n, 3))
+
+    def cadence_reset(self, channel=-1):
+        _check(lib().spangpu_bank_cadence_reset(self.h, channel))
+
+    def cadence_get_state(self, channel):
+        w = np.zeros(lib().spangpu_bank_cadence_state_words(), np.int32)
+        _check(lib().spangpu_bank_cadence_get_state(self.h, channel, w.ctypes.data))
+        return w
+
+    def cadence_set_state(self, channel, words):
+        w = np.ascontiguousarray(words, np.int32)
+        _check(lib().spangpu_bank_cadence_set_state(self.h, channel, w.ctypes.data))
 
     def trace(self, max_blocks=8):
         buf = np.zeros(max_blocks*(self.nbins + 1)*self.n, np.float32)

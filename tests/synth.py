@@ -222,3 +222,34 @@ def sig_tone_channels(n_ch, n_samples, seed, tone_type):
             out[c, pos:pos + len(seg)] += seg
             pos += on + off
     return _finish(out)
+
+
+def cadence_plan_channels(n_ch, n_samples, seed, plans):
+    """Call-progress lines that follow a cadence for a few cycles and then change to another: plans = list of cycles,
+    each a list of (f1, f2, ms) with 0 Hz = silent.  Segment lengths jitter by a few per cent; now and then a segment is
+    cut short or stretched, which breaks the cadence a detector is following."""
+    rng = np.random.default_rng(seed)
+    out = np.zeros((n_ch, n_samples), np.int16)
+    for c in range(n_ch):
+        x = np.zeros(n_samples)
+        pos = int(rng.integers(0, 3000))
+        a = dbm0_to_amp(rng.uniform(-28.0, -9.0))
+        while pos < n_samples:
+            plan = plans[int(rng.integers(0, len(plans)))]
+            for _ in range(int(rng.integers(1, 5))):
+                for f1, f2, ms in plan:
+                    n = int(8*ms*rng.uniform(0.97, 1.03))
+                    if rng.uniform() < 0.08:
+                        n = int(n*rng.choice([0.4, 1.9]))
+                    n = min(n, n_samples - pos)
+                    if n <= 0:
+                        break
+                    t = np.arange(pos, pos + n)
+                    if f1:
+                        x[pos:pos + n] += a*np.sin(2.0*np.pi*f1*t/8000.0)
+                    if f2:
+                        x[pos:pos + n] += a*np.sin(2.0*np.pi*f2*t/8000.0 + 0.7)
+                    pos += n
+        x += rng.normal(0.0, dbm0_to_amp(rng.uniform(-62.0, -45.0))/np.sqrt(2.0), size=n_samples)
+        out[c] = _finish(x)
+    return out

@@ -464,6 +464,88 @@ def bench_mixed(args, dev, stream):
         "cpu_baseline": cpu}
 
 
+def bench_supertone(args, dev, stream):
+    """A bank of super-tone detectors (a nine-frequency call-progress plan of six tones) with the cadences matched on the
+    device: a step = the detector launch + the matcher launch of one 20 ms tick; the detector alone and the tick with the
+    events brought to the host are timed beside it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    import test_cadence_gpu as tc
+    from spandsp_amd import engine
+    from oracle import ref
+    n_ch = args.channels or 65536
+    nf = 100
+    n_src = 512
+    src = torch.tensor(synth.cadence_plan_channels(n_src, nf*FRAME, 81, tc.PLANS), device=dev).view(n_src, nf, FRAME)
+    idx = torch.arange(n_ch, device=dev)
+    frames = src[idx % n_src].permute(1, 0, 2).contiguous()                 # [frame][channel][sample]
+    desc = ref.SuperToneDesc()
+    tc.build(desc)
+    hz = [400, 1100, 350, 440, 480, 620, 950, 1400, 1800]
+    bins = {0: -1}
+    bins.update({f: i for i, f in enumerate(hz)})
+    tones = [[(bins[f1], bins[f2], lo, hi) for f1, f2, lo, hi in t] for t in tc.TONES]
+    bank = engine.ToneBank(engine.SUPER_TONE, n_ch, bin_fac=[engine.goertzel_fac(float(f)) for f in hz])
+    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    bank.set_cadences(tones, want_segments=True)
+    addr = [ctypes.c_void_p(frames.data_ptr() + f*n_ch*FRAME*2) for f in range(nf)]
+
+    def timed(step, steps):
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for i in range(steps):
+            step(args.warmup + i)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0)/steps, ev0.elapsed_time(ev1)/steps
+
+    def detect(i):
+        bank.rx_device(addr[i % nf], FRAME, FRAME)
+
+    def tick(i):
+        bank.rx_device(addr[i % nf], FRAME, FRAME)
+        bank.cadence_run()
+
+    n_events = [0]
+
+    def tick_host(i):
+        bank.rx_device(addr[i % nf], FRAME, FRAME)
+        lst = ctypes.c_void_p()
+        n_events[0] += engine.lib().spangpu_bank_cadence_list(bank.h, ctypes.byref(lst))
+
+    reps = max(1, int(np.ceil(2000/args.steps)))
+    _, det_ms = timed(detect, args.steps*reps)
+    dt, tick_ms = timed(tick, args.steps*reps)
+    dt_host, _ = timed(tick_host, args.steps)
+    value = n_ch*FRAME/dt/1e6
+    alg_read = n_ch*(320 + 9*8 + 160)
+    cpu = None
+    if not args.no_cpu_baseline:
+        L = ref.lib()
+        n_cpu = min(args.cpu_channels, n_ch)
+        cpu = ref_baseline("super_tone_rx()", ref.MT_SUPER_TONE, lambda c: L.glue_super_tone_rx_new(desc.p, L.glue_sink_new(), 1), None,
+                           frames[:, :n_cpu].contiguous().cpu().numpy(), 1.0)
+    return {
+        "metric": "Msamples/s of a super-tone bank with its cadences matched on the device (8 kHz channels at real-time = value*1e6/8000)",
+        "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%d super-tone channels (9 monitored frequencies, 6 tones of 1-4 elements, segment reports on) x "
+                               "%d-sample frames: detector launch + cadence matcher launch per step" % (n_ch, FRAME),
+                   "channels_per_gpu": n_ch, "detector_only_us": det_ms*1e3, "detector_and_matcher_us": tick_ms*1e3,
+                   "with_event_list_on_the_host_ms": dt_host*1e3, "events_per_tick": n_events[0]/float(args.steps + args.warmup)},
+        "roofline": {"bound": "hbm", "kernel": "tone_fast_kernel<MultiDet> + cadence_kernel", "achieved": alg_read/(tick_ms*1e-3)/1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(tick_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
+                     "alg_read_bytes_per_launch": alg_read, "avg_launch_us": tick_ms*1e3,
+                     "note": "avg_launch_us is one step (both launches): events around the timed region / steps in it"},
+        "cpu_baseline": cpu}
+
+
 def bench_fsk(args, dev, stream):
     """a V.21 channel 2 receiver bank in synchronous mode (the FAX control channel), inputs in HBM."""
     import synth
@@ -779,7 +861,7 @@ def bench_dtmf_tx(args, dev, stream):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct", "sigtone", "fax_rx", "v29_tx", "awgn"], default="v29")
+    ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct", "sigtone", "supertone", "fax_rx", "v29_tx", "awgn"], default="v29")
     ap.add_argument("--channels", type=int, default=0)
     ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
@@ -816,6 +898,9 @@ def main():
         return
     if args.workload == "fax_rx":
         print(json.dumps(bench_fax_rx(args, dev, stream)))
+        return
+    if args.workload == "supertone":
+        print(json.dumps(bench_supertone(args, dev, stream)))
         return
     if args.workload == "sigtone":
         sys.path.insert(0, os.path.join(ROOT, "tests"))

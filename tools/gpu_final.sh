@@ -13,7 +13,7 @@ timeout 400 python $GRAFT_REPO_ROOT/bench.py --workload echo > $R/bench_echo.jso
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench_stats -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-e2e > $R/bench_stats.log 2>&1
 find $R/bench_stats -name "*kernel_stats.csv" -exec cp {} $R/bench_kernel_stats.csv \;
 cd $GRAFT_REPO_ROOT
-for w in mixed v29 v17 v27ter echo dtmf_tx fsk mct sigtone fax_rx v29_tx awgn; do
+for w in mixed v29 v17 v27ter echo dtmf_tx fsk mct sigtone supertone fax_rx v29_tx awgn; do
   timeout 500 python tools/bench_paths.py --workload $w > $R/paths/$w.json 2> $R/paths/$w.err; echo "$w rc=$?"
 done
 cat $R/smoke.log | tail -2; cat $R/pytest_gpu.log | tail -3; cat $R/bench.json; head -3 $R/bench_kernel_stats.csv
