@@ -217,17 +217,17 @@ SPANGPU_API int spangpu_bank_set_digits_ring(spangpu_bank_t *bank, void *dev_ptr
    tail of super_tone_chunk()) on the device, for callers that want tone reports and not block records.  The descriptor is
    given as super_tone_rx_add_tone() / _add_element() build it (src/super_tone_rx.c:125-162): tone_elems[t] = how many
    elements tone t has, elems = all of them in order, f1 / f2 = the BIN numbers the frequencies resolved to (-1 = none, the
-   numbering of the bank's bin_fac[]), min_ms / max_ms in milliseconds (max 0 = no upper limit); up to 255 tones of 1024
-   elements in all (the table is staged in LDS).  Giving cadences again
+   numbering of the bank's bin_fac[]), min_ms / max_ms in milliseconds (max 0 = no upper limit).  Giving cadences again
    replaces the tones and keeps every channel's run history.  Events of one launch, per channel in the order the reference
    would call back, two words each at events[(slot*n_channels + channel)*2], counts[channel] of them:
      word 0 = kind | (f1 + 1) << 8 | (f2 + 1) << 16 | block << 24, word 1 = tone (kind 1) or milliseconds (kind 3)
      SPANGPU_CADENCE_TONE_ON   tone_callback(user, tone, -10, 0): the newest runs spell out a tone
      SPANGPU_CADENCE_TONE_OFF  tone_callback(user, -1, -10, 0): the cadence followed broke
      SPANGPU_CADENCE_SEGMENT   segment_callback(user, f1, f2, ms): a run ended (only with want_segments)
-   spangpu_bank_cadence_run() queues the matcher over the records of the last spangpu_bank_rx*() on the bank's stream (once
-   per launch; every launch must be followed by it or by _events(), else its blocks are not counted) and returns the slots
-   per channel; spangpu_bank_cadence_events() does that if it was not done, waits and hands out pinned host copies;
+   The streaming detector kernel matches the cadences itself, in its epilogue; for launches it does not serve (sample-major
+   or unaligned frames, ragged lengths, more than 16 bins, spangpu_banks_rx()) spangpu_bank_cadence_run() queues a matcher
+   launch over the records of the last spangpu_bank_rx*() on the bank's stream (once per launch; every such launch must be
+   followed by it or by _events() / _list(), else its blocks are not counted).  It returns the slots per channel; spangpu_bank_cadence_events() does that if it was not done, waits and hands out pinned host copies;
    spangpu_bank_cadence_device() the device buffers themselves (for a gather). */
 #define SPANGPU_CADENCE_TONE_ON     1
 #define SPANGPU_CADENCE_TONE_OFF    2

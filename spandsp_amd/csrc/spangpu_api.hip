@@ -149,11 +149,27 @@ constexpr int kFastWPB = 4;
 constexpr int kRingLoader = 2;          // segment slots per consumer wave, kernels with a loader wave
 constexpr int kRingSelf = 2;            // ... kernels whose waves fetch for themselves (three slots measured slower: r2_probe.log)
 
+template <class Det> struct is_super_tone { static constexpr bool value = false; };
+template <int N> struct is_super_tone<MultiDet<N, true>> { static constexpr bool value = true; };
+static bool g_cadence_fused = false;    // the launch just made matched the cadences in its epilogue
+
 template <class Det, int LPC, bool G711>
 static void launch_fast(const ToneLaunch &L, hipStream_t st, bool loader)
 {
     const int waves = (L.n_ch + kWave/LPC - 1)/(kWave/LPC);
     const int blocks = (waves + kFastWPB - 1)/kFastWPB;
+    if constexpr (is_super_tone<Det>::value  &&  LPC == 1  &&  !G711)
+    {
+        if (L.cad.state)
+        {
+            if (loader)
+                launch_tone_fast<Det, 1, kRingLoader, false, false, kFastWPB, kToneCadence, true>(L, blocks, st);
+            else
+                launch_tone_fast<Det, 1, kRingSelf, false, false, kFastWPB, kToneCadence, false>(L, blocks, st);
+            g_cadence_fused = true;
+            return;
+        }
+    }
     if constexpr (Det::kDigits)
     {
         // a launch that also reports one digit byte per block runs the variant with those stores compiled in
@@ -266,24 +282,7 @@ __global__ __launch_bounds__(256) void digit_events_kernel(const uint32_t *rec, 
 }
 
 
-// ---- super-tone cadences on the device --------------------------------------------------------------------------------
-// What super_tone_rx.c:164-228 and :364-448 decide from the stream of per-block bin pairs (k1, k2): which run of equal
-// pairs is current, when it ended (the pair seen twice in a row differs from it), whether the cadence being followed is
-// still alive, and whether the newest runs spell out one of the descriptor's tones.  One lane per channel walks the
-// records of the last launch (one or two blocks of a 160-sample frame).  The history of the ten newest runs is kept newest
-// first, so that "the run j places back" is register j: it is read in one go (24 coalesced words in flight together),
-// shifted down when a run ends (a few times a second) and only what changed is written back.  Window limits are kept in
-// blocks (lo <= 128 b  <=>  b >= ceil(lo/128)), which makes every test a 32-bit compare.
-//   state words: 0 seen f1, 1 seen f2, 2 tone followed (-1 none), 3 turn, 4..13 run pair (f1 & 0xFFFF | f2 << 16), newest
-//   first, 14..23 run length in blocks.
-// Events, in the order the reference calls back: two words each at ev[(slot*n_ch + ch)*2]:
-//   word 0 = kind | (f1 + 1) << 8 | (f2 + 1) << 16 | block << 24, word 1 = tone number (kind 1) or milliseconds (kind 3);
-//   kind 1 = tone recognised (tone_callback(user, tone, -10, 0)), 2 = tone lost (tone_callback(user, -1, -10, 0)),
-//   3 = a segment ended (segment_callback(user, f1, f2, ms)).
-static constexpr int kCadHistory = 10;
-static constexpr int kCadWords = 4 + 2*kCadHistory;
-static constexpr int kCadSlotsPerBlock = 3;
-
+// ---- super-tone cadences on the device (cadence_dev.hpp has the walk) ---------------------------------------------------
 struct Cadence
 {
     int n_tones;
@@ -303,12 +302,11 @@ struct Cadence
     int segments;
     unsigned done_serial;   // the launch whose records were matched last
     int last_slots;
+    bool fused;             // the last detector launch matched the cadences itself (tone_fast.hpp, kToneCadence)
+    bool list_due;          // ... and the compact list of its events has not been made yet
 };
 
-__host__ __device__ static inline int32_t cad_pair(int f1, int f2)
-{
-    return (int32_t) (((uint32_t) f1 & 0xFFFFu) | ((uint32_t) f2 << 16));
-}
+static void cadence_args(const spangpu_bank_s *b, const Cadence *c, CadenceArgs &A, int which);
 
 __global__ __launch_bounds__(256) void cadence_init_kernel(int32_t *st, int n_ch, int first, int n)
 {
@@ -320,207 +318,53 @@ __global__ __launch_bounds__(256) void cadence_init_kernel(int32_t *st, int n_ch
         st[(size_t) w*n_ch + ch] = (w == 3  ||  w >= 4 + kCadHistory)  ?  0  :  -1;
 }
 
-static constexpr int kCadMaxTones = 255;
-static constexpr int kCadMaxElems = 1024;
-
-// The descriptor (a few dozen elements as a rule) is copied to LDS first: the walk over it is a chain of dependent reads,
-// and from global memory each link costs a trip to the L2.
-__global__ __launch_bounds__(256) void cadence_kernel(const uint32_t *__restrict__ rec, int n_ch, int maxb, const int32_t *__restrict__ g_first,
-                                                      const int4 *__restrict__ g_elem, int n_tones, int n_elems, int32_t *__restrict__ st,
-                                                      uint32_t *__restrict__ ev, int32_t *__restrict__ count, int segments, uint32_t *list,
-                                                      uint32_t list_cap, int which)
+// A launch of its own over the records of the last detector launch (whatever kernel made them).
+__global__ __launch_bounds__(256) void cadence_kernel(const uint32_t *__restrict__ rec, int n_ch, int maxb, const CadenceArgs A)
 {
-    extern __shared__ int4 cad_lds[];
-    int4 *elem = cad_lds;
-    int32_t *first = (int32_t *) (cad_lds + n_elems);
-    for (int i = (int) threadIdx.x;  i < n_elems;  i += 256)
-        elem[i] = g_elem[i];
-    for (int i = (int) threadIdx.x;  i <= n_tones;  i += 256)
-        first[i] = g_first[i];
     __shared__ uint32_t wg_events;
     __shared__ uint32_t wg_at;
-    __shared__ uint32_t wg_ev[2*kCadSlotsPerBlock][2][256];     // the events of a 160-sample frame, for the compact list
     if (threadIdx.x == 0)
         wg_events = 0;
     __syncthreads();
     // lanes past the end of the bank walk the last channel again and write nothing (they have barriers to keep)
     const bool active = ((int) (blockIdx.x*256 + threadIdx.x) < n_ch);
     const int ch = active  ?  (int) (blockIdx.x*256 + threadIdx.x)  :  n_ch - 1;
-    int32_t pf[kCadHistory];
-    int32_t bl[kCadHistory];
-    int32_t w0[4];
-#pragma unroll
-    for (int i = 0;  i < 4;  i++)
-        w0[i] = st[(size_t) i*n_ch + ch];
-#pragma unroll
-    for (int i = 0;  i < kCadHistory;  i++)
-    {
-        pf[i] = st[(size_t) (4 + i)*n_ch + ch];
-        bl[i] = st[(size_t) (4 + kCadHistory + i)*n_ch + ch];
-    }
     // the records of a 160-sample frame (one or two blocks) are asked for along with the state: one trip to memory in all
     const uint32_t rec0 = (maxb > 0)  ?  rec[ch]  :  0;
     const uint32_t rec1 = (maxb > 1)  ?  rec[(size_t) n_ch + ch]  :  0;
-    int seen1 = w0[0];
-    int seen2 = w0[1];
-    int tone = w0[2];
-    int turn = w0[3];
-    bool shifted = false;
-    bool touched = false;
-    int n_ev = 0;
-    int blk = 0;
-    auto emit = [&](uint32_t kind, int32_t pair, int32_t v)
-    {
-        if (!active)
-            return;
-        uint32_t *e = ev + ((size_t) n_ev*n_ch + ch)*2;
-        const int f1 = (int) (int16_t) (pair & 0xFFFF);
-        const int f2 = pair >> 16;
-        e[0] = kind | ((uint32_t) ((f1 + 1) & 0xFF) << 8) | ((uint32_t) ((f2 + 1) & 0xFF) << 16) | ((uint32_t) blk << 24);
-        e[1] = (uint32_t) v;
-        if (n_ev < 2*kCadSlotsPerBlock)
-        {
-            wg_ev[n_ev][0][threadIdx.x] = e[0];
-            wg_ev[n_ev][1][threadIdx.x] = (uint32_t) v;
-        }
-        n_ev++;
-    };
-    auto fits = [&](const int4 &e, int32_t pair, int32_t blocks) { return e.x == pair  &&  e.y <= blocks  &&  blocks <= e.z; };
-    // Is the cadence followed still alive?  `turn` elements of it have gone by since it was recognised (on its last element),
-    // so the current run must be element (turn - 1) mod n and not yet too long; when a run has just ended, the one before
-    // it must in addition have been a proper element (turn - 2) mod n.
-    auto alive = [&](int t, int turn_now, bool run_ended)
-    {
-        const int e0 = first[t];
-        const int n = first[t + 1] - e0;
-        if (n <= 0)
-            return false;
-        if (run_ended  &&  !fits(elem[e0 + (turn_now + n - 2)%n], pf[1], bl[1]))
-            return false;
-        const int4 e = elem[e0 + (turn_now + n - 1)%n];
-        return e.x == pf[0]  &&  bl[0] <= e.z;
-    };
-    for (blk = 0;  blk < maxb;  blk++)
-    {
-        const uint32_t w = (blk == 0)  ?  rec0  :  (blk == 1)  ?  rec1  :  rec[(size_t) blk*n_ch + ch];
-        if (!((w >> 16) & kBlkValid))
-            continue;
-        touched = true;
-        const int k1 = (int) (w & 0xFF) - 1;
-        const int k2 = (int) ((w >> 8) & 0xFF) - 1;
-        const int32_t pair = cad_pair(k1, k2);
-        const bool repeat = (k1 == seen1  &&  k2 == seen2);
-        seen1 = k1;
-        seen2 = k2;
-        if (!repeat)
-        {
-            // a pair seen for the first time may be a glitch: the block still counts towards the current run
-            bl[0]++;
-        }
-        else if (pair != pf[0])
-        {
-            // seen twice in a row and not what the current run is made of: that run is over
-            if (tone >= 0)
-            {
-                const int t_now = turn++;
-                if (!alive(tone, t_now, true))
-                {
-                    tone = -1;
-                    emit(2, -1, -1);
-                }
-            }
-            if (segments)
-                emit(3, pf[0], (int32_t) ((uint32_t) bl[0]*16u));
-#pragma unroll
-            for (int i = kCadHistory - 1;  i > 0;  i--)
-            {
-                pf[i] = pf[i - 1];
-                bl[i] = bl[i - 1];
-            }
-            pf[0] = pair;
-            bl[0] = 1;
-            shifted = true;
-        }
-        else
-        {
-            // more of the same (tested before this block is counted, as the reference does)
-            if (tone >= 0  &&  !alive(tone, turn, false))
-            {
-                tone = -1;
-                emit(2, -1, -1);
-            }
-            bl[0]++;
-        }
-        if (tone >= 0)
-            continue;
-        // do the newest runs spell out a whole cadence, the current run being its last element?
-        for (int t = 0;  t < n_tones;  t++)
-        {
-            const int e0 = first[t];
-            const int n = first[t + 1] - e0;
-            if (n > kCadHistory)
-                continue;
-            bool ok = true;
-#pragma unroll
-            for (int j = 0;  j < kCadHistory;  j++)
-            {
-                if (j < n)
-                    ok = ok  &&  fits(elem[e0 + n - 1 - j], pf[j], bl[j]);
-            }
-            if (ok)
-            {
-                tone = t;
-                turn = 0;
-                emit(1, -1, t);
-                break;
-            }
-        }
-    }
-    if (active)
-        count[ch] = n_ev;
+    const int n_ev = cadence_walk(A, ch, n_ch, maxb, rec0, rec1, rec, active);
     // the compact list: the workgroup takes room for all its events with one atomic on the list's counter (thousands of lanes
-    // adding to one address cost more than the rest of the kernel), each channel a piece of that, so that a channel's events
-    // stay together and in order
+    // adding to one address cost more than the rest of the kernel), each channel a piece of that
     const uint32_t mine = (n_ev > 0)  ?  atomicAdd(&wg_events, (uint32_t) n_ev)  :  0;
     __syncthreads();
     if (threadIdx.x == 0  &&  wg_events > 0)
-        wg_at = atomicAdd(list + which, wg_events);
+        wg_at = atomicAdd(A.list + A.which, wg_events);
     if (blockIdx.x == 0  &&  threadIdx.x == 0)
-        list[which ^ 1] = 0;                    // the next launch's counter (it starts when this one is over)
+        A.list[A.which ^ 1] = 0;                // the next launch's counter (it starts when this one is over)
     __syncthreads();
     if (n_ev > 0)
-    {
-        const uint32_t at = wg_at + mine;
-        for (int k = 0;  k < n_ev;  k++)
-        {
-            if (at + k < list_cap)
-            {
-                const uint32_t *e = ev + ((size_t) k*n_ch + ch)*2;
-                uint32_t *o = list + 2 + (size_t) (at + k)*3;
-                const bool staged = (k < 2*kCadSlotsPerBlock);
-                o[0] = (uint32_t) ch;
-                o[1] = staged  ?  wg_ev[staged  ?  k  :  0][0][threadIdx.x]  :  e[0];
-                o[2] = staged  ?  wg_ev[staged  ?  k  :  0][1][threadIdx.x]  :  e[1];
-            }
-        }
-    }
-    if (!touched  ||  !active)
-        return;
-    st[(size_t) 0*n_ch + ch] = seen1;
-    st[(size_t) 1*n_ch + ch] = seen2;
-    st[(size_t) 2*n_ch + ch] = tone;
-    st[(size_t) 3*n_ch + ch] = turn;
-    st[(size_t) 4*n_ch + ch] = pf[0];
-    st[(size_t) (4 + kCadHistory)*n_ch + ch] = bl[0];
-    if (shifted)
-    {
-#pragma unroll
-        for (int i = 1;  i < kCadHistory;  i++)
-        {
-            st[(size_t) (4 + i)*n_ch + ch] = pf[i];
-            st[(size_t) (4 + kCadHistory + i)*n_ch + ch] = bl[i];
-        }
-    }
+        cadence_list_copy(A, ch, n_ch, n_ev, wg_at + mine);
+}
+
+// The compact list from the slot arrays, for launches whose detector kernel matched the cadences itself.
+__global__ __launch_bounds__(256) void cadence_list_kernel(int n_ch, const CadenceArgs A)
+{
+    __shared__ uint32_t wg_events;
+    __shared__ uint32_t wg_at;
+    if (threadIdx.x == 0)
+        wg_events = 0;
+    __syncthreads();
+    const int ch = (int) (blockIdx.x*256 + threadIdx.x);
+    const int n_ev = (ch < n_ch)  ?  A.count[ch]  :  0;
+    const uint32_t mine = (n_ev > 0)  ?  atomicAdd(&wg_events, (uint32_t) n_ev)  :  0;
+    __syncthreads();
+    if (threadIdx.x == 0  &&  wg_events > 0)
+        wg_at = atomicAdd(A.list + A.which, wg_events);
+    if (blockIdx.x == 0  &&  threadIdx.x == 0)
+        A.list[A.which ^ 1] = 0;
+    __syncthreads();
+    if (n_ev > 0)
+        cadence_list_copy(A, ch, n_ch, n_ev, wg_at + mine);
 }
 
 static void cadence_free(Cadence *c)
@@ -843,6 +687,16 @@ static void fill_launch(ToneLaunch &L, spangpu_bank_t *b, const int16_t *d_amp, 
     L.si = b->si;
     L.rec = b->ext_rec  ?  b->ext_rec  :  b->rec;
     b->cur_rec = L.rec;
+    memset(&L.cad, 0, sizeof(L.cad));
+    if (b->cad)
+    {
+        // the streaming kernel matches the cadences in its epilogue when the event buffers hold this launch's slots and
+        // every channel takes part (launch_fast() decides; any other kernel leaves them to cadence_kernel)
+        b->cad->fused = false;
+        b->cad->list_due = false;
+        if (kCadSlotsPerBlock*maxb <= b->cad->slots_cap  &&  maxb > 0  &&  b->next_lens == nullptr  &&  !force_end)
+            cadence_args(b, b->cad, L.cad, b->cad->which ^ 1);
+    }
     L.rec_energy = b->rec_energy;
     L.rec_dur = b->rec_dur;
     L.trace = b->trace;
@@ -865,6 +719,7 @@ static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stri
 
     if (b->timing)
         HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    g_cadence_fused = false;
     switch (b->kind)
     {
     case SPANGPU_DTMF:
@@ -905,6 +760,11 @@ static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stri
         return fail(SPANGPU_ERR_UNSUPPORTED, "kind %d", b->kind);
     }
     HIP_TRY(hipGetLastError());
+    if (b->cad  &&  g_cadence_fused)
+    {
+        b->cad->fused = true;
+        b->cad->list_due = true;
+    }
     if (b->timing)
     {
         HIP_TRY(hipEventRecord(b->ev1, b->stream));
@@ -1656,6 +1516,50 @@ int spangpu_bank_reset_channel(spangpu_bank_t *b, int channel, int fillin_only)
     return spangpu_bank_set_state(b, channel, f, b->nsf, w, 4);
 }
 
+}   // extern "C"
+
+static void cadence_args(const spangpu_bank_s *b, const Cadence *c, CadenceArgs &A, int which)
+{
+    A.first = c->d_first;
+    A.elem = c->d_elem;
+    A.state = c->d_state;
+    A.ev = c->d_ev;
+    A.count = c->d_count;
+    A.list = c->d_list;
+    A.list_cap = (uint32_t) ((size_t) c->slots_cap*b->n_ch);
+    A.n_tones = c->n_tones;
+    A.segments = c->segments;
+    A.which = which;
+}
+
+// Event buffers for launches of up to `slots` slots per channel.
+static int cadence_event_room(spangpu_bank_t *b, int slots)
+{
+    Cadence *c = b->cad;
+    if (slots <= c->slots_cap)
+        return SPANGPU_OK;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (c->d_ev) (void) hipFree(c->d_ev);
+    if (c->h_ev) (void) hipHostFree(c->h_ev);
+    if (c->d_list) (void) hipFree(c->d_list);
+    if (c->h_list) (void) hipHostFree(c->h_list);
+    c->d_ev = nullptr;
+    c->h_ev = nullptr;
+    c->d_list = nullptr;
+    c->h_list = nullptr;
+    c->slots_cap = 0;
+    HIP_TRY(hipMalloc(&c->d_ev, (size_t) slots*b->n_ch*2*sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc(&c->h_ev, (size_t) slots*b->n_ch*2*sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&c->d_list, ((size_t) slots*b->n_ch*3 + 2)*sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc(&c->h_list, ((size_t) slots*b->n_ch*3 + 2)*sizeof(uint32_t)));
+    HIP_TRY(hipMemset(c->d_list, 0, 2*sizeof(uint32_t)));
+    c->which = 0;
+    c->slots_cap = slots;
+    return SPANGPU_OK;
+}
+
+extern "C" {
+
 // ---- super-tone cadences (src/super_tone_rx.c:164-228, :364-448) on the device ------------------------------------------
 int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int n_tones, const spangpu_cadence_elem_t *elems,
                               int want_segments)
@@ -1674,8 +1578,6 @@ int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int 
         first[t + 1] = first[t] + tone_elems[t];
     }
     const int n_elems = first[n_tones];
-    if (n_tones > kCadMaxTones  ||  n_elems > kCadMaxElems)
-        return fail(SPANGPU_ERR_UNSUPPORTED, "a bank matches up to %d tones of %d elements in all", kCadMaxTones, kCadMaxElems);
     std::vector<int4> el(n_elems > 0  ?  n_elems  :  1);
     for (int i = 0;  i < n_elems;  i++)
     {
@@ -1704,6 +1606,9 @@ int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int 
         hipLaunchKernelGGL(cadence_init_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, b->stream, c->d_state, b->n_ch, 0, b->n_ch);
         c->done_serial = b->launch_serial;      // what was received before now is not matched
         b->cad = c;
+        const int rc = cadence_event_room(b, kCadSlotsPerBlock*((b->maxb_cap > 2)  ?  b->maxb_cap  :  2));
+        if (rc != SPANGPU_OK)
+            return rc;
     }
     if (c->d_first) (void) hipFree(c->d_first);
     if (c->d_elem) (void) hipFree(c->d_elem);
@@ -1731,33 +1636,25 @@ int spangpu_bank_cadence_run(spangpu_bank_t *b)
         return c->last_slots;
     HIP_TRY(hipSetDevice(b->device));
     const int slots = kCadSlotsPerBlock*b->last_maxb;
-    if (slots > c->slots_cap)
+    if (c->fused)
     {
-        HIP_TRY(hipStreamSynchronize(b->stream));
-        if (c->d_ev) (void) hipFree(c->d_ev);
-        if (c->h_ev) (void) hipHostFree(c->h_ev);
-        c->d_ev = nullptr;
-        c->h_ev = nullptr;
-        c->slots_cap = 0;
-        if (c->d_list) (void) hipFree(c->d_list);
-        if (c->h_list) (void) hipHostFree(c->h_list);
-        c->d_list = nullptr;
-        c->h_list = nullptr;
-        HIP_TRY(hipMalloc(&c->d_ev, (size_t) slots*b->n_ch*2*sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(&c->h_ev, (size_t) slots*b->n_ch*2*sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&c->d_list, ((size_t) slots*b->n_ch*3 + 2)*sizeof(uint32_t)));
-        HIP_TRY(hipHostMalloc(&c->h_list, ((size_t) slots*b->n_ch*3 + 2)*sizeof(uint32_t)));
-        HIP_TRY(hipMemset(c->d_list, 0, 2*sizeof(uint32_t)));
-        c->which = 0;
-        c->slots_cap = slots;
+        // the detector launch did it
+        c->fused = false;
+        c->done_serial = b->launch_serial;
+        c->last_slots = slots;
+        return slots;
     }
+    const int rc = cadence_event_room(b, slots);
+    if (rc != SPANGPU_OK)
+        return rc;
     if (b->last_maxb > 0)
     {
+        CadenceArgs A;
         c->which ^= 1;
-        hipLaunchKernelGGL(cadence_kernel, dim3((b->n_ch + 255)/256), dim3(256), (size_t) c->n_elems*sizeof(int4) + (c->n_tones + 1)*sizeof(int32_t),
-                           b->stream, (const uint32_t *) (b->cur_rec  ?  b->cur_rec  :  b->rec), b->n_ch, b->last_maxb,
-                           (const int32_t *) c->d_first, (const int4 *) c->d_elem, c->n_tones, c->n_elems, c->d_state, c->d_ev, c->d_count,
-                           c->segments, c->d_list, (uint32_t) ((size_t) c->slots_cap*b->n_ch), c->which);
+        c->list_due = false;
+        cadence_args(b, c, A, c->which);
+        hipLaunchKernelGGL(cadence_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, b->stream,
+                           (const uint32_t *) (b->cur_rec  ?  b->cur_rec  :  b->rec), b->n_ch, b->last_maxb, A);
         HIP_TRY(hipGetLastError());
     }
     else
@@ -1794,6 +1691,15 @@ int spangpu_bank_cadence_list(spangpu_bank_t *b, const uint32_t **list)
     Cadence *c = b->cad;
     if (slots == 0  ||  c->d_list == nullptr  ||  b->last_maxb <= 0)
         return 0;
+    if (c->list_due)
+    {
+        CadenceArgs A;
+        c->which ^= 1;
+        c->list_due = false;
+        cadence_args(b, c, A, c->which);
+        hipLaunchKernelGGL(cadence_list_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, b->stream, b->n_ch, A);
+        HIP_TRY(hipGetLastError());
+    }
     // as a rule a tick has few reports: one small copy brings the counters and the first of them
     const size_t cap = (size_t) c->slots_cap*b->n_ch;
     const size_t first = (cap < 4096)  ?  cap  :  4096;

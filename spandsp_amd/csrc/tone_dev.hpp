@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <limits.h>
+#include "cadence_dev.hpp"
 
 namespace spg {
 
@@ -72,6 +73,8 @@ struct ToneLaunch
     int lens_ragged;            // host side only: lengths other than 0 and `samples` occur (the general kernel takes the call)
     const float *chan_parms;    // nullptr: threshold / twists / dial tone filter as set for the bank; else DTMF
                                 // per channel, [4][n_ch]: threshold, normal twist, reverse twist, filter on (0 / 1)
+    CadenceArgs cad;            // super-tone: cad.state != nullptr has the streaming kernel built with kToneCadence match
+                                // the cadences in its epilogue (cadence_dev.hpp)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -314,6 +317,7 @@ __device__ __forceinline__ void write_trace(const ToneLaunch &L, const float (&e
 
 // The digit a block delivered, as one byte (0 = none): DTMF = the debouncer accepted a digit (dtmf.c:318-340: a change to
 // a non-zero code), the MF detectors = the digit of a report (Bell MF: accepted, R2 MF: changed).
+constexpr int kToneCadence = 8192;     // ABL bit: the super-tone cadence epilogue is compiled in (tone_fast.hpp)
 constexpr int kToneDigits = 4096;       // ABL bit: the digit-byte stores are compiled in (a variant of its own: with the
                                         // stores merely switched by a pointer test the plain kernel ran 4 % slower)
 

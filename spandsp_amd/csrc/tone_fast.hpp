@@ -768,6 +768,19 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
                 L.digits[(size_t) b*nch + ch] = 0;
         }
     }
+    if constexpr ((ABL & kToneCadence) != 0)
+    {
+        // Super-tone cadences: the lane that made a channel's records walks them here, before the wave ends -- a launch of
+        // its own for this costs 10 us at 65 536 channels, nearly all of it latency that overlaps nothing.
+        if (L.cad.state)
+        {
+            if (L.maxb > 2)
+                __threadfence_block();          // records past the second were stored by end_block(): read them back whole
+            // (the compact list is made on demand by cadence_list_kernel: an atomic per wave on its counter, a thousand of
+            // them on one address, took longer here than the whole walk)
+            (void) cadence_walk(L.cad, (int) ch, (int) nch, L.maxb, rec0, rec1, L.rec, store  &&  keep);
+        }
+    }
     stamp(15);
 }
 
