@@ -99,9 +99,18 @@ def test_cadences_on_the_device_against_the_oracle(built, segments):
     sd.close()
 
 
-def test_cadences_given_as_bins_var_lengths_reset_and_state(built):
+@pytest.fixture(params=[0, 1, 3], ids=["auto", "general kernel + cadence_kernel", "streaming, no loader waves"])
+def tone_variant(request):
+    from spandsp_amd import engine
+    engine.tune_tone_kernel(request.param)
+    yield request.param
+    engine.tune_tone_kernel(0)
+
+
+def test_cadences_given_as_bins_var_lengths_reset_and_state(built, tone_variant):
     """The plain entry point (bins and milliseconds), ragged frame lengths, a channel reset mid-call, the state words out and
-    back in, and a second set of cadences given to a live bank."""
+    back in, and a second set of cadences given to a live bank -- with the cadences matched in the streaming kernels'
+    epilogue and (general detector kernel) by a launch of cadence_kernel."""
     from oracle import restated as orc
     from spandsp_amd import engine
     n_ch = 70
