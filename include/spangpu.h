@@ -218,7 +218,8 @@ SPANGPU_API int spangpu_bank_set_digits_ring(spangpu_bank_t *bank, void *dev_ptr
    given as super_tone_rx_add_tone() / _add_element() build it (src/super_tone_rx.c:125-162): tone_elems[t] = how many
    elements tone t has, elems = all of them in order, f1 / f2 = the BIN numbers the frequencies resolved to (-1 = none, the
    numbering of the bank's bin_fac[]), min_ms / max_ms in milliseconds (max 0 = no upper limit).  Giving cadences again
-   replaces the tones and keeps every channel's run history.  Events of one launch, per channel in the order the reference
+   replaces the tones and keeps every channel's run history (a tone being followed is forgotten: its number belongs to
+   the old set).  Events of one launch, per channel in the order the reference
    would call back, two words each at events[(slot*n_channels + channel)*2], counts[channel] of them:
      word 0 = kind | (f1 + 1) << 8 | (f2 + 1) << 16 | block << 24, word 1 = tone (kind 1) or milliseconds (kind 3)
      SPANGPU_CADENCE_TONE_ON   tone_callback(user, tone, -10, 0): the newest runs spell out a tone

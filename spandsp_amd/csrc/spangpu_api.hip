@@ -151,7 +151,7 @@ constexpr int kRingSelf = 2;            // ... kernels whose waves fetch for the
 
 template <class Det> struct is_super_tone { static constexpr bool value = false; };
 template <int N> struct is_super_tone<MultiDet<N, true>> { static constexpr bool value = true; };
-static bool g_cadence_fused = false;    // the launch just made matched the cadences in its epilogue
+static thread_local bool g_cadence_fused = false;   // the launch this thread just made matched the cadences in its epilogue
 
 template <class Det, int LPC, bool G711>
 static void launch_fast(const ToneLaunch &L, hipStream_t st, bool loader)
@@ -1618,6 +1618,12 @@ int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int 
     HIP_TRY(hipMalloc(&c->d_elem, el.size()*sizeof(int4)));
     HIP_TRY(hipMemcpy(c->d_first, first.data(), first.size()*sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_elem, el.data(), el.size()*sizeof(int4), hipMemcpyHostToDevice));
+    if (!fresh)
+    {
+        // the tone numbers of the old set mean nothing in the new one: nobody is following a tone (the run histories stay)
+        HIP_TRY(hipMemsetAsync(c->d_state + (size_t) 2*b->n_ch, 0xFF, (size_t) b->n_ch*sizeof(int32_t), b->stream));
+        HIP_TRY(hipMemsetAsync(c->d_state + (size_t) 3*b->n_ch, 0, (size_t) b->n_ch*sizeof(int32_t), b->stream));
+    }
     c->n_tones = n_tones;
     c->n_elems = n_elems;
     c->segments = want_segments  ?  1  :  0;

@@ -155,8 +155,13 @@ def test_cadences_given_as_bins_var_lengths_reset_and_state(built, tone_variant)
         pos += n
         k += 1
     assert total > 5*n_ch
-    # no tones at all: segments only
+    # no tones at all: nobody follows a tone any more (the numbers belonged to the old set), segments only
     bank.set_cadences([], want_segments=True)
+    assert all(bank.cadence_get_state(c)[2] == -1 for c in range(0, n_ch, 7))
+    for _ in range(3):
+        bank.rx_host(np.zeros((n_ch, 160), np.int16))
+        ev = bank.cadence_events()
+        assert all(e[0] == 4 for c in range(n_ch) for e in ev[c])
     with pytest.raises(Exception):
         engine.ToneBank(engine.DTMF, 4).set_cadences(tones)
     with pytest.raises(Exception):
