@@ -479,6 +479,9 @@ def bench_supertone(args, dev, stream):
     src = torch.tensor(synth.cadence_plan_channels(n_src, nf*FRAME, 81, tc.PLANS), device=dev).view(n_src, nf, FRAME)
     idx = torch.arange(n_ch, device=dev)
     frames = src[idx % n_src].permute(1, 0, 2).contiguous()                 # [frame][channel][sample]
+    quiet = float(os.environ.get("SUPERTONE_QUIET", "0"))                   # fraction of the lines that stay silent
+    if quiet > 0.0:
+        frames[:, (idx % 100) < int(100*quiet), :] = 0
     desc = ref.SuperToneDesc()
     tc.build(desc)
     hz = [400, 1100, 350, 440, 480, 620, 950, 1400, 1800]
@@ -536,7 +539,7 @@ def bench_supertone(args, dev, stream):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%d super-tone channels (9 monitored frequencies, 6 tones of 1-4 elements, segment reports on) x "
-                               "%d-sample frames: one launch per step, the cadences matched in the detector kernel's epilogue" % (n_ch, FRAME),
+                               "%d-sample frames: one launch per step, the cadences matched in the detector kernel's epilogue%s" % (n_ch, FRAME, (", %d %% of the lines silent" % int(100*quiet)) if quiet > 0.0 else ""),
                    "channels_per_gpu": n_ch, "detector_only_us": det_ms*1e3, "detector_and_matcher_us": tick_ms*1e3,
                    "with_event_list_on_the_host_ms": dt_host*1e3, "events_per_tick": n_events[0]/float(args.steps + args.warmup)},
         "roofline": {"bound": "hbm", "kernel": "tone_fast_kernel<MultiDet<12, true>, ..., kToneCadence> (detector + cadence epilogue)", "achieved": alg_read/(tick_ms*1e-3)/1e9,
