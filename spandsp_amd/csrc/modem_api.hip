@@ -11,12 +11,15 @@
 #include "../../include/spangpu.h"
 #include "modem_tables.h"
 #include "v29_dev.hpp"
+#include "v29_quad.hpp"
 #include "v27ter_dev.hpp"
 #include "v17_dev.hpp"
 
 using namespace spg;
 
 extern "C" int spangpu_set_error(int code, const char *msg);
+
+static int g_modem_mapping = 0;
 
 #define V29_TRY(expr)                                                                       \
     do                                                                                      \
@@ -202,6 +205,16 @@ int spangpu_modem_state_words(int kind, int *n_floats, int *n_ints)
     if (n_floats) *n_floats = nf;
     if (n_ints) *n_ints = ni;
     return nf + ni;
+}
+
+// Tuning / A-B testing: how the receiver kernels map channels to lanes from now on (0 = by bank size; 1 = one channel
+// per lane; 4 / 8 = four lanes per channel with 16 / 8 channels per wave, V.29 only so far).  Results are identical.
+int spangpu_tune_modem_mapping(int mapping)
+{
+    if (mapping != 0  &&  mapping != 1  &&  mapping != 4  &&  mapping != 8)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "modem mapping must be 0 (auto), 1, 4 or 8");
+    g_modem_mapping = mapping;
+    return SPANGPU_OK;
 }
 
 int spangpu_modem_create(spangpu_modem_t **out, int device, int kind, int n_channels, int bit_rate)
@@ -468,6 +481,9 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
     }
     // enough workgroups to put a wave on every SIMD (256 CUs x 4) before filling the waves
     const int cpw = (m->n_ch >= 64*1024)  ?  64  :  (m->n_ch >= 32*1024)  ?  32  :  16;
+    // lanes per channel: 1 = the one-channel-per-lane kernels, 4 = a quad per channel with 16 channels per wave,
+    // 8 = a quad per channel with 8 channels per wave (two waves per SIMD); spangpu_tune_modem_mapping() overrides
+    const int quad = (g_modem_mapping != 0)  ?  g_modem_mapping  :  (m->n_ch < 32*1024)  ?  4  :  1;
     const dim3 grid((m->n_ch + cpw - 1)/cpw);
     if (m->kind == SPANGPU_V29)
     {
@@ -494,6 +510,17 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
             // LDS per workgroup, one workgroup per CU, a wave on every SIMD (v29_dev.hpp)
             const int waves = (m->n_ch + 63)/64;
             hipLaunchKernelGGL((v29_bank_kernel<64, false, 4, 16, true>), dim3((waves + 3)/4), dim3(256), 0, m->stream, L);
+        }
+        else if (quad == 4)
+        {
+            // banks that cannot fill the chip's 1 024 SIMDs with full waves of one channel per lane: four lanes per
+            // channel, 16 channels per wave, four waves per workgroup sharing the tables (v29_quad.hpp)
+            hipLaunchKernelGGL((v29_quad_kernel<16, 4>), dim3((m->n_ch + 63)/64), dim3(256), 0, m->stream, L);
+        }
+        else if (quad == 8)
+        {
+            // the same with eight channels per wave, eight waves per workgroup: two waves per SIMD
+            hipLaunchKernelGGL((v29_quad_kernel<8, 8>), dim3((m->n_ch + 63)/64), dim3(512), 0, m->stream, L);
         }
         else if (cpw == 32)
             hipLaunchKernelGGL(v29_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);

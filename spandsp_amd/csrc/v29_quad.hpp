@@ -1,0 +1,946 @@
+// v29_quad.hpp -- the V.29 receiver with FOUR LANES PER CHANNEL (reference: src/v29rx.c:400-965, src/godard.c:144-220,
+// src/vector_float.c:890-939, src/complex_vector_float.c:137-219; state word map and helpers: v29_common.hpp).
+//
+// Why: a bank of 16 384 channels (BASELINE configs[3]) is 16 channels per SIMD.  With one channel per lane
+// (v29_dev.hpp) a lone wave per SIMD walks the whole receiver -- about 670 instructions per sample -- with 16 of its 64
+// lanes alive, and the launch takes as long as that one instruction stream.  Here a channel owns a DPP quad, and the
+// work of one baud is dealt over its four lanes wherever the reference's arithmetic leaves a choice:
+//   * a ROUND of the main loop is one baud of a channel: its three or four samples are taken together.  Lane r owns
+//     sample r of the round: it forms that sample's root raised cosine inner products, real and imaginary at once
+//     (27 taps, two independent chains of packed multiply-adds on the same delay line window: the two parts of
+//     vec_circular_dot_prodf() ride in the halves of a packed register, as in v29_dev.hpp).  The polyphase row of every
+//     sample of a baud is known when the baud starts, because only the baud's own timing decision moves it;
+//   * the four windows of a round differ by one sample each.  The delay line keeps the reference's 27 entry ring: the
+//     three oldest taps of each lane's window are read BEFORE the round's samples are written over them, the other 24
+//     after;
+//   * the T/2 spaced equaliser input of the (two) T/2 instants of the round is formed by the lanes that own those
+//     samples, side by side (carrier phase at a sample = phase at the start of the round + accepted samples x rate);
+//   * the equaliser's complex inner product (33 taps) is four chains -- real / imaginary x the two parts of
+//     cvec_circular_dot_prodf() -- one per lane, each in the reference's order.  The delay line sits in LDS in the
+//     reference's ring order as [B | 0 | B | B]: a lane of the first part reads 33 entries from the ring position on and
+//     runs into the zeros, a lane of the second part starts 33 further on and runs out of them (adding +0 is exact: a
+//     sum that starts at +0 is never -0).  Taps are stored {re, im, -re}: the imaginary lanes read one word further on,
+//     and the same three instructions (a*c - b*d) give re*re - im*im on one lane and re*im + im*re on its neighbour.
+//     Should a product with a padding zero be NaN (a tap at infinity: the receiver has been fed garbage), the result is
+//     not finite and the sum is redone with every term selected instead of padded;
+//   * the LMS update is independent per tap: lane r takes taps r, r + 4, ...;
+//   * everything scalar (carrier detect, AGC, Godard filters, the training state machine, descrambler) is replicated
+//     in the four lanes, so every decision is uniform over the quad and no value ever has to be sent back.
+// Results are the reference's bit for bit: tests/test_quad_emul.py runs THIS source on the host (four fibers per
+// channel, quad_ctx.hpp) against the oracle, tests/test_v29_gpu.py runs it on the GPU.
+#pragma once
+
+#include "v29_common.hpp"
+
+namespace spg {
+
+constexpr int kV29QuadTile = 160;                       // samples of PCM staged per channel at a time (a whole frame)
+
+struct V29QuadTables                                    // per workgroup, in LDS
+{
+    float2 rrc[kRrcLen*kRrcSets];                       // [tap][set] {re, im}
+    float sine[2048];
+    float konst[32];                                    // v29tx_constellation_maps.h:58-77
+    uint16_t sqrt_tab[196];
+    uint8_t space_map[400];
+};
+
+struct V29QuadChan                                      // per channel, in LDS
+{
+    uint32_t pcm[kV29QuadTile/2];
+    float2 rrc[2*kRrcLen];                              // pair k < 27: {x[k], 0}; pair 27 + k: {0, x[k]}
+    float2 u[4*kEqLen];                                 // eq_buf in ring order: [B | 0 | B | B]
+    float taps[3*kEqLen + 1];                           // {re, im, -re} per tap (+ padding to 16 bytes)
+};
+
+// tables -> LDS, by all threads of the workgroup (tid of n)
+SPG_FN void v29_quad_tables(V29QuadTables &T, const V29Tables &TB, int tid, int n)
+{
+    for (int i = tid;  i < kRrcSets*kRrcLen;  i += n)
+    {
+        const int set = i/kRrcLen;
+        const int tap = i - set*kRrcLen;
+        T.rrc[tap*kRrcSets + set] = make_float2(TB.rrc_re[i], TB.rrc_im[i]);
+    }
+    for (int i = tid;  i < 2048;  i += n)
+        T.sine[i] = TB.sine[i];
+    for (int i = tid;  i < 194;  i += n)
+        T.sqrt_tab[i] = TB.sqrt_tab[i];
+    for (int i = tid;  i < 400;  i += n)
+        T.space_map[i] = TB.space_map[i];
+    for (int i = tid;  i < 16;  i += n)
+    {
+        const float re[16] = {3, 1, 0, -1, -3, -1, 0, 1, 5, 3, 0, -3, -5, -3, 0, 3};
+        const float im[16] = {0, 1, 3, 1, 0, -1, -3, -1, 0, 3, 5, 3, 0, -3, -5, -3};
+        T.konst[2*i] = re[i];
+        T.konst[2*i + 1] = im[i];
+    }
+}
+
+template <class Q>
+SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTables &T, V29QuadChan &C)
+{
+    const int role = q.role();
+    const V29Tables &TB = *L.tab;
+    const float g0 = TB.godard[0];
+    const float g1 = TB.godard[1];
+    const float g2 = TB.godard[2];
+    const float g3 = TB.godard[3];
+    const float g4 = TB.godard[4];
+    const float g5 = TB.godard[5];
+    const float g6 = TB.godard[6];
+    const float fine_trigger = TB.fine_trigger;
+    const float coarse_trigger = TB.coarse_trigger;
+    const int fine_step = TB.fine_step;
+    const int coarse_step = TB.coarse_step;
+
+    const size_t N = (size_t) L.n_ch;
+    const int mylen = L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;
+    auto ldf = [&](int w) { return __uint_as_float(L.state[(size_t) w*N + ch]); };
+    auto ldi = [&](int w) { return (int32_t) L.state[(size_t) (kV29Floats + w)*N + ch]; };
+    // a NaN goes back as x86's (v29_dev.hpp)
+    auto stf = [&](int w, float v) { L.state[(size_t) w*N + ch] = (v != v)  ?  0xFFC00000u  :  __float_as_uint(v); };
+    auto sti = [&](int w, int32_t v) { L.state[(size_t) (kV29Floats + w)*N + ch] = (uint32_t) v; };
+
+    // ---- state: scalars replicated in the four lanes, arrays into LDS (dealt over the lanes) ---------------------------
+    float agc_scaling = ldf(VF_AGC);
+    float agc_scaling_save = ldf(VF_AGC_SAVE);
+    const float eq_delta = ldf(VF_EQ_DELTA);
+    float training_error = ldf(VF_TRAIN_ERR);
+    float carrier_track_p = ldf(VF_TRACK_P);
+    float carrier_track_i = ldf(VF_TRACK_I);
+    float glow0 = ldf(VF_GLOW);
+    float glow1 = ldf(VF_GLOW + 1);
+    float ghigh0 = ldf(VF_GHIGH);
+    float ghigh1 = ldf(VF_GHIGH + 1);
+    float gdc0 = ldf(VF_GDC);
+    float gdc1 = ldf(VF_GDC + 1);
+    float baud_phase = ldf(VF_BAUD_PHASE);
+    for (int i = role;  i < kRrcLen;  i += 4)
+    {
+        const float v = ldf(VF_RRC + i);
+        C.rrc[i] = make_float2(v, 0.0f);
+        C.rrc[kRrcLen + i] = make_float2(0.0f, v);
+    }
+    for (int i = role;  i < kEqLen;  i += 4)
+    {
+        const float cr = ldf(VF_EQ_COEFF + 2*i);
+        const float ci = ldf(VF_EQ_COEFF + 2*i + 1);
+        C.taps[3*i] = cr;
+        C.taps[3*i + 1] = ci;
+        C.taps[3*i + 2] = -cr;
+        const float2 x = make_float2(ldf(VF_EQ_BUF + 2*i), ldf(VF_EQ_BUF + 2*i + 1));
+        C.u[i] = x;
+        C.u[kEqLen + i] = make_float2(0.0f, 0.0f);
+        C.u[2*kEqLen + i] = x;
+        C.u[3*kEqLen + i] = x;
+    }
+    const int bit_rate = ldi(VI_BIT_RATE);
+    int rrc_step = ldi(VI_RRC_STEP);
+    uint32_t scramble_reg = (uint32_t) ldi(VI_SCRAMBLE);
+    int training_scramble_reg = ldi(VI_TRAIN_SCRAMBLE);
+    const int training_cd = ldi(VI_TRAINING_CD);
+    int old_train = ldi(VI_OLD_TRAIN);
+    int stage = ldi(VI_STAGE);
+    int training_count = ldi(VI_TRAIN_COUNT);
+    int last_sample = ldi(VI_LAST_SAMPLE);
+    int signal_present = ldi(VI_SIGNAL_PRESENT);
+    uint32_t carrier_phase = (uint32_t) ldi(VI_CARRIER_PHASE);
+    int32_t carrier_phase_rate = ldi(VI_PHASE_RATE);
+    int32_t carrier_phase_rate_save = ldi(VI_PHASE_RATE_SAVE);
+    int32_t power_reading = ldi(VI_POWER);
+    const int32_t carrier_on_power = ldi(VI_ON_POWER);
+    const int32_t carrier_off_power = ldi(VI_OFF_POWER);
+    int eq_step = ldi(VI_EQ_STEP);
+    int eq_put_step = ldi(VI_EQ_PUT_STEP);
+    int eq_skip = ldi(VI_EQ_SKIP);
+    int baud_half = ldi(VI_BAUD_HALF);
+    int32_t last_angle0 = ldi(VI_LAST_ANGLES);
+    int32_t last_angle1 = ldi(VI_LAST_ANGLES + 1);
+    int constellation_state = ldi(VI_CONSTEL);
+    int total_corr = ldi(VI_TOTAL_CORR);
+    int high_sample = ldi(VI_HIGH_SAMPLE);
+    int low_samples = ldi(VI_LOW_SAMPLES);
+    int drop_pending = ldi(VI_DROP_PENDING);
+    // diff_angles[16] is only touched during WAIT_FOR_CDCD: it stays in the state array (every lane of the quad stores
+    // the same value and reads it back)
+    auto diff_ld = [&](int k) { return ldi(VI_DIFF_ANGLES + (k & 0xF)); };
+    auto diff_st = [&](int k, int32_t v) { sti(VI_DIFF_ANGLES + (k & 0xF), v); };
+
+    int8_t *evp = L.events + (size_t) ch*L.ev_cap;
+    int n_ev = 0;
+    auto emit = [&](int v)
+    {
+        if (role == 0  &&  n_ev < L.ev_cap)
+            evp[n_ev] = (int8_t) v;
+        n_ev++;
+    };
+
+    // v29_rx_restart(s, bit_rate, false), v29rx.c:1019-1098: all four lanes, the same stores
+    auto restart = [&]()
+    {
+        for (int i = 0;  i < 2*kRrcLen;  i++)
+            C.rrc[i] = make_float2(0.0f, 0.0f);
+        rrc_step = 0;
+        scramble_reg = 0;
+        training_scramble_reg = 0x2A;
+        stage = V29_SYMBOL_ACQUISITION;
+        training_count = 0;
+        signal_present = 0;
+        high_sample = 0;
+        low_samples = 0;
+        drop_pending = 0;
+        old_train = 0;
+        for (int k = 0;  k < 16;  k++)
+            diff_st(k, 0);
+        carrier_phase = 0;
+        power_reading = 0;
+        constellation_state = 0;
+        carrier_phase_rate = v29_f2i(1700.0f*65536.0f*65536.0f/8000);
+        for (int i = 0;  i < kEqLen;  i++)
+        {
+            const float cr = (i == 16)  ?  3.0f  :  0.0f;                   // V29_EQUALIZER_PRE_LEN
+            C.taps[3*i] = cr;
+            C.taps[3*i + 1] = 0.0f;
+            C.taps[3*i + 2] = -cr;
+        }
+        for (int i = 0;  i < 4*kEqLen;  i++)
+            C.u[i] = make_float2(0.0f, 0.0f);
+        eq_put_step = kRrcSets*10/(3*2) - 1;
+        eq_step = 0;
+        agc_scaling_save = 0.0f;
+        agc_scaling = (1.25f/1.0f)/735.0f;
+        carrier_track_i = 8000.0f;
+        carrier_track_p = 8000000.0f;
+        last_sample = 0;
+        eq_skip = 0;
+        glow0 = glow1 = ghigh0 = ghigh1 = gdc0 = gdc1 = 0.0f;
+        baud_phase = 0.0f;
+        total_corr = 0;
+        baud_half = 0;
+    };
+
+    // track_carrier() and tune_equalizer() (v29rx.c:281-331): requested by the stage logic, carried out once after it
+    bool do_track = false;
+    bool do_tune = false;
+    bool do_save = false;
+    float tgt_re = 0.0f;
+    float tgt_im = 0.0f;
+    float use_track_i = 0.0f;
+    float use_track_p = 0.0f;
+    auto track_carrier = [&](float tre, float tim)
+    {
+        do_track = true;
+        tgt_re = tre;
+        tgt_im = tim;
+        use_track_i = carrier_track_i;
+        use_track_p = carrier_track_p;
+    };
+    auto tune_equalizer = [&](float tre, float tim)
+    {
+        do_tune = true;
+        tgt_re = tre;
+        tgt_im = tim;
+    };
+    auto put_bit = [&](int bit)
+    {
+        // v29rx.c:365-397
+        bit &= 1;
+        const int out_bit = (bit ^ (int) (scramble_reg >> 17) ^ (int) (scramble_reg >> 22)) & 1;
+        scramble_reg = (scramble_reg << 1) | (uint32_t) bit;
+        if (stage == V29_NORMAL)
+            emit(out_bit);
+    };
+    auto scrambled_training_bit = [&]()
+    {
+        // v29rx.c:350-362
+        const int bit = training_scramble_reg & 1;
+        training_scramble_reg >>= 1;
+        if (bit ^ (training_scramble_reg & 1))
+            training_scramble_reg |= 0x40;
+        return bit;
+    };
+    auto decode_baud = [&](float zre, float zim)
+    {
+        // v29rx.c:400-481
+        int nearest;
+        if (bit_rate == 4800)
+        {
+            const int b1 = (zim > zre);
+            const int b2 = (zim < -zre);
+            nearest = ((b2 << 1) | (b1 ^ b2)) << 1;
+            const int idx = ((nearest - constellation_state) >> 1) & 3;
+            const int raw_bits = (0x1320 >> (4*idx)) & 0xF;            // phase_steps_4800 = {0, 2, 3, 1}
+            put_bit(raw_bits);
+            put_bit(raw_bits >> 1);
+        }
+        else
+        {
+            int re = v29_f2i((zre + 5.0f)*2.0f);
+            int im = v29_f2i((zim + 5.0f)*2.0f);
+            re = max(0, min(19, re));
+            im = max(0, min(19, im));
+            nearest = T.space_map[re*20 + im];
+            if (bit_rate == 9600)
+                put_bit(nearest >> 3);
+            else
+                nearest &= 7;
+            const int idx = (nearest - constellation_state) & 7;
+            int raw_bits = (int) ((0x51376204u >> (4*idx)) & 0xF);  // phase_steps_9600 = {4,0,2,6,7,3,1,5}
+            put_bit(raw_bits);
+            put_bit(raw_bits >> 1);
+            put_bit(raw_bits >> 2);
+        }
+        const float tre = T.konst[2*nearest];
+        const float tim = T.konst[2*nearest + 1];
+        track_carrier(tre, tim);
+        if (--eq_skip <= 0)
+        {
+            eq_skip = 10;
+            tune_equalizer(tre, tim);
+        }
+        constellation_state = nearest;
+    };
+    auto park = [&]()
+    {
+        agc_scaling_save = 0.0f;
+        stage = V29_PARKED;
+        emit(-5);                                           // SIG_STATUS_TRAINING_FAILED
+    };
+
+    const int16_t *src = L.amp + (size_t) ch*L.stride;
+    q.sync(1);
+    for (int tile = 0;  tile < L.samples;  tile += kV29QuadTile)
+    {
+    const int tn = max(0, min(kV29QuadTile, mylen - tile));
+    // ---- stage the channel's stretch of PCM: pcm[k] = samples 2k, 2k+1 of the tile (16-byte pieces dealt over the lanes)
+    {
+        const int16_t *row = src + tile;
+        const bool wide = ((((uintptr_t) row) & 15) == 0)  &&  (tn == kV29QuadTile);
+        if (wide)
+        {
+            for (int k = role;  k < kV29QuadTile/8;  k += 4)
+            {
+                const int4 v = ((const int4 *) row)[k];
+                C.pcm[4*k + 0] = (uint32_t) v.x;
+                C.pcm[4*k + 1] = (uint32_t) v.y;
+                C.pcm[4*k + 2] = (uint32_t) v.z;
+                C.pcm[4*k + 3] = (uint32_t) v.w;
+            }
+        }
+        else
+        {
+            for (int k = role;  k < (tn + 1)/2;  k += 4)
+            {
+                const uint32_t lo = (uint16_t) row[2*k];
+                const uint32_t hi = (2*k + 1 < tn)  ?  (uint16_t) row[2*k + 1]  :  0u;
+                C.pcm[k] = lo | (hi << 16);
+            }
+        }
+    }
+    q.sync(2);
+    int pos = 0;
+    while (q.any(pos < tn, 1))
+    {
+        // ================= one round: up to four samples, at most one baud =================================================
+        // the three oldest taps of this lane's window (sample pos + role), before the round's samples overwrite them
+        int w0 = rrc_step + role + 1;
+        w0 = (w0 >= kRrcLen)  ?  (w0 - kRrcLen)  :  w0;
+        const float2 *xw = &C.rrc[w0];
+        const float2 xo0 = xw[0];
+        const float2 xo1 = xw[1];
+        const float2 xo2 = xw[2];
+        int my_amp = 0;
+        {
+            const int cand = min(pos + role, kV29QuadTile - 1);
+            const uint32_t pw = C.pcm[cand >> 1];
+            my_amp = (int) (short) ((cand & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
+        }
+        q.sync(3);
+
+        // ---- the plan: carrier detect and T/2 bookkeeping of the round's samples, in order (replicated) -----------------
+        bool stop = false;
+        bool restart_now = false;
+        bool baud_done = false;
+        int accm = 0;                                       // samples of the round that go on into the filters
+        int t2m = 0;                                        // ... and are T/2 instants
+        int e = eq_put_step;
+        int bh = baud_half;
+        int slot_run = eq_step;
+        uint32_t cp_run = carrier_phase;
+        int pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;             // `power` at each sample (for the AGC)
+        bool my_acc = false;
+        bool my_t2 = false;
+        int my_step = 0;
+        int my_slot = 0;
+        uint32_t my_cp = 0;
+        auto plan_sample = [&](const int k, const int amp)
+        {
+            if (stop  ||  pos >= tn)
+                return;
+            pos++;
+            // ---- v29_rx(), v29rx.c:885-961 ----
+            {
+                const float v = (float) amp;
+                C.rrc[rrc_step] = make_float2(v, 0.0f);
+                C.rrc[kRrcLen + rrc_step] = make_float2(0.0f, v);
+            }
+            if (++rrc_step >= kRrcLen)
+                rrc_step = 0;
+            // signal_detect(), v29rx.c:788-865 (with the IAXMODEM_STUFF this snapshot #defines)
+            int power;
+            {
+                const int x = amp >> 1;
+                int diff = (int) (short) (x - last_sample);
+                last_sample = x;
+                power_reading += ((diff*diff - power_reading) >> 4);
+                power = power_reading;
+                diff = (int) (short) abs(diff);
+                if (10*diff < high_sample)
+                {
+                    if (++low_samples > 120)
+                    {
+                        power_reading = 0;
+                        high_sample = 0;
+                        low_samples = 0;
+                    }
+                }
+                else
+                {
+                    low_samples = 0;
+                    if (diff > high_sample)
+                        high_sample = diff;
+                }
+                if (signal_present > 0)
+                {
+                    if (drop_pending  ||  power < carrier_off_power)
+                    {
+                        if (--signal_present <= 0)
+                        {
+                            // v29_rx_restart(): whatever the earlier samples of this round did is wiped by it, so the
+                            // round ends here and the restart is carried out below
+                            restart_now = true;
+                            stop = true;
+                            emit(-1);                       // SIG_STATUS_CARRIER_DOWN
+                            return;
+                        }
+                        drop_pending = 1;
+                    }
+                }
+                else
+                {
+                    if (power < carrier_on_power)
+                        return;
+                    signal_present = 1;
+                    drop_pending = 0;
+                    emit(-2);                               // SIG_STATUS_CARRIER_UP
+                }
+            }
+            if (power == 0  ||  stage == V29_PARKED)
+                return;
+            e -= kRrcSets;
+            int step = -e;
+            if (step < 0)
+                step += kRrcSets;
+            step = max(0, min(kRrcSets - 1, step));
+            const bool t2 = (e <= 0);
+            if (role == k)
+            {
+                my_acc = true;
+                my_t2 = t2;
+                my_step = step;
+                my_slot = slot_run;
+                my_cp = cp_run;
+            }
+            accm |= 1 << k;
+            if (k == 0) pw0 = power;
+            if (k == 1) pw1 = power;
+            if (k == 2) pw2 = power;
+            if (k == 3) pw3 = power;
+            if (t2)
+            {
+                t2m |= 1 << k;
+                e += kRrcSets*10/(3*2);
+                if (++slot_run >= kEqLen)
+                    slot_run = 0;
+                bh ^= 1;
+                if (bh == 0)
+                {
+                    baud_done = true;
+                    stop = true;
+                }
+            }
+            cp_run += (uint32_t) carrier_phase_rate;
+        };
+        plan_sample(0, q.template bcast<0>(my_amp, 1));
+        plan_sample(1, q.template bcast<1>(my_amp, 2));
+        plan_sample(2, q.template bcast<2>(my_amp, 3));
+        plan_sample(3, q.template bcast<3>(my_amp, 4));
+        if (q.any(restart_now, 2))
+        {
+            if (restart_now)
+            {
+                restart();
+                accm = 0;
+                t2m = 0;
+                my_acc = false;
+                my_t2 = false;
+                baud_done = false;
+            }
+        }
+        if (!restart_now)
+        {
+            eq_put_step = e;
+            baud_half = bh;
+            eq_step = slot_run;
+            carrier_phase = cp_run;
+        }
+        q.sync(4);
+        if (!q.any(accm != 0, 3))
+            continue;
+
+        // ---- the round's root raised cosine filters: lane r, sample r, real and imaginary ------------------------------
+        // vec_circular_dot_prodf(rrc_filter, coeffs[step], 27, rrc_step), vector_float.c:890-939, twice
+        float vre;
+        float vim;
+        {
+            const float2 *y = &T.rrc[my_step];
+            f32x2v are = {0.0f, 0.0f};
+            f32x2v aim = {0.0f, 0.0f};
+            {
+                const float2 c0 = y[0*kRrcSets];
+                const float2 c1 = y[1*kRrcSets];
+                const float2 c2 = y[2*kRrcSets];
+                are += (f32x2v) {xo0.x, xo0.y}*(f32x2v) {c0.x, c0.x};
+                aim += (f32x2v) {xo0.x, xo0.y}*(f32x2v) {c0.y, c0.y};
+                are += (f32x2v) {xo1.x, xo1.y}*(f32x2v) {c1.x, c1.x};
+                aim += (f32x2v) {xo1.x, xo1.y}*(f32x2v) {c1.y, c1.y};
+                are += (f32x2v) {xo2.x, xo2.y}*(f32x2v) {c2.x, c2.x};
+                aim += (f32x2v) {xo2.x, xo2.y}*(f32x2v) {c2.y, c2.y};
+            }
+            SPG_UNROLL
+            for (int i0 = 3;  i0 < kRrcLen;  i0 += 8)
+            {
+                float2 xs[8];
+                float2 cs[8];
+                SPG_UNROLL
+                for (int i = 0;  i < 8;  i++)
+                {
+                    xs[i] = xw[i0 + i];
+                    cs[i] = y[(i0 + i)*kRrcSets];
+                }
+                SPG_UNROLL
+                for (int i = 0;  i < 8;  i++)
+                {
+                    are += (f32x2v) {xs[i].x, xs[i].y}*(f32x2v) {cs[i].x, cs[i].x};
+                    aim += (f32x2v) {xs[i].x, xs[i].y}*(f32x2v) {cs[i].y, cs[i].y};
+                }
+            }
+            vre = are.x + are.y;
+            vim = aim.x + aim.y;
+        }
+
+        // ---- AGC and the Godard filters, sample by sample (replicated); each lane keeps its own sample's values --------
+        float my_sre = 0.0f;
+        float my_agc = agc_scaling;
+        auto post_sample = [&](const int k, const float v, const int power)
+        {
+            if ((accm & (1 << k)) == 0)
+                return;
+            const float sre = v*agc_scaling;
+            {
+                // godard_ted_rx(), godard.c:144-162
+                float t = glow0*g0 + glow1*g1 + sre;
+                glow1 = glow0;
+                glow0 = t;
+                t = ghigh0*g3 + ghigh1*g4 + sre;
+                ghigh1 = ghigh0;
+                ghigh0 = t;
+            }
+            if (role == k)
+                my_sre = sre;
+            if (t2m & (1 << k))
+            {
+                if (agc_scaling_save == 0.0f)
+                {
+                    // fixed_sqrt32(), math_fixed.c:158-169
+                    int root_power;
+                    {
+                        uint32_t xx = (uint32_t) power;
+                        const int top = 31 - __builtin_clz(xx);
+                        const int shift = 30 - (top & ~1);
+                        xx <<= shift;
+                        root_power = T.sqrt_tab[((xx >> 24) & 0xFF) - 64] >> (shift >> 1);
+                    }
+                    if (root_power == 0)
+                        root_power = 1;
+                    agc_scaling = (1.25f/1.0f)/(float) root_power;
+                }
+                if (role == k)
+                    my_agc = agc_scaling;
+            }
+        };
+        post_sample(0, q.template bcast<0>(vre, 5), pw0);
+        post_sample(1, q.template bcast<1>(vre, 6), pw1);
+        post_sample(2, q.template bcast<2>(vre, 7), pw2);
+        post_sample(3, q.template bcast<3>(vre, 8), pw3);
+
+        // ---- the T/2 instants of the round, each on the lane that owns the sample ------------------------------------------
+        if (my_t2)
+        {
+            const float sim = vim*my_agc;
+            // dds_lookup_complexf(), dds_float.c:2135,2177
+            const float dre = T.sine[(uint32_t) (my_cp + (1u << 30)) >> 21];
+            const float dim = T.sine[my_cp >> 21];
+            const float hre = my_sre*dre - sim*dim;
+            const float him = -my_sre*dim - sim*dre;
+            const float2 h = make_float2(hre, him);
+            C.u[my_slot] = h;
+            C.u[2*kEqLen + my_slot] = h;
+            C.u[3*kEqLen + my_slot] = h;
+        }
+        q.sync(5);
+        if (!q.any(baud_done, 4))
+            continue;
+
+        // ---- the baud (process_half_baud() of the second T/2 instant, v29rx.c:484-786) ---------------------------------
+        if (baud_done)
+        {
+            // the reference advances the carrier phase after the baud's processing, with the rate that may just have
+            // changed: take the last sample's advance back, redo it at the end
+            carrier_phase -= (uint32_t) carrier_phase_rate;
+            {
+                // godard_ted_per_baud(), godard.c:165-220
+                float cv = glow1*ghigh0*g2 - glow0*ghigh1*g5 + glow1*ghigh1*g6;
+                const float p = cv - gdc1;
+                gdc1 = gdc0;
+                gdc0 = cv;
+                baud_phase -= p;
+                cv = fabsf(baud_phase);
+                if (cv > fine_trigger)
+                {
+                    int i = (cv > coarse_trigger)  ?  coarse_step  :  fine_step;
+                    if (baud_phase < 0.0f)
+                        i = -i;
+                    total_corr += i;
+                    eq_put_step += i;
+                }
+            }
+            // equalizer_get(): cvec_circular_dot_prodf (complex_vector_float.c:137-196), one chain per lane:
+            // role 0 / 1 = real / imaginary of the part from the ring position to the end, 2 / 3 = of the wrapped part
+            float zre;
+            float zim;
+            {
+                const float2 *x = &C.u[eq_step + ((role & 2)  ?  kEqLen  :  0)];
+                const float *c = &C.taps[role & 1];
+                float acc = 0.0f;
+                SPG_UNROLL
+                for (int i0 = 0;  i0 < kEqLen;  i0 += 11)
+                {
+                    float2 xs[11];
+                    float ca[11];
+                    float cb[11];
+                    SPG_UNROLL
+                    for (int i = 0;  i < 11;  i++)
+                    {
+                        xs[i] = x[i0 + i];
+                        ca[i] = c[3*(i0 + i)];
+                        cb[i] = c[3*(i0 + i) + 1];
+                    }
+                    SPG_UNROLL
+                    for (int i = 0;  i < 11;  i++)
+                        acc += xs[i].x*ca[i] - xs[i].y*cb[i];
+                }
+                float z = acc + q.swap2(acc, 1);
+                if (q.any(!(fabsf(z) < __builtin_inff()), 5))
+                {
+                    // not finite: a tap may be, and then a padding zero times it was NaN where the reference has no
+                    // term at all.  Again, with every term of the other part selected away instead of multiplied by zero
+                    const int split = kEqLen - eq_step;
+                    const float2 *xx = &C.u[2*kEqLen + eq_step];
+                    float acc2 = 0.0f;
+                    for (int i = 0;  i < kEqLen;  i++)
+                    {
+                        const float2 xv = xx[i];
+                        const float p = xv.x*c[3*i] - xv.y*c[3*i + 1];
+                        const bool mine = (role & 2)  ?  (i >= split)  :  (i < split);
+                        acc2 += mine  ?  p  :  0.0f;
+                    }
+                    const float z2 = acc2 + q.swap2(acc2, 2);
+                    if (!(fabsf(z) < __builtin_inff()))
+                        z = z2;
+                }
+                zre = q.template bcast<0>(z, 9);
+                zim = q.template bcast<1>(z, 10);
+            }
+
+            do_track = false;
+            do_tune = false;
+            do_save = false;
+            if (stage == V29_NORMAL  ||  stage == V29_TEST_ONES)
+                decode_baud(zre, zim);
+            switch (stage)
+            {
+            case V29_NORMAL:
+                break;
+            case V29_SYMBOL_ACQUISITION:
+                if (++training_count >= 60)
+                {
+                    stage = V29_LOG_PHASE;
+                    for (int k = 0;  k < 16;  k++)
+                        diff_st(k, 0);
+                    last_angle0 = v29_arctan2(zim, zre);
+                    if (agc_scaling_save == 0.0f)
+                        agc_scaling_save = agc_scaling;
+                }
+                break;
+            case V29_LOG_PHASE:
+                last_angle1 = v29_arctan2(zim, zre);
+                training_count = 1;
+                stage = V29_WAIT_FOR_CDCD;
+                break;
+            case V29_WAIT_FOR_CDCD:
+            {
+                const int32_t angle = v29_arctan2(zim, zre);
+                int i = training_count + 1;
+                const int32_t prev = (i & 1)  ?  last_angle1  :  last_angle0;
+                int32_t ang = (int32_t) ((uint32_t) angle - (uint32_t) prev);
+                if (i & 1)
+                    last_angle1 = angle;
+                else
+                    last_angle0 = angle;
+                diff_st(i, (int32_t) ((uint32_t) diff_ld(i - 2) + (uint32_t) (ang >> 4)));
+                if ((ang > 0x20000000  ||  ang < (int32_t) 0xE0000000u)  &&  training_count >= 13)
+                {
+                    i = (training_count - 8) & ~1;
+                    if (i > 1)
+                    {
+                        const int jj = i & 0xF;
+                        ang = (int32_t) ((uint32_t) diff_ld(jj) + (uint32_t) diff_ld(jj | 1))/(i - 1);
+                        carrier_phase_rate += 3*16*(ang/20);
+                    }
+                    if (carrier_phase_rate < v29_f2i((1700.0f - 20.0f)*65536.0f*65536.0f/8000)
+                        ||  carrier_phase_rate > v29_f2i((1700.0f + 20.0f)*65536.0f*65536.0f/8000))
+                    {
+                        park();
+                        break;
+                    }
+                    // v29rx.c:618-624: spin the equaliser delay line (each lane every fourth entry) and the carrier
+                    const float p = ((uint32_t) angle)*2.0f*3.1415926f/(65536.0f*65536.0f);
+                    const float zc = spg_sincosf(p, true);
+                    const float zs = -spg_sincosf(p, false);
+                    for (int k = role;  k < kEqLen;  k += 4)
+                    {
+                        const float2 xv = C.u[k];
+                        const float2 r = make_float2(xv.x*zc - xv.y*zs, xv.x*zs + xv.y*zc);
+                        C.u[k] = r;
+                        C.u[2*kEqLen + k] = r;
+                        C.u[3*kEqLen + k] = r;
+                    }
+                    carrier_phase += (uint32_t) angle;
+                    const int bit = scrambled_training_bit();
+                    constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;   // cdcd_pos = {0,11,0,3,0,2}
+                    training_count = 1;
+                    stage = V29_TRAIN_ON_CDCD;
+                    emit(-3);                           // SIG_STATUS_TRAINING_IN_PROGRESS
+                    break;
+                }
+                if (++training_count > 128)
+                    park();
+                break;
+            }
+            case V29_TRAIN_ON_CDCD:
+            {
+                const int bit = scrambled_training_bit();
+                constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;
+                const float tre = T.konst[2*constellation_state];
+                const float tim = T.konst[2*constellation_state + 1];
+                track_carrier(tre, tim);
+                tune_equalizer(tre, tim);
+                if (++training_count >= 384 - 48)
+                {
+                    stage = V29_TRAIN_ON_CDCD_AND_TEST;
+                    training_error = 0.0f;
+                    carrier_track_i = 200.0f;
+                    carrier_track_p = 1000000.0f;
+                }
+                break;
+            }
+            case V29_TRAIN_ON_CDCD_AND_TEST:
+            {
+                const int bit = scrambled_training_bit();
+                constellation_state = (0x002030B0 >> (4*(training_cd + bit))) & 0xF;
+                const float tre = T.konst[2*constellation_state];
+                const float tim = T.konst[2*constellation_state + 1];
+                track_carrier(tre, tim);
+                tune_equalizer(tre, tim);
+                const float dre2 = zre - tre;
+                const float dim2 = zim - tim;
+                training_error += dre2*dre2 + dim2*dim2;
+                if (++training_count >= 384)
+                {
+                    if (training_error < 48.0f*2.0f)
+                    {
+                        training_error = 0.0f;
+                        training_count = 0;
+                        constellation_state = 0;
+                        stage = V29_TEST_ONES;
+                    }
+                    else
+                    {
+                        park();
+                    }
+                }
+                break;
+            }
+            case V29_TEST_ONES:
+            {
+                const float tre = T.konst[2*constellation_state];
+                const float tim = T.konst[2*constellation_state + 1];
+                const float dre2 = zre - tre;
+                const float dim2 = zim - tim;
+                training_error += dre2*dre2 + dim2*dim2;
+                if (++training_count >= 48)
+                {
+                    if (training_error < 48.0f*1.0f)
+                    {
+                        emit(-4);                       // SIG_STATUS_TRAINING_SUCCEEDED
+                        signal_present = 60;
+                        stage = V29_NORMAL;
+                        do_save = true;                 // taps and carrier rate, once this baud's updates are in
+                        agc_scaling_save = agc_scaling;
+                    }
+                    else
+                    {
+                        park();
+                    }
+                }
+                break;
+            }
+            default:
+                break;
+            }
+            if (do_track)
+            {
+                const float error = zim*tgt_re - zre*tgt_im;
+                carrier_phase_rate += v29_f2i(use_track_i*error);
+                carrier_phase += (uint32_t) v29_f2i(use_track_p*error);
+            }
+            q.sync(6);
+            if (do_tune)
+            {
+                // cvec_circular_lmsf (complex_vector_float.c:201-219): tap i goes with the entry i places on from the ring
+                // position; lane r takes taps r, r + 4, ...
+                const float ere = (tgt_re - zre)*eq_delta;
+                const float eim = (tgt_im - zim)*eq_delta;
+                const float2 *x = &C.u[2*kEqLen + eq_step];
+                SPG_UNROLL
+                for (int j = 0;  j < (kEqLen + 3)/4;  j++)
+                {
+                    const int i = role + 4*j;
+                    if (i < kEqLen)
+                    {
+                        const float2 xv = x[i];
+                        const f32x2v c0 = {C.taps[3*i], C.taps[3*i + 1]};
+                        // {xi*eim + xr*ere, xr*eim - xi*ere}
+                        const f32x2v u = (f32x2v) {xv.y, xv.x}*(f32x2v) {eim, eim};
+                        const f32x2v w = (f32x2v) {xv.x, xv.y}*(f32x2v) {ere, ere};
+                        const f32x2v c = c0*(f32x2v) {0.9999f, 0.9999f} + (u + (f32x2v) {w.x, -w.y});
+                        C.taps[3*i] = c.x;
+                        C.taps[3*i + 1] = c.y;
+                        C.taps[3*i + 2] = -c.x;
+                    }
+                }
+            }
+            q.sync(7);
+            if (do_save)
+            {
+                carrier_phase_rate_save = carrier_phase_rate;
+                for (int k = role;  k < kEqLen;  k += 4)
+                {
+                    stf(VF_EQ_SAVE + 2*k, C.taps[3*k]);
+                    stf(VF_EQ_SAVE + 2*k + 1, C.taps[3*k + 1]);
+                }
+            }
+            carrier_phase += (uint32_t) carrier_phase_rate;     // dds_advancef() with the rate the baud left behind
+        }
+    }
+    }
+
+    // ---- write back (arrays dealt over the lanes, scalars by the first) ------------------------------------------------
+    q.sync(8);
+    for (int i = role;  i < kRrcLen;  i += 4)
+        stf(VF_RRC + i, C.rrc[i].x);
+    for (int i = role;  i < kEqLen;  i += 4)
+    {
+        stf(VF_EQ_COEFF + 2*i, C.taps[3*i]);
+        stf(VF_EQ_COEFF + 2*i + 1, C.taps[3*i + 1]);
+        const float2 x = C.u[i];
+        stf(VF_EQ_BUF + 2*i, x.x);
+        stf(VF_EQ_BUF + 2*i + 1, x.y);
+    }
+    if (role == 0)
+    {
+        stf(VF_AGC, agc_scaling);
+        stf(VF_AGC_SAVE, agc_scaling_save);
+        stf(VF_TRAIN_ERR, training_error);
+        stf(VF_TRACK_P, carrier_track_p);
+        stf(VF_TRACK_I, carrier_track_i);
+        stf(VF_GLOW, glow0);
+        stf(VF_GLOW + 1, glow1);
+        stf(VF_GHIGH, ghigh0);
+        stf(VF_GHIGH + 1, ghigh1);
+        stf(VF_GDC, gdc0);
+        stf(VF_GDC + 1, gdc1);
+        stf(VF_BAUD_PHASE, baud_phase);
+        sti(VI_RRC_STEP, rrc_step);
+        sti(VI_SCRAMBLE, (int32_t) scramble_reg);
+        sti(VI_TRAIN_SCRAMBLE, training_scramble_reg);
+        sti(VI_OLD_TRAIN, old_train);
+        sti(VI_STAGE, stage);
+        sti(VI_TRAIN_COUNT, training_count);
+        sti(VI_LAST_SAMPLE, last_sample);
+        sti(VI_SIGNAL_PRESENT, signal_present);
+        sti(VI_CARRIER_PHASE, (int32_t) carrier_phase);
+        sti(VI_PHASE_RATE, carrier_phase_rate);
+        sti(VI_PHASE_RATE_SAVE, carrier_phase_rate_save);
+        sti(VI_POWER, power_reading);
+        sti(VI_EQ_STEP, eq_step);
+        sti(VI_EQ_PUT_STEP, eq_put_step);
+        sti(VI_EQ_SKIP, eq_skip);
+        sti(VI_BAUD_HALF, baud_half);
+        sti(VI_LAST_ANGLES, last_angle0);
+        sti(VI_LAST_ANGLES + 1, last_angle1);
+        sti(VI_CONSTEL, constellation_state);
+        sti(VI_TOTAL_CORR, total_corr);
+        sti(VI_HIGH_SAMPLE, high_sample);
+        sti(VI_LOW_SAMPLES, low_samples);
+        sti(VI_DROP_PENDING, drop_pending);
+        L.ev_count[ch] = n_ev;
+    }
+}
+
+#if !defined(SPG_HOST_EMUL)
+
+// CPW channels per wave (4*CPW live lanes), WPB waves per workgroup sharing the tables.
+template <int CPW, int WPB>
+__global__ __launch_bounds__(64*WPB)
+void v29_quad_kernel(const V29Launch L)
+{
+    __shared__ V29QuadTables T;
+    __shared__ __attribute__((aligned(16))) V29QuadChan chans[WPB*CPW];
+    v29_quad_tables(T, *L.tab, (int) threadIdx.x, 64*WPB);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = (int) (threadIdx.x >> 6);
+    const int cw = lane >> 2;
+    const int ch = (blockIdx.x*WPB + wv)*CPW + cw;
+    if (cw >= CPW  ||  ch >= L.n_ch)
+        return;
+    QuadDev q{lane & 3};
+    v29_quad_run(q, L, ch, T, chans[wv*CPW + cw]);
+}
+
+#endif
+
+}   // namespace spg

@@ -168,6 +168,7 @@ def lib():
             "spangpu_fsk_set_frame_parameters": (ci, [vp, ci, ci, ci, ci]),
             "spangpu_fsk_fillin": (ci, [vp, ci, ci]),
             "spangpu_tune_echo_lanes_per_channel": (ci, [ci]),
+            "spangpu_tune_modem_mapping": (ci, [ci]),
             "spangpu_echo_lanes_per_channel": (ci, [vp]),
             "spangpu_echo_stats": (ci, [vp, ci]),
             "spangpu_echo_stats_reset": (ci, [vp, ci]),
@@ -238,6 +239,11 @@ def tune_lanes_per_channel(lpc):
 def tune_tone_kernel(variant):
     """0 = per-call choice, 1 = always the general kernel, 2 = streaming with loader waves, 3 = streaming without."""
     _check(lib().spangpu_tune_tone_kernel(variant))
+
+
+def tune_modem_mapping(mapping):
+    """0 = by bank size, 1 = one channel per lane, 4 / 8 = four lanes per channel with 16 / 8 channels per wavefront."""
+    _check(lib().spangpu_tune_modem_mapping(mapping))
 
 
 def goertzel_fac(freq):

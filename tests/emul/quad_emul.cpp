@@ -1,0 +1,183 @@
+// quad_emul.cpp -- TEST INFRASTRUCTURE: runs the four-lanes-per-channel receiver kernels of spandsp_amd/csrc (the very
+// source the GPU runs: v29_quad.hpp ...) on the host, one channel at a time, its four lanes as four fibers that hand over
+// at every exchange point of quad_ctx.hpp.  tests/test_quad_emul.py compares the result with the oracle.  Nothing in the
+// product uses this.
+#define SPG_HOST_EMUL 1
+#include <stdio.h>
+#include <ucontext.h>
+
+#include "../../spandsp_amd/csrc/v29_quad.hpp"
+#include "../../spandsp_amd/csrc/modem_tables.h"
+
+namespace spg {
+
+struct Sched
+{
+    ucontext_t main_ctx;
+    ucontext_t ctx[4];
+    char *stack[4];
+    bool done[4];
+    int order[4];               // the sequence in which the lanes get their turn
+    int where[4];               // lane -> index in order
+    int site[4];
+    int gen_seen[4];
+    int errors;
+    void (*body)(int lane, void *arg);
+    void *arg;
+    int cur;
+};
+
+static Sched *g_sched;
+
+static void next_from(Sched *s, int lane, ucontext_t *from)
+{
+    for (int k = 1;  k <= 4;  k++)
+    {
+        const int nl = s->order[(s->where[lane] + k) & 3];
+        if (nl == lane)
+            break;
+        if (!s->done[nl])
+        {
+            s->cur = nl;
+            swapcontext(from, &s->ctx[nl]);
+            return;
+        }
+    }
+    // nobody else can run
+    bool all = true;
+    for (int k = 0;  k < 4;  k++)
+        all = all  &&  (s->done[k]  ||  k == lane);
+    if (!s->done[lane])
+    {
+        // this lane waits at an exchange, the others have finished: the lanes did not take the same path
+        s->errors++;
+        s->done[lane] = true;
+    }
+    (void) all;
+    swapcontext(from, &s->main_ctx);
+}
+
+void quad_host_yield(QuadHostState *st, int lane, int site)
+{
+    Sched *s = (Sched *) st->impl;
+    // every lane must come by the same call sites in the same order: the first lane of the turn order records the site
+    // of a generation, the others compare (the first lane is never more than one generation ahead)
+    const int g = st->gen[lane];
+    if (lane == s->order[0])
+    {
+        s->site[g & 1] = site;
+        s->gen_seen[g & 1] = g;
+    }
+    else if (s->gen_seen[g & 1] != g  ||  s->site[g & 1] != site)
+    {
+        if (s->errors < 5)
+            fprintf(stderr, "quad_emul: lane %d at site %d gen %d, lane %d was at site %d gen %d\n", lane, site, g, s->order[0], s->site[g & 1], s->gen_seen[g & 1]);
+        s->errors++;
+    }
+    next_from(s, lane, &s->ctx[lane]);
+}
+
+static void trampoline(int lane)
+{
+    Sched *s = g_sched;
+    s->body(lane, s->arg);
+    s->done[lane] = true;
+    next_from(s, lane, &s->ctx[lane]);
+}
+
+static int run_quad(void (*body)(int, void *), void *arg, QuadHostState *st, const int order[4])
+{
+    static Sched s;
+    memset(&s, 0, sizeof(s));
+    g_sched = &s;
+    s.body = body;
+    s.arg = arg;
+    st->impl = &s;
+    for (int k = 0;  k < 4;  k++)
+    {
+        s.order[k] = order[k];
+        s.where[order[k]] = k;
+    }
+    const size_t stack_bytes = 1 << 20;
+    for (int k = 0;  k < 4;  k++)
+    {
+        s.stack[k] = (char *) malloc(stack_bytes);
+        getcontext(&s.ctx[k]);
+        s.ctx[k].uc_stack.ss_sp = s.stack[k];
+        s.ctx[k].uc_stack.ss_size = stack_bytes;
+        s.ctx[k].uc_link = &s.main_ctx;
+        makecontext(&s.ctx[k], (void (*)()) trampoline, 1, k);
+    }
+    s.cur = s.order[0];
+    swapcontext(&s.main_ctx, &s.ctx[s.order[0]]);
+    for (int k = 0;  k < 4;  k++)
+    {
+        if (!s.done[k])
+            s.errors++;
+        free(s.stack[k]);
+    }
+    return s.errors;
+}
+
+struct V29Job
+{
+    V29Launch L;
+    V29QuadTables T;
+    V29QuadChan C;
+    QuadHostState st;
+};
+
+static void v29_body(int lane, void *arg)
+{
+    V29Job *j = (V29Job *) arg;
+    QuadHost q;
+    q.st = &j->st;
+    q.lane = lane;
+    v29_quad_run(q, j->L, 0, j->T, j->C);
+}
+
+}   // namespace spg
+
+using namespace spg;
+
+static V29Tables g_v29_tab;
+static bool g_v29_tab_ready;
+
+// One channel's v29_rx() call: state = the 281 state words (in and out), returns the number of events or < 0.
+extern "C" int emul_v29_rx(uint32_t *state, const int16_t *amp, int n, int8_t *events, int ev_cap, const int *order)
+{
+    if (!g_v29_tab_ready)
+    {
+        memset(&g_v29_tab, 0, sizeof(g_v29_tab));
+        spg_make_rx_pulseshaper(kRrcSets, kRrcLen, 1700.0, 2400.0, 0.5, g_v29_tab.rrc_re, g_v29_tab.rrc_im);
+        spg_make_sine_table(g_v29_tab.sine);
+        spg_make_sqrt_table(g_v29_tab.sqrt_tab);
+        spg_make_godard(1700.0, 2400.0, 0.99, g_v29_tab.godard);
+        g_v29_tab.coarse_trigger = 1000.0f;
+        g_v29_tab.fine_trigger = 30.0f;
+        g_v29_tab.coarse_step = 5;
+        g_v29_tab.fine_step = 1;
+        spg_make_v29_space_map(g_v29_tab.space_map);
+        g_v29_tab_ready = true;
+    }
+    static V29Job job;
+    memset(&job, 0, sizeof(job));
+    int32_t count = 0;
+    job.L.amp = amp;
+    job.L.stride = n;
+    job.L.samples = n;
+    job.L.lens = nullptr;
+    job.L.n_ch = 1;
+    job.L.state = state;
+    job.L.events = events;
+    job.L.ev_count = &count;
+    job.L.ev_cap = ev_cap;
+    job.L.tab = &g_v29_tab;
+    v29_quad_tables(job.T, g_v29_tab, 0, 1);
+    // LDS starts out as rubbish on the device
+    memset(&job.C, 0xA5, sizeof(job.C));
+    const int errs = run_quad(v29_body, &job, &job.st, order);
+    if (errs)
+        return -errs;
+    return count;
+}

@@ -1,0 +1,96 @@
+"""The four-lanes-per-channel receiver kernels (spandsp_amd/csrc/v29_quad.hpp ...) run on the HOST -- the same source the
+GPU runs, a channel's four lanes as four fibers (tests/emul/quad_emul.cpp, spandsp_amd/csrc/quad_ctx.hpp) -- against the
+oracle: events and all state words after every call, for several orders in which the lanes take their turns (an LDS
+word handed from lane to lane without the ordering the lock step of a wavefront gives would show as a difference between
+the orders)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_oracle_pin import GOLDEN, bits, use_golden_modem_tables
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL = os.path.join(HERE, "emul")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    so = os.path.join(EMUL, "libquademul.so")
+    if os.path.exists(os.path.join(EMUL, "Makefile")) and os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        subprocess.run(["make", "-C", EMUL], check=True, capture_output=True)
+    lib = ctypes.CDLL(so)
+    lib.emul_v29_rx.restype = ctypes.c_int
+    lib.emul_v29_rx.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    return lib
+
+
+def channel_signals(bit_rate, n_ch, seed, fixture="v29_%d.npz"):
+    g = np.load(os.path.join(GOLDEN, fixture % bit_rate))
+    base = g["amp"].astype(np.float64)
+    rng = np.random.default_rng(seed)
+    n = len(base) + 64 + 900
+    out = np.zeros((n_ch, n), np.int16)
+    for c in range(n_ch):
+        delay = int(rng.integers(0, 64))
+        gain = 10.0**(rng.uniform(-14.0, 3.0)/20.0) if c else 1.0
+        noise = rng.normal(0.0, rng.choice([0.0, 3.0, 30.0, 120.0, 2000.0]), n) if c else 0.0
+        x = np.zeros(n)
+        x[delay:delay + len(base)] = base
+        if c % 5 == 4:
+            x[delay + 2000:delay + 2000 + 300] = 0.0           # a hole in the carrier: the receiver restarts in mid page
+        out[c] = np.clip(np.rint(x*gain + noise), -32768, 32767).astype(np.int16)
+    return out
+
+
+ORDERS = [(0, 1, 2, 3), (3, 2, 1, 0), (2, 0, 3, 1)]
+
+
+def run_emul_v29(lib, words, x, chunks, order):
+    """-> per call (events, words after)"""
+    out = []
+    ev = np.zeros(4096, np.int8)
+    o = np.array(order, np.int32)
+    k = i = 0
+    w = words.copy()
+    while k < len(x):
+        n = chunks[i % len(chunks)]
+        blk = np.ascontiguousarray(x[k:k + n])
+        got = lib.emul_v29_rx(w.ctypes.data, blk.ctypes.data, len(blk), ev.ctypes.data, len(ev), o.ctypes.data)
+        assert got >= 0, ("the lanes of the quad left their common path", got)
+        out.append((ev[:got].copy(), w.copy()))
+        k += n
+        i += 1
+    return out
+
+
+@pytest.mark.parametrize("bit_rate", [9600, 7200, 4800])
+@pytest.mark.parametrize("chunks", [(160,), (400, 3, 1, 97)])
+def test_v29_quad_on_the_host_matches_oracle(built, emul, bit_rate, chunks):
+    from oracle import restated as orc
+    use_golden_modem_tables()
+    n_ch = 6
+    sig = channel_signals(bit_rate, n_ch, seed=bit_rate + len(chunks))
+    total = 0
+    for c in range(n_ch):
+        o = orc.V29(bit_rate)
+        f0, w0 = o.snapshot()
+        words = np.concatenate([bits(f0), w0.view(np.uint32)]).astype(np.uint32)
+        got = run_emul_v29(emul, words, sig[c], chunks, ORDERS[c % len(ORDERS)])
+        k = i = 0
+        while k < sig.shape[1]:
+            n = chunks[i % len(chunks)]
+            o.sink.clear()
+            o.rx(sig[c, k:k + n])
+            ev = o.sink.events()["a"].astype(np.int8)
+            f, w = o.snapshot()
+            want = np.concatenate([bits(f), w.view(np.uint32)])
+            assert np.array_equal(got[i][0], ev), (bit_rate, "events", c, i)
+            bad = np.nonzero(got[i][1] != want)[0]
+            assert bad.size == 0, (bit_rate, "state words", c, i, bad[:10])
+            total += len(ev)
+            k += n
+            i += 1
+    assert total > 1500*n_ch//2

@@ -872,6 +872,8 @@ def main():
     ap.add_argument("--echo-lanes", type=int, default=0, help="echo: lanes per channel (0 = the library's choice; 2, 4, 8, 16 for A-B runs)")
     ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
     ap.add_argument("--cpu-channels", type=int, default=16384)
+    ap.add_argument("--modem-mapping", type=int, default=0,
+                    help="v29 / v17 / v27ter: 0 = the library's choice, 1 = one channel per lane, 4 / 8 = four lanes per channel (A-B runs)")
     ap.add_argument("--replay-fixture", action="store_true",
                     help="v29 / v27ter / v17: replay the committed reference transmission instead of running the transmitter bank")
     args = ap.parse_args()
@@ -925,6 +927,7 @@ def main():
         frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem=args.workload)
     else:
         frames = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture)
+    engine.tune_modem_mapping(args.modem_mapping)
     bank = engine.ModemBank(kind, n_ch, bit_rate)
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
     frame_bytes = n_ch*FRAME*2
@@ -961,7 +964,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s %d bps RX, %d channels x %d-sample frames, AWGN%s"
                                % (args.workload, bit_rate, n_ch, FRAME, " (BASELINE configs[3])" if args.workload == "v29" else ""),
-                   "channels_per_gpu": n_ch,
+                   "channels_per_gpu": n_ch, "modem_mapping": args.modem_mapping,
                    "sampled_channels_in_data_mode_at_end": "%d of %d" % (trained, len(range(0, n_ch, max(1, n_ch//256)))),
                    "events_in_last_frame": bits_last},
         "roofline": {"bound": "hbm", "kernel": "%s_bank_kernel" % args.workload, "achieved": alg_read/(avg_ms*1e-3)/1e9,
