@@ -41,16 +41,24 @@ struct V29QuadTables                                    // per workgroup, in LDS
     float2 rrc[kRrcLen*kRrcSets];                       // [tap][set] {re, im}
     float sine[2048];
     float konst[32];                                    // v29tx_constellation_maps.h:58-77
-    uint16_t sqrt_tab[196];
     uint8_t space_map[400];
 };
 
-struct V29QuadChan                                      // per channel, in LDS
+// Per channel, in LDS.  The strides from channel to channel are chosen so that the lanes of a half wave (eight channels)
+// that read the same element of their own channel fall into different banks: 4-byte accesses see 32 banks (strides of
+// 4 and 17 words: a quad touches at most three consecutive words of the taps, one of the PCM), 8-byte accesses 64
+// (strides of 8 x odd words: a quad touches up to four consecutive pairs).
+constexpr int kQuadPcmStride = 81;                      // words: 160 samples of PCM (+1)
+constexpr int kQuadRrcStride = 60;                      // pairs: 2 x 27 (+6); 120 words = 64 + 8*7
+constexpr int kQuadEqStride = 4*kEqLen;                 // pairs: 264 words = 4*64 + 8
+constexpr int kQuadTapStride = 100;                     // words: 33 x {re, im, -re} (+1); 100 = 3*32 + 4
+
+struct V29QuadChan
 {
-    uint32_t pcm[kV29QuadTile/2];
-    float2 rrc[2*kRrcLen];                              // pair k < 27: {x[k], 0}; pair 27 + k: {0, x[k]}
-    float2 u[4*kEqLen];                                 // eq_buf in ring order: [B | 0 | B | B]
-    float taps[3*kEqLen + 1];                           // {re, im, -re} per tap (+ padding to 16 bytes)
+    uint32_t *pcm;                                      // [kV29QuadTile/2]
+    float2 *rrc;                                        // [54] pair k < 27: {x[k], 0}; pair 27 + k: {0, x[k]}
+    float2 *u;                                          // [132] eq_buf in ring order: [B | 0 | B | B]
+    float *taps;                                        // [99] {re, im, -re} per tap
 };
 
 // tables -> LDS, by all threads of the workgroup (tid of n)
@@ -64,8 +72,6 @@ SPG_FN void v29_quad_tables(V29QuadTables &T, const V29Tables &TB, int tid, int 
     }
     for (int i = tid;  i < 2048;  i += n)
         T.sine[i] = TB.sine[i];
-    for (int i = tid;  i < 194;  i += n)
-        T.sqrt_tab[i] = TB.sqrt_tab[i];
     for (int i = tid;  i < 400;  i += n)
         T.space_map[i] = TB.space_map[i];
     for (int i = tid;  i < 16;  i += n)
@@ -78,7 +84,7 @@ SPG_FN void v29_quad_tables(V29QuadTables &T, const V29Tables &TB, int tid, int 
 }
 
 template <class Q>
-SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTables &T, V29QuadChan &C)
+SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTables &T, const V29QuadChan C)
 {
     const int role = q.role();
     const V29Tables &TB = *L.tab;
@@ -350,145 +356,121 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
         const float2 xo0 = xw[0];
         const float2 xo1 = xw[1];
         const float2 xo2 = xw[2];
-        int my_amp = 0;
+        // what carrier detection needs of the round's four candidate samples, one per lane: the sample, half of it, its
+        // difference to the sample before (signal_detect(), v29rx.c:796-800) squared and as a magnitude
+        float my_ampf;
+        int my_x;
+        int my_sq;
+        int my_ad;
         {
             const int cand = min(pos + role, kV29QuadTile - 1);
             const uint32_t pw = C.pcm[cand >> 1];
-            my_amp = (int) (short) ((cand & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
+            const int amp = (int) (short) ((cand & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
+            my_ampf = (float) amp;
+            my_x = amp >> 1;
+            const int before = q.prev1(my_x, 1);
+            const int diff = (int) (short) (my_x - ((role == 0)  ?  last_sample  :  before));
+            my_sq = diff*diff;
+            my_ad = (int) (short) abs(diff);
         }
         q.sync(3);
 
         // ---- the plan: carrier detect and T/2 bookkeeping of the round's samples, in order (replicated) -----------------
-        bool stop = false;
-        bool restart_now = false;
-        bool baud_done = false;
-        int accm = 0;                                       // samples of the round that go on into the filters
-        int t2m = 0;                                        // ... and are T/2 instants
+        // Written with selects, and with the outcomes collected as bits of one register, not as booleans: the samples of a
+        // round take this path four times over, and every boolean that leaves a conditional region costs the compiler
+        // a handful of scalar mask instructions per nesting level.
+        enum
+        {
+            F_ACC = 1 << 0,                                 // + k: sample k of the round goes on into the filters
+            F_T2 = 1 << 4,                                  // + k: ... and is a T/2 instant
+            F_UP = 1 << 8,                                  // + k: carrier up reported at sample k
+            F_DOWN = 1 << 12,                               // + k: carrier down
+            F_STOP = 1 << 16,                               // the round takes no further sample
+            F_RESTART = 1 << 17,
+            F_BAUD = 1 << 18                                // the round completed a baud
+        };
+        int flags = 0;
+        int my_t2f = 0;
         int e = eq_put_step;
         int bh = baud_half;
         int slot_run = eq_step;
         uint32_t cp_run = carrier_phase;
         int pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;             // `power` at each sample (for the AGC)
-        bool my_acc = false;
-        bool my_t2 = false;
         int my_step = 0;
         int my_slot = 0;
         uint32_t my_cp = 0;
-        auto plan_sample = [&](const int k, const int amp)
+        auto plan_sample = [&](const int k, const bool mine, const float ampf, const int x, const int sq, const int ad, int &pw_k)
         {
-            if (stop  ||  pos >= tn)
-                return;
-            pos++;
-            // ---- v29_rx(), v29rx.c:885-961 ----
+            if ((flags & F_STOP) == 0  &&  pos < tn)
             {
-                const float v = (float) amp;
-                C.rrc[rrc_step] = make_float2(v, 0.0f);
-                C.rrc[kRrcLen + rrc_step] = make_float2(0.0f, v);
-            }
-            if (++rrc_step >= kRrcLen)
-                rrc_step = 0;
-            // signal_detect(), v29rx.c:788-865 (with the IAXMODEM_STUFF this snapshot #defines)
-            int power;
-            {
-                const int x = amp >> 1;
-                int diff = (int) (short) (x - last_sample);
+                pos++;
+                // ---- v29_rx(), v29rx.c:885-961: the sample into the delay line (the zero halves of the pairs stay) ----
+                C.rrc[rrc_step].x = ampf;
+                C.rrc[kRrcLen + rrc_step].y = ampf;
+                rrc_step = (rrc_step == kRrcLen - 1)  ?  0  :  (rrc_step + 1);
+                // ---- signal_detect(), v29rx.c:788-865 (with the IAXMODEM_STUFF this snapshot #defines) ----
                 last_sample = x;
-                power_reading += ((diff*diff - power_reading) >> 4);
-                power = power_reading;
-                diff = (int) (short) abs(diff);
-                if (10*diff < high_sample)
+                const int power = power_reading + ((sq - power_reading) >> 4);
+                const bool low = (10*ad < high_sample);
+                const int low_inc = low_samples + 1;
+                const bool wipe = low  &&  (low_inc > 120);
+                power_reading = wipe  ?  0  :  power;
+                high_sample = low  ?  (wipe  ?  0  :  high_sample)  :  max(high_sample, ad);
+                low_samples = low  ?  (wipe  ?  0  :  low_inc)  :  0;
+                const bool present = (signal_present > 0);
+                const bool dropping = present  &&  ((drop_pending != 0)  ||  (power < carrier_off_power));
+                const bool down = dropping  &&  (signal_present <= 1);
+                const bool up = !present  &&  (power >= carrier_on_power);
+                signal_present = up  ?  1  :  (dropping  ?  (signal_present - 1)  :  signal_present);
+                drop_pending = up  ?  0  :  (dropping  ?  1  :  drop_pending);
+                // carrier down: v29_rx_restart() wipes whatever the earlier samples of this round did, so the round ends
+                // here and the restart is carried out after it
+                flags |= up  ?  (F_UP << k)  :  0;
+                flags |= down  ?  ((F_DOWN << k) | F_STOP | F_RESTART)  :  0;
+                if (!down  &&  (present  ||  up)  &&  power != 0  &&  stage != V29_PARKED)
                 {
-                    if (++low_samples > 120)
-                    {
-                        power_reading = 0;
-                        high_sample = 0;
-                        low_samples = 0;
-                    }
-                }
-                else
-                {
-                    low_samples = 0;
-                    if (diff > high_sample)
-                        high_sample = diff;
-                }
-                if (signal_present > 0)
-                {
-                    if (drop_pending  ||  power < carrier_off_power)
-                    {
-                        if (--signal_present <= 0)
-                        {
-                            // v29_rx_restart(): whatever the earlier samples of this round did is wiped by it, so the
-                            // round ends here and the restart is carried out below
-                            restart_now = true;
-                            stop = true;
-                            emit(-1);                       // SIG_STATUS_CARRIER_DOWN
-                            return;
-                        }
-                        drop_pending = 1;
-                    }
-                }
-                else
-                {
-                    if (power < carrier_on_power)
-                        return;
-                    signal_present = 1;
-                    drop_pending = 0;
-                    emit(-2);                               // SIG_STATUS_CARRIER_UP
+                    pw_k = power;
+                    e -= kRrcSets;
+                    int step = -e;
+                    step += (step < 0)  ?  kRrcSets  :  0;
+                    step = max(0, min(kRrcSets - 1, step));
+                    const bool t2 = (e <= 0);
+                    flags |= t2  ?  ((F_ACC | F_T2) << k)  :  (F_ACC << k);
+                    my_t2f |= (mine  &&  t2)  ?  1  :  0;
+                    my_step = mine  ?  step  :  my_step;
+                    my_slot = mine  ?  slot_run  :  my_slot;
+                    my_cp = mine  ?  cp_run  :  my_cp;
+                    e += t2  ?  kRrcSets*10/(3*2)  :  0;
+                    const int slot_next = (slot_run == kEqLen - 1)  ?  0  :  (slot_run + 1);
+                    slot_run = t2  ?  slot_next  :  slot_run;
+                    bh ^= t2  ?  1  :  0;
+                    flags |= (t2  &&  bh == 0)  ?  (F_STOP | F_BAUD)  :  0;
+                    cp_run += (uint32_t) carrier_phase_rate;
                 }
             }
-            if (power == 0  ||  stage == V29_PARKED)
-                return;
-            e -= kRrcSets;
-            int step = -e;
-            if (step < 0)
-                step += kRrcSets;
-            step = max(0, min(kRrcSets - 1, step));
-            const bool t2 = (e <= 0);
-            if (role == k)
-            {
-                my_acc = true;
-                my_t2 = t2;
-                my_step = step;
-                my_slot = slot_run;
-                my_cp = cp_run;
-            }
-            accm |= 1 << k;
-            if (k == 0) pw0 = power;
-            if (k == 1) pw1 = power;
-            if (k == 2) pw2 = power;
-            if (k == 3) pw3 = power;
-            if (t2)
-            {
-                t2m |= 1 << k;
-                e += kRrcSets*10/(3*2);
-                if (++slot_run >= kEqLen)
-                    slot_run = 0;
-                bh ^= 1;
-                if (bh == 0)
-                {
-                    baud_done = true;
-                    stop = true;
-                }
-            }
-            cp_run += (uint32_t) carrier_phase_rate;
         };
-        plan_sample(0, q.template bcast<0>(my_amp, 1));
-        plan_sample(1, q.template bcast<1>(my_amp, 2));
-        plan_sample(2, q.template bcast<2>(my_amp, 3));
-        plan_sample(3, q.template bcast<3>(my_amp, 4));
-        if (q.any(restart_now, 2))
+        plan_sample(0, role == 0, q.template bcast<0>(my_ampf, 1), q.template bcast<0>(my_x, 1), q.template bcast<0>(my_sq, 2), q.template bcast<0>(my_ad, 3), pw0);
+        plan_sample(1, role == 1, q.template bcast<1>(my_ampf, 4), q.template bcast<1>(my_x, 4), q.template bcast<1>(my_sq, 5), q.template bcast<1>(my_ad, 6), pw1);
+        plan_sample(2, role == 2, q.template bcast<2>(my_ampf, 7), q.template bcast<2>(my_x, 7), q.template bcast<2>(my_sq, 8), q.template bcast<2>(my_ad, 9), pw2);
+        plan_sample(3, role == 3, q.template bcast<3>(my_ampf, 10), q.template bcast<3>(my_x, 10), q.template bcast<3>(my_sq, 11), q.template bcast<3>(my_ad, 12), pw3);
+        if (q.any((flags & (0xFF*F_UP)) != 0, 2))
         {
-            if (restart_now)
+            // SIG_STATUS_CARRIER_UP (-2) / SIG_STATUS_CARRIER_DOWN (-1), in the order of the samples
+            for (int k = 0;  k < 4;  k++)
+            {
+                if (flags & (F_UP << k))
+                    emit(-2);
+                if (flags & (F_DOWN << k))
+                    emit(-1);
+            }
+            if (flags & F_RESTART)
             {
                 restart();
-                accm = 0;
-                t2m = 0;
-                my_acc = false;
-                my_t2 = false;
-                baud_done = false;
+                flags = F_RESTART;
+                my_t2f = 0;
             }
         }
-        if (!restart_now)
+        if ((flags & F_RESTART) == 0)
         {
             eq_put_step = e;
             baud_half = bh;
@@ -496,8 +478,10 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
             carrier_phase = cp_run;
         }
         q.sync(4);
-        if (!q.any(accm != 0, 3))
+        if (!q.any((flags & (0xF*F_ACC)) != 0, 3))
             continue;
+        const bool my_t2 = (my_t2f != 0);
+        const bool baud_done = (flags & F_BAUD) != 0;
 
         // ---- the round's root raised cosine filters: lane r, sample r, real and imaginary ------------------------------
         // vec_circular_dot_prodf(rrc_filter, coeffs[step], 27, rrc_step), vector_float.c:890-939, twice
@@ -543,47 +527,46 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
         // ---- AGC and the Godard filters, sample by sample (replicated); each lane keeps its own sample's values --------
         float my_sre = 0.0f;
         float my_agc = agc_scaling;
-        auto post_sample = [&](const int k, const float v, const int power)
+        auto post_sample = [&](const bool mine, const float v, const bool acc_k, const bool t2_k, const int power)
         {
-            if ((accm & (1 << k)) == 0)
-                return;
-            const float sre = v*agc_scaling;
+            if (acc_k)
             {
-                // godard_ted_rx(), godard.c:144-162
-                float t = glow0*g0 + glow1*g1 + sre;
-                glow1 = glow0;
-                glow0 = t;
-                t = ghigh0*g3 + ghigh1*g4 + sre;
-                ghigh1 = ghigh0;
-                ghigh0 = t;
-            }
-            if (role == k)
-                my_sre = sre;
-            if (t2m & (1 << k))
-            {
-                if (agc_scaling_save == 0.0f)
+                const float sre = v*agc_scaling;
                 {
-                    // fixed_sqrt32(), math_fixed.c:158-169
-                    int root_power;
-                    {
-                        uint32_t xx = (uint32_t) power;
-                        const int top = 31 - __builtin_clz(xx);
-                        const int shift = 30 - (top & ~1);
-                        xx <<= shift;
-                        root_power = T.sqrt_tab[((xx >> 24) & 0xFF) - 64] >> (shift >> 1);
-                    }
-                    if (root_power == 0)
-                        root_power = 1;
-                    agc_scaling = (1.25f/1.0f)/(float) root_power;
+                    // godard_ted_rx(), godard.c:144-162
+                    const float tl = glow0*g0 + glow1*g1 + sre;
+                    glow1 = glow0;
+                    glow0 = tl;
+                    const float th = ghigh0*g3 + ghigh1*g4 + sre;
+                    ghigh1 = ghigh0;
+                    ghigh0 = th;
                 }
-                if (role == k)
-                    my_agc = agc_scaling;
+                my_sre = mine  ?  sre  :  my_sre;
+                if (q.any(t2_k  &&  agc_scaling_save == 0.0f, 6))
+                {
+                    if (t2_k  &&  agc_scaling_save == 0.0f)
+                    {
+                        // fixed_sqrt32(), math_fixed.c:158-169
+                        int root_power;
+                        {
+                            uint32_t xx = (uint32_t) power;
+                            const int top = 31 - __builtin_clz(xx);
+                            const int shift = 30 - (top & ~1);
+                            xx <<= shift;
+                            root_power = TB.sqrt_tab[((xx >> 24) & 0xFF) - 64] >> (shift >> 1);     // rare: from global memory
+                        }
+                        if (root_power == 0)
+                            root_power = 1;
+                        agc_scaling = (1.25f/1.0f)/(float) root_power;
+                    }
+                }
+                my_agc = (mine  &&  t2_k)  ?  agc_scaling  :  my_agc;
             }
         };
-        post_sample(0, q.template bcast<0>(vre, 5), pw0);
-        post_sample(1, q.template bcast<1>(vre, 6), pw1);
-        post_sample(2, q.template bcast<2>(vre, 7), pw2);
-        post_sample(3, q.template bcast<3>(vre, 8), pw3);
+        post_sample(role == 0, q.template bcast<0>(vre, 5), (flags & (F_ACC << 0)) != 0, (flags & (F_T2 << 0)) != 0, pw0);
+        post_sample(role == 1, q.template bcast<1>(vre, 6), (flags & (F_ACC << 1)) != 0, (flags & (F_T2 << 1)) != 0, pw1);
+        post_sample(role == 2, q.template bcast<2>(vre, 7), (flags & (F_ACC << 2)) != 0, (flags & (F_T2 << 2)) != 0, pw2);
+        post_sample(role == 3, q.template bcast<3>(vre, 8), (flags & (F_ACC << 3)) != 0, (flags & (F_T2 << 3)) != 0, pw3);
 
         // ---- the T/2 instants of the round, each on the lane that owns the sample ------------------------------------------
         if (my_t2)
@@ -928,7 +911,10 @@ __global__ __launch_bounds__(64*WPB)
 void v29_quad_kernel(const V29Launch L)
 {
     __shared__ V29QuadTables T;
-    __shared__ __attribute__((aligned(16))) V29QuadChan chans[WPB*CPW];
+    __shared__ uint32_t s_pcm[WPB*CPW*kQuadPcmStride];
+    __shared__ float2 s_rrc[WPB*CPW*kQuadRrcStride];
+    __shared__ float2 s_u[WPB*CPW*kQuadEqStride];
+    __shared__ float s_taps[WPB*CPW*kQuadTapStride];
     v29_quad_tables(T, *L.tab, (int) threadIdx.x, 64*WPB);
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -938,7 +924,9 @@ void v29_quad_kernel(const V29Launch L)
     if (cw >= CPW  ||  ch >= L.n_ch)
         return;
     QuadDev q{lane & 3};
-    v29_quad_run(q, L, ch, T, chans[wv*CPW + cw]);
+    const int slot = wv*CPW + cw;
+    const V29QuadChan C = {s_pcm + slot*kQuadPcmStride, s_rrc + slot*kQuadRrcStride, s_u + slot*kQuadEqStride, s_taps + slot*kQuadTapStride};
+    v29_quad_run(q, L, ch, T, C);
 }
 
 #endif

@@ -124,6 +124,10 @@ struct V29Job
     V29Launch L;
     V29QuadTables T;
     V29QuadChan C;
+    uint32_t pcm[kQuadPcmStride];
+    float2 rrc[kQuadRrcStride];
+    float2 u[kQuadEqStride];
+    float taps[kQuadTapStride];
     QuadHostState st;
 };
 
@@ -175,7 +179,14 @@ extern "C" int emul_v29_rx(uint32_t *state, const int16_t *amp, int n, int8_t *e
     job.L.tab = &g_v29_tab;
     v29_quad_tables(job.T, g_v29_tab, 0, 1);
     // LDS starts out as rubbish on the device
-    memset(&job.C, 0xA5, sizeof(job.C));
+    memset(job.pcm, 0xA5, sizeof(job.pcm));
+    memset(job.rrc, 0xA5, sizeof(job.rrc));
+    memset(job.u, 0xA5, sizeof(job.u));
+    memset(job.taps, 0xA5, sizeof(job.taps));
+    job.C.pcm = job.pcm;
+    job.C.rrc = job.rrc;
+    job.C.u = job.u;
+    job.C.taps = job.taps;
     const int errs = run_quad(v29_body, &job, &job.st, order);
     if (errs)
         return -errs;
