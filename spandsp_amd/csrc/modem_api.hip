@@ -207,6 +207,19 @@ int spangpu_modem_state_words(int kind, int *n_floats, int *n_ints)
     return nf + ni;
 }
 
+#if defined(SPG_QUAD_PROF)
+// builder's instrument (tools/quad_prof.py): cycles per phase of the quad kernels, summed over waves; reading clears
+extern "C" __attribute__((visibility("default"))) int spangpu_debug_quad_prof(unsigned long long *out)
+{
+    unsigned long long zero[16] = {0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(spg::spg_quad_prof), sizeof(zero)) != hipSuccess)
+        return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(spg::spg_quad_prof), zero, sizeof(zero)) != hipSuccess)
+        return -1;
+    return 0;
+}
+#endif
+
 // Tuning / A-B testing: how the receiver kernels map channels to lanes from now on (0 = by bank size; 1 = one channel
 // per lane; 4 / 8 = four lanes per channel with 16 / 8 channels per wave, V.29 only so far).  Results are identical.
 int spangpu_tune_modem_mapping(int mapping)

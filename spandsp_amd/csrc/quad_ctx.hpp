@@ -30,6 +30,8 @@
 #define SPG_FN              static inline
 #define SPG_FN_NOINLINE     static inline
 #define SPG_UNROLL          _Pragma("unroll")
+#define SPG_SCHED_FENCE()   do { } while (0)
+#define SPG_LOADS_DONE()    do { } while (0)
 
 namespace spg {
 
@@ -100,6 +102,13 @@ struct QuadHost
 #define SPG_FN              __device__ __forceinline__
 #define SPG_FN_NOINLINE     __device__ __noinline__
 #define SPG_UNROLL          _Pragma("unroll")
+// nothing is scheduled across this point: keeps the loads of one group of taps from being hoisted above the arithmetic of
+// the group before (left alone the scheduler requests a whole inner product's operands at once and runs out of registers)
+#define SPG_SCHED_FENCE()   __builtin_amdgcn_sched_barrier(0)
+// s_waitcnt vmcnt(0), once, before a loop that only stores to global memory: the state words loaded ahead of the loop are
+// first used inside it, the compiler therefore puts its vmcnt(0) there, and on gfx9 stores count in vmcnt too -- every
+// iteration would sit out the round trip of the event bytes the one before it stored
+#define SPG_LOADS_DONE()    __builtin_amdgcn_s_waitcnt(0x0F70)
 
 namespace spg {
 

@@ -34,6 +34,18 @@
 
 namespace spg {
 
+// Phase timing for the builder (tools/quad_prof.py; never in the product build): cycles between stamps, summed per wave.
+#if defined(SPG_QUAD_PROF)  &&  !defined(SPG_HOST_EMUL)
+__device__ unsigned long long spg_quad_prof[16];
+#define SPG_PROF_DECL()     unsigned long long prof_last = __builtin_readcyclecounter(); unsigned int prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define SPG_PROF_STAMP(k)   do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[k] += (unsigned int) (now_ - prof_last); prof_last = now_; } while (0)
+#define SPG_PROF_FLUSH()    do { if ((threadIdx.x & 63) == 0) { for (int k_ = 0;  k_ < 10;  k_++) atomicAdd(&spg_quad_prof[k_], (unsigned long long) prof_acc[k_]); } } while (0)
+#else
+#define SPG_PROF_DECL()     do { } while (0)
+#define SPG_PROF_STAMP(k)   do { } while (0)
+#define SPG_PROF_FLUSH()    do { } while (0)
+#endif
+
 constexpr int kV29QuadTile = 160;                       // samples of PCM staged per channel at a time (a whole frame)
 
 struct V29QuadTables                                    // per workgroup, in LDS
@@ -314,7 +326,9 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
         emit(-5);                                           // SIG_STATUS_TRAINING_FAILED
     };
 
+    SPG_PROF_DECL();
     const int16_t *src = L.amp + (size_t) ch*L.stride;
+    SPG_LOADS_DONE();
     q.sync(1);
     for (int tile = 0;  tile < L.samples;  tile += kV29QuadTile)
     {
@@ -348,6 +362,7 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
     int pos = 0;
     while (q.any(pos < tn, 1))
     {
+        SPG_PROF_STAMP(0);
         // ================= one round: up to four samples, at most one baud =================================================
         // the three oldest taps of this lane's window (sample pos + role), before the round's samples overwrite them
         int w0 = rrc_step + role + 1;
@@ -373,8 +388,30 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
             my_sq = diff*diff;
             my_ad = (int) (short) abs(diff);
         }
+        const int my_ad10 = (my_ad << 3) + (my_ad << 1);
+        const float ampf0 = q.template bcast<0>(my_ampf, 1);
+        const float ampf1 = q.template bcast<1>(my_ampf, 2);
+        const float ampf2 = q.template bcast<2>(my_ampf, 3);
+        const float ampf3 = q.template bcast<3>(my_ampf, 4);
+        const int x0 = q.template bcast<0>(my_x, 1);
+        const int x1 = q.template bcast<1>(my_x, 2);
+        const int x2 = q.template bcast<2>(my_x, 3);
+        const int x3 = q.template bcast<3>(my_x, 4);
+        const int sq0 = q.template bcast<0>(my_sq, 5);
+        const int sq1 = q.template bcast<1>(my_sq, 6);
+        const int sq2 = q.template bcast<2>(my_sq, 7);
+        const int sq3 = q.template bcast<3>(my_sq, 8);
+        const int ad0 = q.template bcast<0>(my_ad, 9);
+        const int ad1 = q.template bcast<1>(my_ad, 10);
+        const int ad2 = q.template bcast<2>(my_ad, 11);
+        const int ad3 = q.template bcast<3>(my_ad, 12);
+        const int adt0 = q.template bcast<0>(my_ad10, 13);
+        const int adt1 = q.template bcast<1>(my_ad10, 14);
+        const int adt2 = q.template bcast<2>(my_ad10, 15);
+        const int adt3 = q.template bcast<3>(my_ad10, 16);
         q.sync(3);
 
+        SPG_PROF_STAMP(1);
         // ---- the plan: carrier detect and T/2 bookkeeping of the round's samples, in order (replicated) -----------------
         // Written with selects, and with the outcomes collected as bits of one register, not as booleans: the samples of a
         // round take this path four times over, and every boolean that leaves a conditional region costs the compiler
@@ -399,6 +436,91 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
         int my_step = 0;
         int my_slot = 0;
         uint32_t my_cp = 0;
+        // -- The calm round.  A channel whose carrier is up and not about to drop (and that is not parked) sends every
+        // sample on into the filters, so which of the round's samples are T/2 instants follows from eq_put_step alone, in
+        // closed form and for all four lanes at once; what is left to do sample by sample is the power estimate.  That is
+        // done on copies: should the power fall under the carrier-off threshold on any channel of the wave after all, or
+        // should a channel not be calm to begin with, the general plan below runs from the untouched state (it writes
+        // the same samples into the delay line again).
+        const bool calm = (signal_present > 0)  &&  (drop_pending == 0)  &&  (stage != V29_PARKED);
+        bool fast = !q.any(!calm  &&  pos < tn, 7);
+        if (fast)
+        {
+            const int avail = min(tn - pos, 4);
+            const int E = eq_put_step;
+            // the first T/2 instant falls on sample k1, and leaves eq_put_step at E1; the second on k2
+            const int k1 = ((E > kRrcSets)  ?  1  :  0) + ((E > 2*kRrcSets)  ?  1  :  0) + ((E > 3*kRrcSets)  ?  1  :  0) + ((E > 4*kRrcSets)  ?  1  :  0);
+            const int E1 = E - kRrcSets*(k1 + 1) + kRrcSets*10/(3*2);
+            const int k2 = k1 + 1 + ((E1 > kRrcSets)  ?  1  :  0) + ((E1 > 2*kRrcSets)  ?  1  :  0) + ((E1 > 3*kRrcSets)  ?  1  :  0);
+            const bool second = (baud_half == 0);           // the round starts a baud: it takes two T/2 instants to finish it
+            const int nb = (second  ?  k2  :  k1) + 1;      // samples to the end of the baud
+            const int m = min(nb, avail);                   // samples this round takes
+            const bool t2a = (k1 < m);
+            const bool t2b = second  &&  (k2 < m);
+            // the power estimate over the round's samples (signal_detect(), v29rx.c:788-865), on copies
+            int t_pr = power_reading;
+            int t_high = high_sample;
+            int t_low = low_samples;
+            int badf = 0;
+            const int off1 = max(carrier_off_power, 1);
+            auto calm_sample = [&](const int k, const int sq, const int ad, const int ad10, int &pw_k)
+            {
+                if (k < m)
+                {
+                    const int power = t_pr + ((sq - t_pr) >> 4);
+                    badf |= (power < off1)  ?  1  :  0;
+                    const bool low = (ad10 < t_high);
+                    const int low_inc = t_low + 1;
+                    const bool wipe = low  &&  (low_inc > 120);
+                    t_pr = wipe  ?  0  :  power;
+                    t_high = low  ?  (wipe  ?  0  :  t_high)  :  max(t_high, ad);
+                    t_low = low  ?  (wipe  ?  0  :  low_inc)  :  0;
+                    pw_k = power;
+                }
+            };
+            calm_sample(0, sq0, ad0, adt0, pw0);
+            calm_sample(1, sq1, ad1, adt1, pw1);
+            calm_sample(2, sq2, ad2, adt2, pw2);
+            calm_sample(3, sq3, ad3, adt3, pw3);
+            // the samples into the delay line, each by its lane
+            if (role < m)
+            {
+                int idx = rrc_step + role;
+                idx = (idx >= kRrcLen)  ?  (idx - kRrcLen)  :  idx;
+                C.rrc[idx].x = my_ampf;
+                C.rrc[kRrcLen + idx].y = my_ampf;
+            }
+            fast = !q.any(badf != 0, 8);
+            if (fast)
+            {
+                power_reading = t_pr;
+                high_sample = t_high;
+                low_samples = t_low;
+                last_sample = (m >= 4)  ?  x3  :  (m == 3)  ?  x2  :  (m == 2)  ?  x1  :  (m == 1)  ?  x0  :  last_sample;
+                int rs = rrc_step + m;
+                rrc_step = (rs >= kRrcLen)  ?  (rs - kRrcLen)  :  rs;
+                pos += m;
+                const int c = (t2a  ?  1  :  0) + (t2b  ?  1  :  0);
+                eq_put_step = E - kRrcSets*m + (kRrcSets*10/(3*2))*c;
+                baud_half ^= c & 1;
+                // this lane's sample
+                const bool after1 = (role > k1);
+                const int d = E - kRrcSets*(role + 1) + (after1  ?  kRrcSets*10/(3*2)  :  0);
+                int step = -d;
+                step += (step < 0)  ?  kRrcSets  :  0;
+                my_step = max(0, min(kRrcSets - 1, step));
+                int sl = eq_step + (after1  ?  1  :  0);
+                my_slot = (sl >= kEqLen)  ?  (sl - kEqLen)  :  sl;
+                my_cp = carrier_phase + (uint32_t) role*(uint32_t) carrier_phase_rate;
+                my_t2f = ((role < m)  &&  (role == k1  ||  (second  &&  role == k2)))  ?  1  :  0;
+                int se = eq_step + c;
+                eq_step = (se >= kEqLen)  ?  (se - kEqLen)  :  se;
+                carrier_phase += (uint32_t) m*(uint32_t) carrier_phase_rate;
+                flags = ((1 << m) - 1) | (t2a  ?  (F_T2 << k1)  :  0) | (t2b  ?  (F_T2 << k2)  :  0) | ((nb <= avail)  ?  F_BAUD  :  0);
+            }
+        }
+        if (!fast)
+        {
         auto plan_sample = [&](const int k, const bool mine, const float ampf, const int x, const int sq, const int ad, int &pw_k)
         {
             if ((flags & F_STOP) == 0  &&  pos < tn)
@@ -449,10 +571,10 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                 }
             }
         };
-        plan_sample(0, role == 0, q.template bcast<0>(my_ampf, 1), q.template bcast<0>(my_x, 1), q.template bcast<0>(my_sq, 2), q.template bcast<0>(my_ad, 3), pw0);
-        plan_sample(1, role == 1, q.template bcast<1>(my_ampf, 4), q.template bcast<1>(my_x, 4), q.template bcast<1>(my_sq, 5), q.template bcast<1>(my_ad, 6), pw1);
-        plan_sample(2, role == 2, q.template bcast<2>(my_ampf, 7), q.template bcast<2>(my_x, 7), q.template bcast<2>(my_sq, 8), q.template bcast<2>(my_ad, 9), pw2);
-        plan_sample(3, role == 3, q.template bcast<3>(my_ampf, 10), q.template bcast<3>(my_x, 10), q.template bcast<3>(my_sq, 11), q.template bcast<3>(my_ad, 12), pw3);
+        plan_sample(0, role == 0, ampf0, x0, sq0, ad0, pw0);
+        plan_sample(1, role == 1, ampf1, x1, sq1, ad1, pw1);
+        plan_sample(2, role == 2, ampf2, x2, sq2, ad2, pw2);
+        plan_sample(3, role == 3, ampf3, x3, sq3, ad3, pw3);
         if (q.any((flags & (0xFF*F_UP)) != 0, 2))
         {
             // SIG_STATUS_CARRIER_UP (-2) / SIG_STATUS_CARRIER_DOWN (-1), in the order of the samples
@@ -477,6 +599,8 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
             eq_step = slot_run;
             carrier_phase = cp_run;
         }
+        }
+        SPG_PROF_STAMP(2);
         q.sync(4);
         if (!q.any((flags & (0xF*F_ACC)) != 0, 3))
             continue;
@@ -519,11 +643,13 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                     are += (f32x2v) {xs[i].x, xs[i].y}*(f32x2v) {cs[i].x, cs[i].x};
                     aim += (f32x2v) {xs[i].x, xs[i].y}*(f32x2v) {cs[i].y, cs[i].y};
                 }
+                // SPG_SCHED_FENCE();
             }
             vre = are.x + are.y;
             vim = aim.x + aim.y;
         }
 
+        SPG_PROF_STAMP(3);
         // ---- AGC and the Godard filters, sample by sample (replicated); each lane keeps its own sample's values --------
         float my_sre = 0.0f;
         float my_agc = agc_scaling;
@@ -563,11 +689,37 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                 my_agc = (mine  &&  t2_k)  ?  agc_scaling  :  my_agc;
             }
         };
-        post_sample(role == 0, q.template bcast<0>(vre, 5), (flags & (F_ACC << 0)) != 0, (flags & (F_T2 << 0)) != 0, pw0);
-        post_sample(role == 1, q.template bcast<1>(vre, 6), (flags & (F_ACC << 1)) != 0, (flags & (F_T2 << 1)) != 0, pw1);
-        post_sample(role == 2, q.template bcast<2>(vre, 7), (flags & (F_ACC << 2)) != 0, (flags & (F_T2 << 2)) != 0, pw2);
-        post_sample(role == 3, q.template bcast<3>(vre, 8), (flags & (F_ACC << 3)) != 0, (flags & (F_T2 << 3)) != 0, pw3);
+        if (!q.any(agc_scaling_save == 0.0f, 10))
+        {
+            // the AGC of every channel of the wave has settled: one gain for the whole round
+            my_sre = vre*agc_scaling;
+            auto godard_sample = [&](const bool acc_k, const float sre)
+            {
+                if (acc_k)
+                {
+                    // godard_ted_rx(), godard.c:144-162
+                    const float tl = glow0*g0 + glow1*g1 + sre;
+                    glow1 = glow0;
+                    glow0 = tl;
+                    const float th = ghigh0*g3 + ghigh1*g4 + sre;
+                    ghigh1 = ghigh0;
+                    ghigh0 = th;
+                }
+            };
+            godard_sample((flags & (F_ACC << 0)) != 0, q.template bcast<0>(my_sre, 11));
+            godard_sample((flags & (F_ACC << 1)) != 0, q.template bcast<1>(my_sre, 12));
+            godard_sample((flags & (F_ACC << 2)) != 0, q.template bcast<2>(my_sre, 13));
+            godard_sample((flags & (F_ACC << 3)) != 0, q.template bcast<3>(my_sre, 14));
+        }
+        else
+        {
+            post_sample(role == 0, q.template bcast<0>(vre, 5), (flags & (F_ACC << 0)) != 0, (flags & (F_T2 << 0)) != 0, pw0);
+            post_sample(role == 1, q.template bcast<1>(vre, 6), (flags & (F_ACC << 1)) != 0, (flags & (F_T2 << 1)) != 0, pw1);
+            post_sample(role == 2, q.template bcast<2>(vre, 7), (flags & (F_ACC << 2)) != 0, (flags & (F_T2 << 2)) != 0, pw2);
+            post_sample(role == 3, q.template bcast<3>(vre, 8), (flags & (F_ACC << 3)) != 0, (flags & (F_T2 << 3)) != 0, pw3);
+        }
 
+        SPG_PROF_STAMP(4);
         // ---- the T/2 instants of the round, each on the lane that owns the sample ------------------------------------------
         if (my_t2)
         {
@@ -582,6 +734,7 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
             C.u[2*kEqLen + my_slot] = h;
             C.u[3*kEqLen + my_slot] = h;
         }
+        SPG_PROF_STAMP(5);
         q.sync(5);
         if (!q.any(baud_done, 4))
             continue;
@@ -633,6 +786,7 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                     SPG_UNROLL
                     for (int i = 0;  i < 11;  i++)
                         acc += xs[i].x*ca[i] - xs[i].y*cb[i];
+                    // SPG_SCHED_FENCE();
                 }
                 float z = acc + q.swap2(acc, 1);
                 if (q.any(!(fabsf(z) < __builtin_inff()), 5))
@@ -657,9 +811,86 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                 zim = q.template bcast<1>(z, 10);
             }
 
+            SPG_PROF_STAMP(6);
             do_track = false;
             do_tune = false;
             do_save = false;
+            if (!q.any(stage != V29_NORMAL, 9))
+            {
+                // -- every channel of the wave carries data: decode_baud() (v29rx.c:400-481) and put_bit() (:365-397)
+                // in one straight piece, the baud's bits descrambled together and stored with one access
+                int nearest;
+                int raw;                                    // the baud's bits in put_bit() order, first = bit 0
+                int nbits;
+                if (bit_rate == 4800)
+                {
+                    const int b1 = (zim > zre);
+                    const int b2 = (zim < -zre);
+                    nearest = ((b2 << 1) | (b1 ^ b2)) << 1;
+                    const int idx = ((nearest - constellation_state) >> 1) & 3;
+                    raw = (0x1320 >> (4*idx)) & 0x3;       // phase_steps_4800 = {0, 2, 3, 1}
+                    nbits = 2;
+                }
+                else
+                {
+                    int re = v29_f2i((zre + 5.0f)*2.0f);
+                    int im = v29_f2i((zim + 5.0f)*2.0f);
+                    re = max(0, min(19, re));
+                    im = max(0, min(19, im));
+                    nearest = T.space_map[re*20 + im];
+                    const bool full = (bit_rate == 9600);
+                    const int first = (nearest >> 3) & 1;
+                    nearest = full  ?  nearest  :  (nearest & 7);
+                    const int idx = (nearest - constellation_state) & 7;
+                    const int three = (int) ((0x51376204u >> (4*idx)) & 0x7);     // phase_steps_9600 = {4,0,2,6,7,3,1,5}
+                    raw = full  ?  ((three << 1) | first)  :  three;
+                    nbits = full  ?  4  :  3;
+                }
+                // the self synchronising descrambler: the taps (17, 22) lie beyond the four bits of a baud, so each output
+                // bit only needs the register as it was before the baud
+                uint32_t out = 0;
+                SPG_UNROLL
+                for (int j = 0;  j < 4;  j++)
+                {
+                    const uint32_t o = ((uint32_t) (raw >> j) ^ (scramble_reg >> (17 - j)) ^ (scramble_reg >> (22 - j))) & 1u;
+                    out |= o << (8*j);
+                }
+                {
+                    // put_bit order: bit 0 first, so it ends up highest in the register
+                    uint32_t rev = ((uint32_t) raw & 1u) << 3 | ((uint32_t) raw & 2u) << 1 | ((uint32_t) raw & 4u) >> 1 | ((uint32_t) raw & 8u) >> 3;
+                    rev >>= 4 - nbits;
+                    scramble_reg = (scramble_reg << nbits) | rev;
+                }
+                if (role == 0)
+                {
+                    if (n_ev + 4 <= L.ev_cap)
+                    {
+                        __builtin_memcpy(evp + n_ev, &out, 4);      // bytes past the baud's bits are overwritten by the next
+                    }
+                    else
+                    {
+                        for (int j = 0;  j < nbits;  j++)
+                        {
+                            if (n_ev + j < L.ev_cap)
+                                evp[n_ev + j] = (int8_t) ((out >> (8*j)) & 1u);
+                        }
+                    }
+                }
+                n_ev += nbits;
+                const float tre = T.konst[2*nearest];
+                const float tim = T.konst[2*nearest + 1];
+                do_track = true;
+                tgt_re = tre;
+                tgt_im = tim;
+                use_track_i = carrier_track_i;
+                use_track_p = carrier_track_p;
+                const bool tune_now = (eq_skip <= 1);
+                eq_skip = tune_now  ?  10  :  (eq_skip - 1);
+                do_tune = tune_now;
+                constellation_state = nearest;
+            }
+            else
+            {
             if (stage == V29_NORMAL  ||  stage == V29_TEST_ONES)
                 decode_baud(zre, zim);
             switch (stage)
@@ -803,12 +1034,14 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
             default:
                 break;
             }
+            }
             if (do_track)
             {
                 const float error = zim*tgt_re - zre*tgt_im;
                 carrier_phase_rate += v29_f2i(use_track_i*error);
                 carrier_phase += (uint32_t) v29_f2i(use_track_p*error);
             }
+            SPG_PROF_STAMP(7);
             q.sync(6);
             if (do_tune)
             {
@@ -835,6 +1068,7 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                     }
                 }
             }
+            SPG_PROF_STAMP(8);
             q.sync(7);
             if (do_save)
             {
@@ -850,6 +1084,8 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
     }
     }
 
+    SPG_PROF_STAMP(9);
+    SPG_PROF_FLUSH();
     // ---- write back (arrays dealt over the lanes, scalars by the first) ------------------------------------------------
     q.sync(8);
     for (int i = role;  i < kRrcLen;  i += 4)

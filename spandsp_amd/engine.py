@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libspangpu.so")
+LIB_PATH = os.environ.get("SPANGPU_LIB", os.path.join(HERE, "libspangpu.so"))      # the variable: instrumented builds (tools/quad_prof.py)
 
 # include/spangpu.h
 DTMF, BELL_MF, R2_MF, SUPER_TONE, GOERTZEL, V29, V27TER, V17, ECHO = range(1, 10)
