@@ -14,6 +14,7 @@
 #include "v29_quad.hpp"
 #include "v27ter_dev.hpp"
 #include "v17_dev.hpp"
+#include "v17_quad.hpp"
 
 using namespace spg;
 
@@ -317,6 +318,8 @@ int spangpu_modem_create(spangpu_modem_t **out, int device, int kind, int n_chan
             {
                 t->rrc_re[tap*kV17Sets + set] = re[set*kRrcLen + tap];
                 t->rrc_im[tap*kV17Sets + set] = im[set*kRrcLen + tap];
+                t->rrc_q[2*(tap*kV17Sets + set)] = re[set*kRrcLen + tap];
+                t->rrc_q[2*(tap*kV17Sets + set) + 1] = im[set*kRrcLen + tap];
             }
         }
         spg_make_sine_table(t->sine);
@@ -524,16 +527,11 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
             const int waves = (m->n_ch + 63)/64;
             hipLaunchKernelGGL((v29_bank_kernel<64, false, 4, 16, true>), dim3((waves + 3)/4), dim3(256), 0, m->stream, L);
         }
-        else if (quad == 4)
+        else if (quad == 4  ||  quad == 8)
         {
             // banks that cannot fill the chip's 1 024 SIMDs with full waves of one channel per lane: four lanes per
             // channel, 16 channels per wave, four waves per workgroup sharing the tables (v29_quad.hpp)
             hipLaunchKernelGGL((v29_quad_kernel<16, 4>), dim3((m->n_ch + 63)/64), dim3(256), 0, m->stream, L);
-        }
-        else if (quad == 8)
-        {
-            // the same with eight channels per wave, eight waves per workgroup: two waves per SIMD
-            hipLaunchKernelGGL((v29_quad_kernel<8, 8>), dim3((m->n_ch + 63)/64), dim3(512), 0, m->stream, L);
         }
         else if (cpw == 32)
             hipLaunchKernelGGL(v29_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
@@ -565,6 +563,8 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
             const int waves = (m->n_ch + 63)/64;
             hipLaunchKernelGGL((v17_bank_kernel<64, false, 3, 16, true>), dim3((waves + 2)/3), dim3(192), 0, m->stream, L);
         }
+        else if (quad == 4  ||  quad == 8)
+            hipLaunchKernelGGL((v17_quad_kernel<16, 4>), dim3((m->n_ch + 63)/64), dim3(256), 0, m->stream, L);
         else if (cpw == 32)
             hipLaunchKernelGGL(v17_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
         else

@@ -6,6 +6,7 @@
 // exchange primitives are register moves:
 //   bcast<S>(v)   the value lane S of the quad holds          (v_mov_b32 quad_perm:[S,S,S,S], usually folded into its user)
 //   swap2(v)      the value of the lane two further on         (quad_perm:[2,3,0,1])
+//   swap1(v)      the value of the neighbouring lane            (quad_perm:[1,0,3,2])
 //   prev1(v)      the value of the lane before                  (quad_perm:[0,0,1,2])
 //   any(b)        true if b holds on any lane of the WAVE (a uniform branch around rare work; loop control)
 //   sync()        nothing: LDS operations of one wave are performed in program order
@@ -78,6 +79,8 @@ struct QuadHost
     template <int S> int bcast(int v, int site = 0) { return (int) exchange((uint32_t) v, S, 2000 + site); }
     float swap2(float v, int site = 0) { return __uint_as_float(exchange(__float_as_uint(v), lane ^ 2, 3000 + site)); }
     int prev1(int v, int site = 0) { return (int) exchange((uint32_t) v, (lane > 0)  ?  (lane - 1)  :  0, 6000 + site); }
+    uint32_t swap1(uint32_t v, int site = 0) { return exchange(v, lane ^ 1, 7000 + site); }
+    uint32_t swap2(uint32_t v, int site = 0) { return exchange(v, lane ^ 2, 8000 + site); }
     bool any(bool b, int site = 0)
     {
         const int g = st->gen[lane] & 1;
@@ -127,6 +130,14 @@ struct QuadDev
     __device__ __forceinline__ float swap2(float v, int = 0)
     {
         return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));     // quad_perm:[2,3,0,1]
+    }
+    __device__ __forceinline__ uint32_t swap1(uint32_t v, int = 0)
+    {
+        return (uint32_t) __builtin_amdgcn_mov_dpp((int) v, 0xB1, 0xF, 0xF, true);                     // quad_perm:[1,0,3,2]
+    }
+    __device__ __forceinline__ uint32_t swap2(uint32_t v, int = 0)
+    {
+        return (uint32_t) __builtin_amdgcn_mov_dpp((int) v, 0x4E, 0xF, 0xF, true);
     }
     // the value of the lane before (lane 0 of the quad: its own)
     __device__ __forceinline__ int prev1(int v, int = 0)

@@ -363,381 +363,23 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
     while (q.any(pos < tn, 1))
     {
         SPG_PROF_STAMP(0);
-        // ================= one round: up to four samples, at most one baud =================================================
-        // the three oldest taps of this lane's window (sample pos + role), before the round's samples overwrite them
-        int w0 = rrc_step + role + 1;
-        w0 = (w0 >= kRrcLen)  ?  (w0 - kRrcLen)  :  w0;
-        const float2 *xw = &C.rrc[w0];
-        const float2 xo0 = xw[0];
-        const float2 xo1 = xw[1];
-        const float2 xo2 = xw[2];
-        // what carrier detection needs of the round's four candidate samples, one per lane: the sample, half of it, its
-        // difference to the sample before (signal_detect(), v29rx.c:796-800) squared and as a magnitude
-        float my_ampf;
-        int my_x;
-        int my_sq;
-        int my_ad;
-        {
-            const int cand = min(pos + role, kV29QuadTile - 1);
-            const uint32_t pw = C.pcm[cand >> 1];
-            const int amp = (int) (short) ((cand & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
-            my_ampf = (float) amp;
-            my_x = amp >> 1;
-            const int before = q.prev1(my_x, 1);
-            const int diff = (int) (short) (my_x - ((role == 0)  ?  last_sample  :  before));
-            my_sq = diff*diff;
-            my_ad = (int) (short) abs(diff);
-        }
-        const int my_ad10 = (my_ad << 3) + (my_ad << 1);
-        const float ampf0 = q.template bcast<0>(my_ampf, 1);
-        const float ampf1 = q.template bcast<1>(my_ampf, 2);
-        const float ampf2 = q.template bcast<2>(my_ampf, 3);
-        const float ampf3 = q.template bcast<3>(my_ampf, 4);
-        const int x0 = q.template bcast<0>(my_x, 1);
-        const int x1 = q.template bcast<1>(my_x, 2);
-        const int x2 = q.template bcast<2>(my_x, 3);
-        const int x3 = q.template bcast<3>(my_x, 4);
-        const int sq0 = q.template bcast<0>(my_sq, 5);
-        const int sq1 = q.template bcast<1>(my_sq, 6);
-        const int sq2 = q.template bcast<2>(my_sq, 7);
-        const int sq3 = q.template bcast<3>(my_sq, 8);
-        const int ad0 = q.template bcast<0>(my_ad, 9);
-        const int ad1 = q.template bcast<1>(my_ad, 10);
-        const int ad2 = q.template bcast<2>(my_ad, 11);
-        const int ad3 = q.template bcast<3>(my_ad, 12);
-        const int adt0 = q.template bcast<0>(my_ad10, 13);
-        const int adt1 = q.template bcast<1>(my_ad10, 14);
-        const int adt2 = q.template bcast<2>(my_ad10, 15);
-        const int adt3 = q.template bcast<3>(my_ad10, 16);
-        q.sync(3);
-
-        SPG_PROF_STAMP(1);
-        // ---- the plan: carrier detect and T/2 bookkeeping of the round's samples, in order (replicated) -----------------
-        // Written with selects, and with the outcomes collected as bits of one register, not as booleans: the samples of a
-        // round take this path four times over, and every boolean that leaves a conditional region costs the compiler
-        // a handful of scalar mask instructions per nesting level.
-        enum
-        {
-            F_ACC = 1 << 0,                                 // + k: sample k of the round goes on into the filters
-            F_T2 = 1 << 4,                                  // + k: ... and is a T/2 instant
-            F_UP = 1 << 8,                                  // + k: carrier up reported at sample k
-            F_DOWN = 1 << 12,                               // + k: carrier down
-            F_STOP = 1 << 16,                               // the round takes no further sample
-            F_RESTART = 1 << 17,
-            F_BAUD = 1 << 18                                // the round completed a baud
-        };
-        int flags = 0;
-        int my_t2f = 0;
-        int e = eq_put_step;
-        int bh = baud_half;
-        int slot_run = eq_step;
-        uint32_t cp_run = carrier_phase;
-        int pw0 = 0, pw1 = 0, pw2 = 0, pw3 = 0;             // `power` at each sample (for the AGC)
-        int my_step = 0;
-        int my_slot = 0;
-        uint32_t my_cp = 0;
-        // -- The calm round.  A channel whose carrier is up and not about to drop (and that is not parked) sends every
-        // sample on into the filters, so which of the round's samples are T/2 instants follows from eq_put_step alone, in
-        // closed form and for all four lanes at once; what is left to do sample by sample is the power estimate.  That is
-        // done on copies: should the power fall under the carrier-off threshold on any channel of the wave after all, or
-        // should a channel not be calm to begin with, the general plan below runs from the untouched state (it writes
-        // the same samples into the delay line again).
-        const bool calm = (signal_present > 0)  &&  (drop_pending == 0)  &&  (stage != V29_PARKED);
-        bool fast = !q.any(!calm  &&  pos < tn, 7);
-        if (fast)
-        {
-            const int avail = min(tn - pos, 4);
-            const int E = eq_put_step;
-            // the first T/2 instant falls on sample k1, and leaves eq_put_step at E1; the second on k2
-            const int k1 = ((E > kRrcSets)  ?  1  :  0) + ((E > 2*kRrcSets)  ?  1  :  0) + ((E > 3*kRrcSets)  ?  1  :  0) + ((E > 4*kRrcSets)  ?  1  :  0);
-            const int E1 = E - kRrcSets*(k1 + 1) + kRrcSets*10/(3*2);
-            const int k2 = k1 + 1 + ((E1 > kRrcSets)  ?  1  :  0) + ((E1 > 2*kRrcSets)  ?  1  :  0) + ((E1 > 3*kRrcSets)  ?  1  :  0);
-            const bool second = (baud_half == 0);           // the round starts a baud: it takes two T/2 instants to finish it
-            const int nb = (second  ?  k2  :  k1) + 1;      // samples to the end of the baud
-            const int m = min(nb, avail);                   // samples this round takes
-            const bool t2a = (k1 < m);
-            const bool t2b = second  &&  (k2 < m);
-            // the power estimate over the round's samples (signal_detect(), v29rx.c:788-865), on copies
-            int t_pr = power_reading;
-            int t_high = high_sample;
-            int t_low = low_samples;
-            int badf = 0;
-            const int off1 = max(carrier_off_power, 1);
-            auto calm_sample = [&](const int k, const int sq, const int ad, const int ad10, int &pw_k)
-            {
-                if (k < m)
-                {
-                    const int power = t_pr + ((sq - t_pr) >> 4);
-                    badf |= (power < off1)  ?  1  :  0;
-                    const bool low = (ad10 < t_high);
-                    const int low_inc = t_low + 1;
-                    const bool wipe = low  &&  (low_inc > 120);
-                    t_pr = wipe  ?  0  :  power;
-                    t_high = low  ?  (wipe  ?  0  :  t_high)  :  max(t_high, ad);
-                    t_low = low  ?  (wipe  ?  0  :  low_inc)  :  0;
-                    pw_k = power;
-                }
-            };
-            calm_sample(0, sq0, ad0, adt0, pw0);
-            calm_sample(1, sq1, ad1, adt1, pw1);
-            calm_sample(2, sq2, ad2, adt2, pw2);
-            calm_sample(3, sq3, ad3, adt3, pw3);
-            // the samples into the delay line, each by its lane
-            if (role < m)
-            {
-                int idx = rrc_step + role;
-                idx = (idx >= kRrcLen)  ?  (idx - kRrcLen)  :  idx;
-                C.rrc[idx].x = my_ampf;
-                C.rrc[kRrcLen + idx].y = my_ampf;
-            }
-            fast = !q.any(badf != 0, 8);
-            if (fast)
-            {
-                power_reading = t_pr;
-                high_sample = t_high;
-                low_samples = t_low;
-                last_sample = (m >= 4)  ?  x3  :  (m == 3)  ?  x2  :  (m == 2)  ?  x1  :  (m == 1)  ?  x0  :  last_sample;
-                int rs = rrc_step + m;
-                rrc_step = (rs >= kRrcLen)  ?  (rs - kRrcLen)  :  rs;
-                pos += m;
-                const int c = (t2a  ?  1  :  0) + (t2b  ?  1  :  0);
-                eq_put_step = E - kRrcSets*m + (kRrcSets*10/(3*2))*c;
-                baud_half ^= c & 1;
-                // this lane's sample
-                const bool after1 = (role > k1);
-                const int d = E - kRrcSets*(role + 1) + (after1  ?  kRrcSets*10/(3*2)  :  0);
-                int step = -d;
-                step += (step < 0)  ?  kRrcSets  :  0;
-                my_step = max(0, min(kRrcSets - 1, step));
-                int sl = eq_step + (after1  ?  1  :  0);
-                my_slot = (sl >= kEqLen)  ?  (sl - kEqLen)  :  sl;
-                my_cp = carrier_phase + (uint32_t) role*(uint32_t) carrier_phase_rate;
-                my_t2f = ((role < m)  &&  (role == k1  ||  (second  &&  role == k2)))  ?  1  :  0;
-                int se = eq_step + c;
-                eq_step = (se >= kEqLen)  ?  (se - kEqLen)  :  se;
-                carrier_phase += (uint32_t) m*(uint32_t) carrier_phase_rate;
-                flags = ((1 << m) - 1) | (t2a  ?  (F_T2 << k1)  :  0) | (t2b  ?  (F_T2 << k2)  :  0) | ((nb <= avail)  ?  F_BAUD  :  0);
-            }
-        }
-        if (!fast)
-        {
-        auto plan_sample = [&](const int k, const bool mine, const float ampf, const int x, const int sq, const int ad, int &pw_k)
-        {
-            if ((flags & F_STOP) == 0  &&  pos < tn)
-            {
-                pos++;
-                // ---- v29_rx(), v29rx.c:885-961: the sample into the delay line (the zero halves of the pairs stay) ----
-                C.rrc[rrc_step].x = ampf;
-                C.rrc[kRrcLen + rrc_step].y = ampf;
-                rrc_step = (rrc_step == kRrcLen - 1)  ?  0  :  (rrc_step + 1);
-                // ---- signal_detect(), v29rx.c:788-865 (with the IAXMODEM_STUFF this snapshot #defines) ----
-                last_sample = x;
-                const int power = power_reading + ((sq - power_reading) >> 4);
-                const bool low = (10*ad < high_sample);
-                const int low_inc = low_samples + 1;
-                const bool wipe = low  &&  (low_inc > 120);
-                power_reading = wipe  ?  0  :  power;
-                high_sample = low  ?  (wipe  ?  0  :  high_sample)  :  max(high_sample, ad);
-                low_samples = low  ?  (wipe  ?  0  :  low_inc)  :  0;
-                const bool present = (signal_present > 0);
-                const bool dropping = present  &&  ((drop_pending != 0)  ||  (power < carrier_off_power));
-                const bool down = dropping  &&  (signal_present <= 1);
-                const bool up = !present  &&  (power >= carrier_on_power);
-                signal_present = up  ?  1  :  (dropping  ?  (signal_present - 1)  :  signal_present);
-                drop_pending = up  ?  0  :  (dropping  ?  1  :  drop_pending);
-                // carrier down: v29_rx_restart() wipes whatever the earlier samples of this round did, so the round ends
-                // here and the restart is carried out after it
-                flags |= up  ?  (F_UP << k)  :  0;
-                flags |= down  ?  ((F_DOWN << k) | F_STOP | F_RESTART)  :  0;
-                if (!down  &&  (present  ||  up)  &&  power != 0  &&  stage != V29_PARKED)
-                {
-                    pw_k = power;
-                    e -= kRrcSets;
-                    int step = -e;
-                    step += (step < 0)  ?  kRrcSets  :  0;
-                    step = max(0, min(kRrcSets - 1, step));
-                    const bool t2 = (e <= 0);
-                    flags |= t2  ?  ((F_ACC | F_T2) << k)  :  (F_ACC << k);
-                    my_t2f |= (mine  &&  t2)  ?  1  :  0;
-                    my_step = mine  ?  step  :  my_step;
-                    my_slot = mine  ?  slot_run  :  my_slot;
-                    my_cp = mine  ?  cp_run  :  my_cp;
-                    e += t2  ?  kRrcSets*10/(3*2)  :  0;
-                    const int slot_next = (slot_run == kEqLen - 1)  ?  0  :  (slot_run + 1);
-                    slot_run = t2  ?  slot_next  :  slot_run;
-                    bh ^= t2  ?  1  :  0;
-                    flags |= (t2  &&  bh == 0)  ?  (F_STOP | F_BAUD)  :  0;
-                    cp_run += (uint32_t) carrier_phase_rate;
-                }
-            }
-        };
-        plan_sample(0, role == 0, ampf0, x0, sq0, ad0, pw0);
-        plan_sample(1, role == 1, ampf1, x1, sq1, ad1, pw1);
-        plan_sample(2, role == 2, ampf2, x2, sq2, ad2, pw2);
-        plan_sample(3, role == 3, ampf3, x3, sq3, ad3, pw3);
-        if (q.any((flags & (0xFF*F_UP)) != 0, 2))
-        {
-            // SIG_STATUS_CARRIER_UP (-2) / SIG_STATUS_CARRIER_DOWN (-1), in the order of the samples
-            for (int k = 0;  k < 4;  k++)
-            {
-                if (flags & (F_UP << k))
-                    emit(-2);
-                if (flags & (F_DOWN << k))
-                    emit(-1);
-            }
-            if (flags & F_RESTART)
-            {
-                restart();
-                flags = F_RESTART;
-                my_t2f = 0;
-            }
-        }
-        if ((flags & F_RESTART) == 0)
-        {
-            eq_put_step = e;
-            baud_half = bh;
-            eq_step = slot_run;
-            carrier_phase = cp_run;
-        }
-        }
-        SPG_PROF_STAMP(2);
-        q.sync(4);
-        if (!q.any((flags & (0xF*F_ACC)) != 0, 3))
-            continue;
-        const bool my_t2 = (my_t2f != 0);
-        const bool baud_done = (flags & F_BAUD) != 0;
-
-        // ---- the round's root raised cosine filters: lane r, sample r, real and imaginary ------------------------------
-        // vec_circular_dot_prodf(rrc_filter, coeffs[step], 27, rrc_step), vector_float.c:890-939, twice
-        float vre;
-        float vim;
-        {
-            const float2 *y = &T.rrc[my_step];
-            f32x2v are = {0.0f, 0.0f};
-            f32x2v aim = {0.0f, 0.0f};
-            {
-                const float2 c0 = y[0*kRrcSets];
-                const float2 c1 = y[1*kRrcSets];
-                const float2 c2 = y[2*kRrcSets];
-                are += (f32x2v) {xo0.x, xo0.y}*(f32x2v) {c0.x, c0.x};
-                aim += (f32x2v) {xo0.x, xo0.y}*(f32x2v) {c0.y, c0.y};
-                are += (f32x2v) {xo1.x, xo1.y}*(f32x2v) {c1.x, c1.x};
-                aim += (f32x2v) {xo1.x, xo1.y}*(f32x2v) {c1.y, c1.y};
-                are += (f32x2v) {xo2.x, xo2.y}*(f32x2v) {c2.x, c2.x};
-                aim += (f32x2v) {xo2.x, xo2.y}*(f32x2v) {c2.y, c2.y};
-            }
-            SPG_UNROLL
-            for (int i0 = 3;  i0 < kRrcLen;  i0 += 8)
-            {
-                float2 xs[8];
-                float2 cs[8];
-                SPG_UNROLL
-                for (int i = 0;  i < 8;  i++)
-                {
-                    xs[i] = xw[i0 + i];
-                    cs[i] = y[(i0 + i)*kRrcSets];
-                }
-                SPG_UNROLL
-                for (int i = 0;  i < 8;  i++)
-                {
-                    are += (f32x2v) {xs[i].x, xs[i].y}*(f32x2v) {cs[i].x, cs[i].x};
-                    aim += (f32x2v) {xs[i].x, xs[i].y}*(f32x2v) {cs[i].y, cs[i].y};
-                }
-                // SPG_SCHED_FENCE();
-            }
-            vre = are.x + are.y;
-            vim = aim.x + aim.y;
-        }
-
-        SPG_PROF_STAMP(3);
-        // ---- AGC and the Godard filters, sample by sample (replicated); each lane keeps its own sample's values --------
-        float my_sre = 0.0f;
-        float my_agc = agc_scaling;
-        auto post_sample = [&](const bool mine, const float v, const bool acc_k, const bool t2_k, const int power)
-        {
-            if (acc_k)
-            {
-                const float sre = v*agc_scaling;
-                {
-                    // godard_ted_rx(), godard.c:144-162
-                    const float tl = glow0*g0 + glow1*g1 + sre;
-                    glow1 = glow0;
-                    glow0 = tl;
-                    const float th = ghigh0*g3 + ghigh1*g4 + sre;
-                    ghigh1 = ghigh0;
-                    ghigh0 = th;
-                }
-                my_sre = mine  ?  sre  :  my_sre;
-                if (q.any(t2_k  &&  agc_scaling_save == 0.0f, 6))
-                {
-                    if (t2_k  &&  agc_scaling_save == 0.0f)
-                    {
-                        // fixed_sqrt32(), math_fixed.c:158-169
-                        int root_power;
-                        {
-                            uint32_t xx = (uint32_t) power;
-                            const int top = 31 - __builtin_clz(xx);
-                            const int shift = 30 - (top & ~1);
-                            xx <<= shift;
-                            root_power = TB.sqrt_tab[((xx >> 24) & 0xFF) - 64] >> (shift >> 1);     // rare: from global memory
-                        }
-                        if (root_power == 0)
-                            root_power = 1;
-                        agc_scaling = (1.25f/1.0f)/(float) root_power;
-                    }
-                }
-                my_agc = (mine  &&  t2_k)  ?  agc_scaling  :  my_agc;
-            }
-        };
-        if (!q.any(agc_scaling_save == 0.0f, 10))
-        {
-            // the AGC of every channel of the wave has settled: one gain for the whole round
-            my_sre = vre*agc_scaling;
-            auto godard_sample = [&](const bool acc_k, const float sre)
-            {
-                if (acc_k)
-                {
-                    // godard_ted_rx(), godard.c:144-162
-                    const float tl = glow0*g0 + glow1*g1 + sre;
-                    glow1 = glow0;
-                    glow0 = tl;
-                    const float th = ghigh0*g3 + ghigh1*g4 + sre;
-                    ghigh1 = ghigh0;
-                    ghigh0 = th;
-                }
-            };
-            godard_sample((flags & (F_ACC << 0)) != 0, q.template bcast<0>(my_sre, 11));
-            godard_sample((flags & (F_ACC << 1)) != 0, q.template bcast<1>(my_sre, 12));
-            godard_sample((flags & (F_ACC << 2)) != 0, q.template bcast<2>(my_sre, 13));
-            godard_sample((flags & (F_ACC << 3)) != 0, q.template bcast<3>(my_sre, 14));
-        }
-        else
-        {
-            post_sample(role == 0, q.template bcast<0>(vre, 5), (flags & (F_ACC << 0)) != 0, (flags & (F_T2 << 0)) != 0, pw0);
-            post_sample(role == 1, q.template bcast<1>(vre, 6), (flags & (F_ACC << 1)) != 0, (flags & (F_T2 << 1)) != 0, pw1);
-            post_sample(role == 2, q.template bcast<2>(vre, 7), (flags & (F_ACC << 2)) != 0, (flags & (F_T2 << 2)) != 0, pw2);
-            post_sample(role == 3, q.template bcast<3>(vre, 8), (flags & (F_ACC << 3)) != 0, (flags & (F_T2 << 3)) != 0, pw3);
-        }
-
-        SPG_PROF_STAMP(4);
-        // ---- the T/2 instants of the round, each on the lane that owns the sample ------------------------------------------
-        if (my_t2)
-        {
-            const float sim = vim*my_agc;
-            // dds_lookup_complexf(), dds_float.c:2135,2177
-            const float dre = T.sine[(uint32_t) (my_cp + (1u << 30)) >> 21];
-            const float dim = T.sine[my_cp >> 21];
-            const float hre = my_sre*dre - sim*dim;
-            const float him = -my_sre*dim - sim*dre;
-            const float2 h = make_float2(hre, him);
-            C.u[my_slot] = h;
-            C.u[2*kEqLen + my_slot] = h;
-            C.u[3*kEqLen + my_slot] = h;
-        }
-        SPG_PROF_STAMP(5);
-        q.sync(5);
-        if (!q.any(baud_done, 4))
-            continue;
+#define QF_SETS                 kRrcSets
+#define QF_PUT_ADD              (kRrcSets*10/(3*2))
+#define QF_PARKED               V29_PARKED
+#define QF_AGC_NUM              (1.25f/1.0f)
+#define QF_TILE                 kV29QuadTile
+#define QF_EQLEN                kEqLen
+#define QF_RRC_COEF(tap)        T.rrc[(tap)*kRrcSets + my_step]
+#define QF_EQ_THIRD_COPY(k, h)  C.u[3*kEqLen + (k)] = (h)
+#include "quad_round_front.inc"
+#undef QF_SETS
+#undef QF_PUT_ADD
+#undef QF_PARKED
+#undef QF_AGC_NUM
+#undef QF_TILE
+#undef QF_EQLEN
+#undef QF_RRC_COEF
+#undef QF_EQ_THIRD_COPY
 
         // ---- the baud (process_half_baud() of the second T/2 instant, v29rx.c:484-786) ---------------------------------
         if (baud_done)

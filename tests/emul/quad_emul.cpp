@@ -7,6 +7,7 @@
 #include <ucontext.h>
 
 #include "../../spandsp_amd/csrc/v29_quad.hpp"
+#include "../../spandsp_amd/csrc/v17_quad.hpp"
 #include "../../spandsp_amd/csrc/modem_tables.h"
 
 namespace spg {
@@ -140,6 +141,28 @@ static void v29_body(int lane, void *arg)
     v29_quad_run(q, j->L, 0, j->T, j->C);
 }
 
+struct V17Job
+{
+    V17Launch L;
+    V17QuadTables T;
+    V17QuadChan C;
+    uint32_t pcm[kQuadPcmStride];
+    float2 rrc[kQuadRrcStride];
+    float2 u[kQuad17EqStride];
+    float taps[kQuadTapStride];
+    uint32_t trellis[kQuad17TrellisStride];
+    QuadHostState st;
+};
+
+static void v17_body(int lane, void *arg)
+{
+    V17Job *j = (V17Job *) arg;
+    QuadHost q;
+    q.st = &j->st;
+    q.lane = lane;
+    v17_quad_run(q, j->L, 0, j->T, j->C);
+}
+
 }   // namespace spg
 
 using namespace spg;
@@ -188,6 +211,86 @@ extern "C" int emul_v29_rx(uint32_t *state, const int16_t *amp, int n, int8_t *e
     job.C.u = job.u;
     job.C.taps = job.taps;
     const int errs = run_quad(v29_body, &job, &job.st, order);
+    if (errs)
+        return -errs;
+    return count;
+}
+
+static V17Tables g_v17_tab;
+static int g_v17_rate;
+
+// One channel's v17_rx() call: state = the 547 state words (in and out), returns the number of events or < 0.
+extern "C" int emul_v17_rx(int bit_rate, uint32_t *state, const int16_t *amp, int n, int8_t *events, int ev_cap, const int *order)
+{
+    if (g_v17_rate != bit_rate)
+    {
+        // as spangpu_modem_create() builds them (modem_api.hip)
+        V17Tables *t = &g_v17_tab;
+        memset(t, 0, sizeof(*t));
+        float *re = (float *) malloc(2*kV17Sets*kRrcLen*sizeof(float));
+        uint8_t *maps = (uint8_t *) malloc(4*36*36*8 + 36*36);
+        int8_t pts[128][2];
+        float *im = re + kV17Sets*kRrcLen;
+        spg_make_rx_pulseshaper(kV17Sets, kRrcLen, 1800.0, 2400.0, 0.5, re, im);
+        for (int set = 0;  set < kV17Sets;  set++)
+        {
+            for (int tap = 0;  tap < kRrcLen;  tap++)
+            {
+                t->rrc_re[tap*kV17Sets + set] = re[set*kRrcLen + tap];
+                t->rrc_im[tap*kV17Sets + set] = im[set*kRrcLen + tap];
+                t->rrc_q[2*(tap*kV17Sets + set)] = re[set*kRrcLen + tap];
+                t->rrc_q[2*(tap*kV17Sets + set) + 1] = im[set*kRrcLen + tap];
+            }
+        }
+        spg_make_sine_table(t->sine);
+        spg_make_sqrt_table(t->sqrt_tab);
+        spg_make_godard(1800.0, 2400.0, 0.99, t->godard);
+        t->coarse_trigger = 1000.0f;
+        t->fine_trigger = 100.0f;
+        t->coarse_step = 15;
+        t->fine_step = 1;
+        const int np = spg_make_v17_constellation(bit_rate, pts);
+        for (int k = 0;  k < np;  k++)
+        {
+            t->con[2*k] = (float) pts[k][0];
+            t->con[2*k + 1] = (float) pts[k][1];
+        }
+        spg_make_v17_rx_maps(maps, maps + 4*36*36*8);
+        const int space_map = (bit_rate == 12000)  ?  1  :  (bit_rate == 9600)  ?  2  :  (bit_rate == 7200)  ?  3  :  0;
+        if (bit_rate == 4800)
+            memcpy(t->map, maps + 4*36*36*8, 36*36);
+        else
+            memcpy(t->map, maps + (size_t) space_map*36*36*8, 36*36*8);
+        free(re);
+        free(maps);
+        g_v17_rate = bit_rate;
+    }
+    static V17Job job;
+    memset(&job, 0, sizeof(job));
+    int32_t count = 0;
+    job.L.amp = amp;
+    job.L.stride = n;
+    job.L.samples = n;
+    job.L.lens = nullptr;
+    job.L.n_ch = 1;
+    job.L.bit_rate = bit_rate;
+    job.L.state = state;
+    job.L.events = events;
+    job.L.ev_count = &count;
+    job.L.ev_cap = ev_cap;
+    job.L.tab = &g_v17_tab;
+    v17_quad_tables(job.T, g_v17_tab, 0, 1);
+    memset(job.pcm, 0xA5, sizeof(job.pcm));
+    memset(job.rrc, 0xA5, sizeof(job.rrc));
+    memset(job.u, 0xA5, sizeof(job.u));
+    memset(job.taps, 0xA5, sizeof(job.taps));
+    memset(job.trellis, 0xA5, sizeof(job.trellis));
+    job.C.pcm = job.pcm;
+    job.C.rrc = job.rrc;
+    job.C.u = job.u;
+    job.C.taps = job.taps;
+    job.C.trellis = job.trellis;
+    const int errs = run_quad(v17_body, &job, &job.st, order);
     if (errs)
         return -errs;
     return count;

@@ -24,6 +24,8 @@ def emul():
     lib = ctypes.CDLL(so)
     lib.emul_v29_rx.restype = ctypes.c_int
     lib.emul_v29_rx.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.emul_v17_rx.restype = ctypes.c_int
+    lib.emul_v17_rx.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     return lib
 
 
@@ -48,8 +50,9 @@ def channel_signals(bit_rate, n_ch, seed, fixture="v29_%d.npz"):
 ORDERS = [(0, 1, 2, 3), (3, 2, 1, 0), (2, 0, 3, 1)]
 
 
-def run_emul_v29(lib, words, x, chunks, order):
+def run_emul_v29(lib, words, x, chunks, order, call=None):
     """-> per call (events, words after)"""
+    call = call or lib.emul_v29_rx
     out = []
     ev = np.zeros(4096, np.int8)
     o = np.array(order, np.int32)
@@ -58,7 +61,7 @@ def run_emul_v29(lib, words, x, chunks, order):
     while k < len(x):
         n = chunks[i % len(chunks)]
         blk = np.ascontiguousarray(x[k:k + n])
-        got = lib.emul_v29_rx(w.ctypes.data, blk.ctypes.data, len(blk), ev.ctypes.data, len(ev), o.ctypes.data)
+        got = call(w.ctypes.data, blk.ctypes.data, len(blk), ev.ctypes.data, len(ev), o.ctypes.data)
         assert got >= 0, ("the lanes of the quad left their common path", got)
         out.append((ev[:got].copy(), w.copy()))
         k += n
@@ -94,3 +97,43 @@ def test_v29_quad_on_the_host_matches_oracle(built, emul, bit_rate, chunks):
             k += n
             i += 1
     assert total > 1500*n_ch//2
+
+
+def against_oracle(make_oracle, call, sig, chunks, what):
+    total = 0
+    seen = set()
+    for c in range(sig.shape[0]):
+        o = make_oracle()
+        f0, w0 = o.snapshot()
+        words = np.concatenate([bits(f0), w0.view(np.uint32)]).astype(np.uint32)
+        got = run_emul_v29(None, words, sig[c], chunks, ORDERS[c % len(ORDERS)], call=call)
+        k = i = 0
+        while k < sig.shape[1]:
+            n = chunks[i % len(chunks)]
+            o.sink.clear()
+            o.rx(sig[c, k:k + n])
+            ev = o.sink.events()["a"].astype(np.int8)
+            f, w = o.snapshot()
+            want = np.concatenate([bits(f), w.view(np.uint32)])
+            assert np.array_equal(got[i][0], ev), (what, "events", c, i)
+            bad = np.nonzero(got[i][1] != want)[0]
+            assert bad.size == 0, (what, "state words", c, i, bad[:10])
+            total += len(ev)
+            seen.update(int(v) for v in ev if v < 0)
+            k += n
+            i += 1
+    return total, seen
+
+
+@pytest.mark.parametrize("bit_rate", [14400, 12000, 9600, 7200, 4800])
+@pytest.mark.parametrize("chunks", [(160,), (400, 3, 1, 97)])
+def test_v17_quad_on_the_host_matches_oracle(built, emul, bit_rate, chunks):
+    from oracle import restated as orc
+    use_golden_modem_tables()
+    n_ch = 5
+    sig = channel_signals(bit_rate, n_ch, seed=bit_rate + len(chunks), fixture="v17_%d.npz")
+
+    def call(*a):
+        return emul.emul_v17_rx(bit_rate, *a)
+    total, seen = against_oracle(lambda: orc.V17(bit_rate), call, sig, chunks, ("v17", bit_rate))
+    assert total > 1200*n_ch//3 and {-1, -2, -3, -4} <= seen
