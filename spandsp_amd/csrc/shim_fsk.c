@@ -42,6 +42,8 @@ struct spangpu_line_group_s
     int16_t *stage;
     void **handles;
     int32_t *lens;              /* per channel: samples staged for the tick being collected (0 = none) */
+    int32_t *run;               /* ... and of the tick whose callbacks are being delivered */
+    int delivering;             /* a tick's callbacks are being made: staging from inside them waits for the next flush */
     int n_attached;
     int n_staged;
     pthread_mutex_t lock;       /* staging, attach / detach and the tick itself (recursive: callbacks may call back in) */
@@ -78,6 +80,7 @@ static spangpu_line_group_t *group_new(int n_channels, int max_samples)
     g->stage = (int16_t *) calloc((size_t) n_channels*max_samples, sizeof(int16_t));
     g->handles = (void **) calloc(n_channels, sizeof(void *));
     g->lens = (int32_t *) calloc(n_channels, sizeof(int32_t));
+    g->run = (int32_t *) calloc(n_channels, sizeof(int32_t));
     {
         pthread_mutexattr_t at;
 
@@ -86,7 +89,7 @@ static spangpu_line_group_t *group_new(int n_channels, int max_samples)
         pthread_mutex_init(&g->lock, &at);
         pthread_mutexattr_destroy(&at);
     }
-    if (g->stage == NULL  ||  g->handles == NULL  ||  g->lens == NULL)
+    if (g->stage == NULL  ||  g->handles == NULL  ||  g->lens == NULL  ||  g->run == NULL)
     {
         spangpu_line_group_destroy(g);
         return NULL;
@@ -141,9 +144,23 @@ int spangpu_line_group_destroy(spangpu_line_group_t *g)
     free(g->stage);
     free(g->handles);
     free(g->lens);
+    free(g->run);
     pthread_mutex_destroy(&g->lock);
     free(g);
     return 0;
+}
+
+/* The tick is over, whatever came of it: its frames leave the staging area before anything is delivered -- a failure must
+   not make every later call a "second frame" or run the same frames again, and a callback that stages a new frame finds
+   a clean slate (that frame waits for the next tick).  Returns how many frames the tick had. */
+static int tick_taken(spangpu_line_group_t *g)
+{
+    const int took = g->n_staged;
+
+    memcpy(g->run, g->lens, sizeof(int32_t)*g->n_ch);
+    memset(g->lens, 0, sizeof(int32_t)*g->n_ch);
+    g->n_staged = 0;
+    return took;
 }
 
 /* Run the tick with the receivers that have staged a frame; the others sit it out, untouched (as the reference's are when
@@ -156,23 +173,27 @@ static int line_flush_locked(spangpu_line_group_t *g)
     int n;
     int rc;
 
-    if (g->n_staged == 0)
+    int took;
+
+    if (g->n_staged == 0  ||  g->delivering)
         return 0;
     if (g->is_mct)
     {
         const int32_t *events;
         const int32_t *counts;
 
-        if ((rc = spangpu_mct_rx_var(g->mct, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples)) < 0)
-            return rc;
-        if ((cap = spangpu_mct_events(g->mct, &events, &counts)) < 0)
+        rc = spangpu_mct_rx_var(g->mct, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples);
+        cap = (rc < 0)  ?  rc  :  spangpu_mct_events(g->mct, &events, &counts);
+        took = tick_taken(g);
+        if (cap < 0)
             return cap;
+        g->delivering = 1;
         for (c = 0;  c < g->n_ch;  c++)
         {
             modem_connect_tones_rx_state_t *s = (modem_connect_tones_rx_state_t *) g->handles[c];
 
             n = (counts[c] < cap)  ?  counts[c]  :  cap;
-            if (s  &&  s->tone_callback  &&  g->lens[c] > 0)
+            if (s  &&  s->tone_callback  &&  g->run[c] > 0)
             {
                 /* report_tone_state(), modem_connect_tones.c:420-423 */
                 for (i = 0;  i < n;  i++)
@@ -185,16 +206,18 @@ static int line_flush_locked(spangpu_line_group_t *g)
         const int16_t *events;
         const int32_t *counts;
 
-        if ((rc = spangpu_fsk_rx_var(g->fsk, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples)) < 0)
-            return rc;
-        if ((cap = spangpu_fsk_events(g->fsk, &events, &counts)) < 0)
+        rc = spangpu_fsk_rx_var(g->fsk, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples);
+        cap = (rc < 0)  ?  rc  :  spangpu_fsk_events(g->fsk, &events, &counts);
+        took = tick_taken(g);
+        if (cap < 0)
             return cap;
+        g->delivering = 1;
         for (c = 0;  c < g->n_ch;  c++)
         {
             fsk_rx_state_t *s = (fsk_rx_state_t *) g->handles[c];
 
             n = (counts[c] < cap)  ?  counts[c]  :  cap;
-            if (s  &&  g->lens[c] > 0)
+            if (s  &&  g->run[c] > 0)
             {
                 for (i = 0;  i < n;  i++)
                 {
@@ -209,10 +232,8 @@ static int line_flush_locked(spangpu_line_group_t *g)
             }
         }
     }
-    rc = g->n_staged;
-    memset(g->lens, 0, sizeof(int32_t)*g->n_ch);
-    g->n_staged = 0;
-    return rc;
+    g->delivering = 0;
+    return took;
 }
 
 int spangpu_line_group_flush(spangpu_line_group_t *g)

@@ -26,6 +26,8 @@ struct spangpu_modem_group_s
     int16_t *stage;
     void **handles;
     int32_t *lens;              /* per channel: samples staged for the tick being collected (0 = none) */
+    int32_t *run;               /* ... and of the tick whose callbacks are being delivered */
+    int delivering;             /* a tick's callbacks are being made: staging from inside them waits for the next flush */
     int n_attached;
     int n_staged;
     pthread_mutex_t lock;       /* staging, attach / detach and the tick itself (recursive: callbacks may call back in) */
@@ -83,6 +85,7 @@ spangpu_modem_group_t *spangpu_modem_group_create(int device, int kind, int n_ch
     g->stage = (int16_t *) calloc((size_t) n_channels*max_samples, sizeof(int16_t));
     g->handles = (void **) calloc(n_channels, sizeof(void *));
     g->lens = (int32_t *) calloc(n_channels, sizeof(int32_t));
+    g->run = (int32_t *) calloc(n_channels, sizeof(int32_t));
     {
         pthread_mutexattr_t at;
 
@@ -91,7 +94,7 @@ spangpu_modem_group_t *spangpu_modem_group_create(int device, int kind, int n_ch
         pthread_mutex_init(&g->lock, &at);
         pthread_mutexattr_destroy(&at);
     }
-    if (g->stage == NULL  ||  g->handles == NULL  ||  g->lens == NULL
+    if (g->stage == NULL  ||  g->handles == NULL  ||  g->lens == NULL  ||  g->run == NULL
         ||  spangpu_modem_create(&g->bank, device, kind, n_channels, bit_rate) != SPANGPU_OK)
     {
         spangpu_modem_group_destroy(g);
@@ -109,6 +112,7 @@ int spangpu_modem_group_destroy(spangpu_modem_group_t *g)
     free(g->stage);
     free(g->handles);
     free(g->lens);
+    free(g->run);
     pthread_mutex_destroy(&g->lock);
     free(g);
     return 0;
@@ -176,25 +180,33 @@ static int group_flush_locked(spangpu_modem_group_t *g)
     int c;
     int rc;
 
-    if (g->n_staged == 0)
+    if (g->n_staged == 0  ||  g->delivering)
         return 0;
-    if ((rc = spangpu_modem_rx_var(g->bank, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples)) < 0)
-        return rc;
-    if ((cap = spangpu_modem_events(g->bank, &events, &counts)) < 0)
-        return cap;
-    if (g->qam_tap  &&  (qcap = spangpu_modem_qam_reports(g->bank, &qam, &qcounts)) < 0)
-        return qcap;
+    rc = spangpu_modem_rx_var(g->bank, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples);
+    cap = (rc < 0)  ?  rc  :  spangpu_modem_events(g->bank, &events, &counts);
+    if (cap >= 0  &&  g->qam_tap)
+        qcap = spangpu_modem_qam_reports(g->bank, &qam, &qcounts);
+    /* The tick is over whatever happened: its frames are taken off the staging area before anything is delivered, so
+       that a failure cannot make every later xxx_rx() a "second frame" (or run the same frames again), and so that a
+       callback which stages a new frame sees a clean slate (that frame waits for the next tick). */
     rc = g->n_staged;
+    memcpy(g->run, g->lens, sizeof(int32_t)*g->n_ch);
+    memset(g->lens, 0, sizeof(int32_t)*g->n_ch);
+    g->n_staged = 0;
+    if (cap < 0)
+        return cap;
+    if (qcap < 0)
+        return qcap;
+    g->delivering = 1;
     for (c = 0;  c < g->n_ch;  c++)
     {
-        if (g->handles[c]  &&  g->lens[c] > 0)
+        if (g->handles[c]  &&  g->run[c] > 0)
         {
             deliver((modem_obj_t *) g->handles[c], events + (size_t) c*cap, (counts[c] < cap)  ?  counts[c]  :  cap,
                     qam  ?  qam + (size_t) c*qcap*7  :  NULL, qam  ?  ((qcounts[c] < qcap)  ?  qcounts[c]  :  qcap)  :  0);
         }
-        g->lens[c] = 0;
     }
-    g->n_staged = 0;
+    g->delivering = 0;
     return rc;
 }
 

@@ -32,6 +32,8 @@ struct spangpu_group_s
     int16_t *stage;             /* [n_ch][max_samples] */
     void **handles;             /* per channel: the attached state object or NULL */
     int32_t *lens;              /* per channel: samples staged for the tick being collected (0 = none) */
+    int32_t *run;               /* ... and of the tick whose callbacks are being delivered */
+    int delivering;             /* a tick's callbacks are being made: staging from inside them waits for the next flush */
     int n_attached;
     int n_staged;
     pthread_mutex_t lock;       /* staging, attach / detach and the tick itself (recursive: callbacks may call back in) */
@@ -183,6 +185,7 @@ spangpu_group_t *spangpu_group_create(int device, int kind, int n_channels, int 
     g->stage = (int16_t *) calloc((size_t) n_channels*max_samples, sizeof(int16_t));
     g->handles = (void **) calloc(n_channels, sizeof(void *));
     g->lens = (int32_t *) calloc(n_channels, sizeof(int32_t));
+    g->run = (int32_t *) calloc(n_channels, sizeof(int32_t));
     {
         pthread_mutexattr_t at;
 
@@ -191,7 +194,7 @@ spangpu_group_t *spangpu_group_create(int device, int kind, int n_channels, int 
         pthread_mutex_init(&g->lock, &at);
         pthread_mutexattr_destroy(&at);
     }
-    if (g->stage == NULL  ||  g->handles == NULL  ||  g->lens == NULL)
+    if (g->stage == NULL  ||  g->handles == NULL  ||  g->lens == NULL  ||  g->run == NULL)
     {
         spangpu_group_destroy(g);
         return NULL;
@@ -207,6 +210,7 @@ int spangpu_group_destroy(spangpu_group_t *g)
     free(g->stage);
     free(g->handles);
     free(g->lens);
+    free(g->run);
     free(g->blocks);
     pthread_mutex_destroy(&g->lock);
     free(g);
@@ -229,14 +233,10 @@ static int group_flush_locked(spangpu_group_t *g)
     int start;
     int ch;
 
-    if (g->n_staged == 0)
+    if (g->n_staged == 0  ||  g->delivering)
         return 0;
     rc = spangpu_bank_rx_var(g->bank, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples);
-    if (rc < 0)
-        return rc;
-    n = spangpu_bank_blocks(g->bank, NULL, 0);
-    if (n < 0)
-        return n;
+    n = (rc < 0)  ?  rc  :  spangpu_bank_blocks(g->bank, NULL, 0);
     if (n > g->blocks_cap)
     {
         free(g->blocks);
@@ -244,29 +244,37 @@ static int group_flush_locked(spangpu_group_t *g)
         if ((g->blocks = (spangpu_block_t *) malloc(sizeof(spangpu_block_t)*g->blocks_cap)) == NULL)
         {
             g->blocks_cap = 0;
-            return SPANGPU_ERR_NO_MEMORY;
+            n = SPANGPU_ERR_NO_MEMORY;
         }
     }
-    if (n > 0  &&  (n = spangpu_bank_blocks(g->bank, g->blocks, g->blocks_cap)) < 0)
+    if (n > 0)
+        n = spangpu_bank_blocks(g->bank, g->blocks, g->blocks_cap);
+    /* The tick is over, whatever came of it: its frames leave the staging area before anything is delivered -- a failure
+       must not make every later call a "second frame" or run the same frames again, and a callback that stages a new
+       frame finds a clean slate (that frame waits for the next tick). */
+    rc = g->n_staged;
+    memcpy(g->run, g->lens, sizeof(int32_t)*g->n_ch);
+    memset(g->lens, 0, sizeof(int32_t)*g->n_ch);
+    g->n_staged = 0;
+    if (n < 0)
         return n;
     /* Records arrive in (channel, block) order: replay channel by channel. */
+    g->delivering = 1;
     start = 0;
     for (ch = 0;  ch < g->n_ch;  ch++)
     {
         i = start;
         while (i < n  &&  g->blocks[i].channel == ch)
             i++;
-        if (g->handles[ch]  &&  g->lens[ch] > 0)
+        if (g->handles[ch]  &&  g->run[ch] > 0)
         {
             replay(g, ch, &g->blocks[start], i - start);
             end_of_call(g, ch);
         }
         start = i;
     }
-    n = g->n_staged;
-    memset(g->lens, 0, sizeof(int32_t)*g->n_ch);
-    g->n_staged = 0;
-    return n;
+    g->delivering = 0;
+    return rc;
 }
 
 int spangpu_group_flush(spangpu_group_t *g)

@@ -1050,8 +1050,10 @@ int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, i
         switch (b->kind)
         {
         case SPANGPU_DTMF:
-            if (b->tp.filter_dialtone)
-                return fail(SPANGPU_ERR_UNSUPPORTED, "a DTMF bank with the dial-tone filter cannot share a launch");
+            // the shared launch runs the unfiltered detector: what counts is whether any channel's filter is on (a bank
+            // given per-channel parameters keeps the switch per channel; launch_bank() tests the same)
+            if (b->chan_parms  ?  (b->n_filter_on > 0)  :  (b->tp.filter_dialtone != 0))
+                return fail(SPANGPU_ERR_UNSUPPORTED, "a DTMF bank with a dial-tone filter switched on cannot share a launch");
             M.kind[k] = TONE_K_DTMF;
             break;
         case SPANGPU_BELL_MF: M.kind[k] = TONE_K_BELL; break;
@@ -1064,6 +1066,10 @@ int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, i
         default:
             return fail(SPANGPU_ERR_UNSUPPORTED, "bank kind %d cannot share a launch", b->kind);
         }
+        // the kernels of a shared launch write records, not digit bytes: a bank whose caller collects digit bytes
+        // (spangpu_bank_set_digits_buffer / _ring) would hand on stale bytes and lose a slice of its ring
+        if (b->ext_digits)
+            return fail(SPANGPU_ERR_UNSUPPORTED, "a bank with a digits buffer cannot share a launch (it would get no digit bytes)");
         const long long stride = (strides  &&  strides[k] > 0)  ?  strides[k]  :  samples;
         const int maxb = (samples + b->block_len - 1)/b->block_len;
         const int rc = ensure_outputs(b, (maxb > 0)  ?  maxb  :  1);
@@ -1610,14 +1616,26 @@ int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int 
         if (rc != SPANGPU_OK)
             return rc;
     }
-    if (c->d_first) (void) hipFree(c->d_first);
-    if (c->d_elem) (void) hipFree(c->d_elem);
-    c->d_first = nullptr;
-    c->d_elem = nullptr;
-    HIP_TRY(hipMalloc(&c->d_first, first.size()*sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&c->d_elem, el.size()*sizeof(int4)));
-    HIP_TRY(hipMemcpy(c->d_first, first.data(), first.size()*sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_elem, el.data(), el.size()*sizeof(int4), hipMemcpyHostToDevice));
+    // the new tables are made and filled first and swapped in only when they are complete: a failure leaves the bank on
+    // its old set (a live bank's next launch reads first[] and elem[] on the device)
+    {
+        int32_t *n_first = nullptr;
+        int4 *n_elem = nullptr;
+        if (hipMalloc(&n_first, first.size()*sizeof(int32_t)) != hipSuccess
+            ||  hipMalloc(&n_elem, el.size()*sizeof(int4)) != hipSuccess
+            ||  hipMemcpy(n_first, first.data(), first.size()*sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess
+            ||  hipMemcpy(n_elem, el.data(), el.size()*sizeof(int4), hipMemcpyHostToDevice) != hipSuccess)
+        {
+            if (n_first) (void) hipFree(n_first);
+            if (n_elem) (void) hipFree(n_elem);
+            return fail(SPANGPU_ERR_NO_MEMORY, "out of device memory for the cadence tables");
+        }
+        HIP_TRY(hipStreamSynchronize(b->stream));        // no launch still reads the old ones
+        if (c->d_first) (void) hipFree(c->d_first);
+        if (c->d_elem) (void) hipFree(c->d_elem);
+        c->d_first = n_first;
+        c->d_elem = n_elem;
+    }
     if (!fresh)
     {
         // the tone numbers of the old set mean nothing in the new one: nobody is following a tone (the run histories stay)
