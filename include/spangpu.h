@@ -368,6 +368,9 @@ SPANGPU_API int spangpu_modem_rx(spangpu_modem_t *modem, const int16_t *amp, int
 SPANGPU_API int spangpu_modem_rx_var(spangpu_modem_t *modem, const int16_t *amp, int mem, const int32_t *lens, int max_samples,
                                      long long stride);
 SPANGPU_API int spangpu_modem_events(spangpu_modem_t *modem, const int8_t **events, const int32_t **counts);
+/* The last call's events device to device (for a gather across GPUs): dst = int32 counts[n_ch], int8 events[n_ch][per_channel].
+   Asynchronous on the bank's stream. */
+SPANGPU_API int spangpu_modem_copy_events(spangpu_modem_t *modem, void *dev_dst, size_t dst_bytes, int per_channel);
 /* xxx_rx_set_qam_report_handler() (src/v29rx.c:1149, v27ter_rx.c:1204, v17rx.c:1535): with the tap on, every channel's
    qam_report(user, constel, target, symbol) calls (v29rx.c:769-783, v27ter_rx.c:517,765-777, v17rx.c:1117-1131) of an rx
    call are recorded: counts[c] records of seven words at records + c*cap*7 = {put_bit / status calls before it in

@@ -697,6 +697,27 @@ int spangpu_modem_events(spangpu_modem_t *m, const int8_t **events, const int32_
     return m->last_cap;
 }
 
+// The last call's events, device to device, for a gather across GPUs (the bit stream words of a frame):
+// dst = int32 counts[n_ch], then int8 events[n_ch][per_channel].  Asynchronous on the bank's stream; a channel that made
+// more than per_channel events shows it by its count (the caller sizes per_channel for its frame length: a V.29 9600
+// receiver makes at most 4 per baud, 192 + status reports per 160 samples).
+int spangpu_modem_copy_events(spangpu_modem_t *m, void *dev_dst, size_t dst_bytes, int per_channel)
+{
+    if (m == nullptr  ||  dev_dst == nullptr  ||  per_channel <= 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (m->last_cap <= 0)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "no spangpu_modem_rx() yet");
+    const size_t need = (size_t) m->n_ch*(sizeof(int32_t) + (size_t) per_channel);
+    if (dst_bytes < need)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "destination too small");
+    V29_TRY(hipSetDevice(m->device));
+    V29_TRY(hipMemcpyAsync(dev_dst, m->ev_count, (size_t) m->n_ch*sizeof(int32_t), hipMemcpyDeviceToDevice, m->stream));
+    const int w = (per_channel < m->last_cap)  ?  per_channel  :  m->last_cap;
+    V29_TRY(hipMemcpy2DAsync((char *) dev_dst + (size_t) m->n_ch*sizeof(int32_t), (size_t) per_channel, m->events, (size_t) m->last_cap,
+                             (size_t) w, (size_t) m->n_ch, hipMemcpyDeviceToDevice, m->stream));
+    return SPANGPU_OK;
+}
+
 }   // extern "C"
 
 // ---- host-side state edits: restart, fill-in, cutoff ---------------------------------------------

@@ -195,6 +195,7 @@ def lib():
             "spangpu_modem_rx": (ci, [vp, vp, ci, ci, ll]),
             "spangpu_modem_rx_var": (ci, [vp, vp, ci, vp, ci, ll]),
             "spangpu_modem_events": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_modem_copy_events": (ci, [vp, vp, C.c_size_t, ci]),
             "spangpu_modem_qam_tap": (ci, [vp, ci]),
             "spangpu_modem_qam_reports": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
             "spangpu_modem_state_words": (ci, [ci, C.POINTER(ci), C.POINTER(ci)]),
@@ -658,6 +659,10 @@ class ModemBank:
         raw = np.frombuffer((C.c_char*(cap*self.n)).from_address(ev.value), dtype=np.int8).reshape(self.n, cap)
         assert counts.max(initial=0) <= cap, "event buffer overflow"
         return [raw[c, :counts[c]].copy() for c in range(self.n)]
+
+    def copy_events(self, dst_ptr, nbytes, per_channel):
+        """The last call's events, device to device: int32 counts[n_ch] then int8 events[n_ch][per_channel]."""
+        _check(lib().spangpu_modem_copy_events(self.h, C.c_void_p(dst_ptr), nbytes, per_channel))
 
     def qam_tap(self, on=True):
         """Record the qam_report_handler_t calls of the following rx calls (xxx_rx_set_qam_report_handler)."""

@@ -154,3 +154,59 @@ class FloatGather:
         if self.rank != 0:
             return None
         return torch.stack(self.recv)
+
+
+class BitsGather:
+    """Gather of the modem receivers' event streams of a step (the put_bit bits and status reports of every channel:
+    SURVEY 8(e), 24 bytes per channel and 160-sample frame for V.29 9600) from every rank to rank 0.  What travels per
+    rank and step: int32 counts[n_ch] and int8 events[n_ch][per_channel], written device to device by
+    bank.copy_events() (spangpu_modem_copy_events) behind the receiver kernel, so the collective reads what the kernel
+    wrote without a host round trip.  Two buffers: submit(bank) after a step's launch starts that step's gather;
+    events() waits for the gather started last and, on rank 0, returns it as (counts [world, n_ch] int32,
+    events [world, n_ch, per_channel] int8) -- called after the NEXT step's launch it overlaps the transfer with that
+    kernel.  (The views are good until the submit after next.)"""
+
+    def __init__(self, world, rank, n_ch, per_channel, device):
+        self.world = world
+        self.rank = rank
+        self.n_ch = n_ch
+        self.per = per_channel
+        self.nbytes = n_ch*(4 + per_channel)
+        words = (self.nbytes + 3)//4
+        self.send = [torch.zeros(words, dtype=torch.int32, device=device) for _ in range(2)]
+        self.recv = None
+        if rank == 0:
+            self.recv = [[torch.zeros(words, dtype=torch.int32, device=device) for _ in range(world)] for _ in range(2)]
+        self.handles = [None, None]
+        self.count = 0
+
+    def _wait(self, slot):
+        if self.handles[slot] is not None:
+            self.handles[slot].wait()
+            self.handles[slot] = None
+
+    def submit(self, bank):
+        slot = self.count & 1
+        self._wait(slot)
+        bank.copy_events(self.send[slot].data_ptr(), self.nbytes, self.per)
+        if self.send[slot].is_cuda:
+            bank.sync()                 # the copy runs on the bank's stream, the collective on the process group's
+        self.handles[slot] = dist.gather(self.send[slot], gather_list=self.recv[slot] if self.rank == 0 else None, dst=0,
+                                         async_op=True)
+        self.count += 1
+
+    def drain(self):
+        self._wait(0)
+        self._wait(1)
+
+    def events(self):
+        if self.count == 0:
+            return None
+        slot = (self.count - 1) & 1
+        self._wait(slot)
+        if self.rank != 0:
+            return None
+        raw = torch.stack(self.recv[slot]).contiguous().view(torch.uint8).view(self.world, -1)[:, :self.nbytes]
+        counts = raw[:, :4*self.n_ch].contiguous().view(torch.int32).view(self.world, self.n_ch)
+        ev = raw[:, 4*self.n_ch:].contiguous().view(torch.int8).view(self.world, self.n_ch, self.per)
+        return counts, ev

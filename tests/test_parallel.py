@@ -276,3 +276,70 @@ def test_digit_gather_gloo_world2(every, steps):
         p.join(120)
         assert p.exitcode == 0
     assert out.get(timeout=10) is True
+
+
+class FakeModemBank:
+    """Stands in for engine.ModemBank: copy_events() lays a step's counts and event bytes where it is told."""
+
+    def __init__(self, rank, n_ch):
+        self.rank = rank
+        self.n_ch = n_ch
+        self.step = 0
+
+    @staticmethod
+    def expected(rank, step, n_ch, per):
+        rng = np.random.default_rng(7000*rank + step)
+        counts = rng.integers(0, per + 1, n_ch).astype(np.int32)
+        ev = rng.integers(-5, 2, (n_ch, per)).astype(np.int8)
+        return counts, ev
+
+    def copy_events(self, dst_ptr, nbytes, per):
+        counts, ev = self.expected(self.rank, self.step, self.n_ch, per)
+        assert nbytes == self.n_ch*(4 + per)
+        ctypes.memmove(dst_ptr, counts.ctypes.data, counts.nbytes)
+        ctypes.memmove(dst_ptr + counts.nbytes, ev.ctypes.data, ev.nbytes)
+        self.step += 1
+
+    def sync(self):
+        pass
+
+
+def _bits_worker(rank, world, port, steps, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from spandsp_amd.parallel import BitsGather
+    n_ch, per = 1031, 25                        # 1031 x 29 bytes: not a whole number of words
+    g = BitsGather(world, rank, n_ch, per, torch.device("cpu"))
+    bank = FakeModemBank(rank, n_ch)
+    fine = True
+    for step in range(steps):
+        g.submit(bank)
+        got = g.events()                        # this step's, on rank 0
+        if rank == 0:
+            counts, ev = got
+            for r in range(world):
+                wc, we = FakeModemBank.expected(r, step, n_ch, per)
+                fine = fine and np.array_equal(counts[r].numpy(), wc) and np.array_equal(ev[r].numpy(), we)
+    g.drain()
+    if rank == 0:
+        out.put(bool(fine))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bits_gather_gloo_world2():
+    """the modem banks' bit stream words of every step, gathered to rank 0."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_bits_worker, args=(r, 2, port, 7, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=10) is True
