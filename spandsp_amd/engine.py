@@ -55,6 +55,7 @@ def lib():
         vp, ci, cf, ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
         sigs = {
             "spangpu_device_count": (ci, []),
+            "spangpu_probe_stream_read": (ci, [ci, C.c_size_t, ci, C.POINTER(C.c_double)]),
             "spangpu_last_error": (C.c_char_p, []),
             "spangpu_version": (C.c_char_p, []),
             "spangpu_goertzel_fac": (cf, [cf]),
@@ -231,6 +232,13 @@ def _check(rc):
 
 def device_count():
     return lib().spangpu_device_count()
+
+
+def probe_stream_read(device=0, nbytes=1 << 30, reps=10):
+    """The streaming read rate (GB/s) a plain kernel reaches on this device: the practical ceiling beside the 8 TB/s peak."""
+    v = C.c_double(0.0)
+    _check(lib().spangpu_probe_stream_read(device, nbytes, reps, C.byref(v)))
+    return v.value
 
 
 def tune_lanes_per_channel(lpc):

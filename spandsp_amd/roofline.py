@@ -1,0 +1,60 @@
+"""Bounds quoted beside the HBM roofline in the benchmark lines (bench.py, tools/bench_paths.py):
+
+* `measured_stream_peak()` -- what a plain streaming read kernel reaches on THIS device in THIS run (the practical ceiling
+  under the 8 TB/s datasheet peak);
+* `valu_roof()` -- the VALU issue floor of a workload's dominant kernel: its VALU instruction count per launch (rocprofv3
+  SQ_INSTS_VALU, committed in profiles/valu_counters.json by tools/gpu_valu.sh) spread over the chip's 1 024 SIMDs at
+  one instruction per four cycles (what one wavefront per SIMD can issue; packed fp32 and 64-lane integer operations
+  also occupy the SIMD-32 pipe for four), at the 2.4 GHz peak clock.  frac = floor / measured launch time: how much of
+  the launch is explained by instruction issue alone -- the bound that matters for the state machine kernels (modem
+  receivers, echo canceller), whose HBM fraction is by construction a few per cent."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIMDS = 1024
+CLOCK_MHZ = 2400.0
+CYCLES_PER_VALU = 4.0
+_stream = {}
+
+
+def measured_stream_peak(device=0):
+    """GB/s of a 1 GiB streaming read with 16-byte loads (cached per process); None if it cannot be measured."""
+    if device not in _stream:
+        try:
+            from . import engine
+            _stream[device] = engine.probe_stream_read(device, 1 << 30, 8)
+        except Exception:
+            _stream[device] = None
+    return _stream[device]
+
+
+def valu_roof(key, avg_launch_us, channels=None, samples=160):
+    """The VALU issue floor of workload `key` from profiles/valu_counters.json, scaled to `channels` if the counters were
+    taken at another bank size (instruction counts are per channel-sample)."""
+    path = os.path.join(ROOT, "profiles", "valu_counters.json")
+    try:
+        rec = json.load(open(path))["workloads"].get(key)
+    except Exception:
+        rec = None
+    if not rec or not avg_launch_us:
+        return None
+    valu = float(rec["valu_insts_per_launch"])
+    if channels and rec.get("channels") and channels != rec["channels"]:
+        valu *= float(channels)/float(rec["channels"])
+    floor_us = valu/SIMDS*CYCLES_PER_VALU/CLOCK_MHZ
+    out = {"bound": "valu_issue", "kernel": rec.get("kernel"), "valu_insts_per_launch": valu,
+           "valu_insts_per_wave_sample": rec.get("valu_insts_per_wave_sample"), "issue_floor_us": floor_us,
+           "frac": floor_us/avg_launch_us, "cycles_per_valu": CYCLES_PER_VALU, "simds": SIMDS, "clock_mhz": CLOCK_MHZ,
+           "source": rec.get("source")}
+    return out
+
+
+def add_measured(roof, device=0):
+    """roofline object + the measured stream ceiling and the fraction of it."""
+    if roof is None:
+        return None
+    peak = measured_stream_peak(device)
+    roof["measured_stream_peak"] = peak
+    roof["frac_of_measured_stream"] = (roof["achieved"]/peak) if peak else None
+    return roof

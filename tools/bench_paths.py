@@ -862,6 +862,17 @@ def bench_dtmf_tx(args, dev, stream):
         "cpu_baseline": cpu}
 
 
+def emit(line, key, channels=None):
+    """Print a bench line with the bounds beside the HBM roofline: the measured stream ceiling of this device in this run, and
+    the VALU issue floor of the workload's kernel (spandsp_amd/roofline.py)."""
+    from spandsp_amd import roofline as rl
+    roof = line.get("roofline")
+    if roof:
+        rl.add_measured(roof, 0)
+        line["roofline_valu"] = rl.valu_roof(key, roof.get("avg_launch_us") or roof.get("avg_tick_us"), channels=channels)
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=["v29", "v17", "v27ter", "echo", "mixed", "dtmf_tx", "fsk", "mct", "sigtone", "supertone", "fax_rx", "v29_tx", "awgn"], default="v29")
@@ -886,38 +897,38 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     if args.workload == "echo":
-        print(json.dumps(bench_echo(args, dev, stream)))
+        emit(bench_echo(args, dev, stream), "echo", args.channels or None)
         return
     if args.workload == "mixed":
-        print(json.dumps(bench_mixed(args, dev, stream)))
+        emit(bench_mixed(args, dev, stream), "mixed", args.channels or None)
         return
     if args.workload == "v29_tx":
-        print(json.dumps(bench_v29_tx(args, dev, stream)))
+        emit(bench_v29_tx(args, dev, stream), "v29_tx", args.channels or None)
         return
     if args.workload == "awgn":
-        print(json.dumps(bench_awgn(args, dev, stream)))
+        emit(bench_awgn(args, dev, stream), "awgn", args.channels or None)
         return
     if args.workload == "mct":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        print(json.dumps(bench_mct(args, dev, stream)))
+        emit(bench_mct(args, dev, stream), "mct", args.channels or None)
         return
     if args.workload == "fax_rx":
-        print(json.dumps(bench_fax_rx(args, dev, stream)))
+        emit(bench_fax_rx(args, dev, stream), "fax_rx", args.channels or None)
         return
     if args.workload == "supertone":
-        print(json.dumps(bench_supertone(args, dev, stream)))
+        emit(bench_supertone(args, dev, stream), "supertone", args.channels or None)
         return
     if args.workload == "sigtone":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        print(json.dumps(bench_sigtone(args, dev, stream)))
+        emit(bench_sigtone(args, dev, stream), "sigtone", args.channels or None)
         return
     if args.workload == "fsk":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        print(json.dumps(bench_fsk(args, dev, stream)))
+        emit(bench_fsk(args, dev, stream), "fsk", args.channels or None)
         return
     if args.workload == "dtmf_tx":
         sys.path.insert(0, os.path.join(ROOT, "tests"))
-        print(json.dumps(bench_dtmf_tx(args, dev, stream)))
+        emit(bench_dtmf_tx(args, dev, stream), "dtmf_tx", args.channels or None)
         return
     fixture, bit_rate, n_words = MODEMS[args.workload]
     kind = {"v29": engine.V29, "v17": engine.V17, "v27ter": engine.V27TER}[args.workload]
@@ -957,7 +968,7 @@ def main():
     if not args.no_cpu_baseline:
         cpu = cpu_modem(args.workload, bit_rate, frames[:, :min(args.cpu_channels, n_ch)].contiguous().cpu().numpy())
     value = args.steps*n_ch*FRAME/dt/1e6
-    print(json.dumps({
+    emit({
         "metric": "Msamples/s of batched %s %d bps receive (8 kHz channels at real-time = value*1e6/8000)" % (args.workload, bit_rate),
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
@@ -967,12 +978,12 @@ def main():
                    "channels_per_gpu": n_ch, "modem_mapping": args.modem_mapping,
                    "sampled_channels_in_data_mode_at_end": "%d of %d" % (trained, len(range(0, n_ch, max(1, n_ch//256)))),
                    "events_in_last_frame": bits_last},
-        "roofline": {"bound": "hbm", "kernel": "%s_bank_kernel" % args.workload, "achieved": alg_read/(avg_ms*1e-3)/1e9,
+        "roofline": {"bound": "hbm", "kernel": ("%s_quad_kernel<16, 4>" if (n_ch < 32768 and args.modem_mapping in (0, 4, 8) and args.workload in ("v29", "v17")) else "%s_bank_kernel") % args.workload, "achieved": alg_read/(avg_ms*1e-3)/1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS,
                      "traffic": None, "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
                      "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3, "max_launch_us": max(per)*1e3,
                      "note": "VALU/LDS-issue bound state machine (SURVEY 8(d)); the HBM figure is reported, not targeted"},
-        "cpu_baseline": cpu}))
+        "cpu_baseline": cpu}, args.workload, n_ch)
 
 
 if __name__ == "__main__":
