@@ -150,30 +150,55 @@ def cpu_baseline(frames_host, target_s):
     }
 
 
-def end_to_end(engine, n_ch, frames_dev, device_index, steps):
-    """SURVEY 8(d)'s second number: a tick as a caller with HOST buffers sees it -- H2D of the PCM frame (pinned host
-    memory), the kernel, D2H of the block records and their decode into per-channel block structs on the host."""
+def end_to_end(engine, n_ch, frames_dev, device_index, steps, law=0):
+    """SURVEY 8(d)'s second number: a tick as a caller with HOST buffers sees it, through the pipelined feed
+    (spangpu_feed_*, csrc/feed_api.hip): the frame sits in one of the feed's pinned slots (where the caller's receive
+    path wrote it), commit() queues H2D -> kernel -> digit list -> D2H, collect() hands out the digits of the tick before:
+    tick t + 1's copy down overlaps tick t's kernel and the way back of its digits.  law = 0: int16 PCM; 1 / 2: G.711
+    bytes decoded on the device (half the PCIe volume).  `with_fill` adds one host thread's copy of the frame from
+    ordinary memory into the slot (a caller that cannot receive into the slot directly)."""
+    import numpy as np
     bank = engine.ToneBank(engine.DTMF, n_ch, device=device_index)
+    feed = engine.Feed(bank, FRAME, law=law, depth=3, device=device_index)
     nf = min(frames_dev.shape[0], 8)
-    host = frames_dev[:nf].cpu().pin_memory()
-    views = [host[f].numpy() for f in range(nf)]
-    for f in range(2):
-        bank.rx_host(views[f % nf])
-        bank.blocks()
+    host = frames_dev[:nf].cpu().numpy()
+    if law:
+        host = host.astype(np.uint8) if host.dtype != np.uint8 else host
+
+    def run(n, fill):
+        digits = 0
+        for i in range(n):
+            buf = feed.slot()
+            if fill or i < feed.depth:
+                buf[:, :FRAME] = host[i % nf]
+            feed.commit(FRAME)
+            if i >= 1:
+                digits += len(feed.collect()[0])
+        while True:
+            got = feed.collect()
+            if got is None:
+                break
+            digits += len(got[0])
+        return digits
+    run(6, True)
     t0 = time.perf_counter()
-    n_blocks = 0
-    for i in range(steps):
-        bank.rx_host(views[i % nf])
-        n_blocks += len(bank.blocks())
+    n_digits = run(steps, False)
     dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    run(max(4, steps//4), True)
+    dt_fill = (time.perf_counter() - t0)/max(4, steps//4)
+    feed.close()
+    bank.close()
+    bps = 1 if law else 2
     return {
         "ms_per_step": dt*1e3/steps,
         "value": float(steps)*n_ch*FRAME/dt/1e6,
         "unit": "Msamples/s",
         "steps": steps,
-        "includes": "per step: H2D copy of the %d x %d int16 frame from pinned host memory (%.1f MB), the kernel, D2H of the "
-                    "block records, their decode into spangpu_block_t on the host (%d blocks in all)"
-                    % (n_ch, FRAME, n_ch*FRAME*2/1e6, n_blocks),
+        "ms_per_step_with_fill": dt_fill*1e3,
+        "includes": "per step, pipelined over three pinned slots: H2D copy of the %d x %d %s frame (%.1f MB), the kernel, the digit "
+                    "list made on the device, D2H of the list (4 bytes per digit; %d digits in all), one tick of latency"
+                    % (n_ch, FRAME, "G.711" if law else "int16", n_ch*FRAME*bps/1e6, n_digits),
     }
 
 
@@ -505,8 +530,18 @@ def main():
         host = frames[:min(args.cpu_frames, nf), :nc].contiguous().cpu().numpy()
         cpu = cpu_baseline(host, args.cpu_seconds)
     e2e = None
+    e2e_g711 = None
     if rank == 0 and world == 1 and not args.no_e2e and not law:
-        e2e = end_to_end(engine, n_ch, frames, local_rank, 30)
+        e2e = end_to_end(engine, n_ch, frames, local_rank, 60)
+        # the same frames as u-law bytes (nearest code of the reference's decode table)
+        tab = np.load(os.path.join(ROOT, "tests", "golden", "g711_decode.npz"))["ulaw"].astype(np.int32)
+        order = np.argsort(tab, kind="stable")
+        vals = torch.tensor(tab[order], device=dev, dtype=torch.int32)
+        codes_of = torch.tensor(order.astype(np.uint8), device=dev)
+        x = frames[:8].to(torch.int32)
+        posn = torch.clamp(torch.searchsorted(vals, x.contiguous()), 1, 255)
+        lower = (x - vals[posn - 1]) <= (vals[posn] - x)
+        e2e_g711 = end_to_end(engine, n_ch, codes_of[torch.where(lower, posn - 1, posn)].contiguous(), local_rank, 60, law=2)
 
     if rank == 0:
         total_samples = float(timed_steps)*n_ch*world*FRAME
@@ -542,6 +577,7 @@ def main():
             "roofline_valu": roof_valu,
             "cpu_baseline": cpu,
             "e2e": e2e,
+            "e2e_g711": e2e_g711,
         }
         print(json.dumps(line))
     if world > 1 or force_gather:

@@ -208,6 +208,25 @@ SPANGPU_API long long spangpu_bank_copy_records(spangpu_bank_t *bank, void *dst_
    for the first cap_entries of them, in no particular order (dst holds 1 + cap_entries words; a count above cap_entries
    says the list was cut).  A separate small kernel over the records of the last launch (two stream operations). */
 SPANGPU_API int spangpu_bank_digit_events(spangpu_bank_t *bank, uint32_t *dst_device, int cap_entries);
+
+/* ---- The pipelined host-buffer path (csrc/feed_api.hip) -----------------------------------------------------------------
+   For a caller whose frames live in host memory (what N spandsp callers hold between dtmf_rx() calls): a ring of `depth`
+   slots, each a pinned host buffer the caller's receive path writes a frame into, so that tick t + 1's copy to the device
+   overlaps tick t's kernel and the way back of its digits.  Per tick:
+       buf = spangpu_feed_acquire(feed);   write the frame: channel c at buf + c*spangpu_feed_stride(feed) samples
+       spangpu_feed_commit(feed, samples); returns at once
+       n = spangpu_feed_collect(feed, &entries);   (as late as `depth` - 1 ticks later) the digits of the oldest tick:
+                                                   channel | digit << 20 | block << 28, as spangpu_bank_digit_events()
+   law = 0: 16 bit linear PCM; SPANGPU_G711_ALAW / _ULAW: one byte per sample, decoded on the device (half the PCIe volume).
+   Replaces the per-call sequence of dtmf_rx() + dtmf_rx_get() (src/dtmf.c:164-347, 481-519) for a whole bank. */
+typedef struct spangpu_feed_s spangpu_feed_t;
+SPANGPU_API int spangpu_feed_create(spangpu_feed_t **feed, spangpu_bank_t *bank, int device, int max_samples, int law, int depth);
+SPANGPU_API int spangpu_feed_destroy(spangpu_feed_t *feed);
+SPANGPU_API long long spangpu_feed_stride(const spangpu_feed_t *feed);
+SPANGPU_API void *spangpu_feed_acquire(spangpu_feed_t *feed);
+SPANGPU_API int spangpu_feed_commit(spangpu_feed_t *feed, int samples);
+SPANGPU_API int spangpu_feed_collect(spangpu_feed_t *feed, const uint32_t **entries);
+SPANGPU_API int spangpu_feed_outstanding(const spangpu_feed_t *feed);
 /* One byte per block and channel, written by the detector kernel itself beside its records (no extra launch): launches
    from now on fill dev_ptr as digits[block][channel] = the digit the block delivered, 0 = none (DTMF: digit accepted; Bell
    MF / R2 MF: the digit of a report).  What a multi-GPU run gathers: a quarter of the record words.  NULL turns it off. */

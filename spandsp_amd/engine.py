@@ -169,6 +169,13 @@ def lib():
             "spangpu_fsk_set_frame_parameters": (ci, [vp, ci, ci, ci, ci]),
             "spangpu_fsk_fillin": (ci, [vp, ci, ci]),
             "spangpu_tune_echo_lanes_per_channel": (ci, [ci]),
+            "spangpu_feed_create": (ci, [C.POINTER(vp), vp, ci, ci, ci, ci]),
+            "spangpu_feed_destroy": (ci, [vp]),
+            "spangpu_feed_stride": (ll, [vp]),
+            "spangpu_feed_acquire": (vp, [vp]),
+            "spangpu_feed_commit": (ci, [vp, ci]),
+            "spangpu_feed_collect": (ci, [vp, C.POINTER(vp)]),
+            "spangpu_feed_outstanding": (ci, [vp]),
             "spangpu_tune_modem_mapping": (ci, [ci]),
             "spangpu_echo_lanes_per_channel": (ci, [vp]),
             "spangpu_echo_stats": (ci, [vp, ci]),
@@ -502,6 +509,57 @@ class BanksPlan:
 
 
 ECHO_STATS_DTYPE = np.dtype([("sum_rx2", "<u8"), ("sum_clean2", "<u8"), ("crc", "<u4"), ("samples", "<u4")])
+
+
+class Feed:
+    """The pipelined host-buffer path of a tone bank (spangpu_feed_*): `depth` pinned slots; slot() hands out the numpy view
+    of the next tick's staging buffer ([n_ch, stride] int16, or uint8 for G.711) for the caller to fill, commit() queues the
+    tick, collect() returns the digits of the oldest tick as (channel, digit, block) arrays."""
+
+    def __init__(self, bank, max_samples, law=0, depth=2, device=0):
+        self.bank = bank
+        self.law = law
+        self.h = C.c_void_p()
+        _check(lib().spangpu_feed_create(C.byref(self.h), bank.h, device, max_samples, law, depth))
+        self.stride = int(lib().spangpu_feed_stride(self.h))
+        self.n_ch = bank.n
+        self.depth = depth
+
+    def close(self):
+        if self.h:
+            lib().spangpu_feed_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def slot(self):
+        p = lib().spangpu_feed_acquire(self.h)
+        if not p:
+            raise SpanGpuError(-6, lib().spangpu_last_error().decode())
+        if self.law:
+            buf = (C.c_uint8*(self.n_ch*self.stride)).from_address(p)
+            return np.frombuffer(buf, np.uint8).reshape(self.n_ch, self.stride)
+        buf = (C.c_int16*(self.n_ch*self.stride)).from_address(p)
+        return np.frombuffer(buf, np.int16).reshape(self.n_ch, self.stride)
+
+    def commit(self, samples):
+        _check(lib().spangpu_feed_commit(self.h, samples))
+
+    def collect(self):
+        """-> (channel, digit, block) uint32 arrays of the oldest outstanding tick, or None if there is none."""
+        if lib().spangpu_feed_outstanding(self.h) <= 0:
+            return None
+        ent = C.c_void_p()
+        n = _check(lib().spangpu_feed_collect(self.h, C.byref(ent)))
+        if n == 0:
+            z = np.zeros(0, np.uint32)
+            return z, z, z
+        w = np.frombuffer((C.c_uint32*n).from_address(ent.value), np.uint32).copy()
+        return w & 0xFFFFF, (w >> 20) & 0xFF, (w >> 28) & 0xF
 
 
 class EchoBank:

@@ -1,0 +1,79 @@
+"""The pipelined host-buffer path (spangpu_feed_*, csrc/feed_api.hip): ticks queued three deep deliver exactly the digits
+the serial path (rx_host + blocks, itself held to the oracle elsewhere) delivers, tick for tick, for 16 bit PCM and for
+G.711 bytes; a slot cannot be committed twice, and an empty feed says so."""
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from test_oracle_pin import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def serial_digits(engine, sig, n_ch, frame, law=0, codes=None):
+    bank = engine.ToneBank(engine.DTMF, n_ch)
+    out = []
+    for pos in range(0, sig.shape[1], frame):
+        if law:
+            bank.rx_host_g711(codes[:, pos:pos + frame], law)
+        else:
+            bank.rx_host(sig[:, pos:pos + frame])
+        blk = bank.blocks()
+        out.append(sorted((int(r["channel"]), int(r["code"]), int(r["block"])) for r in blk
+                          if (r["flags"] & engine.BLK_CHANGE) and r["code"]))
+    bank.close()
+    return out
+
+
+@pytest.mark.parametrize("law", [0, 2])
+def test_pipelined_feed_delivers_the_serial_path_digits(built, law):
+    from spandsp_amd import engine
+    n_ch, frame, ticks = 3000, 160, 50
+    sig, _ = synth.dtmf_channels(n_ch, frame*ticks, seed=91)
+    codes = None
+    if law:
+        tab = np.load(os.path.join(GOLDEN, "g711_decode.npz"))["ulaw"].astype(np.int32)
+        order = np.argsort(tab, kind="stable")
+        vals = tab[order]
+        pos = np.clip(np.searchsorted(vals, sig.astype(np.int32)), 1, 255)
+        lower = (sig - vals[pos - 1]) <= (vals[pos] - sig)
+        codes = order[np.where(lower, pos - 1, pos)].astype(np.uint8)
+    want = serial_digits(engine, sig, n_ch, frame, law, codes)
+    bank = engine.ToneBank(engine.DTMF, n_ch)
+    feed = engine.Feed(bank, frame, law=law, depth=3)
+    got = []
+    for t in range(ticks):
+        buf = feed.slot()
+        buf[:, :frame] = (codes if law else sig)[:, t*frame:(t + 1)*frame]
+        feed.commit(frame)
+        if t >= 2:                              # three ticks in flight
+            c, d, b = feed.collect()
+            got.append(sorted(zip(c.tolist(), d.tolist(), b.tolist())))
+    while True:
+        r = feed.collect()
+        if r is None:
+            break
+        got.append(sorted(zip(r[0].tolist(), r[1].tolist(), r[2].tolist())))
+    assert len(got) == ticks
+    assert got == want
+    assert sum(len(g) for g in got) > n_ch//2
+    assert feed.collect() is None
+    feed.close()
+    bank.close()
+
+
+def test_feed_slots_are_bounded(built):
+    from spandsp_amd import engine
+    bank = engine.ToneBank(engine.DTMF, 100)
+    feed = engine.Feed(bank, 160, depth=2)
+    for _ in range(2):
+        feed.slot()[:] = 0
+        feed.commit(160)
+    with pytest.raises(engine.SpanGpuError):
+        feed.slot()                             # both slots hold a tick nobody has collected
+    assert len(feed.collect()[0]) == 0
+    feed.slot()
+    feed.close()
+    bank.close()
