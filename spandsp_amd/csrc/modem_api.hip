@@ -15,6 +15,7 @@
 #include "v27ter_dev.hpp"
 #include "v17_dev.hpp"
 #include "v17_quad.hpp"
+#include "v27ter_quad.hpp"
 
 using namespace spg;
 
@@ -595,6 +596,8 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
             const int waves = (m->n_ch + 63)/64;
             hipLaunchKernelGGL((v27ter_bank_kernel<64, false, 4, 16, true>), dim3((waves + 3)/4), dim3(256), 0, m->stream, L);
         }
+        else if (quad == 4  ||  quad == 8)
+            hipLaunchKernelGGL((v27ter_quad_kernel<16, 4>), dim3((m->n_ch + 63)/64), dim3(256), 0, m->stream, L);
         else if (cpw == 32)
             hipLaunchKernelGGL(v27ter_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
         else

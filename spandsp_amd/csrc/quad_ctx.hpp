@@ -80,6 +80,7 @@ struct QuadHost
     float swap2(float v, int site = 0) { return __uint_as_float(exchange(__float_as_uint(v), lane ^ 2, 3000 + site)); }
     int prev1(int v, int site = 0) { return (int) exchange((uint32_t) v, (lane > 0)  ?  (lane - 1)  :  0, 6000 + site); }
     uint32_t swap1(uint32_t v, int site = 0) { return exchange(v, lane ^ 1, 7000 + site); }
+    float swap1f(float v, int site = 0) { return __uint_as_float(exchange(__float_as_uint(v), lane ^ 1, 7500 + site)); }
     uint32_t swap2(uint32_t v, int site = 0) { return exchange(v, lane ^ 2, 8000 + site); }
     bool any(bool b, int site = 0)
     {
@@ -134,6 +135,10 @@ struct QuadDev
     __device__ __forceinline__ uint32_t swap1(uint32_t v, int = 0)
     {
         return (uint32_t) __builtin_amdgcn_mov_dpp((int) v, 0xB1, 0xF, 0xF, true);                     // quad_perm:[1,0,3,2]
+    }
+    __device__ __forceinline__ float swap1f(float v, int = 0)
+    {
+        return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
     }
     __device__ __forceinline__ uint32_t swap2(uint32_t v, int = 0)
     {

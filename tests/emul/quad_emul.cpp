@@ -8,6 +8,7 @@
 
 #include "../../spandsp_amd/csrc/v29_quad.hpp"
 #include "../../spandsp_amd/csrc/v17_quad.hpp"
+#include "../../spandsp_amd/csrc/v27ter_quad.hpp"
 #include "../../spandsp_amd/csrc/modem_tables.h"
 
 namespace spg {
@@ -163,6 +164,27 @@ static void v17_body(int lane, void *arg)
     v17_quad_run(q, j->L, 0, j->T, j->C);
 }
 
+struct V27Job
+{
+    V27Launch L;
+    V27QuadTables T;
+    V29QuadChan C;
+    uint32_t pcm[kQuadPcmStride];
+    float2 rrc[kQuadRrcStride];
+    float2 u[kQuad27EqStride];
+    float taps[kQuadTapStride];
+    QuadHostState st;
+};
+
+static void v27_body(int lane, void *arg)
+{
+    V27Job *j = (V27Job *) arg;
+    QuadHost q;
+    q.st = &j->st;
+    q.lane = lane;
+    v27_quad_run(q, j->L, 0, j->T, j->C);
+}
+
 }   // namespace spg
 
 using namespace spg;
@@ -291,6 +313,51 @@ extern "C" int emul_v17_rx(int bit_rate, uint32_t *state, const int16_t *amp, in
     job.C.taps = job.taps;
     job.C.trellis = job.trellis;
     const int errs = run_quad(v17_body, &job, &job.st, order);
+    if (errs)
+        return -errs;
+    return count;
+}
+
+static V27Tables g_v27_tab;
+static bool g_v27_ready;
+
+// One channel's v27ter_rx() call: state = the 270 state words (in and out), returns the number of events or < 0.
+extern "C" int emul_v27ter_rx(int bit_rate, uint32_t *state, const int16_t *amp, int n, int8_t *events, int ev_cap, const int *order)
+{
+    if (!g_v27_ready)
+    {
+        V27Tables *t = &g_v27_tab;
+        memset(t, 0, sizeof(*t));
+        spg_make_rx_pulseshaper(8, kRrcLen, 1800.0, 1600.0, 0.5, t->re4800, t->im4800);
+        spg_make_rx_pulseshaper(12, kRrcLen, 1800.0, 1200.0, 0.5, t->re2400, t->im2400);
+        spg_make_sine_table(t->sine);
+        spg_make_sqrt_table(t->sqrt_tab);
+        g_v27_ready = true;
+    }
+    static V27Job job;
+    memset(&job, 0, sizeof(job));
+    int32_t count = 0;
+    job.L.amp = amp;
+    job.L.stride = n;
+    job.L.samples = n;
+    job.L.lens = nullptr;
+    job.L.n_ch = 1;
+    job.L.bit_rate = bit_rate;
+    job.L.state = state;
+    job.L.events = events;
+    job.L.ev_count = &count;
+    job.L.ev_cap = ev_cap;
+    job.L.tab = &g_v27_tab;
+    v27_quad_tables(job.T, g_v27_tab, bit_rate == 4800, 0, 1);
+    memset(job.pcm, 0xA5, sizeof(job.pcm));
+    memset(job.rrc, 0xA5, sizeof(job.rrc));
+    memset(job.u, 0xA5, sizeof(job.u));
+    memset(job.taps, 0xA5, sizeof(job.taps));
+    job.C.pcm = job.pcm;
+    job.C.rrc = job.rrc;
+    job.C.u = job.u;
+    job.C.taps = job.taps;
+    const int errs = run_quad(v27_body, &job, &job.st, order);
     if (errs)
         return -errs;
     return count;

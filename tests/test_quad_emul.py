@@ -24,6 +24,8 @@ def emul():
     lib = ctypes.CDLL(so)
     lib.emul_v29_rx.restype = ctypes.c_int
     lib.emul_v29_rx.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.emul_v27ter_rx.restype = ctypes.c_int
+    lib.emul_v27ter_rx.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.emul_v17_rx.restype = ctypes.c_int
     lib.emul_v17_rx.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     return lib
@@ -137,3 +139,17 @@ def test_v17_quad_on_the_host_matches_oracle(built, emul, bit_rate, chunks):
         return emul.emul_v17_rx(bit_rate, *a)
     total, seen = against_oracle(lambda: orc.V17(bit_rate), call, sig, chunks, ("v17", bit_rate))
     assert total > 1200*n_ch//3 and {-1, -2, -3, -4} <= seen
+
+
+@pytest.mark.parametrize("bit_rate", [4800, 2400])
+@pytest.mark.parametrize("chunks", [(160,), (400, 3, 1, 97)])
+def test_v27ter_quad_on_the_host_matches_oracle(built, emul, bit_rate, chunks):
+    from oracle import restated as orc
+    use_golden_modem_tables()
+    n_ch = 6
+    sig = channel_signals(bit_rate, n_ch, seed=bit_rate + len(chunks), fixture="v27ter_%d.npz")
+
+    def call(*a):
+        return emul.emul_v27ter_rx(bit_rate, *a)
+    total, seen = against_oracle(lambda: orc.V27ter(bit_rate), call, sig, chunks, ("v27ter", bit_rate))
+    assert total > 800*n_ch//3 and {-1, -2, -3, -4} <= seen

@@ -978,7 +978,7 @@ def main():
                    "channels_per_gpu": n_ch, "modem_mapping": args.modem_mapping,
                    "sampled_channels_in_data_mode_at_end": "%d of %d" % (trained, len(range(0, n_ch, max(1, n_ch//256)))),
                    "events_in_last_frame": bits_last},
-        "roofline": {"bound": "hbm", "kernel": ("%s_quad_kernel<16, 4>" if (n_ch < 32768 and args.modem_mapping in (0, 4, 8) and args.workload in ("v29", "v17")) else "%s_bank_kernel") % args.workload, "achieved": alg_read/(avg_ms*1e-3)/1e9,
+        "roofline": {"bound": "hbm", "kernel": ("%s_quad_kernel<16, 4>" if (n_ch < 32768 and args.modem_mapping in (0, 4, 8) and args.workload in ("v29", "v17", "v27ter")) else "%s_bank_kernel") % args.workload, "achieved": alg_read/(avg_ms*1e-3)/1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS,
                      "traffic": None, "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
                      "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3, "max_launch_us": max(per)*1e3,
