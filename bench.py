@@ -220,7 +220,7 @@ def run_echo(args, engine, dev, local_rank, rank, world):
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
-    bank.stats(True)
+    bank.stats(2)                       # energy sums by the update kernel itself (ERLE needs no CRC)
     gather = FloatGather(world, rank, n_ch, dev) if world > 1 else None
     erle_dev = gather.send if gather is not None else torch.zeros(n_ch, dtype=torch.float32, device=dev)
     fb = n_ch*FRAME*2

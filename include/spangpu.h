@@ -348,6 +348,8 @@ typedef struct
 } spangpu_echo_stats_t;
 #define SPANGPU_ECHO_STATS_SUMS     1
 #define SPANGPU_ECHO_STATS_CRC      2
+/* enable: 0 off; 1 energy sums and the CRC of the clean stream, by a pass of their own behind every update; 2 the energy sums
+   only (what ERLE needs), added up by the update kernel itself from the samples it already holds -- no second pass. */
 SPANGPU_API int spangpu_echo_stats(spangpu_echo_t *ec, int enable);
 SPANGPU_API int spangpu_echo_stats_reset(spangpu_echo_t *ec, int what);    /* SPANGPU_ECHO_STATS_SUMS | _CRC */
 SPANGPU_API int spangpu_echo_stats_get(spangpu_echo_t *ec, int first_channel, int n, spangpu_echo_stats_t *out);

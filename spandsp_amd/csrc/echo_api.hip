@@ -45,7 +45,7 @@ struct spangpu_echo_s
     int16_t *d_io;          // staging for host-resident tx / rx / clean: [3][n_ch][cap]
     size_t io_cap;          // samples per channel
     EchoStats *stats;       // per-channel line statistics, allocated by spangpu_echo_stats(ec, 1)
-    bool stats_on;
+    int stats_on;           // 0 off, 1 energy sums and CRC by a pass of their own after the update, 2 energy sums only, by the update kernel itself
     float *d_erle;          // scratch for spangpu_echo_erle() with a host destination
 };
 
@@ -274,6 +274,7 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
     L.taps32 = e->taps32;
     L.taps16 = e->taps16;
     L.hist = e->hist;
+    L.stats = (e->stats_on == 2)  ?  e->stats  :  nullptr;
     const int per_wave = 64/e->group;
     const int waves = (e->n_ch + per_wave - 1)/per_wave;
     const int blocks = (waves + 3)/4;
@@ -315,7 +316,7 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
         }
     }
     ECHO_TRY(hipGetLastError());
-    if (e->stats_on)
+    if (e->stats_on == 1)
     {
         hipLaunchKernelGGL(echo_stats_kernel, dim3((e->n_ch + 255)/256), dim3(256), 0, e->stream,
                            L.rx, (const int16_t *) L.clean, L.stride, samples, e->n_ch, e->stats);
@@ -562,7 +563,7 @@ int spangpu_echo_stats(spangpu_echo_t *e, int enable)
         ECHO_TRY(hipMalloc(&e->stats, (size_t) e->n_ch*sizeof(EchoStats)));
         ECHO_TRY(hipMemsetAsync(e->stats, 0, (size_t) e->n_ch*sizeof(EchoStats), e->stream));
     }
-    e->stats_on = (enable != 0);
+    e->stats_on = (enable == 2)  ?  2  :  (enable != 0)  ?  1  :  0;
     return SPANGPU_OK;
 }
 

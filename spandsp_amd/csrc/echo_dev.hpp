@@ -65,6 +65,15 @@ constexpr int kModeCng = 0x04;
 constexpr int kModeTxHpf = 0x20;
 constexpr int kModeRxHpf = 0x40;
 
+// Per-channel line statistics (the result a multi-GPU echo run reports, see echo_stats_kernel below)
+struct EchoStats
+{
+    unsigned long long sum_rx2;
+    unsigned long long sum_clean2;
+    uint32_t crc;               // running CRC-32 of the clean stream (pre- and post-conditioned as zlib's)
+    uint32_t samples;           // samples in the sums
+};
+
 struct EchoLaunch
 {
     const int16_t *tx;          // [n_ch][stride]
@@ -79,6 +88,7 @@ struct EchoLaunch
     int32_t *taps32;            // [n_ch][T]
     int16_t *taps16;            // [n_ch][4][T]
     int16_t *hist;              // [n_ch][T], window order: hist[i] = history[(i + curr_pos) mod T]
+    EchoStats *stats;           // [n_ch] or nullptr: the update kernel itself adds the frame's energy sums (no second pass)
 };
 
 __device__ __forceinline__ int echo_hpf(int32_t &c0, int32_t &c1, int amp)
@@ -369,11 +379,23 @@ void echo_bank_kernel(const EchoLaunch L)
     {
         const int n = min(kMaxFrame, L.samples - base);
         // ---- stage tx/rx of this pass into LDS (each group copies its own channel) ----------
+        unsigned long long st_part = 0;                     // this lane's share of the pass's received energy (L.stats)
         for (int i = j;  i < n;  i += G)
         {
             const int a = (uint16_t) L.tx[(size_t) ch*L.stride + base + i];
             const int b = (uint16_t) L.rx[(size_t) ch*L.stride + base + i];
             io[wv][g][i] = a | (b << 16);
+            st_part += (unsigned long long) ((int) (short) b*(int) (short) b);
+        }
+        if (L.stats)
+        {
+            // the lanes of a channel each saw every G-th sample: add up, the first lane books the pass.  (Kept out of the
+            // registers that live across the sample loop: four more of them there put spills into the common body.)
+#pragma unroll
+            for (int m = 1;  m < G;  m <<= 1)
+                st_part += __shfl_xor(st_part, m);
+            if (leader)
+                L.stats[ch].sum_rx2 += st_part;
         }
         // (one wave per io/bounce/acfbuf slice; LDS ops of a wave complete in order)
 
@@ -729,15 +751,25 @@ void echo_bank_kernel(const EchoLaunch L)
         }
 
         // ---- clean samples out (each group writes its own channel) ---------------------------
+        unsigned long long cl_part = 0;
         if (live)
         {
             for (int i = j;  i < n;  i += G)
             {
                 const int word = io[wv][g][i];
                 L.clean[(size_t) ch*L.stride + base + i] = (int16_t) (word & 0xFFFF);
+                cl_part += (unsigned long long) ((int) (short) (word & 0xFFFF)*(int) (short) (word & 0xFFFF));
                 if (L.tx_out)
                     L.tx_out[(size_t) ch*L.stride + base + i] = (int16_t) (word >> 16);
             }
+        }
+        if (L.stats)
+        {
+#pragma unroll
+            for (int m = 1;  m < G;  m <<= 1)
+                cl_part += __shfl_xor(cl_part, m);
+            if (leader)
+                L.stats[ch].sum_clean2 += cl_part;
         }
     }
 
@@ -758,6 +790,8 @@ void echo_bank_kernel(const EchoLaunch L)
                 sc[ES_LAST_ACF + j + m*G] = my_acf[m];
         }
     }
+    if (L.stats  &&  leader)
+        L.stats[ch].samples += (uint32_t) L.samples;
     if (leader)
     {
         if (L.samples > 0)
@@ -820,14 +854,6 @@ void echo_hpf_tx_kernel(const int16_t *tx, int16_t *out, long long stride, int s
 // level_measurements do (tests/echo_tests.c:577-594) -- and carries on the CRC-32 (zlib polynomial, the bytes of the
 // int16 little-endian stream) of everything the canceller has put out, for bit-exactness checks against the CPU path.
 // The frame was written a moment ago by echo_bank_kernel and is read from L2; the CRC table sits in LDS.
-struct EchoStats
-{
-    unsigned long long sum_rx2;
-    unsigned long long sum_clean2;
-    uint32_t crc;               // running CRC-32 of the clean stream (pre- and post-conditioned as zlib's)
-    uint32_t samples;           // samples in the sums
-};
-
 __global__ __launch_bounds__(256)
 void echo_stats_kernel(const int16_t *rx, const int16_t *clean, long long stride, int samples, int n_ch, EchoStats *st)
 {

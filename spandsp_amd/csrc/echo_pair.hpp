@@ -321,11 +321,23 @@ void echo_pair_kernel(const EchoLaunch L)
     {
         const int n = min(kMaxFrame, L.samples - base);
         // ---- stage tx/rx of this pass into LDS (each pair of lanes copies its own channel) -------------------
+        unsigned long long st_part = 0;                     // this lane's share of the pass's received energy (L.stats)
         for (int i = j;  i < n;  i += G)
         {
             const int a = (uint16_t) L.tx[(size_t) ch*L.stride + base + i];
             const int b = (uint16_t) L.rx[(size_t) ch*L.stride + base + i];
             io[wv][g][i] = a | (b << 16);
+            st_part += (unsigned long long) ((int) (short) b*(int) (short) b);
+        }
+        if (L.stats)
+        {
+            // the lanes of a channel each saw every G-th sample: add up, the first lane books the pass.  (Kept out of the
+            // registers that live across the sample loop: four more of them there put spills into the common body.)
+#pragma unroll
+            for (int m = 1;  m < G;  m <<= 1)
+                st_part += __shfl_xor(st_part, m);
+            if (leader)
+                L.stats[ch].sum_rx2 += st_part;
         }
         // (one wave per io / bounce / acf slice; LDS ops of a wave complete in order)
 
@@ -613,15 +625,25 @@ void echo_pair_kernel(const EchoLaunch L)
         }
 
         // ---- clean samples out (each pair of lanes writes its own channel) ----------------------------------------
+        unsigned long long cl_part = 0;
         if (live)
         {
             for (int i = j;  i < n;  i += G)
             {
                 const int word = io[wv][g][i];
                 L.clean[(size_t) ch*L.stride + base + i] = (int16_t) (word & 0xFFFF);
+                cl_part += (unsigned long long) ((int) (short) (word & 0xFFFF)*(int) (short) (word & 0xFFFF));
                 if (L.tx_out)
                     L.tx_out[(size_t) ch*L.stride + base + i] = (int16_t) (word >> 16);
             }
+        }
+        if (L.stats)
+        {
+#pragma unroll
+            for (int m = 1;  m < G;  m <<= 1)
+                cl_part += __shfl_xor(cl_part, m);
+            if (leader)
+                L.stats[ch].sum_clean2 += cl_part;
         }
     }
 
@@ -644,6 +666,8 @@ void echo_pair_kernel(const EchoLaunch L)
                 sc[ES_LAST_ACF + j + m*G] = my_acf[m];
         }
     }
+    if (L.stats  &&  leader)
+        L.stats[ch].samples += (uint32_t) L.samples;
     if (leader)
     {
         if (L.samples > 0)

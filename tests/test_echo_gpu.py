@@ -174,3 +174,29 @@ def test_echo_line_statistics(built):
     bank.stats_reset(sums=True, crc=True)
     z = bank.stats_get()
     assert not z["sum_rx2"].any() and not z["crc"].any() and not z["samples"].any()
+
+
+@pytest.mark.parametrize("lanes", [0, 2, 4, 8, 16])
+def test_echo_energy_sums_by_the_update_kernel(built, lanes):
+    """spangpu_echo_stats(ec, 2): the update kernel itself adds up the frame's energy sums (no second pass, no CRC), under
+    every lane mapping, and they are the sums of the samples that went in and came out."""
+    from spandsp_amd import engine
+    n_ch, taps, mode = 200, 128, 0x01
+    n = 160*30
+    tx, rx = make_channels(n_ch, n, taps, seed=777)
+    engine.lib().spangpu_tune_echo_lanes_per_channel(lanes)
+    try:
+        bank = engine.EchoBank(n_ch, taps, mode)
+    finally:
+        engine.lib().spangpu_tune_echo_lanes_per_channel(0)
+    bank.stats(2)
+    clean = np.zeros((n_ch, n), np.int16)
+    for pos in range(0, n, 160):
+        clean[:, pos:pos + 160] = bank.update_host(tx[:, pos:pos + 160], rx[:, pos:pos + 160], use_hpf_tx=False)
+    st = bank.stats_get()
+    r = rx.astype(np.int64)
+    c = clean.astype(np.int64)
+    assert np.array_equal(st["sum_rx2"], (r*r).sum(axis=1).astype(np.uint64))
+    assert np.array_equal(st["sum_clean2"], (c*c).sum(axis=1).astype(np.uint64))
+    assert np.all(st["samples"] == n) and not st["crc"].any()
+    bank.close()
