@@ -6,8 +6,8 @@
 // The ten newest runs are kept newest first, so that "the run j places back" is register j: the 24 state words are read in
 // one go, shifted down when a run ends (a few times a second) and only what changed is written back.  Window limits are
 // kept in blocks (lo <= 128 b  <=>  b >= ceil(lo/128)), which makes every test a 32-bit compare.
-//   state words ([word][channel]): 0 seen f1, 1 seen f2, 2 tone followed (-1 none), 3 turn, 4..13 run pair
-//   (f1 & 0xFFFF | f2 << 16), newest first, 14..23 run length in blocks.
+//   state words ([word][channel]) as spangpu_bank_cadence_get_state() shows them: 0 seen f1, 1 seen f2, 2 tone followed
+//   (-1 none), 3 turn, 4..13 run pair (f1 & 0xFFFF | f2 << 16), newest first, 14..23 run length in blocks.
 // Events, in the order the reference calls back, two words each at ev[(slot*n_ch + ch)*2]:
 //   word 0 = kind | (f1 + 1) << 8 | (f2 + 1) << 16 | block << 24, word 1 = tone number (kind 1) or milliseconds (kind 3);
 //   kind 1 = tone recognised (tone_callback(user, tone, -10, 0)), 2 = tone lost (tone_callback(user, -1, -10, 0)),
@@ -21,6 +21,8 @@ namespace spg {
 constexpr int kCadHistory = 10;
 constexpr int kCadWords = 4 + 2*kCadHistory;
 constexpr int kCadSlotsPerBlock = 3;
+constexpr int kCadLdsTones = 32;              // the streaming kernel keeps the cadence tables in LDS: up to this many tones
+constexpr int kCadLdsElems = 96;              // ... and elements (larger sets are matched by cadence_kernel)
 constexpr uint32_t kCadBlkValid = 0x01;        // SPANGPU_BLK_VALID in the record's flag byte
 
 struct CadenceArgs
@@ -35,7 +37,22 @@ struct CadenceArgs
     int n_tones;
     int segments;
     int which;                  // the counter this launch adds to (it clears the other for the next launch)
+    int n_elems;                // elements in all (first[n_tones])
 };
+
+// A lane's cadence state, asked for early (the streaming kernel requests it with the detector state, a whole frame before
+// it is needed: read at the end of the kernel its latency overlapped nothing)
+struct CadenceRegs
+{
+    int32_t w[kCadWords];
+};
+
+__device__ static inline void cadence_state_load(const CadenceArgs &A, int ch, int n_ch, CadenceRegs &r)
+{
+#pragma unroll
+    for (int i = 0;  i < kCadWords;  i++)
+        r.w[i] = A.state[(size_t) i*n_ch + ch];
+}
 
 __host__ __device__ static inline int32_t cad_pair(int f1, int f2)
 {
@@ -45,29 +62,33 @@ __host__ __device__ static inline int32_t cad_pair(int f1, int f2)
 // Walks the records of one launch for channel ch (rec0 / rec1 = the first two, already in registers; further ones are read
 // from rec).  Returns the number of events left in the slot arrays.  A lane that is not `active` walks along and stores
 // nothing.
-__device__ static inline int cadence_walk(const CadenceArgs &A, int ch, int n_ch, int maxb, uint32_t rec0, uint32_t rec1,
-                                          const uint32_t *rec, bool active)
+// `first` / `elem`: the cadence tables, wherever the caller keeps them (global memory, or its copy in LDS); `r`: the lane's
+// state as cadence_state_load() fetched it.
+//
+// `turn` (word 3) counts the elements of the followed cadence that have gone by, modulo its length.  (A ring for the ten
+// runs in memory, so that a run end rewrites two words instead of twenty, was tried: putting the ring into age order
+// in registers cost more than the stores it saved.)
+template <class FirstT, class ElemT>
+__device__ static inline int cadence_walk_loaded(const CadenceArgs &A, const FirstT &first, const ElemT &elem, const CadenceRegs &r,
+                                                 int ch, int n_ch, int maxb, uint32_t rec0, uint32_t rec1, const uint32_t *rec,
+                                                 bool active)
 {
-    const int32_t *__restrict__ first = A.first;
-    const int4 *__restrict__ elem = A.elem;
     int32_t *st = A.state;
     int32_t pf[kCadHistory];
     int32_t bl[kCadHistory];
-    int32_t w0[4];
+    int seen1 = r.w[0];
+    int seen2 = r.w[1];
+    int tone = r.w[2];
+    int turn = r.w[3];
 #pragma unroll
-    for (int i = 0;  i < 4;  i++)
-        w0[i] = st[(size_t) i*n_ch + ch];
-#pragma unroll
-    for (int i = 0;  i < kCadHistory;  i++)
+    for (int j = 0;  j < kCadHistory;  j++)
     {
-        pf[i] = st[(size_t) (4 + i)*n_ch + ch];
-        bl[i] = st[(size_t) (4 + kCadHistory + i)*n_ch + ch];
+        pf[j] = r.w[4 + j];
+        bl[j] = r.w[4 + kCadHistory + j];
     }
-    int seen1 = w0[0];
-    int seen2 = w0[1];
-    int tone = w0[2];
-    int turn = w0[3];
-    bool shifted = false;
+    const int32_t pf0_in = pf[0];
+    const int32_t bl0_in = bl[0];
+    int shifts = 0;
     bool touched = false;
     int n_ev = 0;
     int blk = 0;
@@ -83,18 +104,24 @@ __device__ static inline int cadence_walk(const CadenceArgs &A, int ch, int n_ch
         n_ev++;
     };
     auto fits = [&](const int4 &e, int32_t pair, int32_t blocks) { return e.x == pair  &&  e.y <= blocks  &&  blocks <= e.z; };
-    // Is the cadence followed still alive?  `turn` elements of it have gone by since it was recognised (on its last element),
-    // so the current run must be element (turn - 1) mod n and not yet too long; when a run has just ended, the one before
-    // it must in addition have been a proper element (turn - 2) mod n.
-    auto alive = [&](int t, int turn_now, bool run_ended)
+    // Is the cadence followed still alive?  `turn_now` elements of it have gone by since it was recognised (on its last
+    // element), counted modulo its length n: the current run must be element turn_now - 1 (mod n) and not yet too long; when
+    // a run has just ended, the one before it must in addition have been a proper element turn_now - 2 (mod n).  `n_out`:
+    // the cadence's length.
+    auto alive = [&](int t, int turn_now, bool run_ended, int &n_out)
     {
         const int e0 = first[t];
         const int n = first[t + 1] - e0;
+        n_out = n;
         if (n <= 0)
             return false;
-        if (run_ended  &&  !fits(elem[e0 + (turn_now + n - 2)%n], pf[1], bl[1]))
+        int i1 = turn_now - 1;
+        i1 += (i1 < 0)  ?  n  :  0;
+        int i2 = i1 - 1;
+        i2 += (i2 < 0)  ?  n  :  0;
+        if (run_ended  &&  !fits(elem[e0 + i2], pf[1], bl[1]))
             return false;
-        const int4 e = elem[e0 + (turn_now + n - 1)%n];
+        const int4 e = elem[e0 + i1];
         return e.x == pf[0]  &&  bl[0] <= e.z;
     };
     for (blk = 0;  blk < maxb;  blk++)
@@ -103,6 +130,7 @@ __device__ static inline int cadence_walk(const CadenceArgs &A, int ch, int n_ch
         if (!((w >> 16) & kCadBlkValid))
             continue;
         touched = true;
+        bool lost_now = false;
         const int k1 = (int) (w & 0xFF) - 1;
         const int k2 = (int) ((w >> 8) & 0xFF) - 1;
         const int32_t pair = cad_pair(k1, k2);
@@ -119,10 +147,14 @@ __device__ static inline int cadence_walk(const CadenceArgs &A, int ch, int n_ch
             // seen twice in a row and not what the current run is made of: that run is over
             if (tone >= 0)
             {
-                const int t_now = turn++;
-                if (!alive(tone, t_now, true))
+                // (the count of elements gone by moves on by one, modulo the cadence's length)
+                int n_t = 0;
+                const bool ok = alive(tone, turn, true, n_t);
+                turn = (turn + 1 >= n_t)  ?  0  :  (turn + 1);
+                if (!ok)
                 {
                     tone = -1;
+                    lost_now = true;
                     emit(2, -1, -1);
                 }
             }
@@ -136,57 +168,106 @@ __device__ static inline int cadence_walk(const CadenceArgs &A, int ch, int n_ch
             }
             pf[0] = pair;
             bl[0] = 1;
-            shifted = true;
+            shifts++;
         }
         else
         {
             // more of the same (tested before this block is counted, as the reference does)
-            if (tone >= 0  &&  !alive(tone, turn, false))
+            if (tone >= 0)
             {
-                tone = -1;
-                emit(2, -1, -1);
+                int n_t = 0;
+                if (!alive(tone, turn, false, n_t))
+                {
+                    tone = -1;
+                    lost_now = true;
+                    emit(2, -1, -1);
+                }
             }
             bl[0]++;
         }
         if (tone >= 0)
             continue;
-        // do the newest runs spell out a whole cadence, the current run being its last element?
+        // Do the newest runs spell out a whole cadence, the current run being its last element?  While a run goes on only its
+        // length changes, by one per block, so a cadence can first fit at the block where the run reaches its last element's
+        // least length (or at once, if that is one block): only there are its other elements looked at, when any lane of
+        // the wave is at that point.  The exception: a channel that has just stopped following a tone (or was told to forget
+        // the one it followed: tone == -2) may find itself in the middle of such a window, and looks at everything once.
+        // The tables are the same for every lane: every cadence's last element is requested first, all together, then the
+        // elements of the cadences that are due, a cadence at a time and without short cuts.
+        const bool look_all = lost_now  ||  (tone == -2);
+        tone = -1;
+        int found = -1;
+        int e_next = first[0];
         for (int t = 0;  t < A.n_tones;  t++)
         {
-            const int e0 = first[t];
-            const int n = first[t + 1] - e0;
+            const int e0 = e_next;
+            e_next = first[t + 1];
+            const int n = e_next - e0;
             if (n > kCadHistory)
                 continue;
+            if (n > 0)
+            {
+                const int4 last = elem[e0 + n - 1];
+                const bool due = look_all  ||  (last.x == pf[0]  &&  bl[0] == ((last.y > 1)  ?  last.y  :  1));
+                if (!__any(due))
+                    continue;
+            }
             bool ok = true;
+            if (n <= 4)
+            {
+                // (what call progress cadences are made of: a batch of four, not of ten)
+                int4 els[4];
 #pragma unroll
-            for (int j = 0;  j < kCadHistory;  j++)
-            {
-                if (j < n)
-                    ok = ok  &&  fits(elem[e0 + n - 1 - j], pf[j], bl[j]);
+                for (int j = 0;  j < 4;  j++)
+                    els[j] = elem[(j < n)  ?  (e0 + n - 1 - j)  :  0];
+#pragma unroll
+                for (int j = 0;  j < 4;  j++)
+                    ok = ok  &  ((j >= n)  |  fits(els[j], pf[j], bl[j]));
             }
-            if (ok)
+            else
             {
-                tone = t;
-                turn = 0;
-                emit(1, -1, t);
-                break;
+                int4 els[kCadHistory];
+#pragma unroll
+                for (int j = 0;  j < kCadHistory;  j++)
+                    els[j] = elem[(j < n)  ?  (e0 + n - 1 - j)  :  0];
+#pragma unroll
+                for (int j = 0;  j < kCadHistory;  j++)
+                    ok = ok  &  ((j >= n)  |  fits(els[j], pf[j], bl[j]));
             }
+            found = (ok  &&  found < 0)  ?  t  :  found;
+        }
+        if (found >= 0)
+        {
+            tone = found;
+            turn = 0;
+            emit(1, -1, found);
         }
     }
     if (active)
         A.count[ch] = n_ev;
     if (touched  &&  active)
     {
-        st[(size_t) 0*n_ch + ch] = seen1;
-        st[(size_t) 1*n_ch + ch] = seen2;
-        st[(size_t) 2*n_ch + ch] = tone;
-        st[(size_t) 3*n_ch + ch] = turn;
-        st[(size_t) 4*n_ch + ch] = pf[0];
-        st[(size_t) (4 + kCadHistory)*n_ch + ch] = bl[0];
-        if (shifted)
+        // only what changed goes back: on a line that stays as it is one word per block (the length of its current run);
+        // after a run end all of the runs
+        if (seen1 != r.w[0])
+            st[(size_t) 0*n_ch + ch] = seen1;
+        if (seen2 != r.w[1])
+            st[(size_t) 1*n_ch + ch] = seen2;
+        if (tone != r.w[2])
+            st[(size_t) 2*n_ch + ch] = tone;
+        if (turn != r.w[3])
+            st[(size_t) 3*n_ch + ch] = turn;
+        if (shifts == 0)
+        {
+            if (pf[0] != pf0_in)
+                st[(size_t) 4*n_ch + ch] = pf[0];
+            if (bl[0] != bl0_in)
+                st[(size_t) (4 + kCadHistory)*n_ch + ch] = bl[0];
+        }
+        else
         {
 #pragma unroll
-            for (int i = 1;  i < kCadHistory;  i++)
+            for (int i = 0;  i < kCadHistory;  i++)
             {
                 st[(size_t) (4 + i)*n_ch + ch] = pf[i];
                 st[(size_t) (4 + kCadHistory + i)*n_ch + ch] = bl[i];
@@ -194,6 +275,14 @@ __device__ static inline int cadence_walk(const CadenceArgs &A, int ch, int n_ch
         }
     }
     return n_ev;
+}
+
+__device__ static inline int cadence_walk(const CadenceArgs &A, int ch, int n_ch, int maxb, uint32_t rec0, uint32_t rec1,
+                                          const uint32_t *rec, bool active)
+{
+    CadenceRegs r;
+    cadence_state_load(A, ch, n_ch, r);
+    return cadence_walk_loaded(A, A.first, A.elem, r, ch, n_ch, maxb, rec0, rec1, rec, active);
 }
 
 // The lane's n_ev events (just written to the slot arrays) onto the compact list at position `at`.

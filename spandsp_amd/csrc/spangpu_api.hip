@@ -287,6 +287,7 @@ struct Cadence
 {
     int n_tones;
     int n_elems;
+    int tone_len[kCadLdsTones + 1];     // elements of each of the first tones (host copy: spangpu_bank_cadence_set_state)
     int32_t *d_first;       // [n_tones + 1]
     int4 *d_elem;           // (pair, least blocks, most blocks, 0)
     int32_t *d_state;       // [kCadWords][n_ch]
@@ -749,7 +750,8 @@ static void fill_launch(ToneLaunch &L, spangpu_bank_t *b, const int16_t *d_amp, 
         // every channel takes part (launch_fast() decides; any other kernel leaves them to cadence_kernel)
         b->cad->fused = false;
         b->cad->list_due = false;
-        if (kCadSlotsPerBlock*maxb <= b->cad->slots_cap  &&  maxb > 0  &&  b->next_lens == nullptr  &&  !force_end)
+        if (kCadSlotsPerBlock*maxb <= b->cad->slots_cap  &&  maxb > 0  &&  b->next_lens == nullptr  &&  !force_end
+            &&  b->cad->n_tones <= kCadLdsTones  &&  b->cad->n_elems <= kCadLdsElems)
             cadence_args(b, b->cad, L.cad, b->cad->which ^ 1);
     }
     L.rec_energy = b->rec_energy;
@@ -1591,6 +1593,7 @@ static void cadence_args(const spangpu_bank_s *b, const Cadence *c, CadenceArgs 
     A.n_tones = c->n_tones;
     A.segments = c->segments;
     A.which = which;
+    A.n_elems = c->n_elems;
 }
 
 // Event buffers for launches of up to `slots` slots per channel.
@@ -1694,11 +1697,15 @@ int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int 
     if (!fresh)
     {
         // the tone numbers of the old set mean nothing in the new one: nobody is following a tone (the run histories stay)
-        HIP_TRY(hipMemsetAsync(c->d_state + (size_t) 2*b->n_ch, 0xFF, (size_t) b->n_ch*sizeof(int32_t), b->stream));
+        // (-2, not -1: "none, and look at every cadence at the next block" -- the channel may be in the middle of a run that
+        // one of the new cadences ends with, see cadence_dev.hpp)
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) (c->d_state + (size_t) 2*b->n_ch), (int) 0xFFFFFFFEu, (size_t) b->n_ch, b->stream));
         HIP_TRY(hipMemsetAsync(c->d_state + (size_t) 3*b->n_ch, 0, (size_t) b->n_ch*sizeof(int32_t), b->stream));
     }
     c->n_tones = n_tones;
     c->n_elems = n_elems;
+    for (int t = 0;  t < n_tones  &&  t < kCadLdsTones;  t++)
+        c->tone_len[t] = first[t + 1] - first[t];
     c->segments = want_segments  ?  1  :  0;
     HIP_TRY(hipStreamSynchronize(b->stream));
     return SPANGPU_OK;
@@ -1837,6 +1844,8 @@ int spangpu_bank_cadence_get_state(spangpu_bank_t *b, int channel, int32_t *word
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipMemcpy2D(words, sizeof(int32_t), b->cad->d_state + channel, (size_t) b->n_ch*sizeof(int32_t), sizeof(int32_t), kCadWords,
                         hipMemcpyDeviceToHost));
+    if (words[2] < -1)
+        words[2] = -1;          // -2 is the engine's own "none, and every cadence is looked at once at the next block" (cadence_dev.hpp)
     return kCadWords;
 }
 
@@ -1846,11 +1855,18 @@ int spangpu_bank_cadence_set_state(spangpu_bank_t *b, int channel, const int32_t
         return fail(SPANGPU_ERR_STATE, "no cadences were given to this bank");
     if (channel < 0  ||  channel >= b->n_ch  ||  words == nullptr)
         return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
-    if (words[2] < -1  ||  words[2] >= b->cad->n_tones)
+    if (words[2] < -1  ||  words[2] >= b->cad->n_tones  ||  words[3] < 0  ||  words[3] > 255)
         return fail(SPANGPU_ERR_BAD_ARG, "state words out of range");
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    HIP_TRY(hipMemcpy2D(b->cad->d_state + channel, (size_t) b->n_ch*sizeof(int32_t), words, sizeof(int32_t), sizeof(int32_t), kCadWords,
+    int32_t w[kCadWords];
+    memcpy(w, words, sizeof(w));
+    if (w[2] == -1)
+        w[2] = -2;              // a state from outside may sit in the middle of a run a cadence ends with: look at all of them once
+    // the elements of the followed cadence that have gone by are counted modulo its length on the device (head of the ring: 0)
+    if (w[2] >= 0  &&  w[2] < kCadLdsTones  &&  b->cad->tone_len[w[2]] > 0)
+        w[3] = w[3]%b->cad->tone_len[w[2]];
+    HIP_TRY(hipMemcpy2D(b->cad->d_state + channel, (size_t) b->n_ch*sizeof(int32_t), w, sizeof(int32_t), sizeof(int32_t), kCadWords,
                         hipMemcpyHostToDevice));
     return SPANGPU_OK;
 }

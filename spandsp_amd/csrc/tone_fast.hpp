@@ -232,6 +232,23 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         __syncthreads();
     }
 
+    // Super-tone cadences: the tables the walk at the end of the kernel looks things up in go to LDS now (a look-up in global
+    // memory there is a full memory latency with nothing to overlap it, and the walk makes two or three in a row)
+    __shared__ int32_t cad_first[((ABL & kToneCadence) != 0)  ?  (kCadLdsTones + 1)  :  1];
+    __shared__ int4 cad_elem[((ABL & kToneCadence) != 0)  ?  kCadLdsElems  :  1];
+    if constexpr ((ABL & kToneCadence) != 0)
+    {
+        // (the host only builds this variant into a launch when the tables fit: kCadLdsTones, kCadLdsElems)
+        if (L.cad.state)
+        {
+            constexpr int kThreads = kWave*(WPB + (LDR  ?  1  :  0));
+            for (int i = threadIdx.x;  i <= L.cad.n_tones  &&  i <= kCadLdsTones;  i += kThreads)
+                cad_first[i] = L.cad.first[i];
+            for (int i = threadIdx.x;  i < L.cad.n_elems  &&  i < kCadLdsElems;  i += kThreads)
+                cad_elem[i] = L.cad.elem[i];
+            __syncthreads();
+        }
+    }
     if (ABL & 128)
         return;                                     // probe: launch + dispatch cost alone
     const unsigned lane = threadIdx.x & (kWave - 1);
@@ -383,6 +400,12 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
     if (Det::kEnergy  &&  !(ABL & 1024))
         energy = ldf(L.sf + (size_t) (2*NB)*nch);
     det.load_extra(L, (int) ch);
+    CadenceRegs cad_regs;
+    if constexpr ((ABL & kToneCadence) != 0)
+    {
+        if (L.cad.state)
+            cadence_state_load(L.cad, (int) ch, (int) nch, cad_regs);     // needed a frame from now: the latency costs nothing here
+    }
     uint32_t w0 = (ABL & 1024)  ?  0u  :  (uint32_t) ldi(L.si);
     int32_t w1 = (ABL & 1024)  ?  0  :  ldi(L.si + (size_t) nch);
 
@@ -778,7 +801,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
                 __threadfence_block();          // records past the second were stored by end_block(): read them back whole
             // (the compact list is made on demand by cadence_list_kernel: an atomic per wave on its counter, a thousand of
             // them on one address, took longer here than the whole walk)
-            (void) cadence_walk(L.cad, (int) ch, (int) nch, L.maxb, rec0, rec1, L.rec, store  &&  keep);
+            (void) cadence_walk_loaded(L.cad, cad_first, cad_elem, cad_regs, (int) ch, (int) nch, L.maxb, rec0, rec1, L.rec, store  &&  keep);
         }
     }
     stamp(15);
