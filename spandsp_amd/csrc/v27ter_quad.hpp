@@ -281,6 +281,7 @@ SPG_FN void v27_quad_run(Q &q, const V27Launch &L, const int ch, const V27QuadTa
         emit(-5);                                           // SIG_STATUS_TRAINING_FAILED
     };
 
+    SPG_PROF_DECL();
     const int16_t *src = L.amp + (size_t) ch*L.stride;
     SPG_LOADS_DONE();
     q.sync(1);
@@ -324,13 +325,103 @@ SPG_FN void v27_quad_run(Q &q, const V27Launch &L, const int ch, const V27QuadTa
     for (int half = 0;  half < 2;  half++)
     {
     const bool take = (half == 1)  ||  (baud_half == 0);
+    SPG_PROF_STAMP(0);
     // ---- phase A: every channel runs its own samples up to its next T/2 instant (replicated; selects, not branches) ----
     bool ready = false;
     bool restart_pending = false;
     int power = 0;
     while (q.any(take  &&  !ready  &&  !restart_pending  &&  pos < tn, 1))
     {
-        if (take  &&  !ready  &&  !restart_pending  &&  pos < tn)
+        const bool want = take  &&  !ready  &&  !restart_pending  &&  pos < tn;
+        // -- The calm stretch.  A channel whose carrier is up and not about to drop (and that is not parked) sends every sample
+        // on, so how many samples it is to the T/2 instant follows from eq_put_step alone: up to four of them are taken
+        // together -- one per lane for the arithmetic that does not depend on the sample before, the power estimate in
+        // order on copies -- and if the power stays above the carrier-off threshold on every channel of the wave, that
+        // is the stretch.  Otherwise nothing of it is kept and the loop takes one sample the long way.
+        {
+            const int cand = min(pos + role, kV29QuadTile - 1);
+            const uint32_t pwc = C.pcm[cand >> 1];
+            const int amp_c = (int) (short) ((cand & 1)  ?  (pwc >> 16)  :  (pwc & 0xFFFF));
+            const float my_ampf = (float) amp_c;
+            const int my_x = amp_c >> 1;
+            const int before = q.prev1(my_x, 2);
+            const int dif = (int) (short) (my_x - ((role == 0)  ?  last_sample  :  before));
+            const int my_sq = dif*dif;
+            const int my_ad = (int) (short) abs(dif);
+            const int my_ad10 = (my_ad << 3) + (my_ad << 1);
+            const int x0 = q.template bcast<0>(my_x, 21);
+            const int x1 = q.template bcast<1>(my_x, 22);
+            const int x2 = q.template bcast<2>(my_x, 23);
+            const int x3 = q.template bcast<3>(my_x, 24);
+            const int sq0 = q.template bcast<0>(my_sq, 25);
+            const int sq1 = q.template bcast<1>(my_sq, 26);
+            const int sq2 = q.template bcast<2>(my_sq, 27);
+            const int sq3 = q.template bcast<3>(my_sq, 28);
+            const int ad0 = q.template bcast<0>(my_ad, 29);
+            const int ad1 = q.template bcast<1>(my_ad, 30);
+            const int ad2 = q.template bcast<2>(my_ad, 31);
+            const int ad3 = q.template bcast<3>(my_ad, 32);
+            const int adt0 = q.template bcast<0>(my_ad10, 33);
+            const int adt1 = q.template bcast<1>(my_ad10, 34);
+            const int adt2 = q.template bcast<2>(my_ad10, 35);
+            const int adt3 = q.template bcast<3>(my_ad10, 36);
+            const bool calm0 = (signal_present > 0)  &&  (drop_pending == 0)  &&  (stage != V27_PARKED);
+            const int E = eq_put_step;
+            const int kn = max(1, ((E > 0)  ?  1  :  0) + ((E > sets)  ?  1  :  0) + ((E > 2*sets)  ?  1  :  0) + ((E > 3*sets)  ?  1  :  0));
+            const int m = want  ?  min(kn, min(tn - pos, 4))  :  0;
+            int t_pr = power_reading;
+            int t_high = high_sample;
+            int t_low = low_samples;
+            int t_power = power;
+            int badf = 0;
+            const int off1 = max(carrier_off_power, 1);
+            auto calm_sample = [&](const int k, const int sq, const int ad, const int ad10)
+            {
+                if (k < m)
+                {
+                    const int pwr = t_pr + ((sq - t_pr) >> 4);
+                    badf |= (pwr < off1)  ?  1  :  0;
+                    const bool low = (ad10 < t_high);
+                    const int low_inc = t_low + 1;
+                    const bool wipe = low  &&  (low_inc > 120);
+                    t_pr = wipe  ?  0  :  pwr;
+                    t_high = low  ?  (wipe  ?  0  :  t_high)  :  max(t_high, ad);
+                    t_low = low  ?  (wipe  ?  0  :  low_inc)  :  0;
+                    t_power = pwr;
+                }
+            };
+            calm_sample(0, sq0, ad0, adt0);
+            calm_sample(1, sq1, ad1, adt1);
+            calm_sample(2, sq2, ad2, adt2);
+            calm_sample(3, sq3, ad3, adt3);
+            if (!q.any(want  &&  (!calm0  ||  badf != 0), 9))
+            {
+                if (role < m)
+                {
+                    int idx = rrc_step + role;
+                    idx = (idx >= kRrcLen)  ?  (idx - kRrcLen)  :  idx;
+                    C.rrc[idx].x = my_ampf;
+                    C.rrc[kRrcLen + idx].y = my_ampf;
+                }
+                if (m > 0)
+                {
+                    power_reading = t_pr;
+                    high_sample = t_high;
+                    low_samples = t_low;
+                    power = t_power;
+                    last_sample = (m >= 4)  ?  x3  :  (m == 3)  ?  x2  :  (m == 2)  ?  x1  :  x0;
+                    int rs = rrc_step + m;
+                    rrc_step = (rs >= kRrcLen)  ?  (rs - kRrcLen)  :  rs;
+                    pos += m;
+                    eq_put_step = E - sets*m;
+                    ready = (eq_put_step <= 0);
+                    carrier_phase += (uint32_t) (ready  ?  (m - 1)  :  m)*(uint32_t) carrier_phase_rate;
+                }
+                q.sync(11);
+                continue;
+            }
+        }
+        if (want)
         {
             const uint32_t pw = C.pcm[pos >> 1];
             const int amp = (int) (short) ((pos & 1)  ?  (pw >> 16)  :  (pw & 0xFFFF));
@@ -387,6 +478,7 @@ SPG_FN void v27_quad_run(Q &q, const V27Launch &L, const int ch, const V27QuadTa
             }
         }
     }
+    SPG_PROF_STAMP(2);
     if (q.any(restart_pending, 3))
     {
         if (restart_pending)
@@ -460,6 +552,7 @@ SPG_FN void v27_quad_run(Q &q, const V27Launch &L, const int ch, const V27QuadTa
             carrier_phase += (uint32_t) carrier_phase_rate;
         }
     }
+    SPG_PROF_STAMP(5);
     q.sync(4);
     }
     if (!q.any(any_ready  ||  restarted, 5))
@@ -532,6 +625,7 @@ SPG_FN void v27_quad_run(Q &q, const V27Launch &L, const int ch, const V27QuadTa
             zim = q.template bcast<1>(z, 10);
         }
 
+        SPG_PROF_STAMP(6);
         do_track = false;
         do_tune = false;
         do_save = false;
@@ -666,6 +760,7 @@ SPG_FN void v27_quad_run(Q &q, const V27Launch &L, const int ch, const V27QuadTa
             carrier_phase_rate += v29_f2i(use_track_i*error);
             carrier_phase += (uint32_t) v29_f2i(use_track_p*error);
         }
+        SPG_PROF_STAMP(7);
         q.sync(6);
         if (do_tune)
         {
@@ -687,6 +782,7 @@ SPG_FN void v27_quad_run(Q &q, const V27Launch &L, const int ch, const V27QuadTa
                 C.taps[3*i + 2] = -cn.x;
             }
         }
+        SPG_PROF_STAMP(8);
         q.sync(7);
         if (do_save)
         {
@@ -702,6 +798,8 @@ SPG_FN void v27_quad_run(Q &q, const V27Launch &L, const int ch, const V27QuadTa
     }
     }
 
+    SPG_PROF_STAMP(9);
+    SPG_PROF_FLUSH();
     // ---- write back (arrays dealt over the lanes, scalars by the first) ----
     q.sync(8);
     for (int i = role;  i < kRrcLen;  i += 4)
