@@ -381,7 +381,41 @@ typedef void (*digits_tx_callback_t)(void *user_data);
 typedef struct fsk_rx_state_s fsk_rx_state_t;
 typedef struct modem_connect_tones_rx_state_s modem_connect_tones_rx_state_t;
 typedef struct dtmf_tx_state_s dtmf_tx_state_t;
+typedef struct spangpu_txbank_s spangpu_txbank_t;
 typedef struct spangpu_line_group_s spangpu_line_group_t;
+
+/* The objects themselves, for callers that bring their own storage (xxx_init(&my_state, ...), ended with xxx_release();
+   spandsp keeps the like under spandsp/private/).  They are handles: the signal state lives in HBM.  Nothing in them is
+   for the caller to touch. */
+struct fsk_rx_state_s
+{
+    spangpu_line_group_t *grp;
+    int channel;
+    int private_grp;
+    span_put_bit_func_t put_bit;
+    void *put_bit_user_data;
+    span_modem_status_func_t status_handler;
+    void *status_user_data;
+    int caller_storage;
+};
+struct modem_connect_tones_rx_state_s
+{
+    spangpu_line_group_t *grp;
+    int channel;
+    int private_grp;
+    span_tone_report_func_t tone_callback;
+    void *callback_data;
+    int caller_storage;
+    int tone_type;
+};
+struct dtmf_tx_state_s
+{
+    spangpu_txbank_t *bank;
+    digits_tx_callback_t callback;
+    void *callback_data;
+    int puts;                   /* dtmf_tx_put() calls that queued digits (the callback's way of answering) */
+    int caller_storage;
+};
 
 SPANGPU_API extern const fsk_spec_t preset_fsk_specs[];
 
@@ -457,6 +491,16 @@ SPANGPU_API int dtmf_tx(dtmf_tx_state_t *s, int16_t amp[], int max_samples);
    signal source bank each; caller-supplied storage (s != NULL) is not supported (state lives in HBM) */
 typedef struct bell_mf_tx_state_s bell_mf_tx_state_t;
 typedef struct r2_mf_tx_state_s r2_mf_tx_state_t;
+struct bell_mf_tx_state_s
+{
+    spangpu_txbank_t *bank;
+    int caller_storage;
+};
+struct r2_mf_tx_state_s
+{
+    spangpu_txbank_t *bank;
+    int caller_storage;
+};
 SPANGPU_API bell_mf_tx_state_t *bell_mf_tx_init(bell_mf_tx_state_t *s);
 SPANGPU_API int bell_mf_tx_release(bell_mf_tx_state_t *s);
 SPANGPU_API int bell_mf_tx_free(bell_mf_tx_state_t *s);

@@ -49,26 +49,6 @@ struct spangpu_line_group_s
     pthread_mutex_t lock;       /* staging, attach / detach and the tick itself (recursive: callbacks may call back in) */
 };
 
-struct fsk_rx_state_s
-{
-    spangpu_line_group_t *grp;
-    int channel;
-    int private_grp;
-    span_put_bit_func_t put_bit;
-    void *put_bit_user_data;
-    span_modem_status_func_t status_handler;
-    void *status_user_data;
-};
-
-struct modem_connect_tones_rx_state_s
-{
-    spangpu_line_group_t *grp;
-    int channel;
-    int private_grp;
-    span_tone_report_func_t tone_callback;
-    void *callback_data;
-};
-
 static spangpu_line_group_t *group_new(int n_channels, int max_samples)
 {
     spangpu_line_group_t *g;
@@ -310,12 +290,16 @@ static void line_detach(spangpu_line_group_t *g, int channel, int private_grp)
 }
 
 /* ---- fsk_rx -------------------------------------------------------------------------------------------- */
-static fsk_rx_state_t *fsk_obj(spangpu_line_group_t *g, int channel, int private_grp, span_put_bit_func_t put_bit, void *user_data)
+static fsk_rx_state_t *fsk_obj(fsk_rx_state_t *s, spangpu_line_group_t *g, int channel, int private_grp, span_put_bit_func_t put_bit,
+                               void *user_data)
 {
-    fsk_rx_state_t *s;
+    const int mine = (s != NULL);
 
-    if ((s = (fsk_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+    if (mine)
+        memset(s, 0, sizeof(*s));
+    else if ((s = (fsk_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
         return NULL;
+    s->caller_storage = mine;
     s->grp = g;
     s->channel = channel;
     s->private_grp = private_grp;
@@ -332,11 +316,10 @@ fsk_rx_state_t *fsk_rx_init(fsk_rx_state_t *s, const fsk_spec_t *spec, int frami
 {
     spangpu_line_group_t *g;
 
-    if (s != NULL)
-        return NULL;                        /* the state is opaque here: caller-provided storage cannot be used */
+    /* s != NULL: the caller's storage (fsk.c:725-733); the handle goes there, the receiver itself is a private one-channel bank */
     if ((g = spangpu_fsk_group_create(0, spec, framing_mode, 1, 4096)) == NULL)
         return NULL;
-    if ((s = fsk_obj(g, 0, 1, put_bit, user_data)) == NULL)
+    if ((s = fsk_obj(s, g, 0, 1, put_bit, user_data)) == NULL)
         spangpu_line_group_destroy(g);
     return s;
 }
@@ -345,7 +328,7 @@ fsk_rx_state_t *spangpu_fsk_rx_attach(spangpu_line_group_t *g, int channel, span
 {
     if (g == NULL  ||  g->is_mct  ||  channel < 0  ||  channel >= g->n_ch  ||  g->handles[channel])
         return NULL;
-    return fsk_obj(g, channel, 0, put_bit, user_data);
+    return fsk_obj(NULL, g, channel, 0, put_bit, user_data);
 }
 
 int fsk_rx(fsk_rx_state_t *s, const int16_t *amp, int len)
@@ -360,18 +343,40 @@ int fsk_rx_fillin(fsk_rx_state_t *s, int len)
 
 int fsk_rx_restart(fsk_rx_state_t *s, const fsk_spec_t *spec, int framing_mode)
 {
-    /* a bank runs one spec (its window length follows the baud rate): only the framing mode can change */
-    if (spec == NULL  ||  spec->freq_zero != s->grp->spec.freq_zero  ||  spec->freq_one != s->grp->spec.freq_one
+    if (spec == NULL)
+        return -1;
+    if (spec->freq_zero != s->grp->spec.freq_zero  ||  spec->freq_one != s->grp->spec.freq_one
         ||  spec->baud_rate != s->grp->spec.baud_rate  ||  spec->min_level != s->grp->spec.min_level)
     {
-        return -1;
+        /* Another modem (fsk.c:670-723 re-initialises everything but the callbacks).  A bank runs one spec -- its window
+           length follows the baud rate -- so an object on a shared bank cannot leave it; an object of its own gets a new
+           one-channel bank. */
+        spangpu_line_group_t *g;
+
+        if (!s->private_grp)
+            return -1;
+        if ((g = spangpu_fsk_group_create(0, spec, framing_mode, 1, 4096)) == NULL)
+            return -1;
+        line_detach(s->grp, s->channel, 1);
+        s->grp = g;
+        s->channel = 0;
+        pthread_mutex_lock(&g->lock);
+        g->handles[0] = s;
+        g->n_attached++;
+        pthread_mutex_unlock(&g->lock);
+        return 0;
     }
     return (spangpu_fsk_restart(s->grp->fsk, s->channel, framing_mode) < 0)  ?  -1  :  0;
 }
 
 int fsk_rx_release(fsk_rx_state_t *s)
 {
-    (void) s;
+    /* what ends an object in the caller's storage: its place on the bank (or its private bank) goes, the storage stays */
+    if (s  &&  s->grp)
+    {
+        line_detach(s->grp, s->channel, s->private_grp);
+        s->grp = NULL;
+    }
     return 0;
 }
 
@@ -379,8 +384,9 @@ int fsk_rx_free(fsk_rx_state_t *s)
 {
     if (s == NULL)
         return 0;
-    line_detach(s->grp, s->channel, s->private_grp);
-    free(s);
+    fsk_rx_release(s);
+    if (!s->caller_storage)
+        free(s);
     return 0;
 }
 
@@ -444,13 +450,16 @@ int fsk_rx_get_framing_errors(fsk_rx_state_t *s, bool reset)
 }
 
 /* ---- modem_connect_tones_rx ---------------------------------------------------------------------------- */
-static modem_connect_tones_rx_state_t *mct_obj(spangpu_line_group_t *g, int channel, int private_grp,
+static modem_connect_tones_rx_state_t *mct_obj(modem_connect_tones_rx_state_t *s, spangpu_line_group_t *g, int channel, int private_grp,
                                                span_tone_report_func_t tone_callback, void *user_data)
 {
-    modem_connect_tones_rx_state_t *s;
+    const int mine = (s != NULL);
 
-    if ((s = (modem_connect_tones_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
+    if (mine)
+        memset(s, 0, sizeof(*s));
+    else if ((s = (modem_connect_tones_rx_state_t *) calloc(1, sizeof(*s))) == NULL)
         return NULL;
+    s->caller_storage = mine;
     s->grp = g;
     s->channel = channel;
     s->private_grp = private_grp;
@@ -468,11 +477,10 @@ modem_connect_tones_rx_state_t *modem_connect_tones_rx_init(modem_connect_tones_
 {
     spangpu_line_group_t *g;
 
-    if (s != NULL)
-        return NULL;
+    /* s != NULL: the caller's storage (modem_connect_tones.c:823-830) */
     if ((g = spangpu_modem_connect_tones_group_create(0, tone_type, tone_callback != NULL, 1, 4096)) == NULL)
         return NULL;
-    if ((s = mct_obj(g, 0, 1, tone_callback, user_data)) == NULL)
+    if ((s = mct_obj(s, g, 0, 1, tone_callback, user_data)) == NULL)
         spangpu_line_group_destroy(g);
     return s;
 }
@@ -482,7 +490,7 @@ modem_connect_tones_rx_state_t *spangpu_modem_connect_tones_rx_attach(spangpu_li
 {
     if (g == NULL  ||  !g->is_mct  ||  channel < 0  ||  channel >= g->n_ch  ||  g->handles[channel])
         return NULL;
-    return mct_obj(g, channel, 0, tone_callback, user_data);
+    return mct_obj(NULL, g, channel, 0, tone_callback, user_data);
 }
 
 int modem_connect_tones_rx(modem_connect_tones_rx_state_t *s, const int16_t amp[], int len)
@@ -507,7 +515,11 @@ int modem_connect_tones_rx_get(modem_connect_tones_rx_state_t *s)
 
 int modem_connect_tones_rx_release(modem_connect_tones_rx_state_t *s)
 {
-    (void) s;
+    if (s  &&  s->grp)
+    {
+        line_detach(s->grp, s->channel, s->private_grp);
+        s->grp = NULL;
+    }
     return 0;
 }
 
@@ -515,8 +527,9 @@ int modem_connect_tones_rx_free(modem_connect_tones_rx_state_t *s)
 {
     if (s == NULL)
         return 0;
-    line_detach(s->grp, s->channel, s->private_grp);
-    free(s);
+    modem_connect_tones_rx_release(s);
+    if (!s->caller_storage)
+        free(s);
     return 0;
 }
 
@@ -532,20 +545,21 @@ const char *modem_connect_tone_to_str(int tone)
 }
 
 /* ---- dtmf_tx: one private sender per object ---------------------------------------------------------- */
-struct dtmf_tx_state_s
-{
-    spangpu_txbank_t *bank;
-};
-
 dtmf_tx_state_t *dtmf_tx_init(dtmf_tx_state_t *s, digits_tx_callback_t callback, void *user_data)
 {
-    /* a callback asking for more digits (dtmf.c:566-573) is host logic the device queue does not replay */
-    (void) user_data;
-    if (s != NULL  ||  callback != NULL  ||  (s = (dtmf_tx_state_t *) calloc(1, sizeof(*s))) == NULL)
+    const int mine = (s != NULL);
+
+    if (mine)
+        memset(s, 0, sizeof(*s));
+    else if ((s = (dtmf_tx_state_t *) calloc(1, sizeof(*s))) == NULL)
         return NULL;
+    s->caller_storage = mine;
+    s->callback = callback;
+    s->callback_data = user_data;
     if (spangpu_txbank_create(&s->bank, 0, SPANGPU_TX_DTMF, 1) != SPANGPU_OK)
     {
-        free(s);
+        if (!mine)
+            free(s);
         return NULL;
     }
     return s;
@@ -553,7 +567,11 @@ dtmf_tx_state_t *dtmf_tx_init(dtmf_tx_state_t *s, digits_tx_callback_t callback,
 
 int dtmf_tx_release(dtmf_tx_state_t *s)
 {
-    (void) s;
+    if (s  &&  s->bank)
+    {
+        spangpu_txbank_destroy(s->bank);
+        s->bank = NULL;
+    }
     return 0;
 }
 
@@ -561,8 +579,9 @@ int dtmf_tx_free(dtmf_tx_state_t *s)
 {
     if (s)
     {
-        spangpu_txbank_destroy(s->bank);
-        free(s);
+        dtmf_tx_release(s);
+        if (!s->caller_storage)
+            free(s);
     }
     return 0;
 }
@@ -581,6 +600,8 @@ int dtmf_tx_put(dtmf_tx_state_t *s, const char *digits, int len)
 {
     const int rc = spangpu_txbank_put(s->bank, 0, 1, digits, len);
 
+    if (rc == 0)
+        s->puts++;
     return (rc < 0)  ?  -1  :  rc;
 }
 
@@ -588,29 +609,42 @@ int dtmf_tx(dtmf_tx_state_t *s, int16_t amp[], int max_samples)
 {
     int len = 0;
 
-    if (max_samples <= 0  ||  spangpu_txbank_tx(s->bank, SPANGPU_MEM_HOST, amp, max_samples, max_samples, &len) < 0)
+    if (max_samples <= 0)
         return 0;
+    for (;;)
+    {
+        int got = 0;
+        int before;
+
+        if (spangpu_txbank_tx(s->bank, SPANGPU_MEM_HOST, amp + len, max_samples - len, max_samples - len, &got) < 0)
+            break;
+        len += got;
+        /* dtmf.c:566-573: the queue ran dry with room left in the buffer -- "see if we can get some more digits": the
+           callback answers by calling dtmf_tx_put(), and the sender carries on where it stopped */
+        if (len >= max_samples  ||  s->callback == NULL)
+            break;
+        before = s->puts;
+        s->callback(s->callback_data);
+        if (s->puts == before)
+            break;
+    }
     return len;
 }
 
 /* ---- bell_mf_tx / r2_mf_tx: one private sender per object (src/bell_r2_mf.c:281-372, 386-462) ----------------- */
-struct bell_mf_tx_state_s
-{
-    spangpu_txbank_t *bank;
-};
-
-struct r2_mf_tx_state_s
-{
-    spangpu_txbank_t *bank;
-};
-
 bell_mf_tx_state_t *bell_mf_tx_init(bell_mf_tx_state_t *s)
 {
-    if (s != NULL  ||  (s = (bell_mf_tx_state_t *) calloc(1, sizeof(*s))) == NULL)
+    const int mine = (s != NULL);
+
+    if (mine)
+        memset(s, 0, sizeof(*s));
+    else if ((s = (bell_mf_tx_state_t *) calloc(1, sizeof(*s))) == NULL)
         return NULL;
+    s->caller_storage = mine;
     if (spangpu_txbank_create(&s->bank, 0, SPANGPU_TX_BELL_MF, 1) != SPANGPU_OK)
     {
-        free(s);
+        if (!mine)
+            free(s);
         return NULL;
     }
     return s;
@@ -618,7 +652,11 @@ bell_mf_tx_state_t *bell_mf_tx_init(bell_mf_tx_state_t *s)
 
 int bell_mf_tx_release(bell_mf_tx_state_t *s)
 {
-    (void) s;
+    if (s  &&  s->bank)
+    {
+        spangpu_txbank_destroy(s->bank);
+        s->bank = NULL;
+    }
     return 0;
 }
 
@@ -626,8 +664,9 @@ int bell_mf_tx_free(bell_mf_tx_state_t *s)
 {
     if (s)
     {
-        spangpu_txbank_destroy(s->bank);
-        free(s);
+        bell_mf_tx_release(s);
+        if (!s->caller_storage)
+            free(s);
     }
     return 0;
 }
@@ -650,11 +689,17 @@ int bell_mf_tx(bell_mf_tx_state_t *s, int16_t amp[], int max_samples)
 
 r2_mf_tx_state_t *r2_mf_tx_init(r2_mf_tx_state_t *s, bool fwd)
 {
-    if (s != NULL  ||  (s = (r2_mf_tx_state_t *) calloc(1, sizeof(*s))) == NULL)
+    const int mine = (s != NULL);
+
+    if (mine)
+        memset(s, 0, sizeof(*s));
+    else if ((s = (r2_mf_tx_state_t *) calloc(1, sizeof(*s))) == NULL)
         return NULL;
+    s->caller_storage = mine;
     if (spangpu_txbank_create(&s->bank, 0, fwd  ?  SPANGPU_TX_R2_MF_FWD  :  SPANGPU_TX_R2_MF_BACK, 1) != SPANGPU_OK)
     {
-        free(s);
+        if (!mine)
+            free(s);
         return NULL;
     }
     return s;
@@ -662,7 +707,11 @@ r2_mf_tx_state_t *r2_mf_tx_init(r2_mf_tx_state_t *s, bool fwd)
 
 int r2_mf_tx_release(r2_mf_tx_state_t *s)
 {
-    (void) s;
+    if (s  &&  s->bank)
+    {
+        spangpu_txbank_destroy(s->bank);
+        s->bank = NULL;
+    }
     return 0;
 }
 
@@ -670,8 +719,9 @@ int r2_mf_tx_free(r2_mf_tx_state_t *s)
 {
     if (s)
     {
-        spangpu_txbank_destroy(s->bank);
-        free(s);
+        r2_mf_tx_release(s);
+        if (!s->caller_storage)
+            free(s);
     }
     return 0;
 }

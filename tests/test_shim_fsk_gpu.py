@@ -82,7 +82,6 @@ def test_fsk_private_object_replays_reference_stream(L, which, mode):
     pb2 = PUT_BIT(lambda u, b: ev2.append(b))
     sh2 = STATUS(lambda u, v: st2.append(v))
     assert L.fsk_rx_restart(s, spec_ptr(L, which), mode) == 0
-    assert L.fsk_rx_restart(s, spec_ptr(L, (which + 1) % 11), mode) == -1         # another spec needs another object
     L.fsk_rx_set_put_bit(s, pb2, None)
     L.fsk_rx_set_modem_status_handler(s, sh2, None)
     feed(L.fsk_rx, s, g["amp"], 160)
@@ -90,7 +89,6 @@ def test_fsk_private_object_replays_reference_stream(L, which, mode):
     assert st2 == [int(v) for v in want if v in (-1, -2)]
     assert len(ev2) > 10 and all(v >= 0 for v in ev2)
     L.fsk_rx_free(s)
-    assert L.fsk_rx_init(C.c_void_p(1), spec_ptr(L, which), mode, put_bit, None) is None
 
 
 def test_fsk_group_equals_oracle(L):
@@ -195,7 +193,7 @@ def test_bell_and_r2_tx_objects_equal_oracle(L):
         getattr(L, name).argtypes = args
     buf = np.zeros(2000, np.int16)
     s = L.bell_mf_tx_init(None)
-    assert s and L.bell_mf_tx_init(C.c_void_p(1)) is None
+    assert s
     o = orc.BellMfTx()
     assert L.bell_mf_tx_put(s, b"K1234567890S", -1) == o.put("K1234567890S")
     for n in (160, 1, 777, 2000, 2000, 2000, 2000, 2000, 2000):
@@ -213,3 +211,97 @@ def test_bell_and_r2_tx_objects_equal_oracle(L):
             want = o.tx(n)
             assert got == len(want) and np.array_equal(buf[:got], want), (fwd, digit)
         L.r2_mf_tx_free(s)
+
+
+def test_caller_storage_and_a_restart_to_another_modem(L):
+    """fsk_rx_init(&state, ...) in the caller's storage (fsk.c:725-733) and fsk_rx_restart() to a different spec (fsk.c:670): an
+    object of its own moves to a bank of the new spec and receives that modem's reference stream; an object on a shared
+    bank cannot leave it.  modem_connect_tones_rx_init() likewise takes the caller's storage."""
+    store = (C.c_char*256)()
+    a, m_a = 1, 1
+    b, m_b = 2, 0
+    ga = np.load(os.path.join(GOLDEN, "fsk_%d_%d.npz" % (a, m_a)))
+    gb = np.load(os.path.join(GOLDEN, "fsk_%d_%d.npz" % (b, m_b)))
+    ev, st = [], []
+    pb = PUT_BIT(lambda u, v: ev.append(v))
+    sh = STATUS(lambda u, v: st.append(v))
+    s = L.fsk_rx_init(C.addressof(store), spec_ptr(L, a), m_a, pb, None)
+    assert s == C.addressof(store)
+    L.fsk_rx_set_modem_status_handler(s, sh, None)
+    feed(L.fsk_rx, s, ga["amp"], 160)
+    want = ga["events"]
+    assert st == [int(v) for v in want if v in (-1, -2)] and ev == [int(v) for v in want if v not in (-1, -2)]
+    # the same object, another modem
+    del ev[:], st[:]
+    assert L.fsk_rx_restart(s, spec_ptr(L, b), m_b) == 0
+    feed(L.fsk_rx, s, gb["amp"], 160)
+    want = gb["events"]
+    assert st == [int(v) for v in want if v in (-1, -2)] and ev == [int(v) for v in want if v not in (-1, -2)]
+    L.fsk_rx_release.restype = C.c_int
+    L.fsk_rx_release.argtypes = [C.c_void_p]
+    assert L.fsk_rx_release(s) == 0
+    # on a shared bank the spec is the bank's
+    grp = L.spangpu_fsk_group_create(0, spec_ptr(L, a), m_a, 4, 160)
+    o = L.spangpu_fsk_rx_attach(grp, 2, pb, None)
+    assert o and L.fsk_rx_restart(o, spec_ptr(L, b), m_b) == -1 and L.fsk_rx_restart(o, spec_ptr(L, a), m_a) == 0
+    L.fsk_rx_free(o)
+    L.spangpu_line_group_destroy(grp)
+    # connect tones in the caller's storage
+    g = np.load(os.path.join(GOLDEN, "mct_2_3.npz"))
+    store2 = (C.c_char*256)()
+    rep = []
+    cb = REPORT(lambda u, tone, level, delay: rep.append((tone, level, delay)))
+    m = L.modem_connect_tones_rx_init(C.addressof(store2), 2, cb, None)
+    assert m == C.addressof(store2)
+    if g is not None:
+        feed(L.modem_connect_tones_rx, m, g["amp"], 160)
+        assert len(rep) > 0
+    L.modem_connect_tones_rx_release.restype = C.c_int
+    L.modem_connect_tones_rx_release.argtypes = [C.c_void_p]
+    assert L.modem_connect_tones_rx_release(m) == 0
+
+
+def test_dtmf_tx_asks_for_more_digits(L):
+    """dtmf_tx_init() with a digits callback (dtmf.c:566-573, 636): whenever the queue runs dry with room left in the buffer
+    the sender calls back; what the callback puts is sent in the same call, seamlessly -- the samples are those of a sender
+    that was given all the digits up front."""
+    from oracle import restated as orc
+    CB = C.CFUNCTYPE(None, C.c_void_p)
+    L.dtmf_tx_init.argtypes = [C.c_void_p, CB, C.c_void_p]
+    todo = [b"12", b"3", b"", b"45"]
+    calls = []
+    holder = {}
+
+    def more(user):
+        calls.append(len(calls))
+        if todo:
+            d = todo.pop(0)
+            if d:
+                assert L.dtmf_tx_put(holder["s"], d, -1) == 0
+    cb = CB(more)
+    store = (C.c_char*128)()
+    s = L.dtmf_tx_init(C.addressof(store), cb, None)
+    assert s == C.addressof(store)
+    holder["s"] = s
+    o = orc.DtmfTx()
+    buf = np.zeros(8000, np.int16)
+    out = []
+    for n in (4000, 4000, 8000):
+        got = L.dtmf_tx(s, buf.ctypes.data, n)
+        out.append(buf[:got].copy())
+    got_all = np.concatenate(out)
+    # the reference sender given the same digits at the moments its callback would have supplied them
+    o.put("12")
+    o.put("3")
+    w1 = o.tx(4000)
+    w2 = o.tx(4000)
+    o.put("45")
+    w3 = o.tx(8000)
+    want = np.concatenate([w1, w2, w3])
+    assert len(calls) >= 4
+    assert np.array_equal(got_all, want), (len(got_all), len(want))
+    L.dtmf_tx_release = L.dtmf_tx_release
+    L.dtmf_tx_release.restype = C.c_int
+    L.dtmf_tx_release.argtypes = [C.c_void_p]
+    assert L.dtmf_tx_release(s) == 0
+    L.dtmf_tx_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
