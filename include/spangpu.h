@@ -538,6 +538,10 @@ SPANGPU_API int spangpu_fsk_rx(spangpu_fsk_t *fsk, const int16_t *amp, int mem, 
 SPANGPU_API int spangpu_fsk_rx_var(spangpu_fsk_t *fsk, const int16_t *amp, int mem, const int32_t *lens, int max_samples, long long stride);
 /* events[channel*cap + i], i < counts[channel]; returns cap.  Valid until the next call on this bank. */
 SPANGPU_API int spangpu_fsk_events(spangpu_fsk_t *fsk, const int16_t **events, const int32_t **counts);
+/* Tuning / A-B testing: how many wavefronts work on 64 receivers (FSK banks, connect-tone banks and signalling-tone
+   receiver banks made or run from now on): 0 = the library's choice, 1 = the whole receiver in one lane of one wavefront,
+   2 = the receiver cut into two instruction streams on two wavefronts (fsk_dev.hpp).  Results are identical. */
+SPANGPU_API int spangpu_tune_fsk_waves(int waves);
 SPANGPU_API int spangpu_fsk_state_words(const spangpu_fsk_t *fsk);
 SPANGPU_API int spangpu_fsk_get_state(spangpu_fsk_t *fsk, int channel, int32_t *words);
 SPANGPU_API int spangpu_fsk_set_state(spangpu_fsk_t *fsk, int channel, const int32_t *words);

@@ -35,15 +35,14 @@ namespace spg
 __global__ __launch_bounds__(64) void fsk_bank_kernel(const FskLaunch L)
 {
     extern __shared__ int32_t win[];        // [4*span][64]
-    __shared__ int16_t quarter[260];        // [257]; a separate object, so that table reads can move across window writes
+    __shared__ uint32_t wave[kFskWave];     // a separate object, so that table reads can move across window writes
     const int lane = threadIdx.x;
     const int ch = blockIdx.x*64 + lane;
     const bool live = ch < L.n_ch;
     const size_t n = (size_t) L.n_ch;
     const int span = L.span;
 
-    for (int i = lane;  i < 257;  i += 64)
-        quarter[i] = L.quarter[i];
+    fsk_fill_wave(wave, L.quarter, lane, 64);
     // (a lane past the end of the bank reads channel 0's words and stops after the barrier)
     int32_t *st = L.st + (live  ?  ch  :  0);
     fsk_load_window(win, st + (size_t) kFskScalars*n, n, span, lane);
@@ -55,37 +54,159 @@ __global__ __launch_bounds__(64) void fsk_bank_kernel(const FskLaunch L)
     fsk_load_regs(r, st, n);
     int16_t *ev = L.events + (size_t) ch*L.ev_cap;
     const int ev_cap = L.ev_cap;
-    auto emit = [&](int v)
+    auto emit = [&](int v) __attribute__((always_inline))
     {
         if (r.n_ev < ev_cap)
             ev[r.n_ev] = (int16_t) v;
         r.n_ev++;
     };
-    const int16_t *row = L.pcm + (size_t) ch*L.stride;
     const int mylen = L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;
-    for (int base = 0;  base < L.samples;  base += 8)
+    auto frame = [&](auto aligned, auto framed) __attribute__((always_inline))
     {
-        const int todo = max(0, min(8, mylen - base));          // per lane when the call carries per-channel lengths
-        int32_t a[8];
-        int32_t c0[8];
-        int32_t q0[8];
-        int32_t c1[8];
-        int32_t q1[8];
-        fsk_block_samples(row, base, todo, L.vec != 0, a);
-        fsk_block_lookups(r, quarter, todo, c0, q0, c1, q1);
-#pragma unroll
-        for (int k = 0;  k < 8;  k++)
+        FskRow<decltype(aligned)::value> row;
+        fsk_row_begin(row, L.pcm + (size_t) ch*L.stride, mylen);
+        for (int base = 0;  base < L.samples;  base += 8)
         {
-            if (k < todo)
-                fsk_step(r, win, lane, span, a[k], c0[k], q0[k], c1[k], q1[k], emit);
+            const int todo = max(0, min(8, mylen - base));      // per lane when the call carries per-channel lengths
+            int32_t a[8];
+            int32_t c0[8];
+            int32_t q0[8];
+            int32_t c1[8];
+            int32_t q1[8];
+            fsk_row_block(row, base, todo, a);
+            fsk_block_lookups(r, wave, todo, c0, q0, c1, q1);
+            // (a whole block in every lane is the common case: no per-sample guard, whose bodies the compiler moves out of line)
+            if (__builtin_expect(__all(todo == 8), 1))
+            {
+#pragma unroll
+                for (int k = 0;  k < 8;  k++)
+                    fsk_step<decltype(framed)::value>(r, win, lane, span, a[k], c0[k], q0[k], c1[k], q1[k], emit);
+            }
+            else
+            {
+#pragma unroll
+                for (int k = 0;  k < 8;  k++)
+                {
+                    if (k < todo)
+                        fsk_step<true>(r, win, lane, span, a[k], c0[k], q0[k], c1[k], q1[k], emit);
+                }
+            }
         }
-    }
+    };
+    // (unaligned rows are the rare case: one copy, the general one)
+    if (!L.vec)
+        frame(std::false_type{}, std::true_type{});
+    else if (__any(r.framing == 2))
+        frame(std::true_type{}, std::true_type{});
+    else
+        frame(std::true_type{}, std::false_type{});
     fsk_store_regs(r, st, n);
     fsk_store_window(win, st + (size_t) kFskScalars*n, n, span, lane);
     L.ev_count[ch] = r.n_ev;
 }
 
+// The same receiver as two waves per 64 channels (fsk_dev.hpp, "A receiver over two waves"): wave 0 is the signal
+// side, wave 1 the bit side, one block behind.
+__global__ __launch_bounds__(128) void fsk_pair_kernel(const FskLaunch L)
+{
+    extern __shared__ int32_t win[];        // [4*span][64], then the two message buffers [2][kFskMsgWords][64]
+    __shared__ uint32_t wave[kFskWave];
+    const int lane = threadIdx.x & 63;
+    const int side = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int ch = blockIdx.x*64 + lane;
+    const bool live = ch < L.n_ch;
+    const size_t n = (size_t) L.n_ch;
+    const int span = L.span;
+    int32_t *msg = win + 4*span*64;
+
+    fsk_fill_wave(wave, L.quarter, threadIdx.x, 128);
+    int32_t *st = L.st + (live  ?  ch  :  0);
+    fsk_load_window_half(win, st + (size_t) kFskScalars*n, n, span, lane, side);
+    __syncthreads();
+
+    const int mylen = !live  ?  0  :  L.lens  ?  min(max(L.lens[ch], 0), L.samples)  :  L.samples;
+    const int n_blk = (L.samples + 7) >> 3;
+    const int16_t *pcm_row = L.pcm + (size_t) (live  ?  ch  :  0)*L.stride;
+    if (side == 0)
+    {
+        FskSigSide s;
+        fsk_sig_load(s, st, n);
+        auto frame = [&](auto aligned) __attribute__((always_inline))
+        {
+            FskRow<decltype(aligned)::value> row;
+            fsk_row_begin(row, pcm_row, mylen);
+            for (int blk = 0;  blk <= n_blk;  blk++)
+            {
+                if (blk < n_blk)
+                    fsk_sig_block(s, win, wave, msg + (blk & 1)*kFskMsgWords*64, lane, span, row, blk*8, max(0, min(8, mylen - blk*8)));
+                __syncthreads();
+            }
+        };
+        if (L.vec)
+            frame(std::true_type{});
+        else
+            frame(std::false_type{});
+        if (live)
+            fsk_sig_store(s, st, n);
+    }
+    else
+    {
+        FskBitSide t;
+        fsk_bit_load(t, st, n);
+        int16_t *ev = L.events + (size_t) (live  ?  ch  :  0)*L.ev_cap;
+        const int ev_cap = L.ev_cap;
+        auto emit = [&](int v) __attribute__((always_inline))
+        {
+            if (t.n_ev < ev_cap)
+                ev[t.n_ev] = (int16_t) v;
+            t.n_ev++;
+        };
+        auto frame = [&](auto aligned, auto framed) __attribute__((always_inline))
+        {
+            FskRow<decltype(aligned)::value> row;
+            fsk_row_begin(row, pcm_row, mylen);
+            for (int blk = 0;  blk <= n_blk;  blk++)
+            {
+                if (blk > 0)
+                    fsk_bit_block<decltype(aligned)::value, decltype(framed)::value>(t, win, wave, msg + ((blk - 1) & 1)*kFskMsgWords*64, lane, span, row, (blk - 1)*8,
+                                  max(0, min(8, mylen - (blk - 1)*8)), emit);
+                __syncthreads();
+            }
+        };
+        if (!L.vec)
+            frame(std::false_type{}, std::true_type{});
+        else if (__any(live  &&  t.b.framing == 2))
+            frame(std::true_type{}, std::true_type{});
+        else
+            frame(std::true_type{}, std::false_type{});
+        if (live)
+        {
+            fsk_bit_store(t, st, n);
+            L.ev_count[ch] = t.n_ev;
+        }
+    }
+    if (live)
+        fsk_store_window_half(win, st + (size_t) kFskScalars*n, n, span, lane, side);
+}
+
 }   // namespace spg
+
+// 0 = the library's choice (two waves per 64 channels), 1 = the whole receiver in one wave, 2 = two waves
+static int g_fsk_waves = 0;
+
+extern "C" int spangpu_tune_fsk_waves(int waves)
+{
+    if (waves < 0  ||  waves > 2)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "0 (the library's choice), 1 or 2 waves per 64 channels");
+    g_fsk_waves = waves;
+    return SPANGPU_OK;
+}
+
+// (for the other bank families the knob covers; not part of the ABI)
+extern "C" __attribute__((visibility("hidden"))) int spangpu_fsk_waves_choice(void)
+{
+    return g_fsk_waves;
+}
 
 struct spangpu_fsk_s
 {
@@ -391,7 +512,10 @@ int spangpu_fsk_rx(spangpu_fsk_t *f, const int16_t *amp, int mem_kind, int sampl
     }
     L.vec = ((L.stride & 7) == 0  &&  (reinterpret_cast<uintptr_t>(L.pcm) & 15) == 0)  ?  1  :  0;
     const size_t lds = (size_t) (4*f->span*64)*sizeof(int32_t);
-    hipLaunchKernelGGL(fsk_bank_kernel, dim3((f->n_ch + 63)/64), dim3(64), lds, f->stream, L);
+    if (g_fsk_waves != 1)
+        hipLaunchKernelGGL(fsk_pair_kernel, dim3((f->n_ch + 63)/64), dim3(128), lds + 2*kFskMsgWords*64*sizeof(int32_t), f->stream, L);
+    else
+        hipLaunchKernelGGL(fsk_bank_kernel, dim3((f->n_ch + 63)/64), dim3(64), lds, f->stream, L);
     FSK_TRY(hipGetLastError());
     f->last_cap = f->ev_cap;
     return SPANGPU_OK;

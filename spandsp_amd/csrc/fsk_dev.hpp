@@ -19,6 +19,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace spg
 {
@@ -96,6 +97,30 @@ __device__ __forceinline__ int32_t fsk_lookup(const int16_t *quarter, uint32_t p
     return (p & 512u)  ?  -amp  :  amp;
 }
 
+// The kernels look the oscillators up in the same sine unfolded over the whole circle, with the cosine beside it:
+// wave[p] = sin(p) in the low half, sin(p + 256) = cos(p) in the high half, p = phase >> 22 (dds_complexi() takes
+// the cosine at phase + 2^30, which is p + 256 with no carry from below).  One LDS read and a shift per oscillator
+// and sample where the quadrant logic was eight instructions a value; 4 KB per workgroup, filled from the quarter
+// wave in HBM at the start of a launch.
+constexpr int kFskWave = 1024;
+
+__device__ __forceinline__ void fsk_fill_wave(uint32_t *wave, const int16_t *quarter_hbm, int tid, int n_threads)
+{
+    for (int p = tid;  p < kFskWave;  p += n_threads)
+    {
+        const uint32_t sn = (uint32_t) fsk_lookup(quarter_hbm, (uint32_t) p << 22) & 0xFFFFu;
+        const uint32_t cs = (uint32_t) fsk_lookup(quarter_hbm, (uint32_t) ((p + 256) & 1023) << 22) & 0xFFFFu;
+        wave[p] = sn | (cs << 16);
+    }
+}
+
+__device__ __forceinline__ void fsk_cos_sin(const uint32_t *wave, uint32_t phase, int32_t &c, int32_t &q)
+{
+    const uint32_t w = wave[phase >> 22];
+    c = (int32_t) w >> 16;
+    q = (int32_t) (int16_t) (w & 0xFFFFu);
+}
+
 __device__ __forceinline__ void fsk_load_regs(FskRegs &r, const int32_t *st, size_t n)
 {
     r.baud_rate = st[FS_BAUD_RATE*n];
@@ -171,70 +196,109 @@ __device__ __forceinline__ void fsk_store_window(const int32_t *win, int32_t *st
         st_win[(size_t) w*n] = win[w*64 + lane];
 }
 
-// One sample of fsk_rx(), fsk.c:408-618; (c0, q0) and (c1, q1) are the two oscillators' cos / sin for this
-// sample.  emit(v) stands for put_bit(v).  Returns without advancing the window slot where the reference
-// `continue`s.
-template <class Emit>
-__device__ __forceinline__ void fsk_step(FskRegs &r, int32_t *win, int lane, int span, int32_t a, int32_t c0, int32_t q0,
-                                         int32_t c1, int32_t q1, Emit &&emit)
+// One tone's correlator for one sample, fsk.c:411-423: the product enters the sliding window, the one it
+// replaces leaves the running sum; returns |dot|^2 on the scale the comparison uses.  `slot` points at the
+// window word of this lane's current slot for this tone (re; im is 64 words on).
+__device__ __forceinline__ int32_t fsk_correlate(int32_t &dotre, int32_t &dotim, int32_t *slot, int32_t a, int32_t c, int32_t q, int32_t shift)
 {
-    int32_t *slot = win + (r.ptr*4)*64 + lane;
-    int32_t sum0;
-    int32_t sum1;
-    {
-        const int32_t c = c0;
-        const int32_t q = q0;
-        const int32_t nre = __mul24(c, a) >> r.shift;        // 16 bit x 16 bit
-        const int32_t nim = __mul24(q, a) >> r.shift;
-        r.dot0re += nre - slot[0];
-        r.dot0im += nim - slot[64];
-        slot[0] = nre;
-        slot[64] = nim;
-        const int32_t dr = r.dot0re >> 15;
-        const int32_t di = r.dot0im >> 15;
-        sum0 = __mul24(dr, dr) + __mul24(di, di);       // |dot| < 2^30 (span values of < 2^30/2^shift), so 24 bit multiplies are exact
-    }
-    {
-        const int32_t c = c1;
-        const int32_t q = q1;
-        const int32_t nre = __mul24(c, a) >> r.shift;        // 16 bit x 16 bit
-        const int32_t nim = __mul24(q, a) >> r.shift;
-        r.dot1re += nre - slot[128];
-        r.dot1im += nim - slot[192];
-        slot[128] = nre;
-        slot[192] = nim;
-        const int32_t dr = r.dot1re >> 15;
-        const int32_t di = r.dot1im >> 15;
-        sum1 = __mul24(dr, dr) + __mul24(di, di);
-    }
-    // power behind a one-tap DC blocker, fsk.c:425-431
+    const int32_t nre = __mul24(c, a) >> shift;         // 16 bit x 16 bit
+    const int32_t nim = __mul24(q, a) >> shift;
+    dotre += nre - slot[0];
+    dotim += nim - slot[64];
+    slot[0] = nre;
+    slot[64] = nim;
+    const int32_t dr = dotre >> 15;
+    const int32_t di = dotim >> 15;
+    return __mul24(dr, dr) + __mul24(di, di);           // |dot| < 2^30 (span values of < 2^30/2^shift), so 24 bit multiplies are exact
+}
+
+// What the carrier detector made of a sample (fsk.c:425-475).  DROP, QUIET and COUNTING are the three places
+// the reference `continue`s (the window slot stays where it is); RISE goes on to the bit clock.
+enum
+{
+    FSK_KIND_NORMAL = 0,
+    FSK_KIND_DROP = 1,          // SIG_STATUS_CARRIER_DOWN
+    FSK_KIND_QUIET = 2,
+    FSK_KIND_COUNTING = 3,
+    FSK_KIND_RISE = 4,          // SIG_STATUS_CARRIER_UP
+    FSK_KIND_NONE = 5           // no sample (past the end of this channel's frame)
+};
+
+// Power behind a one-tap DC blocker and the carrier detector, as selects (the branches are data dependent per
+// lane and nearly all of them just move a counter).  `count_phase` is baud_phase in its role as the counter of
+// the samples a returning carrier has lasted (it is only read while no carrier is present).
+__device__ __forceinline__ int fsk_carrier(int32_t &power, int32_t &last_sample, int32_t &signal_present, int32_t &count_phase,
+                                           int32_t on_power, int32_t off_power, int span, int32_t a)
+{
     const int32_t x = a >> 1;
-    const int32_t diff = (int32_t) (int16_t) (x - r.last_sample);
-    r.power += (__mul24(diff, diff) - r.power) >> 4;
-    r.last_sample = x;
-    // Carrier detect, fsk.c:433-475, as selects (the branches are data dependent per lane and nearly all of
-    // them just move a counter).  drop / quiet / counting are the three places the reference `continue`s.
-    const bool present = (r.signal_present != 0);
-    const bool low_off = (r.power < r.off_power);
-    const bool low_on = (r.power < r.on_power);
+    const int32_t diff = (int32_t) (int16_t) (x - last_sample);
+    power += (__mul24(diff, diff) - power) >> 4;
+    last_sample = x;
+    const bool present = (signal_present != 0);
+    const bool low_off = (power < off_power);
+    const bool low_on = (power < on_power);
     const bool dec = present  &&  low_off;
-    const int32_t sp1 = r.signal_present - 1;
+    const int32_t sp1 = signal_present - 1;
     const bool drop = dec  &&  (sp1 <= 0);
     const bool quiet = !present  &&  low_on;
-    const bool counting = !present  &&  !low_on  &&  (r.baud_phase < (span >> 1) - 30);
+    const bool counting = !present  &&  !low_on  &&  (count_phase < (span >> 1) - 30);
     const bool rise = !present  &&  !low_on  &&  !counting;
-    r.signal_present = dec  ?  sp1  :  (rise  ?  1  :  r.signal_present);
+    signal_present = dec  ?  sp1  :  (rise  ?  1  :  signal_present);
+    count_phase = (drop  ||  quiet  ||  rise)  ?  0  :  (counting  ?  (count_phase + 1)  :  count_phase);
+    int kind = FSK_KIND_NORMAL;
+    kind = drop  ?  FSK_KIND_DROP  :  kind;
+    kind = quiet  ?  FSK_KIND_QUIET  :  kind;
+    kind = counting  ?  FSK_KIND_COUNTING  :  kind;
+    kind = rise  ?  FSK_KIND_RISE  :  kind;
+    return kind;
+}
+
+struct FskBits
+{
+    int32_t frame_pos, frame, baud_phase, last_bit;
+    int32_t baud_rate, framing, parity, total_bits, parity_err, framing_err;
+};
+
+// The carrier detector's effect on the bit clock's words, then -- for the samples that get that far -- the bit
+// clock and the framing, fsk.c:476-614.  Returns false where the reference `continue`s.
+//
+// FRAMED = false is the copy for a wave none of whose channels frames characters (bit-synchronous and asynchronous
+// receivers): a sample is straight-line code there but for the rare events, which sit out of line.  A lone wave pays
+// every taken branch with an empty instruction buffer, and the framing tree is a dozen of them per sample even when
+// no lane enters it.
+template <bool FRAMED, class Emit>
+__device__ __forceinline__ bool fsk_bits(FskBits &r, int kind, int state, Emit &&emit)
+{
+    const bool drop = (kind == FSK_KIND_DROP);
+    const bool quiet = (kind == FSK_KIND_QUIET);
+    const bool counting = (kind == FSK_KIND_COUNTING);
+    const bool rise = (kind == FSK_KIND_RISE);
     r.baud_phase = (drop  ||  quiet  ||  rise)  ?  0  :  (counting  ?  (r.baud_phase + 1)  :  r.baud_phase);
     r.frame_pos = rise  ?  -2  :  r.frame_pos;
     r.frame = rise  ?  0  :  r.frame;
     r.last_bit = rise  ?  0  :  r.last_bit;
-    if (drop)
+    if (__builtin_expect(drop, 0))
         emit(-1);                               // SIG_STATUS_CARRIER_DOWN
-    if (rise)
+    if (__builtin_expect(rise, 0))
         emit(-2);                               // SIG_STATUS_CARRIER_UP
+    if (!FRAMED)
+    {
+        // (the same arithmetic as the branch below, with a sample that stops here leaving every word as it is)
+        const bool go = !(drop  ||  quiet  ||  counting);
+        const bool change = (r.last_bit != state);
+        const int32_t eighth = r.baud_rate >> 3;
+        const int32_t nudged = r.baud_phase + ((r.baud_phase < kFskRateX100/2)  ?  eighth  :  -eighth);
+        const int32_t moved = (r.framing == 1)  ?  nudged  :  (kFskRateX100/2);
+        const int32_t bp = (change  ?  moved  :  r.baud_phase) + r.baud_rate;
+        const bool fire = (bp >= kFskRateX100);
+        r.last_bit = go  ?  state  :  r.last_bit;
+        r.baud_phase = go  ?  (fire  ?  (bp - kFskRateX100)  :  bp)  :  r.baud_phase;
+        if (__builtin_expect(go  &&  fire, 0))
+            emit(state);
+        return go;
+    }
     if (drop  ||  quiet  ||  counting)
-        return;
-    const int state = (sum0 < sum1)  ?  1  :  0;
+        return false;
     if (r.framing != 2)
     {
         // synchronous (fsk.c:489-512): a transition nudges the baud phase towards the middle of the baud;
@@ -247,7 +311,7 @@ __device__ __forceinline__ void fsk_step(FskRegs &r, int32_t *win, int lane, int
         const int32_t bp = (change  ?  moved  :  r.baud_phase) + r.baud_rate;
         const bool fire = (bp >= kFskRateX100);
         r.baud_phase = fire  ?  (bp - kFskRateX100)  :  bp;
-        if (fire)
+        if (__builtin_expect(fire, 0))
             emit(state);
     }
     else if (r.frame_pos == -2)
@@ -333,12 +397,36 @@ __device__ __forceinline__ void fsk_step(FskRegs &r, int32_t *win, int lane, int
             }
         }
     }
-    r.ptr = (r.ptr + 1 >= span)  ?  0  :  (r.ptr + 1);
+    return true;
+}
+
+// One sample of fsk_rx(), fsk.c:408-618, for the kernels that run a whole receiver in one lane; (c0, q0) and
+// (c1, q1) are the two oscillators' cos / sin for this sample.  emit(v) stands for put_bit(v).  Returns without
+// advancing the window slot where the reference `continue`s.
+template <bool FRAMED, class Emit>
+__device__ __forceinline__ void fsk_step(FskRegs &r, int32_t *win, int lane, int span, int32_t a, int32_t c0, int32_t q0,
+                                         int32_t c1, int32_t q1, Emit &&emit)
+{
+    int32_t *slot = win + (r.ptr*4)*64 + lane;
+    const int32_t sum0 = fsk_correlate(r.dot0re, r.dot0im, slot, a, c0, q0, r.shift);
+    const int32_t sum1 = fsk_correlate(r.dot1re, r.dot1im, slot + 128, a, c1, q1, r.shift);
+    int32_t count_phase = r.baud_phase;
+    const int kind = fsk_carrier(r.power, r.last_sample, r.signal_present, count_phase, r.on_power, r.off_power, span, a);
+    FskBits b = {r.frame_pos, r.frame, r.baud_phase, r.last_bit, r.baud_rate, r.framing, r.parity, r.total_bits, r.parity_err, r.framing_err};
+    const bool on = fsk_bits<FRAMED>(b, kind, (sum0 < sum1)  ?  1  :  0, emit);
+    r.frame_pos = b.frame_pos;
+    r.frame = b.frame;
+    r.baud_phase = b.baud_phase;
+    r.last_bit = b.last_bit;
+    r.parity_err = b.parity_err;
+    r.framing_err = b.framing_err;
+    const int32_t next = (r.ptr + 1 >= span)  ?  0  :  (r.ptr + 1);
+    r.ptr = on  ?  next  :  r.ptr;
 }
 
 // The look-ups of a block of up to eight samples, issued together ahead of the sample-serial part: the two
 // oscillators run on whatever the receiver does with a sample (dds_complexi() comes before any early out).
-__device__ __forceinline__ void fsk_block_lookups(FskRegs &r, const int16_t *quarter, int todo, int32_t (&c0)[8], int32_t (&q0)[8],
+__device__ __forceinline__ void fsk_block_lookups(FskRegs &r, const uint32_t *wave, int todo, int32_t (&c0)[8], int32_t (&q0)[8],
                                                   int32_t (&c1)[8], int32_t (&q1)[8])
 {
 #pragma unroll
@@ -346,21 +434,48 @@ __device__ __forceinline__ void fsk_block_lookups(FskRegs &r, const int16_t *qua
     {
         const uint32_t p0 = r.acc0 + (uint32_t) k*(uint32_t) r.rate0;
         const uint32_t p1 = r.acc1 + (uint32_t) k*(uint32_t) r.rate1;
-        c0[k] = fsk_lookup(quarter, p0 + (1u << 30));
-        q0[k] = fsk_lookup(quarter, p0);
-        c1[k] = fsk_lookup(quarter, p1 + (1u << 30));
-        q1[k] = fsk_lookup(quarter, p1);
+        fsk_cos_sin(wave, p0, c0[k], q0[k]);
+        fsk_cos_sin(wave, p1, c1[k], q1[k]);
     }
     r.acc0 += (uint32_t) todo*(uint32_t) r.rate0;
     r.acc1 += (uint32_t) todo*(uint32_t) r.rate1;
 }
 
-// Eight samples of a lane's row (fewer at the end of a frame; the rest read as 0 and are not used)
-__device__ __forceinline__ void fsk_block_samples(const int16_t *row, int base, int todo, bool vec, int32_t (&a)[8])
+// A lane's row of the frame, eight samples (one 16-byte load) at a time, the next eight requested before the current
+// ones are worked on: a wave has nothing else to do while a load is on its way (a bank of 65 536 channels is one or two
+// waves per SIMD), and twenty loads from HBM one after the other are a third of a launch.
+template <bool VEC>        // rows are 16 B aligned (a launch's property: the two cases are separate copies of the sample loop)
+struct FskRow
 {
-    if (vec  &&  todo == 8)
+    const int16_t *row;
+    int mylen;
+    uint4 q_next;
+};
+
+template <bool VEC>
+__device__ __forceinline__ void fsk_row_begin(FskRow<VEC> &w, const int16_t *row, int mylen)
+{
+    w.row = row;
+    w.mylen = mylen;
+    w.q_next = make_uint4(0u, 0u, 0u, 0u);
+    // every load of the prologue home first (vmcnt(0)): the counter is in order, so a state word still on its way at the
+    // top of the sample loop would have the compiler wait for *everything* there on every pass -- the next block included
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (VEC)
+        w.q_next = *reinterpret_cast<const uint4 *>(row);
+}
+
+// Samples base .. base + todo - 1 (todo <= 8; blocks are taken in order; what lies past todo is not used).  With aligned
+// rows every block is one aligned 16-byte load, also a frame's last, shorter one: it starts inside the row, so it cannot
+// leave the page the row's last sample is on.  No lane-dependent branch around the loads, and no other kind of load in
+// the same loop: the compiler waits for everything in flight where such paths join, which would put the wait for the
+// next block right behind its request.
+template <bool VEC>
+__device__ __forceinline__ void fsk_row_block(FskRow<VEC> &w, int base, int todo, int32_t (&a)[8])
+{
+    if (VEC)
     {
-        const uint4 q = *reinterpret_cast<const uint4 *>(row + base);
+        const uint4 q = w.q_next;
         a[0] = (int32_t) (int16_t) (q.x & 0xFFFFu);
         a[1] = (int32_t) q.x >> 16;
         a[2] = (int32_t) (int16_t) (q.y & 0xFFFFu);
@@ -369,12 +484,229 @@ __device__ __forceinline__ void fsk_block_samples(const int16_t *row, int base, 
         a[5] = (int32_t) q.z >> 16;
         a[6] = (int32_t) (int16_t) (q.w & 0xFFFFu);
         a[7] = (int32_t) q.w >> 16;
+        const int next = (base + 8 < w.mylen)  ?  (base + 8)  :  0;
+        w.q_next = *reinterpret_cast<const uint4 *>(w.row + next);
     }
     else
     {
 #pragma unroll
         for (int k = 0;  k < 8;  k++)
-            a[k] = (k < todo)  ?  (int32_t) row[base + k]  :  0;
+            a[k] = (k < todo)  ?  (int32_t) w.row[base + k]  :  0;
+    }
+}
+
+// ---- A receiver over two waves -----------------------------------------------------------------------------
+// A lone wave issues this kind of code (short dependent chains of selects, LDS reads, 24-bit products) at about
+// half the rate two waves reach together, and a bank of 65 536 channels is one wave per SIMD.  So the receiver
+// is cut into two instruction streams of about equal length that run as two waves of one workgroup on the same
+// 64 channels:
+//   the signal side   tone 0's oscillator and correlator, the power meter and the carrier detector;
+//   the bit side      tone 1's oscillator and correlator, the comparison, the bit clock, the framing, put_bit().
+// The carrier detector depends on the samples only, so the signal side never waits for the bit side.  It hands
+// over, per block of eight samples, what the detector made of each sample (a FSK_KIND_* nibble) and tone 0's
+// |dot|^2; the bit side follows one block behind (two message buffers in LDS, one barrier per block).  Each
+// side owns its half of every window slot and of the state words, in LDS and in HBM.
+
+constexpr int kFskMsgWords = 9;             // per lane and block: the kinds, then eight sums
+
+struct FskSigSide
+{
+    int32_t on_power, off_power, power, last_sample, signal_present, count_phase;
+    int32_t rate, dotre, dotim, ptr, shift;
+    uint32_t acc;
+};
+
+struct FskBitSide
+{
+    int32_t rate, dotre, dotim, ptr, shift;
+    uint32_t acc;
+    FskBits b;
+    int32_t n_ev;
+};
+
+// One side's half of the windows (tone = 0 or 1): words 4*slot + 2*tone + {0, 1}
+__device__ __forceinline__ void fsk_load_window_half(int32_t *win, const int32_t *st_win, size_t n, int span, int lane, int tone)
+{
+    for (int s0 = 0;  s0 < span;  s0 += 8)
+    {
+        int32_t t[16];
+#pragma unroll
+        for (int k = 0;  k < 16;  k++)
+        {
+            const int w = 4*(s0 + (k >> 1)) + 2*tone + (k & 1);
+            t[k] = st_win[(size_t) ((s0 + (k >> 1) < span)  ?  w  :  0)*n];
+        }
+#pragma unroll
+        for (int k = 0;  k < 16;  k++)
+        {
+            const int w = 4*(s0 + (k >> 1)) + 2*tone + (k & 1);
+            if (s0 + (k >> 1) < span)
+                win[w*64 + lane] = t[k];
+        }
+    }
+}
+
+__device__ __forceinline__ void fsk_store_window_half(const int32_t *win, int32_t *st_win, size_t n, int span, int lane, int tone)
+{
+    for (int s = 0;  s < span;  s++)
+    {
+        const int w = 4*s + 2*tone;
+        st_win[(size_t) w*n] = win[w*64 + lane];
+        st_win[(size_t) (w + 1)*n] = win[(w + 1)*64 + lane];
+    }
+}
+
+__device__ __forceinline__ void fsk_side_lookups(uint32_t &acc, int32_t rate, const uint32_t *wave, int todo, int32_t (&c)[8], int32_t (&q)[8])
+{
+#pragma unroll
+    for (int k = 0;  k < 8;  k++)
+    {
+        const uint32_t p = acc + (uint32_t) k*(uint32_t) rate;
+        fsk_cos_sin(wave, p, c[k], q[k]);
+    }
+    acc += (uint32_t) todo*(uint32_t) rate;
+}
+
+__device__ __forceinline__ void fsk_sig_load(FskSigSide &s, const int32_t *st, size_t n)
+{
+    s.on_power = st[FS_ON_POWER*n];
+    s.off_power = st[FS_OFF_POWER*n];
+    s.power = st[FS_POWER*n];
+    s.last_sample = st[FS_LAST_SAMPLE*n];
+    s.signal_present = st[FS_SIGNAL_PRESENT*n];
+    s.count_phase = st[FS_BAUD_PHASE*n];
+    s.rate = st[FS_RATE0*n];
+    s.acc = (uint32_t) st[FS_ACC0*n];
+    s.dotre = st[FS_DOT0RE*n];
+    s.dotim = st[FS_DOT0IM*n];
+    s.ptr = st[FS_BUF_PTR*n];
+    s.shift = st[FS_SHIFT*n];
+}
+
+__device__ __forceinline__ void fsk_sig_store(const FskSigSide &s, int32_t *st, size_t n)
+{
+    st[FS_POWER*n] = s.power;
+    st[FS_LAST_SAMPLE*n] = s.last_sample;
+    st[FS_SIGNAL_PRESENT*n] = s.signal_present;
+    st[FS_ACC0*n] = (int32_t) s.acc;
+    st[FS_DOT0RE*n] = s.dotre;
+    st[FS_DOT0IM*n] = s.dotim;
+    st[FS_BUF_PTR*n] = s.ptr;
+}
+
+__device__ __forceinline__ void fsk_bit_load(FskBitSide &t, const int32_t *st, size_t n)
+{
+    t.rate = st[FS_RATE1*n];
+    t.acc = (uint32_t) st[FS_ACC1*n];
+    t.dotre = st[FS_DOT1RE*n];
+    t.dotim = st[FS_DOT1IM*n];
+    t.ptr = st[FS_BUF_PTR*n];
+    t.shift = st[FS_SHIFT*n];
+    t.b.frame_pos = st[FS_FRAME_POS*n];
+    t.b.frame = st[FS_FRAME*n];
+    t.b.baud_phase = st[FS_BAUD_PHASE*n];
+    t.b.last_bit = st[FS_LAST_BIT*n];
+    t.b.baud_rate = st[FS_BAUD_RATE*n];
+    t.b.framing = st[FS_FRAMING*n];
+    t.b.parity = st[FS_PARITY*n];
+    t.b.total_bits = st[FS_TOTAL_BITS*n];
+    t.b.parity_err = st[FS_PARITY_ERR*n];
+    t.b.framing_err = st[FS_FRAMING_ERR*n];
+    t.n_ev = 0;
+}
+
+__device__ __forceinline__ void fsk_bit_store(const FskBitSide &t, int32_t *st, size_t n)
+{
+    st[FS_ACC1*n] = (int32_t) t.acc;
+    st[FS_DOT1RE*n] = t.dotre;
+    st[FS_DOT1IM*n] = t.dotim;
+    st[FS_FRAME_POS*n] = t.b.frame_pos;
+    st[FS_FRAME*n] = t.b.frame;
+    st[FS_BAUD_PHASE*n] = t.b.baud_phase;
+    st[FS_LAST_BIT*n] = t.b.last_bit;
+    st[FS_PARITY_ERR*n] = t.b.parity_err;
+    st[FS_FRAMING_ERR*n] = t.b.framing_err;
+}
+
+// The signal side's block: up to eight samples of the lane's row from `base`; msg = this block's message words
+template <bool VEC>
+__device__ __forceinline__ void fsk_sig_block(FskSigSide &s, int32_t *win, const uint32_t *wave, int32_t *msg, int lane, int span,
+                                              FskRow<VEC> &row, int base, int todo)
+{
+    int32_t a[8];
+    int32_t c[8];
+    int32_t q[8];
+    fsk_row_block(row, base, todo, a);
+    fsk_side_lookups(s.acc, s.rate, wave, todo, c, q);
+    uint32_t kinds = 0;
+    auto sample = [&](int k)
+    {
+        const int32_t sum = fsk_correlate(s.dotre, s.dotim, win + (s.ptr*4)*64 + lane, a[k], c[k], q[k], s.shift);
+        const int kind = fsk_carrier(s.power, s.last_sample, s.signal_present, s.count_phase, s.on_power, s.off_power, span, a[k]);
+        msg[(1 + k)*64 + lane] = sum;
+        const bool on = (kind == FSK_KIND_NORMAL  ||  kind == FSK_KIND_RISE);
+        const int32_t next = (s.ptr + 1 >= span)  ?  0  :  (s.ptr + 1);
+        s.ptr = on  ?  next  :  s.ptr;
+        kinds |= (uint32_t) kind << (4*k);
+    };
+    // (a whole block in every lane is the common case: no per-sample guard, whose bodies the compiler moves out of line)
+    if (__builtin_expect(__all(todo == 8), 1))
+    {
+#pragma unroll
+        for (int k = 0;  k < 8;  k++)
+            sample(k);
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0;  k < 8;  k++)
+        {
+            if (k < todo)
+                sample(k);
+            else
+                kinds |= (uint32_t) FSK_KIND_NONE << (4*k);
+        }
+    }
+    msg[lane] = (int32_t) kinds;
+}
+
+// The bit side's block, from the signal side's message for the same eight samples
+template <bool VEC, bool FRAMED, class Emit>
+__device__ __forceinline__ void fsk_bit_block(FskBitSide &t, int32_t *win, const uint32_t *wave, const int32_t *msg, int lane, int span,
+                                              FskRow<VEC> &row, int base, int todo, Emit &&emit)
+{
+    int32_t a[8];
+    int32_t c[8];
+    int32_t q[8];
+    fsk_row_block(row, base, todo, a);
+    fsk_side_lookups(t.acc, t.rate, wave, todo, c, q);
+    const uint32_t kinds = (uint32_t) msg[lane];
+    if (__builtin_expect(__all(todo == 8), 1))
+    {
+#pragma unroll
+        for (int k = 0;  k < 8;  k++)
+        {
+            const int32_t sum1 = fsk_correlate(t.dotre, t.dotim, win + (t.ptr*4 + 2)*64 + lane, a[k], c[k], q[k], t.shift);
+            const int32_t sum0 = msg[(1 + k)*64 + lane];
+            const bool on = fsk_bits<FRAMED>(t.b, (int) ((kinds >> (4*k)) & 7u), (sum0 < sum1)  ?  1  :  0, emit);
+            const int32_t next = (t.ptr + 1 >= span)  ?  0  :  (t.ptr + 1);
+            t.ptr = on  ?  next  :  t.ptr;
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int k = 0;  k < 8;  k++)
+        {
+            if (k < todo)
+            {
+                const int32_t sum1 = fsk_correlate(t.dotre, t.dotim, win + (t.ptr*4 + 2)*64 + lane, a[k], c[k], q[k], t.shift);
+                const int32_t sum0 = msg[(1 + k)*64 + lane];
+                const bool on = fsk_bits<true>(t.b, (int) ((kinds >> (4*k)) & 7u), (sum0 < sum1)  ?  1  :  0, emit);
+                const int32_t next = (t.ptr + 1 >= span)  ?  0  :  (t.ptr + 1);
+                t.ptr = on  ?  next  :  t.ptr;
+            }
+        }
     }
 }
 

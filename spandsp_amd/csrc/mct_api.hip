@@ -81,12 +81,17 @@ static int32_t power_level_dbm0(float level)
     return (int32_t) (powf(10.0f, level/10.0f)*(32767.0f*32767.0f));
 }
 
+extern "C" int spangpu_fsk_waves_choice(void);       // fsk_api.hip: what spangpu_tune_fsk_waves() was given
+
 template <int TYPE>
 static void launch(const spangpu_mct_s *m, const MctLaunch &L)
 {
     const bool fsk = (TYPE == MCT_FAX_PREAMBLE  ||  TYPE == MCT_FAX_CED_OR_PREAMBLE);
     const size_t lds = fsk  ?  (size_t) (4*kMctV21Span*64)*sizeof(int32_t)  :  0;
-    hipLaunchKernelGGL(mct_bank_kernel<TYPE>, dim3((m->n_ch + 63)/64), dim3(64), lds, m->stream, L);
+    if (TYPE == MCT_FAX_CED_OR_PREAMBLE  &&  spangpu_fsk_waves_choice() != 1)
+        hipLaunchKernelGGL(mct_ced_pair_kernel, dim3((m->n_ch + 63)/64), dim3(128), lds + 3*64*sizeof(int32_t), m->stream, L);
+    else
+        hipLaunchKernelGGL(mct_bank_kernel<TYPE>, dim3((m->n_ch + 63)/64), dim3(64), lds, m->stream, L);
 }
 
 extern "C" {

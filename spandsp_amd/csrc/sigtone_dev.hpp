@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace spg
 {
@@ -199,147 +200,162 @@ __global__ __launch_bounds__(64) void sigtone_rx_kernel(const SigRxLaunch L)
     int32_t *ev = L.events + (size_t) ch*L.ev_cap*3;
     int n_ev = 0;
     int16_t *row = L.pcm + (size_t) ch*L.stride;
-    const bool vec = (L.vec != 0);
 
     // The frame goes through the lane in chunks of eight samples (one 16-byte access each way); the next chunk is requested
     // before the current one is worked on.  The per-sample logic is written as selects, not branches: the lanes of a wave
     // are different lines in different signalling states, and a branch taken by any of them is paid by all.
-    int4 q_next = {0, 0, 0, 0};
-    if (vec  &&  mylen >= 8)
-        q_next = *(const int4 *) row;
-    for (int base = 0;  base < mylen;  base += 8)
+    int32_t a[8];
+    auto sample = [&](int k, int at) __attribute__((always_inline))
     {
-        const int todo = min(8, mylen - base);
-        int32_t a[8];
-        if (vec  &&  todo == 8)
+        const float famp = (float) a[k];
+        duration += (duration < INT_MAX)  ?  1  :  0;
+        // ---- the notch filters and their power meters, sig_tone.c:437-487 ----
+        float notched1 = 0.0f;
+        float notched2 = 0.0f;
+        int32_t np1 = INT_MAX;
+        int32_t np2 = INT_MAX;
+        const float notched0 = sig_notch_step(c0, t[0], famp);
+        const int32_t np0 = sig_meter(t[0].power, sig_to_i16(notched0));
+        if constexpr (NT == 3)
         {
-            const int4 q = q_next;
-            if (base + 16 <= mylen)
-                q_next = *(const int4 *) (row + base + 8);
-            a[0] = (int16_t) q.x;  a[1] = q.x >> 16;
-            a[2] = (int16_t) q.y;  a[3] = q.y >> 16;
-            a[4] = (int16_t) q.z;  a[5] = q.z >> 16;
-            a[6] = (int16_t) q.w;  a[7] = q.w >> 16;
+            notched1 = sig_notch_step(c1, t[1], famp);
+            np1 = sig_meter(t[1].power, sig_to_i16(notched1));
+            notched2 = sig_notch_step(c0, t[2], notched1);
+            np2 = sig_meter(t[2].power, sig_to_i16(notched2));
         }
-        else
+        // ---- sharp or flat, sig_tone.c:488-499 ----
+        const bool present = (state & (SIG_1_PRESENT | SIG_2_PRESENT)) != 0;
+        bool flat = false;
+        float band = famp;
+        if constexpr (kFlat)
         {
-#pragma unroll
-            for (int k = 0;  k < 8;  k++)
-                a[k] = (k < todo)  ?  row[base + k]  :  0;
+            const bool tick = present  &&  (flat_timeout != 0);
+            const int32_t ft = flat_timeout - (tick  ?  1  :  0);
+            flat_mode = present  ?  ((tick  &&  ft == 0)  ?  1  :  flat_mode)  :  0;
+            flat_timeout = present  ?  ft  :  kSharpFlat;
+            flat = (flat_mode != 0);
+            // the flat mode bi-quad, sig_tone.c:507-528: it only runs (its state only moves) in flat mode
+            float v = famp*0.393676f + flat_z0*-0.261778f + flat_z1*-0.359985f;
+            const float x = v;
+            v += flat_z0*-0.5f + flat_z1*-0.5f;
+            band = v;
+            flat_z1 = flat  ?  flat_z0  :  flat_z1;
+            flat_z0 = flat  ?  x  :  flat_z0;
         }
-#pragma unroll
-        for (int k = 0;  k < 8;  k++)
+        const int32_t fp = sig_meter(flat_power, flat  ?  sig_to_i16(band)  :  a[k]);
+        // ---- flat mode, sig_tone.c:530-561: a plain power threshold ----
+        int32_t st_flat = state;
+        int32_t nt_flat = notch_timeout;
+        if constexpr (kFlat)
         {
-            if (k >= todo)
-                continue;
-            const float famp = (float) a[k];
-            duration += (duration < INT_MAX)  ?  1  :  0;
-            // ---- the notch filters and their power meters, sig_tone.c:437-487 ----
-            float notched1 = 0.0f;
-            float notched2 = 0.0f;
-            int32_t np1 = INT_MAX;
-            int32_t np2 = INT_MAX;
-            const float notched0 = sig_notch_step(c0, t[0], famp);
-            const int32_t np0 = sig_meter(t[0].power, sig_to_i16(notched0));
-            if constexpr (NT == 3)
+            st_flat = present  ?  ((fp < L.flat_threshold)  ?  ((state & ~SIG_1_PRESENT) | SIG_1_CHANGE)  :  state)
+                               :  ((fp > L.flat_threshold)  ?  (state | SIG_1_PRESENT | SIG_1_CHANGE)  :  state);
+            nt_flat = (st_flat & (SIG_1_PRESENT | SIG_2_PRESENT))  ?  kNotchLag  :  (notch_timeout - ((notch_timeout != 0)  ?  1  :  0));
+        }
+        // ---- sharp mode, sig_tone.c:563-625: notched against total power, then the persistence checks ----
+        const int m = (np0 < np1)  ?  0  :  1;
+        const int32_t npm = m  ?  np1  :  np0;
+        const bool t1 = (npm >> 6)*L.detection_ratio < (fp >> 6);
+        const bool t2 = (np2 >> 6)*L.detection_ratio < (fp >> 7);
+        const int imm = (fp >= L.sharp_threshold)  ?  (t1  ?  m  :  (t2  ?  2  :  -1))  :  -1;
+        const int32_t p_dec = persistence - 1;
+        const bool miss = (imm != notch_filter);
+        const bool hit = (imm >= 0)  &&  (imm == last_present);
+        const bool off_confirmed = present  &&  miss  &&  (p_dec == 0);
+        const bool on_confirmed = !present  &&  hit  &&  (p_dec == 0);
+        const int32_t pers_sharp = present  ?  (miss  ?  ((p_dec == 0)  ?  kOnCheck  :  p_dec)  :  kOffCheck)
+                                            :  (hit  ?  ((p_dec == 0)  ?  kOffCheck  :  p_dec)  :  kOnCheck);
+        const int bits = (imm == 0)  ?  SIG_1_PRESENT  :  (imm == 1)  ?  SIG_2_PRESENT  :  (SIG_1_PRESENT | SIG_2_PRESENT);
+        int32_t st_sharp = off_confirmed  ?  ((state | ((state & (SIG_1_PRESENT | SIG_2_PRESENT)) << 1)) & ~(SIG_1_PRESENT | SIG_2_PRESENT))  :  state;
+        st_sharp = on_confirmed  ?  (state | bits | (bits << 1))  :  st_sharp;
+        int32_t nt_sharp = present  ?  notch_timeout  :  (notch_timeout - ((notch_timeout != 0)  ?  1  :  0));
+        nt_sharp = on_confirmed  ?  kNotchLag  :  nt_sharp;
+        state = flat  ?  st_flat  :  st_sharp;
+        notch_timeout = flat  ?  nt_flat  :  nt_sharp;
+        persistence = flat  ?  persistence  :  pers_sharp;
+        notch_filter = (!flat  &&  on_confirmed)  ?  imm  :  notch_filter;
+        const int immediate = flat  ?  -1  :  imm;
+        // ---- the report, sig_tone.c:627-635 ----
+        if (__builtin_expect((state & (SIG_1_CHANGE | SIG_2_CHANGE)) != 0, 0))
+        {
+            if (n_ev < L.ev_cap)
             {
-                notched1 = sig_notch_step(c1, t[1], famp);
-                np1 = sig_meter(t[1].power, sig_to_i16(notched1));
-                notched2 = sig_notch_step(c0, t[2], notched1);
-                np2 = sig_meter(t[2].power, sig_to_i16(notched2));
+                ev[3*n_ev] = at;
+                ev[3*n_ev + 1] = state;
+                ev[3*n_ev + 2] = duration;
             }
-            // ---- sharp or flat, sig_tone.c:488-499 ----
-            const bool present = (state & (SIG_1_PRESENT | SIG_2_PRESENT)) != 0;
-            bool flat = false;
-            float band = famp;
-            if constexpr (kFlat)
+            n_ev++;
+            state &= ~(SIG_1_CHANGE | SIG_2_CHANGE);
+            duration = 0;
+        }
+        // ---- the media path, sig_tone.c:637-653 ----
+        const float pick = (NT == 1)  ?  ((notch_filter == 0)  ?  notched0  :  0.0f)
+                                      :  ((notch_filter == 0)  ?  notched0  :  (notch_filter == 1)  ?  notched1  :  notched2);
+        const bool pass = (rx_tone & SIG_RX_PASSTHROUGH) != 0;
+        const bool filter = (rx_tone & SIG_RX_FILTER_TONE)  ||  notch_timeout;
+        a[k] = pass  ?  (filter  ?  sig_fsat(pick)  :  a[k])  :  0;
+        last_present = immediate;
+    };
+    // Two copies of the chunk loop.  With aligned rows every chunk is one aligned 16-byte load, also a frame's last, shorter
+    // one (it starts inside the row, so it cannot leave the page the row's last sample is on), there is no lane-dependent
+    // branch around the loads and no other kind of load in the loop -- where such paths join, the compiler waits for
+    // everything in flight, the chunk just requested included -- and a chunk that is whole in every lane (the common case)
+    // runs its eight samples without guards, whose bodies the compiler would move out of line.
+    auto frame = [&](auto aligned) __attribute__((always_inline))
+    {
+        constexpr bool VEC = decltype(aligned)::value;
+        int4 q_next = {0, 0, 0, 0};
+        __builtin_amdgcn_s_waitcnt(0x0F70);         // the state words home before the first chunk is requested (vmcnt is in order)
+        if (VEC)
+            q_next = *(const int4 *) row;
+        for (int base = 0;  base < mylen;  base += 8)
+        {
+            const int todo = min(8, mylen - base);
+            if (VEC)
             {
-                const bool tick = present  &&  (flat_timeout != 0);
-                const int32_t ft = flat_timeout - (tick  ?  1  :  0);
-                flat_mode = present  ?  ((tick  &&  ft == 0)  ?  1  :  flat_mode)  :  0;
-                flat_timeout = present  ?  ft  :  kSharpFlat;
-                flat = (flat_mode != 0);
-                // the flat mode bi-quad, sig_tone.c:507-528: it only runs (its state only moves) in flat mode
-                float v = famp*0.393676f + flat_z0*-0.261778f + flat_z1*-0.359985f;
-                const float x = v;
-                v += flat_z0*-0.5f + flat_z1*-0.5f;
-                band = v;
-                flat_z1 = flat  ?  flat_z0  :  flat_z1;
-                flat_z0 = flat  ?  x  :  flat_z0;
+                const int4 q = q_next;
+                a[0] = (int16_t) q.x;  a[1] = q.x >> 16;
+                a[2] = (int16_t) q.y;  a[3] = q.y >> 16;
+                a[4] = (int16_t) q.z;  a[5] = q.z >> 16;
+                a[6] = (int16_t) q.w;  a[7] = q.w >> 16;
+                q_next = *(const int4 *) (row + ((base + 8 < mylen)  ?  (base + 8)  :  0));
             }
-            const int32_t fp = sig_meter(flat_power, flat  ?  sig_to_i16(band)  :  a[k]);
-            // ---- flat mode, sig_tone.c:530-561: a plain power threshold ----
-            int32_t st_flat = state;
-            int32_t nt_flat = notch_timeout;
-            if constexpr (kFlat)
+            else
             {
-                st_flat = present  ?  ((fp < L.flat_threshold)  ?  ((state & ~SIG_1_PRESENT) | SIG_1_CHANGE)  :  state)
-                                   :  ((fp > L.flat_threshold)  ?  (state | SIG_1_PRESENT | SIG_1_CHANGE)  :  state);
-                nt_flat = (st_flat & (SIG_1_PRESENT | SIG_2_PRESENT))  ?  kNotchLag  :  (notch_timeout - ((notch_timeout != 0)  ?  1  :  0));
+#pragma unroll
+                for (int k = 0;  k < 8;  k++)
+                    a[k] = (k < todo)  ?  row[base + k]  :  0;
             }
-            // ---- sharp mode, sig_tone.c:563-625: notched against total power, then the persistence checks ----
-            const int m = (np0 < np1)  ?  0  :  1;
-            const int32_t npm = m  ?  np1  :  np0;
-            const bool t1 = (npm >> 6)*L.detection_ratio < (fp >> 6);
-            const bool t2 = (np2 >> 6)*L.detection_ratio < (fp >> 7);
-            const int imm = (fp >= L.sharp_threshold)  ?  (t1  ?  m  :  (t2  ?  2  :  -1))  :  -1;
-            const int32_t p_dec = persistence - 1;
-            const bool miss = (imm != notch_filter);
-            const bool hit = (imm >= 0)  &&  (imm == last_present);
-            const bool off_confirmed = present  &&  miss  &&  (p_dec == 0);
-            const bool on_confirmed = !present  &&  hit  &&  (p_dec == 0);
-            const int32_t pers_sharp = present  ?  (miss  ?  ((p_dec == 0)  ?  kOnCheck  :  p_dec)  :  kOffCheck)
-                                                :  (hit  ?  ((p_dec == 0)  ?  kOffCheck  :  p_dec)  :  kOnCheck);
-            const int bits = (imm == 0)  ?  SIG_1_PRESENT  :  (imm == 1)  ?  SIG_2_PRESENT  :  (SIG_1_PRESENT | SIG_2_PRESENT);
-            int32_t st_sharp = off_confirmed  ?  ((state | ((state & (SIG_1_PRESENT | SIG_2_PRESENT)) << 1)) & ~(SIG_1_PRESENT | SIG_2_PRESENT))  :  state;
-            st_sharp = on_confirmed  ?  (state | bits | (bits << 1))  :  st_sharp;
-            int32_t nt_sharp = present  ?  notch_timeout  :  (notch_timeout - ((notch_timeout != 0)  ?  1  :  0));
-            nt_sharp = on_confirmed  ?  kNotchLag  :  nt_sharp;
-            state = flat  ?  st_flat  :  st_sharp;
-            notch_timeout = flat  ?  nt_flat  :  nt_sharp;
-            persistence = flat  ?  persistence  :  pers_sharp;
-            notch_filter = (!flat  &&  on_confirmed)  ?  imm  :  notch_filter;
-            const int immediate = flat  ?  -1  :  imm;
-            // ---- the report, sig_tone.c:627-635 ----
-            if ((state & (SIG_1_CHANGE | SIG_2_CHANGE)))
+            if (VEC  &&  __builtin_expect(__all(todo == 8), 1))
             {
-                if (n_ev < L.ev_cap)
+#pragma unroll
+                for (int k = 0;  k < 8;  k++)
+                    sample(k, base + k);
+                int4 q;
+                q.x = (a[0] & 0xFFFF) | (a[1] << 16);
+                q.y = (a[2] & 0xFFFF) | (a[3] << 16);
+                q.z = (a[4] & 0xFFFF) | (a[5] << 16);
+                q.w = (a[6] & 0xFFFF) | (a[7] << 16);
+                *(int4 *) (row + base) = q;
+            }
+            else
+            {
+#pragma unroll
+                for (int k = 0;  k < 8;  k++)
                 {
-                    ev[3*n_ev] = base + k;
-                    ev[3*n_ev + 1] = state;
-                    ev[3*n_ev + 2] = duration;
+                    if (k < todo)
+                    {
+                        sample(k, base + k);
+                        row[base + k] = (int16_t) a[k];
+                    }
                 }
-                n_ev++;
-                state &= ~(SIG_1_CHANGE | SIG_2_CHANGE);
-                duration = 0;
-            }
-            // ---- the media path, sig_tone.c:637-653 ----
-            const float pick = (NT == 1)  ?  ((notch_filter == 0)  ?  notched0  :  0.0f)
-                                          :  ((notch_filter == 0)  ?  notched0  :  (notch_filter == 1)  ?  notched1  :  notched2);
-            const bool pass = (rx_tone & SIG_RX_PASSTHROUGH) != 0;
-            const bool filter = (rx_tone & SIG_RX_FILTER_TONE)  ||  notch_timeout;
-            a[k] = pass  ?  (filter  ?  sig_fsat(pick)  :  a[k])  :  0;
-            last_present = immediate;
-        }
-        if (vec  &&  todo == 8)
-        {
-            int4 q;
-            q.x = (a[0] & 0xFFFF) | (a[1] << 16);
-            q.y = (a[2] & 0xFFFF) | (a[3] << 16);
-            q.z = (a[4] & 0xFFFF) | (a[5] << 16);
-            q.w = (a[6] & 0xFFFF) | (a[7] << 16);
-            *(int4 *) (row + base) = q;
-        }
-        else
-        {
-#pragma unroll
-            for (int k = 0;  k < 8;  k++)
-            {
-                if (k < todo)
-                    row[base + k] = (int16_t) a[k];
             }
         }
-    }
+    };
+    if (L.vec)
+        frame(std::true_type{});
+    else
+        frame(std::false_type{});
 
 #pragma unroll
     for (int j = 0;  j < NT;  j++)

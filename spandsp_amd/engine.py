@@ -177,6 +177,7 @@ def lib():
             "spangpu_feed_collect": (ci, [vp, C.POINTER(vp)]),
             "spangpu_feed_outstanding": (ci, [vp]),
             "spangpu_tune_modem_mapping": (ci, [ci]),
+            "spangpu_tune_fsk_waves": (ci, [ci]),
             "spangpu_echo_lanes_per_channel": (ci, [vp]),
             "spangpu_echo_stats": (ci, [vp, ci]),
             "spangpu_echo_stats_reset": (ci, [vp, ci]),
@@ -260,6 +261,12 @@ def tune_tone_kernel(variant):
 def tune_modem_mapping(mapping):
     """0 = by bank size, 1 = one channel per lane, 4 / 8 = four lanes per channel with 16 / 8 channels per wavefront."""
     _check(lib().spangpu_tune_modem_mapping(mapping))
+
+
+def tune_fsk_waves(waves):
+    """FSK / connect-tone / signalling-tone receiver banks: 0 = the library's choice, 1 = a receiver in one lane of one
+    wavefront, 2 = a receiver cut into two instruction streams on two wavefronts.  Results are identical."""
+    _check(lib().spangpu_tune_fsk_waves(waves))
 
 
 def goertzel_fac(freq):

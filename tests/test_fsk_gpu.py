@@ -147,3 +147,40 @@ def test_fsk_device_frames_and_ragged_bank(built):
     assert total > n*20
     for c in range(n):
         assert np.array_equal(bank.get_state(c), orcs[c].snapshot()), c
+
+
+@pytest.mark.parametrize("which,mode", [(1, 1), (0, 2), (3, 0)])
+def test_fsk_one_and_two_waves_agree(built, which, mode):
+    """The receiver cut over two wavefronts (the library's choice) against the whole receiver in one lane: same events,
+    same state words, ragged frame sizes and per-channel lengths included."""
+    from spandsp_amd import engine
+    sp = engine.fsk_preset(which)
+    n = 333
+    sig = synth.fsk_channels(n, 160*40, 900 + which, sp.freq_zero, sp.freq_one, sp.baud_rate)
+    out = []
+    try:
+        for waves in (1, 2):
+            engine.tune_fsk_waves(waves)
+            bank = engine.FskBank(which, n, mode)
+            pos = 0
+            k = 0
+            evs = []
+            while pos < sig.shape[1]:
+                m = min(SIZES[k % len(SIZES)], sig.shape[1] - pos)
+                if k % 4 == 3:
+                    lens = np.random.default_rng(k).integers(0, m + 1, n).astype(np.int32)
+                    bank.rx_host_var(sig[:, pos:pos + m], lens)
+                else:
+                    bank.rx_host(sig[:, pos:pos + m])
+                evs.append([e.copy() for e in bank.events()])
+                pos += m
+                k += 1
+            out.append((evs, [bank.get_state(c) for c in range(n)]))
+    finally:
+        engine.tune_fsk_waves(0)
+    for a, b in zip(out[0][0], out[1][0]):
+        for c in range(n):
+            assert np.array_equal(a[c], b[c]), c
+    for c in range(n):
+        assert np.array_equal(out[0][1][c], out[1][1][c]), c
+    assert sum(len(e[c]) for e in out[0][0] for c in range(n)) > n*5

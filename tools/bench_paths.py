@@ -883,6 +883,8 @@ def main():
     ap.add_argument("--echo-lanes", type=int, default=0, help="echo: lanes per channel (0 = the library's choice; 2, 4, 8, 16 for A-B runs)")
     ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
     ap.add_argument("--cpu-channels", type=int, default=16384)
+    ap.add_argument("--fsk-waves", type=int, default=0,
+                    help="fsk / mct / sigtone: 0 = the library's choice, 1 = one wavefront per 64 receivers, 2 = two (A-B runs)")
     ap.add_argument("--modem-mapping", type=int, default=0,
                     help="v29 / v17 / v27ter: 0 = the library's choice, 1 = one channel per lane, 4 / 8 = four lanes per channel (A-B runs)")
     ap.add_argument("--replay-fixture", action="store_true",
@@ -896,6 +898,7 @@ def main():
     from spandsp_amd import engine
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
+    engine.tune_fsk_waves(args.fsk_waves)
     if args.workload == "echo":
         emit(bench_echo(args, dev, stream), "echo", args.channels or None)
         return
