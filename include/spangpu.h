@@ -248,8 +248,9 @@ SPANGPU_API int spangpu_bank_set_digits_ring(spangpu_bank_t *bank, void *dev_ptr
      SPANGPU_CADENCE_SEGMENT   segment_callback(user, f1, f2, ms): a run ended (only with want_segments)
    The streaming detector kernel matches the cadences itself, in its epilogue; for launches it does not serve (sample-major
    or unaligned frames, ragged lengths, more than 16 bins, spangpu_banks_rx()) spangpu_bank_cadence_run() queues a matcher
-   launch over the records of the last spangpu_bank_rx*() on the bank's stream (once per launch; every such launch must be
-   followed by it or by _events() / _list(), else its blocks are not counted).  It returns the slots per channel; spangpu_bank_cadence_events() does that if it was not done, waits and hands out pinned host copies;
+   launch over the records of the last spangpu_bank_rx*() on the bank's stream (once per launch; the next spangpu_bank_rx*()
+   does it itself if nobody has, so every block is counted whichever kernel served its frame -- only the events of a launch
+   nobody asked about are not kept).  It returns the slots per channel; spangpu_bank_cadence_events() does that if it was not done, waits and hands out pinned host copies;
    spangpu_bank_cadence_device() the device buffers themselves (for a gather). */
 #define SPANGPU_CADENCE_TONE_ON     1
 #define SPANGPU_CADENCE_TONE_OFF    2

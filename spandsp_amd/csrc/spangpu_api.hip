@@ -769,8 +769,22 @@ static void fill_launch(ToneLaunch &L, spangpu_bank_t *b, const int16_t *d_amp, 
     L.reverse_twist = b->reverse_twist;
 }
 
+// A launch is about to overwrite the block records of the one before it.  If cadences are installed and nobody has taken
+// that launch's records to the matcher yet (it was not served by the streaming kernel, and the caller did not ask for its
+// cadence events), do it now: whether a bank's runs are counted must not depend on which kernel its frames happen to get.
+static int cadence_catch_up(spangpu_bank_t *b)
+{
+    if (b->cad == nullptr  ||  b->launch_serial == 0  ||  b->cad->done_serial == b->launch_serial)
+        return SPANGPU_OK;
+    const int rc = spangpu_bank_cadence_run(b);
+    return (rc < 0)  ?  rc  :  SPANGPU_OK;
+}
+
 static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stride, int samples, int layout, int maxb, int force_end)
 {
+    const int caught = cadence_catch_up(b);
+    if (caught != SPANGPU_OK)
+        return caught;
     ToneLaunch L;
     fill_launch(L, b, d_amp, d_stride, samples, layout, maxb, force_end);
 
@@ -1134,6 +1148,9 @@ int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, i
             return rc;
         if (b->ext_rec  &&  (size_t) maxb*b->n_ch*sizeof(uint32_t) > b->ext_rec_bytes)
             return fail(SPANGPU_ERR_BAD_ARG, "records buffer of bank %d too small for %d blocks", k, maxb);
+        const int caught = cadence_catch_up(b);
+        if (caught != SPANGPU_OK)
+            return caught;
         fill_launch(M.bank[k], b, amps[k], stride, samples, SPANGPU_LAYOUT_CHANNEL_MAJOR, maxb, 0);
         all_fast = all_fast  &&  fast_eligible(M.bank[k]);
         b->last_maxb = maxb;

@@ -218,3 +218,46 @@ def test_cadences_65536_channels(built):
             total += len(want)
     assert total > len(picks)
     sd.close()
+
+
+def test_cadence_state_does_not_depend_on_who_asks(built, tone_variant):
+    """A caller that looks at the cadence events only now and then: every block is counted all the same, whichever kernel
+    served the frame (the next launch takes the records of the last one to the matcher if nobody has).  Against a bank that is
+    asked after every frame: the same cadence state after every frame, the same events whenever both are asked."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 40
+    sig = synth.cadence_plan_channels(n_ch, 160*200, 73, PLANS)
+    od = orc.SuperToneDesc()
+    build(od)
+    fac = list(od.fac)
+    hz = [400, 1100, 350, 440, 480, 620, 950, 1400, 1800]
+    bins = {0: -1}
+    bins.update({f: i for i, f in enumerate(hz)})
+    tones = [[(bins[f1], bins[f2], lo, hi) for f1, f2, lo, hi in t] for t in TONES]
+    asked = engine.ToneBank(engine.SUPER_TONE, n_ch, bin_fac=fac)
+    lazy = engine.ToneBank(engine.SUPER_TONE, n_ch, bin_fac=fac)
+    for b in (asked, lazy):
+        b.set_cadences(tones, want_segments=True)
+    sizes = [160, 96, 256, 31, 128, 129]
+    pos = 0
+    k = 0
+    seen = 0
+    while pos < sig.shape[1]:
+        n = min(sizes[k % len(sizes)], sig.shape[1] - pos)
+        fr = np.ascontiguousarray(sig[:, pos:pos + n])
+        asked.rx_host(fr)
+        want = asked.cadence_events()
+        lazy.rx_host(fr)
+        if k % 7 == 6:
+            got = lazy.cadence_events()
+            assert got == want, k
+            seen += sum(len(e) for e in got)
+            for c in range(0, n_ch, 5):
+                assert (lazy.cadence_get_state(c) == asked.cadence_get_state(c)).all(), (k, c)
+        pos += n
+        k += 1
+    lazy.cadence_run()
+    for c in range(n_ch):
+        assert (lazy.cadence_get_state(c) == asked.cadence_get_state(c)).all(), c
+    assert seen > 0
