@@ -70,7 +70,7 @@ extern "C" {
 #define SPANGPU_LAYOUT_CHANNEL_MAJOR 0      /* amp[channel][sample]: what N spandsp callers naturally hold */
 #define SPANGPU_LAYOUT_SAMPLE_MAJOR  1      /* amp[sample][channel]: pre-interleaved */
 
-#define SPANGPU_MAX_BINS            32      /* bins per channel in one Goertzel / super-tone bank */
+#define SPANGPU_MAX_BINS            64      /* bins per channel in one Goertzel / super-tone bank (super_tone_rx.h:44: 64 pitches) */
 
 /* ---- report modes for DTMF (which of the reference's delivery paths is replayed) */
 #define SPANGPU_REPORT_DIGITS       0       /* digits[] buffer / digits_rx_callback_t   (dtmf.c:318-340) */

@@ -239,6 +239,16 @@ static void launch_tone_wide(const ToneLaunch &L, hipStream_t st)
         hipLaunchKernelGGL((tone_bank_kernel<Det, 2>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
 }
 
+// Banks of more than 32 bins per channel (a super-tone descriptor may name 64 pitches, private/super_tone_rx.h:44): four
+// lanes per channel, 16 channels per wavefront, the general kernel.
+template <class Det>
+static void launch_tone_quad(const ToneLaunch &L, hipStream_t st)
+{
+    const int waves = (L.n_ch + 15)/16;
+    const int blocks = (waves + kWavesPerBlock - 1)/kWavesPerBlock;
+    hipLaunchKernelGGL((tone_bank_kernel<Det, 4>), dim3(blocks), dim3(kWave*kWavesPerBlock), 0, st, L);
+}
+
 // dtmf_rx_parms(), dtmf.c:421-445, on top of the defaults of dtmf_rx_init() (dtmf.c:470-476).  A field takes effect when
 // its bit of set_mask is set and the reference's own test passes (twists >= 0 dB, threshold > -99 dBm0); without
 // set_mask (a zeroed struct, or one from a caller built before the mask existed) a positive twist and a non-zero
@@ -604,7 +614,7 @@ int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_chann
             free(b);
             return fail(SPANGPU_ERR_BAD_ARG, "n_bins %d out of range", m);
         }
-        b->nb = (m <= 4)  ?  4  :  (m <= 8)  ?  8  :  (m <= 12)  ?  12  :  (m <= 16)  ?  16  :  (m <= 24)  ?  24  :  32;
+        b->nb = (m <= 4)  ?  4  :  (m <= 8)  ?  8  :  (m <= 12)  ?  12  :  (m <= 16)  ?  16  :  (m <= 24)  ?  24  :  (m <= 32)  ?  32  :  64;
         b->nsf = 2*b->nb + 1;
         b->block_len = (kind == SPANGPU_SUPER_TONE)  ?  128  :  b->tp.block_len;
         if (b->block_len <= 0  ||  b->block_len > 65535)
@@ -813,7 +823,8 @@ static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stri
         case 12: launch_tone<MultiDet<12, true>>(L, b->stream); break;
         case 16: launch_tone<MultiDet<16, true>>(L, b->stream); break;
         case 24: launch_tone_wide<MultiDet<24, true>>(L, b->stream); break;
-        default: launch_tone_wide<MultiDet<32, true>>(L, b->stream); break;
+        case 32: launch_tone_wide<MultiDet<32, true>>(L, b->stream); break;
+        default: launch_tone_quad<MultiDet<64, true>>(L, b->stream); break;
         }
         break;
     case SPANGPU_GOERTZEL:
@@ -824,7 +835,8 @@ static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stri
         case 12: launch_tone<MultiDet<12, false>>(L, b->stream); break;
         case 16: launch_tone<MultiDet<16, false>>(L, b->stream); break;
         case 24: launch_tone_wide<MultiDet<24, false>>(L, b->stream); break;
-        default: launch_tone_wide<MultiDet<32, false>>(L, b->stream); break;
+        case 32: launch_tone_wide<MultiDet<32, false>>(L, b->stream); break;
+        default: launch_tone_quad<MultiDet<64, false>>(L, b->stream); break;
         }
         break;
     default:

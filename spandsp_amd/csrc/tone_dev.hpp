@@ -36,7 +36,7 @@ namespace spg {
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
-constexpr int kMaxBins = 32;            // banks of more than 16 bins run two lanes per channel (16 bins per lane)
+constexpr int kMaxBins = 64;            // banks of more than 16 bins run two lanes per channel, of more than 32 four (16 bins per lane)
 
 // Kernel argument block (passed by value; lives in SGPRs / kernarg segment).
 struct ToneLaunch
@@ -799,6 +799,12 @@ __device__ __forceinline__ void dma_issue<10>(const void *const (&g)[10], uint32
                  : "memory", "scc");
 }
 
+// (the four-lane mapping never issues one: its rows do not divide over the lanes)
+template <>
+__device__ __forceinline__ void dma_issue<1>(const void *const (&)[1], uint32_t)
+{
+}
+
 __device__ __forceinline__ void dma_wait_all()
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -814,9 +820,9 @@ template <int LPC>
 struct ToneLds
 {
     static constexpr int kBufBytes = (kWave/LPC)*kRowBytes;
-    // the LPC = 2 kernels also hold the 256-entry G.711 decode table (the LPC = 1 kernels use every byte of the CU's LDS
-    // for their two workgroups, and take linear PCM only)
-    static constexpr int kLutBytes = (LPC == 2)  ?  1024  :  0;
+    // the LPC = 2 / 4 kernels also hold the 256-entry G.711 decode table (the LPC = 1 kernels use every byte of the CU's
+    // LDS for their two workgroups, and take linear PCM only)
+    static constexpr int kLutBytes = (LPC >= 2)  ?  1024  :  0;
     static constexpr int kBytes = kWavesPerBlock*2*kBufBytes + kLutBytes;
 };
 
@@ -826,17 +832,17 @@ template <class Det, int LPC, int ABL = 0>
 __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg, char *lds_raw)
 {
     constexpr int NB = Det::NB;
-    constexpr int NBH = (LPC == 1)  ?  NB  :  (NB + 1)/2;      // real bins per lane
+    constexpr int NBH = (NB + LPC - 1)/LPC;                     // real bins per lane
     constexpr int NBL = (NBH + 1) & ~1;                         // padded to packed pairs
     constexpr int CPW = kWave/LPC;                              // channels per wave
-    constexpr int NDMA = CPW*kChunksPerRow/kWave;               // LDS-DMA instructions per segment
+    constexpr int NDMA = (LPC <= 2)  ?  CPW*kChunksPerRow/kWave  :  1;      // LDS-DMA instructions per segment (LPC = 4: no DMA)
     constexpr int kBufBytes = CPW*kRowBytes;
     char (*lds)[2][kBufBytes] = (char (*)[2][kBufBytes]) lds_raw;
     const float *lut = (const float *) (lds_raw + kWavesPerBlock*2*kBufBytes);
 
     // G.711 input: the decode table, spandsp/g711.h:165-175 (u-law) and :239-252 (A-law), as floats
-    const int bps = (LPC == 2  &&  L.fmt != 0)  ?  1  :  2;     // bytes per sample
-    if (LPC == 2  &&  L.fmt != 0)
+    const int bps = (LPC >= 2  &&  L.fmt != 0)  ?  1  :  2;     // bytes per sample
+    if (LPC >= 2  &&  L.fmt != 0)
     {
         float *wl = (float *) (lds_raw + kWavesPerBlock*2*kBufBytes);
         for (int code = threadIdx.x;  code < 256;  code += kWave*kWavesPerBlock)
@@ -867,7 +873,7 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
     if (ch0 >= L.n_ch)
         return;                                     // whole wave idle (wave-uniform exit)
     const int cl = (LPC == 1)  ?  lane  :  (lane & (CPW - 1));  // channel within the wave
-    const int sub = (LPC == 1)  ?  0  :  (lane >> 5);           // which half of the bins
+    const int sub = (LPC == 1)  ?  0  :  (lane/CPW);            // which half / quarter of the bins
     const bool in_bank = (ch0 + cl) < L.n_ch;
     const int ch = in_bank  ?  (ch0 + cl)  :  (L.n_ch - 1);     // shadow lanes follow the last channel, never store
     // A call with per-channel lengths: a channel with no samples in it rides along as a shadow lane too (nothing of
@@ -901,7 +907,8 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
             ts[k] = (long long) __builtin_readcyclecounter();
     };
     stamp(0);
-    const bool fast_loader = (L.layout == 0)  &&  L.aligned16  &&  (L.samples > 0);
+    // (sixteen rows of ten chunks do not divide over 64 lanes: the four-lane mapping has its rows fetched by their lanes)
+    const bool fast_loader = (LPC <= 2)  &&  (L.layout == 0)  &&  L.aligned16  &&  (L.samples > 0);
     const int seg_samples = kRowBytes/bps;                      // a 160-byte row is 80 linear samples or 160 G.711 codes
     const int spc = 16/bps;                                     // samples per 16-byte chunk
     const int nseg = (L.samples + seg_samples - 1)/seg_samples;
@@ -952,6 +959,25 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
             f = L.fac[i];
             s2 = L.sf[(size_t) i*L.n_ch + ch];
             s3 = L.sf[(size_t) (NB + i)*L.n_ch + ch];
+        }
+        else if (LPC == 4)
+        {
+            // lane quarter `sub` owns global bins sub*NBH + i, i < NBH (selects, not an index: L.fac[] sits in scalar registers)
+            float fq = 0.0f;
+#pragma unroll
+            for (int q = 0;  q < 4;  q++)
+            {
+                const int gq = q*NBH + i;
+                const float fv = (i < NBH  &&  gq < NB)  ?  L.fac[(gq < kMaxBins)  ?  gq  :  0]  :  0.0f;
+                fq = (sub == q)  ?  fv  :  fq;
+            }
+            f = fq;
+            const int gi = sub*NBH + i;
+            if (i < NBH  &&  gi < NB)
+            {
+                s2 = L.sf[(size_t) gi*L.n_ch + ch];
+                s3 = L.sf[(size_t) (NB + gi)*L.n_ch + ch];
+            }
         }
         else
         {
@@ -1036,6 +1062,20 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
 #pragma unroll
             for (int i = 0;  i < NB;  i++)
                 e[i] = el[i];
+        }
+        else if (LPC == 4)
+        {
+            // every lane of a channel collects all four quarters
+#pragma unroll
+            for (int q = 0;  q < 4;  q++)
+            {
+#pragma unroll
+                for (int i = 0;  i < NBH;  i++)
+                {
+                    if (q*NBH + i < NB)
+                        e[q*NBH + i] = __shfl(el[i], cl + q*CPW);
+                }
+            }
         }
         else
         {
@@ -1243,7 +1283,7 @@ __device__ __forceinline__ void tone_bank_body(const ToneLaunch &L, const int wg
         }
         else
         {
-            // Divergent block phases inside the wave: correct, slower.  (With LPC = 2 the two
+            // Divergent block phases inside the wave: correct, slower.  (With LPC = 2 / 4 the
             // lanes of a channel share its phase, so they reach end_block() together.)
             for (int pos = 0;  pos < seglen;  pos++)
             {

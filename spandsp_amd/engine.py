@@ -17,7 +17,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 CHANNEL_MAJOR, SAMPLE_MAJOR = 0, 1
 REPORT_DIGITS, REPORT_REALTIME = 0, 2
 BLK_VALID, BLK_CHANGE, BLK_REPORT, BLK_TONE_OFF = 1, 2, 4, 8
-MAX_BINS = 32
+MAX_BINS = 64
 
 BLOCK_DTYPE = np.dtype([("channel", "<i4"), ("block", "<i4"), ("hit", "<i4"), ("code", "<i4"),
                         ("flags", "<i4"), ("duration", "<i4"), ("energy", "<f4")])
@@ -459,9 +459,9 @@ class ToneBank:
         return buf[:nb*(self.nbins + 1)*self.n].reshape(nb, self.nbins + 1, self.n)
 
     def get_state(self, channel):
-        f = np.zeros(64, np.float32)
+        f = np.zeros(2*MAX_BINS + 8, np.float32)
         i = np.zeros(4, np.int32)
-        nsf = _check(lib().spangpu_bank_get_state(self.h, channel, f.ctypes.data, 64, i.ctypes.data, 4))
+        nsf = _check(lib().spangpu_bank_get_state(self.h, channel, f.ctypes.data, len(f), i.ctypes.data, 4))
         return f[:nsf].copy(), i
 
     def set_state(self, channel, f, i):

@@ -549,6 +549,80 @@ def test_super_tone_bank_of_more_than_16_bins(built):
     assert sum(1 for c in range(n_ch) for b in g[c] if b[0] >= 0) > n_ch
 
 
+def _st_desc_64(D):
+    """A descriptor that names all 64 pitches super_tone_rx.h:44 has room for (more than two lanes' 32 bins): call-progress
+    pairs from 300 Hz up in 25 Hz steps, the pairs the synthetic lines really send among them."""
+    d = D()
+    sent = [350, 440, 480, 620, 950, 1100, 1400, 1800]
+    rest = [f for f in range(300, 300 + 25*80, 25) if all(abs(f - x) > 10 for x in sent)][:56]
+    base = sent + rest
+    assert len(base) == 64
+    for k in range(0, 64, 2):
+        t = d.add_tone()
+        d.add_element(t, base[k], base[k + 1], 300, 0)
+        d.add_element(t, 0, 0, 200, 0)
+    return d
+
+
+@pytest.mark.parametrize("sizes", [[160], [160, 96, 256, 31]])
+def test_super_tone_bank_of_64_bins(built, sizes):
+    """Four lanes per channel (tone_bank_kernel<MultiDet<64>, 4>): block energies of all 64 bins, the pair picked, bit for bit."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 53                                       # a last wave that is not full (16 channels per wave)
+    sig = synth.call_progress_channels(n_ch, 160*80, seed=35)
+    desc = _st_desc_64(orc.SuperToneDesc)
+    fac = list(desc.fac)
+    assert len(fac) == 64 == engine.MAX_BINS
+    bank = engine.ToneBank(engine.SUPER_TONE, n_ch, bin_fac=fac, trace=True)
+    g = run_gpu(bank, sig, sizes)
+    dets = [orc.SuperTone(desc) for _ in range(n_ch)]
+    o = [[] for _ in dets]
+    for pos, n in frames_of(sig.shape[1], sizes):
+        for c, d in enumerate(dets):
+            o[c].extend(list(d.rx(sig[c, pos:pos + n])))
+    check_blocks(g, o, len(fac), "super-tone, 64 bins")
+    assert sum(1 for c in range(n_ch) for b in g[c] if b[0] >= 0) > n_ch
+
+
+def test_goertzel_bank_of_40_bins_and_its_state(built):
+    """More than 32 plain Goertzel bins: block energies against goertzel_update() / goertzel_result() for frames that do not
+    line up with the blocks, with every channel's state words moved into a second bank half way."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch = 37
+    freqs = [300.0 + 43.0*i for i in range(40)]
+    block = 205
+    sig = synth.call_progress_channels(n_ch, 160*30, seed=43)
+    facs = [engine.goertzel_fac(f) for f in freqs]
+    banks = [engine.ToneBank(engine.GOERTZEL, n_ch, bin_fac=facs, block_len=block, trace=True) for _ in range(2)]
+    got = [[] for _ in range(n_ch)]
+    frames = list(frames_of(sig.shape[1], [160, 96, 31, 256]))
+    for k, (pos, n) in enumerate(frames):
+        if k == len(frames)//2:
+            for c in range(n_ch):
+                banks[1].set_state(c, *banks[0].get_state(c))
+        bank = banks[0] if k < len(frames)//2 else banks[1]
+        bank.rx_host(sig[:, pos:pos + n])
+        blk = bank.blocks()
+        if blk.size:
+            tr = bank.trace()
+            for r in blk:
+                got[r["channel"]].append(tr[r["block"], :len(freqs), r["channel"]].copy())
+    for c in range(n_ch):
+        gs = [orc.Goertzel(f, block) for f in freqs]
+        want = []
+        pos = 0
+        while pos + block <= sig.shape[1]:
+            for gz in gs:
+                assert gz.update(sig[c, pos:pos + block]) == block
+            want.append(np.array([gz.result() for gz in gs], np.float32))
+            pos += block
+        assert len(got[c]) == len(want), c
+        for x, y in zip(got[c], want):
+            assert np.array_equal(f32_bits(x), f32_bits(y)), c
+
+
 def test_goertzel_bank(built):
     from oracle import restated as orc
     from spandsp_amd import engine
