@@ -190,8 +190,20 @@ def end_to_end(engine, n_ch, frames_dev, device_index, steps, law=0):
     feed.close()
     bank.close()
     bps = 1 if law else 2
+    # the floor of this path on this box: the same bytes, pinned host memory -> HBM, nothing else
+    import torch
+    pinned = torch.empty(n_ch*FRAME*bps, dtype=torch.uint8).pin_memory()
+    onboard = torch.empty(n_ch*FRAME*bps, dtype=torch.uint8, device="cuda:%d" % device_index)
+    onboard.copy_(pinned, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        onboard.copy_(pinned, non_blocking=True)
+    torch.cuda.synchronize()
+    h2d_ms = (time.perf_counter() - t0)/20*1e3
     return {
         "ms_per_step": dt*1e3/steps,
+        "h2d_copy_alone_ms": h2d_ms,
         "value": float(steps)*n_ch*FRAME/dt/1e6,
         "unit": "Msamples/s",
         "steps": steps,

@@ -46,6 +46,10 @@ def valu_roof(key, avg_launch_us, channels=None, samples=160):
     out = {"bound": "valu_issue", "kernel": rec.get("kernel"), "valu_insts_per_launch": valu,
            "valu_insts_per_wave_sample": rec.get("valu_insts_per_wave_sample"), "issue_floor_us": floor_us,
            "frac": floor_us/avg_launch_us, "cycles_per_valu": CYCLES_PER_VALU, "simds": SIMDS, "clock_mhz": CLOCK_MHZ,
+           # (for the reader: a lone wavefront also pays about four cycles for every scalar instruction, branch and wait --
+           # DESIGN 4.5; the floor counts vector instructions only)
+           "salu_insts_per_wave_sample": (rec.get("salu_insts_per_launch", 0.0)/max(1.0, rec.get("waves", 1.0))/float(samples)),
+           "waves_per_simd": rec.get("waves", 0.0)/SIMDS, "wait_frac": rec.get("wait_frac"),
            "source": rec.get("source")}
     return out
 

@@ -18,7 +18,7 @@ python3 - <<'PY'
 import csv, glob, collections, json, os
 R = "gpurun_out/valu"
 want = {"dtmf": ("tone_fast_kernel", 65536), "v29": ("v29_quad_kernel", 16384), "v17": ("v17_quad_kernel", 16384), "v27ter": ("v27ter_", 16384),
-        "echo": ("echo_", 131072), "mixed": ("tone_multi", 131072), "fsk": ("fsk_bank_kernel", 65536), "mct": ("mct_bank_kernel", 65536),
+        "echo": ("echo_", 131072), "mixed": ("tone_multi", 131072), "fsk": ("fsk_", 65536), "mct": ("mct_", 65536),
         "sigtone": ("sigtone_rx_kernel", 65536), "supertone": ("tone_fast_kernel", 65536), "dtmf_tx": ("tx_bank_kernel", 65536),
         "v29_tx": ("modemtx_bank_kernel", 65536), "awgn": ("awgn_bank_kernel", 65536)}
 out = {"note": "rocprofv3 --pmc SQ_* (kernel-trace only) means per launch of each workload's dominant kernel (the one with the most "
@@ -45,3 +45,5 @@ for key, (pat, n_ch) in want.items():
 json.dump(out, open(os.path.join(R, "valu_counters.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 PY
+# (the raw per-dispatch tables are tens of MB a workload: only the summary travels back)
+find gpurun_out/valu -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
