@@ -623,7 +623,7 @@ def bench_mct(args, dev, stream):
     idx = torch.arange(n_ch, device=dev)
     fsel = (torch.arange(nf, device=dev).unsqueeze(0) + ((idx//n_src) % nf).unsqueeze(1)) % nf
     frames = src[(idx % n_src).unsqueeze(1), fsel].permute(1, 0, 2).contiguous()
-    bank = engine.MctBank(engine.MCT_FAX_CED_OR_PREAMBLE, n_ch)
+    bank = engine.MctBank(int(os.environ.get("MCT_TYPE", engine.MCT_FAX_CED_OR_PREAMBLE)), n_ch)     # (MCT_TYPE: A-B runs of the other detectors)
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
     frame_bytes = n_ch*FRAME*2
 
