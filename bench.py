@@ -183,7 +183,11 @@ def end_to_end(engine, n_ch, frames_dev, device_index, steps, law=0):
     run(6, True)
     t0 = time.perf_counter()
     n_digits = run(steps, False)
-    dt = time.perf_counter() - t0
+    dt_py = time.perf_counter() - t0
+    # the same loop in C (spangpu_feed_run): what a C caller's media thread gets.  This harness's Python loop pays ~0.1 ms
+    # per tick for three ctypes calls and the interpreter lock on top of it, which is time the copy engine then idles.
+    ms_c, n_digits = feed.run(FRAME, steps, 1)
+    dt = ms_c*1e-3
     t0 = time.perf_counter()
     run(max(4, steps//4), True)
     dt_fill = (time.perf_counter() - t0)/max(4, steps//4)
@@ -203,12 +207,13 @@ def end_to_end(engine, n_ch, frames_dev, device_index, steps, law=0):
     h2d_ms = (time.perf_counter() - t0)/20*1e3
     return {
         "ms_per_step": dt*1e3/steps,
+        "ms_per_step_python_loop": dt_py*1e3/steps,
         "h2d_copy_alone_ms": h2d_ms,
         "value": float(steps)*n_ch*FRAME/dt/1e6,
         "unit": "Msamples/s",
         "steps": steps,
         "ms_per_step_with_fill": dt_fill*1e3,
-        "includes": "per step, pipelined over three pinned slots: H2D copy of the %d x %d %s frame (%.1f MB), the kernel, the digit "
+        "includes": "per step (tick loop in C, spangpu_feed_run()), pipelined over three pinned slots: H2D copy of the %d x %d %s frame (%.1f MB), the kernel, the digit "
                     "list made on the device, D2H of the list (4 bytes per digit; %d digits in all), one tick of latency"
                     % (n_ch, FRAME, "G.711" if law else "int16", n_ch*FRAME*bps/1e6, n_digits),
     }

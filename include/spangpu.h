@@ -227,6 +227,10 @@ SPANGPU_API void *spangpu_feed_acquire(spangpu_feed_t *feed);
 SPANGPU_API int spangpu_feed_commit(spangpu_feed_t *feed, int samples);
 SPANGPU_API int spangpu_feed_collect(spangpu_feed_t *feed, const uint32_t **entries);
 SPANGPU_API int spangpu_feed_outstanding(const spangpu_feed_t *feed);
+/* A caller's tick loop in C, for measurements: `ticks` x { acquire (the slots keep the frames they hold), commit, collect
+   with `lag` ticks (1 .. depth - 1) between a commit and the collect of its digits }, then the rest collected.
+   *elapsed_ms = wall time of the loop, *digits = entries collected. */
+SPANGPU_API int spangpu_feed_run(spangpu_feed_t *feed, int samples, int ticks, int lag, double *elapsed_ms, long long *digits);
 /* One byte per block and channel, written by the detector kernel itself beside its records (no extra launch): launches
    from now on fill dev_ptr as digits[block][channel] = the digit the block delivered, 0 = none (DTMF: digit accepted; Bell
    MF / R2 MF: the digit of a report).  What a multi-GPU run gathers: a quarter of the record words.  NULL turns it off. */

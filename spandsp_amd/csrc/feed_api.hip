@@ -10,6 +10,7 @@
 // entries of spangpu_bank_digit_events().  What crosses PCIe per tick is the frame down and four bytes per digit up,
 // not the 32-bit record of every block of every channel.
 #include <hip/hip_runtime.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -192,6 +193,46 @@ int spangpu_feed_collect(spangpu_feed_t *f, const uint32_t **entries)
 int spangpu_feed_outstanding(const spangpu_feed_t *f)
 {
     return f  ?  (int) (f->n_commit - f->n_collect)  :  SPANGPU_ERR_BAD_ARG;
+}
+
+// A caller's tick loop in C, for measurements (bench.py's `e2e`): `ticks` times acquire (the slots keep the frames they
+// hold: the caller's receive path is not part of this path) / commit / collect with `lag` ticks between a commit and the
+// collect of its digits (1 .. depth - 1), then the rest collected.  *elapsed_ms = wall time of the whole loop.
+int spangpu_feed_run(spangpu_feed_t *f, int samples, int ticks, int lag, double *elapsed_ms, long long *digits)
+{
+    if (f == nullptr  ||  ticks <= 0  ||  lag < 1  ||  lag >= f->depth  ||  spangpu_feed_outstanding(f) != 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments (lag in 1 .. depth - 1, nothing outstanding)");
+    struct timespec t0, t1;
+    long long seen = 0;
+    const uint32_t *entries;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0;  i < ticks;  i++)
+    {
+        if (spangpu_feed_acquire(f) == nullptr)
+            return SPANGPU_ERR_STATE;
+        int rc = spangpu_feed_commit(f, samples);
+        if (rc < 0)
+            return rc;
+        if (spangpu_feed_outstanding(f) > lag)
+        {
+            if ((rc = spangpu_feed_collect(f, &entries)) < 0)
+                return rc;
+            seen += rc;
+        }
+    }
+    while (spangpu_feed_outstanding(f) > 0)
+    {
+        const int rc = spangpu_feed_collect(f, &entries);
+        if (rc < 0)
+            return rc;
+        seen += rc;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (elapsed_ms)
+        *elapsed_ms = (t1.tv_sec - t0.tv_sec)*1e3 + (t1.tv_nsec - t0.tv_nsec)*1e-6;
+    if (digits)
+        *digits = seen;
+    return SPANGPU_OK;
 }
 
 }   // extern "C"

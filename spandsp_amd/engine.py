@@ -176,6 +176,7 @@ def lib():
             "spangpu_feed_commit": (ci, [vp, ci]),
             "spangpu_feed_collect": (ci, [vp, C.POINTER(vp)]),
             "spangpu_feed_outstanding": (ci, [vp]),
+            "spangpu_feed_run": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
             "spangpu_tune_modem_mapping": (ci, [ci]),
             "spangpu_tune_fsk_waves": (ci, [ci]),
             "spangpu_echo_lanes_per_channel": (ci, [vp]),
@@ -555,6 +556,13 @@ class Feed:
 
     def commit(self, samples):
         _check(lib().spangpu_feed_commit(self.h, samples))
+
+    def run(self, samples, ticks, lag=1):
+        """The tick loop in C over the frames the slots hold -> (milliseconds, digits collected)."""
+        ms = C.c_double()
+        digits = C.c_longlong()
+        _check(lib().spangpu_feed_run(self.h, samples, ticks, lag, C.byref(ms), C.byref(digits)))
+        return ms.value, digits.value
 
     def collect(self):
         """-> (channel, digit, block) uint32 arrays of the oldest outstanding tick, or None if there is none."""
