@@ -498,8 +498,9 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
     }
     // enough workgroups to put a wave on every SIMD (256 CUs x 4) before filling the waves
     const int cpw = (m->n_ch >= 64*1024)  ?  64  :  (m->n_ch >= 32*1024)  ?  32  :  16;
-    // lanes per channel: 1 = the one-channel-per-lane kernels, 4 = a quad per channel with 16 channels per wave,
-    // 8 = a quad per channel with 8 channels per wave (two waves per SIMD); spangpu_tune_modem_mapping() overrides
+    // lanes per channel: 1 = the one-channel-per-lane kernels, 4 = a quad per channel with 16 channels per wave (8 is taken as
+    // 4: the variant with 8 channels per wave, two waves per SIMD, was measured -- slower -- and removed);
+    // spangpu_tune_modem_mapping() overrides
     const int quad = (g_modem_mapping != 0)  ?  g_modem_mapping  :  (m->n_ch < 32*1024)  ?  4  :  1;
     const dim3 grid((m->n_ch + cpw - 1)/cpw);
     if (m->kind == SPANGPU_V29)

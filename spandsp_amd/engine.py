@@ -260,7 +260,7 @@ def tune_tone_kernel(variant):
 
 
 def tune_modem_mapping(mapping):
-    """0 = by bank size, 1 = one channel per lane, 4 / 8 = four lanes per channel with 16 / 8 channels per wavefront."""
+    """0 = by bank size, 1 = one channel per lane, 4 = four lanes per channel (16 channels per wavefront)."""
     _check(lib().spangpu_tune_modem_mapping(mapping))
 
 
