@@ -322,7 +322,202 @@ SPG_FN void v27_quad_run(Q &q, const V27Launch &L, const int ch, const V27QuadTa
     bool any_ready = false;
     bool restarted = false;
     bool baud_done = false;
-    for (int half = 0;  half < 2;  half++)
+    bool merged = false;
+    // ---- The calm baud.  A channel at the start of a baud whose carrier is up and not about to drop sends every sample on,
+    // so the whole baud follows from eq_put_step: k1 samples to its first T/2 instant, k2 more to its second (up to four
+    // each), the step of the pulse shaper at either, where the delay line stands, the carrier phase.  Then the samples of
+    // both halves are taken together -- lane r prepares samples r and r + 4, the carrier detector's recurrences run over
+    // them in order on copies (if the power falls under the carrier-off threshold on any channel of the wave, or a channel
+    // is elsewhere in its life, nothing of this is kept and the round goes the long way below) -- and the two instants'
+    // shaping filters run side by side: lanes 0 / 1 the real and imaginary sum of the first, lanes 2 / 3 of the second.
+    // The second half's samples overwrite the oldest entries of the first instant's window (the delay line is exactly one
+    // window long), at most four of them: every lane reads the four oldest taps of its window before they are written.
+    {
+        const int E = eq_put_step;
+        const int k1 = 1 + ((E > sets)  ?  1  :  0) + ((E > 2*sets)  ?  1  :  0) + ((E > 3*sets)  ?  1  :  0);
+        const int E1 = E - k1*sets + put_add;
+        const int k2 = 1 + ((E1 > sets)  ?  1  :  0) + ((E1 > 2*sets)  ?  1  :  0) + ((E1 > 3*sets)  ?  1  :  0);
+        const int need = k1 + k2;
+        const bool idle = (pos >= tn);
+        const bool act = !idle  &&  (signal_present > 0)  &&  (drop_pending == 0)  &&  (stage != V27_PARKED)  &&  (stage != V27_SYMBOL_ACQUISITION)
+                         &&  (baud_half == 0)  &&  (E <= 4*sets)  &&  (E1 <= 4*sets)  &&  (pos + need <= tn);
+        if (!q.any(!(act  ||  idle), 40)  &&  q.any(act, 41))
+        {
+            // lane r: samples r and r + 4 of the baud
+            const int cand0 = min(pos + role, kV29QuadTile - 1);
+            const int cand1 = min(pos + role + 4, kV29QuadTile - 1);
+            const uint32_t pw0 = C.pcm[cand0 >> 1];
+            const uint32_t pw1 = C.pcm[cand1 >> 1];
+            const int amp0 = (int) (short) ((cand0 & 1)  ?  (pw0 >> 16)  :  (pw0 & 0xFFFF));
+            const int amp1 = (int) (short) ((cand1 & 1)  ?  (pw1 >> 16)  :  (pw1 & 0xFFFF));
+            const int x0 = amp0 >> 1;
+            const int x1 = amp1 >> 1;
+            const int bef0 = q.prev1(x0, 42);
+            const int bef1 = q.prev1(x1, 43);
+            const int top0 = q.template bcast<3>(x0, 44);
+            const int dif0 = (int) (short) (x0 - ((role == 0)  ?  last_sample  :  bef0));
+            const int dif1 = (int) (short) (x1 - ((role == 0)  ?  top0  :  bef1));
+            const int sq0 = dif0*dif0;
+            const int sq1 = dif1*dif1;
+            const int ad0 = (int) (short) abs(dif0);
+            const int ad1 = (int) (short) abs(dif1);
+            const int at0 = (ad0 << 3) + (ad0 << 1);
+            const int at1 = (ad1 << 3) + (ad1 << 1);
+            int t_pr = power_reading;
+            int t_high = high_sample;
+            int t_low = low_samples;
+            int badf = 0;
+            const int off1 = max(carrier_off_power, 1);
+            const int m = act  ?  need  :  0;
+            auto step = [&](const int k, const int sq, const int ad, const int ad10)
+            {
+                if (k < m)
+                {
+                    const int pwr = t_pr + ((sq - t_pr) >> 4);
+                    badf |= (pwr < off1)  ?  1  :  0;
+                    const bool low = (ad10 < t_high);
+                    const int low_inc = t_low + 1;
+                    const bool wipe = low  &&  (low_inc > 120);
+                    t_pr = wipe  ?  0  :  pwr;
+                    t_high = low  ?  (wipe  ?  0  :  t_high)  :  max(t_high, ad);
+                    t_low = low  ?  (wipe  ?  0  :  low_inc)  :  0;
+                }
+            };
+            step(0, q.template bcast<0>(sq0, 45), q.template bcast<0>(ad0, 46), q.template bcast<0>(at0, 47));
+            step(1, q.template bcast<1>(sq0, 48), q.template bcast<1>(ad0, 49), q.template bcast<1>(at0, 50));
+            step(2, q.template bcast<2>(sq0, 51), q.template bcast<2>(ad0, 52), q.template bcast<2>(at0, 53));
+            step(3, q.template bcast<3>(sq0, 54), q.template bcast<3>(ad0, 55), q.template bcast<3>(at0, 56));
+            step(4, q.template bcast<0>(sq1, 57), q.template bcast<0>(ad1, 58), q.template bcast<0>(at1, 59));
+            step(5, q.template bcast<1>(sq1, 60), q.template bcast<1>(ad1, 61), q.template bcast<1>(at1, 62));
+            if (q.any(m > 6, 63))
+            {
+                step(6, q.template bcast<2>(sq1, 64), q.template bcast<2>(ad1, 65), q.template bcast<2>(at1, 66));
+                step(7, q.template bcast<3>(sq1, 67), q.template bcast<3>(ad1, 68), q.template bcast<3>(at1, 69));
+            }
+            if (!q.any(act  &&  badf != 0, 70))
+            {
+                merged = true;
+                // the sample the baud ends on, for the next difference
+                const int e0 = q.template bcast<0>((need > 4)  ?  x1  :  x0, 71);
+                const int e1 = q.template bcast<1>((need > 5)  ?  x1  :  x0, 72);
+                const int e2 = q.template bcast<2>((need > 6)  ?  x1  :  x0, 73);
+                const int e3 = q.template bcast<3>((need > 7)  ?  x1  :  x0, 74);
+                const int lastq = (need - 1) & 3;
+                const int x_end = (lastq == 0)  ?  e0  :  (lastq == 1)  ?  e1  :  (lastq == 2)  ?  e2  :  e3;
+                // the first half's samples into the delay line
+                const int j0 = role;
+                const int j1 = role + 4;
+                int i0 = rrc_step + j0;
+                i0 = (i0 >= kRrcLen)  ?  (i0 - kRrcLen)  :  i0;
+                int i1 = rrc_step + j1;
+                i1 = (i1 >= kRrcLen)  ?  (i1 - kRrcLen)  :  i1;
+                const float f0 = (float) amp0;
+                const float f1 = (float) amp1;
+                if (act  &&  j0 < k1)
+                {
+                    C.rrc[i0].x = f0;
+                    C.rrc[kRrcLen + i0].y = f0;
+                }
+                if (act  &&  j1 < k1)
+                {
+                    C.rrc[i1].x = f1;
+                    C.rrc[kRrcLen + i1].y = f1;
+                }
+                q.sync(75);
+                // this lane's instant: where the delay line stands then, the shaper's step, the carrier phase
+                const bool second = (role & 2) != 0;
+                const int taken = second  ?  need  :  k1;
+                int rs = rrc_step + taken;
+                rs = (rs >= kRrcLen)  ?  (rs - kRrcLen)  :  rs;
+                const int e_aft = second  ?  (E1 - k2*sets)  :  (E - k1*sets);
+                const int stp = min(-e_aft, sets - 1);
+                const float *y = ((const float *) &T.rrc[act  ?  stp  :  0]) + (role & 1);
+                const float2 *xw = &C.rrc[act  ?  rs  :  0];
+                float2 xo[4];
+                SPG_UNROLL
+                for (int i = 0;  i < 4;  i++)
+                    xo[i] = xw[i];
+                q.sync(76);
+                if (act  &&  j0 >= k1  &&  j0 < need)
+                {
+                    C.rrc[i0].x = f0;
+                    C.rrc[kRrcLen + i0].y = f0;
+                }
+                if (act  &&  j1 >= k1  &&  j1 < need)
+                {
+                    C.rrc[i1].x = f1;
+                    C.rrc[kRrcLen + i1].y = f1;
+                }
+                q.sync(77);
+                float v;
+                {
+                    f32x2v a = {0.0f, 0.0f};
+                    {
+                        float ys[4];
+                        SPG_UNROLL
+                        for (int i = 0;  i < 4;  i++)
+                            ys[i] = y[2*i*kV27MaxSets];
+                        SPG_UNROLL
+                        for (int i = 0;  i < 4;  i++)
+                            a += (f32x2v) {xo[i].x, xo[i].y}*(f32x2v) {ys[i], ys[i]};
+                    }
+                    SPG_UNROLL
+                    for (int i0b = 4;  i0b < kRrcLen;  i0b += 8)
+                    {
+                        float2 xs[8];
+                        float ys[8];
+                        SPG_UNROLL
+                        for (int i = 0;  i < 8;  i++)
+                        {
+                            if (i0b + i < kRrcLen)
+                            {
+                                xs[i] = xw[i0b + i];
+                                ys[i] = y[2*(i0b + i)*kV27MaxSets];
+                            }
+                        }
+                        SPG_UNROLL
+                        for (int i = 0;  i < 8;  i++)
+                        {
+                            if (i0b + i < kRrcLen)
+                                a += (f32x2v) {xs[i].x, xs[i].y}*(f32x2v) {ys[i], ys[i]};
+                        }
+                    }
+                    v = a.x + a.y;
+                }
+                const float s_mine = v*agc_scaling;
+                const float s_other = q.swap1f(s_mine, 78);
+                if (act)
+                {
+                    const float sre = (role & 1)  ?  s_other  :  s_mine;
+                    const float sim = (role & 1)  ?  s_mine  :  s_other;
+                    const uint32_t cp = carrier_phase + (uint32_t) (taken - 1)*(uint32_t) carrier_phase_rate;
+                    const float dre = T.sine[(uint32_t) (cp + (1u << 30)) >> 21];
+                    const float dim = T.sine[cp >> 21];
+                    const float2 h = make_float2(sre*dre - sim*dim, -sre*dim - sim*dre);
+                    const int e_at = (eq_step + (second  ?  1  :  0)) & (EQN - 1);
+                    if ((role & 1) == 0)
+                    {
+                        C.u[e_at] = h;
+                        C.u[2*EQN + e_at] = h;
+                    }
+                    power_reading = t_pr;
+                    high_sample = t_high;
+                    low_samples = t_low;
+                    last_sample = x_end;
+                    int rs2 = rrc_step + need;
+                    rrc_step = (rs2 >= kRrcLen)  ?  (rs2 - kRrcLen)  :  rs2;
+                    pos += need;
+                    eq_put_step = E1 - k2*sets + put_add;
+                    eq_step = (eq_step + 2) & (EQN - 1);
+                    carrier_phase += (uint32_t) need*(uint32_t) carrier_phase_rate;
+                    any_ready = true;
+                    baud_done = true;
+                }
+                q.sync(79);
+            }
+        }
+    }
+    for (int half = merged  ?  2  :  0;  half < 2;  half++)
     {
     const bool take = (half == 1)  ||  (baud_half == 0);
     SPG_PROF_STAMP(0);
