@@ -418,7 +418,7 @@ SPANGPU_API int spangpu_modem_set_signal_cutoff(spangpu_modem_t *modem, int chan
 /* The constant tables the modem receivers use, as built by this library (host code; see modem_api.hip for `which`). */
 SPANGPU_API int spangpu_modem_table(int which, float *out, int max);
 /* Tuning / A-B testing: how the receiver kernels map channels to lanes from now on: 0 = by bank size (four lanes per channel
-   below 32 768 channels), 1 = one channel per lane, 4 = four lanes per channel, 16 channels per wavefront (8 is accepted
+   below 65 536 channels), 1 = one channel per lane, 4 = four lanes per channel, 16 channels per wavefront (8 is accepted
    and means 4).  Results are identical. */
 SPANGPU_API int spangpu_tune_modem_mapping(int mapping);
 SPANGPU_API int spangpu_v17_rx_maps(uint8_t *maps, uint8_t *map_4800);

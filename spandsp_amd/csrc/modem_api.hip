@@ -501,7 +501,10 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
     // lanes per channel: 1 = the one-channel-per-lane kernels, 4 = a quad per channel with 16 channels per wave (8 is taken as
     // 4: the variant with 8 channels per wave, two waves per SIMD, was measured -- slower -- and removed);
     // spangpu_tune_modem_mapping() overrides
-    const int quad = (g_modem_mapping != 0)  ?  g_modem_mapping  :  (m->n_ch < 32*1024)  ?  4  :  1;
+    // (measured, 16 384-channel rounds of the quad kernels against the one-lane kernels, V.29 / V.17 / V.27ter: 32 768 channels
+    // 0.32 / 0.40 / 0.24 ms against 0.75 / 0.86 / 0.26; 49 152 channels 0.47 / 0.59 / 0.34 against 0.75 / 0.84 / 0.48; from
+    // 65 536 channels the full-wave one-lane kernels win: 0.45 / 0.92 / 0.29 ms against four rounds of 0.156 / 0.215 / 0.111)
+    const int quad = (g_modem_mapping != 0)  ?  g_modem_mapping  :  (m->n_ch < 64*1024)  ?  4  :  1;
     const dim3 grid((m->n_ch + cpw - 1)/cpw);
     if (m->kind == SPANGPU_V29)
     {

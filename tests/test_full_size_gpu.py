@@ -47,6 +47,47 @@ def test_v29_16384_channels(built):
     bank.close()
 
 
+@pytest.mark.parametrize("modem,bit_rate,n_frames", [("v29", 9600, 22), ("v27ter", 4800, 48), ("v17", 14400, 84)])
+def test_quad_kernels_40037_channels(built, modem, bit_rate, n_frames):
+    """A bank between the headline size and the full-wave kernels' (four lanes per channel up to 65 535 channels: several
+    workgroups per CU one after the other, a last workgroup and a last wave that are not full): every channel's events
+    against the oracle's for its signal, state words of a few."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    import importlib
+    use_golden_modem_tables()
+    n_ch, V = 40037, 53
+    sigs = importlib.import_module("test_%s_gpu" % modem).channel_signals
+    base = sigs(bit_rate, V, seed=79)[:, :n_frames*160]
+    reps = (n_ch + V - 1)//V
+    sig = np.tile(base, (reps, 1))[:n_ch]
+    O = {"v29": orc.V29, "v27ter": orc.V27ter, "v17": orc.V17}[modem]
+    B = {"v29": engine.V29Bank, "v27ter": engine.V27terBank, "v17": engine.V17Bank}[modem]
+    bank = B(n_ch, bit_rate)
+    want = []
+    for c in range(V):
+        o = O(bit_rate)
+        per = []
+        for k in range(n_frames):
+            o.sink.clear()
+            o.rx(base[c, k*160:(k + 1)*160])
+            per.append(o.sink.events()["a"].astype(np.int8))
+        want.append((per, o.snapshot()))
+    total = 0
+    for k in range(n_frames):
+        bank.rx_host(sig[:, k*160:(k + 1)*160])
+        ev = bank.events()
+        for c in range(n_ch):
+            assert np.array_equal(ev[c], want[c % V][0][k]), (k, c)
+        total += sum(len(e) for e in ev[:V])
+    assert total > 100*V
+    for c in (0, 15, 16, 63, 64, 16383, 16384, 32767, 32768, n_ch - 2, n_ch - 1):
+        f, w = bank.get_state(c)
+        of, ow = want[c % V][1]
+        assert np.array_equal(w, ow) and np.array_equal(bits(f), bits(of)), c
+    bank.close()
+
+
 def test_v29_full_wave_kernel_65797_channels(built):
     """Banks of 64 K channels and more run the full-wave kernel (four waves per workgroup sharing the tables, the RRC delay
     line as packed int16 pairs): a bank that does not fill its last workgroup nor its last wave, every channel against
