@@ -32,6 +32,7 @@ struct spangpu_feed_s
     int law;                    // 0 = 16 bit linear, SPANGPU_G711_ALAW / _ULAW = one byte per sample
     int depth;
     int cap;                    // digit list entries per tick (no tick can make more: blocks per frame x channels)
+    int quick;                  // entries that travel back with every tick; a livelier tick has the rest fetched when it is collected
     long long stride;           // samples per row of the staging buffers (rows 16-byte aligned)
     size_t frame_bytes;
     void *h_stage[kFeedMaxDepth];
@@ -96,6 +97,9 @@ int spangpu_feed_create(spangpu_feed_t **out, spangpu_bank_t *bank, int device, 
     f->frame_bytes = (size_t) f->stride*bps*n_ch;
     // a block is at least 64 samples long on every detector kind: blocks per frame (+1 for one in progress)
     f->cap = n_ch*(max_samples/64 + 2);
+    f->quick = (n_ch/8 > 4096)  ?  n_ch/8  :  4096;
+    if (f->quick > f->cap)
+        f->quick = f->cap;
     bool ok = (hipSetDevice(device) == hipSuccess)  &&  (hipStreamCreateWithFlags(&f->copy_stream, hipStreamNonBlocking) == hipSuccess);
     for (int k = 0;  ok  &&  k < depth;  k++)
     {
@@ -161,7 +165,7 @@ int spangpu_feed_commit(spangpu_feed_t *f, int samples)
         return rc;
     if ((rc = spangpu_bank_digit_events(f->bank, f->d_list[slot], f->cap)) < 0)
         return rc;
-    FEED_TRY(hipMemcpyAsync(f->h_list[slot], f->d_list[slot], (size_t) (1 + f->cap)*sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
+    FEED_TRY(hipMemcpyAsync(f->h_list[slot], f->d_list[slot], (size_t) (1 + f->quick)*sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
     FEED_TRY(hipEventRecord(f->ev_done[slot], bs));
     f->busy[slot] = true;
     f->n_commit++;
@@ -186,6 +190,12 @@ int spangpu_feed_collect(spangpu_feed_t *f, const uint32_t **entries)
     const uint32_t n = f->h_list[slot][0];
     if (n > (uint32_t) f->cap)
         return spangpu_set_error(SPANGPU_ERR_STATE, "digit list overflow");
+    if (n > (uint32_t) f->quick)
+    {
+        // more digits than travel with every tick (an eighth of the channels delivering one in the same 20 ms): the rest now
+        FEED_TRY(hipMemcpy(f->h_list[slot] + 1 + f->quick, f->d_list[slot] + 1 + f->quick, (size_t) (n - (uint32_t) f->quick)*sizeof(uint32_t),
+                           hipMemcpyDeviceToHost));
+    }
     *entries = f->h_list[slot] + 1;
     return (int) n;
 }

@@ -119,3 +119,27 @@ def test_feed_run_is_the_same_loop_in_c(built):
         feed.close()
         bank.close()
     assert counts[0] == counts[1] > 0
+
+
+def test_feed_tick_with_more_digits_than_travel_with_a_tick(built):
+    """Only a bounded part of the digit list comes back with every tick; when every line of a big bank delivers a digit in
+    the same 20 ms (lines in step), collect() fetches the rest."""
+    from spandsp_amd import engine
+    n_ch, frame, ticks = 40000, 160, 10
+    one, _ = synth.dtmf_channels(1, frame*ticks, seed=93)
+    bank = engine.ToneBank(engine.DTMF, n_ch)
+    feed = engine.Feed(bank, frame, depth=2)
+    per_tick = []
+    for t in range(ticks):
+        buf = feed.slot()
+        buf[:, :frame] = one[0, t*frame:(t + 1)*frame]          # every line the same signal
+        feed.commit(frame)
+        c, d, b = feed.collect()
+        per_tick.append((c, d, b))
+    full = [x for x in per_tick if len(x[0]) > 0]
+    assert full, "the line carries at least one digit"
+    for c, d, b in full:
+        assert len(c) == n_ch and np.array_equal(np.sort(c), np.arange(n_ch, dtype=np.uint32))
+        assert len(set(d.tolist())) == 1 and len(set(b.tolist())) == 1
+    feed.close()
+    bank.close()
