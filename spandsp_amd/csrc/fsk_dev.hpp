@@ -683,11 +683,16 @@ __device__ __forceinline__ void fsk_bit_block(FskBitSide &t, int32_t *win, const
     const uint32_t kinds = (uint32_t) msg[lane];
     if (__builtin_expect(__all(todo == 8), 1))
     {
+        // (the message taken whole: its reads would not move across the window writes by themselves)
+        int32_t sums[8];
+#pragma unroll
+        for (int k = 0;  k < 8;  k++)
+            sums[k] = msg[(1 + k)*64 + lane];
 #pragma unroll
         for (int k = 0;  k < 8;  k++)
         {
             const int32_t sum1 = fsk_correlate(t.dotre, t.dotim, win + (t.ptr*4 + 2)*64 + lane, a[k], c[k], q[k], t.shift);
-            const int32_t sum0 = msg[(1 + k)*64 + lane];
+            const int32_t sum0 = sums[k];
             const bool on = fsk_bits<FRAMED>(t.b, (int) ((kinds >> (4*k)) & 7u), (sum0 < sum1)  ?  1  :  0, emit);
             const int32_t next = (t.ptr + 1 >= span)  ?  0  :  (t.ptr + 1);
             t.ptr = on  ?  next  :  t.ptr;
