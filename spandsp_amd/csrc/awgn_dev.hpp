@@ -32,6 +32,11 @@ enum
     kAwgnWords = AW_R + 2*97
 };
 
+#ifndef SPG_AWGN_WAITING
+#define SPG_AWGN_WAITING 4
+#endif
+constexpr int kAwgnWaiting = SPG_AWGN_WAITING;     // accepted candidates a lane may hold ahead of the wave (awgn_bank_kernel)
+
 struct AwgnLaunch
 {
     int32_t *st;
@@ -138,19 +143,70 @@ __global__ __launch_bounds__(64) void awgn_bank_kernel(AwgnLaunch L)
         awgn_put(L, row, i++, awgn_sample(g, amp2));
         odd = 1;
     }
-    for (  ;  i + 1 < L.samples;  i += 2)
+    // The pairs of this call.  The polar method rejects 21 % of its candidates, and a wave that makes every pair in step
+    // repeats each until its slowest lane accepts (3.7 rounds a pair against 1.27 on average).  So the two halves of a pair
+    // are uncoupled: a lane draws candidates -- its generator's calls in the reference's order, whatever the other lanes do
+    // -- and keeps up to kAwgnWaiting accepted ones waiting; the expensive half (log, divide, square root, scaling, rounding,
+    // the stores) runs when every lane has one waiting, for all lanes at once.
+    const int pairs = (L.samples - i + 1) >> 1;         // pairs this lane still makes (the last one may be used by half)
+    int made = 0;
+    int drawn = 0;
+    int waiting = 0;
+    double w1[kAwgnWaiting];
+    double w2[kAwgnWaiting];
+    double wr[kAwgnWaiting];
+#pragma unroll
+    for (int k = 0;  k < kAwgnWaiting;  k++)
     {
-        double first;
-        awgn_pair(g, col, first, amp2);
-        awgn_put(L, row, i, awgn_sample(g, first));
-        awgn_put(L, row, i + 1, awgn_sample(g, amp2));
+        w1[k] = 0.0;
+        w2[k] = 0.0;
+        wr[k] = 1.0;
     }
-    if (i < L.samples)
+    while (__any(made < pairs))
     {
-        double first;
-        awgn_pair(g, col, first, amp2);
-        awgn_put(L, row, i, awgn_sample(g, first));
-        odd = 0;
+        if (drawn < pairs  &&  waiting < kAwgnWaiting)
+        {
+            const double v1 = 2.0*awgn_uniform(g, col) - 1.0;
+            const double v2 = 2.0*awgn_uniform(g, col) - 1.0;
+            const double r = v1*v1 + v2*v2;
+            if (!(r >= 1.0))
+            {
+#pragma unroll
+                for (int k = 0;  k < kAwgnWaiting;  k++)
+                {
+                    const bool here = (waiting == k);
+                    w1[k] = here  ?  v1  :  w1[k];
+                    w2[k] = here  ?  v2  :  w2[k];
+                    wr[k] = here  ?  r  :  wr[k];
+                }
+                waiting++;
+                drawn++;
+            }
+        }
+        if (__all(made >= pairs  ||  waiting >= 1))
+        {
+            if (made < pairs)
+            {
+                const double r = sqrt(-2.0*glibc_log(wr[0], g.logtab)/wr[0]);
+                const double first = w2[0]*r;
+                amp2 = w1[0]*r;
+                awgn_put(L, row, i, awgn_sample(g, first));
+                if (i + 1 < L.samples)
+                    awgn_put(L, row, i + 1, awgn_sample(g, amp2));
+                else
+                    odd = 0;                            // the pair's second half waits for the next call
+                i += 2;
+                made++;
+#pragma unroll
+                for (int k = 0;  k + 1 < kAwgnWaiting;  k++)
+                {
+                    w1[k] = w1[k + 1];
+                    w2[k] = w2[k + 1];
+                    wr[k] = wr[k + 1];
+                }
+                waiting--;
+            }
+        }
     }
 
     for (int j = 0;  j < 97;  j++)
