@@ -499,8 +499,12 @@ float spangpu_goertzel_fac(float freq_hz)
     return 2.0f*cosf((float) (two_pi*ratio));
 }
 
+static int cadence_catch_up(spangpu_bank_t *b);
+
 static void free_outputs(spangpu_bank_t *b)
 {
+    if (b->cur_rec == b->rec)
+        b->cur_rec = nullptr;           // (a records buffer of the caller's stays what it is)
     if (b->rec) (void) hipFree(b->rec);
     if (b->rec_energy) (void) hipFree(b->rec_energy);
     if (b->rec_dur) (void) hipFree(b->rec_dur);
@@ -522,6 +526,15 @@ static int ensure_outputs(spangpu_bank_t *b, int maxb)
 {
     if (maxb <= b->maxb_cap)
         return SPANGPU_OK;
+    // The records of the launch before may still be owed to the cadence matcher (cadence_catch_up()): it reads them
+    // from the buffer that is about to be freed, so it runs now, and has finished before the buffer goes.
+    if (b->rec)
+    {
+        const int caught = cadence_catch_up(b);
+        if (caught != SPANGPU_OK)
+            return caught;
+        HIP_TRY(hipStreamSynchronize(b->stream));
+    }
     free_outputs(b);
     const size_t n = (size_t) maxb*b->n_ch;
     HIP_TRY(hipMalloc(&b->rec, n*sizeof(uint32_t)));

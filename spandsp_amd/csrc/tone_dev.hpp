@@ -254,17 +254,52 @@ struct Bank
 #undef SPG_C_GAP
 
     // goertzel_result() for every bin: one zero sample, energy, reset (tone_detect.c:160-205)
+    // Written phase by phase over all pairs (the same nine roundings per pair, in the same order:
+    // q = fac*p - a;  r = ((q*q + p*p) - (p*q)*fac)*2): a pair's chain taken alone has every packed operation wait on
+    // the one before it, which hipcc pads with s_nop -- a full issue slot each for a lone wave.
     __device__ __forceinline__ void finish(const f32x2 (&fac)[NP], float (&e)[NBL])
     {
+        f32x2 q[NP];
+        f32x2 t[NP];
+        f32x2 u[NP];
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
+            q[i] = fac[i]*b[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
+            q[i] = q[i] - a[i];                 // becomes v3 (b holds what becomes v2)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
+            t[i] = q[i]*q[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
+            u[i] = b[i]*b[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
+            t[i] = t[i] + u[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
+            u[i] = b[i]*q[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
+            u[i] = u[i]*fac[i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0;  i < NP;  i++)
+            t[i] = t[i] - u[i];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0;  i < NP;  i++)
         {
-            const f32x2 p = b[i];               // becomes v2
-            const f32x2 q = fac[i]*p - a[i];    // becomes v3
-            f32x2 r = q*q + p*p - p*q*fac[i];
-            r *= 2.0f;
-            e[2*i] = r.x;
-            e[2*i + 1] = r.y;
+            t[i] *= 2.0f;
+            e[2*i] = t[i].x;
+            e[2*i + 1] = t[i].y;
             a[i] = f32x2{0.0f, 0.0f};
             b[i] = f32x2{0.0f, 0.0f};
         }
@@ -328,6 +363,26 @@ __device__ __forceinline__ uint8_t tone_digit_byte(uint32_t recw)
     const uint32_t code = (recw >> 8) & 0xFF;
     const bool ev = DTMF  ?  ((flags & kBlkChange)  &&  code != 0)  :  ((flags & kBlkReport) != 0);
     return (uint8_t) (ev  ?  code  :  0u);
+}
+
+// v_max_f32 / v_min_f32 / v_max3_f32 on operands the caller knows to be ordinary numbers
+__device__ __forceinline__ float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 // ---- DTMF (src/dtmf.c:132-361) ------------------------------------------------------
@@ -467,6 +522,72 @@ struct DtmfDet
         w0 = ((uint32_t) last_hit << 16) | ((uint32_t) in_digit << 24);       // cs = 0
         return make_rec(raw, code, flags);
     }
+
+    // The same decision and debounce for the production case -- bank-wide thresholds, no trace, no per-block energy
+    // or duration reports (the streaming kernels test that once per launch) -- in a third of the instructions:
+    //   * the strongest tone of a group is a max tree, the runner-up the second order statistic of the four
+    //     (max(min(a,b), min(c,d), min(max(a,b), max(c,d)))), and "some other tone within 6.309 of the peak"
+    //     (dtmf.c:243-246) is the one test runner_up*6.309f > peak: x -> fl(x*6.309f) is monotonic, so if any tone
+    //     passes that test the largest of them does;
+    //   * which tone the peak was is only looked up to form the key: the first one equal to it, which is what the
+    //     reference's strict > scan from tone 0 keeps (dtmf.c:211-223).
+    // v_max / v_min drop a NaN operand where the reference's compares carry it, so energies that are not all
+    // ordinary numbers (a state imported with infinities in it) go to decide(); `plain_ok` is that test, made by the
+    // caller for the whole wave.
+    static constexpr bool kLean = true;
+    __device__ static __forceinline__ bool lean_inputs_ok(const float (&e)[NB])
+    {
+        const float s = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+        return s == s;          // a NaN anywhere, or infinities of both signs, make the sum a NaN
+    }
+    __device__ __forceinline__ uint32_t decide_plain(const ToneLaunch &L, const float (&e)[NB], float &energy, uint32_t &w0)
+    {
+        // (asm: written with the builtins, hipcc canonicalises every operand first -- a v_max_f32 x, x each -- for the
+        // signalling NaNs the caller has already excluded)
+        const float rh01 = vmax(e[0], e[1]);
+        const float rl01 = vmin(e[0], e[1]);
+        const float rh23 = vmax(e[2], e[3]);
+        const float rl23 = vmin(e[2], e[3]);
+        const float ch01 = vmax(e[4], e[5]);
+        const float cl01 = vmin(e[4], e[5]);
+        const float ch23 = vmax(e[6], e[7]);
+        const float cl23 = vmin(e[6], e[7]);
+        const float er = vmax(rh01, rh23);
+        const float ec = vmax(ch01, ch23);
+        const float sr = vmax3(rl01, rl23, vmin(rh01, rh23));
+        const float sc = vmax3(cl01, cl23, vmin(ch01, ch23));
+        bool ok = (er >= L.threshold)  &  (ec >= L.threshold);
+        ok = ok  &  (ec < er*L.reverse_twist)  &  (ec*L.normal_twist > er);
+        ok = ok  &  !(sr*6.309f > er)  &  !(sc*6.309f > ec);
+        ok = ok  &  ((er + ec) > 83.868f*energy);
+        constexpr uint32_t kRow0 = '1' | ('2' << 8) | ('3' << 16) | ((uint32_t) 'A' << 24);
+        constexpr uint32_t kRow1 = '4' | ('5' << 8) | ('6' << 16) | ((uint32_t) 'B' << 24);
+        constexpr uint32_t kRow2 = '7' | ('8' << 8) | ('9' << 16) | ((uint32_t) 'C' << 24);
+        constexpr uint32_t kRow3 = '*' | ('0' << 8) | ('#' << 16) | ((uint32_t) 'D' << 24);
+        // (selects, not branches: all lanes are here)
+        uint32_t keys = __builtin_unpredictable(e[2] == er)  ?  kRow2  :  kRow3;
+        keys = __builtin_unpredictable(e[1] == er)  ?  kRow1  :  keys;
+        keys = __builtin_unpredictable(e[0] == er)  ?  kRow0  :  keys;
+        uint32_t shift = __builtin_unpredictable(e[6] == ec)  ?  16u  :  24u;
+        shift = __builtin_unpredictable(e[5] == ec)  ?  8u  :  shift;
+        shift = __builtin_unpredictable(e[4] == ec)  ?  0u  :  shift;
+        const uint32_t raw = ok  ?  ((keys >> shift) & 0xFFu)  :  0u;
+
+        // dtmf.c:304-347
+        const uint32_t last_hit = (w0 >> 16) & 0xFFu;
+        const uint32_t in_digit = w0 >> 24;
+        const bool chg = (raw != in_digit)  &  (last_hit != in_digit);
+        const uint32_t conf = (raw == last_hit)  ?  raw  :  0u;       // a hit counts when the block before had it too
+        const uint32_t hit = chg  ?  conf  :  raw;
+        const uint32_t now = chg  ?  conf  :  in_digit;
+        uint32_t flags = kBlkValid;
+        flags |= chg  ?  kBlkChange  :  0;
+        flags |= (chg  &  ((in_digit | conf) != 0))  ?  kBlkReport  :  0;
+        flags |= (chg  &  (in_digit != 0)  &  (conf == 0))  ?  kBlkToneOff  :  0;
+        energy = 0.0f;
+        w0 = (hit << 16) | (now << 24);                               // cs = 0
+        return raw | (now << 8) | (flags << 16);
+    }
 };
 
 // ---- Bell MF / R2 MF (src/bell_r2_mf.c:507-673, :750-880) -------------------------------
@@ -516,6 +637,7 @@ __device__ __forceinline__ int mf_pick_pair(const float (&e)[6], float threshold
 
 struct BellMfDet
 {
+    static constexpr bool kLean = false;
     static constexpr int NB = 6;
     static constexpr bool kEnergy = false;
     static constexpr bool kDuration = false;
@@ -568,6 +690,7 @@ struct BellMfDet
 
 struct R2MfDet
 {
+    static constexpr bool kLean = false;
     static constexpr int NB = 6;
     static constexpr bool kEnergy = false;
     static constexpr bool kDuration = false;
@@ -606,6 +729,7 @@ struct R2MfDet
 template <int NBINS, bool SUPER>
 struct MultiDet
 {
+    static constexpr bool kLean = false;
     static constexpr int NB = NBINS;
     // the generic bank keeps the block's total energy too: the Goertzel users outside tone_detect.c gate their
     // decisions on it (v18.c:1559,1597, ademco_contactid.c:903,920)

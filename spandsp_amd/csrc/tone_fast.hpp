@@ -108,6 +108,10 @@ __device__ __forceinline__ void seg_barrier()
 //   finished segment s-1 when they arrive), request segment s+R-1 into the slot segment s-1 occupied.
 // Every round issues NDMA*WPB instructions whatever the number of live consumer waves (rows past the bank re-read its
 // last row into slots nobody reads), so that the s_waitcnt counts are compile-time constants.
+// (Round 4, measured and dropped: "touches" -- one dword per row requested by the loader two segments ahead, so that the
+// DMA of every segment finds its line in the L2; the loader's stamps show every other segment's DMA taking 2 900 - 3 100
+// ticks from issue to landed against 800 - 900 for the ones in between.  With the touches all of them landed in 800, and
+// the launch took 12.16 us instead of 11.66 (profiles/r4_probe_ab.log).)
 template <int LPC, int R, bool G711, bool NT, int WPB, int ABL>
 __device__ __forceinline__ void tone_loader(const ToneLaunch &L, const int wg, char *lds_raw)
 {
@@ -189,7 +193,7 @@ __device__ __forceinline__ void tone_loader(const ToneLaunch &L, const int wg, c
 
 // The body of the streaming kernel for workgroup `wg` of the bank described by L.  Preconditions (the host checks
 // them and otherwise launches tone_bank_kernel): L.layout == 0, L.aligned16, L.samples > 0, and linear PCM unless
-// G711.  ABL is the tuning-probe knob of tools/probe.hip (bit 3: no recurrence, bit 4: no DMA, bit 5: timestamps, bit 10: no state traffic); the
+// G711.  ABL is the tuning-probe knob of tools/probe.hip (bit 3: no recurrence, bit 4: no DMA, bit 5: timestamps, bit 10: no state traffic, bit 11: the general block-end decision only); the
 // library instantiates ABL = 0 only.
 template <class Det, int LPC, int R, bool G711, bool NT, int WPB, int ABL = 0, bool LDR = false>
 __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg, char *lds_raw)
@@ -508,8 +512,12 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         return x01;
     };
     constexpr int PPC = SPC/2;                      // sample pairs per chunk
-    auto end_block = [&]()
+    // the production case of a block end (wave-uniform): nothing but the decision itself is asked for, with the
+    // bank's own thresholds -- Det::decide_plain() then does what Det::decide() does in a third of the instructions
+    const bool plain = Det::kLean  &&  !L.trace  &&  !L.chan_parms  &&  !L.rec_energy  &&  !L.realtime;
+    auto end_block = [&](auto uni_tag)
     {
+        constexpr bool UNI = decltype(uni_tag)::value;      // every lane of the wave is here, with the same nb
         if (Det::kDuration)
         {
             if (w1 < INT_MAX - take_acc)
@@ -537,15 +545,40 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
                     e[NBH + i] = sub  ?  el[i]  :  other;
             }
         }
-        const uint32_t recw = det.decide(L, e, energy, w0, w1, (int) ch, nb, store);
+        uint32_t recw;
+        bool lean = false;
+        if constexpr (Det::kLean  &&  LPC == 1  &&  !(ABL & 2048))
+            lean = plain  &&  __all(Det::lean_inputs_ok(e));
+        if (lean)
+        {
+            if constexpr (Det::kLean)
+                recw = det.decide_plain(L, e, energy, w0);
+        }
+        else
+        {
+            recw = det.decide(L, e, energy, w0, w1, (int) ch, nb, store);
+        }
         // The record words of the first two blocks of a call (all there are in a 160-sample frame) wait in registers
         // for the write-back: a store here would stand in the memory pipeline's queue with the sample loop behind it.
-        if (nb == 0)
-            rec0 = recw;
-        else if (nb == 1)
-            rec1 = recw;
-        else if (store)
-            *(uint32_t *) ((char *) (L.rec + (size_t) nb*nch) + ch4) = recw;
+        if constexpr (UNI)
+        {
+            const int nbu = __builtin_amdgcn_readfirstlane(nb);
+            if (nbu == 0)
+                rec0 = recw;
+            else if (nbu == 1)
+                rec1 = recw;
+            else if (store)
+                *(uint32_t *) ((char *) (L.rec + (size_t) nbu*nch) + ch4) = recw;
+        }
+        else
+        {
+            if (nb == 0)
+                rec0 = recw;
+            else if (nb == 1)
+                rec1 = recw;
+            else if (store)
+                *(uint32_t *) ((char *) (L.rec + (size_t) nb*nch) + ch4) = recw;
+        }
         if ((ABL & kToneDigits)  &&  L.digits  &&  store)
             L.digits[(size_t) nb*nch + ch] = tone_digit_byte<Det::kDuration>(recw);
         nb++;
@@ -607,7 +640,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
             take_acc += 4*SPC;
             if (cs_s == block)
             {
-                end_block();
+                end_block(std::true_type());
                 cs_s = 0;
             }
             cs = cs_s;
@@ -701,7 +734,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
                 take_acc += m;
                 if (cs_s == block)
                 {
-                    end_block();
+                    end_block(std::true_type());
                     cs_s = 0;
                 }
             }
@@ -724,7 +757,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
                 take_acc++;
                 if (cs >= block)
                 {
-                    end_block();
+                    end_block(std::false_type());
                     cs = 0;
                 }
             }
@@ -735,7 +768,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
     }
     if (L.force_end)
     {
-        end_block();
+        end_block(std::false_type());
         cs = 0;
     }
     if (Det::kDuration)
@@ -747,8 +780,37 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
     // ---- write back -----------------------------------------------------------------------------------
     unsigned st4 = ch4;
     asm volatile("" : "+v"(st4));                   // a fresh value: the offsets of the loads are not kept alive for this
-    auto stf = [&](float *base, float v) { *(float *) ((char *) base + st4) = v; };
-    auto sti = [&](int32_t *base, int32_t v) { *(int32_t *) ((char *) base + st4) = v; };
+    // (probe bits 14 / 15 / 16: the state stores non-temporal / left out altogether / write-through)
+    auto stf = [&](float *base, float v)
+    {
+        if (ABL & 32768)
+            return;
+        if (ABL & 65536)
+            asm volatile("global_store_dword %0, %1, %2 sc0 sc1" :: "v"(st4), "v"(v), "s"(base) : "memory");
+        else if (ABL & 262144)
+            asm volatile("global_store_dword %0, %1, %2 sc1" :: "v"(st4), "v"(v), "s"(base) : "memory");
+        else if (ABL & 524288)
+            asm volatile("global_store_dword %0, %1, %2 sc0 sc1 nt" :: "v"(st4), "v"(v), "s"(base) : "memory");
+        else if (ABL & 16384)
+            __builtin_nontemporal_store(v, (float *) ((char *) base + st4));
+        else
+            *(float *) ((char *) base + st4) = v;
+    };
+    auto sti = [&](int32_t *base, int32_t v)
+    {
+        if (ABL & 32768)
+            return;
+        if (ABL & 65536)
+            asm volatile("global_store_dword %0, %1, %2 sc0 sc1" :: "v"(st4), "v"(v), "s"(base) : "memory");
+        else if (ABL & 262144)
+            asm volatile("global_store_dword %0, %1, %2 sc1" :: "v"(st4), "v"(v), "s"(base) : "memory");
+        else if (ABL & 524288)
+            asm volatile("global_store_dword %0, %1, %2 sc0 sc1 nt" :: "v"(st4), "v"(v), "s"(base) : "memory");
+        else if (ABL & 16384)
+            __builtin_nontemporal_store(v, (int32_t *) ((char *) base + st4));
+        else
+            *(int32_t *) ((char *) base + st4) = v;
+    };
     bool keep = live;
     if (ABL & 1024)
     {
@@ -784,7 +846,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         if (L.maxb > 1)
             sti((int32_t *) L.rec + (size_t) nch, (int32_t) rec1);
         for (int b = max(nb, 2);  b < L.maxb;  b++)
-            sti((int32_t *) L.rec + (size_t) b*nch, 0);    // slots without a completed block
+            *(int32_t *) ((char *) ((int32_t *) L.rec + (size_t) b*nch) + st4) = 0;    // slots without a completed block
         if ((ABL & kToneDigits)  &&  L.digits)
         {
             for (int b = nb;  b < L.maxb;  b++)

@@ -336,6 +336,111 @@ static void sweep_big(int n_ch)
     free_rig(r);
 }
 
+// Round 4: the lean block end (ABL bit 11 = the general decision, i.e. the kernel before), the state write-back as
+// non-temporal / absent / write-through stores, at the headline size and at 1 M channels, eager and from a graph.
+static void sweep_r4(int n_ch, int n_frames, int reps)
+{
+    typedef DtmfDet<false> D;
+    Rig r = make_rig<D>(n_ch, 160, n_frames, 102, false);
+    printf("---- r4: DTMF, %d channels x 160 samples ----\n", n_ch);
+    if (n_ch <= 393216)
+    {
+        const unsigned long long want = NEWL(1, 2, false, 2048);
+        const unsigned long long lean = NEWL(1, 2, false, 0);
+        if (lean != want)
+            printf("   !!! the lean block end differs from the general one\n");
+        if (NEWL(1, 2, false, 131072) != want)
+            printf("   !!! no-touch variant differs\n");
+        NEWL(1, 2, false, 16384);
+        NEWL(1, 2, false, 32768);
+        if (NEWL(1, 2, false, 65536) != want)
+            printf("   !!! write-through variant differs\n");
+        if (NEWL(1, 2, false, 262144) != want)
+            printf("   !!! sc1 variant differs\n");
+        if (NEWL(1, 2, false, 524288) != want)
+            printf("   !!! nt write-through variant differs\n");
+        NEWL(1, 2, false, 128);
+        NEWL(1, 2, false, 256);
+        NEWL(1, 2, false, 32);
+    }
+    else
+    {
+        const unsigned long long want = NEW(1, 2, false, 4, 2048);
+        if (NEW(1, 2, false, 4, 0) != want)
+            printf("   !!! the lean block end differs from the general one\n");
+        NEW(1, 2, false, 4, 32768);
+        if (NEW(1, 2, false, 4, 65536) != want)
+            printf("   !!! write-through variant differs\n");
+    }
+    free_rig(r);
+}
+
+// A-B with the variants taken in turn, several rounds, median and minimum per variant (boxes and moments differ by
+// more than the effects looked for).
+template <class Det, int ABL, bool LDR>
+static float ab_time(Rig &r, int reps, unsigned long long *dg)
+{
+    const int waves = (r.L.n_ch + kWave - 1)/kWave;
+    const int blocks = (waves + 3)/4;
+    int f = 0;
+    auto go = [&] {
+        r.L.amp = r.amp + (size_t) (f % r.n_frames)*r.frame_elems;
+        f++;
+        launch_tone_fast<Det, 1, 2, false, false, 4, ABL, LDR>(r.L, blocks, g_stream);
+    };
+    if (dg)
+    {
+        reset_rig(r, false, 102);
+        go(); go(); go();
+        CK(hipDeviceSynchronize());
+        *dg = digest(r);
+    }
+    return time_ms(go, reps);
+}
+
+template <bool LDR>
+static void ab_r4(int n_ch, int n_frames, int reps, int rounds)
+{
+    typedef DtmfDet<false> D;
+    Rig r = make_rig<D>(n_ch, 160, n_frames, 102, false);
+    printf("---- r4 A-B: DTMF, %d channels x 160 samples, %s, %d rounds ----\n", n_ch, LDR  ?  "loader wave"  :  "self-fetching", rounds);
+    const char *names[] = {"general block end, no touches (round 3)", "lean block end, no touches", "lean + touches", "lean + touches + nt stores",
+                           "lean + touches + sc1 stores", "lean + touches + sc0 sc1 stores", "lean + touches, no stores (ablation)"};
+    constexpr int NV = 7;
+    std::vector<float> t[NV];
+    unsigned long long dg[NV];
+    for (int k = 0;  k < rounds;  k++)
+    {
+        t[0].push_back(ab_time<D, 2048 + 131072, LDR>(r, reps, (k == 0)  ?  &dg[0]  :  nullptr));
+        t[1].push_back(ab_time<D, 131072, LDR>(r, reps, (k == 0)  ?  &dg[1]  :  nullptr));
+        t[2].push_back(ab_time<D, 0, LDR>(r, reps, (k == 0)  ?  &dg[2]  :  nullptr));
+        t[3].push_back(ab_time<D, 16384, LDR>(r, reps, (k == 0)  ?  &dg[3]  :  nullptr));
+        t[4].push_back(ab_time<D, 262144, LDR>(r, reps, (k == 0)  ?  &dg[4]  :  nullptr));
+        t[5].push_back(ab_time<D, 65536, LDR>(r, reps, (k == 0)  ?  &dg[5]  :  nullptr));
+        t[6].push_back(ab_time<D, 32768, LDR>(r, reps, (k == 0)  ?  &dg[6]  :  nullptr));
+    }
+    for (int v = 0;  v < NV;  v++)
+    {
+        std::sort(t[v].begin(), t[v].end());
+        printf("%-44s median %7.2f us  min %7.2f us  %s\n", names[v], t[v][t[v].size()/2]*1e3, t[v][0]*1e3,
+               (v == 6)  ?  ""  :  (dg[v] == dg[0])  ?  "same digest"  :  "!!! digest differs");
+    }
+    free_rig(r);
+}
+
+// Is a block end's cost the code being cold?  Two frames' worth of samples in one launch: three block ends per wave, the
+// stamps show what the first costs against the later ones.
+static void sweep_r4_long(int n_ch)
+{
+    typedef DtmfDet<false> D;
+    Rig r = make_rig<D>(n_ch, 320, 32, 102, false);
+    printf("---- r4: DTMF, %d channels x 320 samples (stamps per 32-sample piece) ----\n", n_ch);
+    const int reps = 100;
+    NEWL(1, 2, false, 0);
+    NEWL(1, 2, false, 32);
+    free_rig(r);
+}
+
 int main(int argc, char **argv)
 {
     hipDeviceProp_t p;
@@ -347,6 +452,31 @@ int main(int argc, char **argv)
         CK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
         sweep_blocks(65536);
         sweep_blocks(1048576);
+        return 0;
+    }
+    if (argc > 1  &&  strcmp(argv[1], "r4") == 0)
+    {
+        CK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        if (argc > 2  &&  strcmp(argv[2], "graph") == 0)
+            g_graph = true;
+        if (argc > 2  &&  strcmp(argv[2], "ab") == 0)
+        {
+            ab_r4<true>(65536, 64, 300, 7);
+            ab_r4<true>(131072, 32, 200, 5);
+            ab_r4<false>(1048576, 6, 30, 5);
+            g_graph = true;
+            printf("(from a hipGraph)\n");
+            ab_r4<true>(65536, 64, 300, 7);
+            return 0;
+        }
+        if (argc > 2  &&  strcmp(argv[2], "long") == 0)
+        {
+            sweep_r4_long(65536);
+            return 0;
+        }
+        sweep_r4(65536, 64, 300);
+        sweep_r4(131072, 32, 200);
+        sweep_r4(1048576, 6, 30);
         return 0;
     }
     if (argc > 1  &&  strcmp(argv[1], "big") == 0)
