@@ -257,7 +257,8 @@ struct Bank
     // Written phase by phase over all pairs (the same nine roundings per pair, in the same order:
     // q = fac*p - a;  r = ((q*q + p*p) - (p*q)*fac)*2): a pair's chain taken alone has every packed operation wait on
     // the one before it, which hipcc pads with s_nop -- a full issue slot each for a lone wave.
-    __device__ __forceinline__ void finish(const f32x2 (&fac)[NP], float (&e)[NBL])
+    // `sum`, if asked for: the energies added up pair-wise (any order does for what it is used for: is one of them a NaN)
+    __device__ __forceinline__ void finish(const f32x2 (&fac)[NP], float (&e)[NBL], f32x2 *sum = nullptr)
     {
         f32x2 q[NP];
         f32x2 t[NP];
@@ -302,6 +303,14 @@ struct Bank
             e[2*i + 1] = t[i].y;
             a[i] = f32x2{0.0f, 0.0f};
             b[i] = f32x2{0.0f, 0.0f};
+        }
+        if (sum)
+        {
+            f32x2 acc = t[0];
+#pragma unroll
+            for (int i = 1;  i < NP;  i++)
+                acc += t[i];
+            *sum = acc;
         }
     }
 };

@@ -99,6 +99,56 @@ __device__ __forceinline__ void seg_barrier()
     asm volatile("" ::: "memory");
 }
 
+#include "tone_pairs_asm.inc"
+
+// Sample pairs [k0, k1) of the sixteen of one row piece through the recurrence, as one asm body that is entered at pair k0
+// and left after pair k1 - 1 (tone_pairs_asm.inc, written by tools/gen_pairs_asm.py): the piece that holds a block end is
+// taken as [0, p), the block end, [p, 16) -- the same straight-line pair blocks either side, two scalar instructions per pair
+// for the exit test, where the rolled loop this replaces cost twice the common segment's time (stamps in
+// profiles/r4_probe.log: 6 000 ticks against 2 860).  ad: LDS byte address of the lane's row piece (chunk j at ad ^ 16 j).
+template <int NP, bool ENERGY>
+__device__ __forceinline__ void pairs_asm(f32x2 (&a)[NP], f32x2 (&b)[NP], float &energy, const f32x2 (&fac)[NP], uint32_t ad, int k0, int k1)
+{
+    const uint32_t ad1 = ad ^ 16u;
+    const uint32_t ad2 = ad ^ 32u;
+    const uint32_t ad3 = ad ^ 48u;
+#define SPG_PA_ADDR [ad0] "v"(ad), [ad1] "v"(ad1), [ad2] "v"(ad2), [ad3] "v"(ad3), [k0] "s"(k0), [k1] "s"(k1)
+    if constexpr (NP == 2)
+    {
+        if constexpr (ENERGY)
+            asm volatile(SPG_PAIRS_ASM_NP2_E1 : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [b0] "+v"(b[0]), [b1] "+v"(b[1]), [en] "+v"(energy)
+                         : [f0] "s"(fac[0]), [f1] "s"(fac[1]), SPG_PA_ADDR : SPG_PAIRS_ASM_CLOBBERS);
+        else
+            asm volatile(SPG_PAIRS_ASM_NP2_E0 : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [b0] "+v"(b[0]), [b1] "+v"(b[1]), [en] "+v"(energy)
+                         : [f0] "s"(fac[0]), [f1] "s"(fac[1]), SPG_PA_ADDR : SPG_PAIRS_ASM_CLOBBERS);
+    }
+    else if constexpr (NP == 3)
+    {
+        if constexpr (ENERGY)
+            asm volatile(SPG_PAIRS_ASM_NP3_E1 : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [b0] "+v"(b[0]), [b1] "+v"(b[1]), [b2] "+v"(b[2]), [en] "+v"(energy)
+                         : [f0] "s"(fac[0]), [f1] "s"(fac[1]), [f2] "s"(fac[2]), SPG_PA_ADDR : SPG_PAIRS_ASM_CLOBBERS);
+        else
+            asm volatile(SPG_PAIRS_ASM_NP3_E0 : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [b0] "+v"(b[0]), [b1] "+v"(b[1]), [b2] "+v"(b[2]), [en] "+v"(energy)
+                         : [f0] "s"(fac[0]), [f1] "s"(fac[1]), [f2] "s"(fac[2]), SPG_PA_ADDR : SPG_PAIRS_ASM_CLOBBERS);
+    }
+    else if constexpr (NP == 4)
+    {
+        if constexpr (ENERGY)
+            asm volatile(SPG_PAIRS_ASM_NP4_E1 : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]),
+                           [b0] "+v"(b[0]), [b1] "+v"(b[1]), [b2] "+v"(b[2]), [b3] "+v"(b[3]), [en] "+v"(energy)
+                         : [f0] "s"(fac[0]), [f1] "s"(fac[1]), [f2] "s"(fac[2]), [f3] "s"(fac[3]), SPG_PA_ADDR : SPG_PAIRS_ASM_CLOBBERS);
+        else
+            asm volatile(SPG_PAIRS_ASM_NP4_E0 : [a0] "+v"(a[0]), [a1] "+v"(a[1]), [a2] "+v"(a[2]), [a3] "+v"(a[3]),
+                           [b0] "+v"(b[0]), [b1] "+v"(b[1]), [b2] "+v"(b[2]), [b3] "+v"(b[3]), [en] "+v"(energy)
+                         : [f0] "s"(fac[0]), [f1] "s"(fac[1]), [f2] "s"(fac[2]), [f3] "s"(fac[3]), SPG_PA_ADDR : SPG_PAIRS_ASM_CLOBBERS);
+    }
+    else
+    {
+        static_assert(NP == 2  ||  NP == 3  ||  NP == 4, "pairs_asm: banks of 4, 6 or 8 bins per lane");
+    }
+#undef SPG_PA_ADDR
+}
+
 // The loader wave of a workgroup (LDR kernels): it issues every LDS-DMA of the workgroup's WPB consumer waves and tells
 // them, one barrier per segment, that a segment has landed.  Why a wave of its own: while the chip streams a frame the
 // memory pipeline is saturated and a global_load_lds is not accepted until there is room for it -- the issuing wave
@@ -512,6 +562,8 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         return x01;
     };
     constexpr int PPC = SPC/2;                      // sample pairs per chunk
+    // (probe bit 17: the rolled loop for every segment with a block end, as before round 4)
+    constexpr bool kPairsAsm = !G711  &&  !Det::kFilter  &&  LPC == 1  &&  NBL/2 >= 2  &&  NBL/2 <= 4  &&  !(ABL & 131072);
     // the production case of a block end (wave-uniform): nothing but the decision itself is asked for, with the
     // bank's own thresholds -- Det::decide_plain() then does what Det::decide() does in a third of the instructions
     const bool plain = Det::kLean  &&  !L.trace  &&  !L.chan_parms  &&  !L.rec_energy  &&  !L.realtime;
@@ -525,7 +577,8 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         }
         take_acc = 0;
         float el[NBL];
-        bk.finish(fac, el);
+        f32x2 esum;
+        bk.finish(fac, el, &esum);
         float e[NB];
         if (LPC == 1)
         {
@@ -548,7 +601,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         uint32_t recw;
         bool lean = false;
         if constexpr (Det::kLean  &&  LPC == 1  &&  !(ABL & 2048))
-            lean = plain  &&  __all(Det::lean_inputs_ok(e));
+            lean = plain  &&  __all((esum.x + esum.y) == (esum.x + esum.y));     // a NaN anywhere, or infinities of both signs, make the sum a NaN
         if (lean)
         {
             if constexpr (Det::kLean)
@@ -644,6 +697,32 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
                 cs_s = 0;
             }
             cs = cs_s;
+        }
+        else if (uniform  &&  kPairsAsm  &&  seglen == 4*SPC  &&  block >= 4*SPC  &&  ((block - cs_s) & 1) == 0)
+        {
+            // A whole segment with a block end inside it, on a pair boundary: pairs [0, p), the block end, pairs [p, 16) --
+            // both through the one asm body (pairs_asm above)
+            if constexpr (kPairsAsm)
+            {
+                const int m = block - cs_s;
+                const uint32_t ad = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) char *) lds_raw + rd;
+                float no_energy = 0.0f;
+#pragma nounroll
+                for (int part = 0;  part < 2;  part++)
+                {
+                    const int k0 = __builtin_amdgcn_readfirstlane(part  ?  (m >> 1)  :  0);
+                    const int k1 = __builtin_amdgcn_readfirstlane(part  ?  4*PPC  :  (m >> 1));
+                    pairs_asm<NBL/2, Det::kEnergy>(bk.a, bk.b, Det::kEnergy  ?  energy  :  no_energy, fac, ad, k0, k1);
+                    if (part == 0)
+                    {
+                        take_acc += m;
+                        end_block(std::true_type());
+                    }
+                }
+                cs_s = 4*SPC - m;
+                take_acc += 4*SPC - m;
+                cs = cs_s;
+            }
         }
         else if (uniform)
         {
@@ -780,36 +859,33 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
     // ---- write back -----------------------------------------------------------------------------------
     unsigned st4 = ch4;
     asm volatile("" : "+v"(st4));                   // a fresh value: the offsets of the loads are not kept alive for this
-    // (probe bits 14 / 15 / 16: the state stores non-temporal / left out altogether / write-through)
+    // The state goes back with write-through stores (sc0 sc1): nothing of it is left dirty in the L2 for the end of the kernel
+    // to flush, and the next launch reads it from the memory side either way.  (Not inline asm: a scalar base that hipcc has
+    // spilled comes back through v_readlane_b32, and a vector memory instruction it cannot see gets none of the five wait
+    // states that needs -- found by the 12-bin banks, whose state rows went to the wrong addresses.)  Measured against plain stores
+    // (profiles/r4_probe_ab.log): 11.34 -> 11.23 us at 65 536 channels, 19.3 -> 18.5 at 131 072, 119 -> 117 at 1 M.
+    // (Probe bits 14 / 15 / 16: non-temporal stores / no stores at all / plain stores.)
     auto stf = [&](float *base, float v)
     {
         if (ABL & 32768)
             return;
-        if (ABL & 65536)
-            asm volatile("global_store_dword %0, %1, %2 sc0 sc1" :: "v"(st4), "v"(v), "s"(base) : "memory");
-        else if (ABL & 262144)
-            asm volatile("global_store_dword %0, %1, %2 sc1" :: "v"(st4), "v"(v), "s"(base) : "memory");
-        else if (ABL & 524288)
-            asm volatile("global_store_dword %0, %1, %2 sc0 sc1 nt" :: "v"(st4), "v"(v), "s"(base) : "memory");
-        else if (ABL & 16384)
+        if (ABL & 16384)
             __builtin_nontemporal_store(v, (float *) ((char *) base + st4));
-        else
+        else if (ABL & 65536)
             *(float *) ((char *) base + st4) = v;
+        else        // (a relaxed atomic store of system scope is what hipcc writes as global_store_dword ... sc0 sc1)
+            __hip_atomic_store((uint32_t *) ((char *) base + st4), __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
     auto sti = [&](int32_t *base, int32_t v)
     {
         if (ABL & 32768)
             return;
-        if (ABL & 65536)
-            asm volatile("global_store_dword %0, %1, %2 sc0 sc1" :: "v"(st4), "v"(v), "s"(base) : "memory");
-        else if (ABL & 262144)
-            asm volatile("global_store_dword %0, %1, %2 sc1" :: "v"(st4), "v"(v), "s"(base) : "memory");
-        else if (ABL & 524288)
-            asm volatile("global_store_dword %0, %1, %2 sc0 sc1 nt" :: "v"(st4), "v"(v), "s"(base) : "memory");
-        else if (ABL & 16384)
+        if (ABL & 16384)
             __builtin_nontemporal_store(v, (int32_t *) ((char *) base + st4));
-        else
+        else if (ABL & 65536)
             *(int32_t *) ((char *) base + st4) = v;
+        else
+            __hip_atomic_store((int32_t *) ((char *) base + st4), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
     bool keep = live;
     if (ABL & 1024)

@@ -404,8 +404,8 @@ static void ab_r4(int n_ch, int n_frames, int reps, int rounds)
     typedef DtmfDet<false> D;
     Rig r = make_rig<D>(n_ch, 160, n_frames, 102, false);
     printf("---- r4 A-B: DTMF, %d channels x 160 samples, %s, %d rounds ----\n", n_ch, LDR  ?  "loader wave"  :  "self-fetching", rounds);
-    const char *names[] = {"general block end, no touches (round 3)", "lean block end, no touches", "lean + touches", "lean + touches + nt stores",
-                           "lean + touches + sc1 stores", "lean + touches + sc0 sc1 stores", "lean + touches, no stores (ablation)"};
+    const char *names[] = {"general block end, rolled loop (round 3)", "lean block end, rolled loop", "lean + asm pairs", "lean + asm pairs + nt stores",
+                           "lean + asm pairs + sc1 stores", "lean + asm pairs + sc0 sc1 stores", "lean + asm pairs, no stores (ablation)"};
     constexpr int NV = 7;
     std::vector<float> t[NV];
     unsigned long long dg[NV];
