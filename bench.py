@@ -106,7 +106,19 @@ def cpu_baseline(frames_host, target_s):
         all_rate, all_loops, all_dt = measure(n_ch, threads, target_s)
         one_ch = min(n_ch, 256)
         one_rate, one_loops, one_dt = measure(one_ch, 1, min(target_s, 2.0))
+        shipped = None
+        if oracle.have_ref_fast():
+            # the same sources as the library ships them (oracle/Makefile: -O2 -ffast-math -msse2, SPANDSP_USE_SSE2): timing only
+            with ref.flavour("fast"):
+                L = ref.lib()
+                f_all = measure(n_ch, threads, 0.6*target_s)
+                f_one = measure(one_ch, 1, min(0.6*target_s, 1.0))
+            L = ref.lib()
+            shipped = {"kind": "reference-fastmath", "value": f_all[0]/1e6, "single_core": f_one[0]/1e6, "unit": "Msamples/s", "cores": threads,
+                       "build": "gcc -std=gnu99 -O2 -ffast-math -msse2 -DSPANDSP_USE_SSE2 (configure.ac:276,346,374-375,509-519); "
+                                "never used for parity"}
         return {
+            "as_shipped": shipped,
             "value": all_rate/1e6,
             "unit": "Msamples/s",
             "cores": threads,
@@ -229,7 +241,10 @@ def run_echo(args, engine, dev, local_rank, rank, world):
     import bench_paths as bp
     from spandsp_amd.parallel import FloatGather
     n_ch = args.channels if args.channels != 65536 else 131072
-    nf = 50
+    # SURVEY 8(d)-5's workload: 10 s of continuous signal per line (G.168 echo path models, tools/bench_paths.py: synth_echo);
+    # the first second warms up, the other nine are the timed region (no frame is played twice: no seam in any line)
+    nf = 50*args.echo_seconds
+    warm = 50
     tx, rx = bp.synth_echo(n_ch, nf, dev, seed=0xEC40 + rank)
     clean = torch.empty(n_ch, FRAME, dtype=torch.int16, device=dev)
     bank = engine.EchoBank(n_ch, bp.ECHO_TAPS, bp.ECHO_MODE, device=local_rank)
@@ -244,33 +259,20 @@ def run_echo(args, engine, dev, local_rank, rank, world):
     report_every = 50
 
     def step(i):
-        k = i % nf
-        bank.update_device(ctypes.c_void_p(tx.data_ptr() + k*fb), ctypes.c_void_p(rx.data_ptr() + k*fb),
+        bank.update_device(ctypes.c_void_p(tx.data_ptr() + i*fb), ctypes.c_void_p(rx.data_ptr() + i*fb),
                            ctypes.c_void_p(clean.data_ptr()), FRAME, FRAME)
         if (i + 1) % report_every == 0:
             bank.erle_device(ctypes.c_void_p(erle_dev.data_ptr()))
             if gather is not None:
                 gather.result()                     # the previous report has arrived
                 gather.gather()
-            bank.stats_reset(sums=True, crc=False)
+            if i + 1 < nf:
+                bank.stats_reset(sums=True, crc=False)
 
-    for i in range(args.warmup):
+    for i in range(warm):
         step(i)
-    torch.cuda.synchronize()
-    ev_a = torch.cuda.Event(enable_timing=True)
-    ev_b = torch.cuda.Event(enable_timing=True)
-    ev_a.record(stream)
-    for i in range(args.steps):
-        step(args.warmup + i)
-    ev_b.record(stream)
-    torch.cuda.synchronize()
-    reps = max(1, int(np.ceil(1.15*args.min_timed_ms/max(ev_a.elapsed_time(ev_b), 1e-3))))      # (the probe runs cold: margin)
-    if world > 1:
-        r = torch.tensor([reps], device=dev, dtype=torch.int64)
-        dist.all_reduce(r, op=dist.ReduceOp.MAX)
-        reps = int(r.item())
-    timed_steps = args.steps*reps
-    first = args.warmup + args.steps
+    timed_steps = nf - warm
+    args.steps, args.warmup = timed_steps, warm
     if gather is not None:
         gather.result()
     torch.cuda.synchronize()
@@ -281,8 +283,8 @@ def run_echo(args, engine, dev, local_rank, rank, world):
     ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    for i in range(timed_steps):
-        step(first + i)
+    for i in range(warm, nf):
+        step(i)
     if gather is not None:
         gather.result()
     ev1.record(stream)
@@ -296,10 +298,8 @@ def run_echo(args, engine, dev, local_rank, rank, world):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     stream_ms = ev0.elapsed_time(ev1)
-    # a final report over everything since the last reset, for the JSON line
-    bank.erle_device(ctypes.c_void_p(erle_dev.data_ptr()))
+    # the last report (step nf - 1) holds the ERLE of every line over the last second
     if gather is not None:
-        gather.gather()
         allr = gather.result()
     else:
         torch.cuda.synchronize()
@@ -314,7 +314,7 @@ def run_echo(args, engine, dev, local_rank, rank, world):
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         nc = min(4096, n_ch)
-        cpu = bp.cpu_echo(tx[:, :nc].contiguous().cpu().numpy(), rx[:, :nc].contiguous().cpu().numpy())
+        cpu = bp.cpu_echo(tx[:60, :nc].contiguous().cpu().numpy(), rx[:60, :nc].contiguous().cpu().numpy())
     value = float(timed_steps)*n_ch*world*FRAME/dt/1e6
     bp.emit({
         "metric": "Msamples/s of batched G.168 echo cancellation, 128 taps (8 kHz channels at real-time = value*1e6/8000)",
@@ -322,8 +322,10 @@ def run_echo(args, engine, dev, local_rank, rank, world):
         "steps": args.steps, "warmup": args.warmup, "timed_steps": timed_steps, "timed_region_ms": dt*1e3,
         "ms_per_step": dt*1e3/timed_steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[4]: echo_can_update 128 taps, ECHO_CAN_USE_ADAPTION, %d channels/GPU x %d-sample "
-                               "frames, per-channel ERLE gathered to rank 0 every %d steps" % (n_ch, FRAME, report_every),
+        "config": {"workload": "BASELINE configs[4], SURVEY 8(d)-5's lines: echo_can_update 128 taps, ECHO_CAN_USE_ADAPTION, %d channels/GPU x "
+                               "%d-sample frames, %d s of continuous signal (white noise at -15 dBm0 through G.168 echo path models D2..D9 "
+                               "by channel mod 8, ERL 6..24 dB, every tenth line with near end talk), per-channel ERLE over the last second "
+                               "gathered to rank 0 every %d steps" % (n_ch, FRAME, args.echo_seconds, report_every),
                    "channels_per_gpu": n_ch, "frame_samples": FRAME,
                    "parallelism": ("channels sharded x%d, RCCL gather of one ERLE float per channel per second of signal" % world)
                                   if world > 1 else "single GPU",
@@ -367,6 +369,8 @@ def main():
     ap.add_argument("--min-timed-ms", type=float, default=50.0,
                     help="the timed region is repeated (whole multiples of --steps) until it lasts at least this long")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--echo-seconds", type=int, default=10, help="--workload echo: seconds of continuous signal per line (first second untimed)")
+    ap.add_argument("--no-paths", action="store_true", help="leave out the `paths` object (BASELINE configs[2], [3], [4] at full size, ~40 s)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -560,6 +564,15 @@ def main():
         lower = (x - vals[posn - 1]) <= (vals[posn] - x)
         e2e_g711 = end_to_end(engine, n_ch, codes_of[torch.where(lower, posn - 1, posn)].contiguous(), local_rank, 60, law=2)
 
+    paths = None
+    if rank == 0 and world == 1 and not args.no_paths and not law:
+        # BASELINE configs[2], [3], [4] under the same clock as the headline (tools/bench_paths.py: paths_for_bench)
+        del frames
+        torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_paths as bp
+        paths = bp.paths_for_bench(dev, stream, args.no_cpu_baseline, roof.get("measured_stream_peak") if roof else None)
+
     if rank == 0:
         total_samples = float(timed_steps)*n_ch*world*FRAME
         value = total_samples/dt/1e6
@@ -595,6 +608,7 @@ def main():
             "cpu_baseline": cpu,
             "e2e": e2e,
             "e2e_g711": e2e_g711,
+            "paths": paths,
         }
         print(json.dumps(line))
     if world > 1 or force_gather:

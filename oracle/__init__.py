@@ -16,6 +16,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libspandsp_ref.so")
+# the reference as it ships (-O2 -ffast-math -msse2, SPANDSP_USE_SSE2): for cpu_baseline timing only, never for parity
+REF_FAST_SO = os.path.join(HERE, "_ref", "libspandsp_ref_fast.so")
 
 
 def build(verbose=False):
@@ -30,3 +32,7 @@ def build(verbose=False):
 
 def have_ref():
     return os.path.exists(REF_SO)
+
+
+def have_ref_fast():
+    return os.path.exists(REF_FAST_SO)

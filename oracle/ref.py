@@ -11,21 +11,36 @@ import os
 
 import numpy as np
 
-from . import REF_SO
+from . import REF_SO, REF_FAST_SO
 
 EVENT_DTYPE = np.dtype([("kind", "<i4"), ("a", "<i4"), ("b", "<i4"), ("c", "<i4")])
 
-_lib = None
+_libs = {}
+_flavour = "strict"
 
 
 def available():
     return os.path.exists(REF_SO)
 
 
+@contextlib.contextmanager
+def flavour(name):
+    """Everything inside the block talks to the named build of the reference: "strict" (-O2 -ffp-contract=off: the oracle
+    every parity test uses) or "fast" (as the library ships: -O2 -ffast-math -msse2 with its SSE2 paths -- for the
+    cpu_baseline legs to time, never to compare results with).  Objects made inside the block belong to that build."""
+    global _flavour
+    assert name in ("strict", "fast")
+    old = _flavour
+    _flavour = name
+    try:
+        yield
+    finally:
+        _flavour = old
+
+
 def lib():
-    global _lib
-    if _lib is None:
-        L = C.CDLL(REF_SO)
+    if _flavour not in _libs:
+        L = C.CDLL(REF_SO if _flavour == "strict" else REF_FAST_SO)
         vp, ci, cf = C.c_void_p, C.c_int, C.c_float
         sigs = {
             # glue
@@ -89,6 +104,7 @@ def lib():
             "tone_gen_init": (vp, [vp, vp]), "tone_gen": (ci, [vp, vp, ci]), "tone_gen_free": (ci, [vp]),
             "awgn_init_dbm0": (vp, [vp, ci, cf]), "awgn": (C.c_int16, [vp]), "awgn_free": (ci, [vp]),
             "glue_awgn_run": (ci, [ci, cf, vp, ci, vp]),
+            "glue_g168_model": (ci, [ci, vp, vp]), "glue_g168_line": (ci, [ci, cf, vp, vp, vp, ci]), "glue_g168_gain": (cf, [ci, cf]),
             "echo_can_init": (vp, [ci, ci]), "echo_can_free": (ci, [vp]), "echo_can_flush": (None, [vp]),
             "echo_can_adaption_mode": (None, [vp, ci]),
             "echo_can_update": (C.c_int16, [vp, C.c_int16, C.c_int16]),
@@ -137,8 +153,8 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = L
-    return _lib
+        _libs[_flavour] = L
+    return _libs[_flavour]
 
 
 @contextlib.contextmanager
@@ -487,6 +503,29 @@ def awgn(seed, level_dbm0, samples):
 def awgn_state_words(seed, level_dbm0, samples):
     """The generator's state after `samples` calls, in the oracle / device word layout."""
     return _awgn_run(seed, level_dbm0, samples)[1]
+
+
+def g168_model(model):
+    """Taps (int32) and gain constant of G.168 line model D`model` (2 .. 9), src/spandsp/g168models.h."""
+    out = np.zeros(256, np.int32)
+    ki = C.c_float(0.0)
+    n = lib().glue_g168_model(model, out.ctypes.data, C.byref(ki))
+    assert n > 0, model
+    return out[:n].copy(), float(ki.value)
+
+
+def g168_gain(model, erl_db):
+    return np.float32(lib().glue_g168_gain(model, erl_db))
+
+
+def g168_line(model, erl_db, rout, sgen):
+    """What comes back from the line: the echo of `rout` through model D`model` at `erl_db` (negative) plus the near end
+    signal `sgen`, by the reference's own fir32() as tests/echo_tests.c's channel_model() uses it (no codec)."""
+    rout = _i16(rout)
+    sgen = _i16(sgen)
+    out = np.zeros(len(rout), np.int16)
+    assert lib().glue_g168_line(model, erl_db, rout.ctypes.data, sgen.ctypes.data, out.ctypes.data, len(rout)) > 0
+    return out
 
 
 def saturated_add(a, b):

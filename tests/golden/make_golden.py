@@ -200,6 +200,29 @@ def sigtone_goldens():
              out_head=out[:4000], snapshots=snaps, requests=np.int32(n))
 
 
+def make_g168():
+    import zlib
+    # the G.168 echo path models (test data of the reference: src/spandsp/g168models.h) and the known answer of
+    # BASELINE.md section 2 (tests/g168.py: KNOWN_D2) from the real echo canceller
+    import g168
+    ms = list(range(2, 10))
+    kw = {"models": np.array(ms), "ki": np.array([ref.g168_model(m)[1] for m in ms], np.float32)}
+    for m in ms:
+        kw["taps_%d" % m] = ref.g168_model(m)[0]
+    erls = [-6.0, -9.0, -12.0, -15.0, -18.0, -21.0, -24.0]
+    kw["gain_model"] = np.array([m for m in ms for _ in erls])
+    kw["gain_erl"] = np.array([e for _ in ms for e in erls])
+    kw["gain_value"] = np.array([ref.g168_gain(m, e) for m in ms for e in erls], np.float32)
+    save("g168_models", **kw)
+    K = g168.KNOWN_D2
+    tx = ref.awgn(K["seed"], K["level_dbm0"], K["samples"])
+    rx = ref.g168_line(K["model"], K["erl_db"], tx, np.zeros(len(tx), np.int16))
+    r = ref.EchoCan(K["taps"], K["mode"])
+    clean = r.run(tx, rx, False)
+    save("g168_d2_known", tx_crc=zlib.crc32(tx.tobytes()), rx_crc=zlib.crc32(rx.tobytes()), clean_crc=zlib.crc32(clean.tobytes()),
+         clean_last_second=clean[-8000:], erle_db=g168.erle_db(rx[-8000:], clean[-8000:]))
+
+
 def main():
     assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
     L = ref.lib()
@@ -270,6 +293,8 @@ def main():
         save("echo_%d_%02x" % (taps, mode), tx_crc=zlib.crc32(tx.tobytes()), rx_crc=zlib.crc32(rx.tobytes()),
              clean=clean, taps32=s["taps32"], taps16=s["taps16"], history=s["history"],
              fields=np.array(ref.ECHO_FIELDS), values=np.array([s[k] for k in ref.ECHO_FIELDS]))
+
+    make_g168()
 
     codes = np.arange(256)
     save("g711_decode", alaw=np.array([L.glue_alaw_to_linear(int(c)) for c in codes], np.int16),
@@ -344,6 +369,9 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["super_tone_range"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         super_tone_range()
+    elif sys.argv[1:] == ["g168"]:
+        assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+        make_g168()
     elif sys.argv[1:] == ["dial_tone"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         dial_tone_tolerance()

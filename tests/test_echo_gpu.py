@@ -2,6 +2,8 @@
 (oracle/echo_oracle.c, pinned to the reference by test_oracle_pin.py): every clean sample
 and the complete per-channel state (control words, 32-bit taps, all four 16-bit tap sets,
 FIR history in the reference's physical order) bit-exact, frame after frame."""
+import os
+
 import numpy as np
 import pytest
 
@@ -199,4 +201,53 @@ def test_echo_energy_sums_by_the_update_kernel(built, lanes):
     assert np.array_equal(st["sum_rx2"], (r*r).sum(axis=1).astype(np.uint64))
     assert np.array_equal(st["sum_clean2"], (c*c).sum(axis=1).astype(np.uint64))
     assert np.all(st["samples"] == n) and not st["crc"].any()
+    bank.close()
+
+
+def test_g168_lines_and_the_known_answer(built):
+    """The contract's echo workload and BASELINE.md section 2's known answer on the GPU: 64 lines through
+    the eight G.168 echo path models (tests/g168.py: the reference test program's line simulator, models by c mod 8, ERL
+    6 ... 24 dB), white noise at -15 dBm0 from the reference's awgn(), 20 s without a break.  Line 0 is the known answer's
+    own set-up: model D2, ERL 12 dB, seed 1234567 -- 54.6 dB ERLE over the last second.  Every clean sample of every line
+    against the oracle, the ERLE of every line from the bank's own statistics."""
+    import zlib
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    import g168
+    K = g168.KNOWN_D2
+    n_ch, n = 64, K["samples"]
+    tx = np.zeros((n_ch, n), np.int16)
+    rx = np.zeros((n_ch, n), np.int16)
+    for c in range(n_ch):
+        model = 2 + c % 8
+        erl = K["erl_db"] if c == 0 else -(6.0 + 18.0*((c*37) % 64)/63.0)
+        tx[c] = orc.Awgn(K["seed"] + 1000*c, K["level_dbm0"]).gen(n)
+        near = None
+        if c % 10 == 9:                                   # one line in ten has the near end talking now and then
+            near = np.zeros(n, np.int16)
+            for k in range(3):
+                a = 20000 + 45000*k
+                near[a:a + 6000] = orc.Awgn(77 + c + k, -18.0).gen(6000)
+        rx[c] = g168.line(model, erl, tx[c], near)
+    g = np.load(os.path.join(g168.GOLDEN, "g168_d2_known.npz"))
+    assert zlib.crc32(tx[0].tobytes()) == int(g["tx_crc"]) and zlib.crc32(rx[0].tobytes()) == int(g["rx_crc"])
+    bank = engine.EchoBank(n_ch, K["taps"], K["mode"])
+    bank.stats(True)
+    dets = [orc.EchoCan(K["taps"], K["mode"]) for _ in range(n_ch)]
+    want = np.stack([d.run(tx[c], rx[c], False) for c, d in enumerate(dets)])
+    got = np.zeros_like(want)
+    step = 1600                                             # ten frames a call: the reference's callers may hand over any length
+    for pos in range(0, n, step):
+        if pos == n - 8000:
+            bank.stats_reset(sums=True, crc=False)
+        got[:, pos:pos + step] = bank.update_host(tx[:, pos:pos + step], rx[:, pos:pos + step], use_hpf_tx=False)
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, bad[:8]
+    assert zlib.crc32(got[0].tobytes()) == int(g["clean_crc"])
+    erle = bank.erle_host()
+    assert abs(float(erle[0]) - K["erle_db"]) < 0.05, erle[0]
+    for c in range(n_ch):
+        assert abs(float(erle[c]) - g168.erle_db(rx[c, -8000:], want[c, -8000:])) < 1e-3, c
+    single = np.array([erle[c] for c in range(n_ch) if c % 10 != 9])
+    assert np.median(single) > 40.0, np.median(single)
     bank.close()

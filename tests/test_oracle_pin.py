@@ -1290,3 +1290,103 @@ def test_golden_modem_qam(built):
     for name, bit_rate, seed, noise in QAM_GOLDEN_CASES:
         q = qam_golden_run({"v29": orc.V29, "v27ter": orc.V27ter, "v17": orc.V17}[name], name, bit_rate, seed, noise)
         assert np.array_equal(q, g["%s_%d" % (name, bit_rate)]), (name, bit_rate)
+
+
+# ---------------------------------------------------------------------------------
+# G.168 line models and BASELINE.md section 2's known answers
+# ---------------------------------------------------------------------------------
+@needs_ref
+def test_g168_line_model_live(built):
+    """tests/g168.py's restatement of the reference test program's line simulator (tests/echo_tests.c:396-487) against the
+    reference's own fir32() over the reference's own tables, every model, near end talk included."""
+    from oracle import ref
+    import g168
+    tx = ref.awgn(99, -15.0, 12000)
+    near = ref.awgn(100, -20.0, 12000)
+    for m in range(2, 10):
+        taps, ki = ref.g168_model(m)
+        assert np.array_equal(taps, g168.models()[0][m][0]) and np.float32(ki) == g168.models()[0][m][1]
+        for erl in (-6.0, -12.0, -24.0, -10.7):
+            assert g168.gain(m, erl) == ref.g168_gain(m, erl), (m, erl)
+            assert np.array_equal(g168.line(m, erl, tx, near), ref.g168_line(m, erl, tx, near)), (m, erl)
+
+
+def g168_known_signals():
+    """tx and rx of BASELINE.md section 2's echo canceller run, from the restatements (what the GPU box can make)."""
+    from oracle import restated as orc
+    import g168
+    K = g168.KNOWN_D2
+    tx = orc.Awgn(K["seed"], K["level_dbm0"]).gen(K["samples"])
+    return tx, g168.line(K["model"], K["erl_db"], tx)
+
+
+@needs_ref
+def test_g168_d2_known_answer_live(built):
+    """echo_can_update(), 128 taps, white noise at -15 dBm0 through model D2 at 12 dB ERL reaches
+    54.6 dB ERLE over the last second of 20 s -- the real reference, and the restatement sample for sample."""
+    from oracle import ref, restated as orc
+    import g168
+    K = g168.KNOWN_D2
+    tx, rx = g168_known_signals()
+    assert np.array_equal(tx, ref.awgn(K["seed"], K["level_dbm0"], K["samples"]))
+    r = ref.EchoCan(K["taps"], K["mode"])
+    clean = r.run(tx, rx, False)
+    assert abs(g168.erle_db(rx[-8000:], clean[-8000:]) - K["erle_db"]) < 0.05
+    o = orc.EchoCan(K["taps"], K["mode"])
+    assert np.array_equal(o.run(tx, rx, False), clean)
+
+
+def test_golden_g168_d2_known_answer(built):
+    import zlib
+    from oracle import restated as orc
+    import g168
+    K = g168.KNOWN_D2
+    g = np.load(os.path.join(GOLDEN, "g168_d2_known.npz"))
+    tx, rx = g168_known_signals()
+    assert zlib.crc32(tx.tobytes()) == int(g["tx_crc"]) and zlib.crc32(rx.tobytes()) == int(g["rx_crc"])
+    clean = orc.EchoCan(K["taps"], K["mode"]).run(tx, rx, False)
+    assert zlib.crc32(clean.tobytes()) == int(g["clean_crc"]) and np.array_equal(clean[-8000:], g["clean_last_second"])
+    assert abs(g168.erle_db(rx[-8000:], clean[-8000:]) - K["erle_db"]) < 0.05 and abs(float(g["erle_db"]) - K["erle_db"]) < 0.05
+
+
+V29_KNOWN = {"bit_rate": 9600, "samples": 320000, "tx_seed": 1, "noise_seed": 1234567, "noise_dbm0": -50.0, "bits": 381500,
+             "status": [-2, -3, -4]}
+
+
+def v29_known_signal(built=None):
+    """v29_tx() (9600 bps, PRBS, default level) + AWGN at -50 dBm0, 40 s, from the restatements."""
+    from oracle import restated as orc
+    K = V29_KNOWN
+    use_v29_tx_table(built)
+    x = orc.V29Tx(K["bit_rate"], False, K["tx_seed"]).tx(K["samples"])
+    return (x.astype(np.int32) + orc.Awgn(K["noise_seed"], K["noise_dbm0"]).gen(len(x)).astype(np.int32)).clip(-32768, 32767).astype(np.int16)
+
+
+def prbs15_bits(seed, n):
+    """The data source the harness gives the transmitters (oracle/ref_glue: glue_fn_prbs_get_bit): x^15 + x^14 + 1."""
+    out = np.zeros(n, np.int8)
+    s = seed & 0x7FFF
+    for i in range(n):
+        bit = ((s >> 14) ^ (s >> 13)) & 1
+        s = ((s << 1) | bit) & 0x7FFF
+        out[i] = bit
+    return out
+
+
+@needs_ref
+def test_v29_known_answer_live(built):
+    """v29_tx -> AWGN -50 dBm0 -> v29_rx delivers 381 500 bits, the statuses CARRIER_UP,
+    TRAINING_IN_PROGRESS, TRAINING_SUCCEEDED and nothing else -- the real reference on the restated signal, and the
+    restated receiver event for event."""
+    from oracle import ref, restated as orc
+    K = V29_KNOWN
+    y = v29_known_signal(built)
+    assert np.array_equal(y, ref.saturated_add(ref.v29_tx(K["bit_rate"], K["samples"], seed=K["tx_seed"]), ref.awgn(K["noise_seed"], K["noise_dbm0"], K["samples"])))
+    r = ref.V29Rx(K["bit_rate"])
+    o = orc.V29(K["bit_rate"])
+    for k in range(0, len(y), 160):
+        r.rx(y[k:k + 160])
+        o.rx(y[k:k + 160])
+    a = r.sink.events()["a"]
+    assert int((a >= 0).sum()) == K["bits"] and [int(v) for v in a[a < 0]] == K["status"]
+    assert np.array_equal(o.sink.events()["a"], a)

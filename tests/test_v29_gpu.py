@@ -145,3 +145,35 @@ def test_modem_edge_cases(built):
     assert engine.lib().spangpu_modem_restart_ex(b17.h, 0, 14400, 0) < 0
     assert engine.lib().spangpu_modem_restart_ex(b17.h, 0, 9600, 1) == 0
     b17.close()
+
+
+def test_v29_known_answer(built):
+    """BASELINE.md section 2 on the GPU: v29_tx (9600 bps) + AWGN at -50 dBm0, 40 s -> 381 500 bits, the statuses
+    CARRIER_UP, TRAINING_IN_PROGRESS, TRAINING_SUCCEEDED and no other, and not one bit in error against the transmitter's
+    data source; the whole put_bit stream equal to the oracle's."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    from test_oracle_pin import V29_KNOWN, v29_known_signal, prbs15_bits
+    K = V29_KNOWN
+    y = v29_known_signal(built)
+    n_ch = 4
+    bank = engine.V29Bank(n_ch, K["bit_rate"])
+    o = orc.V29(K["bit_rate"])
+    ev = [[] for _ in range(n_ch)]
+    frame = 1600
+    for k in range(0, len(y), frame):
+        bank.rx_host(np.tile(y[k:k + frame], (n_ch, 1)))
+        for c, e in enumerate(bank.events()):
+            ev[c].append(e)
+        o.rx(y[k:k + frame])
+    want = o.sink.events()["a"].astype(np.int8)
+    for c in range(n_ch):
+        a = np.concatenate(ev[c])
+        assert np.array_equal(a, want), c
+    a = np.concatenate(ev[0])
+    assert int((a >= 0).sum()) == K["bits"] and [int(v) for v in a[a < 0]] == K["status"]
+    data = a[np.nonzero(a == -4)[0][0] + 1:]
+    src = prbs15_bits(K["tx_seed"], len(data) + 400)
+    hit = [k for k in range(400) if np.array_equal(src[k:k + 64], data[:64])]
+    assert hit and np.array_equal(src[hit[0]:hit[0] + len(data)], data), "bit errors"
+    bank.close()

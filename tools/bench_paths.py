@@ -200,6 +200,19 @@ def run_threads(n_ch, work):
     return cores, time.perf_counter() - t0
 
 
+def as_shipped(measure_both, threads):
+    """The same measurement on the reference as the library ships it (oracle/Makefile's fast flavour: -O2 -ffast-math -msse2,
+    SPANDSP_USE_SSE2 -- configure.ac:276,346,374-375,509-519), beside the strict build the parity tests use.  Timing only."""
+    import oracle
+    from oracle import ref
+    if not oracle.have_ref_fast():
+        return None
+    with ref.flavour("fast"):
+        all_rate, one_rate = measure_both()
+    return {"kind": "reference-fastmath", "value": all_rate/1e6, "single_core": one_rate/1e6, "unit": "Msamples/s", "cores": threads,
+            "build": "gcc -std=gnu99 -O2 -ffast-math -msse2 -DSPANDSP_USE_SSE2; never used for parity"}
+
+
 def ref_baseline(what, kind_id, new_state, free_state, frames_host, seconds=1.0):
     """The reference receiver on the host over a bounded sample of the same frames, driven by the pthread driver of
     oracle/ref_glue/ref_glue_mt.c (every thread loops over its slice of channel objects, frames and passes inside C):
@@ -222,8 +235,9 @@ def ref_baseline(what, kind_id, new_state, free_state, frames_host, seconds=1.0)
     all_rate, all_loops, all_dt = measure(n_ch, threads, seconds)
     one_ch = min(n_ch, 64)
     one_rate, one_loops, one_dt = measure(one_ch, 1, seconds)
+    shipped = as_shipped(lambda: (measure(n_ch, threads, 0.6*seconds)[0], measure(one_ch, 1, 0.6*seconds)[0]), threads)
     return {"value": all_rate/1e6, "unit": "Msamples/s", "cores": threads, "kind": "reference", "single_core": one_rate/1e6,
-            "host_cores": note,
+            "host_cores": note, "as_shipped": shipped,
             "sample": "reference (oracle/_ref) %s, pthread driver: %d channels x %d frames x %d passes on %d threads in %.2f s; "
                       "one core: %d channels x %d passes in %.2f s" % (what, n_ch, n_frames, all_loops, threads, all_dt,
                                                                         one_ch, one_loops, one_dt)}
@@ -245,38 +259,48 @@ ECHO_TAPS = 128
 ECHO_MODE = 0x01                        # ECHO_CAN_USE_ADAPTION (spandsp/echo.h:120-131), as SURVEY 8(d) config 5
 
 
+def g168_models():
+    """The eight echo path models of ITU-T G.168 as the reference's test program uses them (src/spandsp/g168models.h,
+    tests/echo_tests.c:396-446): taps and gain constants, from the committed fixture (tests/golden/g168_models.npz)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g168_models.npz"))
+    return [(g["taps_%d" % m].astype(np.float32), float(g["ki"][i])) for i, m in enumerate(g["models"])]
+
+
 def synth_echo(n_ch, n_frames, dev, seed):
-    """tx = white noise at about -15 dBm0, rx = tx through one of 8 sparse echo paths (ERL 6..24 dB) + low noise;
-    every tenth channel carries near-end talk in part of the frames.  Frames are continuous in time."""
+    """SURVEY 8(d)-5's lines, made on the device: tx = white noise at -15 dBm0; rx = tx through the G.168 echo path model
+    D(2 + c mod 8) at an ERL drawn from 6 ... 24 dB, the way the reference's test program simulates a line
+    (tests/echo_tests.c:443,487: echo = fir32(model, tx*gain), gain = 32768*10^(-ERL/20)*ki); near end silent, except that
+    every tenth line has talk bursts (0.5 s in every 1.5 s).  The frames are one continuous signal of n_frames*160
+    samples -- no loop, no seam.  (The FIR runs in binary32 here: its sums are exact to ~1e-7 of an LSB of the echo.)"""
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     n = n_frames*FRAME
     tx = torch.empty(n_frames, n_ch, FRAME, dtype=torch.int16, device=dev)
     rx = torch.empty_like(tx)
-    paths = torch.zeros(8, 1, ECHO_TAPS, device=dev)
-    rng = np.random.default_rng(seed)
-    for k in range(8):
-        for d in rng.integers(2, 100, 5):
-            paths[k, 0, int(d)] = float(rng.normal(0.0, 0.3))
-    erl = torch.pow(10.0, -torch.empty(n_ch, device=dev).uniform_(6.0, 24.0, generator=gen)/20.0)
-    norm = torch.sqrt((paths**2).sum(dim=2)).clamp_min(1e-3).view(8)
-    chunk = 8192                                            # channels per synthesis chunk
+    models = g168_models()
+    sigma = 32768.0*10.0**((-15.0 - 3.14)/20.0)
+    erl_db = torch.empty(n_ch, device=dev).uniform_(6.0, 24.0, generator=gen)
+    ki = torch.tensor([m[1] for m in models], device=dev)
+    chunk = 4096                                            # lines per synthesis chunk
     for c0 in range(0, n_ch, chunk):
         c1 = min(n_ch, c0 + chunk)
-        t = 4000.0*torch.randn(c1 - c0, n + ECHO_TAPS - 1, device=dev, generator=gen)
-        t = torch.clamp(torch.round(t), -32768, 32767)
         idx = torch.arange(c0, c1, device=dev) % 8
+        t = torch.clamp(torch.round(sigma*torch.randn(c1 - c0, n, device=dev, generator=gen)), -32768, 32767)
+        gain = (32768.0*torch.pow(10.0, -erl_db[c0:c1]/20.0)*ki[idx]).unsqueeze(1)
+        s = torch.trunc(t*gain)
         r = torch.empty(c1 - c0, n, device=dev)
         for k in range(8):
             m = (idx == k).nonzero().squeeze(1)
             if m.numel():
-                r[m] = torch.nn.functional.conv1d(t[m].unsqueeze(1), paths[k:k + 1].flip(2)).squeeze(1)/norm[k]
-        r = r*erl[c0:c1].unsqueeze(1) + 10.0*torch.randn(c1 - c0, n, device=dev, generator=gen)
+                w = torch.tensor(models[k][0], device=dev).flip(0).view(1, 1, -1)
+                x = torch.nn.functional.pad(s[m].unsqueeze(1), (w.shape[2] - 1, 0))
+                r[m] = torch.floor(torch.nn.functional.conv1d(x, w).squeeze(1)/32768.0)
         talk = (torch.arange(c0, c1, device=dev) % 10 == 0).unsqueeze(1)
         burst = ((torch.arange(n, device=dev)//4000) % 3 == 1).unsqueeze(0)
-        r = r + torch.where(talk & burst, 3000.0*torch.randn(c1 - c0, n, device=dev, generator=gen), torch.zeros((), device=dev))
-        tx[:, c0:c1] = t[:, ECHO_TAPS - 1:].to(torch.int16).view(c1 - c0, n_frames, FRAME).permute(1, 0, 2)
-        rx[:, c0:c1] = torch.clamp(torch.round(r), -32768, 32767).to(torch.int16).view(c1 - c0, n_frames, FRAME).permute(1, 0, 2)
+        r = r + torch.where(talk & burst, torch.round(3000.0*torch.randn(c1 - c0, n, device=dev, generator=gen)), torch.zeros((), device=dev))
+        tx[:, c0:c1] = t.to(torch.int16).view(c1 - c0, n_frames, FRAME).permute(1, 0, 2)
+        rx[:, c0:c1] = torch.clamp(r, -32768, 32767).to(torch.int16).view(c1 - c0, n_frames, FRAME).permute(1, 0, 2)
+        del t, s, r
     return tx, rx
 
 
@@ -298,17 +322,36 @@ def cpu_echo(tx_host, rx_host, seconds=1.0):
     all_rate, all_loops, all_dt = measure(n_ch, threads, seconds)
     one_ch = min(n_ch, 32)
     one_rate, one_loops, one_dt = measure(one_ch, 1, seconds)
+    shipped = as_shipped(lambda: (measure(n_ch, threads, 0.6*seconds)[0], measure(one_ch, 1, 0.6*seconds)[0]), threads)
     return {"value": all_rate/1e6, "unit": "Msamples/s", "cores": threads, "kind": "reference", "single_core": one_rate/1e6,
-            "host_cores": note,
+            "host_cores": note, "as_shipped": shipped,
             "sample": "reference (oracle/_ref) echo_can_update() 128 taps, pthread driver: %d channels x %d frames x %d passes on "
                       "%d threads in %.2f s; one core: %d channels x %d passes in %.2f s"
                       % (n_ch, n_frames, all_loops, threads, all_dt, one_ch, one_loops, one_dt)}
 
 
+def echo_spot_check(tx64, rx64, clean64):
+    """The oracle's echo_can_update() (oracle/echo_oracle.c, pinned to the reference) over the same first frames of 64 lines:
+    every clean sample equal?  tx64 / rx64 / clean64: int16 [frames, 64, FRAME] on the host."""
+    from oracle import restated as orc
+    nfr, v, _ = tx64.shape
+    ok = True
+    for c in range(v):
+        d = orc.EchoCan(ECHO_TAPS, ECHO_MODE)
+        want = d.run(np.ascontiguousarray(tx64[:, c]).reshape(-1), np.ascontiguousarray(rx64[:, c]).reshape(-1), False)
+        ok = ok and np.array_equal(want, np.ascontiguousarray(clean64[:, c]).reshape(-1))
+    return {"channels": v, "frames": nfr, "checked": "every clean sample of the first %d frames of lines 0..%d against the oracle's echo_can_update()" % (nfr, v - 1),
+            "bit_exact": bool(ok)}
+
+
 def bench_echo(args, dev, stream):
+    """BASELINE configs[4], one GPU's shard, on SURVEY 8(d)-5's workload: `seconds` of continuous signal on G.168 lines
+    (synth_echo); the first second warms up (and is checked against the oracle on 64 lines), the rest is timed; the ERLE of
+    every line over the last second comes from the bank's own sums."""
     from spandsp_amd import engine
     n_ch = args.channels or 131072
-    nf = min(args.steps + args.warmup, 60)
+    seconds = getattr(args, "echo_seconds", 10)
+    nf = seconds*50
     tx, rx = synth_echo(n_ch, nf, dev, seed=0xEC40)
     clean = torch.empty(n_ch, FRAME, dtype=torch.int16, device=dev)
     if args.echo_lanes:
@@ -316,54 +359,95 @@ def bench_echo(args, dev, stream):
     bank = engine.EchoBank(n_ch, ECHO_TAPS, ECHO_MODE)
     engine.lib().spangpu_tune_echo_lanes_per_channel(0)
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    bank.stats(2)                       # energy sums by the update kernel itself
     fb = n_ch*FRAME*2
-    power_rx = 0.0
-    power_clean = 0.0
+    warm = 50
+    steps = nf - warm
+    v = min(64, n_ch)
+    kept = []
 
-    def step(i):
-        k = i % nf
+    def step(k):
         bank.update_device(ctypes.c_void_p(tx.data_ptr() + k*fb), ctypes.c_void_p(rx.data_ptr() + k*fb),
                            ctypes.c_void_p(clean.data_ptr()), FRAME, FRAME)
-    for i in range(args.warmup):
-        step(i)
+    for k in range(warm):
+        step(k)
+        if k < 25:
+            kept.append(clean[:v].clone())
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        evs[i][0].record(stream)
-        step(args.warmup + i)
-        evs[i][1].record(stream)
+    ev0.record(stream)
+    for k in range(warm, nf):
+        if k == nf - 50:
+            bank.stats_reset(sums=True, crc=False)
+        step(k)
+    ev1.record(stream)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    k = (args.warmup + args.steps - 1) % nf
+    avg_ms = ev0.elapsed_time(ev1)/steps
+    erle = torch.zeros(n_ch, dtype=torch.float32, device=dev)
+    bank.erle_device(ctypes.c_void_p(erle.data_ptr()))
+    torch.cuda.synchronize()
     quiet = torch.arange(n_ch, device=dev) % 10 != 0
-    power_rx = float((rx[k][quiet].float()**2).mean())
-    power_clean = float((clean[quiet].float()**2).mean())
-    per = [a.elapsed_time(b) for a, b in evs]
-    avg_ms = sum(per)/len(per)
+    es = erle[quiet]
     state_bytes = 48*4 + ECHO_TAPS*4 + 4*ECHO_TAPS*2 + ECHO_TAPS*2      # scalars + taps32 + taps16[4] + history
     alg_read = n_ch*(2*FRAME*2 + state_bytes)
     alg_write = n_ch*(FRAME*2 + state_bytes)
     cpu = None
     if not args.no_cpu_baseline:
         nc = min(args.cpu_channels, n_ch, 4096)
-        nfc = min(nf, 60)
-        cpu = cpu_echo(tx[:nfc, :nc].contiguous().cpu().numpy(), rx[:nfc, :nc].contiguous().cpu().numpy())
-    value = args.steps*n_ch*FRAME/dt/1e6
+        cpu = cpu_echo(tx[:60, :nc].contiguous().cpu().numpy(), rx[:60, :nc].contiguous().cpu().numpy(), getattr(args, "cpu_seconds", 1.0))
+        cpu["spot_check"] = echo_spot_check(tx[:25, :v].cpu().numpy(), rx[:25, :v].cpu().numpy(), torch.stack(kept).cpu().numpy())
+    value = steps*n_ch*FRAME/dt/1e6
+    lanes = engine.lib().spangpu_echo_lanes_per_channel(bank.h)
     return {
         "metric": "Msamples/s of batched G.168 echo cancellation, 128 taps (8 kHz channels at real-time = value*1e6/8000)",
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
+        "steps": steps, "warmup": warm, "ms_per_step": dt*1e3/steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[4] (one GPU's shard): echo_can_update 128 taps, %d channels x %d-sample "
-                               "frames, mode ECHO_CAN_USE_ADAPTION" % (n_ch, FRAME), "channels_per_gpu": n_ch,
-                   "erle_db_last_frame_single_talk_channels": 10.0*np.log10(max(power_rx, 1e-9)/max(power_clean, 1e-9))},
-        "roofline": {"bound": "hbm", "kernel": "echo canceller kernel, %d lanes per channel, 128 taps" % engine.lib().spangpu_echo_lanes_per_channel(bank.h), "achieved": alg_read/(avg_ms*1e-3)/1e9,
+        "config": {"workload": "BASELINE configs[4] (one GPU's shard), SURVEY 8(d)-5's lines: echo_can_update 128 taps, mode "
+                               "ECHO_CAN_USE_ADAPTION, %d channels x %d-sample frames, %d s of continuous signal: white noise at "
+                               "-15 dBm0 through G.168 echo path models D2..D9 (by channel mod 8), ERL 6..24 dB, every tenth line "
+                               "with near end talk bursts" % (n_ch, FRAME, seconds), "channels_per_gpu": n_ch,
+                   "erle_db_last_second_single_talk_lines": {"median": float(es.median()), "p10": float(es.quantile(0.1)),
+                                                             "p90": float(es.quantile(0.9))}},
+        "roofline": {"bound": "hbm", "kernel": "echo canceller kernel, %d lanes per channel (echo_%s), 128 taps" % (lanes, "pair_kernel" if lanes == 2 else "bank_kernel"),
+                     "achieved": alg_read/(avg_ms*1e-3)/1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
                      "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
                      "avg_launch_us": avg_ms*1e3,
                      "note": "integer-VALU bound (2 x 128 MACs per sample per channel); the HBM figure is reported, not targeted"},
         "cpu_baseline": cpu}
+
+
+MIXED_ST_PLAN = ([(400, 0, 700, 0)], [(1100, 0, 400, 600), (0, 0, 2800, 3200)], [(350, 440, 400, 0)],
+                 [(480, 620, 450, 550), (0, 0, 450, 550)], [(950, 0, 300, 0)], [(1400, 0, 300, 0)])
+
+
+def mixed_spot_check(srcs, kept):
+    """The oracle's bell_mf_rx() / r2_mf_rx() / super_tone_rx() block decisions (oracle/tone_oracle.c, pinned to the
+    reference) over the first frames of 64 channels of each bank against the records the launch wrote."""
+    from oracle import restated as orc
+    desc = orc.SuperToneDesc()
+    for tone in MIXED_ST_PLAN:
+        t = desc.add_tone()
+        for f1, f2, lo, hi in tone:
+            desc.add_element(t, f1, f2, lo, hi)
+    ok = True
+    blocks = 0
+    for kind in range(3):
+        v, n = srcs[kind].shape
+        for c in range(v):
+            o = orc.BellMf(0) if kind == 0 else orc.R2Mf(True, True) if kind == 1 else orc.SuperTone(desc)
+            want = []
+            for k in range(n//FRAME):
+                want.extend(o.rx(srcs[kind][c, k*FRAME:(k + 1)*FRAME]))
+            got = [(int(r["hit"]), int(r["code"])) for b in kept[kind] for r in b[b["channel"] == c]]
+            ok = ok and got == [(int(x["hit"]), int(x["aux"])) for x in want]
+            blocks += len(want)
+    return {"channels": 3*srcs[0].shape[0], "frames": len(kept[0]), "checked": "hit and code of every block (%d) of the first frames of 64 channels of each bank "
+            "against the oracle's bell_mf_rx / r2_mf_rx / super_tone_rx" % blocks, "bit_exact": bool(ok)}
 
 
 # ---- mixed Goertzel banks ------------------------------------------------------------------------------
@@ -387,7 +471,7 @@ def bench_mixed(args, dev, stream):
         fsel = (torch.arange(nf, device=dev).unsqueeze(0) + rot.unsqueeze(1)) % nf          # [ch, frame]
         f = src[(idx % n_src).unsqueeze(1), fsel]                                            # [ch, frame, FRAME]
         frames.append(f.permute(1, 0, 2).contiguous())
-    st_freqs = [350.0, 400.0, 440.0, 480.0, 620.0, 950.0, 1100.0, 1400.0]
+    st_freqs = [400.0, 1100.0, 350.0, 440.0, 480.0, 620.0, 950.0, 1400.0]      # in the order MIXED_ST_PLAN's descriptor monitors them
     fac = [engine.goertzel_fac(f) for f in st_freqs]
     banks = [engine.ToneBank(engine.BELL_MF, n_each[0]), engine.ToneBank(engine.R2_MF, n_each[1], r2_fwd=True),
              engine.ToneBank(engine.SUPER_TONE, n_each[2], bin_fac=fac)]
@@ -405,8 +489,14 @@ def bench_mixed(args, dev, stream):
             return
         for kind in range(3):
             banks[kind].rx_device(addr[i % nf][kind], FRAME, FRAME)
+    kept = [[] for _ in range(3)]
+    v = 64
     for i in range(args.warmup):
         step(i)
+        if i < 20 and not args.no_cpu_baseline:
+            for kind in range(3):
+                b = banks[kind].blocks()
+                kept[kind].append(b[b["channel"] < v].copy())
     torch.cuda.synchronize()
     # the launch duration: HIP events on the launch stream around the whole timed region / launches in it
     reps = max(1, int(np.ceil(2000/args.steps)))
@@ -446,6 +536,12 @@ def bench_mixed(args, dev, stream):
                "kind": "reference", "single_core": 1.0/sum(w[k]/parts[k]["single_core"] for k in range(3)),
                "host_cores": parts[0]["host_cores"],
                "sample": "channel-weighted harmonic mean of: " + " | ".join(p["sample"] for p in parts)}
+        if all(p.get("as_shipped") for p in parts):
+            cpu["as_shipped"] = dict(parts[0]["as_shipped"],
+                                     value=1.0/sum(w[k]/parts[k]["as_shipped"]["value"] for k in range(3)),
+                                     single_core=1.0/sum(w[k]/parts[k]["as_shipped"]["single_core"] for k in range(3)))
+        if kept[0]:
+            cpu["spot_check"] = mixed_spot_check([srcs[k][:v, :len(kept[k])*FRAME] for k in range(3)], kept)
     return {
         "metric": "Msamples/s of mixed Bell MF + R2 MF + super-tone Goertzel banks (8 kHz channels at real-time = value*1e6/8000)",
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
@@ -862,6 +958,147 @@ def bench_dtmf_tx(args, dev, stream):
         "cpu_baseline": cpu}
 
 
+def modem_spot_check(kind, bit_rate, frames64, events64):
+    """The oracle's receiver (oracle/v29_oracle.c ..., pinned to the reference) over the same first frames of 64 channels:
+    the put_bit stream of every frame equal?  frames64: int16 [frames, 64, FRAME]; events64[frame][channel]: int8 arrays."""
+    from oracle import restated as orc
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_pin import use_golden_modem_tables
+    use_golden_modem_tables()
+    O = {"v29": orc.V29, "v27ter": orc.V27ter, "v17": orc.V17}[kind]
+    nfr, v, _ = frames64.shape
+    ok = True
+    total = 0
+    for c in range(v):
+        o = O(bit_rate)
+        for k in range(nfr):
+            o.sink.clear()
+            o.rx(np.ascontiguousarray(frames64[k, c]))
+            want = o.sink.events()["a"].astype(np.int8)
+            ok = ok and np.array_equal(want, events64[k][c])
+            total += len(want)
+    return {"channels": v, "frames": nfr, "checked": "every put_bit / status call (%d) of the first %d frames of channels 0..%d against the oracle's %s_rx()"
+            % (total, nfr, v - 1, kind), "bit_exact": bool(ok)}
+
+
+def bench_modem(args, dev, stream):
+    from spandsp_amd import engine
+    fixture, bit_rate, n_words = MODEMS[args.workload]
+    kind = {"v29": engine.V29, "v17": engine.V17, "v27ter": engine.V27TER}[args.workload]
+    n_ch = args.channels or 16384
+    nf = args.steps + args.warmup
+    if args.workload in ("v29", "v27ter", "v17") and not args.replay_fixture:
+        frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem=args.workload)
+    else:
+        frames = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture)
+    engine.tune_modem_mapping(args.modem_mapping)
+    bank = engine.ModemBank(kind, n_ch, bit_rate)
+    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    frame_bytes = n_ch*FRAME*2
+    torch.cuda.synchronize()
+    for i in range(args.warmup):
+        bank.rx_device(ctypes.c_void_p(frames.data_ptr() + i*frame_bytes), FRAME, FRAME)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        evs[i][0].record(stream)
+        bank.rx_device(ctypes.c_void_p(frames.data_ptr() + (args.warmup + i)*frame_bytes), FRAME, FRAME)
+        evs[i][1].record(stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = [a.elapsed_time(b) for a, b in evs]
+    avg_ms = sum(per)/len(per)
+    ev = bank.events()
+    bits_last = int(sum(len(e) for e in ev))
+    trained = 0
+    for c in range(0, n_ch, max(1, n_ch//256)):
+        _, w = bank.get_state(c)
+        trained += int(w[6] == 0)
+    alg_read = n_ch*(FRAME*2 + n_words*4)
+    alg_write = n_ch*(n_words*4 + 4 + 208)
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_modem(args.workload, bit_rate, frames[:, :min(args.cpu_channels, n_ch)].contiguous().cpu().numpy())
+        # a 64-channel bank on the first rows of the same frames (the same kernel family as every bank below 65 536 channels)
+        v, nchk = min(64, n_ch), min(40, nf)
+        small = engine.ModemBank(kind, v, bit_rate)
+        ev64 = []
+        for k in range(nchk):
+            small.rx_device(ctypes.c_void_p(frames.data_ptr() + k*frame_bytes), FRAME, FRAME)
+            ev64.append(small.events())
+        cpu["spot_check"] = modem_spot_check(args.workload, bit_rate, frames[:nchk, :v].cpu().numpy(), ev64)
+        small.close()
+    value = args.steps*n_ch*FRAME/dt/1e6
+    return {
+        "metric": "Msamples/s of batched %s %d bps receive (8 kHz channels at real-time = value*1e6/8000)" % (args.workload, bit_rate),
+        "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s %d bps RX, %d channels x %d-sample frames, AWGN%s"
+                               % (args.workload, bit_rate, n_ch, FRAME, " (BASELINE configs[3])" if args.workload == "v29" else ""),
+                   "channels_per_gpu": n_ch, "modem_mapping": args.modem_mapping,
+                   "sampled_channels_in_data_mode_at_end": "%d of %d" % (trained, len(range(0, n_ch, max(1, n_ch//256)))),
+                   "events_in_last_frame": bits_last},
+        "roofline": {"bound": "hbm", "kernel": ("%s_quad_kernel<16, 4>" if (n_ch < 32768 and args.modem_mapping in (0, 4, 8) and args.workload in ("v29", "v17", "v27ter")) else "%s_bank_kernel") % args.workload, "achieved": alg_read/(avg_ms*1e-3)/1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS,
+                     "traffic": None, "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
+                     "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3, "max_launch_us": max(per)*1e3,
+                     "note": "VALU/LDS-issue bound state machine (SURVEY 8(d)); the HBM figure is reported, not targeted"},
+        "cpu_baseline": cpu}
+
+
+
+
+def compact_path(line, key, channels, stream_peak=None):
+    """One BASELINE configuration's line boiled down for bench.py's `paths` object."""
+    from spandsp_amd import roofline as rl
+    roof = dict(line["roofline"])
+    if stream_peak:
+        roof["measured_stream_peak"] = stream_peak
+        roof["frac_of_measured_stream"] = roof["achieved"]/stream_peak
+    out = {"workload": line["config"]["workload"], "channels": channels, "steps": line["steps"], "ms_per_step": line["ms_per_step"],
+           "value": line["value"], "unit": line["unit"], "realtime_channels": line["realtime_channels"], "dtype": line["dtype"],
+           "roofline": roof, "roofline_valu": rl.valu_roof(key, roof.get("avg_launch_us"), channels=channels),
+           "cpu_baseline": line.get("cpu_baseline")}
+    for k in ("erle_db_last_second_single_talk_lines", "sampled_channels_in_data_mode_at_end", "events_in_last_frame", "blocks_with_a_hit_in_last_step"):
+        if k in line["config"]:
+            out[k] = line["config"][k]
+    return out
+
+
+def paths_for_bench(dev, stream, no_cpu_baseline=False, stream_peak=None, echo_seconds=10):
+    """BASELINE configs[2], [3] and [4] at full size for the same JSON line as the headline (bench.py `paths`): each with its
+    step time, the roofline of its kernel, a short cpu_baseline of the reference on the host cores and -- inside that leg --
+    a spot check of 64 channels against the oracle.  Bounded: a few tens of seconds in all."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    base = dict(channels=0, warmup=0, no_cpu_baseline=no_cpu_baseline, echo_lanes=0, separate_launches=False, cpu_channels=4096,
+                fsk_waves=0, modem_mapping=0, replay_fixture=False, echo_seconds=echo_seconds, cpu_seconds=0.7)
+    out = {}
+    t0 = time.perf_counter()
+    try:
+        a = types.SimpleNamespace(workload="mixed", steps=200, **base)
+        a.warmup = 20
+        out["mixed"] = compact_path(bench_mixed(a, dev, stream), "mixed", 131072, stream_peak)
+    except Exception as e:                                    # a path that fails must not take the headline line with it
+        out["mixed"] = {"error": repr(e)}
+    try:
+        a = types.SimpleNamespace(workload="v29", steps=150, **base)
+        out["v29"] = compact_path(bench_modem(a, dev, stream), "v29", 16384, stream_peak)
+    except Exception as e:
+        out["v29"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    try:
+        a = types.SimpleNamespace(workload="echo", steps=0, **base)
+        out["echo"] = compact_path(bench_echo(a, dev, stream), "echo", 131072, stream_peak)
+    except Exception as e:
+        out["echo"] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
 def emit(line, key, channels=None):
     """Print a bench line with the bounds beside the HBM roofline: the measured stream ceiling of this device in this run, and
     the VALU issue floor of the workload's kernel (spandsp_amd/roofline.py)."""
@@ -887,6 +1124,7 @@ def main():
                     help="fsk / mct / sigtone: 0 = the library's choice, 1 = one wavefront per 64 receivers, 2 = two (A-B runs)")
     ap.add_argument("--modem-mapping", type=int, default=0,
                     help="v29 / v17 / v27ter: 0 = the library's choice, 1 = one channel per lane, 4 / 8 = four lanes per channel (A-B runs)")
+    ap.add_argument("--echo-seconds", type=int, default=10, help="echo: seconds of continuous signal (the first one warms up, the rest is timed)")
     ap.add_argument("--replay-fixture", action="store_true",
                     help="v29 / v27ter / v17: replay the committed reference transmission instead of running the transmitter bank")
     args = ap.parse_args()
@@ -933,60 +1171,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         emit(bench_dtmf_tx(args, dev, stream), "dtmf_tx", args.channels or None)
         return
-    fixture, bit_rate, n_words = MODEMS[args.workload]
-    kind = {"v29": engine.V29, "v17": engine.V17, "v27ter": engine.V27TER}[args.workload]
-    n_ch = args.channels or 16384
-    nf = args.steps + args.warmup
-    if args.workload in ("v29", "v27ter", "v17") and not args.replay_fixture:
-        frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem=args.workload)
-    else:
-        frames = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture)
-    engine.tune_modem_mapping(args.modem_mapping)
-    bank = engine.ModemBank(kind, n_ch, bit_rate)
-    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
-    frame_bytes = n_ch*FRAME*2
-    torch.cuda.synchronize()
-    for i in range(args.warmup):
-        bank.rx_device(ctypes.c_void_p(frames.data_ptr() + i*frame_bytes), FRAME, FRAME)
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        evs[i][0].record(stream)
-        bank.rx_device(ctypes.c_void_p(frames.data_ptr() + (args.warmup + i)*frame_bytes), FRAME, FRAME)
-        evs[i][1].record(stream)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    per = [a.elapsed_time(b) for a, b in evs]
-    avg_ms = sum(per)/len(per)
-    ev = bank.events()
-    bits_last = int(sum(len(e) for e in ev))
-    trained = 0
-    for c in range(0, n_ch, max(1, n_ch//256)):
-        _, w = bank.get_state(c)
-        trained += int(w[6] == 0)
-    alg_read = n_ch*(FRAME*2 + n_words*4)
-    alg_write = n_ch*(n_words*4 + 4 + 208)
-    cpu = None
-    if not args.no_cpu_baseline:
-        cpu = cpu_modem(args.workload, bit_rate, frames[:, :min(args.cpu_channels, n_ch)].contiguous().cpu().numpy())
-    value = args.steps*n_ch*FRAME/dt/1e6
-    emit({
-        "metric": "Msamples/s of batched %s %d bps receive (8 kHz channels at real-time = value*1e6/8000)" % (args.workload, bit_rate),
-        "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s %d bps RX, %d channels x %d-sample frames, AWGN%s"
-                               % (args.workload, bit_rate, n_ch, FRAME, " (BASELINE configs[3])" if args.workload == "v29" else ""),
-                   "channels_per_gpu": n_ch, "modem_mapping": args.modem_mapping,
-                   "sampled_channels_in_data_mode_at_end": "%d of %d" % (trained, len(range(0, n_ch, max(1, n_ch//256)))),
-                   "events_in_last_frame": bits_last},
-        "roofline": {"bound": "hbm", "kernel": ("%s_quad_kernel<16, 4>" if (n_ch < 32768 and args.modem_mapping in (0, 4, 8) and args.workload in ("v29", "v17", "v27ter")) else "%s_bank_kernel") % args.workload, "achieved": alg_read/(avg_ms*1e-3)/1e9,
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS,
-                     "traffic": None, "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
-                     "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3, "max_launch_us": max(per)*1e3,
-                     "note": "VALU/LDS-issue bound state machine (SURVEY 8(d)); the HBM figure is reported, not targeted"},
-        "cpu_baseline": cpu}, args.workload, n_ch)
+    emit(bench_modem(args, dev, stream), args.workload, args.channels or 16384)
 
 
 if __name__ == "__main__":
