@@ -723,6 +723,58 @@ SPANGPU_API int spangpu_awgn_tx(spangpu_awgn_t *bank, int mem, int16_t *pcm, lon
 SPANGPU_API int spangpu_awgn_state_words(const spangpu_awgn_t *bank);
 SPANGPU_API int spangpu_awgn_get_state(spangpu_awgn_t *bank, int channel, int32_t *words);
 
+/* ---- The pipelined host path of echo canceller and modem receiver banks (csrc/feed_api.hip, round 4) -----------------------
+   echo_can_update() returns the cleaned sample to its caller (src/echo.c:421-661) and v29_rx() delivers bits through
+   put_bit (src/v29rx.c:867-965; negative "bits" are SIG_STATUS_* reports, spandsp/async.h:66-103): for these paths the way
+   back over PCIe is part of the product.  A slot has a pinned buffer each way; a tick's H2D copy, kernel and D2H copy run on
+   three streams, so tick t + 1's input crosses the link downwards while tick t's kernel runs and tick t - 1's output
+   crosses it upwards (full duplex): a tick costs max(H2D, kernel, D2H).
+   Echo: per tick  spangpu_echo_feed_acquire(feed, &tx, &rx); write channel c at tx / rx + c*stride samples (int16) or bytes
+   (law = SPANGPU_G711_ALAW / _ULAW: decoded on the device, the clean signal encoded on the device -- linear_to_alaw /
+   linear_to_ulaw of spandsp/g711.h:124-237 -- half the volume each way);  spangpu_echo_feed_commit(feed, samples);
+   n = spangpu_echo_feed_collect(feed, &clean)  (up to depth - 1 ticks later): the clean rows in the same format. */
+typedef struct spangpu_xfeed_s spangpu_echo_feed_t;
+typedef struct spangpu_xfeed_s spangpu_modem_feed_t;
+SPANGPU_API int spangpu_echo_feed_create(spangpu_echo_feed_t **feed, spangpu_echo_t *ec, int max_samples, int law, int depth, int use_hpf_tx);
+SPANGPU_API int spangpu_echo_feed_destroy(spangpu_echo_feed_t *feed);
+SPANGPU_API long long spangpu_echo_feed_stride(const spangpu_echo_feed_t *feed);
+SPANGPU_API int spangpu_echo_feed_acquire(spangpu_echo_feed_t *feed, void **tx, void **rx);
+SPANGPU_API int spangpu_echo_feed_commit(spangpu_echo_feed_t *feed, int samples);
+SPANGPU_API int spangpu_echo_feed_collect(spangpu_echo_feed_t *feed, const void **clean);
+SPANGPU_API int spangpu_echo_feed_outstanding(const spangpu_echo_feed_t *feed);
+SPANGPU_API int spangpu_echo_feed_run(spangpu_echo_feed_t *feed, int samples, int ticks, int lag, double *elapsed_ms);
+/* The put_bit stream of the last spangpu_modem_rx() in packed form, device to device on the bank's stream (24
+   bytes of bits per channel and 160-sample frame for V.29 9600, against one byte per put_bit call in spangpu_modem_events()):
+   row c of packed_device[n_ch][words_per_channel]: word 0 = data bits | status reports << 16 of the call (bit 31: the call's
+   event buffer overflowed), then the data bits LSB first; status_device[0] = status reports of the whole bank, then pairs
+   {channel, data bits delivered before it | (code & 0xFFFF) << 16}, a channel's reports in call order.
+   spangpu_modem_packed_words(): row length that holds every bit a call of `samples` samples can deliver at `bit_rate`.
+   spangpu_modem_unpack_events() (host code): the packed form back into the calls -- events[n_ch][cap] int8 and counts[n_ch]
+   exactly as spangpu_modem_events() delivers them -- for a shim that replays put_bit / status callbacks. */
+SPANGPU_API int spangpu_modem_packed_words(int bit_rate, int samples);
+SPANGPU_API int spangpu_modem_pack_events(spangpu_modem_t *modem, uint32_t *packed_device, int words_per_channel, uint32_t *status_device, int status_cap);
+SPANGPU_API int spangpu_modem_unpack_events(const uint32_t *packed, int words_per_channel, const uint32_t *status, int status_cap, int n_ch,
+                                            int8_t *events, int cap, int32_t *counts);
+SPANGPU_API void *spangpu_modem_get_stream(spangpu_modem_t *modem);
+SPANGPU_API int spangpu_modem_bit_rate(const spangpu_modem_t *modem);
+SPANGPU_API int spangpu_modem_device(const spangpu_modem_t *modem);
+SPANGPU_API void *spangpu_echo_get_stream(spangpu_echo_t *ec);
+SPANGPU_API int spangpu_echo_device(const spangpu_echo_t *ec);
+/* Modem: per tick  buf = spangpu_modem_feed_acquire(feed); write channel c's PCM at buf + c*stride samples;
+   spangpu_modem_feed_commit(feed, samples);  n = spangpu_modem_feed_collect(feed, &packed, &status): the tick's put_bit
+   stream packed as above ([n_ch][spangpu_modem_feed_words_per_channel()] rows, status list of
+   spangpu_modem_feed_status_cap() entries).  max_bit_rate sizes the rows (a bank's channels may run different rates). */
+SPANGPU_API int spangpu_modem_feed_create(spangpu_modem_feed_t **feed, spangpu_modem_t *modem, int max_samples, int max_bit_rate, int depth);
+SPANGPU_API int spangpu_modem_feed_destroy(spangpu_modem_feed_t *feed);
+SPANGPU_API long long spangpu_modem_feed_stride(const spangpu_modem_feed_t *feed);
+SPANGPU_API int spangpu_modem_feed_words_per_channel(const spangpu_modem_feed_t *feed);
+SPANGPU_API int spangpu_modem_feed_status_cap(const spangpu_modem_feed_t *feed);
+SPANGPU_API void *spangpu_modem_feed_acquire(spangpu_modem_feed_t *feed);
+SPANGPU_API int spangpu_modem_feed_commit(spangpu_modem_feed_t *feed, int samples);
+SPANGPU_API int spangpu_modem_feed_collect(spangpu_modem_feed_t *feed, const uint32_t **packed, const uint32_t **status);
+SPANGPU_API int spangpu_modem_feed_outstanding(const spangpu_modem_feed_t *feed);
+SPANGPU_API int spangpu_modem_feed_run(spangpu_modem_feed_t *feed, int samples, int ticks, int lag, double *elapsed_ms, long long *bits);
+
 #if defined(__cplusplus)
 }
 #endif

@@ -186,6 +186,9 @@ int spangpu_echo_channels(const spangpu_echo_t *e) { return e  ?  e->n_ch  :  SP
 int spangpu_echo_taps(const spangpu_echo_t *e) { return e  ?  e->taps  :  SPANGPU_ERR_BAD_ARG; }
 int spangpu_echo_lanes_per_channel(const spangpu_echo_t *e) { return e  ?  e->group  :  SPANGPU_ERR_BAD_ARG; }
 
+void *spangpu_echo_get_stream(spangpu_echo_t *e) { return e  ?  (void *) e->stream  :  nullptr; }
+int spangpu_echo_device(const spangpu_echo_t *e) { return e  ?  e->device  :  SPANGPU_ERR_BAD_ARG; }
+
 int spangpu_echo_set_stream(spangpu_echo_t *e, void *hip_stream)
 {
     if (e == nullptr)

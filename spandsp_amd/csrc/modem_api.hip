@@ -725,6 +725,178 @@ int spangpu_modem_copy_events(spangpu_modem_t *m, void *dev_dst, size_t dst_byte
     return SPANGPU_OK;
 }
 
+// ---- the put_bit stream in packed form (24 bytes per channel and frame for V.29 9600) -----------------------
+// spangpu_modem_events() brings one byte per put_bit() call to the host (n_ch x cap bytes a tick).  What a caller needs to
+// replay the calls is less: the data bits, eight to a byte, and -- rarely -- a status report with its place in the bit
+// stream.  Row c of `packed` (words_per_channel words): word 0 = data bits | status reports << 16 of the call, then the
+// bits LSB first.  The status reports of the whole bank go to one list: list[0] = how many, then pairs
+// {channel, data bits that came before it | (code & 0xFFFF) << 16}; the reports of one channel stand in call order.
+__global__ void modem_pack_kernel(const int8_t *events, const int32_t *counts, int n_ch, int cap, uint32_t *packed, int wpc,
+                                  uint32_t *status, int status_cap)
+{
+    const int c = blockIdx.x*blockDim.x + threadIdx.x;
+    if (c >= n_ch)
+        return;
+    const int8_t *ev = events + (size_t) c*cap;
+    const int n = min(counts[c], cap);
+    uint32_t *row = packed + (size_t) c*wpc;
+    const int room = (wpc - 1)*32;
+    uint32_t acc = 0;
+    int nbits = 0;
+    int nstat = 0;
+    // sixteen events a load where the rows allow it (cap a multiple of 16: what spangpu_modem_rx() sizes them to)
+    const bool wide = ((cap & 15) == 0)  &&  (((uintptr_t) events & 15) == 0);
+    uint4 chunk = make_uint4(0, 0, 0, 0);
+    for (int i = 0;  i < n;  i++)
+    {
+        int v;
+        if (wide)
+        {
+            if ((i & 15) == 0)
+                chunk = *(const uint4 *) (ev + i);
+            const int k = i & 15;
+            const uint32_t w = (k < 4)  ?  chunk.x  :  (k < 8)  ?  chunk.y  :  (k < 12)  ?  chunk.z  :  chunk.w;
+            v = (int) (int8_t) (w >> (8*(k & 3)));
+        }
+        else
+        {
+            v = ev[i];
+        }
+        if (v >= 0)
+        {
+            if (nbits < room)
+            {
+                acc |= (uint32_t) (v & 1) << (nbits & 31);
+                if ((nbits & 31) == 31)
+                {
+                    row[1 + (nbits >> 5)] = acc;
+                    acc = 0;
+                }
+            }
+            nbits++;
+        }
+        else
+        {
+            const uint32_t at = atomicAdd(&status[0], 1u);
+            if (at < (uint32_t) status_cap)
+            {
+                status[1 + 2*at] = (uint32_t) c;
+                status[2 + 2*at] = ((uint32_t) nbits & 0xFFFFu) | (((uint32_t) v & 0xFFFFu) << 16);
+            }
+            nstat++;
+        }
+    }
+    if ((nbits & 31) != 0  &&  nbits < room)
+        row[1 + (nbits >> 5)] = acc;
+    // (a count of data bits above what the row holds says the row was too short; counts[c] > cap shows in bit 31)
+    row[0] = ((uint32_t) nbits & 0x7FFFu) | (((uint32_t) nstat & 0x7FFFu) << 16) | ((counts[c] > cap)  ?  0x80000000u  :  0u);
+}
+
+// Words per channel that hold every data bit a call of `samples` samples can deliver at `bit_rate` (one header word + the
+// bits; the receivers deliver a whole number of bauds, so a call can run a baud ahead of its share).
+int spangpu_modem_packed_words(int bit_rate, int samples)
+{
+    if (bit_rate <= 0  ||  samples < 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    const long long bits = ((long long) samples*bit_rate + 7999)/8000 + 16;
+    return 1 + (int) ((bits + 31)/32);
+}
+
+// The last spangpu_modem_rx()'s put_bit stream, packed (see modem_pack_kernel above), device to device on the bank's stream:
+// packed_device [n_ch][words_per_channel], status_device [1 + 2*status_cap] (its first word is cleared here).
+int spangpu_modem_pack_events(spangpu_modem_t *m, uint32_t *packed_device, int words_per_channel, uint32_t *status_device, int status_cap)
+{
+    if (m == nullptr  ||  packed_device == nullptr  ||  status_device == nullptr  ||  words_per_channel < 2  ||  status_cap < 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (m->last_cap <= 0)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "no spangpu_modem_rx() yet");
+    V29_TRY(hipSetDevice(m->device));
+    V29_TRY(hipMemsetAsync(status_device, 0, sizeof(uint32_t), m->stream));
+    hipLaunchKernelGGL(modem_pack_kernel, dim3((m->n_ch + 255)/256), dim3(256), 0, m->stream, (const int8_t *) m->events,
+                       (const int32_t *) m->ev_count, m->n_ch, m->last_cap, packed_device, words_per_channel, status_device, status_cap);
+    V29_TRY(hipGetLastError());
+    return SPANGPU_OK;
+}
+
+// Host side: the packed form back into the form spangpu_modem_events() delivers (events [n_ch][cap] int8, counts[n_ch]),
+// i.e. the put_bit calls of every channel in order -- what a shim replays callbacks from.  n_status = status[0] as
+// delivered (entries beyond status_cap were not recorded: returns SPANGPU_ERR_STATE then, as for a row that was too short).
+int spangpu_modem_unpack_events(const uint32_t *packed, int words_per_channel, const uint32_t *status, int status_cap, int n_ch,
+                                int8_t *events, int cap, int32_t *counts)
+{
+    if (packed == nullptr  ||  status == nullptr  ||  events == nullptr  ||  counts == nullptr  ||  words_per_channel < 2  ||  cap <= 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    const uint32_t n_status = status[0];
+    if (n_status > (uint32_t) status_cap)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "more status reports than the list holds");
+    // a channel's reports stand in order in the list: walk it once, keeping a cursor per channel in counts[] (reused below)
+    int32_t *next = (int32_t *) calloc((size_t) n_ch + 1, sizeof(int32_t));
+    int32_t *order = (int32_t *) malloc((size_t) (n_status + 1)*sizeof(int32_t));
+    if (next == nullptr  ||  order == nullptr)
+    {
+        free(next);
+        free(order);
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of memory");
+    }
+    for (uint32_t k = 0;  k < n_status;  k++)
+    {
+        const uint32_t c = status[1 + 2*k];
+        if (c < (uint32_t) n_ch)
+            next[c + 1]++;
+    }
+    for (int c = 0;  c < n_ch;  c++)
+        next[c + 1] += next[c];                         // next[c] = first slot of channel c in `order`
+    for (uint32_t k = 0;  k < n_status;  k++)
+    {
+        const uint32_t c = status[1 + 2*k];
+        if (c < (uint32_t) n_ch)
+            order[next[c]++] = (int32_t) k;             // (stable: list order is call order within a channel)
+    }
+    int rc = SPANGPU_OK;
+    int32_t first = 0;
+    for (int c = 0;  c < n_ch;  c++)
+    {
+        const uint32_t *row = packed + (size_t) c*words_per_channel;
+        const int nbits = (int) (row[0] & 0x7FFFu);
+        const int nstat = (int) ((row[0] >> 16) & 0x7FFFu);
+        const int32_t last = next[c];                   // one past this channel's reports in `order`
+        if ((row[0] & 0x80000000u)  ||  nbits > (words_per_channel - 1)*32  ||  nstat != last - first  ||  nbits + nstat > cap)
+            rc = SPANGPU_ERR_STATE;
+        int8_t *ev = events + (size_t) c*cap;
+        int n = 0;
+        int32_t s = first;
+        for (int b = 0;  b <= nbits  &&  n < cap;  b++)
+        {
+            while (s < last  &&  (int) (status[2 + 2*order[s]] & 0xFFFFu) == b  &&  n < cap)
+                ev[n++] = (int8_t) (int16_t) (status[2 + 2*order[s++]] >> 16);
+            if (b < nbits  &&  b < (words_per_channel - 1)*32  &&  n < cap)
+                ev[n++] = (int8_t) ((row[1 + (b >> 5)] >> (b & 31)) & 1u);
+        }
+        counts[c] = n;
+        first = last;
+    }
+    free(next);
+    free(order);
+    if (rc != SPANGPU_OK)
+        return spangpu_set_error(rc, "packed events: a row or the status list was too short for what the call produced");
+    return SPANGPU_OK;
+}
+
+void *spangpu_modem_get_stream(spangpu_modem_t *m)
+{
+    return m  ?  (void *) m->stream  :  nullptr;
+}
+
+int spangpu_modem_bit_rate(const spangpu_modem_t *m)
+{
+    return m  ?  m->bit_rate  :  SPANGPU_ERR_BAD_ARG;
+}
+
+int spangpu_modem_device(const spangpu_modem_t *m)
+{
+    return m  ?  m->device  :  SPANGPU_ERR_BAD_ARG;
+}
+
 }   // extern "C"
 
 // ---- host-side state edits: restart, fill-in, cutoff ---------------------------------------------

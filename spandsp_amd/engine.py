@@ -177,6 +177,27 @@ def lib():
             "spangpu_feed_collect": (ci, [vp, C.POINTER(vp)]),
             "spangpu_feed_outstanding": (ci, [vp]),
             "spangpu_feed_run": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+            "spangpu_echo_feed_create": (ci, [C.POINTER(vp), vp, ci, ci, ci, ci]),
+            "spangpu_echo_feed_destroy": (ci, [vp]),
+            "spangpu_echo_feed_stride": (ll, [vp]),
+            "spangpu_echo_feed_acquire": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_echo_feed_commit": (ci, [vp, ci]),
+            "spangpu_echo_feed_collect": (ci, [vp, C.POINTER(vp)]),
+            "spangpu_echo_feed_outstanding": (ci, [vp]),
+            "spangpu_echo_feed_run": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double)]),
+            "spangpu_modem_packed_words": (ci, [ci, ci]),
+            "spangpu_modem_pack_events": (ci, [vp, vp, ci, vp, ci]),
+            "spangpu_modem_unpack_events": (ci, [vp, ci, vp, ci, ci, vp, ci, vp]),
+            "spangpu_modem_feed_create": (ci, [C.POINTER(vp), vp, ci, ci, ci]),
+            "spangpu_modem_feed_destroy": (ci, [vp]),
+            "spangpu_modem_feed_stride": (ll, [vp]),
+            "spangpu_modem_feed_words_per_channel": (ci, [vp]),
+            "spangpu_modem_feed_status_cap": (ci, [vp]),
+            "spangpu_modem_feed_acquire": (vp, [vp]),
+            "spangpu_modem_feed_commit": (ci, [vp, ci]),
+            "spangpu_modem_feed_collect": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
+            "spangpu_modem_feed_outstanding": (ci, [vp]),
+            "spangpu_modem_feed_run": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
             "spangpu_tune_modem_mapping": (ci, [ci]),
             "spangpu_tune_fsk_waves": (ci, [ci]),
             "spangpu_echo_lanes_per_channel": (ci, [vp]),
@@ -575,6 +596,130 @@ class Feed:
             return z, z, z
         w = np.frombuffer((C.c_uint32*n).from_address(ent.value), np.uint32).copy()
         return w & 0xFFFFF, (w >> 20) & 0xFF, (w >> 28) & 0xF
+
+
+class EchoFeed:
+    """The pipelined host path of an echo canceller bank (spangpu_echo_feed_*): slots() hands out the numpy views of the next
+    tick's tx and rx staging rows ([n_ch, stride] int16, or uint8 with a G.711 law), commit() queues the tick (H2D, kernel and
+    D2H on three streams), collect() returns the clean rows of the oldest tick ([n_ch, stride], good until that slot is
+    committed again)."""
+
+    def __init__(self, bank, max_samples, law=0, depth=3, use_hpf_tx=False):
+        self.bank = bank
+        self.law = law
+        self.h = C.c_void_p()
+        _check(lib().spangpu_echo_feed_create(C.byref(self.h), bank.h, max_samples, law, depth, int(use_hpf_tx)))
+        self.stride = int(lib().spangpu_echo_feed_stride(self.h))
+        self.n_ch = bank.n
+        self.depth = depth
+
+    def close(self):
+        if self.h:
+            lib().spangpu_echo_feed_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _view(self, p):
+        if self.law:
+            return np.frombuffer((C.c_uint8*(self.n_ch*self.stride)).from_address(p), np.uint8).reshape(self.n_ch, self.stride)
+        return np.frombuffer((C.c_int16*(self.n_ch*self.stride)).from_address(p), np.int16).reshape(self.n_ch, self.stride)
+
+    def slots(self):
+        tx, rx = C.c_void_p(), C.c_void_p()
+        _check(lib().spangpu_echo_feed_acquire(self.h, C.byref(tx), C.byref(rx)))
+        return self._view(tx.value), self._view(rx.value)
+
+    def commit(self, samples):
+        _check(lib().spangpu_echo_feed_commit(self.h, samples))
+
+    def outstanding(self):
+        return _check(lib().spangpu_echo_feed_outstanding(self.h))
+
+    def collect(self):
+        """-> (clean rows view, samples) of the oldest outstanding tick, or None."""
+        if self.outstanding() <= 0:
+            return None
+        p = C.c_void_p()
+        n = _check(lib().spangpu_echo_feed_collect(self.h, C.byref(p)))
+        return self._view(p.value), n
+
+    def run(self, samples, ticks, lag=1):
+        ms = C.c_double()
+        _check(lib().spangpu_echo_feed_run(self.h, samples, ticks, lag, C.byref(ms)))
+        return ms.value
+
+
+class ModemFeed:
+    """The pipelined host path of a modem receiver bank (spangpu_modem_feed_*): slot() = the next tick's PCM staging rows
+    ([n_ch, stride] int16), commit() queues the tick, collect() returns the oldest tick's put_bit stream -- as the packed rows
+    and status list (raw=True) or unpacked into per-channel int8 arrays like ModemBank.events()."""
+
+    def __init__(self, bank, max_samples, max_bit_rate, depth=3):
+        self.bank = bank
+        self.h = C.c_void_p()
+        _check(lib().spangpu_modem_feed_create(C.byref(self.h), bank.h, max_samples, max_bit_rate, depth))
+        self.stride = int(lib().spangpu_modem_feed_stride(self.h))
+        self.wpc = _check(lib().spangpu_modem_feed_words_per_channel(self.h))
+        self.status_cap = _check(lib().spangpu_modem_feed_status_cap(self.h))
+        self.n_ch = bank.n
+        self.depth = depth
+        self.max_samples = max_samples
+
+    def close(self):
+        if self.h:
+            lib().spangpu_modem_feed_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def slot(self):
+        p = lib().spangpu_modem_feed_acquire(self.h)
+        if not p:
+            raise SpanGpuError(-6, lib().spangpu_last_error().decode())
+        return np.frombuffer((C.c_int16*(self.n_ch*self.stride)).from_address(p), np.int16).reshape(self.n_ch, self.stride)
+
+    def commit(self, samples):
+        _check(lib().spangpu_modem_feed_commit(self.h, samples))
+
+    def outstanding(self):
+        return _check(lib().spangpu_modem_feed_outstanding(self.h))
+
+    def collect(self, raw=False):
+        if self.outstanding() <= 0:
+            return None
+        pk, st = C.c_void_p(), C.c_void_p()
+        _check(lib().spangpu_modem_feed_collect(self.h, C.byref(pk), C.byref(st)))
+        packed = np.frombuffer((C.c_uint32*(self.n_ch*self.wpc)).from_address(pk.value), np.uint32).reshape(self.n_ch, self.wpc)
+        status = np.frombuffer((C.c_uint32*(1 + 2*self.status_cap)).from_address(st.value), np.uint32)
+        if raw:
+            return packed, status
+        return unpack_modem_events(packed, status, self.status_cap, self.max_samples*4 + 64)
+
+    def run(self, samples, ticks, lag=1):
+        ms = C.c_double()
+        bits = C.c_longlong()
+        _check(lib().spangpu_modem_feed_run(self.h, samples, ticks, lag, C.byref(ms), C.byref(bits)))
+        return ms.value, bits.value
+
+
+def unpack_modem_events(packed, status, status_cap, cap):
+    """spangpu_modem_unpack_events(): the packed put_bit stream of a tick -> a list of per-channel int8 arrays."""
+    packed = np.ascontiguousarray(packed, np.uint32)
+    status = np.ascontiguousarray(status, np.uint32)
+    n_ch, wpc = packed.shape
+    ev = np.zeros((n_ch, cap), np.int8)
+    cnt = np.zeros(n_ch, np.int32)
+    _check(lib().spangpu_modem_unpack_events(packed.ctypes.data, wpc, status.ctypes.data, status_cap, n_ch, ev.ctypes.data, cap, cnt.ctypes.data))
+    return [ev[c, :cnt[c]].copy() for c in range(n_ch)]
 
 
 class EchoBank:

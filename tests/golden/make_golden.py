@@ -200,6 +200,14 @@ def sigtone_goldens():
              out_head=out[:4000], snapshots=snaps, requests=np.int32(n))
 
 
+def make_g711_encode():
+    """linear_to_alaw() / linear_to_ulaw() of the reference (spandsp/g711.h:124-237) for every int16 value."""
+    L = ref.lib()
+    v = np.arange(-32768, 32768)
+    save("g711_encode", alaw=np.array([L.glue_linear_to_alaw(int(x)) for x in v], np.uint8),
+         ulaw=np.array([L.glue_linear_to_ulaw(int(x)) for x in v], np.uint8))
+
+
 def make_g168():
     import zlib
     # the G.168 echo path models (test data of the reference: src/spandsp/g168models.h) and the known answer of
@@ -295,6 +303,7 @@ def main():
              fields=np.array(ref.ECHO_FIELDS), values=np.array([s[k] for k in ref.ECHO_FIELDS]))
 
     make_g168()
+    make_g711_encode()
 
     codes = np.arange(256)
     save("g711_decode", alaw=np.array([L.glue_alaw_to_linear(int(c)) for c in codes], np.int16),
@@ -369,6 +378,9 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["super_tone_range"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         super_tone_range()
+    elif sys.argv[1:] == ["g711_encode"]:
+        assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+        make_g711_encode()
     elif sys.argv[1:] == ["g168"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         make_g168()

@@ -143,3 +143,92 @@ def test_feed_tick_with_more_digits_than_travel_with_a_tick(built):
         assert len(set(d.tolist())) == 1 and len(set(b.tolist())) == 1
     feed.close()
     bank.close()
+
+
+@pytest.mark.parametrize("law", [0, 1, 2], ids=["pcm", "alaw", "ulaw"])
+def test_pipelined_echo_feed_equals_the_serial_path(built, law):
+    """spangpu_echo_feed_*: ticks three deep (H2D, kernel and D2H of successive ticks on three streams) return exactly the
+    clean rows of the serial path (update_host, itself held to the oracle in test_echo_gpu.py).  With a G.711 law the rows
+    travel as bytes both ways: decoded on the device (the reference's tables, golden/g711_decode.npz), cancelled, and encoded
+    on the device with the reference's linear_to_alaw() / linear_to_ulaw() (golden/g711_encode.npz: every int16 value)."""
+    from spandsp_amd import engine
+    from test_echo_gpu import make_channels
+    n_ch, taps, frame, ticks = 700, 128, 160, 40
+    tx, rx = make_channels(n_ch, frame*ticks, taps, seed=515)
+    if law:
+        name = "alaw" if law == 1 else "ulaw"
+        dec = np.load(os.path.join(GOLDEN, "g711_decode.npz"))[name].astype(np.int16)
+        enc = np.load(os.path.join(GOLDEN, "g711_encode.npz"))[name]
+        tx_c, rx_c = enc[tx.astype(np.int32) + 32768], enc[rx.astype(np.int32) + 32768]
+        tx, rx = dec[tx_c], dec[rx_c]                                     # what the canceller sees
+    serial = engine.EchoBank(n_ch, taps, 0x01)
+    want = [serial.update_host(tx[:, t*frame:(t + 1)*frame], rx[:, t*frame:(t + 1)*frame], False) for t in range(ticks)]
+    serial.close()
+    bank = engine.EchoBank(n_ch, taps, 0x01)
+    feed = engine.EchoFeed(bank, frame, law=law, depth=3)
+    got = []
+
+    def take():
+        clean, n = feed.collect()
+        assert n == frame
+        got.append(clean[:, :frame].copy())
+    for t in range(ticks):
+        a, b = feed.slots()
+        a[:, :frame] = (tx_c if law else tx)[:, t*frame:(t + 1)*frame]
+        b[:, :frame] = (rx_c if law else rx)[:, t*frame:(t + 1)*frame]
+        feed.commit(frame)
+        if t >= 2:
+            take()
+    while feed.outstanding():
+        take()
+    assert len(got) == ticks
+    for t in range(ticks):
+        w = enc[want[t].astype(np.int32) + 32768] if law else want[t]
+        assert np.array_equal(got[t], w), t
+    with pytest.raises(engine.SpanGpuError):
+        for _ in range(4):
+            feed.slots()
+            feed.commit(frame)
+    feed.close()
+    bank.close()
+
+
+def test_packed_modem_events_and_the_pipelined_modem_feed(built):
+    """spangpu_modem_pack_events / _unpack_events and spangpu_modem_feed_*: the put_bit stream of every tick, packed on the
+    device (a header word + the data bits per channel, one sparse list of status reports per bank), brought back three ticks
+    deep and unpacked on the host, equals the serial path's events call for call -- through training (status reports), data,
+    the end of the carrier and a second call."""
+    from spandsp_amd import engine
+    from test_v29_gpu import channel_signals
+    from test_oracle_pin import use_golden_modem_tables
+    use_golden_modem_tables()
+    n_ch, frame = 300, 160
+    base = channel_signals(9600, n_ch, seed=23)
+    sig = np.concatenate([base, np.zeros((n_ch, 480), np.int16), base[:, :3200]], axis=1)
+    ticks = sig.shape[1]//frame
+    serial = engine.V29Bank(n_ch, 9600)
+    want = []
+    for t in range(ticks):
+        serial.rx_host(sig[:, t*frame:(t + 1)*frame])
+        want.append(serial.events())
+    serial.close()
+    bank = engine.V29Bank(n_ch, 9600)
+    feed = engine.ModemFeed(bank, frame, 9600, depth=3)
+    assert feed.wpc == 8                                        # 32 bytes per channel and tick: a header word + 192 bits + slack
+    got = []
+    for t in range(ticks):
+        feed.slot()[:, :frame] = sig[:, t*frame:(t + 1)*frame]
+        feed.commit(frame)
+        if t >= 2:
+            got.append(feed.collect())
+    while feed.outstanding():
+        got.append(feed.collect())
+    assert len(got) == ticks
+    n_status = 0
+    for t in range(ticks):
+        for c in range(n_ch):
+            assert np.array_equal(got[t][c], want[t][c]), (t, c)
+            n_status += int((want[t][c] < 0).sum())
+    assert n_status >= 5*n_ch                                   # carrier up, training, trained, carrier down, up again ...
+    feed.close()
+    bank.close()

@@ -330,6 +330,80 @@ def cpu_echo(tx_host, rx_host, seconds=1.0):
                       % (n_ch, n_frames, all_loops, threads, all_dt, one_ch, one_loops, one_dt)}
 
 
+def copy_alone_ms(n_bytes, direction, dev):
+    """The floor of a host path leg on this box: the same bytes between pinned host memory and HBM, nothing else."""
+    pinned = torch.empty(max(n_bytes, 16), dtype=torch.uint8).pin_memory()
+    onboard = torch.empty(max(n_bytes, 16), dtype=torch.uint8, device=dev)
+    a, b = (onboard, pinned) if direction == "h2d" else (pinned, onboard)
+    a.copy_(b, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        a.copy_(b, non_blocking=True)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0)/10*1e3
+
+
+def e2e_echo(n_ch, tx, rx, dev, ticks=40):
+    """SURVEY 8(d)'s second number for the echo path: a tick as a caller with HOST buffers sees it, through the pipelined
+    feed (spangpu_echo_feed_*): tx and rx rows down, the clean rows up, three streams, the tick loop in C.  int16 and G.711."""
+    from spandsp_amd import engine
+    out = {}
+    enc = np.load(os.path.join(ROOT, "tests", "golden", "g711_encode.npz"))["ulaw"]
+    for law, name in ((0, "int16"), (2, "ulaw")):
+        bank = engine.EchoBank(n_ch, ECHO_TAPS, ECHO_MODE)
+        feed = engine.EchoFeed(bank, FRAME, law=law, depth=3)
+        for k in range(3):
+            a, b = feed.slots()
+            t = tx[k].cpu().numpy()
+            r = rx[k].cpu().numpy()
+            a[:, :FRAME] = enc[t.astype(np.int32) + 32768] if law else t
+            b[:, :FRAME] = enc[r.astype(np.int32) + 32768] if law else r
+            feed.commit(FRAME)
+        while feed.outstanding():
+            feed.collect()
+        ms = feed.run(FRAME, ticks, 1)
+        ms2 = feed.run(FRAME, ticks, 2)
+        bps = 1 if law else 2
+        down, up = 2*n_ch*feed.stride*bps, n_ch*feed.stride*bps
+        h2d, d2h = copy_alone_ms(down, "h2d", dev), copy_alone_ms(up, "d2h", dev)
+        ms, ms1 = ms2, ms                           # two ticks of latency keep all three legs busy: the headline of this path
+        out[name] = {"ms_per_step": ms/ticks, "ms_per_step_one_tick_of_latency": ms1/ticks, "h2d_copy_alone_ms": h2d, "d2h_copy_alone_ms": d2h, "bytes_down": down, "bytes_up": up,
+                     "over_the_larger_copy": ms/ticks/max(h2d, d2h), "value": n_ch*FRAME/(ms/ticks*1e-3)/1e6, "unit": "Msamples/s"}
+        feed.close()
+        bank.close()
+    out["includes"] = ("per step (tick loop in C, spangpu_echo_feed_run()), pipelined over three pinned slots and three streams: H2D of the tx and rx rows, "
+                       "the canceller kernel (with G.711: decode and encode kernels around it), D2H of the clean rows; one tick of latency")
+    return out
+
+
+def e2e_modem(kind, bit_rate, n_ch, frames, dev, ticks=40):
+    """The same for a modem receiver bank (spangpu_modem_feed_*): PCM rows down, the put_bit stream up in packed form (a
+    header word and the data bits per channel + one status list per bank) instead of a byte per put_bit call."""
+    from spandsp_amd import engine
+    bank = engine.ModemBank(kind, n_ch, bit_rate)
+    feed = engine.ModemFeed(bank, FRAME, bit_rate, depth=3)
+    nf = frames.shape[0]
+    host = [frames[k].cpu().numpy() for k in range(min(nf, 3))]
+    for k in range(3):
+        feed.slot()[:, :FRAME] = host[k % len(host)]
+        feed.commit(FRAME)
+    while feed.outstanding():
+        feed.collect(raw=True)
+    ms, bits = feed.run(FRAME, ticks, 1)
+    down = n_ch*feed.stride*2
+    up = (n_ch*feed.wpc + 1 + 2*feed.status_cap)*4
+    h2d, d2h = copy_alone_ms(down, "h2d", dev), copy_alone_ms(up, "d2h", dev)
+    out = {"ms_per_step": ms/ticks, "h2d_copy_alone_ms": h2d, "d2h_copy_alone_ms": d2h, "bytes_down": down, "bytes_up": up,
+           "bytes_up_per_channel": feed.wpc*4, "bytes_up_as_one_byte_per_call": n_ch*(FRAME*4 + 64),
+           "over_the_larger_copy": ms/ticks/max(h2d, d2h), "value": n_ch*FRAME/(ms/ticks*1e-3)/1e6, "unit": "Msamples/s",
+           "includes": "per step (tick loop in C, spangpu_modem_feed_run()), pipelined over three pinned slots and three streams: H2D of the PCM rows, the "
+                       "receiver kernel, the pack kernel, D2H of the packed put_bit stream; one tick of latency"}
+    feed.close()
+    bank.close()
+    return out
+
+
 def echo_spot_check(tx64, rx64, clean64):
     """The oracle's echo_can_update() (oracle/echo_oracle.c, pinned to the reference) over the same first frames of 64 lines:
     every clean sample equal?  tx64 / rx64 / clean64: int16 [frames, 64, FRAME] on the host."""
@@ -401,7 +475,9 @@ def bench_echo(args, dev, stream):
         cpu["spot_check"] = echo_spot_check(tx[:25, :v].cpu().numpy(), rx[:25, :v].cpu().numpy(), torch.stack(kept).cpu().numpy())
     value = steps*n_ch*FRAME/dt/1e6
     lanes = engine.lib().spangpu_echo_lanes_per_channel(bank.h)
+    e2e = None if getattr(args, "no_e2e", False) else e2e_echo(n_ch, tx, rx, dev)
     return {
+        "e2e": e2e,
         "metric": "Msamples/s of batched G.168 echo cancellation, 128 taps (8 kHz channels at real-time = value*1e6/8000)",
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
         "steps": steps, "warmup": warm, "ms_per_step": dt*1e3/steps, "higher_is_better": True,
@@ -1030,7 +1106,9 @@ def bench_modem(args, dev, stream):
         cpu["spot_check"] = modem_spot_check(args.workload, bit_rate, frames[:nchk, :v].cpu().numpy(), ev64)
         small.close()
     value = args.steps*n_ch*FRAME/dt/1e6
+    e2e = None if getattr(args, "no_e2e", False) else e2e_modem(kind, bit_rate, n_ch, frames[:3], dev)
     return {
+        "e2e": e2e,
         "metric": "Msamples/s of batched %s %d bps receive (8 kHz channels at real-time = value*1e6/8000)" % (args.workload, bit_rate),
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
@@ -1061,6 +1139,8 @@ def compact_path(line, key, channels, stream_peak=None):
            "value": line["value"], "unit": line["unit"], "realtime_channels": line["realtime_channels"], "dtype": line["dtype"],
            "roofline": roof, "roofline_valu": rl.valu_roof(key, roof.get("avg_launch_us"), channels=channels),
            "cpu_baseline": line.get("cpu_baseline")}
+    if line.get("e2e"):
+        out["e2e"] = line["e2e"]
     for k in ("erle_db_last_second_single_talk_lines", "sampled_channels_in_data_mode_at_end", "events_in_last_frame", "blocks_with_a_hit_in_last_step"):
         if k in line["config"]:
             out[k] = line["config"][k]
@@ -1117,6 +1197,7 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="default: 150 (190 for v27ter, whose training alone is 0.7 s)")
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--echo-lanes", type=int, default=0, help="echo: lanes per channel (0 = the library's choice; 2, 4, 8, 16 for A-B runs)")
     ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
     ap.add_argument("--cpu-channels", type=int, default=16384)
