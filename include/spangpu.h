@@ -752,6 +752,8 @@ SPANGPU_API int spangpu_echo_feed_run(spangpu_echo_feed_t *feed, int samples, in
    spangpu_modem_unpack_events() (host code): the packed form back into the calls -- events[n_ch][cap] int8 and counts[n_ch]
    exactly as spangpu_modem_events() delivers them -- for a shim that replays put_bit / status callbacks. */
 SPANGPU_API int spangpu_modem_packed_words(int bit_rate, int samples);
+/* spangpu_modem_events() by way of the packed form: same answer, a twentieth of the bytes over PCIe (what the shim's groups call) */
+SPANGPU_API int spangpu_modem_events_packed(spangpu_modem_t *modem, const int8_t **events, const int32_t **counts);
 SPANGPU_API int spangpu_modem_pack_events(spangpu_modem_t *modem, uint32_t *packed_device, int words_per_channel, uint32_t *status_device, int status_cap);
 SPANGPU_API int spangpu_modem_unpack_events(const uint32_t *packed, int words_per_channel, const uint32_t *status, int status_cap, int n_ch,
                                             int8_t *events, int cap, int32_t *counts);
@@ -774,6 +776,50 @@ SPANGPU_API int spangpu_modem_feed_commit(spangpu_modem_feed_t *feed, int sample
 SPANGPU_API int spangpu_modem_feed_collect(spangpu_modem_feed_t *feed, const uint32_t **packed, const uint32_t **status);
 SPANGPU_API int spangpu_modem_feed_outstanding(const spangpu_modem_feed_t *feed);
 SPANGPU_API int spangpu_modem_feed_run(spangpu_modem_feed_t *feed, int samples, int ticks, int lag, double *elapsed_ms, long long *bits);
+
+/* ---- One logical tone bank over several devices (csrc/shard_api.hip, round 4) ---------------------------------
+   Channels shard as contiguous ranges, one bank, stream and digit buffer per entry of devices[] (a device may be named
+   twice: two shards on one GPU); nothing is exchanged between compute steps; the one exchange is the gather of the digit
+   byte of every block and channel to the first shard's device -- written by each shard's detector kernel into a buffer on
+   its own device and copied device to device (hipMemcpyPeerAsync, xGMI between peers) behind the kernel on the shard's
+   stream.  One host thread drives all shards: every call queues work and returns.
+       spangpu_shard_create(&sh, devices, n, SPANGPU_DTMF, n_channels, 160, &params, sizeof(params));
+       per tick: spangpu_shard_rx(sh, amp_per_shard, 160, 160);   amp_per_shard[i]: shard i's rows on shard i's device
+                 spangpu_shard_digits_device(sh, stream, &digits, &dev, &max_blocks)  or  spangpu_shard_digits_host(sh, out, bytes)
+   What it stands for on a host running the reference: the loop over all its dtmf_rx() objects and their dtmf_rx_get()s. */
+typedef struct spangpu_shard_s spangpu_shard_t;
+SPANGPU_API int spangpu_shard_create(spangpu_shard_t **shard, const int *devices, int n_devices, int kind, int n_channels, int max_samples,
+                                     const void *params, size_t params_size);
+SPANGPU_API int spangpu_shard_destroy(spangpu_shard_t *shard);
+SPANGPU_API int spangpu_shard_count(const spangpu_shard_t *shard);
+SPANGPU_API int spangpu_shard_channels(const spangpu_shard_t *shard);
+SPANGPU_API int spangpu_shard_range(const spangpu_shard_t *shard, int i, int *device, int *first_channel, int *n_channels);
+SPANGPU_API spangpu_bank_t *spangpu_shard_bank(spangpu_shard_t *shard, int i);
+SPANGPU_API int spangpu_shard_rx(spangpu_shard_t *shard, const int16_t *const *amp, int samples, long long stride);
+SPANGPU_API int spangpu_shard_digits_device(spangpu_shard_t *shard, void *hip_stream, const uint8_t **digits, int *collect_device, int *max_blocks);
+SPANGPU_API int spangpu_shard_digits_host(spangpu_shard_t *shard, uint8_t *out, size_t out_bytes);
+SPANGPU_API int spangpu_shard_sync(spangpu_shard_t *shard);
+
+/* ---- The receivers' inner primitives as batched entry points of their own (csrc/prim_api.hip) ----
+   N independent items per launch, one lane each, in the reference's scalar order of operations (every product and sum rounded
+   by itself): bit-exact with the reference's strict build on any input.  Rows are item-major; a stride of 0 shares one row
+   among all items; complex values are {re, im} float pairs and their strides count complex elements; mem says where ALL the
+   arrays of a call live (SPANGPU_MEM_HOST: copied in and out; SPANGPU_MEM_DEVICE: used in place, the call waits for the kernel).
+     spangpu_vec_circular_dot_prodf_batch    vec_circular_dot_prodf(x, y, n, pos)      src/vector_float.c:890-900,932-939
+     spangpu_vec_circular_lmsf_batch         vec_circular_lmsf(x, y, n, pos, error)     src/vector_float.c:942,982-1000
+     spangpu_cvec_circular_dot_prodf_batch   cvec_circular_dot_prodf(x, y, n, pos)     src/complex_vector_float.c:137-150,187-196
+     spangpu_cvec_circular_lmsf_batch        cvec_circular_lmsf(x, y, n, pos, &error)   src/complex_vector_float.c:201-219
+     spangpu_power_meter_update_batch        power_meter_update() over a row of samples  src/power_meter.c:65-70 */
+SPANGPU_API int spangpu_vec_circular_dot_prodf_batch(int device, const float *x, long long x_stride, const float *y, long long y_stride,
+                                                     const int32_t *pos, float *z, int items, int n, int mem);
+SPANGPU_API int spangpu_vec_circular_lmsf_batch(int device, const float *x, long long x_stride, float *y, long long y_stride,
+                                                const int32_t *pos, const float *error, int items, int n, int mem);
+SPANGPU_API int spangpu_cvec_circular_dot_prodf_batch(int device, const float *x, long long x_stride, const float *y, long long y_stride,
+                                                      const int32_t *pos, float *z, int items, int n, int mem);
+SPANGPU_API int spangpu_cvec_circular_lmsf_batch(int device, const float *x, long long x_stride, float *y, long long y_stride,
+                                                 const int32_t *pos, const float *error, int items, int n, int mem);
+SPANGPU_API int spangpu_power_meter_update_batch(int device, const int16_t *amp, long long stride, int32_t *reading, const int32_t *shift,
+                                                 int items, int n, int mem);
 
 #if defined(__cplusplus)
 }

@@ -15,6 +15,11 @@ from . import REF_SO, REF_FAST_SO
 
 EVENT_DTYPE = np.dtype([("kind", "<i4"), ("a", "<i4"), ("b", "<i4"), ("c", "<i4")])
 
+class _Cf(C.Structure):
+    """complexf_t (spandsp/complex.h), as returned by value"""
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
 _libs = {}
 _flavour = "strict"
 
@@ -146,6 +151,8 @@ def lib():
             "fsk_tx": (ci, [vp, vp, ci]), "fsk_tx_free": (ci, [vp]), "fsk_tx_power": (None, [vp, cf]),
             "vec_dot_prodf": (cf, [vp, vp, ci]), "vec_circular_dot_prodf": (cf, [vp, vp, ci, ci]),
             "vec_lmsf": (None, [vp, vp, ci, cf]), "vec_circular_lmsf": (None, [vp, vp, ci, ci, cf]),
+            "cvec_circular_dot_prodf": (_Cf, [vp, vp, ci, ci]), "cvec_circular_lmsf": (None, [vp, vp, ci, ci, vp]),
+            "power_meter_update": (C.c_int32, [vp, C.c_int16]),
         }
         for name, (res, args) in sigs.items():
             if not hasattr(L, name):

@@ -66,6 +66,11 @@ struct spangpu_modem_s
     uint32_t *h_qam;
     int32_t *h_qam_count;
     int last_qam_cap;
+    uint32_t *d_packed;         // spangpu_modem_events_packed(): [n_ch][packed_wpc] rows, then the status list
+    uint32_t *h_packed;
+    int packed_wpc;
+    int packed_status_cap;
+    int last_samples;           // frame length of the last spangpu_modem_rx()
 };
 
 // power_meter_level_dbm0(), power_meter.c:82-92
@@ -392,6 +397,8 @@ int spangpu_modem_destroy(spangpu_modem_t *m)
     if (m->qam_count) (void) hipFree(m->qam_count);
     if (m->h_qam) (void) hipHostFree(m->h_qam);
     if (m->h_qam_count) (void) hipHostFree(m->h_qam_count);
+    if (m->d_packed) (void) hipFree(m->d_packed);
+    if (m->h_packed) (void) hipHostFree(m->h_packed);
     if (m->own_stream  &&  m->stream)
         (void) hipStreamDestroy(m->stream);
     free(m);
@@ -880,6 +887,49 @@ int spangpu_modem_unpack_events(const uint32_t *packed, int words_per_channel, c
     if (rc != SPANGPU_OK)
         return spangpu_set_error(rc, "packed events: a row or the status list was too short for what the call produced");
     return SPANGPU_OK;
+}
+
+// spangpu_modem_events() by way of the packed form: the same answer (events, counts, return value), a twentieth of the bytes
+// over PCIe -- the device packs, one copy brings rows and status list up, the host spreads them out again.  What a shim with
+// many channels on one bank calls.
+int spangpu_modem_events_packed(spangpu_modem_t *m, const int8_t **events, const int32_t **counts)
+{
+    if (m == nullptr  ||  events == nullptr  ||  counts == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (m->last_cap <= 0)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "no spangpu_modem_rx() yet");
+    V29_TRY(hipSetDevice(m->device));
+    const int wpc = 1 + (m->last_cap + 31)/32;              // (no call delivers more data bits than its event buffer has room for)
+    const int scap = (m->n_ch > 1024)  ?  m->n_ch  :  1024;
+    if (wpc > m->packed_wpc  ||  scap > m->packed_status_cap)
+    {
+        if (m->d_packed) (void) hipFree(m->d_packed);
+        if (m->h_packed) (void) hipHostFree(m->h_packed);
+        m->d_packed = nullptr;
+        m->h_packed = nullptr;
+        m->packed_wpc = 0;
+        const size_t words = (size_t) m->n_ch*wpc + 1 + 2*(size_t) scap;
+        V29_TRY(hipMalloc(&m->d_packed, words*sizeof(uint32_t)));
+        V29_TRY(hipHostMalloc(&m->h_packed, words*sizeof(uint32_t)));
+        m->packed_wpc = wpc;
+        m->packed_status_cap = scap;
+    }
+    uint32_t *d_status = m->d_packed + (size_t) m->n_ch*m->packed_wpc;
+    int rc = spangpu_modem_pack_events(m, m->d_packed, m->packed_wpc, d_status, m->packed_status_cap);
+    if (rc < 0)
+        return rc;
+    const size_t words = (size_t) m->n_ch*m->packed_wpc + 1 + 2*(size_t) m->packed_status_cap;
+    V29_TRY(hipMemcpyAsync(m->h_packed, m->d_packed, words*sizeof(uint32_t), hipMemcpyDeviceToHost, m->stream));
+    V29_TRY(hipStreamSynchronize(m->stream));
+    const uint32_t *h_status = m->h_packed + (size_t) m->n_ch*m->packed_wpc;
+    if (h_status[0] > (uint32_t) m->packed_status_cap)
+        return spangpu_modem_events(m, events, counts);     // (more status reports in one call than channels: the plain way)
+    rc = spangpu_modem_unpack_events(m->h_packed, m->packed_wpc, h_status, m->packed_status_cap, m->n_ch, m->h_events, m->last_cap, m->h_count);
+    if (rc < 0)
+        return spangpu_modem_events(m, events, counts);     // (a row too short -- an event buffer overflow shows there: same error path)
+    *events = m->h_events;
+    *counts = m->h_count;
+    return m->last_cap;
 }
 
 void *spangpu_modem_get_stream(spangpu_modem_t *m)

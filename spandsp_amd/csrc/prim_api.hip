@@ -1,0 +1,301 @@
+// prim_api.hip -- the inner primitives of the modem receivers as batched entry points of their own (include/spangpu.h:
+// spangpu_vec_* / spangpu_cvec_* / spangpu_power_meter_*), SURVEY 8(a) rows a11, a12, a19.
+//
+// Inside the receiver kernels these run fused (quad_round_front.inc, v29_quad.hpp ...) and are proven through the receivers'
+// bit-exact float state.  Here each is one launch over N independent items, one lane per item, with the reference's scalar
+// order of operations (this file, like the rest of the library, is built -ffp-contract=off: every product and sum rounded by
+// itself): the direct evidence that the arithmetic is the reference's, on inputs a receiver never produces -- denormals,
+// cancellation, infinities.
+//   vec_circular_dot_prodf   src/vector_float.c:890-900, 932-939      z = dot(x[pos:], y[:n-pos]) + dot(x[:pos], y[n-pos:])
+//   vec_circular_lmsf        src/vector_float.c:982-1000 (leak 0.9999f, :942)
+//   cvec_circular_dot_prodf  src/complex_vector_float.c:137-150, 187-196 (non-conjugating; the two parts added at the end)
+//   cvec_circular_lmsf       src/complex_vector_float.c:201-219
+//   power_meter_update       src/power_meter.c:65-70 (over a row of samples; the reading after the last one)
+// Rows are item-major ([item][n]); x and y of an item may be the same for all items (stride 0).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/spangpu.h"
+
+extern "C" int spangpu_set_error(int code, const char *msg);
+
+#define PR_TRY(x) do { if ((x) != hipSuccess) return spangpu_set_error(SPANGPU_ERR_HIP, #x " failed"); } while (0)
+
+namespace {
+
+__global__ void vec_circ_dot_kernel(const float *x, long long xs, const float *y, long long ys, const int32_t *pos, float *z, int items, int n)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= items)
+        return;
+    const float *xi = x + (size_t) i*xs;
+    const float *yi = y + (size_t) i*ys;
+    const int p = pos[i];
+    float a = 0.0f;
+    for (int k = 0;  k < n - p;  k++)
+        a += xi[p + k]*yi[k];
+    float b = 0.0f;
+    for (int k = 0;  k < p;  k++)
+        b += xi[k]*yi[n - p + k];
+    z[i] = a + b;
+}
+
+__global__ void vec_circ_lms_kernel(const float *x, long long xs, float *y, long long ys, const int32_t *pos, const float *err, int items, int n)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= items)
+        return;
+    const float *xi = x + (size_t) i*xs;
+    float *yi = y + (size_t) i*ys;
+    const int p = pos[i];
+    const float e = err[i];
+    for (int k = 0;  k < n - p;  k++)
+        yi[k] = yi[k]*0.9999f + xi[p + k]*e;
+    for (int k = 0;  k < p;  k++)
+        yi[n - p + k] = yi[n - p + k]*0.9999f + xi[k]*e;
+}
+
+__global__ void cvec_circ_dot_kernel(const float2 *x, long long xs, const float2 *y, long long ys, const int32_t *pos, float2 *z, int items, int n)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= items)
+        return;
+    const float2 *xi = x + (size_t) i*xs;
+    const float2 *yi = y + (size_t) i*ys;
+    const int p = pos[i];
+    float are = 0.0f;
+    float aim = 0.0f;
+    for (int k = 0;  k < n - p;  k++)
+    {
+        are += (xi[p + k].x*yi[k].x - xi[p + k].y*yi[k].y);
+        aim += (xi[p + k].x*yi[k].y + xi[p + k].y*yi[k].x);
+    }
+    float bre = 0.0f;
+    float bim = 0.0f;
+    for (int k = 0;  k < p;  k++)
+    {
+        bre += (xi[k].x*yi[n - p + k].x - xi[k].y*yi[n - p + k].y);
+        bim += (xi[k].x*yi[n - p + k].y + xi[k].y*yi[n - p + k].x);
+    }
+    z[i] = make_float2(are + bre, aim + bim);
+}
+
+__global__ void cvec_circ_lms_kernel(const float2 *x, long long xs, float2 *y, long long ys, const int32_t *pos, const float2 *err, int items, int n)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= items)
+        return;
+    const float2 *xi = x + (size_t) i*xs;
+    float2 *yi = y + (size_t) i*ys;
+    const int p = pos[i];
+    const float2 e = err[i];
+    for (int k = 0;  k < n;  k++)
+    {
+        const float2 xv = (k < n - p)  ?  xi[p + k]  :  xi[k - (n - p)];
+        float2 yv = yi[k];
+        yv.x = yv.x*0.9999f + (xv.y*e.y + xv.x*e.x);
+        yv.y = yv.y*0.9999f + (xv.x*e.y - xv.y*e.x);
+        yi[k] = yv;
+    }
+}
+
+__global__ void power_meter_kernel(const int16_t *amp, long long stride, int32_t *reading, const int32_t *shift, int items, int n)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= items)
+        return;
+    const int16_t *a = amp + (size_t) i*stride;
+    int32_t r = reading[i];
+    const int sh = shift[i];
+    for (int k = 0;  k < n;  k++)
+        r += ((a[k]*a[k] - r) >> sh);
+    reading[i] = r;
+}
+
+// bring a host array to the device (or pass a device pointer through); *owned says whether to free it
+template <typename T>
+int stage_in(const T *src, size_t count, int mem, T **dev, bool *owned)
+{
+    *owned = false;
+    if (mem == SPANGPU_MEM_DEVICE)
+    {
+        *dev = (T *) src;
+        return SPANGPU_OK;
+    }
+    PR_TRY(hipMalloc((void **) dev, count*sizeof(T) + 16));
+    *owned = true;
+    PR_TRY(hipMemcpy(*dev, src, count*sizeof(T), hipMemcpyHostToDevice));
+    return SPANGPU_OK;
+}
+
+struct Staged
+{
+    void *p[6];
+    int n = 0;
+    ~Staged()
+    {
+        for (int i = 0;  i < n;  i++)
+            (void) hipFree(p[i]);
+    }
+    void keep(void *q, bool owned)
+    {
+        if (owned)
+            p[n++] = q;
+    }
+};
+
+int check(int device, int items, int n, const void *a, const void *b, const void *c, const void *d)
+{
+    if (items <= 0  ||  n <= 0  ||  a == nullptr  ||  b == nullptr  ||  c == nullptr  ||  d == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (spangpu_device_count() <= 0)
+        return spangpu_set_error(SPANGPU_ERR_NO_DEVICE, "no HIP device: libspangpu has no CPU fallback");
+    PR_TRY(hipSetDevice(device));
+    return SPANGPU_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+int spangpu_vec_circular_dot_prodf_batch(int device, const float *x, long long x_stride, const float *y, long long y_stride, const int32_t *pos,
+                                         float *z, int items, int n, int mem)
+{
+    int rc = check(device, items, n, x, y, pos, z);
+    if (rc != SPANGPU_OK)
+        return rc;
+    Staged st;
+    float *dx, *dy, *dz;
+    int32_t *dp;
+    bool o;
+    if ((rc = stage_in(x, (size_t) (x_stride  ?  (size_t) x_stride*items  :  (size_t) n), mem, &dx, &o)) < 0) return rc;
+    st.keep(dx, o);
+    if ((rc = stage_in(y, (size_t) (y_stride  ?  (size_t) y_stride*items  :  (size_t) n), mem, &dy, &o)) < 0) return rc;
+    st.keep(dy, o);
+    if ((rc = stage_in(pos, (size_t) items, mem, &dp, &o)) < 0) return rc;
+    st.keep(dp, o);
+    if ((rc = stage_in(z, (size_t) items, mem, &dz, &o)) < 0) return rc;
+    st.keep(dz, o);
+    hipLaunchKernelGGL(vec_circ_dot_kernel, dim3((items + 63)/64), dim3(64), 0, 0, dx, x_stride, dy, y_stride, dp, dz, items, n);
+    PR_TRY(hipGetLastError());
+    if (mem != SPANGPU_MEM_DEVICE)
+        PR_TRY(hipMemcpy(z, dz, (size_t) items*sizeof(float), hipMemcpyDeviceToHost));
+    else
+        PR_TRY(hipDeviceSynchronize());
+    return SPANGPU_OK;
+}
+
+int spangpu_vec_circular_lmsf_batch(int device, const float *x, long long x_stride, float *y, long long y_stride, const int32_t *pos,
+                                    const float *error, int items, int n, int mem)
+{
+    int rc = check(device, items, n, x, y, pos, error);
+    if (rc != SPANGPU_OK)
+        return rc;
+    if (y_stride < n)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "the rows of y are written: they cannot overlap");
+    Staged st;
+    float *dx, *dy, *de;
+    int32_t *dp;
+    bool o;
+    if ((rc = stage_in(x, (size_t) (x_stride  ?  (size_t) x_stride*items  :  (size_t) n), mem, &dx, &o)) < 0) return rc;
+    st.keep(dx, o);
+    if ((rc = stage_in((const float *) y, (size_t) y_stride*items, mem, &dy, &o)) < 0) return rc;
+    st.keep(dy, o);
+    if ((rc = stage_in(pos, (size_t) items, mem, &dp, &o)) < 0) return rc;
+    st.keep(dp, o);
+    if ((rc = stage_in(error, (size_t) items, mem, &de, &o)) < 0) return rc;
+    st.keep(de, o);
+    hipLaunchKernelGGL(vec_circ_lms_kernel, dim3((items + 63)/64), dim3(64), 0, 0, dx, x_stride, dy, y_stride, dp, de, items, n);
+    PR_TRY(hipGetLastError());
+    if (mem != SPANGPU_MEM_DEVICE)
+        PR_TRY(hipMemcpy(y, dy, (size_t) y_stride*items*sizeof(float), hipMemcpyDeviceToHost));
+    else
+        PR_TRY(hipDeviceSynchronize());
+    return SPANGPU_OK;
+}
+
+// complex values as {re, im} float pairs (complexf_t); strides in complex elements
+int spangpu_cvec_circular_dot_prodf_batch(int device, const float *x, long long x_stride, const float *y, long long y_stride, const int32_t *pos,
+                                          float *z, int items, int n, int mem)
+{
+    int rc = check(device, items, n, x, y, pos, z);
+    if (rc != SPANGPU_OK)
+        return rc;
+    Staged st;
+    float *dx, *dy, *dz;
+    int32_t *dp;
+    bool o;
+    if ((rc = stage_in(x, 2*(size_t) (x_stride  ?  (size_t) x_stride*items  :  (size_t) n), mem, &dx, &o)) < 0) return rc;
+    st.keep(dx, o);
+    if ((rc = stage_in(y, 2*(size_t) (y_stride  ?  (size_t) y_stride*items  :  (size_t) n), mem, &dy, &o)) < 0) return rc;
+    st.keep(dy, o);
+    if ((rc = stage_in(pos, (size_t) items, mem, &dp, &o)) < 0) return rc;
+    st.keep(dp, o);
+    if ((rc = stage_in(z, 2*(size_t) items, mem, &dz, &o)) < 0) return rc;
+    st.keep(dz, o);
+    hipLaunchKernelGGL(cvec_circ_dot_kernel, dim3((items + 63)/64), dim3(64), 0, 0, (const float2 *) dx, x_stride, (const float2 *) dy, y_stride, dp,
+                       (float2 *) dz, items, n);
+    PR_TRY(hipGetLastError());
+    if (mem != SPANGPU_MEM_DEVICE)
+        PR_TRY(hipMemcpy(z, dz, 2*(size_t) items*sizeof(float), hipMemcpyDeviceToHost));
+    else
+        PR_TRY(hipDeviceSynchronize());
+    return SPANGPU_OK;
+}
+
+int spangpu_cvec_circular_lmsf_batch(int device, const float *x, long long x_stride, float *y, long long y_stride, const int32_t *pos,
+                                     const float *error, int items, int n, int mem)
+{
+    int rc = check(device, items, n, x, y, pos, error);
+    if (rc != SPANGPU_OK)
+        return rc;
+    if (y_stride < n)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "the rows of y are written: they cannot overlap");
+    Staged st;
+    float *dx, *dy, *de;
+    int32_t *dp;
+    bool o;
+    if ((rc = stage_in(x, 2*(size_t) (x_stride  ?  (size_t) x_stride*items  :  (size_t) n), mem, &dx, &o)) < 0) return rc;
+    st.keep(dx, o);
+    if ((rc = stage_in((const float *) y, 2*(size_t) y_stride*items, mem, &dy, &o)) < 0) return rc;
+    st.keep(dy, o);
+    if ((rc = stage_in(pos, (size_t) items, mem, &dp, &o)) < 0) return rc;
+    st.keep(dp, o);
+    if ((rc = stage_in(error, 2*(size_t) items, mem, &de, &o)) < 0) return rc;
+    st.keep(de, o);
+    hipLaunchKernelGGL(cvec_circ_lms_kernel, dim3((items + 63)/64), dim3(64), 0, 0, (const float2 *) dx, x_stride, (float2 *) dy, y_stride, dp,
+                       (const float2 *) de, items, n);
+    PR_TRY(hipGetLastError());
+    if (mem != SPANGPU_MEM_DEVICE)
+        PR_TRY(hipMemcpy(y, dy, 2*(size_t) y_stride*items*sizeof(float), hipMemcpyDeviceToHost));
+    else
+        PR_TRY(hipDeviceSynchronize());
+    return SPANGPU_OK;
+}
+
+// reading[i] after power_meter_update() over amp[i*stride .. + n) with shift[i], starting from reading[i]
+int spangpu_power_meter_update_batch(int device, const int16_t *amp, long long stride, int32_t *reading, const int32_t *shift, int items, int n, int mem)
+{
+    int rc = check(device, items, n, amp, reading, shift, shift);
+    if (rc != SPANGPU_OK)
+        return rc;
+    Staged st;
+    int16_t *da;
+    int32_t *dr, *ds;
+    bool o;
+    if ((rc = stage_in(amp, (size_t) stride*items, mem, &da, &o)) < 0) return rc;
+    st.keep(da, o);
+    if ((rc = stage_in((const int32_t *) reading, (size_t) items, mem, &dr, &o)) < 0) return rc;
+    st.keep(dr, o);
+    if ((rc = stage_in(shift, (size_t) items, mem, &ds, &o)) < 0) return rc;
+    st.keep(ds, o);
+    hipLaunchKernelGGL(power_meter_kernel, dim3((items + 63)/64), dim3(64), 0, 0, (const int16_t *) da, stride, dr, (const int32_t *) ds, items, n);
+    PR_TRY(hipGetLastError());
+    if (mem != SPANGPU_MEM_DEVICE)
+        PR_TRY(hipMemcpy(reading, dr, (size_t) items*sizeof(int32_t), hipMemcpyDeviceToHost));
+    else
+        PR_TRY(hipDeviceSynchronize());
+    return SPANGPU_OK;
+}
+
+}   // extern "C"

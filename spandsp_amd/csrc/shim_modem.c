@@ -183,7 +183,9 @@ static int group_flush_locked(spangpu_modem_group_t *g)
     if (g->n_staged == 0  ||  g->delivering)
         return 0;
     rc = spangpu_modem_rx_var(g->bank, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples);
-    cap = (rc < 0)  ?  rc  :  spangpu_modem_events(g->bank, &events, &counts);
+    /* the put_bit stream comes up packed (a header word and the data bits per channel, status reports as a sparse list) and is
+       spread out on the host: spangpu_modem_events_packed() */
+    cap = (rc < 0)  ?  rc  :  spangpu_modem_events_packed(g->bank, &events, &counts);
     if (cap >= 0  &&  g->qam_tap)
         qcap = spangpu_modem_qam_reports(g->bank, &qam, &qcounts);
     /* The tick is over whatever happened: its frames are taken off the staging area before anything is delivered, so

@@ -177,6 +177,21 @@ def lib():
             "spangpu_feed_collect": (ci, [vp, C.POINTER(vp)]),
             "spangpu_feed_outstanding": (ci, [vp]),
             "spangpu_feed_run": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+            "spangpu_vec_circular_dot_prodf_batch": (ci, [ci, vp, ll, vp, ll, vp, vp, ci, ci, ci]),
+            "spangpu_vec_circular_lmsf_batch": (ci, [ci, vp, ll, vp, ll, vp, vp, ci, ci, ci]),
+            "spangpu_cvec_circular_dot_prodf_batch": (ci, [ci, vp, ll, vp, ll, vp, vp, ci, ci, ci]),
+            "spangpu_cvec_circular_lmsf_batch": (ci, [ci, vp, ll, vp, ll, vp, vp, ci, ci, ci]),
+            "spangpu_power_meter_update_batch": (ci, [ci, vp, ll, vp, vp, ci, ci, ci]),
+            "spangpu_shard_create": (ci, [C.POINTER(vp), vp, ci, ci, ci, ci, vp, C.c_size_t]),
+            "spangpu_shard_destroy": (ci, [vp]),
+            "spangpu_shard_count": (ci, [vp]),
+            "spangpu_shard_channels": (ci, [vp]),
+            "spangpu_shard_range": (ci, [vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]),
+            "spangpu_shard_bank": (vp, [vp, ci]),
+            "spangpu_shard_rx": (ci, [vp, vp, ci, ll]),
+            "spangpu_shard_digits_device": (ci, [vp, vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci)]),
+            "spangpu_shard_digits_host": (ci, [vp, vp, C.c_size_t]),
+            "spangpu_shard_sync": (ci, [vp]),
             "spangpu_echo_feed_create": (ci, [C.POINTER(vp), vp, ci, ci, ci, ci]),
             "spangpu_echo_feed_destroy": (ci, [vp]),
             "spangpu_echo_feed_stride": (ll, [vp]),
@@ -187,6 +202,7 @@ def lib():
             "spangpu_echo_feed_run": (ci, [vp, ci, ci, ci, C.POINTER(C.c_double)]),
             "spangpu_modem_packed_words": (ci, [ci, ci]),
             "spangpu_modem_pack_events": (ci, [vp, vp, ci, vp, ci]),
+            "spangpu_modem_events_packed": (ci, [vp, C.POINTER(vp), C.POINTER(vp)]),
             "spangpu_modem_unpack_events": (ci, [vp, ci, vp, ci, ci, vp, ci, vp]),
             "spangpu_modem_feed_create": (ci, [C.POINTER(vp), vp, ci, ci, ci]),
             "spangpu_modem_feed_destroy": (ci, [vp]),
@@ -598,6 +614,105 @@ class Feed:
         return w & 0xFFFFF, (w >> 20) & 0xFF, (w >> 28) & 0xF
 
 
+# ---- the receivers' inner primitives, batched (csrc/prim_api.hip); host arrays in, host arrays out ----------------------------
+def vec_circular_dot_prodf(x, y, pos, device=0):
+    """x, y: float32 [items, n] (or [n] shared by all items); pos int32 [items] -> float32 [items]."""
+    pos = np.ascontiguousarray(pos, np.int32)
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    n = x.shape[-1]
+    z = np.zeros(len(pos), np.float32)
+    _check(lib().spangpu_vec_circular_dot_prodf_batch(device, x.ctypes.data, n if x.ndim == 2 else 0, y.ctypes.data, n if y.ndim == 2 else 0,
+                                                      pos.ctypes.data, z.ctypes.data, len(pos), n, MEM_HOST))
+    return z
+
+
+def vec_circular_lmsf(x, y, pos, error, device=0):
+    """y (float32 [items, n]) after y = y*0.9999f + x*error in circular order; x [items, n] or [n]."""
+    pos = np.ascontiguousarray(pos, np.int32)
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.array(y, np.float32, order="C")
+    e = np.ascontiguousarray(error, np.float32)
+    n = y.shape[1]
+    _check(lib().spangpu_vec_circular_lmsf_batch(device, x.ctypes.data, n if x.ndim == 2 else 0, y.ctypes.data, n, pos.ctypes.data, e.ctypes.data,
+                                                 len(pos), n, MEM_HOST))
+    return y
+
+
+def cvec_circular_dot_prodf(x, y, pos, device=0):
+    """x, y: complex64 [items, n] (or [n]); -> complex64 [items]."""
+    pos = np.ascontiguousarray(pos, np.int32)
+    x = np.ascontiguousarray(x, np.complex64)
+    y = np.ascontiguousarray(y, np.complex64)
+    n = x.shape[-1]
+    z = np.zeros(len(pos), np.complex64)
+    _check(lib().spangpu_cvec_circular_dot_prodf_batch(device, x.ctypes.data, n if x.ndim == 2 else 0, y.ctypes.data, n if y.ndim == 2 else 0,
+                                                       pos.ctypes.data, z.ctypes.data, len(pos), n, MEM_HOST))
+    return z
+
+
+def cvec_circular_lmsf(x, y, pos, error, device=0):
+    pos = np.ascontiguousarray(pos, np.int32)
+    x = np.ascontiguousarray(x, np.complex64)
+    y = np.array(y, np.complex64, order="C")
+    e = np.ascontiguousarray(error, np.complex64)
+    n = y.shape[1]
+    _check(lib().spangpu_cvec_circular_lmsf_batch(device, x.ctypes.data, n if x.ndim == 2 else 0, y.ctypes.data, n, pos.ctypes.data, e.ctypes.data,
+                                                  len(pos), n, MEM_HOST))
+    return y
+
+
+def power_meter_update(amp, reading, shift, device=0):
+    """amp int16 [items, n]; reading, shift int32 [items] -> the readings after the rows."""
+    amp = np.ascontiguousarray(amp, np.int16)
+    r = np.array(reading, np.int32)
+    sh = np.ascontiguousarray(shift, np.int32)
+    _check(lib().spangpu_power_meter_update_batch(device, amp.ctypes.data, amp.shape[1], r.ctypes.data, sh.ctypes.data, amp.shape[0], amp.shape[1], MEM_HOST))
+    return r
+
+
+class ShardedToneBank:
+    """One logical DTMF / Bell MF / R2 MF bank over several devices (spangpu_shard_*): contiguous channel ranges, a bank and
+    a stream per shard, the digit byte of every block and channel gathered device to device to the first shard's device."""
+
+    def __init__(self, kind, n_channels, devices, max_samples=160):
+        self.n = n_channels
+        self.h = C.c_void_p()
+        dv = (C.c_int*len(devices))(*devices)
+        _check(lib().spangpu_shard_create(C.byref(self.h), dv, len(devices), kind, n_channels, max_samples, None, 0))
+        self.shards = _check(lib().spangpu_shard_count(self.h))
+        self.ranges = []
+        for i in range(self.shards):
+            d, f, n = C.c_int(), C.c_int(), C.c_int()
+            _check(lib().spangpu_shard_range(self.h, i, C.byref(d), C.byref(f), C.byref(n)))
+            self.ranges.append((d.value, f.value, n.value))
+
+    def close(self):
+        if self.h:
+            lib().spangpu_shard_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rx_device(self, ptrs, samples, stride):
+        """ptrs[i]: device address of shard i's rows (on shard i's device); queues the step, returns blocks per channel."""
+        arr = (C.c_void_p*len(ptrs))(*ptrs)
+        return _check(lib().spangpu_shard_rx(self.h, arr, samples, stride))
+
+    def digits_host(self):
+        """[blocks, n_channels] uint8 of the last step, in the whole bank's channel order."""
+        out = np.zeros((16, self.n), np.uint8)
+        nb = _check(lib().spangpu_shard_digits_host(self.h, out.ctypes.data, out.nbytes))
+        return out[:nb].copy()
+
+    def sync(self):
+        _check(lib().spangpu_shard_sync(self.h))
+
+
 class EchoFeed:
     """The pipelined host path of an echo canceller bank (spangpu_echo_feed_*): slots() hands out the numpy views of the next
     tick's tx and rx staging rows ([n_ch, stride] int16, or uint8 with a G.711 law), commit() queues the tick (H2D, kernel and
@@ -876,11 +991,13 @@ class ModemBank:
         assert frames.shape[0] == self.n and lens.shape == (self.n,)
         _check(lib().spangpu_modem_rx_var(self.h, frames.ctypes.data, MEM_HOST, lens.ctypes.data, frames.shape[1], frames.shape[1]))
 
-    def events(self):
-        """List (per channel) of int8 arrays: 0/1 bits and negative SIG_STATUS codes, in order."""
+    def events(self, packed=False):
+        """List (per channel) of int8 arrays: 0/1 bits and negative SIG_STATUS codes, in order.  packed: by way of the
+        packed form (spangpu_modem_events_packed: the same answer, a fraction of the bytes over PCIe)."""
         ev = C.c_void_p()
         cnt = C.c_void_p()
-        cap = _check(lib().spangpu_modem_events(self.h, C.byref(ev), C.byref(cnt)))
+        fn = lib().spangpu_modem_events_packed if packed else lib().spangpu_modem_events
+        cap = _check(fn(self.h, C.byref(ev), C.byref(cnt)))
         counts = np.frombuffer((C.c_char*(4*self.n)).from_address(cnt.value), dtype=np.int32).copy()
         raw = np.frombuffer((C.c_char*(cap*self.n)).from_address(ev.value), dtype=np.int8).reshape(self.n, cap)
         assert counts.max(initial=0) <= cap, "event buffer overflow"

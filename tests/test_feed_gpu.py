@@ -211,6 +211,9 @@ def test_packed_modem_events_and_the_pipelined_modem_feed(built):
     for t in range(ticks):
         serial.rx_host(sig[:, t*frame:(t + 1)*frame])
         want.append(serial.events())
+        if t % 3 == 0:                                          # spangpu_modem_events_packed(): the same answer by the packed way
+            again = serial.events(packed=True)
+            assert all(np.array_equal(a, b) for a, b in zip(again, want[-1])), t
     serial.close()
     bank = engine.V29Bank(n_ch, 9600)
     feed = engine.ModemFeed(bank, frame, 9600, depth=3)
