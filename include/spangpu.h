@@ -154,6 +154,7 @@ SPANGPU_API int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind,
                                     const void *params, size_t params_size);
 SPANGPU_API int spangpu_bank_destroy(spangpu_bank_t *bank);
 SPANGPU_API int spangpu_bank_kind(const spangpu_bank_t *bank);
+SPANGPU_API int spangpu_bank_device(const spangpu_bank_t *bank);
 SPANGPU_API int spangpu_bank_channels(const spangpu_bank_t *bank);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL = the bank's own stream. */
 SPANGPU_API int spangpu_bank_set_stream(spangpu_bank_t *bank, void *hip_stream);
@@ -219,6 +220,8 @@ SPANGPU_API int spangpu_bank_digit_events(spangpu_bank_t *bank, uint32_t *dst_de
                                                    channel | digit << 20 | block << 28, as spangpu_bank_digit_events()
    law = 0: 16 bit linear PCM; SPANGPU_G711_ALAW / _ULAW: one byte per sample, decoded on the device (half the PCIe volume).
    Replaces the per-call sequence of dtmf_rx() + dtmf_rx_get() (src/dtmf.c:164-347, 481-519) for a whole bank. */
+/* `device` must be the bank's own device (refused otherwise).  The feed uses the bank until it is destroyed: destroy the feed
+   first.  max_samples may not exceed what spangpu_bank_digit_events() can report in one tick (16 blocks per channel). */
 typedef struct spangpu_feed_s spangpu_feed_t;
 SPANGPU_API int spangpu_feed_create(spangpu_feed_t **feed, spangpu_bank_t *bank, int device, int max_samples, int law, int depth);
 SPANGPU_API int spangpu_feed_destroy(spangpu_feed_t *feed);

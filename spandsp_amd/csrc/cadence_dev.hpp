@@ -115,6 +115,10 @@ __device__ static inline int cadence_walk_loaded(const CadenceArgs &A, const Fir
         n_out = n;
         if (n <= 0)
             return false;
+        // (a count set from outside -- spangpu_bank_cadence_set_state(), for a tone whose length the host does not keep -- may
+        // not be reduced yet: never index past the cadence's own elements)
+        while (turn_now >= n)
+            turn_now -= n;
         int i1 = turn_now - 1;
         i1 += (i1 < 0)  ?  n  :  0;
         int i2 = i1 - 1;

@@ -3,6 +3,7 @@
 // behind these entry points.
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -70,7 +71,7 @@ static void init_scalars(int32_t *s, int taps, int mode)
     s[ES_ADAPTION_MODE] = mode;
 }
 
-static int g_echo_group = 0;
+static std::atomic<int> g_echo_group{0};      // spangpu_tune_echo_lanes_per_channel(): process-wide, read once at bank creation
 
 extern "C" {
 
@@ -116,9 +117,10 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     // lanes from 24576 channels, eight from 8192, sixteen below; two lanes on request
     // (spangpu_tune_echo_lanes_per_channel()), for banks whose channels run in step.
     // Slices are at most 32 taps (four lanes) or 16 taps per lane; two lanes take 32, 64 or 128 taps.
-    e->group = (g_echo_group != 0)  ?  g_echo_group  :  (n_channels >= 24576)  ?  4  :  (n_channels >= 8192)  ?  8  :  16;
+    const int tuned = g_echo_group.load(std::memory_order_relaxed);
+    e->group = (tuned != 0)  ?  tuned  :  (n_channels >= 24576)  ?  4  :  (n_channels >= 8192)  ?  8  :  16;
     if (e->group == 2  &&  taps != 128  &&  taps != 64  &&  taps != 32)
-        e->group = (g_echo_group != 0  ||  n_channels >= 131072)  ?  4  :  8;
+        e->group = (tuned != 0  ||  n_channels >= 131072)  ?  4  :  8;
     if (e->group == 4  &&  (taps/4 < 2  ||  taps/4 > 32))
         e->group = 8;
     if (e->group == 8  &&  (taps/8 < 2  ||  taps/8 > 16))

@@ -83,6 +83,13 @@ int spangpu_feed_create(spangpu_feed_t **out, spangpu_bank_t *bank, int device, 
     const int n_ch = spangpu_bank_channels(bank);
     if (n_ch <= 0)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad bank");
+    // the frame buffers and the copy stream live where the kernels read them: on the bank's device, no other
+    if (device != spangpu_bank_device(bank))
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "the feed's device must be the bank's");
+    // spangpu_bank_digit_events() packs the block index in four bits: a tick of more than 16 blocks per channel (the shortest
+    // block is 64 samples) could queue its copy and kernel and then fail to report -- refused here instead of half way
+    if (max_samples > 16*64)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "a feed's ticks hold at most 1024 samples per channel (16 blocks)");
     spangpu_feed_t *f = (spangpu_feed_t *) calloc(1, sizeof(*f));
     if (f == nullptr)
         return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of memory");

@@ -3,6 +3,7 @@
 // exists behind these entry points.
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,7 +22,7 @@ using namespace spg;
 
 extern "C" int spangpu_set_error(int code, const char *msg);
 
-static int g_modem_mapping = 0;
+static std::atomic<int> g_modem_mapping{0};     // spangpu_tune_modem_mapping(): a process-wide knob another thread may turn while a bank launches
 
 #define V29_TRY(expr)                                                                       \
     do                                                                                      \
@@ -227,13 +228,14 @@ extern "C" __attribute__((visibility("default"))) int spangpu_debug_quad_prof(un
 }
 #endif
 
-// Tuning / A-B testing: how the receiver kernels map channels to lanes from now on (0 = by bank size; 1 = one channel
-// per lane; 4 / 8 = four lanes per channel with 16 / 8 channels per wave, V.29 only so far).  Results are identical.
+// Tuning / A-B testing: how the receiver kernels map channels to lanes from now on (0 = by bank size: four lanes per channel
+// below 65 536 channels, one above; 1 = one channel per lane at every size; 4 = four lanes per channel, 16 channels per
+// wave, at every size, all three receivers; 8 is accepted and means 4).  Results are identical.
 int spangpu_tune_modem_mapping(int mapping)
 {
     if (mapping != 0  &&  mapping != 1  &&  mapping != 4  &&  mapping != 8)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "modem mapping must be 0 (auto), 1, 4 or 8");
-    g_modem_mapping = mapping;
+    g_modem_mapping.store(mapping, std::memory_order_relaxed);
     return SPANGPU_OK;
 }
 
@@ -511,7 +513,9 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
     // (measured, 16 384-channel rounds of the quad kernels against the one-lane kernels, V.29 / V.17 / V.27ter: 32 768 channels
     // 0.32 / 0.40 / 0.24 ms against 0.75 / 0.86 / 0.26; 49 152 channels 0.47 / 0.59 / 0.34 against 0.75 / 0.84 / 0.48; from
     // 65 536 channels the full-wave one-lane kernels win: 0.45 / 0.92 / 0.29 ms against four rounds of 0.156 / 0.215 / 0.111)
-    const int quad = (g_modem_mapping != 0)  ?  g_modem_mapping  :  (m->n_ch < 64*1024)  ?  4  :  1;
+    const int mapping = g_modem_mapping.load(std::memory_order_relaxed);        // read once per launch
+    const int quad = (mapping != 0)  ?  mapping  :  (m->n_ch < 64*1024)  ?  4  :  1;
+    const bool forced_quad = (mapping == 4  ||  mapping == 8);       // an explicit four lanes per channel holds at every bank size (A-B runs)
     const dim3 grid((m->n_ch + cpw - 1)/cpw);
     if (m->kind == SPANGPU_V29)
     {
@@ -532,7 +536,7 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         L.qam_cap = m->qam_cap;
         if (m->qam_tap)
             hipLaunchKernelGGL((v29_bank_kernel<16, true>), dim3((m->n_ch + 15)/16), dim3(64), 0, m->stream, L);
-        else if (cpw == 64)
+        else if (cpw == 64  &&  !forced_quad)
         {
             // full waves: four to a workgroup, sharing the tables, the RRC delay line as packed int16 pairs -- 150 KB of
             // LDS per workgroup, one workgroup per CU, a wave on every SIMD (v29_dev.hpp)
@@ -570,7 +574,7 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         L.qam_cap = m->qam_cap;
         if (m->qam_tap)
             hipLaunchKernelGGL((v17_bank_kernel<16, true>), dim3((m->n_ch + 15)/16), dim3(64), 0, m->stream, L);
-        else if (cpw == 64)
+        else if (cpw == 64  &&  !forced_quad)
         {
             const int waves = (m->n_ch + 63)/64;
             hipLaunchKernelGGL((v17_bank_kernel<64, false, 3, 16, true>), dim3((waves + 2)/3), dim3(192), 0, m->stream, L);
@@ -602,7 +606,7 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         L.qam_cap = m->qam_cap;
         if (m->qam_tap)
             hipLaunchKernelGGL((v27ter_bank_kernel<16, true>), dim3((m->n_ch + 15)/16), dim3(64), 0, m->stream, L);
-        else if (cpw == 64)
+        else if (cpw == 64  &&  !forced_quad)
         {
             const int waves = (m->n_ch + 63)/64;
             hipLaunchKernelGGL((v27ter_bank_kernel<64, false, 4, 16, true>), dim3((waves + 3)/4), dim3(256), 0, m->stream, L);

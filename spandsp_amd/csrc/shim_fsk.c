@@ -145,7 +145,7 @@ static int tick_taken(spangpu_line_group_t *g)
 
 /* Run the tick with the receivers that have staged a frame; the others sit it out, untouched (as the reference's are when
    their xxx_rx() is not called), and may stage for the next one.  Returns how many took part. */
-static int line_flush_locked(spangpu_line_group_t *g)
+static int line_flush_locked_tick(spangpu_line_group_t *g)
 {
     int cap;
     int c;
@@ -155,7 +155,7 @@ static int line_flush_locked(spangpu_line_group_t *g)
 
     int took;
 
-    if (g->n_staged == 0  ||  g->delivering)
+    if (g->n_staged == 0)
         return 0;
     if (g->is_mct)
     {
@@ -216,6 +216,28 @@ static int line_flush_locked(spangpu_line_group_t *g)
     return took;
 }
 
+/* The tick(s) that are due.  Callbacks may stage frames (a put_bit handler that answers by feeding its receiver, say): while
+   a tick's callbacks run, a flush from inside them does nothing (`delivering`); when they are over, the tick those frames
+   complete -- every attached channel has staged again -- runs at once instead of waiting for somebody to ask, so that no
+   later xxx_rx() is refused as a second frame of a tick that nobody would ever have run. */
+static int line_flush_locked(spangpu_line_group_t *g)
+{
+    int total = 0;
+    int rc;
+
+    if (g->delivering)
+        return 0;
+    for (;;)
+    {
+        if ((rc = line_flush_locked_tick(g)) < 0)
+            return rc;
+        total += rc;
+        if (g->n_staged == 0  ||  g->n_staged < g->n_attached)
+            break;
+    }
+    return total;
+}
+
 int spangpu_line_group_flush(spangpu_line_group_t *g)
 {
     int rc;
@@ -241,6 +263,8 @@ static int line_rx(spangpu_line_group_t *g, int channel, int private_grp, const 
         return 0;                           /* as the reference: nothing to do (fsk.c:330 loops over len) */
     if (private_grp)
     {
+        if (g->delivering)
+            return -1;                      /* called from inside its own callback: refused, not dropped (the staging row is in use) */
         while (len > 0)
         {
             n = (len > g->max_samples)  ?  g->max_samples  :  len;

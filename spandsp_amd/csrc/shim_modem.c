@@ -169,7 +169,7 @@ static void deliver(modem_obj_t *o, const int8_t *ev, int n, const uint32_t *qam
 
 /* Run the tick with the receivers that have staged a frame; the others sit it out, untouched (as the reference's are
    when their xxx_rx() is not called), and may stage for the next one.  Returns how many took part. */
-static int group_flush_locked(spangpu_modem_group_t *g)
+static int group_flush_locked_tick(spangpu_modem_group_t *g)
 {
     const int8_t *events;
     const int32_t *counts;
@@ -180,7 +180,7 @@ static int group_flush_locked(spangpu_modem_group_t *g)
     int c;
     int rc;
 
-    if (g->n_staged == 0  ||  g->delivering)
+    if (g->n_staged == 0)
         return 0;
     rc = spangpu_modem_rx_var(g->bank, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples);
     /* the put_bit stream comes up packed (a header word and the data bits per channel, status reports as a sparse list) and is
@@ -210,6 +210,28 @@ static int group_flush_locked(spangpu_modem_group_t *g)
     }
     g->delivering = 0;
     return rc;
+}
+
+/* The tick(s) that are due.  Callbacks may stage frames (a put_bit handler that answers by feeding its receiver, say): while
+   a tick's callbacks run, a flush from inside them does nothing (`delivering`); when they are over, the tick those frames
+   complete -- every attached channel has staged again -- runs at once instead of waiting for somebody to ask, so that no
+   later xxx_rx() is refused as a second frame of a tick that nobody would ever have run. */
+static int group_flush_locked(spangpu_modem_group_t *g)
+{
+    int total = 0;
+    int rc;
+
+    if (g->delivering)
+        return 0;
+    for (;;)
+    {
+        if ((rc = group_flush_locked_tick(g)) < 0)
+            return rc;
+        total += rc;
+        if (g->n_staged == 0  ||  g->n_staged < g->n_attached)
+            break;
+    }
+    return total;
 }
 
 int spangpu_modem_group_flush(spangpu_modem_group_t *g)
@@ -305,6 +327,8 @@ static int obj_rx(modem_obj_t *o, const int16_t amp[], int len)
         return 0;                           /* as the reference: nothing to do (v29rx.c:867-965 loops over len) */
     if (o->private_grp)
     {
+        if (g->delivering)
+            return -1;                      /* called from inside its own callback: refused, not dropped (the staging row is in use) */
         while (len > 0)
         {
             n = (len > g->max_samples)  ?  g->max_samples  :  len;

@@ -225,7 +225,7 @@ spangpu_bank_t *spangpu_group_bank(spangpu_group_t *g)
 /* Run the tick with the channels that have staged a frame.  The others sit it out -- their detectors are exactly as they
    were, as the reference's are for a channel whose xxx_rx() was not called -- and may stage for the next one.  Returns
    the number of channels that took part. */
-static int group_flush_locked(spangpu_group_t *g)
+static int group_flush_locked_tick(spangpu_group_t *g)
 {
     int rc;
     int n;
@@ -233,7 +233,7 @@ static int group_flush_locked(spangpu_group_t *g)
     int start;
     int ch;
 
-    if (g->n_staged == 0  ||  g->delivering)
+    if (g->n_staged == 0)
         return 0;
     rc = spangpu_bank_rx_var(g->bank, g->stage, SPANGPU_MEM_HOST, g->lens, g->max_samples, g->max_samples);
     n = (rc < 0)  ?  rc  :  spangpu_bank_blocks(g->bank, NULL, 0);
@@ -275,6 +275,28 @@ static int group_flush_locked(spangpu_group_t *g)
     }
     g->delivering = 0;
     return rc;
+}
+
+/* The tick(s) that are due.  Callbacks may stage frames (a put_bit handler that answers by feeding its receiver, say): while
+   a tick's callbacks run, a flush from inside them does nothing (`delivering`); when they are over, the tick those frames
+   complete -- every attached channel has staged again -- runs at once instead of waiting for somebody to ask, so that no
+   later xxx_rx() is refused as a second frame of a tick that nobody would ever have run. */
+static int group_flush_locked(spangpu_group_t *g)
+{
+    int total = 0;
+    int rc;
+
+    if (g->delivering)
+        return 0;
+    for (;;)
+    {
+        if ((rc = group_flush_locked_tick(g)) < 0)
+            return rc;
+        total += rc;
+        if (g->n_staged == 0  ||  g->n_staged < g->n_attached)
+            break;
+    }
+    return total;
 }
 
 int spangpu_group_flush(spangpu_group_t *g)

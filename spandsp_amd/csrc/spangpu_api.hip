@@ -6,6 +6,7 @@
 // HIP device every call that needs one returns SPANGPU_ERR_NO_DEVICE.
 
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -100,23 +101,26 @@ struct spangpu_bank_s
 
 // Lanes per channel: 2 while the bank is too small to put >= 4 one-channel-per-lane waves
 // on every SIMD (1024 SIMDs x 64 lanes x 4), else 1.  SPANGPU_LPC=1|2 overrides (tuning).
-static int g_forced_lpc = -1;
+static std::atomic<int> g_forced_lpc{-1};      // (the tuning knobs are process-wide and may be turned from any thread: relaxed atomics, read once per use)
 
 static int forced_lpc(void)
 {
-    if (g_forced_lpc < 0)
+    int v = g_forced_lpc.load(std::memory_order_relaxed);
+    if (v < 0)
     {
         const char *e = getenv("SPANGPU_LPC");
-        g_forced_lpc = (e  &&  (e[0] == '1'  ||  e[0] == '2'))  ?  (e[0] - '0')  :  0;
+        v = (e  &&  (e[0] == '1'  ||  e[0] == '2'))  ?  (e[0] - '0')  :  0;
+        g_forced_lpc.store(v, std::memory_order_relaxed);
     }
-    return g_forced_lpc;
+    return v;
 }
 
 // the general kernel's mapping
 static int pick_lpc(int n_ch)
 {
-    if (forced_lpc())
-        return g_forced_lpc;
+    const int f = forced_lpc();
+    if (f)
+        return f;
     return (n_ch < 262144)  ?  2  :  1;
 }
 
@@ -127,7 +131,7 @@ static int pick_lpc(int n_ch)
 // banks the one in which every wave fetches for itself (there the other waves of the SIMD cover it, and a loader wave
 // would only take a wave slot).  Crossover measured in profiles/r2_probe.log.  spangpu_tune_tone_kernel() forces one
 // family (A-B measurements, parity tests of all of them).
-static int g_tone_variant = 0;          // 0 auto, 1 general, 2 streaming with loader waves, 3 streaming without
+static std::atomic<int> g_tone_variant{0};  // 0 auto, 1 general, 2 streaming with loader waves, 3 streaming without
 constexpr int kLoaderMaxChannels = 393216;
 
 static bool fast_eligible(const ToneLaunch &L)
@@ -698,6 +702,7 @@ int spangpu_bank_destroy(spangpu_bank_t *b)
 }
 
 int spangpu_bank_kind(const spangpu_bank_t *b) { return b  ?  b->kind  :  SPANGPU_ERR_BAD_ARG; }
+int spangpu_bank_device(const spangpu_bank_t *b) { return b  ?  b->device  :  SPANGPU_ERR_BAD_ARG; }
 int spangpu_bank_channels(const spangpu_bank_t *b) { return b  ?  b->n_ch  :  SPANGPU_ERR_BAD_ARG; }
 
 int spangpu_bank_set_stream(spangpu_bank_t *b, void *hip_stream)

@@ -305,3 +305,67 @@ def test_dtmf_tx_asks_for_more_digits(L):
     L.dtmf_tx_release.argtypes = [C.c_void_p]
     assert L.dtmf_tx_release(s) == 0
     L.dtmf_tx_init.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+
+
+def test_frames_staged_from_inside_callbacks_run(L):
+    """A put_bit handler that feeds the receivers their next frame: frames staged while a tick's callbacks
+    are being made complete the next tick, and that tick runs when the callbacks are over -- it does not wait for a flush
+    nobody would call, and the fsk_rx() calls that follow are not refused as second frames.  The receivers see every sample
+    once, in order: the bit streams are the oracle's.  A private object refuses the nested call (its one staging row is in
+    use) instead of losing it."""
+    from oracle import restated as orc
+    n, frames = 3, 40
+    sig = synth.fsk_channels(n, 160*frames, 977, 1850, 1650, 30000)
+    grp = L.spangpu_fsk_group_create(0, spec_ptr(L, 1), 1, n, 160)
+    taps = [[] for _ in range(n)]
+    objs = [None]*n
+    shots = {5: None, 17: None}     # ticks whose first callback stages the following frame for everybody
+    rcs = []
+    state = {"tick": -1, "fired": set()}
+
+    def stage(k):
+        for d in range(n):
+            blk = np.ascontiguousarray(sig[d, k*160:(k + 1)*160])
+            rcs.append(L.fsk_rx(objs[d], blk.ctypes.data, 160))
+
+    def on_bit(c, b):
+        taps[c].append(b)
+        t = state["tick"]
+        if t in shots and t not in state["fired"]:
+            state["fired"].add(t)
+            state["tick"] = t + 1
+            stage(t + 1)            # from inside the callback: completes tick t + 1, which must run when this tick's callbacks are over
+    cbs = [PUT_BIT(lambda u, b, c=c: on_bit(c, b)) for c in range(n)]
+    for c in range(n):
+        objs[c] = L.spangpu_fsk_rx_attach(grp, c, cbs[c], None)
+    k = 0
+    while k < frames:
+        state["tick"] = k
+        stage(k)
+        k = state["tick"] + 1       # (a shot has advanced it by one frame)
+    assert state["fired"] == set(shots) and all(r == 0 for r in rcs), rcs
+    for c in range(n):
+        o = orc.Fsk(1, 1)
+        o.rx(sig[c, :160*frames])
+        assert taps[c] == [int(e["a"]) for e in o.sink.events()], c
+    for o in objs:
+        L.fsk_rx_free(o)
+    L.spangpu_line_group_destroy(grp)
+    # a private object: the nested call is refused (-1), the outer one is unharmed
+    got = []
+    inner = []
+    holder = [None]
+
+    def private_bit(u, b):
+        got.append(b)
+        if len(inner) < 3:
+            blk = np.zeros(160, np.int16)
+            inner.append(L.fsk_rx(holder[0], blk.ctypes.data, 160))
+    cb = PUT_BIT(private_bit)
+    holder[0] = L.fsk_rx_init(None, spec_ptr(L, 1), 1, cb, None)
+    x = np.ascontiguousarray(sig[0])
+    assert L.fsk_rx(holder[0], x.ctypes.data, len(x)) == 0
+    o = orc.Fsk(1, 1)
+    o.rx(sig[0])
+    assert inner == [-1, -1, -1] and got == [int(e["a"]) for e in o.sink.events()]
+    L.fsk_rx_free(holder[0])

@@ -404,9 +404,10 @@ static void ab_r4(int n_ch, int n_frames, int reps, int rounds)
     typedef DtmfDet<false> D;
     Rig r = make_rig<D>(n_ch, 160, n_frames, 102, false);
     printf("---- r4 A-B: DTMF, %d channels x 160 samples, %s, %d rounds ----\n", n_ch, LDR  ?  "loader wave"  :  "self-fetching", rounds);
-    const char *names[] = {"general block end, rolled loop (round 3)", "lean block end, rolled loop", "lean + asm pairs", "lean + asm pairs + nt stores",
-                           "lean + asm pairs + sc1 stores", "lean + asm pairs + sc0 sc1 stores", "lean + asm pairs, no stores (ablation)"};
-    constexpr int NV = 7;
+    const char *names[] = {"general block end, rolled loop (round 3)", "lean block end, rolled loop", "product (lean + asm pairs + write-through)", "... nt stores",
+                           "... plain stores", "(spare)", "... no stores (ablation)", "... no DMA issued (ablation)",
+                           "... self-fetching, no DMA: no loader, no barriers (ablation)", "... no recurrence (ablation)"};
+    constexpr int NV = 10;
     std::vector<float> t[NV];
     unsigned long long dg[NV];
     for (int k = 0;  k < rounds;  k++)
@@ -415,15 +416,18 @@ static void ab_r4(int n_ch, int n_frames, int reps, int rounds)
         t[1].push_back(ab_time<D, 131072, LDR>(r, reps, (k == 0)  ?  &dg[1]  :  nullptr));
         t[2].push_back(ab_time<D, 0, LDR>(r, reps, (k == 0)  ?  &dg[2]  :  nullptr));
         t[3].push_back(ab_time<D, 16384, LDR>(r, reps, (k == 0)  ?  &dg[3]  :  nullptr));
-        t[4].push_back(ab_time<D, 262144, LDR>(r, reps, (k == 0)  ?  &dg[4]  :  nullptr));
-        t[5].push_back(ab_time<D, 65536, LDR>(r, reps, (k == 0)  ?  &dg[5]  :  nullptr));
+        t[4].push_back(ab_time<D, 65536, LDR>(r, reps, (k == 0)  ?  &dg[4]  :  nullptr));
+        t[5].push_back(ab_time<D, 0, LDR>(r, reps, (k == 0)  ?  &dg[5]  :  nullptr));
         t[6].push_back(ab_time<D, 32768, LDR>(r, reps, (k == 0)  ?  &dg[6]  :  nullptr));
+        t[7].push_back(ab_time<D, 16, LDR>(r, reps, (k == 0)  ?  &dg[7]  :  nullptr));
+        t[8].push_back(ab_time<D, 16, false>(r, reps, (k == 0)  ?  &dg[8]  :  nullptr));
+        t[9].push_back(ab_time<D, 8, LDR>(r, reps, (k == 0)  ?  &dg[9]  :  nullptr));
     }
     for (int v = 0;  v < NV;  v++)
     {
         std::sort(t[v].begin(), t[v].end());
         printf("%-44s median %7.2f us  min %7.2f us  %s\n", names[v], t[v][t[v].size()/2]*1e3, t[v][0]*1e3,
-               (v == 6)  ?  ""  :  (dg[v] == dg[0])  ?  "same digest"  :  "!!! digest differs");
+               (v >= 6)  ?  ""  :  (dg[v] == dg[0])  ?  "same digest"  :  "!!! digest differs");
     }
     free_rig(r);
 }
