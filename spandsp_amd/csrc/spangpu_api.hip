@@ -1190,11 +1190,28 @@ int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, i
     // lanes per channel: the streaming kernels run one channel per lane unless two are asked for
     const int lpc = all_fast  ?  ((forced_lpc() == 2)  ?  2  :  1)  :  pick_lpc(total_ch);
     const int cpw = kWave/lpc;
+    // Workgroups are dispatched in index order and a launch of this kind fills the chip more than once: the detectors with
+    // the most work per channel go first, so that what runs last, when the chip drains, is the cheap kind (the super-tone
+    // banks' workgroups at the end of the range left a tail of their own length; measured in tools/bench_paths.py mixed).
+    auto cost = [](int kind) { return (kind == TONE_K_ST16)  ?  6  :  (kind == TONE_K_ST12)  ?  5  :  (kind == TONE_K_ST8)  ?  4
+                                      :  (kind == TONE_K_DTMF)  ?  3  :  (kind == TONE_K_ST4)  ?  2  :  1; };
+    for (int i = 1;  i < n_banks;  i++)
+    {
+        for (int k = i;  k > 0  &&  cost(M.kind[k]) > cost(M.kind[k - 1]);  k--)
+        {
+            const int kk = M.kind[k];
+            M.kind[k] = M.kind[k - 1];
+            M.kind[k - 1] = kk;
+            const ToneLaunch tl = M.bank[k];
+            M.bank[k] = M.bank[k - 1];
+            M.bank[k - 1] = tl;
+        }
+    }
     int first = 0;
     for (int k = 0;  k < n_banks;  k++)
     {
         M.first[k] = first;
-        const int waves = (banks[k]->n_ch + cpw - 1)/cpw;
+        const int waves = (M.bank[k].n_ch + cpw - 1)/cpw;
         first += (waves + kWavesPerBlock - 1)/kWavesPerBlock;
     }
     for (int k = n_banks;  k <= kMaxMulti;  k++)

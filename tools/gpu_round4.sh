@@ -16,6 +16,48 @@ probe)
   tail -5 $R/pytest_tone.log
   cd /tmp; timeout 300 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e > $R/bench_quick.json 2> $R/bench_quick.err; tail -c 900 $R/bench_quick.json
   ;;
+bench)
+  cd /tmp
+  timeout 600 python $GRAFT_REPO_ROOT/bench.py > $R/bench.json 2> $R/bench.err
+  timeout 600 python $GRAFT_REPO_ROOT/bench.py --workload echo > $R/bench_echo.json 2> $R/bench_echo.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench_stats -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-e2e --no-paths > $R/bench_stats.log 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/bench_fetch -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-paths > $R/bench_fetch.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/bench_write -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-paths > $R/bench_write.log 2>&1
+  for w in mixed v29 v17 v27ter; do
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/${w}_stats -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --no-cpu-baseline --no-e2e > $R/${w}_stats.log 2>&1
+    cp $(ls $R/${w}_stats/*/*kernel_stats.csv | head -1) $R/${w}_kernel_stats.csv
+  done
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/echo_stats -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload echo --no-cpu-baseline --no-e2e --echo-seconds 3 > $R/echo_stats.log 2>&1
+  cp $(ls $R/echo_stats/*/*kernel_stats.csv | head -1) $R/echo_kernel_stats.csv
+  cp $(ls $R/bench_stats/*/*kernel_stats.csv | head -1) $R/bench_kernel_stats.csv
+  cd $GRAFT_REPO_ROOT
+  python3 - <<'PY'
+import csv, glob, collections, json
+R = "gpurun_out/r4"
+out = {}
+for name in ("bench_fetch", "bench_write"):
+    for f in glob.glob("%s/%s/*/*counter_collection.csv" % (R, name)):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "tone_fast_kernel" in k or "tone_bank_kernel" in k:
+                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            out.setdefault(name, {})[k] = {c: {"launches": len(x), "mean": sum(x)/len(x)} for c, x in v.items()}
+json.dump(out, open(R + "/counters_raw.json", "w"), indent=1)
+print(json.dumps(out)[:1500])
+PY
+  rm -rf $R/bench_stats $R/bench_fetch $R/bench_write $R/*_stats
+  for w in mixed supertone fsk mct sigtone dtmf_tx v29_tx awgn v17 v27ter; do
+    timeout 300 python tools/bench_paths.py --workload $w > $R/paths_$w.json 2> $R/paths_$w.err; echo "$w rc=$?"
+  done
+  tail -c 600 $R/bench.json
+  ;;
+valu)
+  bash tools/gpu_valu.sh > $R/valu.log 2>&1
+  cp gpurun_out/valu/valu_counters.json $R/ 2>/dev/null
+  tail -30 $R/valu.log
+  ;;
 tests)
   python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
   timeout 1500 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log

@@ -6,12 +6,12 @@ R=$GRAFT_REPO_ROOT/gpurun_out/valu
 rm -rf $R; mkdir -p $R
 export TMPDIR=/tmp
 cd /tmp
-timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/dtmf -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e > $R/dtmf.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/dtmf -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-paths > $R/dtmf.log 2>&1
 for w in v29 v17 v27ter; do
-  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$w -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 40 --warmup 110 --no-cpu-baseline > $R/$w.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$w -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 40 --warmup 110 --no-cpu-baseline --no-e2e > $R/$w.log 2>&1
 done
 for w in echo mixed fsk mct sigtone supertone dtmf_tx v29_tx awgn; do
-  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$w -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 30 --no-cpu-baseline > $R/$w.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$w -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 30 --no-cpu-baseline --no-e2e --echo-seconds 2 > $R/$w.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
@@ -41,7 +41,7 @@ for key, (pat, n_ch) in want.items():
                              "wave_cycles_per_wave_sample": 4.0*m.get("SQ_WAVE_CYCLES", 0)/waves/160.0,
                              "active_frac": m.get("SQ_ACTIVE_INST_ANY", 0)/max(1.0, m.get("SQ_WAVE_CYCLES", 1)),
                              "wait_frac": m.get("SQ_WAIT_ANY", 0)/max(1.0, m.get("SQ_WAVE_CYCLES", 1)),
-                             "launches": len(acc[best].get("SQ_INSTS_VALU", [])), "source": "tools/gpu_valu.sh (round 3)"}
+                             "launches": len(acc[best].get("SQ_INSTS_VALU", [])), "source": "tools/gpu_valu.sh (round 4)"}
 json.dump(out, open(os.path.join(R, "valu_counters.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
 PY

@@ -377,16 +377,16 @@ static void sweep_r4(int n_ch, int n_frames, int reps)
 
 // A-B with the variants taken in turn, several rounds, median and minimum per variant (boxes and moments differ by
 // more than the effects looked for).
-template <class Det, int ABL, bool LDR>
+template <class Det, int ABL, bool LDR, int R = 2, int WPB = 4>
 static float ab_time(Rig &r, int reps, unsigned long long *dg)
 {
     const int waves = (r.L.n_ch + kWave - 1)/kWave;
-    const int blocks = (waves + 3)/4;
+    const int blocks = (waves + WPB - 1)/WPB;
     int f = 0;
     auto go = [&] {
         r.L.amp = r.amp + (size_t) (f % r.n_frames)*r.frame_elems;
         f++;
-        launch_tone_fast<Det, 1, 2, false, false, 4, ABL, LDR>(r.L, blocks, g_stream);
+        launch_tone_fast<Det, 1, R, false, false, WPB, ABL, LDR>(r.L, blocks, g_stream);
     };
     if (dg)
     {
@@ -405,7 +405,7 @@ static void ab_r4(int n_ch, int n_frames, int reps, int rounds)
     Rig r = make_rig<D>(n_ch, 160, n_frames, 102, false);
     printf("---- r4 A-B: DTMF, %d channels x 160 samples, %s, %d rounds ----\n", n_ch, LDR  ?  "loader wave"  :  "self-fetching", rounds);
     const char *names[] = {"general block end, rolled loop (round 3)", "lean block end, rolled loop", "product (lean + asm pairs + write-through)", "... nt stores",
-                           "... plain stores", "(spare)", "... no stores (ablation)", "... no DMA issued (ablation)",
+                           "... plain stores", "... ring of 3 slots", "... no stores (ablation)", "... no DMA issued (ablation)",
                            "... self-fetching, no DMA: no loader, no barriers (ablation)", "... no recurrence (ablation)"};
     constexpr int NV = 10;
     std::vector<float> t[NV];
@@ -417,7 +417,7 @@ static void ab_r4(int n_ch, int n_frames, int reps, int rounds)
         t[2].push_back(ab_time<D, 0, LDR>(r, reps, (k == 0)  ?  &dg[2]  :  nullptr));
         t[3].push_back(ab_time<D, 16384, LDR>(r, reps, (k == 0)  ?  &dg[3]  :  nullptr));
         t[4].push_back(ab_time<D, 65536, LDR>(r, reps, (k == 0)  ?  &dg[4]  :  nullptr));
-        t[5].push_back(ab_time<D, 0, LDR>(r, reps, (k == 0)  ?  &dg[5]  :  nullptr));
+        t[5].push_back(ab_time<D, 0, LDR, 3>(r, reps, (k == 0)  ?  &dg[5]  :  nullptr));
         t[6].push_back(ab_time<D, 32768, LDR>(r, reps, (k == 0)  ?  &dg[6]  :  nullptr));
         t[7].push_back(ab_time<D, 16, LDR>(r, reps, (k == 0)  ?  &dg[7]  :  nullptr));
         t[8].push_back(ab_time<D, 16, false>(r, reps, (k == 0)  ?  &dg[8]  :  nullptr));
