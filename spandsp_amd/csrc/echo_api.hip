@@ -48,6 +48,7 @@ struct spangpu_echo_s
     EchoStats *stats;       // per-channel line statistics, allocated by spangpu_echo_stats(ec, 1)
     int stats_on;           // 0 off, 1 energy sums and CRC by a pass of their own after the update, 2 energy sums only, by the update kernel itself
     float *d_erle;          // scratch for spangpu_echo_erle() with a host destination
+    int uniform_mode;       // the adaption mode every channel has, or -1 when they differ: picks the kernel compiled for that mode
 };
 
 __global__ void echo_set_scalar_kernel(int32_t *scal, int lo, int hi, int idx, int value)
@@ -152,6 +153,7 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     }
     for (size_t c = 0;  c < n;  c++)
         init_scalars(h + c*kEchoScalars, taps, adaption_mode);
+    e->uniform_mode = adaption_mode;
     hipError_t rc = hipMemcpyAsync(e->scal, h, n*kEchoScalars*sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
     (void) hipStreamSynchronize(e->stream);
     free(h);
@@ -298,7 +300,13 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
         {
         case 8:  hipLaunchKernelGGL((echo_bank_kernel<8, 4>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
         case 16: hipLaunchKernelGGL((echo_bank_kernel<16, 4>), dim3(blocks), dim3(256), 0, e->stream, L); break;
-        default: hipLaunchKernelGGL((echo_bank_kernel<32, 4>), dim3(blocks), dim3(256), 0, e->stream, L); break;
+        default:
+            // the mode of echo_tests.c's and SURVEY 8(d)-5's lines, and of a bank that has just been created with it
+            if (e->uniform_mode == kModeAdaption)
+                hipLaunchKernelGGL((echo_bank_kernel<32, 4, kModeAdaption>), dim3(blocks), dim3(256), 0, e->stream, L);
+            else
+                hipLaunchKernelGGL((echo_bank_kernel<32, 4>), dim3(blocks), dim3(256), 0, e->stream, L);
+            break;
         }
     }
     else if (e->group == 8)
@@ -407,6 +415,10 @@ int spangpu_echo_set_state(spangpu_echo_t *e, int channel, const int32_t *scal, 
     ECHO_TRY(hipSetDevice(e->device));
     ECHO_TRY(hipStreamSynchronize(e->stream));
     const int T = e->taps;
+    if (scal[ES_ADAPTION_MODE] != e->uniform_mode  &&  e->n_ch > 1)
+        e->uniform_mode = -1;
+    else
+        e->uniform_mode = scal[ES_ADAPTION_MODE];
     ECHO_TRY(hipMemcpy(e->scal + (size_t) channel*kEchoScalars, scal, kEchoScalars*sizeof(int32_t), hipMemcpyHostToDevice));
     if (taps32)
         ECHO_TRY(hipMemcpy(e->taps32 + (size_t) channel*T, taps32, T*sizeof(int32_t), hipMemcpyHostToDevice));
@@ -642,6 +654,10 @@ int spangpu_echo_adaption_mode(spangpu_echo_t *e, int channel, int adaption_mode
     ECHO_TRY(hipStreamSynchronize(e->stream));
     const int lo = (channel < 0)  ?  0  :  channel;
     const int hi = (channel < 0)  ?  e->n_ch  :  (channel + 1);
+    if (hi - lo == e->n_ch)
+        e->uniform_mode = adaption_mode;
+    else if (adaption_mode != e->uniform_mode)
+        e->uniform_mode = -1;
     hipLaunchKernelGGL(echo_set_scalar_kernel, dim3((hi - lo + 255)/256), dim3(256), 0, e->stream,
                        e->scal, lo, hi, (int) ES_ADAPTION_MODE, adaption_mode);
     ECHO_TRY(hipGetLastError());

@@ -108,6 +108,19 @@ __device__ __forceinline__ int top_bit_u32(uint32_t v)
     return (v == 0)  ?  -1  :  (31 - __builtin_clz(v));     // bit_operations.h:45-140
 }
 
+__device__ __forceinline__ int echo_pack_ncf(int narrowband_count, int dtd_onset, int narrowband_score)
+{
+    return (int) (((uint32_t) narrowband_count << 2) & 0x7FFFFFFCu) | (dtd_onset  ?  (int) 0x80000000u  :  0) | ((narrowband_score != 0)  ?  1  :  0);
+}
+
+// echo.c:534-543: max(top_bit(x) - 8, 0), the right shift lms_adapt()'s step gets
+__device__ __forceinline__ int lms_shift(int x)
+{
+    int sh;
+    asm("v_ffbh_u32_e32 %0, %1\n\tv_sub_u32_e64 %0, 23, %0 clamp" : "=&v"(sh) : "v"(x));
+    return sh;
+}
+
 // x86-64 cvttss2si semantics of the reference build: NaN / out of range -> INT32_MIN
 __device__ __forceinline__ int32_t f2i_x86(float v)
 {
@@ -168,26 +181,24 @@ __device__ __forceinline__ void echo_rotate_window(int (&w)[TPL])
     }
 }
 
-// Run the common-sample body for phases PH .. U-1 of a round of U samples.  Returns the number of samples completed,
-// with the window registers back in phase 0 order: after a whole round (a no-op when U == TPL, a physical rotation by
-// U registers otherwise -- TPL moves per U samples, the price of unrolling only U times so that the loop stays inside
-// the instruction cache), or when a phase declines its sample (a set event).
+// Run the common-sample body for phases PH .. U-1 of a round of U samples.  Returns the number of samples completed; the
+// window registers are left in the order of that phase (the caller rotates, through LDS: `rotate_window` in the kernel),
+// which after a whole round of U == TPL samples is phase 0 order again.  A phase declines its sample when some channel of the wave meets a
+// set event on it.
+// `lim` (wave-uniform, 1 .. U) ends the round early: the samples a pass has left after its last whole round stay on the
+// common body (a scalar compare and a branch per phase).
 template <int PH, int U, int TPL, class F>
-__device__ __forceinline__ int echo_fast_round(F &fast, int (&w)[TPL], int idx)
+__device__ __forceinline__ int echo_fast_round(F &fast, int (&w)[TPL], int idx, int lim)
 {
     if constexpr (PH == U)
     {
-        echo_rotate_window<U, TPL>(w);
         return U;
     }
     else
     {
-        if (!fast(idx + PH, std::integral_constant<int, PH>{}))
-        {
-            echo_rotate_window<PH, TPL>(w);
+        if (PH == lim  ||  !fast(idx + PH, std::integral_constant<int, PH>{}))
             return PH;
-        }
-        return echo_fast_round<PH + 1, U, TPL>(fast, w, idx);
+        return echo_fast_round<PH + 1, U, TPL>(fast, w, idx, lim);
     }
 }
 
@@ -247,7 +258,10 @@ constexpr int echo_waves_per_simd(int tpl)
     return (tpl <= 8)  ?  5  :  3;
 }
 
-template <int TPL, int G>
+// MODE >= 0: every channel of the bank has this adaption mode (the host knows: echo_api.hip, `uniform_mode`), so the tests
+// of it are settled when the kernel is compiled and the code of the stages that are off is not there; MODE < 0: each
+// channel's own mode word, tested per lane.
+template <int TPL, int G, int MODE = -1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(echo_waves_per_simd(TPL), echo_waves_per_simd(TPL))))
 void echo_bank_kernel(const EchoLaunch L)
 {
@@ -260,8 +274,14 @@ void echo_bank_kernel(const EchoLaunch L)
     constexpr int U = TPL;
     constexpr int NL = (9 + G - 1)/G;                       // autocorrelation lags per lane: lag = j + m*G < 9
     __shared__ int io[4][kChPerWave][kMaxFrame + 1];        // tx | rx<<16 per sample, then the clean output (+1: read-ahead)
-    __shared__ short bounce[4][kChPerWave][T];              // tap-set / history gathers at set events
-    __shared__ float acfbuf[4][kChPerWave][48];             // narrowband_detect scratch
+    // Scratch of a wave, one use at a time (LDS operations of a wave complete in order):
+    //   bounce   T shorts per channel          tap-set / history gathers at set events
+    //   acfbuf   48 floats per channel         narrowband_detect
+    //   rot      2*TPL rows of 64 shorts       the window registers of every lane, row-major (a row is one register of all 64
+    //                                          lanes: no bank conflicts), written twice over so that a rotation is a row offset
+    constexpr int kScratchBytes = (256*TPL > 192*kChPerWave)  ?  256*TPL  :  192*kChPerWave;
+    __shared__ __attribute__((aligned(16))) char scratch[4][kScratchBytes];
+    __shared__ int cold[4][kChPerWave];                     // narrowband_score: only the complete routine needs its value
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -286,27 +306,35 @@ void echo_bank_kernel(const EchoLaunch L)
     int rx_power1 = sc[ES_RX_POWER1];
     int clean_rx_power = sc[ES_CLEAN_RX_POWER];
     int nonupdate_dwell = sc[ES_NONUPDATE_DWELL];
-    int curr_pos = sc[ES_CURR_POS];
-    const int mode = sc[ES_ADAPTION_MODE];
+    // curr_pos steps T-1, T-2 .. 0, T-1 .. (echo.c:655-658): a sample's value follows from the first one's and the
+    // number of samples since, and only the complete routine needs it
+    const int curr_pos0 = sc[ES_CURR_POS];
+    const int mode = (MODE >= 0)  ?  MODE  :  sc[ES_ADAPTION_MODE];
     int cng = sc[ES_CNG];
-    int dtd_onset = sc[ES_DTD_ONSET];
     int tap_set = sc[ES_TAP_SET];
     int tap_rotate_counter = sc[ES_TAP_ROTATE_COUNTER];
-    int narrowband_count = sc[ES_NARROWBAND_COUNT];
-    int narrowband_score = sc[ES_NARROWBAND_SCORE];
-    int32_t tx_hpf0 = sc[ES_TX_HPF0];
-    int32_t tx_hpf1 = sc[ES_TX_HPF1];
-    int32_t rx_hpf0 = sc[ES_RX_HPF0];
-    int32_t rx_hpf1 = sc[ES_RX_HPF1];
-    int cng_level = sc[ES_CNG_LEVEL];
-    int cng_rndnum = sc[ES_CNG_RNDNUM];
-    int cng_filter = sc[ES_CNG_FILTER];
+    // narrowband_count, dtd_onset and narrowband_score != 0 in one register, as the common body tests and steps them:
+    //   bit 31 dtd_onset  |  bits 30..2 narrowband_count  |  bit 0 narrowband_score != 0
+    // so that count >= 159 is an unsigned compare with 159*4 (true, too, while dtd_onset is set: that sample then takes the
+    // complete routine, which is always right), dtd_onset == 0 a sign test, and count++, dtd_onset = 0 an add and an and.
+    // (Three registers fewer in the common body, where there are none to spare: 168 at three waves per SIMD.)
+    if (j == 0)
+        cold[wv][g] = sc[ES_NARROWBAND_SCORE];
+    int ncf = echo_pack_ncf(sc[ES_NARROWBAND_COUNT], sc[ES_DTD_ONSET], sc[ES_NARROWBAND_SCORE]);
+    // (a kernel compiled for a mode without a stage neither loads nor stores that stage's state: the registers are short)
+    constexpr bool kTxHpf = (MODE < 0)  ||  (MODE & kModeTxHpf);
+    constexpr bool kRxHpf = (MODE < 0)  ||  (MODE & kModeRxHpf);
+    constexpr bool kNlp = (MODE < 0)  ||  (MODE & kModeNlp);
+    int32_t tx_hpf0 = kTxHpf  ?  sc[ES_TX_HPF0]  :  0;
+    int32_t tx_hpf1 = kTxHpf  ?  sc[ES_TX_HPF1]  :  0;
+    int32_t rx_hpf0 = kRxHpf  ?  sc[ES_RX_HPF0]  :  0;
+    int32_t rx_hpf1 = kRxHpf  ?  sc[ES_RX_HPF1]  :  0;
+    int cng_level = kNlp  ?  sc[ES_CNG_LEVEL]  :  0;
+    int cng_rndnum = kNlp  ?  sc[ES_CNG_RNDNUM]  :  0;
+    int cng_filter = kNlp  ?  sc[ES_CNG_FILTER]  :  0;
     int fir_set = sc[ES_FIR_SET];
     int vad = sc[ES_VAD];
-    int my_acf[NL];                                             // lane j holds last_acf[j + m*G]
-#pragma unroll
-    for (int m = 0;  m < NL;  m++)
-        my_acf[m] = (j + m*G < 9)  ?  sc[ES_LAST_ACF + j + m*G]  :  0;
+    // (last_acf[] stays in HBM: lane j reads and rewrites last_acf[j + m*G] when its channel runs the narrow-band test)
 
     // ---- per-lane tap slices ------------------------------------------------------------------
     int t32[TPL];               // fir_taps32
@@ -367,10 +395,7 @@ void echo_bank_kernel(const EchoLaunch L)
         {
             cng = 0;
         }
-        // echo.c:655-658
-        if (curr_pos <= 0)
-            curr_pos = T;
-        curr_pos--;
+        // (echo.c:655-658, the position update: see curr_pos0)
         if (j == 0)
             io[wv][g][idx] = ((int) (short) clean_rx & 0xFFFF) | (tx << 16);    // reuse the slot for the outputs
     };
@@ -397,7 +422,7 @@ void echo_bank_kernel(const EchoLaunch L)
             if (leader)
                 L.stats[ch].sum_rx2 += st_part;
         }
-        // (one wave per io/bounce/acfbuf slice; LDS ops of a wave complete in order)
+        // (one wave per io/scratch slice; LDS ops of a wave complete in order)
 
         // ---- a common sample.  PH is the compile-time rotation phase of the history registers: logical window
         // slot k of this lane lives in w[(k - PH) mod TPL].  Returns false, with nothing changed, when some
@@ -464,10 +489,10 @@ void echo_bank_kernel(const EchoLaunch L)
             const bool single = n_tp1 > n_rp0;
             const bool adapting = loud & single & (n_dwell == 0);
             const bool doubletalk = loud & !single;
-            const bool event = (adapting & ((narrowband_count >= 159) | (tap_rotate_counter <= 1)))
-                               | (doubletalk & (dtd_onset == 0))
+            const bool event = (adapting & (((uint32_t) ncf >= 159u*4u) | (tap_rotate_counter <= 1)))
+                               | (doubletalk & (ncf >= 0))
                                | ((n_rp1 > 2048*2048) & (n_crp > 4*n_rp1));
-            if (__any(event))
+            if (__builtin_amdgcn_ballot_w64(event) != 0)
             {
                 w[NEWP] = w_old;
                 return false;
@@ -486,20 +511,14 @@ void echo_bank_kernel(const EchoLaunch L)
             clean_rx_power = n_crp;
             if (adapting)
             {
-                narrowband_count++;
-                dtd_onset = 0;
+                ncf = (ncf + 4) & 0x7FFFFFFF;               // narrowband_count++, dtd_onset = 0
                 tap_rotate_counter--;
-                if ((mode & kModeAdaption)  &&  narrowband_score == 0)
+                if ((mode & kModeAdaption)  &&  (ncf & 1) == 0)     // narrowband_score == 0
                 {
                     // echo.c:530-553 + lms_adapt(), echo.c:232-249
-                    int factor = clean_rx;
-                    int sh;
-                    if (tx > 4*tx_power3)
-                        sh = top_bit_u32((uint32_t) tx) - 8;
-                    else
-                        sh = top_bit_u32((uint32_t) tx_power3) - 8;
-                    if (sh > 0)
-                        factor >>= sh;
+                    // the shift is max(top_bit(x) - 8, 0) with top_bit(0) = -1: 23 - ffbh(x), an unsigned subtraction that
+                    // clamps at zero (ffbh(0) is all ones)
+                    const int factor = clean_rx >> lms_shift((tx > 4*tx_power3)  ?  tx  :  tx_power3);
 #pragma unroll
                     for (int k = 0;  k < TPL;  k++)
                     {
@@ -513,9 +532,16 @@ void echo_bank_kernel(const EchoLaunch L)
             return true;
         };
 
-        // ---- any sample, registers in phase 0: the whole of echo_can_update() ------------------------------------
+        // ---- any sample: the whole of echo_can_update().  Takes the window registers in the order of phase TPL - 1 (logical
+        // slot k in w[(k + 1) mod TPL]) and leaves them, one sample later, in phase 0 order. ----------------------------
         auto slow = [&](int idx)
         {
+            int narrowband_count = (int) (((uint32_t) ncf >> 2) & 0x1FFFFFFFu);
+            int dtd_onset = (ncf < 0)  ?  1  :  0;
+            int narrowband_score = cold[wv][g];
+            int curr_pos = (curr_pos0 - (base + idx)) & (T - 1);
+            // (opaque: or every expression in curr_pos0 below is computed ahead of the sample loop, and then kept in scratch)
+            asm volatile("" : "+v"(curr_pos));
             const int word = io[wv][g][idx];
             int tx = (int) (short) (word & 0xFFFF);
             int rx = (int) (short) (word >> 16);
@@ -523,14 +549,14 @@ void echo_bank_kernel(const EchoLaunch L)
                 tx = echo_hpf(tx_hpf0, tx_hpf1, tx);            // echo.c:663-669
             if (mode & kModeRxHpf)
                 rx = echo_hpf(rx_hpf0, rx_hpf1, rx);            // echo.c:430
-            w[TPL - 1] = group_shift_in<G>(tx, w[TPL - 1], j);
-            // now logical k -> w[(k - 1) mod TPL]
+            w[0] = group_shift_in<G>(tx, w[0], j);
+            // now logical k -> w[k]
             int y = 0;
             if (__all(fir_set == tap_set))
             {
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
-                    y = mad24(t16[k], w[(k - 1 + TPL)%TPL], y);
+                    y = mad24(t16[k], w[k], y);
             }
             else
             {
@@ -540,7 +566,7 @@ void echo_bank_kernel(const EchoLaunch L)
                 for (int k = 0;  k < TPL;  k++)
                 {
                     const int c = own  ?  t16[k]  :  (int) g16[fir_set*T + k];
-                    y = mad24(c, w[(k - 1 + TPL)%TPL], y);
+                    y = mad24(c, w[k], y);
                 }
             }
             y = group_sum<G>(y);
@@ -560,12 +586,14 @@ void echo_bank_kernel(const EchoLaunch L)
             // fir_taps16[-1] is the FIR history (see the header): history[p] <- set[p]
             auto set_over_history = [&]()
             {
+                short *const bounce = (short *) scratch[wv] + g*T;
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
-                    bounce[wv][g][j*TPL + k] = (short) t16[k];
+                    bounce[j*TPL + k] = (short) t16[k];
+                const unsigned first = (unsigned) (j*TPL + curr_pos);
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
-                    w[(k - 1 + TPL)%TPL] = bounce[wv][g][(j*TPL + k + curr_pos)%T];
+                    w[k] = bounce[(first + k) & (T - 1)];
             };
 
             if (tx_power0 > 64*64)                              // MIN_TX_POWER_FOR_ADAPTION
@@ -577,16 +605,20 @@ void echo_bank_kernel(const EchoLaunch L)
                         if (++narrowband_count >= 160)
                         {
                             narrowband_count = 0;
+                            float *const acfbuf = (float *) scratch[wv] + g*48;
                             // ---- narrowband_detect(), echo.c:120-175 ---------------------------
                             // window samples 0..31 -> LDS, then every lag 0..8 has its lane (lane j: lags j, j + G, ...)
+                            // (every k against a constant: written as i = j*TPL + k against T - curr_pos, the compiler computes the
+                            // TPL values T - i ahead of the sample loop and keeps them in scratch)
+                            const int jt = j*TPL;
+                            const int lead = curr_pos + jt;
 #pragma unroll
                             for (int k = 0;  k < TPL;  k++)
                             {
-                                const int i = j*TPL + k;
-                                if (i < 32)
+                                if (jt < 32 - k)
                                 {
-                                    const bool inside = (T == 256)  ||  (curr_pos + i < T);
-                                    acfbuf[wv][g][i] = inside  ?  (float) w[(k - 1 + TPL)%TPL]  :  0.0f;
+                                    const bool inside = (T == 256)  ||  (lead < T - k);
+                                    (acfbuf + jt)[k] = inside  ?  (float) w[k]  :  0.0f;
                                 }
                             }
                             float temp[NL];
@@ -598,12 +630,12 @@ void echo_bank_kernel(const EchoLaunch L)
                                 if (lag < 9)
                                 {
                                     for (int i = lag;  i < 32;  i++)
-                                        temp[m] += acfbuf[wv][g][i]*acfbuf[wv][g][i - lag];
+                                        temp[m] += acfbuf[i]*acfbuf[i - lag];
                                     if (lag == 0)
-                                        acfbuf[wv][g][32] = temp[m];
+                                        acfbuf[32] = temp[m];
                                 }
                             }
-                            const float scale = (float) 0x1FFFFFFF/acfbuf[wv][g][32];
+                            const float scale = (float) 0x1FFFFFFF/acfbuf[32];
                             auto similar = [](int before, int now) -> bool
                             {
                                 // echo.c:150-168: within a factor of two of the previous value, same sign
@@ -619,10 +651,11 @@ void echo_bank_kernel(const EchoLaunch L)
                             {
                                 const bool mine = (j + m*G < 9);
                                 const int acf = f2i_x86(temp[m]*scale);
-                                const unsigned long long bal = __ballot(mine  &&  similar(my_acf[m], acf));
+                                const int before = mine  ?  sc[ES_LAST_ACF + j + m*G]  :  0;
+                                const unsigned long long bal = __ballot(mine  &&  similar(before, acf));
                                 score += __popcll((bal >> (g*G)) & ((1ull << G) - 1ull));
-                                if (mine)
-                                    my_acf[m] = acf;
+                                if (mine  &&  live)
+                                    sc[ES_LAST_ACF + j + m*G] = acf;
                             }
                             if (score > 6)
                             {
@@ -680,7 +713,7 @@ void echo_bank_kernel(const EchoLaunch L)
 #pragma unroll
                             for (int k = 0;  k < TPL;  k++)
                             {
-                                t32[k] = mad24(w[(k - 1 + TPL)%TPL], factor, t32[k]);
+                                t32[k] = mad24(w[k], factor, t32[k]);
                                 t16[k] = (int) (short) (t32[k] >> 15);
                             }
                         }
@@ -726,26 +759,53 @@ void echo_bank_kernel(const EchoLaunch L)
                 store_set(3, t16);
             }
             finish_sample(idx, tx, clean_rx);
-            // back to phase 0: rotate the window registers once
-            const int last = w[TPL - 1];
+            cold[wv][g] = narrowband_score;                     // (the lanes of a channel agree)
+            ncf = echo_pack_ncf(narrowband_count, dtd_onset, narrowband_score);
+        };
+
+        // ---- the window registers rotated by r (wave-uniform, 0 .. TPL-1) places: new w[k] = old w[(k - r) mod TPL], which
+        // brings phase r order back to phase 0 order.  Through LDS: every register is written to rows i and i + TPL of the
+        // wave's scratch, and row k + (TPL - r) is what register k takes.  (As register moves a rotation by a run-time count
+        // is either a chain of rotations by one -- what the compiler made of thirty-two constant rotations at the exits of
+        // a round, some 540 moves for an average set event, a fifth of the kernel's instructions on mixed lines -- or
+        // log2(TPL) conditional rotations by powers of two, whose temporaries put spills into `slow`: 677 us against 560.)
+        auto rotate_window = [&](int r)
+        {
+            if (r == 0)
+                return;
+            short *const rot = (short *) scratch[wv] + lane;
 #pragma unroll
-            for (int k = TPL - 1;  k > 0;  k--)
-                w[k] = w[k - 1];
-            w[0] = last;
+            for (int k = 0;  k < TPL;  k++)
+            {
+                rot[64*k] = (short) w[k];
+                rot[64*(k + TPL)] = (short) w[k];
+            }
+            const short *from = rot + 64*(TPL - r);
+#pragma unroll
+            for (int k = 0;  k < TPL;  k++)
+                w[k] = from[64*k];
         };
 
         // ---- walk the pass ---------------------------------------------------------------------------------------
         int idx = 0;
         while (idx < n)
         {
-            if (idx + U <= n  &&  __all(fir_set == tap_set))
+            int phase = 0;
+            if (__all(fir_set == tap_set))
             {
+                const int lim = __builtin_amdgcn_readfirstlane(min(U, n - idx));
                 ahead = io[wv][g][idx];
-                const int done = echo_fast_round<0, U, TPL>(fast, w, idx);
+                const int done = __builtin_amdgcn_readfirstlane(echo_fast_round<0, U, TPL>(fast, w, idx, lim));
                 idx += done;
-                if (done == U)
+                if (done == lim)
+                {
+                    rotate_window(done%TPL);
                     continue;
+                }
+                phase = done;
             }
+            // a set event on this sample (or the FIR on another tap set than the one that adapts)
+            rotate_window((phase + 1)%TPL);
             slow(idx);
             idx++;
         }
@@ -783,12 +843,6 @@ void echo_bank_kernel(const EchoLaunch L)
             g16[tap_set*T + k] = (int16_t) t16[k];
             gh[k] = (int16_t) w[k];
         }
-#pragma unroll
-        for (int m = 0;  m < NL;  m++)
-        {
-            if (j + m*G < 9)
-                sc[ES_LAST_ACF + j + m*G] = my_acf[m];
-        }
     }
     if (L.stats  &&  leader)
         L.stats[ch].samples += (uint32_t) L.samples;
@@ -804,21 +858,31 @@ void echo_bank_kernel(const EchoLaunch L)
         sc[ES_RX_POWER1] = rx_power1;
         sc[ES_CLEAN_RX_POWER] = clean_rx_power;
         sc[ES_NONUPDATE_DWELL] = nonupdate_dwell;
+        const int curr_pos = (curr_pos0 - L.samples) & (T - 1);
         sc[ES_CURR_POS] = curr_pos;
         sc[ES_FIR_CURR_POS] = curr_pos;
         sc[ES_CNG] = cng;
-        sc[ES_DTD_ONSET] = dtd_onset;
+        sc[ES_DTD_ONSET] = (ncf < 0)  ?  1  :  0;
         sc[ES_TAP_SET] = tap_set;
         sc[ES_TAP_ROTATE_COUNTER] = tap_rotate_counter;
-        sc[ES_NARROWBAND_COUNT] = narrowband_count;
-        sc[ES_NARROWBAND_SCORE] = narrowband_score;
-        sc[ES_TX_HPF0] = tx_hpf0;
-        sc[ES_TX_HPF1] = tx_hpf1;
-        sc[ES_RX_HPF0] = rx_hpf0;
-        sc[ES_RX_HPF1] = rx_hpf1;
-        sc[ES_CNG_LEVEL] = cng_level;
-        sc[ES_CNG_RNDNUM] = cng_rndnum;
-        sc[ES_CNG_FILTER] = cng_filter;
+        sc[ES_NARROWBAND_COUNT] = (int) (((uint32_t) ncf >> 2) & 0x1FFFFFFFu);
+        sc[ES_NARROWBAND_SCORE] = cold[wv][g];
+        if (kTxHpf)
+        {
+            sc[ES_TX_HPF0] = tx_hpf0;
+            sc[ES_TX_HPF1] = tx_hpf1;
+        }
+        if (kRxHpf)
+        {
+            sc[ES_RX_HPF0] = rx_hpf0;
+            sc[ES_RX_HPF1] = rx_hpf1;
+        }
+        if (kNlp)
+        {
+            sc[ES_CNG_LEVEL] = cng_level;
+            sc[ES_CNG_RNDNUM] = cng_rndnum;
+            sc[ES_CNG_FILTER] = cng_filter;
+        }
         sc[ES_FIR_SET] = fir_set;
         sc[ES_VAD] = vad;
         sc[ES_LATEST_CORRECTION] = 0;

@@ -58,6 +58,33 @@ valu)
   cp gpurun_out/valu/valu_counters.json $R/ 2>/dev/null
   tail -30 $R/valu.log
   ;;
+echo)
+  timeout 900 python -m pytest tests/test_echo_gpu.py tests/test_shim_echo_gpu.py tests/test_full_size_gpu.py -m gpu -q -x -k "echo" > $R/pytest_echo.log 2>&1; echo "pytest rc=$?" >> $R/pytest_echo.log
+  tail -5 $R/pytest_echo.log
+  cd /tmp
+  timeout 300 python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload echo --no-cpu-baseline --no-e2e --echo-seconds 3 > $R/echo_quick.json 2> $R/echo_quick.err; tail -c 1500 $R/echo_quick.json
+  ;;
+echo_pmc)
+  cd /tmp
+  for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM"; do
+    tag=$(echo $set | cut -d' ' -f1)
+    timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/pmc_$tag -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload echo --steps 30 --no-cpu-baseline --no-e2e --echo-seconds 2 > $R/pmc_$tag.log 2>&1
+  done
+  cd $GRAFT_REPO_ROOT
+  python3 - <<'PY'
+import csv, glob, collections, json
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/r4/pmc_*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "echo_bank_kernel" in k or "echo_pair_kernel" in k:
+            acc[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {c: sum(v)/len(v) for c, v in d.items()} for k, d in acc.items()}
+json.dump(out, open("gpurun_out/r4/echo_pmc.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+  rm -rf $R/pmc_SQ_WAVES $R/pmc_SQ_ACTIVE_INST_VALU
+  ;;
 tests)
   python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
   timeout 1500 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log
