@@ -78,6 +78,7 @@ def compare_state(bank, dets, what):
     # four lanes per channel (a DPP quad; the default up to 128 taps)
     (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 4),
     (128, 0x01, [160], 4),
+    (128, 0x01, [160, 1, 31, 77], 4),       # the kernel compiled for mode 0x01: partial rounds of the common body
     (64, 0x01 | 0x02, [160, 1, 31], 4),
     (32, 0x01 | 0x20 | 0x40, [160], 4),
     # two lanes per channel, 16-bit quantities packed in pairs (echo_pair.hpp; the default for big banks)
@@ -135,6 +136,37 @@ def test_echo_flush_and_mode_change(built):
             want = d.run(tx[c, pos:pos + 160], rx[c, pos:pos + 160], False)
             assert np.array_equal(got[c], want), (fi, c)
     compare_state(bank, dets, "flush")
+
+
+def test_echo_kernel_follows_the_modes_of_the_bank(built):
+    """A four-lane bank created in mode ECHO_CAN_USE_ADAPTION runs the kernel compiled for that mode; one channel given
+    another mode sends the bank to the kernel that reads each channel's mode word, every channel back on 0x01 returns it
+    (echo_api.hip, `uniform_mode`).  Same results whichever kernel ran."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n_ch, taps = 37, 128
+    tx, rx = make_channels(n_ch, 160*50, taps, seed=31337)
+    assert engine.lib().spangpu_tune_echo_lanes_per_channel(4) == 0
+    try:
+        bank = engine.EchoBank(n_ch, taps, 0x01)
+    finally:
+        engine.lib().spangpu_tune_echo_lanes_per_channel(0)
+    dets = [orc.EchoCan(taps, 0x01) for _ in range(n_ch)]
+    for fi, pos in enumerate(range(0, tx.shape[1], 160)):
+        if fi == 10:
+            bank.adaption_mode(0x01 | 0x02 | 0x04 | 0x40, channel=3)
+            dets[3].adaption_mode(0x01 | 0x02 | 0x04 | 0x40)
+        if fi == 30:
+            bank.adaption_mode(0x01)
+            for d in dets:
+                d.adaption_mode(0x01)
+        got = bank.update_host(tx[:, pos:pos + 160], rx[:, pos:pos + 160], use_hpf_tx=False)
+        for c, d in enumerate(dets):
+            want = d.run(tx[c, pos:pos + 160], rx[c, pos:pos + 160], False)
+            assert np.array_equal(got[c], want), (fi, c)
+        if fi in (9, 10, 29, 30):
+            compare_state(bank, dets, ("modes", fi))
+    compare_state(bank, dets, "modes")
 
 
 def test_echo_line_statistics(built):

@@ -66,7 +66,9 @@ echo)
   ;;
 echo_pmc)
   cd /tmp
-  for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM"; do
+  SETS=${ECHO_PMC_SETS:-"SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY|SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH SQ_INST_CYCLES_VMEM SQ_INSTS_SMEM"}
+  IFS='|' read -ra SETLIST <<< "$SETS"
+  for set in "${SETLIST[@]}"; do
     tag=$(echo $set | cut -d' ' -f1)
     timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/pmc_$tag -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload echo --steps 30 --no-cpu-baseline --no-e2e --echo-seconds 2 > $R/pmc_$tag.log 2>&1
   done
@@ -83,7 +85,7 @@ out = {k: {c: sum(v)/len(v) for c, v in d.items()} for k, d in acc.items()}
 json.dump(out, open("gpurun_out/r4/echo_pmc.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
-  rm -rf $R/pmc_SQ_WAVES $R/pmc_SQ_ACTIVE_INST_VALU
+  find $R -mindepth 1 -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
   ;;
 tests)
   python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
