@@ -87,6 +87,32 @@ print(json.dumps(out, indent=1))
 PY
   find $R -mindepth 1 -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
   ;;
+modem)
+  timeout 1200 python -m pytest tests/test_v29_gpu.py tests/test_v17_gpu.py tests/test_v27ter_gpu.py tests/test_modem_qam_gpu.py tests/test_modem_var_gpu.py tests/test_full_size_gpu.py tests/test_feed_gpu.py -m gpu -q -x -k "not echo" > $R/pytest_modem.log 2>&1; echo "pytest rc=$?" >> $R/pytest_modem.log
+  tail -3 $R/pytest_modem.log
+  cd /tmp
+  for w in v29 v17 v27ter; do
+    timeout 300 python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --no-cpu-baseline --no-e2e > $R/${w}_quick.json 2> $R/${w}_quick.err
+    grep -o '"avg_launch_us": [0-9.]*' $R/${w}_quick.json | head -1
+    timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $R/pmc_$w -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 40 --warmup 110 --no-cpu-baseline --no-e2e > $R/pmc_$w.log 2>&1
+  done
+  cd $GRAFT_REPO_ROOT
+  python3 - <<'PY'
+import csv, glob, collections, json
+out = {}
+for w in ("v29", "v17", "v27ter"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob("gpurun_out/r4/pmc_%s/*/*counter_collection.csv" % w):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "quad_kernel" in k:
+                acc[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out[w] = {k: {c: sum(v)/len(v) for c, v in d.items()} for k, d in acc.items()}
+json.dump(out, open("gpurun_out/r4/modem_pmc.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
+PY
+  find $R -mindepth 1 -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
+  ;;
 tests)
   python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
   timeout 1500 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log
