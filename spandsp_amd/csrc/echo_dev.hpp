@@ -187,18 +187,24 @@ __device__ __forceinline__ void echo_rotate_window(int (&w)[TPL])
 // set event on it.
 // `lim` (wave-uniform, 1 .. U) ends the round early: the samples a pass has left after its last whole round stay on the
 // common body (a scalar compare and a branch per phase).
-template <int PH, int U, int TPL, class F>
-__device__ __forceinline__ int echo_fast_round(F &fast, int (&w)[TPL], int idx, int lim)
+// `settle` is called with the phase the round ends in (the words the samples step take turns between two sets of registers:
+// the kernel's `hot`).
+template <int PH, int U, int TPL, class F, class S>
+__device__ __forceinline__ int echo_fast_round(F &fast, S &settle, int (&w)[TPL], int idx, int lim)
 {
     if constexpr (PH == U)
     {
+        settle(std::integral_constant<int, PH>{});
         return U;
     }
     else
     {
         if (PH == lim  ||  !fast(idx + PH, std::integral_constant<int, PH>{}))
+        {
+            settle(std::integral_constant<int, PH>{});
             return PH;
-        return echo_fast_round<PH + 1, U, TPL>(fast, w, idx, lim);
+        }
+        return echo_fast_round<PH + 1, U, TPL>(fast, settle, w, idx, lim);
     }
 }
 
@@ -298,14 +304,38 @@ void echo_bank_kernel(const EchoLaunch L)
     int16_t *gh = L.hist + (size_t) ch*T + j*TPL;
 
     // ---- scalars (replicated in the lanes of the group) -----------------------------------
-    int tx_power0 = sc[ES_TX_POWER0];
-    int tx_power1 = sc[ES_TX_POWER1];
-    int tx_power2 = sc[ES_TX_POWER2];
-    int tx_power3 = sc[ES_TX_POWER3];
-    int rx_power0 = sc[ES_RX_POWER0];
-    int rx_power1 = sc[ES_RX_POWER1];
-    int clean_rx_power = sc[ES_CLEAN_RX_POWER];
-    int nonupdate_dwell = sc[ES_NONUPDATE_DWELL];
+    // The words every common sample steps live in TWO sets that take turns: phase PH of a round reads set PH & 1 and writes
+    // the other one.  A phase must hold the old and the new values side by side until it knows that no channel of the wave
+    // meets a set event on its sample (the complete routine starts from the old ones); with one set the new values are then
+    // copied over the old, eight moves a sample.  Everything outside the common body uses set 0, which a round that ends
+    // after an odd number of samples copies its result into (echo_fast_round: `settle`).
+    struct HotWords
+    {
+        int tx_power0, tx_power1, tx_power2, tx_power3, rx_power0, rx_power1, clean_rx_power, nonupdate_dwell;
+        int32_t tx_hpf0, tx_hpf1, rx_hpf0, rx_hpf1;
+    };
+    HotWords hot[2];
+    int &tx_power0 = hot[0].tx_power0;
+    int &tx_power1 = hot[0].tx_power1;
+    int &tx_power2 = hot[0].tx_power2;
+    int &tx_power3 = hot[0].tx_power3;
+    int &rx_power0 = hot[0].rx_power0;
+    int &rx_power1 = hot[0].rx_power1;
+    int &clean_rx_power = hot[0].clean_rx_power;
+    int &nonupdate_dwell = hot[0].nonupdate_dwell;
+    int32_t &tx_hpf0 = hot[0].tx_hpf0;
+    int32_t &tx_hpf1 = hot[0].tx_hpf1;
+    int32_t &rx_hpf0 = hot[0].rx_hpf0;
+    int32_t &rx_hpf1 = hot[0].rx_hpf1;
+    tx_power0 = sc[ES_TX_POWER0];
+    tx_power1 = sc[ES_TX_POWER1];
+    tx_power2 = sc[ES_TX_POWER2];
+    tx_power3 = sc[ES_TX_POWER3];
+    rx_power0 = sc[ES_RX_POWER0];
+    rx_power1 = sc[ES_RX_POWER1];
+    clean_rx_power = sc[ES_CLEAN_RX_POWER];
+    nonupdate_dwell = sc[ES_NONUPDATE_DWELL];
+    hot[1] = hot[0];
     // curr_pos steps T-1, T-2 .. 0, T-1 .. (echo.c:655-658): a sample's value follows from the first one's and the
     // number of samples since, and only the complete routine needs it
     const int curr_pos0 = sc[ES_CURR_POS];
@@ -325,10 +355,10 @@ void echo_bank_kernel(const EchoLaunch L)
     constexpr bool kTxHpf = (MODE < 0)  ||  (MODE & kModeTxHpf);
     constexpr bool kRxHpf = (MODE < 0)  ||  (MODE & kModeRxHpf);
     constexpr bool kNlp = (MODE < 0)  ||  (MODE & kModeNlp);
-    int32_t tx_hpf0 = kTxHpf  ?  sc[ES_TX_HPF0]  :  0;
-    int32_t tx_hpf1 = kTxHpf  ?  sc[ES_TX_HPF1]  :  0;
-    int32_t rx_hpf0 = kRxHpf  ?  sc[ES_RX_HPF0]  :  0;
-    int32_t rx_hpf1 = kRxHpf  ?  sc[ES_RX_HPF1]  :  0;
+    tx_hpf0 = kTxHpf  ?  sc[ES_TX_HPF0]  :  0;
+    tx_hpf1 = kTxHpf  ?  sc[ES_TX_HPF1]  :  0;
+    rx_hpf0 = kRxHpf  ?  sc[ES_RX_HPF0]  :  0;
+    rx_hpf1 = kRxHpf  ?  sc[ES_RX_HPF1]  :  0;
     int cng_level = kNlp  ?  sc[ES_CNG_LEVEL]  :  0;
     int cng_rndnum = kNlp  ?  sc[ES_CNG_RNDNUM]  :  0;
     int cng_filter = kNlp  ?  sc[ES_CNG_FILTER]  :  0;
@@ -364,15 +394,15 @@ void echo_bank_kernel(const EchoLaunch L)
         }
     };
     // echo.c:613-651: the non-linear processor and comfort noise, then the position update and the output slot
-    auto finish_sample = [&](int idx, int tx, int clean_rx)
+    auto finish_sample = [&](int idx, int tx, int clean_rx, const HotWords &now)
     {
         if (mode & kModeNlp)
         {
-            if (rx_power1 < 30000000)
+            if (now.rx_power1 < 30000000)
             {
                 if (!cng)
                 {
-                    cng_level = clean_rx_power;
+                    cng_level = now.clean_rx_power;
                     cng = 1;
                 }
                 if (mode & kModeCng)
@@ -435,10 +465,12 @@ void echo_bank_kernel(const EchoLaunch L)
             ahead = io[wv][g][idx + 1];                         // the next sample's input, a whole sample early
             int tx = (int) (short) (word & 0xFFFF);
             int rx = (int) (short) (word >> 16);
-            int32_t n_txh0 = tx_hpf0;
-            int32_t n_txh1 = tx_hpf1;
-            int32_t n_rxh0 = rx_hpf0;
-            int32_t n_rxh1 = rx_hpf1;
+            const HotWords &old = hot[PH & 1];
+            HotWords &nw = hot[(PH & 1) ^ 1];
+            int32_t n_txh0 = old.tx_hpf0;
+            int32_t n_txh1 = old.tx_hpf1;
+            int32_t n_rxh0 = old.rx_hpf0;
+            int32_t n_rxh1 = old.rx_hpf1;
             if (L.use_hpf_tx  &&  (mode & kModeTxHpf))
                 tx = echo_hpf(n_txh0, n_txh1, tx);              // echo.c:663-669
             if (mode & kModeRxHpf)
@@ -473,15 +505,15 @@ void echo_bank_kernel(const EchoLaunch L)
             y = group_sum<G>(y);
             const int echo_value = (int) (short) (y >> 15);
             const int clean_rx = rx - echo_value;                // echo.c:452
-            const int n_dwell = nonupdate_dwell - ((nonupdate_dwell > 0)  ?  1  :  0);
+            const int n_dwell = old.nonupdate_dwell - ((old.nonupdate_dwell > 0)  ?  1  :  0);
             // echo.c:463-469
-            const int n_tp3 = tx_power3 + ((abs(tx) - tx_power3) >> 5);
-            const int n_tp2 = tx_power2 + ((tx*tx - tx_power2) >> 8);
-            const int n_tp1 = tx_power1 + ((tx*tx - tx_power1) >> 5);
-            const int n_tp0 = tx_power0 + ((tx*tx - tx_power0) >> 3);
-            const int n_rp1 = rx_power1 + ((rx*rx - rx_power1) >> 6);
-            const int n_rp0 = rx_power0 + ((rx*rx - rx_power0) >> 3);
-            const int n_crp = clean_rx_power + (((int) ((uint32_t) clean_rx*(uint32_t) clean_rx) - clean_rx_power) >> 6);
+            const int n_tp3 = old.tx_power3 + ((abs(tx) - old.tx_power3) >> 5);
+            const int n_tp2 = old.tx_power2 + ((tx*tx - old.tx_power2) >> 8);
+            const int n_tp1 = old.tx_power1 + ((tx*tx - old.tx_power1) >> 5);
+            const int n_tp0 = old.tx_power0 + ((tx*tx - old.tx_power0) >> 3);
+            const int n_rp1 = old.rx_power1 + ((rx*rx - old.rx_power1) >> 6);
+            const int n_rp0 = old.rx_power0 + ((rx*rx - old.rx_power0) >> 3);
+            const int n_crp = old.clean_rx_power + (((int) ((uint32_t) clean_rx*(uint32_t) clean_rx) - old.clean_rx_power) >> 6);
             // the set events (plain bit logic: with && and || hipcc builds these from exec-masked branches).  Testing the
             // ones that do not need the FIR's result before it runs was tried: the values kept alive across the FIR cost
             // more in spills than the abandoned work saves.
@@ -489,26 +521,31 @@ void echo_bank_kernel(const EchoLaunch L)
             const bool single = n_tp1 > n_rp0;
             const bool adapting = loud & single & (n_dwell == 0);
             const bool doubletalk = loud & !single;
-            const bool event = (adapting & (((uint32_t) ncf >= 159u*4u) | (tap_rotate_counter <= 1)))
-                               | (doubletalk & (ncf >= 0))
-                               | ((n_rp1 > 2048*2048) & (n_crp > 4*n_rp1));
-            if (__builtin_amdgcn_ballot_w64(event) != 0)
+            // does any channel of the wave meet one?  As arithmetic on the compares' lane masks (a vote on the combined
+            // condition makes the compiler turn the mask into a register and compare that again)
+            typedef unsigned long long mask_t;
+            const mask_t m_loud = __builtin_amdgcn_ballot_w64(loud);
+            const mask_t m_single = __builtin_amdgcn_ballot_w64(single);
+            const mask_t m_adapting = m_loud & m_single & __builtin_amdgcn_ballot_w64(n_dwell == 0);
+            const mask_t m_event = (m_adapting & (__builtin_amdgcn_ballot_w64((uint32_t) ncf >= 159u*4u) | __builtin_amdgcn_ballot_w64(tap_rotate_counter <= 1)))
+                                   | (m_loud & ~m_single & __builtin_amdgcn_ballot_w64(ncf >= 0))
+                                   | (__builtin_amdgcn_ballot_w64(n_rp1 > 2048*2048) & __builtin_amdgcn_ballot_w64(n_crp > 4*n_rp1));
+            if (__builtin_expect(m_event != 0, 0))
             {
                 w[NEWP] = w_old;
                 return false;
             }
-            tx_hpf0 = n_txh0;
-            tx_hpf1 = n_txh1;
-            rx_hpf0 = n_rxh0;
-            rx_hpf1 = n_rxh1;
-            nonupdate_dwell = n_dwell;
-            tx_power3 = n_tp3;
-            tx_power2 = n_tp2;
-            tx_power1 = n_tp1;
-            tx_power0 = n_tp0;
-            rx_power1 = n_rp1;
-            rx_power0 = n_rp0;
-            clean_rx_power = n_crp;
+            nw.tx_hpf0 = n_txh0;
+            nw.tx_hpf1 = n_txh1;
+            nw.rx_hpf0 = n_rxh0;
+            nw.rx_hpf1 = n_rxh1;
+            nw.tx_power3 = n_tp3;
+            nw.tx_power2 = n_tp2;
+            nw.tx_power1 = n_tp1;
+            nw.tx_power0 = n_tp0;
+            nw.rx_power1 = n_rp1;
+            nw.rx_power0 = n_rp0;
+            nw.clean_rx_power = n_crp;
             if (adapting)
             {
                 ncf = (ncf + 4) & 0x7FFFFFFF;               // narrowband_count++, dtd_onset = 0
@@ -518,7 +555,7 @@ void echo_bank_kernel(const EchoLaunch L)
                     // echo.c:530-553 + lms_adapt(), echo.c:232-249
                     // the shift is max(top_bit(x) - 8, 0) with top_bit(0) = -1: 23 - ffbh(x), an unsigned subtraction that
                     // clamps at zero (ffbh(0) is all ones)
-                    const int factor = clean_rx >> lms_shift((tx > 4*tx_power3)  ?  tx  :  tx_power3);
+                    const int factor = clean_rx >> lms_shift((tx > 4*n_tp3)  ?  tx  :  n_tp3);
 #pragma unroll
                     for (int k = 0;  k < TPL;  k++)
                     {
@@ -527,9 +564,16 @@ void echo_bank_kernel(const EchoLaunch L)
                     }
                 }
             }
-            nonupdate_dwell = doubletalk  ?  600  :  nonupdate_dwell;      // NONUPDATE_DWELL_TIME
-            finish_sample(idx, tx, clean_rx);
+            nw.nonupdate_dwell = doubletalk  ?  600  :  n_dwell;             // NONUPDATE_DWELL_TIME
+            finish_sample(idx, tx, clean_rx, nw);
             return true;
+        };
+
+        // a round that ends in an odd phase has its result in the second set
+        auto settle = [&](auto ph_tag)
+        {
+            if constexpr ((decltype(ph_tag)::value & 1) != 0)
+                hot[0] = hot[1];
         };
 
         // ---- any sample: the whole of echo_can_update().  Takes the window registers in the order of phase TPL - 1 (logical
@@ -758,7 +802,7 @@ void echo_bank_kernel(const EchoLaunch L)
                 store_set(2, t16);
                 store_set(3, t16);
             }
-            finish_sample(idx, tx, clean_rx);
+            finish_sample(idx, tx, clean_rx, hot[0]);
             cold[wv][g] = narrowband_score;                     // (the lanes of a channel agree)
             ncf = echo_pack_ncf(narrowband_count, dtd_onset, narrowband_score);
         };
@@ -795,7 +839,7 @@ void echo_bank_kernel(const EchoLaunch L)
             {
                 const int lim = __builtin_amdgcn_readfirstlane(min(U, n - idx));
                 ahead = io[wv][g][idx];
-                const int done = __builtin_amdgcn_readfirstlane(echo_fast_round<0, U, TPL>(fast, w, idx, lim));
+                const int done = __builtin_amdgcn_readfirstlane(echo_fast_round<0, U, TPL>(fast, settle, w, idx, lim));
                 idx += done;
                 if (done == lim)
                 {

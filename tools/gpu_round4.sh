@@ -113,6 +113,14 @@ print(json.dumps(out, indent=1))
 PY
   find $R -mindepth 1 -maxdepth 1 -type d -name 'pmc_*' -exec rm -rf {} +
   ;;
+echo_occ)
+  # the echo kernel at 1, 2, 3, 4, 6, 8, 9, 12 waves per SIMD (four lanes per channel, three waves a SIMD resident)
+  cd /tmp
+  for n in 16384 32768 49152 65536 98304 131072 147456 196608; do
+    timeout 200 python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload echo --channels $n --echo-lanes 4 --no-cpu-baseline --no-e2e --echo-seconds 2 > $R/echo_occ_$n.json 2> $R/echo_occ_$n.err
+    echo "$n $(grep -o '"avg_launch_us": [0-9.]*' $R/echo_occ_$n.json | head -1)" | tee -a $R/echo_occ.log
+  done
+  ;;
 tests)
   python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
   timeout 1500 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log
