@@ -187,24 +187,18 @@ __device__ __forceinline__ void echo_rotate_window(int (&w)[TPL])
 // set event on it.
 // `lim` (wave-uniform, 1 .. U) ends the round early: the samples a pass has left after its last whole round stay on the
 // common body (a scalar compare and a branch per phase).
-// `settle` is called with the phase the round ends in (the words the samples step take turns between two sets of registers:
-// the kernel's `hot`).
-template <int PH, int U, int TPL, class F, class S>
-__device__ __forceinline__ int echo_fast_round(F &fast, S &settle, int (&w)[TPL], int idx, int lim)
+template <int PH, int U, int TPL, class F>
+__device__ __forceinline__ int echo_fast_round(F &fast, int (&w)[TPL], int idx, int lim)
 {
     if constexpr (PH == U)
     {
-        settle(std::integral_constant<int, PH>{});
         return U;
     }
     else
     {
         if (PH == lim  ||  !fast(idx + PH, std::integral_constant<int, PH>{}))
-        {
-            settle(std::integral_constant<int, PH>{});
             return PH;
-        }
-        return echo_fast_round<PH + 1, U, TPL>(fast, settle, w, idx, lim);
+        return echo_fast_round<PH + 1, U, TPL>(fast, w, idx, lim);
     }
 }
 
@@ -240,7 +234,7 @@ __device__ __forceinline__ int group_shift_in(int tx, int v, int j)
         v = dpp_mov<0x111>(tx, v);
         return (j == 0)  ?  tx  :  v;                   // the second channel of the row starts at lane 8
     }
-    v = dpp_mov<0x90>(tx, v);                           // quad_perm [0,0,1,2]
+    v = __builtin_amdgcn_mov_dpp(v, 0x90, 0xF, 0xF, true);     // quad_perm [0,0,1,2]: every lane has a source, no old value to set up
     return (j == 0)  ?  tx  :  v;
 }
 
@@ -304,38 +298,23 @@ void echo_bank_kernel(const EchoLaunch L)
     int16_t *gh = L.hist + (size_t) ch*T + j*TPL;
 
     // ---- scalars (replicated in the lanes of the group) -----------------------------------
-    // The words every common sample steps live in TWO sets that take turns: phase PH of a round reads set PH & 1 and writes
-    // the other one.  A phase must hold the old and the new values side by side until it knows that no channel of the wave
-    // meets a set event on its sample (the complete routine starts from the old ones); with one set the new values are then
-    // copied over the old, eight moves a sample.  Everything outside the common body uses set 0, which a round that ends
-    // after an odd number of samples copies its result into (echo_fast_round: `settle`).
-    struct HotWords
-    {
-        int tx_power0, tx_power1, tx_power2, tx_power3, rx_power0, rx_power1, clean_rx_power, nonupdate_dwell;
-        int32_t tx_hpf0, tx_hpf1, rx_hpf0, rx_hpf1;
-    };
-    HotWords hot[2];
-    int &tx_power0 = hot[0].tx_power0;
-    int &tx_power1 = hot[0].tx_power1;
-    int &tx_power2 = hot[0].tx_power2;
-    int &tx_power3 = hot[0].tx_power3;
-    int &rx_power0 = hot[0].rx_power0;
-    int &rx_power1 = hot[0].rx_power1;
-    int &clean_rx_power = hot[0].clean_rx_power;
-    int &nonupdate_dwell = hot[0].nonupdate_dwell;
-    int32_t &tx_hpf0 = hot[0].tx_hpf0;
-    int32_t &tx_hpf1 = hot[0].tx_hpf1;
-    int32_t &rx_hpf0 = hot[0].rx_hpf0;
-    int32_t &rx_hpf1 = hot[0].rx_hpf1;
-    tx_power0 = sc[ES_TX_POWER0];
-    tx_power1 = sc[ES_TX_POWER1];
-    tx_power2 = sc[ES_TX_POWER2];
-    tx_power3 = sc[ES_TX_POWER3];
-    rx_power0 = sc[ES_RX_POWER0];
-    rx_power1 = sc[ES_RX_POWER1];
-    clean_rx_power = sc[ES_CLEAN_RX_POWER];
-    nonupdate_dwell = sc[ES_NONUPDATE_DWELL];
-    hot[1] = hot[0];
+    // The seven power meters (echo.c:463-469, each p += (x - p) >> s) are DEALT over the lanes of a quad instead of being
+    // repeated in every lane: lane q of a quad keeps tx_power[q] in meterA (x = tx*tx, or |tx| for [3]; s = 3, 5, 8, 5) and
+    // rx_power[0], rx_power[1], clean_rx_power in meterB (x = rx*rx, rx*rx, clean*clean; s = 3, 6, 6; lane 3 idles): two updates
+    // with a per-lane shift do the work of seven, and the decisions take the values they need from their lanes by DPP.
+    const int q4 = j & 3;
+    const int shiftA = (q4 == 0)  ?  3  :  (q4 == 2)  ?  8  :  5;
+    const int shiftB = (q4 == 0)  ?  3  :  6;
+    int meterA = sc[ES_TX_POWER0 + q4];
+    int meterB = (q4 == 0)  ?  sc[ES_RX_POWER0]  :  (q4 == 1)  ?  sc[ES_RX_POWER1]  :  (q4 == 2)  ?  sc[ES_CLEAN_RX_POWER]  :  0;
+    // quad_perm [k,k,k,k]: every lane has a source, so there is no old value to keep (and no move to set one up)
+    auto meter_of = [&](auto lane_tag, int meter) { return __builtin_amdgcn_mov_dpp(meter, decltype(lane_tag)::value*0x55, 0xF, 0xF, true); };
+    const unsigned long long is_lane3 = __builtin_amdgcn_ballot_w64(q4 == 3);      // (every lane of the wave is active here)
+    using lane0 = std::integral_constant<int, 0>;
+    using lane1 = std::integral_constant<int, 1>;
+    using lane2 = std::integral_constant<int, 2>;
+    using lane3 = std::integral_constant<int, 3>;
+    int nonupdate_dwell = sc[ES_NONUPDATE_DWELL];
     // curr_pos steps T-1, T-2 .. 0, T-1 .. (echo.c:655-658): a sample's value follows from the first one's and the
     // number of samples since, and only the complete routine needs it
     const int curr_pos0 = sc[ES_CURR_POS];
@@ -355,10 +334,10 @@ void echo_bank_kernel(const EchoLaunch L)
     constexpr bool kTxHpf = (MODE < 0)  ||  (MODE & kModeTxHpf);
     constexpr bool kRxHpf = (MODE < 0)  ||  (MODE & kModeRxHpf);
     constexpr bool kNlp = (MODE < 0)  ||  (MODE & kModeNlp);
-    tx_hpf0 = kTxHpf  ?  sc[ES_TX_HPF0]  :  0;
-    tx_hpf1 = kTxHpf  ?  sc[ES_TX_HPF1]  :  0;
-    rx_hpf0 = kRxHpf  ?  sc[ES_RX_HPF0]  :  0;
-    rx_hpf1 = kRxHpf  ?  sc[ES_RX_HPF1]  :  0;
+    int32_t tx_hpf0 = kTxHpf  ?  sc[ES_TX_HPF0]  :  0;
+    int32_t tx_hpf1 = kTxHpf  ?  sc[ES_TX_HPF1]  :  0;
+    int32_t rx_hpf0 = kRxHpf  ?  sc[ES_RX_HPF0]  :  0;
+    int32_t rx_hpf1 = kRxHpf  ?  sc[ES_RX_HPF1]  :  0;
     int cng_level = kNlp  ?  sc[ES_CNG_LEVEL]  :  0;
     int cng_rndnum = kNlp  ?  sc[ES_CNG_RNDNUM]  :  0;
     int cng_filter = kNlp  ?  sc[ES_CNG_FILTER]  :  0;
@@ -394,15 +373,15 @@ void echo_bank_kernel(const EchoLaunch L)
         }
     };
     // echo.c:613-651: the non-linear processor and comfort noise, then the position update and the output slot
-    auto finish_sample = [&](int idx, int tx, int clean_rx, const HotWords &now)
+    auto finish_sample = [&](int idx, int tx, int clean_rx, int rx_power1, int clean_rx_power)
     {
         if (mode & kModeNlp)
         {
-            if (now.rx_power1 < 30000000)
+            if (rx_power1 < 30000000)
             {
                 if (!cng)
                 {
-                    cng_level = now.clean_rx_power;
+                    cng_level = clean_rx_power;
                     cng = 1;
                 }
                 if (mode & kModeCng)
@@ -421,10 +400,11 @@ void echo_bank_kernel(const EchoLaunch L)
                 cng = 0;
             }
         }
-        else
+        else if (MODE < 0)
         {
             cng = 0;
         }
+        // (a kernel compiled for a mode without the NLP clears cng once, at write-back)
         // (echo.c:655-658, the position update: see curr_pos0)
         if (j == 0)
             io[wv][g][idx] = ((int) (short) clean_rx & 0xFFFF) | (tx << 16);    // reuse the slot for the outputs
@@ -465,12 +445,10 @@ void echo_bank_kernel(const EchoLaunch L)
             ahead = io[wv][g][idx + 1];                         // the next sample's input, a whole sample early
             int tx = (int) (short) (word & 0xFFFF);
             int rx = (int) (short) (word >> 16);
-            const HotWords &old = hot[PH & 1];
-            HotWords &nw = hot[(PH & 1) ^ 1];
-            int32_t n_txh0 = old.tx_hpf0;
-            int32_t n_txh1 = old.tx_hpf1;
-            int32_t n_rxh0 = old.rx_hpf0;
-            int32_t n_rxh1 = old.rx_hpf1;
+            int32_t n_txh0 = tx_hpf0;
+            int32_t n_txh1 = tx_hpf1;
+            int32_t n_rxh0 = rx_hpf0;
+            int32_t n_rxh1 = rx_hpf1;
             if (L.use_hpf_tx  &&  (mode & kModeTxHpf))
                 tx = echo_hpf(n_txh0, n_txh1, tx);              // echo.c:663-669
             if (mode & kModeRxHpf)
@@ -505,15 +483,19 @@ void echo_bank_kernel(const EchoLaunch L)
             y = group_sum<G>(y);
             const int echo_value = (int) (short) (y >> 15);
             const int clean_rx = rx - echo_value;                // echo.c:452
-            const int n_dwell = old.nonupdate_dwell - ((old.nonupdate_dwell > 0)  ?  1  :  0);
+            const int n_dwell = nonupdate_dwell - ((nonupdate_dwell > 0)  ?  1  :  0);
             // echo.c:463-469
-            const int n_tp3 = old.tx_power3 + ((abs(tx) - old.tx_power3) >> 5);
-            const int n_tp2 = old.tx_power2 + ((tx*tx - old.tx_power2) >> 8);
-            const int n_tp1 = old.tx_power1 + ((tx*tx - old.tx_power1) >> 5);
-            const int n_tp0 = old.tx_power0 + ((tx*tx - old.tx_power0) >> 3);
-            const int n_rp1 = old.rx_power1 + ((rx*rx - old.rx_power1) >> 6);
-            const int n_rp0 = old.rx_power0 + ((rx*rx - old.rx_power0) >> 3);
-            const int n_crp = old.clean_rx_power + (((int) ((uint32_t) clean_rx*(uint32_t) clean_rx) - old.clean_rx_power) >> 6);
+            // (clean*clean is the low 32 bits of the product in the reference, an unsigned multiply: the 24-bit multiplier's, too)
+            int xA;                                                 // (q4 == 3)  ?  abs(tx)  :  tx*tx, as a select: the compiler branches
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(xA) : "v"(tx*tx), "v"(abs(tx)), "s"(is_lane3));
+            const int n_meterA = meterA + ((xA - meterA) >> shiftA);
+            const int yB = (q4 == 2)  ?  clean_rx  :  rx;
+            const int n_meterB = meterB + ((mad24(yB, yB, 0) - meterB) >> shiftB);
+            const int n_tp0 = meter_of(lane0{}, n_meterA);
+            const int n_tp1 = meter_of(lane1{}, n_meterA);
+            const int n_rp0 = meter_of(lane0{}, n_meterB);
+            const int n_rp1 = meter_of(lane1{}, n_meterB);
+            const int n_crp = meter_of(lane2{}, n_meterB);
             // the set events (plain bit logic: with && and || hipcc builds these from exec-masked branches).  Testing the
             // ones that do not need the FIR's result before it runs was tried: the values kept alive across the FIR cost
             // more in spills than the abandoned work saves.
@@ -535,17 +517,13 @@ void echo_bank_kernel(const EchoLaunch L)
                 w[NEWP] = w_old;
                 return false;
             }
-            nw.tx_hpf0 = n_txh0;
-            nw.tx_hpf1 = n_txh1;
-            nw.rx_hpf0 = n_rxh0;
-            nw.rx_hpf1 = n_rxh1;
-            nw.tx_power3 = n_tp3;
-            nw.tx_power2 = n_tp2;
-            nw.tx_power1 = n_tp1;
-            nw.tx_power0 = n_tp0;
-            nw.rx_power1 = n_rp1;
-            nw.rx_power0 = n_rp0;
-            nw.clean_rx_power = n_crp;
+            tx_hpf0 = n_txh0;
+            tx_hpf1 = n_txh1;
+            rx_hpf0 = n_rxh0;
+            rx_hpf1 = n_rxh1;
+            nonupdate_dwell = n_dwell;
+            meterA = n_meterA;
+            meterB = n_meterB;
             if (adapting)
             {
                 ncf = (ncf + 4) & 0x7FFFFFFF;               // narrowband_count++, dtd_onset = 0
@@ -555,6 +533,7 @@ void echo_bank_kernel(const EchoLaunch L)
                     // echo.c:530-553 + lms_adapt(), echo.c:232-249
                     // the shift is max(top_bit(x) - 8, 0) with top_bit(0) = -1: 23 - ffbh(x), an unsigned subtraction that
                     // clamps at zero (ffbh(0) is all ones)
+                    const int n_tp3 = meter_of(lane3{}, n_meterA);
                     const int factor = clean_rx >> lms_shift((tx > 4*n_tp3)  ?  tx  :  n_tp3);
 #pragma unroll
                     for (int k = 0;  k < TPL;  k++)
@@ -564,22 +543,22 @@ void echo_bank_kernel(const EchoLaunch L)
                     }
                 }
             }
-            nw.nonupdate_dwell = doubletalk  ?  600  :  n_dwell;             // NONUPDATE_DWELL_TIME
-            finish_sample(idx, tx, clean_rx, nw);
+            nonupdate_dwell = doubletalk  ?  600  :  nonupdate_dwell;      // NONUPDATE_DWELL_TIME
+            finish_sample(idx, tx, clean_rx, n_rp1, n_crp);
             return true;
-        };
-
-        // a round that ends in an odd phase has its result in the second set
-        auto settle = [&](auto ph_tag)
-        {
-            if constexpr ((decltype(ph_tag)::value & 1) != 0)
-                hot[0] = hot[1];
         };
 
         // ---- any sample: the whole of echo_can_update().  Takes the window registers in the order of phase TPL - 1 (logical
         // slot k in w[(k + 1) mod TPL]) and leaves them, one sample later, in phase 0 order. ----------------------------
         auto slow = [&](int idx)
         {
+            int tx_power0 = meter_of(lane0{}, meterA);
+            int tx_power1 = meter_of(lane1{}, meterA);
+            int tx_power2 = meter_of(lane2{}, meterA);
+            int tx_power3 = meter_of(lane3{}, meterA);
+            int rx_power0 = meter_of(lane0{}, meterB);
+            int rx_power1 = meter_of(lane1{}, meterB);
+            int clean_rx_power = meter_of(lane2{}, meterB);
             int narrowband_count = (int) (((uint32_t) ncf >> 2) & 0x1FFFFFFFu);
             int dtd_onset = (ncf < 0)  ?  1  :  0;
             int narrowband_score = cold[wv][g];
@@ -802,7 +781,9 @@ void echo_bank_kernel(const EchoLaunch L)
                 store_set(2, t16);
                 store_set(3, t16);
             }
-            finish_sample(idx, tx, clean_rx, hot[0]);
+            finish_sample(idx, tx, clean_rx, rx_power1, clean_rx_power);
+            meterA = (q4 == 0)  ?  tx_power0  :  (q4 == 1)  ?  tx_power1  :  (q4 == 2)  ?  tx_power2  :  tx_power3;
+            meterB = (q4 == 0)  ?  rx_power0  :  (q4 == 1)  ?  rx_power1  :  (q4 == 2)  ?  clean_rx_power  :  0;
             cold[wv][g] = narrowband_score;                     // (the lanes of a channel agree)
             ncf = echo_pack_ncf(narrowband_count, dtd_onset, narrowband_score);
         };
@@ -839,7 +820,7 @@ void echo_bank_kernel(const EchoLaunch L)
             {
                 const int lim = __builtin_amdgcn_readfirstlane(min(U, n - idx));
                 ahead = io[wv][g][idx];
-                const int done = __builtin_amdgcn_readfirstlane(echo_fast_round<0, U, TPL>(fast, settle, w, idx, lim));
+                const int done = __builtin_amdgcn_readfirstlane(echo_fast_round<0, U, TPL>(fast, w, idx, lim));
                 idx += done;
                 if (done == lim)
                 {
@@ -890,6 +871,13 @@ void echo_bank_kernel(const EchoLaunch L)
     }
     if (L.stats  &&  leader)
         L.stats[ch].samples += (uint32_t) L.samples;
+    const int tx_power0 = meter_of(lane0{}, meterA);
+    const int tx_power1 = meter_of(lane1{}, meterA);
+    const int tx_power2 = meter_of(lane2{}, meterA);
+    const int tx_power3 = meter_of(lane3{}, meterA);
+    const int rx_power0 = meter_of(lane0{}, meterB);
+    const int rx_power1 = meter_of(lane1{}, meterB);
+    const int clean_rx_power = meter_of(lane2{}, meterB);
     if (leader)
     {
         if (L.samples > 0)
@@ -905,7 +893,7 @@ void echo_bank_kernel(const EchoLaunch L)
         const int curr_pos = (curr_pos0 - L.samples) & (T - 1);
         sc[ES_CURR_POS] = curr_pos;
         sc[ES_FIR_CURR_POS] = curr_pos;
-        sc[ES_CNG] = cng;
+        sc[ES_CNG] = (MODE >= 0  &&  !(MODE & kModeNlp)  &&  L.samples > 0)  ?  0  :  cng;
         sc[ES_DTD_ONSET] = (ncf < 0)  ?  1  :  0;
         sc[ES_TAP_SET] = tap_set;
         sc[ES_TAP_ROTATE_COUNTER] = tap_rotate_counter;
