@@ -406,8 +406,8 @@ void echo_bank_kernel(const EchoLaunch L)
         }
         // (a kernel compiled for a mode without the NLP clears cng once, at write-back)
         // (echo.c:655-658, the position update: see curr_pos0)
-        if (j == 0)
-            io[wv][g][idx] = ((int) (short) clean_rx & 0xFFFF) | (tx << 16);    // reuse the slot for the outputs
+        // (every lane of the channel stores the same word: no narrowing of exec for a leader)
+        io[wv][g][idx] = ((int) (short) clean_rx & 0xFFFF) | (tx << 16);        // reuse the slot for the outputs
     };
 
     for (int base = 0;  base < L.samples;  base += kMaxFrame)
@@ -524,23 +524,21 @@ void echo_bank_kernel(const EchoLaunch L)
             nonupdate_dwell = n_dwell;
             meterA = n_meterA;
             meterB = n_meterB;
-            if (adapting)
+            // (one conditional region, the update's: the two counters step by selects)
+            ncf = adapting  ?  ((ncf + 4) & 0x7FFFFFFF)  :  ncf;            // narrowband_count++, dtd_onset = 0
+            tap_rotate_counter -= adapting  ?  1  :  0;
+            if (adapting  &  ((mode & kModeAdaption) != 0)  &  ((ncf & 1) == 0))     // ... and narrowband_score == 0
             {
-                ncf = (ncf + 4) & 0x7FFFFFFF;               // narrowband_count++, dtd_onset = 0
-                tap_rotate_counter--;
-                if ((mode & kModeAdaption)  &&  (ncf & 1) == 0)     // narrowband_score == 0
-                {
-                    // echo.c:530-553 + lms_adapt(), echo.c:232-249
-                    // the shift is max(top_bit(x) - 8, 0) with top_bit(0) = -1: 23 - ffbh(x), an unsigned subtraction that
-                    // clamps at zero (ffbh(0) is all ones)
-                    const int n_tp3 = meter_of(lane3{}, n_meterA);
-                    const int factor = clean_rx >> lms_shift((tx > 4*n_tp3)  ?  tx  :  n_tp3);
+                // echo.c:530-553 + lms_adapt(), echo.c:232-249
+                // the shift is max(top_bit(x) - 8, 0) with top_bit(0) = -1: 23 - ffbh(x), an unsigned subtraction that
+                // clamps at zero (ffbh(0) is all ones)
+                const int n_tp3 = meter_of(lane3{}, n_meterA);
+                const int factor = clean_rx >> lms_shift((tx > 4*n_tp3)  ?  tx  :  n_tp3);
 #pragma unroll
-                    for (int k = 0;  k < TPL;  k++)
-                    {
-                        t32[k] = mad24(w[(k - PH - 1 + 8*TPL)%TPL], factor, t32[k]);
-                        t16[k] = __builtin_amdgcn_sbfe(t32[k], 15, 16);
-                    }
+                for (int k = 0;  k < TPL;  k++)
+                {
+                    t32[k] = mad24(w[(k - PH - 1 + 8*TPL)%TPL], factor, t32[k]);
+                    t16[k] = __builtin_amdgcn_sbfe(t32[k], 15, 16);
                 }
             }
             nonupdate_dwell = doubletalk  ?  600  :  nonupdate_dwell;      // NONUPDATE_DWELL_TIME
