@@ -301,9 +301,14 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
         case 8:  hipLaunchKernelGGL((echo_bank_kernel<8, 4>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
         case 16: hipLaunchKernelGGL((echo_bank_kernel<16, 4>), dim3(blocks), dim3(256), 0, e->stream, L); break;
         default:
-            // the mode of echo_tests.c's and SURVEY 8(d)-5's lines, and of a bank that has just been created with it
+            // the kernels compiled for one mode: the three echo_tests.c runs its lines in (adaption alone is SURVEY 8(d)-5's,
+            // and what a bank has until somebody changes it); any other mode, or lines of different modes: the general one
             if (e->uniform_mode == kModeAdaption)
                 hipLaunchKernelGGL((echo_bank_kernel<32, 4, kModeAdaption>), dim3(blocks), dim3(256), 0, e->stream, L);
+            else if (e->uniform_mode == (kModeAdaption | kModeNlp))
+                hipLaunchKernelGGL((echo_bank_kernel<32, 4, kModeAdaption | kModeNlp>), dim3(blocks), dim3(256), 0, e->stream, L);
+            else if (e->uniform_mode == (kModeAdaption | kModeNlp | kModeCng))
+                hipLaunchKernelGGL((echo_bank_kernel<32, 4, kModeAdaption | kModeNlp | kModeCng>), dim3(blocks), dim3(256), 0, e->stream, L);
             else
                 hipLaunchKernelGGL((echo_bank_kernel<32, 4>), dim3(blocks), dim3(256), 0, e->stream, L);
             break;

@@ -79,6 +79,8 @@ def compare_state(bank, dets, what):
     (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 4),
     (128, 0x01, [160], 4),
     (128, 0x01, [160, 1, 31, 77], 4),       # the kernel compiled for mode 0x01: partial rounds of the common body
+    (128, 0x01 | 0x02, [160, 77], 4),       # ... for adaption + NLP
+    (128, 0x01 | 0x02 | 0x04, [160, 77], 4),    # ... for adaption + NLP + CNG
     (64, 0x01 | 0x02, [160, 1, 31], 4),
     (32, 0x01 | 0x20 | 0x40, [160], 4),
     # two lanes per channel, 16-bit quantities packed in pairs (echo_pair.hpp; the default for big banks)
