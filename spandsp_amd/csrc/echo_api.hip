@@ -112,6 +112,9 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     //   mixed lines -- single talk, double talk, silence, DC offsets, so that set events fall on different samples in
     //     different channels (tools/bench_paths.py --workload echo --echo-lanes G): 32768: - / 232 / 218 / 265,
     //     65536: - / 400 / 370 / 361, 131072: - / 737 / 624 / 660
+    //   round 4 (rounds leave through LDS, dealt power meters, one conditional region a sample; profiles/r4_echo_lanes.log), mixed
+    //     G.168 lines, 4 / 8 / 16 lanes: 4096: 113 / 88 / 76, 8192: 126 / 90 / 91, 16384: 133 / 114 / 142, 32768: 170 / 194 / 244,
+    //     131072: 489 at four lanes -- the crossovers stand
     // The two-lane kernel executes 10.7 VALU instructions per channel and sample against 15.6 at four lanes and 23.1 at
     // eight (profiles/r2_echo_pmc.txt), but a sample on which ANY of a wave's channels meets a set event takes the whole
     // wave through the complete routine, and its waves hold 32 channels: on mixed lines that eats the gain.  So four

@@ -121,6 +121,16 @@ echo_occ)
     echo "$n $(grep -o '"avg_launch_us": [0-9.]*' $R/echo_occ_$n.json | head -1)" | tee -a $R/echo_occ.log
   done
   ;;
+echo_lanes)
+  # where the lane mappings cross over, after the round-4 kernel work
+  cd /tmp
+  for n in 4096 8192 16384 32768; do
+    for g in 4 8 16; do
+      timeout 200 python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload echo --channels $n --echo-lanes $g --no-cpu-baseline --no-e2e --echo-seconds 2 > $R/echo_lanes_${n}_$g.json 2> $R/echo_lanes_${n}_$g.err
+      echo "$n lanes $g $(grep -o '"avg_launch_us": [0-9.]*' $R/echo_lanes_${n}_$g.json | head -1)" | tee -a $R/echo_lanes.log
+    done
+  done
+  ;;
 tests)
   python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
   timeout 1500 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log
