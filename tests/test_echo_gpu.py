@@ -162,11 +162,17 @@ def test_echo_kernel_follows_the_modes_of_the_bank(built):
             bank.adaption_mode(0x01)
             for d in dets:
                 d.adaption_mode(0x01)
+        if fi in (20, 38):
+            # echo_can_flush() in either kernel: the FIR stays on the old tap set until the next rotation, every sample of
+            # the wave takes the complete routine meanwhile
+            for c in (1, 5, 36):
+                bank.flush(c)
+                dets[c].flush()
         got = bank.update_host(tx[:, pos:pos + 160], rx[:, pos:pos + 160], use_hpf_tx=False)
         for c, d in enumerate(dets):
             want = d.run(tx[c, pos:pos + 160], rx[c, pos:pos + 160], False)
             assert np.array_equal(got[c], want), (fi, c)
-        if fi in (9, 10, 29, 30):
+        if fi in (9, 10, 20, 21, 29, 30, 38, 39):
             compare_state(bank, dets, ("modes", fi))
     compare_state(bank, dets, "modes")
 
