@@ -333,6 +333,12 @@ static void sweep_big(int n_ch)
     NEW(1, 2, false, 4, 32);        // stamps
     NEWL(1, 2, false, 0);
     NEWL(1, 2, false, 32);
+    // ring depth and waves per workgroup at this size (the loader variants)
+    NEWL(1, 3, false, 0);
+    NEWL(1, 4, false, 0);
+    NEW(1, 3, false, 4, 0);
+    NEW(1, 2, false, 8, 0);
+    NEW(1, 3, false, 8, 0);
     free_rig(r);
 }
 
