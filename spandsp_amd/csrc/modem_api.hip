@@ -18,6 +18,14 @@
 #include "v17_quad.hpp"
 #include "v27ter_quad.hpp"
 
+// the four-lane kernels live in translation units of their own, each compiled with the instruction scheduler that suits it
+// (Makefile; modem_v27q.hip says what was measured)
+namespace spg {
+void launch_v29_quad(const V29Launch &L, hipStream_t stream);
+void launch_v17_quad(const V17Launch &L, hipStream_t stream);
+void launch_v27ter_quad(const V27Launch &L, hipStream_t stream);
+}
+
 using namespace spg;
 
 extern "C" int spangpu_set_error(int code, const char *msg);
@@ -547,7 +555,7 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
         {
             // banks that cannot fill the chip's 1 024 SIMDs with full waves of one channel per lane: four lanes per
             // channel, 16 channels per wave, four waves per workgroup sharing the tables (v29_quad.hpp)
-            hipLaunchKernelGGL((v29_quad_kernel<16, 4>), dim3((m->n_ch + 63)/64), dim3(256), 0, m->stream, L);
+            launch_v29_quad(L, m->stream);                          // modem_v29q.hip (a scheduler of its own)
         }
         else if (cpw == 32)
             hipLaunchKernelGGL(v29_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
@@ -580,7 +588,7 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
             hipLaunchKernelGGL((v17_bank_kernel<64, false, 3, 16, true>), dim3((waves + 2)/3), dim3(192), 0, m->stream, L);
         }
         else if (quad == 4  ||  quad == 8)
-            hipLaunchKernelGGL((v17_quad_kernel<16, 4>), dim3((m->n_ch + 63)/64), dim3(256), 0, m->stream, L);
+            launch_v17_quad(L, m->stream);                          // modem_v17q.hip (a scheduler of its own)
         else if (cpw == 32)
             hipLaunchKernelGGL(v17_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
         else
@@ -612,7 +620,7 @@ int spangpu_modem_rx(spangpu_modem_t *m, const int16_t *amp, int mem, int sample
             hipLaunchKernelGGL((v27ter_bank_kernel<64, false, 4, 16, true>), dim3((waves + 3)/4), dim3(256), 0, m->stream, L);
         }
         else if (quad == 4  ||  quad == 8)
-            hipLaunchKernelGGL((v27ter_quad_kernel<16, 4>), dim3((m->n_ch + 63)/64), dim3(256), 0, m->stream, L);
+            launch_v27ter_quad(L, m->stream);                       // modem_v27q.hip (a scheduler of its own)
         else if (cpw == 32)
             hipLaunchKernelGGL(v27ter_bank_kernel<32>, grid, dim3(64), 0, m->stream, L);
         else

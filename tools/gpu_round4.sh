@@ -131,6 +131,20 @@ echo_lanes)
     done
   done
   ;;
+sched)
+  # A-B of the maximum-ILP scheduler: every workload with the product library and with tools/experiments/libspangpu_ilp.so
+  cd /tmp
+  for lib in std ilp; do
+    if [ $lib = ilp ]; then export SPANGPU_LIB=$GRAFT_REPO_ROOT/tools/experiments/libspangpu_ilp.so; else unset SPANGPU_LIB; fi
+    timeout 200 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-paths > $R/sched_${lib}_dtmf.json 2>/dev/null
+    echo "$lib dtmf $(grep -o '"avg_launch_us": [0-9.]*' $R/sched_${lib}_dtmf.json | head -1)" | tee -a $R/sched.log
+    for w in ${SCHED_W:-mixed supertone fsk mct sigtone dtmf_tx v29_tx awgn echo v29 v17 v27ter}; do
+      timeout 200 python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --no-cpu-baseline --no-e2e --echo-seconds 2 > $R/sched_${lib}_$w.json 2>/dev/null
+      echo "$lib $w $(grep -o '"avg_launch_us": [0-9.]*' $R/sched_${lib}_$w.json | head -1) $(grep -o '"ms_per_step": [0-9.]*' $R/sched_${lib}_$w.json | head -1)" | tee -a $R/sched.log
+    done
+  done
+  unset SPANGPU_LIB
+  ;;
 tests)
   python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
   timeout 1500 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log
