@@ -134,8 +134,8 @@ echo_lanes)
 sched)
   # A-B of the maximum-ILP scheduler: every workload with the product library and with tools/experiments/libspangpu_ilp.so
   cd /tmp
-  for lib in std ilp; do
-    if [ $lib = ilp ]; then export SPANGPU_LIB=$GRAFT_REPO_ROOT/tools/experiments/libspangpu_ilp.so; else unset SPANGPU_LIB; fi
+  for lib in ${SCHED_LIBS:-std ilp}; do
+    if [ $lib = ilp ]; then export SPANGPU_LIB=$GRAFT_REPO_ROOT/tools/experiments/${SCHED_LIB:-libspangpu_ilp.so}; else unset SPANGPU_LIB; fi
     timeout 200 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-paths > $R/sched_${lib}_dtmf.json 2>/dev/null
     echo "$lib dtmf $(grep -o '"avg_launch_us": [0-9.]*' $R/sched_${lib}_dtmf.json | head -1)" | tee -a $R/sched.log
     for w in ${SCHED_W:-mixed supertone fsk mct sigtone dtmf_tx v29_tx awgn echo v29 v17 v27ter}; do
