@@ -114,7 +114,8 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     //     65536: - / 400 / 370 / 361, 131072: - / 737 / 624 / 660
     //   round 4 (rounds leave through LDS, dealt power meters, one conditional region a sample; profiles/r4_echo_lanes.log), mixed
     //     G.168 lines, 4 / 8 / 16 lanes: 4096: 113 / 88 / 76, 8192: 126 / 90 / 91, 16384: 133 / 114 / 142, 32768: 170 / 194 / 244,
-    //     131072: 489 at four lanes -- the crossovers stand
+    //     131072: 489 at four lanes -- the crossovers stand (with the kernels compiled for mode 0x01 at 8 and 16 lanes as well,
+    //     profiles/r4_echo_lanes_mode_kernels.log: 4096: - / 76 / 62, 8192: - / 79 / 78, 16384: - / 103 / 119)
     // The two-lane kernel executes 10.7 VALU instructions per channel and sample against 15.6 at four lanes and 23.1 at
     // eight (profiles/r2_echo_pmc.txt), but a sample on which ANY of a wave's channels meets a set event takes the whole
     // wave through the complete routine, and its waves hold 32 channels: on mixed lines that eats the gain.  So four
@@ -323,7 +324,12 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
         {
         case 4:  hipLaunchKernelGGL((echo_bank_kernel<4, 8>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
         case 8:  hipLaunchKernelGGL((echo_bank_kernel<8, 8>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
-        default: hipLaunchKernelGGL((echo_bank_kernel<16, 8>), dim3(blocks), dim3(256), 0, e->stream, L); break;
+        default:
+            if (e->uniform_mode == kModeAdaption)
+                hipLaunchKernelGGL((echo_bank_kernel<16, 8, kModeAdaption>), dim3(blocks), dim3(256), 0, e->stream, L);
+            else
+                hipLaunchKernelGGL((echo_bank_kernel<16, 8>), dim3(blocks), dim3(256), 0, e->stream, L);
+            break;
         }
     }
     else
@@ -332,7 +338,12 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
         {
         case 2:  hipLaunchKernelGGL((echo_bank_kernel<2, 16>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
         case 4:  hipLaunchKernelGGL((echo_bank_kernel<4, 16>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
-        case 8:  hipLaunchKernelGGL((echo_bank_kernel<8, 16>), dim3(blocks), dim3(256), 0, e->stream, L);  break;
+        case 8:
+            if (e->uniform_mode == kModeAdaption)
+                hipLaunchKernelGGL((echo_bank_kernel<8, 16, kModeAdaption>), dim3(blocks), dim3(256), 0, e->stream, L);
+            else
+                hipLaunchKernelGGL((echo_bank_kernel<8, 16>), dim3(blocks), dim3(256), 0, e->stream, L);
+            break;
         default: hipLaunchKernelGGL((echo_bank_kernel<16, 16>), dim3(blocks), dim3(256), 0, e->stream, L); break;
         }
     }

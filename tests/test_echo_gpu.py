@@ -72,7 +72,9 @@ def compare_state(bank, dets, what):
     (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 8),
     (64, 0x01 | 0x02, [160], 8),
     (32, 0x01, [160], 8),
+    (128, 0x01, [160, 77], 8),              # the eight-lane kernel compiled for mode 0x01
     # sixteen lanes per channel (a DPP row)
+    (128, 0x01, [160, 31], 16),             # the sixteen-lane kernel compiled for mode 0x01
     (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 16),
     (64, 0x01 | 0x02, [160], 16),
     # four lanes per channel (a DPP quad; the default up to 128 taps)
