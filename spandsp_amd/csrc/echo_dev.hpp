@@ -113,6 +113,15 @@ __device__ __forceinline__ int echo_pack_ncf(int narrowband_count, int dtd_onset
     return (int) (((uint32_t) narrowband_count << 2) & 0x7FFFFFFCu) | (dtd_onset  ?  (int) 0x80000000u  :  0) | ((narrowband_score != 0)  ?  1  :  0);
 }
 
+// Between the lanes of ONE wave through LDS: what a lane has stored is for the others to read.  The hardware keeps a wave's LDS
+// operations in order; this keeps the compiler from moving a lane's reads over stores that lane may not even execute.
+__device__ __forceinline__ void echo_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // echo.c:534-543: max(top_bit(x) - 8, 0), the right shift lms_adapt()'s step gets
 __device__ __forceinline__ int lms_shift(int x)
 {
@@ -327,8 +336,7 @@ void echo_bank_kernel(const EchoLaunch L)
     // so that count >= 159 is an unsigned compare with 159*4 (true, too, while dtd_onset is set: that sample then takes the
     // complete routine, which is always right), dtd_onset == 0 a sign test, and count++, dtd_onset = 0 an add and an and.
     // (Three registers fewer in the common body, where there are none to spare: 168 at three waves per SIMD.)
-    if (j == 0)
-        cold[wv][g] = sc[ES_NARROWBAND_SCORE];
+    cold[wv][g] = sc[ES_NARROWBAND_SCORE];                  // (every lane of the channel, the same value)
     int ncf = echo_pack_ncf(sc[ES_NARROWBAND_COUNT], sc[ES_DTD_ONSET], sc[ES_NARROWBAND_SCORE]);
     // (a kernel compiled for a mode without a stage neither loads nor stores that stage's state: the registers are short)
     constexpr bool kTxHpf = (MODE < 0)  ||  (MODE & kModeTxHpf);
@@ -433,6 +441,7 @@ void echo_bank_kernel(const EchoLaunch L)
                 L.stats[ch].sum_rx2 += st_part;
         }
         // (one wave per io/scratch slice; LDS ops of a wave complete in order)
+        echo_wave_sync();
 
         // ---- a common sample.  PH is the compile-time rotation phase of the history registers: logical window
         // slot k of this lane lives in w[(k - PH) mod TPL].  Returns false, with nothing changed, when some
@@ -611,6 +620,7 @@ void echo_bank_kernel(const EchoLaunch L)
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
                     bounce[j*TPL + k] = (short) t16[k];
+                echo_wave_sync();
                 const unsigned first = (unsigned) (j*TPL + curr_pos);
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
@@ -626,37 +636,72 @@ void echo_bank_kernel(const EchoLaunch L)
                         if (++narrowband_count >= 160)
                         {
                             narrowband_count = 0;
-                            float *const acfbuf = (float *) scratch[wv] + g*48;
                             // ---- narrowband_detect(), echo.c:120-175 ---------------------------
-                            // window samples 0..31 -> LDS, then every lag 0..8 has its lane (lane j: lags j, j + G, ...)
+                            // The window's first 32 samples go to LDS behind eight zeros: [0..7] zeros, [8..39] samples, [40] the
+                            // lag 0 sum.  Every lag 0..8 has its lane (lane j: lags j, j + G, ...), and a lag's sum over
+                            // i = lag .. 31 of x[i]*x[i - lag] runs over ALL i with x[i - lag] read from the zeros for i < lag:
+                            // a sum that starts at +0 stays what it is when +-0 is added, so the order and the roundings are
+                            // the reference's, and the operands can be fetched eight at a time with one wait instead of one wait per
+                            // term (the loops this replaces were a rolled ds_read / wait / multiply / add per term: some ten
+                            // thousand cycles of LDS latency per test, sixteen tests per wave and frame on lines out of step).
+                            float *const acfbuf = (float *) scratch[wv] + g*48;
+                            // last_acf[] of this lane's lags: asked for now, needed after the sums
+                            int before[NL];
+#pragma unroll
+                            for (int m = 0;  m < NL;  m++)
+                                before[m] = (j + m*G < 9)  ?  sc[ES_LAST_ACF + j + m*G]  :  0;
                             // (every k against a constant: written as i = j*TPL + k against T - curr_pos, the compiler computes the
                             // TPL values T - i ahead of the sample loop and keeps them in scratch)
                             const int jt = j*TPL;
                             const int lead = curr_pos + jt;
+                            if (j < 2)
+                            {
+#pragma unroll
+                                for (int k = 0;  k < 4;  k++)
+                                    acfbuf[4*j + k] = 0.0f;
+                            }
 #pragma unroll
                             for (int k = 0;  k < TPL;  k++)
                             {
                                 if (jt < 32 - k)
                                 {
                                     const bool inside = (T == 256)  ||  (lead < T - k);
-                                    (acfbuf + jt)[k] = inside  ?  (float) w[k]  :  0.0f;
+                                    (acfbuf + 8 + jt)[k] = inside  ?  (float) w[k]  :  0.0f;
                                 }
                             }
+                            echo_wave_sync();
                             float temp[NL];
+                            const float *shifted[NL];
 #pragma unroll
                             for (int m = 0;  m < NL;  m++)
                             {
-                                const int lag = j + m*G;
                                 temp[m] = 0.0f;
-                                if (lag < 9)
+                                shifted[m] = acfbuf + 8 - min(j + m*G, 8);      // (a lag past 8 is nobody's: its sum is not used)
+                            }
+                            // (a rolled loop of four: unrolled, the scheduler asks for all 128 operands at once and spills a thousand registers)
+#pragma nounroll
+                            for (int c = 0;  c < 32;  c += 8)
+                            {
+                                float xv[8];
+#pragma unroll
+                                for (int i = 0;  i < 8;  i++)
+                                    xv[i] = acfbuf[8 + c + i];
+#pragma unroll
+                                for (int m = 0;  m < NL;  m++)
                                 {
-                                    for (int i = lag;  i < 32;  i++)
-                                        temp[m] += acfbuf[i]*acfbuf[i - lag];
-                                    if (lag == 0)
-                                        acfbuf[32] = temp[m];
+                                    float yv[8];
+#pragma unroll
+                                    for (int i = 0;  i < 8;  i++)
+                                        yv[i] = shifted[m][c + i];
+#pragma unroll
+                                    for (int i = 0;  i < 8;  i++)
+                                        temp[m] += xv[i]*yv[i];
                                 }
                             }
-                            const float scale = (float) 0x1FFFFFFF/acfbuf[32];
+                            if (j == 0)
+                                acfbuf[40] = temp[0];
+                            echo_wave_sync();
+                            const float scale = (float) 0x1FFFFFFF/acfbuf[40];
                             auto similar = [](int before, int now) -> bool
                             {
                                 // echo.c:150-168: within a factor of two of the previous value, same sign
@@ -672,8 +717,7 @@ void echo_bank_kernel(const EchoLaunch L)
                             {
                                 const bool mine = (j + m*G < 9);
                                 const int acf = f2i_x86(temp[m]*scale);
-                                const int before = mine  ?  sc[ES_LAST_ACF + j + m*G]  :  0;
-                                const unsigned long long bal = __ballot(mine  &&  similar(before, acf));
+                                const unsigned long long bal = __ballot(mine  &&  similar(before[m], acf));
                                 score += __popcll((bal >> (g*G)) & ((1ull << G) - 1ull));
                                 if (mine  &&  live)
                                     sc[ES_LAST_ACF + j + m*G] = acf;

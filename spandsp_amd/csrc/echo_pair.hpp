@@ -340,6 +340,7 @@ void echo_pair_kernel(const EchoLaunch L)
                 L.stats[ch].sum_rx2 += st_part;
         }
         // (one wave per io / bounce / acf slice; LDS ops of a wave complete in order)
+        echo_wave_sync();
 
         // ---- a common sample.  Returns false, with nothing changed but the history (which has taken the sample), when some
         // channel of the wave meets a set event.
@@ -453,6 +454,7 @@ void echo_pair_kernel(const EchoLaunch L)
                     bounce[j*TPL + 2*k] = (short) half_lo(tp[k]);
                     bounce[j*TPL + 2*k + 1] = (short) half_hi(tp[k]);
                 }
+                echo_wave_sync();
 #pragma unroll
                 for (int k = 0;  k < NP;  k++)
                 {
@@ -483,6 +485,7 @@ void echo_pair_kernel(const EchoLaunch L)
                                     acfbuf[i + 1] = (curr_pos + i + 1 < T)  ?  (float) half_hi(wp[k])  :  0.0f;
                                 }
                             }
+                            echo_wave_sync();                       // (the samples are for both lanes of the pair)
                             float temp[NL];
 #pragma unroll
                             for (int m = 0;  m < NL;  m++)
@@ -497,6 +500,7 @@ void echo_pair_kernel(const EchoLaunch L)
                                         acfbuf[32] = temp[m];
                                 }
                             }
+                            echo_wave_sync();                       // (... and so is the lag 0 sum)
                             const float scale = (float) 0x1FFFFFFF/acfbuf[32];
                             auto similar = [](int before, int now) -> bool
                             {
