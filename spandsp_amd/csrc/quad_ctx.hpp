@@ -150,7 +150,15 @@ struct QuadDev
         return __builtin_amdgcn_mov_dpp(v, 0x90, 0xF, 0xF, true);                                      // quad_perm:[0,0,1,2]
     }
     __device__ __forceinline__ bool any(bool b, int = 0) { return __any(b); }
-    __device__ __forceinline__ void sync(int = 0) {}
+    // The lanes of a quad hand data to each other through LDS at these points.  A wave's LDS operations complete in order, so
+    // there is nothing for the hardware to do; the fence keeps the COMPILER from moving a lane's reads over stores that
+    // lane may not execute itself (its neighbour's are what it is after).
+    __device__ __forceinline__ void sync(int = 0)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 };
 
 }   // namespace spg
