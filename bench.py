@@ -231,6 +231,46 @@ def end_to_end(engine, n_ch, frames_dev, device_index, steps, law=0):
     }
 
 
+def large_banks(engine, dev, local_rank, frames, stream):
+    """Not the headline: the same detector on banks large enough for several waves per SIMD (262 144 and 1 048 576 channels x
+    160-sample frames; the headline's frames tiled along the channel axis), one launch per tick and in queue mode
+    (spangpu_bank_set_queues(bank, 2): the launch cut in two on two hardware queues).  Step time by HIP events on the bank's
+    stream around 100 ticks, the second queue joined before the closing event."""
+    out = {}
+    nf = min(6, frames.shape[0])
+    for n_ch in (262144, 1048576):
+        try:
+            rep = n_ch//frames.shape[1]
+            big = frames[:nf].repeat(1, rep, 1).contiguous()
+            fb = n_ch*FRAME*2
+            res = {}
+            for q in (1, 2):
+                bank = engine.ToneBank(engine.DTMF, n_ch, device=local_rank)
+                bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+                bank.set_queues(q)
+                for i in range(10):
+                    bank.rx_device(ctypes.c_void_p(big.data_ptr() + (i % nf)*fb), FRAME, FRAME)
+                bank.join()
+                torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for i in range(100):
+                    bank.rx_device(ctypes.c_void_p(big.data_ptr() + (i % nf)*fb), FRAME, FRAME)
+                bank.join()
+                e1.record(stream)
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1)*10.0
+                res["queues_%d" % q] = {"us_per_step": us, "roofline_frac": n_ch*ALG_READ_BYTES/(us*1e-6)/1e9/HBM_PEAK_GBPS}
+                bank.close()
+            out[str(n_ch)] = res
+            del big
+            torch.cuda.empty_cache()
+        except Exception as e:                      # never takes the headline line with it
+            out[str(n_ch)] = {"error": repr(e)}
+    return out
+
+
 def run_echo(args, engine, dev, local_rank, rank, world):
     """BASELINE configs[4]: the G.168 canceller (echo.c, 128 taps, ECHO_CAN_USE_ADAPTION) on 131 072 channels per GPU,
     channels sharded over the ranks with no data-path collective; once per second of signal (50 steps) every rank turns
@@ -253,7 +293,8 @@ def run_echo(args, engine, dev, local_rank, rank, world):
     torch.cuda.set_stream(stream)
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
     bank.stats(2)                       # energy sums by the update kernel itself (ERLE needs no CRC)
-    gather = FloatGather(world, rank, n_ch, dev) if world > 1 else None
+    force_gather = world == 1 and os.environ.get("SPANGPU_BENCH_FORCE_GATHER") == "1"
+    gather = FloatGather(world, rank, n_ch, dev) if (world > 1 or force_gather) else None
     erle_dev = gather.send if gather is not None else torch.zeros(n_ch, dtype=torch.float32, device=dev)
     fb = n_ch*FRAME*2
     report_every = 50
@@ -262,9 +303,10 @@ def run_echo(args, engine, dev, local_rank, rank, world):
         bank.update_device(ctypes.c_void_p(tx.data_ptr() + i*fb), ctypes.c_void_p(rx.data_ptr() + i*fb),
                            ctypes.c_void_p(clean.data_ptr()), FRAME, FRAME)
         if (i + 1) % report_every == 0:
+            if gather is not None:
+                gather.result()                     # the previous report has arrived (and the send buffer is free again)
             bank.erle_device(ctypes.c_void_p(erle_dev.data_ptr()))
             if gather is not None:
-                gather.result()                     # the previous report has arrived
                 gather.gather()
             if i + 1 < nf:
                 bank.stats_reset(sums=True, crc=False)
@@ -355,6 +397,10 @@ def main():
                     help="multi-GPU: steps per RCCL gather (25 = one report to rank 0 per 0.5 s of signal; every digit of every "
                          "step travels, a report only batches them: measured on one rank, a collective per 5 steps costs "
                          "3.1 us per step, per 25 steps 1.3 us)")
+    ap.add_argument("--queues", type=int, default=1,
+                    help="spangpu_bank_set_queues(): 2 = the bank's launches cut in two on two hardware queues (pays from 131072 "
+                         "channels: profiles/r5_probe_mq.log), 0 = the library's choice, 1 = one launch per step (the default, and "
+                         "what the headline configuration runs)")
     ap.add_argument("--g711", choices=["none", "alaw", "ulaw"], default="none",
                     help="feed the bank G.711 bytes (decoded on the device) instead of 16 bit linear PCM; not the "
                          "BASELINE configuration -- a variant of it with the wire format of a trunk")
@@ -376,10 +422,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("SPANGPU_BENCH_SPAWN") == "1"):
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU, RCCL over xGMI), the way the
+        # driver's own command line does, hand them this command line, and pass on rank 0's JSON line and the exit code
+        # (SPANGPU_BENCH_SPAWN=1 takes the same road with one rank: the self-test of this path on a one-GPU box)
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ)
+        env.pop("SPANGPU_BENCH_SPAWN", None)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with python -m torch.distributed.run --nproc-per-node %d, "
+                         "or without the rendezvous variables: bench.py then starts its ranks itself)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -426,6 +486,7 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    n_queues = bank.set_queues(args.queues)
     gather = None
     if world > 1 or force_gather:
         if args.gather == "digits":
@@ -481,6 +542,7 @@ def main():
         step(args.warmup + i)
     if gather is not None:
         gather.drain()
+    bank.join()
     ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -564,6 +626,9 @@ def main():
         lower = (x - vals[posn - 1]) <= (vals[posn] - x)
         e2e_g711 = end_to_end(engine, n_ch, codes_of[torch.where(lower, posn - 1, posn)].contiguous(), local_rank, 60, law=2)
 
+    large = None
+    if rank == 0 and world == 1 and not args.no_paths and not law and n_ch == 65536:
+        large = large_banks(engine, dev, local_rank, frames, stream)
     paths = None
     if rank == 0 and world == 1 and not args.no_paths and not law:
         # BASELINE configs[2], [3], [4] under the same clock as the headline (tools/bench_paths.py: paths_for_bench)
@@ -598,6 +663,7 @@ def main():
                             % (n_ch, FRAME, ("G.711 %s bytes (decoded on the device)" % args.g711) if law else "int16", nf),
                 "channels_per_gpu": n_ch,
                 "frame_samples": FRAME,
+                "queues": n_queues,
                 "parallelism": ("channels sharded x%d, RCCL gather of %s every %d steps"
                                 % (world, "one digit byte per block and channel" if args.gather == "digits"
                                    else "all block records", args.gather_every))
@@ -609,6 +675,7 @@ def main():
             "e2e": e2e,
             "e2e_g711": e2e_g711,
             "paths": paths,
+            "large_bank": large,
         }
         print(json.dumps(line))
     if world > 1 or force_gather:

@@ -159,6 +159,18 @@ SPANGPU_API int spangpu_bank_channels(const spangpu_bank_t *bank);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*); NULL = the bank's own stream. */
 SPANGPU_API int spangpu_bank_set_stream(spangpu_bank_t *bank, void *hip_stream);
 SPANGPU_API void *spangpu_bank_get_stream(spangpu_bank_t *bank);
+/* Queue mode.  queues = 2: every launch the streaming kernel serves is cut in two ranges of channels, the second on a stream
+   (hardware queue) the bank owns, so that one half's launch boundary, start burst and write-back lie under the other half's
+   steady state; 1: one launch on the bank's stream (the default); 0: the library's choice (two from 131 072 channels: that is
+   where it pays, profiles/r5_probe_mq.log).  Returns the number of queues now in use, or a negative error.  Results are those
+   of one launch, bit for bit.  Ordering: consecutive spangpu_bank_rx*() calls with nothing else between them run the two
+   queues free of each other (no event per tick: that is the gain) -- so in queue mode a device-resident frame must be complete
+   when the call is made, or have been put on the bank's stream before the last spangpu_bank_get_stream() / _join().  Every
+   spangpu_bank_* call that reads results, edits state, waits or hands out the stream joins the second queue into the bank's
+   stream first, and the launch after it starts behind whatever the bank's stream then holds.  A caller that puts work of its
+   own on the bank's stream behind a launch (an event, a collective reading the records buffer) calls spangpu_bank_join() first. */
+SPANGPU_API int spangpu_bank_set_queues(spangpu_bank_t *bank, int queues);
+SPANGPU_API int spangpu_bank_join(spangpu_bank_t *bank);
 
 /* Advance every channel by `samples` samples.  `amp` is int16 PCM; for
    CHANNEL_MAJOR, channel c starts at amp + c*stride (stride in samples, must be a
@@ -182,9 +194,13 @@ SPANGPU_API int spangpu_bank_rx_var(spangpu_bank_t *bank, const int16_t *amp, in
 SPANGPU_API int spangpu_bank_set_channel_params(spangpu_bank_t *bank, int channel, const spangpu_tone_params_t *params,
                                                 size_t params_size);
 
-/* Advance several banks (<= 4, same device and stream, device-resident channel-major frames) with ONE kernel launch:
-   a tick of a mixed population of small banks then pays the launch and ramp-up cost once.  DTMF (no dial-tone
-   filter), Bell MF, R2 MF and super-tone banks can share a launch.  strides may be NULL (= samples). */
+/* Advance several banks (<= 4, same device, device-resident channel-major frames) in one call.  Banks on ONE stream share ONE
+   kernel launch: a tick of a mixed population of small banks then pays the launch and ramp-up cost once.  DTMF (no dial-tone
+   filter), Bell MF, R2 MF and super-tone banks can share a launch.  Banks that were given streams of their own
+   (spangpu_bank_set_stream) get a launch each, on their streams: with banks large enough to fill the chip between them the
+   free-running hardware queues overlap one bank's launch boundary and start burst with the others' steady state (BASELINE
+   configs[2], 131 072 channels in three banks: 23.7 us a tick as one launch, 18.4 us on three streams; the caller joins the
+   streams when it reads results: spangpu_bank_blocks() etc. wait on the bank's own stream).  strides may be NULL (= samples). */
 SPANGPU_API int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, int n_banks, int samples,
                                  const long long *strides);
 /* Evaluate the current (partial) block of every channel now and restart it: what

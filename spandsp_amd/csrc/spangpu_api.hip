@@ -49,6 +49,19 @@ struct spangpu_bank_s
     hipStream_t stream;
     bool own_stream;
     bool timing;
+    // Queue mode (spangpu_bank_set_queues(bank, 2)): the streaming kernel's launch is cut in two workgroup ranges, the second
+    // on a stream (= hardware queue) of its own, so that one half's launch boundary, start burst and write-back lie under the
+    // other half's steady state (profiles/r5_probe_mq.log).  ev_in orders the second stream behind whatever the bank's stream
+    // held when the launch was queued; ev_q, recorded behind the second half, is what joined() makes the bank's stream wait for.
+    int queues;
+    hipStream_t stream2;
+    hipEvent_t ev_in;
+    hipEvent_t ev_q;
+    bool s2_busy;               // the second stream holds launches the bank's stream has not been made to wait for
+    bool main_touched;          // the bank's stream was handed out or used since the last split launch: the next one orders
+                                // the second stream behind it.  (Between two split launches with nothing else in between
+                                // NO event is recorded or waited for: the two queues run free, which is where the gain is --
+                                // a wait per tick made 131 072 channels take 38 us a tick instead of 16.5.)
     spangpu_tone_params_t tp;
     // geometry of the detector
     int nb;                 // bins compiled into the kernel used
@@ -98,6 +111,21 @@ struct spangpu_bank_s
     hipEvent_t ev1;
     bool ev_valid;
 };
+
+// The bank's stream, with the second queue's last launch joined into it if one is outstanding: every entry point that puts work
+// on the stream, waits for it, or hands it out goes through here (the split launch itself excepted).
+static hipStream_t joined(spangpu_bank_s *b)
+{
+    if (b->s2_busy)
+    {
+        (void) hipEventRecord(b->ev_q, b->stream2);
+        (void) hipStreamWaitEvent(b->stream, b->ev_q, 0);
+        b->s2_busy = false;
+    }
+    b->main_touched = true;
+    return b->stream;
+}
+static hipStream_t joined(const spangpu_bank_s *b) { return joined(const_cast<spangpu_bank_s *>(b)); }
 
 // Lanes per channel: 2 while the bank is too small to put >= 4 one-channel-per-lane waves
 // on every SIMD (1024 SIMDs x 64 lanes x 4), else 1.  SPANGPU_LPC=1|2 overrides (tuning).
@@ -161,7 +189,7 @@ template <class Det, int LPC, bool G711>
 static void launch_fast(const ToneLaunch &L, hipStream_t st, bool loader)
 {
     const int waves = (L.n_ch + kWave/LPC - 1)/(kWave/LPC);
-    const int blocks = (waves + kFastWPB - 1)/kFastWPB;
+    const int blocks = (L.wgn > 0)  ?  L.wgn  :  (waves + kFastWPB - 1)/kFastWPB;
     if constexpr (is_super_tone<Det>::value  &&  LPC == 1  &&  !G711)
     {
         if (L.cad.state)
@@ -537,7 +565,7 @@ static int ensure_outputs(spangpu_bank_t *b, int maxb)
         const int caught = cadence_catch_up(b);
         if (caught != SPANGPU_OK)
             return caught;
-        HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(hipStreamSynchronize(joined(b)));
     }
     free_outputs(b);
     const size_t n = (size_t) maxb*b->n_ch;
@@ -549,18 +577,18 @@ static int ensure_outputs(spangpu_bank_t *b, int maxb)
     {
         HIP_TRY(hipMalloc(&b->rec_energy, n*sizeof(float)));
         HIP_TRY(hipHostMalloc(&b->h_energy, n*sizeof(float)));
-        HIP_TRY(hipMemsetAsync(b->rec_energy, 0, n*sizeof(float), b->stream));
+        HIP_TRY(hipMemsetAsync(b->rec_energy, 0, n*sizeof(float), joined(b)));
     }
     if (b->kind == SPANGPU_DTMF  &&  b->tp.report_mode == SPANGPU_REPORT_REALTIME)
     {
         HIP_TRY(hipMalloc(&b->rec_dur, n*sizeof(int32_t)));
         HIP_TRY(hipHostMalloc(&b->h_dur, n*sizeof(int32_t)));
-        HIP_TRY(hipMemsetAsync(b->rec_dur, 0, n*sizeof(int32_t), b->stream));
+        HIP_TRY(hipMemsetAsync(b->rec_dur, 0, n*sizeof(int32_t), joined(b)));
     }
     if (b->tp.trace  ||  b->kind == SPANGPU_GOERTZEL)
     {
         HIP_TRY(hipMalloc(&b->trace, n*(b->nb + 1)*sizeof(float)));
-        HIP_TRY(hipMemsetAsync(b->trace, 0, n*(b->nb + 1)*sizeof(float), b->stream));
+        HIP_TRY(hipMemsetAsync(b->trace, 0, n*(b->nb + 1)*sizeof(float), joined(b)));
     }
     b->maxb_cap = maxb;
     return SPANGPU_OK;
@@ -668,11 +696,11 @@ int spangpu_bank_create(spangpu_bank_t **bank, int device, int kind, int n_chann
         spangpu_bank_destroy(b);
         return fail(SPANGPU_ERR_NO_MEMORY, "hipMalloc of bank state failed");
     }
-    (void) hipMemsetAsync(b->sf, 0, nf*sizeof(float), b->stream);
-    (void) hipMemsetAsync(b->si, 0, (size_t) 2*b->n_ch*sizeof(int32_t), b->stream);
+    (void) hipMemsetAsync(b->sf, 0, nf*sizeof(float), joined(b));
+    (void) hipMemsetAsync(b->si, 0, (size_t) 2*b->n_ch*sizeof(int32_t), joined(b));
     (void) hipEventCreate(&b->ev0);
     (void) hipEventCreate(&b->ev1);
-    (void) hipStreamSynchronize(b->stream);
+    (void) hipStreamSynchronize(joined(b));
     *bank = b;
     return SPANGPU_OK;
 }
@@ -683,7 +711,14 @@ int spangpu_bank_destroy(spangpu_bank_t *b)
         return SPANGPU_OK;
     (void) hipSetDevice(b->device);
     if (b->stream)
-        (void) hipStreamSynchronize(b->stream);
+        (void) hipStreamSynchronize(joined(b));
+    if (b->stream2)
+    {
+        (void) hipStreamSynchronize(b->stream2);
+        (void) hipStreamDestroy(b->stream2);
+    }
+    if (b->ev_in) (void) hipEventDestroy(b->ev_in);
+    if (b->ev_q) (void) hipEventDestroy(b->ev_q);
     free_outputs(b);
     cadence_free(b->cad);
     if (b->sf) (void) hipFree(b->sf);
@@ -709,7 +744,7 @@ int spangpu_bank_set_stream(spangpu_bank_t *b, void *hip_stream)
 {
     if (b == nullptr)
         return fail(SPANGPU_ERR_BAD_ARG, "null bank");
-    (void) hipStreamSynchronize(b->stream);
+    (void) hipStreamSynchronize(joined(b));
     if (b->own_stream)
         (void) hipStreamDestroy(b->stream);
     if (hip_stream)
@@ -728,7 +763,40 @@ int spangpu_bank_set_stream(spangpu_bank_t *b, void *hip_stream)
 // The HIP stream the bank launches on (its own, unless spangpu_bank_set_stream() gave it another).
 void *spangpu_bank_get_stream(spangpu_bank_t *b)
 {
-    return b  ?  (void *) b->stream  :  nullptr;
+    return b  ?  (void *) joined(b)  :  nullptr;
+}
+
+// Queue mode.  queues = 2: launches the streaming kernel serves are cut in two workgroup ranges, the second on a stream
+// (hardware queue) the bank owns; queues = 1: one launch on the bank's stream (the default); queues = 0: the library's
+// choice -- two from 131 072 channels (measured, profiles/r5_probe_mq.log: 131 072 channels 18.3 -> 16.5 us a tick, 262 144
+// 35.0 -> 29.5, 1 048 576 118 -> 109; 65 536 channels 11.15 -> 11.7: one).  Results are those of one launch, bit for bit.
+// Ordering: the second stream starts a tick behind whatever the bank's stream held when the tick was queued, and every
+// spangpu_bank_* call that reads results, edits state or waits joins it back first.  A caller that puts work of its own on
+// the bank's stream behind a launch -- an event, a collective reading the records buffer -- calls spangpu_bank_join() first.
+int spangpu_bank_set_queues(spangpu_bank_t *b, int queues)
+{
+    if (b == nullptr  ||  queues < 0  ||  queues > 2)
+        return fail(SPANGPU_ERR_BAD_ARG, "queues must be 0 (the library's choice), 1 or 2");
+    HIP_TRY(hipSetDevice(b->device));
+    if (queues == 0)
+        queues = (b->n_ch >= 131072)  ?  2  :  1;
+    (void) joined(b);
+    if (queues == 2  &&  b->stream2 == nullptr)
+    {
+        HIP_TRY(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b->ev_q, hipEventDisableTiming));
+    }
+    b->queues = queues;
+    return queues;
+}
+
+int spangpu_bank_join(spangpu_bank_t *b)
+{
+    if (b == nullptr)
+        return fail(SPANGPU_ERR_BAD_ARG, "null bank");
+    (void) joined(b);
+    return SPANGPU_OK;
 }
 
 int spangpu_bank_set_timing(spangpu_bank_t *b, int on)
@@ -816,51 +884,78 @@ static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stri
     ToneLaunch L;
     fill_launch(L, b, d_amp, d_stride, samples, layout, maxb, force_end);
 
+    // Queue mode: a launch the one-lane streaming kernel serves, of a bank of at least two workgroups per half and without
+    // cadences (their epilogue's list is made on the bank's stream), goes out as two launches on two streams; the second stream
+    // first waits for what the bank's stream holds now (the caller's frame, an earlier launch of another kind).  Anything
+    // else joins the second stream into the bank's stream and runs there as ever.
+    const int total_wg = (b->n_ch + kWave*kFastWPB - 1)/(kWave*kFastWPB);
+    const bool split = b->queues == 2  &&  b->stream2 != nullptr  &&  !b->timing  &&  b->cad == nullptr  &&  b->nb <= 16  &&  total_wg >= 4
+                       &&  fast_eligible(L)  &&  forced_lpc() != 2;
+    if (split  &&  b->main_touched)
+    {
+        // something else went onto the bank's stream since the last split launch (a state edit, a launch of the other kernel
+        // family, work of the caller's behind spangpu_bank_get_stream() / _join()): the second half runs behind it
+        HIP_TRY(hipEventRecord(b->ev_in, b->stream));
+        HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_in, 0));
+        b->main_touched = false;
+    }
+    for (int half = 0;  half < (split  ?  2  :  1);  half++)
+    {
+    hipStream_t st = split  ?  b->stream  :  joined(b);
+    if (split)
+    {
+        L.wg0 = half  ?  total_wg/2  :  0;
+        L.wgn = half  ?  (total_wg - total_wg/2)  :  total_wg/2;
+        st = half  ?  b->stream2  :  b->stream;
+    }
     if (b->timing)
-        HIP_TRY(hipEventRecord(b->ev0, b->stream));
+        HIP_TRY(hipEventRecord(b->ev0, st));
     g_cadence_fused = false;
     switch (b->kind)
     {
     case SPANGPU_DTMF:
         if (b->chan_parms  ?  (b->n_filter_on > 0)  :  (b->tp.filter_dialtone != 0))
-            launch_tone<DtmfDet<true>>(L, b->stream);
+            launch_tone<DtmfDet<true>>(L, st);
         else
-            launch_tone<DtmfDet<false>>(L, b->stream);
+            launch_tone<DtmfDet<false>>(L, st);
         break;
     case SPANGPU_BELL_MF:
-        launch_tone<BellMfDet>(L, b->stream);
+        launch_tone<BellMfDet>(L, st);
         break;
     case SPANGPU_R2_MF:
-        launch_tone<R2MfDet>(L, b->stream);
+        launch_tone<R2MfDet>(L, st);
         break;
     case SPANGPU_SUPER_TONE:
         switch (b->nb)
         {
-        case 4:  launch_tone<MultiDet<4, true>>(L, b->stream);  break;
-        case 8:  launch_tone<MultiDet<8, true>>(L, b->stream);  break;
-        case 12: launch_tone<MultiDet<12, true>>(L, b->stream); break;
-        case 16: launch_tone<MultiDet<16, true>>(L, b->stream); break;
-        case 24: launch_tone_wide<MultiDet<24, true>>(L, b->stream); break;
-        case 32: launch_tone_wide<MultiDet<32, true>>(L, b->stream); break;
-        default: launch_tone_quad<MultiDet<64, true>>(L, b->stream); break;
+        case 4:  launch_tone<MultiDet<4, true>>(L, st);  break;
+        case 8:  launch_tone<MultiDet<8, true>>(L, st);  break;
+        case 12: launch_tone<MultiDet<12, true>>(L, st); break;
+        case 16: launch_tone<MultiDet<16, true>>(L, st); break;
+        case 24: launch_tone_wide<MultiDet<24, true>>(L, st); break;
+        case 32: launch_tone_wide<MultiDet<32, true>>(L, st); break;
+        default: launch_tone_quad<MultiDet<64, true>>(L, st); break;
         }
         break;
     case SPANGPU_GOERTZEL:
         switch (b->nb)
         {
-        case 4:  launch_tone<MultiDet<4, false>>(L, b->stream);  break;
-        case 8:  launch_tone<MultiDet<8, false>>(L, b->stream);  break;
-        case 12: launch_tone<MultiDet<12, false>>(L, b->stream); break;
-        case 16: launch_tone<MultiDet<16, false>>(L, b->stream); break;
-        case 24: launch_tone_wide<MultiDet<24, false>>(L, b->stream); break;
-        case 32: launch_tone_wide<MultiDet<32, false>>(L, b->stream); break;
-        default: launch_tone_quad<MultiDet<64, false>>(L, b->stream); break;
+        case 4:  launch_tone<MultiDet<4, false>>(L, st);  break;
+        case 8:  launch_tone<MultiDet<8, false>>(L, st);  break;
+        case 12: launch_tone<MultiDet<12, false>>(L, st); break;
+        case 16: launch_tone<MultiDet<16, false>>(L, st); break;
+        case 24: launch_tone_wide<MultiDet<24, false>>(L, st); break;
+        case 32: launch_tone_wide<MultiDet<32, false>>(L, st); break;
+        default: launch_tone_quad<MultiDet<64, false>>(L, st); break;
         }
         break;
     default:
         return fail(SPANGPU_ERR_UNSUPPORTED, "kind %d", b->kind);
     }
     HIP_TRY(hipGetLastError());
+    }
+    if (split)
+        b->s2_busy = true;
     if (b->cad  &&  g_cadence_fused)
     {
         b->cad->fused = true;
@@ -868,7 +963,7 @@ static int launch_bank(spangpu_bank_t *b, const int16_t *d_amp, long long d_stri
     }
     if (b->timing)
     {
-        HIP_TRY(hipEventRecord(b->ev1, b->stream));
+        HIP_TRY(hipEventRecord(b->ev1, joined(b)));
         b->ev_valid = true;
     }
     return SPANGPU_OK;
@@ -908,8 +1003,8 @@ int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, 
                 b->d_amp_cap = need;
             }
             HIP_TRY(hipMemcpy2DAsync(b->d_amp, padded*sizeof(int16_t), amp, stride*sizeof(int16_t),
-                                     samples*sizeof(int16_t), b->n_ch, hipMemcpyHostToDevice, b->stream));
-            HIP_TRY(hipStreamSynchronize(b->stream));       // amp[] is only borrowed for the duration of the call
+                                     samples*sizeof(int16_t), b->n_ch, hipMemcpyHostToDevice, joined(b)));
+            HIP_TRY(hipStreamSynchronize(joined(b)));       // amp[] is only borrowed for the duration of the call
             d_stride = padded;
         }
         else
@@ -924,8 +1019,8 @@ int spangpu_bank_rx(spangpu_bank_t *b, const int16_t *amp, int mem, int layout, 
                 b->d_amp_cap = need;
             }
             HIP_TRY(hipMemcpy2DAsync(b->d_amp, b->n_ch*sizeof(int16_t), amp, stride*sizeof(int16_t),
-                                     b->n_ch*sizeof(int16_t), samples, hipMemcpyHostToDevice, b->stream));
-            HIP_TRY(hipStreamSynchronize(b->stream));
+                                     b->n_ch*sizeof(int16_t), samples, hipMemcpyHostToDevice, joined(b)));
+            HIP_TRY(hipStreamSynchronize(joined(b)));
             d_stride = b->n_ch;
         }
         d_amp = b->d_amp;
@@ -980,9 +1075,9 @@ int spangpu_bank_rx_var(spangpu_bank_t *b, const int16_t *amp, int mem, const in
         HIP_TRY(hipMalloc(&b->d_lens, (size_t) b->n_ch*sizeof(int32_t)));
         HIP_TRY(hipHostMalloc(&b->h_lens, (size_t) b->n_ch*sizeof(int32_t), hipHostMallocDefault));
     }
-    HIP_TRY(hipStreamSynchronize(b->stream));               // the previous call's copy out of h_lens is done
+    HIP_TRY(hipStreamSynchronize(joined(b)));               // the previous call's copy out of h_lens is done
     memcpy(b->h_lens, lens, (size_t) b->n_ch*sizeof(int32_t));
-    HIP_TRY(hipMemcpyAsync(b->d_lens, b->h_lens, (size_t) b->n_ch*sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->d_lens, b->h_lens, (size_t) b->n_ch*sizeof(int32_t), hipMemcpyHostToDevice, joined(b)));
     b->next_lens = b->d_lens;
     b->next_ragged = ragged;
     const int rc = spangpu_bank_rx(b, amp, mem, SPANGPU_LAYOUT_CHANNEL_MAJOR, longest, stride);
@@ -1034,7 +1129,7 @@ int spangpu_bank_set_channel_params(spangpu_bank_t *b, int channel, const spangp
     memset(&tp, 0, sizeof(tp));
     memcpy(&tp, params, (params_size < sizeof(tp))  ?  params_size  :  sizeof(tp));
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     const size_t n = (size_t) b->n_ch;
     const int rc0 = ensure_chan_parms(b);
     if (rc0 != SPANGPU_OK)
@@ -1059,11 +1154,11 @@ int spangpu_bank_set_channel_params(spangpu_bank_t *b, int channel, const spangp
         b->n_filter_on += (int) on - (int) h[3*n + channel];
         h[3*n + channel] = on;
         for (int i = 0;  i < 4;  i++)
-            HIP_TRY(hipMemsetAsync(b->sf + (size_t) (17 + i)*n + channel, 0, sizeof(float), b->stream));
+            HIP_TRY(hipMemsetAsync(b->sf + (size_t) (17 + i)*n + channel, 0, sizeof(float), joined(b)));
     }
     for (int i = 0;  i < 4;  i++)
-        HIP_TRY(hipMemcpyAsync(b->chan_parms + (size_t) i*n + channel, &h[(size_t) i*n + channel], sizeof(float), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(hipMemcpyAsync(b->chan_parms + (size_t) i*n + channel, &h[(size_t) i*n + channel], sizeof(float), hipMemcpyHostToDevice, joined(b)));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     return SPANGPU_OK;
 }
 
@@ -1099,8 +1194,8 @@ int spangpu_bank_rx_g711(spangpu_bank_t *b, const uint8_t *codes, int mem, int l
             HIP_TRY(hipMalloc(&b->d_amp, need*sizeof(int16_t)));
             b->d_amp_cap = need;
         }
-        HIP_TRY(hipMemcpy2DAsync(b->d_amp, padded, codes, stride, samples, b->n_ch, hipMemcpyHostToDevice, b->stream));
-        HIP_TRY(hipStreamSynchronize(b->stream));           // codes[] is only borrowed for the duration of the call
+        HIP_TRY(hipMemcpy2DAsync(b->d_amp, padded, codes, stride, samples, b->n_ch, hipMemcpyHostToDevice, joined(b)));
+        HIP_TRY(hipStreamSynchronize(joined(b)));           // codes[] is only borrowed for the duration of the call
         d_codes = (const uint8_t *) b->d_amp;
         d_stride = padded;
     }
@@ -1139,10 +1234,29 @@ int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, i
         spangpu_bank_t *b = banks[k];
         if (b == nullptr  ||  amps[k] == nullptr)
             return fail(SPANGPU_ERR_BAD_ARG, "null bank or frame");
-        if (b->device != banks[0]->device  ||  b->stream != banks[0]->stream)
-            return fail(SPANGPU_ERR_BAD_ARG, "banks of one launch must share a device and a stream (spangpu_bank_set_stream)");
+        if (b->device != banks[0]->device)
+            return fail(SPANGPU_ERR_BAD_ARG, "banks of one call must be on one device");
         total_ch += b->n_ch;
     }
+    // Banks that were given streams of their own (spangpu_bank_set_stream) are advanced by a launch each, every one on its
+    // bank's stream: free-running hardware queues put one bank's launch boundary, start burst and write-back under the other
+    // banks' steady state (configs[2], 131 072 channels in three banks: 23.7 us a tick as one launch, 18.4 us as three
+    // launches on three streams; three launches on ONE stream 32.3 -- profiles/r5_mixed_streams.log).
+    bool own_streams = false;
+    for (int k = 1;  k < n_banks;  k++)
+        own_streams = own_streams  ||  (banks[k]->stream != banks[0]->stream);
+    if (own_streams)
+    {
+        for (int k = 0;  k < n_banks;  k++)
+        {
+            const int rc = spangpu_bank_rx(banks[k], amps[k], SPANGPU_MEM_DEVICE, SPANGPU_LAYOUT_CHANNEL_MAJOR, samples, strides  ?  strides[k]  :  0);
+            if (rc < 0)
+                return rc;
+        }
+        return 0;
+    }
+    for (int k = 0;  k < n_banks;  k++)
+        (void) joined(banks[k]);
     HIP_TRY(hipSetDevice(banks[0]->device));
     bool all_fast = true;
     for (int k = 0;  k < n_banks;  k++)
@@ -1253,7 +1367,7 @@ int spangpu_bank_sync(spangpu_bank_t *b)
 {
     if (b == nullptr)
         return fail(SPANGPU_ERR_BAD_ARG, "null bank");
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     return SPANGPU_OK;
 }
 
@@ -1277,12 +1391,12 @@ int spangpu_bank_blocks(spangpu_bank_t *b, spangpu_block_t *out, int max)
         return 0;
     HIP_TRY(hipSetDevice(b->device));
     const size_t n = (size_t) b->last_maxb*b->n_ch;
-    HIP_TRY(hipMemcpyAsync(b->h_rec, b->cur_rec  ?  b->cur_rec  :  b->rec, n*sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->h_rec, b->cur_rec  ?  b->cur_rec  :  b->rec, n*sizeof(uint32_t), hipMemcpyDeviceToHost, joined(b)));
     if (b->rec_energy)
-        HIP_TRY(hipMemcpyAsync(b->h_energy, b->rec_energy, n*sizeof(float), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->h_energy, b->rec_energy, n*sizeof(float), hipMemcpyDeviceToHost, joined(b)));
     if (b->rec_dur)
-        HIP_TRY(hipMemcpyAsync(b->h_dur, b->rec_dur, n*sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(hipMemcpyAsync(b->h_dur, b->rec_dur, n*sizeof(int32_t), hipMemcpyDeviceToHost, joined(b)));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     int count = 0;
     const bool bias = (b->kind == SPANGPU_SUPER_TONE);
     for (int ch = 0;  ch < b->n_ch;  ch++)
@@ -1334,7 +1448,7 @@ long long spangpu_bank_copy_records(spangpu_bank_t *b, void *dst_device, size_t 
     if (bytes == 0)
         return 0;
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipMemcpyAsync(dst_device, b->cur_rec  ?  b->cur_rec  :  b->rec, bytes, hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(dst_device, b->cur_rec  ?  b->cur_rec  :  b->rec, bytes, hipMemcpyDeviceToDevice, joined(b)));
     return (long long) bytes;
 }
 
@@ -1369,10 +1483,10 @@ int spangpu_bank_digit_events(spangpu_bank_t *b, uint32_t *dst_device, int cap_e
     if (b->n_ch > (1 << 20)  ||  b->last_maxb > 16)
         return fail(SPANGPU_ERR_UNSUPPORTED, "digit events pack the channel in 20 bits and the block in 4");
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipMemsetAsync(dst_device, 0, sizeof(uint32_t), b->stream));
+    HIP_TRY(hipMemsetAsync(dst_device, 0, sizeof(uint32_t), joined(b)));
     if (b->last_maxb > 0)
     {
-        hipLaunchKernelGGL(digit_events_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, b->stream,
+        hipLaunchKernelGGL(digit_events_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, joined(b),
                            (const uint32_t *) (b->cur_rec  ?  b->cur_rec  :  b->rec), b->n_ch, b->last_maxb, dst_device, cap_entries);
         HIP_TRY(hipGetLastError());
     }
@@ -1389,7 +1503,7 @@ int spangpu_bank_trace(spangpu_bank_t *b, float *energies, size_t max_floats)
     if (n > max_floats)
         return fail(SPANGPU_ERR_BAD_ARG, "trace buffer too small: need %zu floats", n);
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     HIP_TRY(hipMemcpy(energies, b->trace, n*sizeof(float), hipMemcpyDeviceToHost));
     return b->last_maxb;
 }
@@ -1406,7 +1520,7 @@ int spangpu_bank_get_state(spangpu_bank_t *b, int channel, float *fstate, int ma
     if (b == nullptr  ||  channel < 0  ||  channel >= b->n_ch  ||  max_f < b->nsf  ||  max_i < 4)
         return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     HIP_TRY(hipMemcpy2D(fstate, sizeof(float), b->sf + channel, (size_t) b->n_ch*sizeof(float),
                         sizeof(float), b->nsf, hipMemcpyDeviceToHost));
     int32_t w[2];
@@ -1424,7 +1538,7 @@ int spangpu_bank_set_state(spangpu_bank_t *b, int channel, const float *fstate, 
     if (b == nullptr  ||  channel < 0  ||  channel >= b->n_ch  ||  n_f != b->nsf  ||  n_i != 4)
         return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     HIP_TRY(hipMemcpy2D(b->sf + channel, (size_t) b->n_ch*sizeof(float), fstate, sizeof(float),
                         sizeof(float), b->nsf, hipMemcpyHostToDevice));
     int32_t w[2];
@@ -1666,7 +1780,7 @@ static int cadence_event_room(spangpu_bank_t *b, int slots)
     Cadence *c = b->cad;
     if (slots <= c->slots_cap)
         return SPANGPU_OK;
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     if (c->d_ev) (void) hipFree(c->d_ev);
     if (c->h_ev) (void) hipHostFree(c->h_ev);
     if (c->d_list) (void) hipFree(c->d_list);
@@ -1697,7 +1811,7 @@ int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int 
     if (b->kind != SPANGPU_SUPER_TONE)
         return fail(SPANGPU_ERR_UNSUPPORTED, "cadences belong to a super-tone bank");
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     std::vector<int32_t> first(n_tones + 1, 0);
     for (int t = 0;  t < n_tones;  t++)
     {
@@ -1731,7 +1845,7 @@ int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int 
             cadence_free(c);
             return fail(SPANGPU_ERR_NO_MEMORY, "out of device memory for the cadence state");
         }
-        hipLaunchKernelGGL(cadence_init_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, b->stream, c->d_state, b->n_ch, 0, b->n_ch);
+        hipLaunchKernelGGL(cadence_init_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, joined(b), c->d_state, b->n_ch, 0, b->n_ch);
         c->done_serial = b->launch_serial;      // what was received before now is not matched
         b->cad = c;
         const int rc = cadence_event_room(b, kCadSlotsPerBlock*((b->maxb_cap > 2)  ?  b->maxb_cap  :  2));
@@ -1752,7 +1866,7 @@ int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int 
             if (n_elem) (void) hipFree(n_elem);
             return fail(SPANGPU_ERR_NO_MEMORY, "out of device memory for the cadence tables");
         }
-        HIP_TRY(hipStreamSynchronize(b->stream));        // no launch still reads the old ones
+        HIP_TRY(hipStreamSynchronize(joined(b)));        // no launch still reads the old ones
         if (c->d_first) (void) hipFree(c->d_first);
         if (c->d_elem) (void) hipFree(c->d_elem);
         c->d_first = n_first;
@@ -1763,15 +1877,15 @@ int spangpu_bank_set_cadences(spangpu_bank_t *b, const int32_t *tone_elems, int 
         // the tone numbers of the old set mean nothing in the new one: nobody is following a tone (the run histories stay)
         // (-2, not -1: "none, and look at every cadence at the next block" -- the channel may be in the middle of a run that
         // one of the new cadences ends with, see cadence_dev.hpp)
-        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) (c->d_state + (size_t) 2*b->n_ch), (int) 0xFFFFFFFEu, (size_t) b->n_ch, b->stream));
-        HIP_TRY(hipMemsetAsync(c->d_state + (size_t) 3*b->n_ch, 0, (size_t) b->n_ch*sizeof(int32_t), b->stream));
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) (c->d_state + (size_t) 2*b->n_ch), (int) 0xFFFFFFFEu, (size_t) b->n_ch, joined(b)));
+        HIP_TRY(hipMemsetAsync(c->d_state + (size_t) 3*b->n_ch, 0, (size_t) b->n_ch*sizeof(int32_t), joined(b)));
     }
     c->n_tones = n_tones;
     c->n_elems = n_elems;
     for (int t = 0;  t < n_tones  &&  t < kCadLdsTones;  t++)
         c->tone_len[t] = first[t + 1] - first[t];
     c->segments = want_segments  ?  1  :  0;
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     return SPANGPU_OK;
 }
 
@@ -1803,13 +1917,13 @@ int spangpu_bank_cadence_run(spangpu_bank_t *b)
         c->which ^= 1;
         c->list_due = false;
         cadence_args(b, c, A, c->which);
-        hipLaunchKernelGGL(cadence_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, b->stream,
+        hipLaunchKernelGGL(cadence_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, joined(b),
                            (const uint32_t *) (b->cur_rec  ?  b->cur_rec  :  b->rec), b->n_ch, b->last_maxb, A);
         HIP_TRY(hipGetLastError());
     }
     else
     {
-        HIP_TRY(hipMemsetAsync(c->d_count, 0, (size_t) b->n_ch*sizeof(int32_t), b->stream));
+        HIP_TRY(hipMemsetAsync(c->d_count, 0, (size_t) b->n_ch*sizeof(int32_t), joined(b)));
     }
     c->done_serial = b->launch_serial;
     c->last_slots = slots;
@@ -1822,10 +1936,10 @@ int spangpu_bank_cadence_events(spangpu_bank_t *b, const uint32_t **events, cons
     if (slots < 0)
         return slots;
     Cadence *c = b->cad;
-    HIP_TRY(hipMemcpyAsync(c->h_count, c->d_count, (size_t) b->n_ch*sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_count, c->d_count, (size_t) b->n_ch*sizeof(int32_t), hipMemcpyDeviceToHost, joined(b)));
     if (slots > 0)
-        HIP_TRY(hipMemcpyAsync(c->h_ev, c->d_ev, (size_t) slots*b->n_ch*2*sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_ev, c->d_ev, (size_t) slots*b->n_ch*2*sizeof(uint32_t), hipMemcpyDeviceToHost, joined(b)));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     if (events)
         *events = c->h_ev;
     if (counts)
@@ -1847,21 +1961,21 @@ int spangpu_bank_cadence_list(spangpu_bank_t *b, const uint32_t **list)
         c->which ^= 1;
         c->list_due = false;
         cadence_args(b, c, A, c->which);
-        hipLaunchKernelGGL(cadence_list_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, b->stream, b->n_ch, A);
+        hipLaunchKernelGGL(cadence_list_kernel, dim3((b->n_ch + 255)/256), dim3(256), 0, joined(b), b->n_ch, A);
         HIP_TRY(hipGetLastError());
     }
     // as a rule a tick has few reports: one small copy brings the counters and the first of them
     const size_t cap = (size_t) c->slots_cap*b->n_ch;
     const size_t first = (cap < 4096)  ?  cap  :  4096;
-    HIP_TRY(hipMemcpyAsync(c->h_list, c->d_list, (2 + 3*first)*sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_list, c->d_list, (2 + 3*first)*sizeof(uint32_t), hipMemcpyDeviceToHost, joined(b)));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     const size_t n = c->h_list[c->which];
     if (n > cap)
         return fail(SPANGPU_ERR_STATE, "cadence event list overran its buffer");
     if (n > first)
     {
-        HIP_TRY(hipMemcpyAsync(c->h_list + 2 + 3*first, c->d_list + 2 + 3*first, 3*(n - first)*sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_list + 2 + 3*first, c->d_list + 2 + 3*first, 3*(n - first)*sizeof(uint32_t), hipMemcpyDeviceToHost, joined(b)));
+        HIP_TRY(hipStreamSynchronize(joined(b)));
     }
     if (list)
         *list = c->h_list + 2;
@@ -1888,7 +2002,7 @@ int spangpu_bank_cadence_reset(spangpu_bank_t *b, int channel)
     HIP_TRY(hipSetDevice(b->device));
     const int first = (channel < 0)  ?  0  :  channel;
     const int n = (channel < 0)  ?  b->n_ch  :  1;
-    hipLaunchKernelGGL(cadence_init_kernel, dim3((n + 255)/256), dim3(256), 0, b->stream, b->cad->d_state, b->n_ch, first, n);
+    hipLaunchKernelGGL(cadence_init_kernel, dim3((n + 255)/256), dim3(256), 0, joined(b), b->cad->d_state, b->n_ch, first, n);
     HIP_TRY(hipGetLastError());
     return SPANGPU_OK;
 }
@@ -1905,7 +2019,7 @@ int spangpu_bank_cadence_get_state(spangpu_bank_t *b, int channel, int32_t *word
     if (channel < 0  ||  channel >= b->n_ch  ||  words == nullptr)
         return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     HIP_TRY(hipMemcpy2D(words, sizeof(int32_t), b->cad->d_state + channel, (size_t) b->n_ch*sizeof(int32_t), sizeof(int32_t), kCadWords,
                         hipMemcpyDeviceToHost));
     if (words[2] < -1)
@@ -1922,7 +2036,7 @@ int spangpu_bank_cadence_set_state(spangpu_bank_t *b, int channel, const int32_t
     if (words[2] < -1  ||  words[2] >= b->cad->n_tones  ||  words[3] < 0  ||  words[3] > 255)
         return fail(SPANGPU_ERR_BAD_ARG, "state words out of range");
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(joined(b)));
     int32_t w[kCadWords];
     memcpy(w, words, sizeof(w));
     if (w[2] == -1)
@@ -1936,3 +2050,75 @@ int spangpu_bank_cadence_set_state(spangpu_bank_t *b, int channel, const int32_t
 }
 
 }   // extern "C"
+
+// ---- test hook: the two block-end decisions of a detector side by side -----------------------------------------------
+// Det::decide() (the reference's scan, every option) and Det::decide_plain() (the production case of the streaming kernels)
+// on caller-made energies and history words -- ties among the energies, zeros, values either side of every threshold: cases a
+// synthesised signal reaches rarely or never (tests/test_tone_gpu.py: test_lean_block_end_*).  kind: SPANGPU_DTMF, _BELL_MF, _R2_MF.
+// e: [n][8] floats (the MF detectors use the first six), energy / w0 / w1: [n]; out: [6][n] words: record, w0, w1 of decide(), then
+// of decide_plain().  Host pointers.  Not part of the drop-in boundary.
+template <class Det>
+__global__ void debug_decide_kernel(const float *e8, const float *energy, const uint32_t *w0in, const int32_t *w1in, uint32_t *out, int n, const ToneLaunch L)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    float e[Det::NB];
+#pragma unroll
+    for (int k = 0;  k < Det::NB;  k++)
+        e[k] = e8[(size_t) i*8 + k];
+    Det det;
+    det.load_extra(L, 0);
+    float en = energy[i];
+    uint32_t w0 = w0in[i] & 0xFFFF0000u;
+    int32_t w1 = w1in[i];
+    out[i] = det.decide(L, e, en, w0, w1, 0, 0, false);
+    out[(size_t) n + i] = w0;
+    out[(size_t) 2*n + i] = (uint32_t) w1;
+    en = energy[i];
+    w0 = w0in[i] & 0xFFFF0000u;
+    w1 = w1in[i];
+    if constexpr (Det::kLean)
+        out[(size_t) 3*n + i] = det.decide_plain(L, e, en, w0, w1);
+    out[(size_t) 4*n + i] = w0;
+    out[(size_t) 5*n + i] = (uint32_t) w1;
+}
+
+extern "C" __attribute__((visibility("default")))
+int spangpu_debug_decide(int kind, const float *e8, const float *energy, const uint32_t *w0, const int32_t *w1, uint32_t *out, int n)
+{
+    if (e8 == nullptr  ||  energy == nullptr  ||  w0 == nullptr  ||  w1 == nullptr  ||  out == nullptr  ||  n <= 0)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    ToneLaunch L;
+    memset(&L, 0, sizeof(L));
+    L.n_ch = 1;
+    L.threshold = 171029200.0f;         // dtmf.c:104-110
+    L.normal_twist = 6.309f;
+    L.reverse_twist = 2.512f;
+    float *d_e = nullptr, *d_en = nullptr;
+    uint32_t *d_w0 = nullptr, *d_out = nullptr;
+    int32_t *d_w1 = nullptr;
+    HIP_TRY(hipMalloc(&d_e, (size_t) n*8*sizeof(float)));
+    HIP_TRY(hipMalloc(&d_en, (size_t) n*sizeof(float)));
+    HIP_TRY(hipMalloc(&d_w0, (size_t) n*4));
+    HIP_TRY(hipMalloc(&d_w1, (size_t) n*4));
+    HIP_TRY(hipMalloc(&d_out, (size_t) n*6*4));
+    HIP_TRY(hipMemcpy(d_e, e8, (size_t) n*8*sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_en, energy, (size_t) n*sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_w0, w0, (size_t) n*4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_w1, w1, (size_t) n*4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_out, 0, (size_t) n*6*4));
+    const dim3 grid((n + 255)/256), block(256);
+    if (kind == SPANGPU_DTMF)
+        hipLaunchKernelGGL(debug_decide_kernel<DtmfDet<false>>, grid, block, 0, 0, d_e, d_en, d_w0, d_w1, d_out, n, L);
+    else if (kind == SPANGPU_BELL_MF)
+        hipLaunchKernelGGL(debug_decide_kernel<BellMfDet>, grid, block, 0, 0, d_e, d_en, d_w0, d_w1, d_out, n, L);
+    else if (kind == SPANGPU_R2_MF)
+        hipLaunchKernelGGL(debug_decide_kernel<R2MfDet>, grid, block, 0, 0, d_e, d_en, d_w0, d_w1, d_out, n, L);
+    else
+        return fail(SPANGPU_ERR_UNSUPPORTED, "no lean block end for detector kind %d", kind);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_out, (size_t) n*6*4, hipMemcpyDeviceToHost));
+    (void) hipFree(d_e); (void) hipFree(d_en); (void) hipFree(d_w0); (void) hipFree(d_w1); (void) hipFree(d_out);
+    return SPANGPU_OK;
+}

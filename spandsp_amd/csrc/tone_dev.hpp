@@ -75,6 +75,8 @@ struct ToneLaunch
                                 // per channel, [4][n_ch]: threshold, normal twist, reverse twist, filter on (0 / 1)
     CadenceArgs cad;            // super-tone: cad.state != nullptr has the streaming kernel built with kToneCadence match
                                 // the cadences in its epilogue (cadence_dev.hpp)
+    int wg0;                    // streaming kernels: the launch covers workgroups wg0 .. wg0 + wgn - 1 of the bank (wgn = 0: all of
+    int wgn;                    // them) -- a bank in queue mode is advanced by two launches on two streams (spangpu_api.hip)
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -393,6 +395,18 @@ __device__ __forceinline__ float vmax3(float a, float b, float c)
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ float vmin3(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmed3(float a, float b, float c)
+{
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 // ---- DTMF (src/dtmf.c:132-361) ------------------------------------------------------
 template <bool FILTER>
@@ -549,7 +563,7 @@ struct DtmfDet
         const float s = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
         return s == s;          // a NaN anywhere, or infinities of both signs, make the sum a NaN
     }
-    __device__ __forceinline__ uint32_t decide_plain(const ToneLaunch &L, const float (&e)[NB], float &energy, uint32_t &w0)
+    __device__ __forceinline__ uint32_t decide_plain(const ToneLaunch &L, const float (&e)[NB], float &energy, uint32_t &w0, int32_t &)
     {
         // (asm: written with the builtins, hipcc canonicalises every operand first -- a v_max_f32 x, x each -- for the
         // signalling NaNs the caller has already excluded)
@@ -644,9 +658,73 @@ __device__ __forceinline__ int mf_pick_pair(const float (&e)[6], float threshold
     return lo*5 + hi - 1;
 }
 
+// The same pick for the production case, on energies the caller knows to be ordinary numbers (no NaN), as the key it
+// leads to (0 = no digit), without the scan:
+//   * the tests need three VALUES only -- the largest, the runner-up and the third of the six (two sorted triples merged:
+//     v_max3 / v_med3 / v_min3).  "Some tone that is neither of the two within rel_peak of the runner-up" is one test on the
+//     third: x -> fl(x*rel_peak) is monotonic, so if any tone passes it the largest of them does;
+//   * WHICH tones the two are matters only when every test has passed, and then the third is strictly below the runner-up
+//     (fl(e3*rel_peak) < es with es >= threshold > 0 and rel_peak > 1), so exactly two tones satisfy e[i] >= es -- the pair,
+//     whatever the reference's >= tie-breaks (bell_r2_mf.c:567-581) did among equal values: the key depends on the
+//     unordered pair only (:642-644 here, lo*5 + hi - 1).
+// The key table is five words, one per lower tone of the pair, holding the keys of the upper tones 2..5 in bytes 0..3; the pair
+// (0, 1) has a constant of its own.  `tab` is the 25-character table of the reference (bell_mf_positions / r2_mf_positions).
+constexpr uint32_t mf_row_word(const char *tab, int lo)
+{
+    uint32_t w = 0;
+    for (int hi = 2;  hi <= 5;  hi++)
+    {
+        if (hi > lo)
+            w |= (uint32_t) (uint8_t) tab[lo*5 + hi - 1] << (8*(hi - 2));
+    }
+    return w;
+}
+
+template <class Tab>
+__device__ __forceinline__ uint32_t mf_pick_key_lean(const float (&e)[6], float threshold, float twist, float rel_peak)
+{
+    const float ha = vmax3(e[0], e[1], e[2]);
+    const float ma = vmed3(e[0], e[1], e[2]);
+    const float la = vmin3(e[0], e[1], e[2]);
+    const float hb = vmax3(e[3], e[4], e[5]);
+    const float mb = vmed3(e[3], e[4], e[5]);
+    const float lb = vmin3(e[3], e[4], e[5]);
+    const float eb = vmax(ha, hb);
+    const float es = vmax3(vmin(ha, hb), ma, mb);
+    const float e3 = vmax(vmax3(la, lb, vmin(ma, hb)), vmin(ha, mb));
+    bool ok = (eb >= threshold)  &  (es >= threshold)  &  (eb < es*twist)  &  (eb*twist > es);
+    ok = ok  &  !(e3*rel_peak >= es);
+    constexpr uint32_t w0 = mf_row_word(Tab::str(), 0);
+    constexpr uint32_t w1 = mf_row_word(Tab::str(), 1);
+    constexpr uint32_t w2 = mf_row_word(Tab::str(), 2);
+    constexpr uint32_t w3 = mf_row_word(Tab::str(), 3);
+    constexpr uint32_t w4 = mf_row_word(Tab::str(), 4);
+    constexpr uint32_t k01 = (uint8_t) Tab::str()[0];
+    const bool c0 = e[0] >= es;
+    const bool c1 = e[1] >= es;
+    const bool c2 = e[2] >= es;
+    const bool c3 = e[3] >= es;
+    const bool c4 = e[4] >= es;
+    const bool c5 = e[5] >= es;
+    // (selects, not branches: all lanes are here)
+    uint32_t row = __builtin_unpredictable(c3)  ?  w3  :  w4;
+    row = __builtin_unpredictable(c2)  ?  w2  :  row;
+    row = __builtin_unpredictable(c1)  ?  w1  :  row;
+    row = __builtin_unpredictable(c0)  ?  w0  :  row;
+    uint32_t sh = __builtin_unpredictable(c3)  ?  8u  :  0u;
+    sh = __builtin_unpredictable(c4)  ?  16u  :  sh;
+    sh = __builtin_unpredictable(c5)  ?  24u  :  sh;
+    uint32_t key = (row >> sh) & 0xFFu;
+    key = __builtin_unpredictable(c0  &  c1)  ?  k01  :  key;
+    return ok  ?  key  :  0u;
+}
+
+struct BellMfTab { __device__ __host__ static constexpr const char *str() { return "1247C-358A--69*---0B----#"; } };     // bell_r2_mf.c:262
+struct R2MfTab { __device__ __host__ static constexpr const char *str() { return "1247B-358C--69D---0E----F"; } };       // bell_r2_mf.c:276
+
 struct BellMfDet
 {
-    static constexpr bool kLean = false;
+    static constexpr bool kLean = true;
     static constexpr int NB = 6;
     static constexpr bool kEnergy = false;
     static constexpr bool kDuration = false;
@@ -695,11 +773,31 @@ struct BellMfDet
         w1 = (int32_t) ((uint32_t) h3 | ((uint32_t) h4 << 8) | ((uint32_t) hit << 16));
         return make_rec(hit, code, flags);
     }
+
+    // The production case (no trace asked for; the streaming kernels test that once per launch): the pick without the scan
+    // (mf_pick_key_lean) and the five-block rule of bell_r2_mf.c:629-635 on the packed history words as they are.
+    __device__ __forceinline__ uint32_t decide_plain(const ToneLaunch &, const float (&e)[NB], float &, uint32_t &w0, int32_t &w1)
+    {
+        const uint32_t hit = mf_pick_key_lean<BellMfTab>(e, 3343803100.0f, 3.981f, 12.589f);
+        const uint32_t u1 = (uint32_t) w1;
+        const uint32_t h0 = (w0 >> 16) & 0xFFu;
+        const uint32_t h1 = w0 >> 24;
+        const uint32_t h2 = u1 & 0xFFu;
+        const uint32_t h34 = (u1 >> 8) & 0xFFFFu;
+        const bool star = (hit == (uint32_t) '*');
+        bool rep = (hit != 0)  &  (h34 == hit*0x0101u)  &  (hit != h1);
+        rep = rep  &  (star  ?  ((hit == h2)  &  (hit != h0))  :  (hit != h2));
+        const uint32_t code = rep  ?  hit  :  0u;
+        const uint32_t flags = rep  ?  (uint32_t) (kBlkValid | kBlkReport)  :  (uint32_t) kBlkValid;
+        w0 = (h1 << 16) | (h2 << 24);                                   // bell_r2_mf.c:657-661; cs = 0
+        w1 = (int32_t) (h34 | (hit << 16));
+        return hit | (code << 8) | (flags << 16);
+    }
 };
 
 struct R2MfDet
 {
-    static constexpr bool kLean = false;
+    static constexpr bool kLean = true;
     static constexpr int NB = 6;
     static constexpr bool kEnergy = false;
     static constexpr bool kDuration = false;
@@ -730,6 +828,14 @@ struct R2MfDet
             flags |= kBlkReport;                                    // bell_r2_mf.c:869-875
         w0 = (uint32_t) digit << 16;
         return make_rec(digit, digit, flags);
+    }
+
+    __device__ __forceinline__ uint32_t decide_plain(const ToneLaunch &, const float (&e)[NB], float &, uint32_t &w0, int32_t &)
+    {
+        const uint32_t digit = mf_pick_key_lean<R2MfTab>(e, 1031766650.0f, 5.012f, 12.589f);
+        const uint32_t flags = (((w0 >> 16) & 0xFFu) != digit)  ?  (uint32_t) (kBlkValid | kBlkReport)  :  (uint32_t) kBlkValid;      // bell_r2_mf.c:869-875
+        w0 = digit << 16;
+        return digit | (digit << 8) | (flags << 16);
     }
 };
 

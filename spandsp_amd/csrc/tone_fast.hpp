@@ -605,7 +605,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         if (lean)
         {
             if constexpr (Det::kLean)
-                recw = det.decide_plain(L, e, energy, w0);
+                recw = det.decide_plain(L, e, energy, w0, w1);
         }
         else
         {
@@ -951,7 +951,7 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
 // segment first.
 template <class Det, int LPC, int R, bool G711, bool NT, int WPB, int ABL = 0, bool LDR = false>
 __global__ __launch_bounds__(kWave*(WPB + (LDR  ?  1  :  0))) __attribute__((amdgpu_waves_per_eu(LDR  ?  2  :  3)))
-void tone_fast_kernel(const int16_t *amp, long long stride, int samples, int n_ch, int layout, int aligned16,
+void tone_fast_kernel(const int16_t *amp, long long stride, int samples, int n_ch, int wg0, int aligned16,
                       float *sf, int32_t *si, uint32_t *rec, const ToneLaunch L0)
 {
     __shared__ __attribute__((aligned(1024))) char lds_raw[FastLds<LPC, R, G711, WPB>::kBytes];
@@ -960,12 +960,13 @@ void tone_fast_kernel(const int16_t *amp, long long stride, int samples, int n_c
     L.stride = stride;
     L.samples = samples;
     L.n_ch = n_ch;
-    L.layout = layout;
+    L.layout = 0;               // (a precondition of this kernel; its slot among the preloaded arguments carries wg0)
     L.aligned16 = aligned16;
     L.sf = sf;
     L.si = si;
     L.rec = rec;
-    tone_fast_body<Det, LPC, R, G711, NT, WPB, ABL, LDR>(L, (int) blockIdx.x, lds_raw);
+    // (wg0: the first workgroup of the bank this launch covers -- a bank in queue mode is advanced by two launches)
+    tone_fast_body<Det, LPC, R, G711, NT, WPB, ABL, LDR>(L, (int) blockIdx.x + wg0, lds_raw);
 }
 
 // Host-side launch of tone_fast_kernel (argument order above).
@@ -973,7 +974,7 @@ template <class Det, int LPC, int R, bool G711, bool NT, int WPB, int ABL = 0, b
 static inline void launch_tone_fast(const ToneLaunch &L, int blocks, hipStream_t st)
 {
     hipLaunchKernelGGL((tone_fast_kernel<Det, LPC, R, G711, NT, WPB, ABL, LDR>), dim3(blocks), dim3(kWave*(WPB + (LDR  ?  1  :  0))), 0, st,
-                       L.amp, L.stride, L.samples, L.n_ch, L.layout, L.aligned16, L.sf, L.si, L.rec, L);
+                       L.amp, L.stride, L.samples, L.n_ch, L.wg0, L.aligned16, L.sf, L.si, L.rec, L);
 }
 
 // Several banks in ONE launch (see tone_multi_kernel in tone_dev.hpp): workgroups [first[k], first[k + 1]) belong to

@@ -66,6 +66,8 @@ def lib():
             "spangpu_bank_kind": (ci, [vp]),
             "spangpu_bank_channels": (ci, [vp]),
             "spangpu_bank_set_stream": (ci, [vp, vp]),
+            "spangpu_bank_set_queues": (ci, [vp, ci]),
+            "spangpu_bank_join": (ci, [vp]),
             "spangpu_bank_rx": (ci, [vp, vp, ci, ci, ci, ll]),
             "spangpu_bank_rx_var": (ci, [vp, vp, ci, vp, ci, ll]),
             "spangpu_bank_set_channel_params": (ci, [vp, ci, vp, C.c_size_t]),
@@ -352,6 +354,18 @@ class ToneBank:
 
     def set_stream(self, hip_stream):
         _check(lib().spangpu_bank_set_stream(self.h, hip_stream))
+
+    def set_queues(self, queues):
+        """Queue mode (spangpu_bank_set_queues): 2 = the streaming kernel's launch cut in two on two hardware queues, 1 = one
+        launch, 0 = the library's choice.  Returns the number in use."""
+        rc = lib().spangpu_bank_set_queues(self.h, int(queues))
+        if rc < 0:
+            _check(rc)
+        return rc
+
+    def join(self):
+        """Make the bank's stream wait for the second queue's last launch (before work of the caller's own on that stream)."""
+        _check(lib().spangpu_bank_join(self.h))
 
     def share_stream(self, other):
         """Launch on the same HIP stream as `other` (needed for banks that share a launch)."""

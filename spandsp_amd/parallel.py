@@ -70,6 +70,8 @@ class ResultGather:
         self.aimed = False
         self.count += 1
         if sub == self.every - 1:
+            if hasattr(bank, "join"):
+                bank.join()             # a bank in queue mode: its second stream's launches are behind the collective too
             self._start(slot)
 
     def drain(self):
@@ -118,6 +120,8 @@ class DigitGather(ResultGather):
         slot, sub = self._claim()
         self.count += 1
         if sub == self.every - 1:
+            if hasattr(bank, "join"):
+                bank.join()             # a bank in queue mode: its second stream's launches are behind the collective too
             self._start(slot)
 
     def digits(self):

@@ -893,3 +893,176 @@ def test_g711_input_equals_decoded_linear_input(built, law):
             fb, ib = b.get_state(c)
             assert np.array_equal(f32_bits(fa), f32_bits(fb)) and np.array_equal(ia, ib), (kind, c)
         assert hits > 50
+
+
+# --------------------------------------------------------------------------------------
+# Round 5: the production block ends of the MF detectors, queue mode, banks on streams of their own
+# --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["dtmf", "bell", "r2"])
+def test_lean_block_end_equals_the_scan(built, kind, lanes_per_channel):
+    """Det::decide_plain() (what the streaming kernels run when nothing but the decision is asked for) against Det::decide()
+    (the reference's scans with their tie-breaks: dtmf.c:209-258, bell_r2_mf.c:556-661,793-876) on energies a synthesised
+    signal rarely produces: equal values in every position, zeros, values a rounding away from every threshold and ratio, and
+    every history the debounce / five-block rules can be in.  Record word and both state words, bit for bit."""
+    from spandsp_amd import engine
+    if lanes_per_channel != 1:
+        pytest.skip("one run is enough: the hook does not go through the bank kernels")
+    L = engine.lib()
+    L.spangpu_debug_decide.restype = C.c_int
+    L.spangpu_debug_decide.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(1234)
+    n = 400000
+    thr = {"dtmf": 171029200.0, "bell": 3343803100.0, "r2": 1031766650.0}[kind]
+    levels = np.array([0.0, thr*0.01, thr/12.589, thr/6.309, thr*0.5, thr, thr*1.5, thr*2.512, thr*3.981, thr*5.012, thr*6.309,
+                       thr*12.589, thr*40.0, thr*83.868], np.float32)
+    e = np.empty((n, 8), np.float32)
+    # a third: values from a small set of levels (ties everywhere); a third: the same, each a few ulps off; a third: log-uniform
+    third = n//3
+    e[:third] = levels[rng.integers(0, len(levels), (third, 8))]
+    base = levels[rng.integers(0, len(levels), (third, 8))]
+    e[third:2*third] = (base.view(np.uint32) + rng.integers(-2, 3, (third, 8)).astype(np.int64)).clip(0, 0x7F000000).astype(np.uint32).view(np.float32)
+    e[2*third:] = (thr*np.exp(rng.uniform(-6.0, 6.0, (n - 2*third, 8)))).astype(np.float32)
+    # mostly two-tone shapes: push all but two (MF) / one per group (DTMF) down in half of the cases
+    quiet = rng.random(n) < 0.5
+    for i in np.nonzero(quiet)[0][:n//4]:
+        keep = rng.choice(6, 2, replace=False) if kind != "dtmf" else np.array([rng.integers(0, 4), 4 + rng.integers(0, 4)])
+        m = np.ones(8, bool)
+        m[keep] = False
+        e[i, m] *= np.float32(1.0e-3)
+    energy = (e[:, :8].sum(axis=1)*rng.choice([0.001, 1.0/83.868, 0.012, 0.02], n)).astype(np.float32)
+    keys = {"dtmf": b"\x00123A456B789C*0#D", "bell": b"\x00123456789*0#ABC", "r2": b"\x00123456789BCDEF"}[kind]
+    pick = lambda: np.frombuffer(keys, np.uint8)[rng.integers(0, len(keys), n)].astype(np.uint32)
+    w0 = (pick() << 16) | (pick() << 24) | rng.integers(0, 102, n).astype(np.uint32)
+    w1 = (pick() | (pick() << 8) | (pick() << 16)).astype(np.int32) if kind == "bell" else rng.integers(0, 100000, n).astype(np.int32)
+    # histories that agree with each other, so that reports happen: copy one key into several positions for a quarter of the cases
+    same = rng.random(n) < 0.25
+    k = pick()
+    w0 = np.where(same, (w0 & 0xFFFF) | (k << 16) | (k << 24), w0).astype(np.uint32)
+    if kind == "bell":
+        w1 = np.where(same & (rng.random(n) < 0.7), (k | (k << 8) | (k << 16)).astype(np.int32), w1).astype(np.int32)
+    out = np.zeros((6, n), np.uint32)
+    kid = {"dtmf": engine.DTMF, "bell": engine.BELL_MF, "r2": engine.R2_MF}[kind]
+
+    def both(w0, w1):
+        w0 = np.ascontiguousarray(w0, np.uint32)
+        w1 = np.ascontiguousarray(w1, np.int32)
+        rc = L.spangpu_debug_decide(kid, e.ctypes.data, energy.ctypes.data, w0.ctypes.data, w1.ctypes.data, out.ctypes.data, n)
+        assert rc == 0, L.spangpu_last_error()
+        bad = np.nonzero((out[0] != out[3]) | (out[1] != out[4]) | (out[2] != out[5]))[0]
+        assert bad.size == 0, (kind, bad[:5], e[bad[:2]], [hex(int(x)) for x in out[:, bad[0]]])
+        return int(((out[0] & 0xFF) != 0).sum()), int((((out[0] >> 16) & engine.BLK_REPORT) != 0).sum())
+    hits, _ = both(w0, w1)
+    assert hits > n//100, hits
+    # again with histories built around the hit each case produced, so that the debounce / five-block / change rules fire:
+    # the hit in the newest positions, the older ones the hit or something else
+    hit = (out[0] & 0xFF).astype(np.uint32)
+    other = pick()
+    a = np.where(rng.random(n) < 0.5, hit, other).astype(np.uint32)
+    b = np.where(rng.random(n) < 0.5, hit, other).astype(np.uint32)
+    c = np.where(rng.random(n) < 0.3, hit, pick()).astype(np.uint32)
+    if kind == "bell":
+        hits, reports = both((c << 16) | (b << 24), (a | (hit << 8) | (hit << 16)).astype(np.int32))      # hits[0..4] = c, b, a, hit, hit
+    else:
+        hits, reports = both((a << 16) | (b << 24), w1)                                                     # last_hit / current = a, in_digit = b
+    assert hits > n//100 and reports > n//50, (hits, reports)
+
+
+def test_queue_mode_equals_one_launch(built, lanes_per_channel):
+    """spangpu_bank_set_queues(bank, 2): the streaming kernel's launch cut in two on two hardware queues leaves the records
+    and the state of one launch, with launches of the other kind (sample-major frames: the general kernel), state reads and a
+    parameter change in between -- every one of which has to join the second queue first."""
+    from spandsp_amd import engine
+    n_ch = 2048 + 70                    # nine workgroups: four on the bank's stream, five on the second
+    n_frames = 40
+    sig, _ = synth.dtmf_channels(n_ch, 160*n_frames, seed=91)
+    one = engine.ToneBank(engine.DTMF, n_ch)
+    two = engine.ToneBank(engine.DTMF, n_ch)
+    assert two.set_queues(2) == 2 and one.set_queues(0) == 1 and one.set_queues(1) == 1
+    total = 0
+    for k in range(n_frames):
+        fr = sig[:, k*160:(k + 1)*160]
+        for b in (one, two):
+            if k % 7 == 3:
+                b.rx_host(np.ascontiguousarray(fr.T), layout=1)
+            else:
+                b.rx_host(fr)
+        r0 = one.blocks()
+        r1 = two.blocks()
+        assert r0.tobytes() == r1.tobytes(), k
+        total += int(((r0["flags"] & engine.BLK_CHANGE) != 0).sum())
+        if k % 5 == 4:
+            for c in (0, 1023, 1024, n_ch - 1):
+                f0, i0 = one.get_state(c)
+                f1, i1 = two.get_state(c)
+                assert np.array_equal(f32_bits(f0), f32_bits(f1)) and np.array_equal(i0, i1), (k, c)
+        if k == 20:
+            for b in (one, two):
+                b.set_channel_params(1500, threshold_dbm0=-30.0)
+    assert total > n_ch//2
+    assert two.set_queues(1) == 1
+    two.rx_host(sig[:, :160])
+    one.rx_host(sig[:, :160])
+    assert one.blocks().tobytes() == two.blocks().tobytes()
+
+
+def test_banks_on_streams_of_their_own(built, lanes_per_channel):
+    """spangpu_banks_rx() with banks that were given streams of their own: a launch each, every one on its bank's stream --
+    the records and state of the shared launch."""
+    import ctypes
+    from spandsp_amd import engine
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), a.nbytes) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data, a.nbytes, 1) == 0
+        return p
+    n = [300, 131, 257]
+    n_frames = 30
+    sigs = [synth.bell_mf_channels(n[0], 160*n_frames, seed=52)[0], synth.r2_mf_channels(n[1], 160*n_frames, seed=53, fwd=True)[0],
+            synth.call_progress_channels(n[2], 160*n_frames, seed=54)]
+    fac = [engine.goertzel_fac(f) for f in (350.0, 400.0, 440.0, 480.0, 620.0, 950.0, 1100.0, 1400.0)]
+
+    def make():
+        return [engine.ToneBank(engine.BELL_MF, n[0]), engine.ToneBank(engine.R2_MF, n[1], r2_fwd=True),
+                engine.ToneBank(engine.SUPER_TONE, n[2], bin_fac=fac)]
+    shared = make()
+    for b in shared[1:]:
+        b.share_stream(shared[0])
+    own = make()
+    streams = []
+    for b in own:
+        s = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0           # hipStreamNonBlocking
+        streams.append(s)
+        b.set_stream(s)
+    dev = [[to_device(x[:, k*160:(k + 1)*160]) for x in sigs] for k in range(n_frames)]
+    # the banks on their own streams run all their ticks before anything is read: the queues run free
+    for k in range(n_frames):
+        engine.banks_rx_device(own, [f.value for f in dev[k]], 160)
+    last = [b.blocks() for b in own]
+    for k in range(n_frames):
+        engine.banks_rx_device(shared, [f.value for f in dev[k]], 160)
+    hits = 0
+    for b0, b1, r1, nn in zip(shared, own, last, n):
+        r0 = b0.blocks()
+        assert r0.tobytes() == r1.tobytes()
+        hits += int((r0["hit"] != 0).sum())
+        for c in (0, nn//2, nn - 1):
+            f0, i0 = b0.get_state(c)
+            f1, i1 = b1.get_state(c)
+            assert np.array_equal(f32_bits(f0), f32_bits(f1)) and np.array_equal(i0, i1), c
+    assert hits > 20
+    for b in own:
+        b.close()
+    for s in streams:
+        hip.hipStreamDestroy(s)
+    for fr in dev:
+        for f in fr:
+            hip.hipFree(f)

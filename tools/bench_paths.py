@@ -551,41 +551,75 @@ def bench_mixed(args, dev, stream):
     fac = [engine.goertzel_fac(f) for f in st_freqs]
     banks = [engine.ToneBank(engine.BELL_MF, n_each[0]), engine.ToneBank(engine.R2_MF, n_each[1], r2_fwd=True),
              engine.ToneBank(engine.SUPER_TONE, n_each[2], bin_fac=fac)]
-    for b in banks:
-        b.set_stream(ctypes.c_void_p(stream.cuda_stream))
-
-    fused = not args.separate_launches
+    # Three ways to run a tick (results identical: tests/test_tone_gpu.py): ONE launch for the three banks on one stream
+    # (tone_multi_fast_kernel); a launch per bank, every bank free-running on a stream (= hardware queue) of its own -- one
+    # bank's launch boundary, start burst and write-back under the other banks' steady state; the banks share nothing and the
+    # host joins the streams when it reads records -- which is how the step is timed unless --one-launch is given; and, for
+    # the record, a launch per bank on one stream (--separate-launches).  spangpu_banks_rx() does the first or the second
+    # according to the streams the banks were given.
+    mode = "separate" if args.separate_launches else "one_launch" if getattr(args, "one_launch", False) else "bank_streams"
+    own = [torch.cuda.Stream(device=dev) for _ in banks]
     plan = engine.BanksPlan(banks)
     handles = [plan.frame([frames[kind].data_ptr() + f*n_each[kind]*FRAME*2 for kind in range(3)]) for f in range(nf)]
     addr = [[ctypes.c_void_p(frames[kind].data_ptr() + f*n_each[kind]*FRAME*2) for kind in range(3)] for f in range(nf)]
 
-    def step(i):
-        if fused:
+    def set_mode(m):
+        torch.cuda.synchronize()
+        for b, s in zip(banks, own):
+            b.set_stream(ctypes.c_void_p((s if m == "bank_streams" else stream).cuda_stream))
+
+    def step(i, m):
+        if m == "separate":
+            for kind in range(3):
+                banks[kind].rx_device(addr[i % nf][kind], FRAME, FRAME)
+        else:
             plan.rx(handles[i % nf], FRAME)
-            return
-        for kind in range(3):
-            banks[kind].rx_device(addr[i % nf][kind], FRAME, FRAME)
+
+    def timed(m, n_steps):
+        """(wall seconds, milliseconds by events on `stream` with the banks' own streams forked from and joined into it)"""
+        set_mode(m)
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        if m == "bank_streams":
+            for s in own:
+                s.wait_event(ev0)
+        for i in range(n_steps):
+            step(timed.pos + i, m)
+        if m == "bank_streams":
+            for s in own:
+                e = torch.cuda.Event()
+                e.record(s)
+                stream.wait_event(e)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        timed.pos += n_steps
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1)
+    timed.pos = 0
+
+    set_mode(mode)
     kept = [[] for _ in range(3)]
     v = 64
     for i in range(args.warmup):
-        step(i)
+        step(i, mode)
         if i < 20 and not args.no_cpu_baseline:
             for kind in range(3):
                 b = banks[kind].blocks()
                 kept[kind].append(b[b["channel"] < v].copy())
+    timed.pos = args.warmup
     torch.cuda.synchronize()
-    # the launch duration: HIP events on the launch stream around the whole timed region / launches in it
+    # the step: HIP events around the whole timed region / steps in it
     reps = max(1, int(np.ceil(2000/args.steps)))
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for i in range(args.steps*reps):
-        step(args.warmup + i)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0)/reps
-    avg_ms = ev0.elapsed_time(ev1)/(args.steps*reps)
+    one_launch_us = None
+    if mode == "bank_streams":
+        timed("one_launch", 200)
+        one_launch_us = timed("one_launch", args.steps*reps)[1]/(args.steps*reps)*1e3     # the per-launch figure of the one-launch form
+        timed(mode, 200)
+    dt, ms = timed(mode, args.steps*reps)
+    dt /= reps
+    avg_ms = ms/(args.steps*reps)
+    fused = mode == "one_launch"
     hits = [int((b.blocks()["hit"] != 0).sum()) for b in banks]
     alg_read = n_each[0]*(320 + 64) + n_each[1]*(320 + 64) + n_each[2]*(320 + 8*8 + 160)       # SURVEY 8(d)
     value = args.steps*n_ch*FRAME/dt/1e6
@@ -625,10 +659,13 @@ def bench_mixed(args, dev, stream):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[2]: %d Bell MF + %d R2 MF + %d super-tone (8 bins) channels x %d-sample "
                                "frames, %s" % (n_each[0], n_each[1], n_each[2], FRAME,
-                                                "one launch per step (spangpu_banks_rx)" if fused else "three launches per step"),
+                                                {"one_launch": "one launch per step (spangpu_banks_rx, the banks on one stream)",
+                                                 "bank_streams": "a launch per bank and step, every bank on a stream of its own (spangpu_banks_rx)",
+                                                 "separate": "three launches per step on one stream"}[mode]),
                    "channels_per_gpu": n_ch, "blocks_with_a_hit_in_last_step": hits},
         "roofline": {"bound": "hbm", "kernel": "tone_multi_fast_kernel (Bell MF + R2 MF + super-tone workgroups in one launch)" if fused
-                               else "tone_fast_kernel<BellMfDet | R2MfDet | MultiDet<8, true>> (3 launches)",
+                               else "tone_fast_kernel<BellMfDet | R2MfDet | MultiDet<8, true>> (3 launches%s)" % (" on 3 streams" if mode == "bank_streams" else ""),
+                     "one_launch_us": one_launch_us,
                      "achieved": alg_read/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
                      "alg_read_bytes_per_launch": alg_read, "avg_launch_us": avg_ms*1e3,
@@ -1153,7 +1190,7 @@ def paths_for_bench(dev, stream, no_cpu_baseline=False, stream_peak=None, echo_s
     a spot check of 64 channels against the oracle.  Bounded: a few tens of seconds in all."""
     import types
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    base = dict(channels=0, warmup=0, no_cpu_baseline=no_cpu_baseline, echo_lanes=0, separate_launches=False, cpu_channels=4096,
+    base = dict(channels=0, warmup=0, no_cpu_baseline=no_cpu_baseline, echo_lanes=0, separate_launches=False, one_launch=False, cpu_channels=4096,
                 fsk_waves=0, modem_mapping=0, replay_fixture=False, echo_seconds=echo_seconds, cpu_seconds=0.7)
     out = {}
     t0 = time.perf_counter()
@@ -1200,6 +1237,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--echo-lanes", type=int, default=0, help="echo: lanes per channel (0 = the library's choice; 2, 4, 8, 16 for A-B runs)")
     ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
+    ap.add_argument("--one-launch", action="store_true", help="mixed: time the one-launch form (the banks on one stream) instead of a launch per bank on streams of their own")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     ap.add_argument("--fsk-waves", type=int, default=0,
                     help="fsk / mct / sigtone: 0 = the library's choice, 1 = one wavefront per 64 receivers, 2 = two (A-B runs)")

@@ -1,0 +1,111 @@
+# Round 5 measurements (run on the GPU box through gpurun): bash tools/gpu_round5.sh <what> [...]
+# Everything lands under gpurun_out/r5/; the summaries that are judged are copied into profiles/ (r5_*).
+cd $GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT/gpurun_out/r5
+mkdir -p $R
+export TMPDIR=/tmp
+for what in "$@"; do
+case "$what" in
+mq)
+  # sub-banks on hardware queues of their own (tools/probe8.hip): the product kernel, K = 1, 2, 4, 8
+  { echo "### tools/probe8 65536"; timeout 400 ./tools/probe8 65536 2000 5; } > $R/probe_mq.log 2>&1
+  { echo "### tools/probe8 131072"; timeout 300 ./tools/probe8 131072 1000 3; } >> $R/probe_mq.log 2>&1
+  cat $R/probe_mq.log
+  ;;
+mq_trace)
+  cd /tmp
+  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $R/mq_trace -- $GRAFT_REPO_ROOT/tools/probe8 65536 200 1 trace > $R/mq_trace.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python3 tools/trace_overlap.py $(ls $R/mq_trace/*/*kernel_trace.csv | head -1) > $R/mq_trace_overlap.txt 2>&1
+  cat $R/mq_trace_overlap.txt
+  rm -rf $R/mq_trace
+  ;;
+hbm)
+  # FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) of the dominant kernel of every BASELINE path
+  cd /tmp
+  for w in ${HBM_W:-mixed v29 echo v17 v27ter}; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/hbm_${w}_$c -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 40 --no-cpu-baseline --no-e2e --echo-seconds 2 > $R/hbm_${w}_$c.log 2>&1
+      echo "$w $c rc=$?"
+    done
+  done
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/hbm_dtmf_FETCH_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-paths > $R/hbm_dtmf_FETCH_SIZE.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/hbm_dtmf_WRITE_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-paths > $R/hbm_dtmf_WRITE_SIZE.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  python3 tools/hbm_summary.py $R > $R/hbm_traffic_raw.json
+  cat $R/hbm_traffic_raw.json
+  find $R -mindepth 1 -maxdepth 1 -type d -name 'hbm_*' -exec rm -rf {} +
+  ;;
+calib)
+  # what FETCH_SIZE / WRITE_SIZE report for 1 GiB moved in the access patterns of this repository's kernels (tools/probe_fetch.hip)
+  cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/calib_$c -- $GRAFT_REPO_ROOT/tools/probe_fetch > $R/calib_$c.log 2>&1
+  done
+  cd $GRAFT_REPO_ROOT
+  python3 - <<'PY' > $R/hbm_calibration.json
+import csv, glob, collections, json
+out = collections.OrderedDict()
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob("gpurun_out/r5/calib_%s/*/*counter_collection.csv" % c):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == c:
+                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            out.setdefault(k, {})[c] = {"launches": len(v), "mean_KiB": sum(v)/len(v), "bytes_moved": 1 << 30,
+                                          "reported_over_moved": sum(v)/len(v)*1024.0/(1 << 30)}
+print(json.dumps(out, indent=1))
+PY
+  cat $R/hbm_calibration.json
+  rm -rf $R/calib_FETCH_SIZE $R/calib_WRITE_SIZE
+  ;;
+mq_big)
+  { echo "### tools/probe8 1048576"; timeout 400 ./tools/probe8 1048576 200 3; } > $R/probe_mq_1M.log 2>&1
+  { echo "### tools/probe8 262144"; timeout 300 ./tools/probe8 262144 500 3; } >> $R/probe_mq_1M.log 2>&1
+  cat $R/probe_mq_1M.log
+  ;;
+mixed_streams)
+  cd /tmp
+  for v in "" "--one-launch" "--separate-launches"; do
+    echo "### mixed $v"
+    timeout 200 python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload mixed --no-cpu-baseline --no-e2e $v > $R/mixed_try.json 2> $R/mixed_try.err
+    grep -o '"avg_launch_us": [0-9.]*\|"ms_per_step": [0-9.]*' $R/mixed_try.json | head -3; tail -2 $R/mixed_try.err
+  done
+  ;;
+tests)
+  python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
+  timeout 1500 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log
+  tail -4 $R/pytest_gpu.log; tail -2 $R/smoke.log
+  ;;
+tone_tests)
+  timeout 900 python -m pytest tests/test_tone_gpu.py tests/test_mitel.py tests/test_feed_gpu.py tests/test_soak_gpu.py tests/test_shard_gpu.py tests/test_cadence_gpu.py -m gpu -q -x > $R/pytest_tone.log 2>&1; echo "pytest rc=$?" >> $R/pytest_tone.log
+  tail -5 $R/pytest_tone.log
+  ;;
+bench_quick)
+  cd /tmp; timeout 300 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-paths > $R/bench_quick.json 2> $R/bench_quick.err; tail -c 1500 $R/bench_quick.json; tail -3 $R/bench_quick.err
+  ;;
+bench_nocpu)
+  cd /tmp; timeout 600 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e > $R/bench_nocpu.json 2> $R/bench_nocpu.err; tail -3 $R/bench_nocpu.err
+  python3 - <<'PY'
+import json
+d = json.loads(open("/root/repo/gpurun_out/r5/bench_nocpu.json").read().strip().splitlines()[-1])
+print("headline", d["roofline"]["avg_launch_us"], d["roofline"]["frac"])
+print("large", json.dumps(d.get("large_bank")))
+for k, v in (d.get("paths") or {}).items():
+    if isinstance(v, dict):
+        print(k, v.get("ms_per_step"), (v.get("roofline") or {}).get("avg_launch_us"), (v.get("roofline") or {}).get("frac"), (v.get("roofline") or {}).get("one_launch_us"), v.get("error"))
+PY
+  ;;
+queues)
+  cd /tmp
+  for n in 131072 262144; do for q in 1 2; do
+    timeout 200 python $GRAFT_REPO_ROOT/bench.py --channels $n --queues $q --distinct-frames 30 --no-cpu-baseline --no-e2e --no-paths > $R/bench_q.json 2> $R/bench_q.err
+    echo "$n queues $q: $(grep -o '"avg_launch_us": [0-9.]*' $R/bench_q.json | head -1) $(grep -o '"ms_per_step": [0-9.]*' $R/bench_q.json | head -1)"; tail -1 $R/bench_q.err
+  done; done
+  ;;
+*)
+  echo "unknown stage $what"
+  ;;
+esac
+done
