@@ -593,12 +593,11 @@ def main():
             "event_pair_avg_launch_us": pair_avg_ms*1e3,
             "event_pair_median_launch_us": per[len(per)//2]*1e3,
         }
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile) and not law:
-            try:
-                roof["traffic"] = json.load(open(tfile)).get("dtmf_bytes_per_launch")
-            except Exception:
-                pass
+        if not law:
+            # HBM bytes per launch by the PMC counters (profiles/hbm_traffic.json), nulled when the kernel's sources are not the
+            # ones the counters were taken on (spandsp_amd/roofline.py: hbm_traffic)
+            from spandsp_amd import roofline as rl_t
+            rl_t.add_traffic(roof, "dtmf", n_ch)
 
     roof_valu = None
     if rank == 0:

@@ -212,7 +212,7 @@ ORC_API void orc_st_init(orc_st_t *s, const orc_st_desc_t *d, int use_segment_cb
 ORC_API int orc_st_rx(orc_st_t *s, const int16_t amp[], int samples, orc_sink_t *sink, orc_block_t *blocks, int max_blocks);
 
 /* ---- G.168 echo canceller ------------------------------------------------------------- */
-#define ORC_ECHO_MAX_TAPS       256
+#define ORC_ECHO_MAX_TAPS       1024
 #define ORC_ECHO_USE_ADAPTION   0x01        /* src/spandsp/echo.h:118-127 */
 #define ORC_ECHO_USE_NLP        0x02
 #define ORC_ECHO_USE_CNG        0x04

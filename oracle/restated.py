@@ -334,7 +334,7 @@ ECHO_FIELDS = ["tx_power0", "tx_power1", "tx_power2", "tx_power3", "rx_power0", 
                "geigel_lag", "dtd_onset", "tap_set", "tap_rotate_counter", "latest_correction",
                "narrowband_count", "narrowband_score", "fir_curr_pos", "tx_hpf0", "tx_hpf1", "rx_hpf0",
                "rx_hpf1", "cng_level", "cng_rndnum", "cng_filter", "fir_set"]
-ECHO_MAX_TAPS = 256
+ECHO_MAX_TAPS = 1024
 
 
 class EchoCan:

@@ -90,8 +90,8 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     if (out == nullptr  ||  n_channels <= 0)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
     *out = nullptr;
-    if (taps != 32  &&  taps != 64  &&  taps != 128  &&  taps != 256)
-        return spangpu_set_error(SPANGPU_ERR_UNSUPPORTED, "echo canceller length must be 32, 64, 128 or 256 taps");
+    if (taps != 32  &&  taps != 64  &&  taps != 128  &&  taps != 256  &&  taps != 512  &&  taps != 1024)
+        return spangpu_set_error(SPANGPU_ERR_UNSUPPORTED, "echo canceller length must be 32, 64, 128, 256, 512 or 1024 taps");
     if (spangpu_device_count() <= 0)
         return spangpu_set_error(SPANGPU_ERR_NO_DEVICE, "no HIP device: libspangpu has no CPU fallback");
     if (device < 0  ||  device >= spangpu_device_count())
@@ -124,6 +124,8 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     // Slices are at most 32 taps (four lanes) or 16 taps per lane; two lanes take 32, 64 or 128 taps.
     const int tuned = g_echo_group.load(std::memory_order_relaxed);
     e->group = (tuned != 0)  ?  tuned  :  (n_channels >= 24576)  ?  4  :  (n_channels >= 8192)  ?  8  :  16;
+    if (taps > 256)
+        e->group = 16;          // 64 and 128 ms tails: a DPP row of lanes per channel, slices of 32 / 64 taps (echo.c:254: any power of two)
     if (e->group == 2  &&  taps != 128  &&  taps != 64  &&  taps != 32)
         e->group = (tuned != 0  ||  n_channels >= 131072)  ?  4  :  8;
     if (e->group == 4  &&  (taps/4 < 2  ||  taps/4 > 32))
@@ -344,6 +346,8 @@ int spangpu_echo_update_tx(spangpu_echo_t *e, const int16_t *tx, const int16_t *
             else
                 hipLaunchKernelGGL((echo_bank_kernel<8, 16>), dim3(blocks), dim3(256), 0, e->stream, L);
             break;
+        case 32: hipLaunchKernelGGL((echo_bank_kernel<32, 16>), dim3(blocks), dim3(256), 0, e->stream, L); break;
+        case 64: hipLaunchKernelGGL((echo_bank_kernel<64, 16>), dim3(blocks), dim3(256), 0, e->stream, L); break;
         default: hipLaunchKernelGGL((echo_bank_kernel<16, 16>), dim3(blocks), dim3(256), 0, e->stream, L); break;
         }
     }
@@ -418,7 +422,7 @@ int spangpu_echo_get_state(spangpu_echo_t *e, int channel, int32_t *scal, int32_
         ECHO_TRY(hipMemcpy(taps16, e->taps16 + (size_t) channel*4*T, 4*T*sizeof(int16_t), hipMemcpyDeviceToHost));
     if (history)
     {
-        int16_t w[256];
+        int16_t w[1024];
         ECHO_TRY(hipMemcpy(w, e->hist + (size_t) channel*T, T*sizeof(int16_t), hipMemcpyDeviceToHost));
         // window order -> physical order: w[i] = history[(i + curr_pos + 1) mod T]
         for (int i = 0;  i < T;  i++)
@@ -434,6 +438,9 @@ int spangpu_echo_set_state(spangpu_echo_t *e, int channel, const int32_t *scal, 
     ECHO_TRY(hipSetDevice(e->device));
     ECHO_TRY(hipStreamSynchronize(e->stream));
     const int T = e->taps;
+    // (the kernels derive every sample's position from this word with & (T - 1): echo_dev.hpp)
+    if (scal[ES_CURR_POS] < 0  ||  scal[ES_CURR_POS] >= T)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "curr_pos outside 0 .. taps - 1");
     if (scal[ES_ADAPTION_MODE] != e->uniform_mode  &&  e->n_ch > 1)
         e->uniform_mode = -1;
     else
@@ -445,7 +452,7 @@ int spangpu_echo_set_state(spangpu_echo_t *e, int channel, const int32_t *scal, 
         ECHO_TRY(hipMemcpy(e->taps16 + (size_t) channel*4*T, taps16, 4*T*sizeof(int16_t), hipMemcpyHostToDevice));
     if (history)
     {
-        int16_t w[256];
+        int16_t w[1024];
         for (int i = 0;  i < T;  i++)
             w[i] = history[(i + scal[ES_CURR_POS] + 1)%T];
         ECHO_TRY(hipMemcpy(e->hist + (size_t) channel*T, w, T*sizeof(int16_t), hipMemcpyHostToDevice));

@@ -262,9 +262,64 @@ __device__ __forceinline__ int group_shift_in(int tx, int v, int j)
 // inactive sets are always current.
 // Register budget by tap slice length: 96 VGPRs (five waves per SIMD) up to 8 taps per lane, 168 (three) at 16,
 // 256 (two) at 32 -- at 32 taps per lane three waves' worth of registers put spills into the common-sample body.
+// A lane's slice of a 16-bit array (a tap set, the history), TPL consecutive shorts at p, as sign-extended registers and
+// back -- moved 16 bytes at a time (8 for slices of four, 4 for slices of two).  As the plain loops this replaces the compiler
+// made one global_load_sshort / global_store_short per element: 64 lanes x 32 two-byte accesses an array, which the memory
+// side counts -- and serves -- as 32-byte partial writes (profiles/r5_hbm_calibration.json: WRITE_SIZE reads 16 x the bytes for
+// that store shape, FETCH_SIZE 1.8 x for the load shape).
+template <int TPL>
+__device__ __forceinline__ void echo_load_shorts(const int16_t *p, int (&dst)[TPL])
+{
+    static_assert(TPL == 2  ||  TPL == 4  ||  (TPL%8) == 0, "slices of 2, 4 or a multiple of 8 taps");
+    auto lo = [](int v) { return __builtin_amdgcn_sbfe(v, 0, 16); };
+    auto hi = [](int v) { return v >> 16; };
+    if constexpr (TPL == 2)
+    {
+        const int v = *(const int *) p;
+        dst[0] = lo(v);
+        dst[1] = hi(v);
+    }
+    else if constexpr (TPL == 4)
+    {
+        const int2 v = *(const int2 *) p;
+        dst[0] = lo(v.x); dst[1] = hi(v.x); dst[2] = lo(v.y); dst[3] = hi(v.y);
+    }
+    else
+    {
+#pragma unroll
+        for (int c = 0;  c < TPL/8;  c++)
+        {
+            const int4 v = ((const int4 *) p)[c];
+            dst[8*c + 0] = lo(v.x); dst[8*c + 1] = hi(v.x); dst[8*c + 2] = lo(v.y); dst[8*c + 3] = hi(v.y);
+            dst[8*c + 4] = lo(v.z); dst[8*c + 5] = hi(v.z); dst[8*c + 6] = lo(v.w); dst[8*c + 7] = hi(v.w);
+        }
+    }
+}
+
+template <int TPL>
+__device__ __forceinline__ void echo_store_shorts(int16_t *p, const int (&src)[TPL])
+{
+    auto pk = [](int a, int b) { return (int) (((uint32_t) a & 0xFFFFu) | ((uint32_t) b << 16)); };
+    if constexpr (TPL == 2)
+    {
+        *(int *) p = pk(src[0], src[1]);
+    }
+    else if constexpr (TPL == 4)
+    {
+        *(int2 *) p = make_int2(pk(src[0], src[1]), pk(src[2], src[3]));
+    }
+    else
+    {
+#pragma unroll
+        for (int c = 0;  c < TPL/8;  c++)
+            ((int4 *) p)[c] = make_int4(pk(src[8*c + 0], src[8*c + 1]), pk(src[8*c + 2], src[8*c + 3]),
+                                        pk(src[8*c + 4], src[8*c + 5]), pk(src[8*c + 6], src[8*c + 7]));
+    }
+}
+
 constexpr int echo_waves_per_simd(int tpl)
 {
-    return (tpl <= 8)  ?  5  :  3;
+    return (tpl <= 8)  ?  5  :  (tpl <= 32)  ?  3  :  2;
 }
 
 // MODE >= 0: every channel of the bank has this adaption mode (the host knows: echo_api.hip, `uniform_mode`), so the tests
@@ -275,6 +330,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(echo_waves_
 void echo_bank_kernel(const EchoLaunch L)
 {
     static_assert(G == 16  ||  G == 8  ||  G == 4, "a channel's lanes are a DPP row, half of one, or a quad");
+    static_assert(((TPL*G) & (TPL*G - 1)) == 0, "positions wrap with & (T - 1)");
+    static_assert(TPL*G <= 256  ||  G == 16, "histories longer than 256 samples: sixteen lanes per channel (narrowband_detect's walk)");
     constexpr int T = TPL*G;
     constexpr int kChPerWave = 64/G;
     constexpr int kMaxFrame = (G == 16)  ?  160  :  (G == 8)  ?  128  :  64;    // samples staged per pass
@@ -359,26 +416,18 @@ void echo_bank_kernel(const EchoLaunch L)
     int w[TPL];                 // history window slice, physical register order (see `phase`)
 #pragma unroll
     for (int k = 0;  k < TPL;  k++)
-    {
         t32[k] = g32[k];
-        t16[k] = g16[tap_set*T + k];
-        w[k] = gh[k];
-    }
+    echo_load_shorts<TPL>(g16 + tap_set*T, t16);
+    echo_load_shorts<TPL>(gh, w);
 
     auto load_set = [&](int set, int (&dst)[TPL])
     {
-#pragma unroll
-        for (int k = 0;  k < TPL;  k++)
-            dst[k] = g16[set*T + k];
+        echo_load_shorts<TPL>(g16 + set*T, dst);
     };
     auto store_set = [&](int set, const int (&src)[TPL])
     {
         if (live)
-        {
-#pragma unroll
-            for (int k = 0;  k < TPL;  k++)
-                g16[set*T + k] = (int16_t) src[k];
-        }
+            echo_store_shorts<TPL>(g16 + set*T, src);
     };
     // echo.c:613-651: the non-linear processor and comfort noise, then the position update and the output slot
     auto finish_sample = [&](int idx, int tx, int clean_rx, int rx_power1, int clean_rx_power)
@@ -423,10 +472,37 @@ void echo_bank_kernel(const EchoLaunch L)
         const int n = min(kMaxFrame, L.samples - base);
         // ---- stage tx/rx of this pass into LDS (each group copies its own channel) ----------
         unsigned long long st_part = 0;                     // this lane's share of the pass's received energy (L.stats)
-        for (int i = j;  i < n;  i += G)
+        // Rows that allow it (16-byte aligned: every frame a caller's 160-sample rows lie in) move 16 bytes -- eight samples -- at
+        // a time, in and out; a sample per lane and instruction, as this was, is a two-byte access a lane, which the memory side
+        // serves as 32-byte partial accesses (profiles/r5_hbm_calibration.json).  Ragged ends and unaligned rows: a sample at a time.
+        const int16_t *const txrow = L.tx + (size_t) ch*L.stride + base;
+        const int16_t *const rxrow = L.rx + (size_t) ch*L.stride + base;
+        int16_t *const cleanrow = L.clean + (size_t) ch*L.stride + base;
+        int16_t *const txoutrow = L.tx_out  ?  (L.tx_out + (size_t) ch*L.stride + base)  :  nullptr;
+        const bool vec = ((L.stride & 7) == 0)
+                         &&  ((((uintptr_t) L.tx | (uintptr_t) L.rx | (uintptr_t) L.clean | (uintptr_t) L.tx_out) & 15) == 0);
+        const int nvec = vec  ?  (n & ~7)  :  0;
+        for (int c = j;  c < (nvec >> 3);  c += G)
         {
-            const int a = (uint16_t) L.tx[(size_t) ch*L.stride + base + i];
-            const int b = (uint16_t) L.rx[(size_t) ch*L.stride + base + i];
+            const int4 a = *(const int4 *) (txrow + 8*c);
+            const int4 b = *(const int4 *) (rxrow + 8*c);
+            int *dst = &io[wv][g][8*c];
+            const int av[4] = {a.x, a.y, a.z, a.w};
+            const int bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int q = 0;  q < 4;  q++)
+            {
+                dst[2*q] = (int) (((uint32_t) av[q] & 0xFFFFu) | ((uint32_t) bv[q] << 16));
+                dst[2*q + 1] = (int) (((uint32_t) av[q] >> 16) | ((uint32_t) bv[q] & 0xFFFF0000u));
+                const int r0 = (int) (short) (bv[q] & 0xFFFF);
+                const int r1 = bv[q] >> 16;
+                st_part += (unsigned long long) (r0*r0) + (unsigned long long) (r1*r1);
+            }
+        }
+        for (int i = nvec + j;  i < n;  i += G)
+        {
+            const int a = (uint16_t) txrow[i];
+            const int b = (uint16_t) rxrow[i];
             io[wv][g][i] = a | (b << 16);
             st_part += (unsigned long long) ((int) (short) b*(int) (short) b);
         }
@@ -660,14 +736,49 @@ void echo_bank_kernel(const EchoLaunch L)
                                 for (int k = 0;  k < 4;  k++)
                                     acfbuf[4*j + k] = 0.0f;
                             }
-#pragma unroll
-                            for (int k = 0;  k < TPL;  k++)
+                            if constexpr (T <= 256)
                             {
-                                if (jt < 32 - k)
+#pragma unroll
+                                for (int k = 0;  k < TPL;  k++)
                                 {
-                                    const bool inside = (T == 256)  ||  (lead < T - k);
-                                    (acfbuf + 8 + jt)[k] = inside  ?  (float) w[k]  :  0.0f;
+                                    if (jt < 32 - k)
+                                    {
+                                        const bool inside = (T == 256)  ||  (lead < T - k);
+                                        (acfbuf + 8 + jt)[k] = inside  ?  (float) w[k]  :  0.0f;
+                                    }
                                 }
+                            }
+                            else
+                            {
+                                // A history longer than the 256 the reference's walk wraps at (echo.c:133-139: k = curr_pos, then k++ and
+                                // back to 0 at 256, whatever the length): sample 0 is history[curr_pos], wherever that lies, and the rest
+                                // run on from there only while below 256 -- from curr_pos >= 256 they are history[0], [1], ...  The
+                                // window goes to LDS in its own order (entry m = history[(curr_pos + m) mod T]) and each of the channel's
+                                // lanes fetches sample j and sample j + 16 from where the walk finds them.
+                                (void) lead;
+                                short *const bounce = (short *) scratch[wv] + g*T;
+#pragma unroll
+                                for (int k = 0;  k < TPL;  k++)
+                                    bounce[jt + k] = (short) w[k];
+                                echo_wave_sync();
+                                float mine[2];
+#pragma unroll
+                                for (int m = 0;  m < 2;  m++)
+                                {
+                                    const int i = j + m*G;
+                                    const int q = (i == 0)  ?  curr_pos  :  (curr_pos >= 256)  ?  (i - 1)  :  ((curr_pos + i) & 255);
+                                    mine[m] = (float) bounce[(q - curr_pos) & (T - 1)];
+                                }
+                                echo_wave_sync();
+                                // (the zeros in front, again: the window stood where they are)
+                                if (j < 2)
+                                {
+#pragma unroll
+                                    for (int k = 0;  k < 4;  k++)
+                                        acfbuf[4*j + k] = 0.0f;
+                                }
+                                acfbuf[8 + j] = mine[0];
+                                acfbuf[8 + j + G] = mine[1];
                             }
                             echo_wave_sync();
                             float temp[NL];
@@ -881,13 +992,33 @@ void echo_bank_kernel(const EchoLaunch L)
         unsigned long long cl_part = 0;
         if (live)
         {
-            for (int i = j;  i < n;  i += G)
+            for (int c = j;  c < (nvec >> 3);  c += G)
+            {
+                const int *src = &io[wv][g][8*c];
+                int lo[4];
+                int hi[4];
+#pragma unroll
+                for (int q = 0;  q < 4;  q++)
+                {
+                    const int w0 = src[2*q];
+                    const int w1 = src[2*q + 1];
+                    lo[q] = (int) (((uint32_t) w0 & 0xFFFFu) | ((uint32_t) w1 << 16));
+                    hi[q] = (int) (((uint32_t) w0 >> 16) | ((uint32_t) w1 & 0xFFFF0000u));
+                    const int c0 = (int) (short) (w0 & 0xFFFF);
+                    const int c1 = (int) (short) (w1 & 0xFFFF);
+                    cl_part += (unsigned long long) (c0*c0) + (unsigned long long) (c1*c1);
+                }
+                *(int4 *) (cleanrow + 8*c) = make_int4(lo[0], lo[1], lo[2], lo[3]);
+                if (txoutrow)
+                    *(int4 *) (txoutrow + 8*c) = make_int4(hi[0], hi[1], hi[2], hi[3]);
+            }
+            for (int i = nvec + j;  i < n;  i += G)
             {
                 const int word = io[wv][g][i];
-                L.clean[(size_t) ch*L.stride + base + i] = (int16_t) (word & 0xFFFF);
+                cleanrow[i] = (int16_t) (word & 0xFFFF);
                 cl_part += (unsigned long long) ((int) (short) (word & 0xFFFF)*(int) (short) (word & 0xFFFF));
-                if (L.tx_out)
-                    L.tx_out[(size_t) ch*L.stride + base + i] = (int16_t) (word >> 16);
+                if (txoutrow)
+                    txoutrow[i] = (int16_t) (word >> 16);
             }
         }
         if (L.stats)
@@ -905,11 +1036,9 @@ void echo_bank_kernel(const EchoLaunch L)
     {
 #pragma unroll
         for (int k = 0;  k < TPL;  k++)
-        {
             g32[k] = t32[k];
-            g16[tap_set*T + k] = (int16_t) t16[k];
-            gh[k] = (int16_t) w[k];
-        }
+        echo_store_shorts<TPL>(g16 + tap_set*T, t16);
+        echo_store_shorts<TPL>(gh, w);
     }
     if (L.stats  &&  leader)
         L.stats[ch].samples += (uint32_t) L.samples;

@@ -62,3 +62,64 @@ def add_measured(roof, device=0):
     roof["measured_stream_peak"] = peak
     roof["frac_of_measured_stream"] = (roof["achieved"]/peak) if peak else None
     return roof
+
+
+# ---- HBM bytes per launch from the PMC counters (profiles/hbm_traffic.json, written by tools/hbm_traffic.py from the rocprofv3
+# FETCH_SIZE / WRITE_SIZE passes of tools/gpu_round5.sh hbm) ---------------------------------------------------------------
+# The counters are taken once per round, in passes of their own; what makes them a statement about the kernel a bench run has
+# just timed is the hash of the kernel's sources recorded with them: sources that differ null the figure.
+_KERNEL_SOURCES = {
+    "dtmf": ["tone_fast.hpp", "tone_dev.hpp", "tone_pairs_asm.inc"],
+    "mixed": ["tone_fast.hpp", "tone_dev.hpp", "tone_pairs_asm.inc"],
+    "v29": ["v29_quad.hpp", "v29_common.hpp", "quad_round_front.inc", "quad_ctx.hpp"],
+    "v17": ["v17_quad.hpp", "v17_common.hpp", "v29_common.hpp", "quad_round_front.inc", "quad_ctx.hpp"],
+    "v27ter": ["v27ter_quad.hpp", "v27ter_common.hpp", "v29_common.hpp", "quad_ctx.hpp"],
+    "echo": ["echo_dev.hpp"],
+}
+
+
+def source_hash(key):
+    import hashlib
+    h = hashlib.sha256()
+    for name in _KERNEL_SOURCES.get(key, []):
+        try:
+            h.update(open(os.path.join(ROOT, "spandsp_amd", "csrc", name), "rb").read())
+        except OSError:
+            h.update(b"missing:" + name.encode())
+    return h.hexdigest()[:16]
+
+
+def hbm_traffic(key, channels=None):
+    """{"bytes": read + written per launch, "read": .., "write": .., ...} of workload `key` from profiles/hbm_traffic.json, scaled
+    to `channels`; None when there is no record or the kernel's sources have changed since the counters were taken."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))["workloads"].get(key)
+    except Exception:
+        rec = None
+    if not rec or rec.get("source_hash") != source_hash(key):
+        return None
+    scale = 1.0
+    if channels and rec.get("channels") and channels != rec["channels"]:
+        scale = float(channels)/float(rec["channels"])
+    return {"bytes": (rec["read_bytes_per_launch"] + rec["write_bytes_per_launch"])*scale,
+            "read": rec["read_bytes_per_launch"]*scale, "write": rec["write_bytes_per_launch"]*scale,
+            "kernel": rec.get("kernel"), "source_hash": rec.get("source_hash"), "round": rec.get("round")}
+
+
+def add_traffic(roof, key, channels=None):
+    """Fill roofline.traffic (HBM bytes per launch, read + written) and the ratios to the algorithmic bytes."""
+    if roof is None:
+        return None
+    t = hbm_traffic(key, channels)
+    if t is None:
+        roof["traffic"] = None
+        return roof
+    roof["traffic"] = t["bytes"]
+    roof["traffic_read"] = t["read"]
+    roof["traffic_write"] = t["write"]
+    if roof.get("alg_read_bytes_per_launch"):
+        roof["traffic_read_over_algorithmic"] = t["read"]/roof["alg_read_bytes_per_launch"]
+    if roof.get("state_bytes_actual_read_per_launch"):
+        roof["traffic_read_over_actual_state"] = t["read"]/roof["state_bytes_actual_read_per_launch"]
+    roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 FETCH_SIZE x 2, WRITE_SIZE x 1: profiles/r5_hbm_calibration.json), kernel sources %s" % t["source_hash"]
+    return roof

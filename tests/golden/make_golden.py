@@ -28,6 +28,20 @@ def save(name, **kw):
     print("wrote", name, {k: getattr(v, "shape", v) for k, v in kw.items()})
 
 
+def echo_goldens():
+    """echo_can_update() of the real reference over tests/test_oracle_pin.py's scenario, every ECHO_CASES length and mode
+    (32 ms to 128 ms tails): the clean samples, the final taps, history and control words"""
+    import zlib
+    for taps, mode in ECHO_CASES:
+        tx, rx = echo_scenario(taps, seed=taps + mode)
+        r = ref.EchoCan(taps, mode)
+        clean = np.concatenate([r.run(tx[k:k + 160], rx[k:k + 160], True) for k in range(0, len(tx), 160)])
+        s = r.snapshot()
+        save("echo_%d_%02x" % (taps, mode), tx_crc=zlib.crc32(tx.tobytes()), rx_crc=zlib.crc32(rx.tobytes()),
+             clean=clean, taps32=s["taps32"], taps16=s["taps16"], history=s["history"],
+             fields=np.array(ref.ECHO_FIELDS), values=np.array([s[k] for k in ref.ECHO_FIELDS]))
+
+
 def mitel_side1():
     """BASELINE configs[0]: Tests 2-7 of tests/dtmf_rx_tests.c on the real reference (signals from its tone_gen / awgn,
     answers from its dtmf_rx / dtmf_rx_get): every answer, a CRC of every signal, and the summary figures."""
@@ -292,16 +306,7 @@ def main():
         r.rx(x[k:k + 160])
     save("super_tone", amp=x, fac_bits=bits(d.fac), events=r.sink.events())
 
-    import zlib
-    for taps, mode in ECHO_CASES[:2]:
-        tx, rx = echo_scenario(taps, seed=taps + mode)
-        r = ref.EchoCan(taps, mode)
-        clean = np.concatenate([r.run(tx[k:k + 160], rx[k:k + 160], True) for k in range(0, len(tx), 160)])
-        s = r.snapshot()
-        save("echo_%d_%02x" % (taps, mode), tx_crc=zlib.crc32(tx.tobytes()), rx_crc=zlib.crc32(rx.tobytes()),
-             clean=clean, taps32=s["taps32"], taps16=s["taps16"], history=s["history"],
-             fields=np.array(ref.ECHO_FIELDS), values=np.array([s[k] for k in ref.ECHO_FIELDS]))
-
+    echo_goldens()
     make_g168()
     make_g711_encode()
 
@@ -381,6 +386,9 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["g711_encode"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         make_g711_encode()
+    elif sys.argv[1:] == ["echo"]:
+        assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+        echo_goldens()
     elif sys.argv[1:] == ["g168"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         make_g168()

@@ -68,6 +68,11 @@ def compare_state(bank, dets, what):
     (256, 0x01 | 0x20 | 0x40, [160], 0),
     (64, 0x01 | 0x02 | 0x04, [80, 240], 0),
     (32, 0x01, [160], 0),
+    # 64 and 128 ms tails (echo_can_init(len): any power of two, echo.c:254-300): sixteen lanes per channel, slices of 32 / 64 taps;
+    # narrowband_detect()'s walk wraps at its hard-coded 256 inside the longer history (echo.c:133-139)
+    (512, 0x01 | 0x02, [160, 77], 0),
+    (512, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 31], 0),
+    (1024, 0x01 | 0x20 | 0x40, [160], 0),
     # the other lane mappings (spangpu_tune_echo_lanes_per_channel): identical results.  Eight lanes (half a DPP row)
     (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40, [160, 77], 8),
     (64, 0x01 | 0x02, [160], 8),
@@ -293,3 +298,30 @@ def test_g168_lines_and_the_known_answer(built):
     single = np.array([erle[c] for c in range(n_ch) if c % 10 != 9])
     assert np.median(single) > 40.0, np.median(single)
     bank.close()
+
+
+def test_echo_golden_direct(built):
+    """The committed outputs of the real reference (tests/golden/echo_*.npz: every clean sample, the final taps, history and
+    control words of echo_can_update() at 64 .. 1024 taps), straight against the GPU -- no oracle in the loop."""
+    import zlib
+    from spandsp_amd import engine
+    from test_oracle_pin import ECHO_CASES, GOLDEN, echo_scenario
+    for taps, mode in ECHO_CASES:
+        g = np.load(os.path.join(GOLDEN, "echo_%d_%02x.npz" % (taps, mode)))
+        tx, rx = echo_scenario(taps, seed=taps + mode)
+        assert zlib.crc32(tx.tobytes()) == int(g["tx_crc"]) and zlib.crc32(rx.tobytes()) == int(g["rx_crc"])
+        n_ch = 5
+        bank = engine.EchoBank(n_ch, taps, mode)
+        clean = []
+        for k in range(0, len(tx), 160):
+            got = bank.update_host(np.tile(tx[k:k + 160], (n_ch, 1)), np.tile(rx[k:k + 160], (n_ch, 1)), use_hpf_tx=True)
+            clean.append(got)
+        clean = np.concatenate(clean, axis=1)
+        for c in range(n_ch):
+            assert np.array_equal(clean[c], g["clean"]), (taps, hex(mode), c, np.nonzero(clean[c] != g["clean"])[0][:5])
+        s = bank.get_state(n_ch - 1)
+        assert np.array_equal(s["taps32"], g["taps32"]) and np.array_equal(s["taps16"], g["taps16"]), (taps, hex(mode))
+        assert np.array_equal(s["history"], g["history"]), (taps, hex(mode))
+        for key, want in zip(g["fields"], g["values"]):
+            assert s[str(key)] == int(want), (taps, hex(mode), key, s[str(key)], int(want))
+        bank.close()

@@ -264,6 +264,8 @@ def echo_scenario(taps, seed, n=160*150):
     h[5 % taps] = 0.4
     h[11 % taps] = -0.2
     h[40 % taps] = 0.1
+    if taps > 256:
+        h[taps - 37] = 0.05           # 64 / 128 ms tails: a reflection near the end of the window
     rx = np.convolve(tx, h)[:n] + rng.normal(0, 20, n)
     rx[n//3:n//3 + 2000] += rng.normal(0, 6000, 2000)
     rx[2*n//3:2*n//3 + 500] += rng.normal(0, 8000, 500)
@@ -271,7 +273,7 @@ def echo_scenario(taps, seed, n=160*150):
     return (np.clip(tx, -32768, 32767).astype(np.int16), np.clip(rx, -32768, 32767).astype(np.int16))
 
 
-ECHO_CASES = [(128, 0x01), (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40), (256, 0x01 | 0x02), (64, 0x01)]
+ECHO_CASES = [(128, 0x01), (128, 0x01 | 0x02 | 0x04 | 0x20 | 0x40), (256, 0x01 | 0x02), (64, 0x01), (512, 0x01), (1024, 0x01 | 0x02)]
 
 
 @needs_ref
@@ -1224,7 +1226,7 @@ def test_golden_super_tone(built):
     assert o.sink.events().tobytes() == g["events"].tobytes()
 
 
-@pytest.mark.parametrize("taps,mode", ECHO_CASES[:2])
+@pytest.mark.parametrize("taps,mode", ECHO_CASES)
 def test_golden_echo(built, taps, mode):
     import zlib
     from oracle import restated as orc

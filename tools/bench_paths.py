@@ -465,9 +465,14 @@ def bench_echo(args, dev, stream):
     torch.cuda.synchronize()
     quiet = torch.arange(n_ch, device=dev) % 10 != 0
     es = erle[quiet]
-    state_bytes = 48*4 + ECHO_TAPS*4 + 4*ECHO_TAPS*2 + ECHO_TAPS*2      # scalars + taps32 + taps16[4] + history
-    alg_read = n_ch*(2*FRAME*2 + state_bytes)
-    alg_write = n_ch*(FRAME*2 + state_bytes)
+    # per channel and frame read 640 B (tx, rx) + 1 300 B of state (taps32 512, the ACTIVE taps16 set 256, history
+    # 256, scalars 276), write 320 B (clean) + 1 300 B -- the contract's algorithmic bytes.  What this implementation keeps per
+    # channel: 48 control words (192 B) + taps32 + history + FOUR taps16 sets, of which a launch reads and writes the active one
+    # (echo_dev.hpp: the prologue / write-back; another set only at a set event).
+    alg_read = n_ch*(2*FRAME*2 + 1300)
+    alg_write = n_ch*(FRAME*2 + 1300)
+    actual_read = n_ch*(2*FRAME*2 + 48*4 + ECHO_TAPS*4 + ECHO_TAPS*2 + ECHO_TAPS*2)
+    state_resident = n_ch*(48*4 + ECHO_TAPS*4 + 4*ECHO_TAPS*2 + ECHO_TAPS*2)
     cpu = None
     if not args.no_cpu_baseline:
         nc = min(args.cpu_channels, n_ch, 4096)
@@ -492,6 +497,7 @@ def bench_echo(args, dev, stream):
                      "achieved": alg_read/(avg_ms*1e-3)/1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
                      "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
+                     "state_bytes_actual_read_per_launch": actual_read, "state_bytes_resident": state_resident,
                      "avg_launch_us": avg_ms*1e3,
                      "note": "integer-VALU bound (2 x 128 MACs per sample per channel); the HBM figure is reported, not targeted"},
         "cpu_baseline": cpu}
@@ -1128,8 +1134,13 @@ def bench_modem(args, dev, stream):
     for c in range(0, n_ch, max(1, n_ch//256)):
         _, w = bank.get_state(c)
         trained += int(w[6] == 0)
-    alg_read = n_ch*(FRAME*2 + n_words*4)
-    alg_write = n_ch*(n_words*4 + 4 + 208)
+    # V.29 reads 320 B of PCM + 768 B of state per channel and frame and writes 768 + 24 B -- the contract's
+    # algorithmic bytes (the hot subset of v29_rx_state_t); this implementation's state is every word the reference's struct
+    # holds for the receiver (n_words: 281 / 270 / 547 for V.29 / V.27ter / V.17), reported beside it
+    contract_state = {"v29": 768}.get(args.workload, n_words*4)
+    alg_read = n_ch*(FRAME*2 + contract_state)
+    alg_write = n_ch*(contract_state + 24)
+    actual_read = n_ch*(FRAME*2 + n_words*4)
     cpu = None
     if not args.no_cpu_baseline:
         cpu = cpu_modem(args.workload, bit_rate, frames[:, :min(args.cpu_channels, n_ch)].contiguous().cpu().numpy())
@@ -1158,6 +1169,7 @@ def bench_modem(args, dev, stream):
         "roofline": {"bound": "hbm", "kernel": ("%s_quad_kernel<16, 4>" if (n_ch < 32768 and args.modem_mapping in (0, 4, 8) and args.workload in ("v29", "v17", "v27ter")) else "%s_bank_kernel") % args.workload, "achieved": alg_read/(avg_ms*1e-3)/1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS,
                      "traffic": None, "alg_read_bytes_per_launch": alg_read, "alg_write_bytes_per_launch": alg_write,
+                     "state_bytes_actual_read_per_launch": actual_read,
                      "avg_launch_us": avg_ms*1e3, "min_launch_us": min(per)*1e3, "max_launch_us": max(per)*1e3,
                      "note": "VALU/LDS-issue bound state machine (SURVEY 8(d)); the HBM figure is reported, not targeted"},
         "cpu_baseline": cpu}
@@ -1168,6 +1180,7 @@ def bench_modem(args, dev, stream):
 def compact_path(line, key, channels, stream_peak=None):
     """One BASELINE configuration's line boiled down for bench.py's `paths` object."""
     from spandsp_amd import roofline as rl
+    rl.add_traffic(line.get("roofline"), key, channels)
     roof = dict(line["roofline"])
     if stream_peak:
         roof["measured_stream_peak"] = stream_peak
@@ -1223,6 +1236,7 @@ def emit(line, key, channels=None):
     roof = line.get("roofline")
     if roof:
         rl.add_measured(roof, 0)
+        rl.add_traffic(roof, key, channels)
         line["roofline_valu"] = rl.valu_roof(key, roof.get("avg_launch_us") or roof.get("avg_tick_us"), channels=channels)
     print(json.dumps(line))
 

@@ -82,6 +82,13 @@ tone_tests)
   timeout 900 python -m pytest tests/test_tone_gpu.py tests/test_mitel.py tests/test_feed_gpu.py tests/test_soak_gpu.py tests/test_shard_gpu.py tests/test_cadence_gpu.py -m gpu -q -x > $R/pytest_tone.log 2>&1; echo "pytest rc=$?" >> $R/pytest_tone.log
   tail -5 $R/pytest_tone.log
   ;;
+echo)
+  timeout 1200 python -m pytest tests/test_echo_gpu.py tests/test_shim_echo_gpu.py tests/test_refstate_gpu.py -m gpu -q -x -k "echo" > $R/pytest_echo.log 2>&1; echo "pytest rc=$?" >> $R/pytest_echo.log
+  tail -5 $R/pytest_echo.log
+  cd /tmp
+  timeout 300 python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload echo --no-cpu-baseline --no-e2e --echo-seconds 3 > $R/echo_quick.json 2> $R/echo_quick.err; grep -o '"avg_launch_us": [0-9.]*\|"ms_per_step": [0-9.]*' $R/echo_quick.json | head -3; tail -2 $R/echo_quick.err
+  cd $GRAFT_REPO_ROOT
+  ;;
 bench_quick)
   cd /tmp; timeout 300 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-paths > $R/bench_quick.json 2> $R/bench_quick.err; tail -c 1500 $R/bench_quick.json; tail -3 $R/bench_quick.err
   ;;
