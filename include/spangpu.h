@@ -818,6 +818,39 @@ SPANGPU_API int spangpu_shard_rx(spangpu_shard_t *shard, const int16_t *const *a
 SPANGPU_API int spangpu_shard_digits_device(spangpu_shard_t *shard, void *hip_stream, const uint8_t **digits, int *collect_device, int *max_blocks);
 SPANGPU_API int spangpu_shard_digits_host(spangpu_shard_t *shard, uint8_t *out, size_t out_bytes);
 SPANGPU_API int spangpu_shard_sync(spangpu_shard_t *shard);
+/* (The gathered bytes have two slots used in turn: a step's bytes stay whole until the step after next is queued.)
+
+   BASELINE configs[4]'s own object -- the echo cancellers of N lines over several devices (echo.c:421-661 per line): contiguous
+   channel ranges, one update launch per device and step on the shard's stream, and per reporting interval the ERLE of every line
+   (10 log10(sum rx^2 / sum clean^2) since the last reset, as tests/echo_tests.c:577-594 measures it) computed on each shard's
+   device and gathered to the first shard's device (hipMemcpyPeerAsync: xGMI where the devices are peers).
+       spangpu_echo_shard_create(&es, devices, n, n_channels, 128, SPANGPU_ECHO_USE_ADAPTION-style mode bits);
+       per step:   spangpu_echo_shard_update(es, tx_per_shard, rx_per_shard, clean_per_shard, 160, 160);   rows on each shard's device
+       per second: spangpu_echo_shard_report(es, 1);  spangpu_echo_shard_erle_device(es, stream, &erle, &dev)  or  _erle_host(es, out, n) */
+typedef struct spangpu_echo_shard_s spangpu_echo_shard_t;
+SPANGPU_API int spangpu_echo_shard_create(spangpu_echo_shard_t **shard, const int *devices, int n_devices, int n_channels, int taps, int adaption_mode);
+SPANGPU_API int spangpu_echo_shard_destroy(spangpu_echo_shard_t *shard);
+SPANGPU_API int spangpu_echo_shard_count(const spangpu_echo_shard_t *shard);
+SPANGPU_API int spangpu_echo_shard_range(const spangpu_echo_shard_t *shard, int i, int *device, int *first_channel, int *n_channels);
+SPANGPU_API spangpu_echo_t *spangpu_echo_shard_bank(spangpu_echo_shard_t *shard, int i);
+SPANGPU_API int spangpu_echo_shard_update(spangpu_echo_shard_t *shard, const int16_t *const *tx, const int16_t *const *rx, int16_t *const *clean,
+                                          int samples, long long stride);
+SPANGPU_API int spangpu_echo_shard_report(spangpu_echo_shard_t *shard, int reset);
+SPANGPU_API int spangpu_echo_shard_erle_device(spangpu_echo_shard_t *shard, void *hip_stream, const float **erle_db, int *collect_device);
+SPANGPU_API int spangpu_echo_shard_erle_host(spangpu_echo_shard_t *shard, float *out, size_t out_floats);
+SPANGPU_API int spangpu_echo_shard_sync(spangpu_echo_shard_t *shard);
+/* Modem receivers (SPANGPU_V29 / _V27TER / _V17) over several devices: per step the put_bit streams of every channel -- what
+   spangpu_modem_copy_events() lays out, int32 counts[n_i] then int8 events[n_i][events_per_channel] per shard -- gathered to
+   the first shard's device; spangpu_modem_shard_events_host() hands them out in the whole bank's channel order. */
+typedef struct spangpu_modem_shard_s spangpu_modem_shard_t;
+SPANGPU_API int spangpu_modem_shard_create(spangpu_modem_shard_t **shard, const int *devices, int n_devices, int kind, int n_channels, int bit_rate,
+                                           int events_per_channel);
+SPANGPU_API int spangpu_modem_shard_destroy(spangpu_modem_shard_t *shard);
+SPANGPU_API int spangpu_modem_shard_range(const spangpu_modem_shard_t *shard, int i, int *device, int *first_channel, int *n_channels);
+SPANGPU_API spangpu_modem_t *spangpu_modem_shard_bank(spangpu_modem_shard_t *shard, int i);
+SPANGPU_API int spangpu_modem_shard_rx(spangpu_modem_shard_t *shard, const int16_t *const *amp, int samples, long long stride);
+SPANGPU_API int spangpu_modem_shard_events_host(spangpu_modem_shard_t *shard, int32_t *counts, int8_t *events);
+SPANGPU_API int spangpu_modem_shard_sync(spangpu_modem_shard_t *shard);
 
 /* ---- The receivers' inner primitives as batched entry points of their own (csrc/prim_api.hip) ----
    N independent items per launch, one lane each, in the reference's scalar order of operations (every product and sum rounded

@@ -310,6 +310,30 @@ SPANGPU_API float filter_step(filter_t *fi, float x);
 SPANGPU_API cfilter_t *cfilter_create(fspec_t *fs);
 SPANGPU_API void cfilter_delete(cfilter_t *cfi);
 SPANGPU_API complexf_t cfilter_step(cfilter_t *cfi, const complexf_t *z);
+/* ---- the receivers' inner primitives under their spandsp names (csrc/shim_prims.c): one item through the batched entry
+ * points of csrc/prim_api.hip per call -- the plumbing form; the receivers run them fused, a caller with many items uses
+ * spangpu_*_batch() (include/spangpu.h).  Reference declarations being replaced:
+ *   vec_circular_dot_prodf, vec_circular_lmsf     src/spandsp/vector_float.h:184,188          src/vector_float.c:932-939,996-1000
+ *   cvec_circular_dot_prodf, cvec_circular_lmsf   src/spandsp/complex_vector_float.h:159,163  src/complex_vector_float.c:187-196,215-219
+ *   power_meter_t, power_meter_init/_release/_free/_damping/_update/_rx/_current
+ *                                                 src/spandsp/power_meter.h:34-94, private/power_meter.h:33-40   src/power_meter.c:44-113
+ * No host arithmetic behind them: without a HIP device the float results are NaN, power_meter_update() returns INT32_MIN. */
+typedef struct power_meter_s
+{
+    int shift;
+    int32_t reading;
+} power_meter_t;
+SPANGPU_API float vec_circular_dot_prodf(const float x[], const float y[], int n, int pos);
+SPANGPU_API void vec_circular_lmsf(const float x[], float y[], int n, int pos, float error);
+SPANGPU_API complexf_t cvec_circular_dot_prodf(const complexf_t x[], const complexf_t y[], int n, int pos);
+SPANGPU_API void cvec_circular_lmsf(const complexf_t x[], complexf_t y[], int n, int pos, const complexf_t *error);
+SPANGPU_API power_meter_t *power_meter_init(power_meter_t *s, int shift);
+SPANGPU_API int power_meter_release(power_meter_t *s);
+SPANGPU_API int power_meter_free(power_meter_t *s);
+SPANGPU_API power_meter_t *power_meter_damping(power_meter_t *s, int shift);
+SPANGPU_API int32_t power_meter_update(power_meter_t *s, int16_t amp);
+SPANGPU_API int32_t power_meter_rx(power_meter_t *s, int16_t amp[], int len);
+SPANGPU_API int32_t power_meter_current(power_meter_t *s);
 SPANGPU_API void goertzel_reset(goertzel_state_t *s);
 SPANGPU_API int goertzel_update(goertzel_state_t *s, const int16_t amp[], int samples);
 SPANGPU_API float goertzel_result(goertzel_state_t *s);

@@ -589,11 +589,13 @@ int spangpu_echo_feed_commit(spangpu_echo_feed_t *feed, int samples)
     {
         const long long n16 = (long long) (2*rows/16);
         hipLaunchKernelGGL(g711_to_linear_kernel, dim3((unsigned) ((n16 + 255)/256)), dim3(256), 0, bs, (const uint8_t *) f->d_in[slot], f->d_pcm_in, n16, f->law);
+        FEED_TRY(hipGetLastError());
         rc = spangpu_echo_update(f->echo, f->d_pcm_in, f->d_pcm_in + rows, f->d_pcm_out, SPANGPU_MEM_DEVICE, samples, f->stride, f->use_hpf_tx);
         if (rc < 0)
             return rc;
         const long long m16 = (long long) (rows/16);
         hipLaunchKernelGGL(linear_to_g711_kernel, dim3((unsigned) ((m16 + 255)/256)), dim3(256), 0, bs, (const int16_t *) f->d_pcm_out, (uint8_t *) f->d_out[slot], m16, f->law);
+        FEED_TRY(hipGetLastError());
     }
     else
     {
@@ -689,7 +691,14 @@ int spangpu_modem_feed_create(spangpu_modem_feed_t **out, spangpu_modem_t *modem
     f->depth = depth;
     f->stride = ((long long) max_samples + 7)/8*8;
     f->wpc = spangpu_modem_packed_words(max_bit_rate, max_samples);
-    f->status_cap = (f->n_ch > 4096)  ?  f->n_ch  :  4096;        // (every channel reporting once in the same tick fits)
+    // What a tick can produce: a receiver reports at most a carrier drop and a new carrier with its training in progress in
+    // 160 samples (SIG_STATUS_CARRIER_DOWN, _CARRIER_UP, _TRAINING_IN_PROGRESS; or _TRAINING_FAILED and _CARRIER_DOWN), and a bank
+    // fed in step does so on every channel in the same tick -- two entries a channel, and one more for every further 160 samples
+    // of the tick.  (One entry a channel, as this was, lost a tick's reports above 4 096 channels: the raw events of a tick are
+    // gone once the next one runs.)
+    const long long per_channel = 2 + (max_samples + 159)/160;
+    const long long cap = (long long) f->n_ch*per_channel;
+    f->status_cap = (int) ((cap > 4096)  ?  ((cap < 0x3FFFFFFF)  ?  cap  :  0x3FFFFFFF)  :  4096);
     f->in_bytes = (size_t) f->stride*sizeof(int16_t)*f->n_ch;
     f->out_bytes = ((size_t) f->n_ch*f->wpc + 1 + 2*(size_t) f->status_cap)*sizeof(uint32_t);
     const int rc = xfeed_alloc(f);

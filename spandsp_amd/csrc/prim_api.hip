@@ -31,6 +31,8 @@ __global__ void vec_circ_dot_kernel(const float *x, long long xs, const float *y
     const float *xi = x + (size_t) i*xs;
     const float *yi = y + (size_t) i*ys;
     const int p = pos[i];
+    if (p < 0  ||  p > n)
+        return;                 // (a position outside the row: nothing is read or written for this item)
     float a = 0.0f;
     for (int k = 0;  k < n - p;  k++)
         a += xi[p + k]*yi[k];
@@ -48,6 +50,8 @@ __global__ void vec_circ_lms_kernel(const float *x, long long xs, float *y, long
     const float *xi = x + (size_t) i*xs;
     float *yi = y + (size_t) i*ys;
     const int p = pos[i];
+    if (p < 0  ||  p > n)
+        return;                 // (a position outside the row: nothing is read or written for this item)
     const float e = err[i];
     for (int k = 0;  k < n - p;  k++)
         yi[k] = yi[k]*0.9999f + xi[p + k]*e;
@@ -63,6 +67,8 @@ __global__ void cvec_circ_dot_kernel(const float2 *x, long long xs, const float2
     const float2 *xi = x + (size_t) i*xs;
     const float2 *yi = y + (size_t) i*ys;
     const int p = pos[i];
+    if (p < 0  ||  p > n)
+        return;                 // (a position outside the row: nothing is read or written for this item)
     float are = 0.0f;
     float aim = 0.0f;
     for (int k = 0;  k < n - p;  k++)
@@ -88,6 +94,8 @@ __global__ void cvec_circ_lms_kernel(const float2 *x, long long xs, float2 *y, l
     const float2 *xi = x + (size_t) i*xs;
     float2 *yi = y + (size_t) i*ys;
     const int p = pos[i];
+    if (p < 0  ||  p > n)
+        return;                 // (a position outside the row: nothing is read or written for this item)
     const float2 e = err[i];
     for (int k = 0;  k < n;  k++)
     {
@@ -106,7 +114,7 @@ __global__ void power_meter_kernel(const int16_t *amp, long long stride, int32_t
         return;
     const int16_t *a = amp + (size_t) i*stride;
     int32_t r = reading[i];
-    const int sh = shift[i];
+    const int sh = shift[i] & 31;            // (what a 32-bit arithmetic shift does with its count on the reference's x86-64, too)
     for (int k = 0;  k < n;  k++)
         r += ((a[k]*a[k] - r) >> sh);
     reading[i] = r;
@@ -123,8 +131,13 @@ int stage_in(const T *src, size_t count, int mem, T **dev, bool *owned)
         return SPANGPU_OK;
     }
     PR_TRY(hipMalloc((void **) dev, count*sizeof(T) + 16));
+    if (hipMemcpy(*dev, src, count*sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+    {
+        (void) hipFree(*dev);           // (the caller's Staged has not been told of it yet)
+        *dev = nullptr;
+        return spangpu_set_error(SPANGPU_ERR_HIP, "hipMemcpy (host to device) failed");
+    }
     *owned = true;
-    PR_TRY(hipMemcpy(*dev, src, count*sizeof(T), hipMemcpyHostToDevice));
     return SPANGPU_OK;
 }
 

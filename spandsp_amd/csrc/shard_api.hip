@@ -33,11 +33,14 @@ struct spangpu_shard_s
     int first[kMaxShards + 1];          // first channel of shard i; first[n] = n_ch
     spangpu_bank_t *bank[kMaxShards];
     uint8_t *digits[kMaxShards];        // [max_blocks][channels of the shard], on the shard's device
-    hipEvent_t done[kMaxShards];        // the shard's bytes of the last step have arrived on the collecting device
-    uint8_t *gathered;                  // on collect_device: shard-major, shard i's [max_blocks][n_i] at max_blocks*first[i]
+    hipEvent_t done[2][kMaxShards];     // the shard's bytes of a step have arrived on the collecting device (per slot)
+    uint8_t *gathered[2];               // on collect_device: shard-major, shard i's [max_blocks][n_i] at max_blocks*first[i].  Two
+                                        // slots used in turn: a step's bytes stay whole while the next step is queued and runs
+                                        // (a reader that takes a step's bytes before the step after next is queued never sees a mix)
     uint8_t *h_gathered;                // pinned host copy (spangpu_shard_digits_host)
     int max_blocks;
     int last_blocks;
+    unsigned steps;                     // spangpu_shard_rx() calls so far; the last one wrote slot (steps - 1) & 1
 };
 
 extern "C" {
@@ -55,10 +58,16 @@ int spangpu_shard_destroy(spangpu_shard_t *s)
             (void) spangpu_bank_destroy(s->bank[i]);
         }
         if (s->digits[i]) (void) hipFree(s->digits[i]);
-        if (s->done[i]) (void) hipEventDestroy(s->done[i]);
+        for (int k = 0;  k < 2;  k++)
+        {
+            if (s->done[k][i]) (void) hipEventDestroy(s->done[k][i]);
+        }
     }
     (void) hipSetDevice(s->collect_device);
-    if (s->gathered) (void) hipFree(s->gathered);
+    for (int k = 0;  k < 2;  k++)
+    {
+        if (s->gathered[k]) (void) hipFree(s->gathered[k]);
+    }
     if (s->h_gathered) (void) hipHostFree(s->h_gathered);
     free(s);
     return SPANGPU_OK;
@@ -111,7 +120,8 @@ int spangpu_shard_create(spangpu_shard_t **out, const int *devices, int n_device
         else if ((rc = spangpu_bank_create(&s->bank[i], devices[i], kind, mine, params, params_size)) == SPANGPU_OK)
         {
             if (hipMalloc((void **) &s->digits[i], (size_t) s->max_blocks*mine) != hipSuccess
-                ||  hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming) != hipSuccess)
+                ||  hipEventCreateWithFlags(&s->done[0][i], hipEventDisableTiming) != hipSuccess
+                ||  hipEventCreateWithFlags(&s->done[1][i], hipEventDisableTiming) != hipSuccess)
                 rc = spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of device memory");
             else
                 rc = spangpu_bank_set_digits_buffer(s->bank[i], s->digits[i], (size_t) s->max_blocks*mine);
@@ -127,7 +137,8 @@ int spangpu_shard_create(spangpu_shard_t **out, const int *devices, int n_device
     if (rc == SPANGPU_OK)
     {
         if (hipSetDevice(s->collect_device) != hipSuccess
-            ||  hipMalloc((void **) &s->gathered, (size_t) s->max_blocks*n_channels) != hipSuccess
+            ||  hipMalloc((void **) &s->gathered[0], (size_t) s->max_blocks*n_channels) != hipSuccess
+            ||  hipMalloc((void **) &s->gathered[1], (size_t) s->max_blocks*n_channels) != hipSuccess
             ||  hipHostMalloc((void **) &s->h_gathered, (size_t) s->max_blocks*n_channels) != hipSuccess)
             rc = spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of memory for the gathered digits");
     }
@@ -171,6 +182,7 @@ int spangpu_shard_rx(spangpu_shard_t *s, const int16_t *const *amp, int samples,
     const int maxb = (samples + block - 1)/block;
     if (maxb > s->max_blocks)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "more samples than the shard was made for");
+    const int slot = (int) (s->steps & 1u);
     for (int i = 0;  i < s->n;  i++)
     {
         const int mine = s->first[i + 1] - s->first[i];
@@ -179,13 +191,14 @@ int spangpu_shard_rx(spangpu_shard_t *s, const int16_t *const *amp, int samples,
         if (rc < 0)
             return rc;
         hipStream_t st = (hipStream_t) spangpu_bank_get_stream(s->bank[i]);
-        uint8_t *dst = s->gathered + (size_t) s->max_blocks*s->first[i];
+        uint8_t *dst = s->gathered[slot] + (size_t) s->max_blocks*s->first[i];
         if (s->device[i] == s->collect_device)
             SH_TRY(hipMemcpyAsync(dst, s->digits[i], (size_t) maxb*mine, hipMemcpyDeviceToDevice, st));
         else
             SH_TRY(hipMemcpyPeerAsync(dst, s->collect_device, s->digits[i], s->device[i], (size_t) maxb*mine, st));
-        SH_TRY(hipEventRecord(s->done[i], st));
+        SH_TRY(hipEventRecord(s->done[slot][i], st));
     }
+    s->steps++;
     s->last_blocks = maxb;
     return maxb;
 }
@@ -197,20 +210,23 @@ int spangpu_shard_digits_device(spangpu_shard_t *s, void *hip_stream, const uint
 {
     if (s == nullptr  ||  digits == nullptr)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (s->steps == 0)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "no step has been queued yet");
+    const int slot = (int) ((s->steps - 1u) & 1u);
     for (int i = 0;  i < s->n;  i++)
     {
         if (hip_stream)
         {
             SH_TRY(hipSetDevice(s->collect_device));
-            SH_TRY(hipStreamWaitEvent((hipStream_t) hip_stream, s->done[i], 0));
+            SH_TRY(hipStreamWaitEvent((hipStream_t) hip_stream, s->done[slot][i], 0));
         }
         else
         {
             SH_TRY(hipSetDevice(s->device[i]));
-            SH_TRY(hipEventSynchronize(s->done[i]));
+            SH_TRY(hipEventSynchronize(s->done[slot][i]));
         }
     }
-    *digits = s->gathered;
+    *digits = s->gathered[slot];
     if (collect_device) *collect_device = s->collect_device;
     if (max_blocks) *max_blocks = s->max_blocks;
     return s->last_blocks;
@@ -248,6 +264,434 @@ int spangpu_shard_sync(spangpu_shard_t *s)
     {
         SH_TRY(hipSetDevice(s->device[i]));
         const int rc = spangpu_bank_sync(s->bank[i]);
+        if (rc < 0)
+            return rc;
+    }
+    return SPANGPU_OK;
+}
+
+
+// ---- BASELINE configs[4]'s own object: the echo cancellers of N lines over several devices --------------------------------
+// Channels in contiguous ranges (multiples of 64), every device owning its lines' taps, history and control words for their
+// lifetime; per step one update launch per device on the shard's own stream (tx / rx rows in, clean rows out, each on its
+// device); per reporting interval every shard turns its lines' energy sums into ERLE on its own device (echo_erle_kernel)
+// and the floats travel to the collecting device (the first shard's) behind that, on the shard's stream: hipMemcpyPeerAsync,
+// xGMI where the devices are peers.  Two result slots used in turn, as above.  (Reference: echo.c:421-661 per line; the
+// ERLE is tests/echo_tests.c:577-594's level measurement, 10 log10(sum rx^2 / sum clean^2).)
+struct spangpu_echo_shard_s
+{
+    int n;
+    int n_ch;
+    int collect_device;
+    int device[kMaxShards];
+    int first[kMaxShards + 1];
+    spangpu_echo_t *bank[kMaxShards];
+    float *erle[kMaxShards];            // [channels of the shard] on the shard's device
+    hipEvent_t done[2][kMaxShards];
+    float *gathered[2];                 // [n_ch] on collect_device, the whole bank's channel order
+    unsigned reports;
+};
+
+// (the dealing of spangpu_shard_create(): contiguous ranges, multiples of 64 but for the last)
+static int deal_channels(int n_channels, int n_devices, int *first)
+{
+    const int per = ((n_channels + n_devices - 1)/n_devices + 63)/64*64;
+    int at = 0;
+    for (int i = 0;  i < n_devices;  i++)
+    {
+        first[i] = at;
+        const int left = n_channels - at;
+        int mine = (i == n_devices - 1)  ?  left  :  ((per < left - (n_devices - 1 - i))  ?  per  :  (left - (n_devices - 1 - i)));
+        if (mine < 1)
+            mine = 1;
+        at += mine;
+    }
+    first[n_devices] = n_channels;
+    return (at == n_channels)  ?  SPANGPU_OK  :  SPANGPU_ERR_BAD_ARG;
+}
+
+static void enable_peer(int from_device, int to_device)
+{
+    int can = 0;
+    if (from_device != to_device  &&  hipDeviceCanAccessPeer(&can, from_device, to_device) == hipSuccess  &&  can)
+        (void) hipDeviceEnablePeerAccess(to_device, 0);
+    (void) hipGetLastError();
+}
+
+int spangpu_echo_shard_destroy(spangpu_echo_shard_t *s)
+{
+    if (s == nullptr)
+        return SPANGPU_OK;
+    for (int i = 0;  i < s->n;  i++)
+    {
+        (void) hipSetDevice(s->device[i]);
+        if (s->bank[i])
+        {
+            (void) spangpu_echo_sync(s->bank[i]);
+            (void) spangpu_echo_destroy(s->bank[i]);
+        }
+        if (s->erle[i]) (void) hipFree(s->erle[i]);
+        for (int k = 0;  k < 2;  k++)
+        {
+            if (s->done[k][i]) (void) hipEventDestroy(s->done[k][i]);
+        }
+    }
+    (void) hipSetDevice(s->collect_device);
+    for (int k = 0;  k < 2;  k++)
+    {
+        if (s->gathered[k]) (void) hipFree(s->gathered[k]);
+    }
+    free(s);
+    return SPANGPU_OK;
+}
+
+int spangpu_echo_shard_create(spangpu_echo_shard_t **out, const int *devices, int n_devices, int n_channels, int taps, int adaption_mode)
+{
+    if (out == nullptr  ||  devices == nullptr  ||  n_devices < 1  ||  n_devices > kMaxShards  ||  n_channels < n_devices)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments (1 .. 64 shards, at least a channel each)");
+    *out = nullptr;
+    spangpu_echo_shard_t *s = (spangpu_echo_shard_t *) calloc(1, sizeof(*s));
+    if (s == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of memory");
+    s->n = n_devices;
+    s->n_ch = n_channels;
+    s->collect_device = devices[0];
+    if (deal_channels(n_channels, n_devices, s->first) != SPANGPU_OK)
+    {
+        free(s);
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "channels do not deal out over the shards");
+    }
+    int rc = SPANGPU_OK;
+    for (int i = 0;  i < n_devices  &&  rc == SPANGPU_OK;  i++)
+    {
+        const int mine = s->first[i + 1] - s->first[i];
+        s->device[i] = devices[i];
+        if (hipSetDevice(devices[i]) != hipSuccess)
+            rc = spangpu_set_error(SPANGPU_ERR_HIP, "hipSetDevice failed");
+        else if ((rc = spangpu_echo_create(&s->bank[i], devices[i], mine, taps, adaption_mode)) == SPANGPU_OK)
+        {
+            if (hipMalloc((void **) &s->erle[i], (size_t) mine*sizeof(float)) != hipSuccess
+                ||  hipEventCreateWithFlags(&s->done[0][i], hipEventDisableTiming) != hipSuccess
+                ||  hipEventCreateWithFlags(&s->done[1][i], hipEventDisableTiming) != hipSuccess)
+                rc = spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of device memory");
+            else
+                rc = spangpu_echo_stats(s->bank[i], 2);         // the update kernel itself keeps the energy sums
+        }
+        if (rc == SPANGPU_OK)
+            enable_peer(devices[i], s->collect_device);
+    }
+    if (rc == SPANGPU_OK)
+    {
+        if (hipSetDevice(s->collect_device) != hipSuccess
+            ||  hipMalloc((void **) &s->gathered[0], (size_t) n_channels*sizeof(float)) != hipSuccess
+            ||  hipMalloc((void **) &s->gathered[1], (size_t) n_channels*sizeof(float)) != hipSuccess)
+            rc = spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of memory for the gathered ERLE");
+    }
+    if (rc != SPANGPU_OK)
+    {
+        spangpu_echo_shard_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return SPANGPU_OK;
+}
+
+int spangpu_echo_shard_count(const spangpu_echo_shard_t *s) { return s  ?  s->n  :  SPANGPU_ERR_BAD_ARG; }
+
+int spangpu_echo_shard_range(const spangpu_echo_shard_t *s, int i, int *device, int *first_channel, int *n_channels)
+{
+    if (s == nullptr  ||  i < 0  ||  i >= s->n)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad shard");
+    if (device) *device = s->device[i];
+    if (first_channel) *first_channel = s->first[i];
+    if (n_channels) *n_channels = s->first[i + 1] - s->first[i];
+    return SPANGPU_OK;
+}
+
+spangpu_echo_t *spangpu_echo_shard_bank(spangpu_echo_shard_t *s, int i)
+{
+    return (s  &&  i >= 0  &&  i < s->n)  ?  s->bank[i]  :  nullptr;
+}
+
+// One step: tx[i], rx[i], clean[i] = shard i's rows on ITS device (its own lines only), `samples` per line.  Queues one
+// update launch per shard and returns.
+int spangpu_echo_shard_update(spangpu_echo_shard_t *s, const int16_t *const *tx, const int16_t *const *rx, int16_t *const *clean,
+                              int samples, long long stride)
+{
+    if (s == nullptr  ||  tx == nullptr  ||  rx == nullptr  ||  clean == nullptr  ||  samples <= 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    for (int i = 0;  i < s->n;  i++)
+    {
+        SH_TRY(hipSetDevice(s->device[i]));
+        const int rc = spangpu_echo_update(s->bank[i], tx[i], rx[i], clean[i], SPANGPU_MEM_DEVICE, samples, stride, 0);
+        if (rc < 0)
+            return rc;
+    }
+    return SPANGPU_OK;
+}
+
+// A report: every shard's ERLE over the samples since its sums were last cleared, gathered to the collecting device (the
+// whole bank's channel order); with `reset` the sums start again behind it.  Queues and returns.
+int spangpu_echo_shard_report(spangpu_echo_shard_t *s, int reset)
+{
+    if (s == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null shard");
+    const int slot = (int) (s->reports & 1u);
+    for (int i = 0;  i < s->n;  i++)
+    {
+        const int mine = s->first[i + 1] - s->first[i];
+        SH_TRY(hipSetDevice(s->device[i]));
+        int rc = spangpu_echo_erle(s->bank[i], s->erle[i], SPANGPU_MEM_DEVICE);
+        if (rc < 0)
+            return rc;
+        hipStream_t st = (hipStream_t) spangpu_echo_get_stream(s->bank[i]);
+        float *dst = s->gathered[slot] + s->first[i];
+        if (s->device[i] == s->collect_device)
+            SH_TRY(hipMemcpyAsync(dst, s->erle[i], (size_t) mine*sizeof(float), hipMemcpyDeviceToDevice, st));
+        else
+            SH_TRY(hipMemcpyPeerAsync(dst, s->collect_device, s->erle[i], s->device[i], (size_t) mine*sizeof(float), st));
+        SH_TRY(hipEventRecord(s->done[slot][i], st));
+        if (reset  &&  (rc = spangpu_echo_stats_reset(s->bank[i], SPANGPU_ECHO_STATS_SUMS)) < 0)
+            return rc;
+    }
+    s->reports++;
+    return SPANGPU_OK;
+}
+
+// The last report: `hip_stream` (of the collecting device; NULL: the calling thread) waits for every shard's floats.
+int spangpu_echo_shard_erle_device(spangpu_echo_shard_t *s, void *hip_stream, const float **erle_db, int *collect_device)
+{
+    if (s == nullptr  ||  erle_db == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (s->reports == 0)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "no report has been queued yet");
+    const int slot = (int) ((s->reports - 1u) & 1u);
+    for (int i = 0;  i < s->n;  i++)
+    {
+        if (hip_stream)
+        {
+            SH_TRY(hipSetDevice(s->collect_device));
+            SH_TRY(hipStreamWaitEvent((hipStream_t) hip_stream, s->done[slot][i], 0));
+        }
+        else
+        {
+            SH_TRY(hipSetDevice(s->device[i]));
+            SH_TRY(hipEventSynchronize(s->done[slot][i]));
+        }
+    }
+    *erle_db = s->gathered[slot];
+    if (collect_device) *collect_device = s->collect_device;
+    return s->n_ch;
+}
+
+int spangpu_echo_shard_erle_host(spangpu_echo_shard_t *s, float *out, size_t out_floats)
+{
+    const float *dev;
+    if (s == nullptr  ||  out == nullptr  ||  out_floats < (size_t) s->n_ch)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    const int n = spangpu_echo_shard_erle_device(s, nullptr, &dev, nullptr);
+    if (n < 0)
+        return n;
+    SH_TRY(hipSetDevice(s->collect_device));
+    SH_TRY(hipMemcpy(out, dev, (size_t) n*sizeof(float), hipMemcpyDeviceToHost));
+    return n;
+}
+
+int spangpu_echo_shard_sync(spangpu_echo_shard_t *s)
+{
+    if (s == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null shard");
+    for (int i = 0;  i < s->n;  i++)
+    {
+        SH_TRY(hipSetDevice(s->device[i]));
+        const int rc = spangpu_echo_sync(s->bank[i]);
+        if (rc < 0)
+            return rc;
+    }
+    return SPANGPU_OK;
+}
+
+// ---- modem receivers over several devices: the put_bit streams of a step gathered to one device ---------------------------
+// What travels per shard and step is what spangpu_modem_copy_events() lays out: int32 counts[n_i], then int8 events[n_i][per]
+// (24 bytes per channel and 160-sample frame for V.29 at 9600 bit/s); shard i's block sits at byte offset
+// (4 + per)*first_channel(i) of the collecting buffer.
+struct spangpu_modem_shard_s
+{
+    int n;
+    int n_ch;
+    int per;
+    int collect_device;
+    int device[kMaxShards];
+    int first[kMaxShards + 1];
+    spangpu_modem_t *bank[kMaxShards];
+    uint8_t *ev[kMaxShards];
+    hipEvent_t done[2][kMaxShards];
+    uint8_t *gathered[2];
+    uint8_t *h_gathered;
+    unsigned steps;
+};
+
+int spangpu_modem_shard_destroy(spangpu_modem_shard_t *s)
+{
+    if (s == nullptr)
+        return SPANGPU_OK;
+    for (int i = 0;  i < s->n;  i++)
+    {
+        (void) hipSetDevice(s->device[i]);
+        if (s->bank[i])
+        {
+            (void) spangpu_modem_sync(s->bank[i]);
+            (void) spangpu_modem_destroy(s->bank[i]);
+        }
+        if (s->ev[i]) (void) hipFree(s->ev[i]);
+        for (int k = 0;  k < 2;  k++)
+        {
+            if (s->done[k][i]) (void) hipEventDestroy(s->done[k][i]);
+        }
+    }
+    (void) hipSetDevice(s->collect_device);
+    for (int k = 0;  k < 2;  k++)
+    {
+        if (s->gathered[k]) (void) hipFree(s->gathered[k]);
+    }
+    if (s->h_gathered) (void) hipHostFree(s->h_gathered);
+    free(s);
+    return SPANGPU_OK;
+}
+
+int spangpu_modem_shard_create(spangpu_modem_shard_t **out, const int *devices, int n_devices, int kind, int n_channels, int bit_rate,
+                               int events_per_channel)
+{
+    if (out == nullptr  ||  devices == nullptr  ||  n_devices < 1  ||  n_devices > kMaxShards  ||  n_channels < n_devices
+        ||  events_per_channel < 1  ||  events_per_channel > 4096)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments (1 .. 64 shards, at least a channel each, 1 .. 4096 events a channel and step)");
+    *out = nullptr;
+    spangpu_modem_shard_t *s = (spangpu_modem_shard_t *) calloc(1, sizeof(*s));
+    if (s == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of memory");
+    s->n = n_devices;
+    s->n_ch = n_channels;
+    s->per = events_per_channel;
+    s->collect_device = devices[0];
+    if (deal_channels(n_channels, n_devices, s->first) != SPANGPU_OK)
+    {
+        free(s);
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "channels do not deal out over the shards");
+    }
+    const size_t per_ch = 4u + (size_t) events_per_channel;
+    int rc = SPANGPU_OK;
+    for (int i = 0;  i < n_devices  &&  rc == SPANGPU_OK;  i++)
+    {
+        const int mine = s->first[i + 1] - s->first[i];
+        s->device[i] = devices[i];
+        if (hipSetDevice(devices[i]) != hipSuccess)
+            rc = spangpu_set_error(SPANGPU_ERR_HIP, "hipSetDevice failed");
+        else if ((rc = spangpu_modem_create(&s->bank[i], devices[i], kind, mine, bit_rate)) == SPANGPU_OK)
+        {
+            if (hipMalloc((void **) &s->ev[i], per_ch*mine) != hipSuccess
+                ||  hipEventCreateWithFlags(&s->done[0][i], hipEventDisableTiming) != hipSuccess
+                ||  hipEventCreateWithFlags(&s->done[1][i], hipEventDisableTiming) != hipSuccess)
+                rc = spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of device memory");
+        }
+        if (rc == SPANGPU_OK)
+            enable_peer(devices[i], s->collect_device);
+    }
+    if (rc == SPANGPU_OK)
+    {
+        if (hipSetDevice(s->collect_device) != hipSuccess
+            ||  hipMalloc((void **) &s->gathered[0], per_ch*n_channels) != hipSuccess
+            ||  hipMalloc((void **) &s->gathered[1], per_ch*n_channels) != hipSuccess
+            ||  hipHostMalloc((void **) &s->h_gathered, per_ch*n_channels) != hipSuccess)
+            rc = spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of memory for the gathered events");
+    }
+    if (rc != SPANGPU_OK)
+    {
+        spangpu_modem_shard_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return SPANGPU_OK;
+}
+
+int spangpu_modem_shard_range(const spangpu_modem_shard_t *s, int i, int *device, int *first_channel, int *n_channels)
+{
+    if (s == nullptr  ||  i < 0  ||  i >= s->n)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad shard");
+    if (device) *device = s->device[i];
+    if (first_channel) *first_channel = s->first[i];
+    if (n_channels) *n_channels = s->first[i + 1] - s->first[i];
+    return SPANGPU_OK;
+}
+
+spangpu_modem_t *spangpu_modem_shard_bank(spangpu_modem_shard_t *s, int i)
+{
+    return (s  &&  i >= 0  &&  i < s->n)  ?  s->bank[i]  :  nullptr;
+}
+
+// One step: amp[i] = shard i's rows on its device; queues per shard the receiver launch, the copy of its event block and
+// the block's trip to the collecting device, and returns.
+int spangpu_modem_shard_rx(spangpu_modem_shard_t *s, const int16_t *const *amp, int samples, long long stride)
+{
+    if (s == nullptr  ||  amp == nullptr  ||  samples <= 0)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    const int slot = (int) (s->steps & 1u);
+    const size_t per_ch = 4u + (size_t) s->per;
+    for (int i = 0;  i < s->n;  i++)
+    {
+        const int mine = s->first[i + 1] - s->first[i];
+        SH_TRY(hipSetDevice(s->device[i]));
+        int rc = spangpu_modem_rx(s->bank[i], amp[i], SPANGPU_MEM_DEVICE, samples, stride);
+        if (rc < 0)
+            return rc;
+        if ((rc = spangpu_modem_copy_events(s->bank[i], s->ev[i], per_ch*mine, s->per)) < 0)
+            return rc;
+        hipStream_t st = (hipStream_t) spangpu_modem_get_stream(s->bank[i]);
+        uint8_t *dst = s->gathered[slot] + per_ch*s->first[i];
+        if (s->device[i] == s->collect_device)
+            SH_TRY(hipMemcpyAsync(dst, s->ev[i], per_ch*mine, hipMemcpyDeviceToDevice, st));
+        else
+            SH_TRY(hipMemcpyPeerAsync(dst, s->collect_device, s->ev[i], s->device[i], per_ch*mine, st));
+        SH_TRY(hipEventRecord(s->done[slot][i], st));
+    }
+    s->steps++;
+    return SPANGPU_OK;
+}
+
+// The last step's events on the host, in the whole bank's channel order: counts[c] = put_bit calls of channel c in the step
+// (bits and negative SIG_STATUS_* codes), events[c*per + k] = the k-th of them (k < min(counts[c], per)).
+int spangpu_modem_shard_events_host(spangpu_modem_shard_t *s, int32_t *counts, int8_t *events)
+{
+    if (s == nullptr  ||  counts == nullptr  ||  events == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    if (s->steps == 0)
+        return spangpu_set_error(SPANGPU_ERR_STATE, "no step has been queued yet");
+    const int slot = (int) ((s->steps - 1u) & 1u);
+    const size_t per_ch = 4u + (size_t) s->per;
+    for (int i = 0;  i < s->n;  i++)
+    {
+        SH_TRY(hipSetDevice(s->device[i]));
+        SH_TRY(hipEventSynchronize(s->done[slot][i]));
+    }
+    SH_TRY(hipSetDevice(s->collect_device));
+    SH_TRY(hipMemcpy(s->h_gathered, s->gathered[slot], per_ch*s->n_ch, hipMemcpyDeviceToHost));
+    for (int i = 0;  i < s->n;  i++)
+    {
+        const int mine = s->first[i + 1] - s->first[i];
+        const uint8_t *blk = s->h_gathered + per_ch*s->first[i];
+        memcpy(counts + s->first[i], blk, (size_t) mine*4u);
+        memcpy(events + (size_t) s->first[i]*s->per, blk + (size_t) mine*4u, (size_t) mine*s->per);
+    }
+    return s->n_ch;
+}
+
+int spangpu_modem_shard_sync(spangpu_modem_shard_t *s)
+{
+    if (s == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null shard");
+    for (int i = 0;  i < s->n;  i++)
+    {
+        SH_TRY(hipSetDevice(s->device[i]));
+        const int rc = spangpu_modem_sync(s->bank[i]);
         if (rc < 0)
             return rc;
     }

@@ -194,6 +194,23 @@ def lib():
             "spangpu_shard_digits_device": (ci, [vp, vp, C.POINTER(vp), C.POINTER(ci), C.POINTER(ci)]),
             "spangpu_shard_digits_host": (ci, [vp, vp, C.c_size_t]),
             "spangpu_shard_sync": (ci, [vp]),
+            "spangpu_echo_shard_create": (ci, [C.POINTER(vp), vp, ci, ci, ci, ci]),
+            "spangpu_echo_shard_destroy": (ci, [vp]),
+            "spangpu_echo_shard_count": (ci, [vp]),
+            "spangpu_echo_shard_range": (ci, [vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]),
+            "spangpu_echo_shard_bank": (vp, [vp, ci]),
+            "spangpu_echo_shard_update": (ci, [vp, vp, vp, vp, ci, ll]),
+            "spangpu_echo_shard_report": (ci, [vp, ci]),
+            "spangpu_echo_shard_erle_device": (ci, [vp, vp, C.POINTER(vp), C.POINTER(ci)]),
+            "spangpu_echo_shard_erle_host": (ci, [vp, vp, C.c_size_t]),
+            "spangpu_echo_shard_sync": (ci, [vp]),
+            "spangpu_modem_shard_create": (ci, [C.POINTER(vp), vp, ci, ci, ci, ci, ci]),
+            "spangpu_modem_shard_destroy": (ci, [vp]),
+            "spangpu_modem_shard_range": (ci, [vp, ci, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]),
+            "spangpu_modem_shard_bank": (vp, [vp, ci]),
+            "spangpu_modem_shard_rx": (ci, [vp, vp, ci, ll]),
+            "spangpu_modem_shard_events_host": (ci, [vp, vp, vp]),
+            "spangpu_modem_shard_sync": (ci, [vp]),
             "spangpu_echo_feed_create": (ci, [C.POINTER(vp), vp, ci, ci, ci, ci]),
             "spangpu_echo_feed_destroy": (ci, [vp]),
             "spangpu_echo_feed_stride": (ll, [vp]),
@@ -691,6 +708,7 @@ class ShardedToneBank:
 
     def __init__(self, kind, n_channels, devices, max_samples=160):
         self.n = n_channels
+        self.max_blocks = max_samples//102 + 2          # (shard_api.hip: the shortest block of the kinds a shard takes)
         self.h = C.c_void_p()
         dv = (C.c_int*len(devices))(*devices)
         _check(lib().spangpu_shard_create(C.byref(self.h), dv, len(devices), kind, n_channels, max_samples, None, 0))
@@ -719,12 +737,94 @@ class ShardedToneBank:
 
     def digits_host(self):
         """[blocks, n_channels] uint8 of the last step, in the whole bank's channel order."""
-        out = np.zeros((16, self.n), np.uint8)
+        out = np.zeros((self.max_blocks, self.n), np.uint8)
         nb = _check(lib().spangpu_shard_digits_host(self.h, out.ctypes.data, out.nbytes))
         return out[:nb].copy()
 
     def sync(self):
         _check(lib().spangpu_shard_sync(self.h))
+
+
+class _Sharded:
+    """Common to the sharded echo and modem objects: the ranges, close()."""
+    _prefix = ""
+
+    def _ranges(self):
+        self.ranges = []
+        i = 0
+        while True:
+            d, f, n = C.c_int(), C.c_int(), C.c_int()
+            if getattr(lib(), self._prefix + "_range")(self.h, i, C.byref(d), C.byref(f), C.byref(n)) < 0:
+                break
+            self.ranges.append((d.value, f.value, n.value))
+            i += 1
+        self.shards = len(self.ranges)
+
+    def close(self):
+        if self.h:
+            getattr(lib(), self._prefix + "_destroy")(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(getattr(lib(), self._prefix + "_sync")(self.h))
+
+
+class ShardedEchoBank(_Sharded):
+    """The echo cancellers of n_channels lines over several devices (spangpu_echo_shard_*, BASELINE configs[4]'s object):
+    update_device() queues a step (rows per shard on its device), report() has every shard compute its lines' ERLE and send
+    it to the first shard's device, erle_host() returns the last report in the whole bank's channel order."""
+    _prefix = "spangpu_echo_shard"
+
+    def __init__(self, n_channels, taps, mode, devices):
+        self.n = n_channels
+        self.h = C.c_void_p()
+        dv = (C.c_int*len(devices))(*devices)
+        _check(lib().spangpu_echo_shard_create(C.byref(self.h), dv, len(devices), n_channels, taps, mode))
+        self._ranges()
+
+    def update_device(self, tx_ptrs, rx_ptrs, clean_ptrs, samples, stride):
+        a = (C.c_void_p*len(tx_ptrs))(*tx_ptrs)
+        b = (C.c_void_p*len(rx_ptrs))(*rx_ptrs)
+        c = (C.c_void_p*len(clean_ptrs))(*clean_ptrs)
+        _check(lib().spangpu_echo_shard_update(self.h, a, b, c, samples, stride))
+
+    def report(self, reset=True):
+        _check(lib().spangpu_echo_shard_report(self.h, int(reset)))
+
+    def erle_host(self):
+        out = np.zeros(self.n, np.float32)
+        _check(lib().spangpu_echo_shard_erle_host(self.h, out.ctypes.data, out.size))
+        return out
+
+
+class ShardedModemBank(_Sharded):
+    """Modem receivers over several devices (spangpu_modem_shard_*): rx_device() queues a step, events_host() returns the
+    step's put_bit streams as (counts [n_channels] int32, events [n_channels, per] int8) in the whole bank's channel order."""
+    _prefix = "spangpu_modem_shard"
+
+    def __init__(self, kind, n_channels, bit_rate, devices, per=64):
+        self.n = n_channels
+        self.per = per
+        self.h = C.c_void_p()
+        dv = (C.c_int*len(devices))(*devices)
+        _check(lib().spangpu_modem_shard_create(C.byref(self.h), dv, len(devices), kind, n_channels, bit_rate, per))
+        self._ranges()
+
+    def rx_device(self, ptrs, samples, stride):
+        arr = (C.c_void_p*len(ptrs))(*ptrs)
+        _check(lib().spangpu_modem_shard_rx(self.h, arr, samples, stride))
+
+    def events_host(self):
+        counts = np.zeros(self.n, np.int32)
+        ev = np.zeros((self.n, self.per), np.int8)
+        _check(lib().spangpu_modem_shard_events_host(self.h, counts.ctypes.data, ev.ctypes.data))
+        return counts, ev
 
 
 class EchoFeed:

@@ -235,3 +235,43 @@ def test_packed_modem_events_and_the_pipelined_modem_feed(built):
     assert n_status >= 5*n_ch                                   # carrier up, training, trained, carrier down, up again ...
     feed.close()
     bank.close()
+
+
+def test_modem_feed_of_a_bank_in_step_above_4096_channels(built):
+    """Every channel of a 4 200-channel bank fed the same line reports its carrier and training changes in the same tick, two and
+    three reports a channel in an 800-sample tick: the feed's status list holds them all (it was sized one report a channel)."""
+    import os
+    from spandsp_amd import engine
+    from test_oracle_pin import GOLDEN, use_golden_modem_tables
+    use_golden_modem_tables()
+    g = np.load(os.path.join(GOLDEN, "v29_9600.npz"))
+    x = g["amp"]
+    frame = 800                                                 # 100 ms ticks: training begins and the carrier is up inside one
+    line = np.concatenate([x[:frame*8], np.zeros(frame, np.int16), x[:frame*5]])
+    ticks = len(line)//frame
+    serial = engine.V29Bank(2, 9600)
+    want = []
+    for t in range(ticks):
+        blk = line[t*frame:(t + 1)*frame]
+        serial.rx_host(np.stack([blk, blk]))
+        want.append(serial.events()[1])
+    serial.close()
+    n_ch = 4200
+    bank = engine.V29Bank(n_ch, 9600)
+    feed = engine.ModemFeed(bank, frame, 9600, depth=3)
+    got = []
+    for t in range(ticks):
+        feed.slot()[:, :frame] = line[t*frame:(t + 1)*frame]
+        feed.commit(frame)
+        if t >= 2:
+            got.append(feed.collect())
+    while feed.outstanding():
+        got.append(feed.collect())
+    most = 0
+    for t in range(ticks):
+        most = max(most, int((want[t] < 0).sum()))
+        for c in (0, 1, 2047, 4095, 4096, n_ch - 1):
+            assert np.array_equal(got[t][c], want[t]), (t, c)
+    assert most >= 2                                            # a tick with two or more reports on every channel at once
+    feed.close()
+    bank.close()

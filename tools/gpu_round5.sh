@@ -89,6 +89,10 @@ echo)
   timeout 300 python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload echo --no-cpu-baseline --no-e2e --echo-seconds 3 > $R/echo_quick.json 2> $R/echo_quick.err; grep -o '"avg_launch_us": [0-9.]*\|"ms_per_step": [0-9.]*' $R/echo_quick.json | head -3; tail -2 $R/echo_quick.err
   cd $GRAFT_REPO_ROOT
   ;;
+misc_tests)
+  timeout 1200 python -m pytest tests/test_shard_gpu.py tests/test_shim_prims_gpu.py tests/test_prim_gpu.py tests/test_feed_gpu.py tests/test_bench_spawn_gpu.py -m gpu -q -x > $R/pytest_misc.log 2>&1; echo "pytest rc=$?" >> $R/pytest_misc.log
+  grep -v "^E2026\|^W2026" $R/pytest_misc.log | tail -30
+  ;;
 bench_quick)
   cd /tmp; timeout 300 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-paths > $R/bench_quick.json 2> $R/bench_quick.err; tail -c 1500 $R/bench_quick.json; tail -3 $R/bench_quick.err
   ;;

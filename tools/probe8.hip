@@ -305,6 +305,10 @@ int main(int argc, char **argv)
         series<true, 4>(amp, n_ch, n_frames, K, false, ticks, rounds, &want);
         series<false, 4>(amp, n_ch, n_frames, K, false, ticks, rounds, &want);
     }
+    // one launch with smaller workgroups
+    series<true, 2>(amp, n_ch, n_frames, 1, false, ticks, rounds, &want);
+    series<false, 2>(amp, n_ch, n_frames, 1, false, ticks, rounds, &want);
+    series<false, 1>(amp, n_ch, n_frames, 1, false, ticks, rounds, &want);
     // half-size workgroups spread a sub-bank over twice the CUs
     series<true, 2>(amp, n_ch, n_frames, 2, false, ticks, rounds, &want);
     series<true, 2>(amp, n_ch, n_frames, 4, false, ticks, rounds, &want);
