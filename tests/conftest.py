@@ -12,6 +12,8 @@ if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "soak: long GPU runs (bank-size soaks, the scheduler-variant builds); part of -m gpu, "
+                                       "left out by -m \"gpu and not soak\"")
 
 
 @pytest.fixture(scope="session")

@@ -15,7 +15,7 @@ import pytest
 import synth
 from test_oracle_pin import GOLDEN, bits, use_golden_modem_tables
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.soak]
 
 
 def test_dtmf_bank_sixty_seconds(built):

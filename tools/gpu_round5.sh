@@ -93,6 +93,75 @@ misc_tests)
   timeout 1200 python -m pytest tests/test_shard_gpu.py tests/test_shim_prims_gpu.py tests/test_prim_gpu.py tests/test_feed_gpu.py tests/test_bench_spawn_gpu.py -m gpu -q -x > $R/pytest_misc.log 2>&1; echo "pytest rc=$?" >> $R/pytest_misc.log
   grep -v "^E2026\|^W2026" $R/pytest_misc.log | tail -30
   ;;
+final_tests)
+  python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke rc=$?" >> $R/smoke.log
+  timeout 1700 python -m pytest tests -m gpu -q > $R/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $R/pytest_gpu.log
+  grep -v "^E2026\|^W2026" $R/pytest_gpu.log | tail -6; tail -2 $R/smoke.log
+  ;;
+final_bench)
+  cd /tmp
+  timeout 900 python $GRAFT_REPO_ROOT/bench.py > $R/bench.json 2> $R/bench.err; tail -2 $R/bench.err
+  timeout 600 python $GRAFT_REPO_ROOT/bench.py --workload echo > $R/bench_echo.json 2> $R/bench_echo.err; tail -2 $R/bench_echo.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/bench_stats -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-e2e --no-paths > $R/bench_stats.log 2>&1
+  cp $(ls $R/bench_stats/*/*kernel_stats.csv | head -1) $R/bench_kernel_stats.csv
+  for w in mixed v29 v17 v27ter; do
+    timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/${w}_stats -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --no-cpu-baseline --no-e2e > $R/${w}_stats.log 2>&1
+    cp $(ls $R/${w}_stats/*/*kernel_stats.csv | head -1) $R/${w}_kernel_stats.csv
+  done
+  # the mixed tick's kernels side by side on their streams (concurrent residency)
+  python3 $GRAFT_REPO_ROOT/tools/trace_overlap.py $(ls $R/mixed_stats/*/*kernel_trace.csv | head -1) "tone_fast_kernel" > $R/mixed_trace_overlap.txt 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/echo_stats -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload echo --no-cpu-baseline --no-e2e --echo-seconds 3 > $R/echo_stats.log 2>&1
+  cp $(ls $R/echo_stats/*/*kernel_stats.csv | head -1) $R/echo_kernel_stats.csv
+  rm -rf $R/bench_stats $R/*_stats
+  cd $GRAFT_REPO_ROOT
+  python3 - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r5/bench.json").read().strip().splitlines()[-1])
+print("headline", d["value"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"], d["roofline"].get("traffic"))
+print("cpu", json.dumps(d.get("cpu_baseline"))[:300])
+print("large", json.dumps(d.get("large_bank")))
+for k, v in (d.get("paths") or {}).items():
+    if isinstance(v, dict):
+        r = v.get("roofline") or {}
+        print(k, v.get("ms_per_step"), r.get("avg_launch_us"), r.get("frac"), r.get("one_launch_us"), r.get("traffic"), v.get("error"))
+        c = v.get("cpu_baseline") or {}
+        print("   cpu", c.get("value"), c.get("cores"), c.get("single_core"), c.get("scaling_efficiency"), (c.get("spot_check") or {}) if not isinstance(c.get("spot_check"), dict) else list(c.get("spot_check").items())[:3])
+PY
+  cat $R/mixed_trace_overlap.txt
+  ;;
+final_counters)
+  VALU_W="echo mixed" bash tools/gpu_valu.sh > $R/valu.log 2>&1
+  cp gpurun_out/valu/valu_counters.json $R/ 2>/dev/null
+  bash tools/gpu_round5.sh hbm > $R/hbm.log 2>&1
+  bash tools/gpu_round4.sh echo_pmc > $R/echo_pmc.log 2>&1; cp gpurun_out/r4/echo_pmc.json $R/echo_pmc.json 2>/dev/null
+  tail -40 $R/hbm.log | head -5
+  python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/r5/valu_counters.json"))["workloads"]
+for k in ("dtmf", "mixed", "v29", "echo"):
+    v = d.get(k, {})
+    print(k, v.get("kernel", "")[:60], v.get("valu_insts_per_wave_sample"), v.get("active_frac"), v.get("wait_frac"), v.get("source"))
+PY
+  ;;
+issue)
+  timeout 300 ./tools/probe_issue > $R/probe_issue.log 2>&1; cat $R/probe_issue.log
+  ;;
+sched_variants)
+  timeout 1700 python -m pytest tests/test_sched_variants_gpu.py -m gpu -q > $R/pytest_sched.log 2>&1; echo "pytest rc=$?" >> $R/pytest_sched.log
+  grep -v "^E2026\|^W2026" $R/pytest_sched.log | tail -8
+  ;;
+mixed_trace)
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/mixed_tr -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload mixed --no-cpu-baseline --no-e2e > $R/mixed_tr.log 2>&1
+  python3 $GRAFT_REPO_ROOT/tools/trace_overlap.py $(ls $R/mixed_tr/*/*kernel_trace.csv | head -1) "tone_fast_kernel" --merge > $R/mixed_trace_overlap.txt 2>&1
+  cat $R/mixed_trace_overlap.txt
+  rm -rf $R/mixed_tr
+  cd $GRAFT_REPO_ROOT
+  ;;
+probe_geo)
+  { echo "### tools/probe8 65536 (with the one-launch geometry variants)"; timeout 400 ./tools/probe8 65536 2000 5; } > $R/probe_mq_geo.log 2>&1
+  grep "K=1" $R/probe_mq_geo.log
+  ;;
 bench_quick)
   cd /tmp; timeout 300 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-paths > $R/bench_quick.json 2> $R/bench_quick.err; tail -c 1500 $R/bench_quick.json; tail -3 $R/bench_quick.err
   ;;

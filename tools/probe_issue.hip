@@ -10,11 +10,18 @@
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define REP64(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X)
 
-template <int OP>
+// LANES: how many lanes of each wave take part (the others leave at once: EXEC has only the low LANES bits set for the whole
+// loop) -- round 5: does a wave with half or a quarter of its lanes alive issue its vector instructions faster?
+template <int OP, int LANES = 64>
 __global__ __launch_bounds__(256) void probe(int *out, int iters, int seed)
 {
+    if ((int) (threadIdx.x & 63) >= LANES)
+        return;
     int r0 = seed + threadIdx.x, r1 = r0*3, r2 = r0*5, r3 = r0*7, r4 = r0*11, r5 = r0*13, r6 = r0*17, r7 = r0*19;
     int a = seed | 1, b = seed*3 + 1;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 p0 = {1.0f + seed, 1.5f}, p1 = {2.0f, 2.5f}, p2 = {3.0f, 3.5f}, p3 = {4.0f, 4.5f};
+    const f32x2 pc = {1.0000001f, 0.9999999f};
     for (int i = 0;  i < iters;  i++)
     {
         if constexpr (OP == 0)
@@ -91,11 +98,20 @@ __global__ __launch_bounds__(256) void probe(int *out, int iters, int seed)
             REP64(X)
 #undef X
         }
+        else if constexpr (OP == 12)
+        {
+            // the tone kernels' packed multiply (register pairs: r0:r1 ... as 64-bit operands)
+            asm volatile(
+#define X(k) "v_pk_mul_f32 %0, %0, %4\n\tv_pk_mul_f32 %1, %1, %4\n\tv_pk_mul_f32 %2, %2, %4\n\tv_pk_mul_f32 %3, %3, %4\n\t"
+                REP8(X) REP8(X)
+#undef X
+                : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pc));
+        }
     }
-    out[blockIdx.x*blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + b;
+    out[blockIdx.x*blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7 + b + (int) (p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y);
 }
 
-template <int OP>
+template <int OP, int LANES = 64>
 static void run(const char *name, int *d_out, int per)
 {
     const int iters = 2000;
@@ -110,7 +126,7 @@ static void run(const char *name, int *d_out, int per)
         for (int r = 0;  r < 7;  r++)
         {
             hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(probe<OP>, dim3(blocks), dim3(256), 0, 0, d_out, iters, r);
+            hipLaunchKernelGGL((probe<OP, LANES>), dim3(blocks), dim3(256), 0, 0, d_out, iters, r);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms;
@@ -141,6 +157,15 @@ int main()
     run<9>("v_cmp + s_and pairs", d_out, 64);
     run<10>("v_add_u32 dependent chain", d_out, 64);
     run<11>("v_mad_i32_i24 dependent chain", d_out, 64);
+    run<12>("v_pk_mul_f32 (4 independent)", d_out, 64);
+    // round 5: waves with 32 / 16 of their 64 lanes alive
+    run<0, 32>("v_add_u32, 32 lanes alive", d_out, 64);
+    run<0, 16>("v_add_u32, 16 lanes alive", d_out, 64);
+    run<1, 32>("v_mad_i32_i24, 32 lanes alive", d_out, 64);
+    run<1, 16>("v_mad_i32_i24, 16 lanes alive", d_out, 64);
+    run<12, 32>("v_pk_mul_f32, 32 lanes alive", d_out, 64);
+    run<12, 16>("v_pk_mul_f32, 16 lanes alive", d_out, 64);
+    run<3, 32>("v_mov_b32_dpp, 32 lanes alive", d_out, 64);
     hipFree(d_out);
     return 0;
 }

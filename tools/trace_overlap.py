@@ -8,8 +8,10 @@ import sys
 
 
 def main():
-    path = sys.argv[1]
-    pat = sys.argv[2] if len(sys.argv) > 2 else "tone_fast_kernel"
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    merge = "--merge" in sys.argv           # all matching kernels as ONE group (banks on streams of their own: a tick is one launch of each)
+    path = args[0]
+    pat = args[1] if len(args) > 1 else "tone_fast_kernel"
     rows = [r for r in csv.DictReader(open(path)) if pat in r["Kernel_Name"]]
     if not rows:
         print("no launches of", pat)
@@ -17,12 +19,12 @@ def main():
     gkey = "Grid_Size_X" if "Grid_Size_X" in rows[0] else ("Grid_Size" if "Grid_Size" in rows[0] else None)
     groups = collections.OrderedDict()
     for r in rows:
-        g = (r["Kernel_Name"][:70], int(r[gkey]) if gkey else 0)
+        g = ("kernels matching '%s'" % pat, 0) if merge else (r["Kernel_Name"][:70], int(r[gkey]) if gkey else 0)
         groups.setdefault(g, []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")))
     for (name, grid), ls in groups.items():
         ls.sort()
-        # drop the first tenth (warm-up, digest launches)
-        ls = ls[len(ls)//10:]
+        # drop the first tenth (warm-up, digest launches); merged: the last third only (the timed region of tools/bench_paths.py)
+        ls = ls[2*len(ls)//3:] if merge else ls[len(ls)//10:]
         queues = sorted(set(q for _, _, q in ls))
         dur = [e - s for s, e, _ in ls]
         ev = []
