@@ -148,6 +148,15 @@ __device__ __forceinline__ int mad24(int a, int b, int c)
     return d;
 }
 
+// d = (the HIGH half of a, as a signed 16-bit number) * (the low half of b, likewise) + c: the FIR's multiply-add with the
+// coefficient taken straight from the upper half of the doubled 32-bit tap (see "the taps, doubled" in echo_bank_kernel)
+__device__ __forceinline__ int mad16hi(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 template <int CTRL>
 __device__ __forceinline__ int dpp_mov(int old, int src)
 {
@@ -317,6 +326,28 @@ __device__ __forceinline__ void echo_store_shorts(int16_t *p, const int (&src)[T
     }
 }
 
+// The upper halves of TPL registers as TPL consecutive shorts at p (a tap set from the doubled taps)
+template <int TPL>
+__device__ __forceinline__ void echo_store_hi(int16_t *p, const int (&src)[TPL])
+{
+    auto pk = [](int a, int b) { return (int) (((uint32_t) a >> 16) | ((uint32_t) b & 0xFFFF0000u)); };
+    if constexpr (TPL == 2)
+    {
+        *(int *) p = pk(src[0], src[1]);
+    }
+    else if constexpr (TPL == 4)
+    {
+        *(int2 *) p = make_int2(pk(src[0], src[1]), pk(src[2], src[3]));
+    }
+    else
+    {
+#pragma unroll
+        for (int c = 0;  c < TPL/8;  c++)
+            ((int4 *) p)[c] = make_int4(pk(src[8*c + 0], src[8*c + 1]), pk(src[8*c + 2], src[8*c + 3]),
+                                        pk(src[8*c + 4], src[8*c + 5]), pk(src[8*c + 6], src[8*c + 7]));
+    }
+}
+
 constexpr int echo_waves_per_simd(int tpl)
 {
     return (tpl <= 8)  ?  5  :  (tpl <= 32)  ?  3  :  2;
@@ -411,14 +442,71 @@ void echo_bank_kernel(const EchoLaunch L)
     // (last_acf[] stays in HBM: lane j reads and rewrites last_acf[j + m*G] when its channel runs the narrow-band test)
 
     // ---- per-lane tap slices ------------------------------------------------------------------
-    int t32[TPL];               // fir_taps32
-    int t16[TPL];               // fir_taps16[tap_set], sign-extended
+    // The taps, doubled (round 5).  The reference keeps fir_taps32[] and, for the FIR, fir_taps16[tap_set][] = (int16_t)
+    // (fir_taps32[] >> 15), rewritten for every tap by every LMS update (echo.c:232-249): a multiply-add and a bit field
+    // extract a tap and sample, and a third instruction for the FIR.  Here ts[k] holds (fir_taps32[k] << 1) mod 2^32: the
+    // update is one multiply-add with the doubled step (wrap-around arithmetic is linear), and bits 15..30 of the tap -- the
+    // 16-bit coefficient, with the reference's wrap -- ARE the upper half of ts[k], which v_mad_i32_i16 takes as its operand.
+    // The extract is gone: 32 of the 166 vector instructions of a wave and sample.
+    // What the doubling loses is bit 31 of the tap, which only the state in HBM needs.  The TRUE taps stay where they live, in
+    // fir_taps32 in HBM, as of the last "rebase"; while the taps have moved by less than 2^30 since then (acc, the sum of the
+    // |step|s since, times the largest sample magnitude 32768, bounds that) the true value is the one in HBM plus the 31-bit
+    // difference of the low parts, sign extended -- rebase(): a load, four instructions and a store a tap, every few rounds.
+    // (Kept in registers the true taps cost 32 of them, and the common body, which never looks at them, two spills a sample:
+    // 0.51 ms where this is 0.4x.)  Rounds of the common body rebase between themselves when acc has passed half its budget; a
+    // sample whose step would overrun it is a set event (the complete routine rebases first, and takes a step too large for one
+    // piece in pieces); the write-back rebases.
+    // "Stale": after a rotation of the tap sets without an update behind it (echo.c:518-527 with narrowband_score != 0) the FIR
+    // runs on the rotated-in set's OLD contents, which are not the taps' upper bits.  Then ts[k] holds that set's coefficient
+    // << 16 (the FIR does not know the difference), HBM the true taps (acc = 0), and bit 1 of ncf says so; the next update
+    // starts from them.  A launch finds out which it is by comparing the active set with the taps.
+    int ts[TPL];                // (fir_taps32 << 1) mod 2^32, or the active set's coefficients << 16 while stale
+    int acc = 0;                // sum of |step| since the last rebase
     int w[TPL];                 // history window slice, physical register order (see `phase`)
+    {
+        int t0[TPL];
+        int a16[TPL];
 #pragma unroll
-    for (int k = 0;  k < TPL;  k++)
-        t32[k] = g32[k];
-    echo_load_shorts<TPL>(g16 + tap_set*T, t16);
+        for (int k = 0;  k < TPL;  k++)
+            t0[k] = g32[k];
+        echo_load_shorts<TPL>(g16 + tap_set*T, a16);
+        bool differ = false;
+#pragma unroll
+        for (int k = 0;  k < TPL;  k++)
+            differ |= (a16[k] != __builtin_amdgcn_sbfe(t0[k], 15, 16));
+        const unsigned long long bal = __ballot(differ);
+        const bool stale0 = ((bal >> ((lane/G)*G)) & ((G == 64)  ?  ~0ull  :  ((1ull << G) - 1ull))) != 0;
+#pragma unroll
+        for (int k = 0;  k < TPL;  k++)
+            ts[k] = stale0  ?  (int) ((uint32_t) a16[k] << 16)  :  (int) ((uint32_t) t0[k] << 1);
+        ncf |= stale0  ?  2  :  0;
+    }
     echo_load_shorts<TPL>(gh, w);
+
+    // the true taps in HBM from the doubled ones (lanes whose taps are stale, or that are told to sit it out, leave theirs)
+    auto rebase = [&](bool skip)
+    {
+        if (!skip)
+        {
+            int t[TPL];
+#pragma unroll
+            for (int k = 0;  k < TPL;  k++)
+                t[k] = g32[k];
+#pragma unroll
+            for (int k = 0;  k < TPL;  k++)
+            {
+                const int d = (int) (((uint32_t) ts[k] >> 1) - (uint32_t) t[k]);
+                t[k] += __builtin_amdgcn_sbfe(d, 0, 31);
+            }
+            if (live)
+            {
+#pragma unroll
+                for (int k = 0;  k < TPL;  k++)
+                    g32[k] = t[k];
+            }
+            acc = 0;
+        }
+    };
 
     auto load_set = [&](int set, int (&dst)[TPL])
     {
@@ -555,7 +643,7 @@ void echo_bank_kernel(const EchoLaunch L)
                 {
 #pragma unroll
                     for (int q = 0;  q < 4;  q++)
-                        ya[q] = mad24(t16[k + q], w[(k + q - PH - 1 + 8*TPL)%TPL], ya[q]);
+                        ya[q] = mad16hi(ts[k + q], w[(k + q - PH - 1 + 8*TPL)%TPL], ya[q]);
                 }
                 y = (ya[0] + ya[1]) + (ya[2] + ya[3]);
             }
@@ -563,7 +651,7 @@ void echo_bank_kernel(const EchoLaunch L)
             {
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
-                    y = mad24(t16[k], w[(k - PH - 1 + 8*TPL)%TPL], y);
+                    y = mad16hi(ts[k], w[(k - PH - 1 + 8*TPL)%TPL], y);
             }
             y = group_sum<G>(y);
             const int echo_value = (int) (short) (y >> 15);
@@ -594,9 +682,19 @@ void echo_bank_kernel(const EchoLaunch L)
             const mask_t m_loud = __builtin_amdgcn_ballot_w64(loud);
             const mask_t m_single = __builtin_amdgcn_ballot_w64(single);
             const mask_t m_adapting = m_loud & m_single & __builtin_amdgcn_ballot_w64(n_dwell == 0);
+            // the update's step (echo.c:530-553; used only by the lanes that update): the shift is max(top_bit(x) - 8, 0) with
+            // top_bit(0) = -1: 23 - ffbh(x), an unsigned subtraction that clamps at zero (ffbh(0) is all ones).  Formed ahead of
+            // the event test, because two things about it are set events of this kernel's own: a step that would take the
+            // taps further from their last rebase than the doubled representation can account for, and an update of taps
+            // that are stale (see "the taps, doubled")
+            const int n_tp3 = meter_of(lane3{}, n_meterA);
+            const int factor = clean_rx >> lms_shift((tx > 4*n_tp3)  ?  tx  :  n_tp3);
+            const int n_acc = acc + abs(factor);
+            const mask_t m_lms = ((mode & kModeAdaption) != 0)  ?  (m_adapting & __builtin_amdgcn_ballot_w64((ncf & 1) == 0))  :  0;
             const mask_t m_event = (m_adapting & (__builtin_amdgcn_ballot_w64((uint32_t) ncf >= 159u*4u) | __builtin_amdgcn_ballot_w64(tap_rotate_counter <= 1)))
                                    | (m_loud & ~m_single & __builtin_amdgcn_ballot_w64(ncf >= 0))
-                                   | (__builtin_amdgcn_ballot_w64(n_rp1 > 2048*2048) & __builtin_amdgcn_ballot_w64(n_crp > 4*n_rp1));
+                                   | (__builtin_amdgcn_ballot_w64(n_rp1 > 2048*2048) & __builtin_amdgcn_ballot_w64(n_crp > 4*n_rp1))
+                                   | (m_lms & (__builtin_amdgcn_ballot_w64(n_acc > 32767) | __builtin_amdgcn_ballot_w64((ncf & 2) != 0)));
             if (__builtin_expect(m_event != 0, 0))
             {
                 w[NEWP] = w_old;
@@ -614,17 +712,13 @@ void echo_bank_kernel(const EchoLaunch L)
             tap_rotate_counter -= adapting  ?  1  :  0;
             if (adapting  &  ((mode & kModeAdaption) != 0)  &  ((ncf & 1) == 0))     // ... and narrowband_score == 0
             {
-                // echo.c:530-553 + lms_adapt(), echo.c:232-249
-                // the shift is max(top_bit(x) - 8, 0) with top_bit(0) = -1: 23 - ffbh(x), an unsigned subtraction that
-                // clamps at zero (ffbh(0) is all ones)
-                const int n_tp3 = meter_of(lane3{}, n_meterA);
-                const int factor = clean_rx >> lms_shift((tx > 4*n_tp3)  ?  tx  :  n_tp3);
+                // lms_adapt(), echo.c:232-249, on the doubled taps: one multiply-add a tap (the coefficient of the FIR is the
+                // upper half of the result)
+                const int factor2 = factor << 1;
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
-                {
-                    t32[k] = mad24(w[(k - PH - 1 + 8*TPL)%TPL], factor, t32[k]);
-                    t16[k] = __builtin_amdgcn_sbfe(t32[k], 15, 16);
-                }
+                    ts[k] = mad24(w[(k - PH - 1 + 8*TPL)%TPL], factor2, ts[k]);
+                acc = n_acc;
             }
             nonupdate_dwell = doubletalk  ?  600  :  nonupdate_dwell;      // NONUPDATE_DWELL_TIME
             finish_sample(idx, tx, clean_rx, n_rp1, n_crp);
@@ -645,6 +739,7 @@ void echo_bank_kernel(const EchoLaunch L)
             int narrowband_count = (int) (((uint32_t) ncf >> 2) & 0x1FFFFFFFu);
             int dtd_onset = (ncf < 0)  ?  1  :  0;
             int narrowband_score = cold[wv][g];
+            bool stale = (ncf & 2) != 0;                        // ts[] holds the active set's coefficients << 16, HBM the taps
             int curr_pos = (curr_pos0 - (base + idx)) & (T - 1);
             // (opaque: or every expression in curr_pos0 below is computed ahead of the sample loop, and then kept in scratch)
             asm volatile("" : "+v"(curr_pos));
@@ -662,7 +757,7 @@ void echo_bank_kernel(const EchoLaunch L)
             {
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
-                    y = mad24(t16[k], w[k], y);
+                    y = mad16hi(ts[k], w[k], y);
             }
             else
             {
@@ -671,7 +766,7 @@ void echo_bank_kernel(const EchoLaunch L)
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
                 {
-                    const int c = own  ?  t16[k]  :  (int) g16[fir_set*T + k];
+                    const int c = own  ?  (ts[k] >> 16)  :  (int) g16[fir_set*T + k];
                     y = mad24(c, w[k], y);
                 }
             }
@@ -690,17 +785,34 @@ void echo_bank_kernel(const EchoLaunch L)
             clean_rx_power += ((int) ((uint32_t) clean_rx*(uint32_t) clean_rx) - clean_rx_power) >> 6;
 
             // fir_taps16[-1] is the FIR history (see the header): history[p] <- set[p]
-            auto set_over_history = [&]()
+            auto set_over_history = [&](const int (&c16)[TPL])
             {
                 short *const bounce = (short *) scratch[wv] + g*T;
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
-                    bounce[j*TPL + k] = (short) t16[k];
+                    bounce[j*TPL + k] = (short) c16[k];
                 echo_wave_sync();
                 const unsigned first = (unsigned) (j*TPL + curr_pos);
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
                     w[k] = bounce[(first + k) & (T - 1)];
+            };
+
+            // echo.c:509-510,570-571: the taps become a coefficient set (fir_taps32[i] = fir_taps16[..][i] << 15) -- true and
+            // doubled at once, nothing stale, nothing to account for
+            auto taps_from_set = [&](const int (&c16)[TPL])
+            {
+#pragma unroll
+                for (int k = 0;  k < TPL;  k++)
+                    ts[k] = (int) ((uint32_t) c16[k] << 16);
+                if (live)
+                {
+#pragma unroll
+                    for (int k = 0;  k < TPL;  k++)
+                        g32[k] = (int) ((uint32_t) c16[k] << 15);
+                }
+                acc = 0;
+                stale = false;
             };
 
             if (tx_power0 > 64*64)                              // MIN_TX_POWER_FOR_ADAPTION
@@ -849,15 +961,14 @@ void echo_bank_kernel(const EchoLaunch L)
                                 if (narrowband_score > 200)
                                 {
                                     // echo.c:504-510: revert to the set saved in [3]
-                                    load_set(3, t16);
+                                    int c16[TPL];
+                                    load_set(3, c16);
                                     const int d2 = (tap_set - 1)%3;
                                     if (d2 >= 0)
-                                        store_set(d2, t16);
+                                        store_set(d2, c16);
                                     else
-                                        set_over_history();
-#pragma unroll
-                                    for (int k = 0;  k < TPL;  k++)
-                                        t32[k] = (int) ((uint32_t) t16[k] << 15);
+                                        set_over_history(c16);
+                                    taps_from_set(c16);
                                     tap_rotate_counter = 1600;
                                 }
                                 narrowband_score = 0;
@@ -866,14 +977,31 @@ void echo_bank_kernel(const EchoLaunch L)
                         dtd_onset = 0;
                         if (--tap_rotate_counter <= 0)
                         {
-                            // echo.c:518-527: rotate to the next tap set
+                            // echo.c:518-527: rotate to the next tap set.  The set that was active goes to HBM; the FIR carries on
+                            // with the OLD contents of the next one until an update rewrites them: stale (the update below,
+                            // if it runs, ends that at once)
                             tap_rotate_counter = 1600;
-                            store_set(tap_set, t16);
+                            {
+                                int c16[TPL];
+#pragma unroll
+                                for (int k = 0;  k < TPL;  k++)
+                                    c16[k] = ts[k] >> 16;
+                                store_set(tap_set, c16);
+                            }
                             tap_set++;
                             if (tap_set > 2)
                                 tap_set = 0;
                             fir_set = tap_set;
-                            load_set(tap_set, t16);
+                            rebase(stale);                      // the true taps, before ts[] changes its meaning
+                            {
+                                int c16[TPL];
+                                load_set(tap_set, c16);
+#pragma unroll
+                                for (int k = 0;  k < TPL;  k++)
+                                    ts[k] = (int) ((uint32_t) c16[k] << 16);
+                            }
+                            acc = 0;
+                            stale = true;
                         }
                         if ((mode & kModeAdaption)  &&  narrowband_score == 0)
                         {
@@ -886,12 +1014,34 @@ void echo_bank_kernel(const EchoLaunch L)
                                 sh = top_bit_u32((uint32_t) tx_power3) - 8;
                             if (sh > 0)
                                 factor >>= sh;
+                            // the update on the doubled taps (see "the taps, doubled"): from the true taps if they were stale;
+                            // rebased first if this step could take them 2^30 from the last rebase; a step too large for
+                            // that on its own (|clean_rx| up to 65 535 unshifted) in pieces of 16 384 with a rebase after each
+                            // (wrap-around arithmetic is linear: the pieces add up to the step)
+                            if (stale)
+                            {
+#pragma unroll
+                                for (int k = 0;  k < TPL;  k++)
+                                    ts[k] = (int) ((uint32_t) g32[k] << 1);
+                                acc = 0;
+                                stale = false;
+                            }
+                            if (acc + abs(factor) > 32767)
+                                rebase(false);
+                            int rem = factor;
+                            while (abs(rem) > 16384)
+                            {
+                                const int piece = (rem > 0)  ?  16384  :  -16384;
+#pragma unroll
+                                for (int k = 0;  k < TPL;  k++)
+                                    ts[k] = mad24(w[k], piece << 1, ts[k]);
+                                rebase(false);
+                                rem -= piece;
+                            }
 #pragma unroll
                             for (int k = 0;  k < TPL;  k++)
-                            {
-                                t32[k] = mad24(w[k], factor, t32[k]);
-                                t16[k] = (int) (short) (t32[k] >> 15);
-                            }
+                                ts[k] = mad24(w[k], rem << 1, ts[k]);
+                            acc += abs(rem);
                         }
                     }
                 }
@@ -902,14 +1052,13 @@ void echo_bank_kernel(const EchoLaunch L)
                         // echo.c:562-573: double talk -- fall back to the older tap set
                         const int src = (tap_set + 1)%3;
                         const int d2 = (tap_set - 1)%3;
-                        load_set(src, t16);
+                        int c16[TPL];
+                        load_set(src, c16);
                         if (d2 >= 0)
-                            store_set(d2, t16);
+                            store_set(d2, c16);
                         else
-                            set_over_history();
-#pragma unroll
-                        for (int k = 0;  k < TPL;  k++)
-                            t32[k] = (int) ((uint32_t) t16[k] << 15);
+                            set_over_history(c16);
+                        taps_from_set(c16);
                         tap_rotate_counter = 1600;
                         dtd_onset = 1;
                     }
@@ -923,22 +1072,21 @@ void echo_bank_kernel(const EchoLaunch L)
             if (rx_power1 > 2048*2048  &&  clean_rx_power > 4*rx_power1)
             {
                 // The canceller is making things worse: zap every tap set
+                int zero[TPL];
 #pragma unroll
                 for (int k = 0;  k < TPL;  k++)
-                {
-                    t32[k] = 0;
-                    t16[k] = 0;
-                }
-                store_set(0, t16);
-                store_set(1, t16);
-                store_set(2, t16);
-                store_set(3, t16);
+                    zero[k] = 0;
+                taps_from_set(zero);
+                store_set(0, zero);
+                store_set(1, zero);
+                store_set(2, zero);
+                store_set(3, zero);
             }
             finish_sample(idx, tx, clean_rx, rx_power1, clean_rx_power);
             meterA = (q4 == 0)  ?  tx_power0  :  (q4 == 1)  ?  tx_power1  :  (q4 == 2)  ?  tx_power2  :  tx_power3;
             meterB = (q4 == 0)  ?  rx_power0  :  (q4 == 1)  ?  rx_power1  :  (q4 == 2)  ?  clean_rx_power  :  0;
             cold[wv][g] = narrowband_score;                     // (the lanes of a channel agree)
-            ncf = echo_pack_ncf(narrowband_count, dtd_onset, narrowband_score);
+            ncf = echo_pack_ncf(narrowband_count, dtd_onset, narrowband_score) | (stale  ?  2  :  0);
         };
 
         // ---- the window registers rotated by r (wave-uniform, 0 .. TPL-1) places: new w[k] = old w[(k - r) mod TPL], which
@@ -971,6 +1119,10 @@ void echo_bank_kernel(const EchoLaunch L)
             int phase = 0;
             if (__all(fir_set == tap_set))
             {
+                // (half the budget used: the true taps are brought up to date here, between rounds, so that no sample of the
+                // common body needs to -- one that would overrun the budget after all is a set event)
+                if (__any(acc > 16383))
+                    rebase((ncf & 2) != 0);
                 const int lim = __builtin_amdgcn_readfirstlane(min(U, n - idx));
                 ahead = io[wv][g][idx];
                 const int done = __builtin_amdgcn_readfirstlane(echo_fast_round<0, U, TPL>(fast, w, idx, lim));
@@ -1034,10 +1186,8 @@ void echo_bank_kernel(const EchoLaunch L)
     // ---- write back -----------------------------------------------------------------------------
     if (live)
     {
-#pragma unroll
-        for (int k = 0;  k < TPL;  k++)
-            g32[k] = t32[k];
-        echo_store_shorts<TPL>(g16 + tap_set*T, t16);
+        rebase((ncf & 2) != 0);                             // the true taps, in place
+        echo_store_hi<TPL>(g16 + tap_set*T, ts);            // (stale or not: the upper halves are the active set's coefficients)
         echo_store_shorts<TPL>(gh, w);
     }
     if (L.stats  &&  leader)

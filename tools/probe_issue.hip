@@ -98,6 +98,24 @@ __global__ __launch_bounds__(256) void probe(int *out, int iters, int seed)
             REP64(X)
 #undef X
         }
+        else if constexpr (OP == 13)
+        {
+#define X(k) asm volatile("v_mad_i32_i16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(r##k) : "v"(a), "v"(b));
+            REP64(X)
+#undef X
+        }
+        else if constexpr (OP == 14)
+        {
+#define X(k) asm volatile("v_mad_i32_i16 %0, %1, %2, %0" : "+v"(r##k) : "v"(a), "v"(b));
+            REP64(X)
+#undef X
+        }
+        else if constexpr (OP == 15)
+        {
+#define X(k) asm volatile("v_dot2_i32_i16 %0, %1, %2, %0" : "+v"(r##k) : "v"(a), "v"(b));
+            REP64(X)
+#undef X
+        }
         else if constexpr (OP == 12)
         {
             // the tone kernels' packed multiply (register pairs: r0:r1 ... as 64-bit operands)
@@ -158,6 +176,9 @@ int main()
     run<10>("v_add_u32 dependent chain", d_out, 64);
     run<11>("v_mad_i32_i24 dependent chain", d_out, 64);
     run<12>("v_pk_mul_f32 (4 independent)", d_out, 64);
+    run<13>("v_mad_i32_i16 op_sel hi", d_out, 64);
+    run<14>("v_mad_i32_i16", d_out, 64);
+    run<15>("v_dot2_i32_i16", d_out, 64);
     // round 5: waves with 32 / 16 of their 64 lanes alive
     run<0, 32>("v_add_u32, 32 lanes alive", d_out, 64);
     run<0, 16>("v_add_u32, 16 lanes alive", d_out, 64);
