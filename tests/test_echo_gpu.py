@@ -169,6 +169,13 @@ def test_echo_kernel_follows_the_modes_of_the_bank(built):
             bank.adaption_mode(0x01)
             for d in dets:
                 d.adaption_mode(0x01)
+        if fi == 42:
+            bank.adaption_mode(0x01 | 0x02, channel=7)
+            dets[7].adaption_mode(0x01 | 0x02)
+        if fi == 45:
+            # ... and one channel at a time: the channels agree again, which the bank finds out at its next update
+            bank.adaption_mode(0x01, channel=7)
+            dets[7].adaption_mode(0x01)
         if fi in (20, 38):
             # echo_can_flush() in either kernel: the FIR stays on the old tap set until the next rotation, every sample of
             # the wave takes the complete routine meanwhile

@@ -162,6 +162,28 @@ probe_geo)
   { echo "### tools/probe8 65536 (with the one-launch geometry variants)"; timeout 400 ./tools/probe8 65536 2000 5; } > $R/probe_mq_geo.log 2>&1
   grep "K=1" $R/probe_mq_geo.log
   ;;
+echo_wide)
+  timeout 1500 python -m pytest tests/test_echo_gpu.py tests/test_shim_echo_gpu.py tests/test_refstate_gpu.py tests/test_feed_gpu.py tests/test_shard_gpu.py tests/test_full_size_gpu.py tests/test_nccl_gpu.py tests/test_soak_gpu.py -m gpu -q -x > $R/pytest_echo_wide.log 2>&1; echo "pytest rc=$?" >> $R/pytest_echo_wide.log
+  grep -v "^E2026\|^W2026" $R/pytest_echo_wide.log | tail -6
+  cd /tmp
+  for n in 8192 32768; do
+    timeout 200 python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload echo --channels $n --no-cpu-baseline --no-e2e --echo-seconds 3 > $R/echo_n.json 2> $R/echo_n.err
+    echo "$n $(grep -o '"avg_launch_us": [0-9.]*' $R/echo_n.json | head -1)"
+  done
+  cd $GRAFT_REPO_ROOT
+  ;;
+echo_counters)
+  VALU_W="echo" VALU_MODEMS="" bash tools/gpu_valu.sh > $R/valu.log 2>&1
+  cp gpurun_out/valu/valu_counters.json $R/ 2>/dev/null
+  HBM_W="echo" bash tools/gpu_round5.sh hbm > $R/hbm.log 2>&1
+  bash tools/gpu_round4.sh echo_pmc > $R/echo_pmc.log 2>&1; cp gpurun_out/r4/echo_pmc.json $R/echo_pmc.json 2>/dev/null
+  python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/r5/valu_counters.json"))["workloads"]
+v = d.get("echo", {})
+print("echo", v.get("kernel", "")[:60], v.get("valu_insts_per_wave_sample"), v.get("active_frac"), v.get("wait_frac"), v.get("source"))
+PY
+  ;;
 bench_quick)
   cd /tmp; timeout 300 python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-e2e --no-paths > $R/bench_quick.json 2> $R/bench_quick.err; tail -c 1500 $R/bench_quick.json; tail -3 $R/bench_quick.err
   ;;

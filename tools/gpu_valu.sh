@@ -7,7 +7,7 @@ rm -rf $R; mkdir -p $R
 export TMPDIR=/tmp
 cd /tmp
 timeout 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/dtmf -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-paths > $R/dtmf.log 2>&1
-for w in v29 v17 v27ter; do
+for w in ${VALU_MODEMS-v29 v17 v27ter}; do
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$w -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 40 --warmup 110 --no-cpu-baseline --no-e2e > $R/$w.log 2>&1
 done
 for w in ${VALU_W:-echo mixed fsk mct sigtone supertone dtmf_tx v29_tx awgn}; do

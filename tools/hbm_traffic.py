@@ -29,6 +29,11 @@ def main():
                          "and of every load shape of these kernels (profiles/r5_hbm_calibration.json: 0.5000 for a dword per lane, 16 bytes "
                          "per lane, and a lane's own 128-byte row); WRITE_SIZE (KiB) as is (1.000 for the same store shapes)",
            "round": rnd, "workloads": {}}
+    # workloads this run did not measure keep their record (and its source hash: it still says what it was taken on)
+    try:
+        out["workloads"].update(json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("workloads", {}))
+    except Exception:
+        pass
     for key, (pat, channels) in WANT.items():
         ks = {k: v for k, v in raw.get(key, {}).items() if pat in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v}
         if not ks:
