@@ -41,3 +41,11 @@ def test_bench_starts_its_own_ranks_echo_with_the_erle_gather(built):
     erle = r["config"]["erle_db_single_talk_channels"]
     assert erle["ranks"] == 1
     assert erle["median"] > 10.0        # the cancellers converged and their ERLE came through the gather
+
+
+def test_bench_with_a_bank_in_queue_mode_and_the_gather(built):
+    """--queues 2 at 131 072 channels with the RCCL digit gather forced on: every collective is queued behind a
+    spangpu_bank_join() (spandsp_amd/parallel.py), and the digits that arrive are checked by bench.py itself."""
+    r = run_bench(["--steps", "50", "--warmup", "10", "--channels", "131072", "--queues", "2", "--distinct-frames", "30",
+                   "--no-cpu-baseline", "--no-e2e", "--no-paths", "--min-timed-ms", "5"])
+    assert r["config"]["queues"] == 2 and r["value"] > 0
