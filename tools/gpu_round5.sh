@@ -158,6 +158,14 @@ mixed_trace)
   rm -rf $R/mixed_tr
   cd $GRAFT_REPO_ROOT
   ;;
+tile)
+  cd $GRAFT_REPO_ROOT
+  { echo "### tools/probe2 tile: the state in wave-major tiles of 16-byte lane vectors (the product); abl1024 = no state traffic"; timeout 600 ./tools/probe2 tile;
+    echo "### tools/probe2_rows tile: the same kernel with the state as word-major rows (the tree before the tiles, built by hand for this A-B); abl1049600 there = abl1024";
+    [ -x ./tools/probe2_rows ] && timeout 600 ./tools/probe2_rows tile;
+    echo "### again: tiles"; timeout 600 ./tools/probe2 tile; } > $R/probe_tile_real.log 2>&1
+  grep -v "^      \|loader waves\|last launch" $R/probe_tile_real.log | grep "abl0 \|###\|----" | cut -c1-118
+  ;;
 probe_geo)
   { echo "### tools/probe8 65536 (with the one-launch geometry variants)"; timeout 400 ./tools/probe8 65536 2000 5; } > $R/probe_mq_geo.log 2>&1
   grep "K=1" $R/probe_mq_geo.log
