@@ -917,10 +917,13 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         det.store_extra(L, (int) ch);
         sti(L.si, (int32_t) (w0 | (uint32_t) cs));
         sti(L.si + (size_t) nch, w1);
-        if (L.maxb > 0)
+        // (probe bit 18: the two record rows not stored -- what they cost the end of a launch, tools/probe2 rec)
+        if (L.maxb > 0  &&  !(ABL & 262144))
             sti((int32_t *) L.rec, (int32_t) rec0);
-        if (L.maxb > 1)
+        if (L.maxb > 1  &&  !(ABL & 262144))
             sti((int32_t *) L.rec + (size_t) nch, (int32_t) rec1);
+        if ((ABL & 262144)  &&  (rec0 ^ rec1) == 0x12345678u)
+            sti((int32_t *) L.rec, (int32_t) rec0);        // (keeps the values alive)
         for (int b = max(nb, 2);  b < L.maxb;  b++)
             *(int32_t *) ((char *) ((int32_t *) L.rec + (size_t) b*nch) + st4) = 0;    // slots without a completed block
         if ((ABL & kToneDigits)  &&  L.digits)

@@ -451,6 +451,28 @@ static void sweep_r4_long(int n_ch)
     free_rig(r);
 }
 
+// Round 5: what do the two record rows' stores cost the end of a launch?  (ABL bit 18: not stored.)  Variants taken in turn.
+static void ab_rec(int n_ch, int n_frames, int reps, int rounds)
+{
+    typedef DtmfDet<false> D;
+    Rig r = make_rig<D>(n_ch, 160, n_frames, 102, false);
+    printf("---- r5 record stores: DTMF, %d channels x 160 samples, %d rounds ----\n", n_ch, rounds);
+    std::vector<float> t[3];
+    for (int k = 0;  k < rounds;  k++)
+    {
+        t[0].push_back(ab_time<D, 0, true>(r, reps, nullptr));
+        t[1].push_back(ab_time<D, 262144, true>(r, reps, nullptr));
+        t[2].push_back(ab_time<D, 32768, true>(r, reps, nullptr));
+    }
+    const char *names[3] = {"product", "... the two record rows not stored", "... no stores at all"};
+    for (int v = 0;  v < 3;  v++)
+    {
+        std::sort(t[v].begin(), t[v].end());
+        printf("%-40s median %7.2f us  min %7.2f us\n", names[v], t[v][t[v].size()/2]*1e3, t[v][0]*1e3);
+    }
+    free_rig(r);
+}
+
 int main(int argc, char **argv)
 {
     hipDeviceProp_t p;
@@ -487,6 +509,13 @@ int main(int argc, char **argv)
         sweep_r4(65536, 64, 300);
         sweep_r4(131072, 32, 200);
         sweep_r4(1048576, 6, 30);
+        return 0;
+    }
+    if (argc > 1  &&  strcmp(argv[1], "rec") == 0)
+    {
+        CK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+        ab_rec(65536, 64, 300, 9);
+        ab_rec(131072, 32, 200, 7);
         return 0;
     }
     if (argc > 1  &&  strcmp(argv[1], "big") == 0)
