@@ -557,7 +557,9 @@ SPG_FN void v17_quad_run(Q &q, const V17Launch &L, const int ch, const V17QuadTa
     }
     q.sync(2);
     int pos = 0;
-    while (q.any(pos < tn, 1))
+    // The round loop, bottom tested (the compiler does not rotate a loop whose test is a cross-lane operation, and with the
+    // test at the top it kept the loop-carried state in two register sets: some forty copies at the head of every round)
+    if (q.any(pos < tn, 1)) do
     {
         SPG_PROF_STAMP(0);
 #define QF_SETS                 kV17Sets
@@ -961,7 +963,7 @@ SPG_FN void v17_quad_run(Q &q, const V17Launch &L, const int ch, const V17QuadTa
             }
             carrier_phase += (uint32_t) carrier_phase_rate;     // dds_advancef() with the rate the baud left behind
         }
-    }
+    } while (q.any(pos < tn, 11));
     }
 
     // ---- write back (arrays dealt over the lanes, scalars by the first) ------------------------------------------------
