@@ -194,6 +194,19 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
         n_ev++;
     };
 
+    // The equaliser's taps as this lane multiplies with them ({re, im} on even lanes, {im, -re} on odd ones), in registers: in
+    // data mode they change with every tenth baud (eq_skip), the sum that reads them runs every baud, and what a lone wave pays
+    // for in that sum is the LDS words it reads (tools/probe_lds.hip: 35 cycles a term with both operands from LDS, 23 with the
+    // taps in registers and the products as one packed multiply).  LDS keeps the copy the LMS update's lanes exchange through;
+    // whoever changes it there (the update, a restart) has the registers loaded again.
+    f32x2v tc[kEqLen];
+    auto load_taps = [&]()
+    {
+        SPG_UNROLL
+        for (int i = 0;  i < kEqLen;  i++)
+            tc[i] = (f32x2v) {C.taps[3*i + (role & 1)], C.taps[3*i + (role & 1) + 1]};
+    };
+
     // v29_rx_restart(s, bit_rate, false), v29rx.c:1019-1098: all four lanes, the same stores
     auto restart = [&]()
     {
@@ -222,6 +235,7 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
             C.taps[3*i + 1] = 0.0f;
             C.taps[3*i + 2] = -cr;
         }
+        load_taps();
         for (int i = 0;  i < 4*kEqLen;  i++)
             C.u[i] = make_float2(0.0f, 0.0f);
         eq_put_step = kRrcSets*10/(3*2) - 1;
@@ -330,6 +344,7 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
     const int16_t *src = L.amp + (size_t) ch*L.stride;
     SPG_LOADS_DONE();
     q.sync(1);
+    load_taps();
     for (int tile = 0;  tile < L.samples;  tile += kV29QuadTile)
     {
     const int tn = max(0, min(kV29QuadTile, mylen - tile));
@@ -418,18 +433,15 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                 for (int i0 = 0;  i0 < kEqLen;  i0 += 11)
                 {
                     float2 xs[11];
-                    float ca[11];
-                    float cb[11];
+                    SPG_UNROLL
+                    for (int i = 0;  i < 11;  i++)
+                        xs[i] = x[i0 + i];
                     SPG_UNROLL
                     for (int i = 0;  i < 11;  i++)
                     {
-                        xs[i] = x[i0 + i];
-                        ca[i] = c[3*(i0 + i)];
-                        cb[i] = c[3*(i0 + i) + 1];
+                        const f32x2v p = (f32x2v) {xs[i].x, xs[i].y}*tc[i0 + i];
+                        acc += p.x - p.y;
                     }
-                    SPG_UNROLL
-                    for (int i = 0;  i < 11;  i++)
-                        acc += xs[i].x*ca[i] - xs[i].y*cb[i];
                     // SPG_SCHED_FENCE();
                 }
                 float z = acc + q.swap2(acc, 1);
@@ -714,6 +726,11 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
             }
             SPG_PROF_STAMP(8);
             q.sync(7);
+            if (q.any(do_tune, 12))
+            {
+                if (do_tune)
+                    load_taps();
+            }
             if (do_save)
             {
                 carrier_phase_rate_save = carrier_phase_rate;
