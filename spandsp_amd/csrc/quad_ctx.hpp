@@ -22,6 +22,14 @@
 
 #include <stdint.h>
 
+namespace spg {
+// a compile-time integer as a function argument: a generic lambda takes QuadTag<k>{} where a function template would take <k>
+template <int K> struct QuadTag
+{
+    static constexpr int value = K;
+};
+}   // namespace spg
+
 #if defined(SPG_HOST_EMUL)
 
 #include <math.h>

@@ -503,17 +503,18 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                     nbits = full  ?  4  :  3;
                 }
                 // the self synchronising descrambler: the taps (17, 22) lie beyond the four bits of a baud, so each output
-                // bit only needs the register as it was before the baud
-                uint32_t out = 0;
-                SPG_UNROLL
-                for (int j = 0;  j < 4;  j++)
-                {
-                    const uint32_t o = ((uint32_t) (raw >> j) ^ (scramble_reg >> (17 - j)) ^ (scramble_reg >> (22 - j))) & 1u;
-                    out |= o << (8*j);
-                }
+                // bit only needs the register as it was before the baud -- bit j of the baud (put_bit() order) goes with the
+                // register's bits 17 - j and 22 - j: the baud's bits as a nibble against the bit-reversed nibbles at 14 and 19
+                const uint32_t rev4 = 0xF7B3D591u;          // bit reversal of a nibble: nibble n - 8 of this word for n = 8 .. 15,
+                const uint32_t rev4lo = 0xE6A2C480u;        // nibble n of this one for n = 0 .. 7
+                const uint32_t taps = ((scramble_reg >> 14) ^ (scramble_reg >> 19)) & 0xFu;
+                const uint32_t taps_r = (((taps & 8u)  ?  rev4  :  rev4lo) >> (4*(taps & 7u))) & 0xFu;
+                // one byte per bit, the first lowest: bit k of the nibble to bit 8k
+                const uint32_t out = ((((uint32_t) raw & 0xFu) ^ taps_r)*0x00204081u) & 0x01010101u;
                 {
                     // put_bit order: bit 0 first, so it ends up highest in the register
-                    uint32_t rev = ((uint32_t) raw & 1u) << 3 | ((uint32_t) raw & 2u) << 1 | ((uint32_t) raw & 4u) >> 1 | ((uint32_t) raw & 8u) >> 3;
+                    const uint32_t rw = (uint32_t) raw & 0xFu;
+                    uint32_t rev = (((rw & 8u)  ?  rev4  :  rev4lo) >> (4*(rw & 7u))) & 0xFu;
                     rev >>= 4 - nbits;
                     scramble_reg = (scramble_reg << nbits) | rev;
                 }

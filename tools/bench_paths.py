@@ -1162,6 +1162,21 @@ def bench_modem(args, dev, stream):
         frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem=args.workload)
     else:
         frames = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture)
+    stagger = int(getattr(args, "stagger", 0) or 0)
+    if stagger:
+        # every channel's transmission that many samples later than the bank's first (drawn per channel): the receivers then
+        # leave training at different bauds, and what they do every n-th baud of data (V.29: the equaliser update, every 10th)
+        # no longer falls on the same round for all channels of a wavefront
+        rng = np.random.default_rng(0x57A6)
+        delay = torch.as_tensor(rng.integers(0, stagger, n_ch), device=dev)
+        t = torch.arange(nf*FRAME, device=dev)
+        for c0 in range(0, n_ch, 1024):
+            c1 = min(n_ch, c0 + 1024)
+            x = frames[:, c0:c1].permute(1, 0, 2).reshape(c1 - c0, nf*FRAME)
+            idx = t[None, :] - delay[c0:c1, None]
+            y = torch.where(idx >= 0, torch.gather(x, 1, idx.clamp(min=0)), torch.zeros((), dtype=x.dtype, device=dev))
+            frames[:, c0:c1] = y.reshape(c1 - c0, nf, FRAME).permute(1, 0, 2)
+        del t, delay
     engine.tune_modem_mapping(args.modem_mapping)
     bank = engine.ModemBank(kind, n_ch, bit_rate)
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
@@ -1213,8 +1228,8 @@ def bench_modem(args, dev, stream):
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s %d bps RX, %d channels x %d-sample frames, AWGN%s"
-                               % (args.workload, bit_rate, n_ch, FRAME, " (BASELINE configs[3])" if args.workload == "v29" else ""),
+        "config": {"workload": "%s %d bps RX, %d channels x %d-sample frames, AWGN%s%s"
+                               % (args.workload, bit_rate, n_ch, FRAME, " (BASELINE configs[3])" if args.workload == "v29" else "", ", starts staggered over %d samples" % stagger if stagger else ""),
                    "channels_per_gpu": n_ch, "modem_mapping": args.modem_mapping,
                    "sampled_channels_in_data_mode_at_end": "%d of %d" % (trained, len(range(0, n_ch, max(1, n_ch//256)))),
                    "events_in_last_frame": bits_last},
@@ -1305,6 +1320,7 @@ def main():
     ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
     ap.add_argument("--one-launch", action="store_true", help="mixed: time the one-launch form (the banks on one stream) instead of a launch per bank on streams of their own")
     ap.add_argument("--cpu-channels", type=int, default=16384)
+    ap.add_argument("--stagger", type=int, default=0, help="v29 / v17 / v27ter: every channel's transmission starts a random number of samples (below this) late")
     ap.add_argument("--fsk-waves", type=int, default=0,
                     help="fsk / mct / sigtone: 0 = the library's choice, 1 = one wavefront per 64 receivers, 2 = two (A-B runs)")
     ap.add_argument("--modem-mapping", type=int, default=0,
