@@ -341,20 +341,15 @@ SPG_FN void v17_quad_run(Q &q, const V17Launch &L, const int ch, const V17QuadTa
                 put_bit(raw >> i);
             return;
         }
-        uint32_t lo = 0;
-        uint32_t hi = 0;
-        uint32_t rev = 0;
-        SPG_UNROLL
-        for (int jb = 0;  jb < 6;  jb++)
-        {
-            const uint32_t b = (uint32_t) (raw >> jb) & 1u;
-            const uint32_t o = (b ^ (scramble_reg >> (17 - jb)) ^ (scramble_reg >> (22 - jb))) & 1u;
-            if (jb < 4)
-                lo |= o << (8*jb);
-            else
-                hi |= o << (8*(jb - 4));
-            rev = (jb < n)  ?  ((rev << 1) | b)  :  rev;
-        }
+        // bit j of the baud goes with the register's bits 17 - j and 22 - j: the baud's six bits against the bit-reversed six at
+        // 12 and 17 (a reversal of six bits = two look-ups of three in a word of nibbles), then one multiply to give every bit
+        // of a nibble a byte of its own
+        const uint32_t rev3 = 0x73516240u;
+        auto rev6 = [&](const uint32_t v) -> uint32_t { return (((rev3 >> (4*(v & 7u))) & 7u) << 3) | ((rev3 >> (4*((v >> 3) & 7u))) & 7u); };
+        const uint32_t o6 = ((uint32_t) raw & 0x3Fu) ^ rev6(((scramble_reg >> 12) ^ (scramble_reg >> 17)) & 0x3Fu);
+        const uint32_t lo = ((o6 & 0xFu)*0x00204081u) & 0x01010101u;
+        const uint32_t hi = ((o6 >> 4)*0x00204081u) & 0x01010101u;
+        const uint32_t rev = rev6((uint32_t) raw & 0x3Fu) >> (6 - n);
         scramble_reg = (scramble_reg << n) | rev;
         if (stage == V17_NORMAL)
         {
