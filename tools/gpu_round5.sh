@@ -6,6 +6,64 @@ mkdir -p $R
 export TMPDIR=/tmp
 for what in "$@"; do
 case "$what" in
+modem_quick)
+  # the three receivers at 16 384 x 160 by tools/bench_paths.py's clock (MQ_LIBS: alternative builds of the library to put beside it)
+  for rep in 1 2; do
+  for lib in product ${MQ_LIBS}; do
+    for w in ${MQ_W:-v29 v17 v27ter}; do
+      if [ $lib = product ]; then unset SPANGPU_LIB; else export SPANGPU_LIB=$GRAFT_REPO_ROOT/tools/experiments/libspangpu_$lib.so; fi
+      timeout 200 python tools/bench_paths.py --workload $w --no-cpu-baseline --no-e2e ${MQ_ARGS} > $R/mq_${w}_${lib}_$rep.json 2> $R/mq_${w}_${lib}_$rep.err
+      echo "$w $lib rep $rep: $(grep -o '"avg_launch_us": [0-9.]*' $R/mq_${w}_${lib}_$rep.json | head -1) $(grep -o '"ms_per_step": [0-9.]*' $R/mq_${w}_${lib}_$rep.json | head -1)"
+    done
+  done
+  done
+  unset SPANGPU_LIB
+  ;;
+modem_tests)
+  timeout 900 python -m pytest tests/test_v29_gpu.py tests/test_v17_gpu.py tests/test_v27ter_gpu.py tests/test_full_size_gpu.py -x -q -m gpu > $R/pytest_modem.log 2>&1; echo "pytest rc=$?"; tail -5 $R/pytest_modem.log
+  ;;
+modem_counters)
+  # SQ counters of a receiver's kernel, the product build beside alternative builds (MQ_LIBS), data mode launches only
+  cd /tmp
+  for lib in product ${MQ_LIBS}; do
+    for w in ${MQ_W:-v29}; do
+      if [ $lib = product ]; then unset SPANGPU_LIB; else export SPANGPU_LIB=$GRAFT_REPO_ROOT/tools/experiments/libspangpu_$lib.so; fi
+      rm -rf /tmp/mc_$lib_$w
+      timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d /tmp/mc_${lib}_$w -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 40 --warmup 110 --no-cpu-baseline --no-e2e > $R/mc_${lib}_$w.log 2>&1
+      python3 - /tmp/mc_${lib}_$w $lib $w <<'PY'
+import csv, glob, collections, sys
+d, lib, w = sys.argv[1:4]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(d + "/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "quad_kernel" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"][:40]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, m in acc.items():
+    last = {c: sum(v[-40:])/len(v[-40:]) for c, v in m.items()}        # the timed region: data mode
+    wv = last.get("SQ_WAVES", 1) or 1
+    print(lib, w, "per wave: VALU %.0f SALU %.0f LDS %.0f  wave-cycles %.0f  active %.3f wait %.3f" % (last["SQ_INSTS_VALU"]/wv, last["SQ_INSTS_SALU"]/wv, last["SQ_INSTS_LDS"]/wv,
+          4*last["SQ_WAVE_CYCLES"]/wv, last["SQ_ACTIVE_INST_ANY"]/last["SQ_WAVE_CYCLES"], last["SQ_WAIT_ANY"]/last["SQ_WAVE_CYCLES"]))
+PY
+      rm -rf /tmp/mc_${lib}_$w
+    done
+  done
+  unset SPANGPU_LIB
+  cd $GRAFT_REPO_ROOT
+  ;;
+modem_final_counters)
+  # the three receivers' kernels after the round's second half: SQ counters (valu_counters.json) and the HBM bytes (hbm_traffic_raw.json)
+  VALU_W="none" bash tools/gpu_valu.sh > $R/valu.log 2>&1
+  cp gpurun_out/valu/valu_counters.json $R/ 2>/dev/null
+  HBM_W="v29 v17 v27ter" HBM_NO_DTMF=1 bash tools/gpu_round5.sh hbm > $R/hbm.log 2>&1
+  python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/r5/valu_counters.json"))["workloads"]
+for k in ("v29", "v17", "v27ter"):
+    v = d.get(k, {})
+    print(k, v.get("kernel", "")[:50], v.get("valu_insts_per_wave_sample"), v.get("active_frac"), v.get("wait_frac"), v.get("source"))
+PY
+  tail -30 $R/hbm.log | head -40
+  ;;
 mq)
   # sub-banks on hardware queues of their own (tools/probe8.hip): the product kernel, K = 1, 2, 4, 8
   { echo "### tools/probe8 65536"; timeout 400 ./tools/probe8 65536 2000 5; } > $R/probe_mq.log 2>&1
@@ -29,8 +87,8 @@ hbm)
       echo "$w $c rc=$?"
     done
   done
-  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/hbm_dtmf_FETCH_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-paths > $R/hbm_dtmf_FETCH_SIZE.log 2>&1
-  timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/hbm_dtmf_WRITE_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-paths > $R/hbm_dtmf_WRITE_SIZE.log 2>&1
+  [ -n "$HBM_NO_DTMF" ] || timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/hbm_dtmf_FETCH_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-paths > $R/hbm_dtmf_FETCH_SIZE.log 2>&1
+  [ -n "$HBM_NO_DTMF" ] || timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/hbm_dtmf_WRITE_SIZE -- python $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-e2e --no-paths > $R/hbm_dtmf_WRITE_SIZE.log 2>&1
   cd $GRAFT_REPO_ROOT
   python3 tools/hbm_summary.py $R > $R/hbm_traffic_raw.json
   cat $R/hbm_traffic_raw.json
