@@ -1283,6 +1283,12 @@ def paths_for_bench(dev, stream, no_cpu_baseline=False, stream_peak=None, echo_s
     try:
         a = types.SimpleNamespace(workload="v29", steps=150, **base)
         out["v29"] = compact_path(bench_modem(a, dev, stream), "v29", 16384, stream_peak)
+        # the same bank with the channels' transmissions starting at different samples: the synthetic workload above starts them
+        # all in one frame, so every receiver of a wavefront updates its equaliser on the same baud; a population of calls does not
+        a = types.SimpleNamespace(workload="v29", steps=150, stagger=160, **dict(base, no_cpu_baseline=True, no_e2e=True))
+        st = bench_modem(a, dev, stream)
+        out["v29"]["starts_staggered"] = {"workload": st["config"]["workload"], "ms_per_step": st["ms_per_step"], "avg_launch_us": st["roofline"]["avg_launch_us"],
+                                          "sampled_channels_in_data_mode_at_end": st["config"]["sampled_channels_in_data_mode_at_end"]}
     except Exception as e:
         out["v29"] = {"error": repr(e)}
     torch.cuda.empty_cache()
