@@ -399,6 +399,11 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
 #undef QF_EQ_THIRD_COPY
 
         // ---- the baud (process_half_baud() of the second T/2 instant, v29rx.c:484-786) ---------------------------------
+        do_track = false;
+        do_tune = false;
+        do_save = false;
+        float zre = 0.0f;                                   // the equaliser's output of this baud
+        float zim = 0.0f;
         if (baud_done)
         {
             // the reference advances the carrier phase after the baud's processing, with the rate that may just have
@@ -423,8 +428,6 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
             }
             // equalizer_get(): cvec_circular_dot_prodf (complex_vector_float.c:137-196), one chain per lane:
             // role 0 / 1 = real / imaginary of the part from the ring position to the end, 2 / 3 = of the wrapped part
-            float zre;
-            float zim;
             {
                 const float2 *x = &C.u[eq_step + ((role & 2)  ?  kEqLen  :  0)];
                 const float *c = &C.taps[role & 1];
@@ -468,9 +471,6 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
             }
 
             SPG_PROF_STAMP(6);
-            do_track = false;
-            do_tune = false;
-            do_save = false;
             if (!q.any(stage != V29_NORMAL, 9))
             {
                 // -- every channel of the wave carries data: decode_baud() (v29rx.c:400-481) and put_bit() (:365-397)
@@ -698,14 +698,60 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                 carrier_phase_rate += v29_f2i(use_track_i*error);
                 carrier_phase += (uint32_t) v29_f2i(use_track_p*error);
             }
-            SPG_PROF_STAMP(7);
-            q.sync(6);
-            if (do_tune)
+            carrier_phase += (uint32_t) carrier_phase_rate;     // dds_advancef() with the rate the baud left behind
+        }
+        SPG_PROF_STAMP(7);
+        q.sync(6);
+        // ---- tune_equalizer(): cvec_circular_lmsf (complex_vector_float.c:201-219), tap i with the entry i places on from the ring
+        // position, for the channels whose stage logic asked for it this baud -----------------------------------------------------
+        if (q.any(do_tune, 12))
+        {
+            const float lms_ere = (tgt_re - zre)*eq_delta;      // (meaningful on the lanes that update)
+            const float lms_eim = (tgt_im - zim)*eq_delta;
+            bool lms_done = false;
+#if !defined(SPG_HOST_EMUL)
             {
-                // cvec_circular_lmsf (complex_vector_float.c:201-219): tap i goes with the entry i places on from the ring
-                // position; lane r takes taps r, r + 4, ...
-                const float ere = (tgt_re - zre)*eq_delta;
-                const float eim = (tgt_im - zim)*eq_delta;
+                // In data mode a channel updates on every tenth baud.  When its neighbours in the wavefront are at other bauds of
+                // their ten -- calls that did not start together -- the update below would run for the whole wave with four lanes
+                // in work, on nearly every round.  A few channels at a time are therefore updated by the WAVE: one lane per tap,
+                // the channel's delay line and taps addressed in LDS from the lane's own (a constant stride per channel), its error
+                // terms and ring position read from its lanes' registers.  The same expressions, one tap per lane instead of nine in
+                // turn.  (16 384 x 160 with the channels' starts spread over a frame: 167.6 -> 155.7 us a launch.)
+                const unsigned long long tuning = __ballot(do_tune) & 0x1111111111111111ull;      // lane 0 of every quad that updates
+                const int n_tuning = __popcll(tuning);
+                if (n_tuning <= 4  &&  __popcll(__ballot(1)) == 64)
+                {
+                    const int wl = (int) (threadIdx.x & 63);
+                    unsigned long long left = tuning;
+                    do
+                    {
+                        const int src = __ffsll((long long) left) - 1;
+                        left &= left - 1;
+                        const float ere = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lms_ere), src));
+                        const float eim = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lms_eim), src));
+                        const int at = __builtin_amdgcn_readlane(eq_step, src);
+                        const int dq = (src >> 2) - (wl >> 2);                  // that channel's arrays from this lane's
+                        if (wl < kEqLen)
+                        {
+                            const float2 xv = (C.u + dq*kQuadEqStride)[2*kEqLen + at + wl];
+                            float *tp = C.taps + dq*kQuadTapStride + 3*wl;
+                            const f32x2v c0 = {tp[0], tp[1]};
+                            const f32x2v u = (f32x2v) {xv.y, xv.x}*(f32x2v) {eim, eim};
+                            const f32x2v w = (f32x2v) {xv.x, xv.y}*(f32x2v) {ere, ere};
+                            const f32x2v c = c0*(f32x2v) {0.9999f, 0.9999f} + (u + (f32x2v) {w.x, -w.y});
+                            tp[0] = c.x;
+                            tp[1] = c.y;
+                            tp[2] = -c.x;
+                        }
+                    }
+                    while (left != 0);
+                    lms_done = true;
+                }
+            }
+#endif
+            if (do_tune  &&  !lms_done)
+            {
+                // lane r takes taps r, r + 4, ...
                 const float2 *x = &C.u[2*kEqLen + eq_step];
                 SPG_UNROLL
                 for (int j = 0;  j < (kEqLen + 3)/4;  j++)
@@ -716,8 +762,8 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                         const float2 xv = x[i];
                         const f32x2v c0 = {C.taps[3*i], C.taps[3*i + 1]};
                         // {xi*eim + xr*ere, xr*eim - xi*ere}
-                        const f32x2v u = (f32x2v) {xv.y, xv.x}*(f32x2v) {eim, eim};
-                        const f32x2v w = (f32x2v) {xv.x, xv.y}*(f32x2v) {ere, ere};
+                        const f32x2v u = (f32x2v) {xv.y, xv.x}*(f32x2v) {lms_eim, lms_eim};
+                        const f32x2v w = (f32x2v) {xv.x, xv.y}*(f32x2v) {lms_ere, lms_ere};
                         const f32x2v c = c0*(f32x2v) {0.9999f, 0.9999f} + (u + (f32x2v) {w.x, -w.y});
                         C.taps[3*i] = c.x;
                         C.taps[3*i + 1] = c.y;
@@ -727,11 +773,11 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
             }
             SPG_PROF_STAMP(8);
             q.sync(7);
-            if (q.any(do_tune, 12))
-            {
-                if (do_tune)
-                    load_taps();
-            }
+            if (do_tune)
+                load_taps();
+        }
+        if (q.any(do_save, 13))
+        {
             if (do_save)
             {
                 carrier_phase_rate_save = carrier_phase_rate;
@@ -741,7 +787,6 @@ SPG_FN void v29_quad_run(Q &q, const V29Launch &L, const int ch, const V29QuadTa
                     stf(VF_EQ_SAVE + 2*k + 1, C.taps[3*k + 1]);
                 }
             }
-            carrier_phase += (uint32_t) carrier_phase_rate;     // dds_advancef() with the rate the baud left behind
         }
     } while (q.any(pos < tn, 11));
     }
