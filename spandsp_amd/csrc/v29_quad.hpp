@@ -23,7 +23,10 @@
 //     and the same three instructions (a*c - b*d) give re*re - im*im on one lane and re*im + im*re on its neighbour.
 //     Should a product with a padding zero be NaN (a tap at infinity: the receiver has been fed garbage), the result is
 //     not finite and the sum is redone with every term selected instead of padded;
-//   * the LMS update is independent per tap: lane r takes taps r, r + 4, ...;
+//     (round 5: the taps a lane multiplies with live in its registers -- `tc` below -- and LDS keeps the copy the update's lanes
+//     exchange through; what a lone wave pays for in such a sum is the LDS words it reads, tools/probe_lds.hip)
+//   * the LMS update is independent per tap: lane r takes taps r, r + 4, ... -- or, when only a few channels of the wave are due
+//     (calls that did not start together), the wave's lanes take a tap each of one such channel after the other;
 //   * everything scalar (carrier detect, AGC, Godard filters, the training state machine, descrambler) is replicated
 //     in the four lanes, so every decision is uniform over the quad and no value ever has to be sent back.
 // Results are the reference's bit for bit: tests/test_quad_emul.py runs THIS source on the host (four fibers per
