@@ -861,7 +861,13 @@ SPANGPU_API int spangpu_modem_shard_sync(spangpu_modem_shard_t *shard);
      spangpu_vec_circular_lmsf_batch         vec_circular_lmsf(x, y, n, pos, error)     src/vector_float.c:942,982-1000
      spangpu_cvec_circular_dot_prodf_batch   cvec_circular_dot_prodf(x, y, n, pos)     src/complex_vector_float.c:137-150,187-196
      spangpu_cvec_circular_lmsf_batch        cvec_circular_lmsf(x, y, n, pos, &error)   src/complex_vector_float.c:201-219
-     spangpu_power_meter_update_batch        power_meter_update() over a row of samples  src/power_meter.c:65-70 */
+     spangpu_power_meter_update_batch        power_meter_update() over a row of samples  src/power_meter.c:65-70
+     spangpu_godard_ted_rx_batch             godard_ted_rx() over a row of samples       src/godard.c:144-162
+     spangpu_godard_ted_per_baud_batch       godard_ted_per_baud()                       src/godard.c:165-220
+   A Godard timing error detector's item is eight state words {low_band_edge[2], high_band_edge[2], dc_filter[2], baud_phase (floats),
+   total_baud_timing_correction (int32)} and twelve descriptor words {low_band_edge_coeff[3], high_band_edge_coeff[3],
+   mixed_band_edges_coeff_3, coarse_trigger, fine_trigger (floats), coarse_step, fine_step (int32), 0}: the reference's structs
+   (src/spandsp/godard.h:57-77, private/godard.h:29-54) word for word.  A descriptor stride of 0 shares one among all items. */
 SPANGPU_API int spangpu_vec_circular_dot_prodf_batch(int device, const float *x, long long x_stride, const float *y, long long y_stride,
                                                      const int32_t *pos, float *z, int items, int n, int mem);
 SPANGPU_API int spangpu_vec_circular_lmsf_batch(int device, const float *x, long long x_stride, float *y, long long y_stride,
@@ -872,6 +878,10 @@ SPANGPU_API int spangpu_cvec_circular_lmsf_batch(int device, const float *x, lon
                                                  const int32_t *pos, const float *error, int items, int n, int mem);
 SPANGPU_API int spangpu_power_meter_update_batch(int device, const int16_t *amp, long long stride, int32_t *reading, const int32_t *shift,
                                                  int items, int n, int mem);
+SPANGPU_API int spangpu_godard_ted_rx_batch(int device, uint32_t *state, const uint32_t *desc, long long desc_stride, const float *samples,
+                                            long long stride, int items, int n, int mem);
+SPANGPU_API int spangpu_godard_ted_per_baud_batch(int device, uint32_t *state, const uint32_t *desc, long long desc_stride, int32_t *correction,
+                                                  int items, int mem);
 
 #if defined(__cplusplus)
 }

@@ -317,12 +317,36 @@ SPANGPU_API complexf_t cfilter_step(cfilter_t *cfi, const complexf_t *z);
  *   cvec_circular_dot_prodf, cvec_circular_lmsf   src/spandsp/complex_vector_float.h:159,163  src/complex_vector_float.c:187-196,215-219
  *   power_meter_t, power_meter_init/_release/_free/_damping/_update/_rx/_current
  *                                                 src/spandsp/power_meter.h:34-94, private/power_meter.h:33-40   src/power_meter.c:44-113
- * No host arithmetic behind them: without a HIP device the float results are NaN, power_meter_update() returns INT32_MIN. */
+ *   godard_ted_descriptor_t, godard_ted_state_t, godard_ted_make_descriptor/_free_descriptor/_init/_release/_free/_correction/_rx/_per_baud
+ *                                                 src/spandsp/godard.h:57-124, private/godard.h:29-54            src/godard.c:70-249
+ *     (the float build's structs, field for field; the descriptor's coefficients are table making and are formed on the host as the
+ *     reference forms them, the detector's arithmetic -- godard_ted_rx(), godard_ted_per_baud() -- is the device's)
+ * No host arithmetic behind them: without a HIP device the float results are NaN, power_meter_update() returns INT32_MIN,
+ * godard_ted_per_baud() returns 0 and leaves the state as it was. */
 typedef struct power_meter_s
 {
     int shift;
     int32_t reading;
 } power_meter_t;
+typedef struct godard_ted_descriptor_s
+{
+    float low_band_edge_coeff[3];
+    float high_band_edge_coeff[3];
+    float mixed_band_edges_coeff_3;
+    float coarse_trigger;
+    float fine_trigger;
+    int coarse_step;
+    int fine_step;
+} godard_ted_descriptor_t;
+typedef struct godard_ted_state_s
+{
+    godard_ted_descriptor_t desc;
+    float low_band_edge[2];
+    float high_band_edge[2];
+    float dc_filter[2];
+    float baud_phase;
+    int total_baud_timing_correction;
+} godard_ted_state_t;
 SPANGPU_API float vec_circular_dot_prodf(const float x[], const float y[], int n, int pos);
 SPANGPU_API void vec_circular_lmsf(const float x[], float y[], int n, int pos, float error);
 SPANGPU_API complexf_t cvec_circular_dot_prodf(const complexf_t x[], const complexf_t y[], int n, int pos);
@@ -334,6 +358,15 @@ SPANGPU_API power_meter_t *power_meter_damping(power_meter_t *s, int shift);
 SPANGPU_API int32_t power_meter_update(power_meter_t *s, int16_t amp);
 SPANGPU_API int32_t power_meter_rx(power_meter_t *s, int16_t amp[], int len);
 SPANGPU_API int32_t power_meter_current(power_meter_t *s);
+SPANGPU_API godard_ted_descriptor_t *godard_ted_make_descriptor(godard_ted_descriptor_t *desc, float sample_rate, float baud_rate, float carrier_freq,
+                                                                float alpha, float coarse_trigger, float fine_trigger, int coarse_step, int fine_step);
+SPANGPU_API int godard_ted_free_descriptor(godard_ted_descriptor_t *s);
+SPANGPU_API int godard_ted_correction(godard_ted_state_t *s);
+SPANGPU_API void godard_ted_rx(godard_ted_state_t *s, float sample);
+SPANGPU_API int godard_ted_per_baud(godard_ted_state_t *s);
+SPANGPU_API godard_ted_state_t *godard_ted_init(godard_ted_state_t *s, const godard_ted_descriptor_t *desc);
+SPANGPU_API int godard_ted_release(godard_ted_state_t *s);
+SPANGPU_API int godard_ted_free(godard_ted_state_t *s);
 SPANGPU_API void goertzel_reset(goertzel_state_t *s);
 SPANGPU_API int goertzel_update(goertzel_state_t *s, const int16_t amp[], int samples);
 SPANGPU_API float goertzel_result(goertzel_state_t *s);

@@ -120,6 +120,64 @@ __global__ void power_meter_kernel(const int16_t *amp, long long stride, int32_t
     reading[i] = r;
 }
 
+// godard_ted_rx(), godard.c:144-162: the two band edge filters over a row of samples (state and descriptor words: spangpu.h)
+__global__ void godard_rx_kernel(uint32_t *state, const uint32_t *desc, long long ds, const float *samples, long long stride, int items, int n)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= items)
+        return;
+    uint32_t *st = state + (size_t) i*8;
+    const uint32_t *d = desc + (size_t) i*ds;
+    const float lc0 = __uint_as_float(d[0]), lc1 = __uint_as_float(d[1]);
+    const float hc0 = __uint_as_float(d[3]), hc1 = __uint_as_float(d[4]);
+    float l0 = __uint_as_float(st[0]), l1 = __uint_as_float(st[1]);
+    float h0 = __uint_as_float(st[2]), h1 = __uint_as_float(st[3]);
+    const float *x = samples + (size_t) i*stride;
+    for (int k = 0;  k < n;  k++)
+    {
+        const float sample = x[k];
+        float v = l0*lc0 + l1*lc1 + sample;
+        l1 = l0;
+        l0 = v;
+        v = h0*hc0 + h1*hc1 + sample;
+        h1 = h0;
+        h0 = v;
+    }
+    st[0] = __float_as_uint(l0);
+    st[1] = __float_as_uint(l1);
+    st[2] = __float_as_uint(h0);
+    st[3] = __float_as_uint(h1);
+}
+
+// godard_ted_per_baud(), godard.c:165-220
+__global__ void godard_baud_kernel(uint32_t *state, const uint32_t *desc, long long ds, int32_t *correction, int items)
+{
+    const int i = blockIdx.x*blockDim.x + threadIdx.x;
+    if (i >= items)
+        return;
+    uint32_t *st = state + (size_t) i*8;
+    const uint32_t *d = desc + (size_t) i*ds;
+    const float l0 = __uint_as_float(st[0]), l1 = __uint_as_float(st[1]);
+    const float h0 = __uint_as_float(st[2]), h1 = __uint_as_float(st[3]);
+    float v = l1*h0*__uint_as_float(d[2]) - l0*h1*__uint_as_float(d[5]) + l1*h1*__uint_as_float(d[6]);
+    const float p = v - __uint_as_float(st[5]);
+    st[5] = st[4];
+    st[4] = __float_as_uint(v);
+    const float phase = __uint_as_float(st[6]) - p;
+    st[6] = __float_as_uint(phase);
+    v = fabsf(phase);
+    int corr = 0;
+    if (v > __uint_as_float(d[8]))                          // fine_trigger
+    {
+        int step = (v > __uint_as_float(d[7]))  ?  (int32_t) d[9]  :  (int32_t) d[10];
+        if (phase < 0.0f)
+            step = -step;
+        corr = step;
+        st[7] = (uint32_t) ((int32_t) st[7] + step);
+    }
+    correction[i] = corr;
+}
+
 // bring a host array to the device (or pass a device pointer through); *owned says whether to free it
 template <typename T>
 int stage_in(const T *src, size_t count, int mem, T **dev, bool *owned)
@@ -308,6 +366,62 @@ int spangpu_power_meter_update_batch(int device, const int16_t *amp, long long s
         PR_TRY(hipMemcpy(reading, dr, (size_t) items*sizeof(int32_t), hipMemcpyDeviceToHost));
     else
         PR_TRY(hipDeviceSynchronize());
+    return SPANGPU_OK;
+}
+
+// items Godard timing error detectors, each over its row of n samples (godard_ted_rx() n times)
+int spangpu_godard_ted_rx_batch(int device, uint32_t *state, const uint32_t *desc, long long desc_stride, const float *samples, long long stride,
+                                int items, int n, int mem)
+{
+    int rc = check(device, items, n, state, desc, samples, samples);
+    if (rc != SPANGPU_OK)
+        return rc;
+    Staged st;
+    uint32_t *dst, *dd;
+    float *dx;
+    bool o;
+    if ((rc = stage_in((const uint32_t *) state, (size_t) items*8, mem, &dst, &o)) < 0) return rc;
+    st.keep(dst, o);
+    if ((rc = stage_in(desc, (desc_stride  ?  (size_t) desc_stride*items  :  (size_t) 12), mem, &dd, &o)) < 0) return rc;
+    st.keep(dd, o);
+    if ((rc = stage_in(samples, (size_t) stride*(items - 1) + n, mem, &dx, &o)) < 0) return rc;
+    st.keep(dx, o);
+    hipLaunchKernelGGL(godard_rx_kernel, dim3((items + 63)/64), dim3(64), 0, 0, dst, (const uint32_t *) dd, desc_stride, (const float *) dx, stride, items, n);
+    PR_TRY(hipGetLastError());
+    if (mem != SPANGPU_MEM_DEVICE)
+        PR_TRY(hipMemcpy(state, dst, (size_t) items*8*sizeof(uint32_t), hipMemcpyDeviceToHost));
+    else
+        PR_TRY(hipDeviceSynchronize());
+    return SPANGPU_OK;
+}
+
+// godard_ted_per_baud() of every item: correction[i] = what the call returns (the step to add to eq_put_step)
+int spangpu_godard_ted_per_baud_batch(int device, uint32_t *state, const uint32_t *desc, long long desc_stride, int32_t *correction, int items, int mem)
+{
+    int rc = check(device, items, 1, state, desc, correction, correction);
+    if (rc != SPANGPU_OK)
+        return rc;
+    Staged st;
+    uint32_t *dst, *dd;
+    int32_t *dc;
+    bool o;
+    if ((rc = stage_in((const uint32_t *) state, (size_t) items*8, mem, &dst, &o)) < 0) return rc;
+    st.keep(dst, o);
+    if ((rc = stage_in(desc, (desc_stride  ?  (size_t) desc_stride*items  :  (size_t) 12), mem, &dd, &o)) < 0) return rc;
+    st.keep(dd, o);
+    if ((rc = stage_in((const int32_t *) correction, (size_t) items, mem, &dc, &o)) < 0) return rc;
+    st.keep(dc, o);
+    hipLaunchKernelGGL(godard_baud_kernel, dim3((items + 63)/64), dim3(64), 0, 0, dst, (const uint32_t *) dd, desc_stride, dc, items);
+    PR_TRY(hipGetLastError());
+    if (mem != SPANGPU_MEM_DEVICE)
+    {
+        PR_TRY(hipMemcpy(state, dst, (size_t) items*8*sizeof(uint32_t), hipMemcpyDeviceToHost));
+        PR_TRY(hipMemcpy(correction, dc, (size_t) items*sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    else
+    {
+        PR_TRY(hipDeviceSynchronize());
+    }
     return SPANGPU_OK;
 }
 

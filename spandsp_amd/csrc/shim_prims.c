@@ -3,6 +3,7 @@
  *   vec_circular_dot_prodf(), vec_circular_lmsf()          src/spandsp/vector_float.h:184,188    src/vector_float.c:932-939,996-1000
  *   cvec_circular_dot_prodf(), cvec_circular_lmsf()        src/spandsp/complex_vector_float.h:159,163   src/complex_vector_float.c:187-196,215-219
  *   power_meter_init/_release/_free/_damping/_update/_rx/_current   src/spandsp/power_meter.h:62-94      src/power_meter.c:44-113
+ *   godard_ted_make_descriptor/_free_descriptor/_init/_release/_free/_correction/_rx/_per_baud   src/spandsp/godard.h:85-118   src/godard.c:70-249
  * Each is one item through the batched entry point of csrc/prim_api.hip (a launch per call: the plumbing form, as a
  * one-channel receiver object is -- the receivers themselves run these fused in their kernels, and a caller with many
  * items uses the *_batch entry points).  The arithmetic is the device's, in the reference's order of operations; there is
@@ -12,6 +13,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "spangpu_spandsp.h"
 
@@ -117,4 +119,97 @@ int32_t power_meter_rx(power_meter_t *s, int16_t amp[], int len)
 int32_t power_meter_current(power_meter_t *s)
 {
     return s->reading;
+}
+
+/* ---- the Godard timing error detector (godard.c).  The descriptor is table making: its seven coefficients are formed on the
+   host with the expressions of godard.c:93-104.  The detector's filters and its per-baud decision run on the device, one
+   item through spangpu_godard_ted_rx_batch() / spangpu_godard_ted_per_baud_batch() a call; the state words those take are
+   this struct's, in place. ---- */
+godard_ted_descriptor_t *godard_ted_make_descriptor(godard_ted_descriptor_t *s, float sample_rate, float baud_rate, float carrier_freq,
+                                                    float alpha, float coarse_trigger, float fine_trigger, int coarse_step, int fine_step)
+{
+    float low_edge;
+    float high_edge;
+
+    if (s == NULL)
+    {
+        if ((s = (godard_ted_descriptor_t *) malloc(sizeof(*s))) == NULL)
+            return NULL;
+    }
+    memset(s, 0, sizeof(*s));
+    low_edge = 2.0f*M_PI*(carrier_freq - baud_rate/2.0f)/sample_rate;
+    high_edge = 2.0f*M_PI*(carrier_freq + baud_rate/2.0f)/sample_rate;
+    s->low_band_edge_coeff[0] = 2.0f*alpha*cosf(low_edge);
+    s->low_band_edge_coeff[1] = -alpha*alpha;
+    s->low_band_edge_coeff[2] = -alpha*sinf(low_edge);
+    s->high_band_edge_coeff[0] = 2.0f*alpha*cosf(high_edge);
+    s->high_band_edge_coeff[1] = -alpha*alpha;
+    s->high_band_edge_coeff[2] = -alpha*sinf(high_edge);
+    s->mixed_band_edges_coeff_3 = -alpha*alpha*(sinf(high_edge)*cosf(low_edge) - sinf(low_edge)*cosf(high_edge));
+    s->coarse_trigger = coarse_trigger;
+    s->fine_trigger = fine_trigger;
+    s->coarse_step = coarse_step;
+    s->fine_step = fine_step;
+    return s;
+}
+
+int godard_ted_free_descriptor(godard_ted_descriptor_t *s)
+{
+    free(s);
+    return 0;
+}
+
+int godard_ted_correction(godard_ted_state_t *s)
+{
+    return s->total_baud_timing_correction;
+}
+
+/* the twelve descriptor words the batched entry points read: the struct's eleven and a zero */
+static void godard_desc_words(const godard_ted_state_t *s, uint32_t w[12])
+{
+    memcpy(w, &s->desc, 11*sizeof(uint32_t));
+    w[11] = 0;
+}
+
+void godard_ted_rx(godard_ted_state_t *s, float sample)
+{
+    uint32_t w[12];
+
+    godard_desc_words(s, w);
+    (void) spangpu_godard_ted_rx_batch(prim_device(), (uint32_t *) s->low_band_edge, w, 0, &sample, 1, 1, 1, SPANGPU_MEM_HOST);
+}
+
+int godard_ted_per_baud(godard_ted_state_t *s)
+{
+    uint32_t w[12];
+    int32_t corr = 0;
+
+    godard_desc_words(s, w);
+    if (spangpu_godard_ted_per_baud_batch(prim_device(), (uint32_t *) s->low_band_edge, w, 0, &corr, 1, SPANGPU_MEM_HOST) < 0)
+        return 0;
+    return corr;
+}
+
+godard_ted_state_t *godard_ted_init(godard_ted_state_t *s, const godard_ted_descriptor_t *desc)
+{
+    if (s == NULL)
+    {
+        if ((s = (godard_ted_state_t *) malloc(sizeof(*s))) == NULL)
+            return NULL;
+    }
+    memset(s, 0, sizeof(*s));
+    s->desc = *desc;
+    return s;
+}
+
+int godard_ted_release(godard_ted_state_t *s)
+{
+    (void) s;
+    return 0;
+}
+
+int godard_ted_free(godard_ted_state_t *s)
+{
+    free(s);
+    return 0;
 }
