@@ -116,6 +116,7 @@ def lib():
             "echo_can_hpf_tx": (C.c_int16, [vp, C.c_int16]),
             "v29_rx": (ci, [vp, vp, ci]), "v29_rx_free": (ci, [vp]), "v29_rx_restart": (ci, [vp, ci, ci]),
             "v29_rx_signal_cutoff": (None, [vp, cf]),
+            "v29_rx_carrier_frequency": (cf, [vp]), "v29_rx_symbol_timing_correction": (cf, [vp]),
             "v29_tx": (ci, [vp, vp, ci]), "v29_tx_free": (ci, [vp]), "v29_tx_power": (None, [vp, cf]),
             "v27ter_rx": (ci, [vp, vp, ci]), "v27ter_rx_free": (ci, [vp]),
             "v27ter_tx": (ci, [vp, vp, ci]), "v27ter_tx_free": (ci, [vp]), "v27ter_tx_power": (None, [vp, cf]),
@@ -643,6 +644,13 @@ class V29Rx:
         w = np.zeros(43, np.int32)
         lib().glue_v29_rx_snapshot(self.p, f.ctypes.data, w.ctypes.data)
         return f, w
+
+    def carrier_frequency(self):
+        return float(lib().v29_rx_carrier_frequency(self.p))
+
+    def symbol_timing_correction(self):
+        """in steps of the pulse shaper's coefficient sets (48 to a sample), v29rx.c:180-183"""
+        return float(lib().v29_rx_symbol_timing_correction(self.p))
 
 
 class V27terRx:

@@ -222,6 +222,19 @@ def make_g711_encode():
          ulaw=np.array([L.glue_linear_to_ulaw(int(x)) for x in v], np.uint8))
 
 
+def modem_offset_goldens():
+    """The three receivers of the real reference on lines with a carrier offset and a sample clock offset (tests/impair.py),
+    three seconds each, and on lines too far off to train: input, every put_bit / status call, the final state words."""
+    from test_oracle_pin import MODEM_OFFSET_CASES, MODEM_OFFSET_GOLDEN, modem_offset_expectations, modem_offset_name, modem_offset_receivers, modem_offset_scenario
+    for i in MODEM_OFFSET_GOLDEN:
+        case = MODEM_OFFSET_CASES[i]
+        x = modem_offset_scenario(case)
+        make_ref, _ = modem_offset_receivers(case[0])
+        ev, f, w = v29_run(make_ref(case[1]), x, (160,))
+        modem_offset_expectations(case, ev)
+        save(modem_offset_name(case), amp=x, carrier_hz=case[4], ppm=case[5], events=ev.astype(np.int8), fwords=f, iwords=w)
+
+
 def make_g168():
     import zlib
     # the G.168 echo path models (test data of the reference: src/spandsp/g168models.h) and the known answer of
@@ -340,6 +353,7 @@ def main():
         assert len(ev) >= 2
         save("mct_%d_%s" % (rx_type, tx_kind), amp=x, events=ev, snapshots=snaps)
     sigtone_goldens()
+    modem_offset_goldens()
     kw = {"table": ref.v29_tx_table()}
     for i, (bit_rate, tep, seed) in enumerate(V29TX_CASES):
         kw["amp_%d" % i], kw["snaps_%d" % i] = v29tx_run(ref.V29Tx(bit_rate, tep, seed), seed)
@@ -377,6 +391,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["sigtone"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         sigtone_goldens()
+    elif sys.argv[1:] == ["modem_offsets"]:
+        assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+        modem_offset_goldens()
     elif sys.argv[1:] == ["dtmf_callbacks"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         dtmf_callbacks()

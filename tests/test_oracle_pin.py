@@ -1162,6 +1162,106 @@ def test_v17_qam_reports_live(built, bit_rate, seed, noise):
 
 
 # ---------------------------------------------------------------------------------
+# the modem receivers off their fixed points: carrier offset and sample clock offset (tests/impair.py)
+# ---------------------------------------------------------------------------------
+# (modem, bit rate, seed, noise dBm0, carrier offset Hz, clock offset ppm, samples of signal).  With the reference's own modulator
+# as the only source (every case above) the carrier loop (v29rx.c:297-331 track_carrier, v17rx.c:311-339, v27ter_rx.c:296-325)
+# and the symbol timing loop (godard.c:165-220; v27ter_rx.c:486-529 symbol_sync) sit at their fixed points.  Here the carrier
+# is 3 .. 7 Hz off and the far end's clock 50 .. 100 ppm off, over three seconds, so that the timing loop
+# steps through the pulse shaper's coefficient sets again and again; three cases are too far off and FAIL training.
+MODEM_OFFSET_CASES = [("v29", 9600, 61, -45.0, 7.0, 100.0, 24000), ("v29", 7200, 62, -42.0, -7.0, -100.0, 24000),
+                      ("v29", 4800, 63, -40.0, 3.0, -50.0, 16000), ("v29", 9600, 64, -45.0, 30.0, 0.0, 6000),
+                      ("v27ter", 4800, 65, -50.0, -7.0, 100.0, 24000), ("v27ter", 2400, 66, -50.0, 7.0, -100.0, 24000),
+                      ("v27ter", 4800, 67, -50.0, 25.0, 0.0, 10000),
+                      ("v17", 14400, 68, -55.0, 7.0, -100.0, 24000), ("v17", 9600, 69, -50.0, -3.0, 50.0, 20000),
+                      ("v17", 7200, 70, -48.0, -7.0, 100.0, 20000), ("v17", 14400, 71, -55.0, 25.0, 0.0, 11200)]
+MODEM_OFFSET_GOLDEN = [0, 1, 3, 4, 6, 7, 10]                # the cases frozen in tests/golden/modem_offset_*.npz
+
+
+def modem_offset_name(case):
+    name, bit_rate, seed, noise, hz, ppm, n = case
+    return "modem_offset_%s_%d_%d" % (name, bit_rate, seed)
+
+
+def modem_offset_scenario(case):
+    """The scenario of the modem's own live test, longer, through tests/impair.py's line."""
+    import impair
+    name, bit_rate, seed, noise, hz, ppm, n = case
+    if name == "v29":
+        x = v29_scenario(bit_rate, seed, noise, n_signal=n)
+    elif name == "v27ter":
+        x = v27ter_scenario(bit_rate, seed, noise, n_signal=n)
+    else:
+        x = v17_scenario(bit_rate, seed, noise, n_long=n)
+    return impair.line(x, hz, ppm)
+
+
+def modem_offset_receivers(name):
+    from oracle import ref, restated as orc
+    return {"v29": (ref.V29Rx, orc.V29), "v27ter": (ref.V27terRx, orc.V27ter), "v17": (ref.V17Rx, orc.V17)}[name]
+
+
+def modem_offset_expectations(case, ev):
+    """What each case is there to show: the receiver trained and carried data with its loops pulled off centre, or it
+    gave up (SIG_STATUS_TRAINING_FAILED = -5) and went back to waiting."""
+    name, bit_rate, seed, noise, hz, ppm, n = case
+    if abs(hz) > 20.0:
+        assert -5 in ev and -4 not in ev and len(ev) < 20
+    else:
+        assert -4 in ev and -5 not in ev and -1 in ev
+        assert len(ev) > 0.45*n*bit_rate/8000
+
+
+@needs_ref
+@pytest.mark.parametrize("case", MODEM_OFFSET_CASES, ids=modem_offset_name)
+@pytest.mark.parametrize("chunks", [(160,), (1, 7, 333, 64)])
+def test_modem_offsets_live(built, case, chunks):
+    use_golden_modem_tables()
+    x = modem_offset_scenario(case)
+    make_ref, make_orc = modem_offset_receivers(case[0])
+    ev_r, f_r, w_r = v29_run(make_ref(case[1]), x, chunks)
+    ev_o, f_o, w_o = v29_run(make_orc(case[1]), x, chunks)
+    modem_offset_expectations(case, ev_r)
+    assert np.array_equal(ev_r, ev_o)
+    assert np.array_equal(w_r, w_o)
+    assert np.array_equal(f_r, f_o)
+
+
+@needs_ref
+def test_modem_offsets_move_the_loops(built):
+    """The point of the cases: with the line's offsets the carrier loop's phase rate ends away from nominal by about the
+    offset, and the timing loop has stepped many times (total_baud_timing_correction); without them neither has."""
+    from oracle import ref
+    use_golden_modem_tables()
+    case = MODEM_OFFSET_CASES[0]
+    name, bit_rate, seed, noise, hz, ppm, n = case
+    rx = ref.V29Rx(bit_rate)
+    v29_run(rx, modem_offset_scenario(case)[:n], (160,))           # stop while the carrier is up
+    off = rx.carrier_frequency() - 1700.0
+    assert abs(off - hz) < 1.0, off
+    rx0 = ref.V29Rx(bit_rate)
+    v29_run(rx0, v29_scenario(bit_rate, seed, noise, n_signal=n)[:n], (160,))
+    assert abs(rx0.carrier_frequency() - 1700.0) < 0.5
+    # v29_rx_symbol_timing_correction() is in bauds; a baud is 160 steps of the 48-sets-a-sample pulse shaper (v29rx.c:151-154).
+    # 100 ppm over 24 000 samples is 2.4 samples = 115 steps beyond what acquisition takes on the unimpaired line
+    moved = (rx.symbol_timing_correction() - rx0.symbol_timing_correction())*160.0
+    assert -125.0 < moved < -105.0, moved                    # more than twice round the 48 coefficient sets
+
+
+@pytest.mark.parametrize("case", [MODEM_OFFSET_CASES[i] for i in MODEM_OFFSET_GOLDEN], ids=modem_offset_name)
+def test_golden_modem_offsets(built, case):
+    use_golden_modem_tables()
+    g = np.load(os.path.join(GOLDEN, modem_offset_name(case) + ".npz"))
+    assert (float(g["carrier_hz"]), float(g["ppm"])) == (case[4], case[5])
+    _, make_orc = modem_offset_receivers(case[0])
+    ev, f, w = v29_run(make_orc(case[1]), g["amp"], (160,))
+    modem_offset_expectations(case, ev)
+    assert np.array_equal(ev, g["events"].astype(np.int32))
+    assert np.array_equal(f, g["fwords"])
+    assert np.array_equal(w, g["iwords"])
+
+
+# ---------------------------------------------------------------------------------
 # frozen pins: golden vectors generated from the reference build
 # ---------------------------------------------------------------------------------
 def test_golden_files_present():

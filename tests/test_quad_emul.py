@@ -153,3 +153,29 @@ def test_v27ter_quad_on_the_host_matches_oracle(built, emul, bit_rate, chunks):
         return emul.emul_v27ter_rx(bit_rate, *a)
     total, seen = against_oracle(lambda: orc.V27ter(bit_rate), call, sig, chunks, ("v27ter", bit_rate))
     assert total > 800*n_ch//3 and {-1, -2, -3, -4} <= seen
+
+
+def _offset_cases():
+    from test_oracle_pin import MODEM_OFFSET_CASES, MODEM_OFFSET_GOLDEN
+    return [MODEM_OFFSET_CASES[i] for i in MODEM_OFFSET_GOLDEN]
+
+
+@pytest.mark.parametrize("case", _offset_cases(), ids=lambda c: "%s_%d_%d" % (c[0], c[1], c[2]))
+def test_quad_on_the_host_with_line_offsets(built, emul, case):
+    """The committed inputs with a carrier offset and a clock offset (tests/golden/modem_offset_*.npz, tests/impair.py): the
+    carrier loop pulled 7 Hz off, the timing loop stepping through the coefficient sets, training that fails."""
+    from oracle import restated as orc
+    from test_oracle_pin import modem_offset_name
+    use_golden_modem_tables()
+    name, bit_rate = case[0], case[1]
+    g = np.load(os.path.join(GOLDEN, modem_offset_name(case) + ".npz"))
+    sig = g["amp"][None, :]
+    if name == "v29":
+        make, call = (lambda: orc.V29(bit_rate)), emul.emul_v29_rx
+    elif name == "v27ter":
+        make, call = (lambda: orc.V27ter(bit_rate)), (lambda *a: emul.emul_v27ter_rx(bit_rate, *a))
+    else:
+        make, call = (lambda: orc.V17(bit_rate)), (lambda *a: emul.emul_v17_rx(bit_rate, *a))
+    total, seen = against_oracle(make, call, sig, (160, 97, 3), (name, bit_rate, case[4], case[5]))
+    assert total == len(g["events"])
+    assert (-5 in seen) == (abs(case[4]) > 20.0)
