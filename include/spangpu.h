@@ -433,7 +433,11 @@ SPANGPU_API int spangpu_modem_restart(spangpu_modem_t *modem, int channel);
 SPANGPU_API int spangpu_modem_restart_ex(spangpu_modem_t *modem, int channel, int bit_rate, int train_flag);
 /* xxx_rx_fillin(s, len) (v29rx.c:967) and xxx_rx_set_signal_cutoff(s, cutoff) (v29rx.c:163) */
 SPANGPU_API int spangpu_modem_fillin(spangpu_modem_t *modem, int channel, int len);
+/* channel -1: every channel of the bank (fax_modems.c:416 gives each of its V.29 receivers -45.5 dBm0; the default, -28.5 dBm0
+ * (v29rx.c:1129), leaves a line below some -26 dBm0 undetected) */
 SPANGPU_API int spangpu_modem_set_signal_cutoff(spangpu_modem_t *modem, int channel, float cutoff_dbm0);
+/* ... and every channel with a cutoff of its own: cutoff_dbm0[n_channels] */
+SPANGPU_API int spangpu_modem_set_signal_cutoffs(spangpu_modem_t *modem, const float *cutoff_dbm0);
 /* The constant tables the modem receivers use, as built by this library (host code; see modem_api.hip for `which`). */
 SPANGPU_API int spangpu_modem_table(int which, float *out, int max);
 /* Tuning / A-B testing: how the receiver kernels map channels to lanes from now on: 0 = by bank size (four lanes per channel
@@ -707,6 +711,11 @@ SPANGPU_API int spangpu_modemtx_channels(const spangpu_modemtx_t *tx);
 SPANGPU_API int spangpu_modemtx_set_stream(spangpu_modemtx_t *tx, void *hip_stream);
 SPANGPU_API int spangpu_modemtx_sync(spangpu_modemtx_t *tx);
 SPANGPU_API int spangpu_modemtx_power(spangpu_modemtx_t *tx, int channel, float power_dbm0);
+/* Every channel's level (xxx_tx_power(), as above) and carrier frequency in Hz in one call; either array may be NULL (left
+ * as it is).  The carrier frequency is a line model, not a reference API: v29_tx_init() fixes the carrier at 1700 Hz
+ * (src/v29tx.c:431), v27ter / v17 at 1800 Hz; a few hertz either side stand for the frequency shift of a carrier system
+ * between the modems (1700 Hz +- 7 Hz). */
+SPANGPU_API int spangpu_modemtx_line(spangpu_modemtx_t *tx, const float *power_dbm0, const float *carrier_hz);
 SPANGPU_API int spangpu_modemtx_restart(spangpu_modemtx_t *tx, int channel, int bit_rate, int tep);
 SPANGPU_API int spangpu_modemtx_restart_ex(spangpu_modemtx_t *tx, int channel, int bit_rate, int tep, int short_train);
 /* pcm[channel*stride + i], i < samples, where mem says; returns samples */

@@ -115,7 +115,7 @@ def lib():
             "echo_can_update": (C.c_int16, [vp, C.c_int16, C.c_int16]),
             "echo_can_hpf_tx": (C.c_int16, [vp, C.c_int16]),
             "v29_rx": (ci, [vp, vp, ci]), "v29_rx_free": (ci, [vp]), "v29_rx_restart": (ci, [vp, ci, ci]),
-            "v29_rx_signal_cutoff": (None, [vp, cf]),
+            "v29_rx_set_signal_cutoff": (None, [vp, cf]), "v27ter_rx_set_signal_cutoff": (None, [vp, cf]), "v17_rx_set_signal_cutoff": (None, [vp, cf]),
             "v29_rx_carrier_frequency": (cf, [vp]), "v29_rx_symbol_timing_correction": (cf, [vp]),
             "v29_tx": (ci, [vp, vp, ci]), "v29_tx_free": (ci, [vp]), "v29_tx_power": (None, [vp, cf]),
             "v27ter_rx": (ci, [vp, vp, ci]), "v27ter_rx_free": (ci, [vp]),
@@ -644,6 +644,9 @@ class V29Rx:
         w = np.zeros(43, np.int32)
         lib().glue_v29_rx_snapshot(self.p, f.ctypes.data, w.ctypes.data)
         return f, w
+
+    def set_signal_cutoff(self, cutoff_dbm0):
+        lib().v29_rx_set_signal_cutoff(self.p, cutoff_dbm0)
 
     def carrier_frequency(self):
         return float(lib().v29_rx_carrier_frequency(self.p))

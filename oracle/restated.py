@@ -430,6 +430,13 @@ class V29:
     def tap_qam(self):
         self.sink.want_qam(True)
 
+    def set_signal_cutoff(self, cutoff_dbm0):
+        """v29_rx_set_signal_cutoff(), v29rx.c:163-169 (init gives -28.5 dBm0; fax_modems.c:416 sets -45.5)"""
+        fn = lib().orc_v29_set_signal_cutoff
+        fn.restype = None
+        fn.argtypes = [C.c_void_p, C.c_float]
+        fn(self.p, cutoff_dbm0)
+
     def rx(self, amp):
         amp = _i16(amp)
         return lib().orc_v29_rx(self.p, amp.ctypes.data, len(amp), self.sink.p)

@@ -1266,17 +1266,53 @@ int spangpu_modem_fillin(spangpu_modem_t *m, int channel, int len)
 // xxx_rx_set_signal_cutoff(s, cutoff) (v29rx.c:163-169)
 int spangpu_modem_set_signal_cutoff(spangpu_modem_t *m, int channel, float cutoff_dbm0)
 {
-    if (m == nullptr  ||  channel < 0  ||  channel >= m->n_ch)
+    if (m == nullptr  ||  channel < -1  ||  channel >= m->n_ch)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    const int i_on = (m->kind == SPANGPU_V29)  ?  VI_ON_POWER  :  (m->kind == SPANGPU_V17)  ?  XI_ON_POWER  :  WI_ON_POWER;
+    if (channel == -1)
+    {
+        // every channel of the bank (what fax_modems.c:416 does for each of its receivers): the two words are rows of the state
+        V29_TRY(hipSetDevice(m->device));
+        V29_TRY(hipStreamSynchronize(m->stream));
+        uint32_t *row = m->state + (size_t) (m->n_floats + i_on)*m->n_ch;
+        V29_TRY(hipMemsetD32((hipDeviceptr_t) row, (int32_t) (level_dbm0(cutoff_dbm0 + 2.5f)*0.4f), (size_t) m->n_ch));
+        V29_TRY(hipMemsetD32((hipDeviceptr_t) (row + m->n_ch), (int32_t) (level_dbm0(cutoff_dbm0 - 2.5f)*0.4f), (size_t) m->n_ch));
+        return SPANGPU_OK;
+    }
     uint32_t w[kMaxWords];
     const int rc = fetch_words(m, channel, w);
     if (rc < 0)
         return rc;
     int32_t *iw = (int32_t *) (w + m->n_floats);
-    const int i_on = (m->kind == SPANGPU_V29)  ?  VI_ON_POWER  :  (m->kind == SPANGPU_V17)  ?  XI_ON_POWER  :  WI_ON_POWER;
     iw[i_on] = (int32_t) (level_dbm0(cutoff_dbm0 + 2.5f)*0.4f);
     iw[i_on + 1] = (int32_t) (level_dbm0(cutoff_dbm0 - 2.5f)*0.4f);
     return store_words(m, channel, w);
+}
+
+// xxx_rx_set_signal_cutoff() of every channel with a cutoff of its own (an installation sets the carrier detector for the
+// level of its lines): two rows of the state
+int spangpu_modem_set_signal_cutoffs(spangpu_modem_t *m, const float *cutoff_dbm0)
+{
+    if (m == nullptr  ||  cutoff_dbm0 == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad arguments");
+    const int i_on = (m->kind == SPANGPU_V29)  ?  VI_ON_POWER  :  (m->kind == SPANGPU_V17)  ?  XI_ON_POWER  :  WI_ON_POWER;
+    int32_t *rows = (int32_t *) malloc((size_t) 2*m->n_ch*sizeof(int32_t));
+    if (rows == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "malloc");
+    for (int c = 0;  c < m->n_ch;  c++)
+    {
+        rows[c] = (int32_t) (level_dbm0(cutoff_dbm0[c] + 2.5f)*0.4f);
+        rows[m->n_ch + c] = (int32_t) (level_dbm0(cutoff_dbm0[c] - 2.5f)*0.4f);
+    }
+    hipError_t e = hipSetDevice(m->device);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(m->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy(m->state + (size_t) (m->n_floats + i_on)*m->n_ch, rows, (size_t) 2*m->n_ch*sizeof(int32_t), hipMemcpyHostToDevice);
+    free(rows);
+    if (e != hipSuccess)
+        return spangpu_set_error(SPANGPU_ERR_HIP, "state upload failed");
+    return SPANGPU_OK;
 }
 
 // The constant tables this library builds (for tests).  which: 0 sine [2048], 1 sqrt (as float) [193],

@@ -332,6 +332,48 @@ int spangpu_modemtx_power(spangpu_modemtx_t *t, int channel, float power_dbm0)
     return rw_words(t, channel, w, true);
 }
 
+// Every channel's level and carrier frequency in one pass over the state words: a population of lines for the receiver
+// banks' workloads (carrier 1700 Hz +- 7 Hz, level -30 .. -10 dBm0).  The level is xxx_tx_power()'s; the
+// carrier frequency is not something the reference's modulator lets a caller choose (v29tx.c:431 fixes it) -- it stands for the
+// frequency shift of the line between the modems.
+int spangpu_modemtx_line(spangpu_modemtx_t *t, const float *power_dbm0, const float *carrier_hz)
+{
+    if (t == NULL)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null bank");
+    if (power_dbm0 == NULL  &&  carrier_hz == NULL)
+        return SPANGPU_OK;
+    for (int c = 0;  carrier_hz  &&  c < t->n_ch;  c++)
+    {
+        if (!(carrier_hz[c] > 0.0f  &&  carrier_hz[c] < 4000.0f))
+            return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "carrier frequency out of range");
+    }
+    VT_TRY(hipSetDevice(t->device));
+    VT_TRY(hipStreamSynchronize(t->stream));
+    const size_t n = (size_t) t->n_ch;
+    int32_t *host = (int32_t *) malloc((size_t) kV29TxWords*n*sizeof(int32_t));
+    if (host == NULL)
+        return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "malloc");
+    hipError_t e = hipMemcpy(host, t->st, (size_t) kV29TxWords*n*sizeof(int32_t), hipMemcpyDeviceToHost);
+    for (int c = 0;  e == hipSuccess  &&  c < t->n_ch;  c++)
+    {
+        int32_t w[kV29TxWords];
+        for (int k = 0;  k < kV29TxWords;  k++)
+            w[k] = host[(size_t) k*n + c];
+        if (power_dbm0)
+            power_words(w, t->kind, power_dbm0[c]);
+        if (carrier_hz)
+            w[VT_CARRIER_RATE] = spg_dds_phase_ratef(carrier_hz[c]);
+        for (int k = 0;  k < kV29TxWords;  k++)
+            host[(size_t) k*n + c] = w[k];
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy(t->st, host, (size_t) kV29TxWords*n*sizeof(int32_t), hipMemcpyHostToDevice);
+    free(host);
+    if (e != hipSuccess)
+        return spangpu_set_error(SPANGPU_ERR_HIP, "state transfer failed");
+    return SPANGPU_OK;
+}
+
 int spangpu_modemtx_restart(spangpu_modemtx_t *t, int channel, int bit_rate, int tep)
 {
     return spangpu_modemtx_restart_ex(t, channel, bit_rate, tep, 0);

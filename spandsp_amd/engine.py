@@ -104,6 +104,7 @@ def lib():
             "spangpu_modemtx_set_stream": (ci, [vp, vp]),
             "spangpu_modemtx_sync": (ci, [vp]),
             "spangpu_modemtx_power": (ci, [vp, ci, cf]),
+            "spangpu_modemtx_line": (ci, [vp, vp, vp]),
             "spangpu_modemtx_restart": (ci, [vp, ci, ci, ci]),
             "spangpu_modemtx_restart_ex": (ci, [vp, ci, ci, ci, ci]),
             "spangpu_modemtx_tx": (ci, [vp, ci, vp, ll, ci]),
@@ -267,6 +268,7 @@ def lib():
             "spangpu_modem_state_words": (ci, [ci, C.POINTER(ci), C.POINTER(ci)]),
             "spangpu_modem_get_state": (ci, [vp, ci, vp]),
             "spangpu_modem_restart": (ci, [vp, ci]),
+            "spangpu_modem_set_signal_cutoff": (ci, [vp, ci, cf]), "spangpu_modem_set_signal_cutoffs": (ci, [vp, vp]),
             "spangpu_modem_table": (ci, [ci, vp, ci]),
             "spangpu_v17_rx_maps": (ci, [vp, vp]),
             "spangpu_echo_create": (ci, [C.POINTER(vp), ci, ci, ci, ci]),
@@ -1143,6 +1145,15 @@ class ModemBank:
     def restart(self, channel):
         _check(lib().spangpu_modem_restart(self.h, channel))
 
+    def set_signal_cutoff(self, channel, cutoff_dbm0):
+        """xxx_rx_set_signal_cutoff(); channel -1 = every channel of the bank"""
+        _check(lib().spangpu_modem_set_signal_cutoff(self.h, channel, cutoff_dbm0))
+
+    def set_signal_cutoffs(self, cutoffs_dbm0):
+        c = np.ascontiguousarray(cutoffs_dbm0, np.float32)
+        assert len(c) == self.n
+        _check(lib().spangpu_modem_set_signal_cutoffs(self.h, c.ctypes.data))
+
 
 class V29Bank(ModemBank):
     def __init__(self, n_channels, bit_rate=9600, device=0):
@@ -1590,6 +1601,13 @@ class ModemTxBank:
 
     def power(self, channel, level_dbm0):
         _check(lib().spangpu_modemtx_power(self.h, channel, level_dbm0))
+
+    def line(self, power_dbm0=None, carrier_hz=None):
+        """every channel's level and / or carrier frequency at once (the carrier: a line model, see include/spangpu.h)"""
+        p = None if power_dbm0 is None else np.ascontiguousarray(power_dbm0, np.float32)
+        f = None if carrier_hz is None else np.ascontiguousarray(carrier_hz, np.float32)
+        assert (p is None or len(p) == self.n) and (f is None or len(f) == self.n)
+        _check(lib().spangpu_modemtx_line(self.h, None if p is None else p.ctypes.data, None if f is None else f.ctypes.data))
 
     def restart(self, channel, bit_rate, tep, short_train=False):
         _check(lib().spangpu_modemtx_restart_ex(self.h, channel, bit_rate, int(tep), int(short_train)))

@@ -195,40 +195,54 @@ def test_v17_full_wave_kernel_65650_channels(built):
         assert np.array_equal(bits(f), bits(fo)), c
 
 
+ST_PLAN = ([(400, 0, 700, 0)], [(1100, 0, 400, 600), (0, 0, 2800, 3200)], [(350, 440, 400, 0)],
+           [(480, 620, 450, 550), (0, 0, 450, 550)], [(950, 0, 300, 0)], [(1400, 0, 300, 0)])
+ST_LINES = ([(400, 0, 1500)], [(1100, 0, 500), (0, 0, 3000)], [(350, 440, 1200), (0, 0, 300)], [(480, 620, 500), (0, 0, 500)],
+            [(950, 0, 330), (1400, 0, 330), (0, 0, 1000)], [(620, 0, 300), (0, 0, 200)])
+
+
 def test_mixed_banks_131072_channels(built):
-    """configs[2]: Bell MF + R2 MF + super-tone, 131 072 channels in all."""
+    """configs[2]: Bell MF + R2 MF + super_tone_rx() -- block decisions AND, for the super-tone third, the cadence matcher's tone
+    and segment reports (super_tone_rx.c:164-228, :369-445) -- 131 072 channels in all."""
     from oracle import restated as orc
     from spandsp_amd import engine
-    V, n_frames = 128, 12
+    V = 128
+    n_frames = [12, 12, 200]                         # 4 s for the super-tone lines: the ring-back cadence needs 3.5 s
     n_each = [43690, 43690, 43692]
-    srcs = [synth.bell_mf_channels(V, n_frames*160, 31)[0], synth.r2_mf_channels(V, n_frames*160, 32, True)[0],
-            synth.call_progress_channels(V, n_frames*160, 33)]
-    # the call-progress plan of the third bank as a super-tone descriptor: 8 monitored frequencies
+    srcs = [synth.bell_mf_channels(V, n_frames[0]*160, 31)[0], synth.r2_mf_channels(V, n_frames[1]*160, 32, True)[0],
+            synth.cadence_plan_channels(V, n_frames[2]*160, 33, ST_LINES)]
+    # the call-progress plan of the third bank as a super-tone descriptor (the one of tests/super_tone_rx_tests.c:361-374 and
+    # four more tones): 8 monitored frequencies
     desc = orc.SuperToneDesc()
-    for tone in ([(400, 0, 700, 0)], [(1100, 0, 400, 600), (0, 0, 2800, 3200)], [(350, 440, 400, 0)],
-                 [(480, 620, 450, 550), (0, 0, 450, 550)], [(950, 0, 300, 0)], [(1400, 0, 300, 0)]):
+    for tone in ST_PLAN:
         t = desc.add_tone()
         for f1, f2, lo, hi in tone:
             desc.add_element(t, f1, f2, lo, hi)
     fac = [float(f) for f in desc.fac]
     assert len(fac) == 8
+    hz = [400, 1100, 350, 440, 480, 620, 950, 1400]                  # the order the descriptor met them in
+    assert [engine.goertzel_fac(float(f)) for f in hz] == fac
+    bins = {0: -1}
+    bins.update({f: i for i, f in enumerate(hz)})
     banks = [engine.ToneBank(engine.BELL_MF, n_each[0]), engine.ToneBank(engine.R2_MF, n_each[1], r2_fwd=True),
              engine.ToneBank(engine.SUPER_TONE, n_each[2], bin_fac=fac)]
+    banks[2].set_cadences([[(bins[f1], bins[f2], lo, hi) for f1, f2, lo, hi in t] for t in ST_PLAN], want_segments=True)
     hits = 0
+    reports = segments = 0
     for kind in range(3):
         n = n_each[kind]
         reps = -(-n//V)
         sig = np.tile(srcs[kind], (reps, 1))[:n]
         per_frame = []
-        for k in range(n_frames):
+        per_frame_cad = []
+        for k in range(n_frames[kind]):
             banks[kind].rx_host(sig[:, k*160:(k + 1)*160])
             per_frame.append(banks[kind].blocks())
-        # replica property: channel c and channel c % V report the same blocks
+            if kind == 2:
+                per_frame_cad.append(banks[kind].cadence_events())
+        # replica property: channel c and channel c % V report the same blocks (and the same cadence events)
         for k, b in enumerate(per_frame):
             first = b[b["channel"] < V]
-            key = {}
-            for r in first:
-                key.setdefault(int(r["channel"]), []).append((int(r["block"]), int(r["hit"]), int(r["code"]), int(r["flags"])))
             nb = len(first)//V
             assert len(b) == nb*n, (kind, k)
             rr = b.reshape(n, nb)
@@ -236,6 +250,10 @@ def test_mixed_banks_131072_channels(built):
             for name in ("block", "hit", "code", "flags"):
                 assert np.array_equal(rr[name], ref_rows[name][np.arange(n) % V]), (kind, k, name)
             hits += int((first["hit"] != 0).sum())
+            if kind == 2:
+                cad = per_frame_cad[k]
+                for c in range(V, n):
+                    assert cad[c] == cad[c % V], (k, c)
         # oracle on the first V channels: hit and code of every block, in order
         for c in range(V):
             if kind == 0:
@@ -243,16 +261,23 @@ def test_mixed_banks_131072_channels(built):
             elif kind == 1:
                 o = orc.R2Mf(True, True)
             else:
-                o = orc.SuperTone(desc)
+                o = orc.SuperTone(desc, True)
             blocks = []
-            for k in range(n_frames):
+            for k in range(n_frames[kind]):
                 blocks.extend(o.rx(srcs[kind][c, k*160:(k + 1)*160]))
+                if kind == 2:
+                    want = [tuple(int(x) for x in e) for e in o.sink.events()]
+                    o.sink.clear()
+                    assert per_frame_cad[k][c] == want, (k, c, per_frame_cad[k][c], want)
+                    reports += sum(1 for e in want if e[0] == 1)
+                    segments += sum(1 for e in want if e[0] == 4)
             got = [(int(r["hit"]), int(r["code"])) for b in per_frame for r in b[b["channel"] == c]]
             assert got == [(int(x["hit"]), int(x["aux"])) for x in blocks], (kind, c)
             if kind == 0:
                 digits = "".join(chr(int(r["code"])) for b in per_frame for r in b[b["channel"] == c] if r["flags"] & engine.BLK_REPORT)
                 assert digits == o.get(), (c, digits)
     assert hits > 100
+    assert reports > V and segments > 4*V, (reports, segments)
     for b in banks:
         b.close()
 

@@ -20,14 +20,20 @@ from test_oracle_pin import (GOLDEN, MODEM_OFFSET_CASES, MODEM_OFFSET_GOLDEN, bi
 pytestmark = pytest.mark.gpu
 
 
-def make_bank(name, n_ch, bit_rate):
+def make_bank(name, n_ch, bit_rate, cutoffs=None):
     from spandsp_amd import engine
-    return {"v29": engine.V29Bank, "v27ter": engine.V27terBank, "v17": engine.V17Bank}[name](n_ch, bit_rate)
+    bank = {"v29": engine.V29Bank, "v27ter": engine.V27terBank, "v17": engine.V17Bank}[name](n_ch, bit_rate)
+    if cutoffs is not None:
+        bank.set_signal_cutoffs(cutoffs)
+    return bank
 
 
-def make_oracle(name, bit_rate):
+def make_oracle(name, bit_rate, cutoff=None):
     from oracle import restated as orc
-    return {"v29": orc.V29, "v27ter": orc.V27ter, "v17": orc.V17}[name](bit_rate)
+    o = {"v29": orc.V29, "v27ter": orc.V27ter, "v17": orc.V17}[name](bit_rate)
+    if cutoff is not None:
+        o.set_signal_cutoff(float(cutoff))
+    return o
 
 
 def make_tx(name, bit_rate, seed):
@@ -44,7 +50,8 @@ def offset_channels(name, bit_rate, n_ch, n_signal, seed):
     lines = []
     for c in range(n_ch):
         tx = make_tx(name, bit_rate, int(rng.integers(1, 0x7FFF)))
-        tx.power(float(rng.uniform(-30.0, -10.0)))
+        level = float(rng.uniform(-30.0, -10.0))
+        tx.power(level)
         sig = tx.tx(n_signal)
         delay = int(rng.integers(0, 160))
         if c % 16 == 5:
@@ -58,15 +65,16 @@ def offset_channels(name, bit_rate, n_ch, n_signal, seed):
         x[40 + delay:40 + delay + len(sig)] = sig
         y = impair.line(x, hz, ppm).astype(np.float64)
         rms = np.sqrt(np.mean(sig.astype(np.float64)**2))
-        snr_db = rng.uniform(25.0, 40.0)
+        # (the reference's V.27ter receiver gives up training below some 35 dB: its lines are kept cleaner than SURVEY 8(d)-4's 25..40 dB)
+        snr_db = rng.uniform(38.0, 50.0) if name == "v27ter" else rng.uniform(25.0, 40.0)
         y += rng.normal(0.0, rms/10.0**(snr_db/20.0), n)
         out[c] = np.clip(np.rint(y), -32768, 32767).astype(np.int16)
-        lines.append((hz, ppm, delay, snr_db))
+        lines.append((hz, ppm, delay, snr_db, level))
     return out, lines
 
 
-def oracle_calls(name, bit_rate, x, chunks):
-    o = make_oracle(name, bit_rate)
+def oracle_calls(name, bit_rate, x, chunks, cutoff=None):
+    o = make_oracle(name, bit_rate, cutoff)
     per_call = []
     k = i = 0
     while k < len(x):
@@ -90,10 +98,16 @@ def test_offset_bank_matches_oracle(built, name, bit_rate, n_signal, chunks):
     use_v17_tx_tables(built)
     n_ch = 70                                   # two workgroups of the four-lane kernels, the second ragged
     sig, lines = offset_channels(name, bit_rate, n_ch, n_signal, seed=bit_rate + len(name))
-    want = [oracle_calls(name, bit_rate, sig[c], chunks) for c in range(n_ch)]
-    bank = make_bank(name, n_ch, bit_rate)
+    # v29_rx_init() leaves the carrier detector at -28.5 dBm0 (v29rx.c:1129), above the quieter lines here; at the FAX front
+    # end's -45.5 dBm0 (fax_modems.c:416) the noise of the louder lines holds it up for ever.  As an installation would, every
+    # V.29 line gets v29_rx_set_signal_cutoff(its level - 12 dB); V.17 and V.27ter stay at their own -45.5 dBm0.
+    cutoffs = np.array([ln[4] - 12.0 for ln in lines], np.float32) if name == "v29" else None
+    want = [oracle_calls(name, bit_rate, sig[c], chunks, None if cutoffs is None else cutoffs[c]) for c in range(n_ch)]
+    bank = make_bank(name, n_ch, bit_rate, cutoffs)
+    if cutoffs is not None:
+        bank.set_signal_cutoff(n_ch - 1, float(cutoffs[n_ch - 1]))      # (the one-channel form of the same call)
     check = sorted(set([0, 1, 5, 9, 15, 16, 63, 64, n_ch - 1]))
-    trained = failed = 0
+    trained, failed = set(), set()
     k = i = 0
     while k < sig.shape[1]:
         n = chunks[i % len(chunks)]
@@ -101,8 +115,8 @@ def test_offset_bank_matches_oracle(built, name, bit_rate, n_signal, chunks):
         got = bank.events()
         for c in range(n_ch):
             assert np.array_equal(got[c], want[c][i][0]), (name, bit_rate, "events", c, i, lines[c])
-            trained += int(-4 in got[c])
-            failed += int(-5 in got[c])
+            trained.update([c] if -4 in got[c] else [])
+            failed.update([c] if -5 in got[c] else [])
         if i % 9 == 0 or k + n >= sig.shape[1]:
             for c in check:
                 f, w = bank.get_state(c)
@@ -113,7 +127,7 @@ def test_offset_bank_matches_oracle(built, name, bit_rate, n_signal, chunks):
         k += n
         i += 1
     # the population is what it claims to be: most lines train with their loops off centre, the far-off ones give up
-    assert trained >= n_ch*3//4 and failed >= n_ch//16, (trained, failed)
+    assert len(trained) >= n_ch*3//4 and len(failed) >= n_ch//16, (len(trained), len(failed))
     bank.close()
 
 

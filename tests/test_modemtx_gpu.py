@@ -188,3 +188,81 @@ def test_v17_tx_feeds_v17_rx_on_device(built):
         hit = [k for k in range(400) if np.array_equal(want[k:k + 64], data[:64])]
         assert hit, c
         assert np.array_equal(want[hit[0]:hit[0] + len(data)], data), c
+
+
+@pytest.mark.parametrize("modem,bit_rate", [("v29", 9600), ("v27ter", 4800), ("v17", 14400)])
+def test_modem_tx_line_levels_and_carriers(built, modem, bit_rate):
+    """spangpu_modemtx_line(): every channel's level (xxx_tx_power) and carrier frequency in one call.  The level words are the
+    oracle's after power(); the carrier word is the DDS phase rate of the frequency asked for, and with that word put into the
+    oracle's state the samples are the oracle's, bit for bit (the modulator itself is unchanged)."""
+    orc, engine = setup_oracle()
+    n = 96
+    rng = np.random.default_rng(bit_rate)
+    seeds = rng.integers(1, 0x7FFF, n).astype(np.uint32)
+    make_bank, make_orc, nominal = {"v29": (engine.V29TxBank, orc.V29Tx, 1700.0), "v27ter": (engine.V27terTxBank, orc.V27terTx, 1800.0),
+                                    "v17": (engine.V17TxBank, orc.V17Tx, 1800.0)}[modem]
+    bank = make_bank(n, bit_rate, False, seeds)
+    tx = [make_orc(bit_rate, False, int(s)) for s in seeds]
+    level = rng.uniform(-30.0, -10.0, n).astype(np.float32)
+    hz = (nominal + rng.uniform(-7.0, 7.0, n)).astype(np.float32)
+    hz[0] = nominal
+    before = bank.get_state(0)
+    bank.line(level, hz)
+    for c in range(n):
+        tx[c].power(float(level[c]))
+        w = bank.get_state(c)
+        rate = int(w[28])
+        assert abs(rate - float(hz[c])*2.0**32/8000.0) <= 512.0, (c, rate)       # float32 arithmetic of dds_phase_ratef()
+        tx[c].buf[28] = rate
+        assert np.array_equal(w, tx[c].snapshot()), c
+    assert bank.get_state(0)[28] == before[28]                                   # the nominal carrier gives the word init gave
+    for m in (160, 160, 77, 1, 333, 160, 1024, 160):
+        pcm = bank.tx_host(m)
+        for c in range(n):
+            assert np.array_equal(pcm[c], tx[c].tx(m)), (m, c)
+    bank.line(None, None)
+    with pytest.raises(Exception):
+        bank.line(None, np.zeros(n, np.float32))
+    bank.close()
+
+
+def test_v29_tx_with_line_offsets_feeds_v29_rx_on_device(built):
+    """SURVEY 8(d)-4's line population without the host: carrier 1700 +- 7 Hz and -30 .. -10 dBm0 per channel from the
+    transmitter bank, straight into the receiver bank; every receiver pulls its carrier in, trains and delivers its
+    transmitter's bit stream without an error."""
+    orc, engine = setup_oracle()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    n, samples, frames = 512, 160, 60
+    rng = np.random.default_rng(29)
+    seeds = ((np.arange(n)*2654435761 + 12345) & 0x7FFF) | 1
+    tx = engine.V29TxBank(n, 9600, False, seeds)
+    tx.line(rng.uniform(-30.0, -10.0, n), 1700.0 + rng.uniform(-7.0, 7.0, n))
+    rx = engine.V29Bank(n, 9600)
+    rx.set_signal_cutoff(-1, -45.5)         # as fax_modems.c:416: v29_rx_init()'s -28.5 dBm0 is above the quieter lines (no noise here)
+    buf = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(buf), n*samples*2) == 0
+    got = [[] for _ in range(n)]
+    for _ in range(frames):
+        tx.tx_device(buf, samples, samples)
+        tx.sync()
+        rx.rx_device(buf, samples, samples)
+        for c, e in enumerate(rx.events()):
+            got[c].extend(int(v) for v in e)
+    hip.hipFree(buf)
+    for c in range(n):
+        ev = got[c]
+        assert -4 in ev and -5 not in ev, c
+        data = np.array([b for b in ev[ev.index(-4) + 1:] if b >= 0])
+        st = int(seeds[c])
+        want = []
+        for _ in range(len(data) + 200):
+            b = ((st >> 14) ^ (st >> 13)) & 1
+            st = ((st << 1) | b) & 0x7FFF
+            want.append(b)
+        want = np.array(want)
+        assert len(data) > 6000
+        hit = [k for k in range(200) if np.array_equal(want[k:k + 64], data[:64])]
+        assert hit, c
+        assert np.array_equal(want[hit[0]:hit[0] + len(data)], data), c

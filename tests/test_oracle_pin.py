@@ -1248,6 +1248,28 @@ def test_modem_offsets_move_the_loops(built):
     assert -125.0 < moved < -105.0, moved                    # more than twice round the 48 coefficient sets
 
 
+@needs_ref
+@pytest.mark.parametrize("cutoff", [None, -45.5, -38.0])
+def test_v29_signal_cutoff_live(built, cutoff):
+    """v29_rx_set_signal_cutoff() (v29rx.c:163-169): a line at -32 dBm0 is below the -28.5 dBm0 v29_rx_init() leaves the carrier
+    detector at and is seen once the cutoff is lowered (fax_modems.c:416 sets -45.5 dBm0)."""
+    from oracle import ref, restated as orc
+    use_golden_modem_tables()
+    sig = ref.v29_tx(9600, 8000, seed=71, level_dbm0=-32.0)
+    x = np.concatenate([np.zeros(230, np.int16), sig, np.zeros(700, np.int16)])
+    x = ref.saturated_add(x, ref.awgn(71*7919, -60.0, len(x)))
+    r, o = ref.V29Rx(9600), orc.V29(9600)
+    if cutoff is not None:
+        r.set_signal_cutoff(cutoff)
+        o.set_signal_cutoff(cutoff)
+    ev_r, f_r, w_r = v29_run(r, x, (160, 1, 77))
+    ev_o, f_o, w_o = v29_run(o, x, (160, 1, 77))
+    assert (len(ev_r) > 5000 and -4 in ev_r) if cutoff is not None else (len(ev_r) == 0)
+    assert np.array_equal(ev_r, ev_o)
+    assert np.array_equal(w_r, w_o)
+    assert np.array_equal(f_r, f_o)
+
+
 @pytest.mark.parametrize("case", [MODEM_OFFSET_CASES[i] for i in MODEM_OFFSET_GOLDEN], ids=modem_offset_name)
 def test_golden_modem_offsets(built, case):
     use_golden_modem_tables()

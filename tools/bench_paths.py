@@ -49,31 +49,55 @@ def synth_v29(n_ch, n_frames, dev, seed, fixture="v29_9600.npz"):
     return out
 
 
-def synth_v29_on_device(n_ch, n_frames, dev, stream, seed, modem="v29"):
+def synth_v29_on_device(n_ch, n_frames, dev, stream, seed, modem="v29", line="contract"):
     """V.29 9600 bps / V.27ter 4800 bps / V.17 14400 bps input made where it is consumed: a transmitter bank (the reference's
-    modulator, bit-exact, on the device) writes every channel's own transmission (its own data bits and level) frame
-    by frame into HBM, and a noise source bank (the reference's awgn()) mixes line noise into it.  Returns int16 [n_frames, n_ch, FRAME]."""
+    modulator, bit-exact, on the device) writes every channel's own transmission (its own data bits) frame by frame into HBM,
+    and a noise source bank (the reference's awgn()) mixes line noise into it.  Returns int16 [n_frames, n_ch, FRAME] and a
+    description of the lines.
+    line = "contract": SURVEY 8(d)-4 as written -- every channel's carrier uniform in nominal +- 7 Hz, its level uniform in
+    -30 .. -10 dBm0, AWGN at an SNR uniform in 25 .. 40 dB (V.27ter: 38 .. 50 dB, its receiver in the reference gives up training
+    below some 35 dB); the random start delay is applied by the caller.  line = "in_step": the rounds-1-to-5 workload (carrier
+    nominal, every 4th channel off -14 dBm0, noise of 1 .. 30 LSB rms)."""
     from spandsp_amd import engine
     rng = np.random.default_rng(seed)
     seeds = rng.integers(1, 0x7FFF, n_ch).astype(np.uint32)
     tx = {"v29": lambda: engine.V29TxBank(n_ch, 9600, False, seeds), "v27ter": lambda: engine.V27terTxBank(n_ch, 4800, False, seeds),
           "v17": lambda: engine.V17TxBank(n_ch, 14400, False, seeds)}[modem]()
     tx.set_stream(ctypes.c_void_p(stream.cuda_stream))
-    for c in range(0, n_ch, 4):                             # a spread of levels (every 4th channel moved off -14 dBm0)
-        tx.power(c, float(rng.uniform(-26.0, -10.0)))
+    nominal = 1700.0 if modem == "v29" else 1800.0
+    if line == "contract":
+        level = rng.uniform(-30.0, -10.0, n_ch)
+        hz = nominal + rng.uniform(-7.0, 7.0, n_ch)
+        snr = rng.uniform(38.0, 50.0, n_ch) if modem == "v27ter" else rng.uniform(25.0, 40.0, n_ch)
+        # (A-B runs of what each condition costs: LINE_PARTS=carrier,level,snr leaves out what is not named)
+        parts = os.environ.get("LINE_PARTS", "carrier,level,snr").split(",")
+        if "carrier" not in parts:
+            hz[:] = nominal
+        if "level" not in parts:
+            level[:] = -14.0
+        if "snr" not in parts:
+            snr[:] = 45.0
+        tx.line(level, hz)
+        noise_dbm0 = level - snr
+        what = "carrier %.0f Hz +- 7 Hz, level -30 .. -10 dBm0, AWGN at SNR %s dB, per channel" % (nominal, "38 .. 50" if modem == "v27ter" else "25 .. 40")
+    else:
+        for c in range(0, n_ch, 4):                             # a spread of levels (every 4th channel moved off -14 dBm0)
+            tx.power(c, float(rng.uniform(-26.0, -10.0)))
+        top = {"v29": 30.0, "v27ter": 12.0, "v17": 10.0}[modem]
+        sigma = rng.uniform(1.0, top, n_ch)
+        noise_dbm0 = 20.0*np.log10(sigma/32768.0) + 3.14 + 3.02
+        what = "carrier nominal, -14 dBm0 (every 4th channel -26 .. -10), AWGN of 1 .. %d LSB rms" % int(top)
     out = torch.empty(n_frames, n_ch, FRAME, dtype=torch.int16, device=dev)
     for f in range(n_frames):
         tx.tx_device(ctypes.c_void_p(out[f].data_ptr()), FRAME, FRAME)
     tx.sync()
-    # line noise from the noise source bank (the reference's awgn(), on the device), 1 .. top LSB rms per channel
-    top = {"v29": 30.0, "v27ter": 12.0, "v17": 10.0}[modem]
-    sigma = rng.uniform(1.0, top, n_ch)
-    noise = engine.AwgnBank(rng.integers(1, 2_000_000, n_ch), 20.0*np.log10(sigma/32768.0) + 3.14 + 3.02)
+    # line noise from the noise source bank (the reference's awgn(), on the device)
+    noise = engine.AwgnBank(rng.integers(1, 2_000_000, n_ch), noise_dbm0)
     noise.set_stream(ctypes.c_void_p(stream.cuda_stream))
     for f in range(n_frames):
         noise.tx_device(ctypes.c_void_p(out[f].data_ptr()), FRAME, FRAME, mix=True)
     noise.sync()
-    return out
+    return out, what, (level if line == "contract" else None)
 
 
 def bench_v29_tx(args, dev, stream):
@@ -243,7 +267,7 @@ def ref_baseline(what, kind_id, new_state, free_state, frames_host, seconds=1.0)
                                                                         one_ch, one_loops, one_dt)}
 
 
-def cpu_modem(kind, bit_rate, frames_host):
+def cpu_modem(kind, bit_rate, frames_host, cutoffs=None):
     """The reference receiver (oracle/_ref) on the host cores over a bounded sample of the same frames."""
     from oracle import ref
     L = ref.lib()
@@ -251,7 +275,13 @@ def cpu_modem(kind, bit_rate, frames_host):
     new.restype = ctypes.c_void_p
     new.argtypes = [ctypes.c_int]
     kind_id = {"v29": ref.MT_V29, "v27ter": ref.MT_V27TER, "v17": ref.MT_V17}[kind]
-    return ref_baseline("%s_rx()" % kind, kind_id, lambda c: new(bit_rate), None, frames_host)
+
+    def make(c):
+        p = new(bit_rate)
+        if cutoffs is not None:
+            getattr(L, "%s_rx_set_signal_cutoff" % kind)(ctypes.c_void_p(p), ctypes.c_float(float(cutoffs[c])))
+        return p
+    return ref_baseline("%s_rx()" % kind, kind_id, make, None, frames_host)
 
 
 # ---- echo canceller -----------------------------------------------------------------------------------
@@ -559,9 +589,25 @@ MIXED_ST_PLAN = ([(400, 0, 700, 0)], [(1100, 0, 400, 600), (0, 0, 2800, 3200)], 
                  [(480, 620, 450, 550), (0, 0, 450, 550)], [(950, 0, 300, 0)], [(1400, 0, 300, 0)])
 
 
-def mixed_spot_check(srcs, kept):
+# the lines the super-tone third of configs[2] listens to: cycles of (f1, f2, ms) that follow MIXED_ST_PLAN's cadences (and one
+# that is in nobody's plan), tests/synth.py cadence_plan_channels
+MIXED_ST_LINES = ([(400, 0, 1500)], [(1100, 0, 500), (0, 0, 3000)], [(350, 440, 1200), (0, 0, 300)], [(480, 620, 500), (0, 0, 500)],
+                  [(950, 0, 330), (1400, 0, 330), (0, 0, 1000)], [(620, 0, 300), (0, 0, 200)])
+MIXED_ST_FREQS = [400, 1100, 350, 440, 480, 620, 950, 1400]          # in the order MIXED_ST_PLAN's descriptor monitors them
+
+
+def mixed_st_cadences():
+    """MIXED_ST_PLAN as spangpu_bank_set_cadences() takes it: bins in place of frequencies (-1 = silence)"""
+    bins = {0: -1}
+    bins.update({f: i for i, f in enumerate(MIXED_ST_FREQS)})
+    return [[(bins[f1], bins[f2], lo, hi) for f1, f2, lo, hi in t] for t in MIXED_ST_PLAN]
+
+
+def mixed_spot_check(srcs, kept, kept_cad):
     """The oracle's bell_mf_rx() / r2_mf_rx() / super_tone_rx() block decisions (oracle/tone_oracle.c, pinned to the
-    reference) over the first frames of 64 channels of each bank against the records the launch wrote."""
+    reference) over the first frames of 64 channels of each bank against the records the launch wrote, and -- the
+    super-tone third -- every tone report and segment report super_tone_rx() makes (its cadence matcher,
+    super_tone_rx.c:164-228, :369-445) against the events the launch's epilogue wrote."""
     from oracle import restated as orc
     desc = orc.SuperToneDesc()
     for tone in MIXED_ST_PLAN:
@@ -570,33 +616,43 @@ def mixed_spot_check(srcs, kept):
             desc.add_element(t, f1, f2, lo, hi)
     ok = True
     blocks = 0
+    reports = segments = 0
     for kind in range(3):
         v, n = srcs[kind].shape
         for c in range(v):
-            o = orc.BellMf(0) if kind == 0 else orc.R2Mf(True, True) if kind == 1 else orc.SuperTone(desc)
+            o = orc.BellMf(0) if kind == 0 else orc.R2Mf(True, True) if kind == 1 else orc.SuperTone(desc, True)
             want = []
             for k in range(n//FRAME):
                 want.extend(o.rx(srcs[kind][c, k*FRAME:(k + 1)*FRAME]))
+                if kind == 2:
+                    ev = [tuple(int(x) for x in e) for e in o.sink.events()]
+                    o.sink.clear()
+                    ok = ok and ev == kept_cad[k][c]
+                    reports += sum(1 for e in ev if e[0] == 1)
+                    segments += sum(1 for e in ev if e[0] == 4)
             got = [(int(r["hit"]), int(r["code"])) for b in kept[kind] for r in b[b["channel"] == c]]
             ok = ok and got == [(int(x["hit"]), int(x["aux"])) for x in want]
             blocks += len(want)
     return {"channels": 3*srcs[0].shape[0], "frames": len(kept[0]), "checked": "hit and code of every block (%d) of the first frames of 64 channels of each bank "
-            "against the oracle's bell_mf_rx / r2_mf_rx / super_tone_rx" % blocks, "bit_exact": bool(ok)}
+            "against the oracle's bell_mf_rx / r2_mf_rx / super_tone_rx, and the super-tone channels' %d tone reports and %d segment reports against "
+            "super_tone_rx()'s callbacks" % (blocks, reports, segments), "tone_reports": reports, "segment_reports": segments,
+            "bit_exact": bool(ok and reports > 0 and segments > 0)}
 
 
 # ---- mixed Goertzel banks ------------------------------------------------------------------------------
 def bench_mixed(args, dev, stream):
-    """BASELINE configs[2]: one third Bell MF, one third R2 MF (forward), one third super-tone (8 monitored
-    frequencies); a step = the three launches of one 20 ms tick."""
+    """BASELINE configs[2]: one third Bell MF, one third R2 MF (forward), one third super_tone_rx() -- 8 monitored frequencies
+    AND its cadence matcher (MIXED_ST_PLAN: the descriptor of tests/super_tone_rx_tests.c:361-374 plus four more tones), tone and
+    segment reports on, matched on the device in the detector launch; a step = the three launches of one 20 ms tick."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import synth
     from spandsp_amd import engine
     n_ch = args.channels or 131072
     n_each = [n_ch//3, n_ch//3, n_ch - 2*(n_ch//3)]
-    nf = 50
+    nf = 200                                                # 4 s of line: long enough for the ring-back cadence (0.5 s on, 3 s off)
     n_src = 512                                             # distinct source channels per kind, tiled with a frame rotation
     srcs = [synth.bell_mf_channels(n_src, nf*FRAME, 21)[0], synth.r2_mf_channels(n_src, nf*FRAME, 22, True)[0],
-            synth.call_progress_channels(n_src, nf*FRAME, 23)]
+            synth.cadence_plan_channels(n_src, nf*FRAME, 23, MIXED_ST_LINES)]
     frames = []
     for kind in range(3):
         src = torch.tensor(srcs[kind], device=dev).view(n_src, nf, FRAME)
@@ -605,10 +661,13 @@ def bench_mixed(args, dev, stream):
         fsel = (torch.arange(nf, device=dev).unsqueeze(0) + rot.unsqueeze(1)) % nf          # [ch, frame]
         f = src[(idx % n_src).unsqueeze(1), fsel]                                            # [ch, frame, FRAME]
         frames.append(f.permute(1, 0, 2).contiguous())
-    st_freqs = [400.0, 1100.0, 350.0, 440.0, 480.0, 620.0, 950.0, 1400.0]      # in the order MIXED_ST_PLAN's descriptor monitors them
+    st_freqs = [float(f) for f in MIXED_ST_FREQS]
     fac = [engine.goertzel_fac(f) for f in st_freqs]
     banks = [engine.ToneBank(engine.BELL_MF, n_each[0]), engine.ToneBank(engine.R2_MF, n_each[1], r2_fwd=True),
              engine.ToneBank(engine.SUPER_TONE, n_each[2], bin_fac=fac)]
+    with_cadences = not getattr(args, "no_cadences", False)
+    if with_cadences:
+        banks[2].set_cadences(mixed_st_cadences(), want_segments=True)
     # Three ways to run a tick (results identical: tests/test_tone_gpu.py): ONE launch for the three banks on one stream
     # (tone_multi_fast_kernel); a launch per bank, every bank free-running on a stream (= hardware queue) of its own -- one
     # bank's launch boundary, start burst and write-back under the other banks' steady state; the banks share nothing and the
@@ -658,14 +717,18 @@ def bench_mixed(args, dev, stream):
 
     set_mode(mode)
     kept = [[] for _ in range(3)]
+    kept_cad = []
     v = 64
-    for i in range(args.warmup):
+    n_check = 190                                           # frames of the spot check: the whole source, bar the frames where the tiling wraps
+    for i in range(max(args.warmup, 0 if args.no_cpu_baseline else n_check)):
         step(i, mode)
-        if i < 20 and not args.no_cpu_baseline:
+        if i < n_check and not args.no_cpu_baseline:
             for kind in range(3):
                 b = banks[kind].blocks()
                 kept[kind].append(b[b["channel"] < v].copy())
-    timed.pos = args.warmup
+            if with_cadences:
+                kept_cad.append(banks[2].cadence_events()[:v])
+    timed.pos = max(args.warmup, 0 if args.no_cpu_baseline else n_check)
     torch.cuda.synchronize()
     # the step: HIP events around the whole timed region / steps in it
     reps = max(1, int(np.ceil(2000/args.steps)))
@@ -679,7 +742,9 @@ def bench_mixed(args, dev, stream):
     avg_ms = ms/(args.steps*reps)
     fused = mode == "one_launch"
     hits = [int((b.blocks()["hit"] != 0).sum()) for b in banks]
-    alg_read = n_each[0]*(320 + 64) + n_each[1]*(320 + 64) + n_each[2]*(320 + 8*8 + 160)
+    # Bell MF / R2 MF read 320 + 64 B per channel and frame; super-tone with M bins 320 + (8M + 160) B, the 160 B
+    # being the cadence matcher's state -- owed only when the matcher runs in the timed region
+    alg_read = n_each[0]*(320 + 64) + n_each[1]*(320 + 64) + n_each[2]*(320 + 8*8 + (160 if with_cadences else 0))
     value = args.steps*n_ch*FRAME/dt/1e6
     cpu = None
     if not args.no_cpu_baseline:
@@ -688,16 +753,17 @@ def bench_mixed(args, dev, stream):
         L = ref.lib()
         n_cpu = min(args.cpu_channels, n_ch)//3
         desc = ref.SuperToneDesc()
-        for f in st_freqs:
+        for tone in MIXED_ST_PLAN:
             t = desc.add_tone()
-            desc.add_element(t, int(f), 0, 300, 0)
+            for f1, f2, lo, hi in tone:
+                desc.add_element(t, f1, f2, lo, hi)
         parts = [
             ref_baseline("bell_mf_rx()", ref.MT_BELL_MF, lambda c: L.glue_bell_mf_rx_new(None, 0), None,
-                         frames[0][:, :n_cpu].contiguous().cpu().numpy(), 0.7),
+                         frames[0][:50, :n_cpu].contiguous().cpu().numpy(), 0.7),
             ref_baseline("r2_mf_rx()", ref.MT_R2_MF, lambda c: L.glue_r2_mf_rx_new(None, 1, 0), None,
-                         frames[1][:, :n_cpu].contiguous().cpu().numpy(), 0.7),
-            ref_baseline("super_tone_rx()", ref.MT_SUPER_TONE, lambda c: L.glue_super_tone_rx_new(desc.p, L.glue_sink_new(), 0), None,
-                         frames[2][:, :n_cpu].contiguous().cpu().numpy(), 0.7),
+                         frames[1][:50, :n_cpu].contiguous().cpu().numpy(), 0.7),
+            ref_baseline("super_tone_rx() with segment reports", ref.MT_SUPER_TONE, lambda c: L.glue_super_tone_rx_new(desc.p, L.glue_sink_new(), 1), None,
+                         frames[2][:50, :n_cpu].contiguous().cpu().numpy(), 0.7),
         ]
         w = [n_each[k]/float(n_ch) for k in range(3)]
         cpu = {"value": 1.0/sum(w[k]/parts[k]["value"] for k in range(3)), "unit": "Msamples/s", "cores": parts[0]["cores"],
@@ -709,20 +775,22 @@ def bench_mixed(args, dev, stream):
                                      value=1.0/sum(w[k]/parts[k]["as_shipped"]["value"] for k in range(3)),
                                      single_core=1.0/sum(w[k]/parts[k]["as_shipped"]["single_core"] for k in range(3)))
         if kept[0]:
-            cpu["spot_check"] = mixed_spot_check([srcs[k][:v, :len(kept[k])*FRAME] for k in range(3)], kept)
+            cpu["spot_check"] = mixed_spot_check([srcs[k][:v, :len(kept[k])*FRAME] for k in range(3)], kept, kept_cad)
     return {
         "metric": "Msamples/s of mixed Bell MF + R2 MF + super-tone Goertzel banks (8 kHz channels at real-time = value*1e6/8000)",
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[2]: %d Bell MF + %d R2 MF + %d super-tone (8 bins) channels x %d-sample "
-                               "frames, %s" % (n_each[0], n_each[1], n_each[2], FRAME,
+        "config": {"workload": "BASELINE configs[2]: %d Bell MF + %d R2 MF + %d super_tone_rx (8 monitored frequencies, %s) channels x %d-sample "
+                               "frames, %s" % (n_each[0], n_each[1], n_each[2],
+                                                "its 6-tone cadence plan matched in the launch, tone and segment reports on" if with_cadences else "block decisions only: NO cadence matcher",
+                                                FRAME,
                                                 {"one_launch": "one launch per step (spangpu_banks_rx, the banks on one stream)",
                                                  "bank_streams": "a launch per bank and step, every bank on a stream of its own (spangpu_banks_rx)",
                                                  "separate": "three launches per step on one stream"}[mode]),
-                   "channels_per_gpu": n_ch, "blocks_with_a_hit_in_last_step": hits},
+                   "channels_per_gpu": n_ch, "blocks_with_a_hit_in_last_step": hits, "cadence_matcher_in_timed_region": with_cadences},
         "roofline": {"bound": "hbm", "kernel": "tone_multi_fast_kernel (Bell MF + R2 MF + super-tone workgroups in one launch)" if fused
-                               else "tone_fast_kernel<BellMfDet | R2MfDet | MultiDet<8, true>> (3 launches%s)" % (" on 3 streams" if mode == "bank_streams" else ""),
+                               else "tone_fast_kernel<BellMfDet | R2MfDet | MultiDet<8, true> + cadence epilogue> (3 launches%s)" % (" on 3 streams" if mode == "bank_streams" else ""),
                      "one_launch_us": one_launch_us,
                      "achieved": alg_read/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
@@ -1017,7 +1085,7 @@ def bench_fax_rx(args, dev, stream):
     from spandsp_amd import engine
     n_ch = args.channels or 16384
     nf = args.steps + args.warmup
-    frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem="v29")
+    frames, _, _ = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem="v29", line="in_step")
     frame_bytes = n_ch*FRAME*2
     s2 = torch.cuda.Stream(device=dev)
 
@@ -1129,7 +1197,7 @@ def bench_dtmf_tx(args, dev, stream):
         "cpu_baseline": cpu}
 
 
-def modem_spot_check(kind, bit_rate, frames64, events64):
+def modem_spot_check(kind, bit_rate, frames64, events64, cutoffs=None):
     """The oracle's receiver (oracle/v29_oracle.c ..., pinned to the reference) over the same first frames of 64 channels:
     the put_bit stream of every frame equal?  frames64: int16 [frames, 64, FRAME]; events64[frame][channel]: int8 arrays."""
     from oracle import restated as orc
@@ -1142,6 +1210,8 @@ def modem_spot_check(kind, bit_rate, frames64, events64):
     total = 0
     for c in range(v):
         o = O(bit_rate)
+        if cutoffs is not None:
+            o.set_signal_cutoff(float(cutoffs[c]))
         for k in range(nfr):
             o.sink.clear()
             o.rx(np.ascontiguousarray(frames64[k, c]))
@@ -1158,15 +1228,17 @@ def bench_modem(args, dev, stream):
     kind = {"v29": engine.V29, "v17": engine.V17, "v27ter": engine.V27TER}[args.workload]
     n_ch = args.channels or 16384
     nf = args.steps + args.warmup
+    line = getattr(args, "line", "contract") or "contract"
     if args.workload in ("v29", "v27ter", "v17") and not args.replay_fixture:
-        frames = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem=args.workload)
+        frames, line_what, line_levels = synth_v29_on_device(n_ch, nf, dev, stream, seed=0x2929, modem=args.workload, line=line)
     else:
-        frames = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture)
-    stagger = int(getattr(args, "stagger", 0) or 0)
+        frames, line_what, line_levels = synth_v29(n_ch, nf, dev, seed=0x29290000, fixture=fixture), "the committed reference transmission replayed with per-channel delay, gain and noise", None
+    stagger = getattr(args, "stagger", None)
+    stagger = (FRAME if line == "contract" else 0) if stagger is None else int(stagger)
     if stagger:
-        # every channel's transmission that many samples later than the bank's first (drawn per channel): the receivers then
-        # leave training at different bauds, and what they do every n-th baud of data (V.29: the equaliser update, every 10th)
-        # no longer falls on the same round for all channels of a wavefront
+        # every channel's transmission that many samples later than the bank's first (drawn per channel; SURVEY 8(d)-4: "random
+        # start delay 0-159 samples"): the receivers then leave training at different bauds, and what they do every n-th baud
+        # of data (V.29: the equaliser update, every 10th) no longer falls on the same round for all channels of a wavefront
         rng = np.random.default_rng(0x57A6)
         delay = torch.as_tensor(rng.integers(0, stagger, n_ch), device=dev)
         t = torch.arange(nf*FRAME, device=dev)
@@ -1179,6 +1251,16 @@ def bench_modem(args, dev, stream):
         del t, delay
     engine.tune_modem_mapping(args.modem_mapping)
     bank = engine.ModemBank(kind, n_ch, bit_rate)
+    # v29_rx_init() leaves the carrier detector at -28.5 dBm0 (v29rx.c:1129): it would never see the contract's lines below some
+    # -26 dBm0; at the -45.5 dBm0 of the reference's FAX front end (fax_modems.c:416) the noise of its louder lines (-10 dBm0 at
+    # 25 dB SNR = -35 dBm0) holds the detector up for ever and a receiver that once failed stays parked.  An installation sets
+    # the detector for the level of its lines: v29_rx_set_signal_cutoff(level - 12 dB) per line -- on the bank, in the host
+    # baseline and in the spot check alike.
+    cutoffs = None
+    if args.workload == "v29" and line == "contract" and not args.replay_fixture:
+        cutoffs = (line_levels - 12.0).astype(np.float32)
+        bank.set_signal_cutoffs(cutoffs)
+        line_what += ", v29_rx_set_signal_cutoff(level - 12 dB) per line"
     bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
     frame_bytes = n_ch*FRAME*2
     torch.cuda.synchronize()
@@ -1210,15 +1292,17 @@ def bench_modem(args, dev, stream):
     actual_read = n_ch*(FRAME*2 + n_words*4)
     cpu = None
     if not args.no_cpu_baseline:
-        cpu = cpu_modem(args.workload, bit_rate, frames[:, :min(args.cpu_channels, n_ch)].contiguous().cpu().numpy())
+        cpu = cpu_modem(args.workload, bit_rate, frames[:, :min(args.cpu_channels, n_ch)].contiguous().cpu().numpy(), cutoffs)
         # a 64-channel bank on the first rows of the same frames (the same kernel family as every bank below 65 536 channels)
         v, nchk = min(64, n_ch), min(40, nf)
         small = engine.ModemBank(kind, v, bit_rate)
+        if cutoffs is not None:
+            small.set_signal_cutoffs(cutoffs[:v])
         ev64 = []
         for k in range(nchk):
             small.rx_device(ctypes.c_void_p(frames.data_ptr() + k*frame_bytes), FRAME, FRAME)
             ev64.append(small.events())
-        cpu["spot_check"] = modem_spot_check(args.workload, bit_rate, frames[:nchk, :v].cpu().numpy(), ev64)
+        cpu["spot_check"] = modem_spot_check(args.workload, bit_rate, frames[:nchk, :v].cpu().numpy(), ev64, cutoffs)
         small.close()
     value = args.steps*n_ch*FRAME/dt/1e6
     e2e = None if getattr(args, "no_e2e", False) else e2e_modem(kind, bit_rate, n_ch, frames[:3], dev)
@@ -1228,8 +1312,9 @@ def bench_modem(args, dev, stream):
         "value": value, "unit": "Msamples/s", "realtime_channels": value*1e6/8000.0, "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt*1e3/args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s %d bps RX, %d channels x %d-sample frames, AWGN%s%s"
-                               % (args.workload, bit_rate, n_ch, FRAME, " (BASELINE configs[3])" if args.workload == "v29" else "", ", starts staggered over %d samples" % stagger if stagger else ""),
+        "config": {"workload": "%s %d bps RX, %d channels x %d-sample frames%s: %s, %s"
+                               % (args.workload, bit_rate, n_ch, FRAME, " (BASELINE configs[3])" if args.workload == "v29" else "", line_what,
+                                  ("random start delay 0 .. %d samples" % (stagger - 1)) if stagger else "all channels starting in step"),
                    "channels_per_gpu": n_ch, "modem_mapping": args.modem_mapping,
                    "sampled_channels_in_data_mode_at_end": "%d of %d" % (trained, len(range(0, n_ch, max(1, n_ch//256)))),
                    "events_in_last_frame": bits_last},
@@ -1281,14 +1366,15 @@ def paths_for_bench(dev, stream, no_cpu_baseline=False, stream_peak=None, echo_s
     except Exception as e:                                    # a path that fails must not take the headline line with it
         out["mixed"] = {"error": repr(e)}
     try:
-        a = types.SimpleNamespace(workload="v29", steps=150, **base)
+        # the contract's workload: carrier 1700 +- 7 Hz, -30 .. -10 dBm0, SNR 25 .. 40 dB, random start delay 0 .. 159
+        a = types.SimpleNamespace(workload="v29", steps=150, line="contract", stagger=None, **base)
         out["v29"] = compact_path(bench_modem(a, dev, stream), "v29", 16384, stream_peak)
-        # the same bank with the channels' transmissions starting at different samples: the synthetic workload above starts them
-        # all in one frame, so every receiver of a wavefront updates its equaliser on the same baud; a population of calls does not
-        a = types.SimpleNamespace(workload="v29", steps=150, stagger=160, **dict(base, no_cpu_baseline=True, no_e2e=True))
+        # beside it, the favourable case the earlier rounds quoted: every channel on the nominal carrier and starting in the same
+        # frame, so that every receiver of a wavefront updates its equaliser on the same baud
+        a = types.SimpleNamespace(workload="v29", steps=150, line="in_step", stagger=0, **dict(base, no_cpu_baseline=True, no_e2e=True))
         st = bench_modem(a, dev, stream)
-        out["v29"]["starts_staggered"] = {"workload": st["config"]["workload"], "ms_per_step": st["ms_per_step"], "avg_launch_us": st["roofline"]["avg_launch_us"],
-                                          "sampled_channels_in_data_mode_at_end": st["config"]["sampled_channels_in_data_mode_at_end"]}
+        out["v29"]["in_step_nominal_carrier"] = {"workload": st["config"]["workload"], "ms_per_step": st["ms_per_step"], "avg_launch_us": st["roofline"]["avg_launch_us"],
+                                                 "sampled_channels_in_data_mode_at_end": st["config"]["sampled_channels_in_data_mode_at_end"]}
     except Exception as e:
         out["v29"] = {"error": repr(e)}
     torch.cuda.empty_cache()
@@ -1326,7 +1412,9 @@ def main():
     ap.add_argument("--separate-launches", action="store_true", help="mixed: one launch per bank instead of one per step")
     ap.add_argument("--one-launch", action="store_true", help="mixed: time the one-launch form (the banks on one stream) instead of a launch per bank on streams of their own")
     ap.add_argument("--cpu-channels", type=int, default=16384)
-    ap.add_argument("--stagger", type=int, default=0, help="v29 / v17 / v27ter: every channel's transmission starts a random number of samples (below this) late")
+    ap.add_argument("--stagger", type=int, default=None, help="v29 / v17 / v27ter: every channel's transmission starts a random number of samples (below this) late (default: 160 with --line contract, 0 with --line in_step)")
+    ap.add_argument("--no-cadences", action="store_true", help="mixed: the super-tone third without its cadence matcher (the rounds-1-to-5 workload; not configs[2])")
+    ap.add_argument("--line", choices=["contract", "in_step"], default="contract", help="v29 / v17 / v27ter: SURVEY 8(d)-4's lines (carrier +- 7 Hz, -30 .. -10 dBm0, SNR 25 .. 40 dB, random start) or the nominal-carrier, all-in-step workload of the earlier rounds")
     ap.add_argument("--fsk-waves", type=int, default=0,
                     help="fsk / mct / sigtone: 0 = the library's choice, 1 = one wavefront per 64 receivers, 2 = two (A-B runs)")
     ap.add_argument("--modem-mapping", type=int, default=0,

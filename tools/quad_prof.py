@@ -20,7 +20,7 @@ steps, warm = 40, 110
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(stream)
-frames = bp.synth_v29_on_device(n_ch, steps + warm, dev, stream, seed=0x2929, modem=workload)
+frames, _, _ = bp.synth_v29_on_device(n_ch, steps + warm, dev, stream, seed=0x2929, modem=workload, line="in_step")
 fixture, bit_rate, n_words = bp.MODEMS[workload]
 kind = {"v29": engine.V29, "v17": engine.V17, "v27ter": engine.V27TER}[workload]
 engine.tune_modem_mapping(4)
