@@ -203,6 +203,12 @@ SPANGPU_API int spangpu_bank_set_channel_params(spangpu_bank_t *bank, int channe
    streams when it reads results: spangpu_bank_blocks() etc. wait on the bank's own stream).  strides may be NULL (= samples). */
 SPANGPU_API int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, int n_banks, int samples,
                                  const long long *strides);
+/* Gives every bank of the list (at most 4) a stream of its own (owned by the bank) on a hardware queue that is not another
+   bank's: the runtime binds fresh streams to its few hardware queues in an order a caller does not control, and two banks
+   that land on one queue run one after the other.  Candidate streams are probed in pairs with a 200 us spin kernel each (on
+   two queues they end together) until every bank has one that runs beside all the others': a few milliseconds, once.
+   Returns the number of banks for which that was proven.  Use before spangpu_banks_rx() for its launch-per-bank form. */
+SPANGPU_API int spangpu_banks_own_queues(spangpu_bank_t *const *banks, int n_banks);
 /* Evaluate the current (partial) block of every channel now and restart it: what
    goertzel_result() called mid-block does (tone_detect.c:160-205).  The results are read
    with spangpu_bank_blocks() / spangpu_bank_trace() as after spangpu_bank_rx(). */

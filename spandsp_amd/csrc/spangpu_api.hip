@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <chrono>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -758,6 +759,98 @@ int spangpu_bank_set_stream(spangpu_bank_t *b, void *hip_stream)
         b->own_stream = true;
     }
     return SPANGPU_OK;
+}
+
+// Streams of their own for the banks of one tick, on hardware queues that are different ones.  A HIP stream is bound to one
+// of a few hardware queues by the runtime, in an order a caller does not control: two of three freshly made streams can land
+// on one queue, and the launches of those two banks then run one after the other (configs[2], round 6: Bell MF and super-tone
+// on one queue, 30 us a tick instead of 17 -- profiles/r6_mixed_trace_overlap_collision.txt).  Stream priorities do give
+// queues of their own, but the lower queues then wait for the higher ones (measured: 42.7 us a tick where three plain streams
+// on three queues take 15.3).  So: candidates are made, and a pair is PROBED -- a spin kernel of 200 us on each, started
+// together: they end together on two queues and one after the other on one -- until every bank has a stream that runs beside
+// all the others' (a few milliseconds, once).  Returns the number of banks whose stream was proven to run beside every other
+// bank's (n_banks unless the device ran out of queues: then the rest share).
+__global__ void queue_probe_kernel(long long ticks)
+{
+    const long long t0 = wall_clock64();           // the 100 MHz constant clock
+    while (wall_clock64() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(8);
+}
+
+static bool probe_streams_overlap(hipStream_t a, hipStream_t b)
+{
+    constexpr long long kTicks = 20000;             // 200 us
+    for (int attempt = 0;  attempt < 3;  attempt++)
+    {
+        (void) hipStreamSynchronize(a);
+        (void) hipStreamSynchronize(b);
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(queue_probe_kernel, dim3(1), dim3(64), 0, a, kTicks);
+        hipLaunchKernelGGL(queue_probe_kernel, dim3(1), dim3(64), 0, b, kTicks);
+        (void) hipStreamSynchronize(a);
+        (void) hipStreamSynchronize(b);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us < 290.0)
+            return true;                            // both spun at once
+        if (us > 390.0  &&  us < 600.0)
+            return false;                           // one behind the other
+        // (anything else: the host was held up; look again)
+    }
+    return false;
+}
+
+int spangpu_banks_own_queues(spangpu_bank_t *const *banks, int n_banks)
+{
+    if (banks == nullptr  ||  n_banks < 1  ||  n_banks > kMaxMulti)
+        return fail(SPANGPU_ERR_BAD_ARG, "bad arguments (at most %d banks)", kMaxMulti);
+    for (int k = 0;  k < n_banks;  k++)
+    {
+        if (banks[k] == nullptr  ||  banks[k]->device != banks[0]->device)
+            return fail(SPANGPU_ERR_BAD_ARG, "null bank, or banks on different devices");
+    }
+    HIP_TRY(hipSetDevice(banks[0]->device));
+    constexpr int kCandidates = 12;
+    hipStream_t cand[kCandidates];
+    int n_cand = 0;
+    hipStream_t chosen[kMaxMulti];
+    int n_chosen = 0;
+    while (n_chosen < n_banks  &&  n_cand < kCandidates)
+    {
+        hipStream_t st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+            break;
+        cand[n_cand++] = st;
+        bool beside_all = true;
+        for (int j = 0;  j < n_chosen  &&  beside_all;  j++)
+            beside_all = probe_streams_overlap(chosen[j], st);
+        if (beside_all)
+        {
+            chosen[n_chosen++] = st;
+            cand[--n_cand] = nullptr;               // (kept: not one of the candidates to give back)
+        }
+    }
+    const int proven = n_chosen;
+    // out of queues (or of candidates): the banks left over take candidates as they are
+    while (n_chosen < n_banks  &&  n_cand > 0)
+        chosen[n_chosen++] = cand[--n_cand];
+    while (n_chosen < n_banks)
+    {
+        hipStream_t st = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        chosen[n_chosen++] = st;
+    }
+    for (int i = 0;  i < n_cand;  i++)
+        (void) hipStreamDestroy(cand[i]);
+    for (int k = 0;  k < n_banks;  k++)
+    {
+        spangpu_bank_t *b = banks[k];
+        HIP_TRY(hipStreamSynchronize(joined(b)));
+        if (b->own_stream)
+            (void) hipStreamDestroy(b->stream);
+        b->stream = chosen[k];
+        b->own_stream = true;
+    }
+    return proven;
 }
 
 // The HIP stream the bank launches on (its own, unless spangpu_bank_set_stream() gave it another).

@@ -94,7 +94,7 @@ def lib():
             "spangpu_bank_set_timing": (ci, [vp, ci]),
             "spangpu_bank_bins": (ci, [vp]),
             "spangpu_bank_force_block": (ci, [vp]),
-            "spangpu_banks_rx": (ci, [vp, vp, ci, ci, vp]),
+            "spangpu_banks_rx": (ci, [vp, vp, ci, ci, vp]), "spangpu_banks_own_queues": (ci, [vp, ci]),
             "spangpu_bank_rx_g711": (ci, [vp, vp, ci, ci, ci, ll]),
             "spangpu_bank_set_records_buffer": (ci, [vp, vp, C.c_size_t]),
             "spangpu_bank_get_stream": (vp, [vp]),
@@ -554,6 +554,12 @@ ECHO_FIELDS = ["tx_power0", "tx_power1", "tx_power2", "tx_power3", "rx_power0", 
                "geigel_lag", "dtd_onset", "tap_set", "tap_rotate_counter", "latest_correction",
                "narrowband_count", "narrowband_score", "fir_curr_pos", "tx_hpf0", "tx_hpf1", "rx_hpf0",
                "rx_hpf1", "cng_level", "cng_rndnum", "cng_filter", "fir_set"]
+
+
+def banks_own_queues(banks):
+    """A stream of its own for every bank of a tick, on hardware queues that are certainly different (spangpu_banks_own_queues)."""
+    hb = (C.c_void_p*len(banks))(*[b.h for b in banks])
+    return _check(lib().spangpu_banks_own_queues(hb, len(banks)))
 
 
 def banks_rx_device(banks, ptrs, samples, strides=None):

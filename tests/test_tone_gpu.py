@@ -1059,7 +1059,18 @@ def test_banks_on_streams_of_their_own(built, lanes_per_channel):
             f1, i1 = b1.get_state(c)
             assert np.array_equal(f32_bits(f0), f32_bits(f1)) and np.array_equal(i0, i1), c
     assert hits > 20
-    for b in own:
+    # ... and on the streams spangpu_banks_own_queues() makes for them (a hardware queue each, by stream priority), a fourth
+    # bank included (more banks than priority levels: it gets a plain stream)
+    third = make() + [engine.ToneBank(engine.DTMF, 97)]
+    levels = engine.banks_own_queues(third)
+    assert 1 <= levels <= 4
+    assert len(set(engine.lib().spangpu_bank_get_stream(b.h) for b in third)) == 4
+    for k in range(n_frames):
+        engine.banks_rx_device(third[:3], [f.value for f in dev[k]], 160)
+    for b0, b2 in zip(shared, third):
+        assert b0.blocks().tobytes() == b2.blocks().tobytes()
+    assert engine.banks_own_queues(third[:2]) >= 1         # again: the streams of before are given back
+    for b in own + third:
         b.close()
     for s in streams:
         hip.hipStreamDestroy(s)

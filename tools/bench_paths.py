@@ -675,15 +675,22 @@ def bench_mixed(args, dev, stream):
     # the record, a launch per bank on one stream (--separate-launches).  spangpu_banks_rx() does the first or the second
     # according to the streams the banks were given.
     mode = "separate" if args.separate_launches else "one_launch" if getattr(args, "one_launch", False) else "bank_streams"
-    own = [torch.cuda.Stream(device=dev) for _ in banks]
+    own = None                                              # the banks' own streams as torch sees them, once they have them
     plan = engine.BanksPlan(banks)
     handles = [plan.frame([frames[kind].data_ptr() + f*n_each[kind]*FRAME*2 for kind in range(3)]) for f in range(nf)]
     addr = [[ctypes.c_void_p(frames[kind].data_ptr() + f*n_each[kind]*FRAME*2) for kind in range(3)] for f in range(nf)]
 
     def set_mode(m):
+        nonlocal own
         torch.cuda.synchronize()
-        for b, s in zip(banks, own):
-            b.set_stream(ctypes.c_void_p((s if m == "bank_streams" else stream).cuda_stream))
+        if m == "bank_streams":
+            # a stream per bank on hardware queues that are certainly different ones (spangpu_banks_own_queues: by stream
+            # priority; three torch streams may or may not share a queue -- profiles/r6_mixed_trace_overlap_collision.txt)
+            engine.banks_own_queues(banks)
+            own = [torch.cuda.ExternalStream(engine.lib().spangpu_bank_get_stream(b.h), device=dev) for b in banks]
+        else:
+            for b in banks:
+                b.set_stream(ctypes.c_void_p(stream.cuda_stream))
 
     def step(i, m):
         if m == "separate":
