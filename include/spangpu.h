@@ -200,7 +200,8 @@ SPANGPU_API int spangpu_bank_set_channel_params(spangpu_bank_t *bank, int channe
    (spangpu_bank_set_stream) get a launch each, on their streams: with banks large enough to fill the chip between them the
    free-running hardware queues overlap one bank's launch boundary and start burst with the others' steady state (BASELINE
    configs[2], 131 072 channels in three banks: 23.7 us a tick as one launch, 18.4 us on three streams; the caller joins the
-   streams when it reads results: spangpu_bank_blocks() etc. wait on the bank's own stream).  strides may be NULL (= samples). */
+   streams when it reads results: spangpu_bank_blocks() etc. wait on the bank's own stream).  Banks are grouped by stream:
+   those that share one (spangpu_bank_set_stream with the same stream) share a launch on it.  strides may be NULL (= samples). */
 SPANGPU_API int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, int n_banks, int samples,
                                  const long long *strides);
 /* Gives every bank of the list (at most 4) a stream of its own (owned by the bank) on a hardware queue that is not another

@@ -766,7 +766,7 @@ int spangpu_bank_set_stream(spangpu_bank_t *b, void *hip_stream)
 // on one queue, and the launches of those two banks then run one after the other (configs[2], round 6: Bell MF and super-tone
 // on one queue, 30 us a tick instead of 17 -- profiles/r6_mixed_trace_overlap_collision.txt).  Stream priorities do give
 // queues of their own, but the lower queues then wait for the higher ones (measured: 42.7 us a tick where three plain streams
-// on three queues take 15.3).  So: candidates are made, and a pair is PROBED -- a spin kernel of 200 us on each, started
+// on three queues take 15.3; only the longest bank's stream at high priority: 25 - 26 us against 20).  So: candidates are made, and a pair is PROBED -- a spin kernel of 200 us on each, started
 // together: they end together on two queues and one after the other on one -- until every bank has a stream that runs beside
 // all the others' (a few milliseconds, once).  Returns the number of banks whose stream was proven to run beside every other
 // bank's (n_banks unless the device ran out of queues: then the rest share).
@@ -1335,14 +1335,36 @@ int spangpu_banks_rx(spangpu_bank_t *const *banks, const int16_t *const *amps, i
     // bank's stream: free-running hardware queues put one bank's launch boundary, start burst and write-back under the other
     // banks' steady state (configs[2], 131 072 channels in three banks: 23.7 us a tick as one launch, 18.4 us as three
     // launches on three streams; three launches on ONE stream 32.3 -- profiles/r5_mixed_streams.log).
+    // (Round 6: banks are grouped by stream -- those that share one share a launch on it, a bank alone on its stream gets its
+    // own: configs[2] as Bell MF + R2 MF in one launch on one queue beside the super-tone bank with its cadence matcher on
+    // another balances the two queues.)
     bool own_streams = false;
     for (int k = 1;  k < n_banks;  k++)
         own_streams = own_streams  ||  (banks[k]->stream != banks[0]->stream);
     if (own_streams)
     {
+        bool done[kMaxMulti] = {false, false, false, false};
         for (int k = 0;  k < n_banks;  k++)
         {
-            const int rc = spangpu_bank_rx(banks[k], amps[k], SPANGPU_MEM_DEVICE, SPANGPU_LAYOUT_CHANNEL_MAJOR, samples, strides  ?  strides[k]  :  0);
+            if (done[k])
+                continue;
+            spangpu_bank_t *grp[kMaxMulti];
+            const int16_t *gamps[kMaxMulti];
+            long long gstrides[kMaxMulti];
+            int n = 0;
+            for (int j = k;  j < n_banks;  j++)
+            {
+                if (!done[j]  &&  banks[j]->stream == banks[k]->stream)
+                {
+                    grp[n] = banks[j];
+                    gamps[n] = amps[j];
+                    gstrides[n] = strides  ?  strides[j]  :  0;
+                    n++;
+                    done[j] = true;
+                }
+            }
+            const int rc = (n == 1)  ?  spangpu_bank_rx(grp[0], gamps[0], SPANGPU_MEM_DEVICE, SPANGPU_LAYOUT_CHANNEL_MAJOR, samples, gstrides[0])
+                                     :  spangpu_banks_rx(grp, gamps, n, samples, strides  ?  gstrides  :  nullptr);
             if (rc < 0)
                 return rc;
         }

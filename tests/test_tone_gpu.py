@@ -1070,6 +1070,16 @@ def test_banks_on_streams_of_their_own(built, lanes_per_channel):
     for b0, b2 in zip(shared, third):
         assert b0.blocks().tobytes() == b2.blocks().tobytes()
     assert engine.banks_own_queues(third[:2]) >= 1         # again: the streams of before are given back
+    # banks are grouped by stream: two of the three on one stream share a launch, the third has its own
+    fourth = make()
+    assert engine.banks_own_queues([fourth[0], fourth[2]]) >= 1
+    fourth[1].share_stream(fourth[0])
+    for k in range(n_frames):
+        engine.banks_rx_device(fourth, [f.value for f in dev[k]], 160)
+    for b0, b4 in zip(shared, fourth):
+        assert b0.blocks().tobytes() == b4.blocks().tobytes()
+    for b in fourth:
+        b.close()
     for b in own + third:
         b.close()
     for s in streams:

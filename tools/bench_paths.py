@@ -674,7 +674,7 @@ def bench_mixed(args, dev, stream):
     # host joins the streams when it reads records -- which is how the step is timed unless --one-launch is given; and, for
     # the record, a launch per bank on one stream (--separate-launches).  spangpu_banks_rx() does the first or the second
     # according to the streams the banks were given.
-    mode = "separate" if args.separate_launches else "one_launch" if getattr(args, "one_launch", False) else "bank_streams"
+    mode = "separate" if args.separate_launches else "one_launch" if getattr(args, "one_launch", False) else "bank_streams" if getattr(args, "three_queues", False) else "two_queues"
     own = None                                              # the banks' own streams as torch sees them, once they have them
     plan = engine.BanksPlan(banks)
     handles = [plan.frame([frames[kind].data_ptr() + f*n_each[kind]*FRAME*2 for kind in range(3)]) for f in range(nf)]
@@ -684,10 +684,16 @@ def bench_mixed(args, dev, stream):
         nonlocal own
         torch.cuda.synchronize()
         if m == "bank_streams":
-            # a stream per bank on hardware queues that are certainly different ones (spangpu_banks_own_queues: by stream
-            # priority; three torch streams may or may not share a queue -- profiles/r6_mixed_trace_overlap_collision.txt)
+            # a stream per bank on hardware queues proven to be different ones (spangpu_banks_own_queues; three torch streams
+            # may or may not share a queue -- profiles/r6_mixed_trace_overlap_collision.txt)
             engine.banks_own_queues(banks)
             own = [torch.cuda.ExternalStream(engine.lib().spangpu_bank_get_stream(b.h), device=dev) for b in banks]
+        elif m == "two_queues":
+            # the super-tone bank, whose launch carries the cadence matcher and is the longest, alone on one queue; Bell MF and
+            # R2 MF share the other and with it a launch (spangpu_banks_rx groups banks by stream)
+            engine.banks_own_queues([banks[0], banks[2]])
+            banks[1].share_stream(banks[0])
+            own = [torch.cuda.ExternalStream(engine.lib().spangpu_bank_get_stream(b.h), device=dev) for b in (banks[0], banks[2])]
         else:
             for b in banks:
                 b.set_stream(ctypes.c_void_p(stream.cuda_stream))
@@ -706,12 +712,12 @@ def bench_mixed(args, dev, stream):
         ev1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
-        if m == "bank_streams":
+        if m in ("bank_streams", "two_queues"):
             for s in own:
                 s.wait_event(ev0)
         for i in range(n_steps):
             step(timed.pos + i, m)
-        if m == "bank_streams":
+        if m in ("bank_streams", "two_queues"):
             for s in own:
                 e = torch.cuda.Event()
                 e.record(s)
@@ -740,7 +746,11 @@ def bench_mixed(args, dev, stream):
     # the step: HIP events around the whole timed region / steps in it
     reps = max(1, int(np.ceil(2000/args.steps)))
     one_launch_us = None
-    if mode == "bank_streams":
+    other_us = None
+    if mode in ("bank_streams", "two_queues"):
+        other = "bank_streams" if mode == "two_queues" else "two_queues"
+        timed(other, 200)
+        other_us = timed(other, args.steps*reps)[1]/(args.steps*reps)*1e3
         timed("one_launch", 200)
         one_launch_us = timed("one_launch", args.steps*reps)[1]/(args.steps*reps)*1e3     # the per-launch figure of the one-launch form
         timed(mode, 200)
@@ -793,12 +803,14 @@ def bench_mixed(args, dev, stream):
                                                 "its 6-tone cadence plan matched in the launch, tone and segment reports on" if with_cadences else "block decisions only: NO cadence matcher",
                                                 FRAME,
                                                 {"one_launch": "one launch per step (spangpu_banks_rx, the banks on one stream)",
-                                                 "bank_streams": "a launch per bank and step, every bank on a stream of its own (spangpu_banks_rx)",
+                                                 "bank_streams": "a launch per bank and step, every bank on a stream (hardware queue) of its own (spangpu_banks_own_queues, spangpu_banks_rx)",
+                                                 "two_queues": "two launches per step on two hardware queues: the super-tone bank with its cadence matcher on one, Bell MF + R2 MF sharing a launch on the other (spangpu_banks_own_queues, spangpu_banks_rx)",
                                                  "separate": "three launches per step on one stream"}[mode]),
                    "channels_per_gpu": n_ch, "blocks_with_a_hit_in_last_step": hits, "cadence_matcher_in_timed_region": with_cadences},
         "roofline": {"bound": "hbm", "kernel": "tone_multi_fast_kernel (Bell MF + R2 MF + super-tone workgroups in one launch)" if fused
+                               else "tone_fast_kernel<MultiDet<8, true> + cadence epilogue> beside tone_multi_fast_kernel (Bell MF + R2 MF), two queues" if mode == "two_queues"
                                else "tone_fast_kernel<BellMfDet | R2MfDet | MultiDet<8, true> + cadence epilogue> (3 launches%s)" % (" on 3 streams" if mode == "bank_streams" else ""),
-                     "one_launch_us": one_launch_us,
+                     "one_launch_us": one_launch_us, ("three_queues_us" if mode == "two_queues" else "two_queues_us"): other_us,
                      "achieved": alg_read/(avg_ms*1e-3)/1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg_read/(avg_ms*1e-3)/1e9/HBM_PEAK_GBPS, "traffic": None,
                      "alg_read_bytes_per_launch": alg_read, "avg_launch_us": avg_ms*1e3,
@@ -1420,6 +1432,7 @@ def main():
     ap.add_argument("--one-launch", action="store_true", help="mixed: time the one-launch form (the banks on one stream) instead of a launch per bank on streams of their own")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     ap.add_argument("--stagger", type=int, default=None, help="v29 / v17 / v27ter: every channel's transmission starts a random number of samples (below this) late (default: 160 with --line contract, 0 with --line in_step)")
+    ap.add_argument("--three-queues", action="store_true", help="mixed: a launch per bank on three hardware queues (the default is two queues: super-tone | Bell MF + R2 MF)")
     ap.add_argument("--no-cadences", action="store_true", help="mixed: the super-tone third without its cadence matcher (the rounds-1-to-5 workload; not configs[2])")
     ap.add_argument("--line", choices=["contract", "in_step"], default="contract", help="v29 / v17 / v27ter: SURVEY 8(d)-4's lines (carrier +- 7 Hz, -30 .. -10 dBm0, SNR 25 .. 40 dB, random start) or the nominal-carrier, all-in-step workload of the earlier rounds")
     ap.add_argument("--fsk-waves", type=int, default=0,
