@@ -898,6 +898,31 @@ SPANGPU_API int spangpu_godard_ted_rx_batch(int device, uint32_t *state, const u
                                             long long stride, int items, int n, int mem);
 SPANGPU_API int spangpu_godard_ted_per_baud_batch(int device, uint32_t *state, const uint32_t *desc, long long desc_stride, int32_t *correction,
                                                   int items, int mem);
+/* A position outside a row (pos < 0 or pos > n) is refused with SPANGPU_ERR_BAD_ARG when the arrays are host memory; in
+   device memory nobody reads them beforehand: such an item's result is NaN (dot products) and its y row is left alone (LMS). */
+
+/* ---- ... and the rest of them (csrc/prim2_api.hip; SURVEY 8(a) a19 and the periodograms of section 2's Goertzel core) ----
+     spangpu_periodogram_batch               periodogram(coeffs, amp, len)                        src/tone_detect.c:208-225
+     spangpu_periodogram_prepare_batch       periodogram_prepare(sum, diff, amp, len)             src/tone_detect.c:228-239
+     spangpu_periodogram_apply_batch         periodogram_apply(coeffs, sum, diff, len)            src/tone_detect.c:242-255
+     spangpu_periodogram_freq_error_batch    periodogram_freq_error(&offset, scale, &last, &now)  src/tone_detect.c:299-310
+     spangpu_fixed_sqrt32_batch              fixed_sqrt32(x)                                      src/math_fixed.c:158-169
+     spangpu_dds_complexf_batch              dds_complexf(&phase_acc, phase_rate) n times (n = 1, rate 0: dds_lookup_complexf(phase);
+                                             the accumulator moves as dds_advancef() moves it)   src/dds_float.c:2135-2187
+     spangpu_arctan2_batch                   arctan2(y, x)                                        src/spandsp/arctan2.h:47-80
+   Same conventions as above.  periodogram rows: coeffs [len/2] complex (periodogram_generate_coeffs(), host table making, by name
+   in libspangpu_prims), amp [len] complex; prepare writes sum and diff as [items][len/2] complex and returns len/2.  The square
+   root and the phasor use the tables the receiver kernels use (csrc/modem_tables.c), arctan2 the receivers' device function. */
+SPANGPU_API int spangpu_periodogram_batch(int device, const float *coeffs, long long c_stride, const float *amp, long long a_stride, float *out,
+                                          int items, int len, int mem);
+SPANGPU_API int spangpu_periodogram_prepare_batch(int device, const float *amp, long long a_stride, float *sum, float *diff, int items, int len, int mem);
+SPANGPU_API int spangpu_periodogram_apply_batch(int device, const float *coeffs, long long c_stride, const float *sum, const float *diff, float *out,
+                                                int items, int len, int mem);
+SPANGPU_API int spangpu_periodogram_freq_error_batch(int device, const float *phase_offset, float scale, const float *last_result,
+                                                     const float *result, float *out, int items, int mem);
+SPANGPU_API int spangpu_fixed_sqrt32_batch(int device, const uint32_t *x, uint16_t *out, int items, int mem);
+SPANGPU_API int spangpu_dds_complexf_batch(int device, uint32_t *phase_acc, const int32_t *phase_rate, float *out, int items, int n, int mem);
+SPANGPU_API int spangpu_arctan2_batch(int device, const float *y, const float *x, int32_t *out, int items, int mem);
 
 #if defined(__cplusplus)
 }

@@ -203,8 +203,16 @@ SPANGPU_API void echo_can_flush(echo_can_state_t *ec);
 SPANGPU_API void echo_can_snapshot(echo_can_state_t *ec);
 SPANGPU_API int spangpu_echo_can_snapshot_taps(echo_can_state_t *ec, int16_t *out, int max);
 SPANGPU_API void echo_can_adaption_mode(echo_can_state_t *ec, int adaption_mode);
-SPANGPU_API int16_t echo_can_update(echo_can_state_t *ec, int16_t tx, int16_t rx);
-SPANGPU_API int16_t echo_can_hpf_tx(echo_can_state_t *ec, int16_t tx);
+/* (a kernel launch per sample: build with -DSPANGPU_WARN_SLOW_CALLS to have the compiler point at every call site) */
+#if defined(SPANGPU_WARN_SLOW_CALLS)
+#define SPANGPU_SLOW_CALL(msg) __attribute__((deprecated(msg)))
+#else
+#define SPANGPU_SLOW_CALL(msg)
+#endif
+SPANGPU_API int16_t echo_can_update(echo_can_state_t *ec, int16_t tx, int16_t rx)
+    SPANGPU_SLOW_CALL("one kernel launch per sample: use spangpu_echo_can_update_block() or spangpu_echo_update()");
+SPANGPU_API int16_t echo_can_hpf_tx(echo_can_state_t *ec, int16_t tx)
+    SPANGPU_SLOW_CALL("one kernel launch per sample: use spangpu_echo_can_update_block(..., use_hpf_tx = 1)");
 SPANGPU_API int spangpu_echo_can_update_block(echo_can_state_t *ec, const int16_t tx[], const int16_t rx[], int16_t clean[],
                                               int16_t tx_out[], int n, int use_hpf_tx);
 SPANGPU_API spangpu_echo_t *spangpu_echo_can_bank(echo_can_state_t *ec);
@@ -310,63 +318,10 @@ SPANGPU_API float filter_step(filter_t *fi, float x);
 SPANGPU_API cfilter_t *cfilter_create(fspec_t *fs);
 SPANGPU_API void cfilter_delete(cfilter_t *cfi);
 SPANGPU_API complexf_t cfilter_step(cfilter_t *cfi, const complexf_t *z);
-/* ---- the receivers' inner primitives under their spandsp names (csrc/shim_prims.c): one item through the batched entry
- * points of csrc/prim_api.hip per call -- the plumbing form; the receivers run them fused, a caller with many items uses
- * spangpu_*_batch() (include/spangpu.h).  Reference declarations being replaced:
- *   vec_circular_dot_prodf, vec_circular_lmsf     src/spandsp/vector_float.h:184,188          src/vector_float.c:932-939,996-1000
- *   cvec_circular_dot_prodf, cvec_circular_lmsf   src/spandsp/complex_vector_float.h:159,163  src/complex_vector_float.c:187-196,215-219
- *   power_meter_t, power_meter_init/_release/_free/_damping/_update/_rx/_current
- *                                                 src/spandsp/power_meter.h:34-94, private/power_meter.h:33-40   src/power_meter.c:44-113
- *   godard_ted_descriptor_t, godard_ted_state_t, godard_ted_make_descriptor/_free_descriptor/_init/_release/_free/_correction/_rx/_per_baud
- *                                                 src/spandsp/godard.h:57-124, private/godard.h:29-54            src/godard.c:70-249
- *     (the float build's structs, field for field; the descriptor's coefficients are table making and are formed on the host as the
- *     reference forms them, the detector's arithmetic -- godard_ted_rx(), godard_ted_per_baud() -- is the device's)
- * No host arithmetic behind them: without a HIP device the float results are NaN, power_meter_update() returns INT32_MIN,
- * godard_ted_per_baud() returns 0 and leaves the state as it was. */
-typedef struct power_meter_s
-{
-    int shift;
-    int32_t reading;
-} power_meter_t;
-typedef struct godard_ted_descriptor_s
-{
-    float low_band_edge_coeff[3];
-    float high_band_edge_coeff[3];
-    float mixed_band_edges_coeff_3;
-    float coarse_trigger;
-    float fine_trigger;
-    int coarse_step;
-    int fine_step;
-} godard_ted_descriptor_t;
-typedef struct godard_ted_state_s
-{
-    godard_ted_descriptor_t desc;
-    float low_band_edge[2];
-    float high_band_edge[2];
-    float dc_filter[2];
-    float baud_phase;
-    int total_baud_timing_correction;
-} godard_ted_state_t;
-SPANGPU_API float vec_circular_dot_prodf(const float x[], const float y[], int n, int pos);
-SPANGPU_API void vec_circular_lmsf(const float x[], float y[], int n, int pos, float error);
-SPANGPU_API complexf_t cvec_circular_dot_prodf(const complexf_t x[], const complexf_t y[], int n, int pos);
-SPANGPU_API void cvec_circular_lmsf(const complexf_t x[], complexf_t y[], int n, int pos, const complexf_t *error);
-SPANGPU_API power_meter_t *power_meter_init(power_meter_t *s, int shift);
-SPANGPU_API int power_meter_release(power_meter_t *s);
-SPANGPU_API int power_meter_free(power_meter_t *s);
-SPANGPU_API power_meter_t *power_meter_damping(power_meter_t *s, int shift);
-SPANGPU_API int32_t power_meter_update(power_meter_t *s, int16_t amp);
-SPANGPU_API int32_t power_meter_rx(power_meter_t *s, int16_t amp[], int len);
-SPANGPU_API int32_t power_meter_current(power_meter_t *s);
-SPANGPU_API godard_ted_descriptor_t *godard_ted_make_descriptor(godard_ted_descriptor_t *desc, float sample_rate, float baud_rate, float carrier_freq,
-                                                                float alpha, float coarse_trigger, float fine_trigger, int coarse_step, int fine_step);
-SPANGPU_API int godard_ted_free_descriptor(godard_ted_descriptor_t *s);
-SPANGPU_API int godard_ted_correction(godard_ted_state_t *s);
-SPANGPU_API void godard_ted_rx(godard_ted_state_t *s, float sample);
-SPANGPU_API int godard_ted_per_baud(godard_ted_state_t *s);
-SPANGPU_API godard_ted_state_t *godard_ted_init(godard_ted_state_t *s, const godard_ted_descriptor_t *desc);
-SPANGPU_API int godard_ted_release(godard_ted_state_t *s);
-SPANGPU_API int godard_ted_free(godard_ted_state_t *s);
+/* The receivers' inner primitives under their spandsp names (vec_*, cvec_*, power_meter_*, godard_ted_*, periodogram*) are
+ * NOT in libspangpu.so: libspandsp calls them from inside its own modules (fsk, v22bis, the modem receivers ...), and a process
+ * that loads both libraries would have those internal calls bound here.  They live in libspangpu_prims.so, which a caller
+ * links only when it wants them: include/spangpu_prims.h. */
 SPANGPU_API void goertzel_reset(goertzel_state_t *s);
 SPANGPU_API int goertzel_update(goertzel_state_t *s, const int16_t amp[], int samples);
 SPANGPU_API float goertzel_result(goertzel_state_t *s);
@@ -438,7 +393,6 @@ typedef void (*digits_tx_callback_t)(void *user_data);
 typedef struct fsk_rx_state_s fsk_rx_state_t;
 typedef struct modem_connect_tones_rx_state_s modem_connect_tones_rx_state_t;
 typedef struct dtmf_tx_state_s dtmf_tx_state_t;
-typedef struct spangpu_txbank_s spangpu_txbank_t;
 typedef struct spangpu_line_group_s spangpu_line_group_t;
 
 /* The objects themselves, for callers that bring their own storage (xxx_init(&my_state, ...), ended with xxx_release();

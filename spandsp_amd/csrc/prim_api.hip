@@ -32,7 +32,10 @@ __global__ void vec_circ_dot_kernel(const float *x, long long xs, const float *y
     const float *yi = y + (size_t) i*ys;
     const int p = pos[i];
     if (p < 0  ||  p > n)
-        return;                 // (a position outside the row: nothing is read or written for this item)
+    {
+        z[i] = __uint_as_float(0x7FC00000u);        // (a position outside the row: nothing is read; the result says so)
+        return;
+    }
     float a = 0.0f;
     for (int k = 0;  k < n - p;  k++)
         a += xi[p + k]*yi[k];
@@ -68,7 +71,10 @@ __global__ void cvec_circ_dot_kernel(const float2 *x, long long xs, const float2
     const float2 *yi = y + (size_t) i*ys;
     const int p = pos[i];
     if (p < 0  ||  p > n)
-        return;                 // (a position outside the row: nothing is read or written for this item)
+    {
+        z[i] = make_float2(__uint_as_float(0x7FC00000u), __uint_as_float(0x7FC00000u));     // (nothing is read; the result says so)
+        return;
+    }
     float are = 0.0f;
     float aim = 0.0f;
     for (int k = 0;  k < n - p;  k++)
@@ -225,6 +231,19 @@ int check(int device, int items, int n, const void *a, const void *b, const void
     return SPANGPU_OK;
 }
 
+// positions in host memory are looked at before anything is staged
+int check_pos(const int32_t *pos, int items, int n, int mem)
+{
+    if (mem != SPANGPU_MEM_HOST)
+        return SPANGPU_OK;
+    for (int i = 0;  i < items;  i++)
+    {
+        if (pos[i] < 0  ||  pos[i] > n)
+            return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "a position outside its row (0 <= pos <= n)");
+    }
+    return SPANGPU_OK;
+}
+
 }   // namespace
 
 extern "C" {
@@ -234,6 +253,8 @@ int spangpu_vec_circular_dot_prodf_batch(int device, const float *x, long long x
 {
     int rc = check(device, items, n, x, y, pos, z);
     if (rc != SPANGPU_OK)
+        return rc;
+    if ((rc = check_pos(pos, items, n, mem)) != SPANGPU_OK)
         return rc;
     Staged st;
     float *dx, *dy, *dz;
@@ -261,6 +282,8 @@ int spangpu_vec_circular_lmsf_batch(int device, const float *x, long long x_stri
 {
     int rc = check(device, items, n, x, y, pos, error);
     if (rc != SPANGPU_OK)
+        return rc;
+    if ((rc = check_pos(pos, items, n, mem)) != SPANGPU_OK)
         return rc;
     if (y_stride < n)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "the rows of y are written: they cannot overlap");
@@ -292,6 +315,8 @@ int spangpu_cvec_circular_dot_prodf_batch(int device, const float *x, long long 
     int rc = check(device, items, n, x, y, pos, z);
     if (rc != SPANGPU_OK)
         return rc;
+    if ((rc = check_pos(pos, items, n, mem)) != SPANGPU_OK)
+        return rc;
     Staged st;
     float *dx, *dy, *dz;
     int32_t *dp;
@@ -319,6 +344,8 @@ int spangpu_cvec_circular_lmsf_batch(int device, const float *x, long long x_str
 {
     int rc = check(device, items, n, x, y, pos, error);
     if (rc != SPANGPU_OK)
+        return rc;
+    if ((rc = check_pos(pos, items, n, mem)) != SPANGPU_OK)
         return rc;
     if (y_stride < n)
         return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "the rows of y are written: they cannot overlap");
@@ -376,6 +403,8 @@ int spangpu_godard_ted_rx_batch(int device, uint32_t *state, const uint32_t *des
     int rc = check(device, items, n, state, desc, samples, samples);
     if (rc != SPANGPU_OK)
         return rc;
+    if ((desc_stride != 0  &&  desc_stride < 12)  ||  stride < 0  ||  (items > 1  &&  stride != 0  &&  stride < n))
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "a descriptor stride is 0 or at least 12 words, a sample stride 0 or at least a row");
     Staged st;
     uint32_t *dst, *dd;
     float *dx;
@@ -401,6 +430,8 @@ int spangpu_godard_ted_per_baud_batch(int device, uint32_t *state, const uint32_
     int rc = check(device, items, 1, state, desc, correction, correction);
     if (rc != SPANGPU_OK)
         return rc;
+    if (desc_stride != 0  &&  desc_stride < 12)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "a descriptor stride is 0 (one for all items) or at least 12 words");
     Staged st;
     uint32_t *dst, *dd;
     int32_t *dc;

@@ -1,5 +1,9 @@
 /*
- * shim_prims.c -- the receivers' inner primitives under their spandsp names, for a caller that links them by name:
+ * shim_prims.c -- libspangpu_prims.so (NOT part of libspangpu.so: include/spangpu_prims.h says why): the receivers' inner
+ * primitives under their spandsp names, for a caller that links them by name:
+ *   vec_dot_prodf(), vec_lmsf(), cvec_dot_prodf(), cvec_lmsf()     src/vector_float.c:890-900,982-992   src/complex_vector_float.c:137-150,201-212
+ *   periodogram(), _prepare(), _apply(), _generate_coeffs(), _generate_phase_offset(), _freq_error()    src/tone_detect.c:208-312
+ *   fixed_sqrt32()   src/math_fixed.c:158-169      dds_lookup_complexf(), dds_complexf(), dds_advancef()   src/dds_float.c:2135-2187
  *   vec_circular_dot_prodf(), vec_circular_lmsf()          src/spandsp/vector_float.h:184,188    src/vector_float.c:932-939,996-1000
  *   cvec_circular_dot_prodf(), cvec_circular_lmsf()        src/spandsp/complex_vector_float.h:159,163   src/complex_vector_float.c:187-196,215-219
  *   power_meter_init/_release/_free/_damping/_update/_rx/_current   src/spandsp/power_meter.h:62-94      src/power_meter.c:44-113
@@ -15,7 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "spangpu_spandsp.h"
+#include "spangpu_prims.h"
 
 static int prim_device(void)
 {
@@ -212,4 +216,161 @@ int godard_ted_free(godard_ted_state_t *s)
 {
     free(s);
     return 0;
+}
+
+
+/* ---- the plain (non-circular) forms: the circular entry points at position 0 -- vec_circular_dot_prodf(x, y, n, 0) is
+   vec_dot_prodf(x, y, n) plus an empty second sum (vector_float.c:932-939), and a sum that started at +0.0f is never -0.0f ---- */
+float vec_dot_prodf(const float x[], const float y[], int n)
+{
+    return vec_circular_dot_prodf(x, y, n, 0);
+}
+
+void vec_lmsf(const float x[], float y[], int n, float error)
+{
+    vec_circular_lmsf(x, y, n, 0, error);
+}
+
+complexf_t cvec_dot_prodf(const complexf_t x[], const complexf_t y[], int n)
+{
+    return cvec_circular_dot_prodf(x, y, n, 0);
+}
+
+void cvec_lmsf(const complexf_t x[], complexf_t y[], int n, const complexf_t *error)
+{
+    cvec_circular_lmsf(x, y, n, 0, error);
+}
+
+/* ---- periodograms (tone_detect.c:208-312).  The coefficient set and the phase offset are table making: formed on the host
+   with the reference's expressions (libm's cosf / sinf, as there).  The sums and the frequency error are the device's. ---- */
+complexf_t periodogram(const complexf_t coeffs[], const complexf_t amp[], int len)
+{
+    complexf_t z;
+
+    z.re = 0.0f;
+    z.im = 0.0f;
+    if (len < 2)
+        return z;
+    if (spangpu_periodogram_batch(prim_device(), (const float *) coeffs, 0, (const float *) amp, 0, (float *) &z, 1, len, SPANGPU_MEM_HOST) < 0)
+    {
+        z.re = NAN;
+        z.im = NAN;
+    }
+    return z;
+}
+
+int periodogram_prepare(complexf_t sum[], complexf_t diff[], const complexf_t amp[], int len)
+{
+    if (len < 2)
+        return 0;
+    if (spangpu_periodogram_prepare_batch(prim_device(), (const float *) amp, 0, (float *) sum, (float *) diff, 1, len, SPANGPU_MEM_HOST) < 0)
+    {
+        for (int i = 0;  i < len/2;  i++)
+            sum[i].re = sum[i].im = diff[i].re = diff[i].im = NAN;
+    }
+    return len/2;
+}
+
+complexf_t periodogram_apply(const complexf_t coeffs[], const complexf_t sum[], const complexf_t diff[], int len)
+{
+    complexf_t z;
+
+    z.re = 0.0f;
+    z.im = 0.0f;
+    if (len < 2)
+        return z;
+    if (spangpu_periodogram_apply_batch(prim_device(), (const float *) coeffs, 0, (const float *) sum, (const float *) diff, (float *) &z, 1, len,
+                                        SPANGPU_MEM_HOST) < 0)
+    {
+        z.re = NAN;
+        z.im = NAN;
+    }
+    return z;
+}
+
+int periodogram_generate_coeffs(complexf_t coeffs[], float freq, int sample_rate, int window_len)
+{
+    float window;
+    float sum;
+    float x;
+    int i;
+
+    /* tone_detect.c:258-283: half a Hamming window times the matched phasor, then scaled for unity gain over the whole window */
+    sum = 0.0f;
+    for (i = 0;  i < window_len/2;  i++)
+    {
+        window = 0.53836f - 0.46164f*cosf(2.0f*3.1415926535f*i/(window_len - 1.0f));
+        x = (i - window_len/2.0f + 0.5f)*freq*2.0f*3.1415926535f/sample_rate;
+        coeffs[i].re = cosf(x)*window;
+        coeffs[i].im = -sinf(x)*window;
+        sum += window;
+    }
+    sum = 1.0f/(2.0f*sum);
+    for (i = 0;  i < window_len/2;  i++)
+    {
+        coeffs[i].re *= sum;
+        coeffs[i].im *= sum;
+    }
+    return window_len/2;
+}
+
+float periodogram_generate_phase_offset(complexf_t *offset, float freq, int sample_rate, int interval)
+{
+    float x;
+
+    /* tone_detect.c:286-296 */
+    x = 2.0f*3.1415926535f*(float) interval/(float) sample_rate;
+    offset->re = cosf(freq*x);
+    offset->im = sinf(freq*x);
+    return 1.0f/x;
+}
+
+float periodogram_freq_error(const complexf_t *phase_offset, float scale, const complexf_t *last_result, const complexf_t *result)
+{
+    float err = NAN;
+
+    if (spangpu_periodogram_freq_error_batch(prim_device(), (const float *) phase_offset, scale, (const float *) last_result, (const float *) result,
+                                             &err, 1, SPANGPU_MEM_HOST) < 0)
+        return NAN;
+    return err;
+}
+
+/* ---- SURVEY 8(a) a19's helpers by name: the receivers' tables and device functions, one item a call ---- */
+uint16_t fixed_sqrt32(uint32_t x)
+{
+    uint16_t r = 0;
+
+    if (spangpu_fixed_sqrt32_batch(prim_device(), &x, &r, 1, SPANGPU_MEM_HOST) < 0)
+        return 0;
+    return r;
+}
+
+complexf_t dds_lookup_complexf(uint32_t phase)
+{
+    complexf_t z;
+    int32_t rate = 0;
+
+    if (spangpu_dds_complexf_batch(prim_device(), &phase, &rate, (float *) &z, 1, 1, SPANGPU_MEM_HOST) < 0)
+    {
+        z.re = NAN;
+        z.im = NAN;
+    }
+    return z;
+}
+
+complexf_t dds_complexf(uint32_t *phase_acc, int32_t phase_rate)
+{
+    complexf_t z;
+
+    if (spangpu_dds_complexf_batch(prim_device(), phase_acc, &phase_rate, (float *) &z, 1, 1, SPANGPU_MEM_HOST) < 0)
+    {
+        z.re = NAN;
+        z.im = NAN;
+    }
+    return z;
+}
+
+void dds_advancef(uint32_t *phase_acc, int32_t phase_rate)
+{
+    *phase_acc += (uint32_t) phase_rate;        /* dds_float.c:2153-2156: an addition, on the host as on the device */
 }

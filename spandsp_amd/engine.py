@@ -8,6 +8,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+PRIMS_LIB_PATH = os.path.join(HERE, "libspangpu_prims.so")        # the opt-in library of spandsp-named primitives (include/spangpu_prims.h)
 LIB_PATH = os.environ.get("SPANGPU_LIB", os.path.join(HERE, "libspangpu.so"))      # the variable: instrumented builds (tools/quad_prof.py)
 
 # include/spangpu.h
@@ -185,6 +186,13 @@ def lib():
             "spangpu_cvec_circular_dot_prodf_batch": (ci, [ci, vp, ll, vp, ll, vp, vp, ci, ci, ci]),
             "spangpu_cvec_circular_lmsf_batch": (ci, [ci, vp, ll, vp, ll, vp, vp, ci, ci, ci]),
             "spangpu_power_meter_update_batch": (ci, [ci, vp, ll, vp, vp, ci, ci, ci]),
+            "spangpu_periodogram_batch": (ci, [ci, vp, ll, vp, ll, vp, ci, ci, ci]),
+            "spangpu_periodogram_prepare_batch": (ci, [ci, vp, ll, vp, vp, ci, ci, ci]),
+            "spangpu_periodogram_apply_batch": (ci, [ci, vp, ll, vp, vp, vp, ci, ci, ci]),
+            "spangpu_periodogram_freq_error_batch": (ci, [ci, vp, cf, vp, vp, vp, ci, ci]),
+            "spangpu_fixed_sqrt32_batch": (ci, [ci, vp, vp, ci, ci]),
+            "spangpu_dds_complexf_batch": (ci, [ci, vp, vp, vp, ci, ci, ci]),
+            "spangpu_arctan2_batch": (ci, [ci, vp, vp, vp, ci, ci]),
             "spangpu_shard_create": (ci, [C.POINTER(vp), vp, ci, ci, ci, ci, vp, C.c_size_t]),
             "spangpu_shard_destroy": (ci, [vp]),
             "spangpu_shard_count": (ci, [vp]),
@@ -708,6 +716,69 @@ def power_meter_update(amp, reading, shift, device=0):
     sh = np.ascontiguousarray(shift, np.int32)
     _check(lib().spangpu_power_meter_update_batch(device, amp.ctypes.data, amp.shape[1], r.ctypes.data, sh.ctypes.data, amp.shape[0], amp.shape[1], MEM_HOST))
     return r
+
+
+# ---- ... and the rest of them (csrc/prim2_api.hip): periodograms, fixed_sqrt32, dds_complexf, arctan2 ------------------------------
+def periodogram(coeffs, amp, device=0):
+    """coeffs float32 [items, len/2, 2] (or [len/2, 2] for all items), amp float32 [items, len, 2] -> float32 [items, 2]"""
+    c = np.ascontiguousarray(coeffs, np.float32)
+    a = np.ascontiguousarray(amp, np.float32)
+    items, n = a.shape[0], a.shape[1]
+    out = np.zeros((items, 2), np.float32)
+    _check(lib().spangpu_periodogram_batch(device, c.ctypes.data, n//2 if c.ndim == 3 else 0, a.ctypes.data, n, out.ctypes.data, items, n, MEM_HOST))
+    return out
+
+
+def periodogram_prepare(amp, device=0):
+    a = np.ascontiguousarray(amp, np.float32)
+    items, n = a.shape[0], a.shape[1]
+    s = np.zeros((items, n//2, 2), np.float32)
+    d = np.zeros((items, n//2, 2), np.float32)
+    assert _check(lib().spangpu_periodogram_prepare_batch(device, a.ctypes.data, n, s.ctypes.data, d.ctypes.data, items, n, MEM_HOST)) == n//2
+    return s, d
+
+
+def periodogram_apply(coeffs, s, d, n, device=0):
+    c = np.ascontiguousarray(coeffs, np.float32)
+    s = np.ascontiguousarray(s, np.float32)
+    d = np.ascontiguousarray(d, np.float32)
+    out = np.zeros((s.shape[0], 2), np.float32)
+    _check(lib().spangpu_periodogram_apply_batch(device, c.ctypes.data, n//2 if c.ndim == 3 else 0, s.ctypes.data, d.ctypes.data, out.ctypes.data,
+                                                 s.shape[0], n, MEM_HOST))
+    return out
+
+
+def periodogram_freq_error(phase_offset, scale, last, now, device=0):
+    off = np.ascontiguousarray(phase_offset, np.float32)
+    a = np.ascontiguousarray(last, np.float32)
+    b = np.ascontiguousarray(now, np.float32)
+    out = np.zeros(a.shape[0], np.float32)
+    _check(lib().spangpu_periodogram_freq_error_batch(device, off.ctypes.data, scale, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.shape[0], MEM_HOST))
+    return out
+
+
+def fixed_sqrt32(x, device=0):
+    x = np.ascontiguousarray(x, np.uint32)
+    out = np.zeros(len(x), np.uint16)
+    _check(lib().spangpu_fixed_sqrt32_batch(device, x.ctypes.data, out.ctypes.data, len(x), MEM_HOST))
+    return out
+
+
+def dds_complexf(phase_acc, phase_rate, n, device=0):
+    """-> (float32 [items, n, 2] phasors, uint32 [items] accumulators after n steps)"""
+    acc = np.array(phase_acc, np.uint32)
+    rate = np.ascontiguousarray(phase_rate, np.int32)
+    out = np.zeros((len(acc), n, 2), np.float32)
+    _check(lib().spangpu_dds_complexf_batch(device, acc.ctypes.data, rate.ctypes.data, out.ctypes.data, len(acc), n, MEM_HOST))
+    return out, acc
+
+
+def arctan2(y, x, device=0):
+    y = np.ascontiguousarray(y, np.float32)
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(len(y), np.int32)
+    _check(lib().spangpu_arctan2_batch(device, y.ctypes.data, x.ctypes.data, out.ctypes.data, len(y), MEM_HOST))
+    return out
 
 
 class ShardedToneBank:

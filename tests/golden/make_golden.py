@@ -235,6 +235,13 @@ def modem_offset_goldens():
         save(modem_offset_name(case), amp=x, carrier_hz=case[4], ppm=case[5], events=ev.astype(np.int8), fwords=f, iwords=w)
 
 
+def prims2_golden():
+    """tests/prims2.py's cases on the real reference: a CRC-32 of every answer (whole-domain sweeps included) and the small answers whole"""
+    import prims2
+    from test_oracle_pin import prims2_reference
+    save("prims2", **prims2.summary(prims2.run(prims2_reference())))
+
+
 def make_g168():
     import zlib
     # the G.168 echo path models (test data of the reference: src/spandsp/g168models.h) and the known answer of
@@ -354,6 +361,7 @@ def main():
         save("mct_%d_%s" % (rx_type, tx_kind), amp=x, events=ev, snapshots=snaps)
     sigtone_goldens()
     modem_offset_goldens()
+    prims2_golden()
     kw = {"table": ref.v29_tx_table()}
     for i, (bit_rate, tep, seed) in enumerate(V29TX_CASES):
         kw["amp_%d" % i], kw["snaps_%d" % i] = v29tx_run(ref.V29Tx(bit_rate, tep, seed), seed)
@@ -391,6 +399,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["sigtone"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         sigtone_goldens()
+    elif sys.argv[1:] == ["prims2"]:
+        assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
+        prims2_golden()
     elif sys.argv[1:] == ["modem_offsets"]:
         assert ref.available(), "build oracle/_ref first (make -C oracle ref)"
         modem_offset_goldens()

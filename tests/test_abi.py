@@ -10,11 +10,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols(header):
+def _declared_symbols(header, macro="SPANGPU_API"):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = "\n".join(ln for ln in text.splitlines() if not ln.lstrip().startswith("#"))
-    return sorted(set(re.findall(r"SPANGPU_API\s+[^;(]*?\b(\w+)\s*\(", text)))
+    return sorted(set(re.findall(macro + r"\s+[^;(]*?\b(\w+)\s*\(", text)))
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return set(ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in ("T", "W", "D", "B"))
 
 
 def test_library_exports_every_declared_symbol(built):
@@ -29,6 +35,24 @@ def test_library_exports_every_declared_symbol(built):
             assert hasattr(L, n), "%s declares %s but libspangpu.so does not export it" % (h, n)
         total += len(names)
     assert total >= 20
+
+
+def test_the_spandsp_named_primitives_are_an_opt_in_library(built):
+    """include/spangpu_prims.h's names (vec_*, cvec_*, power_meter_*, godard_ted_*, periodogram* ...) are what libspandsp calls from
+    inside its own modules: libspangpu.so must export none of them (a process loading both would have those calls captured),
+    libspangpu_prims.so every one, and nothing else."""
+    from spandsp_amd import engine
+    names = _declared_symbols("spangpu_prims.h", "SPANGPU_PRIMS_API")
+    assert len(names) >= 30 and "vec_dot_prodf" in names and "periodogram" in names and "power_meter_update" in names
+    main = _exported(engine.LIB_PATH)
+    prims = _exported(engine.PRIMS_LIB_PATH)
+    for n in names:
+        assert n not in main, "libspangpu.so exports %s" % n
+        assert n in prims, "spangpu_prims.h declares %s but libspangpu_prims.so does not export it" % n
+    assert prims == set(names), sorted(prims ^ set(names))
+    # and the main library exports nothing else under libspandsp's INTERNAL helper names either
+    for n in main:
+        assert not re.match(r"(vec_|cvec_|power_meter_|godard_ted_|periodogram|fixed_|dds_|top_bit|saturate)", n), n
 
 
 def test_no_cpu_fallback(built):

@@ -1284,6 +1284,46 @@ def test_golden_modem_offsets(built, case):
 
 
 # ---------------------------------------------------------------------------------
+# round 6's primitives: periodogram*, the plain dot products and LMS updates, fixed_sqrt32, dds_complexf, arctan2 (tests/prims2.py)
+# ---------------------------------------------------------------------------------
+def prims2_reference():
+    import ctypes as C
+    import prims2
+    from oracle import ref
+    L = ref.lib()
+    for name, args in (("glue_fixed_sqrt32_batch", 3), ("glue_arctan2_batch", 4), ("glue_dds_complexf_batch", 5)):
+        getattr(L, name).restype = None
+        getattr(L, name).argtypes = [C.c_void_p]*(args - 1) + [C.c_int] if args < 5 else [C.c_void_p]*3 + [C.c_int, C.c_int]
+    return prims2.ByName(L)
+
+
+@needs_ref
+def test_prims2_live(built):
+    """The oracle's restatement (oracle/prims_oracle.c, modem_common.h) against the reference's own functions: periodograms
+    of four lengths on nasty inputs, coefficient sets and phase offsets (libm on both sides), the plain vector primitives, and
+    fixed_sqrt32 / dds_complexf / arctan2 over their whole domains -- every answer bit for bit."""
+    import prims2
+    use_golden_modem_tables()
+    d = prims2.inputs()
+    a = prims2.run(prims2_reference(), d)
+    b = prims2.run(prims2.Restated(), d)
+    assert set(a) == set(b) and len(a) > 40
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert len(np.unique(a["sqrt"])) > 1500 and len(np.unique(a["atan"])) > 500000
+
+
+def test_golden_prims2(built):
+    import prims2
+    use_golden_modem_tables()
+    g = np.load(os.path.join(GOLDEN, "prims2.npz"))
+    out = prims2.summary(prims2.run(prims2.Restated()))
+    assert set(out) == set(g.files)
+    for k in out:
+        assert np.array_equal(out[k], g[k]), k
+
+
+# ---------------------------------------------------------------------------------
 # frozen pins: golden vectors generated from the reference build
 # ---------------------------------------------------------------------------------
 def test_golden_files_present():

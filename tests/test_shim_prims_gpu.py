@@ -1,4 +1,4 @@
-"""The receivers' inner primitives under their spandsp names (csrc/shim_prims.c: vec_circular_dot_prodf(), vec_circular_lmsf(),
+"""The receivers' inner primitives under their spandsp names (libspangpu_prims.so, the opt-in library; csrc/shim_prims.c: vec_circular_dot_prodf(), vec_circular_lmsf(),
 cvec_circular_dot_prodf(), cvec_circular_lmsf(), power_meter_*()), as a caller that links them by name finds them: against the
 real reference's functions of the same names (oracle/_ref, which travels with the snapshot) where it is present, and against
 the batched entry points they run through (held to the reference in test_prim_gpu.py) in any case."""
@@ -45,7 +45,7 @@ def bind(L):
 def libs():
     import oracle
     from spandsp_amd import engine
-    gpu = bind(C.CDLL(engine.LIB_PATH))
+    gpu = bind(C.CDLL(engine.PRIMS_LIB_PATH))
     ref = None
     if oracle.have_ref():
         from oracle import ref as r
