@@ -307,7 +307,7 @@ def run_echo(args, engine, dev, local_rank, rank, world):
                 gather.result()                     # the previous report has arrived (and the send buffer is free again)
             bank.erle_device(ctypes.c_void_p(erle_dev.data_ptr()))
             if gather is not None:
-                gather.gather()
+                gather.gather(bank)                 # (checks that the bank launches on the current stream: the collective waits for that one)
             if i + 1 < nf:
                 bank.stats_reset(sums=True, crc=False)
 

@@ -822,6 +822,22 @@ SPANGPU_API int spangpu_modem_feed_run(spangpu_modem_feed_t *feed, int samples, 
        per tick: spangpu_shard_rx(sh, amp_per_shard, 160, 160);   amp_per_shard[i]: shard i's rows on shard i's device
                  spangpu_shard_digits_device(sh, stream, &digits, &dev, &max_blocks)  or  spangpu_shard_digits_host(sh, out, bytes)
    What it stands for on a host running the reference: the loop over all its dtmf_rx() objects and their dtmf_rx_get()s. */
+/* How a shard's results reach the collecting device, and where it sits (spangpu_shard_info() and its echo / modem twins). */
+#define SPANGPU_LINK_SAME           0       /* the shard is on the collecting device */
+#define SPANGPU_LINK_PEER           1       /* peer access enabled: hipMemcpyPeerAsync goes device to device (xGMI) */
+#define SPANGPU_LINK_STAGED         2       /* no peer access (not possible, or enabling it failed): the copy is staged through the host -- correct, slow */
+typedef struct
+{
+    int device;
+    int first_channel;
+    int n_channels;
+    int collect_device;
+    int link;                   /* SPANGPU_LINK_* */
+    int forced_peer_copy;       /* spangpu_tune_force_peer_copy() is on */
+} spangpu_shard_info_t;
+/* Debug knob: shards on the collecting device itself send their results with hipMemcpyPeerAsync too (source and destination
+   device equal), so that the multi-device code path runs on a one-GPU box.  Returns the previous setting. */
+SPANGPU_API int spangpu_tune_force_peer_copy(int on);
 typedef struct spangpu_shard_s spangpu_shard_t;
 SPANGPU_API int spangpu_shard_create(spangpu_shard_t **shard, const int *devices, int n_devices, int kind, int n_channels, int max_samples,
                                      const void *params, size_t params_size);
@@ -829,6 +845,7 @@ SPANGPU_API int spangpu_shard_destroy(spangpu_shard_t *shard);
 SPANGPU_API int spangpu_shard_count(const spangpu_shard_t *shard);
 SPANGPU_API int spangpu_shard_channels(const spangpu_shard_t *shard);
 SPANGPU_API int spangpu_shard_range(const spangpu_shard_t *shard, int i, int *device, int *first_channel, int *n_channels);
+SPANGPU_API int spangpu_shard_info(const spangpu_shard_t *shard, int i, spangpu_shard_info_t *info);
 SPANGPU_API spangpu_bank_t *spangpu_shard_bank(spangpu_shard_t *shard, int i);
 SPANGPU_API int spangpu_shard_rx(spangpu_shard_t *shard, const int16_t *const *amp, int samples, long long stride);
 SPANGPU_API int spangpu_shard_digits_device(spangpu_shard_t *shard, void *hip_stream, const uint8_t **digits, int *collect_device, int *max_blocks);
@@ -848,6 +865,7 @@ SPANGPU_API int spangpu_echo_shard_create(spangpu_echo_shard_t **shard, const in
 SPANGPU_API int spangpu_echo_shard_destroy(spangpu_echo_shard_t *shard);
 SPANGPU_API int spangpu_echo_shard_count(const spangpu_echo_shard_t *shard);
 SPANGPU_API int spangpu_echo_shard_range(const spangpu_echo_shard_t *shard, int i, int *device, int *first_channel, int *n_channels);
+SPANGPU_API int spangpu_echo_shard_info(const spangpu_echo_shard_t *shard, int i, spangpu_shard_info_t *info);
 SPANGPU_API spangpu_echo_t *spangpu_echo_shard_bank(spangpu_echo_shard_t *shard, int i);
 SPANGPU_API int spangpu_echo_shard_update(spangpu_echo_shard_t *shard, const int16_t *const *tx, const int16_t *const *rx, int16_t *const *clean,
                                           int samples, long long stride);
@@ -863,6 +881,7 @@ SPANGPU_API int spangpu_modem_shard_create(spangpu_modem_shard_t **shard, const 
                                            int events_per_channel);
 SPANGPU_API int spangpu_modem_shard_destroy(spangpu_modem_shard_t *shard);
 SPANGPU_API int spangpu_modem_shard_range(const spangpu_modem_shard_t *shard, int i, int *device, int *first_channel, int *n_channels);
+SPANGPU_API int spangpu_modem_shard_info(const spangpu_modem_shard_t *shard, int i, spangpu_shard_info_t *info);
 SPANGPU_API spangpu_modem_t *spangpu_modem_shard_bank(spangpu_modem_shard_t *shard, int i);
 SPANGPU_API int spangpu_modem_shard_rx(spangpu_modem_shard_t *shard, const int16_t *const *amp, int samples, long long stride);
 SPANGPU_API int spangpu_modem_shard_events_host(spangpu_modem_shard_t *shard, int32_t *counts, int8_t *events);

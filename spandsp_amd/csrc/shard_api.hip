@@ -11,6 +11,7 @@
 // One host thread drives all shards: every call below only queues work (a launch and a copy per shard) and returns; the
 // devices run side by side because each shard has a stream of its own on its own device.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,8 +24,52 @@ extern "C" int spangpu_set_error(int code, const char *msg);
 
 enum { kMaxShards = 64 };
 
+// How shard i's results reach the collecting device: SPANGPU_LINK_SAME (it is the collecting device), SPANGPU_LINK_PEER (peer
+// access is on: hipMemcpyPeerAsync goes device to device over xGMI) or SPANGPU_LINK_STAGED (the devices cannot reach each
+// other, or enabling failed: the runtime stages the copy through host memory -- correct, and slow; spangpu_*_shard_info() says so).
+static int link_to(int from_device, int to_device)
+{
+    if (from_device == to_device)
+        return SPANGPU_LINK_SAME;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, from_device, to_device) != hipSuccess  ||  !can)
+    {
+        (void) hipGetLastError();
+        return SPANGPU_LINK_STAGED;
+    }
+    // (the current device is from_device: it is given access to to_device's memory)
+    const hipError_t e = hipDeviceEnablePeerAccess(to_device, 0);
+    (void) hipGetLastError();
+    return (e == hipSuccess  ||  e == hipErrorPeerAccessAlreadyEnabled)  ?  SPANGPU_LINK_PEER  :  SPANGPU_LINK_STAGED;
+}
+
+// Debug knob (spangpu_tune_force_peer_copy): a shard on the collecting device itself sends its results with hipMemcpyPeerAsync
+// too (source and destination device equal: HIP allows it), so that the multi-device code path runs on a one-GPU box.
+static std::atomic<int> g_force_peer{0};
+
+static hipError_t gather_copy(void *dst, int dst_device, const void *src, int src_device, size_t bytes, hipStream_t st)
+{
+    if (src_device == dst_device  &&  !g_force_peer.load())
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    return hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, st);
+}
+
+static int shard_info(int n, const int *device, const int *first, const int *link, int collect_device, int i, spangpu_shard_info_t *info)
+{
+    if (i < 0  ||  i >= n  ||  info == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "bad shard");
+    info->device = device[i];
+    info->first_channel = first[i];
+    info->n_channels = first[i + 1] - first[i];
+    info->collect_device = collect_device;
+    info->link = link[i];
+    info->forced_peer_copy = g_force_peer.load();
+    return SPANGPU_OK;
+}
+
 struct spangpu_shard_s
 {
+    int link[kMaxShards];               // SPANGPU_LINK_*: how shard i's bytes reach the collecting device
     int n;                              // shards
     int n_ch;                           // channels of the whole bank
     int kind;
@@ -126,13 +171,8 @@ int spangpu_shard_create(spangpu_shard_t **out, const int *devices, int n_device
             else
                 rc = spangpu_bank_set_digits_buffer(s->bank[i], s->digits[i], (size_t) s->max_blocks*mine);
         }
-        if (rc == SPANGPU_OK  &&  devices[i] != s->collect_device)
-        {
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, devices[i], s->collect_device) == hipSuccess  &&  can)
-                (void) hipDeviceEnablePeerAccess(s->collect_device, 0);      // (already enabled is fine; without it the copy is staged)
-            (void) hipGetLastError();
-        }
+        if (rc == SPANGPU_OK)
+            s->link[i] = link_to(devices[i], s->collect_device);
     }
     if (rc == SPANGPU_OK)
     {
@@ -166,6 +206,18 @@ int spangpu_shard_range(const spangpu_shard_t *s, int i, int *device, int *first
     return SPANGPU_OK;
 }
 
+int spangpu_shard_info(const spangpu_shard_t *s, int i, spangpu_shard_info_t *info)
+{
+    if (s == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null shard set");
+    return shard_info(s->n, s->device, s->first, s->link, s->collect_device, i, info);
+}
+
+int spangpu_tune_force_peer_copy(int on)
+{
+    return g_force_peer.exchange(on  ?  1  :  0);
+}
+
 spangpu_bank_t *spangpu_shard_bank(spangpu_shard_t *s, int i)
 {
     return (s  &&  i >= 0  &&  i < s->n)  ?  s->bank[i]  :  nullptr;
@@ -192,10 +244,7 @@ int spangpu_shard_rx(spangpu_shard_t *s, const int16_t *const *amp, int samples,
             return rc;
         hipStream_t st = (hipStream_t) spangpu_bank_get_stream(s->bank[i]);
         uint8_t *dst = s->gathered[slot] + (size_t) s->max_blocks*s->first[i];
-        if (s->device[i] == s->collect_device)
-            SH_TRY(hipMemcpyAsync(dst, s->digits[i], (size_t) maxb*mine, hipMemcpyDeviceToDevice, st));
-        else
-            SH_TRY(hipMemcpyPeerAsync(dst, s->collect_device, s->digits[i], s->device[i], (size_t) maxb*mine, st));
+        SH_TRY(gather_copy(dst, s->collect_device, s->digits[i], s->device[i], (size_t) maxb*mine, st));
         SH_TRY(hipEventRecord(s->done[slot][i], st));
     }
     s->steps++;
@@ -280,6 +329,7 @@ int spangpu_shard_sync(spangpu_shard_t *s)
 // ERLE is tests/echo_tests.c:577-594's level measurement, 10 log10(sum rx^2 / sum clean^2).)
 struct spangpu_echo_shard_s
 {
+    int link[kMaxShards];               // SPANGPU_LINK_*
     int n;
     int n_ch;
     int collect_device;
@@ -310,13 +360,6 @@ static int deal_channels(int n_channels, int n_devices, int *first)
     return (at == n_channels)  ?  SPANGPU_OK  :  SPANGPU_ERR_BAD_ARG;
 }
 
-static void enable_peer(int from_device, int to_device)
-{
-    int can = 0;
-    if (from_device != to_device  &&  hipDeviceCanAccessPeer(&can, from_device, to_device) == hipSuccess  &&  can)
-        (void) hipDeviceEnablePeerAccess(to_device, 0);
-    (void) hipGetLastError();
-}
 
 int spangpu_echo_shard_destroy(spangpu_echo_shard_t *s)
 {
@@ -378,7 +421,7 @@ int spangpu_echo_shard_create(spangpu_echo_shard_t **out, const int *devices, in
                 rc = spangpu_echo_stats(s->bank[i], 2);         // the update kernel itself keeps the energy sums
         }
         if (rc == SPANGPU_OK)
-            enable_peer(devices[i], s->collect_device);
+            s->link[i] = link_to(devices[i], s->collect_device);
     }
     if (rc == SPANGPU_OK)
     {
@@ -406,6 +449,13 @@ int spangpu_echo_shard_range(const spangpu_echo_shard_t *s, int i, int *device, 
     if (first_channel) *first_channel = s->first[i];
     if (n_channels) *n_channels = s->first[i + 1] - s->first[i];
     return SPANGPU_OK;
+}
+
+int spangpu_echo_shard_info(const spangpu_echo_shard_t *s, int i, spangpu_shard_info_t *info)
+{
+    if (s == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null shard set");
+    return shard_info(s->n, s->device, s->first, s->link, s->collect_device, i, info);
 }
 
 spangpu_echo_t *spangpu_echo_shard_bank(spangpu_echo_shard_t *s, int i)
@@ -446,10 +496,7 @@ int spangpu_echo_shard_report(spangpu_echo_shard_t *s, int reset)
             return rc;
         hipStream_t st = (hipStream_t) spangpu_echo_get_stream(s->bank[i]);
         float *dst = s->gathered[slot] + s->first[i];
-        if (s->device[i] == s->collect_device)
-            SH_TRY(hipMemcpyAsync(dst, s->erle[i], (size_t) mine*sizeof(float), hipMemcpyDeviceToDevice, st));
-        else
-            SH_TRY(hipMemcpyPeerAsync(dst, s->collect_device, s->erle[i], s->device[i], (size_t) mine*sizeof(float), st));
+        SH_TRY(gather_copy(dst, s->collect_device, s->erle[i], s->device[i], (size_t) mine*sizeof(float), st));
         SH_TRY(hipEventRecord(s->done[slot][i], st));
         if (reset  &&  (rc = spangpu_echo_stats_reset(s->bank[i], SPANGPU_ECHO_STATS_SUMS)) < 0)
             return rc;
@@ -517,6 +564,7 @@ int spangpu_echo_shard_sync(spangpu_echo_shard_t *s)
 // (4 + per)*first_channel(i) of the collecting buffer.
 struct spangpu_modem_shard_s
 {
+    int link[kMaxShards];               // SPANGPU_LINK_*
     int n;
     int n_ch;
     int per;
@@ -594,7 +642,7 @@ int spangpu_modem_shard_create(spangpu_modem_shard_t **out, const int *devices, 
                 rc = spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "out of device memory");
         }
         if (rc == SPANGPU_OK)
-            enable_peer(devices[i], s->collect_device);
+            s->link[i] = link_to(devices[i], s->collect_device);
     }
     if (rc == SPANGPU_OK)
     {
@@ -623,6 +671,13 @@ int spangpu_modem_shard_range(const spangpu_modem_shard_t *s, int i, int *device
     return SPANGPU_OK;
 }
 
+int spangpu_modem_shard_info(const spangpu_modem_shard_t *s, int i, spangpu_shard_info_t *info)
+{
+    if (s == nullptr)
+        return spangpu_set_error(SPANGPU_ERR_BAD_ARG, "null shard set");
+    return shard_info(s->n, s->device, s->first, s->link, s->collect_device, i, info);
+}
+
 spangpu_modem_t *spangpu_modem_shard_bank(spangpu_modem_shard_t *s, int i)
 {
     return (s  &&  i >= 0  &&  i < s->n)  ?  s->bank[i]  :  nullptr;
@@ -647,10 +702,7 @@ int spangpu_modem_shard_rx(spangpu_modem_shard_t *s, const int16_t *const *amp, 
             return rc;
         hipStream_t st = (hipStream_t) spangpu_modem_get_stream(s->bank[i]);
         uint8_t *dst = s->gathered[slot] + per_ch*s->first[i];
-        if (s->device[i] == s->collect_device)
-            SH_TRY(hipMemcpyAsync(dst, s->ev[i], per_ch*mine, hipMemcpyDeviceToDevice, st));
-        else
-            SH_TRY(hipMemcpyPeerAsync(dst, s->collect_device, s->ev[i], s->device[i], per_ch*mine, st));
+        SH_TRY(gather_copy(dst, s->collect_device, s->ev[i], s->device[i], per_ch*mine, st));
         SH_TRY(hipEventRecord(s->done[slot][i], st));
     }
     s->steps++;

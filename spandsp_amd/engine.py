@@ -98,7 +98,7 @@ def lib():
             "spangpu_banks_rx": (ci, [vp, vp, ci, ci, vp]), "spangpu_banks_own_queues": (ci, [vp, ci]),
             "spangpu_bank_rx_g711": (ci, [vp, vp, ci, ci, ci, ll]),
             "spangpu_bank_set_records_buffer": (ci, [vp, vp, C.c_size_t]),
-            "spangpu_bank_get_stream": (vp, [vp]),
+            "spangpu_bank_get_stream": (vp, [vp]), "spangpu_echo_get_stream": (vp, [vp]), "spangpu_modem_get_stream": (vp, [vp]),
             "spangpu_modemtx_create": (ci, [C.POINTER(vp), ci, ci, ci, ci, ci, vp]),
             "spangpu_modemtx_destroy": (None, [vp]),
             "spangpu_modemtx_channels": (ci, [vp]),
@@ -193,6 +193,8 @@ def lib():
             "spangpu_fixed_sqrt32_batch": (ci, [ci, vp, vp, ci, ci]),
             "spangpu_dds_complexf_batch": (ci, [ci, vp, vp, vp, ci, ci, ci]),
             "spangpu_arctan2_batch": (ci, [ci, vp, vp, vp, ci, ci]),
+            "spangpu_tune_force_peer_copy": (ci, [ci]),
+            "spangpu_shard_info": (ci, [vp, ci, vp]), "spangpu_echo_shard_info": (ci, [vp, ci, vp]), "spangpu_modem_shard_info": (ci, [vp, ci, vp]),
             "spangpu_shard_create": (ci, [C.POINTER(vp), vp, ci, ci, ci, ci, vp, C.c_size_t]),
             "spangpu_shard_destroy": (ci, [vp]),
             "spangpu_shard_count": (ci, [vp]),
@@ -381,6 +383,10 @@ class ToneBank:
 
     def set_stream(self, hip_stream):
         _check(lib().spangpu_bank_set_stream(self.h, hip_stream))
+
+    def get_stream(self):
+        """the hipStream_t the bank launches on, as an integer"""
+        return lib().spangpu_bank_get_stream(self.h) or 0
 
     def set_queues(self, queues):
         """Queue mode (spangpu_bank_set_queues): 2 = the streaming kernel's launch cut in two on two hardware queues, 1 = one
@@ -809,6 +815,10 @@ class ShardedToneBank:
         except Exception:
             pass
 
+    def info(self, i):
+        """where shard i sits and how its bytes reach the collecting device (LINK_SAME / LINK_PEER / LINK_STAGED)"""
+        return shard_info("spangpu_shard", self.h, i)
+
     def rx_device(self, ptrs, samples, stride):
         """ptrs[i]: device address of shard i's rows (on shard i's device); queues the step, returns blocks per channel."""
         arr = (C.c_void_p*len(ptrs))(*ptrs)
@@ -824,9 +834,32 @@ class ShardedToneBank:
         _check(lib().spangpu_shard_sync(self.h))
 
 
+LINK_SAME, LINK_PEER, LINK_STAGED = 0, 1, 2
+
+
+class ShardInfo(C.Structure):
+    _fields_ = [("device", C.c_int), ("first_channel", C.c_int), ("n_channels", C.c_int), ("collect_device", C.c_int), ("link", C.c_int),
+                ("forced_peer_copy", C.c_int)]
+
+
+def tune_force_peer_copy(on):
+    """Debug knob: shards on the collecting device send their results with hipMemcpyPeerAsync too.  Returns the previous setting."""
+    return lib().spangpu_tune_force_peer_copy(int(on))
+
+
+def shard_info(prefix, handle, i):
+    info = ShardInfo()
+    _check(getattr(lib(), prefix + "_info")(handle, i, C.byref(info)))
+    return info
+
+
 class _Sharded:
     """Common to the sharded echo and modem objects: the ranges, close()."""
     _prefix = ""
+
+    def info(self, i):
+        """where shard i sits and how its results reach the collecting device (LINK_SAME / LINK_PEER / LINK_STAGED)"""
+        return shard_info(self._prefix, self.h, i)
 
     def _ranges(self):
         self.ranges = []
@@ -1053,6 +1086,10 @@ class EchoBank:
     def set_stream(self, hip_stream):
         _check(lib().spangpu_echo_set_stream(self.h, hip_stream))
 
+    def get_stream(self):
+        """the hipStream_t the bank launches on, as an integer"""
+        return lib().spangpu_echo_get_stream(self.h) or 0
+
     def sync(self):
         _check(lib().spangpu_echo_sync(self.h))
 
@@ -1165,6 +1202,10 @@ class ModemBank:
 
     def set_stream(self, hip_stream):
         _check(lib().spangpu_modem_set_stream(self.h, hip_stream))
+
+    def get_stream(self):
+        """the hipStream_t the bank launches on, as an integer"""
+        return lib().spangpu_modem_get_stream(self.h) or 0
 
     def sync(self):
         _check(lib().spangpu_modem_sync(self.h))

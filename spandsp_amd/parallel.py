@@ -10,6 +10,26 @@ import torch
 import torch.distributed as dist
 
 
+def require_current_stream(bank, tensor):
+    """The ordering contract of every gather below, checked: a collective started with async_op=True is ordered behind what the
+    CURRENT torch stream of the tensor's device holds at that moment -- not behind a bank that launches on some other stream.
+    So the bank whose results are about to travel must launch on the current stream (bank.set_stream(current_stream), as
+    bench.py does), or the caller must have synchronised the bank itself (BitsGather does: bank.sync()).  Raises if neither
+    the bank's stream is the current one nor `tensor` is host memory (gloo: the calls are synchronous there)."""
+    if not tensor.is_cuda:
+        return
+    get = getattr(bank, "get_stream", None)
+    if get is None:
+        return
+    cur = torch.cuda.current_stream(tensor.device).cuda_stream
+    mine = get()
+    mine = getattr(mine, "value", mine) or 0
+    if int(mine) != int(cur):
+        raise RuntimeError("gather started while the bank launches on stream 0x%x and the current torch stream is 0x%x: the collective would "
+                           "not wait for the bank's kernel (bank.set_stream(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), or "
+                           "run the gather inside `with torch.cuda.stream(...)` of the bank's stream)" % (int(mine), int(cur)))
+
+
 def shard_range(total_channels, world, rank):
     """Contiguous [lo, hi) channel range of `rank`; sizes differ by at most one."""
     base, extra = divmod(total_channels, world)
@@ -72,6 +92,7 @@ class ResultGather:
         if sub == self.every - 1:
             if hasattr(bank, "join"):
                 bank.join()             # a bank in queue mode: its second stream's launches are behind the collective too
+            require_current_stream(bank, self.send[slot])
             self._start(slot)
 
     def drain(self):
@@ -122,6 +143,7 @@ class DigitGather(ResultGather):
         if sub == self.every - 1:
             if hasattr(bank, "join"):
                 bank.join()             # a bank in queue mode: its second stream's launches are behind the collective too
+            require_current_stream(bank, self.send[slot])
             self._start(slot)
 
     def digits(self):
@@ -147,7 +169,10 @@ class FloatGather:
         self.recv = [torch.zeros(n_ch, dtype=torch.float32, device=device) for _ in range(world)] if rank == 0 else None
         self.handle = None
 
-    def gather(self):
+    def gather(self, bank=None):
+        """bank: the producer of `send` (its stream must be the current one: require_current_stream())"""
+        if bank is not None:
+            require_current_stream(bank, self.send)
         self.handle = dist.gather(self.send, gather_list=self.recv, dst=0, async_op=True)
         return self.handle
 

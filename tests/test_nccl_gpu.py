@@ -153,3 +153,44 @@ def test_bits_gather_of_a_v29_bank(built, nccl_world1):
     assert np.array_equal(np.concatenate(got_ev), g0["events"][:sum(len(e) for e in got_ev)])
     assert sum(len(e) for e in got_ev) > 1500
     bank.close()
+
+
+def test_a_gather_refuses_a_bank_on_another_stream(built, nccl_world1):
+    """The ordering contract of spandsp_amd/parallel.py, enforced: a collective is ordered behind the CURRENT torch stream, so a
+    bank that launches on a stream of its own (what a fresh bank does) must not have its results gathered -- the gather would
+    read a frame the kernel is still writing.  It raises; with the bank on the current stream it goes through."""
+    import torch
+    from spandsp_amd import engine
+    from spandsp_amd.parallel import FloatGather, ResultGather, require_current_stream
+    dev = nccl_world1
+    n_ch = 512
+    sig, _ = synth.dtmf_channels(n_ch, 160, seed=78)
+    frame = torch.tensor(sig, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    bank = engine.ToneBank(engine.DTMF, n_ch)               # its own stream
+    assert bank.get_stream() != stream.cuda_stream
+    g = ResultGather(1, 0, n_ch, 2, dev, every=1)
+    g.aim(bank)
+    bank.rx_device(ctypes.c_void_p(frame.data_ptr()), 160, 160)
+    with pytest.raises(RuntimeError, match="current torch stream"):
+        g.submit(bank)
+    bank.sync()
+    bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    assert bank.get_stream() == stream.cuda_stream
+    g2 = ResultGather(1, 0, n_ch, 2, dev, every=1)
+    g2.aim(bank)
+    bank.rx_device(ctypes.c_void_p(frame.data_ptr()), 160, 160)
+    g2.submit(bank)
+    g2.drain()
+    assert g2.latest() is not None
+    require_current_stream(bank, torch.zeros(4))            # host tensors (gloo): nothing to check
+    ec = engine.EchoBank(64, 128, 1)
+    fg = FloatGather(1, 0, 64, dev)
+    with pytest.raises(RuntimeError):
+        fg.gather(ec)
+    ec.set_stream(ctypes.c_void_p(stream.cuda_stream))
+    fg.gather(ec)
+    fg.result()
+    bank.close()
+    ec.close()

@@ -119,7 +119,7 @@ def test_by_name_through_the_opt_in_library(built):
             assert np.array_equal(prims2.nan_canon(by_name.vec_lms(x, y, d["verr_%d" % n][:k])), prims2.nan_canon(other.vec_lms(x, y, d["verr_%d" % n][:k])))
             assert np.array_equal(prims2.nan_canon(by_name.cvec_dot(cx, cy)), prims2.nan_canon(other.cvec_dot(cx, cy)))
             assert np.array_equal(prims2.nan_canon(by_name.cvec_lms(cx, cy, d["cerr_%d" % n][:k])), prims2.nan_canon(other.cvec_lms(cx, cy, d["cerr_%d" % n][:k])))
-        xs = d["sqrt_x"][::40000]
+        xs = np.ascontiguousarray(d["sqrt_x"][::40000])
         assert np.array_equal(np.array([lib.fixed_sqrt32(int(v)) for v in xs], np.uint16), other.sqrt32(xs))
         ph = d["dds_phase"][::500].copy()
         want, _ = other.dds(ph.copy(), np.zeros(len(ph), np.int32), 1)

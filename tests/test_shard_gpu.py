@@ -10,8 +10,32 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[0, 1], ids=["plain copies", "hipMemcpyPeerAsync forced"], autouse=True)
+def peer_copy(request, built):
+    """Every test of this file twice: as a one-GPU box runs it (a shard on the collecting device copies with hipMemcpyAsync), and
+    with spangpu_tune_force_peer_copy(1): the same shards send their results with hipMemcpyPeerAsync, source and destination
+    device equal -- the code path a second GPU takes (csrc/shard_api.hip gather_copy())."""
+    from spandsp_amd import engine
+    engine.tune_force_peer_copy(request.param)
+    yield request.param
+    assert engine.tune_force_peer_copy(0) == request.param
+
+
+def check_info(sh, shards, peer_copy):
+    from spandsp_amd import engine
+    at = 0
+    for i in range(shards):
+        info = sh.info(i)
+        assert (info.device, info.collect_device, info.link) == (0, 0, engine.LINK_SAME)
+        assert info.first_channel == at and info.forced_peer_copy == peer_copy
+        at += info.n_channels
+    with pytest.raises(engine.SpanGpuError):
+        sh.info(shards)
+    return at
+
+
 @pytest.mark.parametrize("shards", [2, 5])
-def test_sharded_bank_equals_one_bank(built, shards):
+def test_sharded_bank_equals_one_bank(built, shards, peer_copy):
     import ctypes
     from oracle import restated as orc
     from spandsp_amd import engine
@@ -20,6 +44,7 @@ def test_sharded_bank_equals_one_bank(built, shards):
     one = engine.ToneBank(engine.DTMF, n_ch)
     sh = engine.ShardedToneBank(engine.DTMF, n_ch, [0]*shards, max_samples=frame)
     assert sh.shards == shards and sh.ranges[0][1] == 0 and sum(r[2] for r in sh.ranges) == n_ch
+    assert check_info(sh, shards, peer_copy) == n_ch
     assert all(sh.ranges[i][1] + sh.ranges[i][2] == sh.ranges[i + 1][1] for i in range(shards - 1))
     hip = ctypes.CDLL("libamdhip64.so")
     hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
@@ -82,7 +107,7 @@ def _hip():
 
 
 @pytest.mark.parametrize("shards", [2, 3])
-def test_sharded_echo_bank_equals_one_bank(built, shards):
+def test_sharded_echo_bank_equals_one_bank(built, shards, peer_copy):
     """spangpu_echo_shard_* (BASELINE configs[4]'s object behind the C ABI) with a one-GPU box's device named two and three
     times: every clean sample and every gathered ERLE float equal those of a single bank fed the same lines (itself held to the
     oracle in test_echo_gpu.py), the ERLE of a sample of lines also against the oracle's clean samples, and a report stays whole
@@ -97,6 +122,7 @@ def test_sharded_echo_bank_equals_one_bank(built, shards):
     one.stats(2)
     sh = engine.ShardedEchoBank(n_ch, taps, mode, [0]*shards)
     assert sh.shards == shards and sum(r[2] for r in sh.ranges) == n_ch and sh.ranges[0][1] == 0
+    assert check_info(sh, shards, peer_copy) == n_ch
     bufs = [(dev_alloc(n*frame*2), dev_alloc(n*frame*2), dev_alloc(n*frame*2)) for _, _, n in sh.ranges]
     dets = {c: orc.EchoCan(taps, mode) for c in (0, 63, 64, 333, n_ch - 1)}
     sums = {c: [0, 0] for c in dets}
@@ -157,6 +183,7 @@ def test_sharded_modem_bank_equals_one_bank(built):
     n_ch, frame, per = 200, 160, 256            # (a put_bit call per bit: 192 a frame at 9600 bit/s, and the status reports)
     sh = engine.ShardedModemBank(engine.V29, n_ch, 9600, [0, 0, 0], per=per)
     assert sh.shards == 3 and sum(r[2] for r in sh.ranges) == n_ch
+    assert sum(sh.info(i).n_channels for i in range(3)) == n_ch and sh.info(2).link == engine.LINK_SAME
     bufs = [dev_alloc(n*frame*2) for _, _, n in sh.ranges]
     streams = [[] for _ in range(n_ch)]
     for k in range(0, len(x) - frame + 1, frame):
