@@ -271,6 +271,46 @@ def large_banks(engine, dev, local_rank, frames, stream):
     return out
 
 
+def frames_per_launch(engine, dev, local_rank, frames, stream):
+    """Not the headline (which is one 160-sample frame per launch, a 20 ms tick): the same bank given two and three frames per
+    launch -- a 40 / 60 ms jitter buffer in front of the detector --, which spreads the launch's fixed cost (launch boundary,
+    first burst, state in and out, block ends: DESIGN 4.1) over more samples.  Results are those of one frame at a time (any
+    call length is the same detector: tests/test_tone_gpu.py runs ragged lengths).  Per launch length: microseconds per
+    launch and per frame, and the roofline fraction both on SURVEY 8(d)'s 400 B per channel and frame and on the bytes such a
+    launch actually owes (k x 320 B of PCM + 80 B of state once)."""
+    out = {}
+    n_ch = frames.shape[1]
+    for k in (1, 2, 3):
+        try:
+            sets = max(2, min(6, frames.shape[0]//k))
+            rows = torch.stack([torch.cat([frames[s*k + j] for j in range(k)], dim=1) for s in range(sets)]).contiguous()   # [set][ch][k*160]
+            bank = engine.ToneBank(engine.DTMF, n_ch, device=local_rank)
+            bank.set_stream(ctypes.c_void_p(stream.cuda_stream))
+            rb = n_ch*k*FRAME*2
+            for i in range(20):
+                bank.rx_device(ctypes.c_void_p(rows.data_ptr() + (i % sets)*rb), k*FRAME, k*FRAME)
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            n = 600
+            e0.record(stream)
+            for i in range(n):
+                bank.rx_device(ctypes.c_void_p(rows.data_ptr() + (i % sets)*rb), k*FRAME, k*FRAME)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1)*1e3/n
+            out[str(k)] = {"us_per_launch": us, "us_per_frame": us/k,
+                           "roofline_frac_on_contract_bytes": n_ch*k*ALG_READ_BYTES/(us*1e-6)/1e9/HBM_PEAK_GBPS,
+                           "roofline_frac_on_bytes_owed": n_ch*(k*FRAME*2 + 80)/(us*1e-6)/1e9/HBM_PEAK_GBPS,
+                           "buffered_ms": 20*k}
+            bank.close()
+            del rows
+        except Exception as e:                      # never takes the headline line with it
+            out[str(k)] = {"error": repr(e)}
+    torch.cuda.empty_cache()
+    return out
+
+
 def run_echo(args, engine, dev, local_rank, rank, world):
     """BASELINE configs[4]: the G.168 canceller (echo.c, 128 taps, ECHO_CAN_USE_ADAPTION) on 131 072 channels per GPU,
     channels sharded over the ranks with no data-path collective; once per second of signal (50 steps) every rank turns
@@ -626,8 +666,10 @@ def main():
         e2e_g711 = end_to_end(engine, n_ch, codes_of[torch.where(lower, posn - 1, posn)].contiguous(), local_rank, 60, law=2)
 
     large = None
+    fpl = None
     if rank == 0 and world == 1 and not args.no_paths and not law and n_ch == 65536:
         large = large_banks(engine, dev, local_rank, frames, stream)
+        fpl = frames_per_launch(engine, dev, local_rank, frames, stream)
     paths = None
     if rank == 0 and world == 1 and not args.no_paths and not law:
         # BASELINE configs[2], [3], [4] under the same clock as the headline (tools/bench_paths.py: paths_for_bench)
@@ -675,6 +717,7 @@ def main():
             "e2e_g711": e2e_g711,
             "paths": paths,
             "large_bank": large,
+            "frames_per_launch": fpl,
         }
         print(json.dumps(line))
     if world > 1 or force_gather:

@@ -162,7 +162,8 @@ SPANGPU_API void *spangpu_bank_get_stream(spangpu_bank_t *bank);
 /* Queue mode.  queues = 2: every launch the streaming kernel serves is cut in two ranges of channels, the second on a stream
    (hardware queue) the bank owns, so that one half's launch boundary, start burst and write-back lie under the other half's
    steady state; 1: one launch on the bank's stream (the default); 0: the library's choice (two from 131 072 channels: that is
-   where it pays, profiles/r5_probe_mq.log).  Returns the number of queues now in use, or a negative error.  Results are those
+   where it pays, profiles/r5_probe_mq.log -- but only for a bank on its own stream: on a caller's stream the library cannot
+   see what produces the frames, and chooses one).  Returns the number of queues now in use, or a negative error.  Results are those
    of one launch, bit for bit.  Ordering: consecutive spangpu_bank_rx*() calls with nothing else between them run the two
    queues free of each other (no event per tick: that is the gain) -- so in queue mode a device-resident frame must be complete
    when the call is made, or have been put on the bank's stream before the last spangpu_bank_get_stream() / _join().  Every

@@ -50,6 +50,7 @@ struct spangpu_echo_s
     float *d_erle;          // scratch for spangpu_echo_erle() with a host destination
     int uniform_mode;       // the adaption mode every channel has, or -1 when they differ: picks the kernel compiled for that mode
     bool mode_dirty;        // a single channel's mode was written since the channels were last compared: they may all agree again
+    int *d_span;            // two ints of device scratch for that comparison (made with the bank: nothing is allocated or freed in the update path)
 };
 
 __global__ void echo_set_scalar_kernel(int32_t *scal, int lo, int hi, int idx, int value)
@@ -77,21 +78,23 @@ __global__ void echo_mode_span_kernel(const int32_t *scal, int n_ch, int *out)
 static void refresh_uniform_mode(spangpu_echo_t *e)
 {
     e->mode_dirty = false;
-    if (e->uniform_mode >= 0)
+    if (e->uniform_mode >= 0  ||  e->d_span == nullptr)
         return;
-    int *d = nullptr;
     int h[2] = {0x7FFFFFFF, (int) 0x80000000};
-    if (hipMalloc((void **) &d, sizeof(h)) != hipSuccess)
-        return;
-    if (hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, e->stream) == hipSuccess)
+    if (hipMemcpyAsync(e->d_span, h, sizeof(h), hipMemcpyHostToDevice, e->stream) == hipSuccess)
     {
-        hipLaunchKernelGGL(echo_mode_span_kernel, dim3((e->n_ch + 255)/256), dim3(256), 0, e->stream, (const int32_t *) e->scal, e->n_ch, d);
-        if (hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, e->stream) == hipSuccess
+        hipLaunchKernelGGL(echo_mode_span_kernel, dim3((e->n_ch + 255)/256), dim3(256), 0, e->stream, (const int32_t *) e->scal, e->n_ch, e->d_span);
+        if (hipMemcpyAsync(h, e->d_span, sizeof(h), hipMemcpyDeviceToHost, e->stream) == hipSuccess
             &&  hipStreamSynchronize(e->stream) == hipSuccess  &&  h[0] == h[1])
             e->uniform_mode = h[0];
+        else if (h[0] > h[1])
+            e->mode_dirty = true;       // the comparison did not run (a HIP error): the general kernel stays, and the next update looks again
+    }
+    else
+    {
+        e->mode_dirty = true;
     }
     (void) hipGetLastError();
-    (void) hipFree(d);
 }
 
 static void init_scalars(int32_t *s, int taps, int mode)
@@ -179,7 +182,8 @@ int spangpu_echo_create(spangpu_echo_t **out, int device, int n_channels, int ta
     if (hipMalloc(&e->scal, n*kEchoScalars*sizeof(int32_t)) != hipSuccess
         ||  hipMalloc(&e->taps32, n*taps*sizeof(int32_t)) != hipSuccess
         ||  hipMalloc(&e->taps16, n*4*taps*sizeof(int16_t)) != hipSuccess
-        ||  hipMalloc(&e->hist, n*taps*sizeof(int16_t)) != hipSuccess)
+        ||  hipMalloc(&e->hist, n*taps*sizeof(int16_t)) != hipSuccess
+        ||  hipMalloc((void **) &e->d_span, 2*sizeof(int)) != hipSuccess)
     {
         spangpu_echo_destroy(e);
         return spangpu_set_error(SPANGPU_ERR_NO_MEMORY, "hipMalloc of echo state failed");
@@ -222,6 +226,7 @@ int spangpu_echo_destroy(spangpu_echo_t *e)
     if (e->d_io) (void) hipFree(e->d_io);
     if (e->stats) (void) hipFree(e->stats);
     if (e->d_erle) (void) hipFree(e->d_erle);
+    if (e->d_span) (void) hipFree(e->d_span);
     if (e->own_stream  &&  e->stream)
         (void) hipStreamDestroy(e->stream);
     free(e);

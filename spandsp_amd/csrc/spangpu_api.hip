@@ -871,8 +871,14 @@ int spangpu_bank_set_queues(spangpu_bank_t *b, int queues)
     if (b == nullptr  ||  queues < 0  ||  queues > 2)
         return fail(SPANGPU_ERR_BAD_ARG, "queues must be 0 (the library's choice), 1 or 2");
     HIP_TRY(hipSetDevice(b->device));
+    // The library's own choice is two queues only for a bank on its OWN stream: there every frame reaches the bank through this
+    // library (the host copy, or a device frame that is complete when the call is made), and the second queue's ordering is the
+    // library's business.  On a caller's stream (spangpu_bank_set_stream) frames may be produced by the caller's kernels on
+    // that stream between two ticks, which the second queue would not wait for -- half the channels would read a frame still
+    // being written.  A caller who asks for two queues explicitly takes the contract of include/spangpu.h (frames complete at
+    // the call, or spangpu_bank_join() / _get_stream() behind whatever made them) with it.
     if (queues == 0)
-        queues = (b->n_ch >= 131072)  ?  2  :  1;
+        queues = (b->n_ch >= 131072  &&  b->own_stream)  ?  2  :  1;
     (void) joined(b);
     if (queues == 2  &&  b->stream2 == nullptr)
     {
