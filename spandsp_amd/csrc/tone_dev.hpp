@@ -148,14 +148,17 @@ struct Bank
         for (int i = 0;  i < NP;  i++)
         {
             f32x2 t;
+#if defined(SPG_TONE_FMA)
+#define SPG_STEP1 "v_pk_fma_f32 %0, %2, %3, %1 neg_lo:[0,0,1] neg_hi:[0,0,1]\n\ts_nop 0\n\tv_pk_add_f32 %1, %0, %4 op_sel_hi:[1,0]"
+#else
+#define SPG_STEP1 "v_pk_mul_f32 %0, %2, %3\n\ts_nop 0\n\tv_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\t" \
+                  "v_pk_add_f32 %1, %0, %4 op_sel_hi:[1,0]"
+#endif
             if constexpr (FACS)
-                asm("v_pk_mul_f32 %0, %2, %3\n\ts_nop 0\n\tv_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\t"
-                    "v_pk_add_f32 %1, %0, %4 op_sel_hi:[1,0]"
-                    : "=&v"(t), "+v"(a[i]) : "s"(fac[i]), "v"(b[i]), "v"(xx));
+                asm(SPG_STEP1 : "=&v"(t), "+v"(a[i]) : "s"(fac[i]), "v"(b[i]), "v"(xx));
             else
-                asm("v_pk_mul_f32 %0, %2, %3\n\ts_nop 0\n\tv_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\ts_nop 0\n\t"
-                    "v_pk_add_f32 %1, %0, %4 op_sel_hi:[1,0]"
-                    : "=&v"(t), "+v"(a[i]) : "v"(fac[i]), "v"(b[i]), "v"(xx));
+                asm(SPG_STEP1 : "=&v"(t), "+v"(a[i]) : "v"(fac[i]), "v"(b[i]), "v"(xx));
+#undef SPG_STEP1
             const f32x2 v3 = a[i];
             a[i] = b[i];
             b[i] = v3;
@@ -167,6 +170,38 @@ struct Bank
 #define SPG_C_ADDL(d, t, x)     "v_pk_add_f32 %" #d ", %" #t ", %" #x " op_sel_hi:[1,0]\n\t"
 #define SPG_C_ADDH(d, t, x)     "v_pk_add_f32 %" #d ", %" #t ", %" #x " op_sel:[0,1] op_sel_hi:[1,1]\n\t"
 #define SPG_C_GAP               "s_nop 0\n\t"
+#if !defined(SPG_TONE_FMA)
+#define SPG_CHAIN_G1 SPG_C_MUL(2, 3, 1) SPG_C_GAP SPG_C_SUB(2, 0) SPG_C_GAP SPG_C_ADDL(0, 2, 4) SPG_C_GAP \
+                     SPG_C_MUL(2, 3, 0) SPG_C_GAP SPG_C_SUB(2, 1) SPG_C_GAP SPG_C_ADDH(1, 2, 4)
+#define SPG_CHAIN_G2 SPG_C_MUL(4, 6, 2) SPG_C_MUL(5, 7, 3) SPG_C_SUB(4, 0) SPG_C_SUB(5, 1) SPG_C_ADDL(0, 4, 8) SPG_C_ADDL(1, 5, 8) \
+                     SPG_C_MUL(4, 6, 0) SPG_C_MUL(5, 7, 1) SPG_C_SUB(4, 2) SPG_C_SUB(5, 3) SPG_C_ADDH(2, 4, 8) SPG_C_ADDH(3, 5, 8)
+#define SPG_CHAIN_G3 SPG_C_MUL(6, 9, 3) SPG_C_MUL(7, 10, 4) SPG_C_MUL(8, 11, 5) SPG_C_SUB(6, 0) SPG_C_SUB(7, 1) SPG_C_SUB(8, 2) \
+                     SPG_C_ADDL(0, 6, 12) SPG_C_ADDL(1, 7, 12) SPG_C_ADDL(2, 8, 12) \
+                     SPG_C_MUL(6, 9, 0) SPG_C_MUL(7, 10, 1) SPG_C_MUL(8, 11, 2) SPG_C_SUB(6, 3) SPG_C_SUB(7, 4) SPG_C_SUB(8, 5) \
+                     SPG_C_ADDH(3, 6, 12) SPG_C_ADDH(4, 7, 12) SPG_C_ADDH(5, 8, 12)
+#define SPG_CHAIN_G4 SPG_C_MUL(8, 12, 4) SPG_C_MUL(9, 13, 5) SPG_C_MUL(10, 14, 6) SPG_C_MUL(11, 15, 7) \
+                     SPG_C_SUB(8, 0) SPG_C_SUB(9, 1) SPG_C_SUB(10, 2) SPG_C_SUB(11, 3) \
+                     SPG_C_ADDL(0, 8, 16) SPG_C_ADDL(1, 9, 16) SPG_C_ADDL(2, 10, 16) SPG_C_ADDL(3, 11, 16) \
+                     SPG_C_MUL(8, 12, 0) SPG_C_MUL(9, 13, 1) SPG_C_MUL(10, 14, 2) SPG_C_MUL(11, 15, 3) \
+                     SPG_C_SUB(8, 4) SPG_C_SUB(9, 5) SPG_C_SUB(10, 6) SPG_C_SUB(11, 7) \
+                     SPG_C_ADDH(4, 8, 16) SPG_C_ADDH(5, 9, 16) SPG_C_ADDH(6, 10, 16) SPG_C_ADDH(7, 11, 16)
+#else
+    // -DSPG_TONE_FMA: the experiment of round 6 (a BUILD variant, tools/build_variant.sh fma worktree
+    // EXTRA=-DSPG_TONE_FMA): fac*v2 - v1 as one v_pk_fma_f32 -- one rounding where the reference has two, so the energies are
+    // no longer the reference's to the bit (decisions and digits stay: tools/fma_check.py, profiles/r6_tone_fma.log)
+#define SPG_C_FMA(t, f, s, a)   "v_pk_fma_f32 %" #t ", %" #f ", %" #s ", %" #a " neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+#define SPG_CHAIN_G1 SPG_C_FMA(2, 3, 1, 0) SPG_C_GAP SPG_C_ADDL(0, 2, 4) SPG_C_GAP SPG_C_FMA(2, 3, 0, 1) SPG_C_GAP SPG_C_ADDH(1, 2, 4)
+#define SPG_CHAIN_G2 SPG_C_FMA(4, 6, 2, 0) SPG_C_FMA(5, 7, 3, 1) SPG_C_ADDL(0, 4, 8) SPG_C_ADDL(1, 5, 8) \
+                     SPG_C_FMA(4, 6, 0, 2) SPG_C_FMA(5, 7, 1, 3) SPG_C_ADDH(2, 4, 8) SPG_C_ADDH(3, 5, 8)
+#define SPG_CHAIN_G3 SPG_C_FMA(6, 9, 3, 0) SPG_C_FMA(7, 10, 4, 1) SPG_C_FMA(8, 11, 5, 2) \
+                     SPG_C_ADDL(0, 6, 12) SPG_C_ADDL(1, 7, 12) SPG_C_ADDL(2, 8, 12) \
+                     SPG_C_FMA(6, 9, 0, 3) SPG_C_FMA(7, 10, 1, 4) SPG_C_FMA(8, 11, 2, 5) \
+                     SPG_C_ADDH(3, 6, 12) SPG_C_ADDH(4, 7, 12) SPG_C_ADDH(5, 8, 12)
+#define SPG_CHAIN_G4 SPG_C_FMA(8, 12, 4, 0) SPG_C_FMA(9, 13, 5, 1) SPG_C_FMA(10, 14, 6, 2) SPG_C_FMA(11, 15, 7, 3) \
+                     SPG_C_ADDL(0, 8, 16) SPG_C_ADDL(1, 9, 16) SPG_C_ADDL(2, 10, 16) SPG_C_ADDL(3, 11, 16) \
+                     SPG_C_FMA(8, 12, 0, 4) SPG_C_FMA(9, 13, 1, 5) SPG_C_FMA(10, 14, 2, 6) SPG_C_FMA(11, 15, 3, 7) \
+                     SPG_C_ADDH(4, 8, 16) SPG_C_ADDH(5, 9, 16) SPG_C_ADDH(6, 10, 16) SPG_C_ADDH(7, 11, 16)
+#endif
     // G bin pairs starting at pair O.  Dependent packed ops are G instructions apart; for G = 1 they are adjacent
     // and need the one wait state hipcc would put there.
     template <bool FACS, int O, int G>
@@ -180,25 +215,21 @@ struct Bank
         if constexpr (G == 1)
         {
             if constexpr (FACS)
-                asm(SPG_C_MUL(2, 3, 1) SPG_C_GAP SPG_C_SUB(2, 0) SPG_C_GAP SPG_C_ADDL(0, 2, 4) SPG_C_GAP
-                    SPG_C_MUL(2, 3, 0) SPG_C_GAP SPG_C_SUB(2, 1) SPG_C_GAP SPG_C_ADDH(1, 2, 4)
+                asm(SPG_CHAIN_G1
                     : "+v"(a[O]), "+v"(b[O]), "=&v"(t0) : "s"(fac[O]), "v"(x));
             else
-                asm(SPG_C_MUL(2, 3, 1) SPG_C_GAP SPG_C_SUB(2, 0) SPG_C_GAP SPG_C_ADDL(0, 2, 4) SPG_C_GAP
-                    SPG_C_MUL(2, 3, 0) SPG_C_GAP SPG_C_SUB(2, 1) SPG_C_GAP SPG_C_ADDH(1, 2, 4)
+                asm(SPG_CHAIN_G1
                     : "+v"(a[O]), "+v"(b[O]), "=&v"(t0) : "v"(fac[O]), "v"(x));
         }
         else if constexpr (G == 2)
         {
             constexpr int P = O;
             if constexpr (FACS)
-                asm(SPG_C_MUL(4, 6, 2) SPG_C_MUL(5, 7, 3) SPG_C_SUB(4, 0) SPG_C_SUB(5, 1) SPG_C_ADDL(0, 4, 8) SPG_C_ADDL(1, 5, 8)
-                    SPG_C_MUL(4, 6, 0) SPG_C_MUL(5, 7, 1) SPG_C_SUB(4, 2) SPG_C_SUB(5, 3) SPG_C_ADDH(2, 4, 8) SPG_C_ADDH(3, 5, 8)
+                asm(SPG_CHAIN_G2
                     : "+v"(a[P]), "+v"(a[P + 1]), "+v"(b[P]), "+v"(b[P + 1]), "=&v"(t0), "=&v"(t1)
                     : "s"(fac[P]), "s"(fac[P + 1]), "v"(x));
             else
-                asm(SPG_C_MUL(4, 6, 2) SPG_C_MUL(5, 7, 3) SPG_C_SUB(4, 0) SPG_C_SUB(5, 1) SPG_C_ADDL(0, 4, 8) SPG_C_ADDL(1, 5, 8)
-                    SPG_C_MUL(4, 6, 0) SPG_C_MUL(5, 7, 1) SPG_C_SUB(4, 2) SPG_C_SUB(5, 3) SPG_C_ADDH(2, 4, 8) SPG_C_ADDH(3, 5, 8)
+                asm(SPG_CHAIN_G2
                     : "+v"(a[P]), "+v"(a[P + 1]), "+v"(b[P]), "+v"(b[P + 1]), "=&v"(t0), "=&v"(t1)
                     : "v"(fac[P]), "v"(fac[P + 1]), "v"(x));
         }
@@ -206,18 +237,12 @@ struct Bank
         {
             constexpr int P = O;
             if constexpr (FACS)
-                asm(SPG_C_MUL(6, 9, 3) SPG_C_MUL(7, 10, 4) SPG_C_MUL(8, 11, 5) SPG_C_SUB(6, 0) SPG_C_SUB(7, 1) SPG_C_SUB(8, 2)
-                    SPG_C_ADDL(0, 6, 12) SPG_C_ADDL(1, 7, 12) SPG_C_ADDL(2, 8, 12)
-                    SPG_C_MUL(6, 9, 0) SPG_C_MUL(7, 10, 1) SPG_C_MUL(8, 11, 2) SPG_C_SUB(6, 3) SPG_C_SUB(7, 4) SPG_C_SUB(8, 5)
-                    SPG_C_ADDH(3, 6, 12) SPG_C_ADDH(4, 7, 12) SPG_C_ADDH(5, 8, 12)
+                asm(SPG_CHAIN_G3
                     : "+v"(a[P]), "+v"(a[P + 1]), "+v"(a[P + 2]), "+v"(b[P]), "+v"(b[P + 1]), "+v"(b[P + 2]),
                       "=&v"(t0), "=&v"(t1), "=&v"(t2)
                     : "s"(fac[P]), "s"(fac[P + 1]), "s"(fac[P + 2]), "v"(x));
             else
-                asm(SPG_C_MUL(6, 9, 3) SPG_C_MUL(7, 10, 4) SPG_C_MUL(8, 11, 5) SPG_C_SUB(6, 0) SPG_C_SUB(7, 1) SPG_C_SUB(8, 2)
-                    SPG_C_ADDL(0, 6, 12) SPG_C_ADDL(1, 7, 12) SPG_C_ADDL(2, 8, 12)
-                    SPG_C_MUL(6, 9, 0) SPG_C_MUL(7, 10, 1) SPG_C_MUL(8, 11, 2) SPG_C_SUB(6, 3) SPG_C_SUB(7, 4) SPG_C_SUB(8, 5)
-                    SPG_C_ADDH(3, 6, 12) SPG_C_ADDH(4, 7, 12) SPG_C_ADDH(5, 8, 12)
+                asm(SPG_CHAIN_G3
                     : "+v"(a[P]), "+v"(a[P + 1]), "+v"(a[P + 2]), "+v"(b[P]), "+v"(b[P + 1]), "+v"(b[P + 2]),
                       "=&v"(t0), "=&v"(t1), "=&v"(t2)
                     : "v"(fac[P]), "v"(fac[P + 1]), "v"(fac[P + 2]), "v"(x));
@@ -226,23 +251,13 @@ struct Bank
         {
             constexpr int P = O;
             if constexpr (FACS)
-                asm(SPG_C_MUL(8, 12, 4) SPG_C_MUL(9, 13, 5) SPG_C_MUL(10, 14, 6) SPG_C_MUL(11, 15, 7)
-                    SPG_C_SUB(8, 0) SPG_C_SUB(9, 1) SPG_C_SUB(10, 2) SPG_C_SUB(11, 3)
-                    SPG_C_ADDL(0, 8, 16) SPG_C_ADDL(1, 9, 16) SPG_C_ADDL(2, 10, 16) SPG_C_ADDL(3, 11, 16)
-                    SPG_C_MUL(8, 12, 0) SPG_C_MUL(9, 13, 1) SPG_C_MUL(10, 14, 2) SPG_C_MUL(11, 15, 3)
-                    SPG_C_SUB(8, 4) SPG_C_SUB(9, 5) SPG_C_SUB(10, 6) SPG_C_SUB(11, 7)
-                    SPG_C_ADDH(4, 8, 16) SPG_C_ADDH(5, 9, 16) SPG_C_ADDH(6, 10, 16) SPG_C_ADDH(7, 11, 16)
+                asm(SPG_CHAIN_G4
                     : "+v"(a[P]), "+v"(a[P + 1]), "+v"(a[P + 2]), "+v"(a[P + 3]),
                       "+v"(b[P]), "+v"(b[P + 1]), "+v"(b[P + 2]), "+v"(b[P + 3]),
                       "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
                     : "s"(fac[P]), "s"(fac[P + 1]), "s"(fac[P + 2]), "s"(fac[P + 3]), "v"(x));
             else
-                asm(SPG_C_MUL(8, 12, 4) SPG_C_MUL(9, 13, 5) SPG_C_MUL(10, 14, 6) SPG_C_MUL(11, 15, 7)
-                    SPG_C_SUB(8, 0) SPG_C_SUB(9, 1) SPG_C_SUB(10, 2) SPG_C_SUB(11, 3)
-                    SPG_C_ADDL(0, 8, 16) SPG_C_ADDL(1, 9, 16) SPG_C_ADDL(2, 10, 16) SPG_C_ADDL(3, 11, 16)
-                    SPG_C_MUL(8, 12, 0) SPG_C_MUL(9, 13, 1) SPG_C_MUL(10, 14, 2) SPG_C_MUL(11, 15, 3)
-                    SPG_C_SUB(8, 4) SPG_C_SUB(9, 5) SPG_C_SUB(10, 6) SPG_C_SUB(11, 7)
-                    SPG_C_ADDH(4, 8, 16) SPG_C_ADDH(5, 9, 16) SPG_C_ADDH(6, 10, 16) SPG_C_ADDH(7, 11, 16)
+                asm(SPG_CHAIN_G4
                     : "+v"(a[P]), "+v"(a[P + 1]), "+v"(a[P + 2]), "+v"(a[P + 3]),
                       "+v"(b[P]), "+v"(b[P + 1]), "+v"(b[P + 2]), "+v"(b[P + 3]),
                       "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
@@ -254,6 +269,13 @@ struct Bank
 #undef SPG_C_ADDL
 #undef SPG_C_ADDH
 #undef SPG_C_GAP
+#undef SPG_CHAIN_G1
+#undef SPG_CHAIN_G2
+#undef SPG_CHAIN_G3
+#undef SPG_CHAIN_G4
+#if defined(SPG_TONE_FMA)
+#undef SPG_C_FMA
+#endif
 
     // goertzel_result() for every bin: one zero sample, energy, reset (tone_detect.c:160-205)
     // Written phase by phase over all pairs (the same nine roundings per pair, in the same order:

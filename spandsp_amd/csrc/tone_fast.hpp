@@ -99,7 +99,11 @@ __device__ __forceinline__ void seg_barrier()
     asm volatile("" ::: "memory");
 }
 
+#if defined(SPG_TONE_FMA)
+#include "tone_pairs_asm_fma.inc"
+#else
 #include "tone_pairs_asm.inc"
+#endif
 
 // Sample pairs [k0, k1) of the sixteen of one row piece through the recurrence, as one asm body that is entered at pair k0
 // and left after pair k1 - 1 (tone_pairs_asm.inc, written by tools/gen_pairs_asm.py): the piece that holds a block end is

@@ -36,7 +36,7 @@ def read(k):
     return "ds_read_b32 %s, %%[ad%d] offset:%d" % (D(k), k//4, 4*(k % 4))
 
 
-def body(np_, energy):
+def body(np_, energy, fma=False):
     L = []
     a = lambda i: "%%[a%d]" % i
     b = lambda i: "%%[b%d]" % i
@@ -71,6 +71,29 @@ def body(np_, energy):
         L.append("s_waitcnt lgkmcnt(%d)" % min(3, 15 - k))
         L.append("v_cvt_f32_i32_sdwa %s, sext(%s) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" % (XL, D(k)))
         L.append("v_cvt_f32_i32_sdwa %s, sext(%s) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" % (XH, D(k)))
+        if fma:
+            # the experiment of round 6 (-DSPG_TONE_FMA, NOT bit-exact): fac*v2 - v1 as ONE v_pk_fma_f32 -- 2 packed operations
+            # per bin pair and sample in place of 3 -- then + x as before
+            L += ["v_pk_fma_f32 %s, %s, %s, %s neg_lo:[0,0,1] neg_hi:[0,0,1]" % (T(i), f(i), b(i), a(i)) for i in range(np_)]
+            if energy:
+                L.append("v_pk_mul_f32 %s, %s, %s" % (SQ, X, X))
+            if np_ == 1:
+                L.append("s_nop 0")
+            L += ["v_pk_add_f32 %s, %s, %s op_sel_hi:[1,0]" % (a(i), T(i), X) for i in range(np_)]
+            if energy:
+                L.append("v_add_f32 %%[en], %%[en], %s" % SQL)
+            if np_ == 1:
+                L.append("s_nop 0")
+            L += ["v_pk_fma_f32 %s, %s, %s, %s neg_lo:[0,0,1] neg_hi:[0,0,1]" % (T(i), f(i), a(i), b(i)) for i in range(np_)]
+            if np_ == 1:
+                L.append("s_nop 0")
+            L += ["v_pk_add_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,1]" % (b(i), T(i), X) for i in range(np_)]
+            if energy:
+                L.append("v_add_f32 %%[en], %%[en], %s" % SQH)
+            if k < 15:
+                L.append("s_cmp_eq_u32 %%[k1], %d" % (k + 1))
+                L.append("s_cbranch_scc1 Lx%=")
+            continue
         muls = ["v_pk_mul_f32 %s, %s, %s" % (T(i), f(i), b(i)) for i in range(np_)]
         if energy:
             # cvt, cvt, two products, the squares, the other products, first energy add
@@ -112,19 +135,26 @@ def body(np_, energy):
     return L
 
 
-def main():
+def write(path, fma):
     out = []
-    out.append("// tone_pairs_asm.inc -- GENERATED by tools/gen_pairs_asm.py; do not edit.  See that file and tone_fast.hpp (pairs_asm).")
+    out.append("// %s -- GENERATED by tools/gen_pairs_asm.py; do not edit.  See that file and tone_fast.hpp (pairs_asm)." % os.path.basename(path))
+    if fma:
+        out.append("// The v_pk_fma_f32 form of the recurrence (fac*v2 - v1 fused: NOT the reference's roundings): only built with -DSPG_TONE_FMA.")
     for np_ in (2, 3, 4):
         for energy in (0, 1):
             out.append("#define SPG_PAIRS_ASM_NP%d_E%d \\" % (np_, energy))
-            lines = body(np_, energy)
+            lines = body(np_, energy, fma)
             for i, l in enumerate(lines):
                 out.append('    "%s\\n\\t"%s' % (l, " \\" if i + 1 < len(lines) else ""))
     out.append('#define SPG_PAIRS_ASM_CLOBBERS "memory", "scc", ' + ", ".join('"v%d"' % r for r in range(100, 116)))
-    with open(OUT, "w") as fh:
+    with open(path, "w") as fh:
         fh.write("\n".join(out) + "\n")
-    print("wrote", os.path.normpath(OUT), len(out), "lines")
+    print("wrote", os.path.normpath(path), len(out), "lines")
+
+
+def main():
+    write(OUT, False)
+    write(OUT.replace("tone_pairs_asm.inc", "tone_pairs_asm_fma.inc"), True)
 
 
 if __name__ == "__main__":
