@@ -70,7 +70,7 @@ def add_measured(roof, device=0):
 # just timed is the hash of the kernel's sources recorded with them: sources that differ null the figure.
 _KERNEL_SOURCES = {
     "dtmf": ["tone_fast.hpp", "tone_dev.hpp", "tone_pairs_asm.inc"],
-    "mixed": ["tone_fast.hpp", "tone_dev.hpp", "tone_pairs_asm.inc"],
+    "mixed": ["tone_fast.hpp", "tone_dev.hpp", "tone_pairs_asm.inc", "cadence_dev.hpp"],
     "v29": ["v29_quad.hpp", "v29_common.hpp", "quad_round_front.inc", "quad_ctx.hpp"],
     "v17": ["v17_quad.hpp", "v17_common.hpp", "v29_common.hpp", "quad_round_front.inc", "quad_ctx.hpp"],
     "v27ter": ["v27ter_quad.hpp", "v27ter_common.hpp", "v29_common.hpp", "quad_ctx.hpp"],

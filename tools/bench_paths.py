@@ -747,7 +747,7 @@ def bench_mixed(args, dev, stream):
     reps = max(1, int(np.ceil(2000/args.steps)))
     one_launch_us = None
     other_us = None
-    if mode in ("bank_streams", "two_queues"):
+    if mode in ("bank_streams", "two_queues") and not getattr(args, "single_mode", False):
         other = "bank_streams" if mode == "two_queues" else "two_queues"
         timed(other, 200)
         other_us = timed(other, args.steps*reps)[1]/(args.steps*reps)*1e3
@@ -1432,6 +1432,7 @@ def main():
     ap.add_argument("--one-launch", action="store_true", help="mixed: time the one-launch form (the banks on one stream) instead of a launch per bank on streams of their own")
     ap.add_argument("--cpu-channels", type=int, default=16384)
     ap.add_argument("--stagger", type=int, default=None, help="v29 / v17 / v27ter: every channel's transmission starts a random number of samples (below this) late (default: 160 with --line contract, 0 with --line in_step)")
+    ap.add_argument("--single-mode", action="store_true", help="mixed: time the chosen way of running a tick only (counter passes: every kernel then has one launch a tick)")
     ap.add_argument("--three-queues", action="store_true", help="mixed: a launch per bank on three hardware queues (the default is two queues: super-tone | Bell MF + R2 MF)")
     ap.add_argument("--no-cadences", action="store_true", help="mixed: the super-tone third without its cadence matcher (the rounds-1-to-5 workload; not configs[2])")
     ap.add_argument("--line", choices=["contract", "in_step"], default="contract", help="v29 / v17 / v27ter: SURVEY 8(d)-4's lines (carrier +- 7 Hz, -30 .. -10 dBm0, SNR 25 .. 40 dB, random start) or the nominal-carrier, all-in-step workload of the earlier rounds")

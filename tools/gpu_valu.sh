@@ -11,14 +11,14 @@ for w in ${VALU_MODEMS-v29 v17 v27ter}; do
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$w -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 40 --warmup 110 --no-cpu-baseline --no-e2e > $R/$w.log 2>&1
 done
 for w in ${VALU_W:-echo mixed fsk mct sigtone supertone dtmf_tx v29_tx awgn}; do
-  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$w -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 30 --no-cpu-baseline --no-e2e --echo-seconds 2 > $R/$w.log 2>&1
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$w -- python $GRAFT_REPO_ROOT/tools/bench_paths.py --workload $w --steps 30 --no-cpu-baseline --no-e2e --echo-seconds 2 $( [ $w = mixed ] && echo --single-mode ) > $R/$w.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, collections, json, os
 R = "gpurun_out/valu"
 want = {"dtmf": ("tone_fast_kernel", 65536), "v29": ("v29_quad_kernel", 16384), "v17": ("v17_quad_kernel", 16384), "v27ter": ("v27ter_", 16384),
-        "echo": ("echo_", 131072), "mixed": ("tone_fast_kernel", 131072), "fsk": ("fsk_", 65536), "mct": ("mct_", 65536),
+        "echo": ("echo_", 131072), "mixed": ("_fast_kernel", 131072), "fsk": ("fsk_", 65536), "mct": ("mct_", 65536),
         "sigtone": ("sigtone_rx_kernel", 65536), "supertone": ("tone_fast_kernel", 65536), "dtmf_tx": ("tx_bank_kernel", 65536),
         "v29_tx": ("modemtx_bank_kernel", 65536), "awgn": ("awgn_bank_kernel", 65536)}
 out = {"note": "rocprofv3 --pmc SQ_* (kernel-trace only) means per launch of each workload's dominant kernel (the one with the most "
@@ -48,7 +48,7 @@ for key, (pat, n_ch) in want.items():
                              "wave_cycles_per_wave_sample": 4.0*m.get("SQ_WAVE_CYCLES", 0)/waves/160.0,
                              "active_frac": m.get("SQ_ACTIVE_INST_ANY", 0)/max(1.0, m.get("SQ_WAVE_CYCLES", 1)),
                              "wait_frac": m.get("SQ_WAIT_ANY", 0)/max(1.0, m.get("SQ_WAVE_CYCLES", 1)),
-                             "launches": len(acc[best].get("SQ_INSTS_VALU", [])), "source": "tools/gpu_valu.sh (round 5)"}
+                             "launches": len(acc[best].get("SQ_INSTS_VALU", [])), "source": "tools/gpu_valu.sh (round %s)" % os.environ.get("ROUND", "6")}
 # workloads not measured in this run keep their record (profiles/valu_counters.json)
 try:
     old = json.load(open("profiles/valu_counters.json"))["workloads"]

@@ -12,7 +12,7 @@ from spandsp_amd import roofline as rl  # noqa: E402
 
 WANT = {
     "dtmf": ("tone_fast_kernel<spg::DtmfDet<false>", 65536),
-    "mixed": ("tone_fast_kernel<", 131072),          # three launches a tick on three streams: summed below
+    "mixed": ("_fast_kernel<", 131072),              # a tick's launches (round 6: the super-tone bank with its cadence matcher | Bell MF + R2 MF in one launch): summed below
     "v29": ("v29_quad_kernel", 16384),
     "v17": ("v17_quad_kernel", 16384),
     "v27ter": ("v27ter_quad_kernel", 16384),
