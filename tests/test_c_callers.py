@@ -54,6 +54,7 @@ def _prototypes(header, macro):
     """(name, 'ret (*chk_name)(args)') for every spandsp-named function the header declares"""
     text = open(os.path.join(INC, header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"SPANGPU_SLOW_CALL\(\"[^\"]*\"\)", "", text)       # (an attribute behind two prototypes: not part of the type)
     out = []
     for m in re.finditer(macro + r"\s+([^;{}]*?)\b(\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
         ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
