@@ -290,23 +290,14 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         __syncthreads();
     }
 
-    // Super-tone cadences: the tables the walk at the end of the kernel looks things up in go to LDS now (a look-up in global
-    // memory there is a full memory latency with nothing to overlap it, and the walk makes two or three in a row)
-    __shared__ int32_t cad_first[((ABL & kToneCadence) != 0)  ?  (kCadLdsTones + 1)  :  1];
-    __shared__ int4 cad_elem[((ABL & kToneCadence) != 0)  ?  kCadLdsElems  :  1];
-    if constexpr ((ABL & kToneCadence) != 0)
-    {
-        // (the host only builds this variant into a launch when the tables fit: kCadLdsTones, kCadLdsElems)
-        if (L.cad.state)
-        {
-            constexpr int kThreads = kWave*(WPB + (LDR  ?  1  :  0));
-            for (int i = threadIdx.x;  i <= L.cad.n_tones  &&  i <= kCadLdsTones;  i += kThreads)
-                cad_first[i] = L.cad.first[i];
-            for (int i = threadIdx.x;  i < L.cad.n_elems  &&  i < kCadLdsElems;  i += kThreads)
-                cad_elem[i] = L.cad.elem[i];
-            __syncthreads();
-        }
-    }
+    // Super-tone cadences: the tables the walk at the end of the kernel looks things up in live in LDS (a look-up in global
+    // memory there is a full memory latency with nothing to overlap it, and the walk makes two or three in a row).  Round 6: a copy
+    // per consumer wave, written by the wave itself from loads it issues WITH its state loads (below) -- the workgroup's one copy
+    // was staged at the top of the kernel behind a barrier, and every wave's state loads and first DMA waited a memory round
+    // trip for it.
+    constexpr int kCadCopies = ((ABL & kToneCadence) != 0)  ?  WPB  :  1;
+    __shared__ int32_t cad_first_all[kCadCopies][((ABL & kToneCadence) != 0)  ?  (kCadLdsTones + 1)  :  1];
+    __shared__ int4 cad_elem_all[kCadCopies][((ABL & kToneCadence) != 0)  ?  kCadLdsElems  :  1];
     if (ABL & 128)
         return;                                     // probe: launch + dispatch cost alone
     const unsigned lane = threadIdx.x & (kWave - 1);
@@ -459,10 +450,24 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         energy = ldf(L.sf + (size_t) (2*NB)*nch);
     det.load_extra(L, (int) ch);
     CadenceRegs cad_regs;
+    int32_t cad_tf = 0;
+    int4 cad_te0 = make_int4(0, 0, 0, 0);
+    int4 cad_te1 = make_int4(0, 0, 0, 0);
     if constexpr ((ABL & kToneCadence) != 0)
     {
         if (L.cad.state)
+        {
             cadence_state_load(L.cad, (int) ch, (int) nch, cad_regs);     // needed a frame from now: the latency costs nothing here
+            // ... and this wave's copy of the tables: lane l asks for first[l] and elements l and l + 64 (the host only builds this
+            // variant into a launch when the tables fit: kCadLdsTones, kCadLdsElems)
+            static_assert(kCadLdsTones + 1 <= kWave  &&  kCadLdsElems <= 2*kWave, "a wave's lanes cover the cadence tables");
+            if ((int) lane <= L.cad.n_tones)
+                cad_tf = L.cad.first[lane];
+            if ((int) lane < L.cad.n_elems)
+                cad_te0 = L.cad.elem[lane];
+            if ((int) lane + kWave < L.cad.n_elems)
+                cad_te1 = L.cad.elem[lane + kWave];
+        }
     }
     uint32_t w0 = (ABL & 1024)  ?  0u  :  (uint32_t) ldi(L.si);
     int32_t w1 = (ABL & 1024)  ?  0  :  ldi(L.si + (size_t) nch);
@@ -480,6 +485,20 @@ __device__ __forceinline__ void tone_fast_body(const ToneLaunch &L, const int wg
         uniform = __all(!live  ||  cs == cs_first);
         if (uniform)
             cs = cs_first;
+    }
+    int32_t (&cad_first)[sizeof(cad_first_all[0])/sizeof(int32_t)] = cad_first_all[kCadCopies > 1  ?  wv  :  0];
+    int4 (&cad_elem)[sizeof(cad_elem_all[0])/sizeof(int4)] = cad_elem_all[kCadCopies > 1  ?  wv  :  0];
+    if constexpr ((ABL & kToneCadence) != 0)
+    {
+        if (L.cad.state)
+        {
+            // (the loads came back with the state's; a wave's own LDS operations are performed in order: no barrier)
+            if ((int) lane <= kCadLdsTones)
+                cad_first[lane] = cad_tf;
+            cad_elem[lane] = cad_te0;
+            if ((int) lane + kWave < kCadLdsElems)
+                cad_elem[lane + kWave] = cad_te1;
+        }
     }
     stamp(1);
 
