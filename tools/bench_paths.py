@@ -686,17 +686,19 @@ def bench_mixed(args, dev, stream):
         if m == "bank_streams":
             # a stream per bank on hardware queues proven to be different ones (spangpu_banks_own_queues; three torch streams
             # may or may not share a queue -- profiles/r6_mixed_trace_overlap_collision.txt)
-            engine.banks_own_queues(banks)
+            set_mode.proven = engine.banks_own_queues(banks)
             own = [torch.cuda.ExternalStream(engine.lib().spangpu_bank_get_stream(b.h), device=dev) for b in banks]
         elif m == "two_queues":
             # the super-tone bank, whose launch carries the cadence matcher and is the longest, alone on one queue; Bell MF and
             # R2 MF share the other and with it a launch (spangpu_banks_rx groups banks by stream)
-            engine.banks_own_queues([banks[0], banks[2]])
+            set_mode.proven = engine.banks_own_queues([banks[0], banks[2]])
             banks[1].share_stream(banks[0])
             own = [torch.cuda.ExternalStream(engine.lib().spangpu_bank_get_stream(b.h), device=dev) for b in (banks[0], banks[2])]
         else:
             for b in banks:
                 b.set_stream(ctypes.c_void_p(stream.cuda_stream))
+
+    set_mode.proven = None
 
     def step(i, m):
         if m == "separate":
@@ -806,7 +808,8 @@ def bench_mixed(args, dev, stream):
                                                  "bank_streams": "a launch per bank and step, every bank on a stream (hardware queue) of its own (spangpu_banks_own_queues, spangpu_banks_rx)",
                                                  "two_queues": "two launches per step on two hardware queues: the super-tone bank with its cadence matcher on one, Bell MF + R2 MF sharing a launch on the other (spangpu_banks_own_queues, spangpu_banks_rx)",
                                                  "separate": "three launches per step on one stream"}[mode]),
-                   "channels_per_gpu": n_ch, "blocks_with_a_hit_in_last_step": hits, "cadence_matcher_in_timed_region": with_cadences},
+                   "channels_per_gpu": n_ch, "blocks_with_a_hit_in_last_step": hits, "cadence_matcher_in_timed_region": with_cadences,
+                   "hardware_queues_proven_distinct": set_mode.proven},
         "roofline": {"bound": "hbm", "kernel": "tone_multi_fast_kernel (Bell MF + R2 MF + super-tone workgroups in one launch)" if fused
                                else "tone_fast_kernel<MultiDet<8, true> + cadence epilogue> beside tone_multi_fast_kernel (Bell MF + R2 MF), two queues" if mode == "two_queues"
                                else "tone_fast_kernel<BellMfDet | R2MfDet | MultiDet<8, true> + cadence epilogue> (3 launches%s)" % (" on 3 streams" if mode == "bank_streams" else ""),
