@@ -57,6 +57,24 @@ def test_fsk_bit_modes(built, which, mode):
     assert total > n*20                             # carriers came up and bits were delivered
 
 
+@pytest.mark.parametrize("which,mode,hz,baud_pct", [(1, 1, 12, 1.0), (1, 0, -15, -1.5), (0, 1, -8, 0.7), (6, 1, 20, -1.0), (2, 2, 10, 0.5)])
+def test_fsk_off_frequency_and_off_rate(built, which, mode, hz, baud_pct):
+    """The far end's modem a few hertz off both frequencies (a carrier system's shift) and its baud clock a per cent off: the
+    correlators no longer sit on their bins and the baud phase is nudged at nearly every transition (fsk.c:540-590) -- events and
+    every state word against the oracle, sync / async / framed."""
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    sp = engine.fsk_preset(which)
+    n = 70
+    n_samples = 160*60 if sp.baud_rate >= 30000 else 160*150
+    baud = int(round(sp.baud_rate*(1.0 + baud_pct/100.0)))
+    sig = synth.fsk_channels(n, n_samples, 300 + which*5 + mode, sp.freq_zero + hz, sp.freq_one + hz, baud, framed=(mode == 2))
+    bank = engine.FskBank(which, n, mode)
+    orcs = [orc.Fsk(which, mode) for _ in range(n)]
+    total = run_both(bank, orcs, sig, SIZES if which == 1 else [160], check_every=3)
+    assert total > n*10
+
+
 @pytest.mark.parametrize("which,data_bits,parity", [(1, 8, 0), (0, 7, 1), (7, 5, 0), (2, 8, 2)])
 def test_fsk_framed_mode(built, which, data_bits, parity):
     from oracle import restated as orc
