@@ -74,3 +74,22 @@ def test_mct_hit_latch(built, tone_type, kind):
     orcs = [orc.Mct(tone_type, use_callback=False) for _ in range(n)]
     latched = run_both(bank, orcs, sig, [160], use_callback=False)
     assert any(latched)
+
+
+@pytest.mark.parametrize("tone_type,kind", [(2, "mix"), (7, "mix"), (1, "cng"), (6, "preamble")])
+def test_mct_on_shifted_lines(built, tone_type, kind):
+    """The same lines through a carrier system that shifts every frequency by a few hertz (tests/impair.py; 2100 Hz becomes
+    2090 ... 2112 Hz, the AM and the phase reversals stay): the notch and band filters are off their centres, levels move, some
+    tones are declared later or not at all -- reports and state words against the oracle all the same."""
+    import impair
+    from oracle import restated as orc
+    from spandsp_amd import engine
+    n = 64
+    sig = synth.connect_tone_channels(n, 8000*4, 700 + tone_type, kind)
+    rng = np.random.default_rng(tone_type)
+    for c in range(n):
+        sig[c] = impair.line(sig[c], float(rng.choice([-12.0, -6.0, 4.0, 9.0, 15.0])), float(rng.choice([0.0, 80.0, -80.0])))
+    bank = engine.MctBank(tone_type, n)
+    orcs = [orc.Mct(tone_type) for _ in range(n)]
+    got = run_both(bank, orcs, sig, [160, 160, 80, 1, 333, 160])
+    assert any(len(g) for g in got)
